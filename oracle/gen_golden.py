@@ -1,0 +1,445 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference on CPU (dev container only).
+
+TEST INFRASTRUCTURE -- never imported by the product.
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python3 oracle/gen_golden.py
+
+Imports `/root/reference` (read-only, never copied) through the
+`oracle/refshim/urdf_parser_py` stand-in for the one missing third-party parser,
+runs the reference's own FK / cost / autograd code on seeded inputs and writes
+
+* `torch_robotics_amd/data/urdf/*.urdf` -- kinematics-only robot descriptions
+  (link names + joint origin/axis/limit; no meshes, inertia, visuals) derived
+  from the reference's data files, plus two authored ones (`ur10_allegro`,
+  `dual_panda`).  The reference is run on these stripped files AND on its own
+  originals and the two results are asserted bit-identical.
+* `tests/golden/*.npz` -- inputs and reference outputs (fp32) for every row of
+  SURVEY.md section 8a.
+
+The reference cannot travel to the GPU box; these small files can.
+"""
+import os
+import sys
+import xml.etree.ElementTree as ET
+from pathlib import Path
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(HERE / "refshim"))
+sys.path.insert(0, str(REF))
+
+import io
+import contextlib
+import numpy as np
+import torch
+
+from torch_robotics.torch_kinematics_tree.models.robot_tree import DifferentiableTree  # noqa: E402
+from torch_robotics.torch_kinematics_tree.geometrics.quaternion import rotation_matrix_to_q  # noqa: E402
+from torch_robotics.torch_kinematics_tree.geometrics.utils import SE3_distance  # noqa: E402
+
+GOLD = REPO / "tests" / "golden"
+URDF_OUT = REPO / "torch_robotics_amd" / "data" / "urdf"
+REF_URDF = REF / "torch_robotics" / "data" / "urdf" / "robots"
+TA = dict(device="cpu", dtype=torch.float32)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+# ----------------------------------------------------------------------------
+# kinematics-only URDFs
+# ----------------------------------------------------------------------------
+def strip_urdf(src: Path, dst: Path, prefix: str = ""):
+    """Keep element order; keep only what FK reads."""
+    root = ET.parse(src).getroot()
+    out = ET.Element("robot", {"name": root.get("name", src.stem)})
+    for elem in root:
+        if elem.tag == "link":
+            ET.SubElement(out, "link", {"name": prefix + elem.get("name")})
+        elif elem.tag == "joint":
+            j = ET.SubElement(out, "joint", {"name": prefix + elem.get("name"), "type": elem.get("type")})
+            origin = elem.find("origin")
+            if origin is not None:
+                ET.SubElement(j, "origin", dict(origin.attrib))
+            ET.SubElement(j, "parent", {"link": prefix + elem.find("parent").get("link")})
+            ET.SubElement(j, "child", {"link": prefix + elem.find("child").get("link")})
+            for tag in ("axis", "limit"):
+                sub = elem.find(tag)
+                if sub is not None:
+                    ET.SubElement(j, tag, dict(sub.attrib))
+    ET.indent(out, space="  ")
+    dst.parent.mkdir(parents=True, exist_ok=True)
+    ET.ElementTree(out).write(dst, encoding="utf-8", xml_declaration=True)
+    return out
+
+
+def author_ur10_allegro(dst: Path):
+    """UR10 arm with the Allegro hand rigidly mounted on `ee_link` (BASELINE config 4)."""
+    ur10 = ET.parse(URDF_OUT / "ur10.urdf").getroot()
+    hand = ET.parse(URDF_OUT / "allegro_hand.urdf").getroot()
+    out = ET.Element("robot", {"name": "ur10_allegro"})
+    hand_links = [e for e in hand if e.tag == "link"]
+    for e in ur10:
+        if e.tag == "link":
+            out.append(e)
+    for e in hand_links:
+        e.set("name", "allegro_" + e.get("name"))
+        out.append(e)
+    for e in ur10:
+        if e.tag == "joint":
+            out.append(e)
+    mount = ET.SubElement(out, "joint", {"name": "allegro_mount_joint", "type": "fixed"})
+    ET.SubElement(mount, "origin", {"xyz": "0.02 0 0", "rpy": "0 1.5707963267948966 0"})
+    ET.SubElement(mount, "parent", {"link": "ee_link"})
+    ET.SubElement(mount, "child", {"link": hand_links[0].get("name")})
+    for e in hand:
+        if e.tag == "joint":
+            e.set("name", "allegro_" + e.get("name"))
+            e.find("parent").set("link", "allegro_" + e.find("parent").get("link"))
+            e.find("child").set("link", "allegro_" + e.find("child").get("link"))
+            out.append(e)
+    ET.indent(out, space="  ")
+    ET.ElementTree(out).write(dst, encoding="utf-8", xml_declaration=True)
+
+
+def author_dual_panda(dst: Path):
+    """`world` + two Panda arms side by side (BASELINE config 5)."""
+    out = ET.Element("robot", {"name": "dual_panda"})
+    ET.SubElement(out, "link", {"name": "world"})
+    for prefix, y, yaw in (("left_", 0.35, "0"), ("right_", -0.35, "0")):
+        arm = ET.parse(URDF_OUT / "panda_arm_no_gripper.urdf").getroot()
+        first_link = None
+        elems = list(arm)
+        for e in elems:
+            if e.tag == "link":
+                e.set("name", prefix + e.get("name"))
+                first_link = first_link or e.get("name")
+            else:
+                e.set("name", prefix + e.get("name"))
+                e.find("parent").set("link", prefix + e.find("parent").get("link"))
+                e.find("child").set("link", prefix + e.find("child").get("link"))
+        mount = ET.SubElement(out, "joint", {"name": prefix + "mount", "type": "fixed"})
+        ET.SubElement(mount, "origin", {"xyz": f"0 {y} 0", "rpy": f"0 0 {yaw}"})
+        ET.SubElement(mount, "parent", {"link": "world"})
+        ET.SubElement(mount, "child", {"link": first_link})
+        for e in elems:
+            out.append(e)
+    ET.indent(out, space="  ")
+    ET.ElementTree(out).write(dst, encoding="utf-8", xml_declaration=True)
+
+
+ROBOTS = {
+    # name: path relative to the reference's robots dir
+    "panda_arm_no_gripper": "franka_description/robots/panda_arm_no_gripper.urdf",
+    "panda_arm_hand": "franka_description/robots/panda_arm_hand.urdf",
+    "ur10": "ur10/urdf/ur10.urdf",
+    "allegro_hand": "allegro_hand/allegro_hand.urdf",
+    "iiwa7": "kuka_iiwa/urdf/iiwa7.urdf",
+    "iiwa7_allegro": "kuka_iiwa/urdf/iiwa7_allegro.urdf",
+    "shadow_hand": "shadow_hand/shadow_hand.urdf",
+    "tiago_dual_holobase_minimal_holonomic": "tiago_dual_description/tiago_dual_holobase_minimal_holonomic.urdf",
+    "hab_stretch": "habitat_stretch/urdf/hab_stretch.urdf",
+}
+AUTHORED = {"ur10_allegro": author_ur10_allegro, "dual_panda": author_dual_panda}
+
+
+# ----------------------------------------------------------------------------
+# FK goldens
+# ----------------------------------------------------------------------------
+def limits_of(tree):
+    lo, hi = [], []
+    for idx in tree._controlled_joints:
+        lim = tree._bodies[idx].joint_limits
+        if lim is None:
+            lo.append(-np.pi); hi.append(np.pi)
+        else:
+            lo.append(float(lim["lower"])); hi.append(float(lim["upper"]))
+    return np.asarray(lo), np.asarray(hi)
+
+
+def sample_q(tree, n, gen, widen=0.0):
+    lo, hi = limits_of(tree)
+    span = hi - lo
+    lo, hi = lo - widen * span, hi + widen * span
+    u = torch.rand(n, len(lo), generator=gen, dtype=torch.float64)
+    return (torch.as_tensor(lo) + u * torch.as_tensor(hi - lo)).to(torch.float32)
+
+
+def model_params(tree):
+    """What the reference's model build produced (A1)."""
+    out = dict(
+        link_names=np.array(tree.get_link_names()),
+        n_dofs=np.int32(tree._n_dofs),
+        controlled=np.asarray(tree._controlled_joints, np.int32),
+        trans=np.stack([b.trans.reshape(3).numpy() for b in tree._bodies]),
+        R_fixed=np.stack([b.fixed_rotation.reshape(3, 3).numpy() for b in tree._bodies]),
+        axis=np.stack([b.joint_axis.reshape(3).numpy() for b in tree._bodies]),
+        joint_type=np.array([b.joint_type for b in tree._bodies]),
+        has_limits=np.array([b.joint_limits is not None for b in tree._bodies]),
+        lower=np.array([float(b.joint_limits["lower"]) if b.joint_limits else 0.0 for b in tree._bodies]),
+        upper=np.array([float(b.joint_limits["upper"]) if b.joint_limits else 0.0 for b in tree._bodies]),
+        parent=np.array([-1] + [tree._name_to_idx_map[tree._model.get_name_of_parent_body(b.name)]
+                                for b in tree._bodies[1:]], np.int32),
+    )
+    return out
+
+
+def fk_golden(name, tree, seed):
+    gen = torch.Generator().manual_seed(seed)
+    L = len(tree.get_link_names())
+    out = model_params(tree)
+    for tag, widen in (("in", 0.0), ("out", 0.2)):
+        q = sample_q(tree, 32, gen, widen).requires_grad_(True)
+        H = tree.compute_forward_kinematics_all_links(q)
+        w = torch.randn(32, L, 4, 4, generator=gen)
+        (gq,) = torch.autograd.grad((w * H).sum(), q)
+        out[f"q_{tag}"] = q.detach().numpy()
+        out[f"H_{tag}"] = H.detach().numpy()
+        out[f"w_{tag}"] = w.numpy()
+        out[f"gq_{tag}"] = gq.numpy()
+    # link subset + dict path
+    names = tree.get_link_names()
+    sel = [names[-1], names[len(names) // 2], names[1]]
+    q = torch.as_tensor(out["q_in"])
+    out["sel_names"] = np.array(sel)
+    out["H_sel"] = tree.compute_forward_kinematics_all_links(q, link_list=sel).numpy()
+    np.savez_compressed(GOLD / f"fk_{name}.npz", **out)
+    return out
+
+
+def jacobian_golden(name, tree, links, seed):
+    gen = torch.Generator().manual_seed(seed)
+    q = sample_q(tree, 32, gen, 0.1)
+    qd = 0.1 * torch.randn(32, tree._n_dofs, generator=gen)
+    out = dict(q=q.numpy(), qd=qd.numpy(), links=np.array(links))
+    for k, link in enumerate(links):
+        tree.reset()
+        pos, quat, lin, ang = tree.compute_forward_kinematics_and_geometric_jacobian(q, qd, link)
+        out[f"pos_{k}"] = pos.numpy(); out[f"quat_{k}"] = quat.numpy()
+        out[f"lin_{k}"] = lin.numpy(); out[f"ang_{k}"] = ang.numpy()
+        body = tree._bodies[tree._name_to_idx_map[link]]
+        out[f"vel_lin_{k}"] = body.vel.lin.numpy(); out[f"vel_ang_{k}"] = body.vel.ang.numpy()
+        tree.reset()
+    np.savez_compressed(GOLD / f"jac_{name}.npz", **out)
+
+
+def quat_golden():
+    gen = torch.Generator().manual_seed(77)
+    # random rotations incl. near-180deg cases to hit every branch of the 4-candidate rule
+    A = torch.randn(256, 3, 3, generator=gen, dtype=torch.float64)
+    Q, _ = torch.linalg.qr(A)
+    Q = Q * torch.sign(torch.linalg.det(Q)).reshape(-1, 1, 1)
+    special = torch.stack([torch.diag(torch.tensor(d, dtype=torch.float64)) for d in
+                           ([1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1])])
+    R = torch.cat([Q, special]).to(torch.float32)
+    np.savez_compressed(GOLD / "quat.npz", R=R.numpy(), q_wxyz=rotation_matrix_to_q(R).numpy())
+
+
+# ----------------------------------------------------------------------------
+# cost goldens (Panda)
+# ----------------------------------------------------------------------------
+def scene_arrays(env):
+    """Flatten the env's analytic objects into data (so the build's own scene tables can be checked)."""
+    from torch_robotics.environments.primitives import MultiSphereField, MultiBoxField, MultiSharpBoxField
+    out = {}
+
+    def dump(objs, tag):
+        for oi, obj in enumerate(objs or []):
+            out[f"{tag}{oi}_pos"] = obj.pos.numpy().astype(np.float32)
+            out[f"{tag}{oi}_ori"] = obj.ori.numpy().astype(np.float32)
+            for fi, f in enumerate(obj.fields):
+                key = f"{tag}{oi}_f{fi}"
+                if isinstance(f, MultiSphereField):
+                    out[key + "_kind"] = np.array("sphere")
+                    out[key + "_centers"] = f.centers.numpy(); out[key + "_radii"] = f.radii.numpy()
+                elif isinstance(f, MultiBoxField):
+                    out[key + "_kind"] = np.array("roundbox")
+                    out[key + "_centers"] = f.centers.numpy(); out[key + "_sizes"] = f.sizes.numpy()
+                    out[key + "_radius"] = f.radius.numpy()
+                elif isinstance(f, MultiSharpBoxField):
+                    out[key + "_kind"] = np.array("sharpbox")
+                    out[key + "_centers"] = f.centers.numpy(); out[key + "_sizes"] = f.sizes.numpy()
+    dump(env.obj_fixed_list, "fixed")
+    dump(env.obj_extra_list, "extra")
+    out["limits"] = env.limits.numpy()
+    return out
+
+
+def cost_goldens():
+    from torch_robotics.robots.robot_panda import RobotPanda
+    from torch_robotics.tasks.tasks import PlanningTask
+    from torch_robotics.environments.env_spheres_3d import EnvSpheres3D
+    from torch_robotics.environments.env_table_shelf import EnvTableShelf
+    from torch_robotics.environments.env_maze_boxes_3d import EnvMazeBoxes3D
+    from torch_robotics.environments.env_spheres_3d_extra_objects import EnvSpheres3DExtraObjects
+    from torch_robotics.torch_planning_objectives.fields.distance_fields import EESE3DistanceField
+
+    robot = quiet(RobotPanda, tensor_args=TA)
+    tree = robot.diff_panda
+    gen = torch.Generator().manual_seed(2024)
+    q0 = sample_q(tree, 64, gen, 0.1).reshape(8, 8, 7)
+
+    meta = dict(
+        obj_link_idxs=np.asarray(robot.link_idxs_for_object_collision_checking, np.int32),
+        obj_link_margins=robot.link_margins_for_object_collision_checking_tensor.numpy(),
+        self_link_idxs=np.asarray(robot.link_idxs_for_self_collision_checking, np.int32),
+        self_pairs=np.asarray(robot.df_collision_self.idxs_links_distance_matrix, np.int32),
+        self_margins=robot.df_collision_self.cutoff_margin.numpy(),
+        q_limits=robot.q_limits.numpy(),
+        q=q0.numpy(),
+        fk_map_collision=robot.fk_map_collision(q0).numpy(),
+        ee_pose=robot.get_EE_pose(q0.reshape(-1, 7)).numpy(),
+    )
+    np.savez_compressed(GOLD / "panda_robot.npz", **meta)
+
+    envs = {
+        "spheres3d": (lambda: EnvSpheres3D(tensor_args=TA), 0.03),
+        "spheres3d_grid": (lambda: quiet(EnvSpheres3D, tensor_args=TA, precompute_sdf_obj_fixed=True,
+                                         sdf_cell_size=0.1), 0.03),
+        "table_shelf": (lambda: EnvTableShelf(tensor_args=TA), 0.01),
+        "maze_boxes3d": (lambda: EnvMazeBoxes3D(tensor_args=TA), 0.01),
+        "spheres3d_extra": (lambda: EnvSpheres3DExtraObjects(tensor_args=TA), 0.01),
+    }
+    for name, (make_env, cutoff) in envs.items():
+        env = make_env()
+        task = PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=cutoff, tensor_args=TA)
+        out = scene_arrays(env)
+        out["cutoff"] = np.float32(cutoff)
+        out["q"] = q0.numpy()
+        if env.grid_map_sdf_obj_fixed is not None:
+            g = env.grid_map_sdf_obj_fixed
+            out["grid_sdf"] = g.sdf_tensor.numpy(); out["grid_grad"] = g.grad_sdf_tensor.numpy()
+            out["grid_cmap_dim"] = g.cmap_dim.numpy().astype(np.int32)
+            out["grid_cell"] = np.float32(g.cell_size)
+        # per-field cost + grad w.r.t. link positions (unfused ops) and w.r.t. q (through FK)
+        fields = dict(self=task.df_collision_self, objects=task.df_collision_objects,
+                      ws=task.df_collision_ws_boundaries)
+        if task._collision_fields_extra_objects:
+            fields["extra"] = task._collision_fields_extra_objects[0]
+        for fname, fld in fields.items():
+            q = q0.clone().requires_grad_(True)
+            pos = robot.fk_map_collision(q)
+            pos_leaf = pos.detach().clone().requires_grad_(True)
+            c = fld.compute_cost(q, pos_leaf, field_type="sdf")
+            (gpos,) = torch.autograd.grad(c.sum(), pos_leaf)
+            c2 = fld.compute_cost(q, pos, field_type="sdf")
+            (gq,) = torch.autograd.grad(c2.sum(), q)
+            out[f"cost_{fname}"] = c.detach().numpy()
+            out[f"gpos_{fname}"] = gpos.numpy()
+            out[f"gq_{fname}"] = gq.numpy()
+            out[f"coll_{fname}"] = fld.compute_cost(q0, pos.detach(), field_type="occupancy").numpy()
+            out[f"coll0_{fname}"] = fld.compute_cost(q0, pos.detach(), field_type="occupancy", margin=0.).numpy()
+        q = q0.clone().requires_grad_(True)
+        total = task.compute_collision_cost(q)
+        (gq,) = torch.autograd.grad(total.sum(), q)
+        out["cost_total"] = total.detach().numpy(); out["gq_total"] = gq.numpy()
+        out["coll_total"] = task.compute_collision(q0).numpy()
+        out["coll0_total"] = task.compute_collision(q0, margin=0.).numpy()
+        np.savez_compressed(GOLD / f"cost_{name}.npz", **out)
+
+    # EE SE(3) tracking (A13)
+    out = dict(q=q0.numpy())
+    targets = []
+    gen = torch.Generator().manual_seed(5)
+    Ht0 = torch.eye(4); Ht0[:3, 3] = torch.tensor([0.4, 0.2, 0.5])
+    targets.append(Ht0)
+    for _ in range(2):
+        qq = sample_q(tree, 1, gen, 0.0)
+        targets.append(robot.get_EE_pose(qq)[0, 0])
+    per_sample = robot.get_EE_pose(sample_q(tree, 64, gen, 0.0))[:, 0]
+    for k, Ht in enumerate(targets + [per_sample]):
+        for sq in (True, False):
+            for (wp, wr) in ((1.0, 1.0), (2.0, 0.5)):
+                fld = EESE3DistanceField(Ht, w_pos=wp, w_rot=wr, square=sq, tensor_args=TA)
+                q = q0.reshape(-1, 7).clone().requires_grad_(True)
+                H = tree.compute_forward_kinematics_all_links(q)
+                Hleaf = H.detach().clone().requires_grad_(True)
+                c = fld.compute_costs_impl(q, Hleaf)
+                (gH,) = torch.autograd.grad(c.sum(), Hleaf)
+                c2 = fld.compute_costs_impl(q, H)
+                (gq,) = torch.autograd.grad(c2.sum(), q)
+                key = f"t{k}_sq{int(sq)}_w{wp}_{wr}"
+                out["target_%d" % k] = Ht.numpy()
+                out["cost_" + key] = c.detach().numpy()
+                out["gH_" + key] = gH.numpy()
+                out["gq_" + key] = gq.numpy()
+    np.savez_compressed(GOLD / "cost_ee.npz", **out)
+
+    # bench-shaped composite goldens (C2: objects + EE, C3: self + objects + ws + EE), B=6 x H=64
+    env = EnvSpheres3D(tensor_args=TA)
+    task = PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    gen = torch.Generator().manual_seed(1234)
+    qb = sample_q(tree, 6 * 64, gen, 0.05).reshape(6, 64, 7)
+    fld = EESE3DistanceField(Ht0, w_pos=1.0, w_rot=1.0, square=True, tensor_args=TA)
+    out = dict(q=qb.numpy(), target=Ht0.numpy(), cutoff=np.float32(0.03))
+
+    def ee_cost(q):
+        H = tree.compute_forward_kinematics_all_links(q.reshape(-1, 7))
+        return fld.compute_costs_impl(q, H).reshape(q.shape[:-1])
+
+    q = qb.clone().requires_grad_(True)
+    pos = robot.fk_map_collision(q)
+    c_obj = task.df_collision_objects.compute_cost(q, pos, field_type="sdf")
+    c2 = c_obj + ee_cost(q)
+    (g2,) = torch.autograd.grad(c2.sum(), q)
+    out["pos"] = pos.detach().numpy(); out["cost_c2"] = c2.detach().numpy(); out["gq_c2"] = g2.numpy()
+    q = qb.clone().requires_grad_(True)
+    c3 = task.compute_collision_cost(q) + ee_cost(q)
+    (g3,) = torch.autograd.grad(c3.sum(), q)
+    out["cost_c3"] = c3.detach().numpy(); out["gq_c3"] = g3.numpy()
+    np.savez_compressed(GOLD / "rollout_panda.npz", **out)
+
+
+def misc_goldens():
+    """finite differences / smoothness (A17) and via-point interpolation (8f rank 1)."""
+    from torch_robotics.trajectory.utils import finite_difference_vector, interpolate_traj_via_points
+    from torch_robotics.trajectory.metrics import compute_smoothness
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 16, 7, generator=gen)
+    out = dict(x=x.numpy())
+    for m in ("forward", "backward", "central"):
+        out["fd_" + m] = finite_difference_vector(x, dt=0.25, method=m).numpy()
+    out["interp5"] = interpolate_traj_via_points(x, num_interpolation=5).numpy()
+    try:
+        out["smoothness"] = compute_smoothness(x, None).numpy()
+    except Exception:
+        pass
+    np.savez_compressed(GOLD / "traj.npz", **out)
+
+
+def main():
+    GOLD.mkdir(parents=True, exist_ok=True)
+    URDF_OUT.mkdir(parents=True, exist_ok=True)
+    trees = {}
+    for name, rel in ROBOTS.items():
+        strip_urdf(REF_URDF / rel, URDF_OUT / f"{name}.urdf")
+        t_orig = quiet(DifferentiableTree, str(REF_URDF / rel), name)
+        t_strip = quiet(DifferentiableTree, str(URDF_OUT / f"{name}.urdf"), name)
+        q = sample_q(t_orig, 8, torch.Generator().manual_seed(0), 0.1)
+        assert torch.equal(t_orig.compute_forward_kinematics_all_links(q),
+                           t_strip.compute_forward_kinematics_all_links(q)), name
+        trees[name] = t_strip
+    for name, fn in AUTHORED.items():
+        fn(URDF_OUT / f"{name}.urdf")
+        trees[name] = quiet(DifferentiableTree, str(URDF_OUT / f"{name}.urdf"), name)
+    for k, (name, tree) in enumerate(sorted(trees.items())):
+        out = fk_golden(name, tree, 100 + k)
+        print(f"fk_{name}: L={len(out['link_names'])} D={int(out['n_dofs'])}")
+    jacobian_golden("panda_arm_no_gripper", trees["panda_arm_no_gripper"], ["ee_link", "panda_link5", "panda_link2"], 31)
+    jacobian_golden("ur10", trees["ur10"], [trees["ur10"].get_link_names()[-1], trees["ur10"].get_link_names()[4]], 32)
+    jacobian_golden("iiwa7", trees["iiwa7"], [trees["iiwa7"].get_link_names()[-1]], 33)
+    quat_golden()
+    cost_goldens()
+    misc_goldens()
+    total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
+    print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
+
+
+if __name__ == "__main__":
+    main()
