@@ -1,0 +1,304 @@
+/*
+ * trk.h -- C ABI of libtrk.so: MI355X (gfx950) batched differentiable forward
+ * kinematics + planning-objective kernels.
+ *
+ * This is the drop-in boundary for the hot path of anindex/torch_robotics
+ * (SURVEY.md section 8b).  The reference has no FFI layer: its boundary is a set of
+ * Python methods.  Each entry point below names the reference method whose
+ * arithmetic it replaces (file:line relative to the reference repo); the Python
+ * classes in torch_robotics_amd/ keep the reference's signatures and call these.
+ *
+ * Conventions
+ *  - All tensor arguments are DEVICE pointers to contiguous row-major fp32 unless
+ *    a comment says "host".  The caller allocates every input and output; the
+ *    library owns only the opaque handles it returns.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Launches
+ *    are asynchronous; the caller synchronises.  No hidden global state; handles
+ *    are immutable except through the trk_*_set_* calls, which must not race with
+ *    launches that use the handle.
+ *  - Every function returns TRK_OK (0) or a negative TrkStatus and writes nothing
+ *    on error.  Nothing throws or aborts across the boundary.
+ *  - N = number of samples (batch x horizon folded, reference robot_panda.py:142),
+ *    L = number of links (URDF file order), D = number of DOFs (file order of the
+ *    non-fixed links, reference robot_tree.py:112-115).
+ *  - Homogeneous transforms are 4x4 row-major with the translation in column 3 and
+ *    bottom row [0,0,0,1] (reference frame.py:81-85).  Quaternions are wxyz.
+ */
+#ifndef TRK_H
+#define TRK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRK_ABI_VERSION 1
+#define TRK_MAX_LINKS 64
+#define TRK_MAX_DOFS 32
+#define TRK_MAX_POSE_SLOTS 8
+#define TRK_MAX_OBJECTS 16
+#define TRK_MAX_PRIMS 256
+#define TRK_MAX_COLL_LINKS 64
+#define TRK_MAX_SELF_PAIRS 256
+
+typedef enum TrkStatus {
+    TRK_OK = 0,
+    TRK_ERR_INVALID_ARG = -1,   /* null pointer, negative size, index out of range          */
+    TRK_ERR_UNSUPPORTED = -2,   /* joint type / model size the kernels do not handle         */
+    TRK_ERR_HIP = -3,           /* a HIP runtime call failed (see trk_last_error)            */
+    TRK_ERR_NO_DEVICE = -4      /* no gfx950 device visible                                  */
+} TrkStatus;
+
+typedef enum TrkJointType {
+    TRK_JOINT_FIXED = 0,
+    TRK_JOINT_REVOLUTE = 1,
+    TRK_JOINT_CONTINUOUS = 2,
+    TRK_JOINT_PRISMATIC = 3,
+    TRK_JOINT_UNSUPPORTED = 4
+} TrkJointType;
+
+typedef void* trk_stream_t;
+
+/* ---------------------------------------------------------------------------------
+ * Kinematic model.  Host arrays, copied once at create().  Produced by
+ * torch_robotics_amd/kinmodel.py, which restates the reference's model build
+ * (models/utils.py:199-313, rigid_body.py:74-123, robot_tree.py:77-126).
+ * All per-link arrays are indexed by link (file order) unless marked "by position"
+ * (= index into the DFS pre-order `order`).
+ * --------------------------------------------------------------------------------- */
+typedef struct TrkKinModelDesc {
+    int32_t abi_version;        /* TRK_ABI_VERSION */
+    int32_t n_links;            /* L <= TRK_MAX_LINKS */
+    int32_t n_dofs;             /* D <= TRK_MAX_DOFS  */
+    int32_t n_slots;            /* pose-stack slots used by parent_slot/store_slot */
+    const int32_t* parent;      /* [L] parent link, -1 for the root (link 0) */
+    const int32_t* joint_type;  /* [L] TrkJointType of the joint whose child is the link */
+    const int32_t* dof_idx;     /* [L] DOF index or -1 */
+    const float* R_fixed;       /* [L*9] Rz(yaw)Ry(pitch)Rx(roll), row-major (rigid_body.py:93) */
+    const float* trans;         /* [L*3] joint origin xyz */
+    const float* axis;          /* [L*3] raw <axis>, zeros when absent */
+    const int32_t* rot_axis;    /* [L] stateless FK rotation axis 0/1/2 (rigid_body.py:163-168) */
+    const float* rot_sign;      /* [L] sign(axis_k) in {-1,0,+1} */
+    const int32_t* clamp;       /* [L] stateless FK clamps q to [lower,upper] (rigid_body.py:157-160) */
+    const float* lower;         /* [L] */
+    const float* upper;         /* [L] */
+    const int32_t* sf_rot_axis; /* [L] stateful path axis, sign ignored (rigid_body.py:101-106,226-227) */
+    const int32_t* sf_clamp;    /* [L] stateful path clamps whenever limits exist (rigid_body.py:218-224) */
+    const int32_t* jac_axis;    /* [L] column of the world rotation used as joint axis (robot_tree.py:242-244) */
+    const int32_t* joint_list_idx; /* [L] index of the link's joint in the URDF joint list (robot_tree.py:235-240) */
+    const int32_t* order;       /* [L] DFS pre-order of links, order[0] == 0 */
+    const int32_t* subtree_end; /* [L] by position: one past the last descendant's position */
+    const int32_t* parent_slot; /* [L] by position: -1 = parent is the previous position, else slot to load */
+    const int32_t* store_slot;  /* [L] by position: slot to keep this link's pose in, or -1 */
+    float base_R[9];            /* root pose (robot_tree.py:133-134), identity by default */
+    float base_t[3];
+} TrkKinModelDesc;
+
+typedef struct TrkModel TrkModel;
+
+int trk_abi_version(void);
+/* Human-readable text of the last error on the calling thread ("" if none). */
+const char* trk_last_error(void);
+
+int trk_model_create(const TrkKinModelDesc* desc, TrkModel** out);
+void trk_model_destroy(TrkModel* model);
+/* reference: DifferentiableTree.update_base_pose robot_tree.py:133-134 (pose already converted
+ * to a rotation matrix on the host, quaternion.py:102-120).  Host pointers. */
+int trk_model_set_base_pose(TrkModel* model, const float* R9, const float* t3);
+int trk_model_n_links(const TrkModel* model);
+int trk_model_n_dofs(const TrkModel* model);
+/* 1 if a model-specialised (ahead-of-time unrolled) kernel set is used for this model. */
+int trk_model_is_specialized(const TrkModel* model);
+
+/* ---------------------------------------------------------------------------------
+ * Forward kinematics (stateless path).
+ * --------------------------------------------------------------------------------- */
+
+/* reference: DifferentiableTree.compute_forward_kinematics_all_links robot_tree.py:267-301
+ *            (+ DifferentiableRigidBody.forward_kinematics rigid_body.py:146-211,
+ *               Frame.get_transform_matrix frame.py:81-85).
+ * q [N,D] -> H_out [N, n_sel, 4, 4].  link_sel: host int32[n_sel] link indices in output
+ * order (NULL = all L links in file order, n_sel ignored). */
+int trk_fk_forward(const TrkModel* model, const float* q, int64_t n,
+                   const int32_t* link_sel, int32_t n_sel, float* H_out, trk_stream_t stream);
+
+/* Link origins only.  reference: RobotPanda.fk_map_collision_impl robot_panda.py:138-170
+ * + link_pos_from_link_tensor geometrics/utils.py:321-328.
+ * q [N,D] -> pos_out [N, n_sel, 3]. */
+int trk_fk_positions(const TrkModel* model, const float* q, int64_t n,
+                     const int32_t* link_sel, int32_t n_sel, float* pos_out, trk_stream_t stream);
+
+/* Explicit reverse-mode of trk_fk_forward (replaces autograd through ~350 bmm nodes).
+ * gH [N, n_sel, 4, 4] (bottom row ignored) -> gq [N,D]; zero where the reference clamps
+ * (rigid_body.py:157-160). */
+int trk_fk_backward(const TrkModel* model, const float* q, const float* gH, int64_t n,
+                    const int32_t* link_sel, int32_t n_sel, float* gq, trk_stream_t stream);
+
+/* Explicit reverse-mode of trk_fk_positions.  gpos [N, n_sel, 3] -> gq [N,D]. */
+int trk_fk_positions_backward(const TrkModel* model, const float* q, const float* gpos, int64_t n,
+                              const int32_t* link_sel, int32_t n_sel, float* gq, trk_stream_t stream);
+
+/* Stateful FK + geometric Jacobian of one link.
+ * reference: DifferentiableTree.compute_forward_kinematics_and_geometric_jacobian
+ *            robot_tree.py:218-248 (update_kinematic_state :136-190, Frame.get_quaternion
+ *            frame.py:87-114, q_convert_wxyz quaternion.py:240-242).
+ * q, qd [N,D] -> pos [N,3], quat_wxyz [N,4], lin_jac [N,3,D], ang_jac [N,3,D].
+ * qd may be NULL (velocities are then not computed).  vel_lin / vel_ang [N,3] (the link's
+ * spatial velocity in the link frame, spatial_vector.py:87-97) may be NULL. */
+int trk_fk_jacobian(const TrkModel* model, const float* q, const float* qd, int64_t n, int32_t link,
+                    float* pos, float* quat_wxyz, float* lin_jac, float* ang_jac,
+                    float* vel_lin, float* vel_ang, trk_stream_t stream);
+
+/* reference: rotation_matrix_to_q quaternion.py:135-166 (via link_quat_from_link_tensor
+ * geometrics/utils.py:341-344).  R: n matrices, `stride` floats apart, 3x3 block with row
+ * pitch `row_pitch` (9/3 for packed rotations, 16/4 for 4x4 transforms).  -> quat_wxyz [n,4]. */
+int trk_rotmat_to_quat(const float* R, int64_t n, int32_t stride, int32_t row_pitch,
+                       float* quat_wxyz, trk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Planning objectives ("cost model").  Host arrays, copied at create().
+ * reference: torch_planning_objectives/fields/distance_fields.py, environments/primitives.py,
+ *            environments/grid_map_sdf.py, robots/robot_base.py:105-141.
+ * --------------------------------------------------------------------------------- */
+typedef enum TrkPrimType {
+    TRK_PRIM_SPHERE = 0,        /* MultiSphereField     primitives.py:108-112 */
+    TRK_PRIM_ROUNDED_BOX = 1,   /* MultiBoxField        primitives.py:327-334 */
+    TRK_PRIM_SHARP_BOX = 2      /* MultiSharpBoxField   primitives.py:220-223 */
+} TrkPrimType;
+
+typedef struct TrkPrimitive {
+    int32_t type;               /* TrkPrimType */
+    int32_t object;             /* index into objects[] */
+    float center[3];
+    float half[3];              /* boxes: sizes/2 */
+    float radius;               /* sphere radius, or rounded-box rounding radius (0.15*min size) */
+    float _pad;
+} TrkPrimitive;
+
+typedef struct TrkObject {      /* ObjectField pose, primitives.py:387-405: p' = R^T (p - pos) */
+    float pos[3];
+    float R[9];                 /* q_to_rotation_matrix(ori), row-major */
+    int32_t prim_begin;         /* primitives [prim_begin, prim_end) belong to this object */
+    int32_t prim_end;
+    int32_t is_grid;            /* 1: this "object" is the precomputed grid (GridMapSDF) */
+    int32_t _pad;
+} TrkObject;
+
+typedef struct TrkGridDesc {    /* GridMapSDF grid_map_sdf.py:9-117 (device pointers, caller-owned) */
+    const float* sdf;           /* DEVICE [nx,ny,nz] */
+    const float* grad;          /* DEVICE [nx,ny,nz,3] */
+    int32_t dims[3];
+    float lim_min[3];
+    float map_dim[3];           /* |lim_max - lim_min| */
+} TrkGridDesc;
+
+typedef struct TrkCostModelDesc {
+    int32_t abi_version;
+    int32_t n_links_in;         /* links per sample in the position tensors handed to the cost ops */
+    /* objects + workspace fields (CollisionObjectDistanceField / ...WorkspaceBoundaries...) */
+    int32_t n_obj_links;        /* Lc */
+    const int32_t* obj_link_idx;    /* [Lc] index into the position tensor */
+    const float* obj_link_margin;   /* [Lc] collision_margins + cutoff_margin, added in fp32 on the host
+                                       exactly as distance_fields.py:112 does */
+    int32_t n_objects;
+    const TrkObject* objects;
+    int32_t n_prims;
+    const TrkPrimitive* prims;
+    int32_t has_grid;
+    TrkGridDesc grid;
+    int32_t has_ws;
+    float ws_min[3];
+    float ws_max[3];
+    /* self collision (CollisionSelfField distance_fields.py:180-215) */
+    int32_t n_self_links;       /* Ls */
+    const int32_t* self_link_idx;   /* [Ls] index into the position tensor */
+    int32_t n_self_pairs;       /* P */
+    const int32_t* self_pairs;      /* [P*2] indices into self_link_idx */
+    const float* self_margin;       /* [P] */
+    /* end-effector SE(3) tracking (EESE3DistanceField distance_fields.py:335-359) */
+    int32_t ee_link;            /* link whose pose is tracked (fused op); -1 = none */
+    float ee_w_pos;
+    float ee_w_rot;
+    int32_t ee_square;
+    float ee_target[16];        /* default target, row-major 4x4 */
+} TrkCostModelDesc;
+
+typedef struct TrkCostModel TrkCostModel;
+
+int trk_cost_model_create(const TrkCostModelDesc* desc, TrkCostModel** out);
+void trk_cost_model_destroy(TrkCostModel* cm);
+/* reference: EESE3DistanceField.update_target distance_fields.py:344-345.  Host pointer, 16 floats. */
+int trk_cost_model_set_ee_target(TrkCostModel* cm, const float* H16);
+
+/* Which field a cost op evaluates. */
+typedef enum TrkField {
+    TRK_FIELD_SELF = 1,         /* CollisionSelfField */
+    TRK_FIELD_OBJECTS = 2,      /* CollisionObjectDistanceField (analytic objects and/or grid) */
+    TRK_FIELD_WS = 4            /* CollisionWorkspaceBoundariesDistanceField */
+} TrkField;
+
+/* reference: EmbodimentDistanceFieldBase.compute_embodiment_cost (field_type='sdf')
+ *            distance_fields.py:107-124 for the fields in `fields` (bit-or of TrkField):
+ *            cost[n] = sum over selected fields of  sum_links max_objects (margin - sdf).
+ * link_pos [N, n_links_in, 3] -> cost [N].  g_link_pos (nullable) [N, n_links_in, 3] receives
+ * d(sum_n gcost[n]*cost[n])/d link_pos (gcost NULL = ones): forward and explicit backward in
+ * one pass, because the gradient is a by-product of the arg-min search. */
+int trk_cost_fields(const TrkCostModel* cm, int32_t fields, const float* link_pos, int64_t n,
+                    const float* gcost, float* cost, float* g_link_pos, trk_stream_t stream);
+
+/* reference: compute_embodiment_collision (field_type='occupancy') distance_fields.py:210-215,
+ *            283-291; PlanningTask ORs the fields tasks.py:227-228.
+ * margin_override: NaN = per-link/per-pair default margins, else the scalar `margin=` kwarg.
+ * -> in_collision [N] (uint8 0/1). */
+int trk_collision_fields(const TrkCostModel* cm, int32_t fields, const float* link_pos, int64_t n,
+                         float margin_override, uint8_t* in_collision, trk_stream_t stream);
+
+/* reference: EESE3DistanceField.compute_costs_impl distance_fields.py:347-356 + SE3_distance
+ *            geometrics/utils.py:130-154.
+ * H_ee: n transforms `stride` floats apart (e.g. the last link of [N,L,4,4]: pointer offset
+ * (L-1)*16, stride L*16).  target: DEVICE [16] (per_sample_target=0) or [N,16] (=1); NULL = the
+ * cost model's stored target.  -> cost [N]; gH (nullable), same layout as H_ee, receives
+ * gcost[n]*dcost/dH (gcost NULL = ones; only the 3x4 block is written, the rest is untouched). */
+int trk_ee_cost(const TrkCostModel* cm, const float* H_ee, int64_t n, int64_t stride,
+                const float* target, int32_t per_sample_target,
+                const float* gcost, float* cost, float* gH, int64_t g_stride, trk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused rollout: FK -> costs -> d cost / d q in one kernel (the north-star path).
+ * reference chain replaced: PlanningTask.compute_collision_cost tasks.py:135-137,206-230
+ *   (RobotPanda.fk_map_collision + the three collision fields) + EESE3DistanceField
+ *   + `cost.sum().backward()`.
+ * q [B,H,D] -> link_pos_out (nullable) [B,H,L,3], cost [B,H], gq [B,H,D];
+ * cost = w_self*self + w_obj*objects + w_ws*workspace + w_ee*ee  (a zero weight skips the term);
+ * gq = d cost[b,h] / d q[b,h,:] (samples are independent, so this equals the gradient of
+ * cost.sum()).  cost_sum (nullable): DEVICE float[1], incremented by sum(cost) with one
+ * wave-reduced atomic per wavefront -- the partial a multi-GPU caller all-reduces.
+ * The cost model's link indices refer to the robot's L links (n_links_in == L).
+ * --------------------------------------------------------------------------------- */
+typedef struct TrkRolloutWeights {
+    float w_self, w_obj, w_ws, w_ee;
+} TrkRolloutWeights;
+
+int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const TrkRolloutWeights* w,
+                          const float* q, int64_t batch, int32_t horizon,
+                          float* link_pos_out, float* cost, float* gq, float* cost_sum,
+                          trk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * SDF grid precompute (GridMapSDF.precompute_sdf grid_map_sdf.py:34-63): evaluates the analytic
+ * objects of `cm` and their gradient at the linspace voxel centres.
+ * -> sdf [nx,ny,nz], grad [nx,ny,nz,3] (device, caller-allocated). */
+int trk_grid_precompute(const TrkCostModel* cm, const int32_t dims[3], const float lim_min[3],
+                        const float lim_max[3], float* sdf, float* grad, trk_stream_t stream);
+
+/* Signed distance of arbitrary points to the cost model's objects:
+ * reference: ObjectField.compute_signed_distance primitives.py:387-405 (per object) -> sdf [N, n_objects]
+ * points [N,3]. grad (nullable) [N, n_objects, 3]. */
+int trk_sdf_points(const TrkCostModel* cm, const float* points, int64_t n, float* sdf, float* grad,
+                   trk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRK_H */

@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE: ctypes wrapper over oracle/_build/liboracle.so (the C restatement).
+
+Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.
+The product package never imports this module.
+
+The model / cost descriptions are the same `TrkKinModelDesc` / `TrkCostModelDesc` bytes the
+HIP library receives (torch_robotics_amd/_abi.py), so both sides see identical inputs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from torch_robotics_amd import _abi
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "_build" / "liboracle.so"
+_lib = None
+
+
+def build() -> Path:
+    subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            build()
+        _lib = C.CDLL(str(_LIB_PATH))
+        _lib.orc_max_threads.restype = C.c_int
+    return _lib
+
+
+def _dt(prec):
+    return (np.float32, C.c_float, "_f32") if prec == "f32" else (np.float64, C.c_double, "_f64")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(int(n))
+
+
+class Oracle:
+    """Bound to one KinModel (+ optional CostModelSpec with host grid arrays)."""
+
+    def __init__(self, model, cost_spec=None):
+        self.model = model
+        self.kd, self._keep = _abi.kin_desc(model)
+        self.cd = None
+        if cost_spec is not None:
+            self.set_cost(cost_spec)
+
+    def refresh_model(self):
+        self.kd, self._keep = _abi.kin_desc(self.model)
+
+    def set_cost(self, spec):
+        grid_ptrs = None
+        self._grid_keep = None
+        if spec.grid is not None:
+            sdf = np.ascontiguousarray(np.asarray(spec.grid["sdf"], np.float32))
+            grad = np.ascontiguousarray(np.asarray(spec.grid["grad"], np.float32))
+            self._grid_keep = (sdf, grad)
+            grid_ptrs = (sdf.ctypes.data, grad.ctypes.data)
+        self.spec = spec
+        self.cd, self._ckeep = _abi.cost_desc(spec, grid_ptrs)
+
+    # ------------------------------------------------------------------ FK
+    def fk(self, q, prec="f32", ref_order=False):
+        npdt, _, suf = _dt(prec)
+        q = np.ascontiguousarray(q, npdt).reshape(-1, self.model.n_dofs)
+        n = q.shape[0]
+        H = np.empty((n, self.model.n_links, 4, 4), npdt)
+        fn = getattr(lib(), ("orc_fk_ref_order" if ref_order else "orc_fk") + suf)
+        fn(C.byref(self.kd), _p(q), C.c_int64(n), _p(H))
+        return H
+
+    def fk_backward(self, q, gH, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        q = np.ascontiguousarray(q, npdt).reshape(-1, self.model.n_dofs)
+        gH = np.ascontiguousarray(gH, npdt).reshape(q.shape[0], self.model.n_links, 4, 4)
+        gq = np.empty_like(q)
+        getattr(lib(), "orc_fk_backward" + suf)(C.byref(self.kd), _p(q), _p(gH), C.c_int64(q.shape[0]), _p(gq))
+        return gq
+
+    def jacobian(self, q, qd, link, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        D = self.model.n_dofs
+        q = np.ascontiguousarray(q, npdt).reshape(-1, D)
+        n = q.shape[0]
+        qd_a = None if qd is None else np.ascontiguousarray(qd, npdt).reshape(n, D)
+        pos, quat = np.empty((n, 3), npdt), np.empty((n, 4), npdt)
+        lin, ang = np.empty((n, 3, D), npdt), np.empty((n, 3, D), npdt)
+        vl, va = np.empty((n, 3), npdt), np.empty((n, 3), npdt)
+        getattr(lib(), "orc_fk_jacobian" + suf)(
+            C.byref(self.kd), _p(q), None if qd_a is None else _p(qd_a), C.c_int64(n), C.c_int(int(link)),
+            _p(pos), _p(quat), _p(lin), _p(ang), _p(vl), _p(va))
+        return pos, quat, lin, ang, vl, va
+
+    @staticmethod
+    def rotmat_to_quat(R, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        R = np.ascontiguousarray(R, npdt).reshape(-1, 9)
+        out = np.empty((R.shape[0], 4), npdt)
+        getattr(lib(), "orc_rotmat_to_quat" + suf)(_p(R), C.c_int64(R.shape[0]), _p(out))
+        return out
+
+    # --------------------------------------------------------------- costs
+    def cost_fields(self, fields, link_pos, prec="f32", grad=True):
+        npdt, _, suf = _dt(prec)
+        Lin = self.spec.n_links_in
+        pos = np.ascontiguousarray(link_pos, npdt).reshape(-1, Lin, 3)
+        n = pos.shape[0]
+        cost = np.empty(n, npdt)
+        g = np.empty_like(pos) if grad else None
+        getattr(lib(), "orc_cost_fields" + suf)(C.byref(self.cd), C.c_int(fields), _p(pos), C.c_int64(n),
+                                                _p(cost), None if g is None else _p(g))
+        return (cost, g) if grad else cost
+
+    def collision_fields(self, fields, link_pos, margin=None, prec="f32"):
+        npdt, ct, suf = _dt(prec)
+        Lin = self.spec.n_links_in
+        pos = np.ascontiguousarray(link_pos, npdt).reshape(-1, Lin, 3)
+        out = np.empty(pos.shape[0], np.uint8)
+        getattr(lib(), "orc_collision_fields" + suf)(C.byref(self.cd), C.c_int(fields), _p(pos),
+                                                     C.c_int64(pos.shape[0]),
+                                                     ct(float("nan") if margin is None else margin), _p(out))
+        return out.astype(bool)
+
+    def ee_cost(self, H, target=None, prec="f32", grad=True):
+        npdt, _, suf = _dt(prec)
+        H = np.ascontiguousarray(H, npdt).reshape(-1, 4, 4)
+        n = H.shape[0]
+        per_sample, tgt = 0, None
+        if target is not None:
+            tgt = np.ascontiguousarray(target, npdt)
+            per_sample = int(tgt.ndim == 3)
+        cost = np.empty(n, npdt)
+        gH = np.empty_like(H) if grad else None
+        getattr(lib(), "orc_ee_cost" + suf)(C.byref(self.cd), _p(H), C.c_int64(n),
+                                            None if tgt is None else _p(tgt), C.c_int(per_sample),
+                                            _p(cost), None if gH is None else _p(gH))
+        return (cost, gH) if grad else cost
+
+    def rollout(self, q, weights, prec="f32", want_pos=True):
+        npdt, _, suf = _dt(prec)
+        D, L = self.model.n_dofs, self.model.n_links
+        q = np.ascontiguousarray(q, npdt).reshape(-1, D)
+        n = q.shape[0]
+        w = _abi.RolloutWeights(*[float(v) for v in weights])
+        pos = np.empty((n, L, 3), npdt) if want_pos else None
+        cost, gq = np.empty(n, npdt), np.empty((n, D), npdt)
+        getattr(lib(), "orc_rollout" + suf)(C.byref(self.kd), C.byref(self.cd), C.byref(w), _p(q), C.c_int64(n),
+                                            None if pos is None else _p(pos), _p(cost), _p(gq))
+        return pos, cost, gq
+
+    def grid_precompute(self, dims, lim_min, lim_max, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        dims_a = np.ascontiguousarray(dims, np.int32)
+        lo, hi = np.ascontiguousarray(lim_min, npdt), np.ascontiguousarray(lim_max, npdt)
+        sdf = np.empty(tuple(int(d) for d in dims_a), npdt)
+        grad = np.empty(sdf.shape + (3,), npdt)
+        getattr(lib(), "orc_grid_precompute" + suf)(C.byref(self.cd), _p(dims_a), _p(lo), _p(hi), _p(sdf), _p(grad))
+        return sdf, grad
+
+    def sdf_points(self, pts, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        pts = np.ascontiguousarray(pts, npdt).reshape(-1, 3)
+        no = len(self.spec.objects)
+        sdf = np.empty((pts.shape[0], no), npdt)
+        grad = np.empty((pts.shape[0], no, 3), npdt)
+        getattr(lib(), "orc_sdf_points" + suf)(C.byref(self.cd), _p(pts), C.c_int64(pts.shape[0]), _p(sdf), _p(grad))
+        return sdf, grad

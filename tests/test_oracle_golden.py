@@ -1,0 +1,176 @@
+"""Pins the CPU oracle (oracle/oracle.c) against golden vectors produced by the reference itself.
+
+CPU-only.  Every check compares the C restatement, in fp32 and fp64, with the reference's fp32
+outputs stored under tests/golden/ (generator: oracle/gen_golden.py).  Tolerances are fp32
+round-off: the reference composes poses right-to-left through O(L^2) products
+(rigid_body.py:200-211), the oracle walks the chain once, so the last ulps differ.
+"""
+import numpy as np
+import pytest
+
+from helpers import ROBOTS, gold, model, panda_cost_spec, rel_err
+from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+
+TOL_H = 2e-6        # |dH| relative to max(1, |translation|)
+TOL_G = 5e-6        # gradient, relative to its max magnitude
+TOL_C = 2e-6        # costs, relative
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_fk_forward_backward(oracle_lib, robot, prec):
+    g = gold(f"fk_{robot}")
+    o = oracle_lib.Oracle(model(robot))
+    for tag in ("in", "out"):       # "out": q beyond the joint limits -> exercises clamp + zero gradient
+        q, Hg = g[f"q_{tag}"], g[f"H_{tag}"]
+        scale = max(1.0, float(np.abs(Hg[..., :3, 3]).max()))
+        H = o.fk(q, prec)
+        assert np.abs(H - Hg).max() / scale < TOL_H
+        np.testing.assert_array_equal(H[..., 3, :], np.broadcast_to([0, 0, 0, 1], H[..., 3, :].shape))
+        gq = o.fk_backward(q, g[f"w_{tag}"], prec)
+        assert rel_err(gq, g[f"gq_{tag}"]) < TOL_G
+        if tag == "out":            # clamped joints get exactly zero gradient, like torch.clamp
+            m = o.model
+            lo, hi = m.lower[m.controlled], m.upper[m.controlled]
+            cl = m.clamp[m.controlled].astype(bool)
+            outside = ((q < lo) | (q > hi)) & cl
+            assert outside.any()
+            assert np.all(gq[outside] == 0) and np.all(g["gq_out"][outside] == 0)
+
+
+@pytest.mark.parametrize("robot", ["panda_arm_no_gripper", "allegro_hand", "hab_stretch"])
+def test_fk_reference_association_order(oracle_lib, robot):
+    """The O(L^2) right-to-left variant (the reference's own association) agrees as well."""
+    g = gold(f"fk_{robot}")
+    o = oracle_lib.Oracle(model(robot))
+    Hg = g["H_in"]
+    scale = max(1.0, float(np.abs(Hg[..., :3, 3]).max()))
+    assert np.abs(o.fk(g["q_in"], "f32", ref_order=True) - Hg).max() / scale < TOL_H
+
+
+def test_panda_known_answers(oracle_lib):
+    """KATs from SURVEY.md section 4 (q = 0; joint 4 clamps to -0.0698)."""
+    o = oracle_lib.Oracle(model("panda_arm_no_gripper"))
+    H = o.fk(np.zeros((1, 7), np.float32), "f32")[0]
+    exp = {1: (0, 0, 0.333), 3: (0, 0, 0.649), 4: (0.0825, 0, 0.649), 5: (0.026982, 0, 1.037819),
+           7: (0.114768, 0, 1.031681), 9: (0.107306, 0, 0.924942), 10: (0.100331, 0, 0.825185)}
+    for link, p in exp.items():
+        np.testing.assert_allclose(H[link, :3, 3], p, atol=2e-6)
+    np.testing.assert_allclose(H[10, 0, :3], (-0.704823, 0.705946, -0.069743), atol=2e-6)
+
+
+@pytest.mark.parametrize("robot", ["panda_arm_no_gripper", "ur10", "iiwa7"])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_stateful_fk_and_geometric_jacobian(oracle_lib, robot, prec):
+    g = gold(f"jac_{robot}")
+    m = model(robot)
+    o = oracle_lib.Oracle(m)
+    for k, link in enumerate(g["links"]):
+        pos, quat, lin, ang, vl, va = o.jacobian(g["q"], g["qd"], m.name_to_idx[str(link)], prec)
+        assert np.abs(pos - g[f"pos_{k}"]).max() < 2e-6
+        assert np.abs(quat - g[f"quat_{k}"]).max() < 2e-6
+        assert np.abs(lin - g[f"lin_{k}"]).max() < 3e-6
+        assert np.abs(ang - g[f"ang_{k}"]).max() < 2e-6
+        assert np.abs(vl - g[f"vel_lin_{k}"]).max() < 2e-6
+        assert np.abs(va - g[f"vel_ang_{k}"]).max() < 2e-6
+
+
+def test_rotation_matrix_to_quaternion(oracle_lib):
+    g = gold("quat")
+    for prec in ("f32", "f64"):
+        q = oracle_lib.Oracle.rotmat_to_quat(g["R"], prec)
+        # the 4 exact 180-degree matrices at the end sit on argmax ties; compare up to sign there
+        err = np.minimum(np.abs(q - g["q_wxyz"]).max(-1), np.abs(q + g["q_wxyz"]).max(-1))
+        assert err[:-4].max() < 2e-6 and np.abs(q[:-4] - g["q_wxyz"][:-4]).max() < 2e-6
+        assert err[-4:].max() < 2e-6
+
+
+ENVS = ["spheres3d", "spheres3d_grid", "table_shelf", "maze_boxes3d", "spheres3d_extra"]
+
+
+@pytest.mark.parametrize("env", ENVS)
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_collision_fields(oracle_lib, env, prec):
+    robot, g = gold("panda_robot"), gold(f"cost_{env}")
+    o = oracle_lib.Oracle(model("panda_arm_no_gripper"), panda_cost_spec(g, robot))
+    pos = robot["fk_map_collision"].reshape(-1, 11, 3)
+    for fname, fl in (("self", FIELD_SELF), ("objects", FIELD_OBJECTS), ("ws", FIELD_WS)):
+        c, gp = o.cost_fields(fl, pos, prec)
+        assert rel_err(c, g[f"cost_{fname}"].reshape(-1)) < TOL_C, fname
+        assert rel_err(gp, g[f"gpos_{fname}"].reshape(-1, 11, 3)) < TOL_G, fname
+        if prec == "f32":           # booleans: bit-exact in the reference's own precision
+            np.testing.assert_array_equal(o.collision_fields(fl, pos), g[f"coll_{fname}"].reshape(-1))
+            np.testing.assert_array_equal(o.collision_fields(fl, pos, margin=0.0), g[f"coll0_{fname}"].reshape(-1))
+    if "cost_extra" in g:
+        o2 = oracle_lib.Oracle(model("panda_arm_no_gripper"), panda_cost_spec(g, robot, which="extra"))
+        c, gp = o2.cost_fields(FIELD_OBJECTS, pos, prec)
+        assert rel_err(c, g["cost_extra"].reshape(-1)) < TOL_C
+        assert rel_err(gp, g["gpos_extra"].reshape(-1, 11, 3)) < TOL_G
+    # PlanningTask.compute_collision_cost (+ backward to q) == fused rollout with weights (1,1,1,0)
+    pos_r, c, gq = o.rollout(g["q"].reshape(-1, 7), (1, 1, 1, 0), prec)
+    assert np.abs(pos_r - pos).max() < 2e-6
+    assert rel_err(c, g["cost_total"].reshape(-1)) < TOL_C
+    assert rel_err(gq, g["gq_total"].reshape(-1, 7)) < TOL_G
+    for fname, w in (("self", (1, 0, 0, 0)), ("objects", (0, 1, 0, 0)), ("ws", (0, 0, 1, 0))):
+        _, _, gq = o.rollout(g["q"].reshape(-1, 7), w, prec)
+        assert rel_err(gq, g[f"gq_{fname}"].reshape(-1, 7)) < TOL_G, fname
+    if prec == "f32":
+        all_f = FIELD_SELF | FIELD_OBJECTS | FIELD_WS
+        np.testing.assert_array_equal(o.collision_fields(all_f, pos), g["coll_total"].reshape(-1))
+        np.testing.assert_array_equal(o.collision_fields(all_f, pos, margin=0.0), g["coll0_total"].reshape(-1))
+
+
+def test_grid_precompute_matches_reference_grid(oracle_lib):
+    """GridMapSDF.precompute_sdf (grid_map_sdf.py:34-63): values and stored gradients."""
+    robot, g = gold("panda_robot"), gold("cost_spheres3d_grid")
+    ga = gold("cost_spheres3d")      # analytic scene with the same objects
+    o = oracle_lib.Oracle(model("panda_arm_no_gripper"), panda_cost_spec(ga, robot))
+    sdf, grad = o.grid_precompute(g["grid_cmap_dim"], g["limits"][0], g["limits"][1])
+    assert np.abs(sdf - g["grid_sdf"]).max() < 2e-6
+    # gradient flips between equidistant spheres on ties: compare where the argmin is unambiguous
+    diff = np.abs(grad - g["grid_grad"]).max(-1)
+    assert (diff < 1e-5).mean() > 0.999
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_ee_se3_cost(oracle_lib, prec):
+    g, robot = gold("cost_ee"), gold("panda_robot")
+    m = model("panda_arm_no_gripper")
+    gs = gold("cost_spheres3d")
+    q = g["q"].reshape(-1, 7)
+    for k in range(4):
+        target = g[f"target_{k}"]
+        for sq in (True, False):
+            for wp, wr in ((1.0, 1.0), (2.0, 0.5)):
+                key = f"t{k}_sq{int(sq)}_w{wp}_{wr}"
+                spec = panda_cost_spec(gs, robot, ee_target=np.eye(4, dtype=np.float32),
+                                       ee_kw=dict(ee_w_pos=wp, ee_w_rot=wr, ee_square=sq))
+                o = oracle_lib.Oracle(m, spec)
+                H = o.fk(q, prec)
+                c, gH = o.ee_cost(H[:, -1], target, prec)
+                assert rel_err(c, g["cost_" + key]) < 5e-6, key
+                gH_ref = g["gH_" + key][:, -1]
+                assert rel_err(gH[:, :3, :], gH_ref[:, :3, :]) < 1e-5, key
+                if target.ndim == 2:     # single target: also through the fused rollout
+                    spec.ee_target = target
+                    o.set_cost(spec)
+                    _, c2, gq = o.rollout(q, (0, 0, 0, 1), prec)
+                    assert rel_err(c2, g["cost_" + key]) < 5e-6, key
+                    assert rel_err(gq, g["gq_" + key]) < 2e-5, key
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_rollout_bench_shapes(oracle_lib, prec):
+    """BASELINE configs 2 (objects + EE) and 3 (self + objects + ws + EE) on a (6, 64, 7) batch."""
+    g, robot = gold("rollout_panda"), gold("panda_robot")
+    gs = gold("cost_spheres3d")
+    spec = panda_cost_spec(gs, robot, ee_target=g["target"])
+    o = oracle_lib.Oracle(model("panda_arm_no_gripper"), spec)
+    q = g["q"].reshape(-1, 7)
+    pos, c2, g2 = o.rollout(q, (0, 1, 0, 1), prec)
+    assert np.abs(pos - g["pos"].reshape(-1, 11, 3)).max() < 2e-6
+    assert rel_err(c2, g["cost_c2"].reshape(-1)) < 5e-6
+    assert rel_err(g2, g["gq_c2"].reshape(-1, 7)) < 2e-5
+    _, c3, g3 = o.rollout(q, (1, 1, 1, 1), prec)
+    assert rel_err(c3, g["cost_c3"].reshape(-1)) < 5e-6
+    assert rel_err(g3, g["gq_c3"].reshape(-1, 7)) < 2e-5

@@ -1,0 +1,91 @@
+"""Host-side description of the planning objectives handed to the HIP kernels.
+
+A `CostModelSpec` is the flat form of what the reference spreads over
+`RobotBase` (collision link indices, margins, self-collision pair table --
+robots/robot_base.py:57-141), the environment's `ObjectField`s / `GridMapSDF`
+(environments/primitives.py, grid_map_sdf.py), the workspace box
+(tasks.py:71-82) and `EESE3DistanceField` (distance_fields.py:335-359).
+It maps 1:1 onto `TrkCostModelDesc` (include/trk.h).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from ._abi import PRIM_ROUNDED_BOX, PRIM_SHARP_BOX, PRIM_SPHERE
+
+
+def sphere_prims(centers, radii) -> List[dict]:
+    """MultiSphereField(centers, radii) primitives.py:90-112."""
+    centers = np.asarray(centers, np.float32).reshape(-1, 3)
+    radii = np.broadcast_to(np.asarray(radii, np.float32).reshape(-1), (centers.shape[0],))
+    return [dict(type=PRIM_SPHERE, center=c, radius=r) for c, r in zip(centers, radii)]
+
+
+def box_prims(centers, sizes, rounded=True) -> List[dict]:
+    """MultiBoxField (rounded, radius = 0.15*min(size), primitives.py:315-334) or
+    MultiSharpBoxField (primitives.py:199-223).  Arithmetic in fp32 like the reference."""
+    centers = np.asarray(centers, np.float32).reshape(-1, 3)
+    sizes = np.asarray(sizes, np.float32).reshape(-1, 3)
+    half = sizes / np.float32(2)
+    prims = []
+    for c, s, h in zip(centers, sizes, half):
+        if rounded:
+            prims.append(dict(type=PRIM_ROUNDED_BOX, center=c, half=h,
+                              radius=np.float32(s.min() * np.float32(0.15))))
+        else:
+            prims.append(dict(type=PRIM_SHARP_BOX, center=c, half=h, radius=np.float32(0)))
+    return prims
+
+
+def make_object(prims: List[dict], pos=None, R=None) -> dict:
+    """ObjectField(primitive_fields, pos, ori) primitives.py:346-405 with `ori` already a rotation matrix."""
+    return dict(pos=np.zeros(3, np.float32) if pos is None else np.asarray(pos, np.float32).reshape(3),
+                R=np.eye(3, dtype=np.float32) if R is None else np.asarray(R, np.float32).reshape(3, 3),
+                prims=list(prims), is_grid=0)
+
+
+def grid_object() -> dict:
+    return dict(pos=np.zeros(3, np.float32), R=np.eye(3, dtype=np.float32), prims=[], is_grid=1)
+
+
+@dataclass
+class CostModelSpec:
+    n_links_in: int
+    obj_link_idx: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    obj_link_margin: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    objects: List[dict] = field(default_factory=list)
+    grid: Optional[dict] = None          # dims[3], lim_min[3], map_dim[3], sdf, grad (arrays/tensors)
+    ws_min: Optional[np.ndarray] = None
+    ws_max: Optional[np.ndarray] = None
+    self_link_idx: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    self_pairs: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.int32))
+    self_margin: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    ee_link: int = -1
+    ee_w_pos: float = 1.0
+    ee_w_rot: float = 1.0
+    ee_square: bool = True
+    ee_target: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
+
+    def validate(self) -> None:
+        L = self.n_links_in
+        for name in ("obj_link_idx", "self_link_idx"):
+            idx = np.asarray(getattr(self, name))
+            if idx.size and (idx.min() < 0 or idx.max() >= L):
+                raise ValueError(f"{name} out of range for {L} links")
+        if len(self.obj_link_idx) != len(self.obj_link_margin):
+            raise ValueError("obj_link_idx / obj_link_margin length mismatch")
+        pairs = np.asarray(self.self_pairs).reshape(-1, 2)
+        if pairs.shape[0] != len(self.self_margin):
+            raise ValueError("self_pairs / self_margin length mismatch")
+        if pairs.size and (pairs.min() < 0 or pairs.max() >= len(self.self_link_idx)):
+            raise ValueError("self_pairs index out of range")
+        if self.ee_link >= L:
+            raise ValueError("ee_link out of range")
+        if (self.ws_min is None) != (self.ws_max is None):
+            raise ValueError("ws_min and ws_max must be given together")
+        n_grid = sum(int(o.get("is_grid", 0)) for o in self.objects)
+        if n_grid > 1 or (n_grid == 1) != (self.grid is not None):
+            raise ValueError("exactly one grid object is required when `grid` is set")
