@@ -1,0 +1,290 @@
+"""GPU parity: the HIP kernels, called through the C ABI (ctypes -> libtrk.so), against
+(a) golden vectors produced by the reference itself and (b) the fp64 CPU oracle on fresh seeded inputs.
+
+Tolerances (fp32): |dH| <= 2e-6 * max(1,|t|), cost rel 1e-5, gradient rel 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROBOTS, gold, model, panda_cost_spec, rel_err
+from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+
+pytestmark = pytest.mark.gpu
+
+TOL_H, TOL_C, TOL_G = 2e-6, 1e-5, 1e-4
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from torch_robotics_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_fk_forward_backward_vs_golden(ops, robot):
+    g = gold(f"fk_{robot}")
+    h = ops.ModelHandle(model(robot))
+    for tag in ("in", "out"):
+        Hg = g[f"H_{tag}"]
+        scale = max(1.0, float(np.abs(Hg[..., :3, 3]).max()))
+        H = ops.fk_forward(h, dev(g[f"q_{tag}"])).cpu().numpy()
+        assert np.abs(H - Hg).max() / scale < TOL_H
+        np.testing.assert_array_equal(H[..., 3, :], np.broadcast_to([0, 0, 0, 1], H[..., 3, :].shape))
+        gq = ops.fk_backward(h, dev(g[f"q_{tag}"]), dev(g[f"w_{tag}"])).cpu().numpy()
+        assert rel_err(gq, g[f"gq_{tag}"]) < TOL_G
+        if tag == "out":
+            assert np.all(gq[g["gq_out"] == 0] == 0)      # clamp kills the gradient exactly
+    # link subset, in the caller's order
+    m = h.kin
+    sel = [m.name_to_idx[str(s)] for s in g["sel_names"]]
+    Hs = ops.fk_forward(h, dev(g["q_in"]), sel).cpu().numpy()
+    assert np.abs(Hs - g["H_sel"]).max() / scale < TOL_H
+    pos = ops.fk_positions(h, dev(g["q_in"]), sel).cpu().numpy()
+    assert np.abs(pos - g["H_sel"][..., :3, 3]).max() / scale < TOL_H
+    # backward restricted to the subset == full backward with zeros elsewhere
+    w = g["w_in"][:, sel]
+    wfull = np.zeros_like(g["w_in"]); wfull[:, sel] = w
+    gq_a = ops.fk_backward(h, dev(g["q_in"]), dev(w), sel).cpu().numpy()
+    gq_b = ops.fk_backward(h, dev(g["q_in"]), dev(wfull)).cpu().numpy()
+    np.testing.assert_allclose(gq_a, gq_b, rtol=1e-5, atol=1e-5)
+    gq_p = ops.fk_positions_backward(h, dev(g["q_in"]), dev(w[..., :3, 3]), sel).cpu().numpy()
+    wpos = np.zeros_like(wfull); wpos[:, sel, :3, 3] = w[..., :3, 3]
+    gq_pb = ops.fk_backward(h, dev(g["q_in"]), dev(wpos)).cpu().numpy()
+    np.testing.assert_allclose(gq_p, gq_pb, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("robot", ["panda_arm_no_gripper", "ur10_allegro", "hab_stretch"])
+def test_fk_vs_fp64_oracle_ragged(ops, oracle_lib, robot):
+    """Fresh seeded inputs, batch sizes that are not multiples of the 64-lane wavefront."""
+    m = model(robot)
+    h, o = ops.ModelHandle(m), oracle_lib.Oracle(m)
+    rng = np.random.default_rng(7)
+    for n in (1, 63, 65, 1000):
+        q = rng.uniform(-3.2, 3.2, size=(n, m.n_dofs)).astype(np.float32)
+        w = rng.standard_normal((n, m.n_links, 4, 4)).astype(np.float32)
+        H64 = o.fk(q.astype(np.float64), "f64")
+        scale = max(1.0, float(np.abs(H64[..., :3, 3]).max()))
+        H = ops.fk_forward(h, dev(q)).cpu().numpy()
+        assert np.abs(H - H64).max() / scale < TOL_H
+        gq = ops.fk_backward(h, dev(q), dev(w)).cpu().numpy()
+        assert rel_err(gq, o.fk_backward(q.astype(np.float64), w.astype(np.float64), "f64")) < TOL_G
+    assert ops.fk_forward(h, torch.empty((0, m.n_dofs), device=DEV)).shape == (0, m.n_links, 4, 4)
+
+
+def test_fk_autograd_matches_golden(ops):
+    g = gold("fk_panda_arm_no_gripper")
+    h = ops.ModelHandle(model("panda_arm_no_gripper"))
+    q = dev(g["q_out"]).requires_grad_(True)
+    H = ops.fk(h, q)
+    (H * dev(g["w_out"])).sum().backward()
+    assert rel_err(q.grad.cpu().numpy(), g["gq_out"]) < TOL_G
+
+
+def test_base_pose(ops, oracle_lib):
+    m = model("panda_arm_no_gripper")
+    m.set_base_pose([0.3, -0.2, 0.1, 0.9238795, 0.0, 0.0, 0.3826834])
+    h, o = ops.ModelHandle(m), oracle_lib.Oracle(m)
+    q = np.random.default_rng(1).uniform(-2, 2, (17, 7)).astype(np.float32)
+    assert np.abs(ops.fk_forward(h, dev(q)).cpu().numpy() - o.fk(q.astype(np.float64), "f64")).max() < TOL_H
+    m.reset_base_pose()
+    h.set_base_pose(m.base_R, m.base_t)
+    o.refresh_model()
+    assert np.abs(ops.fk_forward(h, dev(q)).cpu().numpy() - o.fk(q.astype(np.float64), "f64")).max() < TOL_H
+
+
+@pytest.mark.parametrize("robot", ["panda_arm_no_gripper", "ur10", "iiwa7"])
+def test_stateful_fk_and_jacobian(ops, robot):
+    g = gold(f"jac_{robot}")
+    m = model(robot)
+    h = ops.ModelHandle(m)
+    for k, link in enumerate(g["links"]):
+        pos, quat, lin, ang, vl, va = [t.cpu().numpy() for t in
+                                       ops.fk_jacobian(h, dev(g["q"]), dev(g["qd"]), m.name_to_idx[str(link)], want_vel=True)]
+        assert np.abs(pos - g[f"pos_{k}"]).max() < 2e-6
+        assert np.abs(quat - g[f"quat_{k}"]).max() < 2e-6
+        assert np.abs(lin - g[f"lin_{k}"]).max() < 3e-6
+        assert np.abs(ang - g[f"ang_{k}"]).max() < 2e-6
+        assert np.abs(vl - g[f"vel_lin_{k}"]).max() < 2e-6
+        assert np.abs(va - g[f"vel_ang_{k}"]).max() < 2e-6
+
+
+def test_jacobian_tree_vs_oracle(ops, oracle_lib):
+    m = model("ur10_allegro")
+    h, o = ops.ModelHandle(m), oracle_lib.Oracle(m)
+    rng = np.random.default_rng(3)
+    q = rng.uniform(-1.5, 1.5, (70, m.n_dofs)).astype(np.float32)
+    qd = rng.standard_normal((70, m.n_dofs)).astype(np.float32)
+    for link in (m.n_links - 1, 12, 5):
+        got = [t.cpu().numpy() for t in ops.fk_jacobian(h, dev(q), dev(qd), link, want_vel=True)]
+        ref = o.jacobian(q.astype(np.float64), qd.astype(np.float64), link, "f64")
+        for a, b in zip(got, ref):
+            assert np.abs(a - b).max() < 5e-6
+
+
+def test_rotmat_to_quat(ops):
+    g = gold("quat")
+    q = ops.rotmat_to_quat(dev(g["R"])).cpu().numpy()
+    assert np.abs(q[:-4] - g["q_wxyz"][:-4]).max() < 2e-6
+    err = np.minimum(np.abs(q - g["q_wxyz"]).max(-1), np.abs(q + g["q_wxyz"]).max(-1))
+    assert err.max() < 2e-6
+    H = np.tile(np.eye(4, dtype=np.float32), (len(g["R"]), 1, 1)); H[:, :3, :3] = g["R"]
+    q2 = ops.rotmat_to_quat(dev(H)).cpu().numpy()
+    np.testing.assert_array_equal(q, q2)
+
+
+ENVS = ["spheres3d", "spheres3d_grid", "table_shelf", "maze_boxes3d", "spheres3d_extra"]
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_collision_fields_vs_golden(ops, env):
+    robot, g = gold("panda_robot"), gold(f"cost_{env}")
+    spec = panda_cost_spec(g, robot)
+    cm = ops.CostHandle(spec, DEV)
+    h = ops.ModelHandle(model("panda_arm_no_gripper"))
+    q = dev(g["q"].reshape(-1, 7))
+    pos = ops.fk_positions(h, q)
+    assert np.abs(pos.cpu().numpy() - robot["fk_map_collision"].reshape(-1, 11, 3)).max() < TOL_H
+    pos_g = dev(robot["fk_map_collision"].reshape(-1, 11, 3))
+    for fname, fl in (("self", FIELD_SELF), ("objects", FIELD_OBJECTS), ("ws", FIELD_WS)):
+        c, gp = ops.cost_fields(cm, fl, pos_g, want_grad=True)
+        assert rel_err(c.cpu().numpy(), g[f"cost_{fname}"].reshape(-1)) < TOL_C, fname
+        assert rel_err(gp.cpu().numpy(), g[f"gpos_{fname}"].reshape(-1, 11, 3)) < TOL_G, fname
+        np.testing.assert_array_equal(ops.collision_fields(cm, fl, pos_g).cpu().numpy(), g[f"coll_{fname}"].reshape(-1))
+        np.testing.assert_array_equal(ops.collision_fields(cm, fl, pos_g, margin=0.0).cpu().numpy(),
+                                      g[f"coll0_{fname}"].reshape(-1))
+        # autograd chain FK -> field -> sum, like the reference's cost.sum().backward()
+        qq = q.clone().requires_grad_(True)
+        cost = ops.cost_fields_ad(cm, fl, ops.fk_pos(h, qq))
+        cost.sum().backward()
+        assert rel_err(qq.grad.cpu().numpy(), g[f"gq_{fname}"].reshape(-1, 7)) < TOL_G, fname
+    allf = FIELD_SELF | FIELD_OBJECTS | FIELD_WS
+    c = ops.cost_fields(cm, allf, pos_g)
+    assert rel_err(c.cpu().numpy(), g["cost_total"].reshape(-1)) < TOL_C
+    np.testing.assert_array_equal(ops.collision_fields(cm, allf, pos_g).cpu().numpy(), g["coll_total"].reshape(-1))
+    np.testing.assert_array_equal(ops.collision_fields(cm, allf, pos_g, margin=0.0).cpu().numpy(), g["coll0_total"].reshape(-1))
+    # fused rollout == PlanningTask.compute_collision_cost + backward
+    pos_r, cost, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 0), q)
+    assert np.abs(pos_r.cpu().numpy() - robot["fk_map_collision"].reshape(-1, 11, 3)).max() < TOL_H
+    assert rel_err(cost.cpu().numpy(), g["cost_total"].reshape(-1)) < TOL_C
+    assert rel_err(gq.cpu().numpy(), g["gq_total"].reshape(-1, 7)) < TOL_G
+    if "cost_extra" in g:
+        cm2 = ops.CostHandle(panda_cost_spec(g, robot, which="extra"), DEV)
+        c, gp = ops.cost_fields(cm2, FIELD_OBJECTS, pos_g, want_grad=True)
+        assert rel_err(c.cpu().numpy(), g["cost_extra"].reshape(-1)) < TOL_C
+        assert rel_err(gp.cpu().numpy(), g["gpos_extra"].reshape(-1, 11, 3)) < TOL_G
+
+
+def test_grid_precompute_and_sdf_points(ops, oracle_lib):
+    robot, g, ga = gold("panda_robot"), gold("cost_spheres3d_grid"), gold("cost_spheres3d")
+    cm = ops.CostHandle(panda_cost_spec(ga, robot), DEV)
+    sdf, grad = ops.grid_precompute(cm, g["grid_cmap_dim"], g["limits"][0], g["limits"][1])
+    assert np.abs(sdf.cpu().numpy() - g["grid_sdf"]).max() < 2e-6
+    diff = np.abs(grad.cpu().numpy() - g["grid_grad"]).max(-1)
+    assert (diff < 1e-5).mean() > 0.999
+    for env in ("table_shelf", "maze_boxes3d"):
+        ge = gold(f"cost_{env}")
+        spec = panda_cost_spec(ge, robot)
+        cmh, o = ops.CostHandle(spec, DEV), oracle_lib.Oracle(model("panda_arm_no_gripper"), spec)
+        pts = np.random.default_rng(0).uniform(-1, 1.2, (500, 3)).astype(np.float32)
+        s, gr = ops.sdf_points(cmh, dev(pts), want_grad=True)
+        s64, g64 = o.sdf_points(pts.astype(np.float64), "f64")
+        assert np.abs(s.cpu().numpy() - s64).max() < 2e-6
+        assert (np.abs(gr.cpu().numpy() - g64).max(-1) < 1e-5).mean() > 0.995
+
+
+def test_ee_cost_vs_golden(ops):
+    g, robot, gs = gold("cost_ee"), gold("panda_robot"), gold("cost_spheres3d")
+    h = ops.ModelHandle(model("panda_arm_no_gripper"))
+    q = dev(g["q"].reshape(-1, 7))
+    for k in range(4):
+        target = g[f"target_{k}"]
+        for sq in (True, False):
+            for wp, wr in ((1.0, 1.0), (2.0, 0.5)):
+                key = f"t{k}_sq{int(sq)}_w{wp}_{wr}"
+                spec = panda_cost_spec(gs, robot, ee_target=target if target.ndim == 2 else np.eye(4, dtype=np.float32),
+                                       ee_kw=dict(ee_w_pos=wp, ee_w_rot=wr, ee_square=sq))
+                cm = ops.CostHandle(spec, DEV)
+                qq = q.clone().requires_grad_(True)
+                H = ops.fk(h, qq)
+                cost = ops.ee_cost_ad(cm, H[:, -1], dev(target))
+                assert rel_err(cost.detach().cpu().numpy(), g["cost_" + key]) < TOL_C, key
+                cost.sum().backward()
+                assert rel_err(qq.grad.cpu().numpy(), g["gq_" + key]) < TOL_G, key
+                _, gH = ops.ee_cost(cm, H.detach()[:, -1], dev(target), want_grad=True)
+                assert rel_err(gH.cpu().numpy()[:, :3], g["gH_" + key][:, -1, :3]) < TOL_G, key
+                if target.ndim == 2:
+                    _, c2, gq = ops.rollout_cost_grad(h, cm, (0, 0, 0, 1), q)
+                    assert rel_err(c2.cpu().numpy(), g["cost_" + key]) < TOL_C, key
+                    assert rel_err(gq.cpu().numpy(), g["gq_" + key]) < TOL_G, key
+
+
+def test_rollout_bench_shapes_vs_golden(ops):
+    g, robot, gs = gold("rollout_panda"), gold("panda_robot"), gold("cost_spheres3d")
+    cm = ops.CostHandle(panda_cost_spec(gs, robot, ee_target=g["target"]), DEV)
+    h = ops.ModelHandle(model("panda_arm_no_gripper"))
+    q = dev(g["q"])                                     # (6, 64, 7): one wavefront per trajectory
+    csum = torch.zeros(1, device=DEV)
+    pos, c2, g2 = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), q, cost_sum=csum)
+    assert pos.shape == (6, 64, 11, 3) and c2.shape == (6, 64) and g2.shape == (6, 64, 7)
+    assert np.abs(pos.cpu().numpy() - g["pos"]).max() < TOL_H
+    assert rel_err(c2.cpu().numpy(), g["cost_c2"]) < TOL_C
+    assert rel_err(g2.cpu().numpy(), g["gq_c2"]) < TOL_G
+    assert abs(csum.item() - g["cost_c2"].astype(np.float64).sum()) < 1e-4 * abs(g["cost_c2"]).sum()
+    _, c3, g3 = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q, want_pos=False)
+    assert rel_err(c3.cpu().numpy(), g["cost_c3"]) < TOL_C
+    assert rel_err(g3.cpu().numpy(), g["gq_c3"]) < TOL_G
+    # differentiable wrapper
+    qq = q.clone().requires_grad_(True)
+    cost, _ = ops.rollout_ad(h, cm, (1, 1, 1, 1), qq)
+    cost.sum().backward()
+    assert rel_err(qq.grad.cpu().numpy(), g["gq_c3"]) < TOL_G
+
+
+@pytest.mark.parametrize("robot", ["ur10_allegro", "dual_panda", "hab_stretch"])
+def test_rollout_trees_vs_fp64_oracle(ops, oracle_lib, robot):
+    """Branched / deep models (BASELINE configs 4, 5): fused kernel vs fp64 oracle, ragged N."""
+    from torch_robotics_amd.costmodel import CostModelSpec
+    m = model(robot)
+    gs, rb = gold("cost_spheres3d_extra"), gold("panda_robot")
+    base = panda_cost_spec(gs, rb)
+    rng = np.random.default_rng(11)
+    L = m.n_links
+    spec = CostModelSpec(n_links_in=L)
+    spec.obj_link_idx = np.sort(rng.choice(L, size=min(L, 9), replace=False)).astype(np.int32)
+    spec.obj_link_margin = rng.uniform(0.02, 0.12, len(spec.obj_link_idx)).astype(np.float32)
+    spec.objects = base.objects
+    spec.ws_min, spec.ws_max = np.float32([-1, -1, -1]), np.float32([1, 1, 1.2])
+    spec.self_link_idx = np.arange(0, L, 2, dtype=np.int32)
+    ns = len(spec.self_link_idx)
+    pairs = [(a, b) for a in range(ns) for b in range(a + 2, ns)][:40]
+    spec.self_pairs = np.asarray(pairs, np.int32)
+    spec.self_margin = rng.uniform(0.02, 0.08, len(pairs)).astype(np.float32)
+    spec.ee_link = L - 1
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5)
+    spec.ee_target = Ht
+    spec.validate()
+    h, cm, o = ops.ModelHandle(m), ops.CostHandle(spec, DEV), oracle_lib.Oracle(m, spec)
+    for n in (5, 64, 200):
+        q = rng.uniform(-2.5, 2.5, (n, m.n_dofs)).astype(np.float32)
+        for w in ((1, 1, 1, 1), (0, 1, 0, 1), (0.5, 2.0, 0.0, 0.25)):
+            pos, c, gq = ops.rollout_cost_grad(h, cm, w, dev(q))
+            p64, c64, g64 = o.rollout(q.astype(np.float64), w, "f64")
+            scale = max(1.0, float(np.abs(p64).max()))
+            assert np.abs(pos.cpu().numpy() - p64).max() / scale < TOL_H
+            assert rel_err(c.cpu().numpy(), c64) < TOL_C
+            assert rel_err(gq.cpu().numpy(), g64) < TOL_G
+
+
+def test_error_behaviour(ops):
+    h = ops.ModelHandle(model("panda_arm_no_gripper"))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.fk_forward(h, torch.zeros(4, 7))
+    with pytest.raises(ValueError):
+        ops.fk_forward(h, torch.zeros(4, 7, device=DEV), sel=[0, 0])
+    with pytest.raises(ValueError):
+        ops.fk_forward(h, torch.zeros(4, 7, device=DEV), sel=[99])

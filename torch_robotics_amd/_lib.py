@@ -1,0 +1,98 @@
+"""Loader for csrc/libtrk.so (the C ABI in include/trk.h).
+
+The library is the only compute path of this package.  If it is missing, cannot be loaded, or
+finds no GPU, calls raise -- there is deliberately no CPU / eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import torch  # noqa: F401  (must be imported first: libtrk.so binds to the HIP runtime torch loaded)
+
+from . import _abi
+
+_CSRC = Path(__file__).resolve().parent / "csrc"
+LIB_PATH = _CSRC / "libtrk.so"
+_lib = None
+
+EXPORTS = [
+    "trk_abi_version", "trk_last_error", "trk_model_create", "trk_model_destroy", "trk_model_set_base_pose",
+    "trk_model_n_links", "trk_model_n_dofs", "trk_model_is_specialized",
+    "trk_fk_forward", "trk_fk_positions", "trk_fk_backward", "trk_fk_positions_backward", "trk_fk_jacobian",
+    "trk_rotmat_to_quat", "trk_cost_model_create", "trk_cost_model_destroy", "trk_cost_model_set_ee_target",
+    "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_grid_precompute",
+    "trk_sdf_points",
+]
+
+
+class TrkError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> Path:
+    """Compile libtrk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    jobs = str(min(8, os.cpu_count() or 1))
+    res = subprocess.run(["make", "-C", str(_CSRC), "-j", jobs], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise TrkError(f"building libtrk.so failed:\n{res.stdout}\n{res.stderr}")
+    if verbose:
+        print(res.stdout)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise TrkError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or `make -C {_CSRC}`. There is no fallback path.")
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.trk_abi_version.restype = C.c_int
+    L.trk_last_error.restype = C.c_char_p
+    L.trk_model_create.argtypes = [C.POINTER(_abi.KinModelDesc), C.POINTER(vp)]
+    L.trk_model_destroy.argtypes = [vp]
+    L.trk_model_destroy.restype = None
+    L.trk_model_set_base_pose.argtypes = [vp, vp, vp]
+    L.trk_model_n_links.argtypes = [vp]
+    L.trk_model_n_dofs.argtypes = [vp]
+    L.trk_model_is_specialized.argtypes = [vp]
+    L.trk_fk_forward.argtypes = [vp, vp, i64, vp, i32, vp, vp]
+    L.trk_fk_positions.argtypes = [vp, vp, i64, vp, i32, vp, vp]
+    L.trk_fk_backward.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp]
+    L.trk_fk_positions_backward.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp]
+    L.trk_fk_jacobian.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.trk_rotmat_to_quat.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.trk_cost_model_create.argtypes = [C.POINTER(_abi.CostModelDesc), C.POINTER(vp)]
+    L.trk_cost_model_destroy.argtypes = [vp]
+    L.trk_cost_model_destroy.restype = None
+    L.trk_cost_model_set_ee_target.argtypes = [vp, vp]
+    L.trk_cost_fields.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp]
+    L.trk_collision_fields.argtypes = [vp, i32, vp, i64, f32, vp, vp]
+    L.trk_ee_cost.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp, vp, i64, vp]
+    L.trk_rollout_cost_grad.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, vp, vp, vp, vp, vp]
+    L.trk_grid_precompute.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.trk_sdf_points.argtypes = [vp, vp, i64, vp, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)        # AttributeError here = the library does not export the ABI
+        if name not in ("trk_last_error", "trk_model_destroy", "trk_cost_model_destroy"):
+            fn.restype = C.c_int
+    if L.trk_abi_version() != _abi.TRK_ABI_VERSION:
+        raise TrkError("libtrk.so ABI version mismatch; rebuild it")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "libtrk") -> None:
+    if rc == _abi.TRK_OK:
+        return
+    msg = lib().trk_last_error().decode("utf-8", "replace")
+    if rc == _abi.TRK_ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    if rc == _abi.TRK_ERR_INVALID_ARG:
+        raise ValueError(f"{what}: {msg}")
+    raise TrkError(f"{what}: {msg} (status {rc})")

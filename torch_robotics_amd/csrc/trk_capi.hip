@@ -1,0 +1,424 @@
+// trk_capi.hip -- C ABI of libtrk.so (include/trk.h): argument checking, model / cost-model
+// handles (host tables -> device tables, copied once), kernel launches.  No torch types here.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+#include "trk_launch.h"
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return TRK_ERR_HIP;
+}
+#define TRK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+bool g_init_done = false;
+int ensure_init() {
+    if (g_init_done) return TRK_OK;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(TRK_ERR_NO_DEVICE, "no HIP device visible (libtrk.so needs an MI355X / gfx950 GPU)");
+    }
+    if (trk_kernels_init() != 0) return fail(TRK_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    g_init_done = true;
+    return TRK_OK;
+}
+}  // namespace
+
+struct TrkModel {
+    DevModelHdr hdr;
+    std::vector<DevLink> links;     // by position
+    std::vector<int32_t> fin;
+    std::vector<int32_t> joint_list_idx;   // by link
+    DevLink* d_links = nullptr;
+    int32_t* d_fin = nullptr;
+    bool unsupported = false;
+};
+
+struct TrkCostModel {
+    DevCostHdr hdr;
+    void* d_blob = nullptr;
+};
+
+extern "C" {
+
+int trk_abi_version(void) { return TRK_ABI_VERSION; }
+const char* trk_last_error(void) { return g_err.c_str(); }
+
+int trk_model_create(const TrkKinModelDesc* d, TrkModel** out) {
+    if (!d || !out) return fail(TRK_ERR_INVALID_ARG, "trk_model_create: null argument");
+    if (d->abi_version != TRK_ABI_VERSION) return fail(TRK_ERR_INVALID_ARG, "trk_model_create: ABI version mismatch");
+    const int L = d->n_links, D = d->n_dofs;
+    if (L < 1 || L > TRK_MAX_LINKS) return fail(TRK_ERR_UNSUPPORTED, "trk_model_create: n_links out of range [1, 64]");
+    if (D < 0 || D > TRK_MAX_DOFS) return fail(TRK_ERR_UNSUPPORTED, "trk_model_create: n_dofs out of range [0, 32]");
+    if (d->n_slots < 0 || d->n_slots > TRK_MAX_POSE_SLOTS) return fail(TRK_ERR_UNSUPPORTED, "trk_model_create: too many pose slots");
+    const void* ptrs[] = {d->parent, d->joint_type, d->dof_idx, d->R_fixed, d->trans, d->axis, d->rot_axis, d->rot_sign,
+                          d->clamp, d->lower, d->upper, d->sf_rot_axis, d->sf_clamp, d->jac_axis, d->joint_list_idx,
+                          d->order, d->subtree_end, d->parent_slot, d->store_slot};
+    for (const void* p : ptrs) if (!p) return fail(TRK_ERR_INVALID_ARG, "trk_model_create: null table pointer");
+    if (d->order[0] != 0) return fail(TRK_ERR_INVALID_ARG, "trk_model_create: order[0] must be the root link 0");
+    std::vector<char> seen(L, 0), dof_seen(D > 0 ? D : 1, 0);
+    for (int p = 0; p < L; ++p) {
+        const int i = d->order[p];
+        if (i < 0 || i >= L || seen[i]) return fail(TRK_ERR_INVALID_ARG, "trk_model_create: order is not a permutation");
+        seen[i] = 1;
+        if (p > 0) {
+            const int par = d->parent[i];
+            if (par < 0 || par >= L || !seen[par]) return fail(TRK_ERR_INVALID_ARG, "trk_model_create: parent must precede child in order");
+            if (d->parent_slot[p] >= d->n_slots || d->store_slot[p] >= d->n_slots)
+                return fail(TRK_ERR_INVALID_ARG, "trk_model_create: slot index out of range");
+            if (d->parent_slot[p] < 0 && d->order[p - 1] != par)
+                return fail(TRK_ERR_INVALID_ARG, "trk_model_create: parent_slot = -1 but the previous position is not the parent");
+        }
+        if (d->subtree_end[p] <= p || d->subtree_end[p] > L) return fail(TRK_ERR_INVALID_ARG, "trk_model_create: bad subtree_end");
+        const int dof = d->dof_idx[i];
+        if (d->joint_type[i] != TRK_JOINT_FIXED) {
+            if (dof < 0 || dof >= D || dof_seen[dof]) return fail(TRK_ERR_INVALID_ARG, "trk_model_create: bad dof_idx");
+            dof_seen[dof] = 1;
+        } else if (dof >= 0) return fail(TRK_ERR_INVALID_ARG, "trk_model_create: fixed joint with a DOF");
+    }
+    int rc = ensure_init();
+    if (rc != TRK_OK) return rc;
+    TrkModel* m = new (std::nothrow) TrkModel();
+    if (!m) return fail(TRK_ERR_HIP, "out of host memory");
+    std::memset(&m->hdr, 0, sizeof(m->hdr));
+    m->hdr.n_links = L; m->hdr.n_dofs = D; m->hdr.n_slots = d->n_slots;
+    std::memcpy(m->hdr.base_R, d->base_R, sizeof(float) * 9);
+    std::memcpy(m->hdr.base_t, d->base_t, sizeof(float) * 3);
+    m->links.resize(L);
+    m->joint_list_idx.assign(d->joint_list_idx, d->joint_list_idx + L);
+    for (int p = 0; p < L; ++p) {
+        const int i = d->order[p];
+        DevLink& k = m->links[p];
+        std::memset(&k, 0, sizeof(k));
+        std::memcpy(k.Rf, d->R_fixed + 9 * i, sizeof(float) * 9);
+        std::memcpy(k.trans, d->trans + 3 * i, sizeof(float) * 3);
+        std::memcpy(k.axis, d->axis + 3 * i, sizeof(float) * 3);
+        k.lower = d->lower[i]; k.upper = d->upper[i]; k.rot_sign = d->rot_sign[i];
+        k.type = d->joint_type[i]; k.dof = d->dof_idx[i]; k.rot_axis = d->rot_axis[i]; k.clamp = d->clamp[i];
+        k.parent_slot = p == 0 ? -1 : d->parent_slot[p]; k.store_slot = d->store_slot[p]; k.link = i;
+        k.sf_rot_axis = d->sf_rot_axis[i]; k.sf_clamp = d->sf_clamp[i]; k.jac_axis = d->jac_axis[i];
+        if (k.type == TRK_JOINT_UNSUPPORTED || k.type < 0 || k.type > TRK_JOINT_UNSUPPORTED) m->unsupported = true;
+        k.fin_begin = (int32_t)m->fin.size();
+        for (int j = 0; j <= p; ++j)
+            if (m->links[j].dof >= 0 && d->subtree_end[j] == p + 1) m->fin.push_back(m->links[j].dof);
+        k.fin_end = (int32_t)m->fin.size();
+    }
+    if (m->fin.empty()) m->fin.push_back(0);
+    hipError_t e = hipMalloc(&m->d_links, sizeof(DevLink) * L);
+    if (e == hipSuccess) e = hipMalloc(&m->d_fin, sizeof(int32_t) * m->fin.size());
+    if (e == hipSuccess) e = hipMemcpy(m->d_links, m->links.data(), sizeof(DevLink) * L, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->d_fin, m->fin.data(), sizeof(int32_t) * m->fin.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (m->d_links) (void)hipFree(m->d_links);
+        if (m->d_fin) (void)hipFree(m->d_fin);
+        delete m;
+        return hip_fail(e, "trk_model_create: device allocation/copy");
+    }
+    *out = m;
+    return TRK_OK;
+}
+
+void trk_model_destroy(TrkModel* m) {
+    if (!m) return;
+    if (m->d_links) (void)hipFree(m->d_links);
+    if (m->d_fin) (void)hipFree(m->d_fin);
+    delete m;
+}
+
+int trk_model_set_base_pose(TrkModel* m, const float* R9, const float* t3) {
+    if (!m || !R9 || !t3) return fail(TRK_ERR_INVALID_ARG, "trk_model_set_base_pose: null argument");
+    std::memcpy(m->hdr.base_R, R9, sizeof(float) * 9);
+    std::memcpy(m->hdr.base_t, t3, sizeof(float) * 3);
+    return TRK_OK;
+}
+
+int trk_model_n_links(const TrkModel* m) { return m ? m->hdr.n_links : TRK_ERR_INVALID_ARG; }
+int trk_model_n_dofs(const TrkModel* m) { return m ? m->hdr.n_dofs : TRK_ERR_INVALID_ARG; }
+int trk_model_is_specialized(const TrkModel* m) { (void)m; return 0; }
+
+static int make_sel(const TrkModel* m, const int32_t* link_sel, int32_t n_sel, SelMap& sel, int& n_out, const char* who) {
+    const int L = m->hdr.n_links;
+    for (int k = 0; k < TRK_MAX_LINKS; ++k) sel.col[k] = -1;
+    if (!link_sel) {
+        for (int k = 0; k < L; ++k) sel.col[k] = k;
+        n_out = L;
+        return TRK_OK;
+    }
+    if (n_sel < 1 || n_sel > L) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": n_sel out of range");
+    for (int c = 0; c < n_sel; ++c) {
+        const int i = link_sel[c];
+        if (i < 0 || i >= L) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": link index out of range");
+        if (sel.col[i] >= 0) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": duplicate link in link_sel");
+        sel.col[i] = c;
+    }
+    n_out = n_sel;
+    return TRK_OK;
+}
+
+static int check_model(const TrkModel* m, const char* who) {
+    if (!m) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null model");
+    if (m->unsupported) return fail(TRK_ERR_UNSUPPORTED, std::string(who) + ": model has a joint type other than fixed/revolute/continuous/prismatic");
+    return TRK_OK;
+}
+
+static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const int32_t* link_sel, int32_t n_sel,
+                  float* out, trk_stream_t stream, const char* who) {
+    int rc = check_model(m, who);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!out || (!q && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": bad q/out/n");
+    SelMap sel; int ns;
+    rc = make_sel(m, link_sel, n_sel, sel, ns, who);
+    if (rc) return rc;
+    if (n == 0) return TRK_OK;
+    trk_launch_fk_forward(mode, m->hdr, m->d_links, sel, ns, q, n, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_fk_forward(const TrkModel* m, const float* q, int64_t n, const int32_t* link_sel, int32_t n_sel, float* H_out, trk_stream_t stream) {
+    return fk_fwd(0, m, q, n, link_sel, n_sel, H_out, stream, "trk_fk_forward");
+}
+int trk_fk_positions(const TrkModel* m, const float* q, int64_t n, const int32_t* link_sel, int32_t n_sel, float* pos_out, trk_stream_t stream) {
+    return fk_fwd(1, m, q, n, link_sel, n_sel, pos_out, stream, "trk_fk_positions");
+}
+
+static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin, int64_t n, const int32_t* link_sel,
+                  int32_t n_sel, float* gq, trk_stream_t stream, const char* who) {
+    int rc = check_model(m, who);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!gin || ((!q || !gq) && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": bad q/g/n");
+    SelMap sel; int ns;
+    rc = make_sel(m, link_sel, n_sel, sel, ns, who);
+    if (rc) return rc;
+    if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    trk_launch_fk_backward(mode, m->hdr, m->d_links, m->d_fin, sel, ns, q, gin, n, gq, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_fk_backward(const TrkModel* m, const float* q, const float* gH, int64_t n, const int32_t* link_sel, int32_t n_sel, float* gq, trk_stream_t stream) {
+    return fk_bwd(0, m, q, gH, n, link_sel, n_sel, gq, stream, "trk_fk_backward");
+}
+int trk_fk_positions_backward(const TrkModel* m, const float* q, const float* gpos, int64_t n, const int32_t* link_sel, int32_t n_sel, float* gq, trk_stream_t stream) {
+    return fk_bwd(1, m, q, gpos, n, link_sel, n_sel, gq, stream, "trk_fk_positions_backward");
+}
+
+int trk_fk_jacobian(const TrkModel* m, const float* q, const float* qd, int64_t n, int32_t link, float* pos, float* quat,
+                    float* lin_jac, float* ang_jac, float* vel_lin, float* vel_ang, trk_stream_t stream) {
+    int rc = check_model(m, "trk_fk_jacobian");
+    if (rc) return rc;
+    if (link < 0 || link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_fk_jacobian: link out of range");
+    if (n < 0 || (n > 0 && (!q || !pos || !quat || !lin_jac || !ang_jac))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_jacobian: null argument");
+    if (n == 0) return TRK_OK;
+    trk_launch_fk_jacobian(m->hdr, m->d_links, q, qd, n, link, m->joint_list_idx[link], pos, quat, lin_jac, ang_jac,
+                           vel_lin, vel_ang, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_rotmat_to_quat(const float* R, int64_t n, int32_t stride, int32_t row_pitch, float* quat, trk_stream_t stream) {
+    if (n < 0 || stride < 9 || row_pitch < 3 || (n > 0 && (!R || !quat))) return fail(TRK_ERR_INVALID_ARG, "trk_rotmat_to_quat: bad argument");
+    if (n == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_rotmat_to_quat(R, n, stride, row_pitch, quat, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
+    if (!d || !out) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: null argument");
+    if (d->abi_version != TRK_ABI_VERSION) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: ABI version mismatch");
+    const int Lin = d->n_links_in;
+    if (Lin < 1 || Lin > 4 * TRK_MAX_LINKS) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: n_links_in out of range");
+    if (d->n_obj_links < 0 || d->n_obj_links > TRK_MAX_COLL_LINKS || d->n_objects < 0 || d->n_objects > TRK_MAX_OBJECTS ||
+        d->n_prims < 0 || d->n_prims > TRK_MAX_PRIMS || d->n_self_links < 0 || d->n_self_links > TRK_MAX_COLL_LINKS ||
+        d->n_self_pairs < 0 || d->n_self_pairs > TRK_MAX_SELF_PAIRS)
+        return fail(TRK_ERR_UNSUPPORTED, "trk_cost_model_create: table size out of range");
+    if ((d->n_obj_links && (!d->obj_link_idx || !d->obj_link_margin)) || (d->n_objects && !d->objects) ||
+        (d->n_prims && !d->prims) || (d->n_self_links && !d->self_link_idx) ||
+        (d->n_self_pairs && (!d->self_pairs || !d->self_margin)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: null table pointer");
+    for (int l = 0; l < d->n_obj_links; ++l)
+        if (d->obj_link_idx[l] < 0 || d->obj_link_idx[l] >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: obj_link_idx out of range");
+    for (int l = 0; l < d->n_self_links; ++l)
+        if (d->self_link_idx[l] < 0 || d->self_link_idx[l] >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: self_link_idx out of range");
+    for (int p = 0; p < 2 * d->n_self_pairs; ++p)
+        if (d->self_pairs[p] < 0 || d->self_pairs[p] >= d->n_self_links) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: self_pairs out of range");
+    if (d->ee_link >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: ee_link out of range");
+    int n_grid = 0;
+    for (int o = 0; o < d->n_objects; ++o) {
+        const TrkObject& ob = d->objects[o];
+        if (ob.is_grid) { ++n_grid; continue; }
+        if (ob.prim_begin < 0 || ob.prim_end < ob.prim_begin || ob.prim_end > d->n_prims)
+            return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: object primitive range out of bounds");
+        for (int p = ob.prim_begin; p < ob.prim_end; ++p)
+            if (d->prims[p].type < TRK_PRIM_SPHERE || d->prims[p].type > TRK_PRIM_SHARP_BOX)
+                return fail(TRK_ERR_UNSUPPORTED, "trk_cost_model_create: unknown primitive type");
+    }
+    if (n_grid > 1 || (n_grid == 1 && (!d->has_grid || !d->grid.sdf || !d->grid.grad)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: grid object without grid data (or more than one grid)");
+    int rc = ensure_init();
+    if (rc) return rc;
+
+    // one device blob: [obj_link_idx | obj_link_margin | objects | prims | self_pairs | self_margin], 16-B aligned pieces
+    auto al = [](size_t x) { return (x + 15) & ~size_t(15); };
+    const size_t o_idx = 0;
+    const size_t o_mg = o_idx + al(sizeof(int32_t) * (d->n_obj_links + 1));
+    const size_t o_obj = o_mg + al(sizeof(float) * (d->n_obj_links + 1));
+    const size_t o_pr = o_obj + al(sizeof(DevObj) * (d->n_objects + 1));
+    const size_t o_sp = o_pr + al(sizeof(DevPrim) * (d->n_prims + 1));
+    const size_t o_sm = o_sp + al(sizeof(int32_t) * 2 * (d->n_self_pairs + 1));
+    const size_t total = o_sm + al(sizeof(float) * (d->n_self_pairs + 1));
+    std::vector<char> blob(total, 0);
+    if (d->n_obj_links) {
+        std::memcpy(blob.data() + o_idx, d->obj_link_idx, sizeof(int32_t) * d->n_obj_links);
+        std::memcpy(blob.data() + o_mg, d->obj_link_margin, sizeof(float) * d->n_obj_links);
+    }
+    DevObj* objs = reinterpret_cast<DevObj*>(blob.data() + o_obj);
+    for (int o = 0; o < d->n_objects; ++o) {
+        const TrkObject& ob = d->objects[o];
+        std::memcpy(objs[o].pos, ob.pos, sizeof(float) * 3);
+        std::memcpy(objs[o].R, ob.R, sizeof(float) * 9);
+        objs[o].prim_begin = ob.prim_begin; objs[o].prim_end = ob.prim_end; objs[o].is_grid = ob.is_grid ? 1 : 0;
+        const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        objs[o].identity = std::memcmp(ob.R, I, sizeof(I)) == 0 ? 1 : 0;
+    }
+    DevPrim* prims = reinterpret_cast<DevPrim*>(blob.data() + o_pr);
+    for (int p = 0; p < d->n_prims; ++p) {
+        const TrkPrimitive& pr = d->prims[p];
+        prims[p].type = pr.type;
+        prims[p].cx = pr.center[0]; prims[p].cy = pr.center[1]; prims[p].cz = pr.center[2];
+        prims[p].hx = pr.half[0]; prims[p].hy = pr.half[1]; prims[p].hz = pr.half[2];
+        prims[p].r = pr.type == TRK_PRIM_SHARP_BOX ? 0.0f : pr.radius;
+    }
+    int32_t* sp = reinterpret_cast<int32_t*>(blob.data() + o_sp);
+    for (int p = 0; p < 2 * d->n_self_pairs; ++p) sp[p] = d->self_link_idx[d->self_pairs[p]];
+    if (d->n_self_pairs) std::memcpy(blob.data() + o_sm, d->self_margin, sizeof(float) * d->n_self_pairs);
+
+    TrkCostModel* cm = new (std::nothrow) TrkCostModel();
+    if (!cm) return fail(TRK_ERR_HIP, "out of host memory");
+    hipError_t e = hipMalloc(&cm->d_blob, total);
+    if (e == hipSuccess) e = hipMemcpy(cm->d_blob, blob.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (cm->d_blob) (void)hipFree(cm->d_blob);
+        delete cm;
+        return hip_fail(e, "trk_cost_model_create: device allocation/copy");
+    }
+    DevCostHdr& h = cm->hdr;
+    std::memset(&h, 0, sizeof(h));
+    char* base = static_cast<char*>(cm->d_blob);
+    h.n_links_in = Lin;
+    h.n_obj_links = d->n_obj_links; h.n_objects = d->n_objects; h.has_grid = n_grid; h.has_ws = d->has_ws ? 1 : 0;
+    h.n_self_links = d->n_self_links; h.n_self_pairs = d->n_self_pairs;
+    h.ee_link = d->ee_link; h.ee_square = d->ee_square ? 1 : 0; h.ee_w_pos = d->ee_w_pos; h.ee_w_rot = d->ee_w_rot;
+    std::memcpy(h.ws_min, d->ws_min, sizeof(float) * 3);
+    std::memcpy(h.ws_max, d->ws_max, sizeof(float) * 3);
+    std::memcpy(h.ee_target, d->ee_target, sizeof(float) * 16);
+    h.obj_link_idx = reinterpret_cast<const int32_t*>(base + o_idx);
+    h.obj_link_margin = reinterpret_cast<const float*>(base + o_mg);
+    h.objects = reinterpret_cast<const DevObj*>(base + o_obj);
+    h.prims = reinterpret_cast<const DevPrim*>(base + o_pr);
+    h.self_pairs = reinterpret_cast<const int32_t*>(base + o_sp);
+    h.self_margin = reinterpret_cast<const float*>(base + o_sm);
+    if (n_grid) {
+        h.grid.sdf = d->grid.sdf; h.grid.grad = d->grid.grad;
+        for (int k = 0; k < 3; ++k) {
+            h.grid.dims[k] = d->grid.dims[k]; h.grid.lim_min[k] = d->grid.lim_min[k];
+            h.grid.map_dim[k] = d->grid.map_dim[k]; h.grid.fdims[k] = (float)d->grid.dims[k];
+        }
+    }
+    *out = cm;
+    return TRK_OK;
+}
+
+void trk_cost_model_destroy(TrkCostModel* cm) {
+    if (!cm) return;
+    if (cm->d_blob) (void)hipFree(cm->d_blob);
+    delete cm;
+}
+
+int trk_cost_model_set_ee_target(TrkCostModel* cm, const float* H16) {
+    if (!cm || !H16) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_set_ee_target: null argument");
+    std::memcpy(cm->hdr.ee_target, H16, sizeof(float) * 16);
+    return TRK_OK;
+}
+
+int trk_cost_fields(const TrkCostModel* cm, int32_t fields, const float* link_pos, int64_t n, const float* gcost,
+                    float* cost, float* g_link_pos, trk_stream_t stream) {
+    if (!cm) return fail(TRK_ERR_INVALID_ARG, "trk_cost_fields: null cost model");
+    if (n < 0 || (n > 0 && (!link_pos || !cost)) || (fields & ~7) || !fields) return fail(TRK_ERR_INVALID_ARG, "trk_cost_fields: bad argument");
+    if (n == 0) return TRK_OK;
+    trk_launch_cost_fields(cm->hdr, fields, link_pos, n, gcost, cost, g_link_pos, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_collision_fields(const TrkCostModel* cm, int32_t fields, const float* link_pos, int64_t n, float margin_override,
+                         uint8_t* in_collision, trk_stream_t stream) {
+    if (!cm) return fail(TRK_ERR_INVALID_ARG, "trk_collision_fields: null cost model");
+    if (n < 0 || (n > 0 && (!link_pos || !in_collision)) || (fields & ~7) || !fields) return fail(TRK_ERR_INVALID_ARG, "trk_collision_fields: bad argument");
+    if (n == 0) return TRK_OK;
+    const int use_default = std::isnan(margin_override) ? 1 : 0;
+    trk_launch_collision_fields(cm->hdr, fields, link_pos, n, use_default ? 0.0f : margin_override, use_default, in_collision, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_ee_cost(const TrkCostModel* cm, const float* H_ee, int64_t n, int64_t stride, const float* target, int32_t per_sample,
+                const float* gcost, float* cost, float* gH, int64_t g_stride, trk_stream_t stream) {
+    if (!cm) return fail(TRK_ERR_INVALID_ARG, "trk_ee_cost: null cost model");
+    if (n < 0 || stride < 16 || (stride & 3) || (gH && (g_stride < 16 || (g_stride & 3))) || (n > 0 && (!H_ee || !cost)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_ee_cost: bad argument (strides must be multiples of 4 floats, >= 16)");
+    if (n == 0) return TRK_OK;
+    trk_launch_ee_cost(cm->hdr, H_ee, n, stride, target, per_sample, gcost, cost, gH, g_stride, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const float* q,
+                          int64_t batch, int32_t horizon, float* link_pos_out, float* cost, float* gq, float* cost_sum,
+                          trk_stream_t stream) {
+    int rc = check_model(m, "trk_rollout_cost_grad");
+    if (rc) return rc;
+    if (!cm || !w) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad: null argument");
+    if (batch < 0 || horizon < 1) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad: bad batch/horizon");
+    if (cm->hdr.n_links_in != m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad: cost model n_links_in != model n_links");
+    const int64_t n = batch * horizon;
+    if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad: null q/cost/gq");
+    if (n == 0) return TRK_OK;
+    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, cm->hdr, *w, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_grid_precompute(const TrkCostModel* cm, const int32_t dims[3], const float lim_min[3], const float lim_max[3],
+                        float* sdf, float* grad, trk_stream_t stream) {
+    if (!cm || !dims || !lim_min || !lim_max || !sdf || !grad) return fail(TRK_ERR_INVALID_ARG, "trk_grid_precompute: null argument");
+    for (int k = 0; k < 3; ++k) if (dims[k] < 1) return fail(TRK_ERR_INVALID_ARG, "trk_grid_precompute: bad dims");
+    trk_launch_grid_precompute(cm->hdr, dims, lim_min, lim_max, sdf, grad, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_sdf_points(const TrkCostModel* cm, const float* points, int64_t n, float* sdf, float* grad, trk_stream_t stream) {
+    if (!cm) return fail(TRK_ERR_INVALID_ARG, "trk_sdf_points: null cost model");
+    if (n < 0 || (n > 0 && (!points || !sdf))) return fail(TRK_ERR_INVALID_ARG, "trk_sdf_points: bad argument");
+    if (n == 0 || cm->hdr.n_objects == 0) return TRK_OK;
+    trk_launch_sdf_points(cm->hdr, points, n, sdf, grad, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+}  // extern "C"

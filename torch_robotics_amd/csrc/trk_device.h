@@ -1,0 +1,286 @@
+// trk_device.h -- device-side data layout and math shared by the gfx950 kernels.
+//
+// Model and cost tables are wave-uniform: kernels index them with loop counters, so the
+// compiler fetches them with scalar loads (s_load_dwordx*) into SGPRs and feeds them to VALU
+// ops as scalar operands -- no VGPRs, no LDS traffic.  LDS is reserved for what is per-lane:
+// the q / gq / link-position transposes that make HBM accesses coalesced, the pose stack of
+// branched trees, and the per-joint records of the reverse pass.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/trk.h"
+
+#define TRK_WAVE 64
+
+// One record per link, stored by DFS pre-order position (32 dwords = 128 B, one s_load_dwordx16 pair).
+struct alignas(16) DevLink {
+    float Rf[9];        // R_fixed row-major
+    float trans[3];
+    float axis[3];      // raw <axis>
+    float lower, upper;
+    float rot_sign;
+    int32_t type;       // TrkJointType
+    int32_t dof;        // DOF index or -1
+    int32_t rot_axis;   // stateless rotation axis
+    int32_t clamp;
+    int32_t parent_slot;
+    int32_t store_slot;
+    int32_t link;       // file-order link index
+    int32_t sf_rot_axis;
+    int32_t sf_clamp;
+    int32_t jac_axis;
+    int32_t fin_begin;  // joints whose subtree ends after this position: fin[fin_begin, fin_end)
+    int32_t fin_end;
+    int32_t _pad[2];
+};
+static_assert(sizeof(DevLink) == 128, "DevLink must be 32 dwords");
+
+struct DevModelHdr {
+    int32_t n_links, n_dofs, n_slots, _pad;
+    float base_R[9];
+    float base_t[3];
+};
+
+struct alignas(16) DevPrim {   // 8 dwords
+    int32_t type;
+    float cx, cy, cz, hx, hy, hz, r;
+};
+
+struct alignas(16) DevObj {    // 16 dwords
+    float pos[3];
+    float R[9];
+    int32_t prim_begin, prim_end, is_grid, identity;
+};
+
+struct DevGrid {
+    const float* sdf;
+    const float* grad;
+    int32_t dims[3];
+    float lim_min[3];
+    float map_dim[3];
+    float fdims[3];
+};
+
+// Passed to kernels by value (kernarg segment, scalar-loaded).
+struct DevCostHdr {
+    int32_t n_links_in;
+    int32_t n_obj_links, n_objects, has_grid, has_ws;
+    int32_t n_self_links, n_self_pairs;
+    int32_t ee_link, ee_square;
+    float ee_w_pos, ee_w_rot;
+    float ws_min[3], ws_max[3];
+    float ee_target[16];
+    const int32_t* obj_link_idx;   // device
+    const float* obj_link_margin;  // device
+    const DevObj* objects;         // device
+    const DevPrim* prims;          // device
+    const int32_t* self_pairs;     // device: pairs already mapped to position-tensor link indices [P*2]
+    const float* self_margin;      // device
+    DevGrid grid;
+};
+
+struct SelMap {                 // link (file index) -> output column, -1 = not selected
+    int32_t col[TRK_MAX_LINKS];
+};
+
+// ------------------------------------------------------------------------------------------
+// math
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float trk_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp
+__device__ __forceinline__ float trk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
+
+// sin and cos of x together: Cody-Waite reduction by pi/2 (two fmas) + degree-7/8 minimax
+// polynomials on [-pi/4, pi/4].  |error| <= ~1.5 ulp for |x| < 1e4 rad (tests/test_device_math.py).
+// Joint angles are clamped to URDF limits (a few rad), so no large-argument path is needed.
+__host__ __device__ __forceinline__ void trk_sincos(float x, float* s_out, float* c_out) {
+    const float k = rintf(x * 0.636619772367581343f);              // x * 2/pi
+    float r = fmaf(-k, 1.57079637050628662109375f, x);             // pi/2 hi
+    r = fmaf(-k, -4.37113900018624283e-8f, r);                     // pi/2 lo
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    const float sn = fmaf(r * r2, sp, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    const float cs = fmaf(r2 * r2, cp, fmaf(r2, -0.5f, 1.0f));
+    const int n = (int)k;
+    const float a = (n & 1) ? cs : sn;
+    const float b = (n & 1) ? sn : cs;
+    *s_out = (n & 2) ? -a : a;
+    *c_out = ((n + 1) & 2) ? -b : b;
+}
+
+struct Pose {
+    float r[9];
+    float t[3];
+};
+
+__device__ __forceinline__ void pose_from_base(const DevModelHdr& h, Pose& p) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p.r[k] = h.base_R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.t[k] = h.base_t[k];
+}
+
+// Rotate columns (i, j) of a 3x3 (row-major) by angle with sine s and cosine c:
+// col_i' = c*col_i + s*col_j ; col_j' = -s*col_i + c*col_j   (= right-multiplication by Rot_k, k = the third axis)
+__device__ __forceinline__ void rot_cols(float* r, int i, int j, float s, float c) {
+#pragma unroll
+    for (int row = 0; row < 3; ++row) {
+        const float a = r[3 * row + i], b = r[3 * row + j];
+        r[3 * row + i] = fmaf(c, a, s * b);
+        r[3 * row + j] = fmaf(c, b, -s * a);
+    }
+}
+
+// child = parent o joint(link, q).  Stateless path: rigid_body.py:153-190 + geometrics/utils.py:11-17.
+// `stateful` selects the quirks of update_joint_state (rigid_body.py:214-256).
+// Returns the clamp mask (1.0f = gradient passes, 0.0f = q outside the limits).
+template <bool STATEFUL>
+__device__ __forceinline__ float joint_compose(const DevLink& L, const Pose& par, float q, Pose& out) {
+    float pass = 1.0f;
+    float qh = q;
+    const bool is_joint = L.type != TRK_JOINT_FIXED;
+    const int do_clamp = STATEFUL ? L.sf_clamp : L.clamp;
+    if (is_joint && do_clamp) {
+        pass = (q >= L.lower && q <= L.upper) ? 1.0f : 0.0f;
+        qh = fminf(fmaxf(q, L.lower), L.upper);
+    }
+    // translation: t = R_p (trans [+ axis*q]) + t_p
+    float tl0 = L.trans[0], tl1 = L.trans[1], tl2 = L.trans[2];
+    if (L.type == TRK_JOINT_PRISMATIC) {
+        tl0 = fmaf(L.axis[0], qh, tl0); tl1 = fmaf(L.axis[1], qh, tl1); tl2 = fmaf(L.axis[2], qh, tl2);
+    }
+#pragma unroll
+    for (int row = 0; row < 3; ++row)
+        out.t[row] = fmaf(par.r[3 * row], tl0, fmaf(par.r[3 * row + 1], tl1, fmaf(par.r[3 * row + 2], tl2, par.t[row])));
+    // rotation: A = R_p R_fixed, then the joint rotation acts on two columns of A
+    float A[9];
+#pragma unroll
+    for (int row = 0; row < 3; ++row)
+#pragma unroll
+        for (int col = 0; col < 3; ++col)
+            A[3 * row + col] = fmaf(par.r[3 * row], L.Rf[col],
+                                    fmaf(par.r[3 * row + 1], L.Rf[3 + col], par.r[3 * row + 2] * L.Rf[6 + col]));
+    if (L.type == TRK_JOINT_REVOLUTE || L.type == TRK_JOINT_CONTINUOUS) {
+        float s, c;
+        trk_sincos(STATEFUL ? qh : L.rot_sign * qh, &s, &c);
+        const int ax = STATEFUL ? L.sf_rot_axis : L.rot_axis;
+        if (ax == 2) rot_cols(A, 0, 1, s, c);
+        else if (ax == 0) rot_cols(A, 1, 2, s, c);
+        else rot_cols(A, 2, 0, s, c);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out.r[k] = A[k];
+    return pass;
+}
+
+// ------------------------------------------------------------------------------------------
+// signed distance fields (object frame), value + gradient
+// ------------------------------------------------------------------------------------------
+// sphere primitives.py:108-112, rounded box :327-334, sharp box :220-223
+template <bool PRECISE>
+__device__ __forceinline__ float prim_sdf(const DevPrim& P, float x, float y, float z, float& gx, float& gy, float& gz) {
+    const float dx = x - P.cx, dy = y - P.cy, dz = z - P.cz;
+    if (P.type == TRK_PRIM_SPHERE) {
+        const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        const float nrm = PRECISE ? sqrtf(n2) : trk_sqrt(n2);
+        const float inv = nrm > 0.0f ? (PRECISE ? 1.0f / nrm : trk_rcp(nrm)) : 0.0f;
+        gx = dx * inv; gy = dy * inv; gz = dz * inv;
+        return nrm - P.r;
+    }
+    const float sx = dx > 0.0f ? 1.0f : (dx < 0.0f ? -1.0f : 0.0f);
+    const float sy = dy > 0.0f ? 1.0f : (dy < 0.0f ? -1.0f : 0.0f);
+    const float sz = dz > 0.0f ? 1.0f : (dz < 0.0f ? -1.0f : 0.0f);
+    const float ux = fabsf(dx) - P.hx + P.r, uy = fabsf(dy) - P.hy + P.r, uz = fabsf(dz) - P.hz + P.r;
+    // arg-max with "first maximum wins" (torch.max / amax on CPU)
+    int am = 0; float mu = ux;
+    if (uy > mu) { mu = uy; am = 1; }
+    if (uz > mu) { mu = uz; am = 2; }
+    if (P.type == TRK_PRIM_SHARP_BOX) {          // P.r == 0 for sharp boxes
+        gx = am == 0 ? sx : 0.0f; gy = am == 1 ? sy : 0.0f; gz = am == 2 ? sz : 0.0f;
+        return mu;
+    }
+    const float rx = fmaxf(ux, 0.0f), ry = fmaxf(uy, 0.0f), rz = fmaxf(uz, 0.0f);
+    const float n2 = fmaf(rx, rx, fmaf(ry, ry, rz * rz));
+    const float nn = PRECISE ? sqrtf(n2) : trk_sqrt(n2);
+    const float inv = nn > 0.0f ? (PRECISE ? 1.0f / nn : trk_rcp(nn)) : 0.0f;
+    const float inside = mu < 0.0f ? 1.0f : 0.0f;
+    gx = (rx * inv + (am == 0 ? inside : 0.0f)) * sx;
+    gy = (ry * inv + (am == 1 ? inside : 0.0f)) * sy;
+    gz = (rz * inv + (am == 2 ? inside : 0.0f)) * sz;
+    return fminf(mu, 0.0f) + nn - P.r;
+}
+
+// grid_map_sdf.py:84-114: nearest-lower cell, stored gradient
+__device__ __forceinline__ float grid_sdf(const DevGrid& G, float x, float y, float z, float& gx, float& gy, float& gz) {
+    const float p[3] = {x, y, z};
+    int idx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float f = floorf((p[k] - G.lim_min[k]) / G.map_dim[k] * G.fdims[k]);
+        int v = (int)f;
+        v = v < 0 ? 0 : v;
+        v = v > G.dims[k] - 1 ? G.dims[k] - 1 : v;
+        idx[k] = v;
+    }
+    const int64_t lin = ((int64_t)idx[0] * G.dims[1] + idx[1]) * G.dims[2] + idx[2];
+    gx = G.grad[3 * lin]; gy = G.grad[3 * lin + 1]; gz = G.grad[3 * lin + 2];
+    return G.sdf[lin];
+}
+
+// ObjectField primitives.py:387-405: x' = R^T (x - pos), min over primitives, g = R g'
+template <bool PRECISE>
+__device__ __forceinline__ float object_sdf(const DevCostHdr& C, int o, float x, float y, float z,
+                                            float& gx, float& gy, float& gz) {
+    const DevObj& O = C.objects[o];
+    if (O.is_grid) return grid_sdf(C.grid, x, y, z, gx, gy, gz);
+    float lx, ly, lz;
+    if (O.identity) { lx = x - O.pos[0]; ly = y - O.pos[1]; lz = z - O.pos[2]; }
+    else {
+        const float dx = x - O.pos[0], dy = y - O.pos[1], dz = z - O.pos[2];
+        lx = fmaf(O.R[0], dx, fmaf(O.R[3], dy, O.R[6] * dz));
+        ly = fmaf(O.R[1], dx, fmaf(O.R[4], dy, O.R[7] * dz));
+        lz = fmaf(O.R[2], dx, fmaf(O.R[5], dy, O.R[8] * dz));
+    }
+    float best = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
+    for (int pi = O.prim_begin; pi < O.prim_end; ++pi) {
+        float px, py, pz;
+        const float v = prim_sdf<PRECISE>(C.prims[pi], lx, ly, lz, px, py, pz);
+        const bool take = (pi == O.prim_begin) || (v < best);
+        best = take ? v : best; bx = take ? px : bx; by = take ? py : by; bz = take ? pz : bz;
+    }
+    if (O.identity) { gx = bx; gy = by; gz = bz; }
+    else {
+        gx = fmaf(O.R[0], bx, fmaf(O.R[1], by, O.R[2] * bz));
+        gy = fmaf(O.R[3], bx, fmaf(O.R[4], by, O.R[5] * bz));
+        gz = fmaf(O.R[6], bx, fmaf(O.R[7], by, O.R[8] * bz));
+    }
+    return best;
+}
+
+// EE SE(3) tracking, distance_fields.py:347-356 + geometrics/utils.py:148-154.
+// Returns the cost; gR[9], gt[3] receive d cost / d (R, t).
+__device__ __forceinline__ float ee_cost_eval(const float* R, const float* t, const float* Ht /*16*/,
+                                              float w_pos, float w_rot, int square, float* gR, float* gt) {
+    float tr = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tr = fmaf(R[3 * r + c], Ht[4 * r + c], tr);
+    const float dx = t[0] - Ht[3], dy = t[1] - Ht[7], dz = t[2] - Ht[11];
+    const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const float nrm = trk_sqrt(n2);
+    float d = 0.0f;
+    if (w_rot > 0.0f) d = fmaf(w_rot, 1.0f - (tr - 1.0f) * 0.5f, d);
+    if (w_pos > 0.0f) d = fmaf(w_pos, nrm, d);
+    const float sc = square ? 2.0f * d : 1.0f;
+    const float kr = w_rot > 0.0f ? -0.5f * w_rot * sc : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gR[3 * r + c] = kr * Ht[4 * r + c];
+    const float kp = (w_pos > 0.0f && nrm > 0.0f) ? sc * w_pos * trk_rcp(nrm) : 0.0f;
+    gt[0] = kp * dx; gt[1] = kp * dy; gt[2] = kp * dz;
+    return square ? d * d : d;
+}

@@ -1,0 +1,798 @@
+// trk_kernels.hip -- table-driven gfx950 kernels: any URDF tree, any cost model.
+//
+// Mapping: one lane per (batch, horizon) sample, one 64-lane wavefront per workgroup
+// (a wavefront is one trajectory when horizon == 64).  The model tables are wave-uniform and
+// arrive through scalar loads; per-lane state lives in VGPRs; LDS holds the q / gq / position
+// tiles (so every HBM access of a wavefront is one contiguous span) plus the branch-pose stack
+// and the per-joint records of the reverse pass.
+//
+// Reverse mode uses the transpose of the geometric Jacobian instead of matrix adjoints: every
+// link contributes a wrench w_i = (tbar_i, t_i x tbar_i + axial(Rbar_i R_i^T)); a revolute joint's
+// gradient is  s * z_j . (tau_sub - t_j x f_sub)  over the wrenches of its subtree, a prismatic
+// joint's is  (R_parent axis) . f_sub.  In DFS pre-order a subtree is a contiguous range, so the
+// subtree sum is a difference of two running prefix sums and one forward walk suffices
+// (equals autograd through rigid_body.py:146-211).
+#include "trk_device.h"
+
+namespace {
+
+__device__ __forceinline__ void load_tile(float* dst, const float* __restrict__ src, int64_t first, int64_t count, int lane) {
+    // dst[0..count) = src[first .. first+count), contiguous -> fully coalesced dword loads
+    for (int64_t k = lane; k < count; k += TRK_WAVE) dst[k] = src[first + k];
+}
+
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* src, int64_t first, int64_t count, int lane) {
+    for (int64_t k = lane; k < count; k += TRK_WAVE) dst[first + k] = src[k];
+}
+
+// copy a [rows][width] tile kept in LDS with an odd row stride `rs` to/from contiguous global memory
+__device__ __forceinline__ void store_tile_strided(float* __restrict__ dst, const float* src, int64_t first, int rows,
+                                                   int width, int rs, int lane) {
+    int r = lane / width, c = lane - r * width;
+    const int dr = TRK_WAVE / width, dc = TRK_WAVE - dr * width;
+    const int64_t count = (int64_t)rows * width;
+    for (int64_t k = lane; k < count; k += TRK_WAVE) {
+        dst[first + k] = src[r * rs + c];
+        r += dr; c += dc;
+        if (c >= width) { c -= width; ++r; }
+    }
+}
+__device__ __forceinline__ void load_tile_strided(float* dst, const float* __restrict__ src, int64_t first, int rows,
+                                                  int width, int rs, int lane) {
+    int r = lane / width, c = lane - r * width;
+    const int dr = TRK_WAVE / width, dc = TRK_WAVE - dr * width;
+    const int64_t count = (int64_t)rows * width;
+    for (int64_t k = lane; k < count; k += TRK_WAVE) {
+        dst[r * rs + c] = src[first + k];
+        r += dr; c += dc;
+        if (c >= width) { c -= width; ++r; }
+    }
+}
+
+__device__ __forceinline__ void slot_store(float* slots, int slot, int lane, const Pose& p) {
+    float* s = slots + slot * 12 * TRK_WAVE + lane;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k * TRK_WAVE] = p.r[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[(9 + k) * TRK_WAVE] = p.t[k];
+}
+__device__ __forceinline__ void slot_load(const float* slots, int slot, int lane, Pose& p) {
+    const float* s = slots + slot * 12 * TRK_WAVE + lane;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p.r[k] = s[k * TRK_WAVE];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.t[k] = s[(9 + k) * TRK_WAVE];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, TRK_WAVE);
+    return v;
+}
+
+// One step of the forward walk: pose of the link at pre-order position p.
+template <bool STATEFUL>
+__device__ __forceinline__ float walk_step(const DevModelHdr& hdr, const DevLink& L, int p, const float* qs, int D,
+                                           int lane, float* slots, Pose& cur, Pose& par_out) {
+    float pass = 1.0f;
+    if (p == 0) {
+        pose_from_base(hdr, cur);
+        par_out = cur;
+    } else {
+        Pose par;
+        if (L.parent_slot >= 0) slot_load(slots, L.parent_slot, lane, par);
+        else par = cur;
+        const float q = L.dof >= 0 ? qs[lane * D + L.dof] : 0.0f;
+        pass = joint_compose<STATEFUL>(L, par, q, cur);
+        par_out = par;
+    }
+    if (L.store_slot >= 0) slot_store(slots, L.store_slot, lane, cur);
+    return pass;
+}
+
+}  // namespace
+
+// ============================================================================================
+// FK forward.  MODE 0: H [N, n_sel, 4, 4] (robot_tree.py:267-301); MODE 1: positions [N, n_sel, 3]
+// (robot_panda.py:138-170).  LDS: q tile | pose slots | (MODE 1) output tile.
+// ============================================================================================
+template <int MODE>
+__global__ void __launch_bounds__(TRK_WAVE)
+k_fk_forward(DevModelHdr hdr, const DevLink* __restrict__ links, SelMap sel, int n_sel,
+             const float* __restrict__ q, int64_t n, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int D = hdr.n_dofs, L = hdr.n_links;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    float* qs = smem;
+    float* slots = qs + TRK_WAVE * D;
+    float* tile = slots + hdr.n_slots * 12 * TRK_WAVE;
+    const int width = n_sel * 3, rs = width | 1;
+    load_tile(qs, q, base * D, (int64_t)rows * D, lane);
+    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
+    __syncthreads();
+    const int64_t s = base + lane;
+    Pose cur, par;
+    for (int p = 0; p < L; ++p) {
+        const DevLink& Lk = links[p];
+        walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
+        const int col = sel.col[Lk.link];
+        if (col < 0) continue;
+        if (MODE == 0) {
+            if (lane < rows) {
+                float4* o = reinterpret_cast<float4*>(out + (s * n_sel + col) * 16);
+                o[0] = make_float4(cur.r[0], cur.r[1], cur.r[2], cur.t[0]);
+                o[1] = make_float4(cur.r[3], cur.r[4], cur.r[5], cur.t[1]);
+                o[2] = make_float4(cur.r[6], cur.r[7], cur.r[8], cur.t[2]);
+                o[3] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            }
+        } else {
+            float* o = tile + lane * rs + 3 * col;
+            o[0] = cur.t[0]; o[1] = cur.t[1]; o[2] = cur.t[2];
+        }
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        store_tile_strided(out, tile, base * width, rows, width, rs, lane);
+    }
+}
+
+// ============================================================================================
+// Reverse pass shared by fk_backward and the fused rollout.
+// ADJ supplies (Rbar, tbar) of the link at a position.  LDS: q | gq | joint records [7][D][64] | slots.
+// ============================================================================================
+struct JointRec { float a[3], m[3], c; };
+
+template <class ADJ>
+__device__ __forceinline__ void reverse_walk(const DevModelHdr& hdr, const DevLink* __restrict__ links,
+                                             const int32_t* __restrict__ fin, const float* qs, float* gqs,
+                                             float* jst, float* slots, int lane, ADJ& adj) {
+    const int D = hdr.n_dofs, L = hdr.n_links;
+    float Pf[3] = {0.0f, 0.0f, 0.0f}, Pt[3] = {0.0f, 0.0f, 0.0f};
+    Pose cur, par;
+    for (int p = 0; p < L; ++p) {
+        const DevLink& Lk = links[p];
+        const float pass = walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
+        if (Lk.dof >= 0) {
+            float a[3] = {0.0f, 0.0f, 0.0f}, m[3];
+            if (Lk.type == TRK_JOINT_PRISMATIC) {
+                // displacement direction R_parent * axis (axis is not rotated by R_fixed, rigid_body.py:176)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    m[r] = -pass * fmaf(par.r[3 * r], Lk.axis[0], fmaf(par.r[3 * r + 1], Lk.axis[1], par.r[3 * r + 2] * Lk.axis[2]));
+            } else {
+                const float sg = pass * Lk.rot_sign;
+                const int ax = Lk.rot_axis;
+                const float z0 = ax == 0 ? cur.r[0] : (ax == 1 ? cur.r[1] : cur.r[2]);
+                const float z1 = ax == 0 ? cur.r[3] : (ax == 1 ? cur.r[4] : cur.r[5]);
+                const float z2 = ax == 0 ? cur.r[6] : (ax == 1 ? cur.r[7] : cur.r[8]);
+                a[0] = sg * z0; a[1] = sg * z1; a[2] = sg * z2;
+                m[0] = a[1] * cur.t[2] - a[2] * cur.t[1];
+                m[1] = a[2] * cur.t[0] - a[0] * cur.t[2];
+                m[2] = a[0] * cur.t[1] - a[1] * cur.t[0];
+            }
+            const float c = (a[0] * Pt[0] + a[1] * Pt[1] + a[2] * Pt[2]) - (m[0] * Pf[0] + m[1] * Pf[1] + m[2] * Pf[2]);
+            float* j = jst + Lk.dof * TRK_WAVE + lane;
+            const int js = D * TRK_WAVE;
+            j[0] = a[0]; j[js] = a[1]; j[2 * js] = a[2];
+            j[3 * js] = m[0]; j[4 * js] = m[1]; j[5 * js] = m[2]; j[6 * js] = c;
+        }
+        // own wrench
+        float Rb[9], tb[3];
+        if (adj(Lk, p, cur, Rb, tb)) {
+            Pf[0] += tb[0]; Pf[1] += tb[1]; Pf[2] += tb[2];
+            Pt[0] += cur.t[1] * tb[2] - cur.t[2] * tb[1];
+            Pt[1] += cur.t[2] * tb[0] - cur.t[0] * tb[2];
+            Pt[2] += cur.t[0] * tb[1] - cur.t[1] * tb[0];
+            if (adj.has_rot(Lk)) {
+                // M = Rbar R^T ; torque = (M21 - M12, M02 - M20, M10 - M01)
+                const float M21 = Rb[6] * cur.r[3] + Rb[7] * cur.r[4] + Rb[8] * cur.r[5];
+                const float M12 = Rb[3] * cur.r[6] + Rb[4] * cur.r[7] + Rb[5] * cur.r[8];
+                const float M02 = Rb[0] * cur.r[6] + Rb[1] * cur.r[7] + Rb[2] * cur.r[8];
+                const float M20 = Rb[6] * cur.r[0] + Rb[7] * cur.r[1] + Rb[8] * cur.r[2];
+                const float M10 = Rb[3] * cur.r[0] + Rb[4] * cur.r[1] + Rb[5] * cur.r[2];
+                const float M01 = Rb[0] * cur.r[3] + Rb[1] * cur.r[4] + Rb[2] * cur.r[5];
+                Pt[0] += M21 - M12; Pt[1] += M02 - M20; Pt[2] += M10 - M01;
+            }
+        }
+        // joints whose subtree ends here
+        for (int f = Lk.fin_begin; f < Lk.fin_end; ++f) {
+            const int d = fin[f];
+            const float* j = jst + d * TRK_WAVE + lane;
+            const int js = D * TRK_WAVE;
+            const float g = (j[0] * Pt[0] + j[js] * Pt[1] + j[2 * js] * Pt[2]) -
+                            (j[3 * js] * Pf[0] + j[4 * js] * Pf[1] + j[5 * js] * Pf[2]) - j[6 * js];
+            gqs[lane * D + d] = g;
+        }
+    }
+}
+
+struct AdjFromGH {        // gH [N, n_sel, 4, 4]
+    const float* gH; int64_t s; int n_sel; const SelMap& sel; bool valid;
+    __device__ __forceinline__ bool has_rot(const DevLink&) const { return true; }
+    __device__ __forceinline__ bool operator()(const DevLink& Lk, int, const Pose&, float* Rb, float* tb) const {
+        const int col = sel.col[Lk.link];
+        if (col < 0) return false;
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+        if (valid) {
+            const float4* g = reinterpret_cast<const float4*>(gH + (s * n_sel + col) * 16);
+            r0 = g[0]; r1 = g[1]; r2 = g[2];
+        }
+        Rb[0] = r0.x; Rb[1] = r0.y; Rb[2] = r0.z; tb[0] = r0.w;
+        Rb[3] = r1.x; Rb[4] = r1.y; Rb[5] = r1.z; tb[1] = r1.w;
+        Rb[6] = r2.x; Rb[7] = r2.y; Rb[8] = r2.z; tb[2] = r2.w;
+        return true;
+    }
+};
+
+template <bool IDENT>
+struct AdjFromTile {      // tbar from an LDS tile [64][rs] (link-major, 3 floats per link) + optional EE rotation adjoint
+    const float* tile; int rs; int lane; const SelMap& sel; int ee_link; const float* eeRb;
+    __device__ __forceinline__ bool has_rot(const DevLink& Lk) const { return Lk.link == ee_link; }
+    __device__ __forceinline__ bool operator()(const DevLink& Lk, int, const Pose&, float* Rb, float* tb) const {
+        const int col = IDENT ? Lk.link : sel.col[Lk.link];
+        if (col < 0) return false;
+        const float* g = tile + lane * rs + 3 * col;
+        tb[0] = g[0]; tb[1] = g[1]; tb[2] = g[2];
+        if (Lk.link == ee_link) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rb[k] = eeRb[k];
+        }
+        return true;
+    }
+};
+
+// MODE 0: adjoint gH [N,n_sel,4,4]; MODE 1: adjoint gpos [N,n_sel,3].  -> gq [N,D]
+template <int MODE>
+__global__ void __launch_bounds__(TRK_WAVE)
+k_fk_backward(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, SelMap sel, int n_sel,
+              const float* __restrict__ q, const float* __restrict__ gin, int64_t n, float* __restrict__ gq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int D = hdr.n_dofs;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    float* qs = smem;
+    float* gqs = qs + TRK_WAVE * D;
+    float* jst = gqs + TRK_WAVE * D;
+    float* slots = jst + 7 * D * TRK_WAVE;
+    float* tile = slots + hdr.n_slots * 12 * TRK_WAVE;
+    const int width = n_sel * 3, rs = width | 1;
+    load_tile(qs, q, base * D, (int64_t)rows * D, lane);
+    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
+    for (int k = lane; k < TRK_WAVE * D; k += TRK_WAVE) gqs[k] = 0.0f;
+    if (MODE == 1) {
+        for (int k = lane; k < TRK_WAVE * rs; k += TRK_WAVE) tile[k] = 0.0f;
+        __syncthreads();
+        load_tile_strided(tile, gin, base * width, rows, width, rs, lane);
+    }
+    __syncthreads();
+    if (MODE == 0) {
+        AdjFromGH adj{gin, base + lane, n_sel, sel, lane < rows};
+        reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+    } else {
+        AdjFromTile<false> adj{tile, rs, lane, sel, -1, nullptr};
+        reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+    }
+    __syncthreads();
+    store_tile(gq, gqs, base * D, (int64_t)rows * D, lane);
+}
+
+// ============================================================================================
+// Collision fields on link positions held in an LDS tile [64][rs].
+// distance_fields.py:107-124 ('sdf'): objects :298-316, workspace box :319-332, self pairs :194-208.
+// Returns the summed cost of the selected fields; if gtile != nullptr accumulates scale * d cost / d pos.
+// ============================================================================================
+template <bool PRECISE>
+__device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, float w_self, float w_obj, float w_ws,
+                                             const float* tile, float* gtile, int rs, int lane) {
+    float cost = 0.0f;
+    const float* pt = tile + lane * rs;
+    float* gt = gtile ? gtile + lane * rs : nullptr;
+    if ((fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) != 0) {
+        for (int l = 0; l < C.n_obj_links; ++l) {
+            const int li = C.obj_link_idx[l];
+            const float mg = C.obj_link_margin[l];
+            const float x = pt[3 * li], y = pt[3 * li + 1], z = pt[3 * li + 2];
+            float ax = 0.0f, ay = 0.0f, az = 0.0f;
+            if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
+                float best = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
+                for (int o = 0; o < C.n_objects; ++o) {
+                    float gx, gy, gz;
+                    const float v = mg - object_sdf<PRECISE>(C, o, x, y, z, gx, gy, gz);
+                    const bool take = (o == 0) || (v > best);       // max over objects, first maximum wins
+                    best = take ? v : best; bx = take ? gx : bx; by = take ? gy : by; bz = take ? gz : bz;
+                }
+                cost = fmaf(w_obj, best, cost);
+                ax -= w_obj * bx; ay -= w_obj * by; az -= w_obj * bz;
+            }
+            if ((fields & TRK_FIELD_WS) && C.has_ws) {
+                // six plane distances [p - ws_min ; ws_max - p]; max_k (margin - sd_k)
+                const float sd[6] = {x - C.ws_min[0], y - C.ws_min[1], z - C.ws_min[2],
+                                     C.ws_max[0] - x, C.ws_max[1] - y, C.ws_max[2] - z};
+                float best = mg - sd[0]; int bk = 0;
+#pragma unroll
+                for (int k = 1; k < 6; ++k) { const float v = mg - sd[k]; if (v > best) { best = v; bk = k; } }
+                cost = fmaf(w_ws, best, cost);
+                const float sgn = bk < 3 ? -w_ws : w_ws;
+                const int axk = bk < 3 ? bk : bk - 3;
+                ax += axk == 0 ? sgn : 0.0f; ay += axk == 1 ? sgn : 0.0f; az += axk == 2 ? sgn : 0.0f;
+            }
+            if (gt) { gt[3 * li] += ax; gt[3 * li + 1] += ay; gt[3 * li + 2] += az; }
+        }
+    }
+    if (fields & TRK_FIELD_SELF) {
+        for (int pi = 0; pi < C.n_self_pairs; ++pi) {
+            const int a = C.self_pairs[2 * pi], b = C.self_pairs[2 * pi + 1];
+            const float dx = pt[3 * a] - pt[3 * b], dy = pt[3 * a + 1] - pt[3 * b + 1], dz = pt[3 * a + 2] - pt[3 * b + 2];
+            const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+            const float nrm = PRECISE ? sqrtf(n2) : trk_sqrt(n2);
+            cost = fmaf(w_self, C.self_margin[pi] - nrm, cost);
+            if (gt) {
+                const float inv = nrm > 0.0f ? w_self * (PRECISE ? 1.0f / nrm : trk_rcp(nrm)) : 0.0f;
+                const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+                gt[3 * a] -= ux; gt[3 * a + 1] -= uy; gt[3 * a + 2] -= uz;
+                gt[3 * b] += ux; gt[3 * b + 1] += uy; gt[3 * b + 2] += uz;
+            }
+        }
+    }
+    return cost;
+}
+
+// cost [N] and (nullable) g_link_pos [N, Lin, 3] = gcost[n] * d cost[n] / d link_pos
+__global__ void __launch_bounds__(TRK_WAVE)
+k_cost_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos, int64_t n,
+              const float* __restrict__ gcost, float* __restrict__ cost, float* __restrict__ g_link_pos) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int width = C.n_links_in * 3, rs = width | 1;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    float* tile = smem;
+    float* gtile = tile + TRK_WAVE * rs;
+    for (int k = lane; k < TRK_WAVE * rs; k += TRK_WAVE) { tile[k] = 0.0f; gtile[k] = 0.0f; }
+    __syncthreads();
+    load_tile_strided(tile, link_pos, base * width, rows, width, rs, lane);
+    __syncthreads();
+    const float sc = (gcost && lane < rows) ? gcost[base + lane] : 1.0f;
+    const float c = fields_eval<false>(C, fields, 1.0f, 1.0f, 1.0f, tile, g_link_pos ? gtile : nullptr, rs, lane);
+    if (lane < rows) cost[base + lane] = c;
+    if (g_link_pos) {
+        if (gcost) for (int k = 0; k < width; ++k) gtile[lane * rs + k] *= sc;
+        __syncthreads();
+        store_tile_strided(g_link_pos, gtile, base * width, rows, width, rs, lane);
+    }
+}
+
+// distance_fields.py:210-215, 283-291 (field_type='occupancy'); tasks.py:227-228 ORs the fields
+__global__ void __launch_bounds__(TRK_WAVE)
+k_collision_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos, int64_t n,
+                   float margin_override, int use_default, uint8_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int width = C.n_links_in * 3, rs = width | 1;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    float* tile = smem;
+    for (int k = lane; k < TRK_WAVE * rs; k += TRK_WAVE) tile[k] = 0.0f;
+    __syncthreads();
+    load_tile_strided(tile, link_pos, base * width, rows, width, rs, lane);
+    __syncthreads();
+    const float* pt = tile + lane * rs;
+    bool hit = false;
+    if (fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {
+        for (int l = 0; l < C.n_obj_links; ++l) {
+            const int li = C.obj_link_idx[l];
+            const float mg = use_default ? C.obj_link_margin[l] : margin_override;
+            const float x = pt[3 * li], y = pt[3 * li + 1], z = pt[3 * li + 2];
+            if (fields & TRK_FIELD_OBJECTS)
+                for (int o = 0; o < C.n_objects; ++o) {
+                    float gx, gy, gz;
+                    hit |= object_sdf<true>(C, o, x, y, z, gx, gy, gz) < mg;
+                }
+            if ((fields & TRK_FIELD_WS) && C.has_ws) {
+                hit |= (x - C.ws_min[0] < mg) | (y - C.ws_min[1] < mg) | (z - C.ws_min[2] < mg) |
+                       (C.ws_max[0] - x < mg) | (C.ws_max[1] - y < mg) | (C.ws_max[2] - z < mg);
+            }
+        }
+    }
+    if (fields & TRK_FIELD_SELF) {
+        for (int pi = 0; pi < C.n_self_pairs; ++pi) {
+            const int a = C.self_pairs[2 * pi], b = C.self_pairs[2 * pi + 1];
+            const float dx = pt[3 * a] - pt[3 * b], dy = pt[3 * a + 1] - pt[3 * b + 1], dz = pt[3 * a + 2] - pt[3 * b + 2];
+            const float mg = use_default ? C.self_margin[pi] : margin_override;
+            hit |= sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz))) < mg;
+        }
+    }
+    if (lane < rows) out[base + lane] = hit ? 1 : 0;
+}
+
+// EESE3DistanceField.compute_costs_impl distance_fields.py:347-356
+__global__ void __launch_bounds__(256)
+k_ee_cost(DevCostHdr C, const float* __restrict__ H, int64_t n, int64_t stride, const float* __restrict__ target,
+          int per_sample, const float* __restrict__ gcost, float* __restrict__ cost, float* __restrict__ gH, int64_t g_stride) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float4* h = reinterpret_cast<const float4*>(H + s * stride);
+    const float4 h0 = h[0], h1 = h[1], h2 = h[2];
+    const float R[9] = {h0.x, h0.y, h0.z, h1.x, h1.y, h1.z, h2.x, h2.y, h2.z};
+    const float t[3] = {h0.w, h1.w, h2.w};
+    float Ht[16];
+    if (target) {
+        const float* tp = target + (per_sample ? s * 16 : 0);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Ht[k] = tp[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Ht[k] = C.ee_target[k];
+    }
+    float gR[9], gt[3];
+    const float c = ee_cost_eval(R, t, Ht, C.ee_w_pos, C.ee_w_rot, C.ee_square, gR, gt);
+    cost[s] = c;
+    if (gH) {
+        const float sc = gcost ? gcost[s] : 1.0f;
+        float4* g = reinterpret_cast<float4*>(gH + s * g_stride);
+        g[0] = make_float4(sc * gR[0], sc * gR[1], sc * gR[2], sc * gt[0]);
+        g[1] = make_float4(sc * gR[3], sc * gR[4], sc * gR[5], sc * gt[1]);
+        g[2] = make_float4(sc * gR[6], sc * gR[7], sc * gR[8], sc * gt[2]);
+    }
+}
+
+// ============================================================================================
+// Fused rollout, table-driven: walk 1 (FK -> position tile, EE rotation), costs + position adjoints,
+// walk 2 (reverse pass).  q [N,D] -> link_pos [N,L,3] (nullable), cost [N], gq [N,D], cost_sum (nullable).
+// ============================================================================================
+__global__ void __launch_bounds__(TRK_WAVE)
+k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, SelMap sel_unused, DevCostHdr C,
+                  TrkRolloutWeights w, const float* __restrict__ q, int64_t n, float* __restrict__ link_pos,
+                  float* __restrict__ cost, float* __restrict__ gq, float* __restrict__ cost_sum) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int D = hdr.n_dofs, L = hdr.n_links;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    const int width = L * 3, rs = width | 1;
+    float* qs = smem;
+    float* gqs = qs + TRK_WAVE * D;
+    float* jst = gqs + TRK_WAVE * D;
+    float* slots = jst + 7 * D * TRK_WAVE;
+    float* tile = slots + hdr.n_slots * 12 * TRK_WAVE;
+    float* gtile = tile + TRK_WAVE * rs;
+    load_tile(qs, q, base * D, (int64_t)rows * D, lane);
+    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
+    for (int k = lane; k < TRK_WAVE * D; k += TRK_WAVE) gqs[k] = 0.0f;
+    for (int k = lane; k < TRK_WAVE * rs; k += TRK_WAVE) gtile[k] = 0.0f;
+    __syncthreads();
+    // walk 1
+    float eeR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, eet[3] = {0, 0, 0};
+    {
+        Pose cur, par;
+        for (int p = 0; p < L; ++p) {
+            const DevLink& Lk = links[p];
+            walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
+            float* o = tile + lane * rs + 3 * Lk.link;
+            o[0] = cur.t[0]; o[1] = cur.t[1]; o[2] = cur.t[2];
+            if (Lk.link == C.ee_link) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) eeR[k] = cur.r[k];
+                eet[0] = cur.t[0]; eet[1] = cur.t[1]; eet[2] = cur.t[2];
+            }
+        }
+    }
+    // costs and adjoints w.r.t. link positions (per-lane rows of the tiles: no cross-lane hazard)
+    int fields = 0;
+    if (w.w_self != 0.0f) fields |= TRK_FIELD_SELF;
+    if (w.w_obj != 0.0f) fields |= TRK_FIELD_OBJECTS;
+    if (w.w_ws != 0.0f) fields |= TRK_FIELD_WS;
+    float c = fields_eval<false>(C, fields, w.w_self, w.w_obj, w.w_ws, tile, gtile, rs, lane);
+    float eeRb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool use_ee = (w.w_ee != 0.0f) && (C.ee_link >= 0);
+    if (use_ee) {
+        float gt[3];
+        const float ce = ee_cost_eval(eeR, eet, C.ee_target, C.ee_w_pos, C.ee_w_rot, C.ee_square, eeRb, gt);
+        c = fmaf(w.w_ee, ce, c);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) eeRb[k] *= w.w_ee;
+        float* g = gtile + lane * rs + 3 * C.ee_link;
+        g[0] = fmaf(w.w_ee, gt[0], g[0]); g[1] = fmaf(w.w_ee, gt[1], g[1]); g[2] = fmaf(w.w_ee, gt[2], g[2]);
+    }
+    if (lane < rows) cost[base + lane] = c;
+    if (cost_sum) {
+        const float tot = wave_sum(lane < rows ? c : 0.0f);
+        if (lane == 0) atomicAdd(cost_sum, tot);
+    }
+    // walk 2: reverse pass
+    AdjFromTile<true> adj{gtile, rs, lane, sel_unused, use_ee ? C.ee_link : -1, eeRb};
+    reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+    __syncthreads();
+    store_tile(gq, gqs, base * D, (int64_t)rows * D, lane);
+    if (link_pos) store_tile_strided(link_pos, tile, base * width, rows, width, rs, lane);
+}
+
+// ============================================================================================
+// Stateful FK + geometric Jacobian (robot_tree.py:136-190, 218-248; Frame.get_quaternion frame.py:87-114)
+// LDS: q | qd | slots (pose 12 + velocity 6 floats per slot) | joint axes/origins [6][D][64].
+// ============================================================================================
+__device__ __forceinline__ void frame_quat_wxyz(const float* R, float* out) {
+    // trace method with M[3][3] = 1 (frame.py:87-114), then xyzw -> wxyz (quaternion.py:240-242)
+    float t = R[0] + R[4] + R[8] + 1.0f;
+    float qx, qy, qz, qw;
+    if (t > 1.0f) {
+        qw = t; qz = R[3] - R[1]; qy = R[2] - R[6]; qx = R[7] - R[5];
+    } else {
+        // i = arg-max diagonal with the reference's comparison order; (i, j, k) cyclic
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > (i == 0 ? R[0] : R[4])) i = 2;
+        if (i == 0) {
+            t = R[0] - (R[4] + R[8]) + 1.0f;
+            qx = t; qy = R[1] + R[3]; qz = R[6] + R[2]; qw = R[7] - R[5];
+        } else if (i == 1) {
+            t = R[4] - (R[8] + R[0]) + 1.0f;
+            qy = t; qz = R[5] + R[7]; qx = R[1] + R[3]; qw = R[2] - R[6];
+        } else {
+            t = R[8] - (R[0] + R[4]) + 1.0f;
+            qz = t; qx = R[6] + R[2]; qy = R[5] + R[7]; qw = R[3] - R[1];
+        }
+    }
+    const float sc = 0.5f / sqrtf(t);
+    out[0] = qw * sc; out[1] = qx * sc; out[2] = qy * sc; out[3] = qz * sc;
+}
+
+__global__ void __launch_bounds__(TRK_WAVE)
+k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, const float* __restrict__ q, const float* __restrict__ qd,
+              int64_t n, int link, int link_joint_idx, float* __restrict__ pos, float* __restrict__ quat,
+              float* __restrict__ lin_jac, float* __restrict__ ang_jac, float* __restrict__ vel_lin, float* __restrict__ vel_ang) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int D = hdr.n_dofs, L = hdr.n_links;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    float* qs = smem;
+    float* qds = qs + TRK_WAVE * D;
+    float* slots = qds + TRK_WAVE * D;
+    float* vslots = slots + hdr.n_slots * 12 * TRK_WAVE;
+    float* jz = vslots + hdr.n_slots * 6 * TRK_WAVE;      // [6][D][64]: z (3), p (3); z = 0 marks "no column"
+    load_tile(qs, q, base * D, (int64_t)rows * D, lane);
+    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
+    if (qd) load_tile(qds, qd, base * D, (int64_t)rows * D, lane);
+    else for (int k = lane; k < rows * D; k += TRK_WAVE) qds[k] = 0.0f;
+    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qds[k] = 0.0f;
+    for (int k = lane; k < 6 * D * TRK_WAVE; k += TRK_WAVE) jz[k] = 0.0f;
+    __syncthreads();
+    Pose cur, par;
+    float vl[3] = {0, 0, 0}, va[3] = {0, 0, 0};
+    float eR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, et[3] = {0, 0, 0}, evl[3] = {0, 0, 0}, eva[3] = {0, 0, 0};
+    const int js = D * TRK_WAVE;
+    for (int p = 0; p < L; ++p) {
+        const DevLink& Lk = links[p];
+        float pvl[3], pva[3];
+        if (p > 0 && Lk.parent_slot >= 0) {
+            const float* v = vslots + Lk.parent_slot * 6 * TRK_WAVE + lane;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pvl[k] = v[k * TRK_WAVE]; pva[k] = v[(3 + k) * TRK_WAVE]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pvl[k] = vl[k]; pva[k] = va[k]; }
+        }
+        walk_step<true>(hdr, Lk, p, qs, D, lane, slots, cur, par);
+        if (p == 0) { vl[0] = vl[1] = vl[2] = 0.0f; va[0] = va[1] = va[2] = 0.0f; }
+        else {
+            // joint pose J = par^-1 o cur ; parentToChild = J^-1 : R = J.R^T, t = -J.R^T J.t  (frame.py:57-62)
+            // J.R^T = cur.R^T par.R ; J.t = par.R^T (cur.t - par.t)  =>  t_inv = -cur.R^T (cur.t - par.t)
+            float Rt[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    Rt[3 * r + c] = cur.r[r] * par.r[c] + cur.r[3 + r] * par.r[3 + c] + cur.r[6 + r] * par.r[6 + c];
+            const float d0 = cur.t[0] - par.t[0], d1 = cur.t[1] - par.t[1], d2 = cur.t[2] - par.t[2];
+            float ti[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) ti[r] = -(cur.r[r] * d0 + cur.r[3 + r] * d1 + cur.r[6 + r] * d2);
+            float Ra[3], Rl[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                Ra[r] = Rt[3 * r] * pva[0] + Rt[3 * r + 1] * pva[1] + Rt[3 * r + 2] * pva[2];
+                Rl[r] = Rt[3 * r] * pvl[0] + Rt[3 * r + 1] * pvl[1] + Rt[3 * r + 2] * pvl[2];
+            }
+            const float qdv = Lk.dof >= 0 ? qds[lane * D + Lk.dof] : 0.0f;
+            vl[0] = ti[1] * Ra[2] - ti[2] * Ra[1] + Rl[0];
+            vl[1] = ti[2] * Ra[0] - ti[0] * Ra[2] + Rl[1];
+            vl[2] = ti[0] * Ra[1] - ti[1] * Ra[0] + Rl[2];
+            va[0] = Ra[0] + qdv * Lk.axis[0]; va[1] = Ra[1] + qdv * Lk.axis[1]; va[2] = Ra[2] + qdv * Lk.axis[2];
+        }
+        if (Lk.store_slot >= 0) {
+            float* v = vslots + Lk.store_slot * 6 * TRK_WAVE + lane;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { v[k * TRK_WAVE] = vl[k]; v[(3 + k) * TRK_WAVE] = va[k]; }
+        }
+        if (Lk.dof >= 0 && (Lk.link - 1) <= link_joint_idx && Lk.jac_axis >= 0) {   // robot_tree.py:239-244
+            const int ax = Lk.jac_axis;
+            float* j = jz + Lk.dof * TRK_WAVE + lane;
+            j[0] = ax == 0 ? cur.r[0] : (ax == 1 ? cur.r[1] : cur.r[2]);
+            j[js] = ax == 0 ? cur.r[3] : (ax == 1 ? cur.r[4] : cur.r[5]);
+            j[2 * js] = ax == 0 ? cur.r[6] : (ax == 1 ? cur.r[7] : cur.r[8]);
+            j[3 * js] = cur.t[0]; j[4 * js] = cur.t[1]; j[5 * js] = cur.t[2];
+        }
+        if (Lk.link == link) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) eR[k] = cur.r[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { et[k] = cur.t[k]; evl[k] = vl[k]; eva[k] = va[k]; }
+        }
+    }
+    if (lane >= rows) return;
+    const int64_t s = base + lane;
+    pos[s * 3] = et[0]; pos[s * 3 + 1] = et[1]; pos[s * 3 + 2] = et[2];
+    float qo[4];
+    frame_quat_wxyz(eR, qo);
+    quat[s * 4] = qo[0]; quat[s * 4 + 1] = qo[1]; quat[s * 4 + 2] = qo[2]; quat[s * 4 + 3] = qo[3];
+    if (vel_lin) { vel_lin[s * 3] = evl[0]; vel_lin[s * 3 + 1] = evl[1]; vel_lin[s * 3 + 2] = evl[2]; }
+    if (vel_ang) { vel_ang[s * 3] = eva[0]; vel_ang[s * 3 + 1] = eva[1]; vel_ang[s * 3 + 2] = eva[2]; }
+    for (int d = 0; d < D; ++d) {
+        const float* j = jz + d * TRK_WAVE + lane;
+        const float z0 = j[0], z1 = j[js], z2 = j[2 * js];
+        const float r0 = et[0] - j[3 * js], r1 = et[1] - j[4 * js], r2 = et[2] - j[5 * js];
+        lin_jac[(s * 3 + 0) * D + d] = z1 * r2 - z2 * r1;
+        lin_jac[(s * 3 + 1) * D + d] = z2 * r0 - z0 * r2;
+        lin_jac[(s * 3 + 2) * D + d] = z0 * r1 - z1 * r0;
+        ang_jac[(s * 3 + 0) * D + d] = z0;
+        ang_jac[(s * 3 + 1) * D + d] = z1;
+        ang_jac[(s * 3 + 2) * D + d] = z2;
+    }
+}
+
+// rotation_matrix_to_q quaternion.py:135-166
+__global__ void __launch_bounds__(256)
+k_rotmat_to_quat(const float* __restrict__ R, int64_t n, int stride, int pitch, float* __restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float* m = R + s * stride;
+    const float m00 = m[0], m01 = m[1], m02 = m[2];
+    const float m10 = m[pitch], m11 = m[pitch + 1], m12 = m[pitch + 2];
+    const float m20 = m[2 * pitch], m21 = m[2 * pitch + 1], m22 = m[2 * pitch + 2];
+    const float a0 = 1.0f + m00 + m11 + m22, a1 = 1.0f + m00 - m11 - m22;
+    const float a2 = 1.0f - m00 + m11 - m22, a3 = 1.0f - m00 - m11 + m22;
+    const float q0 = a0 > 0.0f ? sqrtf(a0) : 0.0f, q1 = a1 > 0.0f ? sqrtf(a1) : 0.0f;
+    const float q2 = a2 > 0.0f ? sqrtf(a2) : 0.0f, q3 = a3 > 0.0f ? sqrtf(a3) : 0.0f;
+    int best = 0; float qb = q0;
+    if (q1 > qb) { qb = q1; best = 1; }
+    if (q2 > qb) { qb = q2; best = 2; }
+    if (q3 > qb) { qb = q3; best = 3; }
+    const float den = 2.0f * fmaxf(qb, 0.1f);
+    float c0, c1, c2, c3;
+    if (best == 0)      { c0 = q0 * q0; c1 = m21 - m12; c2 = m02 - m20; c3 = m10 - m01; }
+    else if (best == 1) { c0 = m21 - m12; c1 = q1 * q1; c2 = m10 + m01; c3 = m02 + m20; }
+    else if (best == 2) { c0 = m02 - m20; c1 = m10 + m01; c2 = q2 * q2; c3 = m12 + m21; }
+    else                { c0 = m10 - m01; c1 = m20 + m02; c2 = m21 + m12; c3 = q3 * q3; }
+    float4* o = reinterpret_cast<float4*>(out + s * 4);
+    *o = make_float4(c0 / den, c1 / den, c2 / den, c3 / den);
+}
+
+// GridMapSDF.precompute_sdf grid_map_sdf.py:34-63 (analytic objects only) and
+// ObjectField.compute_signed_distance on arbitrary points
+__global__ void __launch_bounds__(256)
+k_grid_precompute(DevCostHdr C, int nx, int ny, int nz, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2,
+                  float* __restrict__ sdf, float* __restrict__ grad) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)nx * ny * nz;
+    if (idx >= total) return;
+    const int iz = (int)(idx % nz), iy = (int)((idx / nz) % ny), ix = (int)(idx / ((int64_t)nz * ny));
+    const int id[3] = {ix, iy, iz}, dims[3] = {nx, ny, nz};
+    const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+    float x[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // torch.linspace: start + i*step for the first half, end - (steps-1-i)*step after
+        const float step = dims[k] > 1 ? (hi[k] - lo[k]) / (float)(dims[k] - 1) : 0.0f;
+        x[k] = id[k] < dims[k] / 2 ? lo[k] + step * (float)id[k] : hi[k] - step * (float)(dims[k] - 1 - id[k]);
+    }
+    float best = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
+    bool first = true;
+    for (int o = 0; o < C.n_objects; ++o) {
+        if (C.objects[o].is_grid) continue;
+        float gx, gy, gz;
+        const float v = object_sdf<true>(C, o, x[0], x[1], x[2], gx, gy, gz);
+        const bool take = first || v < best;
+        best = take ? v : best; bx = take ? gx : bx; by = take ? gy : by; bz = take ? gz : bz;
+        first = false;
+    }
+    sdf[idx] = best;
+    grad[3 * idx] = bx; grad[3 * idx + 1] = by; grad[3 * idx + 2] = bz;
+}
+
+__global__ void __launch_bounds__(256)
+k_sdf_points(DevCostHdr C, const float* __restrict__ pts, int64_t n, float* __restrict__ sdf, float* __restrict__ grad) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float x = pts[3 * s], y = pts[3 * s + 1], z = pts[3 * s + 2];
+    for (int o = 0; o < C.n_objects; ++o) {
+        float gx, gy, gz;
+        sdf[s * C.n_objects + o] = object_sdf<true>(C, o, x, y, z, gx, gy, gz);
+        if (grad) {
+            float* g = grad + (s * C.n_objects + o) * 3;
+            g[0] = gx; g[1] = gy; g[2] = gz;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// host-callable launchers (used by trk_capi.hip)
+// --------------------------------------------------------------------------------------------
+#include "trk_launch.h"
+
+static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+void trk_launch_fk_forward(int mode, const DevModelHdr& hdr, const DevLink* links, const SelMap& sel, int n_sel,
+                           const float* q, int64_t n, float* out, hipStream_t st) {
+    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs + (size_t)hdr.n_slots * 12 * TRK_WAVE +
+                                  (mode == 1 ? (size_t)TRK_WAVE * ((n_sel * 3) | 1) : 0));
+    if (mode == 0) hipLaunchKernelGGL(k_fk_forward<0>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, sel, n_sel, q, n, out);
+    else hipLaunchKernelGGL(k_fk_forward<1>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, sel, n_sel, q, n, out);
+}
+
+void trk_launch_fk_backward(int mode, const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const SelMap& sel,
+                            int n_sel, const float* q, const float* gin, int64_t n, float* gq, hipStream_t st) {
+    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
+                                  (mode == 1 ? (size_t)TRK_WAVE * ((n_sel * 3) | 1) : 0));
+    if (mode == 0) hipLaunchKernelGGL(k_fk_backward<0>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, sel, n_sel, q, gin, n, gq);
+    else hipLaunchKernelGGL(k_fk_backward<1>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, sel, n_sel, q, gin, n, gq);
+}
+
+void trk_launch_cost_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, const float* gcost,
+                            float* cost, float* g_link_pos, hipStream_t st) {
+    size_t lds = sizeof(float) * 2 * (size_t)TRK_WAVE * ((C.n_links_in * 3) | 1);
+    hipLaunchKernelGGL(k_cost_fields, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, C, fields, link_pos, n, gcost, cost, g_link_pos);
+}
+
+void trk_launch_collision_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, float margin,
+                                 int use_default, uint8_t* out, hipStream_t st) {
+    size_t lds = sizeof(float) * (size_t)TRK_WAVE * ((C.n_links_in * 3) | 1);
+    hipLaunchKernelGGL(k_collision_fields, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, C, fields, link_pos, n, margin, use_default, out);
+}
+
+void trk_launch_ee_cost(const DevCostHdr& C, const float* H, int64_t n, int64_t stride, const float* target, int per_sample,
+                        const float* gcost, float* cost, float* gH, int64_t g_stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_ee_cost, dim3(grid_for(n, 256)), dim3(256), 0, st, C, H, n, stride, target, per_sample, gcost, cost, gH, g_stride);
+}
+
+void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevCostHdr& C,
+                                const TrkRolloutWeights& w, const float* q, int64_t n, float* link_pos, float* cost,
+                                float* gq, float* cost_sum, hipStream_t st) {
+    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
+                                  2 * (size_t)TRK_WAVE * ((hdr.n_links * 3) | 1));
+    hipLaunchKernelGGL(k_rollout_generic, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, SelMap{}, C, w, q, n, link_pos, cost, gq, cost_sum);
+}
+
+void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links, const float* q, const float* qd, int64_t n,
+                            int link, int link_joint_idx, float* pos, float* quat, float* lin_jac, float* ang_jac,
+                            float* vel_lin, float* vel_ang, hipStream_t st) {
+    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 8 + (size_t)hdr.n_slots * 18 * TRK_WAVE);
+    hipLaunchKernelGGL(k_fk_jacobian, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, q, qd, n, link, link_joint_idx, pos, quat, lin_jac, ang_jac, vel_lin, vel_ang);
+}
+
+void trk_launch_rotmat_to_quat(const float* R, int64_t n, int stride, int pitch, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_rotmat_to_quat, dim3(grid_for(n, 256)), dim3(256), 0, st, R, n, stride, pitch, out);
+}
+
+void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const float* lo, const float* hi, float* sdf,
+                                float* grad, hipStream_t st) {
+    const int64_t total = (int64_t)dims[0] * dims[1] * dims[2];
+    hipLaunchKernelGGL(k_grid_precompute, dim3(grid_for(total, 256)), dim3(256), 0, st, C, dims[0], dims[1], dims[2],
+                       lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], sdf, grad);
+}
+
+void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st) {
+    hipLaunchKernelGGL(k_sdf_points, dim3(grid_for(n, 256)), dim3(256), 0, st, C, pts, n, sdf, grad);
+}
+
+int trk_kernels_init(void) {
+    const int max_lds = 160 * 1024;
+    hipError_t e = hipSuccess;
+#define TRK_SET(k) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
+    TRK_SET(k_fk_forward<0>); TRK_SET(k_fk_forward<1>); TRK_SET(k_fk_backward<0>); TRK_SET(k_fk_backward<1>);
+    TRK_SET(k_cost_fields); TRK_SET(k_collision_fields); TRK_SET(k_rollout_generic); TRK_SET(k_fk_jacobian);
+#undef TRK_SET
+    return e == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,26 @@
+// trk_launch.h -- host-callable launchers defined next to the kernels they start.
+#pragma once
+#include "trk_device.h"
+
+void trk_launch_fk_forward(int mode, const DevModelHdr& hdr, const DevLink* links, const SelMap& sel, int n_sel,
+                           const float* q, int64_t n, float* out, hipStream_t st);
+void trk_launch_fk_backward(int mode, const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const SelMap& sel,
+                            int n_sel, const float* q, const float* gin, int64_t n, float* gq, hipStream_t st);
+void trk_launch_cost_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, const float* gcost,
+                            float* cost, float* g_link_pos, hipStream_t st);
+void trk_launch_collision_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, float margin,
+                                 int use_default, uint8_t* out, hipStream_t st);
+void trk_launch_ee_cost(const DevCostHdr& C, const float* H, int64_t n, int64_t stride, const float* target, int per_sample,
+                        const float* gcost, float* cost, float* gH, int64_t g_stride, hipStream_t st);
+void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevCostHdr& C,
+                                const TrkRolloutWeights& w, const float* q, int64_t n, float* link_pos, float* cost,
+                                float* gq, float* cost_sum, hipStream_t st);
+void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links, const float* q, const float* qd, int64_t n,
+                            int link, int link_joint_idx, float* pos, float* quat, float* lin_jac, float* ang_jac,
+                            float* vel_lin, float* vel_ang, hipStream_t st);
+void trk_launch_rotmat_to_quat(const float* R, int64_t n, int stride, int pitch, float* out, hipStream_t st);
+void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const float* lo, const float* hi, float* sdf,
+                                float* grad, hipStream_t st);
+void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st);
+// raises the dynamic-LDS ceiling of every kernel once (gfx950: 160 KiB per workgroup)
+int trk_kernels_init(void);

@@ -1,0 +1,390 @@
+"""Raw operators: torch CUDA(ROCm) tensors in, torch tensors out, arithmetic in libtrk.so.
+
+torch is used here for device memory, streams and autograd bookkeeping only; every
+floating-point operation of the path happens in the HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._lib import check, lib
+from .costmodel import CostModelSpec
+from .kinmodel import KinModel
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev_f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; torch_robotics_amd computes only on the GPU "
+                           f"(there is no CPU path)")
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class ModelHandle:
+    """Owns a TrkModel* (device copy of the kinematic tables)."""
+
+    def __init__(self, kin: KinModel):
+        self.kin = kin
+        desc, keep = _abi.kin_desc(kin)
+        h = C.c_void_p()
+        check(lib().trk_model_create(C.byref(desc), C.byref(h)), "trk_model_create")
+        self._h = h
+        self.n_links, self.n_dofs = kin.n_links, kin.n_dofs
+
+    def set_base_pose(self, R: np.ndarray, t: np.ndarray) -> None:
+        R = np.ascontiguousarray(R, np.float32).reshape(9)
+        t = np.ascontiguousarray(t, np.float32).reshape(3)
+        check(lib().trk_model_set_base_pose(self._h, R.ctypes.data, t.ctypes.data), "trk_model_set_base_pose")
+
+    @property
+    def specialized(self) -> bool:
+        return bool(lib().trk_model_is_specialized(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().trk_model_destroy(h)
+            except Exception:
+                pass
+
+
+class CostHandle:
+    """Owns a TrkCostModel* (device copy of the objective tables; keeps grid tensors alive)."""
+
+    def __init__(self, spec: CostModelSpec, device):
+        spec.validate()
+        self.spec = spec
+        self.device = torch.device(device)
+        grid_ptrs = None
+        self._grid = None
+        if spec.grid is not None:
+            sdf = torch.as_tensor(spec.grid["sdf"], dtype=torch.float32).to(self.device).contiguous()
+            grad = torch.as_tensor(spec.grid["grad"], dtype=torch.float32).to(self.device).contiguous()
+            self._grid = (sdf, grad)
+            grid_ptrs = (sdf.data_ptr(), grad.data_ptr())
+        desc, keep = _abi.cost_desc(spec, grid_ptrs)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().trk_cost_model_create(C.byref(desc), C.byref(h)), "trk_cost_model_create")
+        self._h = h
+        self.n_links_in = spec.n_links_in
+        self.n_objects = len(spec.objects)
+
+    def set_ee_target(self, H) -> None:
+        H = np.ascontiguousarray(np.asarray(H, np.float32).reshape(16))
+        check(lib().trk_cost_model_set_ee_target(self._h, H.ctypes.data), "trk_cost_model_set_ee_target")
+        self.spec.ee_target = H.reshape(4, 4).copy()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().trk_cost_model_destroy(h)
+            except Exception:
+                pass
+
+
+def _sel(sel: Optional[Sequence[int]]):
+    if sel is None:
+        return None, 0, None
+    arr = np.ascontiguousarray(sel, np.int32)
+    return arr.ctypes.data, int(arr.size), arr
+
+
+# ----------------------------------------------------------------------------------------------
+# plain (non-autograd) calls
+# ----------------------------------------------------------------------------------------------
+def fk_forward(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
+    q = _dev_f32(q, "fk_forward(q)").reshape(-1, model.n_dofs)
+    n = q.shape[0]
+    p, ns, keep = _sel(sel)
+    ncol = ns if p else model.n_links
+    H = torch.empty((n, ncol, 4, 4), device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        check(lib().trk_fk_forward(model._h, q.data_ptr(), n, p, ns, H.data_ptr(), _stream(q)), "trk_fk_forward")
+    return H
+
+
+def fk_positions(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
+    q = _dev_f32(q, "fk_positions(q)").reshape(-1, model.n_dofs)
+    n = q.shape[0]
+    p, ns, keep = _sel(sel)
+    ncol = ns if p else model.n_links
+    pos = torch.empty((n, ncol, 3), device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        check(lib().trk_fk_positions(model._h, q.data_ptr(), n, p, ns, pos.data_ptr(), _stream(q)), "trk_fk_positions")
+    return pos
+
+
+def fk_backward(model: ModelHandle, q: torch.Tensor, gH: torch.Tensor, sel=None) -> torch.Tensor:
+    q = _dev_f32(q, "fk_backward(q)").reshape(-1, model.n_dofs)
+    gH = _dev_f32(gH, "fk_backward(gH)")
+    n = q.shape[0]
+    p, ns, keep = _sel(sel)
+    gq = torch.zeros_like(q)
+    with torch.cuda.device(q.device):
+        check(lib().trk_fk_backward(model._h, q.data_ptr(), gH.data_ptr(), n, p, ns, gq.data_ptr(), _stream(q)),
+              "trk_fk_backward")
+    return gq
+
+
+def fk_positions_backward(model: ModelHandle, q: torch.Tensor, gpos: torch.Tensor, sel=None) -> torch.Tensor:
+    q = _dev_f32(q, "fk_positions_backward(q)").reshape(-1, model.n_dofs)
+    gpos = _dev_f32(gpos, "fk_positions_backward(gpos)")
+    n = q.shape[0]
+    p, ns, keep = _sel(sel)
+    gq = torch.zeros_like(q)
+    with torch.cuda.device(q.device):
+        check(lib().trk_fk_positions_backward(model._h, q.data_ptr(), gpos.data_ptr(), n, p, ns, gq.data_ptr(),
+                                              _stream(q)), "trk_fk_positions_backward")
+    return gq
+
+
+def fk_jacobian(model: ModelHandle, q: torch.Tensor, qd: Optional[torch.Tensor], link: int, want_vel=False):
+    q = _dev_f32(q, "fk_jacobian(q)").reshape(-1, model.n_dofs)
+    n, D = q.shape[0], model.n_dofs
+    qd_t = None if qd is None else _dev_f32(qd, "fk_jacobian(qd)").reshape(n, D)
+    kw = dict(device=q.device, dtype=torch.float32)
+    pos, quat = torch.empty((n, 3), **kw), torch.empty((n, 4), **kw)
+    lin, ang = torch.empty((n, 3, D), **kw), torch.empty((n, 3, D), **kw)
+    vl = torch.empty((n, 3), **kw) if want_vel else None
+    va = torch.empty((n, 3), **kw) if want_vel else None
+    with torch.cuda.device(q.device):
+        check(lib().trk_fk_jacobian(model._h, q.data_ptr(), _ptr(qd_t), n, int(link), pos.data_ptr(), quat.data_ptr(),
+                                    lin.data_ptr(), ang.data_ptr(), _ptr(vl), _ptr(va), _stream(q)), "trk_fk_jacobian")
+    return (pos, quat, lin, ang, vl, va) if want_vel else (pos, quat, lin, ang)
+
+
+def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
+    """rotation_matrix_to_q on (..., 3, 3) rotations or (..., 4, 4) transforms -> (..., 4) wxyz."""
+    R = _dev_f32(R, "rotmat_to_quat(R)")
+    if R.shape[-2:] == (3, 3):
+        stride, pitch = 9, 3
+    elif R.shape[-2:] == (4, 4):
+        stride, pitch = 16, 4
+    else:
+        raise ValueError("rotmat_to_quat: expected (...,3,3) or (...,4,4)")
+    batch = R.shape[:-2]
+    n = int(np.prod(batch)) if len(batch) else 1
+    out = torch.empty(tuple(batch) + (4,), device=R.device, dtype=torch.float32)
+    with torch.cuda.device(R.device):
+        check(lib().trk_rotmat_to_quat(R.data_ptr(), n, stride, pitch, out.data_ptr(), _stream(R)), "trk_rotmat_to_quat")
+    return out
+
+
+def cost_fields(cm: CostHandle, fields: int, link_pos: torch.Tensor, gcost: Optional[torch.Tensor] = None,
+                want_grad: bool = False):
+    link_pos = _dev_f32(link_pos, "cost_fields(link_pos)").reshape(-1, cm.n_links_in, 3)
+    n = link_pos.shape[0]
+    cost = torch.empty((n,), device=link_pos.device, dtype=torch.float32)
+    g = torch.empty_like(link_pos) if want_grad else None
+    gc = None if gcost is None else _dev_f32(gcost, "cost_fields(gcost)").reshape(n)
+    with torch.cuda.device(link_pos.device):
+        check(lib().trk_cost_fields(cm._h, int(fields), link_pos.data_ptr(), n, _ptr(gc), cost.data_ptr(), _ptr(g),
+                                    _stream(link_pos)), "trk_cost_fields")
+    return (cost, g) if want_grad else cost
+
+
+def collision_fields(cm: CostHandle, fields: int, link_pos: torch.Tensor, margin: Optional[float] = None) -> torch.Tensor:
+    link_pos = _dev_f32(link_pos, "collision_fields(link_pos)").reshape(-1, cm.n_links_in, 3)
+    n = link_pos.shape[0]
+    out = torch.empty((n,), device=link_pos.device, dtype=torch.uint8)
+    with torch.cuda.device(link_pos.device):
+        check(lib().trk_collision_fields(cm._h, int(fields), link_pos.data_ptr(), n,
+                                         float("nan") if margin is None else float(margin), out.data_ptr(),
+                                         _stream(link_pos)), "trk_collision_fields")
+    return out.bool()
+
+
+def ee_cost(cm: CostHandle, H: torch.Tensor, target: Optional[torch.Tensor] = None,
+            gcost: Optional[torch.Tensor] = None, want_grad: bool = False):
+    """H: (N,4,4) contiguous EE transforms (or a strided view made contiguous)."""
+    H = _dev_f32(H, "ee_cost(H)").reshape(-1, 4, 4)
+    n = H.shape[0]
+    per_sample, tgt = 0, None
+    if target is not None:
+        tgt = _dev_f32(target, "ee_cost(target)")
+        per_sample = int(tgt.dim() == 3)
+        if per_sample and tgt.shape[0] != n:
+            raise ValueError("ee_cost: per-sample target batch mismatch")
+    cost = torch.empty((n,), device=H.device, dtype=torch.float32)
+    gH = torch.zeros_like(H) if want_grad else None
+    gc = None if gcost is None else _dev_f32(gcost, "ee_cost(gcost)").reshape(n)
+    with torch.cuda.device(H.device):
+        check(lib().trk_ee_cost(cm._h, H.data_ptr(), n, 16, _ptr(tgt), per_sample, _ptr(gc), cost.data_ptr(),
+                                _ptr(gH), 16, _stream(H)), "trk_ee_cost")
+    return (cost, gH) if want_grad else cost
+
+
+def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True,
+                      cost_sum: Optional[torch.Tensor] = None, out=None):
+    """q (B,H,D) or (N,D) -> (link_pos (…,L,3) or None, cost (…), gq (…,D))."""
+    q = _dev_f32(q, "rollout_cost_grad(q)")
+    lead = q.shape[:-1]
+    if q.dim() == 3:
+        B, Hh = int(q.shape[0]), int(q.shape[1])
+    else:
+        q = q.reshape(-1, model.n_dofs)
+        B, Hh = int(q.shape[0]), 1
+    n, L, D = B * Hh, model.n_links, model.n_dofs
+    if out is None:
+        pos = torch.empty((n, L, 3), device=q.device, dtype=torch.float32) if want_pos else None
+        cost = torch.empty((n,), device=q.device, dtype=torch.float32)
+        gq = torch.empty((n, D), device=q.device, dtype=torch.float32)
+    else:
+        pos, cost, gq = out
+    w = _abi.RolloutWeights(*[float(v) for v in weights])
+    with torch.cuda.device(q.device):
+        check(lib().trk_rollout_cost_grad(model._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos), cost.data_ptr(),
+                                          gq.data_ptr(), _ptr(cost_sum), _stream(q)), "trk_rollout_cost_grad")
+    return (None if pos is None else pos.reshape(tuple(lead) + (L, 3)), cost.reshape(tuple(lead)),
+            gq.reshape(tuple(lead) + (D,)))
+
+
+def grid_precompute(cm: CostHandle, dims, lim_min, lim_max):
+    dims_a = np.ascontiguousarray(dims, np.int32)
+    lo, hi = np.ascontiguousarray(lim_min, np.float32), np.ascontiguousarray(lim_max, np.float32)
+    shape = tuple(int(d) for d in dims_a)
+    sdf = torch.empty(shape, device=cm.device, dtype=torch.float32)
+    grad = torch.empty(shape + (3,), device=cm.device, dtype=torch.float32)
+    with torch.cuda.device(cm.device):
+        check(lib().trk_grid_precompute(cm._h, dims_a.ctypes.data, lo.ctypes.data, hi.ctypes.data, sdf.data_ptr(),
+                                        grad.data_ptr(), torch.cuda.current_stream(cm.device).cuda_stream),
+              "trk_grid_precompute")
+    return sdf, grad
+
+
+def sdf_points(cm: CostHandle, pts: torch.Tensor, want_grad=False):
+    pts = _dev_f32(pts, "sdf_points(pts)").reshape(-1, 3)
+    n = pts.shape[0]
+    sdf = torch.empty((n, cm.n_objects), device=pts.device, dtype=torch.float32)
+    grad = torch.empty((n, cm.n_objects, 3), device=pts.device, dtype=torch.float32) if want_grad else None
+    with torch.cuda.device(pts.device):
+        check(lib().trk_sdf_points(cm._h, pts.data_ptr(), n, sdf.data_ptr(), _ptr(grad), _stream(pts)), "trk_sdf_points")
+    return (sdf, grad) if want_grad else sdf
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: explicit backward kernels instead of a recorded graph
+# ----------------------------------------------------------------------------------------------
+class _FK(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, model, sel):
+        ctx.model, ctx.sel = model, sel
+        ctx.save_for_backward(q)
+        return fk_forward(model, q, sel)
+
+    @staticmethod
+    def backward(ctx, gH):
+        (q,) = ctx.saved_tensors
+        gq = fk_backward(ctx.model, q, gH.contiguous(), ctx.sel)
+        return gq.reshape(q.shape), None, None
+
+
+class _FKPos(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, model, sel):
+        ctx.model, ctx.sel = model, sel
+        ctx.save_for_backward(q)
+        return fk_positions(model, q, sel)
+
+    @staticmethod
+    def backward(ctx, gpos):
+        (q,) = ctx.saved_tensors
+        gq = fk_positions_backward(ctx.model, q, gpos.contiguous(), ctx.sel)
+        return gq.reshape(q.shape), None, None
+
+
+class _CostFields(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, link_pos, cm, fields):
+        ctx.cm, ctx.fields = cm, fields
+        ctx.save_for_backward(link_pos)
+        return cost_fields(cm, fields, link_pos)
+
+    @staticmethod
+    def backward(ctx, gcost):
+        (link_pos,) = ctx.saved_tensors
+        _, g = cost_fields(ctx.cm, ctx.fields, link_pos, gcost=gcost.contiguous(), want_grad=True)
+        return g.reshape(link_pos.shape), None, None
+
+
+class _EECost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H, cm, target):
+        ctx.cm = cm
+        ctx.save_for_backward(H, target if target is not None else torch.empty(0, device=H.device))
+        ctx.has_target = target is not None
+        return ee_cost(cm, H, target)
+
+    @staticmethod
+    def backward(ctx, gcost):
+        H, target = ctx.saved_tensors
+        _, gH = ee_cost(ctx.cm, H, target if ctx.has_target else None, gcost=gcost.contiguous(), want_grad=True)
+        return gH.reshape(H.shape), None, None
+
+
+class _Rollout(torch.autograd.Function):
+    """cost (…), link_pos (…,L,3) from q; backward uses the gradient the fused kernel already produced."""
+
+    @staticmethod
+    def forward(ctx, q, model, cm, weights):
+        pos, cost, gq = rollout_cost_grad(model, cm, weights, q, want_pos=True)
+        ctx.save_for_backward(gq)
+        ctx.mark_non_differentiable(pos)
+        return cost, pos
+
+    @staticmethod
+    def backward(ctx, gcost, _gpos):
+        (gq,) = ctx.saved_tensors
+        return gq * gcost.unsqueeze(-1), None, None, None
+
+
+def fk(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
+    q2 = _dev_f32(q, "fk(q)").reshape(-1, model.n_dofs)
+    if torch.is_grad_enabled() and q.requires_grad:
+        return _FK.apply(q2, model, sel)
+    return fk_forward(model, q2, sel)
+
+
+def fk_pos(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
+    q2 = _dev_f32(q, "fk_pos(q)").reshape(-1, model.n_dofs)
+    if torch.is_grad_enabled() and q.requires_grad:
+        return _FKPos.apply(q2, model, sel)
+    return fk_positions(model, q2, sel)
+
+
+def cost_fields_ad(cm: CostHandle, fields: int, link_pos: torch.Tensor) -> torch.Tensor:
+    lp = _dev_f32(link_pos, "cost_fields(link_pos)").reshape(-1, cm.n_links_in, 3)
+    if torch.is_grad_enabled() and link_pos.requires_grad:
+        return _CostFields.apply(lp, cm, fields)
+    return cost_fields(cm, fields, lp)
+
+
+def ee_cost_ad(cm: CostHandle, H: torch.Tensor, target=None) -> torch.Tensor:
+    Hc = _dev_f32(H, "ee_cost(H)").reshape(-1, 4, 4)
+    if torch.is_grad_enabled() and H.requires_grad:
+        return _EECost.apply(Hc, cm, target)
+    return ee_cost(cm, Hc, target)
+
+
+def rollout_ad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor):
+    """Differentiable fused op: returns (cost, link_pos)."""
+    return _Rollout.apply(_dev_f32(q, "rollout(q)"), model, cm, tuple(float(w) for w in weights))
