@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FK + cost + gradient rollouts/sec (batch x horizon), Franka Panda 7-DOF.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the fused hot path (`trk_rollout_cost_grad`) over one batch of synthetic joint
+trajectories resident in HBM: read q, write link positions, cost and d cost / d q.
+Workload (BASELINE.json configs[1], "c2"): batch 4096 x horizon 64, Panda (11 links / 7 DOF), scene
+EnvSpheres3D (10 spheres, analytic SDF, cutoff 0.03), cost = object collision + EE SE(3) tracking
+(target p=(0.4,0.2,0.5), R=I).  `--config c3` adds self-collision pairs and the workspace box.
+Multi-GPU: the batch is sharded, each rank owns 4096 x 64 samples (weak scaling); the only exchange is an
+RCCL all-reduce of the per-evaluation cost sums, issued once per `--reduce-every` steps on a side stream.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = 192 algorithmic bytes/sample x samples per launch /
+average launch duration (HIP events around the timed region on the launch stream).
+`cpu_baseline` = the C oracle (OpenMP over samples, all host cores) on a bounded sample of the same input.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_sample(D, L):
+    # read q (4D) + write link positions (12L) + cost (4) + gradient (4D)
+    return 4 * D + 12 * L + 4 + 4 * D
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--horizon", type=int, default=64)
+    ap.add_argument("--reduce-every", type=int, default=16)
+    ap.add_argument("--graph", type=int, default=0, help="capture this many steps per hipGraph replay (0 = eager launches)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import torch_robotics_amd as tra
+    from torch_robotics_amd import ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    ta = dict(device=dev, dtype=torch.float32)
+    robot = tra.RobotPanda(tensor_args=ta)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=ta), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=ta)
+    Ht = np.eye(4, dtype=np.float32)
+    Ht[:3, 3] = (0.4, 0.2, 0.5)
+    task.set_ee_target(Ht, w_pos=1.0, w_rot=1.0, square=True)
+    weights = (0.0, 1.0, 0.0, 1.0) if args.config == "c2" else (1.0, 1.0, 1.0, 1.0)
+    B, H = args.batch, args.horizon
+    D, L = robot.q_dim, robot.diff_panda._kin.n_links
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    q = robot.random_q(B * H, generator=gen).reshape(B, H, D).contiguous()
+    model, cm = task._fused_handles(dev)
+    plan = ops.RolloutPlan(model, cm, weights, q, want_pos=True)
+    n_slots = args.warmup + args.steps + 8
+    cost_sums = torch.zeros(n_slots, **ta)
+    slot_ptr = cost_sums.data_ptr()
+    stream = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev) if world > 1 else None
+
+    def reduce_slots(lo, hi):
+        # one small all-reduce for `hi - lo` evaluations, off the launch stream
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            dist.all_reduce(cost_sums[lo:hi])
+
+    graph = None
+    if args.graph > 0:
+        # launch-bound inner loop -> hipGraph: G consecutive evaluations per replay (each into its own sum slot
+        # of a G-wide window; the window is copied out by the caller when it needs the values)
+        G = args.graph
+        gstream = torch.cuda.Stream(dev)
+        window = torch.zeros(G, **ta)
+        with torch.cuda.stream(gstream):
+            for i in range(3):
+                plan.launch(window.data_ptr() + 4 * (i % G), gstream.cuda_stream)
+        gstream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=gstream):
+            for i in range(G):
+                plan.launch(window.data_ptr() + 4 * i, torch.cuda.current_stream(dev).cuda_stream)
+
+    def run(first, count):
+        if graph is not None:
+            assert count % args.graph == 0
+            for _ in range(count // args.graph):
+                graph.replay()
+            return
+        s = stream.cuda_stream
+        for i in range(first, first + count):
+            plan.launch(slot_ptr + 4 * i, s)
+            if side is not None and (i + 1 - first) % args.reduce_every == 0:
+                reduce_slots(i + 1 - args.reduce_every, i + 1)
+
+    if graph is not None:
+        args.steps = max(args.graph, args.steps // args.graph * args.graph)
+        args.warmup = max(args.graph, args.warmup // args.graph * args.graph)
+    run(0, args.warmup)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(args.warmup, args.steps)
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1) if graph is None else elapsed * 1e3
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    samples_per_step = B * H * world
+    value = samples_per_step * args.steps / elapsed
+    bytes_per_launch = algorithmic_bytes_per_sample(D, L) * B * H
+    launch_s = ev_ms * 1e-3 / args.steps
+    achieved = bytes_per_launch / launch_s / 1e9
+
+    # sanity: the outputs of the last step are finite and the cost sums agree with the per-sample costs
+    assert torch.isfinite(plan.cost).all() and torch.isfinite(plan.gq).all()
+    if graph is None:
+        last = cost_sums[args.warmup + args.steps - 1].item()
+        ref = plan.cost.double().sum().item() * (world if side is not None and args.steps % args.reduce_every == 0 else 1)
+        if world == 1:
+            assert abs(last - ref) <= 1e-3 * abs(ref) + 1e-3, (last, ref)
+
+    out = {
+        "metric": "FK+cost+grad rollouts/sec (batch x horizon), Panda 7-DOF",
+        "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: Franka Panda (11 links, 7 DOF), batch={B} x horizon={H} per GPU, "
+                               f"fused FK + " + ("SDF-obstacle (EnvSpheres3D, 10 spheres) + EE-tracking"
+                                                 if args.config == "c2" else
+                                                 "self-collision + SDF-obstacle + workspace box + EE-tracking") +
+                               " cost + gradient, q resident in HBM",
+                   "global_batch": B * world, "horizon": H, "parallelism": f"batch-sharded x{world}",
+                   "launch": "hipGraph x%d" % args.graph if graph is not None else "eager, pre-bound C-ABI call",
+                   "kernel": "specialized" if model.specialized else "table-driven",
+                   "reduce_every": args.reduce_every if world > 1 else None},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_sample": algorithmic_bytes_per_sample(D, L), "launch_us": launch_s * 1e6},
+    }
+
+    if rank == 0 and args.cpu_seconds > 0:
+        from oracle import oracle as orc          # checker / baseline only: never on the product path
+        from torch_robotics_amd.kinmodel import KinModel
+        o = orc.Oracle(robot.diff_panda._kin, task.build_cost_spec())
+        q_host = q.reshape(-1, D).cpu().numpy()
+        cores = orc.max_threads()
+        probe = q_host[:16384]
+        t = time.perf_counter(); o.rollout(probe, weights, "f32"); dt = time.perf_counter() - t
+        n_s = int(min(len(q_host), max(16384, len(probe) / dt * args.cpu_seconds / 3)))
+        reps, best = 3, 1e30
+        for _ in range(reps):
+            t = time.perf_counter(); o.rollout(q_host[:n_s], weights, "f32"); best = min(best, time.perf_counter() - t)
+        out["cpu_baseline"] = {"value": n_s / best, "unit": "rollouts/s", "cores": cores, "kind": "port",
+                               "sample": f"first {n_s} of the {B * H} samples of rank 0's batch, C oracle (fp32, OpenMP "
+                                         f"over samples, {cores} threads), best of {reps}"}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,7 +53,9 @@ def test_fk_forward_backward_vs_golden(ops, robot):
     gq_b = ops.fk_backward(h, dev(g["q_in"]), dev(wfull)).cpu().numpy()
     np.testing.assert_allclose(gq_a, gq_b, rtol=1e-5, atol=1e-5)
     gq_p = ops.fk_positions_backward(h, dev(g["q_in"]), dev(w[..., :3, 3]), sel).cpu().numpy()
-    wpos = np.zeros_like(wfull); wpos[:, sel, :3, 3] = w[..., :3, 3]
+    wpos = np.zeros_like(wfull)
+    for c, li in enumerate(sel):
+        wpos[:, li, :3, 3] = w[:, c, :3, 3]
     gq_pb = ops.fk_backward(h, dev(g["q_in"]), dev(wpos)).cpu().numpy()
     np.testing.assert_allclose(gq_p, gq_pb, rtol=1e-5, atol=1e-5)
 

@@ -1,0 +1,149 @@
+"""CPU-only: the host-side mirror of the reference interface (model compiler, scene tables, cost specs,
+error behaviour) against golden data dumped from the reference."""
+import numpy as np
+import pytest
+import torch
+
+import torch_robotics_amd as tra
+from helpers import GOLD, ROBOTS, URDF, gold, model, objects_from_golden, panda_cost_spec
+from torch_robotics_amd.kinmodel import KinModel
+
+TA = dict(device=torch.device("cpu"), dtype=torch.float32)
+TYPE_NAMES = {0: "fixed", 1: "revolute", 2: "continuous", 3: "prismatic"}
+
+
+@pytest.mark.parametrize("robot", ROBOTS)
+def test_model_compiler_matches_reference_build(robot):
+    """A1: link/DOF order, parents, origins, fixed rotations (bit-exact), axes, types, limits."""
+    g, m = gold(f"fk_{robot}"), model(robot)
+    assert list(g["link_names"]) == m.link_names
+    assert int(g["n_dofs"]) == m.n_dofs
+    np.testing.assert_array_equal(g["controlled"], m.controlled)
+    np.testing.assert_array_equal(g["parent"], m.parent)
+    np.testing.assert_array_equal(g["trans"], m.trans)
+    np.testing.assert_array_equal(g["R_fixed"], m.R_fixed)
+    np.testing.assert_array_equal(g["axis"], m.axis)
+    assert [TYPE_NAMES[int(t)] for t in m.joint_type] == list(g["joint_type"])
+    np.testing.assert_array_equal(g["has_limits"].astype(np.int32), m.has_limits)
+    np.testing.assert_array_equal(g["lower"].astype(np.float32), m.lower)
+    np.testing.assert_array_equal(g["upper"].astype(np.float32), m.upper)
+    # traversal tables are self-consistent
+    assert sorted(m.order) == list(range(m.n_links)) and m.order[0] == 0
+    pos = np.argsort(m.order)
+    for p, i in enumerate(m.order):
+        if p:
+            assert pos[m.parent[i]] < p
+            if m.parent_slot[p] < 0:
+                assert m.order[p - 1] == m.parent[i]
+        assert p < m.subtree_end[p] <= m.n_links
+
+
+def test_reference_originals_give_the_same_model():
+    """The kinematics-only URDFs shipped here compile to the same tables as the reference's own files
+    (only checked where /root/reference exists, i.e. in the development container)."""
+    from pathlib import Path
+    ref = Path("/root/reference/torch_robotics/data/urdf/robots")
+    if not ref.exists():
+        pytest.skip("reference not present")
+    pairs = {"panda_arm_no_gripper": "franka_description/robots/panda_arm_no_gripper.urdf",
+             "ur10": "ur10/urdf/ur10.urdf", "allegro_hand": "allegro_hand/allegro_hand.urdf",
+             "hab_stretch": "habitat_stretch/urdf/hab_stretch.urdf"}
+    for name, rel in pairs.items():
+        a, b = model(name), KinModel.from_urdf(str(ref / rel))
+        for f in ("parent", "joint_type", "dof_idx", "R_fixed", "trans", "axis", "lower", "upper", "order"):
+            np.testing.assert_array_equal(getattr(a, f), getattr(b, f))
+
+
+def test_urdf_error_cases(tmp_path):
+    bad = tmp_path / "r.urdf"
+    bad.write_text('<robot name="r"><link name="a"/><link name="b"/></robot>')
+    with pytest.raises(ValueError, match="not the child of any joint"):
+        KinModel.from_urdf(str(bad))
+    bad.write_text('<robot name="r"><link name="a"/><link name="b"/>'
+                   '<joint name="j" type="floating"><parent link="a"/><child link="b"/></joint></robot>')
+    m = KinModel.from_urdf(str(bad))
+    assert m.has_unsupported_joint() == "b" and m.n_dofs == 1
+    with pytest.raises(NotImplementedError):
+        tra.DifferentiableTree("robot.xml")
+    t = tra.DifferentiableTree(str(bad), device="cpu")
+    with pytest.raises(NotImplementedError):
+        t.compute_forward_kinematics_all_links(torch.zeros(2, 1))
+
+
+def test_tree_api_surface():
+    t = tra.DifferentiableFrankaPanda(device="cpu")
+    assert t._n_dofs == 7 and t._name_to_idx_map["ee_link"] == 10
+    assert t.get_link_names() == [f"panda_link{i}" for i in range(9)] + ["panda_hand", "ee_link"]
+    lo, hi, vlo, vhi = t.get_joint_limit_array()
+    np.testing.assert_allclose(lo, [-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973])
+    np.testing.assert_allclose(hi, [2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973])
+    np.testing.assert_allclose(vhi, [2.175, 2.175, 2.175, 2.175, 2.61, 2.61, 2.61])
+    assert lo.dtype == np.float64
+    assert tra.DifferentiableTiagoDualHoloMove(device="cpu").get_link_names()[0] == \
+        model("tiago_dual_holobase_minimal_holonomic").link_names[3]
+
+
+ENV_CLASSES = {"spheres3d": tra.EnvSpheres3D, "table_shelf": tra.EnvTableShelf, "maze_boxes3d": tra.EnvMazeBoxes3D,
+               "spheres3d_extra": tra.EnvSpheres3DExtraObjects}
+
+
+@pytest.mark.parametrize("env", sorted(ENV_CLASSES))
+def test_scene_tables_match_reference(env):
+    """Scene data (A10): primitive centres / sizes / rounding radii / object poses equal the reference's."""
+    g = gold(f"cost_{env}")
+    e = ENV_CLASSES[env](tensor_args=TA)
+    np.testing.assert_array_equal(e.limits_np, g["limits"])
+    for tag, objs in (("fixed", e.obj_fixed_list), ("extra", e.obj_extra_list)):
+        ref = objects_from_golden(g, tag)
+        mine = [o.as_object() for o in (objs or [])]
+        assert len(ref) == len(mine)
+        for a, b in zip(ref, mine):
+            np.testing.assert_array_equal(a["pos"], b["pos"])
+            np.testing.assert_array_equal(a["R"], b["R"])
+            assert len(a["prims"]) == len(b["prims"])
+            for pa, pb in zip(a["prims"], b["prims"]):
+                assert pa["type"] == pb["type"]
+                np.testing.assert_array_equal(pa["center"], pb["center"])
+                np.testing.assert_array_equal(pa.get("half", 0), pb.get("half", 0))
+                assert np.float32(pa["radius"]) == np.float32(pb["radius"])
+
+
+@pytest.mark.parametrize("env", sorted(ENV_CLASSES))
+def test_planning_task_cost_spec_matches_reference(env):
+    """RobotPanda + PlanningTask assemble the same collision model as the reference (A6, A9, A14)."""
+    g, robot_g = gold(f"cost_{env}"), gold("panda_robot")
+    robot = tra.RobotPanda(tensor_args=TA)
+    np.testing.assert_array_equal(robot.link_idxs_for_object_collision_checking, robot_g["obj_link_idxs"])
+    np.testing.assert_array_equal(robot.link_idxs_for_self_collision_checking, robot_g["self_link_idxs"])
+    np.testing.assert_array_equal(robot.df_collision_self.idxs_links_distance_matrix, robot_g["self_pairs"])
+    np.testing.assert_array_equal(robot.q_limits.numpy(), robot_g["q_limits"])
+    task = tra.PlanningTask(env=ENV_CLASSES[env](tensor_args=TA), robot=robot, obstacle_cutoff_margin=float(g["cutoff"]),
+                            tensor_args=TA)
+    mine, ref = task.build_cost_spec(), panda_cost_spec(g, robot_g)
+    mine.validate()
+    np.testing.assert_array_equal(mine.obj_link_idx, ref.obj_link_idx)
+    np.testing.assert_array_equal(mine.obj_link_margin, ref.obj_link_margin)
+    np.testing.assert_array_equal(mine.self_link_idx, ref.self_link_idx)
+    np.testing.assert_array_equal(mine.self_pairs, ref.self_pairs)
+    np.testing.assert_array_equal(mine.self_margin, ref.self_margin)
+    np.testing.assert_array_equal(mine.ws_min, ref.ws_min)
+    np.testing.assert_array_equal(mine.ws_max, ref.ws_max)
+    assert len(mine.objects) == len(ref.objects)
+    assert task.get_collision_fields() == [task.df_collision_self, task.df_collision_objects, task.df_collision_ws_boundaries]
+
+
+def test_cpu_tensors_are_rejected_not_computed():
+    robot = tra.RobotPanda(tensor_args=TA)
+    if torch.cuda.is_available():
+        pytest.skip("no-GPU behaviour")
+    with pytest.raises(Exception):
+        robot.fk_map_collision(torch.zeros(3, 7))
+
+
+def test_finite_differences_match_reference():
+    """A17: the only 'smoothness' arithmetic the reference has (trajectory/utils.py:53-64)."""
+    from torch_robotics_amd.robots import finite_difference_vector
+    g = gold("traj")
+    x = torch.as_tensor(g["x"])
+    for m in ("forward", "backward", "central"):
+        np.testing.assert_allclose(finite_difference_vector(x, dt=0.25, method=m).numpy(), g["fd_" + m], rtol=0, atol=0)

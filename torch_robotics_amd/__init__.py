@@ -6,5 +6,16 @@ library `csrc/libtrk.so` through the C ABI in `include/trk.h`; there is no CPU
 compute path in this package.
 """
 from .kinmodel import KinModel  # noqa: F401
+from .costmodel import CostModelSpec  # noqa: F401
+from .kinematics import (DifferentiableTree, DifferentiableFrankaPanda, DifferentiableUR10,  # noqa: F401
+                         DifferentiableKUKAiiwa, DifferentiableAllegroHand, DifferentiableShadowHand,
+                         DifferentiableHabitatStretch, DifferentiableTiagoDualHoloMove,
+                         DifferentiableUR10Allegro, DifferentiableDualPanda, Frame)
+from .environments import (MultiSphereField, MultiBoxField, MultiSharpBoxField, ObjectField, GridMapSDF,  # noqa: F401
+                           EnvBase, EnvSpheres3D, EnvSpheres3DExtraObjects, EnvTableShelf, EnvMazeBoxes3D)
+from .fields import (DistanceField, CollisionSelfField, CollisionObjectDistanceField,  # noqa: F401
+                     CollisionWorkspaceBoundariesDistanceField, EESE3DistanceField)
+from .robots import RobotBase, RobotPanda  # noqa: F401
+from .tasks import PlanningTask  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,213 @@
+"""Drop-in for `torch_robotics.torch_planning_objectives.fields.distance_fields` (distance_fields.py:12-359).
+
+Same classes, constructor keywords and call signatures: `compute_cost(q, link_pos, field_type=..., margin=...)`,
+`compute_costs_impl`, `EESE3DistanceField.compute_distance / update_target`.  Evaluation happens in the
+`trk_cost_fields` / `trk_collision_fields` / `trk_ee_cost` kernels; autograd sees one node with an explicit
+backward (ops.py).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from ._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+from .costmodel import CostModelSpec
+from .environments import _np, objects_to_spec_parts
+
+
+class DistanceField:
+    def __init__(self, tensor_args=None):
+        self.tensor_args = tensor_args
+
+    def compute_cost(self, q, link_pos, *args, **kwargs):
+        """Rank normaliser of distance_fields.py:26-55: (b,d) | (b,t,d) | (b,h,t,3) | (b,h,t,4,4) -> cost (b,h)."""
+        shape = link_pos.shape
+        if len(shape) == 2:
+            b, h = shape[0], 1
+            link_pos = link_pos.unsqueeze(1)
+        elif len(shape) == 3:
+            b, h = shape[0], 1
+        elif len(shape) == 4:
+            b, h = shape[0], shape[1]
+            link_pos = link_pos.reshape((b * h,) + tuple(shape[2:]))
+        elif len(shape) == 5:       # the reference raises an EinopsError here (duplicate axis name); the intent is clear
+            b, h = shape[0], shape[1]
+            link_pos = link_pos.reshape((b * h,) + tuple(shape[2:]))
+        else:
+            raise NotImplementedError
+        cost = self.compute_costs_impl(q, link_pos, *args, **kwargs)
+        if cost.ndim == 1:
+            cost = cost.reshape(b, h)
+        return cost
+
+    def compute_costs_impl(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def zero_grad(self):
+        pass
+
+
+class EmbodimentDistanceFieldBase(DistanceField):
+    _field = 0
+
+    def __init__(self, robot, link_idxs_for_collision_checking=None, num_interpolated_points=30,
+                 collision_margins=0.0, cutoff_margin=0.001, field_type="sdf", clamp_sdf=False,
+                 interpolate_link_pos=False, **kwargs):
+        super().__init__(**kwargs)
+        assert robot is not None, "You need to pass a robot instance to the embodiment distance fields"
+        if clamp_sdf or interpolate_link_pos:
+            raise NotImplementedError("clamp_sdf / interpolate_link_pos are never enabled by the reference's callers")
+        if getattr(robot, "grasped_object", None) is not None:
+            raise NotImplementedError("grasped objects are not part of this build yet (SURVEY.md 8f rank 4)")
+        self.robot = robot
+        self.link_idxs_for_collision_checking = link_idxs_for_collision_checking
+        self.num_interpolated_points = num_interpolated_points
+        self.collision_margins = collision_margins
+        self.cutoff_margin = cutoff_margin
+        self.field_type = field_type
+        self._handles = {}
+
+    # subclasses fill the parts of the spec they own
+    def _fill_spec(self, spec: CostModelSpec) -> None:
+        raise NotImplementedError
+
+    def _scene_version(self):
+        return 0
+
+    def _handle(self, n_links_in: int, device) -> ops.CostHandle:
+        key = (n_links_in, str(device), self._scene_version())
+        if key not in self._handles:
+            spec = CostModelSpec(n_links_in=n_links_in)
+            self._fill_spec(spec)
+            self._handles = {key: ops.CostHandle(spec, device)}
+        return self._handles[key]
+
+    def _margin_vector(self) -> np.ndarray:
+        """collision_margins + cutoff_margin in fp32 (distance_fields.py:112)."""
+        cm = torch.as_tensor(_np(self.collision_margins), dtype=torch.float32)
+        co = self.cutoff_margin
+        co = torch.as_tensor(_np(co), dtype=torch.float32) if not isinstance(co, (int, float)) else co
+        out = cm + co
+        n = len(self.link_idxs_for_collision_checking)
+        return np.broadcast_to(out.numpy().astype(np.float32).reshape(-1), (n,)).copy() if out.ndim <= 1 and out.numel() in (1, n) \
+            else out.numpy().astype(np.float32)
+
+    def compute_costs_impl(self, q, link_pos, **kwargs):        # distance_fields.py:134-155
+        return self.compute_embodiment_cost(q, link_pos, **kwargs)
+
+    def compute_embodiment_cost(self, q, link_pos, field_type=None, **kwargs):   # distance_fields.py:107-130
+        if field_type is None:
+            field_type = self.field_type
+        lead = link_pos.shape[:-2]
+        cm = self._handle(link_pos.shape[-2], link_pos.device)
+        if field_type == "sdf":
+            return ops.cost_fields_ad(cm, self._field, link_pos).reshape(lead)
+        if field_type == "occupancy":
+            return self.compute_embodiment_collision(q, link_pos, **kwargs)
+        raise NotImplementedError("field_type {} not implemented".format(field_type))
+
+    def compute_embodiment_collision(self, q, link_pos, **kwargs):
+        lead = link_pos.shape[:-2]
+        cm = self._handle(link_pos.shape[-2], link_pos.device)
+        margin = kwargs.get("margin", None)
+        return ops.collision_fields(cm, self._field, link_pos, margin=margin).reshape(lead)
+
+    def compute_embodiment_signed_distances(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def compute_distance(self, q, link_pos, **kwargs):
+        raise NotImplementedError
+
+
+class CollisionSelfField(EmbodimentDistanceFieldBase):        # distance_fields.py:180-215
+    _field = FIELD_SELF
+
+    def __init__(self, *args, idxs_links_distance_matrix=None, **kwargs):
+        super().__init__(*args, collision_margins=0.0, **kwargs)
+        self.idxs_links_distance_matrix = idxs_links_distance_matrix
+        self.idxs_links_distance_matrix_tuple = tuple(zip(*idxs_links_distance_matrix))
+
+    def _fill_spec(self, spec):
+        spec.self_link_idx = np.asarray(self.link_idxs_for_collision_checking, np.int32)
+        spec.self_pairs = np.asarray(self.idxs_links_distance_matrix, np.int32).reshape(-1, 2)
+        cm = _np(self.cutoff_margin).astype(np.float32).reshape(-1)
+        spec.self_margin = np.broadcast_to(cm, (len(spec.self_pairs),)).copy()
+
+
+class CollisionObjectBase(EmbodimentDistanceFieldBase):       # distance_fields.py:269-295
+    def __init__(self, *args, link_margins_for_object_collision_checking_tensor=None, **kwargs):
+        super().__init__(*args, collision_margins=link_margins_for_object_collision_checking_tensor, **kwargs)
+
+
+class CollisionObjectDistanceField(CollisionObjectBase):      # distance_fields.py:298-316
+    _field = FIELD_OBJECTS
+
+    def __init__(self, *args, df_obj_list_fn=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.df_obj_list_fn = df_obj_list_fn
+
+    def _scene_version(self):
+        objs = self.df_obj_list_fn() if self.df_obj_list_fn is not None else []
+        return tuple((id(o), getattr(o, "pos", np.zeros(0)).tobytes() if hasattr(o, "pos") else b"",
+                      getattr(o, "ori", np.zeros(0)).tobytes() if hasattr(o, "ori") else b"") for o in objs)
+
+    def _fill_spec(self, spec):
+        spec.obj_link_idx = np.asarray(self.link_idxs_for_collision_checking, np.int32)
+        spec.obj_link_margin = self._margin_vector()
+        objs = self.df_obj_list_fn() if self.df_obj_list_fn is not None else []
+        spec.objects, spec.grid = objects_to_spec_parts(objs)
+
+
+class CollisionWorkspaceBoundariesDistanceField(CollisionObjectBase):    # distance_fields.py:319-332
+    _field = FIELD_WS
+
+    def __init__(self, *args, ws_bounds_min=None, ws_bounds_max=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.ws_min, self.ws_max = ws_bounds_min, ws_bounds_max
+
+    def _fill_spec(self, spec):
+        spec.obj_link_idx = np.asarray(self.link_idxs_for_collision_checking, np.int32)
+        spec.obj_link_margin = self._margin_vector()
+        spec.ws_min = _np(self.ws_min).astype(np.float32).reshape(3)
+        spec.ws_max = _np(self.ws_max).astype(np.float32).reshape(3)
+
+
+class EESE3DistanceField(DistanceField):                      # distance_fields.py:335-359
+    def __init__(self, target_H, w_pos=1.0, w_rot=1.0, square=True, **kwargs):
+        super().__init__(**kwargs)
+        self.target_H = target_H
+        self.square, self.w_pos, self.w_rot = square, w_pos, w_rot
+        self._cm: Optional[ops.CostHandle] = None
+
+    def update_target(self, target_H):
+        self.target_H = target_H
+
+    def _handle(self, device, square) -> ops.CostHandle:
+        key = (str(device), bool(square), float(self.w_pos), float(self.w_rot))
+        if self._cm is None or self._cm[0] != key:
+            spec = CostModelSpec(n_links_in=1, ee_link=0, ee_w_pos=self.w_pos, ee_w_rot=self.w_rot, ee_square=square)
+            self._cm = (key, ops.CostHandle(spec, device))
+        return self._cm[1]
+
+    def _eval(self, link_tensor, square):
+        H = link_tensor[..., -1, :, :]                          # the LAST link is the end effector (:350)
+        lead = H.shape[:-2]
+        target = torch.as_tensor(self.target_H, dtype=torch.float32, device=H.device)
+        if target.dim() == 2:
+            tgt = target.contiguous()
+        else:
+            tgt = target.reshape(-1, 4, 4).contiguous()
+        cost = ops.ee_cost_ad(self._handle(H.device, square), H, tgt)
+        return cost.reshape(lead)
+
+    def compute_distance(self, link_tensor):
+        return self._eval(link_tensor, square=False)
+
+    def compute_costs_impl(self, q, link_tensor, **kwargs):
+        return self._eval(link_tensor, square=self.square).squeeze()
+
+    def zero_grad(self):
+        raise NotImplementedError

@@ -1,0 +1,230 @@
+"""Drop-in for the reference's kinematics classes, computed by the HIP kernels.
+
+Mirrors `torch_robotics.torch_kinematics_tree.models.robot_tree.DifferentiableTree`
+(robot_tree.py:75-492) and the robot subclasses of `models/robots.py:16-133`: same
+constructor, method names, argument meaning, tensor layouts and exception types.  The
+recursion over `torch.bmm` is replaced by one kernel launch per call (ops.py -> libtrk.so);
+autograd sees a single node with an explicit backward kernel.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .kinmodel import KinModel
+
+DATA_DIR = Path(__file__).resolve().parent / "data"
+URDF_DIR = DATA_DIR / "urdf"
+
+
+class Frame:
+    """Batch of rigid transforms (reference: geometrics/frame.py:12-129; the accessors FK callers use)."""
+
+    def __init__(self, rot: torch.Tensor, trans: torch.Tensor):
+        self._rot, self._trans = rot, trans
+        self.batch_size = trans.shape[0]
+
+    @property
+    def rotation(self) -> torch.Tensor:
+        return self._rot
+
+    @property
+    def translation(self) -> torch.Tensor:
+        return self._trans
+
+    def get_transform_matrix(self) -> torch.Tensor:          # frame.py:81-85
+        H = torch.zeros((self.batch_size, 4, 4), device=self._rot.device, dtype=self._rot.dtype)
+        H[:, :3, :3] = self._rot
+        H[:, :3, 3] = self._trans
+        H[:, 3, 3] = 1.0
+        return H
+
+    def get_quaternion(self) -> torch.Tensor:
+        """wxyz via rotation_matrix_to_q (the reference's per-sample Python loop frame.py:87-114 returns xyzw)."""
+        return ops.rotmat_to_quat(self._rot)
+
+
+class DifferentiableTree(torch.nn.Module):
+
+    def __init__(self, model_path: str, name="", link_list=None, device="cuda"):
+        super().__init__()
+        self.name = name
+        self.link_list = link_list
+        self._device = torch.device(device)
+        self.model_type = str(model_path).split(".")[-1]
+        if self.model_type != "urdf":
+            # the reference's MJCF ('xml') reader is self-described as not working (models/utils.py:43)
+            raise NotImplementedError(f"{self.model_type} is not supported!")
+        self.model_path = str(model_path)
+        self._kin = KinModel.from_urdf(self.model_path)
+        self._n_dofs = self._kin.n_dofs
+        self._controlled_joints = [int(i) for i in self._kin.controlled]
+        self._name_to_idx_map: Dict[str, int] = dict(self._kin.name_to_idx)
+        self._handle_cache: Optional[ops.ModelHandle] = None
+
+    # -- device handle (created on first use so that construction works without a GPU) ----------
+    @property
+    def _handle(self) -> ops.ModelHandle:
+        if self._handle_cache is None:
+            with torch.cuda.device(self._device if self._device.type == "cuda" else None):
+                self._handle_cache = ops.ModelHandle(self._kin)
+        return self._handle_cache
+
+    def reset(self):
+        """The engine is stateless (no per-body pose cache to contaminate, cf. robot_tree.py:128-131)."""
+        return None
+
+    def update_base_pose(self, pose_vec):                     # robot_tree.py:133-134
+        pose = torch.as_tensor(pose_vec, dtype=torch.float32).detach().cpu().reshape(-1)[:7].numpy()
+        self._kin.set_base_pose(pose)
+        if self._handle_cache is not None:
+            self._handle_cache.set_base_pose(self._kin.base_R, self._kin.base_t)
+
+    def _check_supported(self):
+        bad = self._kin.has_unsupported_joint()
+        if bad is not None:
+            raise NotImplementedError(f"joint type of link {bad!r} is not supported")   # rigid_body.py:184,251
+
+    def _sel_from_names(self, link_list) -> Optional[List[int]]:
+        if link_list is None:
+            return None
+        try:
+            return [self._name_to_idx_map[n] for n in link_list]
+        except KeyError as e:
+            raise KeyError(f"unknown link {e.args[0]!r}") from None
+
+    def _fk_matrices(self, q: torch.Tensor, sel: Optional[List[int]]) -> torch.Tensor:
+        if sel is not None and len(set(sel)) != len(sel):      # duplicates: compute unique, then gather
+            uniq = sorted(set(sel))
+            H = ops.fk(self._handle, q, uniq)
+            return H[:, [uniq.index(s) for s in sel]]
+        return ops.fk(self._handle, q, sel)
+
+    # -- stateless FK (robot_tree.py:267-301) ---------------------------------------------------
+    def compute_forward_kinematics_all_links(self, q: torch.Tensor, return_dict=False, link_list=None):
+        self._check_supported()
+        if q.ndim == 1:
+            q = q.unsqueeze(0)
+        assert q.ndim == 2 and q.shape[1] == self._n_dofs
+        if link_list is None:
+            link_list = self.link_list
+        if not return_dict:
+            if link_list is None:
+                link_list = self.get_link_names()
+                sel = None if len(link_list) == self._kin.n_links else self._sel_from_names(link_list)
+            else:
+                sel = self._sel_from_names(link_list)
+            return self._fk_matrices(q, sel)
+        names = self.get_link_names() if link_list is None else [n for n in self._kin.link_names if n in set(link_list)]
+        H = self._fk_matrices(q, self._sel_from_names(names))
+        return {n: Frame(H[:, k, :3, :3], H[:, k, :3, 3]) for k, n in enumerate(names)}
+
+    # -- stateful path (robot_tree.py:192-248) --------------------------------------------------
+    def compute_forward_kinematics(self, q: torch.Tensor, qd: torch.Tensor, link_name: str, state_less: bool = False):
+        assert q.ndim == 2
+        if state_less:
+            return self.compute_forward_kinematics_all_links(q, link_list=[link_name])
+        pos, quat, _, _ = self._stateful(q, qd, link_name)
+        return pos, quat
+
+    def _stateful(self, q, qd, link_name):
+        self._check_supported()
+        assert q.ndim == 2 and q.shape[1] == self._n_dofs
+        if qd is not None:
+            assert qd.ndim == 2 and qd.shape[1] == self._n_dofs
+        return ops.fk_jacobian(self._handle, q, qd, self._name_to_idx_map[link_name])
+
+    def compute_forward_kinematics_and_geometric_jacobian(self, q: torch.Tensor, qd: torch.Tensor, link_name: str):
+        return self._stateful(q, qd, link_name)
+
+    def compute_analytical_jacobian_all_links(self, q: torch.Tensor):
+        """(N, L, 7, D) Jacobian of [pos, quat_wxyz] of every link (robot_tree.py:250-265)."""
+        raise NotImplementedError(
+            "compute_analytical_jacobian_all_links has no HIP kernel yet (SURVEY.md 8a row A16); "
+            "use compute_forward_kinematics_and_geometric_jacobian or autograd through "
+            "compute_forward_kinematics_all_links")
+
+    # -- model queries ----------------------------------------------------------------------------
+    def get_joint_limits(self) -> List[Optional[Dict[str, float]]]:
+        k, out = self._kin, []
+        for i in self._controlled_joints:
+            if not k.has_limits[i]:
+                out.append(None)
+                continue
+            vel = k.velocity64[i]
+            out.append({"effort": None, "lower": float(k.lower64[i]), "upper": float(k.upper64[i]),
+                        "velocity": None if np.isnan(vel) else float(vel)})
+        return out
+
+    def get_joint_limit_array(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:   # robot_tree.py:455-471
+        k = self._kin
+        idx = np.asarray(self._controlled_joints, int)
+        if not np.all(k.has_limits[idx]):
+            raise TypeError("'NoneType' object is not subscriptable")   # what the reference raises for limit-less joints
+        return (k.lower64[idx].copy(), k.upper64[idx].copy(), -k.velocity64[idx], k.velocity64[idx].copy())
+
+    def get_link_names(self) -> List[str]:
+        return list(self._kin.link_names)
+
+    def print_link_names(self) -> None:
+        for n in self.get_link_names():
+            print(n)
+
+
+def _tree(urdf_name: str, name: str):
+    class _Robot(DifferentiableTree):
+        def __init__(self, link_list: Optional[List[str]] = None, device="cuda", **kwargs):
+            self.model_path = (URDF_DIR / urdf_name).as_posix()
+            super().__init__(self.model_path, name, link_list=link_list, device=device)
+    return _Robot
+
+
+class DifferentiableFrankaPanda(DifferentiableTree):          # robots.py:56-69
+    def __init__(self, link_list=None, gripper=False, device="cuda", grasped_object=None):
+        if grasped_object is not None:
+            raise NotImplementedError("grasped objects are not part of this build yet (SURVEY.md 8f rank 4)")
+        fname = "panda_arm_hand.urdf" if gripper else "panda_arm_no_gripper.urdf"
+        super().__init__((URDF_DIR / fname).as_posix(), "differentiable_franka_panda", link_list=link_list, device=device)
+
+
+DifferentiableKUKAiiwa = _tree("iiwa7.urdf", "differentiable_kuka_iiwa")
+DifferentiableUR10 = _tree("ur10.urdf", "differentiable_ur10")
+DifferentiableHabitatStretch = _tree("hab_stretch.urdf", "differentiable_stretch")
+DifferentiableShadowHand = _tree("shadow_hand.urdf", "differentiable_shadow_hand")
+DifferentiableAllegroHand = _tree("allegro_hand.urdf", "differentiable_allegro_hand")
+DifferentiableUR10Allegro = _tree("ur10_allegro.urdf", "differentiable_ur10_allegro")
+DifferentiableDualPanda = _tree("dual_panda.urdf", "differentiable_dual_panda")
+
+
+class DifferentiableTiagoDualHoloMove(DifferentiableTree):     # robots.py:104-112
+    def __init__(self, link_list=None, device="cuda"):
+        super().__init__((URDF_DIR / "tiago_dual_holobase_minimal_holonomic.urdf").as_posix(),
+                         "differentiable_tiago_dual_holo_move", link_list=link_list, device=device)
+
+    def get_link_names(self):   # the reference pops the three virtual base links (robots.py:111-112)
+        return super().get_link_names()[3:]
+
+
+# tensor helpers with the reference's names (geometrics/utils.py:321-344)
+def link_pos_from_link_tensor(link_tensor):
+    if link_tensor.shape[-1] == 4:
+        return link_tensor[..., :3, 3]
+    if link_tensor.shape[-1] == 3:
+        return link_tensor[..., :2, 2]
+    raise ValueError
+
+
+def link_rot_from_link_tensor(link_tensor):
+    if link_tensor.shape[-1] == 4:
+        return link_tensor[..., :3, :3]
+    if link_tensor.shape[-1] == 3:
+        return link_tensor[..., :2, :2]
+    raise ValueError
+
+
+def link_quat_from_link_tensor(link_tensor):
+    return ops.rotmat_to_quat(link_rot_from_link_tensor(link_tensor).contiguous())

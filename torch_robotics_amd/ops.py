@@ -388,3 +388,32 @@ def ee_cost_ad(cm: CostHandle, H: torch.Tensor, target=None) -> torch.Tensor:
 def rollout_ad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor):
     """Differentiable fused op: returns (cost, link_pos)."""
     return _Rollout.apply(_dev_f32(q, "rollout(q)"), model, cm, tuple(float(w) for w in weights))
+
+
+class RolloutPlan:
+    """Pre-bound fused-rollout launch: every argument is resolved once, so a step costs one ctypes call
+    (a planner's inner loop re-evaluates the same buffers thousands of times)."""
+
+    def __init__(self, model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True):
+        q = _dev_f32(q, "RolloutPlan(q)")
+        if q.dim() != 3:
+            raise ValueError("RolloutPlan: q must be (batch, horizon, dof)")
+        self.model, self.cm, self.q = model, cm, q
+        self.B, self.H = int(q.shape[0]), int(q.shape[1])
+        n, L, D = self.B * self.H, model.n_links, model.n_dofs
+        kw = dict(device=q.device, dtype=torch.float32)
+        self.link_pos = torch.empty((self.B, self.H, L, 3), **kw) if want_pos else None
+        self.cost = torch.empty((self.B, self.H), **kw)
+        self.gq = torch.empty((self.B, self.H, D), **kw)
+        self._w = _abi.RolloutWeights(*[float(v) for v in weights])
+        self._fn = lib().trk_rollout_cost_grad
+        self._args = (model._h, cm._h, C.byref(self._w), q.data_ptr(), self.B, self.H, _ptr(self.link_pos),
+                      self.cost.data_ptr(), self.gq.data_ptr())
+        self.device = q.device
+
+    def launch(self, cost_sum_ptr: Optional[int] = None, stream: Optional[int] = None) -> None:
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._fn(*self._args, cost_sum_ptr, stream)
+        if rc:
+            check(rc, "trk_rollout_cost_grad")

@@ -1,0 +1,124 @@
+"""Drop-in for `torch_robotics.tasks.tasks.PlanningTask` on the hot path (tasks.py:22-232) plus the fused
+entry point `rollout_cost_grad`, which runs FK + every configured objective + d cost / d q in ONE kernel."""
+from __future__ import annotations
+
+from functools import partial
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from ._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+from .costmodel import CostModelSpec
+from .environments import _np, objects_to_spec_parts
+from .fields import CollisionObjectDistanceField, CollisionWorkspaceBoundariesDistanceField
+
+
+class Task:
+    def __init__(self, env=None, robot=None, tensor_args=None, **kwargs):
+        self.env, self.robot, self.tensor_args = env, robot, tensor_args
+
+
+class PlanningTask(Task):
+    def __init__(self, ws_limits=None, use_occupancy_map=False, cell_size=0.01, obstacle_cutoff_margin=0.01, **kwargs):
+        super().__init__(**kwargs)
+        self.ws_limits = self.env.limits if ws_limits is None else ws_limits
+        self.ws_min, self.ws_max = self.ws_limits[0], self.ws_limits[1]
+        if use_occupancy_map:
+            raise NotImplementedError        # tasks.py:160: the occupancy-map branch raises in the reference too
+        self.use_occupancy_map = False
+        self.obstacle_cutoff_margin = obstacle_cutoff_margin
+        r = self.robot
+        self.df_collision_self = r.df_collision_self
+        common = dict(link_idxs_for_collision_checking=r.link_idxs_for_object_collision_checking,
+                      num_interpolated_points=r.num_interpolated_points_for_object_collision_checking,
+                      link_margins_for_object_collision_checking_tensor=r.link_margins_for_object_collision_checking_tensor,
+                      cutoff_margin=obstacle_cutoff_margin, tensor_args=self.tensor_args)
+        self.df_collision_objects = CollisionObjectDistanceField(r, df_obj_list_fn=self.env.get_df_obj_list, **common)
+        if self.env.obj_extra_list is not None:
+            self.df_collision_extra_objects = CollisionObjectDistanceField(
+                r, df_obj_list_fn=partial(self.env.get_df_obj_list, return_extra_objects_only=True), **common)
+            self._collision_fields_extra_objects = [self.df_collision_extra_objects]
+        else:
+            self._collision_fields_extra_objects = []
+        self.df_collision_ws_boundaries = CollisionWorkspaceBoundariesDistanceField(
+            r, ws_bounds_min=self.ws_min, ws_bounds_max=self.ws_max, **common)
+        self._collision_fields = [self.df_collision_self, self.df_collision_objects, self.df_collision_ws_boundaries]
+        self._fused = None
+        self._ee = dict(target=None, w_pos=1.0, w_rot=1.0, square=True, link=None)
+
+    def get_collision_fields(self):
+        return self._collision_fields
+
+    def get_collision_fields_extra_objects(self):
+        return self._collision_fields_extra_objects
+
+    def distance_q(self, q1, q2):
+        return self.robot.distance_q(q1, q2)
+
+    # ---------------------------------------------------------------------------------------------
+    # one cost model for the fused kernel and for compute_collision(_cost)
+    # ---------------------------------------------------------------------------------------------
+    def set_ee_target(self, target_H, w_pos=1.0, w_rot=1.0, square=True, link_name=None):
+        """End-effector SE(3) tracking term of the fused rollout (EESE3DistanceField semantics)."""
+        tree = self.robot.diff_panda
+        link = tree._name_to_idx_map[link_name or self.robot.link_name_ee]
+        new = dict(target=_np(target_H).astype(np.float32).reshape(4, 4), w_pos=w_pos, w_rot=w_rot, square=square, link=link)
+        same_cfg = all(self._ee[k] == new[k] for k in ("w_pos", "w_rot", "square", "link"))
+        self._ee = new
+        if self._fused is not None and same_cfg:
+            self._fused[1].set_ee_target(new["target"])
+        else:
+            self._fused = None
+
+    def build_cost_spec(self) -> CostModelSpec:
+        r, tree = self.robot, self.robot.diff_panda
+        spec = CostModelSpec(n_links_in=tree._kin.n_links)
+        spec.obj_link_idx = np.asarray(r.link_idxs_for_object_collision_checking, np.int32)
+        spec.obj_link_margin = self.df_collision_objects._margin_vector()
+        spec.objects, spec.grid = objects_to_spec_parts(self.env.get_df_obj_list())
+        spec.ws_min, spec.ws_max = _np(self.ws_min).astype(np.float32), _np(self.ws_max).astype(np.float32)
+        if self.df_collision_self is not None:
+            self.df_collision_self._fill_spec(spec)
+        if self._ee["target"] is not None:
+            spec.ee_link, spec.ee_target = self._ee["link"], self._ee["target"]
+            spec.ee_w_pos, spec.ee_w_rot, spec.ee_square = self._ee["w_pos"], self._ee["w_rot"], self._ee["square"]
+        return spec
+
+    def _fused_handles(self, device):
+        if self._fused is None or self._fused[2] != str(device):
+            self._fused = (self.robot.diff_panda._handle, ops.CostHandle(self.build_cost_spec(), device), str(device))
+        return self._fused[0], self._fused[1]
+
+    def rollout_cost_grad(self, x, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=True, cost_sum=None, out=None):
+        """Fused FK + objectives + gradient.  x (B,H,>=D) or (N,>=D) -> (link_pos, cost, d cost/d q)."""
+        q = self.robot.get_position(x)
+        model, cm = self._fused_handles(q.device)
+        return ops.rollout_cost_grad(model, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos, cost_sum=cost_sum, out=out)
+
+    # ---------------------------------------------------------------------------------------------
+    def compute_collision(self, x, **kwargs):                  # tasks.py:131-133
+        return self._compute_collision_or_cost(self.robot.get_position(x), field_type="occupancy", **kwargs)
+
+    def compute_collision_cost(self, x, **kwargs):             # tasks.py:135-137
+        return self._compute_collision_or_cost(self.robot.get_position(x), field_type="sdf", **kwargs)
+
+    def _compute_collision_or_cost(self, q, field_type="occupancy", **kwargs):   # tasks.py:139-232
+        if q.ndim == 1:
+            q = q.unsqueeze(0).unsqueeze(0)
+        elif q.ndim == 2:
+            q = q.unsqueeze(1)
+        elif q.ndim > 3:
+            raise NotImplementedError
+        model, cm = self._fused_handles(q.device)
+        fields = FIELD_OBJECTS | FIELD_WS | (FIELD_SELF if self.df_collision_self is not None else 0)
+        if field_type == "occupancy":
+            pos = ops.fk_positions(model, q.detach())
+            return ops.collision_fields(cm, fields, pos, margin=kwargs.get("margin", None)).reshape(q.shape[:-1])
+        w = (1.0 if self.df_collision_self is not None else 0.0, 1.0, 1.0, 0.0)
+        if torch.is_grad_enabled() and q.requires_grad:
+            cost, _ = ops.rollout_ad(model, cm, w, q)           # one fused kernel; backward reuses its gradient
+            return cost
+        _, cost, _ = ops.rollout_cost_grad(model, cm, w, q, want_pos=False)
+        return cost
