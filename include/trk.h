@@ -108,8 +108,11 @@ void trk_model_destroy(TrkModel* model);
 int trk_model_set_base_pose(TrkModel* model, const float* R9, const float* t3);
 int trk_model_n_links(const TrkModel* model);
 int trk_model_n_dofs(const TrkModel* model);
-/* 1 if a model-specialised (ahead-of-time unrolled) kernel set is used for this model. */
+/* 1 if a model-specialised (ahead-of-time unrolled) fused kernel exists for this model and is enabled. */
 int trk_model_is_specialized(const TrkModel* model);
+/* Switch between the model-specialised fused kernel (default when one was built for these tables) and the
+ * table-driven one; both compute the same function (used by the parity tests to cover both). */
+int trk_model_enable_specialized(TrkModel* model, int enable);
 
 /* ---------------------------------------------------------------------------------
  * Forward kinematics (stateless path).

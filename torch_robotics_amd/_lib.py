@@ -20,7 +20,7 @@ _lib = None
 
 EXPORTS = [
     "trk_abi_version", "trk_last_error", "trk_model_create", "trk_model_destroy", "trk_model_set_base_pose",
-    "trk_model_n_links", "trk_model_n_dofs", "trk_model_is_specialized",
+    "trk_model_n_links", "trk_model_n_dofs", "trk_model_is_specialized", "trk_model_enable_specialized",
     "trk_fk_forward", "trk_fk_positions", "trk_fk_backward", "trk_fk_positions_backward", "trk_fk_jacobian",
     "trk_rotmat_to_quat", "trk_cost_model_create", "trk_cost_model_destroy", "trk_cost_model_set_ee_target",
     "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_grid_precompute",
@@ -35,6 +35,8 @@ class TrkError(RuntimeError):
 def build(verbose: bool = False) -> Path:
     """Compile libtrk.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     jobs = str(min(8, os.cpu_count() or 1))
+    from . import codegen
+    codegen.generate_all(_CSRC / "generated")          # model-specialised kernels (source is a build product)
     res = subprocess.run(["make", "-C", str(_CSRC), "-j", jobs], capture_output=True, text=True)
     if res.returncode != 0:
         raise TrkError(f"building libtrk.so failed:\n{res.stdout}\n{res.stderr}")
@@ -61,6 +63,7 @@ def lib():
     L.trk_model_n_links.argtypes = [vp]
     L.trk_model_n_dofs.argtypes = [vp]
     L.trk_model_is_specialized.argtypes = [vp]
+    L.trk_model_enable_specialized.argtypes = [vp, C.c_int]
     L.trk_fk_forward.argtypes = [vp, vp, i64, vp, i32, vp, vp]
     L.trk_fk_positions.argtypes = [vp, vp, i64, vp, i32, vp, vp]
     L.trk_fk_backward.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp]

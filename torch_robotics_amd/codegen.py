@@ -1,0 +1,399 @@
+"""Model compiler, second stage: KinModel + collision-link template -> straight-line HIP kernel source.
+
+The table-driven kernels (csrc/trk_kernels.hip) work for any URDF.  For the robots a deployment actually
+plans with, this generator unrolls the kinematic tree into one fused FK + objectives + gradient kernel:
+
+* every joint transform is emitted with the URDF constants as literals; entries that are exactly 0 / +-1
+  (after snapping |x| < `snap` to 0 and |x -+ 1| < `snap` to +-1; cos(pi/2) in fp32 is -4.4e-8) are folded away
+  symbolically, so a Panda joint costs 12 FMAs for the rotation instead of 27 + 12;
+* all link poses are named registers -- the compiler's allocator handles branch parents of tree robots;
+* the reverse pass is the transpose of the geometric Jacobian (per-link wrench accumulators pushed towards
+  the root), emitted only for links that can receive an adjoint.
+
+Scene, margins, weights, EE target and base pose stay run-time arguments (scalar loads).  The generated
+translation unit registers itself with libtrk.so; `trk_rollout_cost_grad` picks it when the model hash and
+the cost model's link sets match, and falls back to the table-driven kernel otherwise.
+Math restated from the reference: rigid_body.py:146-211 (joint transforms), SURVEY.md Appendix B (reverse).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .kinmodel import JOINT_CONTINUOUS, JOINT_FIXED, JOINT_PRISMATIC, JOINT_REVOLUTE, KinModel
+
+SNAP = 1e-7
+
+
+def model_hash(kin: KinModel) -> int:
+    """FNV-1a (64 bit) over the kinematic tables; the same bytes are hashed by trk_capi.hip."""
+    h = 0xcbf29ce484222325
+    parts = [np.asarray([kin.n_links, kin.n_dofs], np.int32)]
+    for name, dt in (("parent", np.int32), ("joint_type", np.int32), ("dof_idx", np.int32), ("R_fixed", np.float32),
+                     ("trans", np.float32), ("axis", np.float32), ("rot_axis", np.int32), ("rot_sign", np.float32),
+                     ("clamp", np.int32), ("lower", np.float32), ("upper", np.float32), ("order", np.int32)):
+        parts.append(np.ascontiguousarray(getattr(kin, name), dt).reshape(-1))
+    for arr in parts:
+        for b in arr.tobytes():
+            h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def flit(x: float) -> str:
+    """exact fp32 literal"""
+    v = float(np.float32(x))
+    if v == 0.0:
+        return "0.0f"
+    return f"{v.hex()}f"
+
+
+@dataclass(frozen=True)
+class S:
+    """coef * name ; a constant when name is None"""
+    c: float
+    n: Optional[str] = None
+
+    @property
+    def is_const(self):
+        return self.n is None
+
+    @property
+    def is_zero(self):
+        return self.c == 0.0
+
+    def neg(self):
+        return S(-self.c, self.n)
+
+
+ZERO, ONE = S(0.0), S(1.0)
+
+
+def snap_const(x: float, eps: float) -> float:
+    x = float(np.float32(x))
+    if abs(x) < eps:
+        return 0.0
+    if abs(x - 1.0) < eps:
+        return 1.0
+    if abs(x + 1.0) < eps:
+        return -1.0
+    return x
+
+
+class Emitter:
+    def __init__(self):
+        self.lines: List[str] = []
+        self._k = 0
+
+    def raw(self, line: str):
+        self.lines.append(line)
+
+    def tmp(self, expr: str) -> str:
+        self._k += 1
+        name = f"v{self._k}"
+        self.lines.append(f"    const float {name} = {expr};")
+        return name
+
+    def expr(self, s: S) -> str:
+        if s.n is None:
+            return flit(s.c)
+        if s.c == 1.0:
+            return s.n
+        if s.c == -1.0:
+            return f"-{s.n}"
+        return f"({flit(s.c)} * {s.n})"
+
+    def named(self, s: S) -> S:
+        """make sure the value is a plain +-name (materialise coef * name when |coef| != 1)"""
+        if s.n is None or abs(s.c) == 1.0:
+            return s
+        return S(1.0, self.tmp(self.expr(s)))
+
+    def lincomb(self, pairs: Sequence[Tuple[S, S]], add: S = ZERO) -> S:
+        """sum_i a_i * b_i + add with constant folding; emits at most one fmaf chain."""
+        const = add.c if add.n is None else 0.0
+        terms: List[Tuple[float, str, Optional[str]]] = []
+        if add.n is not None and add.c != 0.0:
+            terms.append((add.c, add.n, None))
+        for a, b in pairs:
+            if a.is_zero or b.is_zero:
+                continue
+            if a.n is None and b.n is None:
+                const += a.c * b.c
+            elif a.n is None:
+                terms.append((a.c * b.c, b.n, None))
+            elif b.n is None:
+                terms.append((a.c * b.c, a.n, None))
+            else:
+                terms.append((a.c * b.c, a.n, b.n))
+        # merge identical single-name terms
+        merged: Dict[Tuple[str, Optional[str]], float] = {}
+        order: List[Tuple[str, Optional[str]]] = []
+        for c, n1, n2 in terms:
+            key = (n1, n2)
+            if key not in merged:
+                merged[key] = 0.0
+                order.append(key)
+            merged[key] += c
+        terms = [(merged[k], k[0], k[1]) for k in order if merged[k] != 0.0]
+        if not terms:
+            return S(float(np.float32(const)))
+        if len(terms) == 1 and const == 0.0:
+            c, n1, n2 = terms[0]
+            if n2 is None:
+                return S(c, n1)                     # pure alias, no instruction
+            return S(c, self.tmp(f"{n1} * {n2}"))
+        # single-name terms first so the accumulator starts cheap
+        terms.sort(key=lambda t: t[2] is not None)
+        acc: Optional[str] = flit(const) if const != 0.0 else None
+        for c, n1, n2 in terms:
+            if n2 is None:
+                if acc is None:
+                    acc = self.expr(S(c, n1))
+                elif c == 1.0:
+                    acc = f"({acc} + {n1})"
+                elif c == -1.0:
+                    acc = f"({acc} - {n1})"
+                else:
+                    acc = f"fmaf({flit(c)}, {n1}, {acc})"
+            else:
+                lhs = n1 if c == 1.0 else (f"-{n1}" if c == -1.0 else f"({flit(c)} * {n1})")
+                acc = f"{lhs} * {n2}" if acc is None else f"fmaf({lhs}, {n2}, {acc})"
+        return S(1.0, self.tmp(acc))
+
+    def add(self, a: S, b: S) -> S:
+        return self.lincomb([(a, ONE), (b, ONE)])
+
+    def cross(self, a: Sequence[S], b: Sequence[S]) -> List[S]:
+        return [self.lincomb([(a[1], b[2]), (a[2].neg(), b[1])]),
+                self.lincomb([(a[2], b[0]), (a[0].neg(), b[2])]),
+                self.lincomb([(a[0], b[1]), (a[1].neg(), b[0])])]
+
+    def dot(self, a: Sequence[S], b: Sequence[S]) -> S:
+        return self.lincomb([(a[0], b[0]), (a[1], b[1]), (a[2], b[2])])
+
+
+@dataclass
+class CollisionTemplate:
+    """Link sets baked into a specialised kernel (the robot's collision model, robot_base.py:57-141)."""
+    obj_links: List[int]
+    self_pairs: List[Tuple[int, int]] = field(default_factory=list)   # LINK indices (a, b)
+    ee_link: int = -1
+
+
+def panda_template(kin: KinModel) -> CollisionTemplate:
+    """RobotPanda's collision model (robot_panda.py:44-136)."""
+    idx = kin.name_to_idx
+    obj = [idx[n] for n in ("panda_link2", "panda_link3", "panda_link5", "panda_link7", "panda_hand")]
+    pairs_by_name = {"panda_link4": ["panda_link1"], "panda_link5": ["panda_link0", "panda_link1", "panda_link2"],
+                     "panda_link6": ["panda_link0", "panda_link1", "panda_link2"],
+                     "panda_hand": ["panda_link0", "panda_link1", "panda_link2"]}
+    # order of robot_base.py:110-118: iterate the sorted unique self-link names, then the listed partners
+    names = sorted(set(list(pairs_by_name) + [v for vs in pairs_by_name.values() for v in vs] +
+                       ["panda_link0", "panda_link1", "panda_link2", "panda_link3"]))
+    pairs = []
+    for a in names:
+        for b in pairs_by_name.get(a, []):
+            pairs.append((idx[a], idx[b]))
+    return CollisionTemplate(obj_links=obj, self_pairs=pairs, ee_link=idx["ee_link"])
+
+
+def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, snap: float = SNAP) -> str:
+    L, D = kin.n_links, kin.n_dofs
+    NL = len(tmpl.obj_links)
+    adj_links = sorted(set(tmpl.obj_links) | {a for p in tmpl.self_pairs for a in p} |
+                       ({tmpl.ee_link} if tmpl.ee_link >= 0 else set()))
+    out: List[str] = []
+    out.append(f"// GENERATED by torch_robotics_amd/codegen.py for model '{kin.name}' ({L} links, {D} DOF) -- do not edit.")
+    out.append('#include "trk_spec_common.h"')
+    out.append(f"namespace spec_{ident} {{")
+    out.append(f"constexpr int L = {L}, D = {D}, NL = {NL};")
+
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
+        E.raw(f"__global__ void __launch_bounds__(TRK_WAVE) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds[TRK_WAVE * {max(3 * L, D)}];")
+        E.raw("    const int lane = threadIdx.x;")
+        E.raw("    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;")
+        E.raw("    const int rows = (int)min((int64_t)TRK_WAVE, A.n - base);")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(A.q, base, rows, lane, lds, q);")
+        # ---------------- forward ----------------
+        R: Dict[int, List[List[S]]] = {}
+        t: Dict[int, List[S]] = {}
+        passv: Dict[int, S] = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        for p in range(1, L):
+            i = int(kin.order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
+            E.raw(f"    // link {i} '{kin.link_names[i]}' (parent {par})")
+            Rf = [[S(snap_const(kin.R_fixed[i][r][c], snap)) for c in range(3)] for r in range(3)]
+            tl = [S(snap_const(kin.trans[i][k], 0.0)) for k in range(3)]
+            qh = None
+            if jt != JOINT_FIXED:
+                if kin.clamp[i]:
+                    lo, hi = flit(kin.lower[i]), flit(kin.upper[i])
+                    E.raw(f"    const float qh{d} = fminf(fmaxf(q[{d}], {lo}), {hi});")
+                    E.raw(f"    const float pass{d} = (q[{d}] >= {lo} && q[{d}] <= {hi}) ? 1.0f : 0.0f;")
+                    passv[i] = S(1.0, f"pass{d}")
+                else:
+                    E.raw(f"    const float qh{d} = q[{d}];")
+                    passv[i] = ONE
+                qh = S(1.0, f"qh{d}")
+            if jt == JOINT_PRISMATIC:
+                tl = [E.lincomb([(S(float(kin.axis[i][k])), qh)], tl[k]) for k in range(3)]
+            Rp, tp = R[par], t[par]
+            t[i] = [E.lincomb([(Rp[r][k], tl[k]) for k in range(3)], tp[r]) for r in range(3)]
+            A = [[E.lincomb([(Rp[r][k], Rf[k][c]) for k in range(3)]) for c in range(3)] for r in range(3)]
+            if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS):
+                sg = float(kin.rot_sign[i])
+                if sg != 0.0:
+                    E.raw(f"    float sn{d}, cs{d};")
+                    E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
+                    s, c = S(sg, f"sn{d}"), S(1.0, f"cs{d}")       # sin(sign*q) = sign*sin(q), cos even
+                    ax = int(kin.rot_axis[i])
+                    ci, cj = [(1, 2), (2, 0), (0, 1)][ax]
+                    newA = [row[:] for row in A]
+                    for r in range(3):
+                        a_i, a_j = E.named(A[r][ci]), E.named(A[r][cj])
+                        newA[r][ci] = E.lincomb([(c, a_i), (s, a_j)])
+                        newA[r][cj] = E.lincomb([(c, a_j), (s.neg(), a_i)])
+                    A = newA
+            R[i] = A
+        # ---------------- outputs that depend only on FK ----------------
+        pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
+        E.raw("    if (A.link_pos) {")
+        E.raw(f"        const float pv[{3 * L}] = {{{pos_list}}};")
+        E.raw(f"        spec_store_rows<{3 * L}>(A.link_pos, base, rows, lane, lds, pv);")
+        E.raw("    }")
+        # ---------------- objectives ----------------
+        E.raw("    float cost = 0.0f;")
+        for i in adj_links:
+            E.raw(f"    float tb{i}_0 = 0.0f, tb{i}_1 = 0.0f, tb{i}_2 = 0.0f;")
+        if NL > 0:
+            for k, nm in enumerate("xyz"):
+                E.raw(f"    const float p{nm}[NL] = {{{', '.join(E.expr(t[i][k]) for i in tmpl.obj_links)}}};")
+            E.raw("    float gx[NL], gy[NL], gz[NL];")
+            E.raw("#pragma unroll")
+            E.raw("    for (int l = 0; l < NL; ++l) { gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }")
+            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz);")
+            E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
+            for j, i in enumerate(tmpl.obj_links):
+                E.raw(f"    tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
+        if tmpl.self_pairs:
+            E.raw("    if (A.w.w_self != 0.0f) {")
+            for pi, (a, b) in enumerate(tmpl.self_pairs):
+                pa = ", ".join(E.expr(t[a][k]) for k in range(3))
+                pb = ", ".join(E.expr(t[b][k]) for k in range(3))
+                E.raw(f"        cost += spec_self_pair(A.w.w_self, A.C.self_margin[{pi}], {pa}, {pb}, "
+                      f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2);")
+            E.raw("    }")
+        ee = tmpl.ee_link
+        if ee >= 0:
+            E.raw("    float eeRb[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};")
+            E.raw("    if (A.w.w_ee != 0.0f) {")
+            E.raw(f"        const float eR[9] = {{{', '.join(E.expr(R[ee][r][c]) for r in range(3) for c in range(3))}}};")
+            E.raw(f"        const float et[3] = {{{', '.join(E.expr(t[ee][k]) for k in range(3))}}};")
+            E.raw("        float gR[9], gt[3];")
+            E.raw("        const float ce = ee_cost_eval(eR, et, A.C.ee_target, A.C.ee_w_pos, A.C.ee_w_rot, A.C.ee_square, gR, gt);")
+            E.raw("        cost = fmaf(A.w.w_ee, ce, cost);")
+            E.raw("#pragma unroll")
+            E.raw("        for (int k = 0; k < 9; ++k) eeRb[k] = A.w.w_ee * gR[k];")
+            E.raw(f"        tb{ee}_0 = fmaf(A.w.w_ee, gt[0], tb{ee}_0); tb{ee}_1 = fmaf(A.w.w_ee, gt[1], tb{ee}_1); "
+                  f"tb{ee}_2 = fmaf(A.w.w_ee, gt[2], tb{ee}_2);")
+            E.raw("    }")
+        E.raw("    if (lane < rows) A.cost[base + lane] = cost;")
+        E.raw("    if (A.cost_sum) {")
+        E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
+        E.raw("        if (lane == 0) atomicAdd(A.cost_sum, tot);")
+        E.raw("    }")
+        # ---------------- reverse: wrench accumulators towards the root ----------------
+        F: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
+        T: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
+        gq_expr: Dict[int, S] = {}
+        for p in range(L - 1, 0, -1):
+            i = int(kin.order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
+            E.raw(f"    // reverse: link {i}")
+            if i in adj_links:
+                tb = [S(1.0, f"tb{i}_{k}") for k in range(3)]
+                own_T = E.cross(t[i], tb)
+                F[i] = [E.add(F[i][k], tb[k]) for k in range(3)]
+                T[i] = [E.add(T[i][k], own_T[k]) for k in range(3)]
+                if i == ee:
+                    Rb = [[S(1.0, f"eeRb[{3 * r + c}]") for c in range(3)] for r in range(3)]
+                    Ri = R[i]
+                    M = lambda a, b: E.lincomb([(Rb[a][k], Ri[b][k]) for k in range(3)])   # (Rbar R^T)[a][b]
+                    tor = [E.lincomb([(M(2, 1), ONE), (M(1, 2), S(-1.0))]),
+                           E.lincomb([(M(0, 2), ONE), (M(2, 0), S(-1.0))]),
+                           E.lincomb([(M(1, 0), ONE), (M(0, 1), S(-1.0))])]
+                    T[i] = [E.add(T[i][k], tor[k]) for k in range(3)]
+            nonzero = any(not s.is_zero for s in F[i] + T[i])
+            if jt != JOINT_FIXED:
+                if not nonzero:
+                    gq_expr[d] = ZERO
+                elif jt == JOINT_PRISMATIC:
+                    dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
+                    g = E.dot(dirw, F[i])
+                    gq_expr[d] = E.lincomb([(passv[i], E.named(g))])
+                else:
+                    sg = float(kin.rot_sign[i])
+                    if sg == 0.0:
+                        gq_expr[d] = ZERO
+                    else:
+                        ax = int(kin.rot_axis[i])
+                        z = [R[i][r][ax] for r in range(3)]
+                        cr = E.cross(t[i], F[i])
+                        diff = [E.lincomb([(T[i][k], ONE), (cr[k], S(-1.0))]) for k in range(3)]
+                        g = E.dot(z, diff)
+                        gq_expr[d] = E.lincomb([(passv[i], E.named(S(g.c * sg, g.n)))])
+            F[par] = [E.add(F[par][k], F[i][k]) for k in range(3)]
+            T[par] = [E.add(T[par][k], T[i][k]) for k in range(3)]
+        E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
+        E.raw("    spec_store_gq<D>(A.gq, base, rows, lane, lds, gv);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
+    obj = ", ".join(str(i) for i in tmpl.obj_links) or "0"
+    pairs = ", ".join(f"{a}, {b}" for a, b in tmpl.self_pairs) or "0"
+    out.append(f"static const int32_t kObjLinks[] = {{{obj}}};")
+    out.append(f"static const int32_t kSelfPairs[] = {{{pairs}}};")
+    out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
+    out.append("    if (base_identity) hipLaunchKernelGGL(k_rollout_bi, dim3(grid), dim3(TRK_WAVE), 0, st, a);")
+    out.append("    else hipLaunchKernelGGL(k_rollout_bg, dim3(grid), dim3(TRK_WAVE), 0, st, a);")
+    out.append("}")
+    out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
+               f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch}};")
+    out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
+    out.append(f"}}  // namespace spec_{ident}")
+    return "\n".join(out) + "\n"
+
+
+# robots that get a specialised kernel at build time: name -> (urdf file, template factory)
+SPEC_ROBOTS = {
+    "panda": ("panda_arm_no_gripper.urdf", panda_template),
+}
+
+
+def generate_all(out_dir) -> List[str]:
+    from pathlib import Path
+    from .kinematics import URDF_DIR
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    written = []
+    for ident, (urdf, tmpl_fn) in SPEC_ROBOTS.items():
+        kin = KinModel.from_urdf(str(URDF_DIR / urdf))
+        src = generate_rollout_source(kin, tmpl_fn(kin), ident)
+        path = out_dir / f"spec_{ident}.hip"
+        if not path.exists() or path.read_text() != src:
+            path.write_text(src)
+        written.append(path.name)
+    return written

@@ -1,6 +1,7 @@
 // trk_capi.hip -- C ABI of libtrk.so (include/trk.h): argument checking, model / cost-model
 // handles (host tables -> device tables, copied once), kernel launches.  No torch types here.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -8,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "trk_launch.h"
+#include "trk_spec_common.h"
 
 namespace {
 thread_local std::string g_err;
@@ -32,7 +34,33 @@ int ensure_init() {
     g_init_done = true;
     return TRK_OK;
 }
+
+uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+// must hash the same bytes, in the same order, as torch_robotics_amd/codegen.py: model_hash
+uint64_t model_hash(const TrkKinModelDesc* d) {
+    const int L = d->n_links;
+    uint64_t h = 0xcbf29ce484222325ull;
+    const int32_t hd[2] = {d->n_links, d->n_dofs};
+    h = fnv1a(h, hd, sizeof(hd));
+    h = fnv1a(h, d->parent, 4 * L); h = fnv1a(h, d->joint_type, 4 * L); h = fnv1a(h, d->dof_idx, 4 * L);
+    h = fnv1a(h, d->R_fixed, 36 * L); h = fnv1a(h, d->trans, 12 * L); h = fnv1a(h, d->axis, 12 * L);
+    h = fnv1a(h, d->rot_axis, 4 * L); h = fnv1a(h, d->rot_sign, 4 * L); h = fnv1a(h, d->clamp, 4 * L);
+    h = fnv1a(h, d->lower, 4 * L); h = fnv1a(h, d->upper, 4 * L); h = fnv1a(h, d->order, 4 * L);
+    return h;
+}
+std::vector<const SpecEntry*>& spec_registry() { static std::vector<const SpecEntry*> r; return r; }
 }  // namespace
+
+void trk_spec_register(const SpecEntry* e) { spec_registry().push_back(e); }
+const SpecEntry* trk_spec_find(uint64_t h, int n_links, int n_dofs) {
+    for (const SpecEntry* e : spec_registry())
+        if (e->model_hash == h && e->n_links == n_links && e->n_dofs == n_dofs) return e;
+    return nullptr;
+}
 
 struct TrkModel {
     DevModelHdr hdr;
@@ -42,11 +70,15 @@ struct TrkModel {
     DevLink* d_links = nullptr;
     int32_t* d_fin = nullptr;
     bool unsupported = false;
+    const SpecEntry* spec = nullptr;     // model-specialised fused kernel, if one was built for these tables
+    bool spec_enabled = true;
 };
 
 struct TrkCostModel {
     DevCostHdr hdr;
     void* d_blob = nullptr;
+    std::vector<int32_t> obj_link_idx;   // host copies, to match a specialised kernel's baked link sets
+    std::vector<int32_t> self_pairs;     // mapped to link indices
 };
 
 extern "C" {
@@ -124,6 +156,7 @@ int trk_model_create(const TrkKinModelDesc* d, TrkModel** out) {
         delete m;
         return hip_fail(e, "trk_model_create: device allocation/copy");
     }
+    m->spec = trk_spec_find(model_hash(d), L, D);
     *out = m;
     return TRK_OK;
 }
@@ -144,7 +177,12 @@ int trk_model_set_base_pose(TrkModel* m, const float* R9, const float* t3) {
 
 int trk_model_n_links(const TrkModel* m) { return m ? m->hdr.n_links : TRK_ERR_INVALID_ARG; }
 int trk_model_n_dofs(const TrkModel* m) { return m ? m->hdr.n_dofs : TRK_ERR_INVALID_ARG; }
-int trk_model_is_specialized(const TrkModel* m) { (void)m; return 0; }
+int trk_model_is_specialized(const TrkModel* m) { return (m && m->spec && m->spec_enabled) ? 1 : 0; }
+int trk_model_enable_specialized(TrkModel* m, int enable) {
+    if (!m) return fail(TRK_ERR_INVALID_ARG, "trk_model_enable_specialized: null model");
+    m->spec_enabled = enable != 0;
+    return TRK_OK;
+}
 
 static int make_sel(const TrkModel* m, const int32_t* link_sel, int32_t n_sel, SelMap& sel, int& n_out, const char* who) {
     const int L = m->hdr.n_links;
@@ -280,8 +318,10 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     const size_t o_pr = o_obj + al(sizeof(DevObj) * (d->n_objects + 1));
     const size_t o_sp = o_pr + al(sizeof(DevPrim) * (d->n_prims + 1));
     const size_t o_sm = o_sp + al(sizeof(int32_t) * 2 * (d->n_self_pairs + 1));
-    const size_t total = o_sm + al(sizeof(float) * (d->n_self_pairs + 1));
+    const size_t o_sph = o_sm + al(sizeof(float) * (d->n_self_pairs + 1));
+    const size_t total = o_sph + al(sizeof(float4) * (d->n_prims + 1));
     std::vector<char> blob(total, 0);
+    std::vector<float4> spheres;
     if (d->n_obj_links) {
         std::memcpy(blob.data() + o_idx, d->obj_link_idx, sizeof(int32_t) * d->n_obj_links);
         std::memcpy(blob.data() + o_mg, d->obj_link_margin, sizeof(float) * d->n_obj_links);
@@ -293,7 +333,20 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
         std::memcpy(objs[o].R, ob.R, sizeof(float) * 9);
         objs[o].prim_begin = ob.prim_begin; objs[o].prim_end = ob.prim_end; objs[o].is_grid = ob.is_grid ? 1 : 0;
         const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        objs[o].identity = std::memcmp(ob.R, I, sizeof(I)) == 0 ? 1 : 0;
+        objs[o].identity = std::memcmp(ob.R, I, sizeof(I)) == 0 ? TRK_OBJ_IDENTITY : 0;
+        if (!ob.is_grid)
+            for (int p = ob.prim_begin; p < ob.prim_end; ++p) {
+                const TrkPrimitive& pr = d->prims[p];
+                if (pr.type != TRK_PRIM_SPHERE) { objs[o].identity |= TRK_OBJ_NONSPHERE; continue; }
+                // world-frame centre: R c + pos (double accumulate, rounded once)
+                float4 sp;
+                double cw[3];
+                for (int r = 0; r < 3; ++r)
+                    cw[r] = (double)ob.R[3 * r] * pr.center[0] + (double)ob.R[3 * r + 1] * pr.center[1] +
+                            (double)ob.R[3 * r + 2] * pr.center[2] + (double)ob.pos[r];
+                sp.x = (float)cw[0]; sp.y = (float)cw[1]; sp.z = (float)cw[2]; sp.w = pr.radius;
+                spheres.push_back(sp);
+            }
     }
     DevPrim* prims = reinterpret_cast<DevPrim*>(blob.data() + o_pr);
     for (int p = 0; p < d->n_prims; ++p) {
@@ -306,6 +359,9 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     int32_t* sp = reinterpret_cast<int32_t*>(blob.data() + o_sp);
     for (int p = 0; p < 2 * d->n_self_pairs; ++p) sp[p] = d->self_link_idx[d->self_pairs[p]];
     if (d->n_self_pairs) std::memcpy(blob.data() + o_sm, d->self_margin, sizeof(float) * d->n_self_pairs);
+    if (!spheres.empty()) std::memcpy(blob.data() + o_sph, spheres.data(), sizeof(float4) * spheres.size());
+    bool uniform_r = !spheres.empty();
+    for (const float4& sp : spheres) uniform_r = uniform_r && sp.w == spheres[0].w;
 
     TrkCostModel* cm = new (std::nothrow) TrkCostModel();
     if (!cm) return fail(TRK_ERR_HIP, "out of host memory");
@@ -332,6 +388,12 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     h.prims = reinterpret_cast<const DevPrim*>(base + o_pr);
     h.self_pairs = reinterpret_cast<const int32_t*>(base + o_sp);
     h.self_margin = reinterpret_cast<const float*>(base + o_sm);
+    cm->obj_link_idx.assign(d->obj_link_idx, d->obj_link_idx + d->n_obj_links);
+    cm->self_pairs.assign(sp, sp + 2 * d->n_self_pairs);
+    h.spheres = reinterpret_cast<const float4*>(base + o_sph);
+    h.n_spheres = (int32_t)spheres.size();
+    h.spheres_uniform_r = uniform_r ? 1 : 0;
+    h.sphere_r = spheres.empty() ? 0.0f : spheres[0].w;
     if (n_grid) {
         h.grid.sdf = d->grid.sdf; h.grid.grad = d->grid.grad;
         for (int k = 0; k < 3; ++k) {
@@ -398,6 +460,30 @@ int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRo
     const int64_t n = batch * horizon;
     if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad: null q/cost/gq");
     if (n == 0) return TRK_OK;
+    if (m->spec && m->spec_enabled) {
+        // the generated kernel has the robot's collision-link sets baked in: use it only when the cost model's match
+        const SpecEntry* e = m->spec;
+        bool ok = true;
+        if (w->w_obj != 0.0f || w->w_ws != 0.0f)
+            ok = ok && (int)cm->obj_link_idx.size() == e->n_obj_links &&
+                 std::equal(cm->obj_link_idx.begin(), cm->obj_link_idx.end(), e->obj_link_idx);
+        if (w->w_self != 0.0f)
+            ok = ok && (int)cm->self_pairs.size() == 2 * e->n_self_pairs &&
+                 std::equal(cm->self_pairs.begin(), cm->self_pairs.end(), e->self_pairs);
+        if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link;
+        if (ok) {
+            SpecArgs a;
+            a.C = cm->hdr; a.w = *w;
+            std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+            std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+            a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
+            const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z[3] = {0, 0, 0};
+            const int base_id = std::memcmp(a.base_R, I, sizeof(I)) == 0 && std::memcmp(a.base_t, Z, sizeof(Z)) == 0;
+            e->launch(a, base_id, (hipStream_t)stream);
+            TRK_HIP(hipGetLastError());
+            return TRK_OK;
+        }
+    }
     trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, cm->hdr, *w, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;

@@ -49,8 +49,12 @@ struct alignas(16) DevPrim {   // 8 dwords
 struct alignas(16) DevObj {    // 16 dwords
     float pos[3];
     float R[9];
-    int32_t prim_begin, prim_end, is_grid, identity;
+    int32_t prim_begin, prim_end, is_grid, identity;   // identity: bit0 = R is I, bit1 = has non-sphere primitives
 };
+#define TRK_OBJ_IDENTITY 1
+#define TRK_OBJ_NONSPHERE 2
+// per-object flag stored in DevPrim.type's upper bits is avoided: sphere primitives are skipped by type in
+// the cost kernels (they live in DevCostHdr::spheres), and visited only by the per-object SDF queries.
 
 struct DevGrid {
     const float* sdf;
@@ -76,6 +80,14 @@ struct DevCostHdr {
     const DevPrim* prims;          // device
     const int32_t* self_pairs;     // device: pairs already mapped to position-tensor link indices [P*2]
     const float* self_margin;      // device
+    // All sphere primitives of all analytic objects, merged and moved to the world frame (a sphere SDF is
+    // rotation-invariant, so the object pose folds into the centre; max over objects of (margin - sdf) is a
+    // min over the union).  float4 = (cx, cy, cz, r).  Objects keep only their non-sphere primitives here.
+    const float4* spheres;         // device
+    int32_t n_spheres;
+    int32_t spheres_uniform_r;     // 1: every radius equals sphere_r (arg-min by squared distance, one sqrt)
+    float sphere_r;
+    int32_t n_box_objects;         // objects that still have non-sphere primitives (or are the grid)
     DevGrid grid;
 };
 
@@ -229,33 +241,114 @@ __device__ __forceinline__ float grid_sdf(const DevGrid& G, float x, float y, fl
     return G.sdf[lin];
 }
 
-// ObjectField primitives.py:387-405: x' = R^T (x - pos), min over primitives, g = R g'
-template <bool PRECISE>
+// ObjectField primitives.py:387-405: x' = R^T (x - pos), min over primitives, g = R g'.
+// SKIP_SPHERES: visit only the non-sphere primitives (the spheres are handled through DevCostHdr::spheres);
+// returns +inf when the object has none.
+template <bool PRECISE, bool SKIP_SPHERES = false>
 __device__ __forceinline__ float object_sdf(const DevCostHdr& C, int o, float x, float y, float z,
                                             float& gx, float& gy, float& gz) {
     const DevObj& O = C.objects[o];
     if (O.is_grid) return grid_sdf(C.grid, x, y, z, gx, gy, gz);
+    const bool ident = (O.identity & TRK_OBJ_IDENTITY) != 0;
     float lx, ly, lz;
-    if (O.identity) { lx = x - O.pos[0]; ly = y - O.pos[1]; lz = z - O.pos[2]; }
+    if (ident) { lx = x - O.pos[0]; ly = y - O.pos[1]; lz = z - O.pos[2]; }
     else {
         const float dx = x - O.pos[0], dy = y - O.pos[1], dz = z - O.pos[2];
         lx = fmaf(O.R[0], dx, fmaf(O.R[3], dy, O.R[6] * dz));
         ly = fmaf(O.R[1], dx, fmaf(O.R[4], dy, O.R[7] * dz));
         lz = fmaf(O.R[2], dx, fmaf(O.R[5], dy, O.R[8] * dz));
     }
-    float best = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
+    float best = __builtin_inff(), bx = 0.0f, by = 0.0f, bz = 0.0f;
     for (int pi = O.prim_begin; pi < O.prim_end; ++pi) {
+        const DevPrim& P = C.prims[pi];
+        if (SKIP_SPHERES && P.type == TRK_PRIM_SPHERE) continue;
         float px, py, pz;
-        const float v = prim_sdf<PRECISE>(C.prims[pi], lx, ly, lz, px, py, pz);
-        const bool take = (pi == O.prim_begin) || (v < best);
+        const float v = prim_sdf<PRECISE>(P, lx, ly, lz, px, py, pz);
+        const bool take = v < best;
         best = take ? v : best; bx = take ? px : bx; by = take ? py : by; bz = take ? pz : bz;
     }
-    if (O.identity) { gx = bx; gy = by; gz = bz; }
+    if (ident) { gx = bx; gy = by; gz = bz; }
     else {
         gx = fmaf(O.R[0], bx, fmaf(O.R[1], by, O.R[2] * bz));
         gy = fmaf(O.R[3], bx, fmaf(O.R[4], by, O.R[5] * bz));
         gz = fmaf(O.R[6], bx, fmaf(O.R[7], by, O.R[8] * bz));
     }
+    return best;
+}
+
+// min over the whole scene (merged spheres, then objects with non-sphere primitives / the grid) of the signed
+// distance at NL points held in registers, with the world-frame gradient of the arg-min primitive.
+// = min_o sdf_o(p)  of distance_fields.py:307-316 + :121-122 (max over objects of margin - sdf).
+template <int NL>
+__device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (&px)[NL], const float (&py)[NL],
+                                              const float (&pz)[NL], float (&s)[NL], float (&gx)[NL], float (&gy)[NL],
+                                              float (&gz)[NL]) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { s[l] = __builtin_inff(); gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }
+    if (C.n_spheres > 0) {
+        if (C.spheres_uniform_r) {
+            // equal radii: arg-min of the squared distance, one sqrt per point at the end
+            float bn[NL]; int bi[NL];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) { bn[l] = __builtin_inff(); bi[l] = 0; }
+            for (int k = 0; k < C.n_spheres; ++k) {
+                const float4 S = C.spheres[k];              // wave-uniform: scalar load
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
+                    const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                    bi[l] = n2 < bn[l] ? k : bi[l];
+                    bn[l] = fminf(bn[l], n2);
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const float4 S = C.spheres[bi[l]];          // per-lane gather of the winning centre (L1/L2 hit)
+                const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
+                const float nrm = trk_sqrt(bn[l]);
+                const float inv = nrm > 0.0f ? trk_rcp(nrm) : 0.0f;
+                s[l] = nrm - C.sphere_r; gx[l] = dx * inv; gy[l] = dy * inv; gz[l] = dz * inv;
+            }
+        } else {
+            for (int k = 0; k < C.n_spheres; ++k) {
+                const float4 S = C.spheres[k];
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
+                    const float nrm = trk_sqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+                    const float v = nrm - S.w;
+                    const bool take = v < s[l];
+                    const float inv = nrm > 0.0f ? trk_rcp(nrm) : 0.0f;
+                    s[l] = take ? v : s[l];
+                    gx[l] = take ? dx * inv : gx[l]; gy[l] = take ? dy * inv : gy[l]; gz[l] = take ? dz * inv : gz[l];
+                }
+            }
+        }
+    }
+    for (int o = 0; o < C.n_objects; ++o) {
+        const DevObj& O = C.objects[o];
+        if (!O.is_grid && !(O.identity & TRK_OBJ_NONSPHERE)) continue;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            float ax, ay, az;
+            const float v = object_sdf<false, true>(C, o, px[l], py[l], pz[l], ax, ay, az);
+            const bool take = v < s[l];
+            s[l] = take ? v : s[l]; gx[l] = take ? ax : gx[l]; gy[l] = take ? ay : gy[l]; gz[l] = take ? az : gz[l];
+        }
+    }
+}
+
+// workspace box, distance_fields.py:326-332: max_k (margin - sd_k) over the six planes; returns the value,
+// adds scale * d/dp to (ax, ay, az)
+__device__ __forceinline__ float ws_cost_point(const DevCostHdr& C, float mg, float x, float y, float z, float scale,
+                                               float& ax, float& ay, float& az) {
+    const float sd[6] = {x - C.ws_min[0], y - C.ws_min[1], z - C.ws_min[2], C.ws_max[0] - x, C.ws_max[1] - y, C.ws_max[2] - z};
+    float best = mg - sd[0]; int bk = 0;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) { const float v = mg - sd[k]; if (v > best) { best = v; bk = k; } }
+    const float sgn = bk < 3 ? -scale : scale;
+    const int axk = bk < 3 ? bk : bk - 3;
+    ax += axk == 0 ? sgn : 0.0f; ay += axk == 1 ? sgn : 0.0f; az += axk == 2 ? sgn : 0.0f;
     return best;
 }
 

@@ -297,28 +297,25 @@ __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, fl
             const float x = pt[3 * li], y = pt[3 * li + 1], z = pt[3 * li + 2];
             float ax = 0.0f, ay = 0.0f, az = 0.0f;
             if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
-                float best = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
-                for (int o = 0; o < C.n_objects; ++o) {
-                    float gx, gy, gz;
-                    const float v = mg - object_sdf<PRECISE>(C, o, x, y, z, gx, gy, gz);
-                    const bool take = (o == 0) || (v > best);       // max over objects, first maximum wins
-                    best = take ? v : best; bx = take ? gx : bx; by = take ? gy : by; bz = take ? gz : bz;
+                if (PRECISE) {
+                    float best = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
+                    for (int o = 0; o < C.n_objects; ++o) {
+                        float gx, gy, gz;
+                        const float v = mg - object_sdf<true>(C, o, x, y, z, gx, gy, gz);
+                        const bool take = (o == 0) || (v > best);       // max over objects, first maximum wins
+                        best = take ? v : best; bx = take ? gx : bx; by = take ? gy : by; bz = take ? gz : bz;
+                    }
+                    cost = fmaf(w_obj, best, cost);
+                    ax -= w_obj * bx; ay -= w_obj * by; az -= w_obj * bz;
+                } else {
+                    const float p1x[1] = {x}, p1y[1] = {y}, p1z[1] = {z};
+                    float s1[1], g1x[1], g1y[1], g1z[1];
+                    scene_min_sdf<1>(C, p1x, p1y, p1z, s1, g1x, g1y, g1z);
+                    cost = fmaf(w_obj, mg - s1[0], cost);
+                    ax -= w_obj * g1x[0]; ay -= w_obj * g1y[0]; az -= w_obj * g1z[0];
                 }
-                cost = fmaf(w_obj, best, cost);
-                ax -= w_obj * bx; ay -= w_obj * by; az -= w_obj * bz;
             }
-            if ((fields & TRK_FIELD_WS) && C.has_ws) {
-                // six plane distances [p - ws_min ; ws_max - p]; max_k (margin - sd_k)
-                const float sd[6] = {x - C.ws_min[0], y - C.ws_min[1], z - C.ws_min[2],
-                                     C.ws_max[0] - x, C.ws_max[1] - y, C.ws_max[2] - z};
-                float best = mg - sd[0]; int bk = 0;
-#pragma unroll
-                for (int k = 1; k < 6; ++k) { const float v = mg - sd[k]; if (v > best) { best = v; bk = k; } }
-                cost = fmaf(w_ws, best, cost);
-                const float sgn = bk < 3 ? -w_ws : w_ws;
-                const int axk = bk < 3 ? bk : bk - 3;
-                ax += axk == 0 ? sgn : 0.0f; ay += axk == 1 ? sgn : 0.0f; az += axk == 2 ? sgn : 0.0f;
-            }
+            if ((fields & TRK_FIELD_WS) && C.has_ws) cost = fmaf(w_ws, ws_cost_point(C, mg, x, y, z, w_ws, ax, ay, az), cost);
             if (gt) { gt[3 * li] += ax; gt[3 * li + 1] += ay; gt[3 * li + 2] += az; }
         }
     }

@@ -1,0 +1,152 @@
+// trk_spec_common.h -- pieces shared by the model-specialised (generated) fused rollout kernels.
+//
+// A generated kernel (torch_robotics_amd/codegen.py) is straight-line code for ONE kinematic tree and ONE
+// set of collision links: the chain is unrolled, URDF constants are literals, structural zeros and +-1 are
+// folded away, every pose lives in named registers.  What stays runtime (wave-uniform, scalar-loaded) is the
+// scene: primitives, margins, workspace box, EE target, weights, base pose.
+//
+// Work mapping: one 64-lane wavefront per workgroup = 64 consecutive samples (one trajectory at horizon 64).
+// LDS (8.25 KiB per wave for Panda) is used only to transpose between "lane owns a sample" and "wave writes a
+// contiguous span": q in, link positions / gradient out -- every HBM access of a wave is a contiguous run.
+#pragma once
+#include "trk_device.h"
+
+struct SpecArgs {
+    DevCostHdr C;
+    TrkRolloutWeights w;
+    float base_R[9];
+    float base_t[3];
+    const float* q;
+    int64_t n;
+    float* link_pos;
+    float* cost;
+    float* gq;
+    float* cost_sum;
+};
+
+typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
+
+struct SpecEntry {
+    uint64_t model_hash;        // FNV-1a over the kinematic tables (see trk_capi.hip: model_hash)
+    int32_t n_links, n_dofs;
+    int32_t n_obj_links;        // baked collision-link template
+    const int32_t* obj_link_idx;
+    int32_t n_self_pairs;
+    const int32_t* self_pairs;  // [2*P] LINK indices (already mapped through self_link_idx)
+    int32_t ee_link;
+    const char* name;
+    SpecLaunchFn launch;
+};
+
+// registry filled by static initialisers of the generated translation units
+void trk_spec_register(const SpecEntry* e);
+const SpecEntry* trk_spec_find(uint64_t model_hash, int n_links, int n_dofs);
+
+// ---------------------------------------------------------------------------------------------------------
+// I/O transposes (one wavefront, `lane` = threadIdx.x)
+// ---------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void spec_load_q(const float* __restrict__ q, int64_t base, int rows, int lane,
+                                            float* lds, float (&qv)[D]) {
+    // D coalesced dword loads per lane over the wave's contiguous 64*D floats, then a stride-D LDS read
+    const int64_t first = base * D;
+    const int count = rows * D;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const int k = lane + TRK_WAVE * j;
+        lds[k] = k < count ? q[first + k] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < D; ++j) qv[j] = lds[lane * D + j];
+    __syncthreads();
+}
+
+template <int D>
+__device__ __forceinline__ void spec_store_gq(float* __restrict__ gq, int64_t base, int rows, int lane,
+                                              float* lds, const float (&gv)[D]) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < D; ++j) lds[lane * D + j] = gv[j];
+    __syncthreads();
+    const int64_t first = base * D;
+    const int count = rows * D;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const int k = lane + TRK_WAVE * j;
+        if (k < count) gq[first + k] = lds[k];
+    }
+}
+
+// link positions: lane writes its 3L floats at stride 3L (odd or not: 3L = 33 for Panda -> conflict-free),
+// then the wave streams the 64*3L contiguous floats out with 16-byte stores
+template <int W>   // W = 3 * L floats per sample
+__device__ __forceinline__ void spec_store_rows(float* __restrict__ out, int64_t base, int rows, int lane,
+                                                float* lds, const float (&v)[W]) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < W; ++j) lds[lane * W + j] = v[j];
+    __syncthreads();
+    float* dst = out + base * W;
+    if (rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        constexpr int NV = W * TRK_WAVE / 4;                     // float4 chunks
+        const float4* src4 = reinterpret_cast<const float4*>(lds);
+        float4* dst4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+        for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            if (k < NV) dst4[k] = src4[k];
+        }
+    } else {
+        const int count = rows * W;
+        for (int k = lane; k < count; k += TRK_WAVE) dst[k] = lds[k];
+    }
+}
+
+__device__ __forceinline__ float spec_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, TRK_WAVE);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// collision objectives on NL link points held in registers.  Adds w * cost to `cost` and
+// w * d cost / d p to (gx, gy, gz) (accumulating).  Margins are C.obj_link_margin[0..NL) in baked order.
+// ---------------------------------------------------------------------------------------------------------
+template <int NL>
+__device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w, const float (&px)[NL],
+                                                   const float (&py)[NL], const float (&pz)[NL], float (&gx)[NL],
+                                                   float (&gy)[NL], float (&gz)[NL]) {
+    float s[NL], ax[NL], ay[NL], az[NL];
+    scene_min_sdf<NL>(C, px, py, pz, s, ax, ay, az);
+    float cost = 0.0f;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        cost += C.obj_link_margin[l] - s[l];                     // sum_l max_o (margin - sdf_o) = sum_l (margin - min_o sdf_o)
+        gx[l] = fmaf(-w, ax[l], gx[l]); gy[l] = fmaf(-w, ay[l], gy[l]); gz[l] = fmaf(-w, az[l], gz[l]);
+    }
+    return w * cost;
+}
+
+template <int NL>
+__device__ __forceinline__ float spec_ws_cost(const DevCostHdr& C, float w, const float (&px)[NL], const float (&py)[NL],
+                                              const float (&pz)[NL], float (&gx)[NL], float (&gy)[NL], float (&gz)[NL]) {
+    float cost = 0.0f;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) cost += ws_cost_point(C, C.obj_link_margin[l], px[l], py[l], pz[l], w, gx[l], gy[l], gz[l]);
+    return w * cost;
+}
+
+// one self-collision pair (distance_fields.py:194-208): returns w*(margin - ||pa - pb||), accumulates gradients
+__device__ __forceinline__ float spec_self_pair(float w, float margin, float ax, float ay, float az, float bx, float by,
+                                                float bz, float& gax, float& gay, float& gaz, float& gbx, float& gby,
+                                                float& gbz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const float nrm = trk_sqrt(n2);
+    const float inv = nrm > 0.0f ? w * trk_rcp(nrm) : 0.0f;
+    const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+    gax -= ux; gay -= uy; gaz -= uz;
+    gbx += ux; gby += uy; gbz += uz;
+    return w * (margin - nrm);
+}

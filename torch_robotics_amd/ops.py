@@ -56,6 +56,9 @@ class ModelHandle:
     def specialized(self) -> bool:
         return bool(lib().trk_model_is_specialized(self._h))
 
+    def enable_specialized(self, enable: bool) -> None:
+        check(lib().trk_model_enable_specialized(self._h, int(bool(enable))), "trk_model_enable_specialized")
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
