@@ -275,8 +275,10 @@ int trk_ee_cost(const TrkCostModel* cm, const float* H_ee, int64_t n, int64_t st
  * q [B,H,D] -> link_pos_out (nullable) [B,H,L,3], cost [B,H], gq [B,H,D];
  * cost = w_self*self + w_obj*objects + w_ws*workspace + w_ee*ee  (a zero weight skips the term);
  * gq = d cost[b,h] / d q[b,h,:] (samples are independent, so this equals the gradient of
- * cost.sum()).  cost_sum (nullable): DEVICE float[1], incremented by sum(cost) with one
- * wave-reduced atomic per wavefront -- the partial a multi-GPU caller all-reduces.
+ * cost.sum()).  cost_block_sums (nullable): DEVICE float[ceil(B*H/64)]; entry w receives the sum of
+ * cost over samples [64w, 64w+64) -- one wave-level reduction and one plain store per wavefront, no
+ * atomics, bit-reproducible.  With horizon 64 these are the per-trajectory costs; trk_reduce_sum folds
+ * them into the scalar a multi-GPU caller all-reduces.
  * The cost model's link indices refer to the robot's L links (n_links_in == L).
  * --------------------------------------------------------------------------------- */
 typedef struct TrkRolloutWeights {
@@ -285,8 +287,11 @@ typedef struct TrkRolloutWeights {
 
 int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const TrkRolloutWeights* w,
                           const float* q, int64_t batch, int32_t horizon,
-                          float* link_pos_out, float* cost, float* gq, float* cost_sum,
+                          float* link_pos_out, float* cost, float* gq, float* cost_block_sums,
                           trk_stream_t stream);
+
+/* Deterministic sum of n floats (fixed association order, one workgroup): x [n] -> out [1]. */
+int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * SDF grid precompute (GridMapSDF.precompute_sdf grid_map_sdf.py:34-63): evaluates the analytic

@@ -214,7 +214,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     for base_identity in (True, False):
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
-        E.raw(f"__global__ void __launch_bounds__(TRK_WAVE) {kname}(SpecArgs A) {{")
+        E.raw(f"__global__ void __launch_bounds__(TRK_WAVE, 4) {kname}(SpecArgs A) {{")
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds[TRK_WAVE * {max(3 * L, D)}];")
         E.raw("    const int lane = threadIdx.x;")
         E.raw("    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;")
@@ -292,7 +292,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             for pi, (a, b) in enumerate(tmpl.self_pairs):
                 pa = ", ".join(E.expr(t[a][k]) for k in range(3))
                 pb = ", ".join(E.expr(t[b][k]) for k in range(3))
-                E.raw(f"        cost += spec_self_pair(A.w.w_self, A.C.self_margin[{pi}], {pa}, {pb}, "
+                E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], {pa}, {pb}, "
                       f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2);")
             E.raw("    }")
         ee = tmpl.ee_link
@@ -312,7 +312,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    if (lane < rows) A.cost[base + lane] = cost;")
         E.raw("    if (A.cost_sum) {")
         E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
-        E.raw("        if (lane == 0) atomicAdd(A.cost_sum, tot);")
+        E.raw("        if (lane == 0) A.cost_sum[blockIdx.x] = tot;")
         E.raw("    }")
         # ---------------- reverse: wrench accumulators towards the root ----------------
         F: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}

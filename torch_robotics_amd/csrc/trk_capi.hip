@@ -489,6 +489,15 @@ int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRo
     return TRK_OK;
 }
 
+int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream) {
+    if (n < 0 || !out || (n > 0 && !x)) return fail(TRK_ERR_INVALID_ARG, "trk_reduce_sum: bad argument");
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_reduce_sum(x, n, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
 int trk_grid_precompute(const TrkCostModel* cm, const int32_t dims[3], const float lim_min[3], const float lim_max[3],
                         float* sdf, float* grad, trk_stream_t stream) {
     if (!cm || !dims || !lim_min || !lim_max || !sdf || !grad) return fail(TRK_ERR_INVALID_ARG, "trk_grid_precompute: null argument");

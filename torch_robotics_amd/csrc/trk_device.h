@@ -95,6 +95,36 @@ struct SelMap {                 // link (file index) -> output column, -1 = not 
     int32_t col[TRK_MAX_LINKS];
 };
 
+// Wave-uniform tables are read through the constant address space: the loads are then invariant, so the
+// compiler emits scalar loads (s_load_dwordx*, scalar cache -> SGPRs) instead of a vector load + full
+// s_waitcnt vmcnt(0) per loop iteration.  The tables are never written by a kernel.
+#define TRK_CAS __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const TRK_CAS T* cptr(const T* p) { return (const TRK_CAS T*)p; }
+
+__device__ __forceinline__ DevPrim load_prim(const DevPrim* prims, int i) {
+    const TRK_CAS DevPrim* c = cptr(prims) + i;
+    DevPrim P;
+    P.type = c->type; P.cx = c->cx; P.cy = c->cy; P.cz = c->cz; P.hx = c->hx; P.hy = c->hy; P.hz = c->hz; P.r = c->r;
+    return P;
+}
+__device__ __forceinline__ DevObj load_obj(const DevObj* objs, int i) {
+    const TRK_CAS DevObj* c = cptr(objs) + i;
+    DevObj O;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) O.pos[k] = c->pos[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) O.R[k] = c->R[k];
+    O.prim_begin = c->prim_begin; O.prim_end = c->prim_end; O.is_grid = c->is_grid; O.identity = c->identity;
+    return O;
+}
+struct F4 { float x, y, z, w; };
+__device__ __forceinline__ F4 load_f4_uniform(const float4* p, int i) {      // wave-uniform index: scalar load
+    const TRK_CAS float* c = (const TRK_CAS float*)p + 4 * i;
+    F4 v; v.x = c[0]; v.y = c[1]; v.z = c[2]; v.w = c[3];
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // math
 // ------------------------------------------------------------------------------------------
@@ -247,7 +277,7 @@ __device__ __forceinline__ float grid_sdf(const DevGrid& G, float x, float y, fl
 template <bool PRECISE, bool SKIP_SPHERES = false>
 __device__ __forceinline__ float object_sdf(const DevCostHdr& C, int o, float x, float y, float z,
                                             float& gx, float& gy, float& gz) {
-    const DevObj& O = C.objects[o];
+    const DevObj O = load_obj(C.objects, o);
     if (O.is_grid) return grid_sdf(C.grid, x, y, z, gx, gy, gz);
     const bool ident = (O.identity & TRK_OBJ_IDENTITY) != 0;
     float lx, ly, lz;
@@ -260,7 +290,7 @@ __device__ __forceinline__ float object_sdf(const DevCostHdr& C, int o, float x,
     }
     float best = __builtin_inff(), bx = 0.0f, by = 0.0f, bz = 0.0f;
     for (int pi = O.prim_begin; pi < O.prim_end; ++pi) {
-        const DevPrim& P = C.prims[pi];
+        const DevPrim P = load_prim(C.prims, pi);
         if (SKIP_SPHERES && P.type == TRK_PRIM_SPHERE) continue;
         float px, py, pz;
         const float v = prim_sdf<PRECISE>(P, lx, ly, lz, px, py, pz);
@@ -292,13 +322,14 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
 #pragma unroll
             for (int l = 0; l < NL; ++l) { bn[l] = __builtin_inff(); bi[l] = 0; }
             for (int k = 0; k < C.n_spheres; ++k) {
-                const float4 S = C.spheres[k];              // wave-uniform: scalar load
+                const F4 S = load_f4_uniform(C.spheres, k);   // wave-uniform: scalar load
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
                     const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                    bi[l] = n2 < bn[l] ? k : bi[l];
-                    bn[l] = fminf(bn[l], n2);
+                    const bool lt = n2 < bn[l];
+                    bi[l] = lt ? k : bi[l];
+                    bn[l] = lt ? n2 : bn[l];
                 }
             }
 #pragma unroll
@@ -311,7 +342,7 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
             }
         } else {
             for (int k = 0; k < C.n_spheres; ++k) {
-                const float4 S = C.spheres[k];
+                const F4 S = load_f4_uniform(C.spheres, k);
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
@@ -326,8 +357,8 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
         }
     }
     for (int o = 0; o < C.n_objects; ++o) {
-        const DevObj& O = C.objects[o];
-        if (!O.is_grid && !(O.identity & TRK_OBJ_NONSPHERE)) continue;
+        const TRK_CAS DevObj* Oc = cptr(C.objects) + o;
+        if (!Oc->is_grid && !(Oc->identity & TRK_OBJ_NONSPHERE)) continue;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             float ax, ay, az;

@@ -292,8 +292,8 @@ __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, fl
     float* gt = gtile ? gtile + lane * rs : nullptr;
     if ((fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) != 0) {
         for (int l = 0; l < C.n_obj_links; ++l) {
-            const int li = C.obj_link_idx[l];
-            const float mg = C.obj_link_margin[l];
+            const int li = cptr(C.obj_link_idx)[l];
+            const float mg = cptr(C.obj_link_margin)[l];
             const float x = pt[3 * li], y = pt[3 * li + 1], z = pt[3 * li + 2];
             float ax = 0.0f, ay = 0.0f, az = 0.0f;
             if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
@@ -321,11 +321,11 @@ __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, fl
     }
     if (fields & TRK_FIELD_SELF) {
         for (int pi = 0; pi < C.n_self_pairs; ++pi) {
-            const int a = C.self_pairs[2 * pi], b = C.self_pairs[2 * pi + 1];
+            const int a = cptr(C.self_pairs)[2 * pi], b = cptr(C.self_pairs)[2 * pi + 1];
             const float dx = pt[3 * a] - pt[3 * b], dy = pt[3 * a + 1] - pt[3 * b + 1], dz = pt[3 * a + 2] - pt[3 * b + 2];
             const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
             const float nrm = PRECISE ? sqrtf(n2) : trk_sqrt(n2);
-            cost = fmaf(w_self, C.self_margin[pi] - nrm, cost);
+            cost = fmaf(w_self, cptr(C.self_margin)[pi] - nrm, cost);
             if (gt) {
                 const float inv = nrm > 0.0f ? w_self * (PRECISE ? 1.0f / nrm : trk_rcp(nrm)) : 0.0f;
                 const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
@@ -380,8 +380,8 @@ k_collision_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos,
     bool hit = false;
     if (fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {
         for (int l = 0; l < C.n_obj_links; ++l) {
-            const int li = C.obj_link_idx[l];
-            const float mg = use_default ? C.obj_link_margin[l] : margin_override;
+            const int li = cptr(C.obj_link_idx)[l];
+            const float mg = use_default ? cptr(C.obj_link_margin)[l] : margin_override;
             const float x = pt[3 * li], y = pt[3 * li + 1], z = pt[3 * li + 2];
             if (fields & TRK_FIELD_OBJECTS)
                 for (int o = 0; o < C.n_objects; ++o) {
@@ -396,9 +396,9 @@ k_collision_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos,
     }
     if (fields & TRK_FIELD_SELF) {
         for (int pi = 0; pi < C.n_self_pairs; ++pi) {
-            const int a = C.self_pairs[2 * pi], b = C.self_pairs[2 * pi + 1];
+            const int a = cptr(C.self_pairs)[2 * pi], b = cptr(C.self_pairs)[2 * pi + 1];
             const float dx = pt[3 * a] - pt[3 * b], dy = pt[3 * a + 1] - pt[3 * b + 1], dz = pt[3 * a + 2] - pt[3 * b + 2];
-            const float mg = use_default ? C.self_margin[pi] : margin_override;
+            const float mg = use_default ? cptr(C.self_margin)[pi] : margin_override;
             hit |= sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz))) < mg;
         }
     }
@@ -495,9 +495,9 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
         g[0] = fmaf(w.w_ee, gt[0], g[0]); g[1] = fmaf(w.w_ee, gt[1], g[1]); g[2] = fmaf(w.w_ee, gt[2], g[2]);
     }
     if (lane < rows) cost[base + lane] = c;
-    if (cost_sum) {
+    if (cost_sum) {     // per-wavefront partial sum: no atomics (4096 same-address atomics cost ~47 us on MI355X)
         const float tot = wave_sum(lane < rows ? c : 0.0f);
-        if (lane == 0) atomicAdd(cost_sum, tot);
+        if (lane == 0) cost_sum[blockIdx.x] = tot;
     }
     // walk 2: reverse pass
     AdjFromTile<true> adj{gtile, rs, lane, sel_unused, use_ee ? C.ee_link : -1, eeRb};
@@ -688,7 +688,7 @@ k_grid_precompute(DevCostHdr C, int nx, int ny, int nz, float lo0, float lo1, fl
     float best = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
     bool first = true;
     for (int o = 0; o < C.n_objects; ++o) {
-        if (C.objects[o].is_grid) continue;
+        if (cptr(C.objects)[o].is_grid) continue;
         float gx, gy, gz;
         const float v = object_sdf<true>(C, o, x[0], x[1], x[2], gx, gy, gz);
         const bool take = first || v < best;
@@ -712,6 +712,21 @@ k_sdf_points(DevCostHdr C, const float* __restrict__ pts, int64_t n, float* __re
             g[0] = gx; g[1] = gy; g[2] = gz;
         }
     }
+}
+
+// deterministic sum: one 256-thread workgroup, fixed strides, LDS tree
+__global__ void __launch_bounds__(256)
+k_reduce_sum(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float part[256];
+    float acc = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) acc += x[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
 }
 
 // --------------------------------------------------------------------------------------------
@@ -778,6 +793,10 @@ void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const 
     const int64_t total = (int64_t)dims[0] * dims[1] * dims[2];
     hipLaunchKernelGGL(k_grid_precompute, dim3(grid_for(total, 256)), dim3(256), 0, st, C, dims[0], dims[1], dims[2],
                        lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], sdf, grad);
+}
+
+void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, x, n, out);
 }
 
 void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st) {

@@ -122,7 +122,7 @@ __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w,
     float cost = 0.0f;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        cost += C.obj_link_margin[l] - s[l];                     // sum_l max_o (margin - sdf_o) = sum_l (margin - min_o sdf_o)
+        cost += cptr(C.obj_link_margin)[l] - s[l];                     // sum_l max_o (margin - sdf_o) = sum_l (margin - min_o sdf_o)
         gx[l] = fmaf(-w, ax[l], gx[l]); gy[l] = fmaf(-w, ay[l], gy[l]); gz[l] = fmaf(-w, az[l], gz[l]);
     }
     return w * cost;
@@ -133,7 +133,7 @@ __device__ __forceinline__ float spec_ws_cost(const DevCostHdr& C, float w, cons
                                               const float (&pz)[NL], float (&gx)[NL], float (&gy)[NL], float (&gz)[NL]) {
     float cost = 0.0f;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) cost += ws_cost_point(C, C.obj_link_margin[l], px[l], py[l], pz[l], w, gx[l], gy[l], gz[l]);
+    for (int l = 0; l < NL; ++l) cost += ws_cost_point(C, cptr(C.obj_link_margin)[l], px[l], py[l], pz[l], w, gx[l], gy[l], gz[l]);
     return w * cost;
 }
 

@@ -261,6 +261,21 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
             gq.reshape(tuple(lead) + (D,)))
 
 
+def reduce_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Deterministic sum of a float32 device vector (fixed association order)."""
+    x = _dev_f32(x, "reduce_sum(x)").reshape(-1)
+    if out is None:
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        check(lib().trk_reduce_sum(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x)), "trk_reduce_sum")
+    return out
+
+
+def n_blocks(n_samples: int) -> int:
+    """Length of the `cost_block_sums` output of the fused rollout (one entry per 64 samples)."""
+    return (int(n_samples) + 63) // 64
+
+
 def grid_precompute(cm: CostHandle, dims, lim_min, lim_max):
     dims_a = np.ascontiguousarray(dims, np.int32)
     lo, hi = np.ascontiguousarray(lim_min, np.float32), np.ascontiguousarray(lim_max, np.float32)
