@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=64)
     ap.add_argument("--reduce-every", type=int, default=16)
     ap.add_argument("--graph", type=int, default=0, help="capture this many steps per hipGraph replay (0 = eager launches)")
+    ap.add_argument("--weights", default=None, help="experiment: w_self,w_obj,w_ws,w_ee override (reported in config)")
+    ap.add_argument("--no-pos", action="store_true", help="experiment: do not write link positions")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -71,12 +73,14 @@ def main():
     Ht[:3, 3] = (0.4, 0.2, 0.5)
     task.set_ee_target(Ht, w_pos=1.0, w_rot=1.0, square=True)
     weights = (0.0, 1.0, 0.0, 1.0) if args.config == "c2" else (1.0, 1.0, 1.0, 1.0)
+    if args.weights:
+        weights = tuple(float(v) for v in args.weights.split(","))
     B, H = args.batch, args.horizon
     D, L = robot.q_dim, robot.diff_panda._kin.n_links
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     q = robot.random_q(B * H, generator=gen).reshape(B, H, D).contiguous()
     model, cm = task._fused_handles(dev)
-    plan = ops.RolloutPlan(model, cm, weights, q, want_pos=True)
+    plan = ops.RolloutPlan(model, cm, weights, q, want_pos=not args.no_pos)
     # the fused kernel leaves one partial cost sum per wavefront (= per trajectory at horizon 64); a rank folds them
     # into a scalar with the deterministic reduce kernel only when a collective needs it
     nb = ops.n_blocks(B * H)
@@ -172,7 +176,9 @@ def main():
                    "global_batch": B * world, "horizon": H, "parallelism": f"batch-sharded x{world}",
                    "launch": "hipGraph x%d" % args.graph if graph is not None else "eager, pre-bound C-ABI call",
                    "kernel": "specialized" if model.specialized else "table-driven",
-                   "reduce_every": args.reduce_every if world > 1 else None},
+                   "reduce_every": args.reduce_every if world > 1 else None,
+                   **({"experiment_weights": list(weights)} if args.weights else {}),
+                   **({"experiment_no_pos": True} if args.no_pos else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "bytes_per_sample": algorithmic_bytes_per_sample(D, L), "launch_us": launch_s * 1e6},

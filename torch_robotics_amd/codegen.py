@@ -214,11 +214,14 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     for base_identity in (True, False):
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
-        E.raw(f"__global__ void __launch_bounds__(TRK_WAVE, 4) {kname}(SpecArgs A) {{")
-        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds[TRK_WAVE * {max(3 * L, D)}];")
-        E.raw("    const int lane = threadIdx.x;")
-        E.raw("    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;")
-        E.raw("    const int rows = (int)min((int64_t)TRK_WAVE, A.n - base);")
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 4) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(3 * L, D)}];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(3 * L, D)});")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;     // index of this wave's 64-sample block")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    float q[D];")
         E.raw("    spec_load_q<D>(A.q, base, rows, lane, lds, q);")
         # ---------------- forward ----------------
@@ -231,6 +234,27 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         else:
             R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
             t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        # joint angles: clamp to the URDF limits (torch.clamp, rigid_body.py:157-160; the gradient mask is
+        # "q inside the limits" == "clamp left q unchanged"), then all sines / cosines, two angles per call
+        rot_dofs = []
+        for i in range(1, L):
+            jt, d = int(kin.joint_type[i]), int(kin.dof_idx[i])
+            if jt == JOINT_FIXED:
+                continue
+            if kin.clamp[i]:
+                E.raw(f"    const float qh{d} = __builtin_amdgcn_fmed3f(q[{d}], {flit(kin.lower[i])}, {flit(kin.upper[i])});")
+                E.raw(f"    const float pass{d} = qh{d} == q[{d}] ? 1.0f : 0.0f;")
+            else:
+                E.raw(f"    const float qh{d} = q[{d}];")
+            if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS) and float(kin.rot_sign[i]) != 0.0:
+                rot_dofs.append(d)
+        for d in rot_dofs:
+            E.raw(f"    float sn{d}, cs{d};")
+        for a, b in zip(rot_dofs[0::2], rot_dofs[1::2]):
+            E.raw(f"    trk_sincos2(qh{a}, qh{b}, &sn{a}, &cs{a}, &sn{b}, &cs{b});")
+        if len(rot_dofs) % 2:
+            d = rot_dofs[-1]
+            E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
         for p in range(1, L):
             i = int(kin.order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
             E.raw(f"    // link {i} '{kin.link_names[i]}' (parent {par})")
@@ -238,14 +262,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             tl = [S(snap_const(kin.trans[i][k], 0.0)) for k in range(3)]
             qh = None
             if jt != JOINT_FIXED:
-                if kin.clamp[i]:
-                    lo, hi = flit(kin.lower[i]), flit(kin.upper[i])
-                    E.raw(f"    const float qh{d} = fminf(fmaxf(q[{d}], {lo}), {hi});")
-                    E.raw(f"    const float pass{d} = (q[{d}] >= {lo} && q[{d}] <= {hi}) ? 1.0f : 0.0f;")
-                    passv[i] = S(1.0, f"pass{d}")
-                else:
-                    E.raw(f"    const float qh{d} = q[{d}];")
-                    passv[i] = ONE
+                passv[i] = S(1.0, f"pass{d}") if kin.clamp[i] else ONE
                 qh = S(1.0, f"qh{d}")
             if jt == JOINT_PRISMATIC:
                 tl = [E.lincomb([(S(float(kin.axis[i][k])), qh)], tl[k]) for k in range(3)]
@@ -255,8 +272,6 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS):
                 sg = float(kin.rot_sign[i])
                 if sg != 0.0:
-                    E.raw(f"    float sn{d}, cs{d};")
-                    E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
                     s, c = S(sg, f"sn{d}"), S(1.0, f"cs{d}")       # sin(sign*q) = sign*sin(q), cos even
                     ax = int(kin.rot_axis[i])
                     ci, cj = [(1, 2), (2, 0), (0, 1)][ax]
@@ -312,7 +327,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    if (lane < rows) A.cost[base + lane] = cost;")
         E.raw("    if (A.cost_sum) {")
         E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
-        E.raw("        if (lane == 0) A.cost_sum[blockIdx.x] = tot;")
+        E.raw("        if (lane == 0 && rows > 0) A.cost_sum[wblock] = tot;")
         E.raw("    }")
         # ---------------- reverse: wrench accumulators towards the root ----------------
         F: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
@@ -366,9 +381,9 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"static const int32_t kObjLinks[] = {{{obj}}};")
     out.append(f"static const int32_t kSelfPairs[] = {{{pairs}}};")
     out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
-    out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
-    out.append("    if (base_identity) hipLaunchKernelGGL(k_rollout_bi, dim3(grid), dim3(TRK_WAVE), 0, st, a);")
-    out.append("    else hipLaunchKernelGGL(k_rollout_bg, dim3(grid), dim3(TRK_WAVE), 0, st, a);")
+    out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+    out.append("    if (base_identity) hipLaunchKernelGGL(k_rollout_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    else hipLaunchKernelGGL(k_rollout_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch}};")

@@ -319,7 +319,9 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     const size_t o_sp = o_pr + al(sizeof(DevPrim) * (d->n_prims + 1));
     const size_t o_sm = o_sp + al(sizeof(int32_t) * 2 * (d->n_self_pairs + 1));
     const size_t o_sph = o_sm + al(sizeof(float) * (d->n_self_pairs + 1));
-    const size_t total = o_sph + al(sizeof(float4) * (d->n_prims + 1));
+    const size_t o_sel = o_sph + al(sizeof(float4) * (d->n_prims + 1));
+    const size_t o_box = o_sel + al(sizeof(float4) * (d->n_prims + 1));
+    const size_t total = o_box + al(sizeof(int32_t) * (d->n_objects + 1));
     std::vector<char> blob(total, 0);
     std::vector<float4> spheres;
     if (d->n_obj_links) {
@@ -360,6 +362,20 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     for (int p = 0; p < 2 * d->n_self_pairs; ++p) sp[p] = d->self_link_idx[d->self_pairs[p]];
     if (d->n_self_pairs) std::memcpy(blob.data() + o_sm, d->self_margin, sizeof(float) * d->n_self_pairs);
     if (!spheres.empty()) std::memcpy(blob.data() + o_sph, spheres.data(), sizeof(float4) * spheres.size());
+    {
+        float4* sel = reinterpret_cast<float4*>(blob.data() + o_sel);
+        for (size_t k = 0; k < spheres.size(); ++k) {
+            const float4& sp = spheres[k];
+            sel[k].x = -2.0f * sp.x; sel[k].y = -2.0f * sp.y; sel[k].z = -2.0f * sp.z;
+            sel[k].w = (float)((double)sp.x * sp.x + (double)sp.y * sp.y + (double)sp.z * sp.z);
+        }
+    }
+    int n_box = 0;
+    {
+        int32_t* box = reinterpret_cast<int32_t*>(blob.data() + o_box);
+        for (int o = 0; o < d->n_objects; ++o)
+            if (!d->objects[o].is_grid && (objs[o].identity & TRK_OBJ_NONSPHERE)) box[n_box++] = o;
+    }
     bool uniform_r = !spheres.empty();
     for (const float4& sp : spheres) uniform_r = uniform_r && sp.w == spheres[0].w;
 
@@ -391,6 +407,9 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     cm->obj_link_idx.assign(d->obj_link_idx, d->obj_link_idx + d->n_obj_links);
     cm->self_pairs.assign(sp, sp + 2 * d->n_self_pairs);
     h.spheres = reinterpret_cast<const float4*>(base + o_sph);
+    h.spheres_sel = reinterpret_cast<const float4*>(base + o_sel);
+    h.box_objects = reinterpret_cast<const int32_t*>(base + o_box);
+    h.n_box_objects = n_box;
     h.n_spheres = (int32_t)spheres.size();
     h.spheres_uniform_r = uniform_r ? 1 : 0;
     h.sphere_r = spheres.empty() ? 0.0f : spheres[0].w;

@@ -84,10 +84,12 @@ struct DevCostHdr {
     // rotation-invariant, so the object pose folds into the centre; max over objects of (margin - sdf) is a
     // min over the union).  float4 = (cx, cy, cz, r).  Objects keep only their non-sphere primitives here.
     const float4* spheres;         // device
+    const float4* spheres_sel;     // device: (-2cx, -2cy, -2cz, |c|^2): |p-c|^2 - |p|^2 = p . sel.xyz + sel.w (3 FMAs)
     int32_t n_spheres;
     int32_t spheres_uniform_r;     // 1: every radius equals sphere_r (arg-min by squared distance, one sqrt)
     float sphere_r;
-    int32_t n_box_objects;         // objects that still have non-sphere primitives (or are the grid)
+    int32_t n_box_objects;         // objects that still have non-sphere primitives (not the grid)
+    const int32_t* box_objects;    // device: their indices into objects[]
     DevGrid grid;
 };
 
@@ -131,26 +133,67 @@ __device__ __forceinline__ F4 load_f4_uniform(const float4* p, int i) {      // 
 __device__ __forceinline__ float trk_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ float trk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
 
-// sin and cos of x together: Cody-Waite reduction by pi/2 (two fmas) + degree-7/8 minimax
-// polynomials on [-pi/4, pi/4].  |error| <= ~1.5 ulp for |x| < 1e4 rad (tests/test_device_math.py).
-// Joint angles are clamped to URDF limits (a few rad), so no large-argument path is needed.
+// sin and cos of x together.  Cody-Waite reduction by pi (two fmas): x = k*pi + r, r in [-pi/2, pi/2], so
+// sin x = (-1)^k sin r and cos x = (-1)^k cos r -- a sign flip (one shift, two xors), no sin/cos swap.
+// sin r = r + r^3 P(r^2), cos r = 1 - r^2/2 + r^4 Q(r^2), P and Q cubic near-minimax fits (Chebyshev nodes).
+// Max abs error 1.5e-7 (sin) / 1.3e-7 (cos) for |x| < 3000 rad against fp64 (tests/test_device_math_cpu.py);
+// joint angles are clamped to URDF limits (a few rad).  20 VALU instructions, 13.5 per angle in the paired form.
+#define TRK_INV_PI 0x1.45f306p-2f
+#define TRK_PI_HI 0x1.921fb6p+1f
+#define TRK_PI_LO -0x1.777a5cp-24f
+#define TRK_S0 -0x1.555554p-3f
+#define TRK_S1 0x1.11104ep-7f
+#define TRK_S2 -0x1.9fb672p-13f
+#define TRK_S3 0x1.619f8p-19f
+#define TRK_C0 0x1.555556p-5f
+#define TRK_C1 -0x1.6c163ep-10f
+#define TRK_C2 0x1.9fd75ap-16f
+#define TRK_C3 -0x1.1d07b4p-22f
+
 __host__ __device__ __forceinline__ void trk_sincos(float x, float* s_out, float* c_out) {
-    const float k = rintf(x * 0.636619772367581343f);              // x * 2/pi
-    float r = fmaf(-k, 1.57079637050628662109375f, x);             // pi/2 hi
-    r = fmaf(-k, -4.37113900018624283e-8f, r);                     // pi/2 lo
-    const float r2 = r * r;
-    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    sp = fmaf(sp, r2, -1.6666654611e-1f);
-    const float sn = fmaf(r * r2, sp, r);
-    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    cp = fmaf(cp, r2, 4.166664568298827e-2f);
-    const float cs = fmaf(r2 * r2, cp, fmaf(r2, -0.5f, 1.0f));
-    const int n = (int)k;
-    const float a = (n & 1) ? cs : sn;
-    const float b = (n & 1) ? sn : cs;
-    *s_out = (n & 2) ? -a : a;
-    *c_out = ((n + 1) & 2) ? -b : b;
+    const float k = rintf(x * TRK_INV_PI);
+    float r = fmaf(-k, TRK_PI_HI, x);
+    r = fmaf(-k, TRK_PI_LO, r);
+    const float u = r * r;
+    float p = fmaf(u, TRK_S3, TRK_S2);
+    p = fmaf(p, u, TRK_S1);
+    p = fmaf(p, u, TRK_S0);
+    const float s = fmaf(r * u, p, r);
+    float q = fmaf(u, TRK_C3, TRK_C2);
+    q = fmaf(q, u, TRK_C1);
+    q = fmaf(q, u, TRK_C0);
+    const float c = fmaf(u * u, q, fmaf(u, -0.5f, 1.0f));
+    const unsigned flip = ((unsigned)(int)k) << 31;
+    unsigned sb, cb;
+    __builtin_memcpy(&sb, &s, 4); __builtin_memcpy(&cb, &c, 4);
+    sb ^= flip; cb ^= flip;
+    __builtin_memcpy(s_out, &sb, 4); __builtin_memcpy(c_out, &cb, 4);
 }
+
+#if defined(__HIPCC__)
+typedef float trk_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned trk_u2 __attribute__((ext_vector_type(2)));
+// two angles at once: the elementwise float2 arithmetic maps onto v_pk_mul_f32 / v_pk_fma_f32
+__device__ __forceinline__ void trk_sincos2(float x0, float x1, float* s0, float* c0, float* s1, float* c1) {
+    const trk_f2 x = {x0, x1};
+    trk_f2 k = x * TRK_INV_PI;
+    k.x = rintf(k.x); k.y = rintf(k.y);
+    trk_f2 r = -k * TRK_PI_HI + x;
+    r = -k * TRK_PI_LO + r;
+    const trk_f2 u = r * r;
+    trk_f2 p = u * TRK_S3 + TRK_S2;
+    p = p * u + TRK_S1;
+    p = p * u + TRK_S0;
+    const trk_f2 s = (r * u) * p + r;
+    trk_f2 q = u * TRK_C3 + TRK_C2;
+    q = q * u + TRK_C1;
+    q = q * u + TRK_C0;
+    const trk_f2 c = (u * u) * q + (u * -0.5f + 1.0f);
+    const unsigned f0 = ((unsigned)(int)k.x) << 31, f1 = ((unsigned)(int)k.y) << 31;
+    *s0 = __uint_as_float(__float_as_uint(s.x) ^ f0); *c0 = __uint_as_float(__float_as_uint(c.x) ^ f0);
+    *s1 = __uint_as_float(__float_as_uint(s.y) ^ f1); *c1 = __uint_as_float(__float_as_uint(c.y) ^ f1);
+}
+#endif
 
 struct Pose {
     float r[9];
@@ -278,7 +321,7 @@ template <bool PRECISE, bool SKIP_SPHERES = false>
 __device__ __forceinline__ float object_sdf(const DevCostHdr& C, int o, float x, float y, float z,
                                             float& gx, float& gy, float& gz) {
     const DevObj O = load_obj(C.objects, o);
-    if (O.is_grid) return grid_sdf(C.grid, x, y, z, gx, gy, gz);
+    if (!SKIP_SPHERES && O.is_grid) return grid_sdf(C.grid, x, y, z, gx, gy, gz);
     const bool ident = (O.identity & TRK_OBJ_IDENTITY) != 0;
     float lx, ly, lz;
     if (ident) { lx = x - O.pos[0]; ly = y - O.pos[1]; lz = z - O.pos[2]; }
@@ -317,26 +360,47 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
     for (int l = 0; l < NL; ++l) { s[l] = __builtin_inff(); gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }
     if (C.n_spheres > 0) {
         if (C.spheres_uniform_r) {
-            // equal radii: arg-min of the squared distance, one sqrt per point at the end
-            float bn[NL]; int bi[NL];
+            // equal radii: arg-min over spheres of |p-c|^2, ranked by |p-c|^2 - |p|^2 = p.(-2c) + |c|^2 (3 FMAs per
+            // sphere and point); the exact distance is recomputed for the winner only (one sqrt per point).
+            int bi[NL];
+            if (C.n_spheres <= 16) {
+                // index rides in the 4 low mantissa bits of the ranking key: one v_bfi + one v_min per sphere and
+                // point.  Only near-ties (relative gap < 2^-19) can pick the other sphere, and then both distances
+                // agree to ~2e-6 -- below the stated cost tolerance; the value itself is always exact.
+                float bk[NL];
 #pragma unroll
-            for (int l = 0; l < NL; ++l) { bn[l] = __builtin_inff(); bi[l] = 0; }
-            for (int k = 0; k < C.n_spheres; ++k) {
-                const F4 S = load_f4_uniform(C.spheres, k);   // wave-uniform: scalar load
+                for (int l = 0; l < NL; ++l) bk[l] = __builtin_inff();
+                for (int k = 0; k < C.n_spheres; ++k) {
+                    const F4 S = load_f4_uniform(C.spheres_sel, k);   // wave-uniform: scalar load
 #pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
-                    const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                    const bool lt = n2 < bn[l];
-                    bi[l] = lt ? k : bi[l];
-                    bn[l] = lt ? n2 : bn[l];
+                    for (int l = 0; l < NL; ++l) {
+                        const float t = fmaf(px[l], S.x, fmaf(py[l], S.y, fmaf(pz[l], S.z, S.w)));
+                        const float key = __uint_as_float((__float_as_uint(t) & ~15u) | (unsigned)k);
+                        bk[l] = __builtin_fminf(bk[l], key);
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < NL; ++l) bi[l] = (int)(__float_as_uint(bk[l]) & 15u);
+            } else {
+                float bn[NL];
+#pragma unroll
+                for (int l = 0; l < NL; ++l) { bn[l] = __builtin_inff(); bi[l] = 0; }
+                for (int k = 0; k < C.n_spheres; ++k) {
+                    const F4 S = load_f4_uniform(C.spheres_sel, k);
+#pragma unroll
+                    for (int l = 0; l < NL; ++l) {
+                        const float t = fmaf(px[l], S.x, fmaf(py[l], S.y, fmaf(pz[l], S.z, S.w)));
+                        const bool lt = t < bn[l];
+                        bi[l] = lt ? k : bi[l];
+                        bn[l] = lt ? t : bn[l];
+                    }
                 }
             }
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 const float4 S = C.spheres[bi[l]];          // per-lane gather of the winning centre (L1/L2 hit)
                 const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
-                const float nrm = trk_sqrt(bn[l]);
+                const float nrm = trk_sqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
                 const float inv = nrm > 0.0f ? trk_rcp(nrm) : 0.0f;
                 s[l] = nrm - C.sphere_r; gx[l] = dx * inv; gy[l] = dy * inv; gz[l] = dz * inv;
             }
@@ -356,13 +420,24 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
             }
         }
     }
-    for (int o = 0; o < C.n_objects; ++o) {
-        const TRK_CAS DevObj* Oc = cptr(C.objects) + o;
-        if (!Oc->is_grid && !(Oc->identity & TRK_OBJ_NONSPHERE)) continue;
+    // objects that still have non-sphere primitives (boxes): empty loop for sphere-only scenes
+    for (int b = 0; b < C.n_box_objects; ++b) {
+        const int o = cptr(C.box_objects)[b];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             float ax, ay, az;
             const float v = object_sdf<false, true>(C, o, px[l], py[l], pz[l], ax, ay, az);
+            const bool take = v < s[l];
+            s[l] = take ? v : s[l]; gx[l] = take ? ax : gx[l]; gy[l] = take ? ay : gy[l]; gz[l] = take ? az : gz[l];
+        }
+    }
+    // precomputed voxel grid (kept out of the loop above: its index arithmetic is loop-invariant and the
+    // compiler would otherwise hoist 15 IEEE divisions in front of every scene, grid or not)
+    if (C.has_grid) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            float ax, ay, az;
+            const float v = grid_sdf(C.grid, px[l], py[l], pz[l], ax, ay, az);
             const bool take = v < s[l];
             s[l] = take ? v : s[l]; gx[l] = take ? ax : gx[l]; gy[l] = take ? ay : gy[l]; gz[l] = take ? az : gz[l];
         }

@@ -5,9 +5,13 @@
 // folded away, every pose lives in named registers.  What stays runtime (wave-uniform, scalar-loaded) is the
 // scene: primitives, margins, workspace box, EE target, weights, base pose.
 //
-// Work mapping: one 64-lane wavefront per workgroup = 64 consecutive samples (one trajectory at horizon 64).
+// Work mapping: one 64-lane wavefront = 64 consecutive samples (one trajectory at horizon 64); SPEC_WAVES
+// wavefronts share a workgroup only to cut the number of workgroups the dispatcher has to place (they never
+// exchange data: each wave owns a private LDS region, `__syncthreads()` is just the cheapest fence).
 // LDS (8.25 KiB per wave for Panda) is used only to transpose between "lane owns a sample" and "wave writes a
 // contiguous span": q in, link positions / gradient out -- every HBM access of a wave is a contiguous run.
+#define SPEC_WAVES 4
+#define SPEC_BLOCK (SPEC_WAVES * TRK_WAVE)
 #pragma once
 #include "trk_device.h"
 
@@ -43,8 +47,16 @@ void trk_spec_register(const SpecEntry* e);
 const SpecEntry* trk_spec_find(uint64_t model_hash, int n_links, int n_dofs);
 
 // ---------------------------------------------------------------------------------------------------------
-// I/O transposes (one wavefront, `lane` = threadIdx.x)
+// I/O transposes (one wavefront, `lane` = lane id; `lds` = this wave's private region)
 // ---------------------------------------------------------------------------------------------------------
+// Ordering between this wave's own LDS writes and reads: DS instructions of one wave execute in order, so no
+// s_barrier is needed -- only a compiler-level fence (a workgroup barrier would make the four waves of a
+// workgroup march in lockstep and serialise their memory phases).
+__device__ __forceinline__ void spec_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <int D>
 __device__ __forceinline__ void spec_load_q(const float* __restrict__ q, int64_t base, int rows, int lane,
                                             float* lds, float (&qv)[D]) {
@@ -56,19 +68,19 @@ __device__ __forceinline__ void spec_load_q(const float* __restrict__ q, int64_t
         const int k = lane + TRK_WAVE * j;
         lds[k] = k < count ? q[first + k] : 0.0f;
     }
-    __syncthreads();
+    spec_wave_sync();
 #pragma unroll
     for (int j = 0; j < D; ++j) qv[j] = lds[lane * D + j];
-    __syncthreads();
+    spec_wave_sync();
 }
 
 template <int D>
 __device__ __forceinline__ void spec_store_gq(float* __restrict__ gq, int64_t base, int rows, int lane,
                                               float* lds, const float (&gv)[D]) {
-    __syncthreads();
+    spec_wave_sync();
 #pragma unroll
     for (int j = 0; j < D; ++j) lds[lane * D + j] = gv[j];
-    __syncthreads();
+    spec_wave_sync();
     const int64_t first = base * D;
     const int count = rows * D;
 #pragma unroll
@@ -83,10 +95,10 @@ __device__ __forceinline__ void spec_store_gq(float* __restrict__ gq, int64_t ba
 template <int W>   // W = 3 * L floats per sample
 __device__ __forceinline__ void spec_store_rows(float* __restrict__ out, int64_t base, int rows, int lane,
                                                 float* lds, const float (&v)[W]) {
-    __syncthreads();
+    spec_wave_sync();
 #pragma unroll
     for (int j = 0; j < W; ++j) lds[lane * W + j] = v[j];
-    __syncthreads();
+    spec_wave_sync();
     float* dst = out + base * W;
     if (rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
         constexpr int NV = W * TRK_WAVE / 4;                     // float4 chunks
