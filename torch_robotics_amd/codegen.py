@@ -200,9 +200,19 @@ def panda_template(kin: KinModel) -> CollisionTemplate:
     return CollisionTemplate(obj_links=obj, self_pairs=pairs, ee_link=idx["ee_link"])
 
 
+def _masked_factory(kin: KinModel):
+    def masked(E: Emitter, i: int, d: int, g: S) -> S:
+        """torch.clamp's gradient mask: pass g where the clamp left q unchanged, else 0 (one v_cndmask)."""
+        if g.is_zero or not kin.clamp[i]:
+            return g
+        return S(1.0, E.tmp(f"(passbits & {1 << d}u) ? {E.expr(g)} : 0.0f"))
+    return masked
+
+
 def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, snap: float = SNAP) -> str:
     L, D = kin.n_links, kin.n_dofs
     NL = len(tmpl.obj_links)
+    masked = _masked_factory(kin)
     adj_links = sorted(set(tmpl.obj_links) | {a for p in tmpl.self_pairs for a in p} |
                        ({tmpl.ee_link} if tmpl.ee_link >= 0 else set()))
     out: List[str] = []
@@ -237,13 +247,14 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # joint angles: clamp to the URDF limits (torch.clamp, rigid_body.py:157-160; the gradient mask is
         # "q inside the limits" == "clamp left q unchanged"), then all sines / cosines, two angles per call
         rot_dofs = []
+        E.raw("    unsigned passbits = 0u;      // bit d set: clamp left q[d] unchanged -> gradient passes (one VGPR instead of 2D)")
         for i in range(1, L):
             jt, d = int(kin.joint_type[i]), int(kin.dof_idx[i])
             if jt == JOINT_FIXED:
                 continue
             if kin.clamp[i]:
                 E.raw(f"    const float qh{d} = __builtin_amdgcn_fmed3f(q[{d}], {flit(kin.lower[i])}, {flit(kin.upper[i])});")
-                E.raw(f"    const float pass{d} = qh{d} == q[{d}] ? 1.0f : 0.0f;")
+                E.raw(f"    passbits |= (qh{d} == q[{d}]) ? {1 << d}u : 0u;")
             else:
                 E.raw(f"    const float qh{d} = q[{d}];")
             if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS) and float(kin.rot_sign[i]) != 0.0:
@@ -284,10 +295,12 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             R[i] = A
         # ---------------- outputs that depend only on FK ----------------
         pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
+        E.raw(f"    PosFlusher<{3 * L}> flush{{nullptr, nullptr, lane, PosFlusher<{3 * L}>::NCHUNK}};")
         E.raw("    if (A.link_pos) {")
         E.raw(f"        const float pv[{3 * L}] = {{{pos_list}}};")
-        E.raw(f"        spec_store_rows<{3 * L}>(A.link_pos, base, rows, lane, lds, pv);")
+        E.raw(f"        flush = spec_stage_rows<{3 * L}>(A.link_pos, base, rows, lane, lds, pv);")
         E.raw("    }")
+        E.raw("    flush(); flush();")
         # ---------------- objectives ----------------
         E.raw("    float cost = 0.0f;")
         for i in adj_links:
@@ -298,7 +311,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw("    float gx[NL], gy[NL], gz[NL];")
             E.raw("#pragma unroll")
             E.raw("    for (int l = 0; l < NL; ++l) { gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }")
-            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz);")
+            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, flush);")
             E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
             for j, i in enumerate(tmpl.obj_links):
                 E.raw(f"    tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
@@ -324,6 +337,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw(f"        tb{ee}_0 = fmaf(A.w.w_ee, gt[0], tb{ee}_0); tb{ee}_1 = fmaf(A.w.w_ee, gt[1], tb{ee}_1); "
                   f"tb{ee}_2 = fmaf(A.w.w_ee, gt[2], tb{ee}_2);")
             E.raw("    }")
+        E.raw("    flush();")
         E.raw("    if (lane < rows) A.cost[base + lane] = cost;")
         E.raw("    if (A.cost_sum) {")
         E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
@@ -336,6 +350,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         for p in range(L - 1, 0, -1):
             i = int(kin.order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
             E.raw(f"    // reverse: link {i}")
+            if p % 2 == 0:
+                E.raw("    flush();")
             if i in adj_links:
                 tb = [S(1.0, f"tb{i}_{k}") for k in range(3)]
                 own_T = E.cross(t[i], tb)
@@ -356,7 +372,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 elif jt == JOINT_PRISMATIC:
                     dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
                     g = E.dot(dirw, F[i])
-                    gq_expr[d] = E.lincomb([(passv[i], E.named(g))])
+                    gq_expr[d] = masked(E, i, d, g)
                 else:
                     sg = float(kin.rot_sign[i])
                     if sg == 0.0:
@@ -367,9 +383,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                         cr = E.cross(t[i], F[i])
                         diff = [E.lincomb([(T[i][k], ONE), (cr[k], S(-1.0))]) for k in range(3)]
                         g = E.dot(z, diff)
-                        gq_expr[d] = E.lincomb([(passv[i], E.named(S(g.c * sg, g.n)))])
+                        gq_expr[d] = masked(E, i, d, S(g.c * sg, g.n))
             F[par] = [E.add(F[par][k], F[i][k]) for k in range(3)]
             T[par] = [E.add(T[par][k], T[i][k]) for k in range(3)]
+        E.raw("    flush.flush();")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D>(A.gq, base, rows, lane, lds, gv);")
         E.raw("}")

@@ -132,6 +132,7 @@ __device__ __forceinline__ F4 load_f4_uniform(const float4* p, int i) {      // 
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float trk_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ float trk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float trk_rsq(float x) { return __builtin_amdgcn_rsqf(x); }     // v_rsq_f32, 1 ulp
 
 // sin and cos of x together.  Cody-Waite reduction by pi (two fmas): x = k*pi + r, r in [-pi/2, pi/2], so
 // sin x = (-1)^k sin r and cos x = (-1)^k cos r -- a sign flip (one shift, two xors), no sin/cos swap.
@@ -352,10 +353,14 @@ __device__ __forceinline__ float object_sdf(const DevCostHdr& C, int o, float x,
 // min over the whole scene (merged spheres, then objects with non-sphere primitives / the grid) of the signed
 // distance at NL points held in registers, with the world-frame gradient of the arg-min primitive.
 // = min_o sdf_o(p)  of distance_fields.py:307-316 + :121-122 (max over objects of margin - sdf).
-template <int NL>
+struct NoTick { __device__ __forceinline__ void operator()() const {} };
+
+// `tick` is called once per trip of the sphere loop: the fused kernel uses it to trickle its link-position
+// stores out between the arithmetic instead of issuing them as one burst (see spec_common: PosFlusher).
+template <int NL, class Tick = NoTick>
 __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (&px)[NL], const float (&py)[NL],
                                               const float (&pz)[NL], float (&s)[NL], float (&gx)[NL], float (&gy)[NL],
-                                              float (&gz)[NL]) {
+                                              float (&gz)[NL], Tick&& tick = Tick()) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) { s[l] = __builtin_inff(); gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }
     if (C.n_spheres > 0) {
@@ -370,13 +375,50 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                 float bk[NL];
 #pragma unroll
                 for (int l = 0; l < NL; ++l) bk[l] = __builtin_inff();
-                for (int k = 0; k < C.n_spheres; ++k) {
-                    const F4 S = load_f4_uniform(C.spheres_sel, k);   // wave-uniform: scalar load
+                // two spheres per trip (one v_min3 per point), points in pairs (v_pk_fma_f32: two points per issue)
+                constexpr int NP = NL / 2;
+                trk_f2 qx[NP > 0 ? NP : 1], qy[NP > 0 ? NP : 1], qz[NP > 0 ? NP : 1];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    qx[j] = trk_f2{px[2 * j], px[2 * j + 1]}; qy[j] = trk_f2{py[2 * j], py[2 * j + 1]};
+                    qz[j] = trk_f2{pz[2 * j], pz[2 * j + 1]};
+                }
+                const int n2 = C.n_spheres & ~1;
+                // software-pipelined scalar loads: the next pair is in flight while the current one is ranked
+                // (every wave of the chip is in this loop at the same time, so nobody else hides the K$ latency)
+                F4 S = load_f4_uniform(C.spheres_sel, 0), T = load_f4_uniform(C.spheres_sel, n2 > 1 ? 1 : 0);
+                for (int k = 0; k < n2; k += 2) {
+                    const int kn = k + 2 < n2 ? k + 2 : k;
+                    const F4 Sn = load_f4_uniform(C.spheres_sel, kn), Tn = load_f4_uniform(C.spheres_sel, kn + 1);
+                    tick();
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        const trk_f2 ts = __builtin_elementwise_fma(qx[j], trk_f2{S.x, S.x}, __builtin_elementwise_fma(qy[j], trk_f2{S.y, S.y}, __builtin_elementwise_fma(qz[j], trk_f2{S.z, S.z}, trk_f2{S.w, S.w})));
+                        const trk_f2 tt = __builtin_elementwise_fma(qx[j], trk_f2{T.x, T.x}, __builtin_elementwise_fma(qy[j], trk_f2{T.y, T.y}, __builtin_elementwise_fma(qz[j], trk_f2{T.z, T.z}, trk_f2{T.w, T.w})));
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float ks = __uint_as_float((__float_as_uint(h ? ts.y : ts.x) & ~15u) | (unsigned)k);
+                            const float kt = __uint_as_float((__float_as_uint(h ? tt.y : tt.x) & ~15u) | (unsigned)(k + 1));
+                            bk[2 * j + h] = __builtin_fminf(bk[2 * j + h], __builtin_fminf(ks, kt));
+                        }
+                    }
+                    if (NL & 1) {
+                        constexpr int l = NL - 1;
+                        const float ts = fmaf(px[l], S.x, fmaf(py[l], S.y, fmaf(pz[l], S.z, S.w)));
+                        const float tt = fmaf(px[l], T.x, fmaf(py[l], T.y, fmaf(pz[l], T.z, T.w)));
+                        const float ks = __uint_as_float((__float_as_uint(ts) & ~15u) | (unsigned)k);
+                        const float kt = __uint_as_float((__float_as_uint(tt) & ~15u) | (unsigned)(k + 1));
+                        bk[l] = __builtin_fminf(bk[l], __builtin_fminf(ks, kt));
+                    }
+                    S = Sn; T = Tn;
+                }
+                if (C.n_spheres & 1) {
+                    const int k = C.n_spheres - 1;
+                    const F4 S = load_f4_uniform(C.spheres_sel, k);
 #pragma unroll
                     for (int l = 0; l < NL; ++l) {
                         const float t = fmaf(px[l], S.x, fmaf(py[l], S.y, fmaf(pz[l], S.z, S.w)));
-                        const float key = __uint_as_float((__float_as_uint(t) & ~15u) | (unsigned)k);
-                        bk[l] = __builtin_fminf(bk[l], key);
+                        bk[l] = __builtin_fminf(bk[l], __uint_as_float((__float_as_uint(t) & ~15u) | (unsigned)k));
                     }
                 }
 #pragma unroll
@@ -400,9 +442,9 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
             for (int l = 0; l < NL; ++l) {
                 const float4 S = C.spheres[bi[l]];          // per-lane gather of the winning centre (L1/L2 hit)
                 const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
-                const float nrm = trk_sqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-                const float inv = nrm > 0.0f ? trk_rcp(nrm) : 0.0f;
-                s[l] = nrm - C.sphere_r; gx[l] = dx * inv; gy[l] = dy * inv; gz[l] = dz * inv;
+                const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                const float inv = n2 > 0.0f ? trk_rsq(n2) : 0.0f;     // one transcendental per point
+                s[l] = fmaf(n2, inv, -C.sphere_r); gx[l] = dx * inv; gy[l] = dy * inv; gz[l] = dz * inv;
             }
         } else {
             for (int k = 0; k < C.n_spheres; ++k) {
@@ -469,7 +511,8 @@ __device__ __forceinline__ float ee_cost_eval(const float* R, const float* t, co
         for (int c = 0; c < 3; ++c) tr = fmaf(R[3 * r + c], Ht[4 * r + c], tr);
     const float dx = t[0] - Ht[3], dy = t[1] - Ht[7], dz = t[2] - Ht[11];
     const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-    const float nrm = trk_sqrt(n2);
+    const float rs = n2 > 0.0f ? trk_rsq(n2) : 0.0f;
+    const float nrm = n2 * rs;
     float d = 0.0f;
     if (w_rot > 0.0f) d = fmaf(w_rot, 1.0f - (tr - 1.0f) * 0.5f, d);
     if (w_pos > 0.0f) d = fmaf(w_pos, nrm, d);
@@ -479,7 +522,7 @@ __device__ __forceinline__ float ee_cost_eval(const float* R, const float* t, co
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) gR[3 * r + c] = kr * Ht[4 * r + c];
-    const float kp = (w_pos > 0.0f && nrm > 0.0f) ? sc * w_pos * trk_rcp(nrm) : 0.0f;
+    const float kp = w_pos > 0.0f ? sc * w_pos * rs : 0.0f;
     gt[0] = kp * dx; gt[1] = kp * dy; gt[2] = kp * dz;
     return square ? d * d : d;
 }

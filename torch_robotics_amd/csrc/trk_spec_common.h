@@ -90,29 +90,49 @@ __device__ __forceinline__ void spec_store_gq(float* __restrict__ gq, int64_t ba
     }
 }
 
-// link positions: lane writes its 3L floats at stride 3L (odd or not: 3L = 33 for Panda -> conflict-free),
-// then the wave streams the 64*3L contiguous floats out with 16-byte stores
-template <int W>   // W = 3 * L floats per sample
-__device__ __forceinline__ void spec_store_rows(float* __restrict__ out, int64_t base, int rows, int lane,
-                                                float* lds, const float (&v)[W]) {
+// Link positions: each lane writes its 3L floats at stride 3L (33 for Panda: conflict-free), then the wave
+// streams the 64*3L contiguous floats out in 1 KiB chunks (one ds_read_b128 + one global_store_dwordx4 per
+// lane and chunk).  The chunks are NOT issued back to back: every wave of the chip reaches this point at the same
+// time, and 16 waves x 8.25 KiB per CU saturate the store path for ~6 us during which nothing computes.
+// `tick()` issues one chunk; the kernel calls it between blocks of arithmetic so the 34.6 MB trickle out at
+// roughly the rate HBM absorbs them.
+template <int W>
+struct PosFlusher {
+    static constexpr int NV = W * TRK_WAVE / 4;                  // float4 chunks per wave
+    static constexpr int NCHUNK = (NV + TRK_WAVE - 1) / TRK_WAVE;
+    const float4* src4;
+    float4* dst4;
+    int lane;
+    int next;                                                    // wave-uniform
+    __device__ __forceinline__ void operator()() {
+        if (next < NCHUNK) {
+            const int k = lane + TRK_WAVE * next;
+            if (k < NV) dst4[k] = src4[k];
+            ++next;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        while (next < NCHUNK) (*this)();
+    }
+};
+
+// stage the wave's rows in LDS; returns a flusher (fast path) or writes everything now (ragged / unaligned tail)
+template <int W>
+__device__ __forceinline__ PosFlusher<W> spec_stage_rows(float* __restrict__ out, int64_t base, int rows, int lane,
+                                                         float* lds, const float (&v)[W]) {
     spec_wave_sync();
 #pragma unroll
     for (int j = 0; j < W; ++j) lds[lane * W + j] = v[j];
     spec_wave_sync();
     float* dst = out + base * W;
-    if (rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-        constexpr int NV = W * TRK_WAVE / 4;                     // float4 chunks
-        const float4* src4 = reinterpret_cast<const float4*>(lds);
-        float4* dst4 = reinterpret_cast<float4*>(dst);
-#pragma unroll
-        for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
-            const int k = lane + TRK_WAVE * j;
-            if (k < NV) dst4[k] = src4[k];
-        }
-    } else {
+    PosFlusher<W> f{reinterpret_cast<const float4*>(lds), reinterpret_cast<float4*>(dst), lane, 0};
+    const bool fast = rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    if (!fast) {
         const int count = rows * W;
         for (int k = lane; k < count; k += TRK_WAVE) dst[k] = lds[k];
+        f.next = PosFlusher<W>::NCHUNK;
     }
+    return f;
 }
 
 __device__ __forceinline__ float spec_wave_sum(float v) {
@@ -125,12 +145,12 @@ __device__ __forceinline__ float spec_wave_sum(float v) {
 // collision objectives on NL link points held in registers.  Adds w * cost to `cost` and
 // w * d cost / d p to (gx, gy, gz) (accumulating).  Margins are C.obj_link_margin[0..NL) in baked order.
 // ---------------------------------------------------------------------------------------------------------
-template <int NL>
+template <int NL, class Tick>
 __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w, const float (&px)[NL],
                                                    const float (&py)[NL], const float (&pz)[NL], float (&gx)[NL],
-                                                   float (&gy)[NL], float (&gz)[NL]) {
+                                                   float (&gy)[NL], float (&gz)[NL], Tick& tick) {
     float s[NL], ax[NL], ay[NL], az[NL];
-    scene_min_sdf<NL>(C, px, py, pz, s, ax, ay, az);
+    scene_min_sdf<NL>(C, px, py, pz, s, ax, ay, az, tick);
     float cost = 0.0f;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -155,8 +175,9 @@ __device__ __forceinline__ float spec_self_pair(float w, float margin, float ax,
                                                 float& gbz) {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
     const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-    const float nrm = trk_sqrt(n2);
-    const float inv = nrm > 0.0f ? w * trk_rcp(nrm) : 0.0f;
+    const float rs = n2 > 0.0f ? trk_rsq(n2) : 0.0f;              // one transcendental: 1/||d|| (0 at d = 0, like torch.norm's backward)
+    const float nrm = n2 * rs;
+    const float inv = w * rs;
     const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
     gax -= ux; gay -= uy; gaz -= uz;
     gbx += ux; gby += uy; gbz += uz;
