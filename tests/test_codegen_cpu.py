@@ -19,7 +19,7 @@ def test_generated_source_is_deterministic_and_folded():
     # structural zeros are folded: the identity-base variant needs far fewer multiplies than 11 dense composes
     body = src.split("k_rollout_bg")[0]
     assert len(re.findall(r"fmaf\(|\*", body)) < 700
-    assert "trk_sincos(qh6" in body and "pass3" in body
+    assert "trk_sincos(qh6" in body and "passbits" in body and "trk_sincos2(qh0, qh1" in body
 
 
 def test_model_hash_distinguishes_models():
