@@ -153,6 +153,11 @@ int trk_fk_jacobian(const TrkModel* model, const float* q, const float* qd, int6
                     float* pos, float* quat_wxyz, float* lin_jac, float* ang_jac,
                     float* vel_lin, float* vel_ang, trk_stream_t stream);
 
+/* reference: DifferentiableTree.compute_analytical_jacobian_all_links robot_tree.py:250-265 (autograd Jacobian of
+ * [pos(3), quat_wxyz(4)] of every link through the stateless FK and rotation_matrix_to_q).
+ * q [N,D] -> J [N, L, 7, D]. */
+int trk_fk_analytic_jacobian(const TrkModel* model, const float* q, int64_t n, float* J, trk_stream_t stream);
+
 /* reference: rotation_matrix_to_q quaternion.py:135-166 (via link_quat_from_link_tensor
  * geometrics/utils.py:341-344).  R: n matrices, `stride` floats apart, 3x3 block with row
  * pitch `row_pitch` (9/3 for packed rotations, 16/4 for 4x4 transforms).  -> quat_wxyz [n,4]. */

@@ -229,6 +229,14 @@ def jacobian_golden(name, tree, links, seed):
     np.savez_compressed(GOLD / f"jac_{name}.npz", **out)
 
 
+def analytic_jacobian_golden(name, tree, seed):
+    """A16: compute_analytical_jacobian_all_links (autograd Jacobian of [pos, quat_wxyz] of every link)."""
+    gen = torch.Generator().manual_seed(seed)
+    q = sample_q(tree, 12, gen, 0.15)            # some samples beyond the limits: clamped joints give zero columns
+    J = tree.compute_analytical_jacobian_all_links(q)
+    np.savez_compressed(GOLD / f"ajac_{name}.npz", q=q.numpy(), J=J.numpy())
+
+
 def quat_golden():
     gen = torch.Generator().manual_seed(77)
     # random rotations incl. near-180deg cases to hit every branch of the 4-candidate rule
@@ -434,6 +442,9 @@ def main():
     jacobian_golden("panda_arm_no_gripper", trees["panda_arm_no_gripper"], ["ee_link", "panda_link5", "panda_link2"], 31)
     jacobian_golden("ur10", trees["ur10"], [trees["ur10"].get_link_names()[-1], trees["ur10"].get_link_names()[4]], 32)
     jacobian_golden("iiwa7", trees["iiwa7"], [trees["iiwa7"].get_link_names()[-1]], 33)
+    analytic_jacobian_golden("panda_arm_no_gripper", trees["panda_arm_no_gripper"], 41)
+    analytic_jacobian_golden("panda_arm_hand", trees["panda_arm_hand"], 42)
+    analytic_jacobian_golden("allegro_hand", trees["allegro_hand"], 43)
     quat_golden()
     cost_goldens()
     misc_goldens()

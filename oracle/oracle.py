@@ -108,6 +108,14 @@ class Oracle:
             _p(pos), _p(quat), _p(lin), _p(ang), _p(vl), _p(va))
         return pos, quat, lin, ang, vl, va
 
+    def analytic_jacobian(self, q, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        D, L = self.model.n_dofs, self.model.n_links
+        q = np.ascontiguousarray(q, npdt).reshape(-1, D)
+        J = np.empty((q.shape[0], L, 7, D), npdt)
+        getattr(lib(), "orc_fk_analytic_jacobian" + suf)(C.byref(self.kd), _p(q), C.c_int64(q.shape[0]), _p(J))
+        return J
+
     @staticmethod
     def rotmat_to_quat(R, prec="f32"):
         npdt, _, suf = _dt(prec)

@@ -57,6 +57,9 @@ def test_geometric_jacobian_api():
     assert np.abs(H.cpu().numpy() - gold("fk_panda_arm_no_gripper")["H_in"]).max() < TOL_H
     quat_all = tra.kinematics.link_quat_from_link_tensor(H)
     assert quat_all.shape == (32, 11, 4)
+    ga = gold("ajac_panda_arm_no_gripper")
+    Ja = tree.compute_analytical_jacobian_all_links(dev(ga["q"]))
+    assert Ja.shape == (12, 11, 7, 7) and np.abs(Ja.cpu().numpy() - ga["J"]).max() < 3e-6
 
 
 def test_update_base_pose():

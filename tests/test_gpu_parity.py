@@ -342,3 +342,21 @@ def test_specialized_rollout_kernel(ops, oracle_lib, env):
     _, c, gq = ops.rollout_cost_grad(h, cm2, (0, 1, 1, 0), dev(q))
     _, c64, g64 = o2.rollout(q.astype(np.float64), (0, 1, 1, 0), "f64")
     assert rel_err(c.cpu().numpy(), c64) < TOL_C and rel_err(gq.cpu().numpy(), g64) < TOL_G
+
+
+@pytest.mark.parametrize("robot", ["panda_arm_no_gripper", "panda_arm_hand", "allegro_hand"])
+def test_analytic_jacobian_all_links(ops, oracle_lib, robot):
+    """A16 vs the reference's autograd Jacobian (golden) and vs the fp64 oracle on ragged fresh inputs."""
+    g = gold(f"ajac_{robot}")
+    m = model(robot)
+    h, o = ops.ModelHandle(m), oracle_lib.Oracle(m)
+    J = ops.fk_analytic_jacobian(h, dev(g["q"])).cpu().numpy()
+    assert J.shape == g["J"].shape
+    assert np.abs(J - g["J"]).max() < 3e-6
+    q = np.random.default_rng(2).uniform(-2.5, 2.5, (131, m.n_dofs)).astype(np.float32)
+    J = ops.fk_analytic_jacobian(h, dev(q)).cpu().numpy()
+    J64 = o.analytic_jacobian(q.astype(np.float64), "f64")
+    # quaternion candidate switches are discontinuous: compare where fp32 and fp64 pick the same one
+    bad = np.abs(J - J64).max(axis=(2, 3)) > 1e-4
+    assert bad.mean() < 0.01
+    assert np.abs((J - J64)[~bad]).max() < 5e-6

@@ -70,6 +70,7 @@ struct TrkModel {
     std::vector<int32_t> joint_list_idx;   // by link
     DevLink* d_links = nullptr;
     int32_t* d_fin = nullptr;
+    int32_t* d_dofs = nullptr;             // [D] {pos, subtree end, joint type, pad}
     bool unsupported = false;
     const SpecEntry* spec = nullptr;     // model-specialised fused kernel, if one was built for these tables
     bool spec_enabled = true;
@@ -147,13 +148,22 @@ int trk_model_create(const TrkKinModelDesc* d, TrkModel** out) {
         k.fin_end = (int32_t)m->fin.size();
     }
     if (m->fin.empty()) m->fin.push_back(0);
+    std::vector<int32_t> dofs(4 * (D > 0 ? D : 1), 0);
+    for (int p = 0; p < L; ++p)
+        if (m->links[p].dof >= 0) {
+            int32_t* r = dofs.data() + 4 * m->links[p].dof;
+            r[0] = p; r[1] = d->subtree_end[p]; r[2] = m->links[p].type; r[3] = 0;
+        }
     hipError_t e = hipMalloc(&m->d_links, sizeof(DevLink) * L);
     if (e == hipSuccess) e = hipMalloc(&m->d_fin, sizeof(int32_t) * m->fin.size());
+    if (e == hipSuccess) e = hipMalloc(&m->d_dofs, sizeof(int32_t) * dofs.size());
+    if (e == hipSuccess) e = hipMemcpy(m->d_dofs, dofs.data(), sizeof(int32_t) * dofs.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_links, m->links.data(), sizeof(DevLink) * L, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->d_fin, m->fin.data(), sizeof(int32_t) * m->fin.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (m->d_links) (void)hipFree(m->d_links);
         if (m->d_fin) (void)hipFree(m->d_fin);
+        if (m->d_dofs) (void)hipFree(m->d_dofs);
         delete m;
         return hip_fail(e, "trk_model_create: device allocation/copy");
     }
@@ -166,6 +176,7 @@ void trk_model_destroy(TrkModel* m) {
     if (!m) return;
     if (m->d_links) (void)hipFree(m->d_links);
     if (m->d_fin) (void)hipFree(m->d_fin);
+    if (m->d_dofs) (void)hipFree(m->d_dofs);
     delete m;
 }
 
@@ -261,6 +272,16 @@ int trk_fk_jacobian(const TrkModel* m, const float* q, const float* qd, int64_t 
     if (n == 0) return TRK_OK;
     trk_launch_fk_jacobian(m->hdr, m->d_links, q, qd, n, link, m->joint_list_idx[link], pos, quat, lin_jac, ang_jac,
                            vel_lin, vel_ang, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_fk_analytic_jacobian(const TrkModel* m, const float* q, int64_t n, float* J, trk_stream_t stream) {
+    int rc = check_model(m, "trk_fk_analytic_jacobian");
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!J || (!q && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_analytic_jacobian: bad q/J/n");
+    if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    trk_launch_fk_analytic_jacobian(m->hdr, m->d_links, m->d_dofs, q, n, J, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }

@@ -641,6 +641,112 @@ k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, const float* _
     }
 }
 
+// ============================================================================================
+// compute_analytical_jacobian_all_links (robot_tree.py:250-265): J [N, L, 7, D] = d [pos, quat_wxyz] / d q of every
+// link.  The reference runs autograd 7L times; here every joint leaves a record (omega = pass*sign*z_j, p_j) in LDS
+// as the walk passes it, and each link combines the records of its ancestors (pre-order range test):
+//   d p_i = omega x (p_i - p_j)   |   prismatic: pass * R_parent axis
+//   d R_i = [omega]x R_i  ->  d quat through the selected candidate of rotation_matrix_to_q (quaternion.py:135-166)
+// LDS: q | slots | joint records [6][D][64] | one link's 7xD block per lane (written out as contiguous 7D-float runs).
+// ============================================================================================
+struct DofRec { int32_t pos, end, type, _pad; };   // pre-order position of the joint's link, end of its subtree
+
+__device__ __forceinline__ void quat_jvp(const float* m, const float* dm, float* dq) {
+    const float a[4] = {1.0f + m[0] + m[4] + m[8], 1.0f + m[0] - m[4] - m[8], 1.0f - m[0] + m[4] - m[8], 1.0f - m[0] - m[4] + m[8]};
+    const float da[4] = {dm[0] + dm[4] + dm[8], dm[0] - dm[4] - dm[8], -dm[0] + dm[4] - dm[8], -dm[0] - dm[4] + dm[8]};
+    float qa[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qa[k] = a[k] > 0.0f ? sqrtf(a[k]) : 0.0f;
+    int b = 0; float qb = qa[0], ab = a[0], dab = da[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (qa[k] > qb) { qb = qa[k]; ab = a[k]; dab = da[k]; b = k; }
+    const bool posa = ab > 0.0f;
+    ab = posa ? ab : 0.0f; dab = posa ? dab : 0.0f;
+    float N[4], dN[4];
+    if (b == 0)      { N[0] = ab; N[1] = m[7] - m[5]; N[2] = m[2] - m[6]; N[3] = m[3] - m[1];
+                       dN[0] = dab; dN[1] = dm[7] - dm[5]; dN[2] = dm[2] - dm[6]; dN[3] = dm[3] - dm[1]; }
+    else if (b == 1) { N[0] = m[7] - m[5]; N[1] = ab; N[2] = m[3] + m[1]; N[3] = m[2] + m[6];
+                       dN[0] = dm[7] - dm[5]; dN[1] = dab; dN[2] = dm[3] + dm[1]; dN[3] = dm[2] + dm[6]; }
+    else if (b == 2) { N[0] = m[2] - m[6]; N[1] = m[3] + m[1]; N[2] = ab; N[3] = m[5] + m[7];
+                       dN[0] = dm[2] - dm[6]; dN[1] = dm[3] + dm[1]; dN[2] = dab; dN[3] = dm[5] + dm[7]; }
+    else             { N[0] = m[3] - m[1]; N[1] = m[6] + m[2]; N[2] = m[7] + m[5]; N[3] = ab;
+                       dN[0] = dm[3] - dm[1]; dN[1] = dm[6] + dm[2]; dN[2] = dm[7] + dm[5]; dN[3] = dab; }
+    const float den = 2.0f * fmaxf(qb, 0.1f);
+    const float dden = (qb > 0.1f && posa) ? dab / qb : 0.0f;
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dq[k] = dN[k] * inv - N[k] * dden * inv * inv;
+}
+
+__global__ void __launch_bounds__(TRK_WAVE)
+k_fk_analytic_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, const DofRec* __restrict__ dofs,
+                       const float* __restrict__ q, int64_t n, float* __restrict__ J) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int D = hdr.n_dofs, L = hdr.n_links;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    const int W = 7 * D, rs = W | 1, js = D * TRK_WAVE;
+    float* qs = smem;
+    float* slots = qs + TRK_WAVE * D;
+    float* jrec = slots + hdr.n_slots * 12 * TRK_WAVE;      // [6][D][64]
+    float* tile = jrec + 6 * D * TRK_WAVE;                  // [64][rs]
+    load_tile(qs, q, base * D, (int64_t)rows * D, lane);
+    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
+    __syncthreads();
+    Pose cur, par;
+    for (int p = 0; p < L; ++p) {
+        const DevLink& Lk = links[p];
+        const float pass = walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
+        if (Lk.dof >= 0) {
+            float* j = jrec + Lk.dof * TRK_WAVE + lane;
+            if (Lk.type == TRK_JOINT_PRISMATIC) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    j[r * js] = pass * fmaf(par.r[3 * r], Lk.axis[0], fmaf(par.r[3 * r + 1], Lk.axis[1], par.r[3 * r + 2] * Lk.axis[2]));
+            } else {
+                const float sg = pass * Lk.rot_sign;
+                const int ax = Lk.rot_axis;
+                j[0] = sg * (ax == 0 ? cur.r[0] : (ax == 1 ? cur.r[1] : cur.r[2]));
+                j[js] = sg * (ax == 0 ? cur.r[3] : (ax == 1 ? cur.r[4] : cur.r[5]));
+                j[2 * js] = sg * (ax == 0 ? cur.r[6] : (ax == 1 ? cur.r[7] : cur.r[8]));
+            }
+            j[3 * js] = cur.t[0]; j[4 * js] = cur.t[1]; j[5 * js] = cur.t[2];
+        }
+        float* row = tile + lane * rs;
+        for (int d = 0; d < D; ++d) {
+            const DofRec T = dofs[d];
+            float dp[3] = {0.0f, 0.0f, 0.0f}, dq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (T.pos <= p && p < T.end) {                  // joint d is on the path root..this link
+                const float* j = jrec + d * TRK_WAVE + lane;
+                const float w0 = j[0], w1 = j[js], w2 = j[2 * js];
+                if (T.type == TRK_JOINT_PRISMATIC) {
+                    dp[0] = w0; dp[1] = w1; dp[2] = w2;    // rotation unchanged: d quat = 0
+                } else {
+                    const float r0 = cur.t[0] - j[3 * js], r1 = cur.t[1] - j[4 * js], r2 = cur.t[2] - j[5 * js];
+                    dp[0] = w1 * r2 - w2 * r1; dp[1] = w2 * r0 - w0 * r2; dp[2] = w0 * r1 - w1 * r0;
+                    float dR[9];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v0 = cur.r[c], v1 = cur.r[3 + c], v2 = cur.r[6 + c];
+                        dR[c] = w1 * v2 - w2 * v1; dR[3 + c] = w2 * v0 - w0 * v2; dR[6 + c] = w0 * v1 - w1 * v0;
+                    }
+                    quat_jvp(cur.r, dR, dq);
+                }
+            }
+            row[d] = dp[0]; row[D + d] = dp[1]; row[2 * D + d] = dp[2];
+            row[3 * D + d] = dq[0]; row[4 * D + d] = dq[1]; row[5 * D + d] = dq[2]; row[6 * D + d] = dq[3];
+        }
+        __syncthreads();
+        // sample r of the wave owns the contiguous run J[base + r][link][:, :] of 7D floats
+        for (int r = 0; r < rows; ++r) {
+            float* dst = J + ((base + r) * L + Lk.link) * W;
+            for (int k = lane; k < W; k += TRK_WAVE) dst[k] = tile[r * rs + k];
+        }
+        __syncthreads();
+    }
+}
+
 // rotation_matrix_to_q quaternion.py:135-166
 __global__ void __launch_bounds__(256)
 k_rotmat_to_quat(const float* __restrict__ R, int64_t n, int stride, int pitch, float* __restrict__ out) {
@@ -784,6 +890,14 @@ void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links, const 
     hipLaunchKernelGGL(k_fk_jacobian, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, q, qd, n, link, link_joint_idx, pos, quat, lin_jac, ang_jac, vel_lin, vel_ang);
 }
 
+void trk_launch_fk_analytic_jacobian(const DevModelHdr& hdr, const DevLink* links, const void* dofs, const float* q,
+                                     int64_t n, float* J, hipStream_t st) {
+    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 7 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
+                                  (size_t)TRK_WAVE * ((7 * hdr.n_dofs) | 1));
+    hipLaunchKernelGGL(k_fk_analytic_jacobian, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links,
+                       static_cast<const DofRec*>(dofs), q, n, J);
+}
+
 void trk_launch_rotmat_to_quat(const float* R, int64_t n, int stride, int pitch, float* out, hipStream_t st) {
     hipLaunchKernelGGL(k_rotmat_to_quat, dim3(grid_for(n, 256)), dim3(256), 0, st, R, n, stride, pitch, out);
 }
@@ -809,6 +923,7 @@ int trk_kernels_init(void) {
 #define TRK_SET(k) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
     TRK_SET(k_fk_forward<0>); TRK_SET(k_fk_forward<1>); TRK_SET(k_fk_backward<0>); TRK_SET(k_fk_backward<1>);
     TRK_SET(k_cost_fields); TRK_SET(k_collision_fields); TRK_SET(k_rollout_generic); TRK_SET(k_fk_jacobian);
+    TRK_SET(k_fk_analytic_jacobian);
 #undef TRK_SET
     return e == hipSuccess ? 0 : -1;
 }

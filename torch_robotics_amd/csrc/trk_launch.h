@@ -18,6 +18,8 @@ void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, co
 void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links, const float* q, const float* qd, int64_t n,
                             int link, int link_joint_idx, float* pos, float* quat, float* lin_jac, float* ang_jac,
                             float* vel_lin, float* vel_ang, hipStream_t st);
+void trk_launch_fk_analytic_jacobian(const DevModelHdr& hdr, const DevLink* links, const void* dofs, const float* q,
+                                     int64_t n, float* J, hipStream_t st);
 void trk_launch_rotmat_to_quat(const float* R, int64_t n, int stride, int pitch, float* out, hipStream_t st);
 void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const float* lo, const float* hi, float* sdf,
                                 float* grad, hipStream_t st);

@@ -142,11 +142,13 @@ class DifferentiableTree(torch.nn.Module):
         return self._stateful(q, qd, link_name)
 
     def compute_analytical_jacobian_all_links(self, q: torch.Tensor):
-        """(N, L, 7, D) Jacobian of [pos, quat_wxyz] of every link (robot_tree.py:250-265)."""
-        raise NotImplementedError(
-            "compute_analytical_jacobian_all_links has no HIP kernel yet (SURVEY.md 8a row A16); "
-            "use compute_forward_kinematics_and_geometric_jacobian or autograd through "
-            "compute_forward_kinematics_all_links")
+        """(N, L, 7, D) Jacobian of [pos, quat_wxyz] of every link (robot_tree.py:250-265): one kernel launch
+        instead of 7L autograd traversals."""
+        self._check_supported()
+        if q.ndim == 1:
+            q = q.unsqueeze(0)
+        assert q.ndim == 2 and q.shape[1] == self._n_dofs
+        return ops.fk_analytic_jacobian(self._handle, q.detach())
 
     # -- model queries ----------------------------------------------------------------------------
     def get_joint_limits(self) -> List[Optional[Dict[str, float]]]:

@@ -175,6 +175,16 @@ def fk_jacobian(model: ModelHandle, q: torch.Tensor, qd: Optional[torch.Tensor],
     return (pos, quat, lin, ang, vl, va) if want_vel else (pos, quat, lin, ang)
 
 
+def fk_analytic_jacobian(model: ModelHandle, q: torch.Tensor) -> torch.Tensor:
+    """(N, L, 7, D) Jacobian of [pos, quat_wxyz] of every link."""
+    q = _dev_f32(q, "fk_analytic_jacobian(q)").reshape(-1, model.n_dofs)
+    n = q.shape[0]
+    J = torch.empty((n, model.n_links, 7, model.n_dofs), device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        check(lib().trk_fk_analytic_jacobian(model._h, q.data_ptr(), n, J.data_ptr(), _stream(q)), "trk_fk_analytic_jacobian")
+    return J
+
+
 def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
     """rotation_matrix_to_q on (..., 3, 3) rotations or (..., 4, 4) transforms -> (..., 4) wxyz."""
     R = _dev_f32(R, "rotmat_to_quat(R)")
