@@ -295,6 +295,12 @@ int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const T
                           float* link_pos_out, float* cost, float* gq, float* cost_block_sums,
                           trk_stream_t stream);
 
+/* reference: interpolate_traj_via_points trajectory/utils.py:37-50 (used by PlanningTask.get_trajs_collision_and_free
+ * tasks.py:234-251): x [T, H, D] -> out [T, (H-1)*n_interp, D], out[t, i*n+a] = x[t,i]*alpha[a] + x[t,i+1]*beta[a];
+ * alpha = linspace(0,1,n+2)[1:n+1], beta = 1 - alpha: DEVICE float[n_interp], computed by the caller. */
+int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, int32_t dim, int32_t n_interp,
+                               const float* alpha, const float* beta, float* out, trk_stream_t stream);
+
 /* Deterministic sum of n floats (fixed association order, one workgroup): x [n] -> out [1]. */
 int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream);
 

@@ -404,6 +404,34 @@ def cost_goldens():
     np.savez_compressed(GOLD / "rollout_panda.npz", **out)
 
 
+def trajs_goldens():
+    """8f rank 1: PlanningTask.get_trajs_collision_and_free (tasks.py:234-308) and the fraction / intensity stats."""
+    from torch_robotics.robots.robot_panda import RobotPanda
+    from torch_robotics.tasks.tasks import PlanningTask
+    from torch_robotics.environments.env_spheres_3d import EnvSpheres3D
+    robot = quiet(RobotPanda, tensor_args=TA)
+    task = PlanningTask(env=EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    gen = torch.Generator().manual_seed(77)
+    lo, hi = robot.q_min, robot.q_max
+    # 12 random-walk trajectories of 16 via points; some leave the joint limits, some hit obstacles
+    start = lo + torch.rand(12, 1, 7, generator=gen) * (hi - lo)
+    steps = 0.08 * torch.randn(12, 16, 7, generator=gen)
+    trajs = start + torch.cumsum(steps, dim=1)
+    trajs[:4] = torch.clamp(trajs[:4], lo + 0.05, hi - 0.05)
+    out = dict(trajs=trajs.numpy())
+    coll, coll_idx, free, free_idx, wp = task.get_trajs_collision_and_free(trajs, return_indices=True, num_interpolation=5)
+    out["waypoints_collisions"] = wp.numpy()
+    out["coll_idx"] = coll_idx.numpy(); out["free_idx"] = free_idx.numpy()
+    out["n_coll"] = np.int32(0 if coll is None else coll.shape[0]); out["n_free"] = np.int32(0 if free is None else free.shape[0])
+    out["fraction_free"] = np.float64(task.compute_fraction_free_trajs(trajs))
+    out["collision_intensity"] = np.float64(task.compute_collision_intensity_trajs(trajs))
+    out["success"] = np.int32(task.compute_success_free_trajs(trajs))
+    t4 = trajs.reshape(3, 4, 16, 7)
+    coll4, coll_idx4, free4, free_idx4, wp4 = task.get_trajs_collision_and_free(t4, return_indices=True)
+    out["waypoints_collisions4"] = wp4.numpy(); out["coll_idx4"] = coll_idx4.numpy(); out["free_idx4"] = free_idx4.numpy()
+    np.savez_compressed(GOLD / "trajs_panda.npz", **out)
+
+
 def misc_goldens():
     """finite differences / smoothness (A17) and via-point interpolation (8f rank 1)."""
     from torch_robotics.trajectory.utils import finite_difference_vector, interpolate_traj_via_points
@@ -447,6 +475,7 @@ def main():
     analytic_jacobian_golden("allegro_hand", trees["allegro_hand"], 43)
     quat_golden()
     cost_goldens()
+    trajs_goldens()
     misc_goldens()
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")

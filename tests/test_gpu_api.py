@@ -159,3 +159,26 @@ def test_fused_task_rollout():
     sd.sum().backward()
     assert sd.shape == (64,) and torch.isfinite(x.grad).all()
     assert np.abs(np.linalg.norm(x.grad.cpu().numpy(), axis=-1) - 1).max() < 1e-5
+
+
+def test_trajectory_validation_like_the_reference():
+    """8f rank 1: get_trajs_collision_and_free + stats (tasks.py:234-328) and interpolate_traj_via_points."""
+    g, gt = gold("trajs_panda"), gold("traj")
+    from torch_robotics_amd import ops
+    interp = ops.interpolate_traj_via_points(dev(gt["x"]), num_interpolation=5)
+    np.testing.assert_array_equal(interp.cpu().numpy(), gt["interp5"])          # bit-exact
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    trajs = dev(g["trajs"])
+    coll, coll_idx, free, free_idx, wp = task.get_trajs_collision_and_free(trajs, return_indices=True, num_interpolation=5)
+    np.testing.assert_array_equal(wp.cpu().numpy(), g["waypoints_collisions"])
+    np.testing.assert_array_equal(coll_idx.cpu().numpy(), g["coll_idx"])
+    np.testing.assert_array_equal(free_idx.cpu().numpy(), g["free_idx"])
+    assert coll.shape[0] == int(g["n_coll"]) and free.shape[0] == int(g["n_free"])
+    assert task.compute_fraction_free_trajs(trajs) == pytest.approx(float(g["fraction_free"]))
+    assert float(task.compute_collision_intensity_trajs(trajs)) == pytest.approx(float(g["collision_intensity"]))
+    assert task.compute_success_free_trajs(trajs) == int(g["success"])
+    c4, ci4, f4, fi4, wp4 = task.get_trajs_collision_and_free(trajs.reshape(3, 4, 16, 7), return_indices=True)
+    np.testing.assert_array_equal(wp4.cpu().numpy(), g["waypoints_collisions4"])
+    np.testing.assert_array_equal(ci4.cpu().numpy(), g["coll_idx4"])
+    np.testing.assert_array_equal(fi4.cpu().numpy(), g["free_idx4"])

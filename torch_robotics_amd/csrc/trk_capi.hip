@@ -530,6 +530,18 @@ int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRo
     return TRK_OK;
 }
 
+int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, int32_t dim, int32_t n_interp,
+                               const float* alpha, const float* beta, float* out, trk_stream_t stream) {
+    if (n_traj < 0 || horizon < 2 || dim < 1 || n_interp < 1 || !alpha || !beta || (n_traj > 0 && (!x || !out)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_interpolate_via_points: bad argument");
+    if (n_traj == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_interpolate(x, n_traj, horizon, dim, n_interp, alpha, beta, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
 int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream) {
     if (n < 0 || !out || (n > 0 && !x)) return fail(TRK_ERR_INVALID_ARG, "trk_reduce_sum: bad argument");
     int rc = ensure_init();

@@ -820,6 +820,26 @@ k_sdf_points(DevCostHdr C, const float* __restrict__ pts, int64_t n, float* __re
     }
 }
 
+// interpolate_traj_via_points (trajectory/utils.py:37-50): between consecutive via points i, i+1 emit
+// x_i * alpha_a + x_{i+1} * (1 - alpha_a) for the n interior alphas (the via points themselves are not emitted).
+// x [T, H, D] -> out [T, (H-1)*n, D]; alpha, beta = 1 - alpha: DEVICE [n] (host computes torch.linspace).
+// Two roundings per product and one for the sum, like the reference's `a * alpha + b * (1 - alpha)`.
+__global__ void __launch_bounds__(256)
+k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, int n_interp,
+                         const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ out) {
+    const int64_t total = T * (int64_t)(H - 1) * n_interp * D;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int d = (int)(idx % D);
+    const int64_t r = idx / D;
+    const int a = (int)(r % n_interp);
+    const int64_t s = r / n_interp;
+    const int i = (int)(s % (H - 1));
+    const int64_t t = s / (H - 1);
+    const float x0 = x[(t * H + i) * D + d], x1 = x[(t * H + i + 1) * D + d];
+    out[idx] = __fadd_rn(__fmul_rn(x0, alpha[a]), __fmul_rn(x1, beta[a]));
+}
+
 // deterministic sum: one 256-thread workgroup, fixed strides, LDS tree
 __global__ void __launch_bounds__(256)
 k_reduce_sum(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
@@ -907,6 +927,12 @@ void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const 
     const int64_t total = (int64_t)dims[0] * dims[1] * dims[2];
     hipLaunchKernelGGL(k_grid_precompute, dim3(grid_for(total, 256)), dim3(256), 0, st, C, dims[0], dims[1], dims[2],
                        lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], sdf, grad);
+}
+
+void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_interp, const float* alpha, const float* beta,
+                            float* out, hipStream_t st) {
+    const int64_t total = T * (int64_t)(H - 1) * n_interp * D;
+    hipLaunchKernelGGL(k_interpolate_via_points, dim3(grid_for(total, 256)), dim3(256), 0, st, x, T, H, D, n_interp, alpha, beta, out);
 }
 
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st) {

@@ -23,6 +23,8 @@ void trk_launch_fk_analytic_jacobian(const DevModelHdr& hdr, const DevLink* link
 void trk_launch_rotmat_to_quat(const float* R, int64_t n, int stride, int pitch, float* out, hipStream_t st);
 void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const float* lo, const float* hi, float* sdf,
                                 float* grad, hipStream_t st);
+void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_interp, const float* alpha, const float* beta,
+                            float* out, hipStream_t st);
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st);
 void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st);
 // raises the dynamic-LDS ceiling of every kernel once (gfx950: 160 KiB per workgroup)

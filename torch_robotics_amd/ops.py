@@ -271,6 +271,25 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
             gq.reshape(tuple(lead) + (D,)))
 
 
+def interpolate_traj_via_points(trajs: torch.Tensor, num_interpolation: int = 10) -> torch.Tensor:
+    """trajectory/utils.py:37-50: (..., H, D) -> (..., (H-1)*num_interpolation, D); identity for num_interpolation <= 0."""
+    if num_interpolation <= 0:
+        return trajs
+    assert trajs.ndim > 1
+    x = _dev_f32(trajs, "interpolate_traj_via_points(trajs)")
+    H, D = x.shape[-2:]
+    lead = x.shape[:-2]
+    T = int(np.prod(lead)) if len(lead) else 1
+    alpha = torch.linspace(0, 1, num_interpolation + 2, dtype=torch.float32)[1:num_interpolation + 1]
+    beta = 1 - alpha
+    alpha, beta = alpha.to(x.device), beta.to(x.device)
+    out = torch.empty(tuple(lead) + ((H - 1) * num_interpolation, D), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        check(lib().trk_interpolate_via_points(x.data_ptr(), T, H, D, int(num_interpolation), alpha.data_ptr(),
+                                               beta.data_ptr(), out.data_ptr(), _stream(x)), "trk_interpolate_via_points")
+    return out
+
+
 def reduce_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Deterministic sum of a float32 device vector (fixed association order)."""
     x = _dev_f32(x, "reduce_sum(x)").reshape(-1)

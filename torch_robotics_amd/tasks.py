@@ -122,3 +122,77 @@ class PlanningTask(Task):
             return cost
         _, cost, _ = ops.rollout_cost_grad(model, cm, w, q, want_pos=False)
         return cost
+
+    # ---------------------------------------------------------------------------------------------
+    # trajectory validation (tasks.py:234-328): same index bookkeeping as the reference; the arithmetic
+    # (via-point interpolation, FK, boolean collision fields) runs in the HIP kernels
+    # ---------------------------------------------------------------------------------------------
+    def get_trajs_collision_and_free(self, trajs, return_indices=False, num_interpolation=5):
+        assert trajs.ndim == 3 or trajs.ndim == 4
+        N = 1
+        if trajs.ndim == 4:
+            N, B, H, D = trajs.shape
+            trajs_new = trajs.reshape(N * B, H, D)
+        else:
+            B, H, D = trajs.shape
+            trajs_new = trajs
+        trajs_interpolated = ops.interpolate_traj_via_points(trajs_new, num_interpolation=num_interpolation)
+        # margin 0: interpolated via points may pass very close to objects without being in collision (tasks.py:247-251)
+        trajs_waypoints_collisions = self.compute_collision(trajs_interpolated, margin=0.)
+        if trajs.ndim == 4:
+            trajs_waypoints_collisions = trajs_waypoints_collisions.reshape(N, B, -1)
+        trajs_free_idxs = torch.argwhere(torch.logical_not(trajs_waypoints_collisions).all(dim=-1))
+        trajs_coll_idxs = torch.argwhere(trajs_waypoints_collisions.any(dim=-1))
+        # trajectories that are collision free must also respect the joint limits (tasks.py:262-284)
+        if trajs_free_idxs.nelement() != 0:
+            if trajs.ndim == 4:
+                trajs_free_tmp = trajs[trajs_free_idxs[:, 0], trajs_free_idxs[:, 1], ...]
+            else:
+                trajs_free_tmp = trajs[trajs_free_idxs.squeeze(), ...]
+            pos = self.robot.get_position(trajs_free_tmp)
+            q_min, q_max = self.robot.q_min.to(pos.device), self.robot.q_max.to(pos.device)
+            inside = torch.logical_and(pos >= q_min, pos <= q_max).all(dim=-1).all(dim=-1)
+            inside = torch.atleast_1d(inside)
+            trajs_free_idxs_try = trajs_free_idxs[torch.argwhere(inside).squeeze()]
+            if trajs_free_idxs_try.nelement() == 0:
+                trajs_coll_idxs = trajs_free_idxs.clone()
+            else:
+                extra = trajs_free_idxs[torch.argwhere(torch.logical_not(inside)).squeeze()]
+                if extra.ndim == 1:
+                    extra = extra[..., None]
+                trajs_coll_idxs = torch.cat((trajs_coll_idxs, extra))
+            trajs_free_idxs = trajs_free_idxs_try
+        if trajs.ndim == 4:
+            trajs_free = trajs[trajs_free_idxs[:, 0], trajs_free_idxs[:, 1], ...]
+            if trajs_free.ndim == 2:
+                trajs_free = trajs_free.unsqueeze(0).unsqueeze(0)
+            trajs_coll = trajs[trajs_coll_idxs[:, 0], trajs_coll_idxs[:, 1], ...]
+            if trajs_coll.ndim == 2:
+                trajs_coll = trajs_coll.unsqueeze(0).unsqueeze(0)
+        else:
+            trajs_free = trajs[trajs_free_idxs.squeeze(), ...]
+            if trajs_free.ndim == 2:
+                trajs_free = trajs_free.unsqueeze(0)
+            trajs_coll = trajs[trajs_coll_idxs.squeeze(), ...]
+            if trajs_coll.ndim == 2:
+                trajs_coll = trajs_coll.unsqueeze(0)
+        if trajs_coll.nelement() == 0:
+            trajs_coll = None
+        if trajs_free.nelement() == 0:
+            trajs_free = None
+        if return_indices:
+            return trajs_coll, trajs_coll_idxs, trajs_free, trajs_free_idxs, trajs_waypoints_collisions
+        return trajs_coll, trajs_free
+
+    def compute_fraction_free_trajs(self, trajs, **kwargs):
+        _, coll_idxs, _, free_idxs, _ = self.get_trajs_collision_and_free(trajs, return_indices=True)
+        n_free, n_coll = free_idxs.nelement(), coll_idxs.nelement()
+        return n_free / (n_free + n_coll)
+
+    def compute_collision_intensity_trajs(self, trajs, **kwargs):
+        _, _, _, _, wp = self.get_trajs_collision_and_free(trajs, return_indices=True)
+        return torch.count_nonzero(wp) / wp.nelement()
+
+    def compute_success_free_trajs(self, trajs, **kwargs):
+        _, trajs_free = self.get_trajs_collision_and_free(trajs)
+        return 1 if (trajs_free is not None and trajs_free.nelement() >= 1) else 0
