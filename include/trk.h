@@ -301,6 +301,11 @@ int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const T
 int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, int32_t dim, int32_t n_interp,
                                const float* alpha, const float* beta, float* out, trk_stream_t stream);
 
+/* Profiling hook (process-global, NULL = off): DEVICE uint64[ceil(N/64)][8]; the model-specialised fused kernel then
+ * records the shader clock (s_memtime) of every wavefront at 8 phase boundaries (entry, q loaded, FK done, positions
+ * staged, objects done, objectives done, reverse done, exit).  Used by tools/phase_profile.py; never set in production. */
+int trk_debug_set_stamp_buffer(void* device_u64);
+
 /* Deterministic sum of n floats (fixed association order, one workgroup): x [n] -> out [1]. */
 int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream);
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-wavefront phase timeline of the fused kernel from in-kernel s_memtime stamps (trk_debug_set_stamp_buffer)."""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np
+import torch
+import torch_robotics_amd as tra
+from torch_robotics_amd import ops
+from torch_robotics_amd._lib import lib
+
+dev = torch.device("cuda:0")
+ta = dict(device=dev, dtype=torch.float32)
+robot = tra.RobotPanda(tensor_args=ta)
+task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=ta), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=ta)
+Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5)
+task.set_ee_target(Ht)
+B, H = 4096, 64
+q = robot.random_q(B * H).reshape(B, H, 7).contiguous()
+model, cm = task._fused_handles(dev)
+plan = ops.RolloutPlan(model, cm, (0, 1, 0, 1), q)
+nb = ops.n_blocks(B * H)
+bs = torch.zeros(nb, **ta)
+for _ in range(20):
+    plan.launch(bs.data_ptr())
+torch.cuda.synchronize()
+stamps = torch.zeros((nb, 8), device=dev, dtype=torch.int64)
+lib().trk_debug_set_stamp_buffer(stamps.data_ptr())
+plan.launch(bs.data_ptr())
+torch.cuda.synchronize()
+lib().trk_debug_set_stamp_buffer(None)
+s = stamps.cpu().numpy().astype(np.float64)
+t0 = s[:, 0].min()
+s -= t0
+names = ["entry", "q loaded", "kernargs arrived", "pos staged", "objects done", "objectives done", "reverse done", "exit"]
+order = [0, 2, 1, 3, 4, 5, 6, 7]
+print("stamp clock: s_memtime ticks (100 MHz REFCLK on gfx9-family = 10 ns per tick, or shader clock; see spread below)")
+print(f"{'phase':18s} {'mean start':>12s} {'p5':>10s} {'p95':>10s} {'mean dur to next':>18s}")
+rel = s - s[:, :1]
+for j, k in enumerate(order):
+    nxt = order[j + 1] if j < 7 else None
+    dur = (s[:, nxt] - s[:, k]).mean() if nxt is not None else 0.0
+    print(f"{names[k]:18s} since entry: mean {rel[:, k].mean():9.1f}  p5 {np.percentile(rel[:, k], 5):9.1f}  p95 {np.percentile(rel[:, k], 95):9.1f}   to next: {dur:9.1f}")
+print("kernel span (first entry -> last exit):", s[:, 7].max(), "ticks;  wave lifetime mean:", (s[:, 7] - s[:, 0]).mean())

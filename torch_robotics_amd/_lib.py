@@ -23,7 +23,7 @@ EXPORTS = [
     "trk_model_n_links", "trk_model_n_dofs", "trk_model_is_specialized", "trk_model_enable_specialized",
     "trk_fk_forward", "trk_fk_positions", "trk_fk_backward", "trk_fk_positions_backward", "trk_fk_jacobian", "trk_fk_analytic_jacobian",
     "trk_rotmat_to_quat", "trk_cost_model_create", "trk_cost_model_destroy", "trk_cost_model_set_ee_target",
-    "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_reduce_sum", "trk_interpolate_via_points",
+    "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_reduce_sum", "trk_debug_set_stamp_buffer", "trk_interpolate_via_points",
     "trk_grid_precompute",
     "trk_sdf_points",
 ]
@@ -81,6 +81,7 @@ def lib():
     L.trk_ee_cost.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp, vp, i64, vp]
     L.trk_rollout_cost_grad.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, vp, vp, vp, vp, vp]
     L.trk_interpolate_via_points.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
+    L.trk_debug_set_stamp_buffer.argtypes = [vp]
     L.trk_reduce_sum.argtypes = [vp, i64, vp, vp]
     L.trk_grid_precompute.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.trk_sdf_points.argtypes = [vp, vp, i64, vp, vp, vp]

@@ -232,8 +232,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;     // index of this wave's 64-sample block")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    spec_stamp(A.stamps, wblock, 0, lane);")
+        E.raw("    if (A.stamps) { asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); if (rows >= 0 && A.q) spec_stamp(A.stamps, wblock, 2, lane); }")
         E.raw("    float q[D];")
         E.raw("    spec_load_q<D>(A.q, base, rows, lane, lds, q);")
+        E.raw("    spec_stamp(A.stamps, wblock, 1, lane);")
         # ---------------- forward ----------------
         R: Dict[int, List[List[S]]] = {}
         t: Dict[int, List[S]] = {}
@@ -301,6 +304,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw(f"        flush = spec_stage_rows<{3 * L}>(A.link_pos, base, rows, lane, lds, pv);")
         E.raw("    }")
         E.raw("    flush(); flush();")
+        E.raw("    spec_stamp(A.stamps, wblock, 3, lane);")
         # ---------------- objectives ----------------
         E.raw("    float cost = 0.0f;")
         for i in adj_links:
@@ -323,6 +327,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], {pa}, {pb}, "
                       f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2);")
             E.raw("    }")
+        E.raw("    spec_stamp(A.stamps, wblock, 4, lane);")
         ee = tmpl.ee_link
         if ee >= 0:
             E.raw("    float eeRb[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};")
@@ -338,7 +343,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                   f"tb{ee}_2 = fmaf(A.w.w_ee, gt[2], tb{ee}_2);")
             E.raw("    }")
         E.raw("    flush();")
-        E.raw("    if (lane < rows) A.cost[base + lane] = cost;")
+        E.raw("    spec_stamp(A.stamps, wblock, 5, lane);")
+        E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
         E.raw("    if (A.cost_sum) {")
         E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
         E.raw("        if (lane == 0 && rows > 0) A.cost_sum[wblock] = tot;")
@@ -386,9 +392,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                         gq_expr[d] = masked(E, i, d, S(g.c * sg, g.n))
             F[par] = [E.add(F[par][k], F[i][k]) for k in range(3)]
             T[par] = [E.add(T[par][k], T[i][k]) for k in range(3)]
+        E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
         E.raw("    flush.flush();")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D>(A.gq, base, rows, lane, lds, gv);")
+        E.raw("    spec_stamp(A.stamps, wblock, 7, lane);")
         E.raw("}")
         out.extend(E.lines)
         out.append("")

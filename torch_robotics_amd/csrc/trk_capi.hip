@@ -14,6 +14,7 @@
 
 namespace {
 thread_local std::string g_err;
+unsigned long long* g_stamps = nullptr;   // profiling hook, see trk_debug_set_stamp_buffer
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 int hip_fail(hipError_t e, const char* what) {
@@ -518,6 +519,7 @@ int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRo
             std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
             a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
+            a.stamps = g_stamps;
             const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z[3] = {0, 0, 0};
             const int base_id = std::memcmp(a.base_R, I, sizeof(I)) == 0 && std::memcmp(a.base_t, Z, sizeof(Z)) == 0;
             e->launch(a, base_id, (hipStream_t)stream);
@@ -539,6 +541,11 @@ int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, 
     if (rc) return rc;
     trk_launch_interpolate(x, n_traj, horizon, dim, n_interp, alpha, beta, out, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_debug_set_stamp_buffer(void* device_u64) {
+    g_stamps = static_cast<unsigned long long*>(device_u64);
     return TRK_OK;
 }
 

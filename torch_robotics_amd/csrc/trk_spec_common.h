@@ -26,6 +26,7 @@ struct SpecArgs {
     float* cost;
     float* gq;
     float* cost_sum;
+    unsigned long long* stamps;   // profiling hook (nullable): [n_waves][8] s_memtime stamps at phase boundaries
 };
 
 typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
@@ -57,6 +58,18 @@ __device__ __forceinline__ void spec_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Output stores are write-through (sc1): a plain store leaves its line dirty in the XCD's L2, and at the kernel
+// boundary up to 32 MB of dirty lines must be written back before the next step's loads get through -- measured as a
+// 2.7 us stall of every wave's first q load.  Write-through lets the 43 MB drain while the kernel computes.
+typedef float trk_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_wt_f4(float4* p, const float4& v) {
+    const trk_f4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void store_wt_f1(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+
 template <int D>
 __device__ __forceinline__ void spec_load_q(const float* __restrict__ q, int64_t base, int rows, int lane,
                                             float* lds, float (&qv)[D]) {
@@ -86,7 +99,7 @@ __device__ __forceinline__ void spec_store_gq(float* __restrict__ gq, int64_t ba
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         const int k = lane + TRK_WAVE * j;
-        if (k < count) gq[first + k] = lds[k];
+        if (k < count) store_wt_f1(gq + first + k, lds[k]);
     }
 }
 
@@ -107,7 +120,7 @@ struct PosFlusher {
     __device__ __forceinline__ void operator()() {
         if (next < NCHUNK) {
             const int k = lane + TRK_WAVE * next;
-            if (k < NV) dst4[k] = src4[k];
+            if (k < NV) store_wt_f4(dst4 + k, src4[k]);
             ++next;
         }
     }
@@ -133,6 +146,14 @@ __device__ __forceinline__ PosFlusher<W> spec_stage_rows(float* __restrict__ out
         f.next = PosFlusher<W>::NCHUNK;
     }
     return f;
+}
+
+// profiling hook: lane 0 of a wave records the shader clock at phase `k` (no-op when A.stamps == nullptr)
+__device__ __forceinline__ void spec_stamp(unsigned long long* stamps, int64_t wblock, int k, int lane) {
+    if (stamps) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) stamps[wblock * 8 + k] = t;
+    }
 }
 
 __device__ __forceinline__ float spec_wave_sum(float v) {
