@@ -225,10 +225,12 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 4) {kname}(SpecArgs A) {{")
-        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(3 * L, D)}];")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(3 * L, D)} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
         E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(3 * L, D)});")
+        E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {max(3 * L, D)}) + wave * TRK_LDS_SPHERES;")
+        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
         E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;     // index of this wave's 64-sample block")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
@@ -315,7 +317,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw("    float gx[NL], gy[NL], gz[NL];")
             E.raw("#pragma unroll")
             E.raw("    for (int l = 0; l < NL; ++l) { gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }")
-            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, flush);")
+            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, flush, lds_sph);")
             E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
             for j, i in enumerate(tmpl.obj_links):
                 E.raw(f"    tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")

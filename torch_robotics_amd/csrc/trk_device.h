@@ -357,10 +357,12 @@ struct NoTick { __device__ __forceinline__ void operator()() const {} };
 
 // `tick` is called once per trip of the sphere loop: the fused kernel uses it to trickle its link-position
 // stores out between the arithmetic instead of issuing them as one burst (see spec_common: PosFlusher).
+#define TRK_LDS_SPHERES 16     // sphere centres a fused kernel may keep in LDS for the arg-min gather
+
 template <int NL, class Tick = NoTick>
 __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (&px)[NL], const float (&py)[NL],
                                               const float (&pz)[NL], float (&s)[NL], float (&gx)[NL], float (&gy)[NL],
-                                              float (&gz)[NL], Tick&& tick = Tick()) {
+                                              float (&gz)[NL], Tick&& tick = Tick(), const float4* lds_spheres = nullptr) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) { s[l] = __builtin_inff(); gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }
     if (C.n_spheres > 0) {
@@ -440,7 +442,9 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
             }
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
-                const float4 S = C.spheres[bi[l]];          // per-lane gather of the winning centre (L1/L2 hit)
+                // per-lane gather of the winning centre: from the wave's LDS copy when there is one (~100 cycles),
+                // else from global memory (L2 hit, ~700 cycles with every wave of the chip asking at once)
+                const float4 S = (lds_spheres && C.n_spheres <= TRK_LDS_SPHERES) ? lds_spheres[bi[l]] : C.spheres[bi[l]];
                 const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
                 const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
                 const float inv = n2 > 0.0f ? trk_rsq(n2) : 0.0f;     // one transcendental per point

@@ -70,6 +70,12 @@ __device__ __forceinline__ void store_wt_f1(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 
+// copy the first TRK_LDS_SPHERES world-frame spheres into this wave's LDS (one 16-byte load per lane, issued together
+// with the q loads so its latency is free)
+__device__ __forceinline__ void spec_load_spheres(const DevCostHdr& C, float4* lds_spheres, int lane) {
+    if (lane < TRK_LDS_SPHERES && lane < C.n_spheres) lds_spheres[lane] = C.spheres[lane];
+}
+
 template <int D>
 __device__ __forceinline__ void spec_load_q(const float* __restrict__ q, int64_t base, int rows, int lane,
                                             float* lds, float (&qv)[D]) {
@@ -169,9 +175,9 @@ __device__ __forceinline__ float spec_wave_sum(float v) {
 template <int NL, class Tick>
 __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w, const float (&px)[NL],
                                                    const float (&py)[NL], const float (&pz)[NL], float (&gx)[NL],
-                                                   float (&gy)[NL], float (&gz)[NL], Tick& tick) {
+                                                   float (&gy)[NL], float (&gz)[NL], Tick& tick, const float4* lds_spheres) {
     float s[NL], ax[NL], ay[NL], az[NL];
-    scene_min_sdf<NL>(C, px, py, pz, s, ax, ay, az, tick);
+    scene_min_sdf<NL>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres);
     float cost = 0.0f;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
