@@ -79,13 +79,26 @@ __device__ __forceinline__ void spec_load_spheres(const DevCostHdr& C, float4* l
 template <int D>
 __device__ __forceinline__ void spec_load_q(const float* __restrict__ q, int64_t base, int rows, int lane,
                                             float* lds, float (&qv)[D]) {
-    // D coalesced dword loads per lane over the wave's contiguous 64*D floats, then a stride-D LDS read
+    // the wave's 64*D floats are one contiguous span: 16-byte loads (2 instructions for D = 7) into LDS, then a
+    // stride-D read back (D odd -> conflict-free); ragged / unaligned tails take the dword path
     const int64_t first = base * D;
-    const int count = rows * D;
+    const float* src = q + first;
+    constexpr int NV = TRK_WAVE * D / 4;
+    if (rows == TRK_WAVE && (TRK_WAVE * D) % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        float4* lds4 = reinterpret_cast<float4*>(lds);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        const int k = lane + TRK_WAVE * j;
-        lds[k] = k < count ? q[first + k] : 0.0f;
+        for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            if (k < NV) lds4[k] = src4[k];
+        }
+    } else {
+        const int count = rows * D;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            lds[k] = k < count ? src[k] : 0.0f;
+        }
     }
     spec_wave_sync();
 #pragma unroll
@@ -101,11 +114,23 @@ __device__ __forceinline__ void spec_store_gq(float* __restrict__ gq, int64_t ba
     for (int j = 0; j < D; ++j) lds[lane * D + j] = gv[j];
     spec_wave_sync();
     const int64_t first = base * D;
-    const int count = rows * D;
+    float* dst = gq + first;
+    constexpr int NV = TRK_WAVE * D / 4;
+    if (rows == TRK_WAVE && (TRK_WAVE * D) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        const float4* lds4 = reinterpret_cast<const float4*>(lds);
+        float4* dst4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        const int k = lane + TRK_WAVE * j;
-        if (k < count) store_wt_f1(gq + first + k, lds[k]);
+        for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            if (k < NV) store_wt_f4(dst4 + k, lds4[k]);
+        }
+    } else {
+        const int count = rows * D;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            if (k < count) store_wt_f1(dst + k, lds[k]);
+        }
     }
 }
 
