@@ -163,6 +163,15 @@ def main():
     ref = plan.cost.double().sum().item()
     assert abs(last - ref) <= 1e-4 * abs(ref) + 1e-3, (last, ref)
 
+    # HBM traffic per launch from the PMC passes recorded under profiles/ (bench.py cannot run rocprofv3 on itself)
+    traffic = None
+    try:
+        key = f"{args.config}:{B}x{H}:{'specialized' if model.specialized else 'table-driven'}"
+        if not args.weights and not args.no_pos:
+            traffic = json.loads((ROOT / "profiles" / "r01_hbm_traffic.json").read_text())["workloads"][key]["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     out = {
         "metric": "FK+cost+grad rollouts/sec (batch x horizon), Panda 7-DOF",
         "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -180,7 +189,7 @@ def main():
                    **({"experiment_weights": list(weights)} if args.weights else {}),
                    **({"experiment_no_pos": True} if args.no_pos else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "bytes_per_sample": algorithmic_bytes_per_sample(D, L), "launch_us": launch_s * 1e6},
     }
 
