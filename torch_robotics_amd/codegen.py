@@ -264,6 +264,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 E.raw(f"    const float qh{d} = q[{d}];")
             if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS) and float(kin.rot_sign[i]) != 0.0:
                 rot_dofs.append(d)
+        # pin the mask in ONE register: without this the compiler re-derives it from q and qh in the reverse pass and
+        # keeps 2D registers alive across the whole kernel (-> spills, and every spill reload is an s_waitcnt vmcnt(0)
+        # that also waits for the wave's outstanding output stores)
+        E.raw('    asm volatile("" : "+v"(passbits));')
         for d in rot_dofs:
             E.raw(f"    float sn{d}, cs{d};")
         for a, b in zip(rot_dofs[0::2], rot_dofs[1::2]):
