@@ -360,3 +360,44 @@ def test_analytic_jacobian_all_links(ops, oracle_lib, robot):
     bad = np.abs(J - J64).max(axis=(2, 3)) > 1e-4
     assert bad.mean() < 0.01
     assert np.abs((J - J64)[~bad]).max() < 5e-6
+
+
+@pytest.mark.parametrize("ident,urdf", [("ur10_allegro", "ur10_allegro"), ("dual_panda", "dual_panda")])
+def test_specialized_tree_kernels(ops, oracle_lib, ident, urdf):
+    """Generated kernels for the tree robots of BASELINE configs 4 / 5, with their baked collision templates,
+    against the table-driven kernel and the fp64 oracle."""
+    from torch_robotics_amd import codegen
+    from torch_robotics_amd.costmodel import CostModelSpec
+    kin, tmpl = codegen.template_for(ident)
+    m = model(urdf)
+    gs, rb = gold("cost_spheres3d_extra"), gold("panda_robot")
+    base = panda_cost_spec(gs, rb)
+    rng = np.random.default_rng(21)
+    spec = CostModelSpec(n_links_in=m.n_links)
+    spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+    spec.obj_link_margin = rng.uniform(0.02, 0.12, len(tmpl.obj_links)).astype(np.float32)
+    spec.objects = base.objects
+    spec.ws_min, spec.ws_max = np.float32([-1, -1, -1]), np.float32([1.2, 1.2, 1.5])
+    self_links = sorted({a for p in tmpl.self_pairs for a in p})
+    spec.self_link_idx = np.asarray(self_links, np.int32)
+    spec.self_pairs = np.asarray([(self_links.index(a), self_links.index(b)) for a, b in tmpl.self_pairs], np.int32)
+    spec.self_margin = rng.uniform(0.02, 0.08, len(tmpl.self_pairs)).astype(np.float32)
+    spec.ee_link = tmpl.ee_link
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.5, 0.1, 0.6)
+    spec.ee_target = Ht
+    spec.validate()
+    h, cm, o = ops.ModelHandle(m), ops.CostHandle(spec, DEV), oracle_lib.Oracle(m, spec)
+    assert h.specialized
+    for n in (64, 300):
+        q = rng.uniform(-2.5, 2.5, (n, m.n_dofs)).astype(np.float32)
+        for w in ((1, 1, 1, 1), (0, 1, 0, 1), (0.5, 2.0, 0.25, 0.0)):
+            h.enable_specialized(True)
+            pos, c, gq = ops.rollout_cost_grad(h, cm, w, dev(q))
+            h.enable_specialized(False)
+            _, c_g, gq_g = ops.rollout_cost_grad(h, cm, w, dev(q))
+            p64, c64, g64 = o.rollout(q.astype(np.float64), w, "f64")
+            scale = max(1.0, float(np.abs(p64).max()))
+            assert np.abs(pos.cpu().numpy() - p64).max() / scale < TOL_H
+            assert rel_err(c.cpu().numpy(), c64) < TOL_C, (n, w)
+            assert rel_err(gq.cpu().numpy(), g64) < TOL_G, (n, w)
+            assert rel_err(gq.cpu().numpy(), gq_g.cpu().numpy()) < TOL_G

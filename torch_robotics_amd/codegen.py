@@ -224,7 +224,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     for base_identity in (True, False):
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
-        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 4) {kname}(SpecArgs A) {{")
+        # small arms fit 128 VGPRs (4 waves/SIMD: the whole 4096 x 64 batch resident); big trees get 256 VGPRs
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(3 * L, D)} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
@@ -423,10 +424,46 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     return "\n".join(out) + "\n"
 
 
+def ur10_allegro_template(kin: KinModel) -> CollisionTemplate:
+    """BASELINE config 4 (UR10 + Allegro hand): arm links, palm and the four fingertips against the scene;
+    fingertip-vs-fingertip / fingertip-vs-forearm self pairs; the arm's `ee_link` is tracked."""
+    idx = kin.name_to_idx
+    obj = [idx[n] for n in ("upper_arm_link", "forearm_link", "wrist_1_link", "wrist_3_link", "allegro_palm_link",
+                            "allegro_index_biotac_tip", "allegro_middle_biotac_tip", "allegro_ring_biotac_tip",
+                            "allegro_thumb_biotac_tip")]
+    tips = ["allegro_index_biotac_tip", "allegro_middle_biotac_tip", "allegro_ring_biotac_tip", "allegro_thumb_biotac_tip"]
+    pairs = [(idx[a], idx[b]) for i, a in enumerate(tips) for b in tips[i + 1:]]
+    pairs += [(idx[t], idx["forearm_link"]) for t in tips]
+    return CollisionTemplate(obj_links=obj, self_pairs=pairs, ee_link=idx["ee_link"])
+
+
+def dual_panda_template(kin: KinModel) -> CollisionTemplate:
+    """BASELINE config 5 (two Panda arms): RobotPanda's object-collision links on both arms, arm-vs-arm self pairs;
+    the left arm's end effector is tracked (one EE term per cost model)."""
+    idx = kin.name_to_idx
+    names = ("panda_link2", "panda_link3", "panda_link5", "panda_link7", "panda_hand")
+    obj = [idx[f"{side}_{n}"] for side in ("left", "right") for n in names]
+    cross = [("panda_hand", "panda_hand"), ("panda_hand", "panda_link5"), ("panda_link5", "panda_hand"),
+             ("panda_link5", "panda_link5"), ("panda_link7", "panda_link7"), ("panda_link3", "panda_link3"),
+             ("panda_hand", "panda_link3"), ("panda_link3", "panda_hand")]
+    pairs = [(idx[f"left_{a}"], idx[f"right_{b}"]) for a, b in cross]
+    return CollisionTemplate(obj_links=obj, self_pairs=pairs, ee_link=idx["left_ee_link"])
+
+
 # robots that get a specialised kernel at build time: name -> (urdf file, template factory)
 SPEC_ROBOTS = {
     "panda": ("panda_arm_no_gripper.urdf", panda_template),
+    "ur10_allegro": ("ur10_allegro.urdf", ur10_allegro_template),
+    "dual_panda": ("dual_panda.urdf", dual_panda_template),
 }
+
+
+def template_for(ident: str):
+    """(KinModel, CollisionTemplate) of a robot in SPEC_ROBOTS."""
+    from .kinematics import URDF_DIR
+    urdf, fn = SPEC_ROBOTS[ident]
+    kin = KinModel.from_urdf(str(URDF_DIR / urdf))
+    return kin, fn(kin)
 
 
 def generate_all(out_dir) -> List[str]:
