@@ -158,6 +158,16 @@ int trk_fk_jacobian(const TrkModel* model, const float* q, const float* qd, int6
  * q [N,D] -> J [N, L, 7, D]. */
 int trk_fk_analytic_jacobian(const TrkModel* model, const float* q, int64_t n, float* J, trk_stream_t stream);
 
+/* One iteration of the batched Adam IK, reference: DifferentiableTree.inverse_kinematics robot_tree.py:345-377 with
+ * loss_fn_ik_per_q :386-417 (SE3_distance w_pos = w_rot = 1 + w_joint_limits * squared hinge on [lower, upper]) and
+ * ik_termination :419-442.  In place: q [N,D] <- Adam(q, d loss / d q) with torch.optim.Adam's defaults (betas 0.9/0.999,
+ * eps 1e-8), state adam_m / adam_v [N,D] (zero before step 1), step = 1-based iteration.  loss [N] and valid [N] (uint8:
+ * inside the limits and SE3 error < se3_eps) are evaluated on q BEFORE the update, as in the reference loop; lr = 0 only
+ * evaluates.  H_target: DEVICE [16] or [N,16]; lower / upper: DEVICE [D].  All nullable outputs may be NULL. */
+int trk_ik_step(const TrkModel* model, int32_t link, const float* H_target, int32_t per_sample_target, const float* lower,
+                const float* upper, float w_joint_limits, float se3_eps, float lr, int32_t step, int64_t n, float* q,
+                float* adam_m, float* adam_v, float* loss, uint8_t* valid, trk_stream_t stream);
+
 /* reference: rotation_matrix_to_q quaternion.py:135-166 (via link_quat_from_link_tensor
  * geometrics/utils.py:341-344).  R: n matrices, `stride` floats apart, 3x3 block with row
  * pitch `row_pitch` (9/3 for packed rotations, 16/4 for 4x4 transforms).  -> quat_wxyz [n,4]. */

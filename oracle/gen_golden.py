@@ -432,6 +432,36 @@ def trajs_goldens():
     np.savez_compressed(GOLD / "trajs_panda.npz", **out)
 
 
+def ik_goldens(trees):
+    """8f rank 2: loss_fn_ik_per_q / ik_termination (robot_tree.py:386-442) and Adam steps on it."""
+    tree = trees["panda_arm_no_gripper"]
+    gen = torch.Generator().manual_seed(404)
+    lower, upper, _, _ = tree.get_joint_limit_array()
+    eps = np.pi / 100
+    lower_t = torch.as_tensor(lower + eps, dtype=torch.float32); upper_t = torch.as_tensor(upper - eps, dtype=torch.float32)
+    q0 = sample_q(tree, 48, gen, 0.1)                      # some joints outside the (shrunk) limits
+    q_goal = sample_q(tree, 48, gen, 0.0)
+    H_target = tree.compute_forward_kinematics_all_links(q_goal, link_list=["ee_link"]).squeeze(1).detach()
+    out = dict(q0=q0.numpy(), H_target=H_target.numpy(), lower=lower_t.numpy(), upper=upper_t.numpy())
+    for tag, Ht in (("per_sample", H_target), ("single", H_target[:1])):
+        q = q0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([q], lr=1e-2)
+        traj_q, traj_err = [], []
+        for it in range(5):
+            opt.zero_grad()
+            idx_valid = tree.ik_termination(q, Ht, "ee_link", lower_t, upper_t, se3_eps=1e-1)
+            err = tree.loss_fn_ik_per_q(q, Ht, "ee_link", w_se3=1.0, w_joint_limits=300.0, lower=lower_t, upper=upper_t)
+            if it == 0:
+                (g0,) = torch.autograd.grad(err.sum(), q, retain_graph=True)
+                out[f"loss0_{tag}"] = err.detach().numpy(); out[f"grad0_{tag}"] = g0.numpy()
+                valid = np.zeros(48, bool); valid[idx_valid.numpy()] = True
+                out[f"valid0_{tag}"] = valid
+            err.sum().backward(); opt.step()
+            traj_q.append(q.detach().clone().numpy()); traj_err.append(err.detach().numpy())
+        out[f"q_steps_{tag}"] = np.stack(traj_q); out[f"err_steps_{tag}"] = np.stack(traj_err)
+    np.savez_compressed(GOLD / "ik_panda.npz", **out)
+
+
 def misc_goldens():
     """finite differences / smoothness (A17) and via-point interpolation (8f rank 1)."""
     from torch_robotics.trajectory.utils import finite_difference_vector, interpolate_traj_via_points
@@ -476,6 +506,7 @@ def main():
     quat_golden()
     cost_goldens()
     trajs_goldens()
+    ik_goldens(trees)
     misc_goldens()
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")

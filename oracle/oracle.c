@@ -22,6 +22,7 @@
 #define SQRT sqrtf
 #define FABS fabsf
 #define FLOOR floorf
+#define POW powf
 #include "oracle_impl.inc"
 #undef REAL
 #undef FN
@@ -30,6 +31,7 @@
 #undef SQRT
 #undef FABS
 #undef FLOOR
+#undef POW
 
 #define REAL double
 #define FN(x) x##_f64
@@ -38,6 +40,7 @@
 #define SQRT sqrt
 #define FABS fabs
 #define FLOOR floor
+#define POW pow
 #include "oracle_impl.inc"
 
 int orc_abi_version(void) { return TRK_ABI_VERSION; }

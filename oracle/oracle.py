@@ -116,6 +116,21 @@ class Oracle:
         getattr(lib(), "orc_fk_analytic_jacobian" + suf)(C.byref(self.kd), _p(q), C.c_int64(q.shape[0]), _p(J))
         return J
 
+    def ik_step(self, link, H_target, lower, upper, q, mom, vel, step, lr=1e-2, w_jl=300.0, se3_eps=1e-1, prec="f32"):
+        """One IK iteration IN PLACE on q / mom / vel; returns (loss, grad, valid) evaluated before the update."""
+        npdt, ct, suf = _dt(prec)
+        D = self.model.n_dofs
+        n = q.shape[0]
+        assert q.dtype == npdt and mom.dtype == npdt and vel.dtype == npdt and q.flags.c_contiguous
+        Ht = np.ascontiguousarray(H_target, npdt)
+        per_sample = int(Ht.ndim == 3)
+        lo, hi = np.ascontiguousarray(lower, npdt), np.ascontiguousarray(upper, npdt)
+        loss, grad, valid = np.empty(n, npdt), np.empty((n, D), npdt), np.empty(n, np.uint8)
+        getattr(lib(), "orc_ik_step" + suf)(C.byref(self.kd), C.c_int(int(link)), _p(Ht), C.c_int(per_sample), _p(lo), _p(hi),
+                                            ct(w_jl), ct(se3_eps), ct(lr), C.c_int(int(step)), C.c_int64(n), _p(q), _p(mom),
+                                            _p(vel), _p(loss), _p(grad), _p(valid))
+        return loss, grad, valid.astype(bool)
+
     @staticmethod
     def rotmat_to_quat(R, prec="f32"):
         npdt, _, suf = _dt(prec)

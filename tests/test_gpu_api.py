@@ -182,3 +182,25 @@ def test_trajectory_validation_like_the_reference():
     np.testing.assert_array_equal(wp4.cpu().numpy(), g["waypoints_collisions4"])
     np.testing.assert_array_equal(ci4.cpu().numpy(), g["coll_idx4"])
     np.testing.assert_array_equal(fi4.cpu().numpy(), g["free_idx4"])
+
+
+def test_inverse_kinematics_like_the_example():
+    """examples/inverse_kinematics.py: a batch of IK problems converges to valid configurations."""
+    tree = tra.DifferentiableFrankaPanda(device=DEV)
+    torch.manual_seed(0)
+    q_goal = (torch.rand(1, 7, device=DEV) - 0.5) * 2.0
+    H_target = tree.compute_forward_kinematics_all_links(q_goal, link_list=["ee_link"]).squeeze(1)
+    q, idx_valid = tree.inverse_kinematics(H_target, link_name="ee_link", batch_size=64, max_iters=800, lr=2e-2,
+                                           se3_eps=5e-2, print_freq=-1, check_every=10)
+    assert q.shape == (64, 7)
+    assert idx_valid.numel() >= 16                               # gradient IK has local minima: a good share of the restarts converge
+    H = tree.compute_forward_kinematics_all_links(q[idx_valid], link_list=["ee_link"]).squeeze(1)
+    assert (H[:, :3, 3] - H_target[0, :3, 3]).norm(dim=-1).max() < 5e-2
+    lo, hi, _, _ = tree.get_joint_limit_array()
+    qv = q[idx_valid].cpu().numpy()
+    assert np.all(qv >= lo) and np.all(qv <= hi)
+    # loss_fn_ik_per_q / ik_termination helpers agree with the golden of the reference
+    g = gold("ik_panda")
+    loss = tree.loss_fn_ik_per_q(dev(g["q0"]), dev(g["H_target"]), "ee_link", w_joint_limits=300.0,
+                                 lower=dev(g["lower"]), upper=dev(g["upper"]))
+    assert rel_err(loss.cpu().numpy(), g["loss0_per_sample"]) < TOL_C

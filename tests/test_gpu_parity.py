@@ -401,3 +401,37 @@ def test_specialized_tree_kernels(ops, oracle_lib, ident, urdf):
             assert rel_err(c.cpu().numpy(), c64) < TOL_C, (n, w)
             assert rel_err(gq.cpu().numpy(), g64) < TOL_G, (n, w)
             assert rel_err(gq.cpu().numpy(), gq_g.cpu().numpy()) < TOL_G
+
+
+def test_ik_step_vs_reference_adam(ops, oracle_lib):
+    """8f rank 2: the fused IK iteration == loss_fn_ik_per_q + ik_termination + torch.optim.Adam (reference goldens)."""
+    g = gold("ik_panda")
+    m = model("panda_arm_no_gripper")
+    h = ops.ModelHandle(m)
+    lo, hi = dev(g["lower"]), dev(g["upper"])
+    for tag, Ht in (("per_sample", g["H_target"]), ("single", g["H_target"][0])):
+        q = dev(g["q0"]).clone()
+        mom, vel = torch.zeros_like(q), torch.zeros_like(q)
+        loss = torch.empty(48, device=DEV); valid = torch.empty(48, device=DEV, dtype=torch.uint8)
+        for it in range(5):
+            ops.ik_step(h, 10, dev(Ht), lo, hi, q, mom, vel, it + 1, lr=1e-2, loss=loss, valid=valid)
+            if it == 0:
+                assert rel_err(loss.cpu().numpy(), g[f"loss0_{tag}"]) < TOL_C
+                np.testing.assert_array_equal(valid.cpu().numpy().astype(bool), g[f"valid0_{tag}"])
+            assert rel_err(loss.cpu().numpy(), g[f"err_steps_{tag}"][it]) < 2e-4
+            assert np.abs(q.cpu().numpy() - g[f"q_steps_{tag}"][it]).max() < 2e-4
+    # ragged size on a tree robot vs the fp64 oracle
+    mt = model("ur10_allegro")
+    ht, ot = ops.ModelHandle(mt), oracle_lib.Oracle(mt)
+    rng = np.random.default_rng(8)
+    q0 = rng.uniform(-1.5, 1.5, (77, mt.n_dofs)).astype(np.float32)
+    Htg = ot.fk(rng.uniform(-1.0, 1.0, (77, mt.n_dofs)).astype(np.float64), "f64")[:, 14].astype(np.float32)
+    lo_t = np.full(mt.n_dofs, -1.2, np.float32); hi_t = np.full(mt.n_dofs, 1.2, np.float32)
+    q = dev(q0).clone(); mom, vel = torch.zeros_like(q), torch.zeros_like(q)
+    q64 = q0.astype(np.float64); m64, v64 = np.zeros_like(q64), np.zeros_like(q64)
+    loss = torch.empty(77, device=DEV)
+    for it in range(3):
+        ops.ik_step(ht, 14, dev(Htg), dev(lo_t), dev(hi_t), q, mom, vel, it + 1, lr=5e-3, loss=loss)
+        l64, _, _ = ot.ik_step(14, Htg.astype(np.float64), lo_t, hi_t, q64, m64, v64, it + 1, lr=5e-3, prec="f64")
+        assert rel_err(loss.cpu().numpy(), l64) < 1e-4
+        assert np.abs(q.cpu().numpy() - q64).max() < 2e-4

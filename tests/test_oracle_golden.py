@@ -198,3 +198,22 @@ def test_analytic_jacobian_all_links(oracle_lib, robot, prec):
             Hp, Hm = o.fk(q + e, "f64"), o.fk(q - e, "f64")
             dpos = (Hp[..., :3, 3] - Hm[..., :3, 3]) / (2 * h)
             assert np.abs(dpos[inside] - J[inside][:, :, :3, d]).max() < 1e-6
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_ik_loss_gradient_and_adam_steps(oracle_lib, prec):
+    """8f rank 2: loss_fn_ik_per_q / ik_termination and five torch.optim.Adam steps on it (robot_tree.py:345-442)."""
+    g = gold("ik_panda")
+    m = model("panda_arm_no_gripper")
+    o = oracle_lib.Oracle(m)
+    dt = np.float32 if prec == "f32" else np.float64
+    for tag, Ht in (("per_sample", g["H_target"]), ("single", g["H_target"][0])):
+        q = g["q0"].astype(dt).copy(); mom = np.zeros_like(q); vel = np.zeros_like(q)
+        for it in range(5):
+            loss, grad, valid = o.ik_step(10, Ht, g["lower"], g["upper"], q, mom, vel, it + 1, prec=prec)
+            if it == 0:
+                assert rel_err(loss, g[f"loss0_{tag}"]) < 5e-6
+                assert rel_err(grad, g[f"grad0_{tag}"]) < 2e-5
+                np.testing.assert_array_equal(valid, g[f"valid0_{tag}"])
+            assert rel_err(loss, g[f"err_steps_{tag}"][it]) < 2e-4
+            assert np.abs(q - g[f"q_steps_{tag}"][it]).max() < 2e-4       # Adam's first steps are +-lr whatever |g| is

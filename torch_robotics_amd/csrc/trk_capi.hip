@@ -287,6 +287,23 @@ int trk_fk_analytic_jacobian(const TrkModel* m, const float* q, int64_t n, float
     return TRK_OK;
 }
 
+int trk_ik_step(const TrkModel* m, int32_t link, const float* H_target, int32_t per_sample_target, const float* lower,
+                const float* upper, float w_joint_limits, float se3_eps, float lr, int32_t step, int64_t n, float* q,
+                float* adam_m, float* adam_v, float* loss, uint8_t* valid, trk_stream_t stream) {
+    int rc = check_model(m, "trk_ik_step");
+    if (rc) return rc;
+    if (link < 0 || link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_ik_step: link out of range");
+    if (n < 0 || step < 1 || !H_target || !lower || !upper || (n > 0 && !q) || (lr > 0.0f && (!adam_m || !adam_v)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_ik_step: bad argument");
+    if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    const float bc1 = 1.0f - std::pow(0.9f, (float)step);
+    const float rsqrt_bc2 = 1.0f / std::sqrt(1.0f - std::pow(0.999f, (float)step));
+    trk_launch_ik_step(m->hdr, m->d_links, m->d_fin, link, H_target, per_sample_target, lower, upper, w_joint_limits,
+                       se3_eps, lr, bc1, rsqrt_bc2, n, q, adam_m, adam_v, loss, valid, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
 int trk_rotmat_to_quat(const float* R, int64_t n, int32_t stride, int32_t row_pitch, float* quat, trk_stream_t stream) {
     if (n < 0 || stride < 9 || row_pitch < 3 || (n > 0 && (!R || !quat))) return fail(TRK_ERR_INVALID_ARG, "trk_rotmat_to_quat: bad argument");
     if (n == 0) return TRK_OK;

@@ -280,6 +280,77 @@ k_fk_backward(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t*
 }
 
 // ============================================================================================
+// One iteration of DifferentiableTree.inverse_kinematics (robot_tree.py:345-377) as ONE kernel: FK of the target link,
+// SE3_distance + joint-limit hinge (loss_fn_ik_per_q :386-417), its gradient (reverse walk), the termination test
+// (ik_termination :419-442, on q BEFORE the update) and the Adam update (torch.optim.Adam defaults), all per lane.
+// The reference runs two FK passes, an autograd backward and ~10 optimizer kernels per iteration.
+// ============================================================================================
+struct AdjIK {            // adjoint of the SE(3) distance on one link, evaluated when the walk reaches it
+    int link; const float* Ht; float err;
+    __device__ __forceinline__ bool has_rot(const DevLink&) const { return true; }
+    __device__ __forceinline__ bool operator()(const DevLink& Lk, int, const Pose& cur, float* Rb, float* tb) {
+        if (Lk.link != link) return false;
+        err = ee_cost_eval(cur.r, cur.t, Ht, 1.0f, 1.0f, 0, Rb, tb);
+        return true;
+    }
+};
+
+__global__ void __launch_bounds__(TRK_WAVE)
+k_ik_step(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, int link,
+          const float* __restrict__ H_target, int per_sample, const float* __restrict__ lower,
+          const float* __restrict__ upper, float w_jl, float se3_eps, float lr, float bc1, float rsqrt_bc2, int64_t n,
+          float* __restrict__ q, float* __restrict__ mom, float* __restrict__ vel, float* __restrict__ loss,
+          uint8_t* __restrict__ valid) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int D = hdr.n_dofs;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    float* qs = smem;
+    float* gqs = qs + TRK_WAVE * D;
+    float* jst = gqs + TRK_WAVE * D;
+    float* slots = jst + 7 * D * TRK_WAVE;
+    load_tile(qs, q, base * D, (int64_t)rows * D, lane);
+    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
+    for (int k = lane; k < TRK_WAVE * D; k += TRK_WAVE) gqs[k] = 0.0f;
+    __syncthreads();
+    float Ht[16];
+    {
+        const int64_t s = min(base + lane, n - 1);
+        const float* tp = H_target + (per_sample ? s * 16 : 0);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Ht[k] = tp[k];
+    }
+    AdjIK adj{link, Ht, 0.0f};
+    reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+    // hinge on the (shrunk) joint limits, termination test, Adam; each lane owns its row of the q / gq tiles
+    bool ok = adj.err < se3_eps;
+    float jl = 0.0f;
+    const int64_t s = base + lane;
+    for (int d = 0; d < D; ++d) {
+        const float qv = qs[lane * D + d], lo = lower[d], hi = upper[d];
+        float g = gqs[lane * D + d];
+        if (qv < lo) { const float e = lo - qv; jl = fmaf(e, e, jl); g = fmaf(-2.0f * w_jl, e, g); }
+        if (qv > hi) { const float e = hi - qv; jl = fmaf(e, e, jl); g = fmaf(-2.0f * w_jl, e, g); }
+        ok = ok && (qv >= lo) && (qv <= hi);
+        if (lane < rows && lr > 0.0f) {
+            const int64_t idx = s * D + d;
+            const float m1 = fmaf(0.9f, mom[idx], 0.1f * g);
+            const float v1 = fmaf(0.999f, vel[idx], 0.001f * g * g);
+            mom[idx] = m1; vel[idx] = v1;
+            const float denom = fmaf(sqrtf(v1), rsqrt_bc2, 1e-8f);
+            qs[lane * D + d] = qv - (lr / bc1) * (m1 / denom);
+        }
+    }
+    if (lane < rows) {
+        if (loss) loss[s] = fmaf(w_jl, jl, adj.err);
+        if (valid) valid[s] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (lr > 0.0f) store_tile(q, qs, base * D, (int64_t)rows * D, lane);
+}
+
+// ============================================================================================
 // Collision fields on link positions held in an LDS tile [64][rs].
 // distance_fields.py:107-124 ('sdf'): objects :298-316, workspace box :319-332, self pairs :194-208.
 // Returns the summed cost of the selected fields; if gtile != nullptr accumulates scale * d cost / d pos.
@@ -878,6 +949,15 @@ void trk_launch_fk_backward(int mode, const DevModelHdr& hdr, const DevLink* lin
     else hipLaunchKernelGGL(k_fk_backward<1>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, sel, n_sel, q, gin, n, gq);
 }
 
+void trk_launch_ik_step(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, int link, const float* H_target,
+                        int per_sample, const float* lower, const float* upper, float w_jl, float se3_eps, float lr,
+                        float bc1, float rsqrt_bc2, int64_t n, float* q, float* mom, float* vel, float* loss,
+                        uint8_t* valid, hipStream_t st) {
+    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE);
+    hipLaunchKernelGGL(k_ik_step, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, link, H_target,
+                       per_sample, lower, upper, w_jl, se3_eps, lr, bc1, rsqrt_bc2, n, q, mom, vel, loss, valid);
+}
+
 void trk_launch_cost_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, const float* gcost,
                             float* cost, float* g_link_pos, hipStream_t st) {
     size_t lds = sizeof(float) * 2 * (size_t)TRK_WAVE * ((C.n_links_in * 3) | 1);
@@ -949,7 +1029,7 @@ int trk_kernels_init(void) {
 #define TRK_SET(k) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
     TRK_SET(k_fk_forward<0>); TRK_SET(k_fk_forward<1>); TRK_SET(k_fk_backward<0>); TRK_SET(k_fk_backward<1>);
     TRK_SET(k_cost_fields); TRK_SET(k_collision_fields); TRK_SET(k_rollout_generic); TRK_SET(k_fk_jacobian);
-    TRK_SET(k_fk_analytic_jacobian);
+    TRK_SET(k_fk_analytic_jacobian); TRK_SET(k_ik_step);
 #undef TRK_SET
     return e == hipSuccess ? 0 : -1;
 }

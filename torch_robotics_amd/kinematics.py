@@ -150,6 +150,71 @@ class DifferentiableTree(torch.nn.Module):
         assert q.ndim == 2 and q.shape[1] == self._n_dofs
         return ops.fk_analytic_jacobian(self._handle, q.detach())
 
+    # -- batched Adam IK (robot_tree.py:303-442): one fused kernel per iteration ------------------------
+    def _ik_limits(self, eps_joint_lim, device):
+        lower, upper, _, _ = self.get_joint_limit_array()
+        lo = torch.as_tensor(lower + eps_joint_lim, dtype=torch.float32, device=device)
+        hi = torch.as_tensor(upper - eps_joint_lim, dtype=torch.float32, device=device)
+        return lo, hi
+
+    def loss_fn_ik_per_q(self, q, H_target, link_name, w_se3=1.0, w_joint_limits=1.0, lower=None, upper=None,
+                         w_q_rest=1.0, q_rest=None, debug=False):
+        if w_se3 != 1.0 or q_rest is not None:
+            raise NotImplementedError("only the configuration inverse_kinematics itself uses (w_se3 = 1, no rest pose)")
+        q = q.detach().contiguous()
+        loss = torch.empty(q.shape[0], device=q.device, dtype=torch.float32)
+        ops.ik_step(self._handle, self._name_to_idx_map[link_name], H_target, lower, upper, q, None, None, 1, lr=0.0,
+                    w_joint_limits=w_joint_limits, loss=loss)
+        return loss
+
+    def ik_termination(self, q, H_target, link_name, lower, upper, se3_eps=1e-1, debug=False):
+        q = q.detach().contiguous()
+        valid = torch.empty(q.shape[0], device=q.device, dtype=torch.uint8)
+        ops.ik_step(self._handle, self._name_to_idx_map[link_name], H_target, lower, upper, q, None, None, 1, lr=0.0,
+                    se3_eps=se3_eps, valid=valid)
+        return torch.atleast_1d(torch.argwhere(valid.bool()).squeeze())
+
+    def inverse_kinematics(self, H_target, link_name="ee_link", batch_size=1, max_iters=1000, lr=1e-2, se3_eps=1e-1,
+                           q0=None, q0_noise=torch.pi / 8, eps_joint_lim=torch.pi / 100, print_freq=50, debug=False,
+                           check_every=1):
+        """Same contract as the reference: returns (q, idx_valid).  `check_every` > 1 tests the termination condition
+        (a device->host sync) only every so many iterations instead of every iteration."""
+        self._check_supported()
+        H_target = torch.as_tensor(H_target, dtype=torch.float32, device=self._device)
+        if H_target.ndim == 2:
+            H_target = H_target.unsqueeze(0)
+        Ht = H_target[0].contiguous() if H_target.shape[0] == 1 else H_target.contiguous()
+        lo, hi = self._ik_limits(eps_joint_lim, self._device)
+        if q0 is None:
+            q0 = lo + torch.rand(batch_size, self._n_dofs, device=self._device) * (hi - lo)
+        else:
+            q0 = torch.as_tensor(q0, dtype=torch.float32, device=self._device)
+            q0 = torch.clamp(q0 + torch.randn(batch_size, self._n_dofs, device=self._device) * q0_noise, lo, hi)
+            assert q0.shape == (batch_size, self._n_dofs)
+        q = q0.clone().contiguous()
+        m, v = torch.zeros_like(q), torch.zeros_like(q)
+        loss = torch.empty(batch_size, device=self._device, dtype=torch.float32)
+        valid = torch.empty(batch_size, device=self._device, dtype=torch.uint8)
+        link = self._name_to_idx_map[link_name]
+        it = 0
+        for it in range(max_iters):
+            q_prev = q.clone() if (it % check_every == 0) else None
+            ops.ik_step(self._handle, link, Ht, lo, hi, q, m, v, it + 1, lr=lr, w_joint_limits=300.0, se3_eps=se3_eps,
+                        loss=loss, valid=valid)
+            if it % check_every == 0 and bool(valid.all()):
+                q = q_prev                      # the reference breaks BEFORE updating once every configuration is valid
+                print(f"\nIK converged for all joint configurations in {it} iterations")
+                break
+            if (it == 0 or (it % print_freq) == 0) and print_freq != -1:
+                print(f"\n---> Iter {it}/{max_iters}")
+                print(f"Error mean, std: {loss.mean():.3f}, {loss.std():.3f}")
+                print(f"idx_valid: {int(valid.sum())}/{batch_size}")
+        else:
+            if max_iters > 0:
+                print("\nIK did not converge for all joint configurations!")
+        idx_valid = torch.atleast_1d(torch.argwhere(valid.bool()).squeeze())
+        return q, idx_valid
+
     # -- model queries ----------------------------------------------------------------------------
     def get_joint_limits(self) -> List[Optional[Dict[str, float]]]:
         k, out = self._kin, []

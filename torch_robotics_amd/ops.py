@@ -185,6 +185,23 @@ def fk_analytic_jacobian(model: ModelHandle, q: torch.Tensor) -> torch.Tensor:
     return J
 
 
+def ik_step(model: ModelHandle, link: int, H_target: torch.Tensor, lower: torch.Tensor, upper: torch.Tensor,
+            q: torch.Tensor, adam_m: Optional[torch.Tensor], adam_v: Optional[torch.Tensor], step: int, lr: float = 1e-2,
+            w_joint_limits: float = 300.0, se3_eps: float = 1e-1, loss: Optional[torch.Tensor] = None,
+            valid: Optional[torch.Tensor] = None) -> None:
+    """One fused IK iteration IN PLACE on q / adam_m / adam_v (all (N, D) float32 contiguous CUDA tensors)."""
+    n, D = q.shape
+    assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and D == model.n_dofs
+    Ht = _dev_f32(H_target, "ik_step(H_target)")
+    per_sample = int(Ht.dim() == 3)
+    if per_sample and Ht.shape[0] != n:
+        raise ValueError("ik_step: per-sample target batch mismatch")
+    with torch.cuda.device(q.device):
+        check(lib().trk_ik_step(model._h, int(link), Ht.data_ptr(), per_sample, lower.data_ptr(), upper.data_ptr(),
+                                float(w_joint_limits), float(se3_eps), float(lr), int(step), n, q.data_ptr(),
+                                _ptr(adam_m), _ptr(adam_v), _ptr(loss), _ptr(valid), _stream(q)), "trk_ik_step")
+
+
 def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
     """rotation_matrix_to_q on (..., 3, 3) rotations or (..., 4, 4) transforms -> (..., 4) wxyz."""
     R = _dev_f32(R, "rotmat_to_quat(R)")
