@@ -142,6 +142,29 @@ int trk_fk_backward(const TrkModel* model, const float* q, const float* gH, int6
 int trk_fk_positions_backward(const TrkModel* model, const float* q, const float* gpos, int64_t n,
                               const int32_t* link_sel, int32_t n_sel, float* gq, trk_stream_t stream);
 
+/* ---- points rigidly attached to links ----------------------------------------------------------------------------
+ * reference: RobotPanda.fk_map_collision_impl robot_panda.py:154-168 (grasped-object collision points,
+ *            GraspedObjectPandaBox.get_base_points_for_collision objects.py:57-89) through Frame.transform_point
+ *            frame.py:116-118:  world = R_link * offset + t_link.  A zero offset is the link origin, so a point set
+ *            {all links, then the grasped points} is exactly what fk_map_collision returns: [N, L + G, 3].
+ *            Also carries per-link collision spheres (data/configs/panda/panda_sphere_config.yaml).
+ * point_link: host int32[n_points] link (file index) each point is fixed to; point_offset: host float[n_points*3]
+ * in that link's frame.  Output column k is point k.  The handle owns small device tables; immutable afterwards. */
+typedef struct TrkPointSet TrkPointSet;
+#define TRK_MAX_POINTS 192
+int trk_point_set_create(const TrkModel* model, const int32_t* point_link, const float* point_offset,
+                         int32_t n_points, TrkPointSet** out);
+void trk_point_set_destroy(TrkPointSet* ps);
+int trk_point_set_size(const TrkPointSet* ps);
+
+/* q [N,D] -> pos_out [N, n_points, 3]. */
+int trk_fk_points(const TrkModel* model, const TrkPointSet* ps, const float* q, int64_t n, float* pos_out,
+                  trk_stream_t stream);
+/* Explicit reverse mode of trk_fk_points (replaces autograd through the FK recursion and transform_point):
+ * gpos [N, n_points, 3] -> gq [N,D]; zero where the reference clamps (rigid_body.py:157-160). */
+int trk_fk_points_backward(const TrkModel* model, const TrkPointSet* ps, const float* q, const float* gpos, int64_t n,
+                           float* gq, trk_stream_t stream);
+
 /* Stateful FK + geometric Jacobian of one link.
  * reference: DifferentiableTree.compute_forward_kinematics_and_geometric_jacobian
  *            robot_tree.py:218-248 (update_kinematic_state :136-190, Frame.get_quaternion
@@ -304,6 +327,14 @@ int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const T
                           const float* q, int64_t batch, int32_t horizon,
                           float* link_pos_out, float* cost, float* gq, float* cost_block_sums,
                           trk_stream_t stream);
+
+/* trk_rollout_cost_grad with the collision fields evaluated on attached points instead of link origins: the cost
+ * model's position columns (n_links_in, obj_link_idx, self_link_idx) index the points of `ps`; ee_link stays a LINK
+ * index of the model.  point_pos_out [batch*horizon, n_points, 3] (nullable).  Same outputs otherwise. */
+int trk_rollout_points_cost_grad(const TrkModel* model, const TrkPointSet* ps, const TrkCostModel* cm,
+                                 const TrkRolloutWeights* w, const float* q, int64_t batch, int32_t horizon,
+                                 float* point_pos_out, float* cost, float* gq, float* cost_block_sums,
+                                 trk_stream_t stream);
 
 /* reference: interpolate_traj_via_points trajectory/utils.py:37-50 (used by PlanningTask.get_trajs_collision_and_free
  * tasks.py:234-251): x [T, H, D] -> out [T, (H-1)*n_interp, D], out[t, i*n+a] = x[t,i]*alpha[a] + x[t,i+1]*beta[a];

@@ -479,9 +479,122 @@ def misc_goldens():
     np.savez_compressed(GOLD / "traj.npz", **out)
 
 
+# ----------------------------------------------------------------------------
+# points fixed in link frames (grasped-object points; Frame.transform_point)
+# ----------------------------------------------------------------------------
+def points_goldens():
+    """`python oracle/gen_golden.py points` regenerates only these files."""
+    # (1) RobotPanda with a grasped box: fk_map_collision -> (b, h, 12 links + 14 points, 3) and its gradient.
+    # The reference would write a modified URDF into its own data directory (robots.py:47-51); its tree ships that
+    # file pre-generated, so the writer is replaced by a function returning the path of the shipped file.
+    import torch_robotics.torch_kinematics_tree.models.robots as ref_robots
+    from torch_robotics.environments.objects import GraspedObjectPandaBox
+    ref_robots.modidy_franka_panda_urdf_grasped_object = \
+        lambda robot_file, grasped_object: Path(str(robot_file).replace(".urdf", "_grasped_object.urdf"))
+    from torch_robotics.robots.robot_panda import RobotPanda
+
+    name = "panda_arm_no_gripper_grasped_object"
+    rel = f"franka_description/robots/{name}.urdf"
+    strip_urdf(REF_URDF / rel, URDF_OUT / f"{name}.urdf")
+    t_strip = quiet(DifferentiableTree, str(URDF_OUT / f"{name}.urdf"), name)
+    go = GraspedObjectPandaBox(tensor_args=TA)
+    robot = quiet(RobotPanda, grasped_object=go, tensor_args=TA)
+    torch.manual_seed(77)
+    gen = torch.Generator().manual_seed(78)
+    q = robot.random_q(32).view(4, 8, 7).clone().requires_grad_(True)
+    lp = robot.fk_map_collision(q)
+    w = torch.randn(lp.shape, generator=gen)
+    (gq,) = torch.autograd.grad((w * lp).sum(), q)
+    q2 = sample_q(robot.diff_panda, 16, gen, 0.2)
+    assert torch.equal(robot.diff_panda.compute_forward_kinematics_all_links(q2),
+                       t_strip.compute_forward_kinematics_all_links(q2))
+    q2 = q2.requires_grad_(True)
+    lp2 = robot.fk_map_collision(q2)
+    w2 = torch.randn(lp2.shape, generator=gen)
+    (gq2,) = torch.autograd.grad((w2 * lp2).sum(), q2)
+    # The reference's cost path with a grasped object raises (compute_costs_impl distance_fields.py:134-155 concatenates
+    # the grasped points onto the full link tensor, then margins (5+14) meet 5 columns; the self field's extra pair rows
+    # index past its 8 selected links).  The evident intent -- robot collision links followed by the grasped points,
+    # with the margins and pair tables RobotBase builds (robot_base.py:71-141) -- is evaluated here with the reference's
+    # own field code by giving each field the point columns explicitly and calling compute_embodiment_cost directly.
+    from torch_robotics.environments.env_spheres_3d import EnvSpheres3D
+    from torch_robotics.torch_planning_objectives.fields.distance_fields import (
+        CollisionObjectDistanceField, CollisionSelfField, CollisionWorkspaceBoundariesDistanceField)
+    env = EnvSpheres3D(tensor_args=TA)
+    L, G = len(robot.diff_panda.get_link_names()), go.n_base_points_for_collision
+    grasp_cols = list(range(L, L + G))
+    obj_cols = list(robot.link_idxs_for_object_collision_checking) + grasp_cols
+    self_cols = list(robot.link_idxs_for_self_collision_checking) + grasp_cols
+    cutoff = 0.03
+    f_obj = CollisionObjectDistanceField(
+        robot, df_obj_list_fn=env.get_df_obj_list, link_idxs_for_collision_checking=obj_cols,
+        link_margins_for_object_collision_checking_tensor=robot.link_margins_for_object_collision_checking_tensor,
+        cutoff_margin=cutoff, tensor_args=TA)
+    f_ws = CollisionWorkspaceBoundariesDistanceField(
+        robot, link_idxs_for_collision_checking=obj_cols,
+        link_margins_for_object_collision_checking_tensor=robot.link_margins_for_object_collision_checking_tensor,
+        cutoff_margin=cutoff, ws_bounds_min=env.limits[0], ws_bounds_max=env.limits[1], tensor_args=TA)
+    f_self = CollisionSelfField(
+        robot, link_idxs_for_collision_checking=self_cols,
+        idxs_links_distance_matrix=robot.df_collision_self.idxs_links_distance_matrix,
+        cutoff_margin=robot.df_collision_self.cutoff_margin, tensor_args=TA)
+    qc = q.detach().clone().requires_grad_(True)
+    lpc = robot.fk_map_collision(qc)
+    flat = lpc.reshape(-1, L + G, 3)
+    costs = {k: f.compute_embodiment_cost(None, flat).reshape(4, 8) for k, f in (("self", f_self), ("obj", f_obj), ("ws", f_ws))}
+    coll = {k: f.compute_embodiment_cost(None, flat, field_type="occupancy").reshape(4, 8)
+            for k, f in (("self", f_self), ("obj", f_obj), ("ws", f_ws))}
+    coll0 = {k: f.compute_embodiment_cost(None, flat, field_type="occupancy", margin=0.0).reshape(4, 8)
+             for k, f in (("self", f_self), ("obj", f_obj), ("ws", f_ws))}
+    total = costs["self"] + costs["obj"] + costs["ws"]
+    (g_lp,) = torch.autograd.grad(total.sum(), lpc, retain_graph=True)
+    (g_q,) = torch.autograd.grad(total.sum(), qc)
+    np.savez_compressed(
+        GOLD / "grasp_panda.npz",
+        cutoff=np.float32(cutoff), limits=env.limits.numpy(),
+        cost_self=costs["self"].detach().numpy(), cost_obj=costs["obj"].detach().numpy(),
+        cost_ws=costs["ws"].detach().numpy(), g_link_pos=g_lp.numpy(), gq_cost=g_q.numpy(),
+        coll_self=coll["self"].numpy(), coll_obj=coll["obj"].numpy(), coll_ws=coll["ws"].numpy(),
+        coll0_self=coll0["self"].numpy(), coll0_obj=coll0["obj"].numpy(), coll0_ws=coll0["ws"].numpy(),
+        link_names=np.array(robot.diff_panda.get_link_names()),
+        grasp_link=np.array(robot.link_name_grasped_object),
+        base_points=go.base_points_for_collision.numpy(),
+        grasp_pos=go.pos.numpy().reshape(3), grasp_ori=go.ori.numpy().reshape(4),
+        obj_margins=robot.link_margins_for_object_collision_checking_tensor.numpy(),
+        obj_link_idxs=np.asarray(robot.link_idxs_for_object_collision_checking, np.int32),
+        self_link_idxs=np.asarray(robot.link_idxs_for_self_collision_checking, np.int32),
+        self_pairs=np.asarray(robot.df_collision_self.idxs_links_distance_matrix, np.int32),
+        self_margins=robot.df_collision_self.cutoff_margin.numpy(),
+        q=q.detach().numpy(), link_pos=lp.detach().numpy(), w=w.numpy(), gq=gq.numpy(),
+        q_out=q2.detach().numpy(), link_pos_out=lp2.detach().numpy(), w_out=w2.numpy(), gq_out=gq2.numpy())
+    print("grasp_panda:", tuple(lp.shape))
+
+    # (2) random points on random links of the tree robots
+    for k, name in enumerate(("ur10_allegro", "dual_panda", "hab_stretch")):
+        tree = quiet(DifferentiableTree, str(URDF_OUT / f"{name}.urdf"), name)
+        names = tree.get_link_names()
+        gen = torch.Generator().manual_seed(900 + k)
+        P = 40
+        plink = torch.randint(0, len(names), (P,), generator=gen)
+        poff = (torch.rand(P, 3, generator=gen) - 0.5) * 0.4
+        poff[::7] = 0.0                                     # some points at link origins
+        q = sample_q(tree, 24, gen, 0.2).requires_grad_(True)
+        frames = tree.compute_forward_kinematics_all_links(q, return_dict=True)
+        cols = [frames[names[int(plink[j])]].transform_point(poff[j:j + 1])[:, 0, :] for j in range(P)]
+        pos = torch.stack(cols, dim=1)                      # (N, P, 3)
+        w = torch.randn(pos.shape, generator=gen)
+        (gq,) = torch.autograd.grad((w * pos).sum(), q)
+        np.savez_compressed(GOLD / f"points_{name}.npz", point_link=plink.numpy().astype(np.int32), point_offset=poff.numpy(),
+                            q=q.detach().numpy(), pos=pos.detach().numpy(), w=w.numpy(), gq=gq.numpy())
+        print(f"points_{name}:", tuple(pos.shape))
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     URDF_OUT.mkdir(parents=True, exist_ok=True)
+    if sys.argv[1:] == ["points"]:
+        points_goldens()
+        return
     trees = {}
     for name, rel in ROBOTS.items():
         strip_urdf(REF_URDF / rel, URDF_OUT / f"{name}.urdf")
@@ -508,6 +621,7 @@ def main():
     trajs_goldens()
     ik_goldens(trees)
     misc_goldens()
+    points_goldens()
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
 

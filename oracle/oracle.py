@@ -188,6 +188,46 @@ class Oracle:
                                             None if pos is None else _p(pos), _p(cost), _p(gq))
         return pos, cost, gq
 
+    # ------------------------------------------------------ attached points
+    @staticmethod
+    def _points(point_link, point_offset):
+        pl = np.ascontiguousarray(point_link, np.int32).reshape(-1)
+        po = np.ascontiguousarray(point_offset, np.float32).reshape(-1, 3)
+        assert pl.shape[0] == po.shape[0]
+        return pl, po
+
+    def fk_points(self, point_link, point_offset, q, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        pl, po = self._points(point_link, point_offset)
+        q = np.ascontiguousarray(q, npdt).reshape(-1, self.model.n_dofs)
+        out = np.empty((q.shape[0], pl.shape[0], 3), npdt)
+        getattr(lib(), "orc_fk_points" + suf)(C.byref(self.kd), _p(pl), _p(po), C.c_int(pl.shape[0]), _p(q),
+                                               C.c_int64(q.shape[0]), _p(out))
+        return out
+
+    def fk_points_backward(self, point_link, point_offset, q, gpos, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        pl, po = self._points(point_link, point_offset)
+        q = np.ascontiguousarray(q, npdt).reshape(-1, self.model.n_dofs)
+        g = np.ascontiguousarray(gpos, npdt).reshape(q.shape[0], pl.shape[0], 3)
+        gq = np.empty_like(q)
+        getattr(lib(), "orc_fk_points_backward" + suf)(C.byref(self.kd), _p(pl), _p(po), C.c_int(pl.shape[0]), _p(q), _p(g),
+                                                        C.c_int64(q.shape[0]), _p(gq))
+        return gq
+
+    def rollout_points(self, point_link, point_offset, q, weights, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        pl, po = self._points(point_link, point_offset)
+        D = self.model.n_dofs
+        q = np.ascontiguousarray(q, npdt).reshape(-1, D)
+        n = q.shape[0]
+        w = _abi.RolloutWeights(*[float(v) for v in weights])
+        pos = np.empty((n, pl.shape[0], 3), npdt)
+        cost, gq = np.empty(n, npdt), np.empty((n, D), npdt)
+        getattr(lib(), "orc_rollout_points" + suf)(C.byref(self.kd), _p(pl), _p(po), C.c_int(pl.shape[0]), C.byref(self.cd),
+                                                    C.byref(w), _p(q), C.c_int64(n), _p(pos), _p(cost), _p(gq))
+        return pos, cost, gq
+
     def grid_precompute(self, dims, lim_min, lim_max, prec="f32"):
         npdt, _, suf = _dt(prec)
         dims_a = np.ascontiguousarray(dims, np.int32)

@@ -80,3 +80,25 @@ def panda_cost_spec(g, robot, which="task", ee_target=None, ee_kw=None) -> CostM
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def grasp_panda_setup():
+    """RobotPanda holding GraspedObjectPandaBox (goldens: grasp_panda.npz, scene of cost_spheres3d.npz):
+    (KinModel, point_link, point_offset, CostModelSpec over the 12 link + 14 grasped-point columns)."""
+    g, gs = gold("grasp_panda"), gold("cost_spheres3d")
+    m = model("panda_arm_no_gripper_grasped_object")
+    L, G = m.n_links, g["base_points"].shape[0]
+    grasp_link = m.link_names.index(str(g["grasp_link"]))
+    point_link = np.concatenate([np.arange(L), np.full(G, grasp_link)]).astype(np.int32)
+    point_offset = np.concatenate([np.zeros((L, 3), np.float32), g["base_points"].astype(np.float32)])
+    cols = np.arange(L, L + G, dtype=np.int32)
+    spec = CostModelSpec(n_links_in=L + G)
+    spec.obj_link_idx = np.concatenate([g["obj_link_idxs"], cols]).astype(np.int32)
+    spec.obj_link_margin = (g["obj_margins"].astype(np.float32) + np.float32(g["cutoff"])).astype(np.float32)
+    spec.objects = objects_from_golden(gs, "fixed")
+    spec.ws_min, spec.ws_max = g["limits"][0], g["limits"][1]
+    spec.self_link_idx = np.concatenate([g["self_link_idxs"], cols]).astype(np.int32)
+    spec.self_pairs = g["self_pairs"]
+    spec.self_margin = g["self_margins"]
+    spec.validate()
+    return m, point_link, point_offset, spec

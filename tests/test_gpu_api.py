@@ -204,3 +204,40 @@ def test_inverse_kinematics_like_the_example():
     loss = tree.loss_fn_ik_per_q(dev(g["q0"]), dev(g["H_target"]), "ee_link", w_joint_limits=300.0,
                                  lower=dev(g["lower"]), upper=dev(g["upper"]))
     assert rel_err(loss.cpu().numpy(), g["loss0_per_sample"]) < TOL_C
+
+
+def test_grasped_object_like_the_reference():
+    """RobotPanda holding a box: fk_map_collision (pinned by the reference), the three fields and the
+    task-level cost over robot links + grasped points (pinned by the reference's field code on explicit columns)."""
+    g = gold("grasp_panda")
+    robot = tra.RobotPanda(grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA), tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=float(g["cutoff"]),
+                            tensor_args=TA)
+    q0 = dev(g["q"])
+    q = q0.clone().requires_grad_(True)
+    pos = robot.fk_map_collision(q)
+    assert pos.shape == (4, 8, 26, 3)
+    assert np.abs(pos.detach().cpu().numpy() - g["link_pos"]).max() < TOL_H
+    (pos * dev(g["w"])).sum().backward()
+    assert rel_err(q.grad.cpu().numpy(), g["gq"]) < TOL_G
+    p2 = robot.fk_map_collision(dev(g["q_out"]))
+    assert np.abs(p2.cpu().numpy() - g["link_pos_out"]).max() < TOL_H
+    for key, fld in zip(("self", "obj", "ws"), task.get_collision_fields()):
+        cost = fld.compute_cost(q0, pos.detach(), field_type="sdf")
+        assert cost.shape == (4, 8)
+        assert rel_err(cost.cpu().numpy(), g[f"cost_{key}"]) < TOL_C, key
+        np.testing.assert_array_equal(fld.compute_cost(q0, pos.detach(), field_type="occupancy").cpu().numpy(), g[f"coll_{key}"])
+        np.testing.assert_array_equal(fld.compute_cost(q0, pos.detach(), field_type="occupancy", margin=0.0).cpu().numpy(),
+                                      g[f"coll0_{key}"])
+    total_ref = g["cost_self"] + g["cost_obj"] + g["cost_ws"]
+    q = q0.clone().requires_grad_(True)
+    total = task.compute_collision_cost(q)
+    assert rel_err(total.detach().cpu().numpy(), total_ref) < TOL_C
+    total.sum().backward()
+    assert rel_err(q.grad.cpu().numpy(), g["gq_cost"]) < TOL_G
+    assert rel_err(task.compute_collision_cost(q0).cpu().numpy(), total_ref) < TOL_C
+    np.testing.assert_array_equal(task.compute_collision(q0).cpu().numpy(), g["coll_self"] | g["coll_obj"] | g["coll_ws"])
+    np.testing.assert_array_equal(task.compute_collision(q0, margin=0.0).cpu().numpy(),
+                                  g["coll0_self"] | g["coll0_obj"] | g["coll0_ws"])
+    ppos, cost, gq = task.rollout_cost_grad(q0)
+    assert ppos.shape == (4, 8, 26, 3) and rel_err(gq.cpu().numpy(), g["gq_cost"]) < TOL_G

@@ -435,3 +435,110 @@ def test_ik_step_vs_reference_adam(ops, oracle_lib):
         l64, _, _ = ot.ik_step(14, Htg.astype(np.float64), lo_t, hi_t, q64, m64, v64, it + 1, lr=5e-3, prec="f64")
         assert rel_err(loss.cpu().numpy(), l64) < 1e-4
         assert np.abs(q.cpu().numpy() - q64).max() < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# points fixed in link frames (grasped-object points, per-link spheres)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("robot", ["ur10_allegro", "dual_panda", "hab_stretch"])
+def test_attached_points_vs_golden(ops, robot):
+    g = gold(f"points_{robot}")
+    h = ops.ModelHandle(model(robot))
+    ps = ops.PointSetHandle(h, g["point_link"], g["point_offset"], DEV)
+    pos = ops.fk_points(ps, dev(g["q"])).cpu().numpy()
+    assert np.abs(pos - g["pos"]).max() / max(1.0, float(np.abs(g["pos"]).max())) < TOL_H
+    gq = ops.fk_points_backward(ps, dev(g["q"]), dev(g["w"])).cpu().numpy()
+    assert rel_err(gq, g["gq"]) < TOL_G
+    # autograd wrapper
+    q = dev(g["q"]).requires_grad_(True)
+    (ops.fk_points_ad(ps, q) * dev(g["w"])).sum().backward()
+    assert rel_err(q.grad.cpu().numpy(), g["gq"]) < TOL_G
+
+
+def test_attached_points_vs_fp64_oracle_ragged(ops, oracle_lib):
+    m = model("ur10_allegro")
+    h, o = ops.ModelHandle(m), oracle_lib.Oracle(m)
+    rng = np.random.default_rng(11)
+    for n, P in ((1, 1), (63, 7), (65, 64), (700, 100)):
+        pl = rng.integers(0, m.n_links, size=P).astype(np.int32)
+        po = rng.uniform(-0.3, 0.3, size=(P, 3)).astype(np.float32)
+        ps = ops.PointSetHandle(h, pl, po, DEV)
+        q = rng.uniform(-3.2, 3.2, size=(n, m.n_dofs)).astype(np.float32)
+        w = rng.standard_normal((n, P, 3)).astype(np.float32)
+        ref = o.fk_points(pl, po, q.astype(np.float64), "f64")
+        pos = ops.fk_points(ps, dev(q)).cpu().numpy()
+        assert np.abs(pos - ref).max() / max(1.0, float(np.abs(ref).max())) < TOL_H
+        gq = ops.fk_points_backward(ps, dev(q), dev(w)).cpu().numpy()
+        assert rel_err(gq, o.fk_points_backward(pl, po, q.astype(np.float64), w.astype(np.float64), "f64")) < TOL_G
+    with pytest.raises(NotImplementedError):
+        ops.PointSetHandle(h, np.zeros(500, np.int32), np.zeros((500, 3), np.float32), DEV)
+    with pytest.raises(ValueError):
+        ops.PointSetHandle(h, np.array([m.n_links], np.int32), np.zeros((1, 3), np.float32), DEV)
+    from torch_robotics_amd._lib import check, lib
+    other = ops.ModelHandle(model("ur10"))
+    ps = ops.PointSetHandle(h, np.zeros(1, np.int32), np.zeros((1, 3), np.float32), DEV)
+    out, qq = torch.empty((1, 1, 3), device=DEV), torch.zeros((1, other.n_dofs), device=DEV)
+    with pytest.raises(ValueError):       # a point set belongs to the model it was built for
+        check(lib().trk_fk_points(other._h, ps._h, qq.data_ptr(), 1, out.data_ptr(), None), "trk_fk_points")
+
+
+def test_grasped_object_vs_golden(ops):
+    """fk_map_collision of RobotPanda + GraspedObjectPandaBox, the three fields on links + grasped points, fused."""
+    from helpers import grasp_panda_setup
+    g = gold("grasp_panda")
+    m, pl, po, spec = grasp_panda_setup()
+    h = ops.ModelHandle(m)
+    ps = ops.PointSetHandle(h, pl, po, DEV)
+    for tag in ("", "_out"):
+        q = g["q" + tag].reshape(-1, 7)
+        pos = ops.fk_points(ps, dev(q)).cpu().numpy()
+        assert np.abs(pos - g["link_pos" + tag].reshape(-1, 26, 3)).max() < TOL_H
+        gq = ops.fk_points_backward(ps, dev(q), dev(g["w" + tag].reshape(-1, 26, 3))).cpu().numpy()
+        assert rel_err(gq, g["gq" + tag].reshape(-1, 7)) < TOL_G
+    cm = ops.CostHandle(spec, DEV)
+    lp = dev(g["link_pos"].reshape(-1, 26, 3))
+    total_g = np.zeros((32, 26, 3), np.float32)
+    for key, f in (("self", FIELD_SELF), ("obj", FIELD_OBJECTS), ("ws", FIELD_WS)):
+        c, gl = ops.cost_fields(cm, f, lp, want_grad=True)
+        assert rel_err(c.cpu().numpy(), g[f"cost_{key}"].reshape(-1)) < TOL_C
+        total_g += gl.cpu().numpy()
+        np.testing.assert_array_equal(ops.collision_fields(cm, f, lp).cpu().numpy(), g[f"coll_{key}"].reshape(-1))
+        np.testing.assert_array_equal(ops.collision_fields(cm, f, lp, 0.0).cpu().numpy(), g[f"coll0_{key}"].reshape(-1))
+    assert rel_err(total_g, g["g_link_pos"].reshape(-1, 26, 3)) < TOL_G
+    pos, cost, gq = ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 0), dev(g["q"]))
+    assert pos.shape == (4, 8, 26, 3) and cost.shape == (4, 8) and gq.shape == (4, 8, 7)
+    assert np.abs(pos.cpu().numpy() - g["link_pos"]).max() < TOL_H
+    assert rel_err(cost.cpu().numpy(), g["cost_self"] + g["cost_obj"] + g["cost_ws"]) < TOL_C
+    assert rel_err(gq.cpu().numpy(), g["gq_cost"]) < TOL_G
+
+
+def test_rollout_points_vs_fp64_oracle(ops, oracle_lib):
+    """Fused rollout over attached points on a tree robot: random spheres per link + EE tracking, ragged sizes."""
+    from torch_robotics_amd.costmodel import CostModelSpec, make_object, sphere_prims
+    m = model("dual_panda")
+    rng = np.random.default_rng(5)
+    P = 60
+    pl = rng.integers(1, m.n_links, size=P).astype(np.int32)
+    po = rng.uniform(-0.1, 0.1, size=(P, 3)).astype(np.float32)
+    spec = CostModelSpec(n_links_in=P)
+    spec.obj_link_idx = np.arange(P, dtype=np.int32)
+    spec.obj_link_margin = rng.uniform(0.02, 0.1, size=P).astype(np.float32)
+    spec.objects = [make_object(sphere_prims(rng.uniform(-0.8, 0.8, size=(12, 3)), rng.uniform(0.05, 0.2, size=12)))]
+    spec.ws_min, spec.ws_max = np.array([-1, -1, -1], np.float32), np.array([1, 1, 1], np.float32)
+    spec.self_link_idx = np.arange(0, P, 3, dtype=np.int32)
+    spec.self_pairs = np.array([(i, j) for i in range(20) for j in range(i) if (i + j) % 5 == 0], np.int32)
+    spec.self_margin = np.full(len(spec.self_pairs), 0.05, np.float32)
+    spec.ee_link = m.name_to_idx["left_ee_link"]
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.3, 0.5)
+    spec.ee_target = T
+    spec.validate()
+    h, o = ops.ModelHandle(m), oracle_lib.Oracle(m, spec)
+    ps, cm = ops.PointSetHandle(h, pl, po, DEV), ops.CostHandle(spec, DEV)
+    for n in (1, 65, 500):
+        q = rng.uniform(-2.5, 2.5, size=(n, m.n_dofs)).astype(np.float32)
+        for wts in ((1, 1, 1, 1), (0, 1, 0, 0), (0.5, 0, 2, 1)):
+            rp, rc, rg = o.rollout_points(pl, po, q.astype(np.float64), wts, "f64")
+            pos, cost, gq = ops.rollout_points_cost_grad(ps, cm, wts, dev(q))
+            assert np.abs(pos.cpu().numpy() - rp).max() < 2 * TOL_H
+            assert rel_err(cost.cpu().numpy(), rc) < TOL_C
+            assert rel_err(gq.cpu().numpy(), rg) < TOL_G

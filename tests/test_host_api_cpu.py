@@ -147,3 +147,33 @@ def test_finite_differences_match_reference():
     x = torch.as_tensor(g["x"])
     for m in ("forward", "backward", "central"):
         np.testing.assert_allclose(finite_difference_vector(x, dt=0.25, method=m).numpy(), g["fd_" + m], rtol=0, atol=0)
+
+
+def test_grasped_object_model_matches_reference():
+    """RobotPanda(grasped_object=GraspedObjectPandaBox) -- SURVEY 8f-4: kinematic tables equal the reference's
+    pre-generated URDF, the collision point set, margins and self-collision pair table equal RobotBase's."""
+    from helpers import grasp_panda_setup
+    g = gold("grasp_panda")
+    go = tra.GraspedObjectPandaBox(tensor_args=TA)
+    np.testing.assert_array_equal(go.base_points_for_collision.numpy(), g["base_points"])
+    np.testing.assert_array_equal(go.pos, g["grasp_pos"])
+    np.testing.assert_array_equal(go.ori, g["grasp_ori"])
+    robot = tra.RobotPanda(grasped_object=go, tensor_args=TA)
+    m_ref, pl, po, spec_ref = grasp_panda_setup()
+    k = robot.diff_panda._kin
+    assert k.link_names == m_ref.link_names == [str(s) for s in g["link_names"]]
+    for name in ("parent", "joint_type", "dof_idx", "R_fixed", "trans", "axis", "lower", "upper", "order"):
+        np.testing.assert_array_equal(getattr(k, name), getattr(m_ref, name), err_msg=name)
+    mine_pl, mine_po = robot.collision_point_set()
+    np.testing.assert_array_equal(mine_pl, pl)
+    np.testing.assert_array_equal(mine_po, po)
+    np.testing.assert_array_equal(robot.link_margins_for_object_collision_checking_tensor.numpy(), g["obj_margins"])
+    np.testing.assert_array_equal(robot.df_collision_self.idxs_links_distance_matrix, g["self_pairs"])
+    np.testing.assert_array_equal(robot.df_collision_self.cutoff_margin.numpy(), g["self_margins"])
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=float(g["cutoff"]),
+                            tensor_args=TA)
+    mine = task.build_cost_spec()
+    mine.validate()
+    assert mine.n_links_in == 26
+    for name in ("obj_link_idx", "obj_link_margin", "self_link_idx", "self_pairs", "self_margin", "ws_min", "ws_max"):
+        np.testing.assert_array_equal(getattr(mine, name), getattr(spec_ref, name), err_msg=name)

@@ -217,3 +217,66 @@ def test_ik_loss_gradient_and_adam_steps(oracle_lib, prec):
                 np.testing.assert_array_equal(valid, g[f"valid0_{tag}"])
             assert rel_err(loss, g[f"err_steps_{tag}"][it]) < 2e-4
             assert np.abs(q - g[f"q_steps_{tag}"][it]).max() < 2e-4       # Adam's first steps are +-lr whatever |g| is
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# points fixed in link frames (grasped-object points; Frame.transform_point)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("robot", ["ur10_allegro", "dual_panda", "hab_stretch"])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_attached_points_on_trees(oracle_lib, robot, prec):
+    g = gold(f"points_{robot}")
+    o = oracle_lib.Oracle(model(robot))
+    pos = o.fk_points(g["point_link"], g["point_offset"], g["q"], prec)
+    assert np.abs(pos - g["pos"]).max() / max(1.0, float(np.abs(g["pos"]).max())) < TOL_H
+    gq = o.fk_points_backward(g["point_link"], g["point_offset"], g["q"], g["w"], prec)
+    assert rel_err(gq, g["gq"]) < TOL_G
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_grasped_object_fk_map_collision(oracle_lib, prec):
+    """RobotPanda(grasped_object=GraspedObjectPandaBox).fk_map_collision: 12 link origins + 14 box points."""
+    from helpers import grasp_panda_setup
+    g = gold("grasp_panda")
+    m, pl, po, spec = grasp_panda_setup()
+    o = oracle_lib.Oracle(m, spec)
+    for tag in ("", "_out"):
+        q, ref = g["q" + tag].reshape(-1, 7), g["link_pos" + tag].reshape(-1, 26, 3)
+        pos = o.fk_points(pl, po, q, prec)
+        assert np.abs(pos - ref).max() < TOL_H
+        gq = o.fk_points_backward(pl, po, q, g["w" + tag].reshape(-1, 26, 3), prec)
+        assert rel_err(gq, g["gq" + tag].reshape(-1, 7)) < TOL_G
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_grasped_object_costs(oracle_lib, prec):
+    """The three collision fields over robot links + grasped points (reference field code on explicit columns)."""
+    from helpers import grasp_panda_setup
+    g = gold("grasp_panda")
+    m, pl, po, spec = grasp_panda_setup()
+    o = oracle_lib.Oracle(m, spec)
+    lp = g["link_pos"].reshape(-1, 26, 3)
+    total_g = np.zeros_like(lp)
+    for key, f in (("self", FIELD_SELF), ("obj", FIELD_OBJECTS), ("ws", FIELD_WS)):
+        c, gl = o.cost_fields(f, lp, prec)
+        assert rel_err(c, g[f"cost_{key}"].reshape(-1)) < 5e-6
+        total_g += gl
+        np.testing.assert_array_equal(o.collision_fields(f, lp, None, prec), g[f"coll_{key}"].reshape(-1))
+        np.testing.assert_array_equal(o.collision_fields(f, lp, 0.0, prec), g[f"coll0_{key}"].reshape(-1))
+    assert rel_err(total_g, g["g_link_pos"].reshape(-1, 26, 3)) < 2e-5
+    pos, cost, gq = o.rollout_points(pl, po, g["q"].reshape(-1, 7), (1, 1, 1, 0), prec)
+    assert np.abs(pos - lp).max() < TOL_H
+    assert rel_err(cost, (g["cost_self"] + g["cost_obj"] + g["cost_ws"]).reshape(-1)) < 5e-6
+    assert rel_err(gq, g["gq_cost"].reshape(-1, 7)) < 2e-5
+
+
+def test_rollout_points_with_link_origins_equals_rollout(oracle_lib):
+    """A point set {every link, zero offset} reduces the point rollout to the link rollout (incl. the EE term)."""
+    g, robot = gold("rollout_panda"), gold("panda_robot")
+    spec = panda_cost_spec(gold("cost_spheres3d"), robot, ee_target=g["target"])
+    o = oracle_lib.Oracle(model("panda_arm_no_gripper"), spec)
+    q = g["q"].reshape(-1, 7)[:64]
+    ref = o.rollout(q, (1, 1, 1, 1), "f64")
+    got = o.rollout_points(np.arange(11), np.zeros((11, 3)), q, (1, 1, 1, 1), "f64")
+    for a, b in zip(ref, got):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)

@@ -12,7 +12,8 @@ from .kinematics import (DifferentiableTree, DifferentiableFrankaPanda, Differen
                          DifferentiableHabitatStretch, DifferentiableTiagoDualHoloMove,
                          DifferentiableUR10Allegro, DifferentiableDualPanda, Frame)
 from .environments import (MultiSphereField, MultiBoxField, MultiSharpBoxField, ObjectField, GridMapSDF,  # noqa: F401
-                           EnvBase, EnvSpheres3D, EnvSpheres3DExtraObjects, EnvTableShelf, EnvMazeBoxes3D)
+                           EnvBase, EnvSpheres3D, EnvSpheres3DExtraObjects, EnvTableShelf, EnvMazeBoxes3D,
+                           GraspedObject, GraspedObjectPandaBox)
 from .fields import (DistanceField, CollisionSelfField, CollisionObjectDistanceField,  # noqa: F401
                      CollisionWorkspaceBoundariesDistanceField, EESE3DistanceField)
 from .robots import RobotBase, RobotPanda  # noqa: F401

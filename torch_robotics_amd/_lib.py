@@ -26,6 +26,8 @@ EXPORTS = [
     "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_reduce_sum", "trk_debug_set_stamp_buffer", "trk_interpolate_via_points",
     "trk_grid_precompute",
     "trk_sdf_points",
+    "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_fk_points", "trk_fk_points_backward",
+    "trk_rollout_points_cost_grad",
 ]
 
 
@@ -86,9 +88,16 @@ def lib():
     L.trk_reduce_sum.argtypes = [vp, i64, vp, vp]
     L.trk_grid_precompute.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.trk_sdf_points.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.trk_point_set_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
+    L.trk_point_set_destroy.argtypes = [vp]
+    L.trk_point_set_destroy.restype = None
+    L.trk_point_set_size.argtypes = [vp]
+    L.trk_fk_points.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.trk_fk_points_backward.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+    L.trk_rollout_points_cost_grad.argtypes = [vp, vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)        # AttributeError here = the library does not export the ABI
-        if name not in ("trk_last_error", "trk_model_destroy", "trk_cost_model_destroy"):
+        if name not in ("trk_last_error", "trk_model_destroy", "trk_cost_model_destroy", "trk_point_set_destroy"):
             fn.restype = C.c_int
     if L.trk_abi_version() != _abi.TRK_ABI_VERSION:
         raise TrkError("libtrk.so ABI version mismatch; rebuild it")

@@ -72,9 +72,16 @@ struct TrkModel {
     DevLink* d_links = nullptr;
     int32_t* d_fin = nullptr;
     int32_t* d_dofs = nullptr;             // [D] {pos, subtree end, joint type, pad}
+    std::vector<int32_t> pos_of_link;      // link (file index) -> pre-order position
     bool unsupported = false;
     const SpecEntry* spec = nullptr;     // model-specialised fused kernel, if one was built for these tables
     bool spec_enabled = true;
+};
+
+struct TrkPointSet {
+    DevPointSet dev;
+    void* d_blob = nullptr;
+    const TrkModel* model = nullptr;
 };
 
 struct TrkCostModel {
@@ -131,6 +138,8 @@ int trk_model_create(const TrkKinModelDesc* d, TrkModel** out) {
     std::memcpy(m->hdr.base_t, d->base_t, sizeof(float) * 3);
     m->links.resize(L);
     m->joint_list_idx.assign(d->joint_list_idx, d->joint_list_idx + L);
+    m->pos_of_link.assign(L, 0);
+    for (int p = 0; p < L; ++p) m->pos_of_link[d->order[p]] = p;
     for (int p = 0; p < L; ++p) {
         const int i = d->order[p];
         DevLink& k = m->links[p];
@@ -262,6 +271,79 @@ int trk_fk_backward(const TrkModel* m, const float* q, const float* gH, int64_t 
 }
 int trk_fk_positions_backward(const TrkModel* m, const float* q, const float* gpos, int64_t n, const int32_t* link_sel, int32_t n_sel, float* gq, trk_stream_t stream) {
     return fk_bwd(1, m, q, gpos, n, link_sel, n_sel, gq, stream, "trk_fk_positions_backward");
+}
+
+int trk_point_set_create(const TrkModel* m, const int32_t* point_link, const float* point_offset, int32_t n_points,
+                         TrkPointSet** out) {
+    if (!m || !out || !point_link || !point_offset) return fail(TRK_ERR_INVALID_ARG, "trk_point_set_create: null argument");
+    if (n_points < 1 || n_points > TRK_MAX_POINTS) return fail(TRK_ERR_UNSUPPORTED, "trk_point_set_create: n_points out of range [1, 192]");
+    const int L = m->hdr.n_links;
+    for (int k = 0; k < n_points; ++k)
+        if (point_link[k] < 0 || point_link[k] >= L) return fail(TRK_ERR_INVALID_ARG, "trk_point_set_create: link index out of range");
+    // sort by the pre-order position of the owning link (stable: keeps the caller's order inside a link)
+    std::vector<int32_t> begin(L + 1, 0);
+    for (int k = 0; k < n_points; ++k) ++begin[m->pos_of_link[point_link[k]] + 1];
+    for (int p = 0; p < L; ++p) begin[p + 1] += begin[p];
+    std::vector<DevPoint> pts(n_points);
+    std::vector<int32_t> fill(begin.begin(), begin.end() - 1);
+    for (int k = 0; k < n_points; ++k) {
+        DevPoint& d = pts[fill[m->pos_of_link[point_link[k]]]++];
+        std::memcpy(d.off, point_offset + 3 * k, sizeof(float) * 3);
+        d.col = k;
+    }
+    const size_t o_begin = sizeof(DevPoint) * n_points;
+    const size_t total = o_begin + sizeof(int32_t) * (L + 1);
+    TrkPointSet* ps = new (std::nothrow) TrkPointSet();
+    if (!ps) return fail(TRK_ERR_HIP, "out of host memory");
+    hipError_t e = hipMalloc(&ps->d_blob, total);
+    if (e == hipSuccess) e = hipMemcpy(ps->d_blob, pts.data(), o_begin, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(static_cast<char*>(ps->d_blob) + o_begin, begin.data(), sizeof(int32_t) * (L + 1), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (ps->d_blob) (void)hipFree(ps->d_blob);
+        delete ps;
+        return hip_fail(e, "trk_point_set_create: device allocation/copy");
+    }
+    ps->dev.pts = static_cast<const DevPoint*>(ps->d_blob);
+    ps->dev.begin = reinterpret_cast<const int32_t*>(static_cast<char*>(ps->d_blob) + o_begin);
+    ps->dev.n_points = n_points; ps->dev._pad = 0;
+    ps->model = m;
+    *out = ps;
+    return TRK_OK;
+}
+
+void trk_point_set_destroy(TrkPointSet* ps) {
+    if (!ps) return;
+    if (ps->d_blob) (void)hipFree(ps->d_blob);
+    delete ps;
+}
+
+int trk_point_set_size(const TrkPointSet* ps) { return ps ? ps->dev.n_points : TRK_ERR_INVALID_ARG; }
+
+static const size_t kMaxLds = 160 * 1024;
+
+int trk_fk_points(const TrkModel* m, const TrkPointSet* ps, const float* q, int64_t n, float* pos_out, trk_stream_t stream) {
+    int rc = check_model(m, "trk_fk_points");
+    if (rc) return rc;
+    if (!ps || ps->model != m) return fail(TRK_ERR_INVALID_ARG, "trk_fk_points: point set does not belong to this model");
+    if (n < 0 || (n > 0 && (!pos_out || (!q && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_points: bad q/out/n");
+    if (trk_lds_fk_points(m->hdr, ps->dev.n_points, false) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_fk_points: point tile exceeds the 160 KiB LDS");
+    if (n == 0) return TRK_OK;
+    trk_launch_fk_points(m->hdr, m->d_links, ps->dev, q, n, pos_out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_fk_points_backward(const TrkModel* m, const TrkPointSet* ps, const float* q, const float* gpos, int64_t n, float* gq,
+                           trk_stream_t stream) {
+    int rc = check_model(m, "trk_fk_points_backward");
+    if (rc) return rc;
+    if (!ps || ps->model != m) return fail(TRK_ERR_INVALID_ARG, "trk_fk_points_backward: point set does not belong to this model");
+    if (n < 0 || (n > 0 && (!gpos || ((!q || !gq) && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_points_backward: bad q/g/n");
+    if (trk_lds_fk_points(m->hdr, ps->dev.n_points, true) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_fk_points_backward: point tile exceeds the 160 KiB LDS");
+    if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    trk_launch_fk_points_backward(m->hdr, m->d_links, m->d_fin, ps->dev, q, gpos, n, gq, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
 }
 
 int trk_fk_jacobian(const TrkModel* m, const float* q, const float* qd, int64_t n, int32_t link, float* pos, float* quat,
@@ -544,7 +626,26 @@ int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRo
             return TRK_OK;
         }
     }
-    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, cm->hdr, *w, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
+    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, nullptr, cm->hdr, *w, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const TrkCostModel* cm, const TrkRolloutWeights* w,
+                                 const float* q, int64_t batch, int32_t horizon, float* point_pos_out, float* cost, float* gq,
+                                 float* cost_sum, trk_stream_t stream) {
+    int rc = check_model(m, "trk_rollout_points_cost_grad");
+    if (rc) return rc;
+    if (!cm || !w) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: null argument");
+    if (!ps || ps->model != m) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: point set does not belong to this model");
+    if (batch < 0 || horizon < 1) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: bad batch/horizon");
+    if (cm->hdr.n_links_in != ps->dev.n_points) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: cost model n_links_in != number of points");
+    if (cm->hdr.ee_link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: ee_link is not a link of the model");
+    if (trk_lds_rollout(m->hdr, ps->dev.n_points) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_points_cost_grad: point tiles exceed the 160 KiB LDS");
+    const int64_t n = batch * horizon;
+    if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: null q/cost/gq");
+    if (n == 0) return TRK_OK;
+    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, &ps->dev, cm->hdr, *w, q, n, point_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }

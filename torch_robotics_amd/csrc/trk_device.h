@@ -93,6 +93,17 @@ struct DevCostHdr {
     DevGrid grid;
 };
 
+// Points rigidly attached to links (grasped-object points robot_panda.py:154-168, per-link collision spheres):
+// world position = R_link * off + t_link (Frame.transform_point frame.py:116-118).  pts[] is sorted by the pre-order
+// position of the owning link; begin[p] .. begin[p+1] is the range of position p; col = output column.
+struct alignas(16) DevPoint { float off[3]; int32_t col; };
+struct DevPointSet {
+    const DevPoint* pts;        // device
+    const int32_t* begin;       // device [n_links + 1]
+    int32_t n_points;
+    int32_t _pad;
+};
+
 struct SelMap {                 // link (file index) -> output column, -1 = not selected
     int32_t col[TRK_MAX_LINKS];
 };

@@ -280,6 +280,102 @@ k_fk_backward(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t*
 }
 
 // ============================================================================================
+// Attached points: world positions of points fixed in link frames, R_link * off + t_link
+// (Frame.transform_point frame.py:116-118 as used by RobotPanda.fk_map_collision_impl robot_panda.py:154-168),
+// and the explicit reverse mode.  A point adjoint g is the wrench (g, p x g) on its link:
+// tbar = sum g, Rbar = sum g off^T  (the shared reverse walk turns Rbar R^T into the torque sum (R off) x g).
+// LDS: q | pose slots | point tile [64][3P|1].
+// ============================================================================================
+__device__ __forceinline__ void points_of_link(const DevPointSet& ps, int p, const Pose& cur, float* row) {
+    const int b = cptr(ps.begin)[p], e = cptr(ps.begin)[p + 1];
+    for (int k = b; k < e; ++k) {
+        const TRK_CAS DevPoint* pt = cptr(ps.pts) + k;
+        const float c0 = pt->off[0], c1 = pt->off[1], c2 = pt->off[2];
+        float* o = row + 3 * pt->col;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            o[r] = fmaf(cur.r[3 * r], c0, fmaf(cur.r[3 * r + 1], c1, fmaf(cur.r[3 * r + 2], c2, cur.t[r])));
+    }
+}
+
+__global__ void __launch_bounds__(TRK_WAVE)
+k_fk_points(DevModelHdr hdr, const DevLink* __restrict__ links, DevPointSet ps, const float* __restrict__ q, int64_t n,
+            float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int D = hdr.n_dofs, L = hdr.n_links;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    float* qs = smem;
+    float* slots = qs + TRK_WAVE * D;
+    float* tile = slots + hdr.n_slots * 12 * TRK_WAVE;
+    const int width = ps.n_points * 3, rs = width | 1;
+    load_tile(qs, q, base * D, (int64_t)rows * D, lane);
+    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
+    __syncthreads();
+    Pose cur, par;
+    for (int p = 0; p < L; ++p) {
+        walk_step<false>(hdr, links[p], p, qs, D, lane, slots, cur, par);
+        points_of_link(ps, p, cur, tile + lane * rs);
+    }
+    __syncthreads();
+    store_tile_strided(out, tile, base * width, rows, width, rs, lane);
+}
+
+struct AdjFromPoints {    // point adjoints from an LDS tile [64][rs] (+ optional EE pose adjoint on one link)
+    const float* gtile; int rs; int lane; DevPointSet ps; int ee_link; const float* eeRb; const float* eetb;
+    __device__ __forceinline__ bool has_rot(const DevLink&) const { return true; }
+    __device__ __forceinline__ bool operator()(const DevLink& Lk, int p, const Pose&, float* Rb, float* tb) const {
+        const int b = cptr(ps.begin)[p], e = cptr(ps.begin)[p + 1];
+        const bool ee = Lk.link == ee_link;
+        if (b == e && !ee) return false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rb[k] = ee ? eeRb[k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tb[k] = ee ? eetb[k] : 0.0f;
+        for (int k = b; k < e; ++k) {
+            const TRK_CAS DevPoint* pt = cptr(ps.pts) + k;
+            const float c0 = pt->off[0], c1 = pt->off[1], c2 = pt->off[2];
+            const float* g = gtile + lane * rs + 3 * pt->col;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float gr = g[r];
+                tb[r] += gr;
+                Rb[3 * r] = fmaf(gr, c0, Rb[3 * r]); Rb[3 * r + 1] = fmaf(gr, c1, Rb[3 * r + 1]); Rb[3 * r + 2] = fmaf(gr, c2, Rb[3 * r + 2]);
+            }
+        }
+        return true;
+    }
+};
+
+__global__ void __launch_bounds__(TRK_WAVE)
+k_fk_points_backward(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, DevPointSet ps,
+                     const float* __restrict__ q, const float* __restrict__ gin, int64_t n, float* __restrict__ gq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x;
+    const int D = hdr.n_dofs;
+    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
+    const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    float* qs = smem;
+    float* gqs = qs + TRK_WAVE * D;
+    float* jst = gqs + TRK_WAVE * D;
+    float* slots = jst + 7 * D * TRK_WAVE;
+    float* tile = slots + hdr.n_slots * 12 * TRK_WAVE;
+    const int width = ps.n_points * 3, rs = width | 1;
+    load_tile(qs, q, base * D, (int64_t)rows * D, lane);
+    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
+    for (int k = lane; k < TRK_WAVE * D; k += TRK_WAVE) gqs[k] = 0.0f;
+    for (int k = lane; k < TRK_WAVE * rs; k += TRK_WAVE) tile[k] = 0.0f;
+    __syncthreads();
+    load_tile_strided(tile, gin, base * width, rows, width, rs, lane);
+    __syncthreads();
+    AdjFromPoints adj{tile, rs, lane, ps, -1, nullptr, nullptr};
+    reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+    __syncthreads();
+    store_tile(gq, gqs, base * D, (int64_t)rows * D, lane);
+}
+
+// ============================================================================================
 // One iteration of DifferentiableTree.inverse_kinematics (robot_tree.py:345-377) as ONE kernel: FK of the target link,
 // SE3_distance + joint-limit hinge (loss_fn_ik_per_q :386-417), its gradient (reverse walk), the termination test
 // (ik_termination :419-442, on q BEFORE the update) and the Adam update (torch.optim.Adam defaults), all per lane.
@@ -511,8 +607,9 @@ k_ee_cost(DevCostHdr C, const float* __restrict__ H, int64_t n, int64_t stride, 
 // Fused rollout, table-driven: walk 1 (FK -> position tile, EE rotation), costs + position adjoints,
 // walk 2 (reverse pass).  q [N,D] -> link_pos [N,L,3] (nullable), cost [N], gq [N,D], cost_sum (nullable).
 // ============================================================================================
+template <bool POINTS>     // POINTS: the cost model's columns are the attached points of `ps`, not the links
 __global__ void __launch_bounds__(TRK_WAVE)
-k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, SelMap sel_unused, DevCostHdr C,
+k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, SelMap sel_unused, DevPointSet ps, DevCostHdr C,
                   TrkRolloutWeights w, const float* __restrict__ q, int64_t n, float* __restrict__ link_pos,
                   float* __restrict__ cost, float* __restrict__ gq, float* __restrict__ cost_sum) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -520,7 +617,7 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     const int D = hdr.n_dofs, L = hdr.n_links;
     const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
     const int rows = (int)min((int64_t)TRK_WAVE, n - base);
-    const int width = L * 3, rs = width | 1;
+    const int width = (POINTS ? ps.n_points : L) * 3, rs = width | 1;
     float* qs = smem;
     float* gqs = qs + TRK_WAVE * D;
     float* jst = gqs + TRK_WAVE * D;
@@ -539,8 +636,11 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
         for (int p = 0; p < L; ++p) {
             const DevLink& Lk = links[p];
             walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
-            float* o = tile + lane * rs + 3 * Lk.link;
-            o[0] = cur.t[0]; o[1] = cur.t[1]; o[2] = cur.t[2];
+            if (POINTS) points_of_link(ps, p, cur, tile + lane * rs);
+            else {
+                float* o = tile + lane * rs + 3 * Lk.link;
+                o[0] = cur.t[0]; o[1] = cur.t[1]; o[2] = cur.t[2];
+            }
             if (Lk.link == C.ee_link) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) eeR[k] = cur.r[k];
@@ -554,7 +654,7 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     if (w.w_obj != 0.0f) fields |= TRK_FIELD_OBJECTS;
     if (w.w_ws != 0.0f) fields |= TRK_FIELD_WS;
     float c = fields_eval<false>(C, fields, w.w_self, w.w_obj, w.w_ws, tile, gtile, rs, lane);
-    float eeRb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float eeRb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, eetb[3] = {0, 0, 0};
     const bool use_ee = (w.w_ee != 0.0f) && (C.ee_link >= 0);
     if (use_ee) {
         float gt[3];
@@ -562,8 +662,11 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
         c = fmaf(w.w_ee, ce, c);
 #pragma unroll
         for (int k = 0; k < 9; ++k) eeRb[k] *= w.w_ee;
-        float* g = gtile + lane * rs + 3 * C.ee_link;
-        g[0] = fmaf(w.w_ee, gt[0], g[0]); g[1] = fmaf(w.w_ee, gt[1], g[1]); g[2] = fmaf(w.w_ee, gt[2], g[2]);
+        if (POINTS) { eetb[0] = w.w_ee * gt[0]; eetb[1] = w.w_ee * gt[1]; eetb[2] = w.w_ee * gt[2]; }
+        else {
+            float* g = gtile + lane * rs + 3 * C.ee_link;
+            g[0] = fmaf(w.w_ee, gt[0], g[0]); g[1] = fmaf(w.w_ee, gt[1], g[1]); g[2] = fmaf(w.w_ee, gt[2], g[2]);
+        }
     }
     if (lane < rows) cost[base + lane] = c;
     if (cost_sum) {     // per-wavefront partial sum: no atomics (4096 same-address atomics cost ~47 us on MI355X)
@@ -571,8 +674,13 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
         if (lane == 0) cost_sum[blockIdx.x] = tot;
     }
     // walk 2: reverse pass
-    AdjFromTile<true> adj{gtile, rs, lane, sel_unused, use_ee ? C.ee_link : -1, eeRb};
-    reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+    if (POINTS) {
+        AdjFromPoints adj{gtile, rs, lane, ps, use_ee ? C.ee_link : -1, eeRb, eetb};
+        reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+    } else {
+        AdjFromTile<true> adj{gtile, rs, lane, sel_unused, use_ee ? C.ee_link : -1, eeRb};
+        reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+    }
     __syncthreads();
     store_tile(gq, gqs, base * D, (int64_t)rows * D, lane);
     if (link_pos) store_tile_strided(link_pos, tile, base * width, rows, width, rs, lane);
@@ -975,12 +1083,34 @@ void trk_launch_ee_cost(const DevCostHdr& C, const float* H, int64_t n, int64_t 
     hipLaunchKernelGGL(k_ee_cost, dim3(grid_for(n, 256)), dim3(256), 0, st, C, H, n, stride, target, per_sample, gcost, cost, gH, g_stride);
 }
 
-void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevCostHdr& C,
-                                const TrkRolloutWeights& w, const float* q, int64_t n, float* link_pos, float* cost,
-                                float* gq, float* cost_sum, hipStream_t st) {
-    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
-                                  2 * (size_t)TRK_WAVE * ((hdr.n_links * 3) | 1));
-    hipLaunchKernelGGL(k_rollout_generic, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, SelMap{}, C, w, q, n, link_pos, cost, gq, cost_sum);
+size_t trk_lds_rollout(const DevModelHdr& hdr, int n_cols) {
+    return sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
+                            2 * (size_t)TRK_WAVE * ((n_cols * 3) | 1));
+}
+size_t trk_lds_fk_points(const DevModelHdr& hdr, int n_points, bool backward) {
+    return sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * (backward ? 9 : 1) + (size_t)hdr.n_slots * 12 * TRK_WAVE +
+                            (size_t)TRK_WAVE * ((n_points * 3) | 1));
+}
+
+void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet* ps,
+                                const DevCostHdr& C, const TrkRolloutWeights& w, const float* q, int64_t n, float* link_pos,
+                                float* cost, float* gq, float* cost_sum, hipStream_t st) {
+    if (ps) hipLaunchKernelGGL(k_rollout_generic<true>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, ps->n_points), st,
+                               hdr, links, fin, SelMap{}, *ps, C, w, q, n, link_pos, cost, gq, cost_sum);
+    else hipLaunchKernelGGL(k_rollout_generic<false>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, hdr.n_links), st,
+                            hdr, links, fin, SelMap{}, DevPointSet{}, C, w, q, n, link_pos, cost, gq, cost_sum);
+}
+
+void trk_launch_fk_points(const DevModelHdr& hdr, const DevLink* links, const DevPointSet& ps, const float* q, int64_t n,
+                          float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_fk_points, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_fk_points(hdr, ps.n_points, false), st,
+                       hdr, links, ps, q, n, out);
+}
+
+void trk_launch_fk_points_backward(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet& ps,
+                                   const float* q, const float* gin, int64_t n, float* gq, hipStream_t st) {
+    hipLaunchKernelGGL(k_fk_points_backward, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_fk_points(hdr, ps.n_points, true), st,
+                       hdr, links, fin, ps, q, gin, n, gq);
 }
 
 void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links, const float* q, const float* qd, int64_t n,
@@ -1028,7 +1158,8 @@ int trk_kernels_init(void) {
     hipError_t e = hipSuccess;
 #define TRK_SET(k) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
     TRK_SET(k_fk_forward<0>); TRK_SET(k_fk_forward<1>); TRK_SET(k_fk_backward<0>); TRK_SET(k_fk_backward<1>);
-    TRK_SET(k_cost_fields); TRK_SET(k_collision_fields); TRK_SET(k_rollout_generic); TRK_SET(k_fk_jacobian);
+    TRK_SET(k_cost_fields); TRK_SET(k_collision_fields); TRK_SET(k_rollout_generic<false>); TRK_SET(k_rollout_generic<true>);
+    TRK_SET(k_fk_jacobian); TRK_SET(k_fk_points); TRK_SET(k_fk_points_backward);
     TRK_SET(k_fk_analytic_jacobian); TRK_SET(k_ik_step);
 #undef TRK_SET
     return e == hipSuccess ? 0 : -1;

@@ -16,9 +16,16 @@ void trk_launch_collision_fields(const DevCostHdr& C, int fields, const float* l
                                  int use_default, uint8_t* out, hipStream_t st);
 void trk_launch_ee_cost(const DevCostHdr& C, const float* H, int64_t n, int64_t stride, const float* target, int per_sample,
                         const float* gcost, float* cost, float* gH, int64_t g_stride, hipStream_t st);
-void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevCostHdr& C,
-                                const TrkRolloutWeights& w, const float* q, int64_t n, float* link_pos, float* cost,
-                                float* gq, float* cost_sum, hipStream_t st);
+// ps == nullptr: the cost model's columns are the links; otherwise the attached points of *ps
+void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet* ps,
+                                const DevCostHdr& C, const TrkRolloutWeights& w, const float* q, int64_t n, float* link_pos,
+                                float* cost, float* gq, float* cost_sum, hipStream_t st);
+void trk_launch_fk_points(const DevModelHdr& hdr, const DevLink* links, const DevPointSet& ps, const float* q, int64_t n,
+                          float* out, hipStream_t st);
+void trk_launch_fk_points_backward(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet& ps,
+                                   const float* q, const float* gin, int64_t n, float* gq, hipStream_t st);
+size_t trk_lds_rollout(const DevModelHdr& hdr, int n_cols);                 // dynamic LDS bytes a launch needs
+size_t trk_lds_fk_points(const DevModelHdr& hdr, int n_points, bool backward);
 void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links, const float* q, const float* qd, int64_t n,
                             int link, int link_joint_idx, float* pos, float* quat, float* lin_jac, float* ang_jac,
                             float* vel_lin, float* vel_ang, hipStream_t st);

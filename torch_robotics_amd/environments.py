@@ -131,6 +131,36 @@ class ObjectField(PrimitiveShapeField):                      # primitives.py:346
         pass
 
 
+class GraspedObject(ObjectField):                             # objects.py:10-34
+    """An object rigidly held by the end effector; pos / ori are relative to `reference_frame` (a robot link)."""
+
+    def __init__(self, primitive_fields, **kwargs):
+        assert len(primitive_fields) == 1                       # only one primitive type
+        super().__init__(primitive_fields, **kwargs)
+        if not isinstance(primitive_fields[0], MultiBoxField):
+            raise NotImplementedError                           # objects.py:29-30
+        self.geometry_size = primitive_fields[0].sizes[0]
+
+    def get_base_points_for_collision(self):
+        raise NotImplementedError
+
+
+class GraspedObjectPandaBox(GraspedObject):                  # objects.py:37-89
+    def __init__(self, tensor_args=None, **kwargs):
+        fields = [MultiBoxField(np.zeros((1, 3), np.float32), np.array([[0.05, 0.05, 0.15]], np.float32), tensor_args=tensor_args)]
+        super().__init__(fields, name="GraspedObjectPandaBox", pos=np.array([0.0, 0.0, 0.11], np.float32),
+                         ori=np.array([0, 0.7071081, 0, 0.7071055], np.float32), reference_frame="panda_hand", **kwargs)
+        self.base_points_for_collision = self.get_base_points_for_collision()
+        self.n_base_points_for_collision = len(self.base_points_for_collision)
+
+    def get_base_points_for_collision(self):
+        """The 8 vertices and 6 face centres of the box, in the object frame (objects.py:57-89), fp32."""
+        x, y, z = (self.fields[0].sizes[0] / np.float32(2)).tolist()
+        vertices = [[x, y, -z], [x, -y, -z], [-x, -y, -z], [-x, y, -z], [x, y, z], [x, -y, z], [-x, -y, z], [-x, y, z]]
+        faces = [[x, 0, 0], [0, -y, 0], [-x, 0, 0], [0, y, 0], [0, 0, z], [0, 0, -z]]
+        return torch.tensor(vertices + faces, dtype=torch.float32)
+
+
 class GridMapSDF:                                            # grid_map_sdf.py:9-117
     """Voxel SDF + stored gradients; built by the `trk_grid_precompute` kernel."""
 

@@ -60,8 +60,6 @@ class EmbodimentDistanceFieldBase(DistanceField):
         assert robot is not None, "You need to pass a robot instance to the embodiment distance fields"
         if clamp_sdf or interpolate_link_pos:
             raise NotImplementedError("clamp_sdf / interpolate_link_pos are never enabled by the reference's callers")
-        if getattr(robot, "grasped_object", None) is not None:
-            raise NotImplementedError("grasped objects are not part of this build yet (SURVEY.md 8f rank 4)")
         self.robot = robot
         self.link_idxs_for_collision_checking = link_idxs_for_collision_checking
         self.num_interpolated_points = num_interpolated_points
@@ -85,13 +83,27 @@ class EmbodimentDistanceFieldBase(DistanceField):
             self._handles = {key: ops.CostHandle(spec, device)}
         return self._handles[key]
 
-    def _margin_vector(self) -> np.ndarray:
+    def _columns(self, n_links_in: int) -> np.ndarray:
+        """Columns of the position tensor this field reads: the selected robot links, then -- when the robot holds an
+        object -- the grasped points, which fk_map_collision appends after the links (robot_panda.py:154-168).
+        The reference's own gather for that case (distance_fields.py:134-155) raises on a shape mismatch; what it
+        evidently means (robot links ++ grasped points, margins and pair rows as RobotBase builds them,
+        robot_base.py:71-141) is what is implemented, and pinned with the reference's field code in
+        tests/golden/grasp_panda.npz."""
+        cols = list(self.link_idxs_for_collision_checking)
+        go = getattr(self.robot, "grasped_object", None)
+        if go is not None:
+            G = go.n_base_points_for_collision
+            cols += list(range(n_links_in - G, n_links_in))
+        return np.asarray(cols, np.int32)
+
+    def _margin_vector(self, n_cols=None) -> np.ndarray:
         """collision_margins + cutoff_margin in fp32 (distance_fields.py:112)."""
         cm = torch.as_tensor(_np(self.collision_margins), dtype=torch.float32)
         co = self.cutoff_margin
         co = torch.as_tensor(_np(co), dtype=torch.float32) if not isinstance(co, (int, float)) else co
         out = cm + co
-        n = len(self.link_idxs_for_collision_checking)
+        n = len(self.link_idxs_for_collision_checking) if n_cols is None else n_cols
         return np.broadcast_to(out.numpy().astype(np.float32).reshape(-1), (n,)).copy() if out.ndim <= 1 and out.numel() in (1, n) \
             else out.numpy().astype(np.float32)
 
@@ -131,7 +143,7 @@ class CollisionSelfField(EmbodimentDistanceFieldBase):        # distance_fields.
         self.idxs_links_distance_matrix_tuple = tuple(zip(*idxs_links_distance_matrix))
 
     def _fill_spec(self, spec):
-        spec.self_link_idx = np.asarray(self.link_idxs_for_collision_checking, np.int32)
+        spec.self_link_idx = self._columns(spec.n_links_in)
         spec.self_pairs = np.asarray(self.idxs_links_distance_matrix, np.int32).reshape(-1, 2)
         cm = _np(self.cutoff_margin).astype(np.float32).reshape(-1)
         spec.self_margin = np.broadcast_to(cm, (len(spec.self_pairs),)).copy()
@@ -155,8 +167,8 @@ class CollisionObjectDistanceField(CollisionObjectBase):      # distance_fields.
                       getattr(o, "ori", np.zeros(0)).tobytes() if hasattr(o, "ori") else b"") for o in objs)
 
     def _fill_spec(self, spec):
-        spec.obj_link_idx = np.asarray(self.link_idxs_for_collision_checking, np.int32)
-        spec.obj_link_margin = self._margin_vector()
+        spec.obj_link_idx = self._columns(spec.n_links_in)
+        spec.obj_link_margin = self._margin_vector(len(spec.obj_link_idx))
         objs = self.df_obj_list_fn() if self.df_obj_list_fn is not None else []
         spec.objects, spec.grid = objects_to_spec_parts(objs)
 
@@ -169,8 +181,8 @@ class CollisionWorkspaceBoundariesDistanceField(CollisionObjectBase):    # dista
         self.ws_min, self.ws_max = ws_bounds_min, ws_bounds_max
 
     def _fill_spec(self, spec):
-        spec.obj_link_idx = np.asarray(self.link_idxs_for_collision_checking, np.int32)
-        spec.obj_link_margin = self._margin_vector()
+        spec.obj_link_idx = self._columns(spec.n_links_in)
+        spec.obj_link_margin = self._margin_vector(len(spec.obj_link_idx))
         spec.ws_min = _np(self.ws_min).astype(np.float32).reshape(3)
         spec.ws_max = _np(self.ws_max).astype(np.float32).reshape(3)
 

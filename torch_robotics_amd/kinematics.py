@@ -16,6 +16,7 @@ import torch
 
 from . import ops
 from .kinmodel import KinModel
+from .urdf import UrdfJoint, parse_urdf
 
 DATA_DIR = Path(__file__).resolve().parent / "data"
 URDF_DIR = DATA_DIR / "urdf"
@@ -60,11 +61,14 @@ class DifferentiableTree(torch.nn.Module):
             # the reference's MJCF ('xml') reader is self-described as not working (models/utils.py:43)
             raise NotImplementedError(f"{self.model_type} is not supported!")
         self.model_path = str(model_path)
-        self._kin = KinModel.from_urdf(self.model_path)
+        self._kin = self._build_kin_model()
         self._n_dofs = self._kin.n_dofs
         self._controlled_joints = [int(i) for i in self._kin.controlled]
         self._name_to_idx_map: Dict[str, int] = dict(self._kin.name_to_idx)
         self._handle_cache: Optional[ops.ModelHandle] = None
+
+    def _build_kin_model(self) -> KinModel:
+        return KinModel.from_urdf(self.model_path)
 
     # -- device handle (created on first use so that construction works without a GPU) ----------
     @property
@@ -250,12 +254,34 @@ def _tree(urdf_name: str, name: str):
     return _Robot
 
 
+def quat_wxyz_to_rpy(q) -> Tuple[float, float, float]:
+    """Roll / pitch / yaw of a wxyz quaternion in fp32 (what the reference writes into the grasped object's fixed
+    joint: q_to_euler quaternion.py:203-215 via robots.py:25-37)."""
+    w, x, y, z = torch.as_tensor(np.asarray(q, np.float32).reshape(4)).unbind(-1)
+    roll = torch.atan2(2.0 * (w * x + y * z), 1.0 - 2.0 * (x * x + y * y))
+    pitch = torch.asin(torch.clamp(2.0 * (w * y - z * x), -1.0, 1.0))
+    yaw = torch.atan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z))
+    return float(roll), float(pitch), float(yaw)
+
+
 class DifferentiableFrankaPanda(DifferentiableTree):          # robots.py:56-69
     def __init__(self, link_list=None, gripper=False, device="cuda", grasped_object=None):
-        if grasped_object is not None:
-            raise NotImplementedError("grasped objects are not part of this build yet (SURVEY.md 8f rank 4)")
         fname = "panda_arm_hand.urdf" if gripper else "panda_arm_no_gripper.urdf"
+        self._grasped_object = grasped_object
         super().__init__((URDF_DIR / fname).as_posix(), "differentiable_franka_panda", link_list=link_list, device=device)
+
+    def _build_kin_model(self) -> KinModel:
+        """With a grasped object the reference rewrites the URDF on disk with one more link, `grasped_object`, fixed
+        to `panda_hand` at the object's pose (modidy_franka_panda_urdf_grasped_object robots.py:24-53).  Here the same
+        link and joint are appended to the parsed description in memory; nothing is written."""
+        urdf = parse_urdf(self.model_path)
+        go = self._grasped_object
+        if go is not None:
+            xyz = [float(v) for v in np.asarray(go.pos, np.float32).reshape(3)]
+            urdf.joints.append(UrdfJoint(name="grasped_object_fixed_joint", type="fixed", parent="panda_hand",
+                                         child="grasped_object", xyz=xyz, rpy=list(quat_wxyz_to_rpy(go.ori))))
+            urdf.links.append("grasped_object")
+        return KinModel.from_parsed(urdf)
 
 
 DifferentiableKUKAiiwa = _tree("iiwa7.urdf", "differentiable_kuka_iiwa")

@@ -104,6 +104,31 @@ class CostHandle:
                 pass
 
 
+class PointSetHandle:
+    """Owns a TrkPointSet*: points rigidly attached to links of one model (link index + offset in the link frame)."""
+
+    def __init__(self, model: ModelHandle, point_link, point_offset, device):
+        pl = np.ascontiguousarray(point_link, np.int32).reshape(-1)
+        po = np.ascontiguousarray(point_offset, np.float32).reshape(-1, 3)
+        if pl.shape[0] != po.shape[0]:
+            raise ValueError("PointSetHandle: point_link and point_offset disagree on the number of points")
+        self.model, self.point_link, self.point_offset = model, pl, po
+        self.n_points = int(pl.shape[0])
+        h = C.c_void_p()
+        with torch.cuda.device(torch.device(device)):
+            check(lib().trk_point_set_create(model._h, pl.ctypes.data, po.ctypes.data, self.n_points, C.byref(h)),
+                  "trk_point_set_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().trk_point_set_destroy(h)
+            except Exception:
+                pass
+
+
 def _sel(sel: Optional[Sequence[int]]):
     if sel is None:
         return None, 0, None
@@ -157,6 +182,28 @@ def fk_positions_backward(model: ModelHandle, q: torch.Tensor, gpos: torch.Tenso
     with torch.cuda.device(q.device):
         check(lib().trk_fk_positions_backward(model._h, q.data_ptr(), gpos.data_ptr(), n, p, ns, gq.data_ptr(),
                                               _stream(q)), "trk_fk_positions_backward")
+    return gq
+
+
+def fk_points(ps: PointSetHandle, q: torch.Tensor) -> torch.Tensor:
+    """q (N,D) -> world positions (N,P,3) of the attached points (robot_panda.py:154-168, frame.py:116-118)."""
+    model = ps.model
+    q = _dev_f32(q, "fk_points(q)").reshape(-1, model.n_dofs)
+    n = q.shape[0]
+    pos = torch.empty((n, ps.n_points, 3), device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        check(lib().trk_fk_points(model._h, ps._h, q.data_ptr(), n, pos.data_ptr(), _stream(q)), "trk_fk_points")
+    return pos
+
+
+def fk_points_backward(ps: PointSetHandle, q: torch.Tensor, gpos: torch.Tensor) -> torch.Tensor:
+    model = ps.model
+    q = _dev_f32(q, "fk_points_backward(q)").reshape(-1, model.n_dofs)
+    gpos = _dev_f32(gpos, "fk_points_backward(gpos)")
+    gq = torch.zeros_like(q)
+    with torch.cuda.device(q.device):
+        check(lib().trk_fk_points_backward(model._h, ps._h, q.data_ptr(), gpos.data_ptr(), q.shape[0], gq.data_ptr(),
+                                           _stream(q)), "trk_fk_points_backward")
     return gq
 
 
@@ -288,6 +335,31 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
             gq.reshape(tuple(lead) + (D,)))
 
 
+def rollout_points_cost_grad(ps: PointSetHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True,
+                             cost_sum: Optional[torch.Tensor] = None):
+    """Fused rollout with the collision fields on attached points: q (B,H,D) or (N,D) ->
+    (point_pos (…,P,3) or None, cost (…), gq (…,D))."""
+    model = ps.model
+    q = _dev_f32(q, "rollout_points_cost_grad(q)")
+    lead = q.shape[:-1]
+    if q.dim() == 3:
+        B, Hh = int(q.shape[0]), int(q.shape[1])
+    else:
+        q = q.reshape(-1, model.n_dofs)
+        B, Hh = int(q.shape[0]), 1
+    n, P, D = B * Hh, ps.n_points, model.n_dofs
+    pos = torch.empty((n, P, 3), device=q.device, dtype=torch.float32) if want_pos else None
+    cost = torch.empty((n,), device=q.device, dtype=torch.float32)
+    gq = torch.empty((n, D), device=q.device, dtype=torch.float32)
+    w = _abi.RolloutWeights(*[float(v) for v in weights])
+    with torch.cuda.device(q.device):
+        check(lib().trk_rollout_points_cost_grad(model._h, ps._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos),
+                                                 cost.data_ptr(), gq.data_ptr(), _ptr(cost_sum), _stream(q)),
+              "trk_rollout_points_cost_grad")
+    return (None if pos is None else pos.reshape(tuple(lead) + (P, 3)), cost.reshape(tuple(lead)),
+            gq.reshape(tuple(lead) + (D,)))
+
+
 def interpolate_traj_via_points(trajs: torch.Tensor, num_interpolation: int = 10) -> torch.Tensor:
     """trajectory/utils.py:37-50: (..., H, D) -> (..., (H-1)*num_interpolation, D); identity for num_interpolation <= 0."""
     if num_interpolation <= 0:
@@ -376,6 +448,20 @@ class _FKPos(torch.autograd.Function):
         return gq.reshape(q.shape), None, None
 
 
+class _FKPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, ps):
+        ctx.ps = ps
+        ctx.save_for_backward(q)
+        return fk_points(ps, q)
+
+    @staticmethod
+    def backward(ctx, gpos):
+        (q,) = ctx.saved_tensors
+        gq = fk_points_backward(ctx.ps, q, gpos.contiguous())
+        return gq.reshape(q.shape), None
+
+
 class _CostFields(torch.autograd.Function):
     @staticmethod
     def forward(ctx, link_pos, cm, fields):
@@ -409,8 +495,11 @@ class _Rollout(torch.autograd.Function):
     """cost (…), link_pos (…,L,3) from q; backward uses the gradient the fused kernel already produced."""
 
     @staticmethod
-    def forward(ctx, q, model, cm, weights):
-        pos, cost, gq = rollout_cost_grad(model, cm, weights, q, want_pos=True)
+    def forward(ctx, q, model, cm, weights, ps):
+        if ps is None:
+            pos, cost, gq = rollout_cost_grad(model, cm, weights, q, want_pos=True)
+        else:
+            pos, cost, gq = rollout_points_cost_grad(ps, cm, weights, q, want_pos=True)
         ctx.save_for_backward(gq)
         ctx.mark_non_differentiable(pos)
         return cost, pos
@@ -418,7 +507,7 @@ class _Rollout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gcost, _gpos):
         (gq,) = ctx.saved_tensors
-        return gq * gcost.unsqueeze(-1), None, None, None
+        return gq * gcost.unsqueeze(-1), None, None, None, None
 
 
 def fk(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
@@ -435,6 +524,13 @@ def fk_pos(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
     return fk_positions(model, q2, sel)
 
 
+def fk_points_ad(ps: PointSetHandle, q: torch.Tensor) -> torch.Tensor:
+    q2 = _dev_f32(q, "fk_points(q)").reshape(-1, ps.model.n_dofs)
+    if torch.is_grad_enabled() and q.requires_grad:
+        return _FKPoints.apply(q2, ps)
+    return fk_points(ps, q2)
+
+
 def cost_fields_ad(cm: CostHandle, fields: int, link_pos: torch.Tensor) -> torch.Tensor:
     lp = _dev_f32(link_pos, "cost_fields(link_pos)").reshape(-1, cm.n_links_in, 3)
     if torch.is_grad_enabled() and link_pos.requires_grad:
@@ -449,9 +545,9 @@ def ee_cost_ad(cm: CostHandle, H: torch.Tensor, target=None) -> torch.Tensor:
     return ee_cost(cm, Hc, target)
 
 
-def rollout_ad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor):
-    """Differentiable fused op: returns (cost, link_pos)."""
-    return _Rollout.apply(_dev_f32(q, "rollout(q)"), model, cm, tuple(float(w) for w in weights))
+def rollout_ad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, ps: Optional[PointSetHandle] = None):
+    """Differentiable fused op: returns (cost, link_pos) -- or (cost, point_pos) when a point set is given."""
+    return _Rollout.apply(_dev_f32(q, "rollout(q)"), model, cm, tuple(float(w) for w in weights), ps)
 
 
 class RolloutPlan:

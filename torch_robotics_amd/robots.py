@@ -47,9 +47,7 @@ class RobotBase:
         self.q_min, self.q_max = q_limits[0], q_limits[1]
         self.q_min_np, self.q_max_np = self.q_min.cpu().numpy(), self.q_max.cpu().numpy()
         self.q_dim = len(self.q_min)
-        if grasped_object is not None:
-            raise NotImplementedError("grasped objects are not part of this build yet (SURVEY.md 8f rank 4)")
-        self.grasped_object = None
+        self.grasped_object = grasped_object
         self.margin_for_grasped_object_collision_checking = margin_for_grasped_object_collision_checking
 
         # objects collision field (robot_base.py:57-82)
@@ -69,6 +67,11 @@ class RobotBase:
             link_margins_for_object_collision_checking, dtype=torch.float32).repeat_interleave(
             int(num_interpolated_points_for_object_collision_checking / len(link_margins_for_object_collision_checking)))
         self.link_margins_for_object_collision_checking_tensor = self.link_margins_for_object_collision_checking_robot_tensor
+        if self.grasped_object is not None:                     # robot_base.py:76-80: the grasped points' margins follow
+            self.link_margins_for_object_collision_checking_tensor = torch.cat((
+                self.link_margins_for_object_collision_checking_tensor,
+                torch.ones(self.grasped_object.n_base_points_for_collision, dtype=torch.float32)
+                * self.margin_for_grasped_object_collision_checking))
         self.link_idxs_for_object_collision_checking = link_idxs_for_object_collision_checking
 
         # self collision field: pair index table (robot_base.py:84-141)
@@ -93,7 +96,16 @@ class RobotBase:
                     for link_2 in link_names_pairs_for_self_collision_checking[link_1]:
                         j = link_names_for_self_collision_checking.index(link_2)
                         idxs.extend([(i * p + m, j * p + n) for m, n in itertools.product(range(p), range(p))])
-            margins = torch.tensor([self.self_collision_margin_robot] * len(idxs), dtype=torch.float32)
+            margin_list = [self.self_collision_margin_robot] * len(idxs)
+            if self.grasped_object is not None:                 # robot_base.py:120-130: grasped points x listed links
+                last_row = n_self * p
+                n_grasped = self.grasped_object.n_base_points_for_collision
+                n_before = len(idxs)
+                for link_1 in link_names_for_self_collision_checking_with_grasped_object:
+                    j = link_names_for_self_collision_checking.index(link_1)
+                    idxs.extend([(last_row + m, j * p + n) for m, n in itertools.product(range(n_grasped), range(p))])
+                margin_list.extend([self.self_collision_margin_grasped_object] * (len(idxs) - n_before))
+            margins = torch.tensor(margin_list, dtype=torch.float32)
             self.df_collision_self = CollisionSelfField(
                 self, link_idxs_for_collision_checking=self.link_idxs_for_self_collision_checking,
                 idxs_links_distance_matrix=idxs,
@@ -172,12 +184,32 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
             link_names_for_self_collision_checking_with_grasped_object=with_grasped,
             self_collision_margin_grasped_object=0.05, tensor_args=tensor_args, **kwargs)
 
+    def collision_point_set(self):
+        """(point_link, point_offset) of what fk_map_collision returns: every link origin, then the grasped object's
+        collision points in the `grasped_object` link frame (robot_panda.py:154-168)."""
+        L = self.diff_panda._kin.n_links
+        if self.grasped_object is None:
+            return np.arange(L, dtype=np.int32), np.zeros((L, 3), np.float32)
+        pts = self.grasped_object.base_points_for_collision.detach().cpu().numpy().astype(np.float32)
+        link = self.diff_panda._name_to_idx_map[self.link_name_grasped_object]
+        return (np.concatenate([np.arange(L), np.full(len(pts), link)]).astype(np.int32),
+                np.concatenate([np.zeros((L, 3), np.float32), pts]))
+
+    def _point_set(self, device) -> "ops.PointSetHandle":
+        key = str(device)
+        if getattr(self, "_ps", None) is None or self._ps[0] != key:
+            self._ps = (key, ops.PointSetHandle(self.diff_panda._handle, *self.collision_point_set(), device))
+        return self._ps[1]
+
     def fk_map_collision_impl(self, q, **kwargs):              # robot_panda.py:138-170
         shape = q.shape
         if len(shape) not in (2, 3):
             raise NotImplementedError
-        pos = ops.fk_pos(self.diff_panda._handle, q)            # all L link origins, (N, L, 3)
-        return pos.reshape(tuple(shape[:-1]) + (self.diff_panda._kin.n_links, 3))
+        if self.grasped_object is None:
+            pos = ops.fk_pos(self.diff_panda._handle, q)        # all L link origins, (N, L, 3)
+        else:
+            pos = ops.fk_points_ad(self._point_set(q.device), q)    # (N, L + G, 3), one launch
+        return pos.reshape(tuple(shape[:-1]) + (pos.shape[-2], 3))
 
     def get_EE_pose(self, q):
         return self.diff_panda.compute_forward_kinematics_all_links(q, link_list=[self.link_name_ee])

@@ -72,11 +72,16 @@ class PlanningTask(Task):
         else:
             self._fused = None
 
+    def _n_columns(self) -> int:
+        """Width of fk_map_collision's output: the links, plus the grasped object's points if there is one."""
+        go = getattr(self.robot, "grasped_object", None)
+        return self.robot.diff_panda._kin.n_links + (0 if go is None else go.n_base_points_for_collision)
+
     def build_cost_spec(self) -> CostModelSpec:
         r, tree = self.robot, self.robot.diff_panda
-        spec = CostModelSpec(n_links_in=tree._kin.n_links)
-        spec.obj_link_idx = np.asarray(r.link_idxs_for_object_collision_checking, np.int32)
-        spec.obj_link_margin = self.df_collision_objects._margin_vector()
+        spec = CostModelSpec(n_links_in=self._n_columns())
+        spec.obj_link_idx = self.df_collision_objects._columns(spec.n_links_in)
+        spec.obj_link_margin = self.df_collision_objects._margin_vector(len(spec.obj_link_idx))
         spec.objects, spec.grid = objects_to_spec_parts(self.env.get_df_obj_list())
         spec.ws_min, spec.ws_max = _np(self.ws_min).astype(np.float32), _np(self.ws_max).astype(np.float32)
         if self.df_collision_self is not None:
@@ -91,10 +96,21 @@ class PlanningTask(Task):
             self._fused = (self.robot.diff_panda._handle, ops.CostHandle(self.build_cost_spec(), device), str(device))
         return self._fused[0], self._fused[1]
 
+    def _points(self, device):
+        """PointSetHandle when the collision columns are not simply the links (grasped object), else None."""
+        if getattr(self.robot, "grasped_object", None) is None:
+            return None
+        return self.robot._point_set(device)
+
     def rollout_cost_grad(self, x, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=True, cost_sum=None, out=None):
         """Fused FK + objectives + gradient.  x (B,H,>=D) or (N,>=D) -> (link_pos, cost, d cost/d q)."""
         q = self.robot.get_position(x)
         model, cm = self._fused_handles(q.device)
+        ps = self._points(q.device)
+        if ps is not None:
+            if out is not None:
+                raise NotImplementedError("pre-allocated outputs are only supported without a grasped object")
+            return ops.rollout_points_cost_grad(ps, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos, cost_sum=cost_sum)
         return ops.rollout_cost_grad(model, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos, cost_sum=cost_sum, out=out)
 
     # ---------------------------------------------------------------------------------------------
@@ -113,13 +129,16 @@ class PlanningTask(Task):
             raise NotImplementedError
         model, cm = self._fused_handles(q.device)
         fields = FIELD_OBJECTS | FIELD_WS | (FIELD_SELF if self.df_collision_self is not None else 0)
+        ps = self._points(q.device)
         if field_type == "occupancy":
-            pos = ops.fk_positions(model, q.detach())
+            pos = ops.fk_positions(model, q.detach()) if ps is None else ops.fk_points(ps, q.detach())
             return ops.collision_fields(cm, fields, pos, margin=kwargs.get("margin", None)).reshape(q.shape[:-1])
         w = (1.0 if self.df_collision_self is not None else 0.0, 1.0, 1.0, 0.0)
         if torch.is_grad_enabled() and q.requires_grad:
-            cost, _ = ops.rollout_ad(model, cm, w, q)           # one fused kernel; backward reuses its gradient
+            cost, _ = ops.rollout_ad(model, cm, w, q, ps)       # one fused kernel; backward reuses its gradient
             return cost
+        if ps is not None:
+            return ops.rollout_points_cost_grad(ps, cm, w, q, want_pos=False)[1]
         _, cost, _ = ops.rollout_cost_grad(model, cm, w, q, want_pos=False)
         return cost
 
