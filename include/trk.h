@@ -39,8 +39,8 @@ extern "C" {
 #define TRK_MAX_POSE_SLOTS 8
 #define TRK_MAX_OBJECTS 16
 #define TRK_MAX_PRIMS 256
-#define TRK_MAX_COLL_LINKS 64
-#define TRK_MAX_SELF_PAIRS 256
+#define TRK_MAX_COLL_LINKS 192
+#define TRK_MAX_SELF_PAIRS 1024
 
 typedef enum TrkStatus {
     TRK_OK = 0,

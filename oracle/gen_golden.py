@@ -589,11 +589,35 @@ def points_goldens():
         print(f"points_{name}:", tuple(pos.shape))
 
 
+def sphere_config_data():
+    """`python oracle/gen_golden.py spheres`: the Panda link-sphere table the reference ships but never reads
+    (data/configs/panda/panda_sphere_config.yaml) -> torch_robotics_amd/data/configs/ (active entries only)."""
+    import yaml
+    src = REF / "torch_robotics" / "data" / "configs" / "panda" / "panda_sphere_config.yaml"
+    table = yaml.safe_load(src.read_text())
+    dst = REPO / "torch_robotics_amd" / "data" / "configs" / "panda_sphere_config.yaml"
+    dst.parent.mkdir(parents=True, exist_ok=True)
+    lines = ["# link -> [x, y, z, radius] in the link frame (collision spheres of the Franka Panda)"]
+    n = 0
+    for link, rows in table.items():
+        if not isinstance(rows, list):                  # trailing scalar entry (`margin`), kept as is
+            lines.append(f"{link}: {rows!r}")
+            continue
+        lines.append(f"{link}:")
+        lines += [f"- [{', '.join(repr(float(v)) for v in row)}]" for row in rows]
+        n += len(rows)
+    dst.write_text("\n".join(lines) + "\n")
+    print("panda_sphere_config:", n, "spheres")
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     URDF_OUT.mkdir(parents=True, exist_ok=True)
     if sys.argv[1:] == ["points"]:
         points_goldens()
+        return
+    if sys.argv[1:] == ["spheres"]:
+        sphere_config_data()
         return
     trees = {}
     for name, rel in ROBOTS.items():
@@ -622,6 +646,7 @@ def main():
     ik_goldens(trees)
     misc_goldens()
     points_goldens()
+    sphere_config_data()
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
 

@@ -241,3 +241,57 @@ def test_grasped_object_like_the_reference():
                                   g["coll0_self"] | g["coll0_obj"] | g["coll0_ws"])
     ppos, cost, gq = task.rollout_cost_grad(q0)
     assert ppos.shape == (4, 8, 26, 3) and rel_err(gq.cpu().numpy(), g["gq_cost"]) < TOL_G
+
+
+def test_link_sphere_model(oracle_lib):
+    """RobotPanda(link_sphere_model="panda"): 45 link-frame collision spheres (the reference ships the table
+    but has no code path for it, so the check is the fp64 oracle on the same tables -- parity build-defined)."""
+    robot = tra.RobotPanda(link_sphere_model="panda", tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.2, 0.5)
+    task.set_ee_target(T)
+    spec = task.build_cost_spec()
+    pl, po = robot.collision_point_set()
+    o = oracle_lib.Oracle(robot.diff_panda._kin, spec)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    q0 = robot.random_q(6 * 64, generator=gen).reshape(6, 64, 7)
+    qn = q0.cpu().numpy().astype(np.float64).reshape(-1, 7)
+    rp, rc, rg = o.rollout_points(pl, po, qn, (1, 1, 1, 0), "f64")
+    q = q0.clone().requires_grad_(True)
+    pos = robot.fk_map_collision(q)
+    assert pos.shape == (6, 64, 56, 3)
+    assert np.abs(pos.detach().cpu().numpy().reshape(-1, 56, 3) - rp).max() < TOL_H
+    total = task.compute_collision_cost(q)
+    assert rel_err(total.detach().cpu().numpy().reshape(-1), rc) < TOL_C
+    total.sum().backward()
+    assert rel_err(q.grad.cpu().numpy().reshape(-1, 7), rg) < TOL_G
+    # unfused chain through the drop-in classes == fused kernel
+    q = q0.clone().requires_grad_(True)
+    lp = robot.fk_map_collision(q)
+    chain = sum(f.compute_cost(q, lp, field_type="sdf") for f in task.get_collision_fields())
+    assert rel_err(chain.detach().cpu().numpy().reshape(-1), rc) < TOL_C
+    chain.sum().backward()
+    assert rel_err(q.grad.cpu().numpy().reshape(-1, 7), rg) < TOL_G
+    # with the EE term
+    _, rc4, rg4 = o.rollout_points(pl, po, qn, (1, 1, 1, 1), "f64")
+    _, c4, g4 = task.rollout_cost_grad(q0, w_ee=1.0)
+    assert rel_err(c4.cpu().numpy().reshape(-1), rc4) < TOL_C and rel_err(g4.cpu().numpy().reshape(-1, 7), rg4) < TOL_G
+    coll = task.compute_collision(q0)
+    ref = o.collision_fields(7, rp, None, "f64").reshape(6, 64)
+    assert (coll.cpu().numpy() != ref).mean() < 0.01       # fp32 vs fp64 at the threshold
+
+
+def test_sphere_model_reduces_to_link_origin_goldens():
+    """One zero-offset sphere per collision link with radius = link margin is the reference's own collision model:
+    the point kernels must then reproduce the reference goldens of the link-origin path."""
+    from torch_robotics_amd import ops
+    from helpers import model, panda_cost_spec
+    g, robot_g = gold("cost_spheres3d"), gold("panda_robot")
+    spec = panda_cost_spec(g, robot_g)
+    m = model("panda_arm_no_gripper")
+    h = ops.ModelHandle(m)
+    ps = ops.PointSetHandle(h, np.arange(11, dtype=np.int32), np.zeros((11, 3), np.float32), DEV)
+    cm = ops.CostHandle(spec, DEV)
+    _, cost, gq = ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 0), dev(g["q"]))
+    assert rel_err(cost.cpu().numpy(), g["cost_total"]) < TOL_C
+    assert rel_err(gq.cpu().numpy(), g["gq_total"]) < TOL_G

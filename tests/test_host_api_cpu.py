@@ -177,3 +177,25 @@ def test_grasped_object_model_matches_reference():
     assert mine.n_links_in == 26
     for name in ("obj_link_idx", "obj_link_margin", "self_link_idx", "self_pairs", "self_margin", "ws_min", "ws_max"):
         np.testing.assert_array_equal(getattr(mine, name), getattr(spec_ref, name), err_msg=name)
+
+
+def test_link_sphere_model_tables():
+    """RobotPanda(link_sphere_model="panda") -- SURVEY 8f-3: 45 link-frame spheres replace the 5 link-origin points."""
+    robot = tra.RobotPanda(link_sphere_model="panda", tensor_args=TA)
+    pl, po = robot.collision_point_set()
+    assert pl.shape == (56,) and po.shape == (56, 3)
+    np.testing.assert_array_equal(pl[:11], np.arange(11))
+    assert not po[:11].any() and po[11:].any()
+    assert robot.link_idxs_for_object_collision_checking == list(range(11, 56))
+    assert robot.link_names_for_object_collision_checking[0] == "panda_link0"
+    assert pl[11] == 0 and np.allclose(po[11], [0, 0, 0.05])
+    assert float(robot.link_margins_for_object_collision_checking_tensor[0]) == np.float32(0.08)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    spec = task.build_cost_spec()
+    spec.validate()
+    assert spec.n_links_in == 56 and len(spec.obj_link_idx) == 45 and len(spec.self_pairs) == 10
+    both = tra.RobotPanda(link_sphere_model="panda", grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA), tensor_args=TA)
+    spec = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=both, tensor_args=TA).build_cost_spec()
+    spec.validate()
+    assert spec.n_links_in == 12 + 45 + 14 and len(spec.obj_link_idx) == 59 and len(spec.self_pairs) == 66
+    np.testing.assert_array_equal(spec.obj_link_idx[-14:], np.arange(57, 71))

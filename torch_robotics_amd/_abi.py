@@ -16,8 +16,8 @@ TRK_MAX_DOFS = 32
 TRK_MAX_POSE_SLOTS = 8
 TRK_MAX_OBJECTS = 16
 TRK_MAX_PRIMS = 256
-TRK_MAX_COLL_LINKS = 64
-TRK_MAX_SELF_PAIRS = 256
+TRK_MAX_COLL_LINKS = 192
+TRK_MAX_SELF_PAIRS = 1024
 
 TRK_OK = 0
 TRK_ERR_INVALID_ARG = -1

@@ -12,7 +12,7 @@ import torch
 from . import ops
 from .environments import DEFAULT_TENSOR_ARGS
 from .fields import CollisionSelfField
-from .kinematics import DifferentiableFrankaPanda, link_pos_from_link_tensor, link_quat_from_link_tensor, \
+from .kinematics import DATA_DIR, DifferentiableFrankaPanda, link_pos_from_link_tensor, link_quat_from_link_tensor, \
     link_rot_from_link_tensor
 
 
@@ -146,8 +146,28 @@ class RobotBase:
         raise NotImplementedError
 
 
+def load_link_spheres(path, name_to_idx):
+    """Link-sphere table `{link: [[x, y, z, r], ...]}` (the format of the reference's
+    data/configs/panda/panda_sphere_config.yaml) -> (link_idx [S], offsets [S,3], radii [S], owner names [S])."""
+    import yaml
+    table = yaml.safe_load(open(path))
+    link, off, rad, names = [], [], [], []
+    for name, rows in table.items():
+        if not isinstance(rows, list):
+            continue
+        for row in rows:
+            link.append(name_to_idx[name]); off.append(row[:3]); rad.append(row[3]); names.append(name)
+    return np.asarray(link, np.int32), np.asarray(off, np.float32).reshape(-1, 3), np.asarray(rad, np.float32), names
+
+
 class RobotPanda(RobotBase):                                   # robot_panda.py:21-184
-    def __init__(self, use_self_collision_storm=False, grasped_object=None, tensor_args=None, **kwargs):
+    """`link_sphere_model` (an extension) replaces the five link-origin collision points by the link-frame
+    spheres of a table such as data/configs/panda_sphere_config.yaml ("panda" = that file): fk_map_collision then
+    returns the L link origins followed by the S sphere centres (followed by grasped-object points), and the object /
+    workspace fields read the sphere columns with the radii as margins.  Self-collision keeps using link origins."""
+
+    def __init__(self, use_self_collision_storm=False, grasped_object=None, tensor_args=None, link_sphere_model=None,
+                 **kwargs):
         tensor_args = DEFAULT_TENSOR_ARGS if tensor_args is None else tensor_args
         if use_self_collision_storm:
             raise NotImplementedError("the STORM self-collision network needs storm_kit weights (out of scope)")
@@ -161,6 +181,13 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
         obj_links = ["panda_link2", "panda_link3", "panda_link5", "panda_link7", "panda_hand"]
         obj_margins = [0.125, 0.125, 0.13, 0.1, 0.08]
         obj_idxs = [self.diff_panda._name_to_idx_map[n] for n in obj_links]
+        self.link_spheres = None
+        if link_sphere_model is not None:
+            path = DATA_DIR / "configs" / "panda_sphere_config.yaml" if link_sphere_model == "panda" else link_sphere_model
+            sl, so, sr, names = load_link_spheres(path, self.diff_panda._name_to_idx_map)
+            self.link_spheres = (sl, so, sr)
+            L = self.diff_panda._kin.n_links
+            obj_links, obj_margins, obj_idxs = names, [float(r) for r in sr], list(range(L, L + len(sl)))
         pairs = OrderedDict({"panda_link4": ["panda_link1"],
                              "panda_link5": ["panda_link0", "panda_link1", "panda_link2"],
                              "panda_link6": ["panda_link0", "panda_link1", "panda_link2"],
@@ -188,12 +215,18 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
         """(point_link, point_offset) of what fk_map_collision returns: every link origin, then the grasped object's
         collision points in the `grasped_object` link frame (robot_panda.py:154-168)."""
         L = self.diff_panda._kin.n_links
-        if self.grasped_object is None:
-            return np.arange(L, dtype=np.int32), np.zeros((L, 3), np.float32)
-        pts = self.grasped_object.base_points_for_collision.detach().cpu().numpy().astype(np.float32)
-        link = self.diff_panda._name_to_idx_map[self.link_name_grasped_object]
-        return (np.concatenate([np.arange(L), np.full(len(pts), link)]).astype(np.int32),
-                np.concatenate([np.zeros((L, 3), np.float32), pts]))
+        link, off = [np.arange(L, dtype=np.int32)], [np.zeros((L, 3), np.float32)]
+        if self.link_spheres is not None:
+            link.append(self.link_spheres[0]); off.append(self.link_spheres[1])
+        if self.grasped_object is not None:
+            pts = self.grasped_object.base_points_for_collision.detach().cpu().numpy().astype(np.float32)
+            link.append(np.full(len(pts), self.diff_panda._name_to_idx_map[self.link_name_grasped_object], np.int32))
+            off.append(pts)
+        return np.concatenate(link).astype(np.int32), np.concatenate(off).astype(np.float32)
+
+    @property
+    def has_extra_points(self) -> bool:
+        return self.grasped_object is not None or self.link_spheres is not None
 
     def _point_set(self, device) -> "ops.PointSetHandle":
         key = str(device)
@@ -205,7 +238,7 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
         shape = q.shape
         if len(shape) not in (2, 3):
             raise NotImplementedError
-        if self.grasped_object is None:
+        if not self.has_extra_points:
             pos = ops.fk_pos(self.diff_panda._handle, q)        # all L link origins, (N, L, 3)
         else:
             pos = ops.fk_points_ad(self._point_set(q.device), q)    # (N, L + G, 3), one launch

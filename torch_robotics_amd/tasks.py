@@ -74,8 +74,9 @@ class PlanningTask(Task):
 
     def _n_columns(self) -> int:
         """Width of fk_map_collision's output: the links, plus the grasped object's points if there is one."""
-        go = getattr(self.robot, "grasped_object", None)
-        return self.robot.diff_panda._kin.n_links + (0 if go is None else go.n_base_points_for_collision)
+        if getattr(self.robot, "has_extra_points", False):
+            return len(self.robot.collision_point_set()[0])
+        return self.robot.diff_panda._kin.n_links
 
     def build_cost_spec(self) -> CostModelSpec:
         r, tree = self.robot, self.robot.diff_panda
@@ -98,7 +99,7 @@ class PlanningTask(Task):
 
     def _points(self, device):
         """PointSetHandle when the collision columns are not simply the links (grasped object), else None."""
-        if getattr(self.robot, "grasped_object", None) is None:
+        if not getattr(self.robot, "has_extra_points", False):
             return None
         return self.robot._point_set(device)
 
