@@ -328,6 +328,14 @@ int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const T
                           float* link_pos_out, float* cost, float* gq, float* cost_block_sums,
                           trk_stream_t stream);
 
+/* trk_rollout_cost_grad with q, link_pos_out and gq stored as IEEE fp16 in HBM -- BASELINE config 5's "fp16 with fp32
+ * cost accumulate": arithmetic, `cost` and `cost_block_sums` stay fp32; inputs are widened and outputs rounded once
+ * (round-to-nearest-even) at the memory boundary.  Build-defined (the reference has no reduced-precision path); the
+ * check is the fp64 oracle on the same fp16-rounded q. */
+int trk_rollout_cost_grad_f16(const TrkModel* model, const TrkCostModel* cm, const TrkRolloutWeights* w,
+                              const void* q_f16, int64_t batch, int32_t horizon, void* link_pos_out_f16, float* cost,
+                              void* gq_f16, float* cost_block_sums, trk_stream_t stream);
+
 /* trk_rollout_cost_grad with the collision fields evaluated on attached points instead of link origins: the cost
  * model's position columns (n_links_in, obj_link_idx, self_link_idx) index the points of `ps`; ee_link stays a LINK
  * index of the model.  point_pos_out [batch*horizon, n_points, 3] (nullable).  Same outputs otherwise. */
@@ -341,6 +349,20 @@ int trk_rollout_points_cost_grad(const TrkModel* model, const TrkPointSet* ps, c
  * alpha = linspace(0,1,n+2)[1:n+1], beta = 1 - alpha: DEVICE float[n_interp], computed by the caller. */
 int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, int32_t dim, int32_t n_interp,
                                const float* alpha, const float* beta, float* out, trk_stream_t stream);
+
+/* Constant-velocity Gaussian-process prior over trajectories -- the "GP-smoothness" term of BASELINE config 5.
+ * BUILD-DEFINED, parity unpinned: the reference contains no such cost (its smoothness is finite differences,
+ * trajectory/utils.py:53-64, metrics.py:27-35; it only carries the hyper-parameter names sigma_gp, dt for external
+ * planners, env_spheres_3d.py:51-76).  The standard GPMP form is used:  per DOF x_t = (q_t, qd_t),
+ * e_t = Phi(dt) x_t - x_{t+1},  Q^-1 = sigma^-2 [[12/dt^3, -6/dt^2], [-6/dt^2, 4/dt]],
+ * cost[b] = weight * 1/2 sum_t sum_dof e_t^T Q^-1 e_t   and   gq, gqd = d cost / d q, d cost / d qd.
+ * q, qd, gq, gqd: [batch, horizon, dof] of `io_dtype` (TRK_F32 / TRK_F16; arithmetic and `cost` are fp32);
+ * accumulate != 0 adds into gq / gqd instead of overwriting (to compose with trk_rollout_cost_grad's gradient). */
+#define TRK_F32 0
+#define TRK_F16 1
+int trk_gp_prior_cost_grad(const void* q, const void* qd, int64_t batch, int32_t horizon, int32_t dof, int32_t io_dtype,
+                           float dt, float sigma, float weight, float* cost, void* gq, void* gqd, int32_t accumulate,
+                           trk_stream_t stream);
 
 /* Profiling hook (process-global, NULL = off): DEVICE uint64[ceil(N/64)][8]; the model-specialised fused kernel then
  * records the shader clock (s_memtime) of every wavefront at 8 phase boundaries (entry, q loaded, FK done, positions

@@ -245,3 +245,15 @@ class Oracle:
         grad = np.empty((pts.shape[0], no, 3), npdt)
         getattr(lib(), "orc_sdf_points" + suf)(C.byref(self.cd), _p(pts), C.c_int64(pts.shape[0]), _p(sdf), _p(grad))
         return sdf, grad
+
+
+def gp_prior(q, qd, dt, sigma, weight=1.0, prec="f64"):
+    """Constant-velocity GP prior (build-defined term of BASELINE config 5): (cost [B], gq, gqd)."""
+    npdt, ct, suf = _dt(prec)
+    q = np.ascontiguousarray(q, npdt)
+    qd = np.ascontiguousarray(qd, npdt)
+    B, H, D = q.shape
+    cost, gq, gqd = np.empty(B, npdt), np.empty_like(q), np.empty_like(q)
+    getattr(lib(), "orc_gp_prior" + suf)(_p(q), _p(qd), C.c_int64(B), C.c_int(H), C.c_int(D), ct(dt), ct(sigma), ct(weight),
+                                         _p(cost), _p(gq), _p(gqd))
+    return cost, gq, gqd

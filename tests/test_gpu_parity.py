@@ -542,3 +542,95 @@ def test_rollout_points_vs_fp64_oracle(ops, oracle_lib):
             assert np.abs(pos.cpu().numpy() - rp).max() < 2 * TOL_H
             assert rel_err(cost.cpu().numpy(), rc) < TOL_C
             assert rel_err(gq.cpu().numpy(), rg) < TOL_G
+
+
+def test_gp_prior_vs_fp64_oracle(ops, oracle_lib):
+    """Constant-velocity GP prior (build-defined, BASELINE config 5): fp32 and fp16 I/O against the fp64 oracle."""
+    rng = np.random.default_rng(22)
+    for (B, H, D, dt, sigma, w) in ((5, 64, 7, 0.08, 0.1, 1.0), (3, 128, 14, 5.0 / 128, 0.5, 0.3), (2, 1, 5, 0.1, 0.2, 1.0),
+                                    (300, 37, 22, 0.05, 0.3, 1.0)):
+        q = np.cumsum(rng.standard_normal((B, H, D)) * 0.05, axis=1).astype(np.float32)
+        qd = (rng.standard_normal((B, H, D)) * 0.3).astype(np.float32)
+        rc, rgq, rgqd = oracle_lib.gp_prior(q.astype(np.float64), qd.astype(np.float64), dt, sigma, w, "f64")
+        c, gq, gqd = ops.gp_prior_cost_grad(dev(q), dev(qd), dt, sigma, w)
+        assert c.dtype == torch.float32 and c.shape == (B,)
+        if H > 1:
+            assert rel_err(c.cpu().numpy(), rc) < 2e-5
+            assert rel_err(gq.cpu().numpy(), rgq) < 1e-4 and rel_err(gqd.cpu().numpy(), rgqd) < 1e-4
+        else:
+            assert not c.any() and not gq.any() and not gqd.any()
+        # accumulate into existing gradients
+        g0, g1 = dev(rng.standard_normal((B, H, D)).astype(np.float32)), dev(rng.standard_normal((B, H, D)).astype(np.float32))
+        a0, a1 = g0.clone(), g1.clone()
+        ops.gp_prior_cost_grad(dev(q), dev(qd), dt, sigma, w, accumulate_into=(a0, a1))
+        np.testing.assert_allclose((a0 - g0).cpu().numpy(), gq.cpu().numpy(), rtol=0, atol=1e-4 * max(1.0, float(gq.abs().max())))
+        # fp16 I/O: the oracle sees the same fp16-rounded inputs; outputs are rounded to fp16 once
+        qh, qdh = dev(q).half(), dev(qd).half()
+        rc, rgq, rgqd = oracle_lib.gp_prior(qh.cpu().numpy().astype(np.float64), qdh.cpu().numpy().astype(np.float64), dt, sigma, w, "f64")
+        c, gq, gqd = ops.gp_prior_cost_grad(qh, qdh, dt, sigma, w)
+        assert gq.dtype == torch.float16 and c.dtype == torch.float32
+        if H > 1:
+            assert rel_err(c.cpu().numpy(), rc) < 2e-5
+            ok = np.isfinite(rgq.astype(np.float16)).all()
+            if ok:
+                assert rel_err(gq.float().cpu().numpy(), rgq) < 1e-3 and rel_err(gqd.float().cpu().numpy(), rgqd) < 1e-3
+    # autograd wrapper
+    q = dev(rng.standard_normal((4, 16, 7)).astype(np.float32)).requires_grad_(True)
+    qd = dev(rng.standard_normal((4, 16, 7)).astype(np.float32)).requires_grad_(True)
+    wv = dev(np.array([1.0, 2.0, 0.5, 0.0], np.float32))
+    (ops.gp_prior_cost(q, qd, 0.1, 0.4) * wv).sum().backward()
+    _, rgq, rgqd = oracle_lib.gp_prior(q.detach().cpu().numpy().astype(np.float64), qd.detach().cpu().numpy().astype(np.float64), 0.1, 0.4, 1.0)
+    assert rel_err(q.grad.cpu().numpy(), rgq * wv.cpu().numpy()[:, None, None]) < 1e-4
+    with pytest.raises(ValueError):
+        ops.gp_prior_cost_grad(dev(np.zeros((2, 3), np.float32)), dev(np.zeros((2, 3), np.float32)), 0.1, 0.1)
+
+
+@pytest.mark.parametrize("robot,ident", [("panda_arm_no_gripper", "panda"), ("dual_panda", "dual_panda")])
+def test_rollout_fp16_io(ops, oracle_lib, robot, ident):
+    """fp16 q / link_pos / gq in HBM, fp32 arithmetic and cost (BASELINE config 5; build-defined): specialised and
+    table-driven kernels against the fp64 oracle evaluated on the same fp16-rounded q.  Tolerance = one fp16 rounding of
+    each output (2^-11 relative) plus the fp32 evaluation error."""
+    from torch_robotics_amd import codegen
+    from torch_robotics_amd.costmodel import CostModelSpec
+    from torch_robotics_amd.environments import EnvSpheres3D
+    kin, tmpl = codegen.template_for(ident)
+    env = EnvSpheres3D(tensor_args=dict(device=DEV, dtype=torch.float32))
+    spec = CostModelSpec(n_links_in=kin.n_links)
+    spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+    spec.obj_link_margin = np.full(len(tmpl.obj_links), 0.13, np.float32)
+    spec.objects = [o.as_object() for o in env.obj_fixed_list]
+    spec.ws_min, spec.ws_max = np.float32([-1, -1, -1]), np.float32([1, 1, 1])
+    sl = sorted({a for p in tmpl.self_pairs for a in p})
+    spec.self_link_idx = np.asarray(sl, np.int32)
+    spec.self_pairs = np.asarray([(sl.index(a), sl.index(b)) for a, b in tmpl.self_pairs], np.int32).reshape(-1, 2)
+    spec.self_margin = np.full(len(tmpl.self_pairs), 0.05, np.float32)
+    spec.ee_link = tmpl.ee_link
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5); spec.ee_target = Ht
+    spec.validate()
+    h, cm, o = ops.ModelHandle(kin), ops.CostHandle(spec, DEV), oracle_lib.Oracle(kin, spec)
+    assert h.specialized
+    rng = np.random.default_rng(9)
+    for shape in ((3, 64), (5, 37), (1, 1)):
+        q = dev((rng.uniform(-2.5, 2.5, size=shape + (kin.n_dofs,))).astype(np.float32)).half()
+        q64 = q.cpu().numpy().astype(np.float64).reshape(-1, kin.n_dofs)
+        rp, rc, rg = o.rollout(q64, (1, 1, 1, 1), "f64")
+        for use_spec in (True, False):
+            h.enable_specialized(use_spec)
+            nb = ops.n_blocks(shape[0] * shape[1])
+            sums = torch.zeros(nb, device=DEV)
+            pos, cost, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q, cost_sum=sums)
+            assert pos.dtype == torch.float16 and gq.dtype == torch.float16 and cost.dtype == torch.float32
+            assert pos.shape == shape + (kin.n_links, 3) and gq.shape == shape + (kin.n_dofs,)
+            assert np.abs(pos.float().cpu().numpy().reshape(rp.shape) - rp).max() < 1e-3 * max(1.0, np.abs(rp).max())
+            assert rel_err(cost.cpu().numpy().reshape(-1), rc) < TOL_C
+            assert rel_err(gq.float().cpu().numpy().reshape(rg.shape), rg) < 1e-3
+            assert abs(float(sums.sum()) - rc.sum()) < 1e-4 * max(1.0, abs(rc.sum()))
+        h.enable_specialized(True)
+    # pre-bound plan in fp16
+    q = dev(rng.uniform(-2, 2, size=(4, 64, kin.n_dofs)).astype(np.float32)).half()
+    plan = ops.RolloutPlan(h, cm, (0, 1, 0, 1), q)
+    plan.launch()
+    torch.cuda.synchronize()
+    _, rc, rg = o.rollout(q.cpu().numpy().astype(np.float64).reshape(-1, kin.n_dofs), (0, 1, 0, 1), "f64")
+    assert plan.gq.dtype == torch.float16 and rel_err(plan.cost.cpu().numpy().reshape(-1), rc) < TOL_C
+    assert rel_err(plan.gq.float().cpu().numpy().reshape(rg.shape), rg) < 1e-3

@@ -280,3 +280,38 @@ def test_rollout_points_with_link_origins_equals_rollout(oracle_lib):
     got = o.rollout_points(np.arange(11), np.zeros((11, 3)), q, (1, 1, 1, 1), "f64")
     for a, b in zip(ref, got):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GP prior (BUILD-DEFINED term of BASELINE config 5; no reference counterpart -> parity unpinned).  The oracle is
+# checked against an independent statement of the same cost in torch fp64 with autograd gradients.
+# ---------------------------------------------------------------------------------------------------------------------
+def _gp_prior_torch(q, qd, dt, sigma, w):
+    import torch
+    q, qd = torch.tensor(q, dtype=torch.float64, requires_grad=True), torch.tensor(qd, dtype=torch.float64, requires_grad=True)
+    D = q.shape[-1]
+    Phi = torch.eye(2 * D, dtype=torch.float64)
+    Phi[:D, D:] = dt * torch.eye(D, dtype=torch.float64)
+    Qc_inv = torch.eye(D, dtype=torch.float64) / sigma ** 2
+    Qinv = torch.cat([torch.cat([12 / dt ** 3 * Qc_inv, -6 / dt ** 2 * Qc_inv], 1),
+                      torch.cat([-6 / dt ** 2 * Qc_inv, 4 / dt * Qc_inv], 1)], 0)
+    x = torch.cat([q, qd], -1)                                   # (B, H, 2D)
+    e = x[:, :-1] @ Phi.T - x[:, 1:]
+    cost = w * 0.5 * torch.einsum("bti,ij,btj->b", e, Qinv, e)
+    gq, gqd = torch.autograd.grad(cost.sum(), (q, qd))
+    return cost.detach().numpy(), gq.numpy(), gqd.numpy()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_gp_prior_against_independent_autograd(oracle_lib, prec):
+    rng = np.random.default_rng(21)
+    for (B, H, D, dt, sigma, w) in ((3, 64, 7, 0.08, 0.1, 1.0), (2, 128, 14, 5.0 / 128, 0.5, 0.3), (4, 2, 3, 1.0, 1.0, 2.0),
+                                    (2, 1, 5, 0.1, 0.2, 1.0)):
+        q = np.cumsum(rng.standard_normal((B, H, D)) * 0.05, axis=1)
+        qd = rng.standard_normal((B, H, D)) * 0.3
+        rc, rgq, rgqd = _gp_prior_torch(q, qd, dt, sigma, w)
+        c, gq, gqd = oracle_lib.gp_prior(q, qd, dt, sigma, w, prec)
+        tol = 1e-12 if prec == "f64" else 2e-5
+        assert rel_err(c, rc) < tol or np.abs(rc).max() == 0
+        assert rel_err(gq, rgq) < tol or np.abs(rgq).max() == 0
+        assert rel_err(gqd, rgqd) < tol or np.abs(rgqd).max() == 0

@@ -225,6 +225,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
         # small arms fit 128 VGPRs (4 waves/SIMD: the whole 4096 x 64 batch resident); big trees get 256 VGPRs
+        E.raw("template <class IO>      // HBM-side type of q / link_pos / gq: float or _Float16")
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(3 * L, D)} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
@@ -238,7 +239,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    spec_stamp(A.stamps, wblock, 0, lane);")
         E.raw("    if (A.stamps) { asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); if (rows >= 0 && A.q) spec_stamp(A.stamps, wblock, 2, lane); }")
         E.raw("    float q[D];")
-        E.raw("    spec_load_q<D>(A.q, base, rows, lane, lds, q);")
+        E.raw("    spec_load_q<D>(static_cast<const IO*>(A.q), base, rows, lane, lds, q);")
         E.raw("    spec_stamp(A.stamps, wblock, 1, lane);")
         # ---------------- forward ----------------
         R: Dict[int, List[List[S]]] = {}
@@ -305,10 +306,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             R[i] = A
         # ---------------- outputs that depend only on FK ----------------
         pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
-        E.raw(f"    PosFlusher<{3 * L}> flush{{nullptr, nullptr, lane, PosFlusher<{3 * L}>::NCHUNK}};")
+        E.raw(f"    PosFlusher<{3 * L}, IO> flush{{nullptr, nullptr, lane, PosFlusher<{3 * L}, IO>::NCHUNK}};")
         E.raw("    if (A.link_pos) {")
         E.raw(f"        const float pv[{3 * L}] = {{{pos_list}}};")
-        E.raw(f"        flush = spec_stage_rows<{3 * L}>(A.link_pos, base, rows, lane, lds, pv);")
+        E.raw(f"        flush = spec_stage_rows<{3 * L}>(static_cast<IO*>(A.link_pos), base, rows, lane, lds, pv);")
         E.raw("    }")
         E.raw("    flush(); flush();")
         E.raw("    spec_stamp(A.stamps, wblock, 3, lane);")
@@ -402,7 +403,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
         E.raw("    flush.flush();")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
-        E.raw("    spec_store_gq<D>(A.gq, base, rows, lane, lds, gv);")
+        E.raw("    spec_store_gq<D>(static_cast<IO*>(A.gq), base, rows, lane, lds, gv);")
         E.raw("    spec_stamp(A.stamps, wblock, 7, lane);")
         E.raw("}")
         out.extend(E.lines)
@@ -414,8 +415,13 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"static const int32_t kSelfPairs[] = {{{pairs}}};")
     out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
-    out.append("    if (base_identity) hipLaunchKernelGGL(k_rollout_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-    out.append("    else hipLaunchKernelGGL(k_rollout_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    if (a.io_f16) {")
+    out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<_Float16>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("        else hipLaunchKernelGGL(k_rollout_bg<_Float16>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    } else {")
+    out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<float>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("        else hipLaunchKernelGGL(k_rollout_bg<float>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    }")
     out.append("}")
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch}};")

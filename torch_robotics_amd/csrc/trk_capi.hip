@@ -590,16 +590,16 @@ int trk_ee_cost(const TrkCostModel* cm, const float* H_ee, int64_t n, int64_t st
     return TRK_OK;
 }
 
-int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const float* q,
-                          int64_t batch, int32_t horizon, float* link_pos_out, float* cost, float* gq, float* cost_sum,
-                          trk_stream_t stream) {
-    int rc = check_model(m, "trk_rollout_cost_grad");
+static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, int io_f16,
+                        const void* q, int64_t batch, int32_t horizon, void* link_pos_out, float* cost, void* gq,
+                        float* cost_sum, trk_stream_t stream) {
+    int rc = check_model(m, who);
     if (rc) return rc;
-    if (!cm || !w) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad: null argument");
-    if (batch < 0 || horizon < 1) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad: bad batch/horizon");
-    if (cm->hdr.n_links_in != m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad: cost model n_links_in != model n_links");
+    if (!cm || !w) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null argument");
+    if (batch < 0 || horizon < 1) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": bad batch/horizon");
+    if (cm->hdr.n_links_in != m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": cost model n_links_in != model n_links");
     const int64_t n = batch * horizon;
-    if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad: null q/cost/gq");
+    if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null q/cost/gq");
     if (n == 0) return TRK_OK;
     if (m->spec && m->spec_enabled) {
         // the generated kernel has the robot's collision-link sets baked in: use it only when the cost model's match
@@ -618,7 +618,7 @@ int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRo
             std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
             a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
-            a.stamps = g_stamps;
+            a.stamps = g_stamps; a.io_f16 = io_f16;
             const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z[3] = {0, 0, 0};
             const int base_id = std::memcmp(a.base_R, I, sizeof(I)) == 0 && std::memcmp(a.base_t, Z, sizeof(Z)) == 0;
             e->launch(a, base_id, (hipStream_t)stream);
@@ -626,9 +626,21 @@ int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRo
             return TRK_OK;
         }
     }
-    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, nullptr, cm->hdr, *w, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
+    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, nullptr, cm->hdr, *w, io_f16, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
+}
+
+int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const float* q,
+                          int64_t batch, int32_t horizon, float* link_pos_out, float* cost, float* gq, float* cost_sum,
+                          trk_stream_t stream) {
+    return rollout_impl("trk_rollout_cost_grad", m, cm, w, 0, q, batch, horizon, link_pos_out, cost, gq, cost_sum, stream);
+}
+
+int trk_rollout_cost_grad_f16(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const void* q_f16,
+                              int64_t batch, int32_t horizon, void* link_pos_out_f16, float* cost, void* gq_f16,
+                              float* cost_sum, trk_stream_t stream) {
+    return rollout_impl("trk_rollout_cost_grad_f16", m, cm, w, 1, q_f16, batch, horizon, link_pos_out_f16, cost, gq_f16, cost_sum, stream);
 }
 
 int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const TrkCostModel* cm, const TrkRolloutWeights* w,
@@ -645,7 +657,7 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
     const int64_t n = batch * horizon;
     if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: null q/cost/gq");
     if (n == 0) return TRK_OK;
-    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, &ps->dev, cm->hdr, *w, q, n, point_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
+    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, &ps->dev, cm->hdr, *w, 0, q, n, point_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }
@@ -658,6 +670,20 @@ int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, 
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_interpolate(x, n_traj, horizon, dim, n_interp, alpha, beta, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_gp_prior_cost_grad(const void* q, const void* qd, int64_t batch, int32_t horizon, int32_t dof, int32_t io_dtype,
+                           float dt, float sigma, float weight, float* cost, void* gq, void* gqd, int32_t accumulate,
+                           trk_stream_t stream) {
+    if (batch < 0 || horizon < 1 || dof < 1 || (io_dtype != TRK_F32 && io_dtype != TRK_F16) || !(dt > 0.0f) || !(sigma > 0.0f) ||
+        batch > 0x7fffffff || (batch > 0 && (!q || !qd || !cost || !gq || !gqd)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_gp_prior_cost_grad: bad argument");
+    if (batch == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_gp_prior(io_dtype == TRK_F16, q, qd, batch, horizon, dof, dt, sigma, weight, cost, gq, gqd, accumulate, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }

@@ -16,23 +16,27 @@
 
 namespace {
 
-__device__ __forceinline__ void load_tile(float* dst, const float* __restrict__ src, int64_t first, int64_t count, int lane) {
-    // dst[0..count) = src[first .. first+count), contiguous -> fully coalesced dword loads
-    for (int64_t k = lane; k < count; k += TRK_WAVE) dst[k] = src[first + k];
+// IO = HBM-side element type (float, or _Float16 for the fp16-I/O rollout); LDS and arithmetic are fp32
+template <class IO>
+__device__ __forceinline__ void load_tile(float* dst, const IO* __restrict__ src, int64_t first, int64_t count, int lane) {
+    // dst[0..count) = src[first .. first+count), contiguous -> fully coalesced loads
+    for (int64_t k = lane; k < count; k += TRK_WAVE) dst[k] = (float)src[first + k];
 }
 
-__device__ __forceinline__ void store_tile(float* __restrict__ dst, const float* src, int64_t first, int64_t count, int lane) {
-    for (int64_t k = lane; k < count; k += TRK_WAVE) dst[first + k] = src[k];
+template <class IO>
+__device__ __forceinline__ void store_tile(IO* __restrict__ dst, const float* src, int64_t first, int64_t count, int lane) {
+    for (int64_t k = lane; k < count; k += TRK_WAVE) dst[first + k] = (IO)src[k];
 }
 
 // copy a [rows][width] tile kept in LDS with an odd row stride `rs` to/from contiguous global memory
-__device__ __forceinline__ void store_tile_strided(float* __restrict__ dst, const float* src, int64_t first, int rows,
+template <class IO>
+__device__ __forceinline__ void store_tile_strided(IO* __restrict__ dst, const float* src, int64_t first, int rows,
                                                    int width, int rs, int lane) {
     int r = lane / width, c = lane - r * width;
     const int dr = TRK_WAVE / width, dc = TRK_WAVE - dr * width;
     const int64_t count = (int64_t)rows * width;
     for (int64_t k = lane; k < count; k += TRK_WAVE) {
-        dst[first + k] = src[r * rs + c];
+        dst[first + k] = (IO)src[r * rs + c];
         r += dr; c += dc;
         if (c >= width) { c -= width; ++r; }
     }
@@ -607,11 +611,11 @@ k_ee_cost(DevCostHdr C, const float* __restrict__ H, int64_t n, int64_t stride, 
 // Fused rollout, table-driven: walk 1 (FK -> position tile, EE rotation), costs + position adjoints,
 // walk 2 (reverse pass).  q [N,D] -> link_pos [N,L,3] (nullable), cost [N], gq [N,D], cost_sum (nullable).
 // ============================================================================================
-template <bool POINTS>     // POINTS: the cost model's columns are the attached points of `ps`, not the links
+template <bool POINTS, class IO>     // POINTS: the cost model's columns are the attached points of `ps`, not the links
 __global__ void __launch_bounds__(TRK_WAVE)
 k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, SelMap sel_unused, DevPointSet ps, DevCostHdr C,
-                  TrkRolloutWeights w, const float* __restrict__ q, int64_t n, float* __restrict__ link_pos,
-                  float* __restrict__ cost, float* __restrict__ gq, float* __restrict__ cost_sum) {
+                  TrkRolloutWeights w, const IO* __restrict__ q, int64_t n, IO* __restrict__ link_pos,
+                  float* __restrict__ cost, IO* __restrict__ gq, float* __restrict__ cost_sum) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int D = hdr.n_dofs, L = hdr.n_links;
@@ -1019,6 +1023,49 @@ k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, i
     out[idx] = __fadd_rn(__fmul_rn(x0, alpha[a]), __fmul_rn(x1, beta[a]));
 }
 
+// ============================================================================================
+// Constant-velocity GP prior over a trajectory (GPMP-style smoothness term; BUILD-DEFINED: the reference has only
+// finite differences, SURVEY.md 8a "items the north star names but the reference does not contain").
+// Per DOF the state is x_t = (p_t, v_t);  e_t = Phi x_t - x_{t+1} = (p_t + dt v_t - p_{t+1}, v_t - v_{t+1});
+// Q^-1 = sigma^-2 [[12/dt^3, -6/dt^2], [-6/dt^2, 4/dt]];  cost_b = w * 1/2 sum_t sum_d e^T Q^-1 e.
+// With r_t = Q^-1 e_t:  d/dx_t = Phi^T r_t - r_{t-1} = (rp_t - rp_{t-1}, dt rp_t + rv_t - rv_{t-1}).
+// The DOFs do not couple (Q^-1 is 2x2 (x) I_D), so there is no matrix contraction to hand to MFMA: this is a
+// streaming kernel.  One workgroup per trajectory; element (t, d) -> thread, fully coalesced; T = float or _Float16 I/O
+// with fp32 arithmetic and an fp32 cost.
+// ============================================================================================
+template <class T>
+__global__ void __launch_bounds__(256)
+k_gp_prior(const T* __restrict__ q, const T* __restrict__ qd, int H, int D, float dt, float a, float b, float c, float w,
+           float* __restrict__ cost, T* __restrict__ gq, T* __restrict__ gqd, int accumulate) {
+    __shared__ float part[4];
+    const int64_t base = (int64_t)blockIdx.x * H * D;
+    const int total = H * D;
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int t = i / D;
+        const float p0 = (float)q[base + i], v0 = (float)qd[base + i];
+        float gp = 0.0f, gv = 0.0f;
+        if (t + 1 < H) {
+            const float ep = fmaf(dt, v0, p0) - (float)q[base + i + D], ev = v0 - (float)qd[base + i + D];
+            const float rp = fmaf(a, ep, b * ev), rv = fmaf(b, ep, c * ev);
+            acc = fmaf(0.5f, fmaf(ep, rp, ev * rv), acc);
+            gp = rp; gv = fmaf(dt, rp, rv);
+        }
+        if (t > 0) {
+            const float pm = (float)q[base + i - D], vm = (float)qd[base + i - D];
+            const float ep = fmaf(dt, vm, pm) - p0, ev = vm - v0;
+            gp -= fmaf(a, ep, b * ev); gv -= fmaf(b, ep, c * ev);
+        }
+        gp *= w; gv *= w;
+        if (accumulate) { gp += (float)gq[base + i]; gv += (float)gqd[base + i]; }
+        gq[base + i] = (T)gp; gqd[base + i] = (T)gv;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) cost[blockIdx.x] = w * ((part[0] + part[1]) + (part[2] + part[3]));
+}
+
 // deterministic sum: one 256-thread workgroup, fixed strides, LDS tree
 __global__ void __launch_bounds__(256)
 k_reduce_sum(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
@@ -1092,13 +1139,24 @@ size_t trk_lds_fk_points(const DevModelHdr& hdr, int n_points, bool backward) {
                             (size_t)TRK_WAVE * ((n_points * 3) | 1));
 }
 
+template <class IO>
+static void launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet* ps,
+                                   const DevCostHdr& C, const TrkRolloutWeights& w, const void* q, int64_t n, void* link_pos,
+                                   float* cost, void* gq, float* cost_sum, hipStream_t st) {
+    const IO* qq = static_cast<const IO*>(q);
+    IO* lp = static_cast<IO*>(link_pos);
+    IO* gg = static_cast<IO*>(gq);
+    if (ps) hipLaunchKernelGGL((k_rollout_generic<true, IO>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, ps->n_points), st,
+                               hdr, links, fin, SelMap{}, *ps, C, w, qq, n, lp, cost, gg, cost_sum);
+    else hipLaunchKernelGGL((k_rollout_generic<false, IO>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, hdr.n_links), st,
+                            hdr, links, fin, SelMap{}, DevPointSet{}, C, w, qq, n, lp, cost, gg, cost_sum);
+}
+
 void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet* ps,
-                                const DevCostHdr& C, const TrkRolloutWeights& w, const float* q, int64_t n, float* link_pos,
-                                float* cost, float* gq, float* cost_sum, hipStream_t st) {
-    if (ps) hipLaunchKernelGGL(k_rollout_generic<true>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, ps->n_points), st,
-                               hdr, links, fin, SelMap{}, *ps, C, w, q, n, link_pos, cost, gq, cost_sum);
-    else hipLaunchKernelGGL(k_rollout_generic<false>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, hdr.n_links), st,
-                            hdr, links, fin, SelMap{}, DevPointSet{}, C, w, q, n, link_pos, cost, gq, cost_sum);
+                                const DevCostHdr& C, const TrkRolloutWeights& w, int io_f16, const void* q, int64_t n,
+                                void* link_pos, float* cost, void* gq, float* cost_sum, hipStream_t st) {
+    if (io_f16) launch_rollout_generic<_Float16>(hdr, links, fin, ps, C, w, q, n, link_pos, cost, gq, cost_sum, st);
+    else launch_rollout_generic<float>(hdr, links, fin, ps, C, w, q, n, link_pos, cost, gq, cost_sum, st);
 }
 
 void trk_launch_fk_points(const DevModelHdr& hdr, const DevLink* links, const DevPointSet& ps, const float* q, int64_t n,
@@ -1145,6 +1203,16 @@ void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_inter
     hipLaunchKernelGGL(k_interpolate_via_points, dim3(grid_for(total, 256)), dim3(256), 0, st, x, T, H, D, n_interp, alpha, beta, out);
 }
 
+void trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
+                         float* cost, void* gq, void* gqd, int accumulate, hipStream_t st) {
+    const float s2 = 1.0f / (sigma * sigma);
+    const float a = 12.0f * s2 / (dt * dt * dt), b = -6.0f * s2 / (dt * dt), c = 4.0f * s2 / dt;
+    if (f16) hipLaunchKernelGGL(k_gp_prior<_Float16>, dim3((unsigned)B), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)qd, H, D,
+                                dt, a, b, c, w, cost, (_Float16*)gq, (_Float16*)gqd, accumulate);
+    else hipLaunchKernelGGL(k_gp_prior<float>, dim3((unsigned)B), dim3(256), 0, st, (const float*)q, (const float*)qd, H, D,
+                            dt, a, b, c, w, cost, (float*)gq, (float*)gqd, accumulate);
+}
+
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, x, n, out);
 }
@@ -1158,7 +1226,8 @@ int trk_kernels_init(void) {
     hipError_t e = hipSuccess;
 #define TRK_SET(k) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)
     TRK_SET(k_fk_forward<0>); TRK_SET(k_fk_forward<1>); TRK_SET(k_fk_backward<0>); TRK_SET(k_fk_backward<1>);
-    TRK_SET(k_cost_fields); TRK_SET(k_collision_fields); TRK_SET(k_rollout_generic<false>); TRK_SET(k_rollout_generic<true>);
+    TRK_SET(k_cost_fields); TRK_SET(k_collision_fields); TRK_SET((k_rollout_generic<false, float>)); TRK_SET((k_rollout_generic<true, float>));
+    TRK_SET((k_rollout_generic<false, _Float16>)); TRK_SET((k_rollout_generic<true, _Float16>));
     TRK_SET(k_fk_jacobian); TRK_SET(k_fk_points); TRK_SET(k_fk_points_backward);
     TRK_SET(k_fk_analytic_jacobian); TRK_SET(k_ik_step);
 #undef TRK_SET

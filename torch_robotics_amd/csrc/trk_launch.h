@@ -17,9 +17,10 @@ void trk_launch_collision_fields(const DevCostHdr& C, int fields, const float* l
 void trk_launch_ee_cost(const DevCostHdr& C, const float* H, int64_t n, int64_t stride, const float* target, int per_sample,
                         const float* gcost, float* cost, float* gH, int64_t g_stride, hipStream_t st);
 // ps == nullptr: the cost model's columns are the links; otherwise the attached points of *ps
+// io_f16: q / link_pos / gq are _Float16 in HBM (fp32 otherwise); arithmetic, cost and cost_sum are always fp32
 void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet* ps,
-                                const DevCostHdr& C, const TrkRolloutWeights& w, const float* q, int64_t n, float* link_pos,
-                                float* cost, float* gq, float* cost_sum, hipStream_t st);
+                                const DevCostHdr& C, const TrkRolloutWeights& w, int io_f16, const void* q, int64_t n,
+                                void* link_pos, float* cost, void* gq, float* cost_sum, hipStream_t st);
 void trk_launch_fk_points(const DevModelHdr& hdr, const DevLink* links, const DevPointSet& ps, const float* q, int64_t n,
                           float* out, hipStream_t st);
 void trk_launch_fk_points_backward(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet& ps,
@@ -36,6 +37,8 @@ void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const 
                                 float* grad, hipStream_t st);
 void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_interp, const float* alpha, const float* beta,
                             float* out, hipStream_t st);
+void trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
+                         float* cost, void* gq, void* gqd, int accumulate, hipStream_t st);
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st);
 void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st);
 // raises the dynamic-LDS ceiling of every kernel once (gfx950: 160 KiB per workgroup)

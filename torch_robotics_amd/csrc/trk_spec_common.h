@@ -20,12 +20,13 @@ struct SpecArgs {
     TrkRolloutWeights w;
     float base_R[9];
     float base_t[3];
-    const float* q;
+    const void* q;                // float or _Float16 (io_f16), like link_pos and gq
     int64_t n;
-    float* link_pos;
+    void* link_pos;
     float* cost;
-    float* gq;
+    void* gq;
     float* cost_sum;
+    int32_t io_f16;               // 1: q / link_pos / gq are fp16 in HBM (arithmetic, cost and cost_sum stay fp32)
     unsigned long long* stamps;   // profiling hook (nullable): [n_waves][8] s_memtime stamps at phase boundaries
 };
 
@@ -70,34 +71,58 @@ __device__ __forceinline__ void store_wt_f1(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 
+// HBM-side element type of q / link_pos / gq: four consecutive elements <-> one float4 of LDS (fp32 arithmetic always).
+typedef _Float16 trk_h4 __attribute__((ext_vector_type(4)));
+template <class IO> struct IoQuad;
+template <> struct IoQuad<float> {
+    static constexpr uintptr_t kAlignMask = 15;
+    static __device__ __forceinline__ float4 load(const float* p, int k) { return reinterpret_cast<const float4*>(p)[k]; }
+    static __device__ __forceinline__ void store_wt(float* p, int k, const float4& v) { store_wt_f4(reinterpret_cast<float4*>(p) + k, v); }
+    static __device__ __forceinline__ void store_wt1(float* p, float v) { store_wt_f1(p, v); }
+};
+template <> struct IoQuad<_Float16> {
+    static constexpr uintptr_t kAlignMask = 7;
+    static __device__ __forceinline__ float4 load(const _Float16* p, int k) {
+        const trk_h4 h = reinterpret_cast<const trk_h4*>(p)[k];
+        return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+    }
+    static __device__ __forceinline__ void store_wt(_Float16* p, int k, const float4& v) {
+        const trk_h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        asm volatile("global_store_dwordx2 %0, %1, off sc1\n s_nop 1" :: "v"(reinterpret_cast<trk_h4*>(p) + k), "v"(h) : "memory");
+    }
+    static __device__ __forceinline__ void store_wt1(_Float16* p, float v) {
+        const _Float16 h = (_Float16)v;
+        asm volatile("global_store_short %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h) : "memory");
+    }
+};
+
 // copy the first TRK_LDS_SPHERES world-frame spheres into this wave's LDS (one 16-byte load per lane, issued together
 // with the q loads so its latency is free)
 __device__ __forceinline__ void spec_load_spheres(const DevCostHdr& C, float4* lds_spheres, int lane) {
     if (lane < TRK_LDS_SPHERES && lane < C.n_spheres) lds_spheres[lane] = C.spheres[lane];
 }
 
-template <int D>
-__device__ __forceinline__ void spec_load_q(const float* __restrict__ q, int64_t base, int rows, int lane,
+template <int D, class IO>
+__device__ __forceinline__ void spec_load_q(const IO* __restrict__ q, int64_t base, int rows, int lane,
                                             float* lds, float (&qv)[D]) {
     // the wave's 64*D floats are one contiguous span: 16-byte loads (2 instructions for D = 7) into LDS, then a
     // stride-D read back (D odd -> conflict-free); ragged / unaligned tails take the dword path
     const int64_t first = base * D;
-    const float* src = q + first;
+    const IO* src = q + first;
     constexpr int NV = TRK_WAVE * D / 4;
-    if (rows == TRK_WAVE && (TRK_WAVE * D) % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-        const float4* src4 = reinterpret_cast<const float4*>(src);
+    if (rows == TRK_WAVE && (TRK_WAVE * D) % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) & IoQuad<IO>::kAlignMask) == 0)) {
         float4* lds4 = reinterpret_cast<float4*>(lds);
 #pragma unroll
         for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
             const int k = lane + TRK_WAVE * j;
-            if (k < NV) lds4[k] = src4[k];
+            if (k < NV) lds4[k] = IoQuad<IO>::load(src, k);
         }
     } else {
         const int count = rows * D;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const int k = lane + TRK_WAVE * j;
-            lds[k] = k < count ? src[k] : 0.0f;
+            lds[k] = k < count ? (float)src[k] : 0.0f;
         }
     }
     spec_wave_sync();
@@ -106,30 +131,29 @@ __device__ __forceinline__ void spec_load_q(const float* __restrict__ q, int64_t
     spec_wave_sync();
 }
 
-template <int D>
-__device__ __forceinline__ void spec_store_gq(float* __restrict__ gq, int64_t base, int rows, int lane,
+template <int D, class IO>
+__device__ __forceinline__ void spec_store_gq(IO* __restrict__ gq, int64_t base, int rows, int lane,
                                               float* lds, const float (&gv)[D]) {
     spec_wave_sync();
 #pragma unroll
     for (int j = 0; j < D; ++j) lds[lane * D + j] = gv[j];
     spec_wave_sync();
     const int64_t first = base * D;
-    float* dst = gq + first;
+    IO* dst = gq + first;
     constexpr int NV = TRK_WAVE * D / 4;
-    if (rows == TRK_WAVE && (TRK_WAVE * D) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+    if (rows == TRK_WAVE && (TRK_WAVE * D) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & IoQuad<IO>::kAlignMask) == 0)) {
         const float4* lds4 = reinterpret_cast<const float4*>(lds);
-        float4* dst4 = reinterpret_cast<float4*>(dst);
 #pragma unroll
         for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
             const int k = lane + TRK_WAVE * j;
-            if (k < NV) store_wt_f4(dst4 + k, lds4[k]);
+            if (k < NV) IoQuad<IO>::store_wt(dst, k, lds4[k]);
         }
     } else {
         const int count = rows * D;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const int k = lane + TRK_WAVE * j;
-            if (k < count) store_wt_f1(dst + k, lds[k]);
+            if (k < count) IoQuad<IO>::store_wt1(dst + k, lds[k]);
         }
     }
 }
@@ -140,18 +164,18 @@ __device__ __forceinline__ void spec_store_gq(float* __restrict__ gq, int64_t ba
 // time, and 16 waves x 8.25 KiB per CU saturate the store path for ~6 us during which nothing computes.
 // `tick()` issues one chunk; the kernel calls it between blocks of arithmetic so the 34.6 MB trickle out at
 // roughly the rate HBM absorbs them.
-template <int W>
+template <int W, class IO>
 struct PosFlusher {
-    static constexpr int NV = W * TRK_WAVE / 4;                  // float4 chunks per wave
+    static constexpr int NV = W * TRK_WAVE / 4;                  // 4-element chunks per wave
     static constexpr int NCHUNK = (NV + TRK_WAVE - 1) / TRK_WAVE;
     const float4* src4;
-    float4* dst4;
+    IO* dst;
     int lane;
     int next;                                                    // wave-uniform
     __device__ __forceinline__ void operator()() {
         if (next < NCHUNK) {
             const int k = lane + TRK_WAVE * next;
-            if (k < NV) store_wt_f4(dst4 + k, src4[k]);
+            if (k < NV) IoQuad<IO>::store_wt(dst, k, src4[k]);
             ++next;
         }
     }
@@ -161,20 +185,20 @@ struct PosFlusher {
 };
 
 // stage the wave's rows in LDS; returns a flusher (fast path) or writes everything now (ragged / unaligned tail)
-template <int W>
-__device__ __forceinline__ PosFlusher<W> spec_stage_rows(float* __restrict__ out, int64_t base, int rows, int lane,
-                                                         float* lds, const float (&v)[W]) {
+template <int W, class IO>
+__device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows(IO* __restrict__ out, int64_t base, int rows, int lane,
+                                                             float* lds, const float (&v)[W]) {
     spec_wave_sync();
 #pragma unroll
     for (int j = 0; j < W; ++j) lds[lane * W + j] = v[j];
     spec_wave_sync();
-    float* dst = out + base * W;
-    PosFlusher<W> f{reinterpret_cast<const float4*>(lds), reinterpret_cast<float4*>(dst), lane, 0};
-    const bool fast = rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    IO* dst = out + base * W;
+    PosFlusher<W, IO> f{reinterpret_cast<const float4*>(lds), dst, lane, 0};
+    const bool fast = rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & IoQuad<IO>::kAlignMask) == 0);
     if (!fast) {
         const int count = rows * W;
-        for (int k = lane; k < count; k += TRK_WAVE) dst[k] = lds[k];
-        f.next = PosFlusher<W>::NCHUNK;
+        for (int k = lane; k < count; k += TRK_WAVE) dst[k] = (IO)lds[k];
+        f.next = PosFlusher<W, IO>::NCHUNK;
     }
     return f;
 }

@@ -312,8 +312,16 @@ def ee_cost(cm: CostHandle, H: torch.Tensor, target: Optional[torch.Tensor] = No
 
 def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True,
                       cost_sum: Optional[torch.Tensor] = None, out=None):
-    """q (B,H,D) or (N,D) -> (link_pos (…,L,3) or None, cost (…), gq (…,D))."""
-    q = _dev_f32(q, "rollout_cost_grad(q)")
+    """q (B,H,D) or (N,D) -> (link_pos (…,L,3) or None, cost (…), gq (…,D)).
+    A float16 q selects the fp16-I/O kernel: link_pos and gq come back as float16, cost stays float32."""
+    f16 = q.dtype == torch.float16
+    if f16:
+        if q.device.type != "cuda":
+            raise ValueError("rollout_cost_grad(q): expected a CUDA/HIP tensor (there is no CPU path)")
+        q = q.contiguous()
+    else:
+        q = _dev_f32(q, "rollout_cost_grad(q)")
+    io = torch.float16 if f16 else torch.float32
     lead = q.shape[:-1]
     if q.dim() == 3:
         B, Hh = int(q.shape[0]), int(q.shape[1])
@@ -322,15 +330,18 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
         B, Hh = int(q.shape[0]), 1
     n, L, D = B * Hh, model.n_links, model.n_dofs
     if out is None:
-        pos = torch.empty((n, L, 3), device=q.device, dtype=torch.float32) if want_pos else None
+        pos = torch.empty((n, L, 3), device=q.device, dtype=io) if want_pos else None
         cost = torch.empty((n,), device=q.device, dtype=torch.float32)
-        gq = torch.empty((n, D), device=q.device, dtype=torch.float32)
+        gq = torch.empty((n, D), device=q.device, dtype=io)
     else:
         pos, cost, gq = out
+        if gq.dtype != io or (pos is not None and pos.dtype != io) or cost.dtype != torch.float32:
+            raise ValueError("rollout_cost_grad(out): link_pos / gq must have q's dtype and cost must be float32")
     w = _abi.RolloutWeights(*[float(v) for v in weights])
+    fn = lib().trk_rollout_cost_grad_f16 if f16 else lib().trk_rollout_cost_grad
     with torch.cuda.device(q.device):
-        check(lib().trk_rollout_cost_grad(model._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos), cost.data_ptr(),
-                                          gq.data_ptr(), _ptr(cost_sum), _stream(q)), "trk_rollout_cost_grad")
+        check(fn(model._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos), cost.data_ptr(),
+                 gq.data_ptr(), _ptr(cost_sum), _stream(q)), "trk_rollout_cost_grad")
     return (None if pos is None else pos.reshape(tuple(lead) + (L, 3)), cost.reshape(tuple(lead)),
             gq.reshape(tuple(lead) + (D,)))
 
@@ -358,6 +369,51 @@ def rollout_points_cost_grad(ps: PointSetHandle, cm: CostHandle, weights, q: tor
               "trk_rollout_points_cost_grad")
     return (None if pos is None else pos.reshape(tuple(lead) + (P, 3)), cost.reshape(tuple(lead)),
             gq.reshape(tuple(lead) + (D,)))
+
+
+def gp_prior_cost_grad(q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: float, weight: float = 1.0,
+                       accumulate_into=None):
+    """Constant-velocity GP prior over (B,H,D) trajectories (build-defined; include/trk.h): -> (cost (B,), gq, gqd).
+    fp32 or fp16 tensors (fp32 arithmetic, fp32 cost).  accumulate_into=(gq, gqd) adds the gradient into existing buffers."""
+    if q.device.type != "cuda" or qd.device != q.device:
+        raise ValueError("gp_prior_cost_grad: q and qd must be tensors on the same GPU (there is no CPU path)")
+    if q.dim() != 3 or qd.shape != q.shape or q.dtype != qd.dtype or q.dtype not in (torch.float32, torch.float16):
+        raise ValueError("gp_prior_cost_grad: q, qd must be (batch, horizon, dof) of the same fp32 / fp16 dtype")
+    q, qd = q.contiguous(), qd.contiguous()
+    B, H, D = (int(v) for v in q.shape)
+    cost = torch.empty((B,), device=q.device, dtype=torch.float32)
+    if accumulate_into is None:
+        gq, gqd, acc = torch.empty_like(q), torch.empty_like(q), 0
+    else:
+        gq, gqd = accumulate_into
+        acc = 1
+        if gq.shape != q.shape or gqd.shape != q.shape or gq.dtype != q.dtype or gqd.dtype != q.dtype or \
+                not (gq.is_contiguous() and gqd.is_contiguous()):
+            raise ValueError("gp_prior_cost_grad: accumulate_into buffers must match q (shape, dtype, contiguous)")
+    with torch.cuda.device(q.device):
+        check(lib().trk_gp_prior_cost_grad(q.data_ptr(), qd.data_ptr(), B, H, D, int(q.dtype == torch.float16), float(dt),
+                                           float(sigma), float(weight), cost.data_ptr(), gq.data_ptr(), gqd.data_ptr(), acc,
+                                           _stream(q)), "trk_gp_prior_cost_grad")
+    return cost, gq, gqd
+
+
+class _GPPrior(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, qd, dt, sigma):
+        cost, gq, gqd = gp_prior_cost_grad(q, qd, dt, sigma)
+        ctx.save_for_backward(gq, gqd)
+        return cost
+
+    @staticmethod
+    def backward(ctx, gcost):
+        gq, gqd = ctx.saved_tensors
+        sc = gcost.reshape(-1, 1, 1)
+        return (gq * sc).to(gq.dtype), (gqd * sc).to(gqd.dtype), None, None
+
+
+def gp_prior_cost(q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: float) -> torch.Tensor:
+    """Differentiable GP-prior cost per trajectory, (B,H,D) x 2 -> (B,)."""
+    return _GPPrior.apply(q, qd, float(dt), float(sigma))
 
 
 def interpolate_traj_via_points(trajs: torch.Tensor, num_interpolation: int = 10) -> torch.Tensor:
@@ -555,18 +611,19 @@ class RolloutPlan:
     (a planner's inner loop re-evaluates the same buffers thousands of times)."""
 
     def __init__(self, model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True):
-        q = _dev_f32(q, "RolloutPlan(q)")
+        f16 = q.dtype == torch.float16
+        q = q.contiguous() if (f16 and q.device.type == "cuda") else _dev_f32(q, "RolloutPlan(q)")
         if q.dim() != 3:
             raise ValueError("RolloutPlan: q must be (batch, horizon, dof)")
         self.model, self.cm, self.q = model, cm, q
         self.B, self.H = int(q.shape[0]), int(q.shape[1])
         n, L, D = self.B * self.H, model.n_links, model.n_dofs
-        kw = dict(device=q.device, dtype=torch.float32)
+        kw = dict(device=q.device, dtype=q.dtype)
         self.link_pos = torch.empty((self.B, self.H, L, 3), **kw) if want_pos else None
-        self.cost = torch.empty((self.B, self.H), **kw)
+        self.cost = torch.empty((self.B, self.H), device=q.device, dtype=torch.float32)
         self.gq = torch.empty((self.B, self.H, D), **kw)
         self._w = _abi.RolloutWeights(*[float(v) for v in weights])
-        self._fn = lib().trk_rollout_cost_grad
+        self._fn = lib().trk_rollout_cost_grad_f16 if f16 else lib().trk_rollout_cost_grad
         self._args = (model._h, cm._h, C.byref(self._w), q.data_ptr(), self.B, self.H, _ptr(self.link_pos),
                       self.cost.data_ptr(), self.gq.data_ptr())
         self.device = q.device
