@@ -353,7 +353,7 @@ int trk_fk_jacobian(const TrkModel* m, const float* q, const float* qd, int64_t 
     if (link < 0 || link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_fk_jacobian: link out of range");
     if (n < 0 || (n > 0 && (!q || !pos || !quat || !lin_jac || !ang_jac))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_jacobian: null argument");
     if (n == 0) return TRK_OK;
-    trk_launch_fk_jacobian(m->hdr, m->d_links, q, qd, n, link, m->joint_list_idx[link], pos, quat, lin_jac, ang_jac,
+    trk_launch_fk_jacobian(m->hdr, m->d_links, m->links.data(), q, qd, n, link, m->joint_list_idx[link], pos, quat, lin_jac, ang_jac,
                            vel_lin, vel_ang, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
@@ -683,7 +683,8 @@ int trk_gp_prior_cost_grad(const void* q, const void* qd, int64_t batch, int32_t
     if (batch == 0) return TRK_OK;
     int rc = ensure_init();
     if (rc) return rc;
-    trk_launch_gp_prior(io_dtype == TRK_F16, q, qd, batch, horizon, dof, dt, sigma, weight, cost, gq, gqd, accumulate, (hipStream_t)stream);
+    if (trk_launch_gp_prior(io_dtype == TRK_F16, q, qd, batch, horizon, dof, dt, sigma, weight, cost, gq, gqd, accumulate, (hipStream_t)stream))
+        return fail(TRK_ERR_UNSUPPORTED, "trk_gp_prior_cost_grad: one trajectory (horizon x dof x 2 floats) must fit the 160 KiB LDS");
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }

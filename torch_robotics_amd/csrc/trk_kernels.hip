@@ -12,6 +12,7 @@
 // joint's is  (R_parent axis) . f_sub.  In DFS pre-order a subtree is a contiguous range, so the
 // subtree sum is a difference of two running prefix sums and one forward walk suffices
 // (equals autograd through rigid_body.py:146-211).
+#include <algorithm>
 #include "trk_device.h"
 
 namespace {
@@ -720,81 +721,96 @@ __device__ __forceinline__ void frame_quat_wxyz(const float* R, float* out) {
     out[0] = qw * sc; out[1] = qx * sc; out[2] = qy * sc; out[3] = qz * sc;
 }
 
+struct JacCols {                // DOF -> record slot of the Jacobian columns this call produces (-1: column stays zero)
+    int8_t slot[TRK_MAX_DOFS];
+    int32_t n_cols;
+    int32_t p_end;              // the walk may stop after this pre-order position
+};
+
+// The column records (z, p) of the contributing joints live in LDS lane-major with an odd stride, so both the walk's
+// per-lane writes and the final transposed reads are bank-conflict free; lin_jac / ang_jac [N,3,D] leave as contiguous
+// 64*3D-float runs per wavefront (a per-lane store of 3D floats at a 12D-byte stride touches 64 lines per instruction:
+// measured 361 us at 4096 x 64 on UR10+Allegro before this layout).
 __global__ void __launch_bounds__(TRK_WAVE)
-k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, const float* __restrict__ q, const float* __restrict__ qd,
-              int64_t n, int link, int link_joint_idx, float* __restrict__ pos, float* __restrict__ quat,
-              float* __restrict__ lin_jac, float* __restrict__ ang_jac, float* __restrict__ vel_lin, float* __restrict__ vel_ang) {
+k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, JacCols cols, const float* __restrict__ q,
+              const float* __restrict__ qd, int64_t n, int link, int link_joint_idx, float* __restrict__ pos,
+              float* __restrict__ quat, float* __restrict__ lin_jac, float* __restrict__ ang_jac,
+              float* __restrict__ vel_lin, float* __restrict__ vel_ang) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
-    const int D = hdr.n_dofs, L = hdr.n_links;
+    const int D = hdr.n_dofs;
     const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
     const int rows = (int)min((int64_t)TRK_WAVE, n - base);
+    const int rstride = (6 * cols.n_cols + 3) | 1;          // per lane: n_cols x (z, p) + the link position
     float* qs = smem;
-    float* qds = qs + TRK_WAVE * D;
-    float* slots = qds + TRK_WAVE * D;
+    float* qds = qs + TRK_WAVE * D;                         // only when qd != nullptr
+    float* slots = qds + (qd ? TRK_WAVE * D : 0);
     float* vslots = slots + hdr.n_slots * 12 * TRK_WAVE;
-    float* jz = vslots + hdr.n_slots * 6 * TRK_WAVE;      // [6][D][64]: z (3), p (3); z = 0 marks "no column"
+    float* rec = vslots + (qd ? hdr.n_slots * 6 * TRK_WAVE : 0);
     load_tile(qs, q, base * D, (int64_t)rows * D, lane);
     for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
-    if (qd) load_tile(qds, qd, base * D, (int64_t)rows * D, lane);
-    else for (int k = lane; k < rows * D; k += TRK_WAVE) qds[k] = 0.0f;
-    for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qds[k] = 0.0f;
-    for (int k = lane; k < 6 * D * TRK_WAVE; k += TRK_WAVE) jz[k] = 0.0f;
+    if (qd) {
+        load_tile(qds, qd, base * D, (int64_t)rows * D, lane);
+        for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qds[k] = 0.0f;
+    }
+    float* myrec = rec + lane * rstride;
+    for (int k = 0; k < rstride; ++k) myrec[k] = 0.0f;
     __syncthreads();
     Pose cur, par;
     float vl[3] = {0, 0, 0}, va[3] = {0, 0, 0};
     float eR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, et[3] = {0, 0, 0}, evl[3] = {0, 0, 0}, eva[3] = {0, 0, 0};
-    const int js = D * TRK_WAVE;
-    for (int p = 0; p < L; ++p) {
+    for (int p = 0; p < cols.p_end; ++p) {
         const DevLink& Lk = links[p];
-        float pvl[3], pva[3];
-        if (p > 0 && Lk.parent_slot >= 0) {
-            const float* v = vslots + Lk.parent_slot * 6 * TRK_WAVE + lane;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { pvl[k] = v[k * TRK_WAVE]; pva[k] = v[(3 + k) * TRK_WAVE]; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { pvl[k] = vl[k]; pva[k] = va[k]; }
-        }
         walk_step<true>(hdr, Lk, p, qs, D, lane, slots, cur, par);
-        if (p == 0) { vl[0] = vl[1] = vl[2] = 0.0f; va[0] = va[1] = va[2] = 0.0f; }
-        else {
-            // joint pose J = par^-1 o cur ; parentToChild = J^-1 : R = J.R^T, t = -J.R^T J.t  (frame.py:57-62)
-            // J.R^T = cur.R^T par.R ; J.t = par.R^T (cur.t - par.t)  =>  t_inv = -cur.R^T (cur.t - par.t)
-            float Rt[9];
+        if (qd) {
+            float pvl[3], pva[3];
+            if (p > 0 && Lk.parent_slot >= 0) {
+                const float* v = vslots + Lk.parent_slot * 6 * TRK_WAVE + lane;
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < 3; ++k) { pvl[k] = v[k * TRK_WAVE]; pva[k] = v[(3 + k) * TRK_WAVE]; }
+            } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    Rt[3 * r + c] = cur.r[r] * par.r[c] + cur.r[3 + r] * par.r[3 + c] + cur.r[6 + r] * par.r[6 + c];
-            const float d0 = cur.t[0] - par.t[0], d1 = cur.t[1] - par.t[1], d2 = cur.t[2] - par.t[2];
-            float ti[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) ti[r] = -(cur.r[r] * d0 + cur.r[3 + r] * d1 + cur.r[6 + r] * d2);
-            float Ra[3], Rl[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                Ra[r] = Rt[3 * r] * pva[0] + Rt[3 * r + 1] * pva[1] + Rt[3 * r + 2] * pva[2];
-                Rl[r] = Rt[3 * r] * pvl[0] + Rt[3 * r + 1] * pvl[1] + Rt[3 * r + 2] * pvl[2];
+                for (int k = 0; k < 3; ++k) { pvl[k] = vl[k]; pva[k] = va[k]; }
             }
-            const float qdv = Lk.dof >= 0 ? qds[lane * D + Lk.dof] : 0.0f;
-            vl[0] = ti[1] * Ra[2] - ti[2] * Ra[1] + Rl[0];
-            vl[1] = ti[2] * Ra[0] - ti[0] * Ra[2] + Rl[1];
-            vl[2] = ti[0] * Ra[1] - ti[1] * Ra[0] + Rl[2];
-            va[0] = Ra[0] + qdv * Lk.axis[0]; va[1] = Ra[1] + qdv * Lk.axis[1]; va[2] = Ra[2] + qdv * Lk.axis[2];
-        }
-        if (Lk.store_slot >= 0) {
-            float* v = vslots + Lk.store_slot * 6 * TRK_WAVE + lane;
+            if (p == 0) { vl[0] = vl[1] = vl[2] = 0.0f; va[0] = va[1] = va[2] = 0.0f; }
+            else {
+                // joint pose J = par^-1 o cur ; parentToChild = J^-1 : R = J.R^T, t = -J.R^T J.t  (frame.py:57-62)
+                // J.R^T = cur.R^T par.R ; J.t = par.R^T (cur.t - par.t)  =>  t_inv = -cur.R^T (cur.t - par.t)
+                float Rt[9];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { v[k * TRK_WAVE] = vl[k]; v[(3 + k) * TRK_WAVE] = va[k]; }
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        Rt[3 * r + c] = cur.r[r] * par.r[c] + cur.r[3 + r] * par.r[3 + c] + cur.r[6 + r] * par.r[6 + c];
+                const float d0 = cur.t[0] - par.t[0], d1 = cur.t[1] - par.t[1], d2 = cur.t[2] - par.t[2];
+                float ti[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) ti[r] = -(cur.r[r] * d0 + cur.r[3 + r] * d1 + cur.r[6 + r] * d2);
+                float Ra[3], Rl[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    Ra[r] = Rt[3 * r] * pva[0] + Rt[3 * r + 1] * pva[1] + Rt[3 * r + 2] * pva[2];
+                    Rl[r] = Rt[3 * r] * pvl[0] + Rt[3 * r + 1] * pvl[1] + Rt[3 * r + 2] * pvl[2];
+                }
+                const float qdv = Lk.dof >= 0 ? qds[lane * D + Lk.dof] : 0.0f;
+                vl[0] = ti[1] * Ra[2] - ti[2] * Ra[1] + Rl[0];
+                vl[1] = ti[2] * Ra[0] - ti[0] * Ra[2] + Rl[1];
+                vl[2] = ti[0] * Ra[1] - ti[1] * Ra[0] + Rl[2];
+                va[0] = Ra[0] + qdv * Lk.axis[0]; va[1] = Ra[1] + qdv * Lk.axis[1]; va[2] = Ra[2] + qdv * Lk.axis[2];
+            }
+            if (Lk.store_slot >= 0) {
+                float* v = vslots + Lk.store_slot * 6 * TRK_WAVE + lane;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { v[k * TRK_WAVE] = vl[k]; v[(3 + k) * TRK_WAVE] = va[k]; }
+            }
         }
         if (Lk.dof >= 0 && (Lk.link - 1) <= link_joint_idx && Lk.jac_axis >= 0) {   // robot_tree.py:239-244
             const int ax = Lk.jac_axis;
-            float* j = jz + Lk.dof * TRK_WAVE + lane;
+            float* j = myrec + 6 * cols.slot[Lk.dof];
             j[0] = ax == 0 ? cur.r[0] : (ax == 1 ? cur.r[1] : cur.r[2]);
-            j[js] = ax == 0 ? cur.r[3] : (ax == 1 ? cur.r[4] : cur.r[5]);
-            j[2 * js] = ax == 0 ? cur.r[6] : (ax == 1 ? cur.r[7] : cur.r[8]);
-            j[3 * js] = cur.t[0]; j[4 * js] = cur.t[1]; j[5 * js] = cur.t[2];
+            j[1] = ax == 0 ? cur.r[3] : (ax == 1 ? cur.r[4] : cur.r[5]);
+            j[2] = ax == 0 ? cur.r[6] : (ax == 1 ? cur.r[7] : cur.r[8]);
+            j[3] = cur.t[0]; j[4] = cur.t[1]; j[5] = cur.t[2];
         }
         if (Lk.link == link) {
 #pragma unroll
@@ -803,25 +819,40 @@ k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, const float* _
             for (int k = 0; k < 3; ++k) { et[k] = cur.t[k]; evl[k] = vl[k]; eva[k] = va[k]; }
         }
     }
+    myrec[6 * cols.n_cols] = et[0]; myrec[6 * cols.n_cols + 1] = et[1]; myrec[6 * cols.n_cols + 2] = et[2];
+    __syncthreads();
+    // [rows][3][D] blocks of lin_jac and ang_jac: element k of the wave's contiguous run -> (sample, row, dof)
+    {
+        const int w3 = 3 * D;
+        int sl = lane / w3, rem = lane - sl * w3;
+        const int ds = TRK_WAVE / w3, dr = TRK_WAVE - ds * w3;
+        const int64_t count = (int64_t)rows * w3;
+        float* lo = lin_jac + base * w3;
+        float* ao = ang_jac + base * w3;
+        for (int64_t k = lane; k < count; k += TRK_WAVE) {
+            const int r = rem / D, d = rem - r * D;
+            const int c = cols.slot[d];
+            float lv = 0.0f, av = 0.0f;
+            if (c >= 0) {
+                const float* j = rec + sl * rstride + 6 * c;
+                const float* e = rec + sl * rstride + 6 * cols.n_cols;
+                const int r1 = r == 2 ? 0 : r + 1, r2 = r == 0 ? 2 : r - 1;
+                av = j[r];
+                lv = j[r1] * (e[r2] - j[3 + r2]) - j[r2] * (e[r1] - j[3 + r1]);      // (z x (p_link - p_joint))_r
+            }
+            lo[k] = lv; ao[k] = av;
+            sl += ds; rem += dr;
+            if (rem >= w3) { rem -= w3; ++sl; }
+        }
+    }
     if (lane >= rows) return;
     const int64_t s = base + lane;
     pos[s * 3] = et[0]; pos[s * 3 + 1] = et[1]; pos[s * 3 + 2] = et[2];
     float qo[4];
     frame_quat_wxyz(eR, qo);
-    quat[s * 4] = qo[0]; quat[s * 4 + 1] = qo[1]; quat[s * 4 + 2] = qo[2]; quat[s * 4 + 3] = qo[3];
+    *reinterpret_cast<float4*>(quat + s * 4) = make_float4(qo[0], qo[1], qo[2], qo[3]);
     if (vel_lin) { vel_lin[s * 3] = evl[0]; vel_lin[s * 3 + 1] = evl[1]; vel_lin[s * 3 + 2] = evl[2]; }
     if (vel_ang) { vel_ang[s * 3] = eva[0]; vel_ang[s * 3 + 1] = eva[1]; vel_ang[s * 3 + 2] = eva[2]; }
-    for (int d = 0; d < D; ++d) {
-        const float* j = jz + d * TRK_WAVE + lane;
-        const float z0 = j[0], z1 = j[js], z2 = j[2 * js];
-        const float r0 = et[0] - j[3 * js], r1 = et[1] - j[4 * js], r2 = et[2] - j[5 * js];
-        lin_jac[(s * 3 + 0) * D + d] = z1 * r2 - z2 * r1;
-        lin_jac[(s * 3 + 1) * D + d] = z2 * r0 - z0 * r2;
-        lin_jac[(s * 3 + 2) * D + d] = z0 * r1 - z1 * r0;
-        ang_jac[(s * 3 + 0) * D + d] = z0;
-        ang_jac[(s * 3 + 1) * D + d] = z1;
-        ang_jac[(s * 3 + 2) * D + d] = z2;
-    }
 }
 
 // ============================================================================================
@@ -1033,32 +1064,83 @@ k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, i
 // streaming kernel.  One workgroup per trajectory; element (t, d) -> thread, fully coalesced; T = float or _Float16 I/O
 // with fp32 arithmetic and an fp32 cost.
 // ============================================================================================
-template <class T>
+template <class T> struct GpVec;          // 4 consecutive elements <-> float4
+template <> struct GpVec<float> {
+    static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void store(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct GpVec<_Float16> {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ float4 load(const _Float16* p) {
+        const h4 h = *reinterpret_cast<const h4*>(p);
+        return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+    }
+    static __device__ __forceinline__ void store(_Float16* p, const float4& v) {
+        const h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<h4*>(p) = h;
+    }
+};
+
+// One workgroup per trajectory.  VEC: H*D is a multiple of 4 and the buffers are 16-byte aligned -> the trajectory's q
+// and qd go to LDS with 4-element loads, each thread then owns 4 consecutive elements and writes them with one store.
+template <class T, bool VEC>
 __global__ void __launch_bounds__(256)
 k_gp_prior(const T* __restrict__ q, const T* __restrict__ qd, int H, int D, float dt, float a, float b, float c, float w,
            float* __restrict__ cost, T* __restrict__ gq, T* __restrict__ gqd, int accumulate) {
-    __shared__ float part[4];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t base = (int64_t)blockIdx.x * H * D;
     const int total = H * D;
+    float* ps = smem;
+    float* vs = smem + ((total + 3) & ~3);
+    float* part = vs + ((total + 3) & ~3);        // 4 floats: per-wavefront partial sums
+    if (VEC) {
+        for (int i = 4 * threadIdx.x; i < total; i += 4 * 256) {
+            *reinterpret_cast<float4*>(ps + i) = GpVec<T>::load(q + base + i);
+            *reinterpret_cast<float4*>(vs + i) = GpVec<T>::load(qd + base + i);
+        }
+    } else {
+        for (int i = threadIdx.x; i < total; i += 256) { ps[i] = (float)q[base + i]; vs[i] = (float)qd[base + i]; }
+    }
+    __syncthreads();
     float acc = 0.0f;
-    for (int i = threadIdx.x; i < total; i += 256) {
+    auto element = [&](int i, float& gp, float& gv) {
         const int t = i / D;
-        const float p0 = (float)q[base + i], v0 = (float)qd[base + i];
-        float gp = 0.0f, gv = 0.0f;
+        const float p0 = ps[i], v0 = vs[i];
+        gp = 0.0f; gv = 0.0f;
         if (t + 1 < H) {
-            const float ep = fmaf(dt, v0, p0) - (float)q[base + i + D], ev = v0 - (float)qd[base + i + D];
+            const float ep = fmaf(dt, v0, p0) - ps[i + D], ev = v0 - vs[i + D];
             const float rp = fmaf(a, ep, b * ev), rv = fmaf(b, ep, c * ev);
             acc = fmaf(0.5f, fmaf(ep, rp, ev * rv), acc);
             gp = rp; gv = fmaf(dt, rp, rv);
         }
         if (t > 0) {
-            const float pm = (float)q[base + i - D], vm = (float)qd[base + i - D];
+            const float pm = ps[i - D], vm = vs[i - D];
             const float ep = fmaf(dt, vm, pm) - p0, ev = vm - v0;
             gp -= fmaf(a, ep, b * ev); gv -= fmaf(b, ep, c * ev);
         }
         gp *= w; gv *= w;
-        if (accumulate) { gp += (float)gq[base + i]; gv += (float)gqd[base + i]; }
-        gq[base + i] = (T)gp; gqd[base + i] = (T)gv;
+    };
+    if (VEC) {
+        for (int i = 4 * threadIdx.x; i < total; i += 4 * 256) {
+            float gp[4], gv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) element(i + k, gp[k], gv[k]);
+            float4 o0 = make_float4(gp[0], gp[1], gp[2], gp[3]), o1 = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            if (accumulate) {
+                const float4 c0 = GpVec<T>::load(gq + base + i), c1 = GpVec<T>::load(gqd + base + i);
+                o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w;
+                o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+            }
+            GpVec<T>::store(gq + base + i, o0);
+            GpVec<T>::store(gqd + base + i, o1);
+        }
+    } else {
+        for (int i = threadIdx.x; i < total; i += 256) {
+            float gp, gv;
+            element(i, gp, gv);
+            if (accumulate) { gp += (float)gq[base + i]; gv += (float)gqd[base + i]; }
+            gq[base + i] = (T)gp; gqd[base + i] = (T)gv;
+        }
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -1171,11 +1253,26 @@ void trk_launch_fk_points_backward(const DevModelHdr& hdr, const DevLink* links,
                        hdr, links, fin, ps, q, gin, n, gq);
 }
 
-void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links, const float* q, const float* qd, int64_t n,
-                            int link, int link_joint_idx, float* pos, float* quat, float* lin_jac, float* ang_jac,
-                            float* vel_lin, float* vel_ang, hipStream_t st) {
-    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 8 + (size_t)hdr.n_slots * 18 * TRK_WAVE);
-    hipLaunchKernelGGL(k_fk_jacobian, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, q, qd, n, link, link_joint_idx, pos, quat, lin_jac, ang_jac, vel_lin, vel_ang);
+void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links_dev, const DevLink* links_host, const float* q,
+                            const float* qd, int64_t n, int link, int link_joint_idx, float* pos, float* quat,
+                            float* lin_jac, float* ang_jac, float* vel_lin, float* vel_ang, hipStream_t st) {
+    // which DOFs get a column (robot_tree.py:239-244, the reference's serial-chain rule applied to every visited link)
+    JacCols cols;
+    for (int d = 0; d < TRK_MAX_DOFS; ++d) cols.slot[d] = -1;
+    cols.n_cols = 0; cols.p_end = 1;
+    for (int p = 0; p < hdr.n_links; ++p) {
+        const DevLink& Lk = links_host[p];
+        if (Lk.link == link) cols.p_end = std::max(cols.p_end, p + 1);
+        if (Lk.dof >= 0 && (Lk.link - 1) <= link_joint_idx && Lk.jac_axis >= 0) {
+            cols.slot[Lk.dof] = (int8_t)cols.n_cols++;
+            cols.p_end = std::max(cols.p_end, p + 1);
+        }
+    }
+    const int rstride = (6 * cols.n_cols + 3) | 1;
+    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * (qd ? 2 : 1) + (size_t)hdr.n_slots * (qd ? 18 : 12) * TRK_WAVE +
+                                  (size_t)TRK_WAVE * rstride);
+    hipLaunchKernelGGL(k_fk_jacobian, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links_dev, cols, q, qd, n, link,
+                       link_joint_idx, pos, quat, lin_jac, ang_jac, vel_lin, vel_ang);
 }
 
 void trk_launch_fk_analytic_jacobian(const DevModelHdr& hdr, const DevLink* links, const void* dofs, const float* q,
@@ -1203,14 +1300,23 @@ void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_inter
     hipLaunchKernelGGL(k_interpolate_via_points, dim3(grid_for(total, 256)), dim3(256), 0, st, x, T, H, D, n_interp, alpha, beta, out);
 }
 
-void trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
-                         float* cost, void* gq, void* gqd, int accumulate, hipStream_t st) {
+int trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
+                        float* cost, void* gq, void* gqd, int accumulate, hipStream_t st) {
     const float s2 = 1.0f / (sigma * sigma);
     const float a = 12.0f * s2 / (dt * dt * dt), b = -6.0f * s2 / (dt * dt), c = 4.0f * s2 / dt;
-    if (f16) hipLaunchKernelGGL(k_gp_prior<_Float16>, dim3((unsigned)B), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)qd, H, D,
-                                dt, a, b, c, w, cost, (_Float16*)gq, (_Float16*)gqd, accumulate);
-    else hipLaunchKernelGGL(k_gp_prior<float>, dim3((unsigned)B), dim3(256), 0, st, (const float*)q, (const float*)qd, H, D,
-                            dt, a, b, c, w, cost, (float*)gq, (float*)gqd, accumulate);
+    const size_t total = (size_t)H * D;
+    const size_t lds = sizeof(float) * (2 * ((total + 3) & ~(size_t)3) + 4);
+    if (lds > 160 * 1024) return -1;
+    const size_t esz = f16 ? 2 : 4;
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(qd) | reinterpret_cast<uintptr_t>(gq) |
+                           reinterpret_cast<uintptr_t>(gqd);
+    const bool vec = total % 4 == 0 && (ptrs & (4 * esz - 1)) == 0;
+#define TRK_GP(T, V) hipLaunchKernelGGL((k_gp_prior<T, V>), dim3((unsigned)B), dim3(256), lds, st, (const T*)q, (const T*)qd, H, D, \
+                                        dt, a, b, c, w, cost, (T*)gq, (T*)gqd, accumulate)
+    if (f16) { if (vec) TRK_GP(_Float16, true); else TRK_GP(_Float16, false); }
+    else { if (vec) TRK_GP(float, true); else TRK_GP(float, false); }
+#undef TRK_GP
+    return 0;
 }
 
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st) {
@@ -1230,6 +1336,8 @@ int trk_kernels_init(void) {
     TRK_SET((k_rollout_generic<false, _Float16>)); TRK_SET((k_rollout_generic<true, _Float16>));
     TRK_SET(k_fk_jacobian); TRK_SET(k_fk_points); TRK_SET(k_fk_points_backward);
     TRK_SET(k_fk_analytic_jacobian); TRK_SET(k_ik_step);
+    TRK_SET((k_gp_prior<float, true>)); TRK_SET((k_gp_prior<float, false>));
+    TRK_SET((k_gp_prior<_Float16, true>)); TRK_SET((k_gp_prior<_Float16, false>));
 #undef TRK_SET
     return e == hipSuccess ? 0 : -1;
 }

@@ -27,9 +27,9 @@ void trk_launch_fk_points_backward(const DevModelHdr& hdr, const DevLink* links,
                                    const float* q, const float* gin, int64_t n, float* gq, hipStream_t st);
 size_t trk_lds_rollout(const DevModelHdr& hdr, int n_cols);                 // dynamic LDS bytes a launch needs
 size_t trk_lds_fk_points(const DevModelHdr& hdr, int n_points, bool backward);
-void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links, const float* q, const float* qd, int64_t n,
-                            int link, int link_joint_idx, float* pos, float* quat, float* lin_jac, float* ang_jac,
-                            float* vel_lin, float* vel_ang, hipStream_t st);
+void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links_dev, const DevLink* links_host, const float* q,
+                            const float* qd, int64_t n, int link, int link_joint_idx, float* pos, float* quat,
+                            float* lin_jac, float* ang_jac, float* vel_lin, float* vel_ang, hipStream_t st);
 void trk_launch_fk_analytic_jacobian(const DevModelHdr& hdr, const DevLink* links, const void* dofs, const float* q,
                                      int64_t n, float* J, hipStream_t st);
 void trk_launch_rotmat_to_quat(const float* R, int64_t n, int stride, int pitch, float* out, hipStream_t st);
@@ -37,7 +37,7 @@ void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const 
                                 float* grad, hipStream_t st);
 void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_interp, const float* alpha, const float* beta,
                             float* out, hipStream_t st);
-void trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
+int trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
                          float* cost, void* gq, void* gqd, int accumulate, hipStream_t st);
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st);
 void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st);
