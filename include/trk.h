@@ -156,6 +156,8 @@ int trk_point_set_create(const TrkModel* model, const int32_t* point_link, const
                          int32_t n_points, TrkPointSet** out);
 void trk_point_set_destroy(TrkPointSet* ps);
 int trk_point_set_size(const TrkPointSet* ps);
+/* 1 if a generated fused kernel with exactly this point set baked in was built (see trk_model_is_specialized). */
+int trk_point_set_is_specialized(const TrkPointSet* ps);
 
 /* q [N,D] -> pos_out [N, n_points, 3]. */
 int trk_fk_points(const TrkModel* model, const TrkPointSet* ps, const float* q, int64_t n, float* pos_out,

@@ -241,6 +241,21 @@ def test_grasped_object_like_the_reference():
                                   g["coll0_self"] | g["coll0_obj"] | g["coll0_ws"])
     ppos, cost, gq = task.rollout_cost_grad(q0)
     assert ppos.shape == (4, 8, 26, 3) and rel_err(gq.cpu().numpy(), g["gq_cost"]) < TOL_G
+    # generated kernel (spec_panda_grasp) vs table-driven kernel, both against the reference-derived golden
+    assert robot._point_set(torch.device(DEV)).specialized
+    model, _ = task._fused_handles(torch.device(DEV))
+    model.enable_specialized(False)
+    _, cost_g, gq_g = task.rollout_cost_grad(q0)
+    model.enable_specialized(True)
+    for c, gr in ((cost, gq), (cost_g, gq_g)):
+        assert rel_err(c.cpu().numpy(), total_ref) < TOL_C and rel_err(gr.cpu().numpy(), g["gq_cost"]) < TOL_G
+    task.set_ee_target(np.array([[1, 0, 0, 0.4], [0, 1, 0, 0.2], [0, 0, 1, 0.5], [0, 0, 0, 1]], np.float32))
+    model, _ = task._fused_handles(torch.device(DEV))
+    _, c_s, g_s = task.rollout_cost_grad(q0, w_ee=1.0)
+    model.enable_specialized(False)
+    _, c_g, g_g = task.rollout_cost_grad(q0, w_ee=1.0)
+    model.enable_specialized(True)
+    assert rel_err(c_s.cpu().numpy(), c_g.cpu().numpy()) < TOL_C and rel_err(g_s.cpu().numpy(), g_g.cpu().numpy()) < TOL_G
 
 
 def test_link_sphere_model(oracle_lib):
@@ -279,6 +294,27 @@ def test_link_sphere_model(oracle_lib):
     coll = task.compute_collision(q0)
     ref = o.collision_fields(7, rp, None, "f64").reshape(6, 64)
     assert (coll.cpu().numpy() != ref).mean() < 0.01       # fp32 vs fp64 at the threshold
+    # the generated kernel (this point set is baked into spec_panda_spheres) and the table-driven one agree
+    ps = robot._point_set(torch.device(DEV))
+    assert ps.specialized
+    model, cm = task._fused_handles(torch.device(DEV))
+    from torch_robotics_amd import ops
+    for wts in ((1, 1, 1, 1), (0, 1, 0, 0), (1, 0, 0, 0), (0, 0, 1, 1)):
+        _, rcw, rgw = o.rollout_points(pl, po, qn, wts, "f64")
+        for n_rows in (6 * 64, 70, 1):
+            qq = q0.reshape(-1, 7)[:n_rows].contiguous()
+            model.enable_specialized(True)
+            ps_, cs, gs = ops.rollout_points_cost_grad(ps, cm, wts, qq)
+            model.enable_specialized(False)
+            pg, cg, gg = ops.rollout_points_cost_grad(ps, cm, wts, qq)
+            model.enable_specialized(True)
+            assert np.abs(ps_.cpu().numpy() - rp[:n_rows]).max() < TOL_H and np.abs(pg.cpu().numpy() - rp[:n_rows]).max() < TOL_H
+            assert rel_err(cs.cpu().numpy(), rcw[:n_rows]) < TOL_C and rel_err(cg.cpu().numpy(), rcw[:n_rows]) < TOL_C
+            assert rel_err(gs.cpu().numpy(), rgw[:n_rows]) < TOL_G and rel_err(gg.cpu().numpy(), rgw[:n_rows]) < TOL_G
+        nb = ops.n_blocks(6 * 64)
+        sums = torch.zeros(nb, device=DEV)
+        _, cs, _ = ops.rollout_points_cost_grad(ps, cm, wts, q0, want_pos=False, cost_sum=sums)
+        assert abs(float(sums.sum()) - float(cs.double().sum())) < 1e-3 * max(1.0, abs(float(cs.double().sum())))
 
 
 def test_sphere_model_reduces_to_link_origin_goldens():

@@ -180,16 +180,21 @@ def test_grasped_object_model_matches_reference():
 
 
 def test_link_sphere_model_tables():
-    """RobotPanda(link_sphere_model="panda") -- SURVEY 8f-3: 45 link-frame spheres replace the 5 link-origin points."""
+    """RobotPanda(link_sphere_model="panda") -- SURVEY 8f-3: 45 link-frame spheres replace the 5 link-origin points.
+    Columns are link-sorted: each link origin is followed by that link's spheres."""
     robot = tra.RobotPanda(link_sphere_model="panda", tensor_args=TA)
     pl, po = robot.collision_point_set()
     assert pl.shape == (56,) and po.shape == (56, 3)
-    np.testing.assert_array_equal(pl[:11], np.arange(11))
-    assert not po[:11].any() and po[11:].any()
-    assert robot.link_idxs_for_object_collision_checking == list(range(11, 56))
+    assert list(pl) == sorted(pl)                                   # a chain: walk order == file order
+    origin_cols = [int(np.nonzero(pl == i)[0][0]) for i in range(11)]
+    assert not po[origin_cols].any()
+    obj = robot.link_idxs_for_object_collision_checking
+    assert len(obj) == 45 and not set(obj) & set(origin_cols) and sorted(obj + origin_cols) == list(range(56))
     assert robot.link_names_for_object_collision_checking[0] == "panda_link0"
-    assert pl[11] == 0 and np.allclose(po[11], [0, 0, 0.05])
+    assert pl[obj[0]] == 0 and np.allclose(po[obj[0]], [0, 0, 0.05])
     assert float(robot.link_margins_for_object_collision_checking_tensor[0]) == np.float32(0.08)
+    plain = tra.RobotPanda(tensor_args=TA)
+    assert robot.link_idxs_for_self_collision_checking == [origin_cols[i] for i in plain.link_idxs_for_self_collision_checking]
     task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
     spec = task.build_cost_spec()
     spec.validate()
@@ -199,3 +204,4 @@ def test_link_sphere_model_tables():
     spec.validate()
     assert spec.n_links_in == 12 + 45 + 14 and len(spec.obj_link_idx) == 59 and len(spec.self_pairs) == 66
     np.testing.assert_array_equal(spec.obj_link_idx[-14:], np.arange(57, 71))
+    np.testing.assert_array_equal(spec.self_link_idx[-14:], np.arange(57, 71))

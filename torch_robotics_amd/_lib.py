@@ -26,7 +26,7 @@ EXPORTS = [
     "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_reduce_sum", "trk_debug_set_stamp_buffer", "trk_interpolate_via_points",
     "trk_grid_precompute",
     "trk_sdf_points",
-    "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_fk_points", "trk_fk_points_backward",
+    "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_point_set_is_specialized", "trk_fk_points", "trk_fk_points_backward",
     "trk_rollout_points_cost_grad", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16",
 ]
 
@@ -94,6 +94,7 @@ def lib():
     L.trk_point_set_destroy.argtypes = [vp]
     L.trk_point_set_destroy.restype = None
     L.trk_point_set_size.argtypes = [vp]
+    L.trk_point_set_is_specialized.argtypes = [vp]
     L.trk_fk_points.argtypes = [vp, vp, vp, i64, vp, vp]
     L.trk_fk_points_backward.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.trk_rollout_points_cost_grad.argtypes = [vp, vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, vp, vp, vp, vp, vp]

@@ -209,6 +209,86 @@ def _masked_factory(kin: KinModel):
     return masked
 
 
+def _emit_angles(E: "Emitter", kin: KinModel) -> None:
+    """joint angles: clamp to the URDF limits (torch.clamp, rigid_body.py:157-160; the gradient mask is
+    "q inside the limits" == "clamp left q unchanged"), then all sines / cosines, two angles per call"""
+    L = kin.n_links
+    rot_dofs = []
+    E.raw("    unsigned passbits = 0u;      // bit d set: clamp left q[d] unchanged -> gradient passes (one VGPR instead of 2D)")
+    for i in range(1, L):
+        jt, d = int(kin.joint_type[i]), int(kin.dof_idx[i])
+        if jt == JOINT_FIXED:
+            continue
+        if kin.clamp[i]:
+            E.raw(f"    const float qh{d} = __builtin_amdgcn_fmed3f(q[{d}], {flit(kin.lower[i])}, {flit(kin.upper[i])});")
+            E.raw(f"    passbits |= (qh{d} == q[{d}]) ? {1 << d}u : 0u;")
+        else:
+            E.raw(f"    const float qh{d} = q[{d}];")
+        if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS) and float(kin.rot_sign[i]) != 0.0:
+            rot_dofs.append(d)
+    # pin the mask in ONE register: without this the compiler re-derives it from q and qh in the reverse pass and
+    # keeps 2D registers alive across the whole kernel (-> spills, and every spill reload is an s_waitcnt vmcnt(0)
+    # that also waits for the wave's outstanding output stores)
+    E.raw('    asm volatile("" : "+v"(passbits));')
+    for d in rot_dofs:
+        E.raw(f"    float sn{d}, cs{d};")
+    for a, b in zip(rot_dofs[0::2], rot_dofs[1::2]):
+        E.raw(f"    trk_sincos2(qh{a}, qh{b}, &sn{a}, &cs{a}, &sn{b}, &cs{b});")
+    if len(rot_dofs) % 2:
+        d = rot_dofs[-1]
+        E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
+
+
+def _emit_fk_link(E: "Emitter", kin: KinModel, i: int, R, t, passv, snap: float) -> None:
+    """world pose of link i from its parent's (rigid_body.py:162-182), URDF constants folded symbolically"""
+    par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
+    E.raw(f"    // link {i} '{kin.link_names[i]}' (parent {par})")
+    Rf = [[S(snap_const(kin.R_fixed[i][r][c], snap)) for c in range(3)] for r in range(3)]
+    tl = [S(snap_const(kin.trans[i][k], 0.0)) for k in range(3)]
+    qh = None
+    if jt != JOINT_FIXED:
+        passv[i] = S(1.0, f"pass{d}") if kin.clamp[i] else ONE
+        qh = S(1.0, f"qh{d}")
+    if jt == JOINT_PRISMATIC:
+        tl = [E.lincomb([(S(float(kin.axis[i][k])), qh)], tl[k]) for k in range(3)]
+    Rp, tp = R[par], t[par]
+    t[i] = [E.lincomb([(Rp[r][k], tl[k]) for k in range(3)], tp[r]) for r in range(3)]
+    A = [[E.lincomb([(Rp[r][k], Rf[k][c]) for k in range(3)]) for c in range(3)] for r in range(3)]
+    if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS):
+        sg = float(kin.rot_sign[i])
+        if sg != 0.0:
+            s, c = S(sg, f"sn{d}"), S(1.0, f"cs{d}")       # sin(sign*q) = sign*sin(q), cos even
+            ax = int(kin.rot_axis[i])
+            ci, cj = [(1, 2), (2, 0), (0, 1)][ax]
+            newA = [row[:] for row in A]
+            for r in range(3):
+                a_i, a_j = E.named(A[r][ci]), E.named(A[r][cj])
+                newA[r][ci] = E.lincomb([(c, a_i), (s, a_j)])
+                newA[r][cj] = E.lincomb([(c, a_j), (s.neg(), a_i)])
+            A = newA
+    R[i] = A
+
+
+def _emit_joint_gradient(E: "Emitter", kin: KinModel, i: int, R, t, Fi, Ti, masked) -> S:
+    """d cost / d q of link i's joint from the wrench (F, T about the world origin) of its subtree:
+    revolute  s z_i . (T - t_i x F),  prismatic  (R_parent axis) . F   """
+    par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
+    if not any(not s.is_zero for s in Fi + Ti):
+        return ZERO
+    if jt == JOINT_PRISMATIC:
+        dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
+        return masked(E, i, d, E.dot(dirw, Fi))
+    sg = float(kin.rot_sign[i])
+    if sg == 0.0:
+        return ZERO
+    ax = int(kin.rot_axis[i])
+    z = [R[i][r][ax] for r in range(3)]
+    cr = E.cross(t[i], Fi)
+    diff = [E.lincomb([(Ti[k], ONE), (cr[k], S(-1.0))]) for k in range(3)]
+    g = E.dot(z, diff)
+    return masked(E, i, d, S(g.c * sg, g.n))
+
+
 def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, snap: float = SNAP) -> str:
     L, D = kin.n_links, kin.n_dofs
     NL = len(tmpl.obj_links)
@@ -251,59 +331,9 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         else:
             R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
             t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
-        # joint angles: clamp to the URDF limits (torch.clamp, rigid_body.py:157-160; the gradient mask is
-        # "q inside the limits" == "clamp left q unchanged"), then all sines / cosines, two angles per call
-        rot_dofs = []
-        E.raw("    unsigned passbits = 0u;      // bit d set: clamp left q[d] unchanged -> gradient passes (one VGPR instead of 2D)")
-        for i in range(1, L):
-            jt, d = int(kin.joint_type[i]), int(kin.dof_idx[i])
-            if jt == JOINT_FIXED:
-                continue
-            if kin.clamp[i]:
-                E.raw(f"    const float qh{d} = __builtin_amdgcn_fmed3f(q[{d}], {flit(kin.lower[i])}, {flit(kin.upper[i])});")
-                E.raw(f"    passbits |= (qh{d} == q[{d}]) ? {1 << d}u : 0u;")
-            else:
-                E.raw(f"    const float qh{d} = q[{d}];")
-            if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS) and float(kin.rot_sign[i]) != 0.0:
-                rot_dofs.append(d)
-        # pin the mask in ONE register: without this the compiler re-derives it from q and qh in the reverse pass and
-        # keeps 2D registers alive across the whole kernel (-> spills, and every spill reload is an s_waitcnt vmcnt(0)
-        # that also waits for the wave's outstanding output stores)
-        E.raw('    asm volatile("" : "+v"(passbits));')
-        for d in rot_dofs:
-            E.raw(f"    float sn{d}, cs{d};")
-        for a, b in zip(rot_dofs[0::2], rot_dofs[1::2]):
-            E.raw(f"    trk_sincos2(qh{a}, qh{b}, &sn{a}, &cs{a}, &sn{b}, &cs{b});")
-        if len(rot_dofs) % 2:
-            d = rot_dofs[-1]
-            E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
+        _emit_angles(E, kin)
         for p in range(1, L):
-            i = int(kin.order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
-            E.raw(f"    // link {i} '{kin.link_names[i]}' (parent {par})")
-            Rf = [[S(snap_const(kin.R_fixed[i][r][c], snap)) for c in range(3)] for r in range(3)]
-            tl = [S(snap_const(kin.trans[i][k], 0.0)) for k in range(3)]
-            qh = None
-            if jt != JOINT_FIXED:
-                passv[i] = S(1.0, f"pass{d}") if kin.clamp[i] else ONE
-                qh = S(1.0, f"qh{d}")
-            if jt == JOINT_PRISMATIC:
-                tl = [E.lincomb([(S(float(kin.axis[i][k])), qh)], tl[k]) for k in range(3)]
-            Rp, tp = R[par], t[par]
-            t[i] = [E.lincomb([(Rp[r][k], tl[k]) for k in range(3)], tp[r]) for r in range(3)]
-            A = [[E.lincomb([(Rp[r][k], Rf[k][c]) for k in range(3)]) for c in range(3)] for r in range(3)]
-            if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS):
-                sg = float(kin.rot_sign[i])
-                if sg != 0.0:
-                    s, c = S(sg, f"sn{d}"), S(1.0, f"cs{d}")       # sin(sign*q) = sign*sin(q), cos even
-                    ax = int(kin.rot_axis[i])
-                    ci, cj = [(1, 2), (2, 0), (0, 1)][ax]
-                    newA = [row[:] for row in A]
-                    for r in range(3):
-                        a_i, a_j = E.named(A[r][ci]), E.named(A[r][cj])
-                        newA[r][ci] = E.lincomb([(c, a_i), (s, a_j)])
-                        newA[r][cj] = E.lincomb([(c, a_j), (s.neg(), a_i)])
-                    A = newA
-            R[i] = A
+            _emit_fk_link(E, kin, int(kin.order[p]), R, t, passv, snap)
         # ---------------- outputs that depend only on FK ----------------
         pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
         E.raw(f"    PosFlusher<{3 * L}, IO> flush{{nullptr, nullptr, lane, PosFlusher<{3 * L}, IO>::NCHUNK}};")
@@ -424,10 +454,326 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("    }")
     out.append("}")
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
-               f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch}};")
+               f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Attached-point kernels: the cost model's columns are points fixed in link frames (link spheres, grasped-object points)
+# ----------------------------------------------------------------------------------------------------------------------
+def points_hash(point_link, point_offset) -> int:
+    """FNV-1a (64 bit) over (n_points, point_link, point_offset) -- the same bytes trk_point_set_create hashes."""
+    pl = np.ascontiguousarray(point_link, np.int32).reshape(-1)
+    po = np.ascontiguousarray(point_offset, np.float32).reshape(-1, 3)
+    h = 0xcbf29ce484222325
+    for arr in (np.asarray([len(pl)], np.int32), pl, po.reshape(-1)):
+        for b in arr.tobytes():
+            h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@dataclass
+class PointsTemplate:
+    """Point set + collision model baked into a generated attached-point kernel.  Columns must be produced in
+    increasing order by a walk of the tree (each link's columns follow those of the links visited before it)."""
+    point_link: np.ndarray                  # int32 [P]
+    point_offset: np.ndarray                # float32 [P, 3], link frame
+    obj_cols: List[int]                     # columns evaluated against objects / workspace box, margins in this order
+    self_pairs: List[Tuple[int, int]] = field(default_factory=list)   # COLUMN pairs
+    ee_link: int = -1                       # LINK index
+
+
+CHUNK_FLOATS = 36          # 12 columns: 144 B per sample and chunk, a multiple of 16 B
+OBJ_GROUP = 6              # points evaluated against the scene together (register arrays of this size)
+
+
+def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str, snap: float = SNAP) -> str:
+    """Fused FK + objectives + gradient with the collision fields on attached points.  Differences to the link kernel:
+
+    * each link's points are produced, scored against the scene and folded into ONE running wrench (f, p x f about the
+      world origin) as soon as the link's pose exists -- no position or adjoint tile in LDS, no per-link accumulators;
+    * reverse mode is the prefix-sum form of the transposed geometric Jacobian (the table-driven kernels' idea, in
+      registers): in walk order a joint's subtree is a contiguous range, so its gradient is
+      s z_j . ((Pt1 - Pt0) - t_j x (Pf1 - Pf0)) with the running wrench sampled at the range's start and end;
+      a force that lands on an EARLIER link (the far side of a self-collision pair) is applied directly to that link's
+      ancestor joints, s z_j . ((p - t_j) x f), instead of entering the running sums;
+    * positions leave through one 36-float chunk buffer per wavefront (spec_flush_chunk)."""
+    L, D, P = kin.n_links, kin.n_dofs, len(pt.point_link)
+    W = 3 * P
+    V = 4 if W % 4 == 0 else (2 if W % 2 == 0 else 1)
+    pl = [int(v) for v in pt.point_link]
+    po = np.asarray(pt.point_offset, np.float32).reshape(-1, 3)
+    pos_of = {int(kin.order[p]): p for p in range(L)}
+    walk_rank = [pos_of[i] for i in pl]
+    if any(walk_rank[k] > walk_rank[k + 1] for k in range(P - 1)):
+        raise ValueError("generate_points_rollout_source: columns must follow the walk order of their links")
+    cols_of_link: Dict[int, List[int]] = {i: [c for c in range(P) if pl[c] == i] for i in range(L)}
+    obj_rank = {c: k for k, c in enumerate(pt.obj_cols)}
+    if sorted(pt.obj_cols) != list(pt.obj_cols):
+        raise ValueError("generate_points_rollout_source: obj_cols must be increasing (margins are read in groups)")
+    # a pair is scored when the walk reaches its later column; pairs_at[link] = [(pair index, late col, early col, late_is_a)]
+    pairs_at: Dict[int, List[Tuple[int, int, int, bool]]] = {i: [] for i in range(L)}
+    for pi, (a, b) in enumerate(pt.self_pairs):
+        late_is_a = (walk_rank[a], a) >= (walk_rank[b], b)
+        late, early = (a, b) if late_is_a else (b, a)
+        pairs_at[pl[late]].append((pi, late, early, late_is_a))
+    masked = _masked_factory(kin)
+    LS = CHUNK_FLOATS
+    lds_per_lane = max(LS, D)
+    joint_links = [i for i in range(1, L) if int(kin.joint_type[i]) != JOINT_FIXED]
+    ancestors: Dict[int, List[int]] = {}
+    for i in range(L):
+        chain, a = [], i
+        while a > 0:
+            if int(kin.joint_type[a]) != JOINT_FIXED:
+                chain.append(a)
+            a = int(kin.parent[a])
+        ancestors[i] = chain                   # links whose joints move link i (incl. i itself)
+
+    out: List[str] = []
+    out.append(f"// GENERATED by torch_robotics_amd/codegen.py for model '{kin.name}' ({L} links, {D} DOF) with {P} attached points -- do not edit.")
+    out.append('#include "trk_spec_common.h"')
+    out.append(f"namespace spec_{ident} {{")
+    out.append(f"constexpr int L = {L}, D = {D}, P = {P}, W = {W};")
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_per_lane} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_per_lane});")
+        E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {lds_per_lane}) + wave * TRK_LDS_SPHERES;")
+        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    float* pos_out = static_cast<float*>(A.link_pos);")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        E.raw(f"    float* row = lds + lane * {LS};          // this lane's slice of the chunk buffer")
+        E.raw("    NoTick notick;")
+        R: Dict[int, List[List[S]]] = {}
+        t: Dict[int, List[S]] = {}
+        passv: Dict[int, S] = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        _emit_angles(E, kin)
+        E.raw("    float cost = 0.0f;")
+        E.raw("    float pf0 = 0.0f, pf1 = 0.0f, pf2 = 0.0f, pt0 = 0.0f, pt1 = 0.0f, pt2 = 0.0f;   // running wrench of the links visited so far")
+        for i in joint_links:
+            E.raw(f"    float late{int(kin.dof_idx[i])} = 0.0f;")
+        PF = [S(1.0, f"pf{k}") for k in range(3)]
+        PT = [S(1.0, f"pt{k}") for k in range(3)]
+        colpos: Dict[int, List[S]] = {}
+        snap_c: Dict[int, S] = {}
+        gq_expr: Dict[int, S] = {}
+        chunk_start = 0                       # first float of the chunk being filled
+
+        def joint_functional(i: int) -> S:
+            """z_i . (Pt - t_i x Pf) with the CURRENT running wrench (prismatic: (R_parent axis) . Pf)"""
+            jt = int(kin.joint_type[i])
+            if jt == JOINT_PRISMATIC:
+                par = int(kin.parent[i])
+                dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
+                return E.dot(dirw, PF)
+            ax = int(kin.rot_axis[i])
+            z = [R[i][r][ax] for r in range(3)]
+            cr = E.cross(t[i], PF)
+            return E.dot(z, [E.lincomb([(PT[k], ONE), (cr[k], S(-1.0))]) for k in range(3)])
+
+        def in_order(p: List[S], g: List[str]):
+            """force g (C expressions) at world point p on the link the walk stands on -> running wrench"""
+            px, py, pz = (E.expr(v) for v in p)
+            E.raw(f"    pf0 += {g[0]}; pf1 += {g[1]}; pf2 += {g[2]};")
+            E.raw(f"    pt0 += {py} * {g[2]} - {pz} * {g[1]}; pt1 += {pz} * {g[0]} - {px} * {g[2]}; pt2 += {px} * {g[1]} - {py} * {g[0]};")
+
+        def late_force(link: int, p: List[S], g: List[str]):
+            """force g at world point p on an EARLIER link: straight onto the joints that move that link"""
+            gS = [S(1.0, x) for x in g]
+            for j in ancestors[link]:
+                d = int(kin.dof_idx[j]); jt = int(kin.joint_type[j])
+                if jt == JOINT_PRISMATIC:
+                    par = int(kin.parent[j])
+                    dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[j][k]))) for k in range(3)]) for r in range(3)]
+                    val = E.dot(dirw, gS)
+                else:
+                    if float(kin.rot_sign[j]) == 0.0:
+                        continue
+                    ax = int(kin.rot_axis[j])
+                    z = [R[j][r][ax] for r in range(3)]
+                    arm = [E.lincomb([(p[k], ONE), (t[j][k], S(-1.0))]) for k in range(3)]
+                    val = E.dot(z, E.cross(arm, gS))
+                if not val.is_zero:
+                    E.raw(f"    late{d} += {E.expr(val)};")
+
+        def finish_joint(i: int):
+            d = int(kin.dof_idx[i]); jt = int(kin.joint_type[i])
+            sg = 1.0 if jt == JOINT_PRISMATIC else float(kin.rot_sign[i])
+            if sg == 0.0:
+                gq_expr[d] = ZERO
+                return
+            end = joint_functional(i)
+            g = E.lincomb([(end, ONE), (snap_c[i], S(-1.0)), (S(1.0, f"late{d}"), ONE)])
+            gq_expr[d] = masked(E, i, d, S(g.c * sg, g.n))
+
+        for p in range(L):
+            i = int(kin.order[p])
+            if p > 0:
+                _emit_fk_link(E, kin, i, R, t, passv, snap)
+                if int(kin.joint_type[i]) != JOINT_FIXED:
+                    # running wrench BEFORE this link's subtree: a COPY (pf/pt are mutable; the expression may be a bare alias)
+                    snap_c[i] = S(1.0, E.tmp(E.expr(joint_functional(i))))
+            cols = cols_of_link[i]
+            # ---- positions of this link's columns, staged for output
+            for c in cols:
+                off = [S(snap_const(po[c][k], 0.0)) for k in range(3)]
+                if all(o.is_zero for o in off):
+                    colpos[c] = t[i]
+                else:
+                    colpos[c] = [E.named(E.lincomb([(R[i][r][k], off[k]) for k in range(3)], t[i][r])) for r in range(3)]
+                for k in range(3):
+                    f = 3 * c + k
+                    E.raw(f"    row[{f - chunk_start}] = {E.expr(colpos[c][k])};")
+                    if f + 1 - chunk_start == LS or f + 1 == W:
+                        nf = f + 1 - chunk_start
+                        E.raw(f"    if (pos_out) spec_flush_chunk<W, {nf}, {LS}, {V}>(pos_out, base, {chunk_start}, rows, lane, lds);")
+                        chunk_start = f + 1
+            # ---- objects / workspace box on this link's collision columns, a few at a time
+            ocols = [c for c in cols if c in obj_rank]
+            for g0 in range(0, len(ocols), OBJ_GROUP):
+                grp = ocols[g0:g0 + OBJ_GROUP]
+                n = len(grp)
+                mb = obj_rank[grp[0]]
+                assert [obj_rank[c] for c in grp] == list(range(mb, mb + n))
+                E.raw("    {")
+                for k, nm in enumerate("xyz"):
+                    E.raw(f"        const float p{nm}[{n}] = {{{', '.join(E.expr(colpos[c][k]) for c in grp)}}};")
+                E.raw(f"        float gx[{n}], gy[{n}], gz[{n}];")
+                E.raw("#pragma unroll")
+                E.raw(f"        for (int l = 0; l < {n}; ++l) {{ gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }}")
+                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, notick, lds_sph, {mb});")
+                E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<{n}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {mb});")
+                E.raw("#pragma unroll")
+                E.raw(f"        for (int l = 0; l < {n}; ++l) {{")
+                E.raw("            pf0 += gx[l]; pf1 += gy[l]; pf2 += gz[l];")
+                E.raw("            pt0 += py[l] * gz[l] - pz[l] * gy[l]; pt1 += pz[l] * gx[l] - px[l] * gz[l]; pt2 += px[l] * gy[l] - py[l] * gx[l];")
+                E.raw("        }")
+                E.raw("    }")
+            # ---- self-collision pairs whose later column belongs to this link
+            if pairs_at[i]:
+                E.raw("    if (A.w.w_self != 0.0f) {")
+                E.raw("        float gl0, gl1, gl2, ge0, ge1, ge2;")
+                for pi, late, early, late_is_a in pairs_at[i]:
+                    pa, pb = (late, early) if late_is_a else (early, late)
+                    ga, gb = ("gl", "ge") if late_is_a else ("ge", "gl")
+                    E.raw("        gl0 = gl1 = gl2 = ge0 = ge1 = ge2 = 0.0f;")
+                    E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], "
+                          f"{', '.join(E.expr(colpos[pa][k]) for k in range(3))}, {', '.join(E.expr(colpos[pb][k]) for k in range(3))}, "
+                          f"{ga}0, {ga}1, {ga}2, {gb}0, {gb}1, {gb}2);")
+                    in_order(colpos[late], ["gl0", "gl1", "gl2"])
+                    if pl[early] == i:
+                        in_order(colpos[early], ["ge0", "ge1", "ge2"])
+                    else:
+                        late_force(pl[early], colpos[early], ["ge0", "ge1", "ge2"])
+                E.raw("    }")
+            # ---- end-effector tracking when the walk stands on the EE link
+            if i == pt.ee_link:
+                E.raw("    if (A.w.w_ee != 0.0f) {")
+                E.raw(f"        const float eR[9] = {{{', '.join(E.expr(R[i][r][c]) for r in range(3) for c in range(3))}}};")
+                E.raw(f"        const float et[3] = {{{', '.join(E.expr(t[i][k]) for k in range(3))}}};")
+                E.raw("        float gR[9], gt[3];")
+                E.raw("        const float ce = ee_cost_eval(eR, et, A.C.ee_target, A.C.ee_w_pos, A.C.ee_w_rot, A.C.ee_square, gR, gt);")
+                E.raw("        cost = fmaf(A.w.w_ee, ce, cost);")
+                E.raw("        gt[0] *= A.w.w_ee; gt[1] *= A.w.w_ee; gt[2] *= A.w.w_ee;")
+                E.raw("        pf0 += gt[0]; pf1 += gt[1]; pf2 += gt[2];")
+                # torque = t x gt + axial(Rbar R^T), Rbar = w gR
+                E.raw("        float M[9];")
+                E.raw("#pragma unroll")
+                E.raw("        for (int a = 0; a < 3; ++a)")
+                E.raw("#pragma unroll")
+                E.raw("            for (int b = 0; b < 3; ++b) M[3 * a + b] = A.w.w_ee * (gR[3 * a] * eR[3 * b] + gR[3 * a + 1] * eR[3 * b + 1] + gR[3 * a + 2] * eR[3 * b + 2]);")
+                E.raw("        pt0 += et[1] * gt[2] - et[2] * gt[1] + (M[7] - M[5]);")
+                E.raw("        pt1 += et[2] * gt[0] - et[0] * gt[2] + (M[2] - M[6]);")
+                E.raw("        pt2 += et[0] * gt[1] - et[1] * gt[0] + (M[3] - M[1]);")
+                E.raw("    }")
+            # ---- joints whose subtree ends after this link
+            for j in joint_links:
+                if int(kin.subtree_end[pos_of[j]]) == p + 1:
+                    finish_joint(j)
+        assert chunk_start == W
+        E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
+        E.raw("    if (A.cost_sum) {")
+        E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
+        E.raw("        if (lane == 0 && rows > 0) A.cost_sum[wblock] = tot;")
+        E.raw("    }")
+        E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
+        E.raw("    spec_store_gq<D>(static_cast<float*>(A.gq), base, rows, lane, lds, gv);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
+    obj = ", ".join(str(c) for c in pt.obj_cols) or "0"
+    pairs = ", ".join(f"{a}, {b}" for a, b in pt.self_pairs) or "0"
+    out.append(f"static const int32_t kObjCols[] = {{{obj}}};")
+    out.append(f"static const int32_t kSelfPairs[] = {{{pairs}}};")
+    out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+    out.append("    if (base_identity) hipLaunchKernelGGL(k_rollout_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    else hipLaunchKernelGGL(k_rollout_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("}")
+    out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, {len(pt.obj_cols)}, kObjCols, "
+               f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, P, "
+               f"0x{points_hash(pt.point_link, pt.point_offset):016x}ull}};")
+    out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
+    out.append(f"}}  // namespace spec_{ident}")
+    return "\n".join(out) + "\n"
+
+
+def _panda_pairs(idx) -> List[Tuple[int, int]]:
+    pairs_by_name = {"panda_link4": ["panda_link1"], "panda_link5": ["panda_link0", "panda_link1", "panda_link2"],
+                     "panda_link6": ["panda_link0", "panda_link1", "panda_link2"],
+                     "panda_hand": ["panda_link0", "panda_link1", "panda_link2"]}
+    names = sorted(set(list(pairs_by_name) + [v for vs in pairs_by_name.values() for v in vs] +
+                       ["panda_link0", "panda_link1", "panda_link2", "panda_link3"]))
+    return [(idx[a], idx[b]) for a in names for b in pairs_by_name.get(a, [])], names
+
+
+def panda_spheres_points(kin: KinModel) -> PointsTemplate:
+    """RobotPanda(link_sphere_model="panda"): link origins + the 45 link spheres, link-sorted columns; objects and the
+    workspace box on the spheres, self-collision pairs on the link origins (robots.py)."""
+    from .costmodel import link_sorted_point_set, load_link_spheres
+    from .kinematics import DATA_DIR
+    sl, so, _sr, _names = load_link_spheres(DATA_DIR / "configs" / "panda_sphere_config.yaml", kin.name_to_idx)
+    pl, po, origin_col, sphere_col = link_sorted_point_set(kin.order, sl, so)
+    pairs, _ = _panda_pairs(kin.name_to_idx)
+    return PointsTemplate(point_link=pl, point_offset=po, obj_cols=[int(c) for c in sphere_col],
+                          self_pairs=[(int(origin_col[a]), int(origin_col[b])) for a, b in pairs],
+                          ee_link=kin.name_to_idx["ee_link"])
+
+
+def panda_grasp_points(kin: KinModel) -> PointsTemplate:
+    """RobotPanda(grasped_object=GraspedObjectPandaBox()): 12 link origins + 14 box points on `grasped_object`;
+    objects / workspace on the 5 collision links + the 14 points; RobotBase's pair table incl. grasped rows."""
+    from .costmodel import panda_box_base_points
+    idx = kin.name_to_idx
+    L = kin.n_links
+    pts = panda_box_base_points()
+    G = len(pts)
+    pl = np.concatenate([np.arange(L), np.full(G, idx["grasped_object"])]).astype(np.int32)
+    po = np.concatenate([np.zeros((L, 3), np.float32), pts])
+    obj = [idx[n] for n in ("panda_link2", "panda_link3", "panda_link5", "panda_link7", "panda_hand")] + list(range(L, L + G))
+    pairs, names = _panda_pairs(idx)
+    pairs = list(pairs)
+    for n in ("panda_link0", "panda_link1", "panda_link2", "panda_link3"):       # robot_base.py:120-130
+        pairs += [(L + m, idx[n]) for m in range(G)]
+    return PointsTemplate(point_link=pl, point_offset=po, obj_cols=obj, self_pairs=pairs, ee_link=idx["ee_link"])
 
 
 def ur10_allegro_template(kin: KinModel) -> CollisionTemplate:
@@ -464,6 +810,13 @@ SPEC_ROBOTS = {
 }
 
 
+# attached-point kernels: name -> (urdf file, PointsTemplate factory)
+SPEC_POINT_ROBOTS = {
+    "panda_spheres": ("panda_arm_no_gripper.urdf", panda_spheres_points),
+    "panda_grasp": ("panda_arm_no_gripper_grasped_object.urdf", panda_grasp_points),
+}
+
+
 def template_for(ident: str):
     """(KinModel, CollisionTemplate) of a robot in SPEC_ROBOTS."""
     from .kinematics import URDF_DIR
@@ -481,6 +834,13 @@ def generate_all(out_dir) -> List[str]:
     for ident, (urdf, tmpl_fn) in SPEC_ROBOTS.items():
         kin = KinModel.from_urdf(str(URDF_DIR / urdf))
         src = generate_rollout_source(kin, tmpl_fn(kin), ident)
+        path = out_dir / f"spec_{ident}.hip"
+        if not path.exists() or path.read_text() != src:
+            path.write_text(src)
+        written.append(path.name)
+    for ident, (urdf, tmpl_fn) in SPEC_POINT_ROBOTS.items():
+        kin = KinModel.from_urdf(str(URDF_DIR / urdf))
+        src = generate_points_rollout_source(kin, tmpl_fn(kin), ident)
         path = out_dir / f"spec_{ident}.hip"
         if not path.exists() or path.read_text() != src:
             path.write_text(src)

@@ -89,3 +89,53 @@ class CostModelSpec:
         n_grid = sum(int(o.get("is_grid", 0)) for o in self.objects)
         if n_grid > 1 or (n_grid == 1) != (self.grid is not None):
             raise ValueError("exactly one grid object is required when `grid` is set")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Collision point layouts shared by the robots (robots.py) and the kernel generator (codegen.py)
+# ----------------------------------------------------------------------------------------------------------------------
+def panda_box_base_points(size=(0.05, 0.05, 0.15)) -> np.ndarray:
+    """GraspedObjectPandaBox.get_base_points_for_collision (objects.py:57-89): the 8 vertices and 6 face centres of the
+    box in the object frame, fp32."""
+    x, y, z = (np.asarray(size, np.float32) / np.float32(2)).tolist()
+    vertices = [[x, y, -z], [x, -y, -z], [-x, -y, -z], [-x, y, -z], [x, y, z], [x, -y, z], [-x, -y, z], [-x, y, z]]
+    faces = [[x, 0, 0], [0, -y, 0], [-x, 0, 0], [0, y, 0], [0, 0, z], [0, 0, -z]]
+    return np.asarray(vertices + faces, np.float32)
+
+
+def load_link_spheres(path, name_to_idx):
+    """Link-sphere table `{link: [[x, y, z, r], ...]}` (the format of the reference's
+    data/configs/panda/panda_sphere_config.yaml) -> (link_idx [S], offsets [S,3], radii [S], owner names [S])."""
+    import yaml
+    with open(path) as fh:
+        table = yaml.safe_load(fh)
+    link, off, rad, names = [], [], [], []
+    for name, rows in table.items():
+        if not isinstance(rows, list):
+            continue
+        for row in rows:
+            link.append(name_to_idx[name]); off.append(row[:3]); rad.append(row[3]); names.append(name)
+    return np.asarray(link, np.int32), np.asarray(off, np.float32).reshape(-1, 3), np.asarray(rad, np.float32), names
+
+
+def link_sorted_point_set(order, sphere_link=None, sphere_offset=None):
+    """Column layout of a robot with a link-sphere model: for every link in walk order (`order` = KinModel.order) its
+    origin, then its spheres in table order.  Returns (point_link [P], point_offset [P,3], origin_col [L],
+    sphere_col [S]).  With no spheres the layout is simply the link origins IN FILE ORDER (the reference's
+    fk_map_collision), not walk order."""
+    L = len(order)
+    if sphere_link is None or len(sphere_link) == 0:
+        return (np.arange(L, dtype=np.int32), np.zeros((L, 3), np.float32), np.arange(L, dtype=np.int32),
+                np.zeros(0, np.int32))
+    sphere_link = np.asarray(sphere_link, np.int32)
+    sphere_offset = np.asarray(sphere_offset, np.float32).reshape(-1, 3)
+    pl, po = [], []
+    origin_col = np.zeros(L, np.int32)
+    sphere_col = np.zeros(len(sphere_link), np.int32)
+    for i in (int(v) for v in order):
+        origin_col[i] = len(pl)
+        pl.append(i); po.append((0.0, 0.0, 0.0))
+        for k in np.nonzero(sphere_link == i)[0]:
+            sphere_col[k] = len(pl)
+            pl.append(i); po.append(tuple(float(v) for v in sphere_offset[k]))
+    return np.asarray(pl, np.int32), np.asarray(po, np.float32).reshape(-1, 3), origin_col, sphere_col

@@ -60,7 +60,12 @@ std::vector<const SpecEntry*>& spec_registry() { static std::vector<const SpecEn
 void trk_spec_register(const SpecEntry* e) { spec_registry().push_back(e); }
 const SpecEntry* trk_spec_find(uint64_t h, int n_links, int n_dofs) {
     for (const SpecEntry* e : spec_registry())
-        if (e->model_hash == h && e->n_links == n_links && e->n_dofs == n_dofs) return e;
+        if (e->n_points == 0 && e->model_hash == h && e->n_links == n_links && e->n_dofs == n_dofs) return e;
+    return nullptr;
+}
+const SpecEntry* trk_spec_find_points(uint64_t h, uint64_t points_hash, int n_points) {
+    for (const SpecEntry* e : spec_registry())
+        if (e->n_points == n_points && n_points > 0 && e->model_hash == h && e->points_hash == points_hash) return e;
     return nullptr;
 }
 
@@ -76,12 +81,14 @@ struct TrkModel {
     bool unsupported = false;
     const SpecEntry* spec = nullptr;     // model-specialised fused kernel, if one was built for these tables
     bool spec_enabled = true;
+    uint64_t hash = 0;                   // model_hash of the tables
 };
 
 struct TrkPointSet {
     DevPointSet dev;
     void* d_blob = nullptr;
     const TrkModel* model = nullptr;
+    const SpecEntry* spec = nullptr;     // generated kernel with exactly this point set baked in, if one was built
 };
 
 struct TrkCostModel {
@@ -177,7 +184,8 @@ int trk_model_create(const TrkKinModelDesc* d, TrkModel** out) {
         delete m;
         return hip_fail(e, "trk_model_create: device allocation/copy");
     }
-    m->spec = trk_spec_find(model_hash(d), L, D);
+    m->hash = model_hash(d);
+    m->spec = trk_spec_find(m->hash, L, D);
     *out = m;
     return TRK_OK;
 }
@@ -307,6 +315,13 @@ int trk_point_set_create(const TrkModel* m, const int32_t* point_link, const flo
     ps->dev.begin = reinterpret_cast<const int32_t*>(static_cast<char*>(ps->d_blob) + o_begin);
     ps->dev.n_points = n_points; ps->dev._pad = 0;
     ps->model = m;
+    {   // must hash the same bytes as torch_robotics_amd/codegen.py: points_hash
+        uint64_t h = 0xcbf29ce484222325ull;
+        h = fnv1a(h, &n_points, sizeof(int32_t));
+        h = fnv1a(h, point_link, sizeof(int32_t) * n_points);
+        h = fnv1a(h, point_offset, sizeof(float) * 3 * n_points);
+        ps->spec = trk_spec_find_points(m->hash, h, n_points);
+    }
     *out = ps;
     return TRK_OK;
 }
@@ -318,6 +333,7 @@ void trk_point_set_destroy(TrkPointSet* ps) {
 }
 
 int trk_point_set_size(const TrkPointSet* ps) { return ps ? ps->dev.n_points : TRK_ERR_INVALID_ARG; }
+int trk_point_set_is_specialized(const TrkPointSet* ps) { return (ps && ps->spec && ps->model->spec_enabled) ? 1 : 0; }
 
 static const size_t kMaxLds = 160 * 1024;
 
@@ -657,6 +673,31 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
     const int64_t n = batch * horizon;
     if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: null q/cost/gq");
     if (n == 0) return TRK_OK;
+    if (ps->spec && m->spec_enabled && (reinterpret_cast<uintptr_t>(point_pos_out) & 15) == 0) {
+        // generated kernel with this point set baked in: the cost model's columns must be the baked ones
+        const SpecEntry* e = ps->spec;
+        bool ok = true;
+        if (w->w_obj != 0.0f || w->w_ws != 0.0f)
+            ok = ok && (int)cm->obj_link_idx.size() == e->n_obj_links &&
+                 std::equal(cm->obj_link_idx.begin(), cm->obj_link_idx.end(), e->obj_link_idx);
+        if (w->w_self != 0.0f)
+            ok = ok && (int)cm->self_pairs.size() == 2 * e->n_self_pairs &&
+                 std::equal(cm->self_pairs.begin(), cm->self_pairs.end(), e->self_pairs);
+        if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link;
+        if (ok) {
+            SpecArgs a;
+            a.C = cm->hdr; a.w = *w;
+            std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+            std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+            a.q = q; a.n = n; a.link_pos = point_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
+            a.stamps = nullptr; a.io_f16 = 0;
+            const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z[3] = {0, 0, 0};
+            const int base_id = std::memcmp(a.base_R, I, sizeof(I)) == 0 && std::memcmp(a.base_t, Z, sizeof(Z)) == 0;
+            e->launch(a, base_id, (hipStream_t)stream);
+            TRK_HIP(hipGetLastError());
+            return TRK_OK;
+        }
+    }
     trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, &ps->dev, cm->hdr, *w, 0, q, n, point_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;

@@ -36,17 +36,20 @@ struct SpecEntry {
     uint64_t model_hash;        // FNV-1a over the kinematic tables (see trk_capi.hip: model_hash)
     int32_t n_links, n_dofs;
     int32_t n_obj_links;        // baked collision-link template
-    const int32_t* obj_link_idx;
+    const int32_t* obj_link_idx;   // LINK indices -- COLUMN indices when n_points > 0
     int32_t n_self_pairs;
-    const int32_t* self_pairs;  // [2*P] LINK indices (already mapped through self_link_idx)
+    const int32_t* self_pairs;  // [2*P] LINK indices (already mapped through self_link_idx) -- COLUMNS when n_points > 0
     int32_t ee_link;
     const char* name;
     SpecLaunchFn launch;
+    int32_t n_points;           // 0: the kernel's columns are the link origins; else: a baked attached-point set
+    uint64_t points_hash;       // FNV-1a over (n_points, point_link[], point_offset[]) in the caller's order
 };
 
 // registry filled by static initialisers of the generated translation units
 void trk_spec_register(const SpecEntry* e);
 const SpecEntry* trk_spec_find(uint64_t model_hash, int n_links, int n_dofs);
+const SpecEntry* trk_spec_find_points(uint64_t model_hash, uint64_t points_hash, int n_points);
 
 // ---------------------------------------------------------------------------------------------------------
 // I/O transposes (one wavefront, `lane` = lane id; `lds` = this wave's private region)
@@ -66,6 +69,11 @@ typedef float trk_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_wt_f4(float4* p, const float4& v) {
     const trk_f4 x = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(x) : "memory");
+}
+typedef float trk_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_wt_f2(float* p, float a, float b) {
+    const trk_f2 x = {a, b};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(x) : "memory");
 }
 __device__ __forceinline__ void store_wt_f1(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(v) : "memory");
@@ -203,6 +211,33 @@ __device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows(IO* __restrict__ ou
     return f;
 }
 
+// Wide rows (attached points: W = 3P floats per sample) do not fit a whole-row staging buffer, so they leave in column
+// chunks: a chunk is the NF consecutive floats [c0, c0 + NF) of every sample's row.  Each lane has put its NF floats at
+// lds[lane * LS ...]; the wave then streams the rows' segments as V-float vectors (V | NF, V | W, V | c0: 16/8/4-byte
+// aligned), vector e -> sample e / (NF / V).  A sample's segment is contiguous, neighbouring chunks complete its lines.
+template <int W, int NF, int LS, int V>
+__device__ __forceinline__ void spec_flush_chunk(float* __restrict__ out, int64_t base, int c0, int rows, int lane,
+                                                 const float* lds) {
+    constexpr int NVEC = NF / V;
+    static_assert(NF % V == 0 && W % V == 0 && LS % V == 0, "chunk geometry must keep the vectors aligned");
+    spec_wave_sync();
+    const int total = rows * NVEC;
+    float* dst0 = out + base * W + c0;
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) {
+        const int e = lane + TRK_WAVE * j;
+        if (e < total) {
+            const int smp = e / NVEC, v = e - smp * NVEC;
+            const float* src = lds + smp * LS + v * V;
+            float* dst = dst0 + (int64_t)smp * W + v * V;
+            if (V == 4) store_wt_f4(reinterpret_cast<float4*>(dst), *reinterpret_cast<const float4*>(src));
+            else if (V == 2) store_wt_f2(dst, src[0], src[1]);
+            else store_wt_f1(dst, src[0]);
+        }
+    }
+    spec_wave_sync();           // the chunk buffer may be overwritten from here on
+}
+
 // profiling hook: lane 0 of a wave records the shader clock at phase `k` (no-op when A.stamps == nullptr)
 __device__ __forceinline__ void spec_stamp(unsigned long long* stamps, int64_t wblock, int k, int lane) {
     if (stamps) {
@@ -224,13 +259,14 @@ __device__ __forceinline__ float spec_wave_sum(float v) {
 template <int NL, class Tick>
 __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w, const float (&px)[NL],
                                                    const float (&py)[NL], const float (&pz)[NL], float (&gx)[NL],
-                                                   float (&gy)[NL], float (&gz)[NL], Tick& tick, const float4* lds_spheres) {
+                                                   float (&gy)[NL], float (&gz)[NL], Tick& tick, const float4* lds_spheres,
+                                                   int mbase = 0) {
     float s[NL], ax[NL], ay[NL], az[NL];
     scene_min_sdf<NL>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres);
     float cost = 0.0f;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        cost += cptr(C.obj_link_margin)[l] - s[l];                     // sum_l max_o (margin - sdf_o) = sum_l (margin - min_o sdf_o)
+        cost += cptr(C.obj_link_margin)[mbase + l] - s[l];                     // sum_l max_o (margin - sdf_o) = sum_l (margin - min_o sdf_o)
         gx[l] = fmaf(-w, ax[l], gx[l]); gy[l] = fmaf(-w, ay[l], gy[l]); gz[l] = fmaf(-w, az[l], gz[l]);
     }
     return w * cost;
@@ -238,10 +274,11 @@ __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w,
 
 template <int NL>
 __device__ __forceinline__ float spec_ws_cost(const DevCostHdr& C, float w, const float (&px)[NL], const float (&py)[NL],
-                                              const float (&pz)[NL], float (&gx)[NL], float (&gy)[NL], float (&gz)[NL]) {
+                                              const float (&pz)[NL], float (&gx)[NL], float (&gy)[NL], float (&gz)[NL],
+                                              int mbase = 0) {
     float cost = 0.0f;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) cost += ws_cost_point(C, cptr(C.obj_link_margin)[l], px[l], py[l], pz[l], w, gx[l], gy[l], gz[l]);
+    for (int l = 0; l < NL; ++l) cost += ws_cost_point(C, cptr(C.obj_link_margin)[mbase + l], px[l], py[l], pz[l], w, gx[l], gy[l], gz[l]);
     return w * cost;
 }
 

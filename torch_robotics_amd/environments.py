@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .costmodel import CostModelSpec, box_prims, grid_object, make_object, sphere_prims
+from .costmodel import panda_box_base_points, CostModelSpec, box_prims, grid_object, make_object, sphere_prims
 from .kinmodel import quat_wxyz_to_rot
 
 DEFAULT_TENSOR_ARGS = {"device": torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu"),
@@ -155,10 +155,7 @@ class GraspedObjectPandaBox(GraspedObject):                  # objects.py:37-89
 
     def get_base_points_for_collision(self):
         """The 8 vertices and 6 face centres of the box, in the object frame (objects.py:57-89), fp32."""
-        x, y, z = (self.fields[0].sizes[0] / np.float32(2)).tolist()
-        vertices = [[x, y, -z], [x, -y, -z], [-x, -y, -z], [-x, y, -z], [x, y, z], [x, -y, z], [-x, -y, z], [-x, y, z]]
-        faces = [[x, 0, 0], [0, -y, 0], [-x, 0, 0], [0, y, 0], [0, 0, z], [0, 0, -z]]
-        return torch.tensor(vertices + faces, dtype=torch.float32)
+        return torch.from_numpy(panda_box_base_points(self.fields[0].sizes[0]))
 
 
 class GridMapSDF:                                            # grid_map_sdf.py:9-117

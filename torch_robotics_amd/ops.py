@@ -120,6 +120,10 @@ class PointSetHandle:
                   "trk_point_set_create")
         self._h = h
 
+    @property
+    def specialized(self) -> bool:
+        return bool(lib().trk_point_set_is_specialized(self._h))
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .costmodel import link_sorted_point_set, load_link_spheres
 from .environments import DEFAULT_TENSOR_ARGS
 from .fields import CollisionSelfField
 from .kinematics import DATA_DIR, DifferentiableFrankaPanda, link_pos_from_link_tensor, link_quat_from_link_tensor, \
@@ -146,25 +147,12 @@ class RobotBase:
         raise NotImplementedError
 
 
-def load_link_spheres(path, name_to_idx):
-    """Link-sphere table `{link: [[x, y, z, r], ...]}` (the format of the reference's
-    data/configs/panda/panda_sphere_config.yaml) -> (link_idx [S], offsets [S,3], radii [S], owner names [S])."""
-    import yaml
-    table = yaml.safe_load(open(path))
-    link, off, rad, names = [], [], [], []
-    for name, rows in table.items():
-        if not isinstance(rows, list):
-            continue
-        for row in rows:
-            link.append(name_to_idx[name]); off.append(row[:3]); rad.append(row[3]); names.append(name)
-    return np.asarray(link, np.int32), np.asarray(off, np.float32).reshape(-1, 3), np.asarray(rad, np.float32), names
-
-
 class RobotPanda(RobotBase):                                   # robot_panda.py:21-184
     """`link_sphere_model` (an extension) replaces the five link-origin collision points by the link-frame
     spheres of a table such as data/configs/panda_sphere_config.yaml ("panda" = that file): fk_map_collision then
-    returns the L link origins followed by the S sphere centres (followed by grasped-object points), and the object /
-    workspace fields read the sphere columns with the radii as margins.  Self-collision keeps using link origins."""
+    returns, link by link in walk order, the link origin followed by that link's sphere centres (L + S columns; a grasped
+    object's points still come last), and the object / workspace fields read the sphere columns with the radii as
+    margins.  Self-collision keeps using the link origins (their columns)."""
 
     def __init__(self, use_self_collision_storm=False, grasped_object=None, tensor_args=None, link_sphere_model=None,
                  **kwargs):
@@ -181,13 +169,6 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
         obj_links = ["panda_link2", "panda_link3", "panda_link5", "panda_link7", "panda_hand"]
         obj_margins = [0.125, 0.125, 0.13, 0.1, 0.08]
         obj_idxs = [self.diff_panda._name_to_idx_map[n] for n in obj_links]
-        self.link_spheres = None
-        if link_sphere_model is not None:
-            path = DATA_DIR / "configs" / "panda_sphere_config.yaml" if link_sphere_model == "panda" else link_sphere_model
-            sl, so, sr, names = load_link_spheres(path, self.diff_panda._name_to_idx_map)
-            self.link_spheres = (sl, so, sr)
-            L = self.diff_panda._kin.n_links
-            obj_links, obj_margins, obj_idxs = names, [float(r) for r in sr], list(range(L, L + len(sl)))
         pairs = OrderedDict({"panda_link4": ["panda_link1"],
                              "panda_link5": ["panda_link0", "panda_link1", "panda_link2"],
                              "panda_link6": ["panda_link0", "panda_link1", "panda_link2"],
@@ -200,6 +181,17 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
         self_links.extend(with_grasped)
         self_links = sorted(list(set(self_links)))
         self_idxs = [self.diff_panda._name_to_idx_map[n] for n in self_links]
+        self.link_spheres = None
+        kin = self.diff_panda._kin
+        self._base_points = link_sorted_point_set(kin.order)[:2]
+        if link_sphere_model is not None:
+            path = DATA_DIR / "configs" / "panda_sphere_config.yaml" if link_sphere_model == "panda" else link_sphere_model
+            sl, so, sr, names = load_link_spheres(path, self.diff_panda._name_to_idx_map)
+            self.link_spheres = (sl, so, sr)
+            pl, po, origin_col, sphere_col = link_sorted_point_set(kin.order, sl, so)
+            self._base_points = (pl, po)
+            obj_links, obj_margins, obj_idxs = names, [float(r) for r in sr], [int(c) for c in sphere_col]
+            self_idxs = [int(origin_col[i]) for i in self_idxs]       # link origins moved to their new columns
         super().__init__(
             name="RobotPanda", q_limits=q_limits, grasped_object=grasped_object,
             link_names_for_object_collision_checking=obj_links, link_margins_for_object_collision_checking=obj_margins,
@@ -212,12 +204,10 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
             self_collision_margin_grasped_object=0.05, tensor_args=tensor_args, **kwargs)
 
     def collision_point_set(self):
-        """(point_link, point_offset) of what fk_map_collision returns: every link origin, then the grasped object's
-        collision points in the `grasped_object` link frame (robot_panda.py:154-168)."""
-        L = self.diff_panda._kin.n_links
-        link, off = [np.arange(L, dtype=np.int32)], [np.zeros((L, 3), np.float32)]
-        if self.link_spheres is not None:
-            link.append(self.link_spheres[0]); off.append(self.link_spheres[1])
+        """(point_link, point_offset) of what fk_map_collision returns: every link origin (with a link-sphere model: each
+        followed by its spheres), then the grasped object's collision points in the `grasped_object` link frame
+        (robot_panda.py:154-168)."""
+        link, off = [self._base_points[0]], [self._base_points[1]]
         if self.grasped_object is not None:
             pts = self.grasped_object.base_points_for_collision.detach().cpu().numpy().astype(np.float32)
             link.append(np.full(len(pts), self.diff_panda._name_to_idx_map[self.link_name_grasped_object], np.int32))
