@@ -25,3 +25,38 @@ def test_generated_source_is_deterministic_and_folded():
 def test_model_hash_distinguishes_models():
     hashes = {codegen.model_hash(model(n)) for n in ("panda_arm_no_gripper", "panda_arm_hand", "ur10", "iiwa7")}
     assert len(hashes) == 4
+
+
+def test_point_templates_match_the_robots():
+    """The point sets / collision columns baked into the generated attached-point kernels are exactly what RobotPanda
+    and PlanningTask build at run time (else the dispatcher would silently fall back to the table-driven kernel)."""
+    import numpy as np
+    import torch
+    import torch_robotics_amd as tra
+    from torch_robotics_amd import codegen
+    from torch_robotics_amd.kinematics import URDF_DIR
+    from torch_robotics_amd.kinmodel import KinModel
+    TA = dict(device="cpu", dtype=torch.float32)
+    cases = {"panda_spheres": dict(link_sphere_model="panda"),
+             "panda_grasp": dict(grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA)),
+             "panda_spheres_grasp": dict(link_sphere_model="panda", grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA))}
+    assert set(cases) == set(codegen.SPEC_POINT_ROBOTS)
+    for ident, kw in cases.items():
+        robot = tra.RobotPanda(tensor_args=TA, **kw)
+        spec = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, tensor_args=TA).build_cost_spec()
+        urdf, fn = codegen.SPEC_POINT_ROBOTS[ident]
+        kin = KinModel.from_urdf(str(URDF_DIR / urdf))
+        pt = fn(kin)
+        pl, po = robot.collision_point_set()
+        np.testing.assert_array_equal(pl, pt.point_link)
+        np.testing.assert_array_equal(po, pt.point_offset)
+        assert list(spec.obj_link_idx) == list(pt.obj_cols)
+        assert [tuple(int(v) for v in spec.self_link_idx[p]) for p in spec.self_pairs] == [tuple(p) for p in pt.self_pairs]
+        assert spec.ee_link in (-1, pt.ee_link)
+        assert codegen.model_hash(kin) == codegen.model_hash(robot.diff_panda._kin)
+        src = codegen.generate_points_rollout_source(kin, pt, ident)
+        assert f"0x{codegen.points_hash(pl, po):016x}ull" in src and "spec_flush_chunk<W" in src
+    with __import__("pytest").raises(ValueError):       # columns must follow the walk order of their links
+        kin = KinModel.from_urdf(str(URDF_DIR / "panda_arm_no_gripper.urdf"))
+        bad = codegen.PointsTemplate(point_link=np.array([3, 1], np.int32), point_offset=np.zeros((2, 3), np.float32), obj_cols=[0, 1])
+        codegen.generate_points_rollout_source(kin, bad, "bad")

@@ -331,3 +331,26 @@ def test_sphere_model_reduces_to_link_origin_goldens():
     _, cost, gq = ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 0), dev(g["q"]))
     assert rel_err(cost.cpu().numpy(), g["cost_total"]) < TOL_C
     assert rel_err(gq.cpu().numpy(), g["gq_total"]) < TOL_G
+
+
+def test_spheres_and_grasped_box_together(oracle_lib):
+    """Link spheres + grasped box (71 columns): generated kernel spec_panda_spheres_grasp vs table-driven vs fp64 oracle."""
+    from torch_robotics_amd import ops
+    robot = tra.RobotPanda(link_sphere_model="panda", grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA), tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.2, 0.5)
+    task.set_ee_target(T)
+    pl, po = robot.collision_point_set()
+    o = oracle_lib.Oracle(robot.diff_panda._kin, task.build_cost_spec())
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    q0 = robot.random_q(3 * 64 + 5, generator=gen)
+    rp, rc, rg = o.rollout_points(pl, po, q0.cpu().numpy().astype(np.float64), (1, 1, 1, 1), "f64")
+    ps = robot._point_set(torch.device(DEV))
+    assert ps.specialized and ps.n_points == 71
+    model, cm = task._fused_handles(torch.device(DEV))
+    for use_spec in (True, False):
+        model.enable_specialized(use_spec)
+        pos, cost, gq = ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 1), q0)
+        assert np.abs(pos.cpu().numpy() - rp).max() < TOL_H
+        assert rel_err(cost.cpu().numpy(), rc) < TOL_C and rel_err(gq.cpu().numpy(), rg) < TOL_G
+    model.enable_specialized(True)

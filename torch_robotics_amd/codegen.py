@@ -540,6 +540,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
     for base_identity in (True, False):
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
+        E.raw("template <bool FAST>      // FAST: scene_is_fast(A.C) -- only the few-equal-spheres scene path is compiled in")
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_per_lane} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
@@ -658,7 +659,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                 E.raw(f"        float gx[{n}], gy[{n}], gz[{n}];")
                 E.raw("#pragma unroll")
                 E.raw(f"        for (int l = 0; l < {n}; ++l) {{ gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }}")
-                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, notick, lds_sph, {mb});")
+                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}, NoTick, FAST>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, notick, lds_sph, {mb});")
                 E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<{n}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {mb});")
                 E.raw("#pragma unroll")
                 E.raw(f"        for (int l = 0; l < {n}; ++l) {{")
@@ -725,8 +726,14 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
     out.append(f"static const int32_t kSelfPairs[] = {{{pairs}}};")
     out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
-    out.append("    if (base_identity) hipLaunchKernelGGL(k_rollout_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-    out.append("    else hipLaunchKernelGGL(k_rollout_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    const bool fast = scene_is_fast(a.C) || a.w.w_obj == 0.0f;")
+    out.append("    if (fast) {")
+    out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<true>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("        else hipLaunchKernelGGL(k_rollout_bg<true>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    } else {")
+    out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<false>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("        else hipLaunchKernelGGL(k_rollout_bg<false>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    }")
     out.append("}")
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, P, "
@@ -810,10 +817,31 @@ SPEC_ROBOTS = {
 }
 
 
+def panda_spheres_grasp_points(kin: KinModel) -> PointsTemplate:
+    """RobotPanda(link_sphere_model="panda", grasped_object=GraspedObjectPandaBox()): link-sorted origins + spheres, then
+    the 14 box points; objects / workspace on spheres + box points; pair table incl. grasped rows (on origin columns)."""
+    from .costmodel import link_sorted_point_set, load_link_spheres, panda_box_base_points
+    from .kinematics import DATA_DIR
+    idx = kin.name_to_idx
+    sl, so, _sr, _names = load_link_spheres(DATA_DIR / "configs" / "panda_sphere_config.yaml", idx)
+    pl, po, origin_col, sphere_col = link_sorted_point_set(kin.order, sl, so)
+    pts = panda_box_base_points()
+    G, P0 = len(pts), len(pl)
+    pl = np.concatenate([pl, np.full(G, idx["grasped_object"])]).astype(np.int32)
+    po = np.concatenate([po, pts]).astype(np.float32)
+    pairs, _ = _panda_pairs(idx)
+    cpairs = [(int(origin_col[a]), int(origin_col[b])) for a, b in pairs]
+    for n in ("panda_link0", "panda_link1", "panda_link2", "panda_link3"):
+        cpairs += [(P0 + m, int(origin_col[idx[n]])) for m in range(G)]
+    return PointsTemplate(point_link=pl, point_offset=po, obj_cols=[int(c) for c in sphere_col] + list(range(P0, P0 + G)),
+                          self_pairs=cpairs, ee_link=idx["ee_link"])
+
+
 # attached-point kernels: name -> (urdf file, PointsTemplate factory)
 SPEC_POINT_ROBOTS = {
     "panda_spheres": ("panda_arm_no_gripper.urdf", panda_spheres_points),
     "panda_grasp": ("panda_arm_no_gripper_grasped_object.urdf", panda_grasp_points),
+    "panda_spheres_grasp": ("panda_arm_no_gripper_grasped_object.urdf", panda_spheres_grasp_points),
 }
 
 

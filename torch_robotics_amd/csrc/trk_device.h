@@ -370,18 +370,25 @@ struct NoTick { __device__ __forceinline__ void operator()() const {} };
 // stores out between the arithmetic instead of issuing them as one burst (see spec_common: PosFlusher).
 #define TRK_LDS_SPHERES 16     // sphere centres a fused kernel may keep in LDS for the arg-min gather
 
-template <int NL, class Tick = NoTick>
+// FAST: the caller guarantees (wave-uniformly, from the cost model header: scene_is_fast) that the scene is 1..16
+// spheres of one radius and nothing else, so only that path is compiled -- a kernel that inlines this function many
+// times (attached-point kernels: once per group of points) would otherwise not fit the instruction cache.
+__host__ __device__ inline bool scene_is_fast(const DevCostHdr& C) {
+    return C.n_spheres > 0 && C.n_spheres <= 16 && C.spheres_uniform_r && C.n_box_objects == 0 && !C.has_grid;
+}
+
+template <int NL, class Tick = NoTick, bool FAST = false>
 __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (&px)[NL], const float (&py)[NL],
                                               const float (&pz)[NL], float (&s)[NL], float (&gx)[NL], float (&gy)[NL],
                                               float (&gz)[NL], Tick&& tick = Tick(), const float4* lds_spheres = nullptr) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) { s[l] = __builtin_inff(); gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }
-    if (C.n_spheres > 0) {
-        if (C.spheres_uniform_r) {
+    if (FAST || C.n_spheres > 0) {
+        if (FAST || C.spheres_uniform_r) {
             // equal radii: arg-min over spheres of |p-c|^2, ranked by |p-c|^2 - |p|^2 = p.(-2c) + |c|^2 (3 FMAs per
             // sphere and point); the exact distance is recomputed for the winner only (one sqrt per point).
             int bi[NL];
-            if (C.n_spheres <= 16) {
+            if (FAST || C.n_spheres <= 16) {
                 // index rides in the 4 low mantissa bits of the ranking key: one v_bfi + one v_min per sphere and
                 // point.  Only near-ties (relative gap < 2^-19) can pick the other sphere, and then both distances
                 // agree to ~2e-6 -- below the stated cost tolerance; the value itself is always exact.
@@ -455,7 +462,7 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
             for (int l = 0; l < NL; ++l) {
                 // per-lane gather of the winning centre: from the wave's LDS copy when there is one (~100 cycles),
                 // else from global memory (L2 hit, ~700 cycles with every wave of the chip asking at once)
-                const float4 S = (lds_spheres && C.n_spheres <= TRK_LDS_SPHERES) ? lds_spheres[bi[l]] : C.spheres[bi[l]];
+                const float4 S = (lds_spheres && (FAST || C.n_spheres <= TRK_LDS_SPHERES)) ? lds_spheres[bi[l]] : C.spheres[bi[l]];
                 const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
                 const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
                 const float inv = n2 > 0.0f ? trk_rsq(n2) : 0.0f;     // one transcendental per point
@@ -477,6 +484,7 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
             }
         }
     }
+    if (FAST) return;
     // objects that still have non-sphere primitives (boxes): empty loop for sphere-only scenes
     for (int b = 0; b < C.n_box_objects; ++b) {
         const int o = cptr(C.box_objects)[b];

@@ -256,13 +256,13 @@ __device__ __forceinline__ float spec_wave_sum(float v) {
 // collision objectives on NL link points held in registers.  Adds w * cost to `cost` and
 // w * d cost / d p to (gx, gy, gz) (accumulating).  Margins are C.obj_link_margin[0..NL) in baked order.
 // ---------------------------------------------------------------------------------------------------------
-template <int NL, class Tick>
+template <int NL, class Tick, bool FAST = false>
 __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w, const float (&px)[NL],
                                                    const float (&py)[NL], const float (&pz)[NL], float (&gx)[NL],
                                                    float (&gy)[NL], float (&gz)[NL], Tick& tick, const float4* lds_spheres,
                                                    int mbase = 0) {
     float s[NL], ax[NL], ay[NL], az[NL];
-    scene_min_sdf<NL>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres);
+    scene_min_sdf<NL, Tick&, FAST>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres);
     float cost = 0.0f;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
