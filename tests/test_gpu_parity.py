@@ -634,3 +634,37 @@ def test_rollout_fp16_io(ops, oracle_lib, robot, ident):
     _, rc, rg = o.rollout(q.cpu().numpy().astype(np.float64).reshape(-1, kin.n_dofs), (0, 1, 0, 1), "f64")
     assert plan.gq.dtype == torch.float16 and rel_err(plan.cost.cpu().numpy().reshape(-1), rc) < TOL_C
     assert rel_err(plan.gq.float().cpu().numpy().reshape(rg.shape), rg) < 1e-3
+
+
+@pytest.mark.parametrize("ident", ["panda", "dual_panda", "ur10_allegro"])
+def test_generated_fk_positions_and_backward(ops, oracle_lib, ident):
+    """trk_fk_positions / trk_fk_positions_backward with all links selected run the generated kernels for the robots
+    that have one: against the fp64 oracle and the table-driven kernels, ragged sizes, with and without a base pose."""
+    from torch_robotics_amd import codegen
+    kin, _ = codegen.template_for(ident)
+    h, o = ops.ModelHandle(kin), oracle_lib.Oracle(kin)
+    assert h.specialized
+    rng = np.random.default_rng(17)
+    L, D = kin.n_links, kin.n_dofs
+    for base in (False, True):
+        if base:
+            kin.set_base_pose(np.array([0.1234, -0.2345, 0.0567, 0.9238795, 0.0, 0.3826834, 0.0], np.float32))
+            h.set_base_pose(kin.base_R, kin.base_t)
+            o.refresh_model()
+        for n in (1, 64, 65, 777):
+            q = rng.uniform(-3.2, 3.2, size=(n, D)).astype(np.float32)
+            w = rng.standard_normal((n, L, 3)).astype(np.float32)
+            H64 = o.fk(q.astype(np.float64), "f64")
+            gH = np.zeros((n, L, 4, 4)); gH[..., :3, 3] = w
+            g64 = o.fk_backward(q.astype(np.float64), gH, "f64")
+            res = {}
+            for use_spec in (True, False):
+                h.enable_specialized(use_spec)
+                pos = ops.fk_positions(h, dev(q)).cpu().numpy()
+                gq = ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy()
+                scale = max(1.0, float(np.abs(H64[..., :3, 3]).max()))
+                assert np.abs(pos - H64[..., :3, 3]).max() / scale < TOL_H
+                assert rel_err(gq, g64) < TOL_G
+                res[use_spec] = (pos, gq)
+            h.enable_specialized(True)
+            np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=4e-6)

@@ -289,6 +289,56 @@ def _emit_joint_gradient(E: "Emitter", kin: KinModel, i: int, R, t, Fi, Ti, mask
     return masked(E, i, d, S(g.c * sg, g.n))
 
 
+def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, List[str]], ee: int, masked,
+                        tick: Optional[str] = None) -> Dict[int, S]:
+    """Reverse pass of the link kernels: per-link wrench accumulators (F, T about the world origin) pushed towards the
+    root; `tb_names[i]` = the three C expressions holding link i's position adjoint; the EE link adds axial(eeRb R^T)."""
+    L = kin.n_links
+    F: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
+    T: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
+    gq_expr: Dict[int, S] = {}
+    for p in range(L - 1, 0, -1):
+        i = int(kin.order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
+        E.raw(f"    // reverse: link {i}")
+        if tick is not None and p % 2 == 0:
+            E.raw(tick)
+        if i in tb_names:
+            tb = [S(1.0, n) for n in tb_names[i]]
+            own_T = E.cross(t[i], tb)
+            F[i] = [E.add(F[i][k], tb[k]) for k in range(3)]
+            T[i] = [E.add(T[i][k], own_T[k]) for k in range(3)]
+            if i == ee:
+                Rb = [[S(1.0, f"eeRb[{3 * r + c}]") for c in range(3)] for r in range(3)]
+                Ri = R[i]
+                M = lambda a, b: E.lincomb([(Rb[a][k], Ri[b][k]) for k in range(3)])   # (Rbar R^T)[a][b]
+                tor = [E.lincomb([(M(2, 1), ONE), (M(1, 2), S(-1.0))]),
+                       E.lincomb([(M(0, 2), ONE), (M(2, 0), S(-1.0))]),
+                       E.lincomb([(M(1, 0), ONE), (M(0, 1), S(-1.0))])]
+                T[i] = [E.add(T[i][k], tor[k]) for k in range(3)]
+        nonzero = any(not s.is_zero for s in F[i] + T[i])
+        if jt != JOINT_FIXED:
+            if not nonzero:
+                gq_expr[d] = ZERO
+            elif jt == JOINT_PRISMATIC:
+                dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
+                g = E.dot(dirw, F[i])
+                gq_expr[d] = masked(E, i, d, g)
+            else:
+                sg = float(kin.rot_sign[i])
+                if sg == 0.0:
+                    gq_expr[d] = ZERO
+                else:
+                    ax = int(kin.rot_axis[i])
+                    z = [R[i][r][ax] for r in range(3)]
+                    cr = E.cross(t[i], F[i])
+                    diff = [E.lincomb([(T[i][k], ONE), (cr[k], S(-1.0))]) for k in range(3)]
+                    g = E.dot(z, diff)
+                    gq_expr[d] = masked(E, i, d, S(g.c * sg, g.n))
+        F[par] = [E.add(F[par][k], F[i][k]) for k in range(3)]
+        T[par] = [E.add(T[par][k], T[i][k]) for k in range(3)]
+    return gq_expr
+
+
 def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, snap: float = SNAP) -> str:
     L, D = kin.n_links, kin.n_dofs
     NL = len(tmpl.obj_links)
@@ -341,6 +391,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw(f"        const float pv[{3 * L}] = {{{pos_list}}};")
         E.raw(f"        flush = spec_stage_rows<{3 * L}>(static_cast<IO*>(A.link_pos), base, rows, lane, lds, pv);")
         E.raw("    }")
+        E.raw("    if (!A.gq) { flush.flush(); return; }      // positions only (trk_fk_positions): wave-uniform exit")
         E.raw("    flush(); flush();")
         E.raw("    spec_stamp(A.stamps, wblock, 3, lane);")
         # ---------------- objectives ----------------
@@ -388,53 +439,47 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("        if (lane == 0 && rows > 0) A.cost_sum[wblock] = tot;")
         E.raw("    }")
         # ---------------- reverse: wrench accumulators towards the root ----------------
-        F: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
-        T: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
-        gq_expr: Dict[int, S] = {}
-        for p in range(L - 1, 0, -1):
-            i = int(kin.order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
-            E.raw(f"    // reverse: link {i}")
-            if p % 2 == 0:
-                E.raw("    flush();")
-            if i in adj_links:
-                tb = [S(1.0, f"tb{i}_{k}") for k in range(3)]
-                own_T = E.cross(t[i], tb)
-                F[i] = [E.add(F[i][k], tb[k]) for k in range(3)]
-                T[i] = [E.add(T[i][k], own_T[k]) for k in range(3)]
-                if i == ee:
-                    Rb = [[S(1.0, f"eeRb[{3 * r + c}]") for c in range(3)] for r in range(3)]
-                    Ri = R[i]
-                    M = lambda a, b: E.lincomb([(Rb[a][k], Ri[b][k]) for k in range(3)])   # (Rbar R^T)[a][b]
-                    tor = [E.lincomb([(M(2, 1), ONE), (M(1, 2), S(-1.0))]),
-                           E.lincomb([(M(0, 2), ONE), (M(2, 0), S(-1.0))]),
-                           E.lincomb([(M(1, 0), ONE), (M(0, 1), S(-1.0))])]
-                    T[i] = [E.add(T[i][k], tor[k]) for k in range(3)]
-            nonzero = any(not s.is_zero for s in F[i] + T[i])
-            if jt != JOINT_FIXED:
-                if not nonzero:
-                    gq_expr[d] = ZERO
-                elif jt == JOINT_PRISMATIC:
-                    dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
-                    g = E.dot(dirw, F[i])
-                    gq_expr[d] = masked(E, i, d, g)
-                else:
-                    sg = float(kin.rot_sign[i])
-                    if sg == 0.0:
-                        gq_expr[d] = ZERO
-                    else:
-                        ax = int(kin.rot_axis[i])
-                        z = [R[i][r][ax] for r in range(3)]
-                        cr = E.cross(t[i], F[i])
-                        diff = [E.lincomb([(T[i][k], ONE), (cr[k], S(-1.0))]) for k in range(3)]
-                        g = E.dot(z, diff)
-                        gq_expr[d] = masked(E, i, d, S(g.c * sg, g.n))
-            F[par] = [E.add(F[par][k], F[i][k]) for k in range(3)]
-            T[par] = [E.add(T[par][k], T[i][k]) for k in range(3)]
+        gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"tb{i}_{k}" for k in range(3)] for i in adj_links}, ee, masked,
+                                      tick="    flush();")
         E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
         E.raw("    flush.flush();")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D>(static_cast<IO*>(A.gq), base, rows, lane, lds, gv);")
         E.raw("    spec_stamp(A.stamps, wblock, 7, lane);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
+    # ---- explicit reverse mode of the link positions (trk_fk_positions_backward with all links selected):
+    # FK again (cheaper than storing poses), the adjoint rows [64][3L] come in through the LDS transpose, reverse pass
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_posbwd_bi" if base_identity else "k_posbwd_bg"
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(3 * L, D)}];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(3 * L, D)});")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        E.raw(f"    float gp[{3 * L}];                       // this sample's position adjoints, link-major")
+        E.raw(f"    spec_load_q<{3 * L}>(static_cast<const float*>(A.link_pos), base, rows, lane, lds, gp);")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        _emit_angles(E, kin)
+        for p in range(1, L):
+            _emit_fk_link(E, kin, int(kin.order[p]), R, t, passv, snap)
+        gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"gp[{3 * i + k}]" for k in range(3)] for i in range(1, L)}, -1, masked)
+        E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
+        E.raw("    spec_store_gq<D>(static_cast<float*>(A.gq), base, rows, lane, lds, gv);")
         E.raw("}")
         out.extend(E.lines)
         out.append("")
@@ -453,8 +498,13 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("        else hipLaunchKernelGGL(k_rollout_bg<float>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    }")
     out.append("}")
+    out.append("static void launch_posbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+    out.append("    if (base_identity) hipLaunchKernelGGL(k_posbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    else hipLaunchKernelGGL(k_posbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("}")
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
-               f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull}};")
+               f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -670,19 +720,25 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
             # ---- self-collision pairs whose later column belongs to this link
             if pairs_at[i]:
                 E.raw("    if (A.w.w_self != 0.0f) {")
-                E.raw("        float gl0, gl1, gl2, ge0, ge1, ge2;")
+                E.raw("        float gl0, gl1, gl2;")
+                earlies = sorted({early for _, _, early, _ in pairs_at[i]})
+                for e in earlies:             # all pairs of one earlier column push on the same point: sum the forces first
+                    E.raw(f"        float ge{e}_0 = 0.0f, ge{e}_1 = 0.0f, ge{e}_2 = 0.0f;")
                 for pi, late, early, late_is_a in pairs_at[i]:
                     pa, pb = (late, early) if late_is_a else (early, late)
-                    ga, gb = ("gl", "ge") if late_is_a else ("ge", "gl")
-                    E.raw("        gl0 = gl1 = gl2 = ge0 = ge1 = ge2 = 0.0f;")
+                    gl, ge = "gl0, gl1, gl2", f"ge{early}_0, ge{early}_1, ge{early}_2"
+                    ga, gb = (gl, ge) if late_is_a else (ge, gl)
+                    E.raw("        gl0 = gl1 = gl2 = 0.0f;")
                     E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], "
                           f"{', '.join(E.expr(colpos[pa][k]) for k in range(3))}, {', '.join(E.expr(colpos[pb][k]) for k in range(3))}, "
-                          f"{ga}0, {ga}1, {ga}2, {gb}0, {gb}1, {gb}2);")
+                          f"{ga}, {gb});")
                     in_order(colpos[late], ["gl0", "gl1", "gl2"])
-                    if pl[early] == i:
-                        in_order(colpos[early], ["ge0", "ge1", "ge2"])
+                for e in earlies:
+                    g = [f"ge{e}_0", f"ge{e}_1", f"ge{e}_2"]
+                    if pl[e] == i:
+                        in_order(colpos[e], g)
                     else:
-                        late_force(pl[early], colpos[early], ["ge0", "ge1", "ge2"])
+                        late_force(pl[e], colpos[e], g)
                 E.raw("    }")
             # ---- end-effector tracking when the walk stands on the EE link
             if i == pt.ee_link:
@@ -737,7 +793,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
     out.append("}")
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, P, "
-               f"0x{points_hash(pt.point_link, pt.point_offset):016x}ull}};")
+               f"0x{points_hash(pt.point_link, pt.point_offset):016x}ull, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"

@@ -233,6 +233,17 @@ static int make_sel(const TrkModel* m, const int32_t* link_sel, int32_t n_sel, S
     return TRK_OK;
 }
 
+static int base_is_identity(const TrkModel* m) {
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z[3] = {0, 0, 0};
+    return std::memcmp(m->hdr.base_R, I, sizeof(I)) == 0 && std::memcmp(m->hdr.base_t, Z, sizeof(Z)) == 0;
+}
+// the generated kernels produce / consume all links in file order
+static bool spec_all_links(const TrkModel* m, const SelMap& sel, int ns) {
+    if (!m->spec || !m->spec_enabled || ns != m->hdr.n_links) return false;
+    for (int k = 0; k < ns; ++k) if (sel.col[k] != k) return false;
+    return true;
+}
+
 static int check_model(const TrkModel* m, const char* who) {
     if (!m) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null model");
     if (m->unsupported) return fail(TRK_ERR_UNSUPPORTED, std::string(who) + ": model has a joint type other than fixed/revolute/continuous/prismatic");
@@ -248,6 +259,17 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
     rc = make_sel(m, link_sel, n_sel, sel, ns, who);
     if (rc) return rc;
     if (n == 0) return TRK_OK;
+    if (mode == 1 && spec_all_links(m, sel, ns)) {
+        // generated kernel, positions-only exit (gq == nullptr): same FK code as the fused rollout
+        SpecArgs a;
+        std::memset(&a, 0, sizeof(a));
+        std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+        std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+        a.q = q; a.n = n; a.link_pos = out;
+        m->spec->launch(a, base_is_identity(m), (hipStream_t)stream);
+        TRK_HIP(hipGetLastError());
+        return TRK_OK;
+    }
     trk_launch_fk_forward(mode, m->hdr, m->d_links, sel, ns, q, n, out, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
@@ -269,6 +291,16 @@ static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin,
     rc = make_sel(m, link_sel, n_sel, sel, ns, who);
     if (rc) return rc;
     if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    if (mode == 1 && spec_all_links(m, sel, ns) && m->spec->launch_posbwd) {
+        SpecArgs a;
+        std::memset(&a, 0, sizeof(a));
+        std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+        std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+        a.q = q; a.n = n; a.link_pos = const_cast<float*>(gin); a.gq = gq;
+        m->spec->launch_posbwd(a, base_is_identity(m), (hipStream_t)stream);
+        TRK_HIP(hipGetLastError());
+        return TRK_OK;
+    }
     trk_launch_fk_backward(mode, m->hdr, m->d_links, m->d_fin, sel, ns, q, gin, n, gq, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;

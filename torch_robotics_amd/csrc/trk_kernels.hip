@@ -17,11 +17,27 @@
 
 namespace {
 
-// IO = HBM-side element type (float, or _Float16 for the fp16-I/O rollout); LDS and arithmetic are fp32
+// IO = HBM-side element type (float, or _Float16 for the fp16-I/O rollout); LDS and arithmetic are fp32.
+// Loads are issued in batches of TRK_LOAD_BATCH before the first one is consumed: a plain `dst[k] = src[k]` loop
+// compiles to load / s_waitcnt vmcnt(0) / ds_write per trip, i.e. ONE 256-byte request in flight per wavefront --
+// measured 30 us for the 35 MB of k_cost_fields (33 serialized round trips per wavefront).
+#define TRK_LOAD_BATCH 8
 template <class IO>
 __device__ __forceinline__ void load_tile(float* dst, const IO* __restrict__ src, int64_t first, int64_t count, int lane) {
     // dst[0..count) = src[first .. first+count), contiguous -> fully coalesced loads
-    for (int64_t k = lane; k < count; k += TRK_WAVE) dst[k] = (float)src[first + k];
+    for (int64_t k0 = lane; k0 < count; k0 += TRK_WAVE * TRK_LOAD_BATCH) {
+        float v[TRK_LOAD_BATCH];
+#pragma unroll
+        for (int j = 0; j < TRK_LOAD_BATCH; ++j) {
+            const int64_t k = k0 + TRK_WAVE * j;
+            v[j] = k < count ? (float)src[first + k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < TRK_LOAD_BATCH; ++j) {
+            const int64_t k = k0 + TRK_WAVE * j;
+            if (k < count) dst[k] = v[j];
+        }
+    }
 }
 
 template <class IO>
@@ -47,10 +63,20 @@ __device__ __forceinline__ void load_tile_strided(float* dst, const float* __res
     int r = lane / width, c = lane - r * width;
     const int dr = TRK_WAVE / width, dc = TRK_WAVE - dr * width;
     const int64_t count = (int64_t)rows * width;
-    for (int64_t k = lane; k < count; k += TRK_WAVE) {
-        dst[r * rs + c] = src[first + k];
-        r += dr; c += dc;
-        if (c >= width) { c -= width; ++r; }
+    for (int64_t k0 = lane; k0 < count; k0 += TRK_WAVE * TRK_LOAD_BATCH) {
+        float v[TRK_LOAD_BATCH];
+#pragma unroll
+        for (int j = 0; j < TRK_LOAD_BATCH; ++j) {
+            const int64_t k = k0 + TRK_WAVE * j;
+            v[j] = k < count ? src[first + k] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < TRK_LOAD_BATCH; ++j) {
+            const int64_t k = k0 + TRK_WAVE * j;
+            if (k < count) dst[r * rs + c] = v[j];
+            r += dr; c += dc;
+            if (c >= width) { c -= width; ++r; }
+        }
     }
 }
 
@@ -456,6 +482,40 @@ k_ik_step(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __r
 // distance_fields.py:107-124 ('sdf'): objects :298-316, workspace box :319-332, self pairs :194-208.
 // Returns the summed cost of the selected fields; if gtile != nullptr accumulates scale * d cost / d pos.
 // ============================================================================================
+// objects + workspace box for NB collision links [l0, l0 + NB) at once (independent chains for the scheduler)
+template <int NB>
+__device__ __forceinline__ float fields_links(const DevCostHdr& C, int fields, float w_obj, float w_ws, int l0,
+                                              const float* pt, float* gt) {
+    int li[NB];
+    float mg[NB], x[NB], y[NB], z[NB], ax[NB], ay[NB], az[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        li[k] = cptr(C.obj_link_idx)[l0 + k];
+        mg[k] = cptr(C.obj_link_margin)[l0 + k];
+        x[k] = pt[3 * li[k]]; y[k] = pt[3 * li[k] + 1]; z[k] = pt[3 * li[k] + 2];
+        ax[k] = 0.0f; ay[k] = 0.0f; az[k] = 0.0f;
+    }
+    float cost = 0.0f;
+    if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
+        float s[NB], gx[NB], gy[NB], gz[NB];
+        scene_min_sdf<NB>(C, x, y, z, s, gx, gy, gz);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            cost = fmaf(w_obj, mg[k] - s[k], cost);
+            ax[k] -= w_obj * gx[k]; ay[k] -= w_obj * gy[k]; az[k] -= w_obj * gz[k];
+        }
+    }
+    if ((fields & TRK_FIELD_WS) && C.has_ws) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) cost = fmaf(w_ws, ws_cost_point(C, mg[k], x[k], y[k], z[k], w_ws, ax[k], ay[k], az[k]), cost);
+    }
+    if (gt) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { gt[3 * li[k]] += ax[k]; gt[3 * li[k] + 1] += ay[k]; gt[3 * li[k] + 2] += az[k]; }
+    }
+    return cost;
+}
+
 template <bool PRECISE>
 __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, float w_self, float w_obj, float w_ws,
                                              const float* tile, float* gtile, int rs, int lane) {
@@ -463,13 +523,13 @@ __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, fl
     const float* pt = tile + lane * rs;
     float* gt = gtile ? gtile + lane * rs : nullptr;
     if ((fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) != 0) {
-        for (int l = 0; l < C.n_obj_links; ++l) {
-            const int li = cptr(C.obj_link_idx)[l];
-            const float mg = cptr(C.obj_link_margin)[l];
-            const float x = pt[3 * li], y = pt[3 * li + 1], z = pt[3 * li + 2];
-            float ax = 0.0f, ay = 0.0f, az = 0.0f;
-            if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
-                if (PRECISE) {
+        if (PRECISE) {
+            for (int l = 0; l < C.n_obj_links; ++l) {
+                const int li = cptr(C.obj_link_idx)[l];
+                const float mg = cptr(C.obj_link_margin)[l];
+                const float x = pt[3 * li], y = pt[3 * li + 1], z = pt[3 * li + 2];
+                float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
                     float best = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
                     for (int o = 0; o < C.n_objects; ++o) {
                         float gx, gy, gz;
@@ -479,16 +539,15 @@ __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, fl
                     }
                     cost = fmaf(w_obj, best, cost);
                     ax -= w_obj * bx; ay -= w_obj * by; az -= w_obj * bz;
-                } else {
-                    const float p1x[1] = {x}, p1y[1] = {y}, p1z[1] = {z};
-                    float s1[1], g1x[1], g1y[1], g1z[1];
-                    scene_min_sdf<1>(C, p1x, p1y, p1z, s1, g1x, g1y, g1z);
-                    cost = fmaf(w_obj, mg - s1[0], cost);
-                    ax -= w_obj * g1x[0]; ay -= w_obj * g1y[0]; az -= w_obj * g1z[0];
                 }
+                if ((fields & TRK_FIELD_WS) && C.has_ws) cost = fmaf(w_ws, ws_cost_point(C, mg, x, y, z, w_ws, ax, ay, az), cost);
+                if (gt) { gt[3 * li] += ax; gt[3 * li + 1] += ay; gt[3 * li + 2] += az; }
             }
-            if ((fields & TRK_FIELD_WS) && C.has_ws) cost = fmaf(w_ws, ws_cost_point(C, mg, x, y, z, w_ws, ax, ay, az), cost);
-            if (gt) { gt[3 * li] += ax; gt[3 * li + 1] += ay; gt[3 * li + 2] += az; }
+        } else {
+            int l = 0;
+            for (; l + 4 <= C.n_obj_links; l += 4) cost += fields_links<4>(C, fields, w_obj, w_ws, l, pt, gt);
+            if (l + 2 <= C.n_obj_links) { cost += fields_links<2>(C, fields, w_obj, w_ws, l, pt, gt); l += 2; }
+            if (l < C.n_obj_links) cost += fields_links<1>(C, fields, w_obj, w_ws, l, pt, gt);
         }
     }
     if (fields & TRK_FIELD_SELF) {
@@ -519,8 +578,9 @@ k_cost_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos, int6
     const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
     const int rows = (int)min((int64_t)TRK_WAVE, n - base);
     float* tile = smem;
-    float* gtile = tile + TRK_WAVE * rs;
-    for (int k = lane; k < TRK_WAVE * rs; k += TRK_WAVE) { tile[k] = 0.0f; gtile[k] = 0.0f; }
+    float* gtile = tile + TRK_WAVE * rs;                      // allocated only when g_link_pos != nullptr
+    if (g_link_pos) for (int k = lane; k < TRK_WAVE * rs; k += TRK_WAVE) gtile[k] = 0.0f;
+    if (rows < TRK_WAVE) for (int k = rows * rs + lane; k < TRK_WAVE * rs; k += TRK_WAVE) tile[k] = 0.0f;   // lanes past the end compute on zeros
     __syncthreads();
     load_tile_strided(tile, link_pos, base * width, rows, width, rs, lane);
     __syncthreads();
@@ -1197,7 +1257,7 @@ void trk_launch_ik_step(const DevModelHdr& hdr, const DevLink* links, const int3
 
 void trk_launch_cost_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, const float* gcost,
                             float* cost, float* g_link_pos, hipStream_t st) {
-    size_t lds = sizeof(float) * 2 * (size_t)TRK_WAVE * ((C.n_links_in * 3) | 1);
+    size_t lds = sizeof(float) * (g_link_pos ? 2 : 1) * (size_t)TRK_WAVE * ((C.n_links_in * 3) | 1);
     hipLaunchKernelGGL(k_cost_fields, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, C, fields, link_pos, n, gcost, cost, g_link_pos);
 }
 
