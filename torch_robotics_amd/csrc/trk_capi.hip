@@ -301,7 +301,10 @@ static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin,
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
-    trk_launch_fk_backward(mode, m->hdr, m->d_links, m->d_fin, sel, ns, q, gin, n, gq, (hipStream_t)stream);
+    SelMap selp;
+    for (int k = 0; k < TRK_MAX_LINKS; ++k) selp.col[k] = -1;
+    for (int p = 0; p < m->hdr.n_links; ++p) selp.col[p] = sel.col[m->links[p].link];
+    trk_launch_fk_backward(mode, m->hdr, m->d_links, m->d_fin, sel, selp, ns, q, gin, n, gq, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }

@@ -80,6 +80,24 @@ __device__ __forceinline__ void load_tile_strided(float* dst, const float* __res
     }
 }
 
+// One link record through the scalar cache (2 x s_load_dwordx16).  The walks fetch the record of position p + 1
+// while they work on position p: a record loaded at its first use stalls the wavefront for a scalar-cache round trip
+// per link, and nothing else hides it when only 2-3 wavefronts share a SIMD.
+__device__ __forceinline__ DevLink load_link(const DevLink* __restrict__ links, int p) {
+    const TRK_CAS DevLink* c = cptr(links) + p;
+    DevLink L;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) L.Rf[k] = c->Rf[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { L.trans[k] = c->trans[k]; L.axis[k] = c->axis[k]; }
+    L.lower = c->lower; L.upper = c->upper; L.rot_sign = c->rot_sign;
+    L.type = c->type; L.dof = c->dof; L.rot_axis = c->rot_axis; L.clamp = c->clamp;
+    L.parent_slot = c->parent_slot; L.store_slot = c->store_slot; L.link = c->link;
+    L.sf_rot_axis = c->sf_rot_axis; L.sf_clamp = c->sf_clamp; L.jac_axis = c->jac_axis;
+    L.fin_begin = c->fin_begin; L.fin_end = c->fin_end;
+    return L;
+}
+
 __device__ __forceinline__ void slot_store(float* slots, int slot, int lane, const Pose& p) {
     float* s = slots + slot * 12 * TRK_WAVE + lane;
 #pragma unroll
@@ -145,19 +163,32 @@ k_fk_forward(DevModelHdr hdr, const DevLink* __restrict__ links, SelMap sel, int
     __syncthreads();
     const int64_t s = base + lane;
     Pose cur, par;
+    DevLink nxt = load_link(links, 0);
     for (int p = 0; p < L; ++p) {
-        const DevLink& Lk = links[p];
+        const DevLink Lk = nxt;
+        nxt = load_link(links, p + 1 < L ? p + 1 : p);
         walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
         const int col = sel.col[Lk.link];
         if (col < 0) continue;
         if (MODE == 0) {
-            if (lane < rows) {
-                float4* o = reinterpret_cast<float4*>(out + (s * n_sel + col) * 16);
-                o[0] = make_float4(cur.r[0], cur.r[1], cur.r[2], cur.t[0]);
-                o[1] = make_float4(cur.r[3], cur.r[4], cur.r[5], cur.t[1]);
-                o[2] = make_float4(cur.r[6], cur.r[7], cur.r[8], cur.t[2]);
-                o[3] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            // A lane writing its own 64-byte matrix with four 16-byte stores makes every store instruction touch 64
+            // different lines.  Through LDS instead: 4 lanes cover one sample's matrix, so an instruction writes 16
+            // whole 64-byte blocks (4x fewer line visits; stride 20 floats keeps ds_*_b128 aligned and spread).
+            float4* st = reinterpret_cast<float4*>(tile + lane * 20);
+            st[0] = make_float4(cur.r[0], cur.r[1], cur.r[2], cur.t[0]);
+            st[1] = make_float4(cur.r[3], cur.r[4], cur.r[5], cur.t[1]);
+            st[2] = make_float4(cur.r[6], cur.r[7], cur.r[8], cur.t[2]);
+            st[3] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            __syncthreads();
+            const int sub = lane & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sl = (lane >> 2) + 16 * j;
+                if (sl < rows)
+                    *reinterpret_cast<float4*>(out + ((base + sl) * n_sel + col) * 16 + 4 * sub) =
+                        *reinterpret_cast<const float4*>(tile + sl * 20 + 4 * sub);
             }
+            __syncthreads();
         } else {
             float* o = tile + lane * rs + 3 * col;
             o[0] = cur.t[0]; o[1] = cur.t[1]; o[2] = cur.t[2];
@@ -182,8 +213,11 @@ __device__ __forceinline__ void reverse_walk(const DevModelHdr& hdr, const DevLi
     const int D = hdr.n_dofs, L = hdr.n_links;
     float Pf[3] = {0.0f, 0.0f, 0.0f}, Pt[3] = {0.0f, 0.0f, 0.0f};
     Pose cur, par;
+    DevLink nxt = load_link(links, 0);
+    adj.prefetch(0);
     for (int p = 0; p < L; ++p) {
-        const DevLink& Lk = links[p];
+        const DevLink Lk = nxt;
+        nxt = load_link(links, p + 1 < L ? p + 1 : p);
         const float pass = walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
         if (Lk.dof >= 0) {
             float a[3] = {0.0f, 0.0f, 0.0f}, m[3];
@@ -227,6 +261,7 @@ __device__ __forceinline__ void reverse_walk(const DevModelHdr& hdr, const DevLi
                 Pt[0] += M21 - M12; Pt[1] += M02 - M20; Pt[2] += M10 - M01;
             }
         }
+        if (p + 1 < L) adj.prefetch(p + 1);       // the next position's adjoint travels while this one is finished
         // joints whose subtree ends here
         for (int f = Lk.fin_begin; f < Lk.fin_end; ++f) {
             const int d = fin[f];
@@ -240,8 +275,13 @@ __device__ __forceinline__ void reverse_walk(const DevModelHdr& hdr, const DevLi
 }
 
 struct AdjFromGH {        // gH [N, n_sel, 4, 4]
+    // Plain per-lane loads at the point of use.  Two "smarter" variants were measured slower on MI355X (4096 x 64,
+    // Panda, 42 us as written): a cooperative 4-lanes-per-matrix fetch through LDS (the mirror of k_fk_forward's
+    // store path; 77 us -- a full round trip between two barriers per link) and a one-position-ahead register
+    // prefetch (69 us).
     const float* gH; int64_t s; int n_sel; const SelMap& sel; bool valid;
     __device__ __forceinline__ bool has_rot(const DevLink&) const { return true; }
+    __device__ __forceinline__ void prefetch(int) const {}
     __device__ __forceinline__ bool operator()(const DevLink& Lk, int, const Pose&, float* Rb, float* tb) const {
         const int col = sel.col[Lk.link];
         if (col < 0) return false;
@@ -261,6 +301,7 @@ template <bool IDENT>
 struct AdjFromTile {      // tbar from an LDS tile [64][rs] (link-major, 3 floats per link) + optional EE rotation adjoint
     const float* tile; int rs; int lane; const SelMap& sel; int ee_link; const float* eeRb;
     __device__ __forceinline__ bool has_rot(const DevLink& Lk) const { return Lk.link == ee_link; }
+    __device__ __forceinline__ void prefetch(int) const {}
     __device__ __forceinline__ bool operator()(const DevLink& Lk, int, const Pose&, float* Rb, float* tb) const {
         const int col = IDENT ? Lk.link : sel.col[Lk.link];
         if (col < 0) return false;
@@ -277,8 +318,8 @@ struct AdjFromTile {      // tbar from an LDS tile [64][rs] (link-major, 3 float
 // MODE 0: adjoint gH [N,n_sel,4,4]; MODE 1: adjoint gpos [N,n_sel,3].  -> gq [N,D]
 template <int MODE>
 __global__ void __launch_bounds__(TRK_WAVE)
-k_fk_backward(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, SelMap sel, int n_sel,
-              const float* __restrict__ q, const float* __restrict__ gin, int64_t n, float* __restrict__ gq) {
+k_fk_backward(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, SelMap sel, SelMap selp,
+              int n_sel, const float* __restrict__ q, const float* __restrict__ gin, int64_t n, float* __restrict__ gq) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int D = hdr.n_dofs;
@@ -345,8 +386,11 @@ k_fk_points(DevModelHdr hdr, const DevLink* __restrict__ links, DevPointSet ps, 
     for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
     __syncthreads();
     Pose cur, par;
+    DevLink nxt = load_link(links, 0);
     for (int p = 0; p < L; ++p) {
-        walk_step<false>(hdr, links[p], p, qs, D, lane, slots, cur, par);
+        const DevLink Lk = nxt;
+        nxt = load_link(links, p + 1 < L ? p + 1 : p);
+        walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
         points_of_link(ps, p, cur, tile + lane * rs);
     }
     __syncthreads();
@@ -356,6 +400,7 @@ k_fk_points(DevModelHdr hdr, const DevLink* __restrict__ links, DevPointSet ps, 
 struct AdjFromPoints {    // point adjoints from an LDS tile [64][rs] (+ optional EE pose adjoint on one link)
     const float* gtile; int rs; int lane; DevPointSet ps; int ee_link; const float* eeRb; const float* eetb;
     __device__ __forceinline__ bool has_rot(const DevLink&) const { return true; }
+    __device__ __forceinline__ void prefetch(int) const {}
     __device__ __forceinline__ bool operator()(const DevLink& Lk, int p, const Pose&, float* Rb, float* tb) const {
         const int b = cptr(ps.begin)[p], e = cptr(ps.begin)[p + 1];
         const bool ee = Lk.link == ee_link;
@@ -415,6 +460,7 @@ k_fk_points_backward(DevModelHdr hdr, const DevLink* __restrict__ links, const i
 struct AdjIK {            // adjoint of the SE(3) distance on one link, evaluated when the walk reaches it
     int link; const float* Ht; float err;
     __device__ __forceinline__ bool has_rot(const DevLink&) const { return true; }
+    __device__ __forceinline__ void prefetch(int) const {}
     __device__ __forceinline__ bool operator()(const DevLink& Lk, int, const Pose& cur, float* Rb, float* tb) {
         if (Lk.link != link) return false;
         err = ee_cost_eval(cur.r, cur.t, Ht, 1.0f, 1.0f, 0, Rb, tb);
@@ -698,8 +744,10 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     float eeR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, eet[3] = {0, 0, 0};
     {
         Pose cur, par;
+        DevLink nxt = load_link(links, 0);
         for (int p = 0; p < L; ++p) {
-            const DevLink& Lk = links[p];
+            const DevLink Lk = nxt;
+            nxt = load_link(links, p + 1 < L ? p + 1 : p);
             walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
             if (POINTS) points_of_link(ps, p, cur, tile + lane * rs);
             else {
@@ -819,8 +867,10 @@ k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, JacCols cols, 
     Pose cur, par;
     float vl[3] = {0, 0, 0}, va[3] = {0, 0, 0};
     float eR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, et[3] = {0, 0, 0}, evl[3] = {0, 0, 0}, eva[3] = {0, 0, 0};
+    DevLink nxt = load_link(links, 0);
     for (int p = 0; p < cols.p_end; ++p) {
-        const DevLink& Lk = links[p];
+        const DevLink Lk = nxt;
+        nxt = load_link(links, p + 1 < cols.p_end ? p + 1 : p);
         walk_step<true>(hdr, Lk, p, qs, D, lane, slots, cur, par);
         if (qd) {
             float pvl[3], pva[3];
@@ -969,8 +1019,10 @@ k_fk_analytic_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, const
     for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
     __syncthreads();
     Pose cur, par;
+    DevLink nxt = load_link(links, 0);
     for (int p = 0; p < L; ++p) {
-        const DevLink& Lk = links[p];
+        const DevLink Lk = nxt;
+        nxt = load_link(links, p + 1 < L ? p + 1 : p);
         const float pass = walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
         if (Lk.dof >= 0) {
             float* j = jrec + Lk.dof * TRK_WAVE + lane;
@@ -1233,17 +1285,17 @@ static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + b
 void trk_launch_fk_forward(int mode, const DevModelHdr& hdr, const DevLink* links, const SelMap& sel, int n_sel,
                            const float* q, int64_t n, float* out, hipStream_t st) {
     size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs + (size_t)hdr.n_slots * 12 * TRK_WAVE +
-                                  (mode == 1 ? (size_t)TRK_WAVE * ((n_sel * 3) | 1) : 0));
+                                  (mode == 1 ? (size_t)TRK_WAVE * ((n_sel * 3) | 1) : (size_t)TRK_WAVE * 20));
     if (mode == 0) hipLaunchKernelGGL(k_fk_forward<0>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, sel, n_sel, q, n, out);
     else hipLaunchKernelGGL(k_fk_forward<1>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, sel, n_sel, q, n, out);
 }
 
 void trk_launch_fk_backward(int mode, const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const SelMap& sel,
-                            int n_sel, const float* q, const float* gin, int64_t n, float* gq, hipStream_t st) {
+                            const SelMap& selp, int n_sel, const float* q, const float* gin, int64_t n, float* gq, hipStream_t st) {
     size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
                                   (mode == 1 ? (size_t)TRK_WAVE * ((n_sel * 3) | 1) : 0));
-    if (mode == 0) hipLaunchKernelGGL(k_fk_backward<0>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, sel, n_sel, q, gin, n, gq);
-    else hipLaunchKernelGGL(k_fk_backward<1>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, sel, n_sel, q, gin, n, gq);
+    if (mode == 0) hipLaunchKernelGGL(k_fk_backward<0>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, sel, selp, n_sel, q, gin, n, gq);
+    else hipLaunchKernelGGL(k_fk_backward<1>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, sel, selp, n_sel, q, gin, n, gq);
 }
 
 void trk_launch_ik_step(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, int link, const float* H_target,

@@ -4,8 +4,9 @@
 
 void trk_launch_fk_forward(int mode, const DevModelHdr& hdr, const DevLink* links, const SelMap& sel, int n_sel,
                            const float* q, int64_t n, float* out, hipStream_t st);
+// selp = sel re-indexed by walk position (selp.col[p] = sel.col[link at position p])
 void trk_launch_fk_backward(int mode, const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const SelMap& sel,
-                            int n_sel, const float* q, const float* gin, int64_t n, float* gq, hipStream_t st);
+                            const SelMap& selp, int n_sel, const float* q, const float* gin, int64_t n, float* gq, hipStream_t st);
 void trk_launch_ik_step(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, int link, const float* H_target,
                         int per_sample, const float* lower, const float* upper, float w_jl, float se3_eps, float lr,
                         float bc1, float rsqrt_bc2, int64_t n, float* q, float* mom, float* vel, float* loss,
