@@ -549,7 +549,13 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
       s z_j . ((Pt1 - Pt0) - t_j x (Pf1 - Pf0)) with the running wrench sampled at the range's start and end;
       a force that lands on an EARLIER link (the far side of a self-collision pair) is applied directly to that link's
       ancestor joints, s z_j . ((p - t_j) x f), instead of entering the running sums;
-    * positions leave through one 36-float chunk buffer per wavefront (spec_flush_chunk)."""
+    * positions leave through one 36-float chunk buffer per wavefront (spec_flush_chunk).
+
+    The kernel needs the full 256-VGPR budget (2 wavefronts per SIMD).  A two-sweep variant for serial chains (root->tip
+    for the positions, then tip->root stepping the pose back through the inverse joint transforms with a single suffix
+    wrench; 168 VGPRs, 3 wavefronts per SIMD) was built and measured: 79 vs 76 us for the 45-sphere Panda -- the kernel
+    is bound by its ~6900 VALU instructions per wavefront (SQ_INSTS_VALU), so the recomputation ate what the occupancy
+    gave, and it was dropped."""
     L, D, P = kin.n_links, kin.n_dofs, len(pt.point_link)
     W = 3 * P
     V = 4 if W % 4 == 0 else (2 if W % 2 == 0 else 1)
@@ -776,6 +782,12 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         out.extend(E.lines)
         out.append("")
 
+    out.extend(_points_entry_lines(kin, pt, ident))
+    return "\n".join(out) + "\n"
+
+
+def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str) -> List[str]:
+    out: List[str] = []
     obj = ", ".join(str(c) for c in pt.obj_cols) or "0"
     pairs = ", ".join(f"{a}, {b}" for a, b in pt.self_pairs) or "0"
     out.append(f"static const int32_t kObjCols[] = {{{obj}}};")
@@ -791,12 +803,12 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
     out.append("        else hipLaunchKernelGGL(k_rollout_bg<false>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    }")
     out.append("}")
-    out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, {len(pt.obj_cols)}, kObjCols, "
-               f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, P, "
+    out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
+               f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {len(pt.point_link)}, "
                f"0x{points_hash(pt.point_link, pt.point_offset):016x}ull, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
-    return "\n".join(out) + "\n"
+    return out
 
 
 def _panda_pairs(idx) -> List[Tuple[int, int]]:

@@ -570,6 +570,7 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     h.ee_link = d->ee_link; h.ee_square = d->ee_square ? 1 : 0; h.ee_w_pos = d->ee_w_pos; h.ee_w_rot = d->ee_w_rot;
     std::memcpy(h.ws_min, d->ws_min, sizeof(float) * 3);
     std::memcpy(h.ws_max, d->ws_max, sizeof(float) * 3);
+    for (int k = 0; k < 3; ++k) { h.ws_c[k] = 0.5f * (d->ws_min[k] + d->ws_max[k]); h.ws_h[k] = 0.5f * (d->ws_max[k] - d->ws_min[k]); }
     std::memcpy(h.ee_target, d->ee_target, sizeof(float) * 16);
     h.obj_link_idx = reinterpret_cast<const int32_t*>(base + o_idx);
     h.obj_link_margin = reinterpret_cast<const float*>(base + o_mg);

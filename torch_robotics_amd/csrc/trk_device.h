@@ -73,6 +73,7 @@ struct DevCostHdr {
     int32_t ee_link, ee_square;
     float ee_w_pos, ee_w_rot;
     float ws_min[3], ws_max[3];
+    float ws_c[3], ws_h[3];        // box centre and half widths (host, fp32): distance to the nearest plane of axis k = h_k - |p_k - c_k|
     float ee_target[16];
     const int32_t* obj_link_idx;   // device
     const float* obj_link_margin;  // device
@@ -513,14 +514,17 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
 // adds scale * d/dp to (ax, ay, az)
 __device__ __forceinline__ float ws_cost_point(const DevCostHdr& C, float mg, float x, float y, float z, float scale,
                                                float& ax, float& ay, float& az) {
-    const float sd[6] = {x - C.ws_min[0], y - C.ws_min[1], z - C.ws_min[2], C.ws_max[0] - x, C.ws_max[1] - y, C.ws_max[2] - z};
-    float best = mg - sd[0]; int bk = 0;
-#pragma unroll
-    for (int k = 1; k < 6; ++k) { const float v = mg - sd[k]; if (v > best) { best = v; bk = k; } }
-    const float sgn = bk < 3 ? -scale : scale;
-    const int axk = bk < 3 ? bk : bk - 3;
-    ax += axk == 0 ? sgn : 0.0f; ay += axk == 1 ? sgn : 0.0f; az += axk == 2 ? sgn : 0.0f;
-    return best;
+    // the six signed plane distances are {p_k - min_k, max_k - p_k}; per axis the smaller one is h_k - |p_k - c_k|,
+    // so max_planes (margin - sd) = margin - min_k (h_k - |d_k|) and the gradient is sign(d_a) on the arg-min axis
+    // (20 instructions instead of 35; differs from the plane form by fp32 rounding of c and h, ~1e-7)
+    const float dx = x - C.ws_c[0], dy = y - C.ws_c[1], dz = z - C.ws_c[2];
+    const float mx = C.ws_h[0] - __builtin_fabsf(dx), my = C.ws_h[1] - __builtin_fabsf(dy), mz = C.ws_h[2] - __builtin_fabsf(dz);
+    const float m = __builtin_fminf(__builtin_fminf(mx, my), mz);
+    const bool e0 = mx == m, e1 = (my == m) && !e0, e2 = !(e0 || e1);          // first arg-min axis wins
+    ax += e0 ? __builtin_copysignf(scale, dx) : 0.0f;
+    ay += e1 ? __builtin_copysignf(scale, dy) : 0.0f;
+    az += e2 ? __builtin_copysignf(scale, dz) : 0.0f;
+    return mg - m;
 }
 
 // EE SE(3) tracking, distance_fields.py:347-356 + geometrics/utils.py:148-154.
