@@ -42,11 +42,13 @@ def main():
     ap.add_argument("--config", default="c2", choices=["c2", "c3"])
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=64)
-    ap.add_argument("--reduce-every", type=int, default=16)
+    ap.add_argument("--reduce-every", type=int, default=64)
     ap.add_argument("--graph", type=int, default=0, help="capture this many steps per hipGraph replay (0 = eager launches)")
     ap.add_argument("--weights", default=None, help="experiment: w_self,w_obj,w_ws,w_ee override (reported in config)")
     ap.add_argument("--no-pos", action="store_true", help="experiment: do not write link positions")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' + --single-device lets the N>1 control flow run on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -60,11 +62,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.single_device else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     ta = dict(device=dev, dtype=torch.float32)
     robot = tra.RobotPanda(tensor_args=ta)

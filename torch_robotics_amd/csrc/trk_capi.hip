@@ -379,6 +379,17 @@ int trk_fk_points(const TrkModel* m, const TrkPointSet* ps, const float* q, int6
     if (n < 0 || (n > 0 && (!pos_out || (!q && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_points: bad q/out/n");
     if (trk_lds_fk_points(m->hdr, ps->dev.n_points, false) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_fk_points: point tile exceeds the 160 KiB LDS");
     if (n == 0) return TRK_OK;
+    if (ps->spec && m->spec_enabled && (reinterpret_cast<uintptr_t>(pos_out) & 15) == 0) {
+        // generated kernel with this point set baked in, all weights zero and no gradient output: FK + positions only
+        SpecArgs a;
+        std::memset(&a, 0, sizeof(a));
+        std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+        std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+        a.q = q; a.n = n; a.link_pos = pos_out;
+        ps->spec->launch(a, base_is_identity(m), (hipStream_t)stream);
+        TRK_HIP(hipGetLastError());
+        return TRK_OK;
+    }
     trk_launch_fk_points(m->hdr, m->d_links, ps->dev, q, n, pos_out, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
