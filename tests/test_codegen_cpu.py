@@ -60,3 +60,17 @@ def test_point_templates_match_the_robots():
         kin = KinModel.from_urdf(str(URDF_DIR / "panda_arm_no_gripper.urdf"))
         bad = codegen.PointsTemplate(point_link=np.array([3, 1], np.int32), point_offset=np.zeros((2, 3), np.float32), obj_cols=[0, 1])
         codegen.generate_points_rollout_source(kin, bad, "bad")
+
+
+def test_runtime_model_compiler_builds_and_loads_a_unit():
+    """jit.specialize: generate + hipcc (cross-compiles without a GPU) + dlopen; the unit registers itself with libtrk.so."""
+    from torch_robotics_amd import jit
+    from torch_robotics_amd.kinematics import URDF_DIR
+    from torch_robotics_amd.kinmodel import KinModel
+    kin = KinModel.from_urdf(str(URDF_DIR / "iiwa7.urdf"))
+    ident = jit.specialize(kin, obj_links=[3, 5, 7], self_pairs=[(7, 1), (6, 2)], ee_link=kin.n_links - 1)
+    so = jit.JIT_DIR / f"spec_{ident}.so"
+    assert so.exists() and so.stat().st_size > 10000
+    assert jit.specialize(kin, obj_links=[3, 5, 7], self_pairs=[(7, 1), (6, 2)], ee_link=kin.n_links - 1) == ident   # idempotent
+    other = jit.unit_ident(kin, __import__("torch_robotics_amd").codegen.CollisionTemplate(obj_links=[3, 5], ee_link=-1))
+    assert other != ident

@@ -668,3 +668,50 @@ def test_generated_fk_positions_and_backward(ops, oracle_lib, ident):
                 res[use_spec] = (pos, gq)
             h.enable_specialized(True)
             np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=4e-6)
+
+
+def test_runtime_compiled_kernel_for_another_robot(ops, oracle_lib):
+    """A robot without an ahead-of-time unit (KUKA iiwa7): table-driven until jit.specialize() loads a generated kernel;
+    then the fused rollout, positions and positions-backward all take the generated path and agree with the fp64 oracle."""
+    from torch_robotics_amd import jit
+    from torch_robotics_amd.costmodel import CostModelSpec
+    from torch_robotics_amd.environments import EnvSpheres3D
+    m = model("iiwa7")
+    env = EnvSpheres3D(tensor_args=dict(device=DEV, dtype=torch.float32))
+    spec = CostModelSpec(n_links_in=m.n_links)
+    spec.obj_link_idx = np.array([3, 5, 7], np.int32)
+    spec.obj_link_margin = np.array([0.1, 0.09, 0.08], np.float32)
+    spec.objects = [o.as_object() for o in env.obj_fixed_list]
+    spec.ws_min, spec.ws_max = np.float32([-1, -1, -1]), np.float32([1, 1, 1])
+    spec.self_link_idx = np.array([1, 2, 6, 7], np.int32)
+    spec.self_pairs = np.array([[3, 0], [2, 1]], np.int32)        # (7,1), (6,2)
+    spec.self_margin = np.array([0.05, 0.05], np.float32)
+    spec.ee_link = m.n_links - 1
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.2, 0.5); spec.ee_target = T
+    spec.validate()
+    h, cm, o = ops.ModelHandle(m), ops.CostHandle(spec, DEV), oracle_lib.Oracle(m, spec)
+    rng = np.random.default_rng(31)
+    q = rng.uniform(-2.5, 2.5, size=(5, 64, m.n_dofs)).astype(np.float32)
+    rp, rc, rg = o.rollout(q.reshape(-1, m.n_dofs).astype(np.float64), (1, 1, 1, 1), "f64")
+    pos_g, cost_g, gq_g = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), dev(q))            # table-driven (or an earlier unit)
+    ident = jit.specialize_for_cost_spec(m, spec)
+    assert ident is not None and h.specialized
+    pos_s, cost_s, gq_s = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), dev(q))
+    for pos, cost, gq in ((pos_g, cost_g, gq_g), (pos_s, cost_s, gq_s)):
+        assert np.abs(pos.cpu().numpy().reshape(rp.shape) - rp).max() < TOL_H
+        assert rel_err(cost.cpu().numpy().reshape(-1), rc) < TOL_C and rel_err(gq.cpu().numpy().reshape(rg.shape), rg) < TOL_G
+    # a different collision template of the same robot: no matching unit -> table-driven, still correct
+    spec2 = CostModelSpec(n_links_in=m.n_links)
+    spec2.obj_link_idx = np.array([2, 4], np.int32); spec2.obj_link_margin = np.array([0.1, 0.1], np.float32)
+    spec2.objects = spec.objects
+    cm2, o2 = ops.CostHandle(spec2, DEV), oracle_lib.Oracle(m, spec2)
+    _, c2, g2 = ops.rollout_cost_grad(h, cm2, (0, 1, 0, 0), dev(q))
+    _, rc2, rg2 = o2.rollout(q.reshape(-1, m.n_dofs).astype(np.float64), (0, 1, 0, 0), "f64")
+    assert rel_err(c2.cpu().numpy().reshape(-1), rc2) < TOL_C and rel_err(g2.cpu().numpy().reshape(rg2.shape), rg2) < TOL_G
+    # FK positions / backward of all links through the generated unit
+    w = rng.standard_normal((320, m.n_links, 3)).astype(np.float32)
+    pos = ops.fk_positions(h, dev(q.reshape(-1, m.n_dofs))).cpu().numpy()
+    assert np.abs(pos - rp).max() < TOL_H
+    gH = np.zeros((320, m.n_links, 4, 4)); gH[..., :3, 3] = w
+    gq = ops.fk_positions_backward(h, dev(q.reshape(-1, m.n_dofs)), dev(w)).cpu().numpy()
+    assert rel_err(gq, o.fk_backward(q.reshape(-1, m.n_dofs).astype(np.float64), gH, "f64")) < TOL_G

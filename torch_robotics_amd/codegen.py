@@ -772,6 +772,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                     finish_joint(j)
         assert chunk_start == W
         E.raw("    if (!A.gq) return;                       // positions only (trk_fk_points): weights are zero, nothing else to write")
+        E.raw("    if (!A.gq) return;                       // positions only (trk_fk_points): weights are zero, nothing else to write")
         E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
         E.raw("    if (A.cost_sum) {")
         E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")

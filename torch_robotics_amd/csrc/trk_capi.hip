@@ -79,10 +79,18 @@ struct TrkModel {
     int32_t* d_dofs = nullptr;             // [D] {pos, subtree end, joint type, pad}
     std::vector<int32_t> pos_of_link;      // link (file index) -> pre-order position
     bool unsupported = false;
-    const SpecEntry* spec = nullptr;     // model-specialised fused kernel, if one was built for these tables
+    mutable const SpecEntry* spec = nullptr;   // any generated unit for these tables (FK-only entry points use it)
     bool spec_enabled = true;
     uint64_t hash = 0;                   // model_hash of the tables
 };
+
+// Generated units may be loaded AFTER the model was created (torch_robotics_amd/jit.py dlopens them), so look again
+// while there is none.  Several units can exist for one model (different collision templates).
+static const SpecEntry* model_spec(const TrkModel* m) {
+    if (!m->spec) m->spec = trk_spec_find(m->hash, m->hdr.n_links, m->hdr.n_dofs);
+    return m->spec;
+}
+static const SpecEntry* model_spec_for(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w);
 
 struct TrkPointSet {
     DevPointSet dev;
@@ -97,6 +105,25 @@ struct TrkCostModel {
     std::vector<int32_t> obj_link_idx;   // host copies, to match a specialised kernel's baked link sets
     std::vector<int32_t> self_pairs;     // mapped to link indices
 };
+
+static bool spec_matches(const SpecEntry* e, const TrkCostModel* cm, const TrkRolloutWeights* w) {
+    bool ok = true;
+    if (w->w_obj != 0.0f || w->w_ws != 0.0f)
+        ok = ok && (int)cm->obj_link_idx.size() == e->n_obj_links &&
+             std::equal(cm->obj_link_idx.begin(), cm->obj_link_idx.end(), e->obj_link_idx);
+    if (w->w_self != 0.0f)
+        ok = ok && (int)cm->self_pairs.size() == 2 * e->n_self_pairs &&
+             std::equal(cm->self_pairs.begin(), cm->self_pairs.end(), e->self_pairs);
+    if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link;
+    return ok;
+}
+static const SpecEntry* model_spec_for(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w) {
+    for (const SpecEntry* e : spec_registry())
+        if (e->n_points == 0 && e->model_hash == m->hash && e->n_links == m->hdr.n_links && e->n_dofs == m->hdr.n_dofs &&
+            spec_matches(e, cm, w))
+            return e;
+    return nullptr;
+}
 
 extern "C" {
 
@@ -207,7 +234,7 @@ int trk_model_set_base_pose(TrkModel* m, const float* R9, const float* t3) {
 
 int trk_model_n_links(const TrkModel* m) { return m ? m->hdr.n_links : TRK_ERR_INVALID_ARG; }
 int trk_model_n_dofs(const TrkModel* m) { return m ? m->hdr.n_dofs : TRK_ERR_INVALID_ARG; }
-int trk_model_is_specialized(const TrkModel* m) { return (m && m->spec && m->spec_enabled) ? 1 : 0; }
+int trk_model_is_specialized(const TrkModel* m) { return (m && model_spec(m) && m->spec_enabled) ? 1 : 0; }
 int trk_model_enable_specialized(TrkModel* m, int enable) {
     if (!m) return fail(TRK_ERR_INVALID_ARG, "trk_model_enable_specialized: null model");
     m->spec_enabled = enable != 0;
@@ -233,13 +260,34 @@ static int make_sel(const TrkModel* m, const int32_t* link_sel, int32_t n_sel, S
     return TRK_OK;
 }
 
+// SpecArgs for launches that evaluate no objective (all weights zero): every table pointer of the cost header points at a
+// small zero-filled device buffer instead of NULL, so a scalar load the compiler moved out of a weight-guarded branch
+// reads zeros rather than faulting.
+static void* g_zero_blob = nullptr;
+static int blank_spec_args(SpecArgs& a) {
+    if (!g_zero_blob) {
+        hipError_t e = hipMalloc(&g_zero_blob, 4096);
+        if (e == hipSuccess) e = hipMemset(g_zero_blob, 0, 4096);
+        if (e != hipSuccess) { g_zero_blob = nullptr; return hip_fail(e, "zero table allocation"); }
+    }
+    std::memset(&a, 0, sizeof(a));
+    DevCostHdr& h = a.C;
+    h.ee_link = -1;
+    h.obj_link_idx = static_cast<const int32_t*>(g_zero_blob); h.obj_link_margin = static_cast<const float*>(g_zero_blob);
+    h.objects = static_cast<const DevObj*>(g_zero_blob); h.prims = static_cast<const DevPrim*>(g_zero_blob);
+    h.self_pairs = static_cast<const int32_t*>(g_zero_blob); h.self_margin = static_cast<const float*>(g_zero_blob);
+    h.spheres = static_cast<const float4*>(g_zero_blob); h.spheres_sel = static_cast<const float4*>(g_zero_blob);
+    h.box_objects = static_cast<const int32_t*>(g_zero_blob);
+    return TRK_OK;
+}
+
 static int base_is_identity(const TrkModel* m) {
     const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z[3] = {0, 0, 0};
     return std::memcmp(m->hdr.base_R, I, sizeof(I)) == 0 && std::memcmp(m->hdr.base_t, Z, sizeof(Z)) == 0;
 }
 // the generated kernels produce / consume all links in file order
 static bool spec_all_links(const TrkModel* m, const SelMap& sel, int ns) {
-    if (!m->spec || !m->spec_enabled || ns != m->hdr.n_links) return false;
+    if (!model_spec(m) || !m->spec_enabled || ns != m->hdr.n_links) return false;
     for (int k = 0; k < ns; ++k) if (sel.col[k] != k) return false;
     return true;
 }
@@ -262,7 +310,8 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
     if (mode == 1 && spec_all_links(m, sel, ns)) {
         // generated kernel, positions-only exit (gq == nullptr): same FK code as the fused rollout
         SpecArgs a;
-        std::memset(&a, 0, sizeof(a));
+        rc = blank_spec_args(a);
+        if (rc) return rc;
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = out;
@@ -293,7 +342,8 @@ static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin,
     if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
     if (mode == 1 && spec_all_links(m, sel, ns) && m->spec->launch_posbwd) {
         SpecArgs a;
-        std::memset(&a, 0, sizeof(a));
+        rc = blank_spec_args(a);
+        if (rc) return rc;
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = const_cast<float*>(gin); a.gq = gq;
@@ -382,7 +432,8 @@ int trk_fk_points(const TrkModel* m, const TrkPointSet* ps, const float* q, int6
     if (ps->spec && m->spec_enabled && (reinterpret_cast<uintptr_t>(pos_out) & 15) == 0) {
         // generated kernel with this point set baked in, all weights zero and no gradient output: FK + positions only
         SpecArgs a;
-        std::memset(&a, 0, sizeof(a));
+        rc = blank_spec_args(a);
+        if (rc) return rc;
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = pos_out;
@@ -664,27 +715,16 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
     const int64_t n = batch * horizon;
     if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null q/cost/gq");
     if (n == 0) return TRK_OK;
-    if (m->spec && m->spec_enabled) {
-        // the generated kernel has the robot's collision-link sets baked in: use it only when the cost model's match
-        const SpecEntry* e = m->spec;
-        bool ok = true;
-        if (w->w_obj != 0.0f || w->w_ws != 0.0f)
-            ok = ok && (int)cm->obj_link_idx.size() == e->n_obj_links &&
-                 std::equal(cm->obj_link_idx.begin(), cm->obj_link_idx.end(), e->obj_link_idx);
-        if (w->w_self != 0.0f)
-            ok = ok && (int)cm->self_pairs.size() == 2 * e->n_self_pairs &&
-                 std::equal(cm->self_pairs.begin(), cm->self_pairs.end(), e->self_pairs);
-        if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link;
-        if (ok) {
+    if (m->spec_enabled) {
+        // a generated kernel has the robot's collision-link sets baked in: use the unit whose sets equal the cost model's
+        if (const SpecEntry* e = model_spec_for(m, cm, w)) {
             SpecArgs a;
             a.C = cm->hdr; a.w = *w;
             std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
             a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
             a.stamps = g_stamps; a.io_f16 = io_f16;
-            const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z[3] = {0, 0, 0};
-            const int base_id = std::memcmp(a.base_R, I, sizeof(I)) == 0 && std::memcmp(a.base_t, Z, sizeof(Z)) == 0;
-            e->launch(a, base_id, (hipStream_t)stream);
+            e->launch(a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }

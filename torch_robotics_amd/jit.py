@@ -1,0 +1,91 @@
+"""Run-time model compiler: a generated fused kernel for ANY robot + collision template.
+
+`csrc/generated/` holds the units built ahead of time for the robots of the benchmark configs.  For any other
+`KinModel` (or another collision-link template of the same robot) `specialize()` runs the same generator
+(`codegen.generate_rollout_source`), compiles the unit with hipcc for gfx950 into `csrc/jit/spec_<ident>.so`, and loads it;
+the unit's static initialiser registers it with libtrk.so (`trk_spec_register`), and `trk_rollout_cost_grad` /
+`trk_fk_positions(_backward)` pick it up by the model hash.  Nothing changes for the caller except the speed
+(table-driven -> generated: ~10x on the fused rollout).  Compilation takes tens of seconds per robot and is cached on disk
+by (model hash, template hash, generator source hash).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import subprocess
+from pathlib import Path
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, codegen
+from .kinmodel import KinModel
+
+JIT_DIR = Path(__file__).resolve().parent / "csrc" / "jit"
+_CSRC = JIT_DIR.parent
+_loaded: Dict[str, C.CDLL] = {}
+
+
+def template_hash(tmpl: codegen.CollisionTemplate) -> str:
+    h = hashlib.sha1()
+    h.update(np.asarray(tmpl.obj_links, np.int32).tobytes())
+    h.update(np.asarray(tmpl.self_pairs, np.int32).reshape(-1).tobytes())
+    h.update(np.asarray([tmpl.ee_link], np.int32).tobytes())
+    return h.hexdigest()[:8]
+
+
+def _generator_stamp() -> str:
+    h = hashlib.sha1()
+    for f in (Path(codegen.__file__), _CSRC / "trk_spec_common.h", _CSRC / "trk_device.h"):
+        h.update(f.read_bytes())
+    return h.hexdigest()[:8]
+
+
+def unit_ident(kin: KinModel, tmpl: codegen.CollisionTemplate) -> str:
+    return f"jit_{codegen.model_hash(kin):016x}_{template_hash(tmpl)}"
+
+
+def build_unit(kin: KinModel, tmpl: codegen.CollisionTemplate, verbose: bool = False) -> Path:
+    """Generate + compile (no GPU needed: hipcc cross-compiles); returns the path of the shared object."""
+    ident = unit_ident(kin, tmpl)
+    JIT_DIR.mkdir(parents=True, exist_ok=True)
+    src, so, stamp = JIT_DIR / f"spec_{ident}.hip", JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
+    want = _generator_stamp()
+    if so.exists() and stamp.exists() and stamp.read_text() == want:
+        return so
+    src.write_text(codegen.generate_rollout_source(kin, tmpl, ident))
+    if not _lib.LIB_PATH.exists():
+        raise _lib.TrkError(f"{_lib.LIB_PATH} not found: build libtrk.so first")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+           "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
+           "-Xarch_device", "-mno-amdgpu-ieee", "-shared", str(src), "-o", str(so), f"-L{_CSRC}", "-ltrk",
+           "-Wl,-rpath,$ORIGIN/.."]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise _lib.TrkError(f"compiling {src.name} failed:\n{res.stdout}\n{res.stderr}")
+    if verbose:
+        print(res.stderr)
+    stamp.write_text(want)
+    return so
+
+
+def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tuple[int, int]] = (), ee_link: int = -1,
+               verbose: bool = False) -> str:
+    """Make sure a generated fused kernel for (kin, collision template) is registered with libtrk.so.  Idempotent.
+    Returns the unit's identifier.  Robots that already have an ahead-of-time unit with the same template need nothing."""
+    tmpl = codegen.CollisionTemplate(obj_links=[int(i) for i in obj_links],
+                                     self_pairs=[(int(a), int(b)) for a, b in self_pairs], ee_link=int(ee_link))
+    ident = unit_ident(kin, tmpl)
+    if ident not in _loaded:
+        _lib.lib()                                  # libtrk.so first: the unit's initialiser calls into it
+        _loaded[ident] = C.CDLL(str(build_unit(kin, tmpl, verbose)))
+    return ident
+
+
+def specialize_for_cost_spec(kin: KinModel, spec, verbose: bool = False) -> Optional[str]:
+    """Template from a CostModelSpec whose columns are the links (no attached points)."""
+    if spec.n_links_in != kin.n_links:
+        return None
+    sl = np.asarray(spec.self_link_idx, np.int32)
+    pairs = [(int(sl[a]), int(sl[b])) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2)]
+    return specialize(kin, [int(i) for i in spec.obj_link_idx], pairs, int(spec.ee_link), verbose)

@@ -97,6 +97,17 @@ class PlanningTask(Task):
             self._fused = (self.robot.diff_panda._handle, ops.CostHandle(self.build_cost_spec(), device), str(device))
         return self._fused[0], self._fused[1]
 
+    def specialize(self, verbose: bool = False):
+        """Compile (once, cached on disk) and load a generated fused kernel for THIS robot and collision model
+        (torch_robotics_amd/jit.py).  The robots of the benchmark configs ship with one; any other URDF gets the
+        table-driven kernels until this is called.  Returns the unit identifier, or None when the collision columns are
+        attached points (those have their own ahead-of-time units)."""
+        from . import jit
+        if getattr(self.robot, "has_extra_points", False):
+            return None
+        ident = jit.specialize_for_cost_spec(self.robot.diff_panda._kin, self.build_cost_spec(), verbose)
+        return ident
+
     def _points(self, device):
         """PointSetHandle when the collision columns are not simply the links (grasped object), else None."""
         if not getattr(self.robot, "has_extra_points", False):
