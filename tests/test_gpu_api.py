@@ -354,3 +354,11 @@ def test_spheres_and_grasped_box_together(oracle_lib):
         assert np.abs(pos.cpu().numpy() - rp).max() < TOL_H
         assert rel_err(cost.cpu().numpy(), rc) < TOL_C and rel_err(gq.cpu().numpy(), rg) < TOL_G
     model.enable_specialized(True)
+    # fk_map_collision and its reverse mode: generated (positions-only exit / k_posbwd) vs table-driven vs fp64 oracle
+    w = torch.randn(q0.shape[0], 71, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+    rgq = o.fk_points_backward(pl, po, q0.cpu().numpy().astype(np.float64), w.cpu().numpy().astype(np.float64), "f64")
+    for use_spec in (True, False):
+        model.enable_specialized(use_spec)
+        assert np.abs(ops.fk_points(ps, q0).cpu().numpy() - rp).max() < TOL_H
+        assert rel_err(ops.fk_points_backward(ps, q0, w).cpu().numpy(), rgq) < TOL_G
+    model.enable_specialized(True)

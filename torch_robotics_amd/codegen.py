@@ -784,6 +784,90 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         out.extend(E.lines)
         out.append("")
 
+    # ---- explicit reverse mode of the point positions (trk_fk_points_backward): FK again, the adjoint rows arrive through
+    # the chunk buffer in column order, each adjoint g at point p joins the running wrench (g, p x g); prefix-sum gradients
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_posbwd_bi" if base_identity else "k_posbwd_bg"
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_per_lane}];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_per_lane});")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    const float* gpos = static_cast<const float*>(A.link_pos);")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        E.raw(f"    const float* row = lds + lane * {LS};")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        _emit_angles(E, kin)
+        E.raw("    float pf0 = 0.0f, pf1 = 0.0f, pf2 = 0.0f, pt0 = 0.0f, pt1 = 0.0f, pt2 = 0.0f;")
+        PF = [S(1.0, f"pf{k}") for k in range(3)]
+        PT = [S(1.0, f"pt{k}") for k in range(3)]
+        snap_c = {}; gq_expr = {}
+
+        def functional(i: int) -> S:
+            jt = int(kin.joint_type[i])
+            if jt == JOINT_PRISMATIC:
+                par = int(kin.parent[i])
+                dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
+                return E.dot(dirw, PF)
+            ax = int(kin.rot_axis[i])
+            z = [R[i][r][ax] for r in range(3)]
+            cr = E.cross(t[i], PF)
+            return E.dot(z, [E.lincomb([(PT[k], ONE), (cr[k], S(-1.0))]) for k in range(3)])
+
+        chunk_start = -1
+        for p in range(L):
+            i = int(kin.order[p])
+            if p > 0:
+                _emit_fk_link(E, kin, i, R, t, passv, snap)
+                if int(kin.joint_type[i]) != JOINT_FIXED:
+                    snap_c[i] = S(1.0, E.tmp(E.expr(functional(i))))
+            for c in cols_of_link[i]:
+                f0 = 3 * c
+                # the three floats of a column may straddle two chunks: fetch component by component
+                comp = []
+                for k in range(3):
+                    f = f0 + k
+                    cs = (f // LS) * LS
+                    if cs != chunk_start:
+                        nf = min(LS, W - cs)
+                        E.raw(f"    spec_load_chunk<W, {nf}, {LS}, {V}>(gpos, base, {cs}, rows, lane, lds);")
+                        chunk_start = cs
+                    comp.append(E.tmp(f"row[{f - cs}]"))
+                if p == 0:
+                    continue                        # the root does not move with q
+                off = [S(snap_const(po[c][k], 0.0)) for k in range(3)]
+                pc = t[i] if all(o.is_zero for o in off) else \
+                    [E.named(E.lincomb([(R[i][r][k], off[k]) for k in range(3)], t[i][r])) for r in range(3)]
+                px, py, pz = (E.expr(v) for v in pc)
+                E.raw(f"    pf0 += {comp[0]}; pf1 += {comp[1]}; pf2 += {comp[2]};")
+                E.raw(f"    pt0 += {py} * {comp[2]} - {pz} * {comp[1]}; pt1 += {pz} * {comp[0]} - {px} * {comp[2]}; "
+                      f"pt2 += {px} * {comp[1]} - {py} * {comp[0]};")
+            for j in [j for j in range(1, L) if int(kin.joint_type[j]) != JOINT_FIXED]:
+                if int(kin.subtree_end[pos_of[j]]) == p + 1:
+                    d = int(kin.dof_idx[j]); jt = int(kin.joint_type[j])
+                    sg = 1.0 if jt == JOINT_PRISMATIC else float(kin.rot_sign[j])
+                    if sg == 0.0:
+                        gq_expr[d] = ZERO
+                    else:
+                        g = E.lincomb([(functional(j), ONE), (snap_c[j], S(-1.0))])
+                        gq_expr[d] = masked(E, j, d, S(g.c * sg, g.n))
+        E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
+        E.raw("    spec_store_gq<D>(static_cast<float*>(A.gq), base, rows, lane, lds, gv);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
     out.extend(_points_entry_lines(kin, pt, ident))
     return "\n".join(out) + "\n"
 
@@ -805,9 +889,14 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str) -> List[s
     out.append("        else hipLaunchKernelGGL(k_rollout_bg<false>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    }")
     out.append("}")
+    out.append("static void launch_posbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+    out.append("    if (base_identity) hipLaunchKernelGGL(k_posbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    else hipLaunchKernelGGL(k_posbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("}")
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {len(pt.point_link)}, "
-               f"0x{points_hash(pt.point_link, pt.point_offset):016x}ull, nullptr}};")
+               f"0x{points_hash(pt.point_link, pt.point_offset):016x}ull, launch_posbwd}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out

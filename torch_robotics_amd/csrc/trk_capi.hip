@@ -454,6 +454,17 @@ int trk_fk_points_backward(const TrkModel* m, const TrkPointSet* ps, const float
     if (n < 0 || (n > 0 && (!gpos || ((!q || !gq) && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_points_backward: bad q/g/n");
     if (trk_lds_fk_points(m->hdr, ps->dev.n_points, true) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_fk_points_backward: point tile exceeds the 160 KiB LDS");
     if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    if (ps->spec && ps->spec->launch_posbwd && m->spec_enabled && (reinterpret_cast<uintptr_t>(gpos) & 15) == 0) {
+        SpecArgs a;
+        rc = blank_spec_args(a);
+        if (rc) return rc;
+        std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+        std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+        a.q = q; a.n = n; a.link_pos = const_cast<float*>(gpos); a.gq = gq;
+        ps->spec->launch_posbwd(a, base_is_identity(m), (hipStream_t)stream);
+        TRK_HIP(hipGetLastError());
+        return TRK_OK;
+    }
     trk_launch_fk_points_backward(m->hdr, m->d_links, m->d_fin, ps->dev, q, gpos, n, gq, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;

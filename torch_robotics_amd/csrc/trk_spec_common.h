@@ -239,6 +239,30 @@ __device__ __forceinline__ void spec_flush_chunk(float* __restrict__ out, int64_
     spec_wave_sync();           // the chunk buffer may be overwritten from here on
 }
 
+// mirror of spec_flush_chunk: floats [c0, c0 + NF) of the wave's rows -> lds[smp * LS + ...]; each lane then reads its own row
+template <int W, int NF, int LS, int V>
+__device__ __forceinline__ void spec_load_chunk(const float* __restrict__ in, int64_t base, int c0, int rows, int lane,
+                                                float* lds) {
+    constexpr int NVEC = NF / V;
+    static_assert(NF % V == 0 && W % V == 0 && LS % V == 0, "chunk geometry must keep the vectors aligned");
+    spec_wave_sync();           // everybody has consumed the previous chunk
+    const int total = rows * NVEC;
+    const float* src0 = in + base * W + c0;
+#pragma unroll
+    for (int j = 0; j < NVEC; ++j) {
+        const int e = lane + TRK_WAVE * j;
+        if (e < total) {
+            const int smp = e / NVEC, v = e - smp * NVEC;
+            const float* src = src0 + (int64_t)smp * W + v * V;
+            float* dst = lds + smp * LS + v * V;
+            if (V == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+            else if (V == 2) *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(src);
+            else dst[0] = src[0];
+        }
+    }
+    spec_wave_sync();
+}
+
 // profiling hook: lane 0 of a wave records the shader clock at phase `k` (no-op when A.stamps == nullptr)
 __device__ __forceinline__ void spec_stamp(unsigned long long* stamps, int64_t wblock, int k, int lane) {
     if (stamps) {
