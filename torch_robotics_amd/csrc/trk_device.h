@@ -146,6 +146,23 @@ __device__ __forceinline__ float trk_sqrt(float x) { return __builtin_amdgcn_sqr
 __device__ __forceinline__ float trk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
 __device__ __forceinline__ float trk_rsq(float x) { return __builtin_amdgcn_rsqf(x); }     // v_rsq_f32, 1 ulp
 
+// Sum over the wavefront, broadcast to every lane.  DPP adds (row_shr 1/2/4/8, row_bcast 15/31) run at VALU speed; the
+// __shfl_xor butterfly is six dependent ds_bpermute round trips (~100 cycles each) at the very end of the kernel, where no
+// other work is left to hide them.  Deterministic (fixed association), result taken from lane 63.
+__device__ __forceinline__ float trk_wave_sum(float v) {
+    int x = __float_as_int(v);
+#define TRK_DPP_ADD(ctrl, rmask)                                                                          \
+    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, true)))
+    TRK_DPP_ADD(0x111, 0xf);      // row_shr:1
+    TRK_DPP_ADD(0x112, 0xf);      // row_shr:2
+    TRK_DPP_ADD(0x114, 0xf);      // row_shr:4
+    TRK_DPP_ADD(0x118, 0xf);      // row_shr:8  -> lane 15 of each row holds the row's sum
+    TRK_DPP_ADD(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    TRK_DPP_ADD(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+#undef TRK_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+
 // sin and cos of x together.  Cody-Waite reduction by pi (two fmas): x = k*pi + r, r in [-pi/2, pi/2], so
 // sin x = (-1)^k sin r and cos x = (-1)^k cos r -- a sign flip (one shift, two xors), no sin/cos swap.
 // sin r = r + r^3 P(r^2), cos r = 1 - r^2/2 + r^4 Q(r^2), P and Q cubic near-minimax fits (Chebyshev nodes).

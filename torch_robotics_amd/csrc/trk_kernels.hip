@@ -113,11 +113,7 @@ __device__ __forceinline__ void slot_load(const float* slots, int slot, int lane
     for (int k = 0; k < 3; ++k) p.t[k] = s[(9 + k) * TRK_WAVE];
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, TRK_WAVE);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return trk_wave_sum(v); }
 
 // One step of the forward walk: pose of the link at pre-order position p.
 template <bool STATEFUL>

@@ -271,22 +271,7 @@ __device__ __forceinline__ void spec_stamp(unsigned long long* stamps, int64_t w
     }
 }
 
-// Sum over the wavefront, broadcast to every lane.  DPP adds (row_shr 1/2/4/8, row_bcast 15/31) run at VALU speed; the
-// __shfl_xor butterfly is six dependent ds_bpermute round trips (~100 cycles each) at the very end of the kernel, where no
-// other work is left to hide them.  Deterministic (fixed association), result taken from lane 63.
-__device__ __forceinline__ float spec_wave_sum(float v) {
-    int x = __float_as_int(v);
-#define TRK_DPP_ADD(ctrl, rmask)                                                                          \
-    x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, true)))
-    TRK_DPP_ADD(0x111, 0xf);      // row_shr:1
-    TRK_DPP_ADD(0x112, 0xf);      // row_shr:2
-    TRK_DPP_ADD(0x114, 0xf);      // row_shr:4
-    TRK_DPP_ADD(0x118, 0xf);      // row_shr:8  -> lane 15 of each row holds the row's sum
-    TRK_DPP_ADD(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
-    TRK_DPP_ADD(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-#undef TRK_DPP_ADD
-    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
-}
+__device__ __forceinline__ float spec_wave_sum(float v) { return trk_wave_sum(v); }
 
 // ---------------------------------------------------------------------------------------------------------
 // collision objectives on NL link points held in registers.  Adds w * cost to `cost` and
