@@ -539,7 +539,8 @@ CHUNK_FLOATS = 36          # 12 columns: 144 B per sample and chunk, a multiple 
 OBJ_GROUP = 6              # points evaluated against the scene together (register arrays of this size)
 
 
-def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str, snap: float = SNAP) -> str:
+def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str, snap: float = SNAP,
+                                   link_mode: bool = False) -> str:
     """Fused FK + objectives + gradient with the collision fields on attached points.  Differences to the link kernel:
 
     * each link's points are produced, scored against the scene and folded into ONE running wrench (f, p x f about the
@@ -555,7 +556,13 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
     for the positions, then tip->root stepping the pose back through the inverse joint transforms with a single suffix
     wrench; 168 VGPRs, 3 wavefronts per SIMD) was built and measured: 79 vs 76 us for the 45-sphere Panda -- the kernel
     is bound by its ~6900 VALU instructions per wavefront (SQ_INSTS_VALU), so the recomputation ate what the occupancy
-    gave, and it was dropped."""
+    gave, and it was dropped.
+
+    link_mode: the columns are exactly the links in file order with zero offsets and the unit registers as an ordinary
+    link kernel (n_points = 0).  For TREES this pipeline beats generate_rollout_source: a finger's or an arm's joints are
+    finished (and their axes / origins die) when their subtree ends, instead of living until a reverse pass."""
+    if link_mode:
+        assert [int(v) for v in pt.point_link] == list(range(kin.n_links)) and not np.asarray(pt.point_offset).any()
     L, D, P = kin.n_links, kin.n_dofs, len(pt.point_link)
     W = 3 * P
     V = 4 if W % 4 == 0 else (2 if W % 2 == 0 else 1)
@@ -596,7 +603,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
     for base_identity in (True, False):
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
-        E.raw("template <bool FAST>      // FAST: scene_is_fast(A.C) -- only the few-equal-spheres scene path is compiled in")
+        E.raw("template <bool FAST, class IO>   // FAST: scene_is_fast(A.C) -- only the few-equal-spheres scene path is compiled in")
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_per_lane} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
@@ -607,9 +614,9 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
-        E.raw("    float* pos_out = static_cast<float*>(A.link_pos);")
+        E.raw("    IO* pos_out = static_cast<IO*>(A.link_pos);")
         E.raw("    float q[D];")
-        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        E.raw("    spec_load_q<D>(static_cast<const IO*>(A.q), base, rows, lane, lds, q);")
         E.raw(f"    float* row = lds + lane * {LS};          // this lane's slice of the chunk buffer")
         E.raw("    NoTick notick;")
         R: Dict[int, List[List[S]]] = {}
@@ -670,15 +677,17 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                 if not val.is_zero:
                     E.raw(f"    late{d} += {E.expr(val)};")
 
+        gfin: Dict[int, S] = {}
+
         def finish_joint(i: int):
+            """subtree of joint i complete: its share of the running wrench is final.  `late` forces may still arrive
+            (a pair whose later column sits in ANOTHER branch of a tree), so they are added at the very end."""
             d = int(kin.dof_idx[i]); jt = int(kin.joint_type[i])
             sg = 1.0 if jt == JOINT_PRISMATIC else float(kin.rot_sign[i])
             if sg == 0.0:
-                gq_expr[d] = ZERO
                 return
             end = joint_functional(i)
-            g = E.lincomb([(end, ONE), (snap_c[i], S(-1.0)), (S(1.0, f"late{d}"), ONE)])
-            gq_expr[d] = masked(E, i, d, S(g.c * sg, g.n))
+            gfin[i] = S(1.0, E.tmp(E.expr(E.named(E.lincomb([(end, ONE), (snap_c[i], S(-1.0))])))))
 
         for p in range(L):
             i = int(kin.order[p])
@@ -700,7 +709,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                     E.raw(f"    row[{f - chunk_start}] = {E.expr(colpos[c][k])};")
                     if f + 1 - chunk_start == LS or f + 1 == W:
                         nf = f + 1 - chunk_start
-                        E.raw(f"    if (pos_out) spec_flush_chunk<W, {nf}, {LS}, {V}>(pos_out, base, {chunk_start}, rows, lane, lds);")
+                        E.raw(f"    if (pos_out) spec_flush_chunk<W, {nf}, {LS}, {V}, IO>(pos_out, base, {chunk_start}, rows, lane, lds);")
                         chunk_start = f + 1
             # ---- objects / workspace box on this link's collision columns, a few at a time
             ocols = [c for c in cols if c in obj_rank]
@@ -771,6 +780,14 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                 if int(kin.subtree_end[pos_of[j]]) == p + 1:
                     finish_joint(j)
         assert chunk_start == W
+        for i in joint_links:
+            d = int(kin.dof_idx[i]); jt = int(kin.joint_type[i])
+            sg = 1.0 if jt == JOINT_PRISMATIC else float(kin.rot_sign[i])
+            if i not in gfin:
+                gq_expr[d] = ZERO
+                continue
+            g = E.lincomb([(gfin[i], ONE), (S(1.0, f"late{d}"), ONE)])
+            gq_expr[d] = masked(E, i, d, S(g.c * sg, g.n))
         E.raw("    if (!A.gq) return;                       // positions only (trk_fk_points): weights are zero, nothing else to write")
         E.raw("    if (!A.gq) return;                       // positions only (trk_fk_points): weights are zero, nothing else to write")
         E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
@@ -779,7 +796,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         E.raw("        if (lane == 0 && rows > 0) A.cost_sum[wblock] = tot;")
         E.raw("    }")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
-        E.raw("    spec_store_gq<D>(static_cast<float*>(A.gq), base, rows, lane, lds, gv);")
+        E.raw("    spec_store_gq<D>(static_cast<IO*>(A.gq), base, rows, lane, lds, gv);")
         E.raw("}")
         out.extend(E.lines)
         out.append("")
@@ -868,38 +885,57 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         out.extend(E.lines)
         out.append("")
 
-    out.extend(_points_entry_lines(kin, pt, ident))
+    out.extend(_points_entry_lines(kin, pt, ident, link_mode))
     return "\n".join(out) + "\n"
 
 
-def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str) -> List[str]:
+def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode: bool = False) -> List[str]:
     out: List[str] = []
     obj = ", ".join(str(c) for c in pt.obj_cols) or "0"
     pairs = ", ".join(f"{a}, {b}" for a, b in pt.self_pairs) or "0"
     out.append(f"static const int32_t kObjCols[] = {{{obj}}};")
     out.append(f"static const int32_t kSelfPairs[] = {{{pairs}}};")
-    out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("template <class IO>")
+    out.append("static void launch_io(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     out.append("    const bool fast = scene_is_fast(a.C) || a.w.w_obj == 0.0f;")
     out.append("    if (fast) {")
-    out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<true>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-    out.append("        else hipLaunchKernelGGL(k_rollout_bg<true>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<true, IO>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("        else hipLaunchKernelGGL((k_rollout_bg<true, IO>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    } else {")
-    out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<false>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-    out.append("        else hipLaunchKernelGGL(k_rollout_bg<false>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<false, IO>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("        else hipLaunchKernelGGL((k_rollout_bg<false, IO>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    }")
+    out.append("}")
+    out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    if link_mode:
+        out.append("    if (a.io_f16) launch_io<_Float16>(a, base_identity, st); else launch_io<float>(a, base_identity, st);")
+    else:
+        out.append("    launch_io<float>(a, base_identity, st);")
     out.append("}")
     out.append("static void launch_posbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     out.append("    if (base_identity) hipLaunchKernelGGL(k_posbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_posbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
+    n_points = 0 if link_mode else len(pt.point_link)
+    phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
-               f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {len(pt.point_link)}, "
-               f"0x{points_hash(pt.point_link, pt.point_offset):016x}ull, launch_posbwd}};")
+               f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
+               f"0x{phash:016x}ull, launch_posbwd}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out
+
+
+def link_points_template(kin: KinModel, tmpl: CollisionTemplate) -> PointsTemplate:
+    """a CollisionTemplate expressed as a point set: every link origin, file order (requires file order == walk order)"""
+    if [int(v) for v in kin.order] != list(range(kin.n_links)):
+        raise ValueError("link_points_template: the URDF's link order is not a pre-order walk of the tree")
+    L = kin.n_links
+    return PointsTemplate(point_link=np.arange(L, dtype=np.int32), point_offset=np.zeros((L, 3), np.float32),
+                          obj_cols=[int(i) for i in tmpl.obj_links], self_pairs=[(int(a), int(b)) for a, b in tmpl.self_pairs],
+                          ee_link=int(tmpl.ee_link))
 
 
 def _panda_pairs(idx) -> List[Tuple[int, int]]:
@@ -1004,6 +1040,25 @@ SPEC_POINT_ROBOTS = {
 }
 
 
+def _is_tree(kin: KinModel) -> bool:
+    kids = np.bincount(np.asarray(kin.parent[1:], np.int64), minlength=kin.n_links)
+    return bool((kids > 1).any())
+
+
+def generate_link_kernel_source(kin: KinModel, tmpl: CollisionTemplate, ident: str) -> str:
+    """Serial chains: generate_rollout_source (FK, batched objectives, reverse pass).  Trees whose file order is a
+    pre-order walk with increasing collision links: the per-link pipeline of generate_points_rollout_source."""
+    use_pipeline = (_is_tree(kin) and [int(v) for v in kin.order] == list(range(kin.n_links)) and
+                    sorted(tmpl.obj_links) == list(tmpl.obj_links) and TREE_PIPELINE)
+    if use_pipeline:
+        return generate_points_rollout_source(kin, link_points_template(kin, tmpl), ident, link_mode=True)
+    return generate_rollout_source(kin, tmpl, ident)
+
+
+TREE_PIPELINE = False     # measured on MI355X: dual Panda 23.5 -> 37.8 us, UR10+Allegro 36.9 -> 41.7 us: one scene evaluation per link
+                          # (NL = 1) loses the ILP of the batched NL = 10 evaluation; kept switchable for robots with many links per DOF
+
+
 def template_for(ident: str):
     """(KinModel, CollisionTemplate) of a robot in SPEC_ROBOTS."""
     from .kinematics import URDF_DIR
@@ -1020,7 +1075,7 @@ def generate_all(out_dir) -> List[str]:
     written = []
     for ident, (urdf, tmpl_fn) in SPEC_ROBOTS.items():
         kin = KinModel.from_urdf(str(URDF_DIR / urdf))
-        src = generate_rollout_source(kin, tmpl_fn(kin), ident)
+        src = generate_link_kernel_source(kin, tmpl_fn(kin), ident)
         path = out_dir / f"spec_{ident}.hip"
         if not path.exists() or path.read_text() != src:
             path.write_text(src)

@@ -88,6 +88,7 @@ template <> struct IoQuad<float> {
     static __device__ __forceinline__ float4 load(const float* p, int k) { return reinterpret_cast<const float4*>(p)[k]; }
     static __device__ __forceinline__ void store_wt(float* p, int k, const float4& v) { store_wt_f4(reinterpret_cast<float4*>(p) + k, v); }
     static __device__ __forceinline__ void store_wt1(float* p, float v) { store_wt_f1(p, v); }
+    static __device__ __forceinline__ void store_wt2(float* p, float a, float b) { store_wt_f2(p, a, b); }
 };
 template <> struct IoQuad<_Float16> {
     static constexpr uintptr_t kAlignMask = 7;
@@ -102,6 +103,11 @@ template <> struct IoQuad<_Float16> {
     static __device__ __forceinline__ void store_wt1(_Float16* p, float v) {
         const _Float16 h = (_Float16)v;
         asm volatile("global_store_short %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h) : "memory");
+    }
+    static __device__ __forceinline__ void store_wt2(_Float16* p, float a, float b) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 h = {(_Float16)a, (_Float16)b};
+        asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h) : "memory");
     }
 };
 
@@ -216,24 +222,24 @@ __device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows(IO* __restrict__ ou
 // chunks: a chunk is the NF consecutive floats [c0, c0 + NF) of every sample's row.  Each lane has put its NF floats at
 // lds[lane * LS ...]; the wave then streams the rows' segments as V-float vectors (V | NF, V | W, V | c0: 16/8/4-byte
 // aligned), vector e -> sample e / (NF / V).  A sample's segment is contiguous, neighbouring chunks complete its lines.
-template <int W, int NF, int LS, int V>
-__device__ __forceinline__ void spec_flush_chunk(float* __restrict__ out, int64_t base, int c0, int rows, int lane,
+template <int W, int NF, int LS, int V, class IO = float>
+__device__ __forceinline__ void spec_flush_chunk(IO* __restrict__ out, int64_t base, int c0, int rows, int lane,
                                                  const float* lds) {
     constexpr int NVEC = NF / V;
     static_assert(NF % V == 0 && W % V == 0 && LS % V == 0, "chunk geometry must keep the vectors aligned");
     spec_wave_sync();
     const int total = rows * NVEC;
-    float* dst0 = out + base * W + c0;
+    IO* dst0 = out + base * W + c0;
 #pragma unroll
     for (int j = 0; j < NVEC; ++j) {
         const int e = lane + TRK_WAVE * j;
         if (e < total) {
             const int smp = e / NVEC, v = e - smp * NVEC;
             const float* src = lds + smp * LS + v * V;
-            float* dst = dst0 + (int64_t)smp * W + v * V;
-            if (V == 4) store_wt_f4(reinterpret_cast<float4*>(dst), *reinterpret_cast<const float4*>(src));
-            else if (V == 2) store_wt_f2(dst, src[0], src[1]);
-            else store_wt_f1(dst, src[0]);
+            IO* dst = dst0 + (int64_t)smp * W + v * V;
+            if (V == 4) IoQuad<IO>::store_wt(dst, 0, *reinterpret_cast<const float4*>(src));
+            else if (V == 2) IoQuad<IO>::store_wt2(dst, src[0], src[1]);
+            else IoQuad<IO>::store_wt1(dst, src[0]);
         }
     }
     spec_wave_sync();           // the chunk buffer may be overwritten from here on

@@ -41,19 +41,23 @@ def _generator_stamp() -> str:
     return h.hexdigest()[:8]
 
 
-def unit_ident(kin: KinModel, tmpl: codegen.CollisionTemplate) -> str:
-    return f"jit_{codegen.model_hash(kin):016x}_{template_hash(tmpl)}"
+def unit_ident(kin: KinModel, tmpl: codegen.CollisionTemplate, pipeline: bool = False) -> str:
+    return f"jit_{codegen.model_hash(kin):016x}_{template_hash(tmpl)}" + ("_p" if pipeline else "")
 
 
-def build_unit(kin: KinModel, tmpl: codegen.CollisionTemplate, verbose: bool = False) -> Path:
-    """Generate + compile (no GPU needed: hipcc cross-compiles); returns the path of the shared object."""
-    ident = unit_ident(kin, tmpl)
+def build_unit(kin: KinModel, tmpl: codegen.CollisionTemplate, verbose: bool = False, pipeline: bool = False) -> Path:
+    """Generate + compile (no GPU needed: hipcc cross-compiles); returns the path of the shared object.
+    pipeline: force the per-link pipeline generator (codegen.generate_points_rollout_source in link mode)."""
+    ident = unit_ident(kin, tmpl, pipeline)
     JIT_DIR.mkdir(parents=True, exist_ok=True)
     src, so, stamp = JIT_DIR / f"spec_{ident}.hip", JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
     want = _generator_stamp()
     if so.exists() and stamp.exists() and stamp.read_text() == want:
         return so
-    src.write_text(codegen.generate_rollout_source(kin, tmpl, ident))
+    if pipeline:
+        src.write_text(codegen.generate_points_rollout_source(kin, codegen.link_points_template(kin, tmpl), ident, link_mode=True))
+    else:
+        src.write_text(codegen.generate_link_kernel_source(kin, tmpl, ident))
     if not _lib.LIB_PATH.exists():
         raise _lib.TrkError(f"{_lib.LIB_PATH} not found: build libtrk.so first")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
@@ -70,15 +74,15 @@ def build_unit(kin: KinModel, tmpl: codegen.CollisionTemplate, verbose: bool = F
 
 
 def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tuple[int, int]] = (), ee_link: int = -1,
-               verbose: bool = False) -> str:
+               verbose: bool = False, pipeline: bool = False) -> str:
     """Make sure a generated fused kernel for (kin, collision template) is registered with libtrk.so.  Idempotent.
     Returns the unit's identifier.  Robots that already have an ahead-of-time unit with the same template need nothing."""
     tmpl = codegen.CollisionTemplate(obj_links=[int(i) for i in obj_links],
                                      self_pairs=[(int(a), int(b)) for a, b in self_pairs], ee_link=int(ee_link))
-    ident = unit_ident(kin, tmpl)
+    ident = unit_ident(kin, tmpl, pipeline)
     if ident not in _loaded:
         _lib.lib()                                  # libtrk.so first: the unit's initialiser calls into it
-        _loaded[ident] = C.CDLL(str(build_unit(kin, tmpl, verbose)))
+        _loaded[ident] = C.CDLL(str(build_unit(kin, tmpl, verbose, pipeline)))
     return ident
 
 
