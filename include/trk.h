@@ -265,6 +265,10 @@ typedef struct TrkCostModelDesc {
     float ee_w_rot;
     int32_t ee_square;
     float ee_target[16];        /* default target, row-major 4x4 */
+    /* a second tracked link with its own target, same weights / square flag (two-arm scenes: BASELINE config 5 tracks
+     * "EE on both arms"; the reference would sum two EESE3DistanceFields).  -1 = none. */
+    int32_t ee2_link;
+    float ee2_target[16];
 } TrkCostModelDesc;
 
 typedef struct TrkCostModel TrkCostModel;
@@ -273,6 +277,7 @@ int trk_cost_model_create(const TrkCostModelDesc* desc, TrkCostModel** out);
 void trk_cost_model_destroy(TrkCostModel* cm);
 /* reference: EESE3DistanceField.update_target distance_fields.py:344-345.  Host pointer, 16 floats. */
 int trk_cost_model_set_ee_target(TrkCostModel* cm, const float* H16);
+int trk_cost_model_set_ee2_target(TrkCostModel* cm, const float* H16);
 
 /* Which field a cost op evaluates. */
 typedef enum TrkField {

@@ -383,6 +383,9 @@ def test_specialized_tree_kernels(ops, oracle_lib, ident, urdf):
     spec.self_pairs = np.asarray([(self_links.index(a), self_links.index(b)) for a, b in tmpl.self_pairs], np.int32)
     spec.self_margin = rng.uniform(0.02, 0.08, len(tmpl.self_pairs)).astype(np.float32)
     spec.ee_link = tmpl.ee_link
+    if tmpl.ee2_link >= 0:          # two-arm template: the second arm tracks its own target
+        spec.ee2_link = tmpl.ee2_link
+        Ht2 = np.eye(4, dtype=np.float32); Ht2[:3, 3] = (0.4, -0.3, 0.5); spec.ee2_target = Ht2
     Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.5, 0.1, 0.6)
     spec.ee_target = Ht
     spec.validate()
@@ -605,6 +608,9 @@ def test_rollout_fp16_io(ops, oracle_lib, robot, ident):
     spec.self_pairs = np.asarray([(sl.index(a), sl.index(b)) for a, b in tmpl.self_pairs], np.int32).reshape(-1, 2)
     spec.self_margin = np.full(len(tmpl.self_pairs), 0.05, np.float32)
     spec.ee_link = tmpl.ee_link
+    if tmpl.ee2_link >= 0:          # two-arm template: the second arm tracks its own target
+        spec.ee2_link = tmpl.ee2_link
+        Ht2 = np.eye(4, dtype=np.float32); Ht2[:3, 3] = (0.4, -0.3, 0.5); spec.ee2_target = Ht2
     Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5); spec.ee_target = Ht
     spec.validate()
     h, cm, o = ops.ModelHandle(kin), ops.CostHandle(spec, DEV), oracle_lib.Oracle(kin, spec)
@@ -755,3 +761,48 @@ def test_pipeline_generator_on_a_tree(ops, oracle_lib):
             assert np.abs(pos.cpu().numpy() - rp).max() < TOL_H
             assert rel_err(cost.cpu().numpy(), rc) < TOL_C, (n, w)
             assert rel_err(gq.cpu().numpy(), rg) < TOL_G, (n, w)
+
+
+def test_two_tracked_end_effectors(ops, oracle_lib):
+    """Dual Panda, EE tracking on BOTH arms (BASELINE config 5): generated kernel (baked ee_link + ee2_link), table-driven
+    kernel and fp64 oracle; a cost model tracking only the left arm does not match the unit and still agrees."""
+    from torch_robotics_amd import codegen
+    from torch_robotics_amd.costmodel import CostModelSpec
+    from torch_robotics_amd.environments import EnvSpheres3D
+    kin, tmpl = codegen.template_for("dual_panda")
+    assert tmpl.ee2_link == kin.name_to_idx["right_ee_link"]
+    env = EnvSpheres3D(tensor_args=dict(device=DEV, dtype=torch.float32))
+
+    def make(ee2):
+        spec = CostModelSpec(n_links_in=kin.n_links)
+        spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+        spec.obj_link_margin = np.full(len(tmpl.obj_links), 0.1, np.float32)
+        spec.objects = [o.as_object() for o in env.obj_fixed_list]
+        spec.ee_link = tmpl.ee_link
+        T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.5, 0.5); spec.ee_target = T
+        if ee2:
+            spec.ee2_link = tmpl.ee2_link
+            T2 = np.array([[0, -1, 0, 0.4], [1, 0, 0, -0.5], [0, 0, 1, 0.45], [0, 0, 0, 1]], np.float32); spec.ee2_target = T2
+        spec.validate()
+        return spec
+    h = ops.ModelHandle(kin)
+    rng = np.random.default_rng(51)
+    q = rng.uniform(-2.5, 2.5, size=(3, 64, kin.n_dofs)).astype(np.float32)
+    for ee2 in (True, False):
+        spec = make(ee2)
+        cm, o = ops.CostHandle(spec, DEV), oracle_lib.Oracle(kin, spec)
+        rp, rc, rg = o.rollout(q.reshape(-1, kin.n_dofs).astype(np.float64), (0, 1, 0, 1), "f64")
+        for use_spec in (True, False):
+            h.enable_specialized(use_spec)
+            _, cost, gq = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), dev(q))
+            assert rel_err(cost.cpu().numpy().reshape(-1), rc) < TOL_C, (ee2, use_spec)
+            assert rel_err(gq.cpu().numpy().reshape(rg.shape), rg) < TOL_G, (ee2, use_spec)
+        h.enable_specialized(True)
+        if ee2:      # the right arm's joints must feel the second target
+            assert np.abs(rg[:, 7:]).max() > 1e-3
+            T3 = np.eye(4, dtype=np.float32); T3[:3, 3] = (0.3, -0.4, 0.6)
+            cm.set_ee2_target(T3); spec.ee2_target = T3
+            o2 = oracle_lib.Oracle(kin, spec)
+            _, rc2, rg2 = o2.rollout(q.reshape(-1, kin.n_dofs).astype(np.float64), (0, 1, 0, 1), "f64")
+            _, cost, gq = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), dev(q))
+            assert rel_err(cost.cpu().numpy().reshape(-1), rc2) < TOL_C and rel_err(gq.cpu().numpy().reshape(rg2.shape), rg2) < TOL_G

@@ -39,6 +39,9 @@ def setup(ident):
     spec.obj_link_margin = np.full(len(tmpl.obj_links), 0.13, np.float32)
     spec.objects = [o.as_object() for o in env.obj_fixed_list]
     spec.ee_link = tmpl.ee_link
+    if tmpl.ee2_link >= 0:          # two-arm template: the second arm tracks its own target
+        spec.ee2_link = tmpl.ee2_link
+        Ht2 = np.eye(4, dtype=np.float32); Ht2[:3, 3] = (0.4, -0.3, 0.5); spec.ee2_target = Ht2
     Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5); spec.ee_target = Ht
     return kin, ops.ModelHandle(kin), ops.CostHandle(spec, dev)
 

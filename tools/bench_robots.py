@@ -36,6 +36,9 @@ for ident in ("panda", "dual_panda", "ur10_allegro"):
     spec.self_pairs = np.asarray([(sl.index(a), sl.index(b)) for a, b in tmpl.self_pairs], np.int32).reshape(-1, 2)
     spec.self_margin = np.full(len(tmpl.self_pairs), 0.05, np.float32)
     spec.ee_link = tmpl.ee_link
+    if tmpl.ee2_link >= 0:          # two-arm template: the second arm tracks its own target
+        spec.ee2_link = tmpl.ee2_link
+        Ht2 = np.eye(4, dtype=np.float32); Ht2[:3, 3] = (0.4, -0.3, 0.5); spec.ee2_target = Ht2
     Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5); spec.ee_target = Ht
     h, cm = ops.ModelHandle(kin), ops.CostHandle(spec, dev)
     B, H, D, L = 4096, 64, kin.n_dofs, kin.n_links

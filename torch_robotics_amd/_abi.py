@@ -72,6 +72,7 @@ class CostModelDesc(C.Structure):
         ("n_self_pairs", C.c_int32), ("self_pairs", _i32p), ("self_margin", _f32p),
         ("ee_link", C.c_int32), ("ee_w_pos", C.c_float), ("ee_w_rot", C.c_float), ("ee_square", C.c_int32),
         ("ee_target", C.c_float * 16),
+        ("ee2_link", C.c_int32), ("ee2_target", C.c_float * 16),
     ]
 
 
@@ -164,4 +165,6 @@ def cost_desc(spec, grid_ptrs=None) -> Tuple[CostModelDesc, list]:
     d.ee_link = int(spec.ee_link)
     d.ee_w_pos, d.ee_w_rot, d.ee_square = float(spec.ee_w_pos), float(spec.ee_w_rot), int(bool(spec.ee_square))
     d.ee_target = (C.c_float * 16)(*_f32(spec.ee_target).reshape(16))
+    d.ee2_link = int(spec.ee2_link)
+    d.ee2_target = (C.c_float * 16)(*_f32(spec.ee2_target).reshape(16))
     return d, keep

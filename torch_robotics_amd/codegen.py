@@ -181,6 +181,7 @@ class CollisionTemplate:
     obj_links: List[int]
     self_pairs: List[Tuple[int, int]] = field(default_factory=list)   # LINK indices (a, b)
     ee_link: int = -1
+    ee2_link: int = -1          # second tracked link (two-arm scenes), same weights
 
 
 def panda_template(kin: KinModel) -> CollisionTemplate:
@@ -289,10 +290,11 @@ def _emit_joint_gradient(E: "Emitter", kin: KinModel, i: int, R, t, Fi, Ti, mask
     return masked(E, i, d, S(g.c * sg, g.n))
 
 
-def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, List[str]], ee: int, masked,
+def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, List[str]], rot_adj: Dict[int, str], masked,
                         tick: Optional[str] = None) -> Dict[int, S]:
     """Reverse pass of the link kernels: per-link wrench accumulators (F, T about the world origin) pushed towards the
-    root; `tb_names[i]` = the three C expressions holding link i's position adjoint; the EE link adds axial(eeRb R^T)."""
+    root; `tb_names[i]` = the three C expressions holding link i's position adjoint; a tracked link i adds
+    axial(Rb R^T) with Rb = the 9-float array named rot_adj[i]."""
     L = kin.n_links
     F: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
     T: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
@@ -307,8 +309,8 @@ def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, L
             own_T = E.cross(t[i], tb)
             F[i] = [E.add(F[i][k], tb[k]) for k in range(3)]
             T[i] = [E.add(T[i][k], own_T[k]) for k in range(3)]
-            if i == ee:
-                Rb = [[S(1.0, f"eeRb[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            if i in rot_adj:
+                Rb = [[S(1.0, f"{rot_adj[i]}[{3 * r + c}]") for c in range(3)] for r in range(3)]
                 Ri = R[i]
                 M = lambda a, b: E.lincomb([(Rb[a][k], Ri[b][k]) for k in range(3)])   # (Rbar R^T)[a][b]
                 tor = [E.lincomb([(M(2, 1), ONE), (M(1, 2), S(-1.0))]),
@@ -343,8 +345,9 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     L, D = kin.n_links, kin.n_dofs
     NL = len(tmpl.obj_links)
     masked = _masked_factory(kin)
-    adj_links = sorted(set(tmpl.obj_links) | {a for p in tmpl.self_pairs for a in p} |
-                       ({tmpl.ee_link} if tmpl.ee_link >= 0 else set()))
+    tracked = [(l, tgt, rb) for l, tgt, rb in ((tmpl.ee_link, "A.C.ee_target", "eeRb"), (tmpl.ee2_link, "A.C.ee2_target", "ee2Rb"))
+               if l >= 0]
+    adj_links = sorted(set(tmpl.obj_links) | {a for p in tmpl.self_pairs for a in p} | {l for l, _, _ in tracked})
     out: List[str] = []
     out.append(f"// GENERATED by torch_robotics_amd/codegen.py for model '{kin.name}' ({L} links, {D} DOF) -- do not edit.")
     out.append('#include "trk_spec_common.h"')
@@ -417,19 +420,22 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                       f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2);")
             E.raw("    }")
         E.raw("    spec_stamp(A.stamps, wblock, 4, lane);")
-        ee = tmpl.ee_link
-        if ee >= 0:
-            E.raw("    float eeRb[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};")
+        for ee, tgt, rb in tracked:
+            E.raw(f"    float {rb}[9] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};")
+        if tracked:
             E.raw("    if (A.w.w_ee != 0.0f) {")
-            E.raw(f"        const float eR[9] = {{{', '.join(E.expr(R[ee][r][c]) for r in range(3) for c in range(3))}}};")
-            E.raw(f"        const float et[3] = {{{', '.join(E.expr(t[ee][k]) for k in range(3))}}};")
-            E.raw("        float gR[9], gt[3];")
-            E.raw("        const float ce = ee_cost_eval(eR, et, A.C.ee_target, A.C.ee_w_pos, A.C.ee_w_rot, A.C.ee_square, gR, gt);")
-            E.raw("        cost = fmaf(A.w.w_ee, ce, cost);")
-            E.raw("#pragma unroll")
-            E.raw("        for (int k = 0; k < 9; ++k) eeRb[k] = A.w.w_ee * gR[k];")
-            E.raw(f"        tb{ee}_0 = fmaf(A.w.w_ee, gt[0], tb{ee}_0); tb{ee}_1 = fmaf(A.w.w_ee, gt[1], tb{ee}_1); "
-                  f"tb{ee}_2 = fmaf(A.w.w_ee, gt[2], tb{ee}_2);")
+            for ee, tgt, rb in tracked:
+                E.raw("      {")
+                E.raw(f"        const float eR[9] = {{{', '.join(E.expr(R[ee][r][c]) for r in range(3) for c in range(3))}}};")
+                E.raw(f"        const float et[3] = {{{', '.join(E.expr(t[ee][k]) for k in range(3))}}};")
+                E.raw("        float gR[9], gt[3];")
+                E.raw(f"        const float ce = ee_cost_eval(eR, et, {tgt}, A.C.ee_w_pos, A.C.ee_w_rot, A.C.ee_square, gR, gt);")
+                E.raw("        cost = fmaf(A.w.w_ee, ce, cost);")
+                E.raw("#pragma unroll")
+                E.raw(f"        for (int k = 0; k < 9; ++k) {rb}[k] = A.w.w_ee * gR[k];")
+                E.raw(f"        tb{ee}_0 = fmaf(A.w.w_ee, gt[0], tb{ee}_0); tb{ee}_1 = fmaf(A.w.w_ee, gt[1], tb{ee}_1); "
+                      f"tb{ee}_2 = fmaf(A.w.w_ee, gt[2], tb{ee}_2);")
+                E.raw("      }")
             E.raw("    }")
         E.raw("    flush();")
         E.raw("    spec_stamp(A.stamps, wblock, 5, lane);")
@@ -439,8 +445,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("        if (lane == 0 && rows > 0) A.cost_sum[wblock] = tot;")
         E.raw("    }")
         # ---------------- reverse: wrench accumulators towards the root ----------------
-        gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"tb{i}_{k}" for k in range(3)] for i in adj_links}, ee, masked,
-                                      tick="    flush();")
+        gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"tb{i}_{k}" for k in range(3)] for i in adj_links},
+                                      {l: rb for l, _, rb in tracked}, masked, tick="    flush();")
         E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
         E.raw("    flush.flush();")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
@@ -477,7 +483,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         _emit_angles(E, kin)
         for p in range(1, L):
             _emit_fk_link(E, kin, int(kin.order[p]), R, t, passv, snap)
-        gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"gp[{3 * i + k}]" for k in range(3)] for i in range(1, L)}, -1, masked)
+        gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"gp[{3 * i + k}]" for k in range(3)] for i in range(1, L)}, {}, masked)
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D>(static_cast<float*>(A.gq), base, rows, lane, lds, gv);")
         E.raw("}")
@@ -504,7 +510,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("    else hipLaunchKernelGGL(k_posbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
-               f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd}};")
+               f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -533,6 +539,7 @@ class PointsTemplate:
     obj_cols: List[int]                     # columns evaluated against objects / workspace box, margins in this order
     self_pairs: List[Tuple[int, int]] = field(default_factory=list)   # COLUMN pairs
     ee_link: int = -1                       # LINK index
+    ee2_link: int = -1                      # second tracked LINK (two-arm scenes)
 
 
 CHUNK_FLOATS = 36          # 12 columns: 144 B per sample and chunk, a multiple of 16 B
@@ -756,12 +763,13 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                         late_force(pl[e], colpos[e], g)
                 E.raw("    }")
             # ---- end-effector tracking when the walk stands on the EE link
-            if i == pt.ee_link:
+            if i in (pt.ee_link, pt.ee2_link) and i >= 0:
+                tgt_name = "A.C.ee_target" if i == pt.ee_link else "A.C.ee2_target"
                 E.raw("    if (A.w.w_ee != 0.0f) {")
                 E.raw(f"        const float eR[9] = {{{', '.join(E.expr(R[i][r][c]) for r in range(3) for c in range(3))}}};")
                 E.raw(f"        const float et[3] = {{{', '.join(E.expr(t[i][k]) for k in range(3))}}};")
                 E.raw("        float gR[9], gt[3];")
-                E.raw("        const float ce = ee_cost_eval(eR, et, A.C.ee_target, A.C.ee_w_pos, A.C.ee_w_rot, A.C.ee_square, gR, gt);")
+                E.raw(f"        const float ce = ee_cost_eval(eR, et, {tgt_name}, A.C.ee_w_pos, A.C.ee_w_rot, A.C.ee_square, gR, gt);")
                 E.raw("        cost = fmaf(A.w.w_ee, ce, cost);")
                 E.raw("        gt[0] *= A.w.w_ee; gt[1] *= A.w.w_ee; gt[2] *= A.w.w_ee;")
                 E.raw("        pf0 += gt[0]; pf1 += gt[1]; pf2 += gt[2];")
@@ -922,7 +930,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
-               f"0x{phash:016x}ull, launch_posbwd}};")
+               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out
@@ -935,7 +943,7 @@ def link_points_template(kin: KinModel, tmpl: CollisionTemplate) -> PointsTempla
     L = kin.n_links
     return PointsTemplate(point_link=np.arange(L, dtype=np.int32), point_offset=np.zeros((L, 3), np.float32),
                           obj_cols=[int(i) for i in tmpl.obj_links], self_pairs=[(int(a), int(b)) for a, b in tmpl.self_pairs],
-                          ee_link=int(tmpl.ee_link))
+                          ee_link=int(tmpl.ee_link), ee2_link=int(tmpl.ee2_link))
 
 
 def _panda_pairs(idx) -> List[Tuple[int, int]]:
@@ -993,7 +1001,8 @@ def ur10_allegro_template(kin: KinModel) -> CollisionTemplate:
 
 def dual_panda_template(kin: KinModel) -> CollisionTemplate:
     """BASELINE config 5 (two Panda arms): RobotPanda's object-collision links on both arms, arm-vs-arm self pairs;
-    the left arm's end effector is tracked (one EE term per cost model)."""
+    both end effectors are tracked (ee_link = left, ee2_link = right; a cost model that tracks only one arm does not
+    match this unit and takes the table-driven kernel)."""
     idx = kin.name_to_idx
     names = ("panda_link2", "panda_link3", "panda_link5", "panda_link7", "panda_hand")
     obj = [idx[f"{side}_{n}"] for side in ("left", "right") for n in names]
@@ -1001,7 +1010,7 @@ def dual_panda_template(kin: KinModel) -> CollisionTemplate:
              ("panda_link5", "panda_link5"), ("panda_link7", "panda_link7"), ("panda_link3", "panda_link3"),
              ("panda_hand", "panda_link3"), ("panda_link3", "panda_hand")]
     pairs = [(idx[f"left_{a}"], idx[f"right_{b}"]) for a, b in cross]
-    return CollisionTemplate(obj_links=obj, self_pairs=pairs, ee_link=idx["left_ee_link"])
+    return CollisionTemplate(obj_links=obj, self_pairs=pairs, ee_link=idx["left_ee_link"], ee2_link=idx["right_ee_link"])
 
 
 # robots that get a specialised kernel at build time: name -> (urdf file, template factory)

@@ -68,6 +68,8 @@ class CostModelSpec:
     ee_w_rot: float = 1.0
     ee_square: bool = True
     ee_target: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
+    ee2_link: int = -1                   # a second tracked link (two-arm scenes), same weights / square flag
+    ee2_target: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
 
     def validate(self) -> None:
         L = self.n_links_in
@@ -82,8 +84,10 @@ class CostModelSpec:
             raise ValueError("self_pairs / self_margin length mismatch")
         if pairs.size and (pairs.min() < 0 or pairs.max() >= len(self.self_link_idx)):
             raise ValueError("self_pairs index out of range")
-        if self.ee_link >= L:
+        if self.ee_link >= L or self.ee2_link >= L:
             raise ValueError("ee_link out of range")
+        if self.ee2_link >= 0 and self.ee_link < 0:
+            raise ValueError("ee2_link needs ee_link")
         if (self.ws_min is None) != (self.ws_max is None):
             raise ValueError("ws_min and ws_max must be given together")
         n_grid = sum(int(o.get("is_grid", 0)) for o in self.objects)

@@ -114,7 +114,7 @@ static bool spec_matches(const SpecEntry* e, const TrkCostModel* cm, const TrkRo
     if (w->w_self != 0.0f)
         ok = ok && (int)cm->self_pairs.size() == 2 * e->n_self_pairs &&
              std::equal(cm->self_pairs.begin(), cm->self_pairs.end(), e->self_pairs);
-    if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link;
+    if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link && cm->hdr.ee2_link == e->ee2_link;
     return ok;
 }
 static const SpecEntry* model_spec_for(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w) {
@@ -272,7 +272,7 @@ static int blank_spec_args(SpecArgs& a) {
     }
     std::memset(&a, 0, sizeof(a));
     DevCostHdr& h = a.C;
-    h.ee_link = -1;
+    h.ee_link = -1; h.ee2_link = -1;
     h.obj_link_idx = static_cast<const int32_t*>(g_zero_blob); h.obj_link_margin = static_cast<const float*>(g_zero_blob);
     h.objects = static_cast<const DevObj*>(g_zero_blob); h.prims = static_cast<const DevPrim*>(g_zero_blob);
     h.self_pairs = static_cast<const int32_t*>(g_zero_blob); h.self_margin = static_cast<const float*>(g_zero_blob);
@@ -540,7 +540,8 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
         if (d->self_link_idx[l] < 0 || d->self_link_idx[l] >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: self_link_idx out of range");
     for (int p = 0; p < 2 * d->n_self_pairs; ++p)
         if (d->self_pairs[p] < 0 || d->self_pairs[p] >= d->n_self_links) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: self_pairs out of range");
-    if (d->ee_link >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: ee_link out of range");
+    if (d->ee_link >= Lin || d->ee2_link >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: ee_link out of range");
+    if (d->ee2_link >= 0 && d->ee_link < 0) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: ee2_link needs ee_link");
     int n_grid = 0;
     for (int o = 0; o < d->n_objects; ++o) {
         const TrkObject& ob = d->objects[o];
@@ -645,6 +646,8 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     std::memcpy(h.ws_max, d->ws_max, sizeof(float) * 3);
     for (int k = 0; k < 3; ++k) { h.ws_c[k] = 0.5f * (d->ws_min[k] + d->ws_max[k]); h.ws_h[k] = 0.5f * (d->ws_max[k] - d->ws_min[k]); }
     std::memcpy(h.ee_target, d->ee_target, sizeof(float) * 16);
+    h.ee2_link = d->ee2_link;
+    std::memcpy(h.ee2_target, d->ee2_target, sizeof(float) * 16);
     h.obj_link_idx = reinterpret_cast<const int32_t*>(base + o_idx);
     h.obj_link_margin = reinterpret_cast<const float*>(base + o_mg);
     h.objects = reinterpret_cast<const DevObj*>(base + o_obj);
@@ -680,6 +683,12 @@ void trk_cost_model_destroy(TrkCostModel* cm) {
 int trk_cost_model_set_ee_target(TrkCostModel* cm, const float* H16) {
     if (!cm || !H16) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_set_ee_target: null argument");
     std::memcpy(cm->hdr.ee_target, H16, sizeof(float) * 16);
+    return TRK_OK;
+}
+
+int trk_cost_model_set_ee2_target(TrkCostModel* cm, const float* H16) {
+    if (!cm || !H16) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_set_ee2_target: null argument");
+    std::memcpy(cm->hdr.ee2_target, H16, sizeof(float) * 16);
     return TRK_OK;
 }
 
@@ -766,7 +775,8 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
     if (!ps || ps->model != m) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: point set does not belong to this model");
     if (batch < 0 || horizon < 1) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: bad batch/horizon");
     if (cm->hdr.n_links_in != ps->dev.n_points) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: cost model n_links_in != number of points");
-    if (cm->hdr.ee_link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: ee_link is not a link of the model");
+    if (cm->hdr.ee_link >= m->hdr.n_links || cm->hdr.ee2_link >= m->hdr.n_links)
+        return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: ee_link is not a link of the model");
     if (trk_lds_rollout(m->hdr, ps->dev.n_points) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_points_cost_grad: point tiles exceed the 160 KiB LDS");
     const int64_t n = batch * horizon;
     if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: null q/cost/gq");
@@ -781,7 +791,7 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
         if (w->w_self != 0.0f)
             ok = ok && (int)cm->self_pairs.size() == 2 * e->n_self_pairs &&
                  std::equal(cm->self_pairs.begin(), cm->self_pairs.end(), e->self_pairs);
-        if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link;
+        if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link && cm->hdr.ee2_link == e->ee2_link;
         if (ok) {
             SpecArgs a;
             a.C = cm->hdr; a.w = *w;

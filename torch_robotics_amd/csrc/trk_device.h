@@ -75,6 +75,8 @@ struct DevCostHdr {
     float ws_min[3], ws_max[3];
     float ws_c[3], ws_h[3];        // box centre and half widths (host, fp32): distance to the nearest plane of axis k = h_k - |p_k - c_k|
     float ee_target[16];
+    int32_t ee2_link; int32_t _pad_ee2;   // second tracked link (-1 = none), same weights
+    float ee2_target[16];
     const int32_t* obj_link_idx;   // device
     const float* obj_link_margin;  // device
     const DevObj* objects;         // device

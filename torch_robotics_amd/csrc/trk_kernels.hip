@@ -294,9 +294,9 @@ struct AdjFromGH {        // gH [N, n_sel, 4, 4]
 };
 
 template <bool IDENT>
-struct AdjFromTile {      // tbar from an LDS tile [64][rs] (link-major, 3 floats per link) + optional EE rotation adjoint
-    const float* tile; int rs; int lane; const SelMap& sel; int ee_link; const float* eeRb;
-    __device__ __forceinline__ bool has_rot(const DevLink& Lk) const { return Lk.link == ee_link; }
+struct AdjFromTile {      // tbar from an LDS tile [64][rs] (link-major, 3 floats per link) + optional EE rotation adjoints
+    const float* tile; int rs; int lane; const SelMap& sel; int ee_link; const float* eeRb; int ee2_link = -1; const float* ee2Rb = nullptr;
+    __device__ __forceinline__ bool has_rot(const DevLink& Lk) const { return Lk.link == ee_link || Lk.link == ee2_link; }
     __device__ __forceinline__ void prefetch(int) const {}
     __device__ __forceinline__ bool operator()(const DevLink& Lk, int, const Pose&, float* Rb, float* tb) const {
         const int col = IDENT ? Lk.link : sel.col[Lk.link];
@@ -306,6 +306,9 @@ struct AdjFromTile {      // tbar from an LDS tile [64][rs] (link-major, 3 float
         if (Lk.link == ee_link) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) Rb[k] = eeRb[k];
+        } else if (Lk.link == ee2_link) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rb[k] = ee2Rb[k];
         }
         return true;
     }
@@ -395,16 +398,17 @@ k_fk_points(DevModelHdr hdr, const DevLink* __restrict__ links, DevPointSet ps, 
 
 struct AdjFromPoints {    // point adjoints from an LDS tile [64][rs] (+ optional EE pose adjoint on one link)
     const float* gtile; int rs; int lane; DevPointSet ps; int ee_link; const float* eeRb; const float* eetb;
+    int ee2_link = -1; const float* ee2Rb = nullptr; const float* ee2tb = nullptr;
     __device__ __forceinline__ bool has_rot(const DevLink&) const { return true; }
     __device__ __forceinline__ void prefetch(int) const {}
     __device__ __forceinline__ bool operator()(const DevLink& Lk, int p, const Pose&, float* Rb, float* tb) const {
         const int b = cptr(ps.begin)[p], e = cptr(ps.begin)[p + 1];
-        const bool ee = Lk.link == ee_link;
-        if (b == e && !ee) return false;
+        const bool ee = Lk.link == ee_link, ee2 = Lk.link == ee2_link;
+        if (b == e && !ee && !ee2) return false;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rb[k] = ee ? eeRb[k] : 0.0f;
+        for (int k = 0; k < 9; ++k) Rb[k] = ee ? eeRb[k] : (ee2 ? ee2Rb[k] : 0.0f);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tb[k] = ee ? eetb[k] : 0.0f;
+        for (int k = 0; k < 3; ++k) tb[k] = ee ? eetb[k] : (ee2 ? ee2tb[k] : 0.0f);
         for (int k = b; k < e; ++k) {
             const TRK_CAS DevPoint* pt = cptr(ps.pts) + k;
             const float c0 = pt->off[0], c1 = pt->off[1], c2 = pt->off[2];
@@ -738,6 +742,7 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     __syncthreads();
     // walk 1
     float eeR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, eet[3] = {0, 0, 0};
+    float e2R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, e2t[3] = {0, 0, 0};
     {
         Pose cur, par;
         DevLink nxt = load_link(links, 0);
@@ -754,6 +759,11 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
 #pragma unroll
                 for (int k = 0; k < 9; ++k) eeR[k] = cur.r[k];
                 eet[0] = cur.t[0]; eet[1] = cur.t[1]; eet[2] = cur.t[2];
+            }
+            if (Lk.link == C.ee2_link) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) e2R[k] = cur.r[k];
+                e2t[0] = cur.t[0]; e2t[1] = cur.t[1]; e2t[2] = cur.t[2];
             }
         }
     }
@@ -777,6 +787,20 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
             g[0] = fmaf(w.w_ee, gt[0], g[0]); g[1] = fmaf(w.w_ee, gt[1], g[1]); g[2] = fmaf(w.w_ee, gt[2], g[2]);
         }
     }
+    float e2Rb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, e2tb[3] = {0, 0, 0};
+    const bool use_ee2 = use_ee && (C.ee2_link >= 0);
+    if (use_ee2) {      // second tracked link (two-arm scenes): same weights, its own target
+        float gt[3];
+        const float ce = ee_cost_eval(e2R, e2t, C.ee2_target, C.ee_w_pos, C.ee_w_rot, C.ee_square, e2Rb, gt);
+        c = fmaf(w.w_ee, ce, c);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e2Rb[k] *= w.w_ee;
+        if (POINTS) { e2tb[0] = w.w_ee * gt[0]; e2tb[1] = w.w_ee * gt[1]; e2tb[2] = w.w_ee * gt[2]; }
+        else {
+            float* g = gtile + lane * rs + 3 * C.ee2_link;
+            g[0] = fmaf(w.w_ee, gt[0], g[0]); g[1] = fmaf(w.w_ee, gt[1], g[1]); g[2] = fmaf(w.w_ee, gt[2], g[2]);
+        }
+    }
     if (lane < rows) cost[base + lane] = c;
     if (cost_sum) {     // per-wavefront partial sum: no atomics (4096 same-address atomics cost ~47 us on MI355X)
         const float tot = wave_sum(lane < rows ? c : 0.0f);
@@ -784,10 +808,10 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     }
     // walk 2: reverse pass
     if (POINTS) {
-        AdjFromPoints adj{gtile, rs, lane, ps, use_ee ? C.ee_link : -1, eeRb, eetb};
+        AdjFromPoints adj{gtile, rs, lane, ps, use_ee ? C.ee_link : -1, eeRb, eetb, use_ee2 ? C.ee2_link : -1, e2Rb, e2tb};
         reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
     } else {
-        AdjFromTile<true> adj{gtile, rs, lane, sel_unused, use_ee ? C.ee_link : -1, eeRb};
+        AdjFromTile<true> adj{gtile, rs, lane, sel_unused, use_ee ? C.ee_link : -1, eeRb, use_ee2 ? C.ee2_link : -1, e2Rb};
         reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
     }
     __syncthreads();

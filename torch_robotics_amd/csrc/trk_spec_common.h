@@ -45,6 +45,7 @@ struct SpecEntry {
     int32_t n_points;           // 0: the kernel's columns are the link origins; else: a baked attached-point set
     uint64_t points_hash;       // FNV-1a over (n_points, point_link[], point_offset[]) in the caller's order
     SpecLaunchFn launch_posbwd; // reverse mode of the link positions (q, gpos = link_pos -> gq); nullptr if not generated
+    int32_t ee2_link;           // second tracked link baked into the unit (-1 = none)
 };
 
 // registry filled by static initialisers of the generated translation units

@@ -30,7 +30,7 @@ def template_hash(tmpl: codegen.CollisionTemplate) -> str:
     h = hashlib.sha1()
     h.update(np.asarray(tmpl.obj_links, np.int32).tobytes())
     h.update(np.asarray(tmpl.self_pairs, np.int32).reshape(-1).tobytes())
-    h.update(np.asarray([tmpl.ee_link], np.int32).tobytes())
+    h.update(np.asarray([tmpl.ee_link, tmpl.ee2_link], np.int32).tobytes())
     return h.hexdigest()[:8]
 
 
@@ -74,11 +74,12 @@ def build_unit(kin: KinModel, tmpl: codegen.CollisionTemplate, verbose: bool = F
 
 
 def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tuple[int, int]] = (), ee_link: int = -1,
-               verbose: bool = False, pipeline: bool = False) -> str:
+               verbose: bool = False, pipeline: bool = False, ee2_link: int = -1) -> str:
     """Make sure a generated fused kernel for (kin, collision template) is registered with libtrk.so.  Idempotent.
     Returns the unit's identifier.  Robots that already have an ahead-of-time unit with the same template need nothing."""
     tmpl = codegen.CollisionTemplate(obj_links=[int(i) for i in obj_links],
-                                     self_pairs=[(int(a), int(b)) for a, b in self_pairs], ee_link=int(ee_link))
+                                     self_pairs=[(int(a), int(b)) for a, b in self_pairs], ee_link=int(ee_link),
+                                     ee2_link=int(ee2_link))
     ident = unit_ident(kin, tmpl, pipeline)
     if ident not in _loaded:
         _lib.lib()                                  # libtrk.so first: the unit's initialiser calls into it
@@ -92,4 +93,4 @@ def specialize_for_cost_spec(kin: KinModel, spec, verbose: bool = False) -> Opti
         return None
     sl = np.asarray(spec.self_link_idx, np.int32)
     pairs = [(int(sl[a]), int(sl[b])) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2)]
-    return specialize(kin, [int(i) for i in spec.obj_link_idx], pairs, int(spec.ee_link), verbose)
+    return specialize(kin, [int(i) for i in spec.obj_link_idx], pairs, int(spec.ee_link), verbose, ee2_link=int(spec.ee2_link))

@@ -95,6 +95,11 @@ class CostHandle:
         check(lib().trk_cost_model_set_ee_target(self._h, H.ctypes.data), "trk_cost_model_set_ee_target")
         self.spec.ee_target = H.reshape(4, 4).copy()
 
+    def set_ee2_target(self, H) -> None:
+        H = np.ascontiguousarray(np.asarray(H, np.float32).reshape(16))
+        check(lib().trk_cost_model_set_ee2_target(self._h, H.ctypes.data), "trk_cost_model_set_ee2_target")
+        self.spec.ee2_target = H.reshape(4, 4).copy()
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
