@@ -161,6 +161,21 @@ def test_fused_task_rollout():
     assert np.abs(np.linalg.norm(x.grad.cpu().numpy(), axis=-1) - 1).max() < 1e-5
 
 
+def test_rollout_plan_matches_rollout_cost_grad():
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.2, 0.5)
+    task.set_ee_target(T)
+    q = robot.random_q(5 * 64).reshape(5, 64, 7).contiguous()
+    plan = task.rollout_plan(q, w_ee=1.0)
+    for _ in range(2):
+        plan.launch()
+        pos, cost, gq = task.rollout_cost_grad(q, w_ee=1.0)
+        torch.cuda.synchronize()
+        assert torch.equal(plan.cost, cost) and torch.equal(plan.gq, gq) and torch.equal(plan.link_pos, pos)
+        q.copy_(robot.random_q(5 * 64).reshape(5, 64, 7))      # the plan reads q in place
+
+
 def test_trajectory_validation_like_the_reference():
     """8f rank 1: get_trajs_collision_and_free + stats (tasks.py:234-328) and interpolate_traj_via_points."""
     g, gt = gold("trajs_panda"), gold("traj")

@@ -125,6 +125,15 @@ class PlanningTask(Task):
             return ops.rollout_points_cost_grad(ps, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos, cost_sum=cost_sum)
         return ops.rollout_cost_grad(model, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos, cost_sum=cost_sum, out=out)
 
+    def rollout_plan(self, q, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=True) -> "ops.RolloutPlan":
+        """Pre-bound fused evaluation for a planner's inner loop: buffers and arguments are resolved once, `plan.launch()`
+        is one C call (~3 us of host time instead of ~18 us through `rollout_cost_grad`); results land in
+        `plan.link_pos / plan.cost / plan.gq`.  q (B,H,D) is read in place on every launch (update it between launches)."""
+        if self._points(q.device) is not None:
+            raise NotImplementedError("rollout_plan is for link-column cost models (no grasped object / link spheres)")
+        model, cm = self._fused_handles(q.device)
+        return ops.RolloutPlan(model, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos)
+
     # ---------------------------------------------------------------------------------------------
     def compute_collision(self, x, **kwargs):                  # tasks.py:131-133
         return self._compute_collision_or_cost(self.robot.get_position(x), field_type="occupancy", **kwargs)
