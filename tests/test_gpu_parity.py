@@ -806,3 +806,47 @@ def test_two_tracked_end_effectors(ops, oracle_lib):
             _, rc2, rg2 = o2.rollout(q.reshape(-1, kin.n_dofs).astype(np.float64), (0, 1, 0, 1), "f64")
             _, cost, gq = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), dev(q))
             assert rel_err(cost.cpu().numpy().reshape(-1), rc2) < TOL_C and rel_err(gq.cpu().numpy().reshape(rg2.shape), rg2) < TOL_G
+
+
+@pytest.mark.parametrize("robot", ["hab_stretch", "tiago_dual_holobase_minimal_holonomic", "shadow_hand"])
+def test_runtime_compiled_kernels_on_trees_with_prismatic_joints(ops, oracle_lib, robot):
+    """jit.specialize on the reference's other robots: trees, prismatic joints, axes that degenerate to +-z, a URDF whose
+    file order is not a pre-order walk (hab_stretch) -- generated kernel vs table-driven vs fp64 oracle."""
+    from torch_robotics_amd import jit
+    from torch_robotics_amd.costmodel import CostModelSpec
+    from torch_robotics_amd.environments import EnvSpheres3D
+    m = model(robot)
+    leaves = [i for i in range(m.n_links) if not (m.parent == i).any()]
+    obj = sorted(set(leaves[:5] + [m.n_links // 2]))
+    pairs = [(leaves[0], leaves[-1])] + ([(leaves[1], leaves[0])] if len(leaves) > 1 else [])
+    ee = leaves[-1]
+    env = EnvSpheres3D(tensor_args=dict(device=DEV, dtype=torch.float32))
+    spec = CostModelSpec(n_links_in=m.n_links)
+    spec.obj_link_idx = np.asarray(obj, np.int32)
+    spec.obj_link_margin = np.full(len(obj), 0.07, np.float32)
+    spec.objects = [o.as_object() for o in env.obj_fixed_list]
+    spec.ws_min, spec.ws_max = np.float32([-1, -1, -1]), np.float32([1, 1, 1.5])
+    sl = sorted({a for p in pairs for a in p})
+    spec.self_link_idx = np.asarray(sl, np.int32)
+    spec.self_pairs = np.asarray([(sl.index(a), sl.index(b)) for a, b in pairs], np.int32)
+    spec.self_margin = np.full(len(pairs), 0.04, np.float32)
+    spec.ee_link = ee
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.3, 0.1, 0.8); spec.ee_target = T
+    spec.validate()
+    assert jit.specialize_for_cost_spec(m, spec) is not None
+    h, cm, o = ops.ModelHandle(m), ops.CostHandle(spec, DEV), oracle_lib.Oracle(m, spec)
+    assert h.specialized
+    rng = np.random.default_rng(61)
+    q = rng.uniform(-1.5, 1.5, size=(130, m.n_dofs)).astype(np.float32)       # beyond many of the limits: clamps
+    rp, rc, rg = o.rollout(q.astype(np.float64), (1, 1, 1, 1), "f64")
+    scale = max(1.0, float(np.abs(rp).max()))
+    for use_spec in (True, False):
+        h.enable_specialized(use_spec)
+        pos, cost, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), dev(q))
+        assert np.abs(pos.cpu().numpy() - rp).max() / scale < TOL_H, use_spec
+        assert rel_err(cost.cpu().numpy(), rc) < TOL_C, use_spec
+        assert rel_err(gq.cpu().numpy(), rg) < TOL_G, use_spec
+    h.enable_specialized(True)
+    w = rng.standard_normal((130, m.n_links, 3)).astype(np.float32)
+    gH = np.zeros((130, m.n_links, 4, 4)); gH[..., :3, 3] = w
+    assert rel_err(ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy(), o.fk_backward(q.astype(np.float64), gH, "f64")) < TOL_G
