@@ -84,7 +84,44 @@ def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tup
     if ident not in _loaded:
         _lib.lib()                                  # libtrk.so first: the unit's initialiser calls into it
         _loaded[ident] = C.CDLL(str(build_unit(kin, tmpl, verbose, pipeline)))
+        _loaded_templates[ident] = (codegen.model_hash(kin), tmpl)
     return ident
+
+
+def _template_of(kin: KinModel, spec) -> Optional[codegen.CollisionTemplate]:
+    if spec.n_links_in != kin.n_links:
+        return None
+    sl = np.asarray(spec.self_link_idx, np.int32)
+    pairs = [(int(sl[a]), int(sl[b])) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2)]
+    return codegen.CollisionTemplate(obj_links=[int(i) for i in spec.obj_link_idx], self_pairs=pairs,
+                                     ee_link=int(spec.ee_link), ee2_link=int(spec.ee2_link))
+
+
+def _serves(unit: codegen.CollisionTemplate, want: codegen.CollisionTemplate) -> bool:
+    """the dispatcher's rule (trk_capi.hip: spec_matches) for a caller that may use every weight"""
+    if list(unit.obj_links) != list(want.obj_links) or [tuple(p) for p in unit.self_pairs] != [tuple(p) for p in want.self_pairs]:
+        return False
+    return want.ee_link < 0 or (unit.ee_link == want.ee_link and unit.ee2_link == want.ee2_link)
+
+
+_loaded_templates: Dict[str, Tuple[int, codegen.CollisionTemplate]] = {}
+
+
+def has_matching_unit(kin: KinModel, spec) -> bool:
+    """True if an ahead-of-time unit (codegen.SPEC_ROBOTS) or an already loaded run-time unit serves this robot and
+    collision model."""
+    want = _template_of(kin, spec)
+    if want is None:
+        return False
+    h = codegen.model_hash(kin)
+    for mh, tm in _loaded_templates.values():
+        if mh == h and _serves(tm, want):
+            return True
+    for ident in codegen.SPEC_ROBOTS:
+        k2, t2 = codegen.template_for(ident)
+        if codegen.model_hash(k2) == h and _serves(t2, want):
+            return True
+    return False
 
 
 def specialize_for_cost_spec(kin: KinModel, spec, verbose: bool = False) -> Optional[str]:

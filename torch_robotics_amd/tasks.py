@@ -2,6 +2,7 @@
 entry point `rollout_cost_grad`, which runs FK + every configured objective + d cost / d q in ONE kernel."""
 from __future__ import annotations
 
+import os
 from functools import partial
 from typing import Optional
 
@@ -21,8 +22,13 @@ class Task:
 
 
 class PlanningTask(Task):
-    def __init__(self, ws_limits=None, use_occupancy_map=False, cell_size=0.01, obstacle_cutoff_margin=0.01, **kwargs):
+    def __init__(self, ws_limits=None, use_occupancy_map=False, cell_size=0.01, obstacle_cutoff_margin=0.01,
+                 auto_specialize=True, **kwargs):
         super().__init__(**kwargs)
+        # the first fused evaluation compiles + loads a generated kernel for this robot / collision model when none is
+        # registered yet (~2 s with hipcc, cached on disk); TRK_NO_JIT=1 or auto_specialize=False keeps the table-driven path
+        self.auto_specialize = bool(auto_specialize) and os.environ.get("TRK_NO_JIT", "0") != "1"
+        self._jit_failed = False
         self.ws_limits = self.env.limits if ws_limits is None else ws_limits
         self.ws_min, self.ws_max = self.ws_limits[0], self.ws_limits[1]
         if use_occupancy_map:
@@ -94,7 +100,17 @@ class PlanningTask(Task):
 
     def _fused_handles(self, device):
         if self._fused is None or self._fused[2] != str(device):
-            self._fused = (self.robot.diff_panda._handle, ops.CostHandle(self.build_cost_spec(), device), str(device))
+            spec = self.build_cost_spec()
+            self._fused = (self.robot.diff_panda._handle, ops.CostHandle(spec, device), str(device))
+            if self.auto_specialize and not self._jit_failed and not getattr(self.robot, "has_extra_points", False):
+                try:                                   # a unit whose template equals this cost model may already exist
+                    from . import jit
+                    if not jit.has_matching_unit(self.robot.diff_panda._kin, spec):
+                        jit.specialize_for_cost_spec(self.robot.diff_panda._kin, spec)
+                except Exception as e:                 # no hipcc / compile error: the table-driven kernels still serve
+                    import warnings
+                    self._jit_failed = True
+                    warnings.warn(f"run-time kernel specialisation skipped ({type(e).__name__}: {e}); using the table-driven kernels")
         return self._fused[0], self._fused[1]
 
     def specialize(self, verbose: bool = False):
