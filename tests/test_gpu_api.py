@@ -400,3 +400,31 @@ def test_planning_task_specialises_itself_at_run_time():
     model.enable_specialized(True)
     assert np.abs(pos.cpu().numpy() - pos_g.cpu().numpy()).max() < 2 * TOL_H
     assert rel_err(cost.cpu().numpy(), cost_g.cpu().numpy()) < TOL_C and rel_err(gq.cpu().numpy(), gq_g.cpu().numpy()) < TOL_G
+
+
+def test_custom_sphere_table_gets_its_own_kernel(tmp_path, oracle_lib):
+    """RobotPanda with ANOTHER link-sphere table: no ahead-of-time unit has that point set, so the task compiles one at
+    run time (jit.specialize_points); generated vs table-driven vs fp64 oracle."""
+    from torch_robotics_amd import jit, ops
+    table = tmp_path / "spheres.yaml"
+    table.write_text("panda_link2:\n- [0.0, 0.0, 0.05, 0.07]\n- [0.0, -0.1, 0.0, 0.06]\n"
+                     "panda_link5:\n- [0.0, 0.06, 0.0, 0.06]\n- [0.0, 0.0, -0.2, 0.055]\n- [0.01, 0.08, -0.1, 0.03]\n"
+                     "panda_hand:\n- [0.0, 0.04, 0.02, 0.03]\n- [0.0, -0.04, 0.02, 0.03]\n- [0.0, 0.0, 0.06, 0.025]\n")
+    robot = tra.RobotPanda(link_sphere_model=str(table), tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.02, tensor_args=TA)
+    pl, po = robot.collision_point_set()
+    assert len(pl) == 11 + 8
+    assert not jit.has_matching_points_unit(robot.diff_panda._kin, pl, po, task.build_cost_spec())
+    q = robot.random_q(2 * 64 + 3)
+    pos, cost, gq = task.rollout_cost_grad(q)                                 # compiles + loads the unit
+    ps = robot._point_set(torch.device(DEV))
+    assert ps.specialized and jit.has_matching_points_unit(robot.diff_panda._kin, pl, po, task.build_cost_spec())
+    o = oracle_lib.Oracle(robot.diff_panda._kin, task.build_cost_spec())
+    rp, rc, rg = o.rollout_points(pl, po, q.cpu().numpy().astype(np.float64), (1, 1, 1, 0), "f64")
+    model, cm = task._fused_handles(torch.device(DEV))
+    model.enable_specialized(False)
+    pos_g, cost_g, gq_g = task.rollout_cost_grad(q)
+    model.enable_specialized(True)
+    for p_, c_, g_ in ((pos, cost, gq), (pos_g, cost_g, gq_g)):
+        assert np.abs(p_.cpu().numpy() - rp).max() < TOL_H
+        assert rel_err(c_.cpu().numpy(), rc) < TOL_C and rel_err(g_.cpu().numpy(), rg) < TOL_G

@@ -96,7 +96,8 @@ struct TrkPointSet {
     DevPointSet dev;
     void* d_blob = nullptr;
     const TrkModel* model = nullptr;
-    const SpecEntry* spec = nullptr;     // generated kernel with exactly this point set baked in, if one was built
+    mutable const SpecEntry* spec = nullptr;   // any generated unit with exactly this point set baked in (positions-only launches)
+    uint64_t hash = 0;                   // FNV-1a over (n_points, point_link, point_offset)
 };
 
 struct TrkCostModel {
@@ -116,6 +117,18 @@ static bool spec_matches(const SpecEntry* e, const TrkCostModel* cm, const TrkRo
              std::equal(cm->self_pairs.begin(), cm->self_pairs.end(), e->self_pairs);
     if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link && cm->hdr.ee2_link == e->ee2_link;
     return ok;
+}
+// point-set units: like model_spec / model_spec_for (late registration, several templates per point set)
+static const SpecEntry* points_spec(const TrkPointSet* ps) {
+    if (!ps->spec) ps->spec = trk_spec_find_points(ps->model->hash, ps->hash, ps->dev.n_points);
+    return ps->spec;
+}
+static const SpecEntry* points_spec_for(const TrkPointSet* ps, const TrkCostModel* cm, const TrkRolloutWeights* w) {
+    for (const SpecEntry* e : spec_registry())
+        if (e->n_points == ps->dev.n_points && e->n_points > 0 && e->model_hash == ps->model->hash &&
+            e->points_hash == ps->hash && spec_matches(e, cm, w))
+            return e;
+    return nullptr;
 }
 static const SpecEntry* model_spec_for(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w) {
     for (const SpecEntry* e : spec_registry())
@@ -405,6 +418,7 @@ int trk_point_set_create(const TrkModel* m, const int32_t* point_link, const flo
         h = fnv1a(h, &n_points, sizeof(int32_t));
         h = fnv1a(h, point_link, sizeof(int32_t) * n_points);
         h = fnv1a(h, point_offset, sizeof(float) * 3 * n_points);
+        ps->hash = h;
         ps->spec = trk_spec_find_points(m->hash, h, n_points);
     }
     *out = ps;
@@ -418,7 +432,7 @@ void trk_point_set_destroy(TrkPointSet* ps) {
 }
 
 int trk_point_set_size(const TrkPointSet* ps) { return ps ? ps->dev.n_points : TRK_ERR_INVALID_ARG; }
-int trk_point_set_is_specialized(const TrkPointSet* ps) { return (ps && ps->spec && ps->model->spec_enabled) ? 1 : 0; }
+int trk_point_set_is_specialized(const TrkPointSet* ps) { return (ps && points_spec(ps) && ps->model->spec_enabled) ? 1 : 0; }
 
 static const size_t kMaxLds = 160 * 1024;
 
@@ -429,7 +443,7 @@ int trk_fk_points(const TrkModel* m, const TrkPointSet* ps, const float* q, int6
     if (n < 0 || (n > 0 && (!pos_out || (!q && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_points: bad q/out/n");
     if (trk_lds_fk_points(m->hdr, ps->dev.n_points, false) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_fk_points: point tile exceeds the 160 KiB LDS");
     if (n == 0) return TRK_OK;
-    if (ps->spec && m->spec_enabled && (reinterpret_cast<uintptr_t>(pos_out) & 15) == 0) {
+    if (points_spec(ps) && m->spec_enabled && (reinterpret_cast<uintptr_t>(pos_out) & 15) == 0) {
         // generated kernel with this point set baked in, all weights zero and no gradient output: FK + positions only
         SpecArgs a;
         rc = blank_spec_args(a);
@@ -454,7 +468,7 @@ int trk_fk_points_backward(const TrkModel* m, const TrkPointSet* ps, const float
     if (n < 0 || (n > 0 && (!gpos || ((!q || !gq) && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_points_backward: bad q/g/n");
     if (trk_lds_fk_points(m->hdr, ps->dev.n_points, true) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_fk_points_backward: point tile exceeds the 160 KiB LDS");
     if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
-    if (ps->spec && ps->spec->launch_posbwd && m->spec_enabled && (reinterpret_cast<uintptr_t>(gpos) & 15) == 0) {
+    if (points_spec(ps) && ps->spec->launch_posbwd && m->spec_enabled && (reinterpret_cast<uintptr_t>(gpos) & 15) == 0) {
         SpecArgs a;
         rc = blank_spec_args(a);
         if (rc) return rc;
@@ -781,27 +795,16 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
     const int64_t n = batch * horizon;
     if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: null q/cost/gq");
     if (n == 0) return TRK_OK;
-    if (ps->spec && m->spec_enabled && (reinterpret_cast<uintptr_t>(point_pos_out) & 15) == 0) {
-        // generated kernel with this point set baked in: the cost model's columns must be the baked ones
-        const SpecEntry* e = ps->spec;
-        bool ok = true;
-        if (w->w_obj != 0.0f || w->w_ws != 0.0f)
-            ok = ok && (int)cm->obj_link_idx.size() == e->n_obj_links &&
-                 std::equal(cm->obj_link_idx.begin(), cm->obj_link_idx.end(), e->obj_link_idx);
-        if (w->w_self != 0.0f)
-            ok = ok && (int)cm->self_pairs.size() == 2 * e->n_self_pairs &&
-                 std::equal(cm->self_pairs.begin(), cm->self_pairs.end(), e->self_pairs);
-        if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link && cm->hdr.ee2_link == e->ee2_link;
-        if (ok) {
+    if (m->spec_enabled && (reinterpret_cast<uintptr_t>(point_pos_out) & 15) == 0) {
+        // generated kernel with this point set baked in whose cost columns equal the cost model's
+        if (const SpecEntry* e = points_spec_for(ps, cm, w)) {
             SpecArgs a;
             a.C = cm->hdr; a.w = *w;
             std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
             a.q = q; a.n = n; a.link_pos = point_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
             a.stamps = nullptr; a.io_f16 = 0;
-            const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Z[3] = {0, 0, 0};
-            const int base_id = std::memcmp(a.base_R, I, sizeof(I)) == 0 && std::memcmp(a.base_t, Z, sizeof(Z)) == 0;
-            e->launch(a, base_id, (hipStream_t)stream);
+            e->launch(a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }

@@ -131,3 +131,88 @@ def specialize_for_cost_spec(kin: KinModel, spec, verbose: bool = False) -> Opti
     sl = np.asarray(spec.self_link_idx, np.int32)
     pairs = [(int(sl[a]), int(sl[b])) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2)]
     return specialize(kin, [int(i) for i in spec.obj_link_idx], pairs, int(spec.ee_link), verbose, ee2_link=int(spec.ee2_link))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# attached-point units (link spheres, grasped-object points): same mechanism, codegen.generate_points_rollout_source
+# ----------------------------------------------------------------------------------------------------------------------
+def _points_template_of(kin: KinModel, point_link, point_offset, spec) -> Optional[codegen.PointsTemplate]:
+    pl = np.ascontiguousarray(point_link, np.int32).reshape(-1)
+    po = np.ascontiguousarray(point_offset, np.float32).reshape(-1, 3)
+    if spec.n_links_in != len(pl):
+        return None
+    pos_of = {int(kin.order[p]): p for p in range(kin.n_links)}
+    rank = [pos_of[int(i)] for i in pl]
+    obj = [int(c) for c in spec.obj_link_idx]
+    if any(rank[k] > rank[k + 1] for k in range(len(rank) - 1)) or sorted(obj) != obj:
+        return None                                # the generator needs walk-ordered columns / increasing collision columns
+    sl = np.asarray(spec.self_link_idx, np.int32)
+    pairs = [(int(sl[a]), int(sl[b])) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2)]
+    return codegen.PointsTemplate(point_link=pl, point_offset=po, obj_cols=obj, self_pairs=pairs, ee_link=int(spec.ee_link),
+                                  ee2_link=int(spec.ee2_link))
+
+
+def _points_template_hash(pt: codegen.PointsTemplate) -> str:
+    h = hashlib.sha1()
+    h.update(np.asarray(pt.obj_cols, np.int32).tobytes())
+    h.update(np.asarray(pt.self_pairs, np.int32).reshape(-1).tobytes())
+    h.update(np.asarray([pt.ee_link, pt.ee2_link], np.int32).tobytes())
+    return h.hexdigest()[:8]
+
+
+def _points_serves(unit: codegen.PointsTemplate, want: codegen.PointsTemplate) -> bool:
+    if codegen.points_hash(unit.point_link, unit.point_offset) != codegen.points_hash(want.point_link, want.point_offset):
+        return False
+    if list(unit.obj_cols) != list(want.obj_cols) or [tuple(p) for p in unit.self_pairs] != [tuple(p) for p in want.self_pairs]:
+        return False
+    return want.ee_link < 0 or (unit.ee_link == want.ee_link and unit.ee2_link == want.ee2_link)
+
+
+_loaded_point_templates: Dict[str, Tuple[int, codegen.PointsTemplate]] = {}
+
+
+def has_matching_points_unit(kin: KinModel, point_link, point_offset, spec) -> bool:
+    want = _points_template_of(kin, point_link, point_offset, spec)
+    if want is None:
+        return False
+    h = codegen.model_hash(kin)
+    for mh, pt in _loaded_point_templates.values():
+        if mh == h and _points_serves(pt, want):
+            return True
+    from .kinematics import URDF_DIR
+    for ident, (urdf, fn) in codegen.SPEC_POINT_ROBOTS.items():
+        k2 = KinModel.from_urdf(str(URDF_DIR / urdf))
+        if codegen.model_hash(k2) == h and _points_serves(fn(k2), want):
+            return True
+    return False
+
+
+def specialize_points(kin: KinModel, point_link, point_offset, spec, verbose: bool = False) -> Optional[str]:
+    """Generated fused kernel for a robot whose collision columns are attached points (RobotPanda with another sphere
+    table, another grasped object ...).  Returns None when the column layout is not one the generator handles."""
+    pt = _points_template_of(kin, point_link, point_offset, spec)
+    if pt is None:
+        return None
+    ident = (f"jitp_{codegen.model_hash(kin):016x}_{codegen.points_hash(pt.point_link, pt.point_offset):016x}_"
+             f"{_points_template_hash(pt)}")
+    if ident in _loaded:
+        return ident
+    JIT_DIR.mkdir(parents=True, exist_ok=True)
+    src, so, stamp = JIT_DIR / f"spec_{ident}.hip", JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
+    want = _generator_stamp()
+    if not (so.exists() and stamp.exists() and stamp.read_text() == want):
+        src.write_text(codegen.generate_points_rollout_source(kin, pt, ident))
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+               "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
+               "-Xarch_device", "-mno-amdgpu-ieee", "-shared", str(src), "-o", str(so), f"-L{_CSRC}", "-ltrk",
+               "-Wl,-rpath,$ORIGIN/.."]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise _lib.TrkError(f"compiling {src.name} failed:\n{res.stdout}\n{res.stderr}")
+        if verbose:
+            print(res.stderr)
+        stamp.write_text(want)
+    _lib.lib()
+    _loaded[ident] = C.CDLL(str(so))
+    _loaded_point_templates[ident] = (codegen.model_hash(kin), pt)
+    return ident

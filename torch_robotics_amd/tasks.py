@@ -102,11 +102,16 @@ class PlanningTask(Task):
         if self._fused is None or self._fused[2] != str(device):
             spec = self.build_cost_spec()
             self._fused = (self.robot.diff_panda._handle, ops.CostHandle(spec, device), str(device))
-            if self.auto_specialize and not self._jit_failed and not getattr(self.robot, "has_extra_points", False):
+            if self.auto_specialize and not self._jit_failed:
                 try:                                   # a unit whose template equals this cost model may already exist
                     from . import jit
-                    if not jit.has_matching_unit(self.robot.diff_panda._kin, spec):
-                        jit.specialize_for_cost_spec(self.robot.diff_panda._kin, spec)
+                    kin = self.robot.diff_panda._kin
+                    if getattr(self.robot, "has_extra_points", False):
+                        pl, po = self.robot.collision_point_set()
+                        if not jit.has_matching_points_unit(kin, pl, po, spec):
+                            jit.specialize_points(kin, pl, po, spec)
+                    elif not jit.has_matching_unit(kin, spec):
+                        jit.specialize_for_cost_spec(kin, spec)
                 except Exception as e:                 # no hipcc / compile error: the table-driven kernels still serve
                     import warnings
                     self._jit_failed = True
