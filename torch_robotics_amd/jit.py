@@ -22,6 +22,8 @@ from . import _lib, codegen
 from .kinmodel import KinModel
 
 JIT_DIR = Path(__file__).resolve().parent / "csrc" / "jit"
+# same code-generation flags as csrc/Makefile uses for the ahead-of-time units
+GENFLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 _CSRC = JIT_DIR.parent
 _loaded: Dict[str, C.CDLL] = {}
 
@@ -38,6 +40,7 @@ def _generator_stamp() -> str:
     h = hashlib.sha1()
     for f in (Path(codegen.__file__), _CSRC / "trk_spec_common.h", _CSRC / "trk_device.h"):
         h.update(f.read_bytes())
+    h.update(" ".join(GENFLAGS).encode())
     return h.hexdigest()[:8]
 
 
@@ -62,7 +65,7 @@ def build_unit(kin: KinModel, tmpl: codegen.CollisionTemplate, verbose: bool = F
         raise _lib.TrkError(f"{_lib.LIB_PATH} not found: build libtrk.so first")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
            "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
-           "-Xarch_device", "-mno-amdgpu-ieee", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-shared", str(src), "-o", str(so), f"-L{_CSRC}", "-ltrk",
+           "-Xarch_device", "-mno-amdgpu-ieee", *GENFLAGS, "-shared", str(src), "-o", str(so), f"-L{_CSRC}", "-ltrk",
            "-Wl,-rpath,$ORIGIN/.."]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
@@ -204,7 +207,7 @@ def specialize_points(kin: KinModel, point_link, point_offset, spec, verbose: bo
         src.write_text(codegen.generate_points_rollout_source(kin, pt, ident))
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
                "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
-               "-Xarch_device", "-mno-amdgpu-ieee", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-shared", str(src), "-o", str(so), f"-L{_CSRC}", "-ltrk",
+               "-Xarch_device", "-mno-amdgpu-ieee", *GENFLAGS, "-shared", str(src), "-o", str(so), f"-L{_CSRC}", "-ltrk",
                "-Wl,-rpath,$ORIGIN/.."]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
