@@ -200,7 +200,6 @@ def main():
 
     if rank == 0 and args.cpu_seconds > 0:
         from oracle import oracle as orc          # checker / baseline only: never on the product path
-        from torch_robotics_amd.kinmodel import KinModel
         o = orc.Oracle(robot.diff_panda._kin, task.build_cost_spec())
         q_host = q.reshape(-1, D).cpu().numpy()
         cores = orc.max_threads()

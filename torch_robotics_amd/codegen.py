@@ -17,7 +17,6 @@ Math restated from the reference: rigid_body.py:146-211 (joint transforms), SURV
 """
 from __future__ import annotations
 
-import struct
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 

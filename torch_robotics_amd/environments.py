@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import itertools
 from copy import copy
-from typing import List, Optional
+from typing import List
 
 import numpy as np
 import torch

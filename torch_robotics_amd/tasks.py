@@ -4,7 +4,6 @@ from __future__ import annotations
 
 import os
 from functools import partial
-from typing import Optional
 
 import numpy as np
 import torch
