@@ -364,11 +364,13 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # small arms fit 128 VGPRs (4 waves/SIMD: the whole 4096 x 64 batch resident); big trees get 256 VGPRs
         E.raw("template <class IO>      // HBM-side type of q / link_pos / gq: float or _Float16")
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
-        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(3 * L, D)} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
+        chunked = 3 * L > CHUNKED_STAGING_MIN_FLOATS and [int(v) for v in kin.order] == list(range(L))
+        lds_lane = max(CHUNK_FLOATS, D) if chunked else max(3 * L, D)
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_lane} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
-        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(3 * L, D)});")
-        E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {max(3 * L, D)}) + wave * TRK_LDS_SPHERES;")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_lane});")
+        E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {lds_lane}) + wave * TRK_LDS_SPHERES;")
         E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
         E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;     // index of this wave's 64-sample block")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
@@ -389,15 +391,42 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
             t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
         _emit_angles(E, kin)
+        if chunked:
+            # Many links: a full [64][3L] staging tile per wavefront (92 KB per workgroup for 30 links) leaves ONE workgroup per
+            # CU.  The positions leave in 36-float column chunks instead (spec_flush_chunk), each link written as it exists.
+            E.raw("    IO* pos_out = static_cast<IO*>(A.link_pos);")
+            E.raw(f"    float* prow = lds + lane * {CHUNK_FLOATS};")
+            E.raw("    spec_wave_sync();")
+            chunk_start = 0
+            W = 3 * L
+            V = 4 if W % 4 == 0 else (2 if W % 2 == 0 else 1)
+            assert [int(v) for v in kin.order] == list(range(L)), "chunked staging needs file order == walk order"
+
+            def stage_link(i):
+                nonlocal chunk_start
+                for k in range(3):
+                    f = 3 * i + k
+                    E.raw(f"    prow[{f - chunk_start}] = {E.expr(t[i][k])};")
+                    if f + 1 - chunk_start == CHUNK_FLOATS or f + 1 == W:
+                        nf = f + 1 - chunk_start
+                        E.raw(f"    if (pos_out) spec_flush_chunk<{W}, {nf}, {CHUNK_FLOATS}, {V}, IO>(pos_out, base, {chunk_start}, rows, lane, lds);")
+                        chunk_start = f + 1
+            stage_link(0)
         for p in range(1, L):
-            _emit_fk_link(E, kin, int(kin.order[p]), R, t, passv, snap)
+            i = int(kin.order[p])
+            _emit_fk_link(E, kin, i, R, t, passv, snap)
+            if chunked:
+                stage_link(i)
         # ---------------- outputs that depend only on FK ----------------
-        pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
-        E.raw(f"    PosFlusher<{3 * L}, IO> flush{{nullptr, nullptr, lane, PosFlusher<{3 * L}, IO>::NCHUNK}};")
-        E.raw("    if (A.link_pos) {")
-        E.raw(f"        const float pv[{3 * L}] = {{{pos_list}}};")
-        E.raw(f"        flush = spec_stage_rows<{3 * L}>(static_cast<IO*>(A.link_pos), base, rows, lane, lds, pv);")
-        E.raw("    }")
+        if chunked:
+            E.raw("    NoFlush flush;")
+        else:
+            E.raw(f"    PosFlusher<{3 * L}, IO> flush{{nullptr, nullptr, lane, PosFlusher<{3 * L}, IO>::NCHUNK}};")
+            pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
+            E.raw("    if (A.link_pos) {")
+            E.raw(f"        const float pv[{3 * L}] = {{{pos_list}}};")
+            E.raw(f"        flush = spec_stage_rows<{3 * L}>(static_cast<IO*>(A.link_pos), base, rows, lane, lds, pv);")
+            E.raw("    }")
         E.raw("    if (!A.gq) { flush.flush(); return; }      // positions only (trk_fk_positions): wave-uniform exit")
         E.raw("    flush(); flush();")
         E.raw("    spec_stamp(A.stamps, wblock, 3, lane);")
@@ -405,7 +434,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    float cost = 0.0f;")
         for i in adj_links:
             E.raw(f"    float tb{i}_0 = 0.0f, tb{i}_1 = 0.0f, tb{i}_2 = 0.0f;")
-        if NL > 0:
+        if 0 < NL <= LINK_OBJ_GROUP_MAX:
             for k, nm in enumerate("xyz"):
                 E.raw(f"    const float p{nm}[NL] = {{{', '.join(E.expr(t[i][k]) for i in tmpl.obj_links)}}};")
             E.raw("    float gx[NL], gy[NL], gz[NL];")
@@ -415,6 +444,25 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
             for j, i in enumerate(tmpl.obj_links):
                 E.raw(f"    tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
+        elif NL > 0:
+            # many collision links (tree robots): score them in groups so the working set of one scene evaluation
+            # (positions, keys, gradients: ~10 registers per link) does not sit on top of everything the reverse pass keeps
+            n_groups = -(-NL // LINK_OBJ_GROUP)
+            size = -(-NL // n_groups)
+            for g0 in range(0, NL, size):
+                grp = list(tmpl.obj_links[g0:g0 + size])
+                n = len(grp)
+                E.raw("    {")
+                for k, nm in enumerate("xyz"):
+                    E.raw(f"        const float p{nm}[{n}] = {{{', '.join(E.expr(t[i][k]) for i in grp)}}};")
+                E.raw(f"        float gx[{n}], gy[{n}], gz[{n}];")
+                E.raw("#pragma unroll")
+                E.raw(f"        for (int l = 0; l < {n}; ++l) {{ gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }}")
+                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, flush, lds_sph, {g0});")
+                E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<{n}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {g0});")
+                for j, i in enumerate(grp):
+                    E.raw(f"        tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
+                E.raw("    }")
         if tmpl.self_pairs:
             E.raw("    if (A.w.w_self != 0.0f) {")
             for pi, (a, b) in enumerate(tmpl.self_pairs):
@@ -449,6 +497,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("        if (lane == 0 && rows > 0) A.cost_sum[wblock] = tot;")
         E.raw("    }")
         # ---------------- reverse: wrench accumulators towards the root ----------------
+        # (A second FK walk with prefix-sum gradients instead of this reverse pass -- so that the joints' axes / origins need not
+        # stay alive -- was measured on UR10+Allegro: 41.3 vs 37.5 us.  These kernels are bound by VALU issue, not by occupancy.)
         gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"tb{i}_{k}" for k in range(3)] for i in adj_links},
                                       {l: rb for l, _, rb in tracked}, masked, tick="    flush();")
         E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
@@ -546,6 +596,9 @@ class PointsTemplate:
     ee2_link: int = -1                      # second tracked LINK (two-arm scenes)
 
 
+CHUNKED_STAGING_MIN_FLOATS = 80       # link kernels with more position floats per sample than this stream them out in chunks
+LINK_OBJ_GROUP_MAX = 12    # link kernels: up to this many collision links are scored in one scene evaluation (more ILP: dual Panda 5+5 was ~1 us slower) ...
+LINK_OBJ_GROUP = 5         # ... more are split into groups of about this size
 CHUNK_FLOATS = 36          # 12 columns: 144 B per sample and chunk, a multiple of 16 B
 OBJ_GROUP = 6              # points evaluated against the scene together (register arrays of this size)
 

@@ -200,6 +200,12 @@ struct PosFlusher {
     }
 };
 
+// stand-in for PosFlusher in kernels whose positions leave through spec_flush_chunk instead
+struct NoFlush {
+    __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void flush() const {}
+};
+
 // stage the wave's rows in LDS; returns a flusher (fast path) or writes everything now (ragged / unaligned tail)
 template <int W, class IO>
 __device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows(IO* __restrict__ out, int64_t base, int rows, int lane,
@@ -268,6 +274,23 @@ __device__ __forceinline__ void spec_load_chunk(const float* __restrict__ in, in
         }
     }
     spec_wave_sync();
+}
+
+// same, for rows the kernel has already written to lds[lane * W + j] piecemeal (robots with many links: staging each
+// link's position as soon as it exists keeps 3L values from being live at once)
+template <int W, class IO>
+__device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows_prefilled(IO* __restrict__ out, int64_t base, int rows, int lane,
+                                                                       float* lds) {
+    spec_wave_sync();
+    IO* dst = out + base * W;
+    PosFlusher<W, IO> f{reinterpret_cast<const float4*>(lds), dst, lane, 0};
+    const bool fast = rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & IoQuad<IO>::kAlignMask) == 0);
+    if (!fast) {
+        const int count = rows * W;
+        for (int k = lane; k < count; k += TRK_WAVE) dst[k] = (IO)lds[k];
+        f.next = PosFlusher<W, IO>::NCHUNK;
+    }
+    return f;
 }
 
 // profiling hook: lane 0 of a wave records the shader clock at phase `k` (no-op when A.stamps == nullptr)
