@@ -588,7 +588,7 @@ def test_gp_prior_vs_fp64_oracle(ops, oracle_lib):
         ops.gp_prior_cost_grad(dev(np.zeros((2, 3), np.float32)), dev(np.zeros((2, 3), np.float32)), 0.1, 0.1)
 
 
-@pytest.mark.parametrize("robot,ident", [("panda_arm_no_gripper", "panda"), ("dual_panda", "dual_panda")])
+@pytest.mark.parametrize("robot,ident", [("panda_arm_no_gripper", "panda"), ("dual_panda", "dual_panda"), ("ur10_allegro", "ur10_allegro")])
 def test_rollout_fp16_io(ops, oracle_lib, robot, ident):
     """fp16 q / link_pos / gq in HBM, fp32 arithmetic and cost (BASELINE config 5; build-defined): specialised and
     table-driven kernels against the fp64 oracle evaluated on the same fp16-rounded q.  Tolerance = one fp16 rounding of
