@@ -808,10 +808,10 @@ def test_two_tracked_end_effectors(ops, oracle_lib):
             assert rel_err(cost.cpu().numpy().reshape(-1), rc2) < TOL_C and rel_err(gq.cpu().numpy().reshape(rg2.shape), rg2) < TOL_G
 
 
-@pytest.mark.parametrize("robot", ["hab_stretch", "tiago_dual_holobase_minimal_holonomic", "shadow_hand"])
+@pytest.mark.parametrize("robot", ROBOTS)
 def test_runtime_compiled_kernels_on_trees_with_prismatic_joints(ops, oracle_lib, robot):
-    """jit.specialize on the reference's other robots: trees, prismatic joints, axes that degenerate to +-z, a URDF whose
-    file order is not a pre-order walk (hab_stretch) -- generated kernel vs table-driven vs fp64 oracle."""
+    """jit.specialize on every robot of the golden set: chains, trees, prismatic joints, axes that degenerate to +-z, a URDF
+    whose file order is not a pre-order walk (hab_stretch) -- generated kernel vs table-driven vs fp64 oracle."""
     from torch_robotics_amd import jit
     from torch_robotics_amd.costmodel import CostModelSpec
     from torch_robotics_amd.environments import EnvSpheres3D
