@@ -850,3 +850,34 @@ def test_runtime_compiled_kernels_on_trees_with_prismatic_joints(ops, oracle_lib
     w = rng.standard_normal((130, m.n_links, 3)).astype(np.float32)
     gH = np.zeros((130, m.n_links, 4, 4)); gH[..., :3, 3] = w
     assert rel_err(ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy(), o.fk_backward(q.astype(np.float64), gH, "f64")) < TOL_G
+
+
+def test_empty_batches_everywhere(ops):
+    """N = 0 through every entry point: no launch, correctly shaped empty outputs, no error."""
+    m = model("panda_arm_no_gripper")
+    h = ops.ModelHandle(m)
+    spec = panda_cost_spec(gold("cost_spheres3d"), gold("panda_robot"), ee_target=np.eye(4, dtype=np.float32))
+    cm = ops.CostHandle(spec, DEV)
+    q0 = torch.empty((0, 7), device=DEV)
+    assert ops.fk_forward(h, q0).shape == (0, 11, 4, 4)
+    assert ops.fk_positions(h, q0).shape == (0, 11, 3)
+    assert ops.fk_backward(h, q0, torch.empty((0, 11, 4, 4), device=DEV)).shape == (0, 7)
+    assert ops.fk_positions_backward(h, q0, torch.empty((0, 11, 3), device=DEV)).shape == (0, 7)
+    pos, quat, lin, ang = ops.fk_jacobian(h, q0, None, 10)[:4]
+    assert pos.shape == (0, 3) and lin.shape == (0, 3, 7)
+    assert ops.fk_analytic_jacobian(h, q0).shape == (0, 11, 7, 7)
+    assert ops.rotmat_to_quat(torch.empty((0, 3, 3), device=DEV)).shape[0] == 0
+    lp = torch.empty((0, 11, 3), device=DEV)
+    assert ops.cost_fields(cm, 7, lp).shape == (0,)
+    assert ops.collision_fields(cm, 7, lp).shape == (0,)
+    assert ops.ee_cost(cm, torch.empty((0, 4, 4), device=DEV)).shape == (0,)
+    pos, cost, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), torch.empty((0, 64, 7), device=DEV))
+    assert pos.shape == (0, 64, 11, 3) and cost.shape == (0, 64) and gq.shape == (0, 64, 7)
+    ps = ops.PointSetHandle(h, np.arange(11, dtype=np.int32), np.zeros((11, 3), np.float32), DEV)
+    assert ops.fk_points(ps, q0).shape == (0, 11, 3)
+    assert ops.fk_points_backward(ps, q0, lp).shape == (0, 7)
+    assert ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 1), q0)[1].shape == (0,)
+    c, gq_, gqd = ops.gp_prior_cost_grad(torch.empty((0, 8, 7), device=DEV), torch.empty((0, 8, 7), device=DEV), 0.1, 0.1)
+    assert c.shape == (0,) and gq_.shape == (0, 8, 7)
+    assert ops.interpolate_traj_via_points(torch.empty((0, 8, 7), device=DEV), 5).shape == (0, 35, 7)
+    assert float(ops.reduce_sum(torch.empty((0,), device=DEV))) == 0.0
