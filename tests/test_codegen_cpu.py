@@ -74,3 +74,28 @@ def test_runtime_model_compiler_builds_and_loads_a_unit():
     assert jit.specialize(kin, obj_links=[3, 5, 7], self_pairs=[(7, 1), (6, 2)], ee_link=kin.n_links - 1) == ident   # idempotent
     other = jit.unit_ident(kin, __import__("torch_robotics_amd").codegen.CollisionTemplate(obj_links=[3, 5], ee_link=-1))
     assert other != ident
+
+
+def test_concurrent_jit_builds_do_not_corrupt_each_other(tmp_path):
+    """One process per GPU means several ranks may compile the same unit at once: every file must appear atomically."""
+    import subprocess, sys
+    from torch_robotics_amd import jit
+    from torch_robotics_amd.kinematics import URDF_DIR
+    from torch_robotics_amd.kinmodel import KinModel
+    kin = KinModel.from_urdf(str(URDF_DIR / "ur10.urdf"))
+    tmpl = __import__("torch_robotics_amd").codegen.CollisionTemplate(obj_links=[2, 4, 6], ee_link=kin.n_links - 1)
+    ident = jit.unit_ident(kin, tmpl)
+    for ext in ("so", "hip", "stamp"):
+        (jit.JIT_DIR / f"spec_{ident}.{ext}").unlink(missing_ok=True)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from torch_robotics_amd import jit\n"
+            "from torch_robotics_amd.kinematics import URDF_DIR\n"
+            "from torch_robotics_amd.kinmodel import KinModel\n"
+            "kin = KinModel.from_urdf(str(URDF_DIR / 'ur10.urdf'))\n"
+            "print(jit.specialize(kin, [2, 4, 6], [], kin.n_links - 1))\n") % str(jit.JIT_DIR.parents[2])
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(3)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-400:] for o in outs]
+    assert all(o[0].strip().endswith(ident) for o in outs)
+    assert (jit.JIT_DIR / f"spec_{ident}.so").stat().st_size > 10000
+    assert not list(jit.JIT_DIR.glob("*.tmp*"))

@@ -44,6 +44,39 @@ def _generator_stamp() -> str:
     return h.hexdigest()[:8]
 
 
+def _compile_unit(source: str, ident: str, verbose: bool) -> Path:
+    """source -> csrc/jit/spec_<ident>.so.  Every file appears under its final name by an atomic rename, so several
+    processes (one per GPU) compiling the same unit at the same time cannot hand each other a half-written object."""
+    import os
+    JIT_DIR.mkdir(parents=True, exist_ok=True)
+    src, so, stamp = JIT_DIR / f"spec_{ident}.hip", JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
+    want = _generator_stamp()
+    if so.exists() and stamp.exists() and stamp.read_text() == want:
+        return so
+    if not _lib.LIB_PATH.exists():
+        raise _lib.TrkError(f"{_lib.LIB_PATH} not found: build libtrk.so first")
+    tag = f".tmp{os.getpid()}"
+    src_tmp = JIT_DIR / f"spec_{ident}{tag}.hip"
+    so_tmp = JIT_DIR / f"spec_{ident}{tag}.so"
+    src_tmp.write_text(source)
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+           "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
+           "-Xarch_device", "-mno-amdgpu-ieee", *GENFLAGS, "-shared", str(src_tmp), "-o", str(so_tmp), f"-L{_CSRC}", "-ltrk",
+           "-Wl,-rpath,$ORIGIN/.."]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        src_tmp.unlink(missing_ok=True)
+        raise _lib.TrkError(f"compiling spec_{ident}.hip failed:\n{res.stdout}\n{res.stderr}")
+    if verbose:
+        print(res.stderr)
+    os.replace(src_tmp, src)
+    os.replace(so_tmp, so)
+    stamp_tmp = JIT_DIR / f"spec_{ident}{tag}.stamp"
+    stamp_tmp.write_text(want)
+    os.replace(stamp_tmp, stamp)
+    return so
+
+
 def unit_ident(kin: KinModel, tmpl: codegen.CollisionTemplate, pipeline: bool = False) -> str:
     return f"jit_{codegen.model_hash(kin):016x}_{template_hash(tmpl)}" + ("_p" if pipeline else "")
 
@@ -52,28 +85,14 @@ def build_unit(kin: KinModel, tmpl: codegen.CollisionTemplate, verbose: bool = F
     """Generate + compile (no GPU needed: hipcc cross-compiles); returns the path of the shared object.
     pipeline: force the per-link pipeline generator (codegen.generate_points_rollout_source in link mode)."""
     ident = unit_ident(kin, tmpl, pipeline)
-    JIT_DIR.mkdir(parents=True, exist_ok=True)
-    src, so, stamp = JIT_DIR / f"spec_{ident}.hip", JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
-    want = _generator_stamp()
-    if so.exists() and stamp.exists() and stamp.read_text() == want:
+    so, stamp = JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
+    if so.exists() and stamp.exists() and stamp.read_text() == _generator_stamp():
         return so
     if pipeline:
-        src.write_text(codegen.generate_points_rollout_source(kin, codegen.link_points_template(kin, tmpl), ident, link_mode=True))
+        source = codegen.generate_points_rollout_source(kin, codegen.link_points_template(kin, tmpl), ident, link_mode=True)
     else:
-        src.write_text(codegen.generate_link_kernel_source(kin, tmpl, ident))
-    if not _lib.LIB_PATH.exists():
-        raise _lib.TrkError(f"{_lib.LIB_PATH} not found: build libtrk.so first")
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
-           "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
-           "-Xarch_device", "-mno-amdgpu-ieee", *GENFLAGS, "-shared", str(src), "-o", str(so), f"-L{_CSRC}", "-ltrk",
-           "-Wl,-rpath,$ORIGIN/.."]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise _lib.TrkError(f"compiling {src.name} failed:\n{res.stdout}\n{res.stderr}")
-    if verbose:
-        print(res.stderr)
-    stamp.write_text(want)
-    return so
+        source = codegen.generate_link_kernel_source(kin, tmpl, ident)
+    return _compile_unit(source, ident, verbose)
 
 
 def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tuple[int, int]] = (), ee_link: int = -1,
@@ -200,21 +219,9 @@ def specialize_points(kin: KinModel, point_link, point_offset, spec, verbose: bo
              f"{_points_template_hash(pt)}")
     if ident in _loaded:
         return ident
-    JIT_DIR.mkdir(parents=True, exist_ok=True)
-    src, so, stamp = JIT_DIR / f"spec_{ident}.hip", JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
-    want = _generator_stamp()
-    if not (so.exists() and stamp.exists() and stamp.read_text() == want):
-        src.write_text(codegen.generate_points_rollout_source(kin, pt, ident))
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
-               "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
-               "-Xarch_device", "-mno-amdgpu-ieee", *GENFLAGS, "-shared", str(src), "-o", str(so), f"-L{_CSRC}", "-ltrk",
-               "-Wl,-rpath,$ORIGIN/.."]
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise _lib.TrkError(f"compiling {src.name} failed:\n{res.stdout}\n{res.stderr}")
-        if verbose:
-            print(res.stderr)
-        stamp.write_text(want)
+    so, stamp = JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
+    if not (so.exists() and stamp.exists() and stamp.read_text() == _generator_stamp()):
+        so = _compile_unit(codegen.generate_points_rollout_source(kin, pt, ident), ident, verbose)
     _lib.lib()
     _loaded[ident] = C.CDLL(str(so))
     _loaded_point_templates[ident] = (codegen.model_hash(kin), pt)
