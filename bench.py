@@ -198,7 +198,7 @@ def main():
                      "bytes_per_sample": algorithmic_bytes_per_sample(D, L), "launch_us": launch_s * 1e6},
     }
 
-    if rank == 0 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:       # CPU baseline: rank 0 at N = 1 only
         from oracle import oracle as orc          # checker / baseline only: never on the product path
         o = orc.Oracle(robot.diff_panda._kin, task.build_cost_spec())
         q_host = q.reshape(-1, D).cpu().numpy()
