@@ -10,7 +10,8 @@ Workload (BASELINE.json configs[1], "c2"): batch 4096 x horizon 64, Panda (11 li
 EnvSpheres3D (10 spheres, analytic SDF, cutoff 0.03), cost = object collision + EE SE(3) tracking
 (target p=(0.4,0.2,0.5), R=I).  `--config c3` adds self-collision pairs and the workspace box.
 Multi-GPU: the batch is sharded, each rank owns 4096 x 64 samples (weak scaling); the only exchange is an
-RCCL all-reduce of the summed cost, issued once per `--reduce-every` steps on a side stream.
+RCCL all-reduce of the packed sums [cost | cost per time step | gradient per time step and joint] (2 kB), issued once per
+`--reduce-every` steps on a side stream.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = 192 algorithmic bytes/sample x samples per launch /
 average launch duration (HIP events around the timed region on the launch stream).
@@ -92,18 +93,22 @@ def main():
     block_sums = torch.zeros(nb, **ta)
     bs_ptr = block_sums.data_ptr()
     n_slots = (args.warmup + args.steps) // max(1, args.reduce_every) + 8
-    cost_sums = torch.zeros(n_slots, **ta)
+    # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
+    packed = torch.zeros((n_slots, 1 + H + H * D), **ta)
     stream = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev) if world > 1 else None
 
     def reduce_slot(k):
-        # scalar of the latest evaluation -> one tiny all-reduce, off the launch stream
-        ops.reduce_sum(block_sums, out=cost_sums[k:k + 1])
+        # sums of the latest evaluation -> one small all-reduce (2 kB), off the launch stream
+        buf = packed[k]
+        ops.reduce_sum(block_sums, out=buf[0:1])
+        torch.sum(plan.cost, dim=0, out=buf[1:1 + H])
+        torch.sum(plan.gq, dim=0, out=buf[1 + H:].view(H, D))
         ev = torch.cuda.Event()
         ev.record(stream)
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            dist.all_reduce(cost_sums[k:k + 1])
+            dist.all_reduce(buf)
 
     graph = None
     if args.graph > 0:
