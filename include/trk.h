@@ -371,6 +371,16 @@ int trk_gp_prior_cost_grad(const void* q, const void* qd, int64_t batch, int32_t
                            float dt, float sigma, float weight, float* cost, void* gq, void* gqd, int32_t accumulate,
                            trk_stream_t stream);
 
+/* reference: finite_difference_vector trajectory/utils.py:53-64 (RobotBase.get_velocity / get_acceleration
+ * robot_base.py:151-166): zero-padded differences along the horizon.  x, out [batch, horizon, dim];
+ * method 0 = forward, 1 = backward, 2 = central. */
+int trk_finite_difference(const float* x, int64_t batch, int32_t horizon, int32_t dim, float dt, int32_t method,
+                          float* out, trk_stream_t stream);
+/* reference: compute_path_length / compute_smoothness trajectory/metrics.py:7-12, 27-35:
+ * out[b] = sum_t || x[b, t+1, c0:c0+dim] - x[b, t, c0:c0+dim] ||, x [batch, horizon, state_dim]. */
+int trk_traj_diff_norm_sum(const float* x, int64_t batch, int32_t horizon, int32_t state_dim, int32_t c0, int32_t dim,
+                           float* out, trk_stream_t stream);
+
 /* Profiling hook (process-global, NULL = off): DEVICE uint64[ceil(N/64)][8]; the model-specialised fused kernel then
  * records the shader clock (s_memtime) of every wavefront at 8 phase boundaries (entry, q loaded, FK done, positions
  * staged, objects done, objectives done, reverse done, exit).  Used by tools/phase_profile.py; never set in production. */

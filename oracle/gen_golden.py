@@ -432,6 +432,23 @@ def trajs_goldens():
     np.savez_compressed(GOLD / "trajs_panda.npz", **out)
 
 
+def metrics_goldens():
+    """A17: compute_path_length / compute_smoothness (trajectory/metrics.py:7-12, 27-35), RobotBase.get_velocity /
+    get_acceleration (robot_base.py:151-166).  `python oracle/gen_golden.py metrics` regenerates only this file."""
+    from torch_robotics.robots.robot_panda import RobotPanda
+    from torch_robotics.trajectory.metrics import compute_path_length, compute_smoothness
+    robot = quiet(RobotPanda, tensor_args=TA)
+    gen = torch.Generator().manual_seed(88)
+    trajs = torch.cumsum(0.05 * torch.randn(9, 33, 7, generator=gen), dim=1)
+    full = torch.cat([trajs, 0.3 * torch.randn(9, 33, 7, generator=gen)], dim=-1)      # positions + velocities
+    np.savez_compressed(GOLD / "metrics_panda.npz", trajs=trajs.numpy(), full=full.numpy(),
+                        path_length=compute_path_length(trajs, robot).numpy(),
+                        smoothness_fd=compute_smoothness(trajs, robot).numpy(),       # velocities by finite differences
+                        smoothness_vel=compute_smoothness(full, robot).numpy(),       # velocities carried in the state
+                        vel_fd=robot.get_velocity(trajs).numpy(), acc_fd=robot.get_acceleration(trajs).numpy())
+    print("metrics_panda: 9 x 33")
+
+
 def ik_goldens(trees):
     """8f rank 2: loss_fn_ik_per_q / ik_termination (robot_tree.py:386-442) and Adam steps on it."""
     tree = trees["panda_arm_no_gripper"]
@@ -616,6 +633,9 @@ def main():
     if sys.argv[1:] == ["points"]:
         points_goldens()
         return
+    if sys.argv[1:] == ["metrics"]:
+        metrics_goldens()
+        return
     if sys.argv[1:] == ["spheres"]:
         sphere_config_data()
         return
@@ -647,6 +667,7 @@ def main():
     misc_goldens()
     points_goldens()
     sphere_config_data()
+    metrics_goldens()
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
 

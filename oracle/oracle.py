@@ -257,3 +257,22 @@ def gp_prior(q, qd, dt, sigma, weight=1.0, prec="f64"):
     getattr(lib(), "orc_gp_prior" + suf)(_p(q), _p(qd), C.c_int64(B), C.c_int(H), C.c_int(D), ct(dt), ct(sigma), ct(weight),
                                          _p(cost), _p(gq), _p(gqd))
     return cost, gq, gqd
+
+
+def finite_difference(x, dt=1.0, method="forward", prec="f64"):
+    npdt, ct, suf = _dt(prec)
+    x = np.ascontiguousarray(x, npdt)
+    H, D = x.shape[-2], x.shape[-1]
+    out = np.empty_like(x)
+    getattr(lib(), "orc_finite_difference" + suf)(_p(x), C.c_int64(x.size // (H * D)), C.c_int(H), C.c_int(D), ct(dt),
+                                                  C.c_int({"forward": 0, "backward": 1, "central": 2}[method]), _p(out))
+    return out
+
+
+def traj_diff_norm_sum(x, c0, dim, prec="f64"):
+    npdt, _, suf = _dt(prec)
+    x = np.ascontiguousarray(x, npdt)
+    B, H, S = x.shape
+    out = np.empty(B, npdt)
+    getattr(lib(), "orc_traj_diff_norm_sum" + suf)(_p(x), C.c_int64(B), C.c_int(H), C.c_int(S), C.c_int(c0), C.c_int(dim), _p(out))
+    return out

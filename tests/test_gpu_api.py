@@ -428,3 +428,20 @@ def test_custom_sphere_table_gets_its_own_kernel(tmp_path, oracle_lib):
     for p_, c_, g_ in ((pos, cost, gq), (pos_g, cost_g, gq_g)):
         assert np.abs(p_.cpu().numpy() - rp).max() < TOL_H
         assert rel_err(c_.cpu().numpy(), rc) < TOL_C and rel_err(g_.cpu().numpy(), rg) < TOL_G
+
+
+def test_trajectory_metrics_like_the_reference():
+    """A17: get_velocity / get_acceleration (finite differences), compute_path_length, compute_smoothness vs the reference."""
+    g, gm = gold("traj"), gold("metrics_panda")
+    robot = tra.RobotPanda(tensor_args=TA)
+    for m in ("forward", "backward", "central"):
+        out = tra.finite_difference_vector(dev(g["x"]), dt=0.25, method=m)
+        np.testing.assert_allclose(out.cpu().numpy(), g["fd_" + m], rtol=0, atol=0)
+    trajs, full = dev(gm["trajs"]), dev(gm["full"])
+    np.testing.assert_allclose(robot.get_velocity(trajs).cpu().numpy(), gm["vel_fd"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(robot.get_acceleration(trajs).cpu().numpy(), gm["acc_fd"], rtol=0, atol=1e-7)
+    assert rel_err(tra.compute_path_length(trajs, robot).cpu().numpy(), gm["path_length"]) < 2e-6
+    assert rel_err(tra.compute_smoothness(trajs, robot).cpu().numpy(), gm["smoothness_fd"]) < 2e-6
+    assert rel_err(tra.compute_smoothness(full, robot).cpu().numpy(), gm["smoothness_vel"]) < 2e-6
+    assert rel_err(tra.compute_smoothness(None, robot, trajs_vel=robot.get_velocity(full)).cpu().numpy(), gm["smoothness_vel"]) < 2e-6
+    assert tra.compute_path_length(trajs[:0], robot).shape == (0,)

@@ -140,13 +140,17 @@ def test_cpu_tensors_are_rejected_not_computed():
         robot.fk_map_collision(torch.zeros(3, 7))
 
 
-def test_finite_differences_match_reference():
-    """A17: the only 'smoothness' arithmetic the reference has (trajectory/utils.py:53-64)."""
-    from torch_robotics_amd.robots import finite_difference_vector
-    g = gold("traj")
-    x = torch.as_tensor(g["x"])
-    for m in ("forward", "backward", "central"):
-        np.testing.assert_allclose(finite_difference_vector(x, dt=0.25, method=m).numpy(), g["fd_" + m], rtol=0, atol=0)
+def test_trajectory_plumbing_has_no_cpu_path():
+    """A17 (finite differences, path length, smoothness) runs in HIP kernels: CPU tensors are rejected, not computed."""
+    from torch_robotics_amd.robots import compute_path_length, finite_difference_vector
+    x = torch.as_tensor(gold("traj")["x"])
+    with pytest.raises((ValueError, RuntimeError)):
+        finite_difference_vector(x, dt=0.25, method="central")
+    with pytest.raises((ValueError, RuntimeError)):
+        compute_path_length(x, tra.RobotPanda(tensor_args=TA))
+    with pytest.raises(NotImplementedError):
+        from torch_robotics_amd import ops
+        ops.finite_difference(x, method="nope")
 
 
 def test_grasped_object_model_matches_reference():

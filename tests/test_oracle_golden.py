@@ -315,3 +315,21 @@ def test_gp_prior_against_independent_autograd(oracle_lib, prec):
         assert rel_err(c, rc) < tol or np.abs(rc).max() == 0
         assert rel_err(gq, rgq) < tol or np.abs(rgq).max() == 0
         assert rel_err(gqd, rgqd) < tol or np.abs(rgqd).max() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A17: finite differences and trajectory metrics
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_finite_differences_and_trajectory_metrics(oracle_lib, prec):
+    g = gold("traj")
+    for m in ("forward", "backward", "central"):
+        out = oracle_lib.finite_difference(g["x"], 0.25, m, prec)
+        np.testing.assert_allclose(out, g["fd_" + m], rtol=0, atol=0 if prec == "f32" else 2e-6)
+    gm = gold("metrics_panda")
+    vel = oracle_lib.finite_difference(gm["trajs"], 1.0, "central", prec)
+    np.testing.assert_allclose(vel, gm["vel_fd"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(oracle_lib.finite_difference(vel, 1.0, "central", prec), gm["acc_fd"], rtol=0, atol=1e-7)
+    assert rel_err(oracle_lib.traj_diff_norm_sum(gm["trajs"], 0, 7, prec), gm["path_length"]) < 2e-6
+    assert rel_err(oracle_lib.traj_diff_norm_sum(vel, 0, 7, prec), gm["smoothness_fd"]) < 2e-6
+    assert rel_err(oracle_lib.traj_diff_norm_sum(gm["full"], 7, 7, prec), gm["smoothness_vel"]) < 2e-6

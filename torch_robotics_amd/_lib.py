@@ -27,7 +27,7 @@ EXPORTS = [
     "trk_grid_precompute",
     "trk_sdf_points",
     "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_point_set_is_specialized", "trk_fk_points", "trk_fk_points_backward",
-    "trk_rollout_points_cost_grad", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16",
+    "trk_rollout_points_cost_grad", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16", "trk_finite_difference", "trk_traj_diff_norm_sum",
 ]
 
 
@@ -90,6 +90,8 @@ def lib():
     L.trk_grid_precompute.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.trk_sdf_points.argtypes = [vp, vp, i64, vp, vp, vp]
     L.trk_rollout_cost_grad_f16.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, vp, vp, vp, vp, vp]
+    L.trk_finite_difference.argtypes = [vp, i64, i32, i32, f32, i32, vp, vp]
+    L.trk_traj_diff_norm_sum.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp]
     L.trk_gp_prior_cost_grad.argtypes = [vp, vp, i64, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp]
     L.trk_point_set_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
     L.trk_point_set_destroy.argtypes = [vp]

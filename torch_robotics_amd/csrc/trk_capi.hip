@@ -841,6 +841,30 @@ int trk_gp_prior_cost_grad(const void* q, const void* qd, int64_t batch, int32_t
     return TRK_OK;
 }
 
+int trk_finite_difference(const float* x, int64_t batch, int32_t horizon, int32_t dim, float dt, int32_t method, float* out,
+                          trk_stream_t stream) {
+    if (batch < 0 || horizon < 1 || dim < 1 || method < 0 || method > 2 || !(dt != 0.0f) || (batch > 0 && (!x || !out)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_finite_difference: bad argument");
+    if (batch == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_finite_difference(x, batch, horizon, dim, dt, method, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_traj_diff_norm_sum(const float* x, int64_t batch, int32_t horizon, int32_t state_dim, int32_t c0, int32_t dim, float* out,
+                           trk_stream_t stream) {
+    if (batch < 0 || batch > 0x7fffffff || horizon < 1 || dim < 1 || c0 < 0 || c0 + dim > state_dim || (batch > 0 && (!x || !out)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_traj_diff_norm_sum: bad argument");
+    if (batch == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_traj_diff_norm_sum(x, batch, horizon, state_dim, c0, dim, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
 int trk_debug_set_stamp_buffer(void* device_u64) {
     g_stamps = static_cast<unsigned long long*>(device_u64);
     return TRK_OK;

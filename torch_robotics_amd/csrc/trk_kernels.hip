@@ -1280,6 +1280,44 @@ k_gp_prior(const T* __restrict__ q, const T* __restrict__ qd, int H, int D, floa
     if (threadIdx.x == 0) cost[blockIdx.x] = w * ((part[0] + part[1]) + (part[2] + part[3]));
 }
 
+// ============================================================================================
+// Trajectory plumbing of the reference (A17): zero-padded finite differences along the horizon
+// (finite_difference_vector trajectory/utils.py:53-64, used by RobotBase.get_velocity / get_acceleration robot_base.py:151-166)
+// and  sum_t || x[t+1] - x[t] ||  over selected state columns (compute_path_length / compute_smoothness
+// trajectory/metrics.py:7-12, 27-35).  Streaming kernels; same operation order as the torch expressions.
+// ============================================================================================
+__global__ void __launch_bounds__(256)
+k_finite_difference(const float* __restrict__ x, int64_t total, int H, int D, float dt, int method, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int t = (int)((idx / D) % H);
+    float v = 0.0f;
+    if (method == 0) { if (t + 1 < H) v = (x[idx + D] - x[idx]) / dt; }                       // forward:  diff[:-1] = (x[1:] - x[:-1]) / dt
+    else if (method == 1) { if (t > 0) v = (x[idx] - x[idx - D]) / dt; }                       // backward: diff[1:]  = (x[1:] - x[:-1]) / dt
+    else { if (t > 0 && t + 1 < H) v = (x[idx + D] - x[idx - D]) / (2.0f * dt); }             // central:  diff[1:-1] = (x[2:] - x[:-2]) / (2 dt)
+    out[idx] = v;
+}
+
+// one workgroup per trajectory; x [B, H, S], columns [c0, c0 + D)
+__global__ void __launch_bounds__(256)
+k_traj_diff_norm_sum(const float* __restrict__ x, int H, int S, int c0, int D, float* __restrict__ out) {
+    __shared__ float part[4];
+    const float* tr = x + (int64_t)blockIdx.x * H * S + c0;
+    float acc = 0.0f;
+    for (int t = threadIdx.x; t + 1 < H; t += 256) {
+        float n2 = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const float df = tr[(int64_t)(t + 1) * S + d] - tr[(int64_t)t * S + d];
+            n2 = fmaf(df, df, n2);
+        }
+        acc += sqrtf(n2);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // deterministic sum: one 256-thread workgroup, fixed strides, LDS tree
 __global__ void __launch_bounds__(256)
 k_reduce_sum(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
@@ -1449,6 +1487,15 @@ int trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H
     else { if (vec) TRK_GP(float, true); else TRK_GP(float, false); }
 #undef TRK_GP
     return 0;
+}
+
+void trk_launch_finite_difference(const float* x, int64_t B, int H, int D, float dt, int method, float* out, hipStream_t st) {
+    const int64_t total = B * H * D;
+    hipLaunchKernelGGL(k_finite_difference, dim3(grid_for(total, 256)), dim3(256), 0, st, x, total, H, D, dt, method, out);
+}
+
+void trk_launch_traj_diff_norm_sum(const float* x, int64_t B, int H, int S, int c0, int D, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_traj_diff_norm_sum, dim3((unsigned)B), dim3(256), 0, st, x, H, S, c0, D, out);
 }
 
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st) {

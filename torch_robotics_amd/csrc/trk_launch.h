@@ -40,6 +40,8 @@ void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_inter
                             float* out, hipStream_t st);
 int trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
                          float* cost, void* gq, void* gqd, int accumulate, hipStream_t st);
+void trk_launch_finite_difference(const float* x, int64_t B, int H, int D, float dt, int method, float* out, hipStream_t st);
+void trk_launch_traj_diff_norm_sum(const float* x, int64_t B, int H, int S, int c0, int D, float* out, hipStream_t st);
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st);
 void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st);
 // raises the dynamic-LDS ceiling of every kernel once (gfx950: 160 KiB per workgroup)

@@ -425,6 +425,36 @@ def gp_prior_cost(q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: float) ->
     return _GPPrior.apply(q, qd, float(dt), float(sigma))
 
 
+_FD_METHODS = {"forward": 0, "backward": 1, "central": 2}
+
+
+def finite_difference(x: torch.Tensor, dt: float = 1.0, method: str = "forward") -> torch.Tensor:
+    """Zero-padded finite differences along the horizon (trajectory/utils.py:53-64): x (..., H, D) -> same shape."""
+    if method not in _FD_METHODS:
+        raise NotImplementedError
+    x = _dev_f32(x, "finite_difference(x)")
+    H, D = int(x.shape[-2]), int(x.shape[-1])
+    B = int(x.numel() // max(1, H * D))
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().trk_finite_difference(x.data_ptr(), B, H, D, float(dt), _FD_METHODS[method], out.data_ptr(), _stream(x)),
+              "trk_finite_difference")
+    return out
+
+
+def traj_diff_norm_sum(x: torch.Tensor, c0: int, dim: int) -> torch.Tensor:
+    """sum_t || x[b, t+1, c0:c0+dim] - x[b, t, c0:c0+dim] ||  for x (B, H, S) -> (B,)  (trajectory/metrics.py:7-12, 27-35)."""
+    x = _dev_f32(x, "traj_diff_norm_sum(x)")
+    if x.dim() != 3:
+        raise ValueError("traj_diff_norm_sum: x must be (batch, horizon, state_dim)")
+    B, H, S = (int(v) for v in x.shape)
+    out = torch.empty((B,), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        check(lib().trk_traj_diff_norm_sum(x.data_ptr(), B, H, S, int(c0), int(dim), out.data_ptr(), _stream(x)),
+              "trk_traj_diff_norm_sum")
+    return out
+
+
 def interpolate_traj_via_points(trajs: torch.Tensor, num_interpolation: int = 10) -> torch.Tensor:
     """trajectory/utils.py:37-50: (..., H, D) -> (..., (H-1)*num_interpolation, D); identity for num_interpolation <= 0."""
     if num_interpolation <= 0:

@@ -18,17 +18,26 @@ from .kinematics import DATA_DIR, DifferentiableFrankaPanda, link_pos_from_link_
 
 
 def finite_difference_vector(x, dt=1.0, method="forward"):
-    """trajectory/utils.py:53-64 (zero-padded finite differences along the horizon); tensor plumbing."""
-    diff = torch.zeros_like(x)
-    if method == "forward":
-        diff[..., :-1, :] = torch.diff(x, dim=-2) / dt
-    elif method == "backward":
-        diff[..., 1:, :] = (x[..., 1:, :] - x[..., :-1, :]) / dt
-    elif method == "central":
-        diff[..., 1:-1, :] = (x[..., 2:, :] - x[..., :-2, :]) / (2 * dt)
+    """trajectory/utils.py:53-64 (zero-padded finite differences along the horizon), one streaming kernel."""
+    return ops.finite_difference(x, dt=dt, method=method)
+
+
+def compute_path_length(trajs, robot):
+    """trajectory/metrics.py:7-12: sum over the horizon of the joint-space step lengths, (B, H, S) -> (B,)."""
+    assert trajs.ndim == 3
+    return ops.traj_diff_norm_sum(trajs, 0, robot.q_dim)
+
+
+def compute_smoothness(trajs, robot, trajs_vel=None):
+    """trajectory/metrics.py:27-35: sum_t || v[t+1] - v[t] ||; velocities from the state, else by central differences."""
+    if trajs_vel is None:
+        assert trajs.ndim == 3
+        if trajs.shape[-1] >= 2 * robot.q_dim:                       # velocities are carried in the state: read them in place
+            return ops.traj_diff_norm_sum(trajs, robot.q_dim, robot.q_dim)
+        trajs_vel = robot.get_velocity(trajs)
     else:
-        raise NotImplementedError
-    return diff
+        assert trajs_vel.ndim == 3
+    return ops.traj_diff_norm_sum(trajs_vel, 0, trajs_vel.shape[-1])
 
 
 class RobotBase:
