@@ -445,3 +445,24 @@ def test_trajectory_metrics_like_the_reference():
     assert rel_err(tra.compute_smoothness(full, robot).cpu().numpy(), gm["smoothness_vel"]) < 2e-6
     assert rel_err(tra.compute_smoothness(None, robot, trajs_vel=robot.get_velocity(full)).cpu().numpy(), gm["smoothness_vel"]) < 2e-6
     assert tra.compute_path_length(trajs[:0], robot).shape == (0,)
+
+
+def test_grid_map_sdf_query(oracle_lib):
+    """GridMapSDF(X): nearest-lower-cell value, gradient = the stored gradient of that cell (grid_map_sdf.py:84-114)."""
+    from torch_robotics_amd.costmodel import CostModelSpec, grid_object
+    env = tra.EnvSpheres3D(tensor_args=TA, precompute_sdf_obj_fixed=True, sdf_cell_size=0.1)
+    grid = env.grid_map_sdf_obj_fixed
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    X = ((torch.rand(500, 3, device=DEV, generator=gen) - 0.5) * 2.4).requires_grad_(True)     # some points outside the limits
+    sdf = grid(X)
+    assert sdf.shape == (500,)
+    sdf.sum().backward()
+    spec = CostModelSpec(n_links_in=1, objects=[grid_object()])
+    d = grid.grid_dict()
+    spec.grid = dict(dims=d["dims"], lim_min=d["lim_min"], map_dim=d["map_dim"], sdf=d["sdf"].cpu().numpy(), grad=d["grad"].cpu().numpy())
+    from helpers import model
+    o = oracle_lib.Oracle(model("panda_arm_no_gripper"), spec)
+    rs, rg = o.sdf_points(X.detach().cpu().numpy(), "f32")
+    np.testing.assert_array_equal(sdf.detach().cpu().numpy(), rs[:, 0])
+    np.testing.assert_array_equal(X.grad.cpu().numpy(), rg[:, 0, :])
+    assert grid(X.detach().reshape(20, 25, 3)).shape == (20, 25)

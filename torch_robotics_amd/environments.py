@@ -186,6 +186,24 @@ class GridMapSDF:                                            # grid_map_sdf.py:9
         return dict(dims=self.cmap_dim.numpy().astype(np.int32), lim_min=self.limits[0].numpy(),
                     map_dim=self.map_dim.numpy(), sdf=self.sdf_tensor, grad=self.grad_sdf_tensor)
 
+    def _query_handle(self, device):
+        if getattr(self, "_qcm", None) is None or self._qcm.device != torch.device(device):
+            spec = CostModelSpec(n_links_in=1, objects=[grid_object()])
+            spec.grid = self.grid_dict()
+            self._qcm = ops.CostHandle(spec, device)
+        return self._qcm
+
+    def compute_signed_distance(self, X, **kwargs):           # grid_map_sdf.py:81-114
+        """Nearest-lower-cell lookup; differentiable w.r.t. X with the STORED gradient of that cell, like the reference's
+        `sdf[idx] + (X * g).sum() - (X.detach() * g).sum()`."""
+        cm = self._query_handle(X.device)
+        flat = X.reshape(-1, 3)
+        if torch.is_grad_enabled() and X.requires_grad:
+            return _SDFPoints.apply(flat.contiguous(), cm).reshape(X.shape[:-1])
+        return ops.sdf_points(cm, flat).reshape(X.shape[:-1])
+
+    __call__ = compute_signed_distance
+
     def zero_grad(self):
         pass
 
