@@ -39,6 +39,29 @@ class PrimitiveShapeField:
     def compute_signed_distance(self, x):
         return ObjectField([self]).compute_signed_distance(x)
 
+    def compute_sdf(self, x, reshape_shape=None):             # env_base.py:140-169
+        """Signed distance of the scene (min over the fixed objects -- or their precomputed grid -- and the extra objects) at
+        points x (..., 3); differentiable w.r.t. x.  One `trk_sdf_points` launch for all objects."""
+        objs = self.get_df_obj_list()
+        if not objs:
+            return None
+        key = (str(x.device), tuple(id(o) for o in objs))
+        if getattr(self, "_sdf_cm", None) is None or self._sdf_cm[0] != key:
+            spec = CostModelSpec(n_links_in=1)
+            spec.objects, spec.grid = objects_to_spec_parts(objs)
+            self._sdf_cm = (key, ops.CostHandle(spec, x.device))
+        cm = self._sdf_cm[1]
+        flat = x.reshape(-1, 3)
+        if torch.is_grad_enabled() and x.requires_grad:
+            per_obj = _SDFPoints.apply(flat.contiguous(), cm)
+        else:
+            per_obj = ops.sdf_points(cm, flat)
+        sdf = per_obj.reshape(flat.shape[0], -1).min(dim=1).values
+        return sdf.reshape(reshape_shape) if reshape_shape else sdf.reshape(x.shape[:-1])
+
+    def add_obj(self, obj):                                   # env_base.py:90-92
+        raise NotImplementedError
+
     def zero_grad(self):
         pass
 
@@ -127,6 +150,29 @@ class ObjectField(PrimitiveShapeField):                      # primitives.py:346
 
     compute_signed_distance_impl = compute_signed_distance
 
+    def compute_sdf(self, x, reshape_shape=None):             # env_base.py:140-169
+        """Signed distance of the scene (min over the fixed objects -- or their precomputed grid -- and the extra objects) at
+        points x (..., 3); differentiable w.r.t. x.  One `trk_sdf_points` launch for all objects."""
+        objs = self.get_df_obj_list()
+        if not objs:
+            return None
+        key = (str(x.device), tuple(id(o) for o in objs))
+        if getattr(self, "_sdf_cm", None) is None or self._sdf_cm[0] != key:
+            spec = CostModelSpec(n_links_in=1)
+            spec.objects, spec.grid = objects_to_spec_parts(objs)
+            self._sdf_cm = (key, ops.CostHandle(spec, x.device))
+        cm = self._sdf_cm[1]
+        flat = x.reshape(-1, 3)
+        if torch.is_grad_enabled() and x.requires_grad:
+            per_obj = _SDFPoints.apply(flat.contiguous(), cm)
+        else:
+            per_obj = ops.sdf_points(cm, flat)
+        sdf = per_obj.reshape(flat.shape[0], -1).min(dim=1).values
+        return sdf.reshape(reshape_shape) if reshape_shape else sdf.reshape(x.shape[:-1])
+
+    def add_obj(self, obj):                                   # env_base.py:90-92
+        raise NotImplementedError
+
     def zero_grad(self):
         pass
 
@@ -204,6 +250,29 @@ class GridMapSDF:                                            # grid_map_sdf.py:9
 
     __call__ = compute_signed_distance
 
+    def compute_sdf(self, x, reshape_shape=None):             # env_base.py:140-169
+        """Signed distance of the scene (min over the fixed objects -- or their precomputed grid -- and the extra objects) at
+        points x (..., 3); differentiable w.r.t. x.  One `trk_sdf_points` launch for all objects."""
+        objs = self.get_df_obj_list()
+        if not objs:
+            return None
+        key = (str(x.device), tuple(id(o) for o in objs))
+        if getattr(self, "_sdf_cm", None) is None or self._sdf_cm[0] != key:
+            spec = CostModelSpec(n_links_in=1)
+            spec.objects, spec.grid = objects_to_spec_parts(objs)
+            self._sdf_cm = (key, ops.CostHandle(spec, x.device))
+        cm = self._sdf_cm[1]
+        flat = x.reshape(-1, 3)
+        if torch.is_grad_enabled() and x.requires_grad:
+            per_obj = _SDFPoints.apply(flat.contiguous(), cm)
+        else:
+            per_obj = ops.sdf_points(cm, flat)
+        sdf = per_obj.reshape(flat.shape[0], -1).min(dim=1).values
+        return sdf.reshape(reshape_shape) if reshape_shape else sdf.reshape(x.shape[:-1])
+
+    def add_obj(self, obj):                                   # env_base.py:90-92
+        raise NotImplementedError
+
     def zero_grad(self):
         pass
 
@@ -240,6 +309,29 @@ class EnvBase:                                               # env_base.py:17-10
         if self.obj_extra_list is not None:
             out.extend(self.obj_extra_list)
         return out
+
+    def compute_sdf(self, x, reshape_shape=None):             # env_base.py:140-169
+        """Signed distance of the scene (min over the fixed objects -- or their precomputed grid -- and the extra objects) at
+        points x (..., 3); differentiable w.r.t. x.  One `trk_sdf_points` launch for all objects."""
+        objs = self.get_df_obj_list()
+        if not objs:
+            return None
+        key = (str(x.device), tuple(id(o) for o in objs))
+        if getattr(self, "_sdf_cm", None) is None or self._sdf_cm[0] != key:
+            spec = CostModelSpec(n_links_in=1)
+            spec.objects, spec.grid = objects_to_spec_parts(objs)
+            self._sdf_cm = (key, ops.CostHandle(spec, x.device))
+        cm = self._sdf_cm[1]
+        flat = x.reshape(-1, 3)
+        if torch.is_grad_enabled() and x.requires_grad:
+            per_obj = _SDFPoints.apply(flat.contiguous(), cm)
+        else:
+            per_obj = ops.sdf_points(cm, flat)
+        sdf = per_obj.reshape(flat.shape[0], -1).min(dim=1).values
+        return sdf.reshape(reshape_shape) if reshape_shape else sdf.reshape(x.shape[:-1])
+
+    def add_obj(self, obj):                                   # env_base.py:90-92
+        raise NotImplementedError
 
     def zero_grad(self):
         pass
