@@ -494,3 +494,17 @@ def test_env_compute_sdf(oracle_lib, grid):
     clear = (gap[:, 1] - gap[:, 0] > 1e-5) if rs.shape[1] > 1 else np.ones(len(k), bool)     # away from arg-min ties between objects
     assert np.abs(X.grad.cpu().numpy().reshape(-1, 3)[clear] - refg[clear]).max() < (1e-5 if not grid else 1e-6)
     assert env.compute_sdf(X.detach(), reshape_shape=(420,)).shape == (420,)
+
+
+def test_random_collision_free_configurations():
+    """PlanningTask.random_coll_free_q / sample_q (tasks.py:97-129): every returned configuration is inside the limits
+    and collision free according to the same boolean fields; shapes follow the reference (squeezed)."""
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    q = task.random_coll_free_q(n_samples=50, max_samples=200)
+    assert q.shape == (50, 7) and q.device.type == "cuda"
+    assert not task.compute_collision(q).any()
+    assert bool(((q >= robot.q_min.to(q.device)) & (q <= robot.q_max.to(q.device))).all())
+    assert task.random_coll_free_q(n_samples=1).shape == (7,)
+    assert task.sample_q(n_samples=3).shape == (3, 7)
+    assert task.sample_q(without_collision=False, n_samples=4).shape == (4, 7)

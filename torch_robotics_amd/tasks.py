@@ -3,6 +3,7 @@ entry point `rollout_cost_grad`, which runs FK + every configured objective + d 
 from __future__ import annotations
 
 import os
+import sys
 from functools import partial
 
 import numpy as np
@@ -61,6 +62,34 @@ class PlanningTask(Task):
 
     def distance_q(self, q1, q2):
         return self.robot.distance_q(q1, q2)
+
+    def sample_q(self, without_collision=True, **kwargs):      # tasks.py:97-101
+        if without_collision:
+            return self.random_coll_free_q(**kwargs)
+        return self.robot.random_q(**kwargs)
+
+    def random_coll_free_q(self, n_samples=1, max_samples=1000, max_tries=1000):   # tasks.py:103-129
+        """Rejection sampling of collision-free configurations: batches of `max_samples` uniform draws go through the
+        boolean collision kernels until `n_samples` survive.  Same control flow and return shapes as the reference."""
+        dev = self.tensor_args["device"]
+        samples = torch.zeros((n_samples, self.robot.q_dim), device=dev, dtype=torch.float32)
+        idx_begin, reject = 0, True
+        for _ in range(max_tries):
+            qs = self.robot.random_q(max_samples)
+            free = torch.argwhere(self.compute_collision(qs).reshape(-1) == False).reshape(-1)   # noqa: E712
+            if free.nelement() == 0:
+                continue
+            pick = free[torch.randperm(len(free), device=free.device)[:n_samples]]
+            free_qs = qs[pick]
+            idx_end = min(idx_begin + free_qs.shape[0], samples.shape[0])
+            samples[idx_begin:idx_end] = free_qs[:idx_end - idx_begin]
+            idx_begin = idx_end
+            if idx_end >= n_samples:
+                reject = False
+                break
+        if reject:
+            sys.exit("Could not find a collision free configuration")
+        return samples.squeeze()
 
     # ---------------------------------------------------------------------------------------------
     # one cost model for the fused kernel and for compute_collision(_cost)
