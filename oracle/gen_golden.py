@@ -449,6 +449,27 @@ def metrics_goldens():
     print("metrics_panda: 9 x 33")
 
 
+def pointmass_goldens():
+    """RobotPointMass3D (robot_point_mass.py:101-109: identity FK, one collision point) through PlanningTask on
+    EnvSpheres3D.  `python oracle/gen_golden.py pointmass` regenerates only this file."""
+    from torch_robotics.robots.robot_point_mass import RobotPointMass3D
+    from torch_robotics.tasks.tasks import PlanningTask
+    from torch_robotics.environments.env_spheres_3d import EnvSpheres3D
+    robot = quiet(RobotPointMass3D, tensor_args=TA)
+    env = EnvSpheres3D(tensor_args=TA)
+    task = PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=0.02, tensor_args=TA)
+    gen = torch.Generator().manual_seed(99)
+    q = ((torch.rand(6, 16, 3, generator=gen) - 0.5) * 2.2).requires_grad_(True)       # some points outside the workspace box
+    cost = task.compute_collision_cost(q)
+    (gq,) = torch.autograd.grad(cost.sum(), q)
+    np.savez_compressed(GOLD / "pointmass3d.npz", q=q.detach().numpy(), cost=cost.detach().numpy(), gq=gq.numpy(),
+                        coll=task.compute_collision(q.detach()).numpy(), coll0=task.compute_collision(q.detach(), margin=0.0).numpy(),
+                        fk=robot.fk_map_collision(q.detach()).numpy(), q_limits=robot.q_limits.numpy(),
+                        margins=robot.link_margins_for_object_collision_checking_tensor.numpy(), cutoff=np.float32(0.02),
+                        limits=env.limits.numpy(), has_self=np.bool_(robot.df_collision_self is not None))
+    print("pointmass3d:", tuple(cost.shape), "self field:", robot.df_collision_self is not None)
+
+
 def ik_goldens(trees):
     """8f rank 2: loss_fn_ik_per_q / ik_termination (robot_tree.py:386-442) and Adam steps on it."""
     tree = trees["panda_arm_no_gripper"]
@@ -633,6 +654,9 @@ def main():
     if sys.argv[1:] == ["points"]:
         points_goldens()
         return
+    if sys.argv[1:] == ["pointmass"]:
+        pointmass_goldens()
+        return
     if sys.argv[1:] == ["metrics"]:
         metrics_goldens()
         return
@@ -668,6 +692,7 @@ def main():
     points_goldens()
     sphere_config_data()
     metrics_goldens()
+    pointmass_goldens()
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
 

@@ -508,3 +508,23 @@ def test_random_collision_free_configurations():
     assert task.random_coll_free_q(n_samples=1).shape == (7,)
     assert task.sample_q(n_samples=3).shape == (3, 7)
     assert task.sample_q(without_collision=False, n_samples=4).shape == (4, 7)
+
+
+def test_point_mass_robot_like_the_reference():
+    """RobotPointMass3D + PlanningTask (identity kinematics, one collision point): cost, gradient, booleans vs the reference."""
+    g = gold("pointmass3d")
+    robot = tra.RobotPointMass3D(tensor_args=TA)
+    np.testing.assert_array_equal(robot.q_limits.cpu().numpy(), g["q_limits"])
+    np.testing.assert_array_equal(robot.link_margins_for_object_collision_checking_tensor.numpy(), g["margins"])
+    assert (robot.df_collision_self is not None) == bool(g["has_self"])
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=float(g["cutoff"]), tensor_args=TA)
+    q = dev(g["q"]).requires_grad_(True)
+    np.testing.assert_array_equal(robot.fk_map_collision(q.detach()).cpu().numpy(), g["fk"])
+    cost = task.compute_collision_cost(q)
+    assert cost.shape == (6, 16) and rel_err(cost.detach().cpu().numpy(), g["cost"]) < TOL_C
+    cost.sum().backward()
+    assert rel_err(q.grad.cpu().numpy(), g["gq"]) < TOL_G
+    np.testing.assert_array_equal(task.compute_collision(q.detach()).cpu().numpy(), g["coll"])
+    np.testing.assert_array_equal(task.compute_collision(q.detach(), margin=0.0).cpu().numpy(), g["coll0"])
+    free = task.random_coll_free_q(n_samples=5)
+    assert free.shape == (5, 3) and not task.compute_collision(free).any()

@@ -156,6 +156,25 @@ class RobotBase:
         raise NotImplementedError
 
 
+class RobotPointMass(RobotBase):                               # robot_point_mass.py:13-32
+    """A point in configuration space == task space: no kinematics, one collision point (margin 0.01)."""
+
+    def __init__(self, name="RobotPointMass", q_limits=((-1, -1), (1, 1)), tensor_args=None, **kwargs):
+        tensor_args = DEFAULT_TENSOR_ARGS if tensor_args is None else tensor_args
+        super().__init__(name=name, q_limits=torch.as_tensor(q_limits, dtype=torch.float32).to(tensor_args["device"]),
+                         link_names_for_object_collision_checking=["link_0"], link_margins_for_object_collision_checking=[0.01],
+                         link_idxs_for_object_collision_checking=[0], num_interpolated_points_for_object_collision_checking=1,
+                         tensor_args=tensor_args, **kwargs)
+
+    def fk_map_collision_impl(self, q, **kwargs):
+        return q.unsqueeze(-2)                                 # identity "kinematics": add the link dimension
+
+
+class RobotPointMass3D(RobotPointMass):                        # robot_point_mass.py:101-109
+    def __init__(self, tensor_args=None, **kwargs):
+        super().__init__(name="RobotPointMass3D", q_limits=((-1, -1, -1), (1, 1, 1)), tensor_args=tensor_args, **kwargs)
+
+
 class RobotPanda(RobotBase):                                   # robot_panda.py:21-184
     """`link_sphere_model` (an extension) replaces the five link-origin collision points by the link-frame
     spheres of a table such as data/configs/panda_sphere_config.yaml ("panda" = that file): fk_map_collision then

@@ -106,14 +106,23 @@ class PlanningTask(Task):
         else:
             self._fused = None
 
+    @property
+    def _has_tree(self) -> bool:
+        """False for robots without kinematics (RobotPointMass3D: task space == configuration space)."""
+        return getattr(self.robot, "diff_panda", None) is not None
+
     def _n_columns(self) -> int:
         """Width of fk_map_collision's output: the links, plus the grasped object's points if there is one."""
+        if not self._has_tree:
+            if self.robot.q_dim != 3:
+                raise NotImplementedError("2-D point robots are outside the 3-D hot path")
+            return 1
         if getattr(self.robot, "has_extra_points", False):
             return len(self.robot.collision_point_set()[0])
         return self.robot.diff_panda._kin.n_links
 
     def build_cost_spec(self) -> CostModelSpec:
-        r, tree = self.robot, self.robot.diff_panda
+        r = self.robot
         spec = CostModelSpec(n_links_in=self._n_columns())
         spec.obj_link_idx = self.df_collision_objects._columns(spec.n_links_in)
         spec.obj_link_margin = self.df_collision_objects._margin_vector(len(spec.obj_link_idx))
@@ -129,6 +138,9 @@ class PlanningTask(Task):
     def _fused_handles(self, device):
         if self._fused is None or self._fused[2] != str(device):
             spec = self.build_cost_spec()
+            if not self._has_tree:                         # no kinematics: only the cost model is needed
+                self._fused = (None, ops.CostHandle(spec, device), str(device))
+                return self._fused[0], self._fused[1]
             self._fused = (self.robot.diff_panda._handle, ops.CostHandle(spec, device), str(device))
             if self.auto_specialize and not self._jit_failed:
                 try:                                   # a unit whose template equals this cost model may already exist
@@ -199,6 +211,11 @@ class PlanningTask(Task):
             raise NotImplementedError
         model, cm = self._fused_handles(q.device)
         fields = FIELD_OBJECTS | FIELD_WS | (FIELD_SELF if self.df_collision_self is not None else 0)
+        if model is None:                                  # RobotPointMass3D: positions are q itself (robot_point_mass.py:29-32)
+            pos = self.robot.fk_map_collision(q)
+            if field_type == "occupancy":
+                return ops.collision_fields(cm, fields, pos.detach(), margin=kwargs.get("margin", None)).reshape(q.shape[:-1])
+            return ops.cost_fields_ad(cm, fields, pos).reshape(q.shape[:-1])
         ps = self._points(q.device)
         if field_type == "occupancy":
             pos = ops.fk_positions(model, q.detach()) if ps is None else ops.fk_points(ps, q.detach())
