@@ -141,6 +141,23 @@ def test_ee_field_like_the_reference():
     assert rel_err(d.cpu().numpy(), g["cost_t1_sq0_w1.0_1.0"]) < TOL_C
 
 
+def test_se3_distance_function():
+    """SE3_distance (geometrics/utils.py:130-178) as a function: values and gradient w.r.t. the poses vs the reference."""
+    g = gold("cost_ee")
+    tree = tra.DifferentiableFrankaPanda(device=DEV)
+    q = dev(g["q"].reshape(-1, 7))
+    for t in range(4):
+        for wp, wr in ((1.0, 1.0), (2.0, 0.5)):
+            H = tree.compute_forward_kinematics_all_links(q, link_list=["ee_link"])[:, 0].detach().requires_grad_(True)
+            d = tra.SE3_distance(H, dev(g[f"target_{t}"]), w_pos=wp, w_rot=wr)
+            assert d.shape == (64,)
+            assert rel_err(d.detach().cpu().numpy(), g[f"cost_t{t}_sq0_w{wp}_{wr}"]) < TOL_C
+            d.sum().backward()
+            assert rel_err(H.grad.cpu().numpy()[:, :3, :], g[f"gH_t{t}_sq0_w{wp}_{wr}"][:, -1, :3, :]) < TOL_G
+    with pytest.raises(NotImplementedError):
+        tra.SE3_distance(H, dev(g["target_0"]), vel_batch=H)
+
+
 def test_fused_task_rollout():
     g = gold("rollout_panda")
     robot = tra.RobotPanda(tensor_args=TA)

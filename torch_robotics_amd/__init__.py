@@ -15,7 +15,7 @@ from .environments import (MultiSphereField, MultiBoxField, MultiSharpBoxField, 
                            EnvBase, EnvSpheres3D, EnvSpheres3DExtraObjects, EnvTableShelf, EnvMazeBoxes3D,
                            GraspedObject, GraspedObjectPandaBox)
 from .fields import (DistanceField, CollisionSelfField, CollisionObjectDistanceField,  # noqa: F401
-                     CollisionWorkspaceBoundariesDistanceField, EESE3DistanceField)
+                     CollisionWorkspaceBoundariesDistanceField, EESE3DistanceField, SE3_distance)
 from .robots import RobotBase, RobotPanda, RobotPointMass, RobotPointMass3D, compute_path_length, compute_smoothness, finite_difference_vector  # noqa: F401
 from .tasks import PlanningTask  # noqa: F401
 

@@ -223,3 +223,22 @@ class EESE3DistanceField(DistanceField):                      # distance_fields.
 
     def zero_grad(self):
         raise NotImplementedError
+
+
+_se3_handles = {}
+
+
+def SE3_distance(H_batch, H_target, vel_batch=None, vel_target=None, w_pos=1.0, w_rot=1.0, **kwargs):
+    """geometrics/utils.py:130-178 on the pose part: w_rot (1 - (tr(R R_t^T) - 1) / 2) + w_pos ||p - p_t|| for H_batch (..., 4, 4)
+    against one (4, 4) or per-sample (..., 4, 4) target; differentiable w.r.t. H_batch (`trk_ee_cost`).  The velocity terms of the
+    reference signature are not part of the planning path."""
+    if vel_batch is not None or vel_target is not None:
+        raise NotImplementedError("SE3_distance: velocity terms are outside the built path")
+    key = (str(H_batch.device), float(w_pos), float(w_rot))
+    if key not in _se3_handles:
+        spec = CostModelSpec(n_links_in=1, ee_link=0, ee_w_pos=float(w_pos), ee_w_rot=float(w_rot), ee_square=False)
+        _se3_handles[key] = ops.CostHandle(spec, H_batch.device)
+    lead = H_batch.shape[:-2]
+    target = torch.as_tensor(H_target, dtype=torch.float32, device=H_batch.device)
+    tgt = target.contiguous() if target.dim() == 2 else target.reshape(-1, 4, 4).contiguous()
+    return ops.ee_cost_ad(_se3_handles[key], H_batch, tgt).reshape(lead)
