@@ -141,6 +141,21 @@ def test_ee_field_like_the_reference():
     assert rel_err(d.cpu().numpy(), g["cost_t1_sq0_w1.0_1.0"]) < TOL_C
 
 
+def test_frame_algebra_on_fk_output():
+    """Frame.transform_point / inverse / multiply_transform on the frames of `return_dict=True` (frame.py:55-78, 116-118):
+    transform_point of the grasped-object frame reproduces the reference's grasped columns of fk_map_collision."""
+    g = gold("grasp_panda")
+    tree = tra.DifferentiableFrankaPanda(device=DEV, grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA))
+    q = dev(g["q"].reshape(-1, 7))
+    frames = tree.compute_forward_kinematics_all_links(q, return_dict=True)
+    pts = frames["grasped_object"].transform_point(dev(g["base_points"]))
+    assert np.abs(pts.cpu().numpy() - g["link_pos"].reshape(-1, 26, 3)[:, 12:]).max() < TOL_H
+    f = frames["panda_hand"]
+    ident = f.multiply_transform(f.inverse())
+    assert np.abs(ident.rotation.cpu().numpy() - np.eye(3)).max() < 1e-6 and np.abs(ident.translation.cpu().numpy()).max() < 1e-6
+    assert len(f.get_euler()) == 3
+
+
 def test_se3_distance_function():
     """SE3_distance (geometrics/utils.py:130-178) as a function: values and gradient w.r.t. the poses vs the reference."""
     g = gold("cost_ee")

@@ -48,6 +48,23 @@ class Frame:
         """wxyz via rotation_matrix_to_q (the reference's per-sample Python loop frame.py:87-114 returns xyzw)."""
         return ops.rotmat_to_quat(self._rot)
 
+    # Pose algebra on the tensors a Frame already holds (frame.py:55-78, 116-121): tensor plumbing for callers that work
+    # with the `return_dict=True` frames; the batched paths (points on links, composed chains) are the kernels.
+    def inverse(self) -> "Frame":
+        rt = self._rot.transpose(-2, -1)
+        return Frame(rt, -(rt @ self._trans.unsqueeze(2)).squeeze(2))
+
+    def multiply_transform(self, frame: "Frame") -> "Frame":
+        return Frame(self._rot @ frame.rotation, (self._rot @ frame.translation.unsqueeze(2)).squeeze(2) + self._trans)
+
+    def transform_point(self, point: torch.Tensor) -> torch.Tensor:
+        """point (P, 3) in this frame -> (B, P, 3) in the world (what fk_map_collision does for grasped-object points)."""
+        return (self._rot @ point.unsqueeze(0).transpose(-1, -2)).transpose(-1, -2) + self._trans.unsqueeze(-2)
+
+    def get_euler(self):
+        return (torch.atan2(self._rot[:, 2, 1], self._rot[:, 2, 2]), torch.asin(-self._rot[:, 2, 0]),
+                torch.atan2(self._rot[:, 1, 0], self._rot[:, 0, 0]))
+
 
 class DifferentiableTree(torch.nn.Module):
 
