@@ -113,6 +113,10 @@ int trk_model_is_specialized(const TrkModel* model);
 /* Switch between the model-specialised fused kernel (default when one was built for these tables) and the
  * table-driven one; both compute the same function (used by the parity tests to cover both). */
 int trk_model_enable_specialized(TrkModel* model, int enable);
+/* Number of model-specialised units registered with the library (ahead-of-time ones plus run-time compiled ones that were
+ * dlopen'ed).  A unit compiled against another layout of the launch structures is refused at registration and not counted;
+ * the run-time compiler (torch_robotics_amd/jit.py) uses this to detect -- and rebuild -- a stale on-disk unit. */
+int trk_spec_count(void);
 
 /* ---------------------------------------------------------------------------------
  * Forward kinematics (stateless path).
@@ -198,6 +202,34 @@ int trk_ik_step(const TrkModel* model, int32_t link, const float* H_target, int3
  * pitch `row_pitch` (9/3 for packed rotations, 16/4 for 4x4 transforms).  -> quat_wxyz [n,4]. */
 int trk_rotmat_to_quat(const float* R, int64_t n, int32_t stride, int32_t row_pitch,
                        float* quat_wxyz, trk_stream_t stream);
+
+/* Frame algebra on packed poses: R [n,9] row-major, t [n,3] (reference: geometrics/frame.py:55-121, the `Frame`s that
+ * compute_forward_kinematics_all_links(return_dict=True) returns, robot_tree.py:283-297).  A frame given once (na / nb == 1)
+ * broadcasts against the other; n_out = max(na, nb).
+ *   TRK_FRAME_COMPOSE      out = a o b       Frame.multiply_transform     frame.py:64-68, geometrics/utils.py:11-17
+ *   TRK_FRAME_INVERSE      out = a^-1        Frame.inverse                frame.py:57-62  (b ignored)
+ *   TRK_FRAME_INV_COMPOSE  out = b^-1 o a    Frame.multiply_inv_transform frame.py:70-76, geometrics/utils.py:21-29 */
+#define TRK_FRAME_COMPOSE 0
+#define TRK_FRAME_INVERSE 1
+#define TRK_FRAME_INV_COMPOSE 2
+int trk_frame_compose(int32_t op, const float* Ra, const float* ta, int64_t na, const float* Rb, const float* tb, int64_t nb,
+                      float* R_out, float* t_out, trk_stream_t stream);
+/* Reverse mode of the above for equal batch sizes (a broadcast input is expanded by the caller): (gR, gt) [n] ->
+ * gRa, gta [n] and -- unless op is TRK_FRAME_INVERSE -- gRb, gtb [n]. */
+int trk_frame_compose_backward(int32_t op, const float* Ra, const float* ta, const float* Rb, const float* tb, const float* gR,
+                               const float* gt, int64_t n, float* gRa, float* gta, float* gRb, float* gtb, trk_stream_t stream);
+/* Frame.transform_point frame.py:116-118: points [P,3] in the frames -> out [n,P,3] = R_s p + t_s (what fk_map_collision
+ * does with a grasped object's points, robot_panda.py:154-168). */
+int trk_frame_transform_points(const float* R, const float* t, int64_t n, const float* points, int32_t n_points, float* out,
+                               trk_stream_t stream);
+/* its reverse mode w.r.t. the poses: gout [n,P,3] -> gR [n,9] = sum_p g_p p^T, gt [n,3] = sum_p g_p */
+int trk_frame_transform_points_backward(const float* gout, int64_t n, const float* points, int32_t n_points, float* gR,
+                                        float* gt, trk_stream_t stream);
+/* Frame.get_quaternion frame.py:87-114 (trace method; XYZW, the reference converts with q_convert_wxyz at
+ * robot_tree.py:214-215) and Frame.get_euler frame.py:120-121 (roll, pitch, yaw).  R as in trk_rotmat_to_quat.
+ * Either output may be NULL. */
+int trk_frame_quat_euler(const float* R, int64_t n, int32_t stride, int32_t row_pitch, float* quat_xyzw, float* euler,
+                         trk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Planning objectives ("cost model").  Host arrays, copied at create().

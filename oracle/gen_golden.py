@@ -648,6 +648,57 @@ def sphere_config_data():
     print("panda_sphere_config:", n, "spheres")
 
 
+def frame_goldens():
+    """geometrics/frame.py:55-121 -- Frame.inverse / multiply_transform / multiply_inv_transform / transform_point /
+    get_quaternion (trace method, xyzw) / get_euler on random poses, incl. the diagonal rotations that take every branch of
+    the trace method, a batch-1 frame broadcast against a batch, and gradients of a fixed weighted sum of the outputs."""
+    from torch_robotics.torch_kinematics_tree.geometrics.frame import Frame
+    gen = torch.Generator().manual_seed(91)
+
+    def rand_rot(n):
+        A = torch.randn(n, 3, 3, generator=gen, dtype=torch.float64)
+        Q, _ = torch.linalg.qr(A)
+        return (Q * torch.sign(torch.linalg.det(Q)).reshape(-1, 1, 1)).to(torch.float32)
+
+    special = torch.stack([torch.diag(torch.tensor(d, dtype=torch.float32)) for d in
+                           ([1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1])])
+    Ra = torch.cat([rand_rot(60), special]).requires_grad_(True)
+    ta = torch.randn(64, 3, generator=gen).requires_grad_(True)
+    Rb = rand_rot(64).requires_grad_(True)
+    tb = torch.randn(64, 3, generator=gen).requires_grad_(True)
+    R1, t1 = rand_rot(1), torch.randn(1, 3, generator=gen)
+    pts = torch.randn(14, 3, generator=gen)
+    wR, wt, wp = torch.randn(64, 3, 3, generator=gen), torch.randn(64, 3, generator=gen), torch.randn(64, 14, 3, generator=gen)
+    fa, fb, f1 = Frame(Ra, ta), Frame(Rb, tb), Frame(R1, t1)
+    out = dict(Ra=Ra.detach().numpy(), ta=ta.detach().numpy(), Rb=Rb.detach().numpy(), tb=tb.detach().numpy(),
+               R1=R1.numpy(), t1=t1.numpy(), pts=pts.numpy(), wR=wR.numpy(), wt=wt.numpy(), wp=wp.numpy())
+
+    def grads(loss):
+        g = torch.autograd.grad(loss, [Ra, ta, Rb, tb], allow_unused=True)
+        return [np.zeros(x.shape, np.float32) if gi is None else gi.numpy() for gi, x in zip(g, [Ra, ta, Rb, tb])]
+
+    inv = fa.inverse()
+    out["inv_R"], out["inv_t"] = inv.rotation.detach().numpy(), inv.translation.detach().numpy()
+    out["inv_gRa"], out["inv_gta"], _, _ = grads((inv.rotation * wR).sum() + (inv.translation * wt).sum())
+    mul = fa.multiply_transform(fb)
+    out["mul_R"], out["mul_t"] = mul.rotation.detach().numpy(), mul.translation.detach().numpy()
+    out["mul_gRa"], out["mul_gta"], out["mul_gRb"], out["mul_gtb"] = grads((mul.rotation * wR).sum() + (mul.translation * wt).sum())
+    mi = fa.multiply_inv_transform(fb)                      # = fb^-1 o fa
+    out["mulinv_R"], out["mulinv_t"] = mi.rotation.detach().numpy(), mi.translation.detach().numpy()
+    out["mulinv_gRa"], out["mulinv_gta"], out["mulinv_gRb"], out["mulinv_gtb"] = \
+        grads((mi.rotation * wR).sum() + (mi.translation * wt).sum())
+    m1 = f1.multiply_transform(fb)                          # batch-1 frame broadcast over a batch
+    out["mul1_R"], out["mul1_t"] = m1.rotation.detach().numpy(), m1.translation.detach().numpy()
+    tp = fa.transform_point(pts)
+    out["tp"] = tp.detach().numpy()
+    out["tp_gRa"], out["tp_gta"], _, _ = grads((tp * wp).sum())
+    with torch.no_grad():
+        out["quat_xyzw"] = fa.get_quaternion().numpy()
+        out["euler"] = torch.stack(fa.get_euler(), -1).numpy()
+        out["H"] = fa.get_transform_matrix().numpy()
+    np.savez_compressed(GOLD / "frame_algebra.npz", **out)
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     URDF_OUT.mkdir(parents=True, exist_ok=True)
@@ -659,6 +710,9 @@ def main():
         return
     if sys.argv[1:] == ["metrics"]:
         metrics_goldens()
+        return
+    if sys.argv[1:] == ["frames"]:
+        frame_goldens()
         return
     if sys.argv[1:] == ["spheres"]:
         sphere_config_data()
@@ -693,6 +747,7 @@ def main():
     sphere_config_data()
     metrics_goldens()
     pointmass_goldens()
+    frame_goldens()
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
 

@@ -23,6 +23,8 @@
 #define FABS fabsf
 #define FLOOR floorf
 #define POW powf
+#define ATAN2 atan2f
+#define ASIN asinf
 #include "oracle_impl.inc"
 #undef REAL
 #undef FN
@@ -32,6 +34,8 @@
 #undef FABS
 #undef FLOOR
 #undef POW
+#undef ATAN2
+#undef ASIN
 
 #define REAL double
 #define FN(x) x##_f64
@@ -41,6 +45,8 @@
 #define FABS fabs
 #define FLOOR floor
 #define POW pow
+#define ATAN2 atan2
+#define ASIN asin
 #include "oracle_impl.inc"
 
 int orc_abi_version(void) { return TRK_ABI_VERSION; }

@@ -139,6 +139,50 @@ class Oracle:
         getattr(lib(), "orc_rotmat_to_quat" + suf)(_p(R), C.c_int64(R.shape[0]), _p(out))
         return out
 
+    # --------------------------------------------------------------- Frame algebra (geometrics/frame.py:55-121)
+    @staticmethod
+    def frame_compose(op, Ra, ta, Rb=None, tb=None, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        Ra, ta = np.ascontiguousarray(Ra, npdt).reshape(-1, 9), np.ascontiguousarray(ta, npdt).reshape(-1, 3)
+        if Rb is None:
+            Rb, tb = np.zeros((1, 9), npdt), np.zeros((1, 3), npdt)
+        Rb, tb = np.ascontiguousarray(Rb, npdt).reshape(-1, 9), np.ascontiguousarray(tb, npdt).reshape(-1, 3)
+        n = Ra.shape[0] if op == 1 else max(Ra.shape[0], Rb.shape[0])
+        Ro, to = np.empty((n, 3, 3), npdt), np.empty((n, 3), npdt)
+        getattr(lib(), "orc_frame_compose" + suf)(C.c_int(op), _p(Ra), _p(ta), C.c_int64(Ra.shape[0]), _p(Rb), _p(tb),
+                                                  C.c_int64(Rb.shape[0]), _p(Ro), _p(to))
+        return Ro, to
+
+    @staticmethod
+    def frame_compose_backward(op, Ra, ta, Rb, tb, gR, gt, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        arrs = [np.ascontiguousarray(a, npdt) for a in (Ra, ta, Rb, tb, gR, gt)]
+        n = arrs[0].reshape(-1, 9).shape[0]
+        outs = [np.zeros((n, 3, 3), npdt), np.zeros((n, 3), npdt), np.zeros((n, 3, 3), npdt), np.zeros((n, 3), npdt)]
+        getattr(lib(), "orc_frame_compose_backward" + suf)(C.c_int(op), *[_p(a) for a in arrs], C.c_int64(n), *[_p(o) for o in outs])
+        return outs
+
+    @staticmethod
+    def frame_transform_points(R, t, pts, g=None, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        R, t = np.ascontiguousarray(R, npdt).reshape(-1, 9), np.ascontiguousarray(t, npdt).reshape(-1, 3)
+        pts = np.ascontiguousarray(pts, npdt).reshape(-1, 3)
+        n, P = R.shape[0], pts.shape[0]
+        out = np.empty((n, P, 3), npdt)
+        gR, gt = np.zeros((n, 3, 3), npdt), np.zeros((n, 3), npdt)
+        gg = None if g is None else np.ascontiguousarray(g, npdt)
+        getattr(lib(), "orc_frame_transform_points" + suf)(_p(R), _p(t), C.c_int64(n), _p(pts), C.c_int(P), _p(out),
+                                                           None if gg is None else _p(gg), _p(gR), _p(gt))
+        return (out, gR, gt) if g is not None else out
+
+    @staticmethod
+    def frame_quat_euler(R, prec="f32"):
+        npdt, _, suf = _dt(prec)
+        R = np.ascontiguousarray(R, npdt).reshape(-1, 9)
+        quat, eul = np.empty((R.shape[0], 4), npdt), np.empty((R.shape[0], 3), npdt)
+        getattr(lib(), "orc_frame_quat_euler" + suf)(_p(R), C.c_int64(R.shape[0]), _p(quat), _p(eul))
+        return quat, eul
+
     # --------------------------------------------------------------- costs
     def cost_fields(self, fields, link_pos, prec="f32", grad=True):
         npdt, _, suf = _dt(prec)

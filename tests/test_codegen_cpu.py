@@ -22,6 +22,17 @@ def test_generated_source_is_deterministic_and_folded():
     assert "trk_sincos(qh6" in body and "passbits" in body and "trk_sincos2(qh0, qh1" in body
 
 
+def test_committed_generated_sources_equal_the_generator_output(tmp_path):
+    """csrc/generated/spec_*.hip are committed so the headline kernels can be read without running the build; they must be
+    exactly what `codegen.generate_all` writes (the build rewrites a file only when it differs, so a clean tree stays clean)."""
+    from pathlib import Path
+    committed = Path(codegen.__file__).resolve().parent / "csrc" / "generated"
+    names = codegen.generate_all(tmp_path)
+    assert sorted(names) == sorted(p.name for p in committed.glob("spec_*.hip"))
+    for n in names:
+        assert (tmp_path / n).read_text() == (committed / n).read_text(), f"{n} is stale: run __graft_entry__.build()"
+
+
 def test_model_hash_distinguishes_models():
     hashes = {codegen.model_hash(model(n)) for n in ("panda_arm_no_gripper", "panda_arm_hand", "ur10", "iiwa7")}
     assert len(hashes) == 4
@@ -99,3 +110,33 @@ def test_concurrent_jit_builds_do_not_corrupt_each_other(tmp_path):
     assert all(o[0].strip().endswith(ident) for o in outs)
     assert (jit.JIT_DIR / f"spec_{ident}.so").stat().st_size > 10000
     assert not list(jit.JIT_DIR.glob("*.tmp*"))
+
+
+def test_unit_with_another_struct_layout_is_refused():
+    """A stale on-disk unit (compiled before a change to SpecArgs / SpecEntry / trk.h) must never be dispatched: the entry's
+    layout stamp is checked by `trk_spec_register` and the run-time compiler's cache key covers every header and the flags."""
+    import ctypes as C
+    from torch_robotics_amd import _lib, jit
+    L = _lib.lib()
+    reg = getattr(L, "_Z17trk_spec_registerPK9SpecEntry")
+    reg.restype, reg.argtypes = C.c_int, [C.c_void_p]
+    before = L.trk_spec_count()
+    assert before >= 3                                            # the ahead-of-time units registered themselves
+    stale = (C.c_uint32 * 64)()                                   # abi 0, sizes 0: an old-layout entry
+    assert reg(C.addressof(stale)) != 0 and L.trk_spec_count() == before
+    stale[0] = 1002                                               # right version, wrong sizeof(SpecArgs)
+    stale[1] = 8
+    assert reg(C.addressof(stale)) != 0 and L.trk_spec_count() == before
+    assert reg(None) != 0
+    # the cache stamp depends on include/trk.h and on the compile command, not on where the package lives
+    stamp = jit._generator_stamp()
+    cmd = " ".join(jit._compile_cmd("<src>", "<out>"))
+    assert "-fno-honor-nans" in cmd and "max-ilp" in cmd
+    real = jit._REPO_INCLUDE / "trk.h"
+    orig = real.read_bytes()
+    try:
+        real.write_bytes(orig + b"\n/* layout change */\n")
+        assert jit._generator_stamp() != stamp
+    finally:
+        real.write_bytes(orig)
+    assert jit._generator_stamp() == stamp

@@ -156,6 +156,102 @@ def test_frame_algebra_on_fk_output():
     assert len(f.get_euler()) == 3
 
 
+def test_frame_algebra_vs_reference_golden():
+    """Frame.inverse / multiply_transform / multiply_inv_transform / transform_point / get_quaternion (XYZW, trace method) /
+    get_euler and their gradients against the reference's own Frame (tests/golden/frame_algebra.npz, frame.py:55-121)."""
+    from torch_robotics_amd.kinematics import Frame
+    g = gold("frame_algebra")
+    leaf = {k: dev(g[k]).requires_grad_(True) for k in ("Ra", "ta", "Rb", "tb")}
+    fa, fb = Frame(leaf["Ra"], leaf["ta"]), Frame(leaf["Rb"], leaf["tb"])
+    wR, wt, wp = dev(g["wR"]), dev(g["wt"]), dev(g["wp"])
+
+    def check(name, frame, keys):
+        assert np.abs(frame.rotation.detach().cpu().numpy() - g[f"{name}_R"]).max() < 1e-6, name
+        assert np.abs(frame.translation.detach().cpu().numpy() - g[f"{name}_t"]).max() < 2e-6, name
+        grads = torch.autograd.grad((frame.rotation * wR).sum() + (frame.translation * wt).sum(), [leaf[k] for k in keys])
+        for k, gk in zip(keys, grads):
+            assert np.abs(gk.cpu().numpy() - g[f"{name}_g{k}"]).max() < 5e-6, (name, k)
+
+    check("inv", fa.inverse(), ["Ra", "ta"])
+    check("mul", fa.multiply_transform(fb), ["Ra", "ta", "Rb", "tb"])
+    check("mulinv", fa.multiply_inv_transform(fb), ["Ra", "ta", "Rb", "tb"])
+    m1 = Frame(dev(g["R1"]), dev(g["t1"])).multiply_transform(Frame(dev(g["Rb"]), dev(g["tb"])))     # batch-1 broadcast
+    assert np.abs(m1.rotation.cpu().numpy() - g["mul1_R"]).max() < 1e-6 and np.abs(m1.translation.cpu().numpy() - g["mul1_t"]).max() < 2e-6
+    # a broadcast frame that needs a gradient gets the batch-summed adjoint
+    R1 = dev(g["R1"]).requires_grad_(True)
+    m1g = Frame(R1, dev(g["t1"])).multiply_transform(Frame(dev(g["Rb"]), dev(g["tb"])))
+    (gR1,) = torch.autograd.grad((m1g.rotation * wR).sum(), [R1])
+    ref = np.einsum("nij,nkj->ik", g["wR"].astype(np.float64), g["Rb"].astype(np.float64))
+    assert gR1.shape == (1, 3, 3) and np.abs(gR1[0].cpu().numpy() - ref).max() < 2e-5
+    tp = fa.transform_point(dev(g["pts"]))
+    assert np.abs(tp.detach().cpu().numpy() - g["tp"]).max() < 2e-6
+    gRa, gta = torch.autograd.grad((tp * wp).sum(), [leaf["Ra"], leaf["ta"]])
+    assert np.abs(gRa.cpu().numpy() - g["tp_gRa"]).max() < 1e-5 and np.abs(gta.cpu().numpy() - g["tp_gta"]).max() < 1e-5
+    quat = fa.get_quaternion()                                  # XYZW like the reference, not WXYZ
+    assert np.abs(quat.cpu().numpy() - g["quat_xyzw"]).max() < 1e-6
+    np.testing.assert_array_equal(quat[-4:].cpu().numpy(), [[0, 0, 0, 1], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]])
+    wxyz = fa.get_quaternion_wxyz().cpu().numpy()
+    assert np.abs(np.abs((wxyz[:, [1, 2, 3, 0]] * g["quat_xyzw"]).sum(1)) - 1).max() < 1e-5      # same rotation, other order
+    assert np.abs(torch.stack(fa.get_euler(), -1).cpu().numpy() - g["euler"]).max() < 2e-6
+    assert np.abs(fa.get_transform_matrix().detach().cpu().numpy() - g["H"]).max() == 0
+
+
+def test_moved_scene_object_is_seen_by_every_cached_cost_model():
+    """`ObjectField.set_position_orientation` between two evaluations: the reference reads the pose on every call
+    (primitives.py:387-405), so PlanningTask's fused cost model, the per-field one and EnvBase.compute_sdf must all follow."""
+    robot = tra.RobotPanda(tensor_args=TA)
+    env = tra.EnvSpheres3DExtraObjects(tensor_args=TA)
+    task = tra.PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    q = dev(gold("cost_spheres3d_extra")["q"])
+    X = dev(np.array([[0.25, 0.0, 0.0], [2.25, 3.0, 0.5]], np.float32))
+    c0, k0, s0 = task.compute_collision_cost(q), task.compute_collision(q), env.compute_sdf(X)
+    _, r0, _ = task.rollout_cost_grad(q, w_self=0, w_ws=0)
+    f0 = task.df_collision_objects.compute_cost(q, robot.fk_map_collision(q))
+    extra = env.obj_extra_list[0]
+    extra.set_position_orientation(pos=(2.0, 3.0, 0.5))                   # far outside the robot's reach
+    c1, k1, s1 = task.compute_collision_cost(q), task.compute_collision(q), env.compute_sdf(X)
+    _, r1, _ = task.rollout_cost_grad(q, w_self=0, w_ws=0)
+    f1 = task.df_collision_objects.compute_cost(q, robot.fk_map_collision(q))
+    assert (c1 - c0).abs().max() > 1e-3 and (r1 - r0).abs().max() > 1e-3 and (f1 - f0).abs().max() > 1e-3
+    assert s0[0] < -0.1 and s1[0] > 0.1 and s1[1] < -0.1                  # the sphere at (0.25,0,0) left, one arrived at X[1]
+    assert k1.sum() <= k0.sum()
+    # identical to a task built on the moved scene from scratch; the per-field path and the fused path agree
+    env2 = tra.EnvSpheres3DExtraObjects(tensor_args=TA)
+    env2.obj_extra_list[0].set_position_orientation(pos=(2.0, 3.0, 0.5))
+    task2 = tra.PlanningTask(env=env2, robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    np.testing.assert_array_equal(task2.compute_collision_cost(q).cpu().numpy(), c1.cpu().numpy())
+    np.testing.assert_array_equal(task2.compute_collision(q).cpu().numpy(), k1.cpu().numpy())
+    assert rel_err(r1.cpu().numpy(), f1.cpu().numpy()) < TOL_C
+    extra.set_position_orientation(pos=(0.0, 0.0, 0.0))                   # and back
+    np.testing.assert_array_equal(task.compute_collision_cost(q).cpu().numpy(), c0.cpu().numpy())
+
+
+def test_rollout_rejects_q_of_another_width():
+    """A (B,H,D') tensor with D' != n_dofs (full state with velocities) must raise instead of being read with a wrong stride."""
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, tensor_args=TA)
+    model, cm = task._fused_handles(DEV)
+    x = torch.zeros(4, 8, 14, device=DEV)
+    for bad in (x, x[..., :6], x.to(torch.float16)):
+        with pytest.raises(ValueError, match="DOF"):
+            tra.ops.rollout_cost_grad(model, cm, (1, 1, 1, 0), bad)
+        with pytest.raises(ValueError, match="DOF"):
+            tra.ops.RolloutPlan(model, cm, (1, 1, 1, 0), bad)
+    q = x[..., :7].contiguous()
+    n = 32
+    good = (torch.empty(n, 11, 3, device=DEV), torch.empty(n, device=DEV), torch.empty(n, 7, device=DEV))
+    tra.ops.rollout_cost_grad(model, cm, (1, 1, 1, 0), q, out=good)
+    for k, bad_buf in ((0, torch.empty(n, 10, 3, device=DEV)), (1, torch.empty(n, device=DEV, dtype=torch.float64)),
+                       (2, torch.empty(n, 7)), (2, torch.empty(n, 14, device=DEV)[:, ::2])):
+        out = list(good)
+        out[k] = bad_buf
+        with pytest.raises(ValueError):
+            tra.ops.rollout_cost_grad(model, cm, (1, 1, 1, 0), q, out=tuple(out))
+    with pytest.raises(ValueError):
+        tra.ops.rollout_cost_grad(model, cm, (1, 1, 1, 0), q, cost_sum=torch.zeros(0, device=DEV))
+    task.rollout_cost_grad(x)                                   # the Task API slices the positions out of a full state itself
+
+
 def test_se3_distance_function():
     """SE3_distance (geometrics/utils.py:130-178) as a function: values and gradient w.r.t. the poses vs the reference."""
     g = gold("cost_ee")

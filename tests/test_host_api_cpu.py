@@ -209,3 +209,41 @@ def test_link_sphere_model_tables():
     assert spec.n_links_in == 12 + 45 + 14 and len(spec.obj_link_idx) == 59 and len(spec.self_pairs) == 66
     np.testing.assert_array_equal(spec.obj_link_idx[-14:], np.arange(57, 71))
     np.testing.assert_array_equal(spec.self_link_idx[-14:], np.arange(57, 71))
+
+
+def test_scene_version_follows_object_poses():
+    """Every cached device cost model is keyed by `scene_version`: identity and CURRENT pose of each object (a
+    moved object must not keep evaluating the old scene)."""
+    import torch
+    from torch_robotics_amd.environments import EnvSpheres3DExtraObjects, scene_version
+    ta = dict(device=torch.device("cpu"), dtype=torch.float32)
+    env = EnvSpheres3DExtraObjects(tensor_args=ta)
+    v0 = scene_version(env.get_df_obj_list())
+    assert scene_version(env.get_df_obj_list()) == v0 and len(v0) == 2
+    env.obj_extra_list[0].set_position_orientation(pos=(0.1, 0.0, 0.0))
+    v1 = scene_version(env.get_df_obj_list())
+    assert v1 != v0 and v1[0] == v0[0]
+    env.obj_extra_list[0].set_position_orientation(ori=(0.0, 1.0, 0.0, 0.0))
+    assert scene_version(env.get_df_obj_list()) != v1
+    env.obj_extra_list[0].set_position_orientation(pos=(0.0, 0.0, 0.0), ori=(1.0, 0.0, 0.0, 0.0))
+    assert scene_version(env.get_df_obj_list()) == v0
+    # compute_sdf lives on EnvBase only (the other scene classes have no object list to serve it)
+    from torch_robotics_amd import environments as E
+    assert hasattr(E.EnvBase, "compute_sdf")
+    for cls in (E.PrimitiveShapeField, E.ObjectField, E.GridMapSDF):
+        assert not hasattr(cls, "compute_sdf") and not hasattr(cls, "add_obj")
+
+
+def test_q_width_check():
+    import torch
+    from torch_robotics_amd.ops import _check_buffer, _check_q_dofs
+    _check_q_dofs(torch.zeros(3, 4, 7), 7, "x")
+    for bad in (torch.zeros(3, 4, 14), torch.zeros(6), torch.zeros(())):
+        with pytest.raises(ValueError):
+            _check_q_dofs(bad, 7, "x")
+    dev = torch.device("cpu")
+    _check_buffer(torch.zeros(8), 8, torch.float32, dev, "b")
+    _check_buffer(torch.zeros(9), 8, torch.float32, dev, "b", at_least=True)
+    for bad in (torch.zeros(7), torch.zeros(8, dtype=torch.float64), torch.zeros(16)[::2]):
+        with pytest.raises(ValueError):
+            _check_buffer(bad, 8, torch.float32, dev, "b")

@@ -333,3 +333,27 @@ def test_finite_differences_and_trajectory_metrics(oracle_lib, prec):
     assert rel_err(oracle_lib.traj_diff_norm_sum(gm["trajs"], 0, 7, prec), gm["path_length"]) < 2e-6
     assert rel_err(oracle_lib.traj_diff_norm_sum(vel, 0, 7, prec), gm["smoothness_fd"]) < 2e-6
     assert rel_err(oracle_lib.traj_diff_norm_sum(gm["full"], 7, 7, prec), gm["smoothness_vel"]) < 2e-6
+
+
+# -----------------------------------------------------------------------------------------------
+# Frame algebra (geometrics/frame.py:55-121)
+# -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_frame_algebra_vs_reference(prec):
+    """orc_frame_* against the reference's own Frame: inverse / multiply_transform / multiply_inv_transform (+ broadcast),
+    transform_point, get_quaternion (XYZW trace method) and get_euler, values and gradients."""
+    from oracle.oracle import Oracle as O
+    g = gold("frame_algebra")
+    tol = 0 if prec == "f32" else 1e-6                           # the fp32 restatement is bit-exact on the forward values
+    for op, name, a, b in ((1, "inv", ("Ra", "ta"), None), (0, "mul", ("Ra", "ta"), ("Rb", "tb")),
+                           (2, "mulinv", ("Ra", "ta"), ("Rb", "tb")), (0, "mul1", ("R1", "t1"), ("Rb", "tb"))):
+        R, t = O.frame_compose(op, g[a[0]], g[a[1]], None if b is None else g[b[0]], None if b is None else g[b[1]], prec=prec)
+        assert np.abs(R - g[f"{name}_R"]).max() <= tol and np.abs(t - g[f"{name}_t"]).max() <= tol, name
+        if name != "mul1":
+            grads = O.frame_compose_backward(op, g["Ra"], g["ta"], g["Rb"], g["tb"], g["wR"], g["wt"], prec=prec)
+            for gk, key in zip(grads, ["gRa", "gta", "gRb", "gtb"] if op != 1 else ["gRa", "gta"]):
+                assert np.abs(gk - g[f"{name}_{key}"]).max() < 1e-6, (name, key)
+    out, gR, gt = O.frame_transform_points(g["Ra"], g["ta"], g["pts"], g["wp"], prec=prec)
+    assert np.abs(out - g["tp"]).max() <= tol and np.abs(gR - g["tp_gRa"]).max() < 2e-6 and np.abs(gt - g["tp_gta"]).max() < 2e-6
+    quat, eul = O.frame_quat_euler(g["Ra"], prec=prec)
+    assert np.abs(quat - g["quat_xyzw"]).max() < 2e-7 and np.abs(eul - g["euler"]).max() < 2e-7

@@ -20,11 +20,13 @@ _lib = None
 
 EXPORTS = [
     "trk_abi_version", "trk_last_error", "trk_model_create", "trk_model_destroy", "trk_model_set_base_pose",
-    "trk_model_n_links", "trk_model_n_dofs", "trk_model_is_specialized", "trk_model_enable_specialized",
+    "trk_model_n_links", "trk_model_n_dofs", "trk_model_is_specialized", "trk_model_enable_specialized", "trk_spec_count",
     "trk_fk_forward", "trk_fk_positions", "trk_fk_backward", "trk_fk_positions_backward", "trk_fk_jacobian", "trk_fk_analytic_jacobian", "trk_ik_step",
     "trk_rotmat_to_quat", "trk_cost_model_create", "trk_cost_model_destroy", "trk_cost_model_set_ee_target", "trk_cost_model_set_ee2_target",
     "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_reduce_sum", "trk_debug_set_stamp_buffer", "trk_interpolate_via_points",
     "trk_grid_precompute",
+    "trk_frame_compose", "trk_frame_compose_backward", "trk_frame_transform_points", "trk_frame_transform_points_backward",
+    "trk_frame_quat_euler",
     "trk_sdf_points",
     "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_point_set_is_specialized", "trk_fk_points", "trk_fk_points_backward",
     "trk_rollout_points_cost_grad", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16", "trk_finite_difference", "trk_traj_diff_norm_sum",
@@ -67,6 +69,7 @@ def lib():
     L.trk_model_n_dofs.argtypes = [vp]
     L.trk_model_is_specialized.argtypes = [vp]
     L.trk_model_enable_specialized.argtypes = [vp, C.c_int]
+    L.trk_spec_count.argtypes = []
     L.trk_fk_forward.argtypes = [vp, vp, i64, vp, i32, vp, vp]
     L.trk_fk_positions.argtypes = [vp, vp, i64, vp, i32, vp, vp]
     L.trk_fk_backward.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp]
@@ -75,6 +78,11 @@ def lib():
     L.trk_fk_analytic_jacobian.argtypes = [vp, vp, i64, vp, vp]
     L.trk_ik_step.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, f32, i32, i64, vp, vp, vp, vp, vp, vp]
     L.trk_rotmat_to_quat.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.trk_frame_compose.argtypes = [i32, vp, vp, i64, vp, vp, i64, vp, vp, vp]
+    L.trk_frame_compose_backward.argtypes = [i32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.trk_frame_transform_points.argtypes = [vp, vp, i64, vp, i32, vp, vp]
+    L.trk_frame_transform_points_backward.argtypes = [vp, i64, vp, i32, vp, vp, vp]
+    L.trk_frame_quat_euler.argtypes = [vp, i64, i32, i32, vp, vp, vp]
     L.trk_cost_model_create.argtypes = [C.POINTER(_abi.CostModelDesc), C.POINTER(vp)]
     L.trk_cost_model_destroy.argtypes = [vp]
     L.trk_cost_model_destroy.restype = None

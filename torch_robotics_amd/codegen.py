@@ -563,7 +563,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("    if (base_identity) hipLaunchKernelGGL(k_posbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_posbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
-    out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
+    out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
@@ -985,7 +985,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     out.append("}")
     n_points = 0 if link_mode else len(pt.point_link)
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
-    out.append(f"static const SpecEntry kEntry = {{0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
+    out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
                f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")

@@ -57,7 +57,18 @@ uint64_t model_hash(const TrkKinModelDesc* d) {
 std::vector<const SpecEntry*>& spec_registry() { static std::vector<const SpecEntry*> r; return r; }
 }  // namespace
 
-void trk_spec_register(const SpecEntry* e) { spec_registry().push_back(e); }
+int trk_spec_register(const SpecEntry* e) {
+    // the first four fields are the layout stamp in every version of SpecEntry; nothing else is read before they match
+    if (!e || e->spec_abi_version != TRK_SPEC_ABI_VERSION || e->sizeof_args != sizeof(SpecArgs) ||
+        e->sizeof_entry != sizeof(SpecEntry) || e->sizeof_cost_hdr != sizeof(DevCostHdr)) {
+        fprintf(stderr, "libtrk: refusing a generated unit compiled against another SpecArgs/SpecEntry layout "
+                        "(stale JIT cache?) -- it will not be dispatched\n");
+        return TRK_ERR_INVALID_ARG;
+    }
+    spec_registry().push_back(e);
+    return 0;
+}
+int trk_spec_count(void) { return (int)spec_registry().size(); }
 const SpecEntry* trk_spec_find(uint64_t h, int n_links, int n_dofs) {
     for (const SpecEntry* e : spec_registry())
         if (e->n_points == 0 && e->model_hash == h && e->n_links == n_links && e->n_dofs == n_dofs) return e;
@@ -530,6 +541,77 @@ int trk_rotmat_to_quat(const float* R, int64_t n, int32_t stride, int32_t row_pi
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_rotmat_to_quat(R, n, stride, row_pitch, quat, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame algebra (geometrics/frame.py:55-121)
+int trk_frame_compose(int32_t op, const float* Ra, const float* ta, int64_t na, const float* Rb, const float* tb, int64_t nb,
+                      float* R_out, float* t_out, trk_stream_t stream) {
+    if (op < TRK_FRAME_COMPOSE || op > TRK_FRAME_INV_COMPOSE) return fail(TRK_ERR_INVALID_ARG, "trk_frame_compose: unknown op");
+    const bool two = op != TRK_FRAME_INVERSE;
+    if (na < 0 || (two && nb < 0)) return fail(TRK_ERR_INVALID_ARG, "trk_frame_compose: negative size");
+    const int64_t n = two ? std::max(na, nb) : na;
+    if (two && na != nb && na != 1 && nb != 1 && n > 0)
+        return fail(TRK_ERR_INVALID_ARG, "trk_frame_compose: batch sizes differ and neither is 1");
+    if (two && (na == 0 || nb == 0)) return TRK_OK;
+    if (n == 0) return TRK_OK;
+    if (!Ra || !ta || (two && (!Rb || !tb)) || !R_out || !t_out) return fail(TRK_ERR_INVALID_ARG, "trk_frame_compose: null pointer");
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_frame_compose(op, Ra, ta, two && na == 1 && n > 1, Rb, tb, two && nb == 1 && n > 1, n, R_out, t_out,
+                             (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_frame_compose_backward(int32_t op, const float* Ra, const float* ta, const float* Rb, const float* tb, const float* gR,
+                               const float* gt, int64_t n, float* gRa, float* gta, float* gRb, float* gtb, trk_stream_t stream) {
+    if (op < TRK_FRAME_COMPOSE || op > TRK_FRAME_INV_COMPOSE) return fail(TRK_ERR_INVALID_ARG, "trk_frame_compose_backward: unknown op");
+    if (n < 0) return fail(TRK_ERR_INVALID_ARG, "trk_frame_compose_backward: negative size");
+    if (n == 0) return TRK_OK;
+    const bool two = op != TRK_FRAME_INVERSE;
+    if (!Ra || !ta || !gR || !gt || !gRa || !gta || (two && (!Rb || !tb || !gRb || !gtb)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_frame_compose_backward: null pointer");
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_frame_compose_bwd(op, Ra, ta, Rb, tb, gR, gt, n, gRa, gta, gRb, gtb, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_frame_transform_points(const float* R, const float* t, int64_t n, const float* points, int32_t P, float* out,
+                               trk_stream_t stream) {
+    if (n < 0 || P < 0) return fail(TRK_ERR_INVALID_ARG, "trk_frame_transform_points: negative size");
+    if (n == 0 || P == 0) return TRK_OK;
+    if (!R || !t || !points || !out) return fail(TRK_ERR_INVALID_ARG, "trk_frame_transform_points: null pointer");
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_frame_transform_points(R, t, n, points, P, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_frame_transform_points_backward(const float* gout, int64_t n, const float* points, int32_t P, float* gR, float* gt,
+                                        trk_stream_t stream) {
+    if (n < 0 || P < 0) return fail(TRK_ERR_INVALID_ARG, "trk_frame_transform_points_backward: negative size");
+    if (n == 0) return TRK_OK;
+    if ((P > 0 && (!gout || !points)) || !gR || !gt) return fail(TRK_ERR_INVALID_ARG, "trk_frame_transform_points_backward: null pointer");
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_frame_transform_points_bwd(gout, n, points, P, gR, gt, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_frame_quat_euler(const float* R, int64_t n, int32_t stride, int32_t row_pitch, float* quat_xyzw, float* euler,
+                         trk_stream_t stream) {
+    if (n < 0 || stride < 9 || row_pitch < 3 || (n > 0 && !R)) return fail(TRK_ERR_INVALID_ARG, "trk_frame_quat_euler: bad argument");
+    if (n == 0 || (!quat_xyzw && !euler)) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_frame_quat_euler(R, n, stride, row_pitch, quat_xyzw, euler, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }

@@ -1120,6 +1120,176 @@ k_rotmat_to_quat(const float* __restrict__ R, int64_t n, int stride, int pitch, 
     *o = make_float4(c0 / den, c1 / den, c2 / den, c3 / den);
 }
 
+// ============================================================================================
+// Frame algebra on packed poses (geometrics/frame.py:55-121): R [n,9] row-major, t [n,3]; a frame given once (n == 1)
+// broadcasts.  One lane per pose; 48 bytes in / out per pose, so these are plain streaming kernels.
+// ============================================================================================
+struct Pose3 { float r[9], t[3]; };
+__device__ __forceinline__ Pose3 pose_load(const float* R, const float* t, int64_t i) {
+    Pose3 p;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p.r[k] = R[i * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p.t[k] = t[i * 3 + k];
+    return p;
+}
+// frame.py:57-62: (R^T, -(R^T t))
+__device__ __forceinline__ Pose3 pose_inverse(const Pose3& a) {
+    Pose3 o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o.r[3 * i + j] = a.r[3 * j + i];
+        o.t[i] = -(a.r[i] * a.t[0] + a.r[3 + i] * a.t[1] + a.r[6 + i] * a.t[2]);
+    }
+    return o;
+}
+// geometrics/utils.py:11-17: (Ra Rb, Ra tb + ta)
+__device__ __forceinline__ Pose3 pose_mul(const Pose3& a, const Pose3& b) {
+    Pose3 o;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            o.r[3 * i + j] = a.r[3 * i] * b.r[j] + a.r[3 * i + 1] * b.r[3 + j] + a.r[3 * i + 2] * b.r[6 + j];
+        o.t[i] = (a.r[3 * i] * b.t[0] + a.r[3 * i + 1] * b.t[1] + a.r[3 * i + 2] * b.t[2]) + a.t[i];
+    }
+    return o;
+}
+// adjoint of pose_mul: (gRa, gta, gRb, gtb) from (gR, gt)
+__device__ __forceinline__ void pose_mul_bwd(const Pose3& a, const Pose3& b, const Pose3& g, Pose3& ga, Pose3& gb) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            // gRa[i][k] = sum_j gR[i][j] Rb[k][j] + gt[i] tb[k];   gRb[i][k] = sum_j Ra[j][i] gR[j][k]
+            ga.r[3 * i + k] = g.r[3 * i] * b.r[3 * k] + g.r[3 * i + 1] * b.r[3 * k + 1] + g.r[3 * i + 2] * b.r[3 * k + 2] +
+                              g.t[i] * b.t[k];
+            gb.r[3 * i + k] = a.r[i] * g.r[k] + a.r[3 + i] * g.r[3 + k] + a.r[6 + i] * g.r[6 + k];
+        }
+        ga.t[i] = g.t[i];
+        gb.t[i] = a.r[i] * g.t[0] + a.r[3 + i] * g.t[1] + a.r[6 + i] * g.t[2];
+    }
+}
+// adjoint of pose_inverse
+__device__ __forceinline__ void pose_inverse_bwd(const Pose3& a, const Pose3& g, Pose3& ga) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ga.r[3 * j + i] = g.r[3 * i + j] - a.t[j] * g.t[i];
+        ga.t[j] = -(a.r[3 * j] * g.t[0] + a.r[3 * j + 1] * g.t[1] + a.r[3 * j + 2] * g.t[2]);
+    }
+}
+__device__ __forceinline__ void pose_store(float* R, float* t, int64_t i, const Pose3& p) {
+    if (R) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[i * 9 + k] = p.r[k];
+    }
+    if (t) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[i * 3 + k] = p.t[k];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_frame_compose(int op, const float* __restrict__ Ra, const float* __restrict__ ta, int a_bcast, const float* __restrict__ Rb,
+                const float* __restrict__ tb, int b_bcast, int64_t n, float* __restrict__ Ro, float* __restrict__ to) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const Pose3 a = pose_load(Ra, ta, a_bcast ? 0 : s);
+    Pose3 o;
+    if (op == TRK_FRAME_INVERSE) o = pose_inverse(a);
+    else {
+        const Pose3 b = pose_load(Rb, tb, b_bcast ? 0 : s);
+        o = op == TRK_FRAME_COMPOSE ? pose_mul(a, b) : pose_mul(pose_inverse(b), a);
+    }
+    pose_store(Ro, to, s, o);
+}
+
+__global__ void __launch_bounds__(256)
+k_frame_compose_bwd(int op, const float* __restrict__ Ra, const float* __restrict__ ta, const float* __restrict__ Rb,
+                    const float* __restrict__ tb, const float* __restrict__ gR, const float* __restrict__ gt, int64_t n,
+                    float* __restrict__ gRa, float* __restrict__ gta, float* __restrict__ gRb, float* __restrict__ gtb) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const Pose3 a = pose_load(Ra, ta, s), g = pose_load(gR, gt, s);
+    Pose3 ga, gb;
+    if (op == TRK_FRAME_INVERSE) {
+        pose_inverse_bwd(a, g, ga);
+        pose_store(gRa, gta, s, ga);
+        return;
+    }
+    const Pose3 b = pose_load(Rb, tb, s);
+    if (op == TRK_FRAME_COMPOSE) pose_mul_bwd(a, b, g, ga, gb);
+    else {                                     // out = inv(b) o a
+        Pose3 gib;
+        pose_mul_bwd(pose_inverse(b), a, g, gib, ga);
+        pose_inverse_bwd(b, gib, gb);
+    }
+    pose_store(gRa, gta, s, ga);
+    pose_store(gRb, gtb, s, gb);
+}
+
+// frame.py:116-118: out[s, p, :] = R_s point_p + t_s.  One workgroup row per pose block; lanes sweep the (pose, point)
+// pairs so the [n, P, 3] output leaves as contiguous runs.
+__global__ void __launch_bounds__(256)
+k_frame_transform_points(const float* __restrict__ R, const float* __restrict__ t, int64_t n, const float* __restrict__ pts,
+                         int P, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * P) return;
+    const int64_t s = idx / P;
+    const int p = (int)(idx - s * P);
+    const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
+    const float* r = R + s * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[idx * 3 + i] = (r[3 * i] * x + r[3 * i + 1] * y + r[3 * i + 2] * z) + t[s * 3 + i];
+}
+// reverse mode w.r.t. the pose: gR = sum_p g_p point_p^T, gt = sum_p g_p
+__global__ void __launch_bounds__(256)
+k_frame_transform_points_bwd(const float* __restrict__ g, int64_t n, const float* __restrict__ pts, int P,
+                             float* __restrict__ gR, float* __restrict__ gt) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int p = 0; p < P; ++p) {
+        const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float gi = g[(s * P + p) * 3 + i];
+            a[3 * i] += gi * x; a[3 * i + 1] += gi * y; a[3 * i + 2] += gi * z;
+            b[i] += gi;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gR[s * 9 + k] = a[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gt[s * 3 + k] = b[k];
+}
+
+// Frame.get_quaternion frame.py:87-114 (trace method, XYZW) and Frame.get_euler frame.py:120-121
+__global__ void __launch_bounds__(256)
+k_frame_quat_euler(const float* __restrict__ R, int64_t n, int stride, int pitch, float* __restrict__ quat_xyzw,
+                   float* __restrict__ euler) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float* m = R + s * stride;
+    float r[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r[3 * i + j] = m[i * pitch + j];
+    if (quat_xyzw) {
+        float q[4];
+        frame_quat_wxyz(r, q);
+        *reinterpret_cast<float4*>(quat_xyzw + s * 4) = make_float4(q[1], q[2], q[3], q[0]);
+    }
+    if (euler) {
+        euler[s * 3] = atan2f(r[7], r[8]);
+        euler[s * 3 + 1] = asinf(-r[6]);
+        euler[s * 3 + 2] = atan2f(r[3], r[0]);
+    }
+}
+
 // GridMapSDF.precompute_sdf grid_map_sdf.py:34-63 (analytic objects only) and
 // ObjectField.compute_signed_distance on arbitrary points
 __global__ void __launch_bounds__(256)
@@ -1455,6 +1625,28 @@ void trk_launch_fk_analytic_jacobian(const DevModelHdr& hdr, const DevLink* link
 
 void trk_launch_rotmat_to_quat(const float* R, int64_t n, int stride, int pitch, float* out, hipStream_t st) {
     hipLaunchKernelGGL(k_rotmat_to_quat, dim3(grid_for(n, 256)), dim3(256), 0, st, R, n, stride, pitch, out);
+}
+
+void trk_launch_frame_compose(int op, const float* Ra, const float* ta, int a_bcast, const float* Rb, const float* tb, int b_bcast,
+                              int64_t n, float* Ro, float* to, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_compose, dim3(grid_for(n, 256)), dim3(256), 0, st, op, Ra, ta, a_bcast, Rb, tb, b_bcast, n, Ro, to);
+}
+void trk_launch_frame_compose_bwd(int op, const float* Ra, const float* ta, const float* Rb, const float* tb, const float* gR,
+                                  const float* gt, int64_t n, float* gRa, float* gta, float* gRb, float* gtb, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_compose_bwd, dim3(grid_for(n, 256)), dim3(256), 0, st, op, Ra, ta, Rb, tb, gR, gt, n, gRa, gta,
+                       gRb, gtb);
+}
+void trk_launch_frame_transform_points(const float* R, const float* t, int64_t n, const float* pts, int P, float* out,
+                                       hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_transform_points, dim3(grid_for(n * P, 256)), dim3(256), 0, st, R, t, n, pts, P, out);
+}
+void trk_launch_frame_transform_points_bwd(const float* g, int64_t n, const float* pts, int P, float* gR, float* gt,
+                                           hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_transform_points_bwd, dim3(grid_for(n, 256)), dim3(256), 0, st, g, n, pts, P, gR, gt);
+}
+void trk_launch_frame_quat_euler(const float* R, int64_t n, int stride, int pitch, float* quat_xyzw, float* euler,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_quat_euler, dim3(grid_for(n, 256)), dim3(256), 0, st, R, n, stride, pitch, quat_xyzw, euler);
 }
 
 void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const float* lo, const float* hi, float* sdf,

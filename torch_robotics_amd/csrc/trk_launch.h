@@ -34,6 +34,16 @@ void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links_dev, co
 void trk_launch_fk_analytic_jacobian(const DevModelHdr& hdr, const DevLink* links, const void* dofs, const float* q,
                                      int64_t n, float* J, hipStream_t st);
 void trk_launch_rotmat_to_quat(const float* R, int64_t n, int stride, int pitch, float* out, hipStream_t st);
+void trk_launch_frame_compose(int op, const float* Ra, const float* ta, int a_bcast, const float* Rb, const float* tb, int b_bcast,
+                              int64_t n, float* Ro, float* to, hipStream_t st);
+void trk_launch_frame_compose_bwd(int op, const float* Ra, const float* ta, const float* Rb, const float* tb, const float* gR,
+                                  const float* gt, int64_t n, float* gRa, float* gta, float* gRb, float* gtb, hipStream_t st);
+void trk_launch_frame_transform_points(const float* R, const float* t, int64_t n, const float* pts, int P, float* out,
+                                       hipStream_t st);
+void trk_launch_frame_transform_points_bwd(const float* g, int64_t n, const float* pts, int P, float* gR, float* gt,
+                                           hipStream_t st);
+void trk_launch_frame_quat_euler(const float* R, int64_t n, int stride, int pitch, float* quat_xyzw, float* euler,
+                                 hipStream_t st);
 void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const float* lo, const float* hi, float* sdf,
                                 float* grad, hipStream_t st);
 void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_interp, const float* alpha, const float* beta,

@@ -32,7 +32,16 @@ struct SpecArgs {
 
 typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
 
+// Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
+// (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
+// to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 2)
+
 struct SpecEntry {
+    int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
+    uint32_t sizeof_args;       // sizeof(SpecArgs) the unit was compiled with
+    uint32_t sizeof_entry;      // sizeof(SpecEntry) the unit was compiled with
+    uint32_t sizeof_cost_hdr;   // sizeof(DevCostHdr)
     uint64_t model_hash;        // FNV-1a over the kinematic tables (see trk_capi.hip: model_hash)
     int32_t n_links, n_dofs;
     int32_t n_obj_links;        // baked collision-link template
@@ -49,7 +58,9 @@ struct SpecEntry {
 };
 
 // registry filled by static initialisers of the generated translation units
-void trk_spec_register(const SpecEntry* e);
+// returns 0 when the unit was accepted, TRK_ERR_INVALID_ARG (and registers nothing) when its layout stamp differs
+int trk_spec_register(const SpecEntry* e);
+#define SPEC_ENTRY_STAMP TRK_SPEC_ABI_VERSION, (uint32_t)sizeof(SpecArgs), (uint32_t)sizeof(SpecEntry), (uint32_t)sizeof(DevCostHdr)
 const SpecEntry* trk_spec_find(uint64_t model_hash, int n_links, int n_dofs);
 const SpecEntry* trk_spec_find_points(uint64_t model_hash, uint64_t points_hash, int n_points);
 

@@ -28,6 +28,19 @@ def _np(x):
     return np.asarray(x)
 
 
+def scene_version(df_obj_list) -> tuple:
+    """What a device cost model built from these objects depends on: identity AND current pose of every ObjectField, identity
+    of a grid's tensors.  The reference evaluates each object from its current pose on every call (primitives.py:387-405), so
+    every cache of a `CostHandle` is keyed by this and a moved object rebuilds it."""
+    out = []
+    for o in df_obj_list:
+        if isinstance(o, GridMapSDF):
+            out.append((id(o), id(o.sdf_tensor)))
+        else:
+            out.append((id(o), o.pos.tobytes(), o.ori.tobytes()))
+    return tuple(out)
+
+
 class PrimitiveShapeField:
     def __init__(self, dim=3, tensor_args=None):
         self.dim = dim
@@ -38,32 +51,6 @@ class PrimitiveShapeField:
 
     def compute_signed_distance(self, x):
         return ObjectField([self]).compute_signed_distance(x)
-
-    def compute_sdf(self, x, reshape_shape=None):             # env_base.py:140-169
-        """Signed distance of the scene (min over the fixed objects -- or their precomputed grid -- and the extra objects) at
-        points x (..., 3); differentiable w.r.t. x.  One `trk_sdf_points` launch for all objects."""
-        objs = self.get_df_obj_list()
-        if not objs:
-            return None
-        key = (str(x.device), tuple(id(o) for o in objs))
-        if getattr(self, "_sdf_cm", None) is None or self._sdf_cm[0] != key:
-            spec = CostModelSpec(n_links_in=1)
-            spec.objects, spec.grid = objects_to_spec_parts(objs)
-            self._sdf_cm = (key, ops.CostHandle(spec, x.device))
-        cm = self._sdf_cm[1]
-        flat = x.reshape(-1, 3)
-        if torch.is_grad_enabled() and x.requires_grad:
-            per_obj = _SDFPoints.apply(flat.contiguous(), cm)
-        else:
-            per_obj = ops.sdf_points(cm, flat)
-        sdf = per_obj.reshape(flat.shape[0], -1).min(dim=1).values
-        return sdf.reshape(reshape_shape) if reshape_shape else sdf.reshape(x.shape[:-1])
-
-    def add_obj(self, obj):                                   # env_base.py:90-92
-        raise NotImplementedError
-
-    def zero_grad(self):
-        pass
 
 
 class MultiSphereField(PrimitiveShapeField):                 # primitives.py:88-121
@@ -150,32 +137,6 @@ class ObjectField(PrimitiveShapeField):                      # primitives.py:346
 
     compute_signed_distance_impl = compute_signed_distance
 
-    def compute_sdf(self, x, reshape_shape=None):             # env_base.py:140-169
-        """Signed distance of the scene (min over the fixed objects -- or their precomputed grid -- and the extra objects) at
-        points x (..., 3); differentiable w.r.t. x.  One `trk_sdf_points` launch for all objects."""
-        objs = self.get_df_obj_list()
-        if not objs:
-            return None
-        key = (str(x.device), tuple(id(o) for o in objs))
-        if getattr(self, "_sdf_cm", None) is None or self._sdf_cm[0] != key:
-            spec = CostModelSpec(n_links_in=1)
-            spec.objects, spec.grid = objects_to_spec_parts(objs)
-            self._sdf_cm = (key, ops.CostHandle(spec, x.device))
-        cm = self._sdf_cm[1]
-        flat = x.reshape(-1, 3)
-        if torch.is_grad_enabled() and x.requires_grad:
-            per_obj = _SDFPoints.apply(flat.contiguous(), cm)
-        else:
-            per_obj = ops.sdf_points(cm, flat)
-        sdf = per_obj.reshape(flat.shape[0], -1).min(dim=1).values
-        return sdf.reshape(reshape_shape) if reshape_shape else sdf.reshape(x.shape[:-1])
-
-    def add_obj(self, obj):                                   # env_base.py:90-92
-        raise NotImplementedError
-
-    def zero_grad(self):
-        pass
-
 
 class GraspedObject(ObjectField):                             # objects.py:10-34
     """An object rigidly held by the end effector; pos / ori are relative to `reference_frame` (a robot link)."""
@@ -250,32 +211,6 @@ class GridMapSDF:                                            # grid_map_sdf.py:9
 
     __call__ = compute_signed_distance
 
-    def compute_sdf(self, x, reshape_shape=None):             # env_base.py:140-169
-        """Signed distance of the scene (min over the fixed objects -- or their precomputed grid -- and the extra objects) at
-        points x (..., 3); differentiable w.r.t. x.  One `trk_sdf_points` launch for all objects."""
-        objs = self.get_df_obj_list()
-        if not objs:
-            return None
-        key = (str(x.device), tuple(id(o) for o in objs))
-        if getattr(self, "_sdf_cm", None) is None or self._sdf_cm[0] != key:
-            spec = CostModelSpec(n_links_in=1)
-            spec.objects, spec.grid = objects_to_spec_parts(objs)
-            self._sdf_cm = (key, ops.CostHandle(spec, x.device))
-        cm = self._sdf_cm[1]
-        flat = x.reshape(-1, 3)
-        if torch.is_grad_enabled() and x.requires_grad:
-            per_obj = _SDFPoints.apply(flat.contiguous(), cm)
-        else:
-            per_obj = ops.sdf_points(cm, flat)
-        sdf = per_obj.reshape(flat.shape[0], -1).min(dim=1).values
-        return sdf.reshape(reshape_shape) if reshape_shape else sdf.reshape(x.shape[:-1])
-
-    def add_obj(self, obj):                                   # env_base.py:90-92
-        raise NotImplementedError
-
-    def zero_grad(self):
-        pass
-
 
 class EnvBase:                                               # env_base.py:17-100
     def __init__(self, name="NameEnvBase", limits=None, obj_fixed_list=None, obj_extra_list=None,
@@ -316,7 +251,7 @@ class EnvBase:                                               # env_base.py:17-10
         objs = self.get_df_obj_list()
         if not objs:
             return None
-        key = (str(x.device), tuple(id(o) for o in objs))
+        key = (str(x.device), scene_version(objs))
         if getattr(self, "_sdf_cm", None) is None or self._sdf_cm[0] != key:
             spec = CostModelSpec(n_links_in=1)
             spec.objects, spec.grid = objects_to_spec_parts(objs)

@@ -15,7 +15,7 @@ import torch
 from . import ops
 from ._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
 from .costmodel import CostModelSpec
-from .environments import _np, objects_to_spec_parts
+from .environments import _np, objects_to_spec_parts, scene_version
 
 
 class DistanceField:
@@ -162,9 +162,7 @@ class CollisionObjectDistanceField(CollisionObjectBase):      # distance_fields.
         self.df_obj_list_fn = df_obj_list_fn
 
     def _scene_version(self):
-        objs = self.df_obj_list_fn() if self.df_obj_list_fn is not None else []
-        return tuple((id(o), getattr(o, "pos", np.zeros(0)).tobytes() if hasattr(o, "pos") else b"",
-                      getattr(o, "ori", np.zeros(0)).tobytes() if hasattr(o, "ori") else b"") for o in objs)
+        return scene_version(self.df_obj_list_fn() if self.df_obj_list_fn is not None else [])
 
     def _fill_spec(self, spec):
         spec.obj_link_idx = self._columns(spec.n_links_in)

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import hashlib
+import os
 import subprocess
 from pathlib import Path
 from typing import Dict, Optional, Sequence, Tuple
@@ -21,11 +22,21 @@ import numpy as np
 from . import _lib, codegen
 from .kinmodel import KinModel
 
-JIT_DIR = Path(__file__).resolve().parent / "csrc" / "jit"
+_CSRC = Path(__file__).resolve().parent / "csrc"
+# Units are cached in the package tree by default (they then travel with it, like libtrk.so); TRK_JIT_DIR moves the cache,
+# e.g. to a per-user directory when the package is installed read-only or shared between users.
+JIT_DIR = Path(os.environ["TRK_JIT_DIR"]).resolve() if os.environ.get("TRK_JIT_DIR") else _CSRC / "jit"
 # same code-generation flags as csrc/Makefile uses for the ahead-of-time units
 GENFLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-_CSRC = JIT_DIR.parent
+_REPO_INCLUDE = _CSRC.parent.parent / "include"
 _loaded: Dict[str, C.CDLL] = {}
+
+
+def _compile_cmd(src: str, out: str):
+    return ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+            "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
+            "-Xarch_device", "-mno-amdgpu-ieee", *GENFLAGS, "-shared", src, "-o", out, f"-L{_CSRC}", "-ltrk",
+            "-Wl,-rpath,$ORIGIN/.." if JIT_DIR == _CSRC / "jit" else f"-Wl,-rpath,{_CSRC}"]
 
 
 def template_hash(tmpl: codegen.CollisionTemplate) -> str:
@@ -37,17 +48,32 @@ def template_hash(tmpl: codegen.CollisionTemplate) -> str:
 
 
 def _generator_stamp() -> str:
+    """Everything a cached unit's machine code and struct layouts depend on: the generator, EVERY header the unit includes
+    (trk_device.h pulls in include/trk.h: TrkRolloutWeights, the TRK_MAX_* limits, TRK_ABI_VERSION), and the full compile
+    command.  A unit whose stamp differs is recompiled; should one slip through anyway (hand-copied cache), its SpecEntry
+    carries the layout stamp and `trk_spec_register` refuses it (see `_load_unit`)."""
     h = hashlib.sha1()
-    for f in (Path(codegen.__file__), _CSRC / "trk_spec_common.h", _CSRC / "trk_device.h"):
+    for f in (Path(codegen.__file__), _CSRC / "trk_spec_common.h", _CSRC / "trk_device.h", _CSRC / "trk_launch.h",
+              _REPO_INCLUDE / "trk.h"):
         h.update(f.read_bytes())
-    h.update(" ".join(GENFLAGS).encode())
-    return h.hexdigest()[:8]
+    h.update(" ".join(_compile_cmd("<src>", "<out>")).replace(str(_CSRC), "<csrc>").encode())   # location-independent
+    return h.hexdigest()[:12]
+
+
+def _load_unit(so: Path, ident: str) -> C.CDLL:
+    """dlopen a unit and make sure libtrk.so accepted its registration (it refuses another struct layout)."""
+    L = _lib.lib()                                  # libtrk.so first: the unit's initialiser calls into it
+    before = L.trk_spec_count()
+    handle = C.CDLL(str(so))
+    if L.trk_spec_count() != before + 1:
+        raise _lib.TrkError(f"{so.name}: libtrk.so refused the unit (compiled against another SpecArgs/SpecEntry layout); "
+                            f"delete {so} and retry")
+    return handle
 
 
 def _compile_unit(source: str, ident: str, verbose: bool) -> Path:
     """source -> csrc/jit/spec_<ident>.so.  Every file appears under its final name by an atomic rename, so several
     processes (one per GPU) compiling the same unit at the same time cannot hand each other a half-written object."""
-    import os
     JIT_DIR.mkdir(parents=True, exist_ok=True)
     src, so, stamp = JIT_DIR / f"spec_{ident}.hip", JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
     want = _generator_stamp()
@@ -59,10 +85,7 @@ def _compile_unit(source: str, ident: str, verbose: bool) -> Path:
     src_tmp = JIT_DIR / f"spec_{ident}{tag}.hip"
     so_tmp = JIT_DIR / f"spec_{ident}{tag}.so"
     src_tmp.write_text(source)
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
-           "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
-           "-Xarch_device", "-mno-amdgpu-ieee", *GENFLAGS, "-shared", str(src_tmp), "-o", str(so_tmp), f"-L{_CSRC}", "-ltrk",
-           "-Wl,-rpath,$ORIGIN/.."]
+    cmd = _compile_cmd(str(src_tmp), str(so_tmp))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         src_tmp.unlink(missing_ok=True)
@@ -104,8 +127,7 @@ def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tup
                                      ee2_link=int(ee2_link))
     ident = unit_ident(kin, tmpl, pipeline)
     if ident not in _loaded:
-        _lib.lib()                                  # libtrk.so first: the unit's initialiser calls into it
-        _loaded[ident] = C.CDLL(str(build_unit(kin, tmpl, verbose, pipeline)))
+        _loaded[ident] = _load_unit(build_unit(kin, tmpl, verbose, pipeline), ident)
         _loaded_templates[ident] = (codegen.model_hash(kin), tmpl)
     return ident
 
@@ -222,7 +244,6 @@ def specialize_points(kin: KinModel, point_link, point_offset, spec, verbose: bo
     so, stamp = JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
     if not (so.exists() and stamp.exists() and stamp.read_text() == _generator_stamp()):
         so = _compile_unit(codegen.generate_points_rollout_source(kin, pt, ident), ident, verbose)
-    _lib.lib()
-    _loaded[ident] = C.CDLL(str(so))
+    _loaded[ident] = _load_unit(so, ident)
     _loaded_point_templates[ident] = (codegen.model_hash(kin), pt)
     return ident

@@ -45,25 +45,33 @@ class Frame:
         return H
 
     def get_quaternion(self) -> torch.Tensor:
-        """wxyz via rotation_matrix_to_q (the reference's per-sample Python loop frame.py:87-114 returns xyzw)."""
+        """XYZW by the trace method, exactly as the reference's per-sample loop (frame.py:87-114; its callers convert with
+        `q_convert_wxyz`, robot_tree.py:214-215).  One `trk_frame_quat_euler` launch for the whole batch."""
+        return ops.frame_quat_euler(self._rot)[0]
+
+    def get_quaternion_wxyz(self) -> torch.Tensor:
+        """WXYZ through `rotation_matrix_to_q` (quaternion.py:135-166) -- what `link_quat_from_link_tensor` returns."""
         return ops.rotmat_to_quat(self._rot)
 
-    # Pose algebra on the tensors a Frame already holds (frame.py:55-78, 116-121): tensor plumbing for callers that work
-    # with the `return_dict=True` frames; the batched paths (points on links, composed chains) are the kernels.
+    # Pose algebra (frame.py:55-78, 116-121) runs in the trk_frame_* kernels with an explicit reverse mode, so frames taken
+    # from `return_dict=True` compose and differentiate like the reference's.
     def inverse(self) -> "Frame":
-        rt = self._rot.transpose(-2, -1)
-        return Frame(rt, -(rt @ self._trans.unsqueeze(2)).squeeze(2))
+        return Frame(*ops.frame_compose(ops.FRAME_INVERSE, self._rot, self._trans))
 
     def multiply_transform(self, frame: "Frame") -> "Frame":
-        return Frame(self._rot @ frame.rotation, (self._rot @ frame.translation.unsqueeze(2)).squeeze(2) + self._trans)
+        return Frame(*ops.frame_compose(ops.FRAME_COMPOSE, self._rot, self._trans, frame.rotation, frame.translation))
+
+    def multiply_inv_transform(self, frame: "Frame") -> "Frame":
+        """frame^-1 o self (frame.py:70-76 calls multiply_inv_transform(frame.rot, frame.trans, self.rot, self.trans))."""
+        return Frame(*ops.frame_compose(ops.FRAME_INV_COMPOSE, self._rot, self._trans, frame.rotation, frame.translation))
 
     def transform_point(self, point: torch.Tensor) -> torch.Tensor:
         """point (P, 3) in this frame -> (B, P, 3) in the world (what fk_map_collision does for grasped-object points)."""
-        return (self._rot @ point.unsqueeze(0).transpose(-1, -2)).transpose(-1, -2) + self._trans.unsqueeze(-2)
+        return ops.frame_transform_points(self._rot, self._trans, point)
 
     def get_euler(self):
-        return (torch.atan2(self._rot[:, 2, 1], self._rot[:, 2, 2]), torch.asin(-self._rot[:, 2, 0]),
-                torch.atan2(self._rot[:, 1, 0], self._rot[:, 0, 0]))
+        e = ops.frame_quat_euler(self._rot, want_quat=False, want_euler=True)[1]
+        return e[:, 0], e[:, 1], e[:, 2]
 
 
 class DifferentiableTree(torch.nn.Module):

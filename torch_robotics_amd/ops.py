@@ -32,6 +32,25 @@ def _dev_f32(t: torch.Tensor, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _check_q_dofs(q: torch.Tensor, n_dofs: int, what: str) -> None:
+    """The C ABI sees only a pointer plus (B, H): a q whose last dimension is not the model's DOF count (a full state with
+    velocities, another robot's trajectory) would be read with the wrong stride, so it is refused here."""
+    if q.dim() == 0 or int(q.shape[-1]) != int(n_dofs):
+        raise ValueError(f"{what}: last dimension of q is {tuple(q.shape)[-1] if q.dim() else '()'}, the model has "
+                         f"{n_dofs} DOF (pass robot.get_position(x) for a state with velocities)")
+
+
+def _check_buffer(t: Optional[torch.Tensor], shape_numel: int, dtype, device, what: str, at_least: bool = False) -> None:
+    """Caller-provided output buffer: right device, dtype, size, and contiguous (the kernels write raw pointers)."""
+    if t is None:
+        return
+    if not isinstance(t, torch.Tensor) or t.device != device:
+        raise ValueError(f"{what}: must be a tensor on {device}")
+    if t.dtype != dtype or not t.is_contiguous() or (t.numel() < shape_numel if at_least else t.numel() != shape_numel):
+        raise ValueError(f"{what}: expected a contiguous {dtype} tensor of {shape_numel} elements, got "
+                         f"{t.dtype} {tuple(t.shape)}{'' if t.is_contiguous() else ' (non-contiguous)'}")
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -275,6 +294,130 @@ def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Frame algebra (geometrics/frame.py:55-121): trk_frame_* kernels, explicit reverse mode
+# ----------------------------------------------------------------------------------------------------------------------
+FRAME_COMPOSE, FRAME_INVERSE, FRAME_INV_COMPOSE = 0, 1, 2
+
+
+def _pose_args(R: torch.Tensor, t: torch.Tensor, what: str):
+    R, t = _dev_f32(R, what + "(rot)"), _dev_f32(t, what + "(trans)")
+    if R.dim() != 3 or R.shape[1:] != (3, 3) or t.dim() != 2 or t.shape[1] != 3 or t.shape[0] != R.shape[0]:
+        raise ValueError(f"{what}: expected rot (n,3,3) and trans (n,3), got {tuple(R.shape)} / {tuple(t.shape)}")
+    return R, t
+
+
+def _frame_compose_raw(op, Ra, ta, Rb, tb):
+    na = int(Ra.shape[0])
+    nb = int(Rb.shape[0]) if Rb is not None else na
+    if op != FRAME_INVERSE and na != nb and na != 1 and nb != 1:
+        raise ValueError(f"frame algebra: batch sizes {na} and {nb} do not broadcast")
+    n = na if op == FRAME_INVERSE else max(na, nb)
+    Ro = torch.empty((n, 3, 3), device=Ra.device, dtype=torch.float32)
+    to = torch.empty((n, 3), device=Ra.device, dtype=torch.float32)
+    with torch.cuda.device(Ra.device):
+        check(lib().trk_frame_compose(op, Ra.data_ptr(), ta.data_ptr(), na, _ptr(Rb), _ptr(tb), nb, Ro.data_ptr(),
+                                      to.data_ptr(), _stream(Ra)), "trk_frame_compose")
+    return Ro, to
+
+
+class _FrameCompose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, Ra, ta, Rb, tb):
+        ctx.op = op
+        ctx.save_for_backward(Ra, ta, Rb, tb)
+        return _frame_compose_raw(op, Ra, ta, Rb, tb)
+
+    @staticmethod
+    def backward(ctx, gR, gt):
+        Ra, ta, Rb, tb = ctx.saved_tensors
+        n = int(Ra.shape[0])
+        gR = torch.zeros_like(Ra) if gR is None else _dev_f32(gR, "frame backward")
+        gt = torch.zeros_like(ta) if gt is None else _dev_f32(gt, "frame backward")
+        gRa, gta = torch.empty_like(Ra), torch.empty_like(ta)
+        two = ctx.op != FRAME_INVERSE
+        gRb, gtb = (torch.empty_like(Rb), torch.empty_like(tb)) if two else (None, None)
+        with torch.cuda.device(Ra.device):
+            check(lib().trk_frame_compose_backward(ctx.op, Ra.data_ptr(), ta.data_ptr(), _ptr(Rb) if two else None,
+                                                   _ptr(tb) if two else None, gR.data_ptr(), gt.data_ptr(), n, gRa.data_ptr(),
+                                                   gta.data_ptr(), _ptr(gRb), _ptr(gtb), _stream(Ra)),
+                  "trk_frame_compose_backward")
+        return None, gRa, gta, gRb, gtb
+
+
+def frame_compose(op: int, Ra, ta, Rb=None, tb=None):
+    """(rot, trans) of `a o b` (FRAME_COMPOSE), `a^-1` (FRAME_INVERSE) or `b^-1 o a` (FRAME_INV_COMPOSE); differentiable
+    w.r.t. every input pose.  A batch-1 frame broadcasts (it is expanded first when a gradient has to flow into it)."""
+    Ra, ta = _pose_args(Ra, ta, "frame_compose(a)")
+    if op == FRAME_INVERSE:
+        Rb, tb = Ra, ta                                         # placeholders for the autograd signature
+    else:
+        Rb, tb = _pose_args(Rb, tb, "frame_compose(b)")
+    needs_grad = torch.is_grad_enabled() and any(x.requires_grad for x in (Ra, ta, Rb, tb))
+    if not needs_grad:
+        return _frame_compose_raw(op, Ra, ta, None if op == FRAME_INVERSE else Rb, None if op == FRAME_INVERSE else tb)
+    n = max(Ra.shape[0], Rb.shape[0])
+    if Ra.shape[0] != n:
+        Ra, ta = Ra.expand(n, 3, 3).contiguous(), ta.expand(n, 3).contiguous()
+    if Rb.shape[0] != n:
+        Rb, tb = Rb.expand(n, 3, 3).contiguous(), tb.expand(n, 3).contiguous()
+    return _FrameCompose.apply(op, Ra, ta, Rb, tb)
+
+
+class _FrameTransformPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R, t, pts):
+        n, P = int(R.shape[0]), int(pts.shape[0])
+        out = torch.empty((n, P, 3), device=R.device, dtype=torch.float32)
+        with torch.cuda.device(R.device):
+            check(lib().trk_frame_transform_points(R.data_ptr(), t.data_ptr(), n, pts.data_ptr(), P, out.data_ptr(), _stream(R)),
+                  "trk_frame_transform_points")
+        ctx.save_for_backward(pts)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (pts,) = ctx.saved_tensors
+        g = _dev_f32(g, "transform_point backward")
+        gR = torch.empty((ctx.n, 3, 3), device=g.device, dtype=torch.float32)
+        gt = torch.empty((ctx.n, 3), device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            check(lib().trk_frame_transform_points_backward(g.data_ptr(), ctx.n, pts.data_ptr(), int(pts.shape[0]),
+                                                            gR.data_ptr(), gt.data_ptr(), _stream(g)),
+                  "trk_frame_transform_points_backward")
+        return gR, gt, None
+
+
+def frame_transform_points(R, t, points):
+    """points (P,3) in the frames -> (n,P,3) in their parent frame; differentiable w.r.t. the poses (the reference's callers
+    transform constant point sets -- grasped-object vertices -- so no gradient is produced for `points`)."""
+    R, t = _pose_args(R, t, "frame_transform_points")
+    pts = _dev_f32(points, "frame_transform_points(points)").reshape(-1, 3)
+    if torch.is_grad_enabled() and pts.requires_grad:
+        raise NotImplementedError("frame_transform_points: no gradient w.r.t. the points (constant point sets only)")
+    return _FrameTransformPoints.apply(R, t, pts)
+
+
+def frame_quat_euler(R: torch.Tensor, want_quat=True, want_euler=False):
+    """Frame.get_quaternion (trace method, XYZW -- frame.py:87-114) / Frame.get_euler (frame.py:120-121) of (n,3,3) rotations
+    or (n,4,4) transforms.  Not differentiable (neither is the reference's per-sample loop in practice)."""
+    R = _dev_f32(R.detach(), "frame_quat_euler(R)")
+    if R.shape[-2:] == (3, 3):
+        stride, pitch = 9, 3
+    elif R.shape[-2:] == (4, 4):
+        stride, pitch = 16, 4
+    else:
+        raise ValueError("frame_quat_euler: expected (...,3,3) or (...,4,4)")
+    batch = R.shape[:-2]
+    n = int(np.prod(batch)) if len(batch) else 1
+    quat = torch.empty(tuple(batch) + (4,), device=R.device, dtype=torch.float32) if want_quat else None
+    eul = torch.empty(tuple(batch) + (3,), device=R.device, dtype=torch.float32) if want_euler else None
+    with torch.cuda.device(R.device):
+        check(lib().trk_frame_quat_euler(R.data_ptr(), n, stride, pitch, _ptr(quat), _ptr(eul), _stream(R)), "trk_frame_quat_euler")
+    return quat, eul
+
+
 def cost_fields(cm: CostHandle, fields: int, link_pos: torch.Tensor, gcost: Optional[torch.Tensor] = None,
                 want_grad: bool = False):
     link_pos = _dev_f32(link_pos, "cost_fields(link_pos)").reshape(-1, cm.n_links_in, 3)
@@ -331,6 +474,7 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
     else:
         q = _dev_f32(q, "rollout_cost_grad(q)")
     io = torch.float16 if f16 else torch.float32
+    _check_q_dofs(q, model.n_dofs, "rollout_cost_grad(q)")
     lead = q.shape[:-1]
     if q.dim() == 3:
         B, Hh = int(q.shape[0]), int(q.shape[1])
@@ -344,8 +488,12 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
         gq = torch.empty((n, D), device=q.device, dtype=io)
     else:
         pos, cost, gq = out
-        if gq.dtype != io or (pos is not None and pos.dtype != io) or cost.dtype != torch.float32:
-            raise ValueError("rollout_cost_grad(out): link_pos / gq must have q's dtype and cost must be float32")
+        _check_buffer(pos, n * L * 3, io, q.device, "rollout_cost_grad(out[0] = link_pos)")
+        _check_buffer(cost, n, torch.float32, q.device, "rollout_cost_grad(out[1] = cost)")
+        _check_buffer(gq, n * D, io, q.device, "rollout_cost_grad(out[2] = gq)")
+        if cost is None or gq is None:
+            raise ValueError("rollout_cost_grad(out): cost and gq buffers are required (link_pos may be None)")
+    _check_buffer(cost_sum, n_blocks(n), torch.float32, q.device, "rollout_cost_grad(cost_sum)", at_least=True)
     w = _abi.RolloutWeights(*[float(v) for v in weights])
     fn = lib().trk_rollout_cost_grad_f16 if f16 else lib().trk_rollout_cost_grad
     with torch.cuda.device(q.device):
@@ -361,6 +509,7 @@ def rollout_points_cost_grad(ps: PointSetHandle, cm: CostHandle, weights, q: tor
     (point_pos (…,P,3) or None, cost (…), gq (…,D))."""
     model = ps.model
     q = _dev_f32(q, "rollout_points_cost_grad(q)")
+    _check_q_dofs(q, model.n_dofs, "rollout_points_cost_grad(q)")
     lead = q.shape[:-1]
     if q.dim() == 3:
         B, Hh = int(q.shape[0]), int(q.shape[1])
@@ -371,6 +520,7 @@ def rollout_points_cost_grad(ps: PointSetHandle, cm: CostHandle, weights, q: tor
     pos = torch.empty((n, P, 3), device=q.device, dtype=torch.float32) if want_pos else None
     cost = torch.empty((n,), device=q.device, dtype=torch.float32)
     gq = torch.empty((n, D), device=q.device, dtype=torch.float32)
+    _check_buffer(cost_sum, n_blocks(n), torch.float32, q.device, "rollout_points_cost_grad(cost_sum)", at_least=True)
     w = _abi.RolloutWeights(*[float(v) for v in weights])
     with torch.cuda.device(q.device):
         check(lib().trk_rollout_points_cost_grad(model._h, ps._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos),
@@ -654,6 +804,7 @@ class RolloutPlan:
         q = q.contiguous() if (f16 and q.device.type == "cuda") else _dev_f32(q, "RolloutPlan(q)")
         if q.dim() != 3:
             raise ValueError("RolloutPlan: q must be (batch, horizon, dof)")
+        _check_q_dofs(q, model.n_dofs, "RolloutPlan(q)")
         self.model, self.cm, self.q = model, cm, q
         self.B, self.H = int(q.shape[0]), int(q.shape[1])
         n, L, D = self.B * self.H, model.n_links, model.n_dofs

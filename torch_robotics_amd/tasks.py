@@ -12,7 +12,7 @@ import torch
 from . import ops
 from ._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
 from .costmodel import CostModelSpec
-from .environments import _np, objects_to_spec_parts
+from .environments import _np, objects_to_spec_parts, scene_version
 from .fields import CollisionObjectDistanceField, CollisionWorkspaceBoundariesDistanceField
 
 
@@ -136,12 +136,15 @@ class PlanningTask(Task):
         return spec
 
     def _fused_handles(self, device):
-        if self._fused is None or self._fused[2] != str(device):
+        # keyed by device AND the scene's current object poses: the reference reads each object's pose on every evaluation,
+        # so `obj.set_position_orientation(...)` between two calls must be seen here too (a moved object rebuilds the tables)
+        key = (str(device), scene_version(self.env.get_df_obj_list()))
+        if self._fused is None or self._fused[2] != key:
             spec = self.build_cost_spec()
             if not self._has_tree:                         # no kinematics: only the cost model is needed
-                self._fused = (None, ops.CostHandle(spec, device), str(device))
+                self._fused = (None, ops.CostHandle(spec, device), key)
                 return self._fused[0], self._fused[1]
-            self._fused = (self.robot.diff_panda._handle, ops.CostHandle(spec, device), str(device))
+            self._fused = (self.robot.diff_panda._handle, ops.CostHandle(spec, device), key)
             if self.auto_specialize and not self._jit_failed:
                 try:                                   # a unit whose template equals this cost model may already exist
                     from . import jit
