@@ -19,18 +19,32 @@ task.set_ee_target(Ht)
 B, H = 4096, 64
 q = robot.random_q(B * H).reshape(B, H, 7).contiguous()
 model, cm = task._fused_handles(dev)
-plan = ops.RolloutPlan(model, cm, (0, 1, 0, 1), q)
+NO_POS = "--no-pos" in sys.argv
+W = tuple(float(v) for v in sys.argv[sys.argv.index("--weights") + 1].split(",")) if "--weights" in sys.argv else (0, 1, 0, 1)
+TAG = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "default"
+plan = ops.RolloutPlan(model, cm, W, q, want_pos=not NO_POS)
 nb = ops.n_blocks(B * H)
 bs = torch.zeros(nb, **ta)
-for _ in range(20):
+for _ in range(200):
     plan.launch(bs.data_ptr())
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(2000):
+    plan.launch(bs.data_ptr())
+e1.record()
+torch.cuda.synchronize()
+print(f"[{TAG}] launch time by events: {e0.elapsed_time(e1) / 2000 * 1e3:.2f} us")
 stamps = torch.zeros((nb, 8), device=dev, dtype=torch.int64)
 lib().trk_debug_set_stamp_buffer(stamps.data_ptr())
 plan.launch(bs.data_ptr())
 torch.cuda.synchronize()
 lib().trk_debug_set_stamp_buffer(None)
-s = stamps.cpu().numpy().astype(np.float64)
+raw = stamps.cpu().numpy()
+out_dir = ROOT / "gpurun_out"
+out_dir.mkdir(exist_ok=True)
+np.save(out_dir / f"phase_stamps_{TAG}.npy", raw)                      # raw ticks, for offline analysis
+s = raw.astype(np.float64)
 t0 = s[:, 0].min()
 s -= t0
 names = ["entry", "q loaded", "kernargs arrived", "pos staged", "objects done", "objectives done", "reverse done", "exit"]

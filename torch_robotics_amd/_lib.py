@@ -15,7 +15,8 @@ import torch  # noqa: F401  (must be imported first: libtrk.so binds to the HIP 
 from . import _abi
 
 _CSRC = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = _CSRC / "libtrk.so"
+# TRK_LIBTRK=<path> loads another build of the same ABI (same-box A/B measurements of two kernel versions)
+LIB_PATH = Path(os.environ["TRK_LIBTRK"]).resolve() if os.environ.get("TRK_LIBTRK") else _CSRC / "libtrk.so"
 _lib = None
 
 EXPORTS = [

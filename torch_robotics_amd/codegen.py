@@ -17,6 +17,8 @@ Math restated from the reference: rigid_body.py:146-211 (joint transforms), SURV
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -290,7 +292,7 @@ def _emit_joint_gradient(E: "Emitter", kin: KinModel, i: int, R, t, Fi, Ti, mask
 
 
 def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, List[str]], rot_adj: Dict[int, str], masked,
-                        tick: Optional[str] = None) -> Dict[int, S]:
+                        tick=None) -> Dict[int, S]:
     """Reverse pass of the link kernels: per-link wrench accumulators (F, T about the world origin) pushed towards the
     root; `tb_names[i]` = the three C expressions holding link i's position adjoint; a tracked link i adds
     axial(Rb R^T) with Rb = the 9-float array named rot_adj[i]."""
@@ -302,7 +304,7 @@ def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, L
         i = int(kin.order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
         E.raw(f"    // reverse: link {i}")
         if tick is not None and p % 2 == 0:
-            E.raw(tick)
+            E.raw(tick())                       # a callable: every tick carries its own compile-time chunk number
         if i in tb_names:
             tb = [S(1.0, n) for n in tb_names[i]]
             own_T = E.cross(t[i], tb)
@@ -340,6 +342,10 @@ def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, L
     return gq_expr
 
 
+# tick slots handed to one scene evaluation (csrc/trk_device.h: TRK_OBJ_TICK_SLOTS must agree)
+OBJ_TICK_SLOTS = int(os.environ.get("TRK_EXP_OBJ_SLOTS", "5"))
+
+
 def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, snap: float = SNAP) -> str:
     L, D = kin.n_links, kin.n_dofs
     NL = len(tmpl.obj_links)
@@ -357,6 +363,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append('#include "trk_spec_common.h"')
     out.append(f"namespace spec_{ident} {{")
     out.append(f"constexpr int L = {L}, D = {D}, NL = {NL};")
+    out.append(f'static_assert(TRK_OBJ_TICK_SLOTS == {OBJ_TICK_SLOTS}, "chunk numbering of this unit assumes another TRK_OBJ_TICK_SLOTS");')
 
     for base_identity in (True, False):
         E = Emitter()
@@ -376,7 +383,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    spec_stamp(A.stamps, wblock, 0, lane);")
-        E.raw("    if (A.stamps) { asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); if (rows >= 0 && A.q) spec_stamp(A.stamps, wblock, 2, lane); }")
+        E.raw("    spec_stamp_real(A.stamps, wblock, 2, lane);      // 100 MHz chip-wide clock: aligns the per-CU s_memtime domains")
         E.raw("    float q[D];")
         E.raw("    spec_load_q<D>(static_cast<const IO*>(A.q), base, rows, lane, lds, q);")
         E.raw("    spec_stamp(A.stamps, wblock, 1, lane);")
@@ -421,14 +428,24 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         if chunked:
             E.raw("    NoFlush flush;")
         else:
-            E.raw(f"    PosFlusher<{3 * L}, IO> flush{{nullptr, nullptr, lane, PosFlusher<{3 * L}, IO>::NCHUNK}};")
+            E.raw(f"    PosFlusher<{3 * L}, IO> flush{{nullptr, 0u, 0ull, false, lane}};")
             pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
             E.raw("    if (A.link_pos) {")
             E.raw(f"        const float pv[{3 * L}] = {{{pos_list}}};")
             E.raw(f"        flush = spec_stage_rows<{3 * L}>(static_cast<IO*>(A.link_pos), base, rows, lane, lds, pv);")
             E.raw("    }")
-        E.raw("    if (!A.gq) { flush.flush(); return; }      // positions only (trk_fk_positions): wave-uniform exit")
-        E.raw("    flush(); flush();")
+        E.raw("    if (!A.gq) { flush.template rest<0>(); return; }      // positions only (trk_fk_positions): wave-uniform exit")
+        # position chunks leave at tick points with COMPILE-TIME chunk numbers (PosFlusher::chunk<CH>); `next_chunk` counts them
+        next_chunk = [0]
+
+        def tick_line(indent="    "):
+            c = next_chunk[0]
+            next_chunk[0] += 1
+            return f"{indent}flush.template chunk<{c}>();"
+        # experiment knob: TRK_EXP_FIRST_BURST=n issues the first n chunks right after staging (default none: +0.35 us with 2)
+        first = int(os.environ.get("TRK_EXP_FIRST_BURST", "0"))
+        for _ in range(first):
+            E.raw(tick_line())
         E.raw("    spec_stamp(A.stamps, wblock, 3, lane);")
         # ---------------- objectives ----------------
         E.raw("    float cost = 0.0f;")
@@ -440,7 +457,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw("    float gx[NL], gy[NL], gz[NL];")
             E.raw("#pragma unroll")
             E.raw("    for (int l = 0; l < NL; ++l) { gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }")
-            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, flush, lds_sph);")
+            c0 = next_chunk[0]
+            next_chunk[0] += OBJ_TICK_SLOTS     # the scene evaluation owns these tick slots, used or flushed on every path
+            E.raw(f"    const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
+            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph);")
+            E.raw(f"    else flush.template range<{c0}, {next_chunk[0]}>();")
             E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
             for j, i in enumerate(tmpl.obj_links):
                 E.raw(f"    tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
@@ -458,7 +479,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 E.raw(f"        float gx[{n}], gy[{n}], gz[{n}];")
                 E.raw("#pragma unroll")
                 E.raw(f"        for (int l = 0; l < {n}; ++l) {{ gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }}")
-                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, flush, lds_sph, {g0});")
+                c0 = next_chunk[0]
+                next_chunk[0] += OBJ_TICK_SLOTS
+                E.raw(f"        const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
+                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, {g0});")
+                E.raw(f"        else flush.template range<{c0}, {c0 + OBJ_TICK_SLOTS}>();")
                 E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<{n}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {g0});")
                 for j, i in enumerate(grp):
                     E.raw(f"        tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
@@ -489,7 +514,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                       f"tb{ee}_2 = fmaf(A.w.w_ee, gt[2], tb{ee}_2);")
                 E.raw("      }")
             E.raw("    }")
-        E.raw("    flush();")
+        E.raw(tick_line())
         E.raw("    spec_stamp(A.stamps, wblock, 5, lane);")
         E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
         E.raw("    if (A.cost_sum) {")
@@ -500,9 +525,9 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # (A second FK walk with prefix-sum gradients instead of this reverse pass -- so that the joints' axes / origins need not
         # stay alive -- was measured on UR10+Allegro: 41.3 vs 37.5 us.  These kernels are bound by VALU issue, not by occupancy.)
         gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"tb{i}_{k}" for k in range(3)] for i in adj_links},
-                                      {l: rb for l, _, rb in tracked}, masked, tick="    flush();")
+                                      {l: rb for l, _, rb in tracked}, masked, tick=tick_line)
         E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
-        E.raw("    flush.flush();")
+        E.raw(f"    flush.template rest<{next_chunk[0]}>();")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D>(static_cast<IO*>(A.gq), base, rows, lane, lds, gv);")
         E.raw("    spec_stamp(A.stamps, wblock, 7, lane);")

@@ -664,7 +664,8 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     const size_t o_sph = o_sm + al(sizeof(float) * (d->n_self_pairs + 1));
     const size_t o_sel = o_sph + al(sizeof(float4) * (d->n_prims + 1));
     const size_t o_box = o_sel + al(sizeof(float4) * (d->n_prims + 1));
-    const size_t total = o_box + al(sizeof(int32_t) * (d->n_objects + 1));
+    const size_t o_pair = o_box + al(sizeof(int32_t) * (d->n_objects + 1));
+    const size_t total = o_pair + al(sizeof(float) * 8 * ((d->n_prims + 2) / 2));
     std::vector<char> blob(total, 0);
     std::vector<float4> spheres;
     if (d->n_obj_links) {
@@ -704,6 +705,10 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     int32_t* sp = reinterpret_cast<int32_t*>(blob.data() + o_sp);
     for (int p = 0; p < 2 * d->n_self_pairs; ++p) sp[p] = d->self_link_idx[d->self_pairs[p]];
     if (d->n_self_pairs) std::memcpy(blob.data() + o_sm, d->self_margin, sizeof(float) * d->n_self_pairs);
+    const size_t n_real_spheres = spheres.size();
+    // An odd table gets a copy of its last sphere appended: the ranking loop then works on whole PAIRS, and whichever index
+    // of the duplicate wins addresses the same centre (n_spheres stays the real count for every other path).
+    if (spheres.size() & 1) spheres.push_back(spheres.back());
     if (!spheres.empty()) std::memcpy(blob.data() + o_sph, spheres.data(), sizeof(float4) * spheres.size());
     {
         float4* sel = reinterpret_cast<float4*>(blob.data() + o_sel);
@@ -711,6 +716,14 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
             const float4& sp = spheres[k];
             sel[k].x = -2.0f * sp.x; sel[k].y = -2.0f * sp.y; sel[k].z = -2.0f * sp.z;
             sel[k].w = (float)((double)sp.x * sp.x + (double)sp.y * sp.y + (double)sp.z * sp.z);
+        }
+        // the same rows, two spheres (S, T) interleaved per record: [Sx Tx | Sy Ty | Sz Tz | Sw Tw] -- the operand layout of
+        // v_pk_fma_f32 with one packed lane per sphere
+        float* pair = reinterpret_cast<float*>(blob.data() + o_pair);
+        for (size_t j = 0; j + 1 < spheres.size(); j += 2) {
+            const float4 &S = sel[j], &T = sel[j + 1];
+            float* r = pair + 4 * j;
+            r[0] = S.x; r[1] = T.x; r[2] = S.y; r[3] = T.y; r[4] = S.z; r[5] = T.z; r[6] = S.w; r[7] = T.w;
         }
     }
     int n_box = 0;
@@ -721,6 +734,7 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     }
     bool uniform_r = !spheres.empty();
     for (const float4& sp : spheres) uniform_r = uniform_r && sp.w == spheres[0].w;
+    const int n_sphere_pairs = (int)(spheres.size() / 2);
 
     TrkCostModel* cm = new (std::nothrow) TrkCostModel();
     if (!cm) return fail(TRK_ERR_HIP, "out of host memory");
@@ -756,7 +770,9 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     h.spheres_sel = reinterpret_cast<const float4*>(base + o_sel);
     h.box_objects = reinterpret_cast<const int32_t*>(base + o_box);
     h.n_box_objects = n_box;
-    h.n_spheres = (int32_t)spheres.size();
+    h.n_spheres = (int32_t)n_real_spheres;
+    h.sphere_pairs = reinterpret_cast<const float*>(base + o_pair);
+    h.n_sphere_pairs = n_sphere_pairs;
     h.spheres_uniform_r = uniform_r ? 1 : 0;
     h.sphere_r = spheres.empty() ? 0.0f : spheres[0].w;
     if (n_grid) {

@@ -94,6 +94,11 @@ struct DevCostHdr {
     int32_t n_box_objects;         // objects that still have non-sphere primitives (not the grid)
     const int32_t* box_objects;    // device: their indices into objects[]
     DevGrid grid;
+    // spheres_sel again, two spheres per record: [Sx Tx | Sy Ty | Sz Tz | Sw Tw] (S = sphere 2j, T = sphere 2j + 1).  An odd
+    // table is padded with a copy of its last sphere (spheres[] / spheres_sel[] hold the copy too, n_spheres does not count it).
+    const float* sphere_pairs;     // device
+    int32_t n_sphere_pairs;
+    int32_t _pad_pairs;
 };
 
 // Points rigidly attached to links (grasped-object points robot_panda.py:154-168, per-link collision spheres):
@@ -133,6 +138,13 @@ __device__ __forceinline__ DevObj load_obj(const DevObj* objs, int i) {
     for (int k = 0; k < 9; ++k) O.R[k] = c->R[k];
     O.prim_begin = c->prim_begin; O.prim_end = c->prim_end; O.is_grid = c->is_grid; O.identity = c->identity;
     return O;
+}
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 load_f8_uniform(const __attribute__((address_space(4))) float* p, int i) {   // one s_load_dwordx8
+    F8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.v[k] = p[8 * i + k];
+    return r;
 }
 struct F4 { float x, y, z, w; };
 __device__ __forceinline__ F4 load_f4_uniform(const float4* p, int i) {      // wave-uniform index: scalar load
@@ -384,7 +396,42 @@ __device__ __forceinline__ float object_sdf(const DevCostHdr& C, int o, float x,
 // min over the whole scene (merged spheres, then objects with non-sphere primitives / the grid) of the signed
 // distance at NL points held in registers, with the world-frame gradient of the arg-min primitive.
 // = min_o sdf_o(p)  of distance_fields.py:307-316 + :121-122 (max over objects of margin - sdf).
-struct NoTick { __device__ __forceinline__ void operator()() const {} };
+// Tick slots the scene evaluation owns: one per sphere pair for the first pairs.  The generator numbers the position chunks
+// at compile time, so this must equal codegen.OBJ_TICK_SLOTS.  Same-box A/B on the headline workload (4096 x 64, 9 chunks,
+// 5 pairs): 8 slots 10.58 us (the three slots behind the last pair fire back to back), 6 -> 10.42, 5 -> 10.21, 4 -> 10.27,
+// 3 -> 10.35; chunks issued right after staging cost +0.35 us.  The store pipe wants a smooth, late trickle: a wave that
+// issues faster than HBM drains just sits at its next store.
+#ifndef TRK_OBJ_TICK_SLOTS
+#define TRK_OBJ_TICK_SLOTS 5
+#endif
+struct NoTick { template <int J> __device__ __forceinline__ void at() const {} };
+
+template <int J, class Tick>
+__device__ __forceinline__ void scene_all_ticks(const Tick& tick) {
+    if constexpr (J < TRK_OBJ_TICK_SLOTS) { tick.template at<J>(); scene_all_ticks<J + 1>(tick); }
+}
+// One guarded trip of the pair-ranking loop (see scene_min_sdf): pair J of at most 8.
+template <int NL, int J, class Tick>
+__device__ __forceinline__ void scene_rank_pairs(const TRK_CAS float* tab, int np, const float (&px)[NL], const float (&py)[NL],
+                                                 const float (&pz)[NL], float (&bk)[NL], const Tick& tick) {
+    if constexpr (J < 8) {
+        if constexpr (J < TRK_OBJ_TICK_SLOTS) tick.template at<J>();
+        if (J < np) {
+            const trk_f2 cx = {tab[8 * J + 0], tab[8 * J + 1]}, cy = {tab[8 * J + 2], tab[8 * J + 3]},
+                         cz = {tab[8 * J + 4], tab[8 * J + 5]}, cw = {tab[8 * J + 6], tab[8 * J + 7]};
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const trk_f2 key = __builtin_elementwise_fma(trk_f2{px[l], px[l]}, cx,
+                                   __builtin_elementwise_fma(trk_f2{py[l], py[l]}, cy,
+                                   __builtin_elementwise_fma(trk_f2{pz[l], pz[l]}, cz, cw)));
+                const float ks = __uint_as_float((__float_as_uint(key.x) & ~15u) | (unsigned)(2 * J));
+                const float kt = __uint_as_float((__float_as_uint(key.y) & ~15u) | (unsigned)(2 * J + 1));
+                bk[l] = __builtin_fminf(bk[l], __builtin_fminf(ks, kt));
+            }
+        }
+        scene_rank_pairs<NL, J + 1>(tab, np, px, py, pz, bk, tick);
+    }
+}
 
 // `tick` is called once per trip of the sphere loop: the fused kernel uses it to trickle its link-position
 // stores out between the arithmetic instead of issuing them as one burst (see spec_common: PosFlusher).
@@ -403,64 +450,33 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                                               float (&gz)[NL], Tick&& tick = Tick(), const float4* lds_spheres = nullptr) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) { s[l] = __builtin_inff(); gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }
+    // contract with the caller: all TRK_OBJ_TICK_SLOTS tick slots are issued on every path -- interleaved with the pair ranking when
+    // that path runs, in one go otherwise
+    const bool paired = FAST || (C.n_spheres > 0 && C.spheres_uniform_r && C.n_spheres <= 16);
+    if (!paired) {
+        scene_all_ticks<0>(tick);
+    }
     if (FAST || C.n_spheres > 0) {
         if (FAST || C.spheres_uniform_r) {
             // equal radii: arg-min over spheres of |p-c|^2, ranked by |p-c|^2 - |p|^2 = p.(-2c) + |c|^2 (3 FMAs per
             // sphere and point); the exact distance is recomputed for the winner only (one sqrt per point).
             int bi[NL];
             if (FAST || C.n_spheres <= 16) {
-                // index rides in the 4 low mantissa bits of the ranking key: one v_bfi + one v_min per sphere and
+                // index rides in the 4 low mantissa bits of the ranking key: one v_and_or + half a v_min3 per sphere and
                 // point.  Only near-ties (relative gap < 2^-19) can pick the other sphere, and then both distances
                 // agree to ~2e-6 -- below the stated cost tolerance; the value itself is always exact.
+                // Two spheres (S, T) per trip, one packed lane each: key(S), key(T) of a point are ONE v_pk_fma_f32 chain
+                // over the pair record [Sx Tx | Sy Ty | Sz Tz | Sw Tw] (measured on gfx950: v_pk_fma_f32 4.4 cycles per
+                // wave = 2.2 per FMA, a scalar FMA with an SGPR operand 4.2; tools/valu_microbench3.hip).
                 float bk[NL];
 #pragma unroll
                 for (int l = 0; l < NL; ++l) bk[l] = __builtin_inff();
-                // two spheres per trip (one v_min3 per point), points in pairs (v_pk_fma_f32: two points per issue)
-                constexpr int NP = NL / 2;
-                trk_f2 qx[NP > 0 ? NP : 1], qy[NP > 0 ? NP : 1], qz[NP > 0 ? NP : 1];
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    qx[j] = trk_f2{px[2 * j], px[2 * j + 1]}; qy[j] = trk_f2{py[2 * j], py[2 * j + 1]};
-                    qz[j] = trk_f2{pz[2 * j], pz[2 * j + 1]};
-                }
-                const int n2 = C.n_spheres & ~1;
-                // software-pipelined scalar loads: the next pair is in flight while the current one is ranked
-                // (every wave of the chip is in this loop at the same time, so nobody else hides the K$ latency)
-                F4 S = load_f4_uniform(C.spheres_sel, 0), T = load_f4_uniform(C.spheres_sel, n2 > 1 ? 1 : 0);
-                for (int k = 0; k < n2; k += 2) {
-                    const int kn = k + 2 < n2 ? k + 2 : k;
-                    const F4 Sn = load_f4_uniform(C.spheres_sel, kn), Tn = load_f4_uniform(C.spheres_sel, kn + 1);
-                    tick();
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) {
-                        const trk_f2 ts = __builtin_elementwise_fma(qx[j], trk_f2{S.x, S.x}, __builtin_elementwise_fma(qy[j], trk_f2{S.y, S.y}, __builtin_elementwise_fma(qz[j], trk_f2{S.z, S.z}, trk_f2{S.w, S.w})));
-                        const trk_f2 tt = __builtin_elementwise_fma(qx[j], trk_f2{T.x, T.x}, __builtin_elementwise_fma(qy[j], trk_f2{T.y, T.y}, __builtin_elementwise_fma(qz[j], trk_f2{T.z, T.z}, trk_f2{T.w, T.w})));
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const float ks = __uint_as_float((__float_as_uint(h ? ts.y : ts.x) & ~15u) | (unsigned)k);
-                            const float kt = __uint_as_float((__float_as_uint(h ? tt.y : tt.x) & ~15u) | (unsigned)(k + 1));
-                            bk[2 * j + h] = __builtin_fminf(bk[2 * j + h], __builtin_fminf(ks, kt));
-                        }
-                    }
-                    if (NL & 1) {
-                        constexpr int l = NL - 1;
-                        const float ts = fmaf(px[l], S.x, fmaf(py[l], S.y, fmaf(pz[l], S.z, S.w)));
-                        const float tt = fmaf(px[l], T.x, fmaf(py[l], T.y, fmaf(pz[l], T.z, T.w)));
-                        const float ks = __uint_as_float((__float_as_uint(ts) & ~15u) | (unsigned)k);
-                        const float kt = __uint_as_float((__float_as_uint(tt) & ~15u) | (unsigned)(k + 1));
-                        bk[l] = __builtin_fminf(bk[l], __builtin_fminf(ks, kt));
-                    }
-                    S = Sn; T = Tn;
-                }
-                if (C.n_spheres & 1) {
-                    const int k = C.n_spheres - 1;
-                    const F4 S = load_f4_uniform(C.spheres_sel, k);
-#pragma unroll
-                    for (int l = 0; l < NL; ++l) {
-                        const float t = fmaf(px[l], S.x, fmaf(py[l], S.y, fmaf(pz[l], S.z, S.w)));
-                        bk[l] = __builtin_fminf(bk[l], __uint_as_float((__float_as_uint(t) & ~15u) | (unsigned)k));
-                    }
-                }
+                // <= 8 pairs, unrolled with a wave-uniform guard each: the sphere indices are immediates, the records sit at
+                // immediate offsets (first four requested together, the rest while pairs 2-3 are ranked), and the caller's
+                // eight tick slots are interleaved one per pair whatever the sphere count is.
+                const TRK_CAS float* tab = cptr(C.sphere_pairs);
+                const int np = C.n_sphere_pairs;
+                scene_rank_pairs<NL, 0>(tab, np, px, py, pz, bk, tick);
 #pragma unroll
                 for (int l = 0; l < NL; ++l) bi[l] = (int)(__float_as_uint(bk[l]) & 15u);
             } else {
@@ -485,7 +501,8 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                 const float4 S = (lds_spheres && (FAST || C.n_spheres <= TRK_LDS_SPHERES)) ? lds_spheres[bi[l]] : C.spheres[bi[l]];
                 const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
                 const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
-                const float inv = n2 > 0.0f ? trk_rsq(n2) : 0.0f;     // one transcendental per point
+                // torch.norm backward is 0 at p == c: with n2 floored, d * inv = 0 * 1.8e19 = 0 there (and n2 * inv = 0)
+                const float inv = trk_rsq(__builtin_fmaxf(n2, 1.17549435e-38f));     // one transcendental per point
                 s[l] = fmaf(n2, inv, -C.sphere_r); gx[l] = dx * inv; gy[l] = dy * inv; gz[l] = dz * inv;
             }
         } else {

@@ -35,7 +35,7 @@ typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 2)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 3)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -78,18 +78,24 @@ __device__ __forceinline__ void spec_wave_sync() {
 // Output stores are write-through (sc1): a plain store leaves its line dirty in the XCD's L2, and at the kernel
 // boundary up to 32 MB of dirty lines must be written back before the next step's loads get through -- measured as a
 // 2.7 us stall of every wave's first q load.  Write-through lets the 43 MB drain while the kernel computes.
+// The output stores are `asm volatile` (never dropped, never reordered among themselves); they write memory the kernel never
+// reads back, so they carry NO "memory" clobber: with one, every store is a full compiler barrier that chops the arithmetic
+// between two ticks into separate scheduling regions.
+#ifndef TRK_STORE_CLOBBER
+#define TRK_STORE_CLOBBER
+#endif
 typedef float trk_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_wt_f4(float4* p, const float4& v) {
     const trk_f4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(x)  TRK_STORE_CLOBBER);
 }
 typedef float trk_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void store_wt_f2(float* p, float a, float b) {
     const trk_f2 x = {a, b};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(x)  TRK_STORE_CLOBBER);
 }
 __device__ __forceinline__ void store_wt_f1(float* p, float v) {
-    asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(v)  TRK_STORE_CLOBBER);
 }
 
 // HBM-side element type of q / link_pos / gq: four consecutive elements <-> one float4 of LDS (fp32 arithmetic always).
@@ -99,6 +105,11 @@ template <> struct IoQuad<float> {
     static constexpr uintptr_t kAlignMask = 15;
     static __device__ __forceinline__ float4 load(const float* p, int k) { return reinterpret_cast<const float4*>(p)[k]; }
     static __device__ __forceinline__ void store_wt(float* p, int k, const float4& v) { store_wt_f4(reinterpret_cast<float4*>(p) + k, v); }
+    // SGPR base + 32-bit per-lane byte offset: no 64-bit address arithmetic per lane
+    static __device__ __forceinline__ void store_wt_s(unsigned long long base, unsigned voff, const float4& v) {
+        const trk_f4 x = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n s_nop 1" :: "v"(voff), "v"(x), "s"(base)  TRK_STORE_CLOBBER);
+    }
     static __device__ __forceinline__ void store_wt1(float* p, float v) { store_wt_f1(p, v); }
     static __device__ __forceinline__ void store_wt2(float* p, float a, float b) { store_wt_f2(p, a, b); }
 };
@@ -110,23 +121,27 @@ template <> struct IoQuad<_Float16> {
     }
     static __device__ __forceinline__ void store_wt(_Float16* p, int k, const float4& v) {
         const trk_h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        asm volatile("global_store_dwordx2 %0, %1, off sc1\n s_nop 1" :: "v"(reinterpret_cast<trk_h4*>(p) + k), "v"(h) : "memory");
+        asm volatile("global_store_dwordx2 %0, %1, off sc1\n s_nop 1" :: "v"(reinterpret_cast<trk_h4*>(p) + k), "v"(h)  TRK_STORE_CLOBBER);
+    }
+    static __device__ __forceinline__ void store_wt_s(unsigned long long base, unsigned voff, const float4& v) {
+        const trk_h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        asm volatile("global_store_dwordx2 %0, %1, %2 sc1\n s_nop 1" :: "v"(voff), "v"(h), "s"(base)  TRK_STORE_CLOBBER);
     }
     static __device__ __forceinline__ void store_wt1(_Float16* p, float v) {
         const _Float16 h = (_Float16)v;
-        asm volatile("global_store_short %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h) : "memory");
+        asm volatile("global_store_short %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h)  TRK_STORE_CLOBBER);
     }
     static __device__ __forceinline__ void store_wt2(_Float16* p, float a, float b) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const h2 h = {(_Float16)a, (_Float16)b};
-        asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h) : "memory");
+        asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h)  TRK_STORE_CLOBBER);
     }
 };
 
 // copy the first TRK_LDS_SPHERES world-frame spheres into this wave's LDS (one 16-byte load per lane, issued together
 // with the q loads so its latency is free)
 __device__ __forceinline__ void spec_load_spheres(const DevCostHdr& C, float4* lds_spheres, int lane) {
-    if (lane < TRK_LDS_SPHERES && lane < C.n_spheres) lds_spheres[lane] = C.spheres[lane];
+    if (lane < TRK_LDS_SPHERES && lane < 2 * C.n_sphere_pairs) lds_spheres[lane] = C.spheres[lane];     // incl. the pad copy
 }
 
 template <int D, class IO>
@@ -193,29 +208,68 @@ __device__ __forceinline__ void spec_store_gq(IO* __restrict__ gq, int64_t base,
 // roughly the rate HBM absorbs them.
 template <int W, class IO>
 struct PosFlusher {
-    static constexpr int NV = W * TRK_WAVE / 4;                  // 4-element chunks per wave
+    static constexpr int NV = W * TRK_WAVE / 4;                  // 4-element vectors per wave
     static constexpr int NCHUNK = (NV + TRK_WAVE - 1) / TRK_WAVE;
-    const float4* src4;
-    IO* dst;
+    static constexpr int TAIL = NV - (NCHUNK - 1) * TRK_WAVE;    // lanes of the last chunk (64 = full)
+    static constexpr int CB = TRK_WAVE * 4 * sizeof(IO);         // bytes of one chunk in HBM
+    // Chunks are numbered at COMPILE time (the generator knows where every tick sits), so a tick is: two scalar adds for the
+    // chunk's address, one ds_read_b128 at an immediate offset, one store with an SGPR base -- no VALU work at all.  (The
+    // first version carried a chunk counter and rebuilt a 64-bit per-lane address and an exec mask per tick: ~9 VALU
+    // instructions, most of them in the 4-cycle class, 9 ticks per wavefront.)
+    const float4* src;                                           // this lane's vector of chunk 0, in LDS
+    unsigned voff;                                               // lane * bytes per vector in HBM
+    unsigned long long g0;                                       // wave-uniform: address of the wave's first byte
+    bool active;                                                 // wave-uniform: false = nothing staged / already written
     int lane;
-    int next;                                                    // wave-uniform
-    __device__ __forceinline__ void operator()() {
-        if (next < NCHUNK) {
-            const int k = lane + TRK_WAVE * next;
-            if (k < NV) IoQuad<IO>::store_wt(dst, k, src4[k]);
-            ++next;
+    template <int CH>
+    __device__ __forceinline__ void chunk() const {
+        if constexpr (CH >= 0 && CH < NCHUNK) {
+            if (active) {
+                const unsigned long long g = g0 + (unsigned long long)CH * CB;
+#ifdef TRK_EXP_NO_STORE       // experiment: stage + read back from LDS, but do not issue the global store
+                { const float4 v = src[CH * TRK_WAVE]; asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+#else
+                if (CH < NCHUNK - 1 || TAIL == TRK_WAVE) IoQuad<IO>::store_wt_s(g, voff, src[CH * TRK_WAVE]);
+                else if (lane < TAIL) IoQuad<IO>::store_wt_s(g, voff, src[CH * TRK_WAVE]);
+#endif
+            }
         }
     }
-    __device__ __forceinline__ void flush() {
-        while (next < NCHUNK) (*this)();
+    template <int A, int B>                                      // chunks A .. B-1
+    __device__ __forceinline__ void range() const {
+        if constexpr (A < B && A < NCHUNK) { chunk<A>(); range<A + 1, B>(); }
     }
+    template <int A> __device__ __forceinline__ void rest() const { range<A, NCHUNK>(); }
+};
+
+// What the scene evaluation is handed: its tick slots `at<0>() .. at<TRK_OBJ_TICK_SLOTS - 1>()` = chunks BASE .. of the flusher.
+template <class F, int BASE>
+struct TickFrom {
+    const F& f;
+    template <int J> __device__ __forceinline__ void at() const { f.template chunk<BASE + J>(); }
 };
 
 // stand-in for PosFlusher in kernels whose positions leave through spec_flush_chunk instead
 struct NoFlush {
-    __device__ __forceinline__ void operator()() const {}
-    __device__ __forceinline__ void flush() const {}
+    template <int CH> __device__ __forceinline__ void chunk() const {}
+    template <int A, int B> __device__ __forceinline__ void range() const {}
+    template <int A> __device__ __forceinline__ void rest() const {}
 };
+
+template <int W, class IO>
+__device__ __forceinline__ PosFlusher<W, IO> spec_make_flusher(IO* __restrict__ out, int64_t base, int rows, int lane, float* lds) {
+    IO* dst = out + base * W;
+    const bool fast = rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & IoQuad<IO>::kAlignMask) == 0);
+    if (!fast) {                                                 // ragged last wavefront / unaligned view: plain copy, now
+        const int count = rows * W;
+        for (int k = lane; k < count; k += TRK_WAVE) dst[k] = (IO)lds[k];
+    }
+    // the address is wave-uniform by construction; say so, so that it is held in SGPRs
+    const unsigned long long g = (unsigned long long)reinterpret_cast<uintptr_t>(dst);
+    const unsigned long long gu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+    return PosFlusher<W, IO>{reinterpret_cast<const float4*>(lds) + lane, (unsigned)(lane * 4 * sizeof(IO)), gu, fast, lane};
+}
 
 // stage the wave's rows in LDS; returns a flusher (fast path) or writes everything now (ragged / unaligned tail)
 template <int W, class IO>
@@ -225,15 +279,7 @@ __device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows(IO* __restrict__ ou
 #pragma unroll
     for (int j = 0; j < W; ++j) lds[lane * W + j] = v[j];
     spec_wave_sync();
-    IO* dst = out + base * W;
-    PosFlusher<W, IO> f{reinterpret_cast<const float4*>(lds), dst, lane, 0};
-    const bool fast = rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & IoQuad<IO>::kAlignMask) == 0);
-    if (!fast) {
-        const int count = rows * W;
-        for (int k = lane; k < count; k += TRK_WAVE) dst[k] = (IO)lds[k];
-        f.next = PosFlusher<W, IO>::NCHUNK;
-    }
-    return f;
+    return spec_make_flusher<W, IO>(out, base, rows, lane, lds);
 }
 
 // Wide rows (attached points: W = 3P floats per sample) do not fit a whole-row staging buffer, so they leave in column
@@ -293,21 +339,25 @@ template <int W, class IO>
 __device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows_prefilled(IO* __restrict__ out, int64_t base, int rows, int lane,
                                                                        float* lds) {
     spec_wave_sync();
-    IO* dst = out + base * W;
-    PosFlusher<W, IO> f{reinterpret_cast<const float4*>(lds), dst, lane, 0};
-    const bool fast = rows == TRK_WAVE && (W * TRK_WAVE) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & IoQuad<IO>::kAlignMask) == 0);
-    if (!fast) {
-        const int count = rows * W;
-        for (int k = lane; k < count; k += TRK_WAVE) dst[k] = (IO)lds[k];
-        f.next = PosFlusher<W, IO>::NCHUNK;
-    }
-    return f;
+    return spec_make_flusher<W, IO>(out, base, rows, lane, lds);
 }
 
 // profiling hook: lane 0 of a wave records the shader clock at phase `k` (no-op when A.stamps == nullptr)
 __device__ __forceinline__ void spec_stamp(unsigned long long* stamps, int64_t wblock, int k, int lane) {
     if (stamps) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) stamps[wblock * 8 + k] = t;
+    }
+}
+
+// s_memtime counts shader clocks in a per-CU domain (tools/clock_calib.hip: 2.39 GHz, unsynchronised between CUs); the
+// constant 100 MHz s_memrealtime is chip-wide, so one such stamp per wave places the waves on a common time axis.
+__device__ __forceinline__ void spec_stamp_real(unsigned long long* stamps, int64_t wblock, int k, int lane) {
+    if (stamps) {
+        // bits 0..43 time, 44..59 HW_ID[15:0] (wave, simd, pipe, cu, sh, se), 60..63 XCC_ID -- where the wave ran
+        const unsigned long long hw = (unsigned)__builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffffu;
+        const unsigned long long xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;
+        const unsigned long long t = (__builtin_amdgcn_s_memrealtime() & ((1ull << 44) - 1)) | (hw << 44) | (xcc << 60);
         if (lane == 0) stamps[wblock * 8 + k] = t;
     }
 }
@@ -321,10 +371,10 @@ __device__ __forceinline__ float spec_wave_sum(float v) { return trk_wave_sum(v)
 template <int NL, class Tick, bool FAST = false>
 __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w, const float (&px)[NL],
                                                    const float (&py)[NL], const float (&pz)[NL], float (&gx)[NL],
-                                                   float (&gy)[NL], float (&gz)[NL], Tick& tick, const float4* lds_spheres,
+                                                   float (&gy)[NL], float (&gz)[NL], const Tick& tick, const float4* lds_spheres,
                                                    int mbase = 0) {
     float s[NL], ax[NL], ay[NL], az[NL];
-    scene_min_sdf<NL, Tick&, FAST>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres);
+    scene_min_sdf<NL, const Tick&, FAST>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres);
     float cost = 0.0f;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
