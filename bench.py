@@ -178,7 +178,7 @@ def main():
     try:
         key = f"{args.config}:{B}x{H}:{'specialized' if model.specialized else 'table-driven'}"
         if not args.weights and not args.no_pos:
-            traffic = json.loads((ROOT / "profiles" / "r01_hbm_traffic.json").read_text())["workloads"][key]["traffic_bytes_per_launch"]
+            traffic = json.loads((ROOT / "profiles" / "r02_hbm_traffic.json").read_text())["workloads"][key]["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
 

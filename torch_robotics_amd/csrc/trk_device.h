@@ -406,6 +406,10 @@ __device__ __forceinline__ float object_sdf(const DevCostHdr& C, int o, float x,
 #endif
 struct NoTick { template <int J> __device__ __forceinline__ void at() const {} };
 
+template <class T> struct TickIsNoTick { static constexpr bool value = false; };
+template <> struct TickIsNoTick<NoTick> { static constexpr bool value = true; };
+template <> struct TickIsNoTick<const NoTick&> { static constexpr bool value = true; };
+template <> struct TickIsNoTick<NoTick&> { static constexpr bool value = true; };
 template <int J, class Tick>
 __device__ __forceinline__ void scene_all_ticks(const Tick& tick) {
     if constexpr (J < TRK_OBJ_TICK_SLOTS) { tick.template at<J>(); scene_all_ticks<J + 1>(tick); }
@@ -476,7 +480,29 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                 // eight tick slots are interleaved one per pair whatever the sphere count is.
                 const TRK_CAS float* tab = cptr(C.sphere_pairs);
                 const int np = C.n_sphere_pairs;
-                scene_rank_pairs<NL, 0>(tab, np, px, py, pz, bk, tick);
+                if constexpr (TickIsNoTick<Tick>::value) {
+                    // nothing to interleave (table-driven kernels, attached-point kernels that evaluate the scene once
+                    // per group of points): a rolled loop keeps those kernels inside the instruction cache
+                    for (int j = 0; j < np; ++j) {
+                        const F8 rec = load_f8_uniform(tab, j);
+                        const unsigned k0 = 2u * (unsigned)j;
+                        unsigned k1;                               // k0 | 1, kept opaque: else the compiler splits the
+                        asm("s_or_b32 %0, %1, 1" : "=s"(k1) : "s"(k0) : "scc");   // second v_and_or into v_and + v_or3
+                        const trk_f2 cx = {rec.v[0], rec.v[1]}, cy = {rec.v[2], rec.v[3]}, cz = {rec.v[4], rec.v[5]},
+                                     cw = {rec.v[6], rec.v[7]};
+#pragma unroll
+                        for (int l = 0; l < NL; ++l) {
+                            const trk_f2 key = __builtin_elementwise_fma(trk_f2{px[l], px[l]}, cx,
+                                               __builtin_elementwise_fma(trk_f2{py[l], py[l]}, cy,
+                                               __builtin_elementwise_fma(trk_f2{pz[l], pz[l]}, cz, cw)));
+                            const float ks = __uint_as_float((__float_as_uint(key.x) & ~15u) | k0);
+                            const float kt = __uint_as_float((__float_as_uint(key.y) & ~15u) | k1);
+                            bk[l] = __builtin_fminf(bk[l], __builtin_fminf(ks, kt));
+                        }
+                    }
+                } else {
+                    scene_rank_pairs<NL, 0>(tab, np, px, py, pz, bk, tick);
+                }
 #pragma unroll
                 for (int l = 0; l < NL; ++l) bi[l] = (int)(__float_as_uint(bk[l]) & 15u);
             } else {
