@@ -367,6 +367,18 @@ int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const T
                           float* link_pos_out, float* cost, float* gq, float* cost_block_sums,
                           trk_stream_t stream);
 
+/* Fused FK + boolean collision fields: q [batch*horizon, D] -> in_collision [batch*horizon] (1 = at least one selected field
+ * has a signed distance below its margin).  No link positions, costs or gradients are written.
+ * reference: PlanningTask.compute_collision tasks.py:131-133 -> _compute_collision_or_cost(field_type='occupancy') tasks.py:139-232
+ * = fk_map_collision (robot_base.py:171-174) + the OR of the fields' compute_embodiment_collision (distance_fields.py:210-215,
+ * 283-291); get_trajs_collision_and_free calls it with margin=0. on the interpolated via points (tasks.py:247-251).
+ * margin_override: NaN = each field's own margins (per-link margin + cutoff, per-pair margin), else this margin for every test.
+ * link_pos_ws: DEVICE scratch [N, L, 3], used only when no generated kernel serves this model / cost model (then the
+ * table-driven FK and field kernels run back to back); may be NULL otherwise. */
+int trk_rollout_collision(const TrkModel* model, const TrkCostModel* cm, int32_t fields, const float* q, int64_t batch,
+                          int32_t horizon, float margin_override, uint8_t* in_collision, float* link_pos_ws,
+                          trk_stream_t stream);
+
 /* trk_rollout_cost_grad with q, link_pos_out and gq stored as IEEE fp16 in HBM -- BASELINE config 5's "fp16 with fp32
  * cost accumulate": arithmetic, `cost` and `cost_block_sums` stay fp32; inputs are widened and outputs rounded once
  * (round-to-nearest-even) at the memory boundary.  Build-defined (the reference has no reduced-precision path); the

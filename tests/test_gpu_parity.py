@@ -181,6 +181,57 @@ def test_collision_fields_vs_golden(ops, env):
         assert rel_err(gp.cpu().numpy(), g["gpos_extra"].reshape(-1, 11, 3)) < TOL_G
 
 
+@pytest.mark.parametrize("env", ENVS)
+def test_fused_collision_vs_golden_and_two_step(ops, oracle_lib, env):
+    """trk_rollout_collision (FK + boolean fields in one launch, one byte per sample) == the reference's booleans on the goldens,
+    == table-driven FK followed by trk_collision_fields byte for byte on fresh ragged inputs, for every field mask, with the
+    fields' own margins and with the margin=0 override of get_trajs_collision_and_free; generated kernel (identity and general
+    base pose) and the scratch fallback."""
+    robot, g = gold("panda_robot"), gold(f"cost_{env}")
+    spec = panda_cost_spec(g, robot)
+    m = model("panda_arm_no_gripper")
+    h, cm = ops.ModelHandle(m), ops.CostHandle(spec, DEV)
+    assert h.specialized
+    qg = dev(g["q"])                                           # (8, 8, 7)
+    allf = FIELD_SELF | FIELD_OBJECTS | FIELD_WS
+    for fname, fl in (("self", FIELD_SELF), ("objects", FIELD_OBJECTS), ("ws", FIELD_WS), ("total", allf)):
+        got = ops.rollout_collision(h, cm, fl, qg)
+        assert got.shape == (8, 8) and got.dtype == torch.bool
+        np.testing.assert_array_equal(got.cpu().numpy(), g[f"coll_{fname}"].astype(bool), err_msg=fname)
+        np.testing.assert_array_equal(ops.rollout_collision(h, cm, fl, qg, margin=0.0).cpu().numpy(), g[f"coll0_{fname}"].astype(bool))
+    rng = np.random.default_rng(11)
+    seen = set()
+    for n in (1, 63, 65, 1000, 4133):
+        q = dev(rng.uniform(-3.0, 3.9, (n, 7)).astype(np.float32))
+        pos = ops.fk_positions(h, q)
+        for fl in (FIELD_SELF, FIELD_OBJECTS, FIELD_WS, FIELD_OBJECTS | FIELD_WS, allf):
+            for margin in (None, 0.0, 0.07):
+                want = ops.collision_fields(cm, fl, pos, margin=margin).cpu().numpy().astype(bool)
+                seen |= set(np.unique(want).tolist())
+                h.enable_specialized(True)
+                got = ops.rollout_collision(h, cm, fl, q, margin=margin).cpu().numpy()
+                h.enable_specialized(False)                    # table-driven FK into the scratch + the field kernel
+                got_fb = ops.rollout_collision(h, cm, fl, q, margin=margin).cpu().numpy()
+                h.enable_specialized(True)
+                # the generated FK differs from the table-driven one in the last ulp of a position, so a byte may differ only
+                # where some signed distance sits within 1e-6 of its margin; the fallback is the two-step path itself
+                np.testing.assert_array_equal(got_fb, want)
+                if not np.array_equal(got, want):
+                    bad = np.flatnonzero(got != want)
+                    assert len(bad) <= max(1, n // 2000), (env, n, fl, margin, len(bad))
+    assert seen == {False, True}                               # both outcomes occurred
+    # general base pose (the _bg variant of the generated kernel)
+    m.set_base_pose([0.1234, -0.2345, 0.0567, 0.9659258, 0.0, 0.0, 0.2588190])
+    h.set_base_pose(m.base_R, m.base_t)
+    q = dev(rng.uniform(-2.5, 2.5, (700, 7)).astype(np.float32))
+    want = ops.collision_fields(cm, allf, ops.fk_positions(h, q)).cpu().numpy().astype(bool)
+    got = ops.rollout_collision(h, cm, allf, q).cpu().numpy()
+    assert (got != want).sum() <= 1
+    assert ops.rollout_collision(h, cm, allf, torch.empty((0, 64, 7), device=DEV)).shape == (0, 64)
+    with pytest.raises(ValueError):
+        ops.rollout_collision(h, cm, allf, torch.zeros(4, 14, device=DEV))
+
+
 def test_grid_precompute_and_sdf_points(ops, oracle_lib):
     robot, g, ga = gold("panda_robot"), gold("cost_spheres3d_grid"), gold("cost_spheres3d")
     cm = ops.CostHandle(panda_cost_spec(ga, robot), DEV)

@@ -75,6 +75,15 @@ def main():
         rec("trk_cost_fields (objects, fwd)", 12 * L + 4, lambda: ops.cost_fields(cm, FIELD_OBJECTS, pos))
         rec("trk_cost_fields (all 3, fwd+grad)", 12 * L + 4 + 12 * L, lambda: ops.cost_fields(cm, allf, pos, want_grad=True))
         rec("trk_collision_fields (all 3)", 12 * L + 1, lambda: ops.collision_fields(cm, allf, pos))
+        rec("trk_rollout_collision (fused FK + booleans, all 3)", 4 * D + 1, lambda: ops.rollout_collision(h, cm, allf, q))
+        rec("trk_rollout_collision (margin 0, objects + ws)", 4 * D + 1, lambda: ops.rollout_collision(h, cm, FIELD_OBJECTS | FIELD_WS, q, margin=0.0))
+        # the caller every planner runs after optimisation (tasks.py:234-308): 4096 trajectories x 64 way points, 5 via points
+        trajs = q.reshape(4096, -1, D)[:, :64].contiguous() if n >= 4096 * 64 else None
+        if trajs is not None:
+            n_interp = 4096 * ((64 - 1) * 6 + 1)
+            t = timeit(lambda: task.get_trajs_collision_and_free(trajs, return_indices=True), iters=20, warm=3)
+            rows.append(dict(op="PlanningTask.get_trajs_collision_and_free (4096 x 64, 5 via points)", us=t * 1e6, bytes_per_sample=4 * D + 1,
+                             GBps=(4 * D + 1) * n_interp / t / 1e9, frac_of_8TBps=(4 * D + 1) * n_interp / t / 8e12))
         Hee = H[:, -1].contiguous()
         rec("trk_ee_cost (fwd+grad)", 64 + 4 + 64, lambda: ops.ee_cost(cm, Hee, want_grad=True))
         h.enable_specialized(False)

@@ -424,6 +424,31 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             _emit_fk_link(E, kin, i, R, t, passv, snap)
             if chunked:
                 stage_link(i)
+        # ---------------- boolean mode: fused FK + collision fields (trk_rollout_collision) ----------------
+        E.raw("    if (A.coll_out) {")
+        E.raw("        bool hit = false;")
+        if NL > 0:
+            grp_size = NL if NL <= LINK_OBJ_GROUP_MAX else -(-NL // (-(-NL // LINK_OBJ_GROUP)))
+            E.raw("        if (A.coll_fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {")
+            for g0 in range(0, NL, grp_size):
+                grp = list(tmpl.obj_links[g0:g0 + grp_size])
+                n = len(grp)
+                E.raw("            {")
+                for k, nm in enumerate("xyz"):
+                    E.raw(f"                const float p{nm}[{n}] = {{{', '.join(E.expr(t[i][k]) for i in grp)}}};")
+                E.raw(f"                hit |= spec_collision_links<{n}>(A.C, A.coll_fields, A.coll_margin, A.coll_use_default, px, py, pz, lds_sph, {g0});")
+                E.raw("            }")
+            E.raw("        }")
+        if tmpl.self_pairs:
+            E.raw("        if (A.coll_fields & TRK_FIELD_SELF) {")
+            for pi, (a, b) in enumerate(tmpl.self_pairs):
+                pa = ", ".join(E.expr(t[a][k]) for k in range(3))
+                pb = ", ".join(E.expr(t[b][k]) for k in range(3))
+                E.raw(f"            hit |= spec_self_hit(A.coll_use_default ? cptr(A.C.self_margin)[{pi}] : A.coll_margin, {pa}, {pb});")
+            E.raw("        }")
+        E.raw("        if (lane < rows) A.coll_out[base + lane] = hit ? 1 : 0;")
+        E.raw("        return;")
+        E.raw("    }")
         # ---------------- outputs that depend only on FK ----------------
         if chunked:
             E.raw("    NoFlush flush;")

@@ -333,7 +333,7 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
     if (n == 0) return TRK_OK;
     if (mode == 1 && spec_all_links(m, sel, ns)) {
         // generated kernel, positions-only exit (gq == nullptr): same FK code as the fused rollout
-        SpecArgs a;
+        SpecArgs a{};
         rc = blank_spec_args(a);
         if (rc) return rc;
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
@@ -365,7 +365,7 @@ static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin,
     if (rc) return rc;
     if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
     if (mode == 1 && spec_all_links(m, sel, ns) && m->spec->launch_posbwd) {
-        SpecArgs a;
+        SpecArgs a{};
         rc = blank_spec_args(a);
         if (rc) return rc;
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
@@ -456,7 +456,7 @@ int trk_fk_points(const TrkModel* m, const TrkPointSet* ps, const float* q, int6
     if (n == 0) return TRK_OK;
     if (points_spec(ps) && m->spec_enabled && (reinterpret_cast<uintptr_t>(pos_out) & 15) == 0) {
         // generated kernel with this point set baked in, all weights zero and no gradient output: FK + positions only
-        SpecArgs a;
+        SpecArgs a{};
         rc = blank_spec_args(a);
         if (rc) return rc;
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
@@ -480,7 +480,7 @@ int trk_fk_points_backward(const TrkModel* m, const TrkPointSet* ps, const float
     if (trk_lds_fk_points(m->hdr, ps->dev.n_points, true) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_fk_points_backward: point tile exceeds the 160 KiB LDS");
     if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
     if (points_spec(ps) && ps->spec->launch_posbwd && m->spec_enabled && (reinterpret_cast<uintptr_t>(gpos) & 15) == 0) {
-        SpecArgs a;
+        SpecArgs a{};
         rc = blank_spec_args(a);
         if (rc) return rc;
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
@@ -850,7 +850,7 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
     if (m->spec_enabled) {
         // a generated kernel has the robot's collision-link sets baked in: use the unit whose sets equal the cost model's
         if (const SpecEntry* e = model_spec_for(m, cm, w)) {
-            SpecArgs a;
+            SpecArgs a{};
             a.C = cm->hdr; a.w = *w;
             std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
@@ -862,6 +862,45 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
         }
     }
     trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, nullptr, cm->hdr, *w, io_f16, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fields, const float* q, int64_t batch, int32_t horizon,
+                          float margin_override, uint8_t* in_collision, float* link_pos_ws, trk_stream_t stream) {
+    int rc = check_model(m, "trk_rollout_collision");
+    if (rc) return rc;
+    if (!cm) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision: null cost model");
+    if (batch < 0 || horizon < 1 || (fields & ~7) || !fields) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision: bad batch / horizon / fields");
+    if (cm->hdr.n_links_in != m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision: cost model n_links_in != model n_links");
+    const int64_t n = batch * horizon;
+    if (n > 0 && (!q || !in_collision)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision: null q / in_collision");
+    if (n == 0) return TRK_OK;
+    const int use_default = std::isnan(margin_override) ? 1 : 0;
+    if (m->spec_enabled) {
+        // the unit's baked link sets must equal the cost model's for every field that is asked for
+        TrkRolloutWeights w{};
+        w.w_self = (fields & TRK_FIELD_SELF) ? 1.0f : 0.0f;
+        w.w_obj = (fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) ? 1.0f : 0.0f;
+        w.w_ws = (fields & TRK_FIELD_WS) ? 1.0f : 0.0f;
+        if (const SpecEntry* e = model_spec_for(m, cm, &w)) {
+            SpecArgs a{};
+            a.C = cm->hdr; a.w = w;
+            std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+            std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+            a.q = q; a.n = n;
+            a.coll_out = in_collision; a.coll_fields = fields; a.coll_use_default = use_default;
+            a.coll_margin = use_default ? 0.0f : margin_override;
+            e->launch(a, base_is_identity(m), (hipStream_t)stream);
+            TRK_HIP(hipGetLastError());
+            return TRK_OK;
+        }
+    }
+    // no generated unit serves this model / cost model: table-driven FK into the caller's scratch, then the field kernel
+    if (!link_pos_ws) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision: no generated kernel for this model and no link_pos_ws scratch given");
+    rc = trk_fk_positions(m, q, n, nullptr, 0, link_pos_ws, stream);
+    if (rc) return rc;
+    trk_launch_collision_fields(cm->hdr, fields, link_pos_ws, n, use_default ? 0.0f : margin_override, use_default, in_collision, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }
@@ -896,7 +935,7 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
     if (m->spec_enabled && (reinterpret_cast<uintptr_t>(point_pos_out) & 15) == 0) {
         // generated kernel with this point set baked in whose cost columns equal the cost model's
         if (const SpecEntry* e = points_spec_for(ps, cm, w)) {
-            SpecArgs a;
+            SpecArgs a{};
             a.C = cm->hdr; a.w = *w;
             std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));

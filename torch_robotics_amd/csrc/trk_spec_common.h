@@ -28,6 +28,13 @@ struct SpecArgs {
     float* cost_sum;
     int32_t io_f16;               // 1: q / link_pos / gq are fp16 in HBM (arithmetic, cost and cost_sum stay fp32)
     unsigned long long* stamps;   // profiling hook (nullable): [n_waves][8] s_memtime stamps at phase boundaries
+    // boolean mode (trk_rollout_collision): when coll_out != nullptr the kernel stops after FK, ORs the selected fields'
+    // "signed distance < margin" tests and writes one byte per sample -- no positions, cost or gradient leave the chip
+    uint8_t* coll_out;
+    int32_t coll_fields;          // TRK_FIELD_* mask
+    int32_t coll_use_default;     // 1: per-link margins + cutoff of the cost model, 0: coll_margin for every test
+    float coll_margin;
+    int32_t _pad_coll;
 };
 
 typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
@@ -35,7 +42,7 @@ typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 3)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 4)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -382,6 +389,52 @@ __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w,
         gx[l] = fmaf(-w, ax[l], gx[l]); gy[l] = fmaf(-w, ay[l], gy[l]); gz[l] = fmaf(-w, az[l], gz[l]);
     }
     return w * cost;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// boolean collision fields on NL link points held in registers (distance_fields.py:210-215, 283-291; tasks.py:227-228 ORs the
+// fields).  Objects: the scene's minimum signed distance comes from the same ranking as the cost (one rsq per point); a
+// lane whose distance lies within 1e-5 of its margin -- where the last-ulp difference between n2 * rsq(n2) and the
+// reference's sqrt could flip the comparison -- re-evaluates that point with IEEE sqrt object by object, so the byte equals
+// the table-driven kernel's (and the oracle's) on every input.
+// ---------------------------------------------------------------------------------------------------------
+template <int NL>
+__device__ __forceinline__ bool spec_collision_links(const DevCostHdr& C, int fields, float margin, int use_default,
+                                                     const float (&px)[NL], const float (&py)[NL], const float (&pz)[NL],
+                                                     const float4* lds_spheres, int mbase = 0) {
+    bool hit = false;
+    float mg[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) mg[l] = use_default ? cptr(C.obj_link_margin)[mbase + l] : margin;
+    if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
+        float s[NL], ax[NL], ay[NL], az[NL];
+        NoTick nt;
+        scene_min_sdf<NL, const NoTick&, false>(C, px, py, pz, s, ax, ay, az, nt, lds_spheres);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            bool h = s[l] < mg[l];
+            if (__builtin_fabsf(s[l] - mg[l]) < 1e-5f) {            // rare: exact re-evaluation, object by object
+                h = false;
+                for (int o = 0; o < C.n_objects; ++o) {
+                    float gx, gy, gz;
+                    h |= object_sdf<true>(C, o, px[l], py[l], pz[l], gx, gy, gz) < mg[l];
+                }
+            }
+            hit |= h;
+        }
+    }
+    if ((fields & TRK_FIELD_WS) && C.has_ws) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            hit |= (px[l] - C.ws_min[0] < mg[l]) | (py[l] - C.ws_min[1] < mg[l]) | (pz[l] - C.ws_min[2] < mg[l]) |
+                   (C.ws_max[0] - px[l] < mg[l]) | (C.ws_max[1] - py[l] < mg[l]) | (C.ws_max[2] - pz[l] < mg[l]);
+    }
+    return hit;
+}
+// one self-collision pair, boolean (distance_fields.py:210-215): ||pa - pb|| < margin, IEEE sqrt like torch.linalg.norm
+__device__ __forceinline__ bool spec_self_hit(float margin, float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __builtin_sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz))) < margin;
 }
 
 template <int NL>

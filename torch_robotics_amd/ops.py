@@ -503,6 +503,31 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
             gq.reshape(tuple(lead) + (D,)))
 
 
+def rollout_collision(model: ModelHandle, cm: CostHandle, fields: int, q: torch.Tensor, margin: Optional[float] = None) -> torch.Tensor:
+    """Fused FK + boolean collision fields: q (B,H,D) or (N,D) -> bool (B,H) / (N,).  One launch, one byte per sample out
+    (`PlanningTask.compute_collision`, tasks.py:131-133); `margin=None` uses the fields' own margins."""
+    q = _dev_f32(q, "rollout_collision(q)")
+    _check_q_dofs(q, model.n_dofs, "rollout_collision(q)")
+    lead = q.shape[:-1]
+    if q.dim() == 3:
+        B, Hh = int(q.shape[0]), int(q.shape[1])
+    else:
+        q = q.reshape(-1, model.n_dofs)
+        B, Hh = int(q.shape[0]), 1
+    n = B * Hh
+    out = torch.empty((n,), device=q.device, dtype=torch.bool)      # the kernel writes 0 / 1 bytes
+    # scratch for the table-driven fallback only (a model / cost model that no generated kernel serves)
+    ws = None if model.specialized else torch.empty((n, model.n_links, 3), device=q.device, dtype=torch.float32)
+    m = float("nan") if margin is None else float(margin)
+    with torch.cuda.device(q.device):
+        rc = lib().trk_rollout_collision(model._h, cm._h, int(fields), q.data_ptr(), B, Hh, m, out.data_ptr(), _ptr(ws), _stream(q))
+        if rc == _abi.TRK_ERR_INVALID_ARG and ws is None:       # a unit exists for the model, but not for this cost model
+            ws = torch.empty((n, model.n_links, 3), device=q.device, dtype=torch.float32)
+            rc = lib().trk_rollout_collision(model._h, cm._h, int(fields), q.data_ptr(), B, Hh, m, out.data_ptr(), ws.data_ptr(), _stream(q))
+        check(rc, "trk_rollout_collision")
+    return out.reshape(tuple(lead))
+
+
 def rollout_points_cost_grad(ps: PointSetHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True,
                              cost_sum: Optional[torch.Tensor] = None):
     """Fused rollout with the collision fields on attached points: q (B,H,D) or (N,D) ->

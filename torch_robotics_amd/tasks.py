@@ -221,7 +221,9 @@ class PlanningTask(Task):
             return ops.cost_fields_ad(cm, fields, pos).reshape(q.shape[:-1])
         ps = self._points(q.device)
         if field_type == "occupancy":
-            pos = ops.fk_positions(model, q.detach()) if ps is None else ops.fk_points(ps, q.detach())
+            if ps is None:                                    # FK + boolean fields in one launch, one byte per sample out
+                return ops.rollout_collision(model, cm, fields, q.detach(), margin=kwargs.get("margin", None))
+            pos = ops.fk_points(ps, q.detach())
             return ops.collision_fields(cm, fields, pos, margin=kwargs.get("margin", None)).reshape(q.shape[:-1])
         w = (1.0 if self.df_collision_self is not None else 0.0, 1.0, 1.0, 0.0)
         if torch.is_grad_enabled() and q.requires_grad:
