@@ -203,6 +203,17 @@ int trk_ik_step(const TrkModel* model, int32_t link, const float* H_target, int3
 int trk_rotmat_to_quat(const float* R, int64_t n, int32_t stride, int32_t row_pitch,
                        float* quat_wxyz, trk_stream_t stream);
 
+/* Rotation matrices from angles or quaternions: R [n,9] row-major.
+ *   TRK_ROT_X / _Y / _Z   in = angle [n]      x_rot / y_rot / z_rot        geometrics/spatial_vector.py:8-47
+ *   TRK_ROT_QUAT_WXYZ     in = quat  [n,4]    q_to_rotation_matrix         geometrics/quaternion.py:102-120
+ * trk_rotation_from_backward (axis rotations only): gR [n,9] -> gangle [n]. */
+#define TRK_ROT_X 0
+#define TRK_ROT_Y 1
+#define TRK_ROT_Z 2
+#define TRK_ROT_QUAT_WXYZ 3
+int trk_rotation_from(int32_t kind, const float* in, int64_t n, float* R_out, trk_stream_t stream);
+int trk_rotation_from_backward(int32_t kind, const float* angle, const float* gR, int64_t n, float* gangle, trk_stream_t stream);
+
 /* Frame algebra on packed poses: R [n,9] row-major, t [n,3] (reference: geometrics/frame.py:55-121, the `Frame`s that
  * compute_forward_kinematics_all_links(return_dict=True) returns, robot_tree.py:283-297).  A frame given once (na / nb == 1)
  * broadcasts against the other; n_out = max(na, nb).

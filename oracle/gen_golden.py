@@ -692,6 +692,18 @@ def frame_goldens():
     tp = fa.transform_point(pts)
     out["tp"] = tp.detach().numpy()
     out["tp_gRa"], out["tp_gta"], _, _ = grads((tp * wp).sum())
+    # axis rotations and quaternion -> rotation (spatial_vector.py:8-47, quaternion.py:102-120), with d sum(w R) / d angle
+    from torch_robotics.torch_kinematics_tree.geometrics.spatial_vector import x_rot, y_rot, z_rot
+    from torch_robotics.torch_kinematics_tree.geometrics.quaternion import q_to_rotation_matrix
+    ang = ((torch.rand(64, generator=gen) - 0.5) * 8.0).requires_grad_(True)
+    out["angle"] = ang.detach().numpy()
+    for nm, fn in (("x", x_rot), ("y", y_rot), ("z", z_rot)):
+        Rr = fn(ang.unsqueeze(1))            # (B,1), as rigid_body.py calls it; a (B,) vector trips to_torch_2d_min
+        out[f"rot_{nm}"] = Rr.detach().numpy()
+        out[f"rot_{nm}_gangle"] = torch.autograd.grad((Rr * wR).sum(), [ang])[0].numpy()
+    qu = torch.randn(64, 4, generator=gen)
+    qu[:8] *= 3.0                                             # not normalised: the formula divides by |q|^2
+    out["quat_in"], out["quat_R"] = qu.numpy(), q_to_rotation_matrix(qu).numpy()
     with torch.no_grad():
         out["quat_xyzw"] = fa.get_quaternion().numpy()
         out["euler"] = torch.stack(fa.get_euler(), -1).numpy()

@@ -139,6 +139,16 @@ class Oracle:
         getattr(lib(), "orc_rotmat_to_quat" + suf)(_p(R), C.c_int64(R.shape[0]), _p(out))
         return out
 
+    @staticmethod
+    def rotation_from(kind, x, prec="f32"):
+        """kind 0/1/2: x_rot / y_rot / z_rot of angles (n,); kind 3: q_to_rotation_matrix of wxyz quaternions (n,4)."""
+        npdt, _, suf = _dt(prec)
+        x = np.ascontiguousarray(x, npdt)
+        n = x.shape[0]
+        R = np.empty((n, 3, 3), npdt)
+        getattr(lib(), "orc_rotation_from" + suf)(C.c_int(kind), _p(x), C.c_int64(n), _p(R))
+        return R
+
     # --------------------------------------------------------------- Frame algebra (geometrics/frame.py:55-121)
     @staticmethod
     def frame_compose(op, Ra, ta, Rb=None, tb=None, prec="f32"):

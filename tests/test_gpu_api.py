@@ -196,6 +196,52 @@ def test_frame_algebra_vs_reference_golden():
     assert np.abs(fa.get_transform_matrix().detach().cpu().numpy() - g["H"]).max() == 0
 
 
+def test_rotation_builders_and_frame_constructor():
+    """x_rot / y_rot / z_rot (spatial_vector.py:8-47) with their gradients, q_to_rotation_matrix (quaternion.py:102-120) and the
+    reference's Frame constructor (identity defaults, pose = x y z qw qx qy qz) against vectors from the reference."""
+    g = gold("frame_algebra")
+    ang = dev(g["angle"]).requires_grad_(True)
+    wR = dev(g["wR"])
+    for nm, fn in (("x", tra.x_rot), ("y", tra.y_rot), ("z", tra.z_rot)):
+        R = fn(ang.unsqueeze(1))                                  # (B,1), as rigid_body.py calls it
+        assert R.shape == (64, 3, 3) and np.abs(R.detach().cpu().numpy() - g[f"rot_{nm}"]).max() < 3e-7
+        (ga,) = torch.autograd.grad((R * wR).sum(), [ang])
+        assert np.abs(ga.cpu().numpy() - g[f"rot_{nm}_gangle"]).max() < 2e-6
+        assert fn(ang.detach()[0]).shape == (1, 3, 3)             # 0-d angle gets a batch dimension
+    Rq = tra.q_to_rotation_matrix(dev(g["quat_in"]))
+    assert np.abs(Rq.cpu().numpy() - g["quat_R"]).max() < 1e-6 * np.abs(g["quat_R"]).max() + 1e-6
+    ident = tra.Frame(device=DEV)
+    assert ident.batch_size == 1 and torch.equal(ident.rotation[0].cpu(), torch.eye(3)) and not ident.translation.any()
+    pose = torch.tensor([0.1, -0.2, 0.3, 0.5, 0.5, -0.5, 0.5])
+    fp = tra.Frame(pose=pose, device=DEV)
+    from torch_robotics_amd.kinmodel import quat_wxyz_to_rot
+    assert np.abs(fp.rotation[0].cpu().numpy() - quat_wxyz_to_rot(pose[3:].numpy())).max() < 1e-6
+    np.testing.assert_allclose(fp.translation.cpu().numpy(), [[0.1, -0.2, 0.3]])
+    one = tra.Frame(rot=torch.eye(3), trans=torch.tensor([1.0, 2.0, 3.0]), device=DEV)      # 2-D / 1-D inputs get a batch dim
+    assert one.rotation.shape == (1, 3, 3) and one.get_transform_matrix().shape == (1, 4, 4)
+
+
+def test_examples_run_like_the_reference_examples():
+    """examples/forward_kinematics.py and examples/inverse_kinematics.py: the reference's two example scripts on this package."""
+    import importlib.util
+    from pathlib import Path
+    ex = Path(__file__).resolve().parent.parent / "examples"
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, ex / f"{name}.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    res = load("forward_kinematics").main(batch_size=10, device="cuda:0", verbose=False)
+    assert set(res) == {"Panda", "UR10", "Habitat Stretch", "Tiago", "Shadow Hand", "Allegro Hand"}
+    H, gq = res["Panda"]
+    assert H.shape == (10, 11, 4, 4) and gq.shape == (10, 7) and torch.isfinite(gq).all()
+    q_ik, idx_valid, err, H_target = load("inverse_kinematics").main(batch_size=16, device="cuda:0", verbose=False)
+    assert q_ik.shape == (16, 7) and idx_valid.nelement() >= 12        # the reference converges for (nearly) all samples too
+    assert float(err[idx_valid].max()) < 5e-2                           # se3_eps of the call
+    np.testing.assert_allclose(H_target[0, :3, 3].cpu().numpy(), [0.2, 0.4, 0.1], atol=1e-7)
+
+
 def test_moved_scene_object_is_seen_by_every_cached_cost_model():
     """`ObjectField.set_position_orientation` between two evaluations: the reference reads the pose on every call
     (primitives.py:387-405), so PlanningTask's fused cost model, the per-field one and EnvBase.compute_sdf must all follow."""

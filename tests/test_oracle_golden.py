@@ -355,5 +355,8 @@ def test_frame_algebra_vs_reference(prec):
                 assert np.abs(gk - g[f"{name}_{key}"]).max() < 1e-6, (name, key)
     out, gR, gt = O.frame_transform_points(g["Ra"], g["ta"], g["pts"], g["wp"], prec=prec)
     assert np.abs(out - g["tp"]).max() <= tol and np.abs(gR - g["tp_gRa"]).max() < 2e-6 and np.abs(gt - g["tp_gta"]).max() < 2e-6
+    for k, nm in enumerate("xyz"):
+        assert np.abs(O.rotation_from(k, g["angle"], prec) - g[f"rot_{nm}"]).max() < 1e-7
+    assert np.abs(O.rotation_from(3, g["quat_in"], prec) - g["quat_R"]).max() <= tol
     quat, eul = O.frame_quat_euler(g["Ra"], prec=prec)
     assert np.abs(quat - g["quat_xyzw"]).max() < 2e-7 and np.abs(eul - g["euler"]).max() < 2e-7

@@ -10,7 +10,9 @@ from .costmodel import CostModelSpec  # noqa: F401
 from .kinematics import (DifferentiableTree, DifferentiableFrankaPanda, DifferentiableUR10,  # noqa: F401
                          DifferentiableKUKAiiwa, DifferentiableAllegroHand, DifferentiableShadowHand,
                          DifferentiableHabitatStretch, DifferentiableTiagoDualHoloMove,
-                         DifferentiableUR10Allegro, DifferentiableDualPanda, Frame)
+                         DifferentiableUR10Allegro, DifferentiableDualPanda, Frame, x_rot, y_rot, z_rot,
+                         q_to_rotation_matrix, link_pos_from_link_tensor, link_rot_from_link_tensor,
+                         link_quat_from_link_tensor)
 from .environments import (MultiSphereField, MultiBoxField, MultiSharpBoxField, ObjectField, GridMapSDF,  # noqa: F401
                            EnvBase, EnvSpheres3D, EnvSpheres3DExtraObjects, EnvTableShelf, EnvMazeBoxes3D,
                            GraspedObject, GraspedObjectPandaBox)

@@ -27,7 +27,7 @@ EXPORTS = [
     "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_reduce_sum", "trk_debug_set_stamp_buffer", "trk_interpolate_via_points",
     "trk_grid_precompute",
     "trk_frame_compose", "trk_frame_compose_backward", "trk_frame_transform_points", "trk_frame_transform_points_backward",
-    "trk_frame_quat_euler",
+    "trk_frame_quat_euler", "trk_rotation_from", "trk_rotation_from_backward",
     "trk_sdf_points",
     "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_point_set_is_specialized", "trk_fk_points", "trk_fk_points_backward",
     "trk_rollout_points_cost_grad", "trk_rollout_collision", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16", "trk_finite_difference", "trk_traj_diff_norm_sum",
@@ -79,6 +79,8 @@ def lib():
     L.trk_fk_analytic_jacobian.argtypes = [vp, vp, i64, vp, vp]
     L.trk_ik_step.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, f32, i32, i64, vp, vp, vp, vp, vp, vp]
     L.trk_rotmat_to_quat.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.trk_rotation_from.argtypes = [i32, vp, i64, vp, vp]
+    L.trk_rotation_from_backward.argtypes = [i32, vp, vp, i64, vp, vp]
     L.trk_frame_compose.argtypes = [i32, vp, vp, i64, vp, vp, i64, vp, vp, vp]
     L.trk_frame_compose_backward.argtypes = [i32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]
     L.trk_frame_transform_points.argtypes = [vp, vp, i64, vp, i32, vp, vp]

@@ -545,6 +545,26 @@ int trk_rotmat_to_quat(const float* R, int64_t n, int32_t stride, int32_t row_pi
     return TRK_OK;
 }
 
+int trk_rotation_from(int32_t kind, const float* in, int64_t n, float* R_out, trk_stream_t stream) {
+    if (kind < TRK_ROT_X || kind > TRK_ROT_QUAT_WXYZ || n < 0 || (n > 0 && (!in || !R_out))) return fail(TRK_ERR_INVALID_ARG, "trk_rotation_from: bad argument");
+    if (n == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_rotation_from(kind, in, n, R_out, nullptr, nullptr, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_rotation_from_backward(int32_t kind, const float* angle, const float* gR, int64_t n, float* gangle, trk_stream_t stream) {
+    if (kind < TRK_ROT_X || kind > TRK_ROT_Z || n < 0 || (n > 0 && (!angle || !gR || !gangle))) return fail(TRK_ERR_INVALID_ARG, "trk_rotation_from_backward: bad argument");
+    if (n == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_rotation_from(kind, angle, n, nullptr, gR, gangle, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Frame algebra (geometrics/frame.py:55-121)
 int trk_frame_compose(int32_t op, const float* Ra, const float* ta, int64_t na, const float* Rb, const float* tb, int64_t nb,

@@ -1290,6 +1290,40 @@ k_frame_quat_euler(const float* __restrict__ R, int64_t n, int stride, int pitch
     }
 }
 
+// x_rot / y_rot / z_rot spatial_vector.py:8-47 (axis 0 / 1 / 2) and q_to_rotation_matrix quaternion.py:102-120 (axis 3, input
+// wxyz [n,4]): -> R [n,9].  gR != nullptr: reverse mode of the axis rotations, gangle[s] = <gR_s, dR/dangle>.
+__global__ void __launch_bounds__(256)
+k_rotation_from(int axis, const float* __restrict__ in, int64_t n, float* __restrict__ R, const float* __restrict__ gR,
+                float* __restrict__ gin) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    float r[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (axis == 3) {
+        const float4 q = reinterpret_cast<const float4*>(in)[s];
+        const float w = q.x, x = q.y, y = q.z, z = q.w;
+        const float dc = 2.0f / (((w * w + x * x) + y * y) + z * z);        // torch sums the squares left to right
+        r[0] = 1.0f - dc * (y * y + z * z); r[1] = dc * (x * y - z * w); r[2] = dc * (x * z + y * w);
+        r[3] = dc * (x * y + z * w); r[4] = 1.0f - dc * (x * x + z * z); r[5] = dc * (y * z - x * w);
+        r[6] = dc * (x * z - y * w); r[7] = dc * (y * z + x * w); r[8] = 1.0f - dc * (x * x + y * y);
+    } else {
+        const float a = in[s];
+        const float c = cosf(a), sn = sinf(a);
+        // (i, j): the two axes the rotation mixes, in the sign convention of the reference
+        const int i = axis == 0 ? 1 : 0, j = axis == 2 ? 1 : 2;
+        const float sg = axis == 1 ? -1.0f : 1.0f;                           // y_rot has +sin above the diagonal
+        r[4 * axis] = 1.0f;
+        r[3 * i + i] = c; r[3 * j + j] = c; r[3 * i + j] = -sg * sn; r[3 * j + i] = sg * sn;
+        if (gR) {
+            const float* g = gR + s * 9;
+            gin[s] = -sn * (g[3 * i + i] + g[3 * j + j]) + c * sg * (g[3 * j + i] - g[3 * i + j]);
+        }
+    }
+    if (R) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[s * 9 + k] = r[k];
+    }
+}
+
 // GridMapSDF.precompute_sdf grid_map_sdf.py:34-63 (analytic objects only) and
 // ObjectField.compute_signed_distance on arbitrary points
 __global__ void __launch_bounds__(256)
@@ -1647,6 +1681,10 @@ void trk_launch_frame_transform_points_bwd(const float* g, int64_t n, const floa
 void trk_launch_frame_quat_euler(const float* R, int64_t n, int stride, int pitch, float* quat_xyzw, float* euler,
                                  hipStream_t st) {
     hipLaunchKernelGGL(k_frame_quat_euler, dim3(grid_for(n, 256)), dim3(256), 0, st, R, n, stride, pitch, quat_xyzw, euler);
+}
+
+void trk_launch_rotation_from(int axis, const float* in, int64_t n, float* R, const float* gR, float* gin, hipStream_t st) {
+    hipLaunchKernelGGL(k_rotation_from, dim3(grid_for(n, 256)), dim3(256), 0, st, axis, in, n, R, gR, gin);
 }
 
 void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const float* lo, const float* hi, float* sdf,

@@ -44,6 +44,7 @@ void trk_launch_frame_transform_points_bwd(const float* g, int64_t n, const floa
                                            hipStream_t st);
 void trk_launch_frame_quat_euler(const float* R, int64_t n, int stride, int pitch, float* quat_xyzw, float* euler,
                                  hipStream_t st);
+void trk_launch_rotation_from(int axis, const float* in, int64_t n, float* R, const float* gR, float* gin, hipStream_t st);
 void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const float* lo, const float* hi, float* sdf,
                                 float* grad, hipStream_t st);
 void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_interp, const float* alpha, const float* beta,

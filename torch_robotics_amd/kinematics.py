@@ -23,11 +23,45 @@ URDF_DIR = DATA_DIR / "urdf"
 
 
 class Frame:
-    """Batch of rigid transforms (reference: geometrics/frame.py:12-129; the accessors FK callers use)."""
+    """Batch of rigid transforms (reference: geometrics/frame.py:12-129): same constructor -- `Frame(rot=None, trans=None,
+    pose=None, device=...)`, identity by default, a single (3,3) / (3,) gets a batch dimension, `pose` = x y z qw qx qy qz."""
 
-    def __init__(self, rot: torch.Tensor, trans: torch.Tensor):
-        self._rot, self._trans = rot, trans
-        self.batch_size = trans.shape[0]
+    def __init__(self, rot: Optional[torch.Tensor] = None, trans: Optional[torch.Tensor] = None,
+                 pose: Optional[torch.Tensor] = None, device=None):
+        if device is None:
+            device = rot.device if rot is not None else (trans.device if trans is not None else
+                                                         (pose.device if pose is not None else "cuda"))
+        self.device = torch.device(device)
+        if rot is None:
+            self._rot = torch.eye(3, device=self.device).unsqueeze(0)
+        else:
+            self._rot = rot.to(self.device)
+            if self._rot.dim() == 2:
+                self._rot = self._rot.unsqueeze(0)
+        if trans is None:
+            self._trans = torch.zeros(1, 3, device=self.device)
+        else:
+            self._trans = trans.to(self.device)
+            if self._trans.dim() == 1:
+                self._trans = self._trans.unsqueeze(0)
+        if pose is not None:
+            self.set_pose(pose)
+        assert self._trans.shape[0] == self._rot.shape[0]
+        self.batch_size = self._trans.shape[0]
+
+    def set_pose(self, pose: torch.Tensor) -> None:              # frame.py:41-49
+        if pose.dim() == 1:
+            pose = pose.unsqueeze(0)
+        pose = pose.to(self.device)
+        self._trans = pose[:, :3].clone()
+        self._rot = ops.quat_to_rotmat(pose[:, 3:])
+        self.batch_size = self._trans.shape[0]
+
+    def set_translation(self, t: torch.Tensor) -> None:
+        self._trans = t.to(self.device)
+
+    def set_rotation(self, rot: torch.Tensor) -> None:
+        self._rot = rot.to(self.device)
 
     @property
     def rotation(self) -> torch.Tensor:
@@ -328,6 +362,22 @@ class DifferentiableTiagoDualHoloMove(DifferentiableTree):     # robots.py:104-1
 
 
 # tensor helpers with the reference's names (geometrics/utils.py:321-344)
+def x_rot(angle):                                            # spatial_vector.py:8-20
+    return ops.axis_rotation(0, angle)
+
+
+def y_rot(angle):                                            # spatial_vector.py:22-34
+    return ops.axis_rotation(1, angle)
+
+
+def z_rot(angle):                                            # spatial_vector.py:36-47
+    return ops.axis_rotation(2, angle)
+
+
+def q_to_rotation_matrix(q):                                 # quaternion.py:102-120
+    return ops.quat_to_rotmat(q)
+
+
 def link_pos_from_link_tensor(link_tensor):
     if link_tensor.shape[-1] == 4:
         return link_tensor[..., :3, 3]

@@ -294,6 +294,47 @@ def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _AxisRotation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, angle):
+        n = int(angle.shape[0])
+        R = torch.empty((n, 3, 3), device=angle.device, dtype=torch.float32)
+        with torch.cuda.device(angle.device):
+            check(lib().trk_rotation_from(kind, angle.data_ptr(), n, R.data_ptr(), _stream(angle)), "trk_rotation_from")
+        ctx.kind = kind
+        ctx.save_for_backward(angle)
+        return R
+
+    @staticmethod
+    def backward(ctx, gR):
+        (angle,) = ctx.saved_tensors
+        gR = _dev_f32(gR, "axis rotation backward")
+        ga = torch.empty_like(angle)
+        with torch.cuda.device(angle.device):
+            check(lib().trk_rotation_from_backward(ctx.kind, angle.data_ptr(), gR.data_ptr(), int(angle.shape[0]), ga.data_ptr(),
+                                                   _stream(angle)), "trk_rotation_from_backward")
+        return None, ga
+
+
+def axis_rotation(kind: int, angle: torch.Tensor) -> torch.Tensor:
+    """x_rot / y_rot / z_rot (kind 0 / 1 / 2; spatial_vector.py:8-47): angles (n,) | (n,1) | () -> (n,3,3); differentiable."""
+    a = _dev_f32(angle, "axis_rotation(angle)").reshape(-1)
+    return _AxisRotation.apply(int(kind), a)
+
+
+def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
+    """q_to_rotation_matrix (quaternion.py:102-120): wxyz (..., 4), not necessarily normalised -> (..., 3, 3)."""
+    q = _dev_f32(q.detach(), "quat_to_rotmat(q)")
+    if q.dim() == 1:
+        q = q.unsqueeze(0)
+    lead = q.shape[:-1]
+    flat = q.reshape(-1, 4).contiguous()
+    R = torch.empty((flat.shape[0], 3, 3), device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        check(lib().trk_rotation_from(3, flat.data_ptr(), int(flat.shape[0]), R.data_ptr(), _stream(q)), "trk_rotation_from")
+    return R.reshape(tuple(lead) + (3, 3))
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # Frame algebra (geometrics/frame.py:55-121): trk_frame_* kernels, explicit reverse mode
 # ----------------------------------------------------------------------------------------------------------------------
