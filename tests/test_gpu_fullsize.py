@@ -1,0 +1,246 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties of the domain (the oracle finishes only small
+cases in seconds): linearity of the objective in its weights, rigid-motion equivariance of FK and the costs, a checksum of
+checksums against the deterministic reduction, sharding invariance (what the N-GPU batch split relies on), a directional
+finite-difference check of the gradient summed over the whole batch, monotonicity of the boolean fields in the margin --
+plus an fp64-oracle spot check of a random subset of the full-size outputs.
+
+configs[1]: Panda 4096 x 64, obstacles + EE      configs[2]: Panda, one GPU's 4096 x 64 share of 32768 x 64, all four terms
+configs[3]: UR10 + Allegro 4096 x 64             configs[4]: dual Panda, one GPU's 2048 x 128 share, fp16 I/O + GP prior
+"""
+import numpy as np
+import pytest
+import torch
+
+import torch_robotics_amd as tra
+from helpers import rel_err
+from torch_robotics_amd import codegen
+from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+from torch_robotics_amd.costmodel import CostModelSpec
+from torch_robotics_amd.kinmodel import quat_wxyz_to_rot
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TA = dict(device=DEV, dtype=torch.float32)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from torch_robotics_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def oracle_lib():
+    from oracle import oracle as orc
+    return orc
+
+
+def panda_task(all_terms):
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5)
+    task.set_ee_target(Ht)
+    gen = torch.Generator(device=DEV).manual_seed(1234)
+    q = robot.random_q(4096 * 64, generator=gen).reshape(4096, 64, 7).contiguous()
+    return robot, task, q, ((1.0, 1.0, 1.0, 1.0) if all_terms else (0.0, 1.0, 0.0, 1.0))
+
+
+@pytest.mark.parametrize("all_terms", [False, True], ids=["config2_obj_ee", "config3_all_terms"])
+def test_panda_full_size_properties(ops, oracle_lib, all_terms):
+    robot, task, q, w = panda_task(all_terms)
+    model, cm = task._fused_handles(DEV)
+    assert model.specialized
+    B, H = 4096, 64
+    n = B * H
+    sums = torch.zeros(ops.n_blocks(n), **TA)
+    pos, cost, gq = ops.rollout_cost_grad(model, cm, w, q, cost_sum=sums)
+    assert pos.shape == (B, H, 11, 3) and cost.shape == (B, H) and gq.shape == (B, H, 7)
+    assert torch.isfinite(pos).all() and torch.isfinite(cost).all() and torch.isfinite(gq).all()
+
+    # idempotence / determinism: a second evaluation gives the same bits
+    pos2, cost2, gq2 = ops.rollout_cost_grad(model, cm, w, q)
+    assert torch.equal(pos, pos2) and torch.equal(cost, cost2) and torch.equal(gq, gq2)
+
+    # checksum of checksums: per-wavefront sums (= per-trajectory costs at horizon 64) and their deterministic total
+    per_traj = cost.double().sum(1)
+    np.testing.assert_allclose(sums.double().cpu().numpy(), per_traj.cpu().numpy(), rtol=3e-6, atol=1e-5)
+    total = ops.reduce_sum(sums).item()
+    assert abs(total - per_traj.sum().item()) <= 2e-6 * per_traj.abs().sum().item()
+    assert ops.reduce_sum(sums).item() == total                 # fixed association order
+
+    # linearity in the weights: cost(w) = sum_i w_i cost(e_i), same for the gradient
+    acc_c, acc_g = torch.zeros_like(cost, dtype=torch.float64), torch.zeros_like(gq, dtype=torch.float64)
+    coef = (0.5, 2.0, 0.25, 3.0)
+    for i in range(4):
+        e = [0.0] * 4
+        e[i] = 1.0
+        if not all_terms and i in (0, 2):
+            continue
+        _, ci, gi = ops.rollout_cost_grad(model, cm, e, q, want_pos=False)
+        acc_c += coef[i] * ci.double(); acc_g += coef[i] * gi.double()
+    wmix = tuple(c if (all_terms or i in (1, 3)) else 0.0 for i, c in enumerate(coef))
+    _, cm_, gm_ = ops.rollout_cost_grad(model, cm, wmix, q, want_pos=False)
+    assert rel_err(cm_.cpu().numpy(), acc_c.cpu().numpy()) < 1e-5
+    assert rel_err(gm_.cpu().numpy(), acc_g.cpu().numpy()) < 2e-5
+
+    # sharding invariance: the two halves of the batch evaluated separately == the full batch, bit for bit
+    for lo, hi in ((0, B // 2), (B // 2, B), (1000, 1003)):
+        p_s, c_s, g_s = ops.rollout_cost_grad(model, cm, w, q[lo:hi].contiguous())
+        assert torch.equal(p_s, pos[lo:hi]) and torch.equal(c_s, cost[lo:hi]) and torch.equal(g_s, gq[lo:hi])
+
+    # gradient: directional finite difference, summed over the whole batch (kinks at arg-min switches / joint limits are
+    # measure-zero events; the batch sum averages them out)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    dq = torch.randn(q.shape, generator=gen, **TA)
+    eps = 1e-3
+    lo_, hi_ = robot.q_min.to(DEV), robot.q_max.to(DEV)
+    inside = ((q - eps * dq.abs() > lo_) & (q + eps * dq.abs() < hi_)).all(-1)          # stay off the clamps
+    _, cp, _ = ops.rollout_cost_grad(model, cm, w, q + eps * dq, want_pos=False)
+    _, cn, _ = ops.rollout_cost_grad(model, cm, w, q - eps * dq, want_pos=False)
+    fd_i = ((cp.double() - cn.double()) / (2 * eps))[inside]
+    an_i = (gq.double() * dq.double()).sum(-1)[inside]
+    # per sample: equal up to the fp32 rounding of the two costs (~1e-7 * cost / eps) except where the +-eps segment crosses
+    # a kink of the objective (arg-min switch between spheres / planes: a small fraction of the samples)
+    tol_i = 2e-3 * an_i.abs() + 2e-3 * (1.0 + cp[inside].abs().double())
+    frac_bad = ((fd_i - an_i).abs() > tol_i).double().mean().item()
+    assert frac_bad < (0.02 if all_terms else 0.01), frac_bad
+    # whole batch: the kink errors have random sign, so the sums agree to a small fraction of sum |terms|
+    assert abs(fd_i.sum().item() - an_i.sum().item()) <= 3e-5 * an_i.abs().sum().item(), (fd_i.sum().item(), an_i.sum().item())
+
+    # rigid-motion equivariance: base pose T on the robot + the same T on scene, workspace-free terms and EE target
+    if not all_terms:                                           # the axis-aligned workspace box is not rotation invariant
+        pose = np.array([0.3, -0.2, 0.1, 0.9238795, 0.0, 0.0, 0.3826834], np.float32)     # 45 deg about z
+        R, t = quat_wxyz_to_rot(pose[3:]), pose[:3]
+        robot2 = tra.RobotPanda(tensor_args=TA)
+        robot2.diff_panda.update_base_pose(torch.from_numpy(pose))
+        env2 = tra.EnvSpheres3D(tensor_args=TA)
+        env2.obj_fixed_list[0].set_position_orientation(pos=t, ori=pose[3:])
+        task2 = tra.PlanningTask(env=env2, robot=robot2, obstacle_cutoff_margin=0.03, tensor_args=TA)
+        Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5)
+        T = np.eye(4, dtype=np.float32); T[:3, :3] = R; T[:3, 3] = t
+        task2.set_ee_target(T @ Ht)
+        m2, c2 = task2._fused_handles(DEV)
+        p_b, c_b, g_b = ops.rollout_cost_grad(m2, c2, w, q)
+        want = pos.reshape(-1, 3) @ torch.from_numpy(R.T).to(DEV) + torch.from_numpy(t).to(DEV)
+        assert (p_b.reshape(-1, 3) - want).abs().max().item() < 3e-6
+        assert rel_err(c_b.cpu().numpy(), cost.cpu().numpy()) < 2e-5
+        # the gradient jumps where two spheres are equidistant from a link (arg-min switch): a rotated scene rounds such a
+        # near-tie the other way for a handful of the 262 144 samples; everywhere else the gradients agree
+        bad = ((g_b - gq).abs().amax(-1) > 2e-4 * gq.abs().max()).sum().item()
+        assert bad <= n // 20000, bad
+
+    # boolean fields at full size: fused == positions + field kernel; monotone in the margin; consistent with the cost's sign
+    fields = FIELD_OBJECTS | FIELD_WS | (FIELD_SELF if all_terms else 0)
+    c_def = ops.rollout_collision(model, cm, fields, q)
+    assert c_def.shape == (B, H)
+    two_step = ops.collision_fields(cm, fields, pos.reshape(-1, 11, 3)).reshape(B, H).bool()
+    assert (c_def != two_step).sum().item() <= 2                # last-ulp FK differences can only matter at a margin
+    c0, c1 = ops.rollout_collision(model, cm, fields, q, margin=0.0), ops.rollout_collision(model, cm, fields, q, margin=0.05)
+    assert not (c0 & ~c1).any()                                 # in collision at margin 0  =>  in collision at margin 0.05
+    assert 0 < int(c0.sum()) < n
+
+    # fp64 oracle on a random subset of the full-size outputs
+    o = oracle_lib.Oracle(robot.diff_panda._kin, task.build_cost_spec())
+    idx = np.random.default_rng(3).choice(n, 2048, replace=False)
+    q_h = q.reshape(-1, 7)[idx].cpu().numpy()
+    p64, c64, g64 = o.rollout(q_h.astype(np.float64), w, "f64")
+    assert np.abs(pos.reshape(-1, 11, 3)[idx].cpu().numpy() - p64).max() < 2e-6
+    assert rel_err(cost.reshape(-1)[idx].cpu().numpy(), c64) < 1e-5
+    assert rel_err(gq.reshape(-1, 7)[idx].cpu().numpy(), g64) < 1e-4
+
+
+def tree_setup(ident):
+    kin, tmpl = codegen.template_for(ident)
+    env = tra.EnvSpheres3D(tensor_args=TA)
+    spec = CostModelSpec(n_links_in=kin.n_links)
+    spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+    spec.obj_link_margin = np.full(len(tmpl.obj_links), 0.13, np.float32)
+    spec.objects = [o.as_object() for o in env.obj_fixed_list]
+    spec.ee_link = tmpl.ee_link
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5); spec.ee_target = Ht
+    if tmpl.ee2_link >= 0:
+        spec.ee2_link = tmpl.ee2_link
+        Ht2 = np.eye(4, dtype=np.float32); Ht2[:3, 3] = (0.4, -0.3, 0.5); spec.ee2_target = Ht2
+    return kin, spec
+
+
+def test_ur10_allegro_full_size(ops, oracle_lib):
+    """configs[3]: UR10 + Allegro (30 links, 22 DOF), 4096 x 64, FK + obstacles + EE + gradient and the geometric Jacobian."""
+    kin, spec = tree_setup("ur10_allegro")
+    h, cm = ops.ModelHandle(kin), ops.CostHandle(spec, DEV)
+    assert h.specialized
+    B, H, D, L = 4096, 64, kin.n_dofs, kin.n_links
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    q = ((torch.rand(B, H, D, generator=gen, **TA) - 0.5) * 3.0).contiguous()
+    w = (0.0, 1.0, 0.0, 1.0)
+    pos, cost, gq = ops.rollout_cost_grad(h, cm, w, q)
+    assert pos.shape == (B, H, L, 3) and torch.isfinite(cost).all() and torch.isfinite(gq).all()
+    p2, c2, g2 = ops.rollout_cost_grad(h, cm, w, q[B // 2:].contiguous())                 # sharding invariance
+    assert torch.equal(p2, pos[B // 2:]) and torch.equal(c2, cost[B // 2:]) and torch.equal(g2, gq[B // 2:])
+    # generated == table-driven on a slice (both full-size launches would only repeat the small-size parity tests)
+    h.enable_specialized(False)
+    pt, ct, gt = ops.rollout_cost_grad(h, cm, w, q[:64].contiguous())
+    h.enable_specialized(True)
+    assert (pt - pos[:64]).abs().max().item() < 3e-6 and rel_err(ct.cpu().numpy(), cost[:64].cpu().numpy()) < 1e-5
+    assert rel_err(gt.cpu().numpy(), gq[:64].cpu().numpy()) < 1e-4
+    # geometric Jacobian of ee_link: J_lin * dq == directional derivative of the position (finite difference), whole batch
+    ee = kin.name_to_idx["ee_link"]
+    qf = q.reshape(-1, D)
+    p_ee, quat, lin, ang = ops.fk_jacobian(h, qf, None, ee)[:4]
+    assert (p_ee - pos.reshape(-1, L, 3)[:, ee]).abs().max().item() < 3e-6
+    dq = torch.randn(qf.shape, generator=gen, **TA)
+    eps = 1e-3
+    lo, hi = torch.as_tensor(kin.lower[kin.controlled], **TA), torch.as_tensor(kin.upper[kin.controlled], **TA)
+    inside = ((qf - eps > lo) & (qf + eps < hi)).all(-1)
+    pp = ops.fk_positions(h, qf + eps * dq, [ee])[:, 0]
+    pn = ops.fk_positions(h, qf - eps * dq, [ee])[:, 0]
+    fd = (pp - pn) / (2 * eps)
+    an = torch.einsum("nkd,nd->nk", lin, dq)
+    err = (fd - an)[inside].abs().max().item()
+    assert err < 5e-3 * max(1.0, an[inside].abs().max().item()), err
+    # oracle subset
+    o = oracle_lib.Oracle(kin, spec)
+    idx = np.random.default_rng(4).choice(B * H, 512, replace=False)
+    p64, c64, g64 = o.rollout(qf[idx].cpu().numpy().astype(np.float64), w, "f64")
+    assert np.abs(pos.reshape(-1, L, 3)[idx].cpu().numpy() - p64).max() < 3e-6
+    assert rel_err(cost.reshape(-1)[idx].cpu().numpy(), c64) < 1e-5 and rel_err(gq.reshape(-1, D)[idx].cpu().numpy(), g64) < 1e-4
+
+
+def test_dual_panda_fp16_gp_full_size(ops, oracle_lib):
+    """configs[4]: dual Panda, one GPU's 2048 x 128 share of the 8192 x 128 batch, fp16 q / link positions / gradient in HBM,
+    fp32 arithmetic and cost, GP prior accumulated into the same gradient."""
+    kin, spec = tree_setup("dual_panda")
+    h, cm = ops.ModelHandle(kin), ops.CostHandle(spec, DEV)
+    B, H, D, L = 2048, 128, kin.n_dofs, kin.n_links
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    q = (torch.cumsum(torch.randn(B, H, D, generator=gen, **TA) * 0.02, 1) + (torch.rand(B, 1, D, generator=gen, **TA) - 0.5) * 2.0)
+    qd = torch.randn(B, H, D, generator=gen, **TA) * 0.1
+    qh, qdh = q.half().contiguous(), qd.half().contiguous()
+    w = (0.0, 1.0, 0.0, 1.0)
+    pos, cost, gq = ops.rollout_cost_grad(h, cm, w, qh)
+    assert pos.dtype == torch.float16 and gq.dtype == torch.float16 and cost.dtype == torch.float32
+    assert pos.shape == (B, H, L, 3) and torch.isfinite(cost).all() and torch.isfinite(gq.float()).all()
+    # fp32 I/O on the fp16-rounded inputs: the outputs differ by one fp16 rounding only, the cost not at all beyond fp32 noise
+    p32, c32, g32 = ops.rollout_cost_grad(h, cm, w, qh.float())
+    assert rel_err(cost.cpu().numpy(), c32.cpu().numpy()) < 2e-6
+    assert (pos.float() - p32).abs().max().item() <= 2.0 ** -11 * max(1.0, p32.abs().max().item()) * 1.01
+    assert rel_err(gq.float().cpu().numpy(), g32.cpu().numpy()) < 2.0 ** -10
+    # GP prior accumulated into the rollout's gradient == sum of the two gradients
+    gqd = torch.zeros_like(gq)
+    acc = gq.clone()
+    c_gp, _, _ = ops.gp_prior_cost_grad(qh, qdh, 5.0 / H, 0.1, 1.0, accumulate_into=(acc, gqd))
+    c_gp2, g_gp, _ = ops.gp_prior_cost_grad(qh, qdh, 5.0 / H, 0.1, 1.0)
+    assert torch.equal(c_gp, c_gp2) and c_gp.shape == (B,)
+    ok = torch.isfinite(g_gp.float()) & torch.isfinite(acc.float())
+    ref = gq.float() + g_gp.float()
+    assert ((acc.float() - ref)[ok].abs() <= 2.0 ** -9 * ref[ok].abs() + 1e-3).all()
+    # sharding invariance of both kernels (whole trajectories stay on one rank)
+    _, c_s, g_s = ops.rollout_cost_grad(h, cm, w, qh[B // 2:].contiguous(), want_pos=False)
+    assert torch.equal(c_s, cost[B // 2:]) and torch.equal(g_s, gq[B // 2:])
+    assert torch.equal(ops.gp_prior_cost_grad(qh[:7].contiguous(), qdh[:7].contiguous(), 5.0 / H, 0.1, 1.0)[0], c_gp[:7])
+    # oracle subset (the oracle sees the same fp16-rounded q)
+    o = oracle_lib.Oracle(kin, spec)
+    idx = np.random.default_rng(6).choice(B * H, 512, replace=False)
+    p64, c64, g64 = o.rollout(qh.reshape(-1, D)[idx].float().cpu().numpy().astype(np.float64), w, "f64")
+    assert rel_err(cost.reshape(-1)[idx].cpu().numpy(), c64) < 1e-5
+    assert np.abs(pos.reshape(-1, L, 3)[idx].float().cpu().numpy() - p64).max() < 2.0 ** -10 * max(1.0, np.abs(p64).max())
