@@ -94,8 +94,8 @@ def main():
     bs_ptr = block_sums.data_ptr()
     # the collective fires in the MIDDLE of every `reduce_every`-step interval (a planner consumes the sums a few evaluations
     # later), and the interval shrinks for short runs so that the timed region always contains at least one all-reduce
-    R = max(2, min(args.reduce_every, args.steps // 2)) if world > 1 else max(1, args.reduce_every)
-    n_slots = 2 * (args.warmup + args.steps) // R + 8
+    R = max(1, min(args.reduce_every, args.steps))
+    n_slots = 2 * ((args.warmup + args.steps) // R + 2) + 8
     # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
     packed = torch.zeros((n_slots, 1 + H + H * D), **ta)
     stream = torch.cuda.current_stream(dev)
@@ -128,6 +128,8 @@ def main():
             for i in range(G):
                 plan.launch(bs_ptr, torch.cuda.current_stream(dev).cuda_stream)
 
+    slot = [0]
+
     def run(first, count):
         if graph is not None:
             assert count % args.graph == 0
@@ -135,29 +137,42 @@ def main():
                 graph.replay()
             return
         s = stream.cuda_stream
-        for i in range(first, first + count):
+        for j in range(count):
             plan.launch(bs_ptr, s)
-            if side is not None and (i + 1) % R == R // 2:
-                reduce_slot((i + 1) // R)
+            if side is not None and j % R == R // 2:        # counted from the start of this (warm-up or timed) region
+                reduce_slot(slot[0])
+                slot[0] += 1
 
     if graph is not None:
         args.steps = max(args.graph, args.steps // args.graph * args.graph)
         args.warmup = max(args.graph, args.warmup // args.graph * args.graph)
+    def barrier():
+        if args.dist_backend == "nccl":
+            dist.barrier(device_ids=[dev.index])
+        else:
+            dist.barrier()
+
     def measure(first):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize brackets; returns (wall s, event ms)."""
         run(first, args.warmup)
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            barrier()
             torch.cuda.synchronize(dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
         run(first + args.warmup, args.steps)
         ev1.record(stream)
+        ta_ = time.perf_counter()
         while not ev1.query():          # spin on the completion signal: a blocking wait adds ~6 us of wake-up latency
             pass
+        tb_ = time.perf_counter()
         torch.cuda.synchronize(dev)
+        if os.environ.get("TRK_BENCH_TRACE"):
+            tc_ = time.perf_counter()
+            print(f"[trace] submit {1e6 * (ta_ - t0):.1f} us, wait {1e6 * (tb_ - ta_):.1f} us, sync {1e6 * (tc_ - tb_):.1f} us, "
+                  f"events {1e3 * ev0.elapsed_time(ev1):.1f} us", file=sys.stderr)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
