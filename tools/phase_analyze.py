@@ -24,6 +24,8 @@ for k in (1, 3, 4, 5, 6, 7):
     print(f"  {names[k]:16s} at p5 {np.percentile(t,5):5.2f} p50 {np.percentile(t,50):5.2f} p95 {np.percentile(t,95):5.2f} max {t.max():5.2f} us | phase duration mean {d.mean():.2f} us")
 wg = np.arange(n) // 4
 for x in range(8):
+    if not ((wg % 8) == x).any():
+        continue
     m = (wg % 8) == x
     print(f"  xcd{x}: entry p50 {np.percentile(entry_us[m],50):.2f} max {entry_us[m].max():.2f} | exit p50 {np.percentile(exit_us[m],50):.2f} max {exit_us[m].max():.2f} | life mean {life_us[m].mean():.2f}")
 # occupancy over time: waves alive at t

@@ -16,7 +16,8 @@ robot = tra.RobotPanda(tensor_args=ta)
 task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=ta), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=ta)
 Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5)
 task.set_ee_target(Ht)
-B, H = 4096, 64
+B = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 4096
+H = 64
 q = robot.random_q(B * H).reshape(B, H, 7).contiguous()
 model, cm = task._fused_handles(dev)
 NO_POS = "--no-pos" in sys.argv
@@ -37,7 +38,10 @@ torch.cuda.synchronize()
 print(f"[{TAG}] launch time by events: {e0.elapsed_time(e1) / 2000 * 1e3:.2f} us")
 stamps = torch.zeros((nb, 8), device=dev, dtype=torch.int64)
 lib().trk_debug_set_stamp_buffer(stamps.data_ptr())
-plan.launch(bs.data_ptr())
+# default: the stamped launch is the LAST of a back-to-back train (steady state: the XCDs are awake; an isolated launch after a
+# sync shows them starting ~0.17 us apart, tools/dispatch_ramp.hip); --isolated stamps a single launch on an idle GPU
+for _ in range(1 if "--isolated" in sys.argv else 6):
+    plan.launch(bs.data_ptr())
 torch.cuda.synchronize()
 lib().trk_debug_set_stamp_buffer(None)
 raw = stamps.cpu().numpy()
