@@ -544,7 +544,9 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
         E.raw("    if (A.cost_sum) {")
         E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
-        E.raw("        if (lane == 0 && rows > 0) A.cost_sum[wblock] = tot;")
+        # write-through like every other output: the plain 4-byte store left 4096 dirty partial lines for the end-of-kernel
+        # write-back (same-box A/B 9.94 -> 9.77 us)
+        E.raw("        if (lane == 0 && rows > 0) store_wt_f1(A.cost_sum + wblock, tot);")
         E.raw("    }")
         # ---------------- reverse: wrench accumulators towards the root ----------------
         # (A second FK walk with prefix-sum gradients instead of this reverse pass -- so that the joints' axes / origins need not
@@ -908,7 +910,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
         E.raw("    if (A.cost_sum) {")
         E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
-        E.raw("        if (lane == 0 && rows > 0) A.cost_sum[wblock] = tot;")
+        E.raw("        if (lane == 0 && rows > 0) store_wt_f1(A.cost_sum + wblock, tot);")
         E.raw("    }")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D>(static_cast<IO*>(A.gq), base, rows, lane, lds, gv);")
