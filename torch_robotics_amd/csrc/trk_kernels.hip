@@ -562,6 +562,43 @@ __device__ __forceinline__ float fields_links(const DevCostHdr& C, int fields, f
     return cost;
 }
 
+// boolean version of fields_links (distance_fields.py:210-215, 283-291): NB collision links [l0, l0 + NB) at once
+template <int NB>
+__device__ __forceinline__ bool collision_links(const DevCostHdr& C, int fields, int l0, float margin_override, int use_default,
+                                                const float* pt) {
+    float mg[NB], x[NB], y[NB], z[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int li = cptr(C.obj_link_idx)[l0 + k];
+        mg[k] = use_default ? cptr(C.obj_link_margin)[l0 + k] : margin_override;
+        x[k] = pt[3 * li]; y[k] = pt[3 * li + 1]; z[k] = pt[3 * li + 2];
+    }
+    bool hit = false;
+    if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
+        float s[NB], gx[NB], gy[NB], gz[NB];
+        scene_min_sdf<NB>(C, x, y, z, s, gx, gy, gz);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            bool h = s[k] < mg[k];
+            if (__builtin_fabsf(s[k] - mg[k]) < 1e-5f) {
+                h = false;
+                for (int o = 0; o < C.n_objects; ++o) {
+                    float ax, ay, az;
+                    h |= object_sdf<true>(C, o, x[k], y[k], z[k], ax, ay, az) < mg[k];
+                }
+            }
+            hit |= h;
+        }
+    }
+    if ((fields & TRK_FIELD_WS) && C.has_ws) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            hit |= (x[k] - C.ws_min[0] < mg[k]) | (y[k] - C.ws_min[1] < mg[k]) | (z[k] - C.ws_min[2] < mg[k]) |
+                   (C.ws_max[0] - x[k] < mg[k]) | (C.ws_max[1] - y[k] < mg[k]) | (C.ws_max[2] - z[k] < mg[k]);
+    }
+    return hit;
+}
+
 template <bool PRECISE>
 __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, float w_self, float w_obj, float w_ws,
                                              const float* tile, float* gtile, int rs, int lane) {
@@ -657,20 +694,12 @@ k_collision_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos,
     const float* pt = tile + lane * rs;
     bool hit = false;
     if (fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {
-        for (int l = 0; l < C.n_obj_links; ++l) {
-            const int li = cptr(C.obj_link_idx)[l];
-            const float mg = use_default ? cptr(C.obj_link_margin)[l] : margin_override;
-            const float x = pt[3 * li], y = pt[3 * li + 1], z = pt[3 * li + 2];
-            if (fields & TRK_FIELD_OBJECTS)
-                for (int o = 0; o < C.n_objects; ++o) {
-                    float gx, gy, gz;
-                    hit |= object_sdf<true>(C, o, x, y, z, gx, gy, gz) < mg;
-                }
-            if ((fields & TRK_FIELD_WS) && C.has_ws) {
-                hit |= (x - C.ws_min[0] < mg) | (y - C.ws_min[1] < mg) | (z - C.ws_min[2] < mg) |
-                       (C.ws_max[0] - x < mg) | (C.ws_max[1] - y < mg) | (C.ws_max[2] - z < mg);
-            }
-        }
+        // four links at a time through the scene's minimum distance (the ranking of the cost kernels: one rsq per link), exact
+        // object-by-object re-evaluation only for a lane whose distance lies within 1e-5 of its margin
+        int l = 0;
+        for (; l + 4 <= C.n_obj_links; l += 4) hit |= collision_links<4>(C, fields, l, margin_override, use_default, pt);
+        if (l + 2 <= C.n_obj_links) { hit |= collision_links<2>(C, fields, l, margin_override, use_default, pt); l += 2; }
+        if (l < C.n_obj_links) hit |= collision_links<1>(C, fields, l, margin_override, use_default, pt);
     }
     if (fields & TRK_FIELD_SELF) {
         for (int pi = 0; pi < C.n_self_pairs; ++pi) {
