@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TRK_ABI_VERSION 1
+#define TRK_ABI_VERSION 2
 #define TRK_MAX_LINKS 64
 #define TRK_MAX_DOFS 32
 #define TRK_MAX_POSE_SLOTS 8
@@ -312,6 +312,10 @@ typedef struct TrkCostModelDesc {
      * "EE on both arms"; the reference would sum two EESE3DistanceFields).  -1 = none. */
     int32_t ee2_link;
     float ee2_target[16];
+    /* clamp_sdf=True of the fields (distance_fields.py:114-117): TRK_FIELD_* mask of the fields whose per-link (per-pair)
+     * terms are relu(margin - signed distance) instead of margin - signed distance -- the hinge form planners optimise */
+    int32_t clamp_fields;
+    int32_t _pad_clamp;
 } TrkCostModelDesc;
 
 typedef struct TrkCostModel TrkCostModel;

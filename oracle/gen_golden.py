@@ -648,6 +648,53 @@ def sphere_config_data():
     print("panda_sphere_config:", n, "spheres")
 
 
+def clamp_goldens():
+    """clamp_sdf=True (distance_fields.py:114-117: relu(margin - sdf) before the max over objects and the sum over links) on the
+    three fields a PlanningTask builds, for two scenes; same q as cost_<env>.npz, whose scene arrays the tests reuse."""
+    from torch_robotics.robots.robot_panda import RobotPanda
+    from torch_robotics.tasks.tasks import PlanningTask
+    from torch_robotics.environments.env_spheres_3d import EnvSpheres3D
+    from torch_robotics.environments.env_table_shelf import EnvTableShelf
+    robot = quiet(RobotPanda, tensor_args=TA)
+    gen = torch.Generator().manual_seed(2024)
+    q0 = sample_q(robot.diff_panda, 64, gen, 0.1).reshape(8, 8, 7)
+    out = dict(q=q0.numpy())
+    tight_ws = torch.tensor([[-0.35, -0.35, 0.0], [0.35, 0.35, 0.75]], **TA)
+    out["tight_ws"] = tight_ws.numpy()
+    for name, make_env, cutoff, ws, self_margin in (
+            ("spheres3d", lambda: EnvSpheres3D(tensor_args=TA), 0.03, None, None),
+            ("table_shelf", lambda: EnvTableShelf(tensor_args=TA), 0.01, None, None),
+            # a workspace the arm leaves and a self-collision margin it violates, so that all three hinges are active
+            ("spheres3d_tight", lambda: EnvSpheres3D(tensor_args=TA), 0.03, tight_ws, 0.3)):
+        task = PlanningTask(env=make_env(), robot=robot, obstacle_cutoff_margin=cutoff, tensor_args=TA,
+                            **({} if ws is None else {"ws_limits": ws}))
+        fields = dict(self=task.df_collision_self, objects=task.df_collision_objects, ws=task.df_collision_ws_boundaries)
+        old_self_margin = task.df_collision_self.cutoff_margin
+        if self_margin is not None:
+            task.df_collision_self.cutoff_margin = torch.full_like(old_self_margin, self_margin)
+            out["tight_self_margin"] = task.df_collision_self.cutoff_margin.numpy()
+        for fld in fields.values():
+            fld.clamp_sdf = True
+        try:
+            for fname, fld in fields.items():
+                q = q0.clone().requires_grad_(True)
+                pos = robot.fk_map_collision(q)
+                pos_leaf = pos.detach().clone().requires_grad_(True)
+                c = fld.compute_cost(q, pos_leaf, field_type="sdf")
+                (gpos,) = torch.autograd.grad(c.sum(), pos_leaf)
+                (gq,) = torch.autograd.grad(fld.compute_cost(q, pos, field_type="sdf").sum(), q)
+                out[f"{name}_cost_{fname}"], out[f"{name}_gpos_{fname}"], out[f"{name}_gq_{fname}"] = c.detach().numpy(), gpos.numpy(), gq.numpy()
+            q = q0.clone().requires_grad_(True)
+            total = task.compute_collision_cost(q)
+            (gq,) = torch.autograd.grad(total.sum(), q)
+            out[f"{name}_cost_total"], out[f"{name}_gq_total"] = total.detach().numpy(), gq.numpy()
+        finally:
+            for fld in fields.values():
+                fld.clamp_sdf = False          # robot.df_collision_self is shared
+            task.df_collision_self.cutoff_margin = old_self_margin
+    np.savez_compressed(GOLD / "cost_clamp.npz", **out)
+
+
 def frame_goldens():
     """geometrics/frame.py:55-121 -- Frame.inverse / multiply_transform / multiply_inv_transform / transform_point /
     get_quaternion (trace method, xyzw) / get_euler on random poses, incl. the diagonal rotations that take every branch of
@@ -723,6 +770,9 @@ def main():
     if sys.argv[1:] == ["metrics"]:
         metrics_goldens()
         return
+    if sys.argv[1:] == ["clamp"]:
+        clamp_goldens()
+        return
     if sys.argv[1:] == ["frames"]:
         frame_goldens()
         return
@@ -760,6 +810,7 @@ def main():
     metrics_goldens()
     pointmass_goldens()
     frame_goldens()
+    clamp_goldens()
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
 

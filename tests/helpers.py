@@ -102,3 +102,17 @@ def grasp_panda_setup():
     spec.self_margin = g["self_margins"]
     spec.validate()
     return m, point_link, point_offset, spec
+
+
+def clamp_cost_spec(name, ee_target=None):
+    """(CostModelSpec, golden prefix) of a clamp_sdf=True case of tests/golden/cost_clamp.npz: the scene of cost_<env>.npz with all
+    three fields clamped; 'spheres3d_tight' also shrinks the workspace and raises the self-collision margin."""
+    gc = gold("cost_clamp")
+    env = "spheres3d" if name == "spheres3d_tight" else name
+    spec = panda_cost_spec(gold(f"cost_{env}"), gold("panda_robot"), ee_target=ee_target)
+    spec.clamp_fields = _abi.FIELD_SELF | _abi.FIELD_OBJECTS | _abi.FIELD_WS
+    if name == "spheres3d_tight":
+        spec.ws_min, spec.ws_max = gc["tight_ws"][0].astype(np.float32), gc["tight_ws"][1].astype(np.float32)
+        spec.self_margin = gc["tight_self_margin"].astype(np.float32)
+    spec.validate()
+    return spec

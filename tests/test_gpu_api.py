@@ -240,6 +240,10 @@ def test_examples_run_like_the_reference_examples():
     assert q_ik.shape == (16, 7) and idx_valid.nelement() >= 12        # the reference converges for (nearly) all samples too
     assert float(err[idx_valid].max()) < 5e-2                           # se3_eps of the call
     np.testing.assert_allclose(H_target[0, :3, 3].cpu().numpy(), [0.2, 0.4, 0.1], atol=1e-7)
+    # a batch trajectory optimiser on the fused kernels (hinge collision costs + GP prior), validated like the reference does
+    q_opt, n_free, coll0 = load("plan_trajectories").main(batch=64, horizon=64, iters=300, device="cuda:0", verbose=False)
+    assert q_opt.shape == (64, 64, 7) and torch.isfinite(q_opt).all()
+    assert coll0 > 0.5 and n_free >= 40                                # most straight lines collide; most optimised ones do not
 
 
 def test_moved_scene_object_is_seen_by_every_cached_cost_model():
@@ -270,6 +274,31 @@ def test_moved_scene_object_is_seen_by_every_cached_cost_model():
     assert rel_err(r1.cpu().numpy(), f1.cpu().numpy()) < TOL_C
     extra.set_position_orientation(pos=(0.0, 0.0, 0.0))                   # and back
     np.testing.assert_array_equal(task.compute_collision_cost(q).cpu().numpy(), c0.cpu().numpy())
+
+
+def test_clamp_sdf_fields_and_task():
+    """`clamp_sdf=True` on the fields (distance_fields.py:114-117) and on a PlanningTask: hinge costs like the reference's."""
+    g, rg = gold("cost_clamp"), gold("panda_robot")
+    robot = tra.RobotPanda(tensor_args=TA)
+    env = tra.EnvSpheres3D(tensor_args=TA)
+    task = tra.PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=0.03, clamp_sdf=True, tensor_args=TA)
+    q0 = dev(g["q"])
+    for fname, fld in (("objects", task.df_collision_objects), ("ws", task.df_collision_ws_boundaries)):
+        assert fld.clamp_sdf
+        q = q0.clone().requires_grad_(True)
+        cost = fld.compute_cost(q, robot.fk_map_collision(q), field_type="sdf")
+        assert rel_err(cost.detach().cpu().numpy(), g[f"spheres3d_cost_{fname}"]) < TOL_C and (cost >= 0).all()
+        cost.sum().backward()
+        ref = g[f"spheres3d_gq_{fname}"]
+        assert np.abs(q.grad.cpu().numpy() - ref).max() < TOL_G * max(1.0, np.abs(ref).max())
+    q = q0.clone().requires_grad_(True)
+    total = task.compute_collision_cost(q)
+    assert rel_err(total.detach().cpu().numpy(), g["spheres3d_cost_total"]) < TOL_C
+    total.sum().backward()
+    assert rel_err(q.grad.cpu().numpy(), g["spheres3d_gq_total"]) < TOL_G
+    # the unclamped task on the same inputs is a different (unbounded below) objective
+    plain = tra.PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA).compute_collision_cost(q0)
+    assert (plain < 0).any() and (total >= 0).all()
 
 
 def test_rollout_rejects_q_of_another_width():

@@ -232,6 +232,50 @@ def test_fused_collision_vs_golden_and_two_step(ops, oracle_lib, env):
         ops.rollout_collision(h, cm, allf, torch.zeros(4, 14, device=DEV))
 
 
+@pytest.mark.parametrize("name", ["spheres3d", "table_shelf", "spheres3d_tight"])
+def test_clamp_sdf_vs_golden_and_oracle(ops, oracle_lib, name):
+    """clamp_sdf=True -- relu(margin - sdf) per link / pair (distance_fields.py:114-117): the field kernel, the generated and the
+    table-driven fused kernels against the reference's clamped fields (goldens) and the fp64 oracle on ragged random inputs."""
+    from helpers import clamp_cost_spec
+    g, robot = gold("cost_clamp"), gold("panda_robot")
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5)
+    spec = clamp_cost_spec(name, ee_target=Ht)
+    m = model("panda_arm_no_gripper")
+    h, cm, o = ops.ModelHandle(m), ops.CostHandle(spec, DEV), oracle_lib.Oracle(m, spec)
+    pos_g = dev(robot["fk_map_collision"].reshape(-1, 11, 3))
+    qg = dev(g["q"].reshape(-1, 7))
+    for fname, fl, w in (("self", FIELD_SELF, (1, 0, 0, 0)), ("objects", FIELD_OBJECTS, (0, 1, 0, 0)), ("ws", FIELD_WS, (0, 0, 1, 0))):
+        c, gp = ops.cost_fields(cm, fl, pos_g, want_grad=True)
+        ref_c, ref_g = g[f"{name}_cost_{fname}"].reshape(-1), g[f"{name}_gpos_{fname}"].reshape(-1, 11, 3)
+        assert np.abs(c.cpu().numpy() - ref_c).max() < 1e-5 * max(1.0, np.abs(ref_c).max()), fname
+        assert np.abs(gp.cpu().numpy() - ref_g).max() < 1e-4 * max(1.0, np.abs(ref_g).max()), fname
+        for spec_on in (True, False):
+            h.enable_specialized(spec_on)
+            _, c2, gq = ops.rollout_cost_grad(h, cm, w, qg)
+            ref_q = g[f"{name}_gq_{fname}"].reshape(-1, 7)
+            assert np.abs(c2.cpu().numpy() - ref_c).max() < 1e-5 * max(1.0, np.abs(ref_c).max()), (fname, spec_on)
+            assert np.abs(gq.cpu().numpy() - ref_q).max() < 1e-4 * max(1.0, np.abs(ref_q).max()), (fname, spec_on)
+    h.enable_specialized(True)
+    _, c, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 0), qg)
+    assert rel_err(c.cpu().numpy(), g[f"{name}_cost_total"].reshape(-1)) < TOL_C
+    assert rel_err(gq.cpu().numpy(), g[f"{name}_gq_total"].reshape(-1, 7)) < TOL_G
+    assert (c >= 0).all()
+    rng = np.random.default_rng(21)
+    for n in (37, 64, 1000):
+        q = rng.uniform(-3.0, 3.9, (n, 7)).astype(np.float32)
+        for w in ((1, 1, 1, 1), (0.5, 2.0, 0.25, 0.0)):
+            p64, c64, g64 = o.rollout(q.astype(np.float64), w, "f64")
+            for spec_on in (True, False):
+                h.enable_specialized(spec_on)
+                pos, c, gq = ops.rollout_cost_grad(h, cm, w, dev(q))
+                assert np.abs(pos.cpu().numpy() - p64).max() < TOL_H
+                assert rel_err(c.cpu().numpy(), c64) < TOL_C, (n, w, spec_on)
+                # a hinge switching on exactly at the fp32 / fp64 rounding boundary flips a whole gradient term: allow a few samples
+                bad = (np.abs(gq.cpu().numpy() - g64).max(1) > TOL_G * max(1.0, np.abs(g64).max())).sum()
+                assert bad <= max(1, n // 300), (n, w, spec_on, bad)
+    h.enable_specialized(True)
+
+
 def test_grid_precompute_and_sdf_points(ops, oracle_lib):
     robot, g, ga = gold("panda_robot"), gold("cost_spheres3d_grid"), gold("cost_spheres3d")
     cm = ops.CostHandle(panda_cost_spec(ga, robot), DEV)

@@ -360,3 +360,27 @@ def test_frame_algebra_vs_reference(prec):
     assert np.abs(O.rotation_from(3, g["quat_in"], prec) - g["quat_R"]).max() <= tol
     quat, eul = O.frame_quat_euler(g["Ra"], prec=prec)
     assert np.abs(quat - g["quat_xyzw"]).max() < 2e-7 and np.abs(eul - g["euler"]).max() < 2e-7
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("name", ["spheres3d", "table_shelf", "spheres3d_tight"])
+def test_clamp_sdf_costs(oracle_lib, name, prec):
+    """clamp_sdf=True (distance_fields.py:114-117): relu(margin - sdf) per link / pair for all three fields -- per-field costs,
+    position gradients, gradients w.r.t. q and the PlanningTask total against the reference's own fields."""
+    from helpers import clamp_cost_spec
+    g, robot = gold("cost_clamp"), gold("panda_robot")
+    o = oracle_lib.Oracle(model("panda_arm_no_gripper"), clamp_cost_spec(name))
+    pos = robot["fk_map_collision"].reshape(-1, 11, 3)
+    for fname, fl, w in (("self", FIELD_SELF, (1, 0, 0, 0)), ("objects", FIELD_OBJECTS, (0, 1, 0, 0)), ("ws", FIELD_WS, (0, 0, 1, 0))):
+        c, gp = o.cost_fields(fl, pos, prec)
+        ref_c, ref_g = g[f"{name}_cost_{fname}"].reshape(-1), g[f"{name}_gpos_{fname}"].reshape(-1, 11, 3)
+        assert np.abs(c - ref_c).max() < 1e-5 * max(1.0, np.abs(ref_c).max()), fname
+        assert np.abs(gp - ref_g).max() < 1e-4 * max(1.0, np.abs(ref_g).max()), fname
+        assert ((c == 0) == (ref_c == 0)).mean() > 0.98                  # the hinge is off for the same samples
+        _, _, gq = o.rollout(g["q"].reshape(-1, 7), w, prec)
+        ref_q = g[f"{name}_gq_{fname}"].reshape(-1, 7)
+        assert np.abs(gq - ref_q).max() < 1e-4 * max(1.0, np.abs(ref_q).max()), fname
+    _, c, gq = o.rollout(g["q"].reshape(-1, 7), (1, 1, 1, 0), prec)
+    assert rel_err(c, g[f"{name}_cost_total"].reshape(-1)) < TOL_C
+    assert rel_err(gq, g[f"{name}_gq_total"].reshape(-1, 7)) < TOL_G
+    assert (g[f"{name}_cost_total"] >= 0).all() and (g[f"{name}_cost_total"] > 0).any()

@@ -519,7 +519,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 pa = ", ".join(E.expr(t[a][k]) for k in range(3))
                 pb = ", ".join(E.expr(t[b][k]) for k in range(3))
                 E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], {pa}, {pb}, "
-                      f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2);")
+                      f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2, (A.C.clamp_fields & TRK_FIELD_SELF) != 0);")
             E.raw("    }")
         E.raw("    spec_stamp(A.stamps, wblock, 4, lane);")
         for ee, tgt, rb in tracked:
@@ -862,7 +862,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                     E.raw("        gl0 = gl1 = gl2 = 0.0f;")
                     E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], "
                           f"{', '.join(E.expr(colpos[pa][k]) for k in range(3))}, {', '.join(E.expr(colpos[pb][k]) for k in range(3))}, "
-                          f"{ga}, {gb});")
+                          f"{ga}, {gb}, (A.C.clamp_fields & TRK_FIELD_SELF) != 0);")
                     in_order(colpos[late], ["gl0", "gl1", "gl2"])
                 for e in earlies:
                     g = [f"ge{e}_0", f"ge{e}_1", f"ge{e}_2"]

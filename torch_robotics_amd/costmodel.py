@@ -70,6 +70,9 @@ class CostModelSpec:
     ee_target: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
     ee2_link: int = -1                   # a second tracked link (two-arm scenes), same weights / square flag
     ee2_target: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
+    # FIELD_* mask: fields evaluated with clamp_sdf=True, i.e. relu(margin - signed distance) per link / pair
+    # (distance_fields.py:114-117) -- the hinge form a planner optimises
+    clamp_fields: int = 0
 
     def validate(self) -> None:
         L = self.n_links_in

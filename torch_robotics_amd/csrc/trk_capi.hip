@@ -793,6 +793,7 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     h.n_spheres = (int32_t)n_real_spheres;
     h.sphere_pairs = reinterpret_cast<const float*>(base + o_pair);
     h.n_sphere_pairs = n_sphere_pairs;
+    h.clamp_fields = d->clamp_fields & 7;
     h.spheres_uniform_r = uniform_r ? 1 : 0;
     h.sphere_r = spheres.empty() ? 0.0f : spheres[0].w;
     if (n_grid) {

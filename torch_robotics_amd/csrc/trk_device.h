@@ -98,7 +98,7 @@ struct DevCostHdr {
     // table is padded with a copy of its last sphere (spheres[] / spheres_sel[] hold the copy too, n_spheres does not count it).
     const float* sphere_pairs;     // device
     int32_t n_sphere_pairs;
-    int32_t _pad_pairs;
+    int32_t clamp_fields;          // TRK_FIELD_* mask: relu(margin - sdf) per link / pair (clamp_sdf=True, distance_fields.py:114-117)
 };
 
 // Points rigidly attached to links (grasped-object points robot_panda.py:154-168, per-link collision spheres):
@@ -576,6 +576,7 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
 // adds scale * d/dp to (ax, ay, az)
 __device__ __forceinline__ float ws_cost_point(const DevCostHdr& C, float mg, float x, float y, float z, float scale,
                                                float& ax, float& ay, float& az) {
+    const bool clamp = (C.clamp_fields & TRK_FIELD_WS) != 0;         // wave-uniform
     // the six signed plane distances are {p_k - min_k, max_k - p_k}; per axis the smaller one is h_k - |p_k - c_k|,
     // so max_planes (margin - sd) = margin - min_k (h_k - |d_k|) and the gradient is sign(d_a) on the arg-min axis
     // (20 instructions instead of 35; differs from the plane form by fp32 rounding of c and h, ~1e-7)
@@ -583,10 +584,12 @@ __device__ __forceinline__ float ws_cost_point(const DevCostHdr& C, float mg, fl
     const float mx = C.ws_h[0] - __builtin_fabsf(dx), my = C.ws_h[1] - __builtin_fabsf(dy), mz = C.ws_h[2] - __builtin_fabsf(dz);
     const float m = __builtin_fminf(__builtin_fminf(mx, my), mz);
     const bool e0 = mx == m, e1 = (my == m) && !e0, e2 = !(e0 || e1);          // first arg-min axis wins
+    const float v = mg - m;
+    if (clamp) scale = v > 0.0f ? scale : 0.0f;                      // relu: no gradient at or below zero
     ax += e0 ? __builtin_copysignf(scale, dx) : 0.0f;
     ay += e1 ? __builtin_copysignf(scale, dy) : 0.0f;
     az += e2 ? __builtin_copysignf(scale, dz) : 0.0f;
-    return mg - m;
+    return clamp ? __builtin_fmaxf(v, 0.0f) : v;
 }
 
 // EE SE(3) tracking, distance_fields.py:347-356 + geometrics/utils.py:148-154.

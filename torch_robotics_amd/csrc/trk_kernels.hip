@@ -547,8 +547,11 @@ __device__ __forceinline__ float fields_links(const DevCostHdr& C, int fields, f
         scene_min_sdf<NB>(C, x, y, z, s, gx, gy, gz);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            cost = fmaf(w_obj, mg[k] - s[k], cost);
-            ax[k] -= w_obj * gx[k]; ay[k] -= w_obj * gy[k]; az[k] -= w_obj * gz[k];
+            const float v = mg[k] - s[k];
+            const bool off = (C.clamp_fields & TRK_FIELD_OBJECTS) && !(v > 0.0f);       // clamp_sdf: relu(margin - sdf)
+            const float wk = off ? 0.0f : w_obj;
+            cost = fmaf(wk, v, cost);
+            ax[k] -= wk * gx[k]; ay[k] -= wk * gy[k]; az[k] -= wk * gz[k];
         }
     }
     if ((fields & TRK_FIELD_WS) && C.has_ws) {
@@ -620,8 +623,9 @@ __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, fl
                         const bool take = (o == 0) || (v > best);       // max over objects, first maximum wins
                         best = take ? v : best; bx = take ? gx : bx; by = take ? gy : by; bz = take ? gz : bz;
                     }
-                    cost = fmaf(w_obj, best, cost);
-                    ax -= w_obj * bx; ay -= w_obj * by; az -= w_obj * bz;
+                    const float wk = ((C.clamp_fields & TRK_FIELD_OBJECTS) && !(best > 0.0f)) ? 0.0f : w_obj;   // clamp_sdf
+                    cost = fmaf(wk, best, cost);
+                    ax -= wk * bx; ay -= wk * by; az -= wk * bz;
                 }
                 if ((fields & TRK_FIELD_WS) && C.has_ws) cost = fmaf(w_ws, ws_cost_point(C, mg, x, y, z, w_ws, ax, ay, az), cost);
                 if (gt) { gt[3 * li] += ax; gt[3 * li + 1] += ay; gt[3 * li + 2] += az; }
@@ -639,9 +643,11 @@ __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, fl
             const float dx = pt[3 * a] - pt[3 * b], dy = pt[3 * a + 1] - pt[3 * b + 1], dz = pt[3 * a + 2] - pt[3 * b + 2];
             const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
             const float nrm = PRECISE ? sqrtf(n2) : trk_sqrt(n2);
-            cost = fmaf(w_self, cptr(C.self_margin)[pi] - nrm, cost);
+            const float vs = cptr(C.self_margin)[pi] - nrm;
+            const float wsf = ((C.clamp_fields & TRK_FIELD_SELF) && !(vs > 0.0f)) ? 0.0f : w_self;          // clamp_sdf
+            cost = fmaf(wsf, vs, cost);
             if (gt) {
-                const float inv = nrm > 0.0f ? w_self * (PRECISE ? 1.0f / nrm : trk_rcp(nrm)) : 0.0f;
+                const float inv = nrm > 0.0f ? wsf * (PRECISE ? 1.0f / nrm : trk_rcp(nrm)) : 0.0f;
                 const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
                 gt[3 * a] -= ux; gt[3 * a + 1] -= uy; gt[3 * a + 2] -= uz;
                 gt[3 * b] += ux; gt[3 * b + 1] += uy; gt[3 * b + 2] += uz;

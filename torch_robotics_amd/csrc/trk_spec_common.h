@@ -42,7 +42,7 @@ typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 4)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 5)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -383,6 +383,16 @@ __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w,
     float s[NL], ax[NL], ay[NL], az[NL];
     scene_min_sdf<NL, const Tick&, FAST>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres);
     float cost = 0.0f;
+    if (C.clamp_fields & TRK_FIELD_OBJECTS) {                                  // wave-uniform: the hinge form (clamp_sdf=True)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const float v = cptr(C.obj_link_margin)[mbase + l] - s[l];
+            const float wl = v > 0.0f ? w : 0.0f;                              // relu: value and gradient vanish at or below zero
+            cost += __builtin_fmaxf(v, 0.0f);
+            gx[l] = fmaf(-wl, ax[l], gx[l]); gy[l] = fmaf(-wl, ay[l], gy[l]); gz[l] = fmaf(-wl, az[l], gz[l]);
+        }
+        return w * cost;
+    }
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         cost += cptr(C.obj_link_margin)[mbase + l] - s[l];                     // sum_l max_o (margin - sdf_o) = sum_l (margin - min_o sdf_o)
@@ -450,11 +460,12 @@ __device__ __forceinline__ float spec_ws_cost(const DevCostHdr& C, float w, cons
 // one self-collision pair (distance_fields.py:194-208): returns w*(margin - ||pa - pb||), accumulates gradients
 __device__ __forceinline__ float spec_self_pair(float w, float margin, float ax, float ay, float az, float bx, float by,
                                                 float bz, float& gax, float& gay, float& gaz, float& gbx, float& gby,
-                                                float& gbz) {
+                                                float& gbz, bool clamp = false) {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
     const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
     const float rs = n2 > 0.0f ? trk_rsq(n2) : 0.0f;              // one transcendental: 1/||d|| (0 at d = 0, like torch.norm's backward)
     const float nrm = n2 * rs;
+    if (clamp) w = margin - nrm > 0.0f ? w : 0.0f;                // relu(margin - d): value and gradient vanish at or below zero
     const float inv = w * rs;
     const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
     gax -= ux; gay -= uy; gaz -= uz;

@@ -58,8 +58,9 @@ class EmbodimentDistanceFieldBase(DistanceField):
                  interpolate_link_pos=False, **kwargs):
         super().__init__(**kwargs)
         assert robot is not None, "You need to pass a robot instance to the embodiment distance fields"
-        if clamp_sdf or interpolate_link_pos:
-            raise NotImplementedError("clamp_sdf / interpolate_link_pos are never enabled by the reference's callers")
+        if interpolate_link_pos:
+            raise NotImplementedError("interpolate_link_pos double-indexes the links in the reference (never enabled by its callers)")
+        self.clamp_sdf = bool(clamp_sdf)        # relu(margin - sdf) per link / pair (distance_fields.py:114-117)
         self.robot = robot
         self.link_idxs_for_collision_checking = link_idxs_for_collision_checking
         self.num_interpolated_points = num_interpolated_points
@@ -76,10 +77,11 @@ class EmbodimentDistanceFieldBase(DistanceField):
         return 0
 
     def _handle(self, n_links_in: int, device) -> ops.CostHandle:
-        key = (n_links_in, str(device), self._scene_version())
+        key = (n_links_in, str(device), self._scene_version(), bool(self.clamp_sdf))
         if key not in self._handles:
             spec = CostModelSpec(n_links_in=n_links_in)
             self._fill_spec(spec)
+            spec.clamp_fields = self._field if self.clamp_sdf else 0
             self._handles = {key: ops.CostHandle(spec, device)}
         return self._handles[key]
 

@@ -23,7 +23,7 @@ class Task:
 
 class PlanningTask(Task):
     def __init__(self, ws_limits=None, use_occupancy_map=False, cell_size=0.01, obstacle_cutoff_margin=0.01,
-                 auto_specialize=True, **kwargs):
+                 auto_specialize=True, clamp_sdf=False, **kwargs):
         super().__init__(**kwargs)
         # the first fused evaluation compiles + loads a generated kernel for this robot / collision model when none is
         # registered yet (~2 s with hipcc, cached on disk); TRK_NO_JIT=1 or auto_specialize=False keeps the table-driven path
@@ -37,7 +37,10 @@ class PlanningTask(Task):
         self.obstacle_cutoff_margin = obstacle_cutoff_margin
         r = self.robot
         self.df_collision_self = r.df_collision_self
-        common = dict(link_idxs_for_collision_checking=r.link_idxs_for_object_collision_checking,
+        # clamp_sdf (not a keyword of the reference's PlanningTask, which builds its fields with the default False): the three
+        # fields become hinges relu(margin - sdf), the form an optimiser needs -- the plain cost decreases without bound
+        self.clamp_sdf = bool(clamp_sdf)
+        common = dict(link_idxs_for_collision_checking=r.link_idxs_for_object_collision_checking, clamp_sdf=self.clamp_sdf,
                       num_interpolated_points=r.num_interpolated_points_for_object_collision_checking,
                       link_margins_for_object_collision_checking_tensor=r.link_margins_for_object_collision_checking_tensor,
                       cutoff_margin=obstacle_cutoff_margin, tensor_args=self.tensor_args)
@@ -130,6 +133,10 @@ class PlanningTask(Task):
         spec.ws_min, spec.ws_max = _np(self.ws_min).astype(np.float32), _np(self.ws_max).astype(np.float32)
         if self.df_collision_self is not None:
             self.df_collision_self._fill_spec(spec)
+        for fld, bit in ((self.df_collision_self, FIELD_SELF), (self.df_collision_objects, FIELD_OBJECTS),
+                         (self.df_collision_ws_boundaries, FIELD_WS)):
+            if fld is not None and (self.clamp_sdf or getattr(fld, "clamp_sdf", False)):
+                spec.clamp_fields |= bit
         if self._ee["target"] is not None:
             spec.ee_link, spec.ee_target = self._ee["link"], self._ee["target"]
             spec.ee_w_pos, spec.ee_w_rot, spec.ee_square = self._ee["w_pos"], self._ee["w_rot"], self._ee["square"]
