@@ -231,6 +231,10 @@ def test_dual_panda_fp16_gp_full_size(ops, oracle_lib):
     c_gp, _, _ = ops.gp_prior_cost_grad(qh, qdh, 5.0 / H, 0.1, 1.0, accumulate_into=(acc, gqd))
     c_gp2, g_gp, _ = ops.gp_prior_cost_grad(qh, qdh, 5.0 / H, 0.1, 1.0)
     assert torch.equal(c_gp, c_gp2) and c_gp.shape == (B,)
+    acc2, gqd2 = gq.clone(), torch.zeros_like(gq)                       # the pre-bound launch gives the same bits
+    gp_plan = ops.GPPriorPlan(qh, qdh, 5.0 / H, 0.1, 1.0, accumulate_into=(acc2, gqd2))
+    gp_plan.launch()
+    assert torch.equal(gp_plan.cost, c_gp) and torch.equal(acc2, acc) and torch.equal(gqd2, gqd)
     ok = torch.isfinite(g_gp.float()) & torch.isfinite(acc.float())
     ref = gq.float() + g_gp.float()
     assert ((acc.float() - ref)[ok].abs() <= 2.0 ** -9 * ref[ok].abs() + 1e-3).all()

@@ -76,8 +76,11 @@ gqd = torch.zeros_like(qh)
 dt, sigma = 5.0 / H, 0.1
 
 
+gp_plan = ops.GPPriorPlan(qh, qdh, dt, sigma, 1.0, accumulate_into=(plan.gq, gqd))      # pre-bound, like the rollout
+
+
 def gp():
-    ops.gp_prior_cost_grad(qh, qdh, dt, sigma, 1.0, accumulate_into=(plan.gq, gqd))
+    gp_plan.launch()
 
 
 def both():

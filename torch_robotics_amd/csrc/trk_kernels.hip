@@ -1438,7 +1438,13 @@ k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, i
 template <class T> struct GpVec;          // 4 consecutive elements <-> float4
 template <> struct GpVec<float> {
     static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
-    static __device__ __forceinline__ void store(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+    // write-through like the fused kernel's outputs: plain stores leave the gradients dirty in the L2s and their write-back at
+    // the kernel boundary stalls the next launch (measured on the rollout kernel: 12.97 -> 10.87 us)
+    static __device__ __forceinline__ void store(float* p, const float4& v) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 x = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+    }
 };
 template <> struct GpVec<_Float16> {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -1448,7 +1454,7 @@ template <> struct GpVec<_Float16> {
     }
     static __device__ __forceinline__ void store(_Float16* p, const float4& v) {
         const h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        *reinterpret_cast<h4*>(p) = h;
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(h) : "memory");
     }
 };
 
