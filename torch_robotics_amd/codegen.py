@@ -241,8 +241,10 @@ def _emit_angles(E: "Emitter", kin: KinModel) -> None:
         E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
 
 
-def _emit_fk_link(E: "Emitter", kin: KinModel, i: int, R, t, passv, snap: float) -> None:
-    """world pose of link i from its parent's (rigid_body.py:162-182), URDF constants folded symbolically"""
+def _emit_fk_link(E: "Emitter", kin: KinModel, i: int, R, t, passv, snap: float, stateful: bool = False) -> None:
+    """world pose of link i from its parent's (rigid_body.py:162-182), URDF constants folded symbolically.
+    stateful: the stateful path's joint transform (rigid_body.py:213-251): rotation about `sf_rot_axis` with the axis SIGN
+    IGNORED, whatever the stateless rule says (a missing axis still rotates about z)."""
     par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
     E.raw(f"    // link {i} '{kin.link_names[i]}' (parent {par})")
     Rf = [[S(snap_const(kin.R_fixed[i][r][c], snap)) for c in range(3)] for r in range(3)]
@@ -257,10 +259,10 @@ def _emit_fk_link(E: "Emitter", kin: KinModel, i: int, R, t, passv, snap: float)
     t[i] = [E.lincomb([(Rp[r][k], tl[k]) for k in range(3)], tp[r]) for r in range(3)]
     A = [[E.lincomb([(Rp[r][k], Rf[k][c]) for k in range(3)]) for c in range(3)] for r in range(3)]
     if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS):
-        sg = float(kin.rot_sign[i])
+        sg = 1.0 if stateful else float(kin.rot_sign[i])
         if sg != 0.0:
             s, c = S(sg, f"sn{d}"), S(1.0, f"cs{d}")       # sin(sign*q) = sign*sin(q), cos even
-            ax = int(kin.rot_axis[i])
+            ax = int(kin.sf_rot_axis[i]) if stateful else int(kin.rot_axis[i])
             ci, cj = [(1, 2), (2, 0), (0, 1)][ax]
             newA = [row[:] for row in A]
             for r in range(3):
@@ -342,6 +344,7 @@ def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, L
     return gq_expr
 
 
+TRK_WAVE_ = 64
 # tick slots handed to one scene evaluation (csrc/trk_device.h: TRK_OBJ_TICK_SLOTS must agree)
 OBJ_TICK_SLOTS = int(os.environ.get("TRK_EXP_OBJ_SLOTS", "5"))
 
@@ -596,6 +599,87 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.extend(E.lines)
         out.append("")
 
+    # ---- stateful FK + geometric Jacobian of ONE link (trk_fk_jacobian; robot_tree.py:136-190, 218-248): the walk unrolled
+    # with the stateful path's quirks (clamp wherever limits exist, rotation about the axis with its sign ignored); every
+    # joint that can receive a column leaves a record (z, p) in LDS, the target link (a run-time argument) is picked by a
+    # wave-uniform switch, and the read-out is the table-driven kernel's (trk_jac_readout).  One wavefront per workgroup.
+    jac_joints = [i for i in range(1, L) if int(kin.dof_idx[i]) >= 0 and int(kin.jac_axis[i]) >= 0]
+    NJ = len(jac_joints)
+    RS = (6 * NJ + 3) | 1
+    JAC_LDS = max(RS, D)
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_jac_bi" if base_identity else "k_jac_bg"
+        E.raw(f"__global__ void __launch_bounds__(TRK_WAVE) {kname}(SpecArgs A) {{")
+        E.raw("    extern __shared__ __attribute__((aligned(16))) float lds[];     // 64 x max(record stride, D) floats + the slot table")
+        E.raw("    const int rstride = (6 * A.jac_n_cols + 3) | 1;       // records only for the joints that get a column")
+        E.raw("    const int lane = threadIdx.x;")
+        E.raw("    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        rot_dofs = []
+        for i in range(1, L):
+            jt, d = int(kin.joint_type[i]), int(kin.dof_idx[i])
+            if jt == JOINT_FIXED:
+                continue
+            if kin.sf_clamp[i]:                  # rigid_body.py:218-224: clamp whenever limits exist, continuous joints too
+                E.raw(f"    const float qh{d} = __builtin_amdgcn_fmed3f(q[{d}], {flit(kin.lower[i])}, {flit(kin.upper[i])});")
+            else:
+                E.raw(f"    const float qh{d} = q[{d}];")
+            if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS):
+                rot_dofs.append(d)
+        for d in rot_dofs:
+            E.raw(f"    float sn{d}, cs{d};")
+        for a, b in zip(rot_dofs[0::2], rot_dofs[1::2]):
+            E.raw(f"    trk_sincos2(qh{a}, qh{b}, &sn{a}, &cs{a}, &sn{b}, &cs{b});")
+        if len(rot_dofs) % 2:
+            d = rot_dofs[-1]
+            E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
+        E.raw("    float* rec = lds + lane * rstride;")
+        E.raw("    spec_wave_sync();                  // the q transpose is done with this LDS")
+        E.raw("    float eR[9] = {1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f}, et[3] = {0.0f, 0.0f, 0.0f};")
+
+        def capture(i):
+            rl = "; ".join(f"eR[{3 * r + c}] = {E.expr(R[i][r][c])}" for r in range(3) for c in range(3))
+            tl = "; ".join(f"et[{r}] = {E.expr(t[i][r])}" for r in range(3))
+            E.raw(f"    if (A.jac_link == {i}) {{ {rl}; {tl}; }}       // wave-uniform")
+        capture(int(kin.order[0]))
+        E.raw("    do {                               // the walk stops after the last pre-order position that matters")
+        for p in range(1, L):
+            i = int(kin.order[p])
+            E.raw(f"    if (A.jac_p_end <= {p}) break;")
+            _emit_fk_link(E, kin, i, R, t, passv, snap, stateful=True)
+            if i in jac_joints:
+                d, ax = int(kin.dof_idx[i]), int(kin.jac_axis[i])
+                vals = [E.expr(R[i][r][ax]) for r in range(3)] + [E.expr(t[i][r]) for r in range(3)]
+                body = " ".join(f"j[{r}] = {v};" for r, v in enumerate(vals))
+                E.raw(f"    if (A.jac_slot[{d}] >= 0) {{ float* j = rec + 6 * A.jac_slot[{d}]; {body} }}      // wave-uniform")
+            capture(i)
+        E.raw("    } while (0);")
+        E.raw("    rec[6 * A.jac_n_cols] = et[0]; rec[6 * A.jac_n_cols + 1] = et[1]; rec[6 * A.jac_n_cols + 2] = et[2];")
+        E.raw(f"    int* slot = reinterpret_cast<int*>(lds + TRK_WAVE * max(rstride, {D}));")
+        for d in range(D):
+            E.raw(f"    if (lane == {d}) slot[{d}] = A.jac_slot[{d}];")
+        E.raw("    spec_wave_sync();")
+        E.raw("    trk_jac_readout(lds, slot, rstride, A.jac_n_cols, D, rows, A.jac_lin + base * 3 * D, A.jac_ang + base * 3 * D, lane);")
+        E.raw("    if (lane >= rows) return;")
+        E.raw("    const int64_t s = base + lane;")
+        E.raw("    A.jac_pos[s * 3] = et[0]; A.jac_pos[s * 3 + 1] = et[1]; A.jac_pos[s * 3 + 2] = et[2];")
+        E.raw("    float qo[4];")
+        E.raw("    frame_quat_wxyz(eR, qo);")
+        E.raw("    *reinterpret_cast<float4*>(A.jac_quat + s * 4) = make_float4(qo[0], qo[1], qo[2], qo[3]);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
     obj = ", ".join(str(i) for i in tmpl.obj_links) or "0"
     pairs = ", ".join(f"{a}, {b}" for a, b in tmpl.self_pairs) or "0"
     out.append(f"static const int32_t kObjLinks[] = {{{obj}}};")
@@ -615,8 +699,17 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("    if (base_identity) hipLaunchKernelGGL(k_posbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_posbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
+    out.append("static void launch_jac(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
+    out.append("    const int rstride = (6 * a.jac_n_cols + 3) | 1;")
+    out.append("    const size_t lds = sizeof(float) * ((size_t)TRK_WAVE * (rstride > D ? rstride : D) + TRK_MAX_DOFS);")
+    out.append("    if (base_identity) hipLaunchKernelGGL(k_jac_bi, dim3(grid), dim3(TRK_WAVE), lds, st, a);")
+    out.append("    else hipLaunchKernelGGL(k_jac_bg, dim3(grid), dim3(TRK_WAVE), lds, st, a);")
+    out.append("}")
+    jac_ok = (TRK_WAVE_ * JAC_LDS + 32) * 4 <= 64 * 1024            # default dynamic-LDS limit of a launch
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
-               f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}}};")
+               f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
+               f"{'launch_jac' if jac_ok else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -1039,7 +1132,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
-               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}}};")
+               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out

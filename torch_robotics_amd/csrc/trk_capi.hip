@@ -502,6 +502,30 @@ int trk_fk_jacobian(const TrkModel* m, const float* q, const float* qd, int64_t 
     if (link < 0 || link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_fk_jacobian: link out of range");
     if (n < 0 || (n > 0 && (!q || !pos || !quat || !lin_jac || !ang_jac))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_jacobian: null argument");
     if (n == 0) return TRK_OK;
+    if (m->spec_enabled && m->spec && m->spec->launch_jac && !vel_lin && !vel_ang) {
+        // generated kernel: the stateful walk unrolled with the URDF constants folded; the link velocities stay table-driven
+        SpecArgs a{};
+        rc = blank_spec_args(a);
+        if (rc) return rc;
+        std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+        std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+        a.q = q; a.n = n; a.jac_link = link; a.jac_joint_idx = m->joint_list_idx[link];
+        // which DOFs get a column and where the walk may stop (same rule as trk_launch_fk_jacobian: robot_tree.py:239-244)
+        a.jac_p_end = 1; a.jac_n_cols = 0;
+        for (int d = 0; d < TRK_MAX_DOFS; ++d) a.jac_slot[d] = -1;
+        for (int p = 0; p < m->hdr.n_links; ++p) {
+            const DevLink& Lk = m->links[p];
+            if (Lk.link == link) a.jac_p_end = std::max(a.jac_p_end, p + 1);
+            if (Lk.dof >= 0 && (Lk.link - 1) <= a.jac_joint_idx && Lk.jac_axis >= 0) {
+                a.jac_slot[Lk.dof] = (int8_t)a.jac_n_cols++;
+                a.jac_p_end = std::max(a.jac_p_end, p + 1);
+            }
+        }
+        a.jac_pos = pos; a.jac_quat = quat; a.jac_lin = lin_jac; a.jac_ang = ang_jac;
+        m->spec->launch_jac(a, base_is_identity(m), (hipStream_t)stream);
+        TRK_HIP(hipGetLastError());
+        return TRK_OK;
+    }
     trk_launch_fk_jacobian(m->hdr, m->d_links, m->links.data(), q, qd, n, link, m->joint_list_idx[link], pos, quat, lin_jac, ang_jac,
                            vel_lin, vel_ang, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());

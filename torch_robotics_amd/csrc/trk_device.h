@@ -572,6 +572,93 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
     }
 }
 
+// Geometric Jacobian read-out (robot_tree.py:230-246): the walk has left, per lane, one record (z, p) per contributing joint and
+// the target link's position in `rec` (lane-major, odd stride `rstride`: conflict-free both ways); `slot[d]` = record of DOF d or
+// -1 (column stays zero).  lin_jac / ang_jac [N,3,D] leave as the wave's contiguous run of 64 * 3D floats: four consecutive
+// elements per lane and one 16-byte write-through store per array.
+__device__ __forceinline__ void trk_jac_readout(float* rec, const int* slot, int rstride, int n_cols, int D, int rows,
+                                                float* lo, float* ao, int lane) {
+    const int w3 = 3 * D;
+    {   // each lane first turns its own records (z, p_joint) into (z, z x (p_link - p_joint)): the transposed read-out below
+        // is then one LDS read per output element instead of five reads and a cross-product component
+        float* mine = rec + lane * rstride;
+        const float e0 = mine[6 * n_cols], e1 = mine[6 * n_cols + 1], e2 = mine[6 * n_cols + 2];
+        for (int c = 0; c < n_cols; ++c) {
+            float* j = mine + 6 * c;
+            const float z0 = j[0], z1 = j[1], z2 = j[2], r0 = e0 - j[3], r1 = e1 - j[4], r2 = e2 - j[5];
+            j[3] = z1 * r2 - z2 * r1; j[4] = z2 * r0 - z0 * r2; j[5] = z0 * r1 - z1 * r0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    auto element = [&](int sl, int rem, float& lv, float& av) {
+        const int r = (rem >= D) + (rem >= 2 * D), d = rem - r * D;
+        const int c = slot[d];
+        lv = 0.0f; av = 0.0f;
+        if (c >= 0) {
+            const float* j = rec + sl * rstride + 6 * c;
+            av = j[r]; lv = j[3 + r];
+        }
+    };
+    if (rows == TRK_WAVE && ((reinterpret_cast<uintptr_t>(lo) | reinterpret_cast<uintptr_t>(ao)) & 15) == 0) {
+        const float inv_w3 = 1.0f / (float)w3;
+        for (int e = lane; e < 16 * w3; e += TRK_WAVE) {              // 64 * 3D floats = 16 * 3D float4 per array
+            const int k0 = 4 * e;
+            int sl = (int)((float)k0 * inv_w3);
+            sl -= (sl * w3 > k0); sl += ((sl + 1) * w3 <= k0);
+            int rem = k0 - sl * w3;
+            float lv[4], av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                element(sl, rem, lv[j], av[j]);
+                if (++rem == w3) { rem = 0; ++sl; }
+            }
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 l4 = {lv[0], lv[1], lv[2], lv[3]}, a4 = {av[0], av[1], av[2], av[3]};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(lo + k0), "v"(l4) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ao + k0), "v"(a4) : "memory");
+        }
+    } else {
+        int sl = lane / w3, rem = lane - sl * w3;
+        const int ds = TRK_WAVE / w3, dr = TRK_WAVE - ds * w3;
+        const int64_t count = (int64_t)rows * w3;
+        for (int64_t k = lane; k < count; k += TRK_WAVE) {
+            float lv, av;
+            element(sl, rem, lv, av);
+            lo[k] = lv; ao[k] = av;
+            sl += ds; rem += dr;
+            if (rem >= w3) { rem -= w3; ++sl; }
+        }
+    }
+}
+
+// Frame.get_quaternion (trace method with M[3][3] = 1, frame.py:87-114), then xyzw -> wxyz (quaternion.py:240-242)
+__device__ __forceinline__ void frame_quat_wxyz(const float* R, float* out) {
+    float t = R[0] + R[4] + R[8] + 1.0f;
+    float qx, qy, qz, qw;
+    if (t > 1.0f) {
+        qw = t; qz = R[3] - R[1]; qy = R[2] - R[6]; qx = R[7] - R[5];
+    } else {
+        // i = arg-max diagonal with the reference's comparison order; (i, j, k) cyclic
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > (i == 0 ? R[0] : R[4])) i = 2;
+        if (i == 0) {
+            t = R[0] - (R[4] + R[8]) + 1.0f;
+            qx = t; qy = R[1] + R[3]; qz = R[6] + R[2]; qw = R[7] - R[5];
+        } else if (i == 1) {
+            t = R[4] - (R[8] + R[0]) + 1.0f;
+            qy = t; qz = R[5] + R[7]; qx = R[1] + R[3]; qw = R[2] - R[6];
+        } else {
+            t = R[8] - (R[0] + R[4]) + 1.0f;
+            qz = t; qx = R[6] + R[2]; qy = R[5] + R[7]; qw = R[3] - R[1];
+        }
+    }
+    const float sc = 0.5f / sqrtf(t);
+    out[0] = qw * sc; out[1] = qx * sc; out[2] = qy * sc; out[3] = qz * sc;
+}
+
 // workspace box, distance_fields.py:326-332: max_k (margin - sd_k) over the six planes; returns the value,
 // adds scale * d/dp to (ax, ay, az)
 __device__ __forceinline__ float ws_cost_point(const DevCostHdr& C, float mg, float x, float y, float z, float scale,

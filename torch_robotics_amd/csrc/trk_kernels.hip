@@ -858,32 +858,6 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
 // Stateful FK + geometric Jacobian (robot_tree.py:136-190, 218-248; Frame.get_quaternion frame.py:87-114)
 // LDS: q | qd | slots (pose 12 + velocity 6 floats per slot) | joint axes/origins [6][D][64].
 // ============================================================================================
-__device__ __forceinline__ void frame_quat_wxyz(const float* R, float* out) {
-    // trace method with M[3][3] = 1 (frame.py:87-114), then xyzw -> wxyz (quaternion.py:240-242)
-    float t = R[0] + R[4] + R[8] + 1.0f;
-    float qx, qy, qz, qw;
-    if (t > 1.0f) {
-        qw = t; qz = R[3] - R[1]; qy = R[2] - R[6]; qx = R[7] - R[5];
-    } else {
-        // i = arg-max diagonal with the reference's comparison order; (i, j, k) cyclic
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > (i == 0 ? R[0] : R[4])) i = 2;
-        if (i == 0) {
-            t = R[0] - (R[4] + R[8]) + 1.0f;
-            qx = t; qy = R[1] + R[3]; qz = R[6] + R[2]; qw = R[7] - R[5];
-        } else if (i == 1) {
-            t = R[4] - (R[8] + R[0]) + 1.0f;
-            qy = t; qz = R[5] + R[7]; qx = R[1] + R[3]; qw = R[2] - R[6];
-        } else {
-            t = R[8] - (R[0] + R[4]) + 1.0f;
-            qz = t; qx = R[6] + R[2]; qy = R[5] + R[7]; qw = R[3] - R[1];
-        }
-    }
-    const float sc = 0.5f / sqrtf(t);
-    out[0] = qw * sc; out[1] = qx * sc; out[2] = qy * sc; out[3] = qz * sc;
-}
-
 struct JacCols {                // DOF -> record slot of the Jacobian columns this call produces (-1: column stays zero)
     int8_t slot[TRK_MAX_DOFS];
     int32_t n_cols;
@@ -918,6 +892,12 @@ k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, JacCols cols, 
     }
     float* myrec = rec + lane * rstride;
     for (int k = 0; k < rstride; ++k) myrec[k] = 0.0f;
+    // DOF -> column slot, in LDS: the read-out below indexes it per lane, and a per-lane index into a by-value kernel
+    // argument array goes through scratch memory
+    int* slot_lds = reinterpret_cast<int*>(rec + TRK_WAVE * rstride);
+#pragma unroll
+    for (int d = 0; d < TRK_MAX_DOFS; ++d)
+        if (lane == d) slot_lds[d] = cols.slot[d];
     __syncthreads();
     Pose cur, par;
     float vl[3] = {0, 0, 0}, va[3] = {0, 0, 0};
@@ -971,7 +951,7 @@ k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, JacCols cols, 
         }
         if (Lk.dof >= 0 && (Lk.link - 1) <= link_joint_idx && Lk.jac_axis >= 0) {   // robot_tree.py:239-244
             const int ax = Lk.jac_axis;
-            float* j = myrec + 6 * cols.slot[Lk.dof];
+            float* j = myrec + 6 * slot_lds[Lk.dof];
             j[0] = ax == 0 ? cur.r[0] : (ax == 1 ? cur.r[1] : cur.r[2]);
             j[1] = ax == 0 ? cur.r[3] : (ax == 1 ? cur.r[4] : cur.r[5]);
             j[2] = ax == 0 ? cur.r[6] : (ax == 1 ? cur.r[7] : cur.r[8]);
@@ -986,30 +966,7 @@ k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, JacCols cols, 
     }
     myrec[6 * cols.n_cols] = et[0]; myrec[6 * cols.n_cols + 1] = et[1]; myrec[6 * cols.n_cols + 2] = et[2];
     __syncthreads();
-    // [rows][3][D] blocks of lin_jac and ang_jac: element k of the wave's contiguous run -> (sample, row, dof)
-    {
-        const int w3 = 3 * D;
-        int sl = lane / w3, rem = lane - sl * w3;
-        const int ds = TRK_WAVE / w3, dr = TRK_WAVE - ds * w3;
-        const int64_t count = (int64_t)rows * w3;
-        float* lo = lin_jac + base * w3;
-        float* ao = ang_jac + base * w3;
-        for (int64_t k = lane; k < count; k += TRK_WAVE) {
-            const int r = rem / D, d = rem - r * D;
-            const int c = cols.slot[d];
-            float lv = 0.0f, av = 0.0f;
-            if (c >= 0) {
-                const float* j = rec + sl * rstride + 6 * c;
-                const float* e = rec + sl * rstride + 6 * cols.n_cols;
-                const int r1 = r == 2 ? 0 : r + 1, r2 = r == 0 ? 2 : r - 1;
-                av = j[r];
-                lv = j[r1] * (e[r2] - j[3 + r2]) - j[r2] * (e[r1] - j[3 + r1]);      // (z x (p_link - p_joint))_r
-            }
-            lo[k] = lv; ao[k] = av;
-            sl += ds; rem += dr;
-            if (rem >= w3) { rem -= w3; ++sl; }
-        }
-    }
+    trk_jac_readout(rec, slot_lds, rstride, cols.n_cols, D, rows, lin_jac + base * 3 * D, ang_jac + base * 3 * D, lane);
     if (lane >= rows) return;
     const int64_t s = base + lane;
     pos[s * 3] = et[0]; pos[s * 3 + 1] = et[1]; pos[s * 3 + 2] = et[2];
@@ -1685,7 +1642,7 @@ void trk_launch_fk_jacobian(const DevModelHdr& hdr, const DevLink* links_dev, co
     }
     const int rstride = (6 * cols.n_cols + 3) | 1;
     size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * (qd ? 2 : 1) + (size_t)hdr.n_slots * (qd ? 18 : 12) * TRK_WAVE +
-                                  (size_t)TRK_WAVE * rstride);
+                                  (size_t)TRK_WAVE * rstride + TRK_MAX_DOFS);
     hipLaunchKernelGGL(k_fk_jacobian, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links_dev, cols, q, qd, n, link,
                        link_joint_idx, pos, quat, lin_jac, ang_jac, vel_lin, vel_ang);
 }

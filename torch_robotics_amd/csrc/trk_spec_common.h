@@ -35,6 +35,12 @@ struct SpecArgs {
     int32_t coll_use_default;     // 1: per-link margins + cutoff of the cost model, 0: coll_margin for every test
     float coll_margin;
     int32_t _pad_coll;
+    // geometric-Jacobian kernel (trk_fk_jacobian, launch_jac): target link, index of its parent joint in the file's joint
+    // list (the reference's column rule), outputs pos [N,3], quat_wxyz [N,4], lin_jac / ang_jac [N,3,D]
+    int32_t jac_link, jac_joint_idx;
+    int32_t jac_p_end, jac_n_cols;    // the walk may stop after this pre-order position; number of joints that get a column
+    int8_t jac_slot[TRK_MAX_DOFS];    // DOF -> record slot of its column (-1: the column stays zero), in walk order
+    float* jac_pos; float* jac_quat; float* jac_lin; float* jac_ang;
 };
 
 typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
@@ -42,7 +48,7 @@ typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 5)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 8)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -62,6 +68,7 @@ struct SpecEntry {
     uint64_t points_hash;       // FNV-1a over (n_points, point_link[], point_offset[]) in the caller's order
     SpecLaunchFn launch_posbwd; // reverse mode of the link positions (q, gpos = link_pos -> gq); nullptr if not generated
     int32_t ee2_link;           // second tracked link baked into the unit (-1 = none)
+    SpecLaunchFn launch_jac;    // stateful FK + geometric Jacobian of one link (robot_tree.py:136-248); nullptr if not generated
 };
 
 // registry filled by static initialisers of the generated translation units
