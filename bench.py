@@ -47,7 +47,10 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="capture this many steps per hipGraph replay (0 = eager launches)")
     ap.add_argument("--weights", default=None, help="experiment: w_self,w_obj,w_ws,w_ee override (reported in config)")
     ap.add_argument("--no-pos", action="store_true", help="experiment: do not write link positions")
-    ap.add_argument("--no-streams", action="store_true", help="skip the secondary 3-stream throughput figure")
+    ap.add_argument("--independent-streams", type=int, default=0,
+                    help="also report the throughput of unrelated batches alternated over this many HIP streams (secondary "
+                         "figure `independent_batches`; off by default so that a rocprofv3 run of the default command sees only "
+                         "back-to-back launches of one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' + --single-device lets the N>1 control flow run on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0")
@@ -231,12 +234,12 @@ def main():
                      "bytes_per_sample": algorithmic_bytes_per_sample(D, L), "launch_us": launch_s * 1e6},
     }
 
-    if rank == 0 and world == 1 and graph is None and not args.no_streams:
+    if rank == 0 and world == 1 and graph is None and args.independent_streams > 1:
         # Secondary figure (never `value`): INDEPENDENT batches alternated over three HIP streams.  With one stream a launch waits
         # for the previous one's ~2 us write tail; with three, the next launch's dispatch, kernarg / q fetch and FK overlap it.
         # A planner's iterations depend on each other, so the headline keeps one stream; a server evaluating unrelated batches
         # gets this rate.  Kernels overlap here, so this is a throughput, not a kernel duration.
-        ns = 3
+        ns = args.independent_streams
         streams3 = [torch.cuda.Stream(dev) for _ in range(ns)]
         plans3 = [plan] + [ops.RolloutPlan(model, cm, weights, robot.random_q(B * H, generator=gen).reshape(B, H, D).contiguous(),
                                            want_pos=not args.no_pos) for _ in range(ns - 1)]
@@ -254,7 +257,7 @@ def main():
         t3 = time.perf_counter() - t3
         out["independent_batches"] = {"streams": ns, "steps": n3, "ms_per_step": t3 * 1e3 / n3, "value": B * H * n3 / t3,
                                       "unit": "rollouts/s", "frac_of_hbm_peak": bytes_per_launch * n3 / t3 / 1e9 / HBM_PEAK_GBS,
-                                      "note": "secondary: unrelated batches round-robin over 3 streams (launches overlap); "
+                                      "note": f"secondary: unrelated batches round-robin over {ns} streams (launches overlap); "
                                               "the headline value above is one stream, launch after launch"}
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:       # CPU baseline: rank 0 at N = 1 only

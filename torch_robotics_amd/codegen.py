@@ -427,31 +427,6 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             _emit_fk_link(E, kin, i, R, t, passv, snap)
             if chunked:
                 stage_link(i)
-        # ---------------- boolean mode: fused FK + collision fields (trk_rollout_collision) ----------------
-        E.raw("    if (A.coll_out) {")
-        E.raw("        bool hit = false;")
-        if NL > 0:
-            grp_size = NL if NL <= LINK_OBJ_GROUP_MAX else -(-NL // (-(-NL // LINK_OBJ_GROUP)))
-            E.raw("        if (A.coll_fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {")
-            for g0 in range(0, NL, grp_size):
-                grp = list(tmpl.obj_links[g0:g0 + grp_size])
-                n = len(grp)
-                E.raw("            {")
-                for k, nm in enumerate("xyz"):
-                    E.raw(f"                const float p{nm}[{n}] = {{{', '.join(E.expr(t[i][k]) for i in grp)}}};")
-                E.raw(f"                hit |= spec_collision_links<{n}>(A.C, A.coll_fields, A.coll_margin, A.coll_use_default, px, py, pz, lds_sph, {g0});")
-                E.raw("            }")
-            E.raw("        }")
-        if tmpl.self_pairs:
-            E.raw("        if (A.coll_fields & TRK_FIELD_SELF) {")
-            for pi, (a, b) in enumerate(tmpl.self_pairs):
-                pa = ", ".join(E.expr(t[a][k]) for k in range(3))
-                pb = ", ".join(E.expr(t[b][k]) for k in range(3))
-                E.raw(f"            hit |= spec_self_hit(A.coll_use_default ? cptr(A.C.self_margin)[{pi}] : A.coll_margin, {pa}, {pb});")
-            E.raw("        }")
-        E.raw("        if (lane < rows) A.coll_out[base + lane] = hit ? 1 : 0;")
-        E.raw("        return;")
-        E.raw("    }")
         # ---------------- outputs that depend only on FK ----------------
         if chunked:
             E.raw("    NoFlush flush;")
@@ -599,6 +574,59 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.extend(E.lines)
         out.append("")
 
+    # ---- boolean mode (trk_rollout_collision): FK + the OR of the selected fields' "signed distance < margin" tests, one byte
+    # per sample out.  Its own kernel: inside k_rollout the extra SpecArgs fields and the cold path cost the hot path
+    # ~100 SGPR spill moves (v_writelane / v_readlane) per wavefront.
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_coll_bi" if base_identity else "k_coll_bg"
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * D + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw("    float* lds = lds_all + wave * (TRK_WAVE * D);")
+        E.raw("    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * D) + wave * TRK_LDS_SPHERES;")
+        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        _emit_angles(E, kin)
+        for p in range(1, L):
+            _emit_fk_link(E, kin, int(kin.order[p]), R, t, passv, snap)
+        E.raw("    bool hit = false;")
+        if NL > 0:
+            grp_size = NL if NL <= LINK_OBJ_GROUP_MAX else -(-NL // (-(-NL // LINK_OBJ_GROUP)))
+            E.raw("    if (A.coll_fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {")
+            for g0 in range(0, NL, grp_size):
+                grp = list(tmpl.obj_links[g0:g0 + grp_size])
+                n = len(grp)
+                E.raw("        {")
+                for k, nm in enumerate("xyz"):
+                    E.raw(f"            const float p{nm}[{n}] = {{{', '.join(E.expr(t[i][k]) for i in grp)}}};")
+                E.raw(f"            hit |= spec_collision_links<{n}>(A.C, A.coll_fields, A.coll_margin, A.coll_use_default, px, py, pz, lds_sph, {g0});")
+                E.raw("        }")
+            E.raw("    }")
+        if tmpl.self_pairs:
+            E.raw("    if (A.coll_fields & TRK_FIELD_SELF) {")
+            for pi, (a_, b_) in enumerate(tmpl.self_pairs):
+                pa = ", ".join(E.expr(t[a_][k]) for k in range(3))
+                pb = ", ".join(E.expr(t[b_][k]) for k in range(3))
+                E.raw(f"        hit |= spec_self_hit(A.coll_use_default ? cptr(A.C.self_margin)[{pi}] : A.coll_margin, {pa}, {pb});")
+            E.raw("    }")
+        E.raw("    if (lane < rows) A.coll_out[base + lane] = hit ? 1 : 0;")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
     # ---- stateful FK + geometric Jacobian of ONE link (trk_fk_jacobian; robot_tree.py:136-190, 218-248): the walk unrolled
     # with the stateful path's quirks (clamp wherever limits exist, rotation about the axis with its sign ignored); every
     # joint that can receive a column leaves a record (z, p) in LDS, the target link (a run-time argument) is picked by a
@@ -699,6 +727,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("    if (base_identity) hipLaunchKernelGGL(k_posbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_posbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
+    out.append("static void launch_coll(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+    out.append("    if (base_identity) hipLaunchKernelGGL(k_coll_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    else hipLaunchKernelGGL(k_coll_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("}")
     out.append("static void launch_jac(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
     out.append("    const int rstride = (6 * a.jac_n_cols + 3) | 1;")
@@ -709,7 +742,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     jac_ok = (TRK_WAVE_ * JAC_LDS + 32) * 4 <= 64 * 1024            # default dynamic-LDS limit of a launch
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
-               f"{'launch_jac' if jac_ok else 'nullptr'}}};")
+               f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -1132,7 +1165,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
-               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr}};")
+               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out

@@ -928,7 +928,8 @@ int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fie
         w.w_self = (fields & TRK_FIELD_SELF) ? 1.0f : 0.0f;
         w.w_obj = (fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) ? 1.0f : 0.0f;
         w.w_ws = (fields & TRK_FIELD_WS) ? 1.0f : 0.0f;
-        if (const SpecEntry* e = model_spec_for(m, cm, &w)) {
+        const SpecEntry* e = model_spec_for(m, cm, &w);
+        if (e && e->launch_coll) {
             SpecArgs a{};
             a.C = cm->hdr; a.w = w;
             std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
@@ -936,7 +937,7 @@ int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fie
             a.q = q; a.n = n;
             a.coll_out = in_collision; a.coll_fields = fields; a.coll_use_default = use_default;
             a.coll_margin = use_default ? 0.0f : margin_override;
-            e->launch(a, base_is_identity(m), (hipStream_t)stream);
+            e->launch_coll(a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }

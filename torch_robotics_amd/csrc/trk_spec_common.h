@@ -48,7 +48,7 @@ typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 8)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 9)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -69,6 +69,7 @@ struct SpecEntry {
     SpecLaunchFn launch_posbwd; // reverse mode of the link positions (q, gpos = link_pos -> gq); nullptr if not generated
     int32_t ee2_link;           // second tracked link baked into the unit (-1 = none)
     SpecLaunchFn launch_jac;    // stateful FK + geometric Jacobian of one link (robot_tree.py:136-248); nullptr if not generated
+    SpecLaunchFn launch_coll;   // FK + boolean collision fields (trk_rollout_collision); nullptr if not generated
 };
 
 // registry filled by static initialisers of the generated translation units
