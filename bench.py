@@ -13,6 +13,10 @@ Multi-GPU: the batch is sharded, each rank owns 4096 x 64 samples (weak scaling)
 RCCL all-reduce of the packed sums [cost | cost per time step | gradient per time step and joint] (2 kB), issued once per
 `--reduce-every` steps on a side stream.
 
+Timed region: W untimed warm-up steps, then exactly K steps bracketed on both sides by a barrier (N > 1: a one-element all-reduce
+enqueued on the launch stream -- it completes only when every rank has reached it) + `torch.cuda.synchronize()`; the maximum over the
+ranks is taken.  The whole measurement is rehearsed once and discarded first.
+
 Prints ONE JSON line (rank 0).  `roofline.achieved` = 192 algorithmic bytes/sample x samples per launch /
 average launch duration (HIP events around the timed region on the launch stream).
 `cpu_baseline` = the C oracle (OpenMP over samples, all host cores) on a bounded sample of the same input.
@@ -150,37 +154,36 @@ def main():
     if graph is not None:
         args.steps = max(args.graph, args.steps // args.graph * args.graph)
         args.warmup = max(args.graph, args.warmup // args.graph * args.graph)
-    def barrier():
-        if args.dist_backend == "nccl":
-            dist.barrier(device_ids=[dev.index])
-        else:
-            dist.barrier()
+    flag = torch.zeros(1, **ta)
+
+    def barrier_in_stream():
+        """A barrier that costs no host round trip: a one-element all-reduce enqueued on the launch stream completes on a rank
+        only after every rank has reached it, so the `torch.cuda.synchronize()` that follows returns when all ranks are done."""
+        dist.all_reduce(flag)
 
     def measure(first):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize brackets; returns (wall s, event ms)."""
         run(first, args.warmup)
-        torch.cuda.synchronize(dev)
         if world > 1:
-            barrier()
-            torch.cuda.synchronize(dev)
+            barrier_in_stream()
+        torch.cuda.synchronize(dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
         run(first + args.warmup, args.steps)
         ev1.record(stream)
         ta_ = time.perf_counter()
-        while not ev1.query():          # spin on the completion signal: a blocking wait adds ~6 us of wake-up latency
-            pass
+        if world > 1:
+            barrier_in_stream()         # closing bracket: in-stream barrier, then ONE synchronize (all streams, all ranks done)
+        else:
+            while not ev1.query():      # spin on the completion signal: a blocking wait adds ~6 us of wake-up latency
+                pass
         tb_ = time.perf_counter()
         torch.cuda.synchronize(dev)
-        if os.environ.get("TRK_BENCH_TRACE"):
-            tc_ = time.perf_counter()
-            print(f"[trace] submit {1e6 * (ta_ - t0):.1f} us, wait {1e6 * (tb_ - ta_):.1f} us, sync {1e6 * (tc_ - tb_):.1f} us, "
-                  f"events {1e3 * ev0.elapsed_time(ev1):.1f} us", file=sys.stderr)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
         wall = time.perf_counter() - t0
+        if os.environ.get("TRK_BENCH_TRACE"):
+            print(f"[trace] submit {1e6 * (ta_ - t0):.1f} us, wait {1e6 * (tb_ - ta_):.1f} us, sync {1e6 * (wall - (tb_ - t0)):.1f} us, "
+                  f"events {1e3 * ev0.elapsed_time(ev1):.1f} us", file=sys.stderr)
         return wall, (ev0.elapsed_time(ev1) if graph is None else wall * 1e3)
 
     # one rehearsal of the whole measurement (discarded): the first pass through the event / sync / launch code paths of a
