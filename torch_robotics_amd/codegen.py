@@ -367,15 +367,35 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"namespace spec_{ident} {{")
     out.append(f"constexpr int L = {L}, D = {D}, NL = {NL};")
     out.append(f'static_assert(TRK_OBJ_TICK_SLOTS == {OBJ_TICK_SLOTS}, "chunk numbering of this unit assumes another TRK_OBJ_TICK_SLOTS");')
+    chunked = 3 * L > CHUNKED_STAGING_MIN_FLOATS and [int(v) for v in kin.order] == list(range(L))
+    if chunked:
+        # ring staging: the pieces of the whole chunks leave between the links that follow them; the tail chunk's pieces are what
+        # the objectives' tick slots issue (flush.chunk<CH>() -> RingTail)
+        rp = ring_plan(3 * L)
+        ring_t = f"RingFlusher<{rp.W}, {rp.V}, {'true' if rp.aligned else 'false'}, IO>"
+        out.append("template <class R> struct RingTail {      // tick slot CH of the objectives -> store piece CH of the tail chunk")
+        out.append("    const R& r;")
+        out.append("    template <int CH> __device__ __forceinline__ void chunk() const { r.template piece<R::NFULL, CH>(); }")
+        out.append("    template <int A, int B> __device__ __forceinline__ void range() const { if constexpr (A < B && A < R::NP) { chunk<A>(); range<A + 1, B>(); } }")
+        out.append("    template <int A> __device__ __forceinline__ void rest() const { range<A, R::NP>(); }")
+        out.append("};")
 
     for base_identity in (True, False):
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
         # small arms fit 128 VGPRs (4 waves/SIMD: the whole 4096 x 64 batch resident); big trees get 256 VGPRs
-        E.raw("template <class IO>      // HBM-side type of q / link_pos / gq: float or _Float16")
+        if chunked:
+            # POS: the launch wants the link positions.  A compile-time switch, because the ring staging costs the launches that
+            # only want cost + gradient (the planners' inner loop) 2-4 us even with every store masked off.
+            E.raw("template <class IO, bool POS>      // IO: HBM-side type of q / link_pos / gq (float or _Float16)")
+        else:
+            E.raw("template <class IO>      // HBM-side type of q / link_pos / gq: float or _Float16")
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
-        chunked = 3 * L > CHUNKED_STAGING_MIN_FLOATS and [int(v) for v in kin.order] == list(range(L))
-        lds_lane = max(CHUNK_FLOATS, D) if chunked else max(3 * L, D)
+        if chunked:
+            E.raw(f"    constexpr int LDS_LANE = POS ? {max(64 + rp.hx + 1, D)} : {D};")
+            lds_lane = "LDS_LANE"
+        else:
+            lds_lane = max(3 * L, D)
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_lane} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
@@ -403,33 +423,61 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         _emit_angles(E, kin)
         if chunked:
             # Many links: a full [64][3L] staging tile per wavefront (92 KB per workgroup for 30 links) leaves ONE workgroup per
-            # CU.  The positions leave in 36-float column chunks instead (spec_flush_chunk), each link written as it exists.
-            E.raw("    IO* pos_out = static_cast<IO*>(A.link_pos);")
-            E.raw(f"    float* prow = lds + lane * {CHUNK_FLOATS};")
-            E.raw("    spec_wave_sync();")
-            chunk_start = 0
+            # CU.  The positions go through a 64-float ring per lane instead (RingFlusher): each link is staged as it exists, a
+            # complete 32-float chunk leaves piece by piece between the links that fill the other half of the ring.
             W = 3 * L
-            V = 4 if W % 4 == 0 else (2 if W % 2 == 0 else 1)
-            assert [int(v) for v in kin.order] == list(range(L)), "chunked staging needs file order == walk order"
+            E.raw(f"    static_assert({ring_t}::LS == {64 + rp.hx + 1} && {ring_t}::NFULL == {rp.n_full} && {ring_t}::NP == {rp.pieces}, "
+                  '"generator and RingFlusher disagree on the ring geometry");')
+            E.raw(f"    const {ring_t} ring = spec_make_ring<{rp.W}, {rp.V}, {'true' if rp.aligned else 'false'}, IO>("
+                  "static_cast<IO*>(A.link_pos), base, rows, lane, lds);")
+            E.raw("    float* const prow = ring.row();        // this lane's ring; prow_a: the same, shifted by the lane's head")
+            E.raw("    float* const prow_a = ring.row_a();")
+            E.raw("    spec_wave_sync();")
+            assert [int(v) for v in kin.order] == list(range(L)), "ring staging needs file order == walk order"
+            ready_at: Dict[int, List[int]] = {}
+            for c in range(rp.n_full + 1):
+                ready_at.setdefault(rp.ready_float(c), []).append(c)
+            pending: List[Tuple[int, int]] = []       # (chunk, piece) not yet issued, oldest first
 
             def stage_link(i):
-                nonlocal chunk_start
                 for k in range(3):
                     f = 3 * i + k
-                    E.raw(f"    prow[{f - chunk_start}] = {E.expr(t[i][k])};")
-                    if f + 1 - chunk_start == CHUNK_FLOATS or f + 1 == W:
-                        nf = f + 1 - chunk_start
-                        E.raw(f"    if (pos_out) spec_flush_chunk<{W}, {nf}, {CHUNK_FLOATS}, {V}, IO>(pos_out, base, {chunk_start}, rows, lane, lds);")
-                        chunk_start = f + 1
+                    assert all(rp.reuse_float(c) > f for c, _ in pending), "ring half reused before its pieces were issued"
+                    x = E.expr(t[i][k])
+                    if rp.regular(f):
+                        E.raw(f"    if constexpr (POS) prow_a[{f & 63}] = {x};")
+                    else:
+                        E.raw(f"    if constexpr (POS) prow[ring.slot({f})] = {x};")
+                    if f < rp.hx:
+                        E.raw(f"    if constexpr (POS) prow[{64 + f}] = {x};")
+                    for c in ready_at.get(f, []):
+                        E.raw(f"    if constexpr (POS) ring.template done<{c}>();")
+                        if c < rp.n_full:
+                            pending.extend((c, kk) for kk in range(rp.pieces))
+
+            def issue_pieces(i):
+                """slot after link i: the pending pieces (of one chunk) are spread evenly over the slots that remain until the
+                link whose staging re-uses their half of the ring (or the end of the walk)"""
+                if not pending:
+                    return
+                c = pending[0][0]
+                last_slot = min(L - 1, rp.reuse_float(c) // 3 - 1)
+                slots = max(1, last_slot - i + 1)
+                for _ in range(-(-sum(1 for cc, _ in pending if cc == c) // slots)):
+                    cc, kk = pending.pop(0)
+                    E.raw(f"    if constexpr (POS) ring.template piece<{cc}, {kk}>();")
             stage_link(0)
+            issue_pieces(0)
         for p in range(1, L):
             i = int(kin.order[p])
             _emit_fk_link(E, kin, i, R, t, passv, snap)
             if chunked:
                 stage_link(i)
+                issue_pieces(i)
         # ---------------- outputs that depend only on FK ----------------
         if chunked:
-            E.raw("    NoFlush flush;")
+            assert not pending
+            E.raw("    const std::conditional_t<POS, RingTail<decltype(ring)>, NoFlushOf<decltype(ring)>> flush{ring};")
         else:
             E.raw(f"    PosFlusher<{3 * L}, IO> flush{{nullptr, 0u, 0ull, false, lane}};")
             pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
@@ -714,13 +762,24 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"static const int32_t kSelfPairs[] = {{{pairs}}};")
     out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
-    out.append("    if (a.io_f16) {")
-    out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<_Float16>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-    out.append("        else hipLaunchKernelGGL(k_rollout_bg<_Float16>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-    out.append("    } else {")
-    out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<float>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-    out.append("        else hipLaunchKernelGGL(k_rollout_bg<float>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-    out.append("    }")
+    if chunked:
+        out.append("    const bool pos = a.link_pos != nullptr;")
+        for cond, io in (("a.io_f16", "_Float16"), ("", "float")):
+            out.append(f"    {'if (' + cond + ') ' if cond else 'else '}{{")
+            for bi, kn in (("base_identity && pos", "k_rollout_bi<IOT, true>"), ("base_identity", "k_rollout_bi<IOT, false>"),
+                           ("pos", "k_rollout_bg<IOT, true>"), ("", "k_rollout_bg<IOT, false>")):
+                pre = f"if ({bi}) " if bi else ""
+                el = "" if bi == "base_identity && pos" else "else "
+                out.append(f"        {el}{pre}hipLaunchKernelGGL(({kn.replace('IOT', io)}), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+            out.append("    }")
+    else:
+        out.append("    if (a.io_f16) {")
+        out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<_Float16>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("        else hipLaunchKernelGGL(k_rollout_bg<_Float16>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    } else {")
+        out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<float>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("        else hipLaunchKernelGGL(k_rollout_bg<float>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    }")
     out.append("}")
     out.append("static void launch_posbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
@@ -778,6 +837,45 @@ CHUNKED_STAGING_MIN_FLOATS = 80       # link kernels with more position floats p
 LINK_OBJ_GROUP_MAX = 12    # link kernels: up to this many collision links are scored in one scene evaluation (more ILP: dual Panda 5+5 was ~1 us slower) ...
 LINK_OBJ_GROUP = 5         # ... more are split into groups of about this size
 CHUNK_FLOATS = 36          # 12 columns: 144 B per sample and chunk, a multiple of 16 B
+RING_FLOATS = 32           # link kernels with ring staging (RingFlusher in trk_spec_common.h): floats per chunk
+RING_HEAD_MAX = 6          # sector-aligned rings: the longest head ((-W s) mod 8 for even W)
+
+
+@dataclass
+class RingPlan:
+    """Geometry of RingFlusher<W, V, ALIGNED, IO> (mirrors its constants; see the comment there)."""
+    W: int
+    V: int
+    aligned: bool
+    n_full: int
+    tail: int               # floats of the tail chunk
+    pieces: int             # store instructions per chunk
+
+    @property
+    def hx(self) -> int:
+        return RING_HEAD_MAX if self.aligned else 0
+
+    def ready_float(self, c: int) -> int:
+        """chunk c is complete in every lane's ring once this float has been staged"""
+        return self.W - 1 if c >= self.n_full else min(self.W - 1, RING_FLOATS * c + RING_FLOATS - 1 + self.hx)
+
+    def reuse_float(self, c: int) -> int:
+        """the first float whose staging overwrites chunk c's half of the ring (W if none does)"""
+        return min(self.W, RING_FLOATS * (c + 2))
+
+    def regular(self, f: int) -> bool:
+        """the float's ring slot is the same offset from the lane's row pointer for every head"""
+        return (f & 63) >= self.hx
+
+
+def ring_plan(W: int) -> RingPlan:
+    assert W >= RING_FLOATS
+    aligned = W % 2 == 0 and ((W - RING_HEAD_MAX) % RING_FLOATS) + RING_HEAD_MAX <= RING_FLOATS
+    V = 2 if W % 2 == 0 else 1
+    n_full = (W - RING_HEAD_MAX) // RING_FLOATS if aligned else (W - 1) // RING_FLOATS
+    return RingPlan(W=W, V=V, aligned=aligned, n_full=n_full, tail=W - RING_FLOATS * n_full, pieces=64 // (64 // (RING_FLOATS // V)))
+
+
 OBJ_GROUP = 6              # points evaluated against the scene together (register arrays of this size)
 
 

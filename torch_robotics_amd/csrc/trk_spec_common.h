@@ -127,6 +127,26 @@ template <> struct IoQuad<float> {
     }
     static __device__ __forceinline__ void store_wt1(float* p, float v) { store_wt_f1(p, v); }
     static __device__ __forceinline__ void store_wt2(float* p, float a, float b) { store_wt_f2(p, a, b); }
+    static __device__ __forceinline__ void store_wt2_s(unsigned long long base, unsigned voff, float a, float b) {
+        const trk_f2 x = {a, b};
+        asm volatile("global_store_dwordx2 %0, %1, %2 sc1\n s_nop 1" :: "v"(voff), "v"(x), "s"(base)  TRK_STORE_CLOBBER);
+    }
+    static __device__ __forceinline__ void store_wt1_s(unsigned long long base, unsigned voff, float a) {
+        asm volatile("global_store_dword %0, %1, %2 sc1\n s_nop 1" :: "v"(voff), "v"(a), "s"(base)  TRK_STORE_CLOBBER);
+    }
+    // the same under a lane mask applied INSIDE the asm block (exec &= mask; store; restore): no control flow for the compiler,
+    // so a masked store does not end a scheduling region; an all-zero mask makes it a no-op
+    static __device__ __forceinline__ void store_wt2_sm(unsigned long long base, unsigned voff, float a, float b, unsigned long long mask) {
+        const trk_f2 x = {a, b};
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %4\n global_store_dwordx2 %1, %2, %3 sc1\n s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(voff), "v"(x), "s"(base), "s"(mask) : "scc");
+    }
+    static __device__ __forceinline__ void store_wt1_sm(unsigned long long base, unsigned voff, float a, unsigned long long mask) {
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %3\n global_store_dword %1, %2, %4 sc1\n s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(voff), "v"(a), "s"(mask), "s"(base) : "scc");
+    }
 };
 template <> struct IoQuad<_Float16> {
     static constexpr uintptr_t kAlignMask = 7;
@@ -150,6 +170,28 @@ template <> struct IoQuad<_Float16> {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const h2 h = {(_Float16)a, (_Float16)b};
         asm volatile("global_store_dword %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h)  TRK_STORE_CLOBBER);
+    }
+    static __device__ __forceinline__ void store_wt2_s(unsigned long long base, unsigned voff, float a, float b) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 h = {(_Float16)a, (_Float16)b};
+        asm volatile("global_store_dword %0, %1, %2 sc1\n s_nop 1" :: "v"(voff), "v"(h), "s"(base)  TRK_STORE_CLOBBER);
+    }
+    static __device__ __forceinline__ void store_wt1_s(unsigned long long base, unsigned voff, float a) {
+        const _Float16 h = (_Float16)a;
+        asm volatile("global_store_short %0, %1, %2 sc1\n s_nop 1" :: "v"(voff), "v"(h), "s"(base)  TRK_STORE_CLOBBER);
+    }
+    static __device__ __forceinline__ void store_wt2_sm(unsigned long long base, unsigned voff, float a, float b, unsigned long long mask) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 h = {(_Float16)a, (_Float16)b};
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %4\n global_store_dword %1, %2, %3 sc1\n s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(voff), "v"(h), "s"(base), "s"(mask) : "scc");
+    }
+    static __device__ __forceinline__ void store_wt1_sm(unsigned long long base, unsigned voff, float a, unsigned long long mask) {
+        const _Float16 h = (_Float16)a;
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %3\n global_store_short %1, %2, %4 sc1\n s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(voff), "v"(h), "s"(mask), "s"(base) : "scc");
     }
 };
 
@@ -271,6 +313,10 @@ struct NoFlush {
     template <int A> __device__ __forceinline__ void rest() const {}
 };
 
+template <class R> struct NoFlushOf : NoFlush {      // the same, constructible from a flusher it ignores
+    __device__ __forceinline__ NoFlushOf(const R&) {}
+};
+
 template <int W, class IO>
 __device__ __forceinline__ PosFlusher<W, IO> spec_make_flusher(IO* __restrict__ out, int64_t base, int rows, int lane, float* lds) {
     IO* dst = out + base * W;
@@ -322,6 +368,113 @@ __device__ __forceinline__ void spec_flush_chunk(IO* __restrict__ out, int64_t b
         }
     }
     spec_wave_sync();           // the chunk buffer may be overwritten from here on
+}
+
+// Ring staging for link kernels with many links.  spec_flush_chunk issues a chunk's stores back to back: every wave of the chip
+// reaches that point together, the store path fills, and nothing computes until the burst has drained (UR10+Allegro, 4096 x 64:
+// 30.0 us with positions against 13.5 us without -- exactly the 94 MB at HBM write speed, no overlap).  Here every lane stages
+// its sample's floats in a 64-float RING in LDS (two 32-float chunks: one being filled, one leaving) and a complete chunk
+// leaves as single store instructions ("pieces") that the generator spreads over the code that follows -- the links that fill
+// the other half of the ring, then the objectives.
+//
+// Sector alignment (ALIGNED, rows of an even number of floats): a row of W floats starts at byte 4 W s, in general in the
+// middle of a 32-byte HBM sector, so fixed column chunks [32c, 32c + 32) split two sectors per sample and chunk between
+// different store instructions (measured: WRITE_SIZE 137 MB for 118 MB of output).  Instead sample s owns a HEAD of
+// h(s) = (-W s) mod 8 floats -- the part of its row that shares a sector with the end of row s - 1 -- and its chunk c is the
+// floats [h + 32c, h + 32c + 32): four whole sectors.  Ring position of float f: (f - h) & 63.  What is left, the TAIL chunk,
+// is the last T - h floats of the row plus the head (T floats per sample whatever h is); a tail piece holds S consecutive
+// samples, S a multiple of the period of h, so the head of row s and the end of row s - 1 leave in the SAME instruction and
+// every sector is written exactly once.  The head floats are kept twice (ring + HX extra floats per lane) because their ring
+// slots are overwritten before the tail leaves.
+//
+// Piece K of a chunk covers the S = 64 / (32 / V) samples [K S, K S + S); lane -> (sample lane / NVEC, vector lane % NVEC) is
+// the same for every piece, so a piece costs two scalar adds, an LDS read at an immediate offset and one store with an SGPR base.
+template <int W, int V, bool ALIGNED, class IO>
+struct RingFlusher {
+    static_assert(V == 1 || V == 2, "ring pieces are 1- or 2-float vectors (the ring stride is odd)");
+    static_assert(!ALIGNED || (V == 2 && W % 2 == 0), "sector alignment needs rows of an even number of floats");
+    static constexpr int CS = 32;                                   // floats per chunk
+    static constexpr int HX = ALIGNED ? 6 : 0;                      // longest head
+    static constexpr int LS = 64 + HX + 1;                          // per-lane stride: odd -> the per-lane row writes are conflict-free
+    static constexpr int NFULL = ALIGNED ? (W - HX) / CS : (W - 1) / CS;     // whole chunks of every sample
+    static constexpr int T = W - CS * NFULL;                        // floats of a sample's tail chunk (head included)
+    static constexpr int NVEC = CS / V, S = TRK_WAVE / NVEC, NP = TRK_WAVE / S;   // vectors per sample, samples per piece, pieces per chunk
+    static constexpr int NVT = T / V;
+    static_assert(T % V == 0 && T >= HX && T <= CS && W >= CS, "row length not supported by the ring geometry");
+    IO* out;                    // nullptr: positions not wanted
+    int64_t base;
+    int rows, lane;
+    float* lds;                 // this wave's ring: [64][LS]
+    unsigned long long g0;      // wave-uniform: address of the wave's first output element
+    bool fast;                  // wave-uniform: full wave and aligned rows -> pieces; else every chunk is copied when complete
+    unsigned long long pieces_on;   // wave-uniform lane mask of the pieces: all lanes, or none (no output / copy path)
+    static __device__ __forceinline__ int head(int smp) { return ALIGNED ? ((-W * smp) & 7) : 0; }
+    // this lane's staging pointers: regular floats go to row_a()[f & 63], the few whose ring slot depends on the head
+    // (f < HX or (f & 63) < HX) to row()[(f - head) & 63], floats f < HX additionally to row()[64 + f]
+    __device__ __forceinline__ float* row() const { return lds + lane * LS; }
+    __device__ __forceinline__ float* row_a() const { return lds + lane * LS - head(lane); }
+    __device__ __forceinline__ int slot(int f) const { return (f - head(lane)) & 63; }
+
+    // chunk C (C == NFULL: the tail) is complete in the ring
+    template <int C>
+    __device__ __forceinline__ void done() const {
+        spec_wave_sync();
+        if (out && !fast) {                                          // ragged last wavefront / unaligned view: plain copy, now
+            if constexpr (C < NFULL) {
+                for (int e = lane; e < rows * CS; e += TRK_WAVE) {
+                    const int smp = e / CS, j = e - smp * CS;
+                    out[(base + smp) * W + head(smp) + CS * C + j] = (IO)lds[smp * LS + ((CS * C + j) & 63)];
+                }
+            } else {
+                for (int e = lane; e < rows * T; e += TRK_WAVE) {
+                    const int smp = e / T, j = e - smp * T, h = head(smp);
+                    if (j < T - h) out[(base + smp) * W + h + CS * NFULL + j] = (IO)lds[smp * LS + ((CS * NFULL + j) & 63)];
+                    else out[(base + smp) * W + (j - (T - h))] = (IO)lds[smp * LS + 64 + (j - (T - h))];
+                }
+            }
+            spec_wave_sync();
+        }
+    }
+    // Store piece K of chunk C.  Straight-line code: the lane mask (nothing when the positions are not wanted or the wave took
+    // the copy path) is applied inside the store's asm block -- 48 wave-uniform branches would cut the FK arithmetic into 48
+    // scheduling regions (measured on the launches WITHOUT positions: +2 us).
+    template <int C, int K>
+    __device__ __forceinline__ void piece() const {
+        static_assert(C >= 0 && C <= NFULL, "no such chunk");
+        if constexpr (K >= 0 && K < NP) {
+            int idx, elem;                                       // LDS float index / output element, both relative to sample K S
+            const unsigned long long mask = pieces_on;
+            if constexpr (C < NFULL) {
+                const int ds = lane / NVEC, v = lane - ds * NVEC;
+                idx = ds * LS + ((CS * C) & 63) + v * V;
+                elem = ds * W + head(ds) + CS * C + v * V;
+            } else {
+                // lanes past the S * NVT vectors of a piece repeat the first lanes' store (same address, same data): no mask
+                const int ln = lane < S * NVT ? lane : lane - S * NVT;
+                const int ds = ln / NVT, v = ln - ds * NVT, h = head(ds), nt = (T - h) / V;
+                const bool ring = v < nt;
+                idx = ds * LS + (ring ? ((CS * NFULL) & 63) + v * V : 64 + (v - nt) * V);
+                elem = ds * W + (ring ? h + CS * NFULL + v * V : (v - nt) * V);
+            }
+            const float* s = lds + K * S * LS + idx;
+            // the piece's offset goes into the per-lane offset (one VALU add): as a scalar add to the base the scheduler hoists
+            // 48 address pairs to the top and spills them (sgpr_spill_count 24 -> 50)
+            const unsigned voff = (unsigned)((elem + K * S * W) * (int)sizeof(IO));
+            if (V == 2) IoQuad<IO>::store_wt2_sm(g0, voff, s[0], s[1], mask);
+            else IoQuad<IO>::store_wt1_sm(g0, voff, s[0], mask);
+        }
+    }
+};
+
+template <int W, int V, bool ALIGNED, class IO>
+__device__ __forceinline__ RingFlusher<W, V, ALIGNED, IO> spec_make_ring(IO* __restrict__ out, int64_t base, int rows, int lane, float* lds) {
+    IO* dst = out + base * W;
+    const bool fast = rows == TRK_WAVE && ((reinterpret_cast<uintptr_t>(dst) & (V * sizeof(IO) - 1)) == 0);
+    const unsigned long long g = (unsigned long long)reinterpret_cast<uintptr_t>(dst);
+    const unsigned long long gu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+    // a ballot is scalar by definition (an SGPR pair): all lanes, or none
+    return RingFlusher<W, V, ALIGNED, IO>{out, base, rows, lane, lds, gu, fast, __builtin_amdgcn_ballot_w64(out != nullptr && fast)};
 }
 
 // mirror of spec_flush_chunk: floats [c0, c0 + NF) of the wave's rows -> lds[smp * LS + ...]; each lane then reads its own row
