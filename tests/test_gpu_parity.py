@@ -976,3 +976,68 @@ def test_empty_batches_everywhere(ops):
     assert c.shape == (0,) and gq_.shape == (0, 8, 7)
     assert ops.interpolate_traj_via_points(torch.empty((0, 8, 7), device=DEV), 5).shape == (0, 35, 7)
     assert float(ops.reduce_sum(torch.empty((0,), device=DEV))) == 0.0
+
+
+def _chain_urdf(path, n_links):
+    """Serial chain in file order == walk order: every third joint revolute (axes cycling x, y, z), the others fixed."""
+    axes = ["1 0 0", "0 1 0", "0 0 1"]
+    lines = ['<?xml version="1.0"?>', f'<robot name="chain{n_links}">', '  <link name="l0"/>']
+    nj = 0
+    for i in range(1, n_links):
+        lines.append(f'  <link name="l{i}"/>')
+        xyz = f"{0.03 + 0.01 * (i % 3):.3f} {0.02 * ((i % 5) - 2):.3f} {0.05 + 0.005 * (i % 4):.3f}"
+        rpy = f"{0.1 * (i % 3):.2f} {-0.07 * (i % 4):.2f} {0.05 * (i % 5):.2f}"
+        if i % 3 == 1:
+            lines += [f'  <joint name="j{i}" type="revolute">', f'    <parent link="l{i - 1}"/><child link="l{i}"/>',
+                      f'    <origin xyz="{xyz}" rpy="{rpy}"/><axis xyz="{axes[nj % 3]}"/>',
+                      '    <limit lower="-2.5" upper="2.5" effort="1" velocity="1"/>', '  </joint>']
+            nj += 1
+        else:
+            lines += [f'  <joint name="j{i}" type="fixed">', f'    <parent link="l{i - 1}"/><child link="l{i}"/>',
+                      f'    <origin xyz="{xyz}" rpy="{rpy}"/>', '  </joint>']
+    lines.append("</robot>")
+    path.write_text("\n".join(lines))
+
+
+@pytest.mark.parametrize("n_links", [27, 28, 34, 44])
+def test_ring_staging_geometries(ops, oracle_lib, tmp_path, n_links):
+    """The ring staging of the link positions (RingFlusher) on rows of 81 floats (odd row: plain ring, 1-float pieces), 84
+    (sector-aligned, heads of period 2), 102 (sector-aligned, three whole chunks, the last of them complete only with the last
+    float) and 132 (plain ring, 2-float pieces, four whole chunks and a 4-float tail): full and ragged wavefronts, fp32 and fp16
+    output, against the fp64 oracle."""
+    from torch_robotics_amd import codegen, jit
+    from torch_robotics_amd.costmodel import CostModelSpec
+    from torch_robotics_amd.environments import EnvSpheres3D
+    from torch_robotics_amd.kinmodel import KinModel
+    urdf = tmp_path / f"chain{n_links}.urdf"
+    _chain_urdf(urdf, n_links)
+    m = KinModel.from_urdf(str(urdf))
+    assert m.n_links == n_links and 3 * n_links > codegen.CHUNKED_STAGING_MIN_FLOATS
+    rp = codegen.ring_plan(3 * n_links)
+    assert (rp.V, rp.aligned, rp.n_full, rp.tail) == {27: (1, False, 2, 17), 28: (2, True, 2, 20), 34: (2, True, 3, 6),
+                                                     44: (2, False, 4, 4)}[n_links]
+    env = EnvSpheres3D(tensor_args=dict(device=DEV, dtype=torch.float32))
+    spec = CostModelSpec(n_links_in=m.n_links)
+    spec.obj_link_idx = np.array([5, 11, n_links - 1], np.int32)
+    spec.obj_link_margin = np.array([0.1, 0.09, 0.08], np.float32)
+    spec.objects = [o.as_object() for o in env.obj_fixed_list]
+    spec.ee_link = m.n_links - 1
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.2, 0.5); spec.ee_target = T
+    spec.validate()
+    h, cm, o = ops.ModelHandle(m), ops.CostHandle(spec, DEV), oracle_lib.Oracle(m, spec)
+    assert jit.specialize_for_cost_spec(m, spec) is not None and h.specialized
+    rng = np.random.default_rng(n_links)
+    for n in (64, 65, 300):
+        q = rng.uniform(-2.5, 2.5, size=(n, m.n_dofs)).astype(np.float32)
+        p64, c64, g64 = o.rollout(q.astype(np.float64), (0, 1, 0, 1), "f64")
+        scale = max(1.0, float(np.abs(p64).max()))
+        pos, c, gq = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), dev(q))
+        assert np.abs(pos.cpu().numpy() - p64).max() / scale < TOL_H, n
+        assert rel_err(c.cpu().numpy(), c64) < TOL_C and rel_err(gq.cpu().numpy(), g64) < TOL_G
+        assert np.abs(ops.fk_positions(h, dev(q)).cpu().numpy() - p64).max() / scale < TOL_H        # positions-only exit
+        _, c_np, gq_np = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), dev(q), want_pos=False)        # the kernel without staging
+        assert rel_err(c_np.cpu().numpy(), c64) < TOL_C and rel_err(gq_np.cpu().numpy(), g64) < TOL_G
+        plan = ops.RolloutPlan(h, cm, (0, 1, 0, 1), dev(q).half().reshape(1, n, m.n_dofs))         # fp16 I/O: 2-byte elements
+        plan.launch(); torch.cuda.synchronize()
+        p16, _, _ = o.rollout(q.astype(np.float16).astype(np.float64), (0, 1, 0, 1), "f64")
+        assert np.abs(plan.link_pos.float().cpu().numpy().reshape(p16.shape) - p16).max() / scale < 2e-3

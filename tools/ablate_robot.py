@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Run-time ablation of a generated rollout kernel (no rebuild): python tools/ablate_robot.py [ur10_allegro|dual_panda|panda]"""
+"""Run-time ablation of a generated rollout kernel (no rebuild): python tools/ablate_robot.py [ur10_allegro|dual_panda|panda]
+[first] [stamps]   -- `first`: only the first configuration; `stamps`: also dump the per-wave phase stamps of that configuration
+to gpurun_out/phase_stamps_<robot>_<k>.npy (read them with tools/phase_analyze.py)."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -34,3 +36,14 @@ for name, w, pos in (("obj+ee, positions", (0, 1, 0, 1), True), ("obj+ee, no pos
     for _ in range(300): plan.launch()
     e1.record(); torch.cuda.synchronize()
     print(f"  {name:30s} {e0.elapsed_time(e1) / 300 * 1e3:7.2f} us")
+    if "stamps" in sys.argv:
+        from torch_robotics_amd._lib import lib
+        nb = ops.n_blocks(B * H)
+        stamps = torch.zeros((nb, 8), device=dev, dtype=torch.int64)
+        lib().trk_debug_set_stamp_buffer(stamps.data_ptr())
+        for _ in range(6): plan.launch()
+        torch.cuda.synchronize()
+        lib().trk_debug_set_stamp_buffer(None)
+        out = Path(__file__).resolve().parent.parent / "gpurun_out"; out.mkdir(exist_ok=True)
+        tag = name.replace(" ", "_").replace(",", "").replace("+", "_")
+        np.save(out / f"phase_stamps_{ident}_{tag}.npy", stamps.cpu().numpy())

@@ -463,7 +463,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 c = pending[0][0]
                 last_slot = min(L - 1, rp.reuse_float(c) // 3 - 1)
                 slots = max(1, last_slot - i + 1)
-                for _ in range(-(-sum(1 for cc, _ in pending if cc == c) // slots)):
+                n = -(-sum(1 for cc, _ in pending if cc == c) // slots)
+                for _ in range(n):
                     cc, kk = pending.pop(0)
                     E.raw(f"    if constexpr (POS) ring.template piece<{cc}, {kk}>();")
             stage_link(0)

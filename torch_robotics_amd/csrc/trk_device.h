@@ -520,11 +520,25 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                     }
                 }
             }
+            // per-lane gather of the winning centre: from the wave's LDS copy when there is one (~100 cycles), else from global
+            // memory (L2 hit, ~700 cycles with every wave of the chip asking at once).  Two separate loops, NOT
+            // `cond ? lds[i] : global[i]`: that is one load through a selected pointer, i.e. a FLAT load, whose
+            // `s_waitcnt vmcnt(0)` also waits for every output store the wave has in flight -- the position stream then
+            // stops at the gather until HBM has taken all of it.
+            float4 Sv[NL];
+            if (lds_spheres && (FAST || C.n_spheres <= TRK_LDS_SPHERES)) {
+                // an explicit LDS pointer: as two generic pointers the compiler sinks both loops' loads into one flat load again
+                typedef __attribute__((address_space(3))) const float lds_cfloat;
+                lds_cfloat* lp = (lds_cfloat*)reinterpret_cast<const float*>(lds_spheres);
+#pragma unroll
+                for (int l = 0; l < NL; ++l) Sv[l] = make_float4(lp[4 * bi[l]], lp[4 * bi[l] + 1], lp[4 * bi[l] + 2], 0.0f);
+            } else {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) Sv[l] = C.spheres[bi[l]];
+            }
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
-                // per-lane gather of the winning centre: from the wave's LDS copy when there is one (~100 cycles),
-                // else from global memory (L2 hit, ~700 cycles with every wave of the chip asking at once)
-                const float4 S = (lds_spheres && (FAST || C.n_spheres <= TRK_LDS_SPHERES)) ? lds_spheres[bi[l]] : C.spheres[bi[l]];
+                const float4 S = Sv[l];
                 const float dx = px[l] - S.x, dy = py[l] - S.y, dz = pz[l] - S.z;
                 const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
                 // torch.norm backward is 0 at p == c: with n2 floored, d * inv = 0 * 1.8e19 = 0 there (and n2 * inv = 0)

@@ -438,31 +438,47 @@ struct RingFlusher {
     // Store piece K of chunk C.  Straight-line code: the lane mask (nothing when the positions are not wanted or the wave took
     // the copy path) is applied inside the store's asm block -- 48 wave-uniform branches would cut the FK arithmetic into 48
     // scheduling regions (measured on the launches WITHOUT positions: +2 us).
+    // A piece in two halves (ring read, store).  Reading a piece one slot before storing it, so that the LDS latency hides behind
+    // a link's arithmetic, was measured: no change (32.2 vs 31.9 us) -- the stores, not the reads, are what the wave waits for.
+    struct Vec { float a, b; };
+    template <int C>
+    __device__ __forceinline__ void lane_map(int& idx, int& elem) const {      // LDS float index / output element, relative to sample K S
+        if constexpr (C < NFULL) {
+            const int ds = lane / NVEC, v = lane - ds * NVEC;
+            idx = ds * LS + ((CS * C) & 63) + v * V;
+            elem = ds * W + head(ds) + CS * C + v * V;
+        } else {
+            // lanes past the S * NVT vectors of a piece repeat the first lanes' store (same address, same data): no mask
+            const int ln = lane < S * NVT ? lane : lane - S * NVT;
+            const int ds = ln / NVT, v = ln - ds * NVT, h = head(ds), nt = (T - h) / V;
+            const bool ring = v < nt;
+            idx = ds * LS + (ring ? ((CS * NFULL) & 63) + v * V : 64 + (v - nt) * V);
+            elem = ds * W + (ring ? h + CS * NFULL + v * V : (v - nt) * V);
+        }
+    }
+    template <int C, int K>
+    __device__ __forceinline__ Vec fetch() const {
+        static_assert(C >= 0 && C <= NFULL && K >= 0 && K < NP, "no such piece");
+        int idx, elem;
+        lane_map<C>(idx, elem);
+        const float* s = lds + K * S * LS + idx;
+        return Vec{s[0], V == 2 ? s[1] : 0.0f};
+    }
+    template <int C, int K>
+    __device__ __forceinline__ void store(const Vec& x) const {
+        int idx, elem;
+        lane_map<C>(idx, elem);
+        // the piece's offset goes into the per-lane offset (one VALU add): as a scalar add to the base the scheduler hoists
+        // 48 address pairs to the top and spills them (sgpr_spill_count 24 -> 50)
+        const unsigned voff = (unsigned)((elem + K * S * W) * (int)sizeof(IO));
+        if (V == 2) IoQuad<IO>::store_wt2_sm(g0, voff, x.a, x.b, pieces_on);
+        else IoQuad<IO>::store_wt1_sm(g0, voff, x.a, pieces_on);
+    }
+    // Store piece K of chunk C.  Straight-line code: the lane mask (nothing when the wave took the copy path) is applied inside
+    // the store's asm block -- 48 wave-uniform branches would cut the FK arithmetic into 48 scheduling regions.
     template <int C, int K>
     __device__ __forceinline__ void piece() const {
-        static_assert(C >= 0 && C <= NFULL, "no such chunk");
-        if constexpr (K >= 0 && K < NP) {
-            int idx, elem;                                       // LDS float index / output element, both relative to sample K S
-            const unsigned long long mask = pieces_on;
-            if constexpr (C < NFULL) {
-                const int ds = lane / NVEC, v = lane - ds * NVEC;
-                idx = ds * LS + ((CS * C) & 63) + v * V;
-                elem = ds * W + head(ds) + CS * C + v * V;
-            } else {
-                // lanes past the S * NVT vectors of a piece repeat the first lanes' store (same address, same data): no mask
-                const int ln = lane < S * NVT ? lane : lane - S * NVT;
-                const int ds = ln / NVT, v = ln - ds * NVT, h = head(ds), nt = (T - h) / V;
-                const bool ring = v < nt;
-                idx = ds * LS + (ring ? ((CS * NFULL) & 63) + v * V : 64 + (v - nt) * V);
-                elem = ds * W + (ring ? h + CS * NFULL + v * V : (v - nt) * V);
-            }
-            const float* s = lds + K * S * LS + idx;
-            // the piece's offset goes into the per-lane offset (one VALU add): as a scalar add to the base the scheduler hoists
-            // 48 address pairs to the top and spills them (sgpr_spill_count 24 -> 50)
-            const unsigned voff = (unsigned)((elem + K * S * W) * (int)sizeof(IO));
-            if (V == 2) IoQuad<IO>::store_wt2_sm(g0, voff, s[0], s[1], mask);
-            else IoQuad<IO>::store_wt1_sm(g0, voff, s[0], mask);
-        }
+        if constexpr (K >= 0 && K < NP) store<C, K>(fetch<C, K>());
     }
 };
 
