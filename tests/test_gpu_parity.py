@@ -999,12 +999,13 @@ def _chain_urdf(path, n_links):
     path.write_text("\n".join(lines))
 
 
-@pytest.mark.parametrize("n_links", [27, 28, 34, 44])
+@pytest.mark.parametrize("n_links", [27, 28, 32, 34, 43, 44])
 def test_ring_staging_geometries(ops, oracle_lib, tmp_path, n_links):
-    """The ring staging of the link positions (RingFlusher) on rows of 81 floats (odd row: plain ring, 1-float pieces), 84
-    (sector-aligned, heads of period 2), 102 (sector-aligned, three whole chunks, the last of them complete only with the last
-    float) and 132 (plain ring, 2-float pieces, four whole chunks and a 4-float tail): full and ragged wavefronts, fp32 and fp16
-    output, against the fp64 oracle."""
+    """The ring staging of the link positions (RingFlusher) on rows of 81 floats (odd row: heads of period 8, tail units that end
+    inside a 2-float vector), 84 (heads 0 / 4), 96 (rows that are whole sectors: no heads, a full-chunk tail), 102 (three whole
+    chunks, the last of them complete only with the last float), 129 (the tail unit would not fit: unaligned ring, 1-float pieces)
+    and 132 (four whole chunks, tail units of 8 and 0 floats): full and ragged wavefronts, fp32 and fp16 output, against the
+    fp64 oracle."""
     from torch_robotics_amd import codegen, jit
     from torch_robotics_amd.costmodel import CostModelSpec
     from torch_robotics_amd.environments import EnvSpheres3D
@@ -1014,8 +1015,9 @@ def test_ring_staging_geometries(ops, oracle_lib, tmp_path, n_links):
     m = KinModel.from_urdf(str(urdf))
     assert m.n_links == n_links and 3 * n_links > codegen.CHUNKED_STAGING_MIN_FLOATS
     rp = codegen.ring_plan(3 * n_links)
-    assert (rp.V, rp.aligned, rp.n_full, rp.tail) == {27: (1, False, 2, 17), 28: (2, True, 2, 20), 34: (2, True, 3, 6),
-                                                     44: (2, False, 4, 4)}[n_links]
+    assert (rp.V, rp.aligned, rp.hx, rp.n_full, rp.tail) == {27: (2, True, 7, 2, 17), 28: (2, True, 4, 2, 20), 32: (2, True, 0, 2, 32),
+                                                            34: (2, True, 6, 3, 6), 43: (1, False, 0, 4, 1),
+                                                            44: (2, True, 4, 4, 4)}[n_links]
     env = EnvSpheres3D(tensor_args=dict(device=DEV, dtype=torch.float32))
     spec = CostModelSpec(n_links_in=m.n_links)
     spec.obj_link_idx = np.array([5, 11, n_links - 1], np.int32)

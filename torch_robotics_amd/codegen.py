@@ -294,7 +294,7 @@ def _emit_joint_gradient(E: "Emitter", kin: KinModel, i: int, R, t, Fi, Ti, mask
 
 
 def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, List[str]], rot_adj: Dict[int, str], masked,
-                        tick=None) -> Dict[int, S]:
+                        tick=None, order=None) -> Dict[int, S]:
     """Reverse pass of the link kernels: per-link wrench accumulators (F, T about the world origin) pushed towards the
     root; `tb_names[i]` = the three C expressions holding link i's position adjoint; a tracked link i adds
     axial(Rb R^T) with Rb = the 9-float array named rot_adj[i]."""
@@ -302,8 +302,9 @@ def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, L
     F: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
     T: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
     gq_expr: Dict[int, S] = {}
+    order = kin.order if order is None else order       # any order with parents before children (walked backwards here)
     for p in range(L - 1, 0, -1):
-        i = int(kin.order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
+        i = int(order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
         E.raw(f"    // reverse: link {i}")
         if tick is not None and p % 2 == 0:
             E.raw(tick())                       # a callable: every tick carries its own compile-time chunk number
@@ -367,7 +368,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"namespace spec_{ident} {{")
     out.append(f"constexpr int L = {L}, D = {D}, NL = {NL};")
     out.append(f'static_assert(TRK_OBJ_TICK_SLOTS == {OBJ_TICK_SLOTS}, "chunk numbering of this unit assumes another TRK_OBJ_TICK_SLOTS");')
-    chunked = 3 * L > CHUNKED_STAGING_MIN_FLOATS and [int(v) for v in kin.order] == list(range(L))
+    # the walk: file order when that puts every parent before its children (then a link's floats are staged where they sit in
+    # the output row, which is what the ring staging needs), else the model's DFS pre-order
+    walk = list(range(L)) if all(int(kin.parent[i]) < i for i in range(1, L)) else [int(v) for v in kin.order]
+    chunked = 3 * L > CHUNKED_STAGING_MIN_FLOATS and walk == list(range(L))
     if chunked:
         # ring staging: the pieces of the whole chunks leave between the links that follow them; the tail chunk's pieces are what
         # the objectives' tick slots issue (flush.chunk<CH>() -> RingTail)
@@ -392,7 +396,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw("template <class IO>      // HBM-side type of q / link_pos / gq: float or _Float16")
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
         if chunked:
-            E.raw(f"    constexpr int LDS_LANE = POS ? {max(64 + rp.hx + 1, D)} : {D};")
+            E.raw(f"    constexpr int LDS_LANE = POS ? {max(rp.stride, D)} : {D};")
             lds_lane = "LDS_LANE"
         else:
             lds_lane = max(3 * L, D)
@@ -426,14 +430,13 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             # CU.  The positions go through a 64-float ring per lane instead (RingFlusher): each link is staged as it exists, a
             # complete 32-float chunk leaves piece by piece between the links that fill the other half of the ring.
             W = 3 * L
-            E.raw(f"    static_assert({ring_t}::LS == {64 + rp.hx + 1} && {ring_t}::NFULL == {rp.n_full} && {ring_t}::NP == {rp.pieces}, "
+            E.raw(f"    static_assert({ring_t}::LS == {rp.stride} && {ring_t}::HX == {rp.hx} && {ring_t}::NFULL == {rp.n_full} && {ring_t}::NP == {rp.pieces}, "
                   '"generator and RingFlusher disagree on the ring geometry");')
             E.raw(f"    const {ring_t} ring = spec_make_ring<{rp.W}, {rp.V}, {'true' if rp.aligned else 'false'}, IO>("
                   "static_cast<IO*>(A.link_pos), base, rows, lane, lds);")
             E.raw("    float* const prow = ring.row();        // this lane's ring; prow_a: the same, shifted by the lane's head")
             E.raw("    float* const prow_a = ring.row_a();")
             E.raw("    spec_wave_sync();")
-            assert [int(v) for v in kin.order] == list(range(L)), "ring staging needs file order == walk order"
             ready_at: Dict[int, List[int]] = {}
             for c in range(rp.n_full + 1):
                 ready_at.setdefault(rp.ready_float(c), []).append(c)
@@ -470,7 +473,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             stage_link(0)
             issue_pieces(0)
         for p in range(1, L):
-            i = int(kin.order[p])
+            i = walk[p]
             _emit_fk_link(E, kin, i, R, t, passv, snap)
             if chunked:
                 stage_link(i)
@@ -579,7 +582,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # (A second FK walk with prefix-sum gradients instead of this reverse pass -- so that the joints' axes / origins need not
         # stay alive -- was measured on UR10+Allegro: 41.3 vs 37.5 us.  These kernels are bound by VALU issue, not by occupancy.)
         gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"tb{i}_{k}" for k in range(3)] for i in adj_links},
-                                      {l: rb for l, _, rb in tracked}, masked, tick=tick_line)
+                                      {l: rb for l, _, rb in tracked}, masked, tick=tick_line, order=walk)
         E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
         E.raw(f"    flush.template rest<{next_chunk[0]}>();")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
@@ -839,22 +842,20 @@ LINK_OBJ_GROUP_MAX = 12    # link kernels: up to this many collision links are s
 LINK_OBJ_GROUP = 5         # ... more are split into groups of about this size
 CHUNK_FLOATS = 36          # 12 columns: 144 B per sample and chunk, a multiple of 16 B
 RING_FLOATS = 32           # link kernels with ring staging (RingFlusher in trk_spec_common.h): floats per chunk
-RING_HEAD_MAX = 6          # sector-aligned rings: the longest head ((-W s) mod 8 for even W)
-
-
 @dataclass
 class RingPlan:
     """Geometry of RingFlusher<W, V, ALIGNED, IO> (mirrors its constants; see the comment there)."""
     W: int
     V: int
     aligned: bool
+    hx: int                 # longest head
     n_full: int
-    tail: int               # floats of the tail chunk
+    tail: int               # floats of a sample's tail + head
     pieces: int             # store instructions per chunk
 
     @property
-    def hx(self) -> int:
-        return RING_HEAD_MAX if self.aligned else 0
+    def stride(self) -> int:
+        return (64 + self.hx) | 1
 
     def ready_float(self, c: int) -> int:
         """chunk c is complete in every lane's ring once this float has been staged"""
@@ -871,10 +872,15 @@ class RingPlan:
 
 def ring_plan(W: int) -> RingPlan:
     assert W >= RING_FLOATS
-    aligned = W % 2 == 0 and ((W - RING_HEAD_MAX) % RING_FLOATS) + RING_HEAD_MAX <= RING_FLOATS
+    g = W % 8
+    hx = 0 if g == 0 else (7 if g % 2 else (4 if g == 4 else 6))
+    n_full = (W - max(hx, 1)) // RING_FLOATS
+    tail = W - RING_FLOATS * n_full
+    if tail + (8 - g if g else 0) <= RING_FLOATS:        # the longest tail unit (tail of row s + head of row s + 1) fits a chunk
+        return RingPlan(W=W, V=2, aligned=True, hx=hx, n_full=n_full, tail=tail, pieces=16)
     V = 2 if W % 2 == 0 else 1
-    n_full = (W - RING_HEAD_MAX) // RING_FLOATS if aligned else (W - 1) // RING_FLOATS
-    return RingPlan(W=W, V=V, aligned=aligned, n_full=n_full, tail=W - RING_FLOATS * n_full, pieces=64 // (64 // (RING_FLOATS // V)))
+    n_full = (W - 1) // RING_FLOATS
+    return RingPlan(W=W, V=V, aligned=False, hx=0, n_full=n_full, tail=W - RING_FLOATS * n_full, pieces=64 // (64 // (RING_FLOATS // V)))
 
 
 OBJ_GROUP = 6              # points evaluated against the scene together (register arrays of this size)

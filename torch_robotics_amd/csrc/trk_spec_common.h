@@ -377,30 +377,33 @@ __device__ __forceinline__ void spec_flush_chunk(IO* __restrict__ out, int64_t b
 // leaves as single store instructions ("pieces") that the generator spreads over the code that follows -- the links that fill
 // the other half of the ring, then the objectives.
 //
-// Sector alignment (ALIGNED, rows of an even number of floats): a row of W floats starts at byte 4 W s, in general in the
-// middle of a 32-byte HBM sector, so fixed column chunks [32c, 32c + 32) split two sectors per sample and chunk between
-// different store instructions (measured: WRITE_SIZE 137 MB for 118 MB of output).  Instead sample s owns a HEAD of
-// h(s) = (-W s) mod 8 floats -- the part of its row that shares a sector with the end of row s - 1 -- and its chunk c is the
-// floats [h + 32c, h + 32c + 32): four whole sectors.  Ring position of float f: (f - h) & 63.  What is left, the TAIL chunk,
-// is the last T - h floats of the row plus the head (T floats per sample whatever h is); a tail piece holds S consecutive
-// samples, S a multiple of the period of h, so the head of row s and the end of row s - 1 leave in the SAME instruction and
-// every sector is written exactly once.  The head floats are kept twice (ring + HX extra floats per lane) because their ring
-// slots are overwritten before the tail leaves.
+// Sector alignment (ALIGNED): a row of W floats starts at byte 4 W s, in general in the middle of a 32-byte HBM sector, so
+// fixed column chunks [32c, 32c + 32) split two sectors per sample and chunk between different store instructions (measured:
+// WRITE_SIZE 137 MB for 118 MB of output).  Instead sample s owns a HEAD of h(s) = (-W s) mod 8 floats -- the part of its row
+// that shares a sector with the end of row s - 1 -- and its chunk c is the floats [h + 32c, h + 32c + 32): four whole sectors.
+// Ring position of float f: (f - h) & 63.  What is left of a row is its TAIL, T - h floats; the tail of row s and the head of
+// row s + 1 are contiguous in memory and together a whole number of sectors (T - g or T - g + 8 floats, g = W mod 8), and they
+// leave together as one UNIT: every sector of the output is written exactly once, by one instruction.  The head floats are
+// kept twice (ring + HX extra floats per lane) because their ring slots are overwritten before the tail leaves; a unit reads the
+// head from the NEXT lane's row.
 //
-// Piece K of a chunk covers the S = 64 / (32 / V) samples [K S, K S + S); lane -> (sample lane / NVEC, vector lane % NVEC) is
-// the same for every piece, so a piece costs two scalar adds, an LDS read at an immediate offset and one store with an SGPR base.
+// Piece K of a chunk covers the S = 64 / (32 / V) samples [K S, K S + S), lane -> (sample lane / NVEC, vector lane % NVEC): a
+// piece costs a few integer instructions, an LDS read at an immediate offset and one store with an SGPR base.
+// Unaligned rings (ALIGNED = false: h = 0 everywhere) serve the row lengths whose tail unit would exceed a chunk.
 template <int W, int V, bool ALIGNED, class IO>
 struct RingFlusher {
     static_assert(V == 1 || V == 2, "ring pieces are 1- or 2-float vectors (the ring stride is odd)");
-    static_assert(!ALIGNED || (V == 2 && W % 2 == 0), "sector alignment needs rows of an even number of floats");
+    static_assert(!ALIGNED || V == 2, "sector-aligned chunks leave as 2-float vectors");
     static constexpr int CS = 32;                                   // floats per chunk
-    static constexpr int HX = ALIGNED ? 6 : 0;                      // longest head
-    static constexpr int LS = 64 + HX + 1;                          // per-lane stride: odd -> the per-lane row writes are conflict-free
-    static constexpr int NFULL = ALIGNED ? (W - HX) / CS : (W - 1) / CS;     // whole chunks of every sample
-    static constexpr int T = W - CS * NFULL;                        // floats of a sample's tail chunk (head included)
+    static constexpr int G = W % 8;                                 // a row start advances by G floats within its sector
+    static constexpr int HX = !ALIGNED || G == 0 ? 0 : (G % 2 ? 7 : (G == 4 ? 4 : 6));   // longest head
+    static constexpr int LS = (64 + HX) | 1;                        // per-lane stride: odd -> the per-lane row writes are conflict-free
+    static constexpr int NFULL = (W - (HX > 1 ? HX : 1)) / CS;      // whole chunks of every sample (the tail is never empty)
+    static constexpr int T = W - CS * NFULL;                        // floats of a sample's tail + head
     static constexpr int NVEC = CS / V, S = TRK_WAVE / NVEC, NP = TRK_WAVE / S;   // vectors per sample, samples per piece, pieces per chunk
-    static constexpr int NVT = T / V;
-    static_assert(T % V == 0 && T >= HX && T <= CS && W >= CS, "row length not supported by the ring geometry");
+    static constexpr int UMAX = ALIGNED && G ? T - G + 8 : T;       // longest tail unit
+    static constexpr int NVT = (UMAX + V - 1) / V;
+    static_assert(UMAX % V == 0 && T >= HX && UMAX <= CS && W >= CS, "row length not supported by the ring geometry");
     IO* out;                    // nullptr: positions not wanted
     int64_t base;
     int rows, lane;
@@ -425,7 +428,7 @@ struct RingFlusher {
                     const int smp = e / CS, j = e - smp * CS;
                     out[(base + smp) * W + head(smp) + CS * C + j] = (IO)lds[smp * LS + ((CS * C + j) & 63)];
                 }
-            } else {
+            } else {                                                 // every sample writes its own tail and its own head
                 for (int e = lane; e < rows * T; e += TRK_WAVE) {
                     const int smp = e / T, j = e - smp * T, h = head(smp);
                     if (j < T - h) out[(base + smp) * W + h + CS * NFULL + j] = (IO)lds[smp * LS + ((CS * NFULL + j) & 63)];
@@ -437,48 +440,41 @@ struct RingFlusher {
     }
     // Store piece K of chunk C.  Straight-line code: the lane mask (nothing when the positions are not wanted or the wave took
     // the copy path) is applied inside the store's asm block -- 48 wave-uniform branches would cut the FK arithmetic into 48
-    // scheduling regions (measured on the launches WITHOUT positions: +2 us).
-    // A piece in two halves (ring read, store).  Reading a piece one slot before storing it, so that the LDS latency hides behind
-    // a link's arithmetic, was measured: no change (32.2 vs 31.9 us) -- the stores, not the reads, are what the wave waits for.
-    struct Vec { float a, b; };
-    template <int C>
-    __device__ __forceinline__ void lane_map(int& idx, int& elem) const {      // LDS float index / output element, relative to sample K S
-        if constexpr (C < NFULL) {
-            const int ds = lane / NVEC, v = lane - ds * NVEC;
-            idx = ds * LS + ((CS * C) & 63) + v * V;
-            elem = ds * W + head(ds) + CS * C + v * V;
-        } else {
-            // lanes past the S * NVT vectors of a piece repeat the first lanes' store (same address, same data): no mask
-            const int ln = lane < S * NVT ? lane : lane - S * NVT;
-            const int ds = ln / NVT, v = ln - ds * NVT, h = head(ds), nt = (T - h) / V;
-            const bool ring = v < nt;
-            idx = ds * LS + (ring ? ((CS * NFULL) & 63) + v * V : 64 + (v - nt) * V);
-            elem = ds * W + (ring ? h + CS * NFULL + v * V : (v - nt) * V);
-        }
-    }
-    template <int C, int K>
-    __device__ __forceinline__ Vec fetch() const {
-        static_assert(C >= 0 && C <= NFULL && K >= 0 && K < NP, "no such piece");
-        int idx, elem;
-        lane_map<C>(idx, elem);
-        const float* s = lds + K * S * LS + idx;
-        return Vec{s[0], V == 2 ? s[1] : 0.0f};
-    }
-    template <int C, int K>
-    __device__ __forceinline__ void store(const Vec& x) const {
-        int idx, elem;
-        lane_map<C>(idx, elem);
-        // the piece's offset goes into the per-lane offset (one VALU add): as a scalar add to the base the scheduler hoists
-        // 48 address pairs to the top and spills them (sgpr_spill_count 24 -> 50)
-        const unsigned voff = (unsigned)((elem + K * S * W) * (int)sizeof(IO));
-        if (V == 2) IoQuad<IO>::store_wt2_sm(g0, voff, x.a, x.b, pieces_on);
-        else IoQuad<IO>::store_wt1_sm(g0, voff, x.a, pieces_on);
-    }
-    // Store piece K of chunk C.  Straight-line code: the lane mask (nothing when the wave took the copy path) is applied inside
-    // the store's asm block -- 48 wave-uniform branches would cut the FK arithmetic into 48 scheduling regions.
+    // scheduling regions (measured on the launches WITHOUT positions: +2 us).  The piece's offset goes into the per-lane offset
+    // (one VALU add): as a scalar add to the base the scheduler hoists 48 address pairs to the top and spills them.
+    // Reading a piece one slot before storing it, so that the LDS latency hides behind a link's arithmetic, was measured: no
+    // change (32.2 vs 31.9 us) -- the stores, not the reads, are what the wave waits for.
     template <int C, int K>
     __device__ __forceinline__ void piece() const {
-        if constexpr (K >= 0 && K < NP) store<C, K>(fetch<C, K>());
+        static_assert(C >= 0 && C <= NFULL, "no such chunk");
+        if constexpr (K >= 0 && K < NP) {
+            const float* r0 = lds + K * S * LS;                      // row of the piece's first sample
+            if constexpr (C < NFULL) {
+                const int ds = lane / NVEC, v = lane - ds * NVEC;
+                const float* s = r0 + ds * LS + ((CS * C) & 63) + v * V;
+                const int elem = (K * S + ds) * W + head(K * S + ds) + CS * C + v * V;
+                put(elem, s[0], V == 2 ? s[1] : 0.0f, pieces_on);
+            } else {
+                // tail unit of sample s = K S + ds: its last T - h(s) floats, then the head of row s + 1 (contiguous in memory)
+                const int dq = lane / NVT, v = lane - dq * NVT;
+                const int ds = dq < S ? dq : S - 1;                  // lanes past the piece's S units are masked off; keep their reads in range
+                const int h = head(K * S + ds), hn = (K * S + ds + 1 < TRK_WAVE) ? head(K * S + ds + 1) : 0;
+                const int nt = T - h;                                // floats that come from this row's ring
+                const int j = v * V;
+                const float* own = r0 + ds * LS;
+                const float* nxt = own + LS + 64;                    // the next lane's head copy
+                const float a = j < nt ? own[(CS * NFULL + j) & 63] : nxt[j - nt];
+                const float b = V == 2 ? (j + 1 < nt ? own[(CS * NFULL + j + 1) & 63] : nxt[j + 1 - nt]) : 0.0f;
+                const bool on = dq < S && j < nt + hn;
+                const int elem = (K * S + ds) * W + h + CS * NFULL + j;
+                put(elem, a, b, pieces_on & __builtin_amdgcn_ballot_w64(on));
+            }
+        }
+    }
+    __device__ __forceinline__ void put(int elem, float a, float b, unsigned long long mask) const {
+        const unsigned voff = (unsigned)(elem * (int)sizeof(IO));
+        if (V == 2) IoQuad<IO>::store_wt2_sm(g0, voff, a, b, mask);
+        else IoQuad<IO>::store_wt1_sm(g0, voff, a, mask);
     }
 };
 
