@@ -607,8 +607,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    float q[D];")
         E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
-        E.raw(f"    float gp[{3 * L}];                       // this sample's position adjoints, link-major")
-        E.raw(f"    spec_load_q<{3 * L}>(static_cast<const float*>(A.link_pos), base, rows, lane, lds, gp);")
+        early = 3 * L <= 48        # the loads in flight cost 3L/4 registers per lane: only for the small arms
+        if early:
+            E.raw(f"    // the position adjoints are needed only by the reverse pass: their loads are in flight during the forward pass")
+            E.raw(f"    const RowsInFlight<{3 * L}> gp_rows = spec_load_rows_issue<{3 * L}>(static_cast<const float*>(A.link_pos), base, rows, lane);")
         R = {}; t = {}; passv = {}
         if base_identity:
             R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
@@ -619,6 +621,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         _emit_angles(E, kin)
         for p in range(1, L):
             _emit_fk_link(E, kin, int(kin.order[p]), R, t, passv, snap)
+        E.raw(f"    float gp[{3 * L}];                       // this sample's position adjoints, link-major")
+        if early:
+            E.raw(f"    spec_load_rows_finish<{3 * L}>(gp_rows, static_cast<const float*>(A.link_pos), base, rows, lane, lds, gp);")
+        else:
+            E.raw(f"    spec_load_q<{3 * L}>(static_cast<const float*>(A.link_pos), base, rows, lane, lds, gp);")
         gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"gp[{3 * i + k}]" for k in range(3)] for i in range(1, L)}, {}, masked)
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D>(static_cast<float*>(A.gq), base, rows, lane, lds, gv);")

@@ -230,6 +230,44 @@ __device__ __forceinline__ void spec_load_q(const IO* __restrict__ q, int64_t ba
     spec_wave_sync();
 }
 
+// spec_load_q in two halves: `issue` starts the wave's 16-byte loads (held in registers, nothing waits), `finish` runs the LDS
+// transpose.  Whatever the kernel computes in between overlaps the HBM latency (k_posbwd: the forward pass needs only q, the
+// adjoint rows are not touched before the reverse pass).
+template <int D>
+struct RowsInFlight {
+    static constexpr int NV = TRK_WAVE * D / 4, NJ = (NV + TRK_WAVE - 1) / TRK_WAVE;
+    float4 v[NJ];
+    bool fast;
+};
+template <int D, class IO>
+__device__ __forceinline__ RowsInFlight<D> spec_load_rows_issue(const IO* __restrict__ in, int64_t base, int rows, int lane) {
+    RowsInFlight<D> r;
+    const IO* src = in + base * D;
+    r.fast = rows == TRK_WAVE && (TRK_WAVE * D) % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) & IoQuad<IO>::kAlignMask) == 0);
+#pragma unroll
+    for (int j = 0; j < RowsInFlight<D>::NJ; ++j) {
+        const int k = lane + TRK_WAVE * j;
+        r.v[j] = (r.fast && k < RowsInFlight<D>::NV) ? IoQuad<IO>::load(src, k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    return r;
+}
+template <int D, class IO>
+__device__ __forceinline__ void spec_load_rows_finish(const RowsInFlight<D>& r, const IO* __restrict__ in, int64_t base, int rows,
+                                                      int lane, float* lds, float (&qv)[D]) {
+    if (!r.fast) { spec_load_q<D>(in, base, rows, lane, lds, qv); return; }      // ragged / unaligned: the one-step path, now
+    spec_wave_sync();
+    float4* lds4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int j = 0; j < RowsInFlight<D>::NJ; ++j) {
+        const int k = lane + TRK_WAVE * j;
+        if (k < RowsInFlight<D>::NV) lds4[k] = r.v[j];
+    }
+    spec_wave_sync();
+#pragma unroll
+    for (int j = 0; j < D; ++j) qv[j] = lds[lane * D + j];
+    spec_wave_sync();
+}
+
 template <int D, class IO>
 __device__ __forceinline__ void spec_store_gq(IO* __restrict__ gq, int64_t base, int rows, int lane,
                                               float* lds, const float (&gv)[D]) {
