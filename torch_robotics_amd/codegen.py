@@ -346,6 +346,7 @@ def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, L
 
 
 TRK_WAVE_ = 64
+JAC_DIRECT_MAX_DOFS = 16    # k_jac: robots up to this many DOF write their columns straight into the output tiles (Panda 17.0 -> 13.1 us, dual Panda 34.6 -> 27.3)
 # tick slots handed to one scene evaluation (csrc/trk_device.h: TRK_OBJ_TICK_SLOTS must agree)
 OBJ_TICK_SLOTS = int(os.environ.get("TRK_EXP_OBJ_SLOTS", "5"))
 
@@ -693,13 +694,19 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     jac_joints = [i for i in range(1, L) if int(kin.dof_idx[i]) >= 0 and int(kin.jac_axis[i]) >= 0]
     NJ = len(jac_joints)
     RS = (6 * NJ + 3) | 1
-    JAC_LDS = max(RS, D)
+    # Small arms: the lane writes its columns straight into two [64][3D] output tiles (static offsets; non-ancestor columns stay
+    # zero), finishes z x (p_link - p_joint) in place, and the read-out is a contiguous 16-byte copy.  The record scheme below
+    # needs less LDS when the target link has few ancestors among many joints (a finger tip of UR10+Allegro: 10 of 22), but its
+    # read-out maps every output element through the slot table at run time -- half of the Panda kernel's time.
+    direct = D <= JAC_DIRECT_MAX_DOFS
+    JAC_LDS = 6 * D if direct else max(RS, D)
     for base_identity in (True, False):
         E = Emitter()
         kname = "k_jac_bi" if base_identity else "k_jac_bg"
         E.raw(f"__global__ void __launch_bounds__(TRK_WAVE) {kname}(SpecArgs A) {{")
         E.raw("    extern __shared__ __attribute__((aligned(16))) float lds[];     // 64 x max(record stride, D) floats + the slot table")
-        E.raw("    const int rstride = (6 * A.jac_n_cols + 3) | 1;       // records only for the joints that get a column")
+        if not direct:
+            E.raw("    const int rstride = (6 * A.jac_n_cols + 3) | 1;       // records only for the joints that get a column")
         E.raw("    const int lane = threadIdx.x;")
         E.raw("    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
@@ -730,8 +737,15 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         if len(rot_dofs) % 2:
             d = rot_dofs[-1]
             E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
-        E.raw("    float* rec = lds + lane * rstride;")
-        E.raw("    spec_wave_sync();                  // the q transpose is done with this LDS")
+        if direct:
+            E.raw(f"    float* lin_row = lds + lane * {3 * D};                       // this sample's row of the two [64][3D] output tiles")
+            E.raw(f"    float* ang_row = lds + TRK_WAVE * {3 * D} + lane * {3 * D};")
+            E.raw("    spec_wave_sync();                  // the q transpose is done with this LDS")
+            E.raw("#pragma unroll")
+            E.raw(f"    for (int k = 0; k < {3 * D}; ++k) {{ lin_row[k] = 0.0f; ang_row[k] = 0.0f; }}")
+        else:
+            E.raw("    float* rec = lds + lane * rstride;")
+            E.raw("    spec_wave_sync();                  // the q transpose is done with this LDS")
         E.raw("    float eR[9] = {1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f}, et[3] = {0.0f, 0.0f, 0.0f};")
 
         def capture(i):
@@ -747,16 +761,33 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             if i in jac_joints:
                 d, ax = int(kin.dof_idx[i]), int(kin.jac_axis[i])
                 vals = [E.expr(R[i][r][ax]) for r in range(3)] + [E.expr(t[i][r]) for r in range(3)]
-                body = " ".join(f"j[{r}] = {v};" for r, v in enumerate(vals))
-                E.raw(f"    if (A.jac_slot[{d}] >= 0) {{ float* j = rec + 6 * A.jac_slot[{d}]; {body} }}      // wave-uniform")
+                if direct:      # the axis is final (angular rows); the joint origin waits in the linear rows for the link's position
+                    body = " ".join([f"ang_row[{r * D + d}] = {vals[r]};" for r in range(3)] +
+                                    [f"lin_row[{r * D + d}] = {vals[3 + r]};" for r in range(3)])
+                    E.raw(f"    if (A.jac_slot[{d}] >= 0) {{ {body} }}      // wave-uniform")
+                else:
+                    body = " ".join(f"j[{r}] = {v};" for r, v in enumerate(vals))
+                    E.raw(f"    if (A.jac_slot[{d}] >= 0) {{ float* j = rec + 6 * A.jac_slot[{d}]; {body} }}      // wave-uniform")
             capture(i)
         E.raw("    } while (0);")
-        E.raw("    rec[6 * A.jac_n_cols] = et[0]; rec[6 * A.jac_n_cols + 1] = et[1]; rec[6 * A.jac_n_cols + 2] = et[2];")
-        E.raw(f"    int* slot = reinterpret_cast<int*>(lds + TRK_WAVE * max(rstride, {D}));")
-        for d in range(D):
-            E.raw(f"    if (lane == {d}) slot[{d}] = A.jac_slot[{d}];")
-        E.raw("    spec_wave_sync();")
-        E.raw("    trk_jac_readout(lds, slot, rstride, A.jac_n_cols, D, rows, A.jac_lin + base * 3 * D, A.jac_ang + base * 3 * D, lane);")
+        if direct:
+            for i in jac_joints:
+                d = int(kin.dof_idx[i])
+                E.raw(f"    if (A.jac_slot[{d}] >= 0) {{      // wave-uniform: lin = z x (p_link - p_joint)")
+                E.raw(f"        const float z0 = ang_row[{d}], z1 = ang_row[{D + d}], z2 = ang_row[{2 * D + d}];")
+                E.raw(f"        const float r0 = et[0] - lin_row[{d}], r1 = et[1] - lin_row[{D + d}], r2 = et[2] - lin_row[{2 * D + d}];")
+                E.raw(f"        lin_row[{d}] = z1 * r2 - z2 * r1; lin_row[{D + d}] = z2 * r0 - z0 * r2; lin_row[{2 * D + d}] = z0 * r1 - z1 * r0;")
+                E.raw("    }")
+            E.raw("    spec_wave_sync();")
+            E.raw(f"    spec_store_tile<{3 * D}>(A.jac_lin, base, rows, lane, lds);")
+            E.raw(f"    spec_store_tile<{3 * D}>(A.jac_ang, base, rows, lane, lds + TRK_WAVE * {3 * D});")
+        else:
+            E.raw("    rec[6 * A.jac_n_cols] = et[0]; rec[6 * A.jac_n_cols + 1] = et[1]; rec[6 * A.jac_n_cols + 2] = et[2];")
+            E.raw(f"    int* slot = reinterpret_cast<int*>(lds + TRK_WAVE * max(rstride, {D}));")
+            for d in range(D):
+                E.raw(f"    if (lane == {d}) slot[{d}] = A.jac_slot[{d}];")
+            E.raw("    spec_wave_sync();")
+            E.raw("    trk_jac_readout(lds, slot, rstride, A.jac_n_cols, D, rows, A.jac_lin + base * 3 * D, A.jac_ang + base * 3 * D, lane);")
         E.raw("    if (lane >= rows) return;")
         E.raw("    const int64_t s = base + lane;")
         E.raw("    A.jac_pos[s * 3] = et[0]; A.jac_pos[s * 3 + 1] = et[1]; A.jac_pos[s * 3 + 2] = et[2];")
@@ -804,8 +835,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("}")
     out.append("static void launch_jac(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
-    out.append("    const int rstride = (6 * a.jac_n_cols + 3) | 1;")
-    out.append("    const size_t lds = sizeof(float) * ((size_t)TRK_WAVE * (rstride > D ? rstride : D) + TRK_MAX_DOFS);")
+    if direct:
+        out.append(f"    const size_t lds = sizeof(float) * (size_t)TRK_WAVE * {6 * D};")
+    else:
+        out.append("    const int rstride = (6 * a.jac_n_cols + 3) | 1;")
+        out.append("    const size_t lds = sizeof(float) * ((size_t)TRK_WAVE * (rstride > D ? rstride : D) + TRK_MAX_DOFS);")
     out.append("    if (base_identity) hipLaunchKernelGGL(k_jac_bi, dim3(grid), dim3(TRK_WAVE), lds, st, a);")
     out.append("    else hipLaunchKernelGGL(k_jac_bg, dim3(grid), dim3(TRK_WAVE), lds, st, a);")
     out.append("}")

@@ -295,6 +295,24 @@ __device__ __forceinline__ void spec_store_gq(IO* __restrict__ gq, int64_t base,
     }
 }
 
+// copy this wave's [64][W] tile (rows contiguous in LDS, 16-byte aligned) to out[base .. base + rows) as 16-byte write-through stores
+template <int W>
+__device__ __forceinline__ void spec_store_tile(float* __restrict__ out, int64_t base, int rows, int lane, const float* tile) {
+    float* dst = out + base * W;
+    constexpr int NV = TRK_WAVE * W / 4;
+    if (rows == TRK_WAVE && (TRK_WAVE * W) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+#pragma unroll
+        for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            if (k < NV) IoQuad<float>::store_wt(dst, k, t4[k]);
+        }
+    } else {
+        const int count = rows * W;
+        for (int k = lane; k < count; k += TRK_WAVE) dst[k] = tile[k];
+    }
+}
+
 // Link positions: each lane writes its 3L floats at stride 3L (33 for Panda: conflict-free), then the wave
 // streams the 64*3L contiguous floats out in 1 KiB chunks (one ds_read_b128 + one global_store_dwordx4 per
 // lane and chunk).  The chunks are NOT issued back to back: every wave of the chip reaches this point at the same
