@@ -354,7 +354,8 @@ int trk_collision_fields(const TrkCostModel* cm, int32_t fields, const float* li
  * H_ee: n transforms `stride` floats apart (e.g. the last link of [N,L,4,4]: pointer offset
  * (L-1)*16, stride L*16).  target: DEVICE [16] (per_sample_target=0) or [N,16] (=1); NULL = the
  * cost model's stored target.  -> cost [N]; gH (nullable), same layout as H_ee, receives
- * gcost[n]*dcost/dH (gcost NULL = ones; only the 3x4 block is written, the rest is untouched). */
+ * gcost[n]*dcost/dH (gcost NULL = ones; all 16 floats of each transform are written, the constant
+ * bottom row as zeros; other links' blocks of a strided gH are untouched). */
 int trk_ee_cost(const TrkCostModel* cm, const float* H_ee, int64_t n, int64_t stride,
                 const float* target, int32_t per_sample_target,
                 const float* gcost, float* cost, float* gH, int64_t g_stride, trk_stream_t stream);

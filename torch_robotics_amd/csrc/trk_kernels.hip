@@ -746,6 +746,7 @@ k_ee_cost(DevCostHdr C, const float* __restrict__ H, int64_t n, int64_t stride, 
         g[0] = make_float4(sc * gR[0], sc * gR[1], sc * gR[2], sc * gt[0]);
         g[1] = make_float4(sc * gR[3], sc * gR[4], sc * gR[5], sc * gt[1]);
         g[2] = make_float4(sc * gR[6], sc * gR[7], sc * gR[8], sc * gt[2]);
+        g[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);           // the bottom row of H is constant: the caller need not pre-zero gH
     }
 }
 

@@ -17,8 +17,45 @@ from .costmodel import CostModelSpec
 from .kinmodel import KinModel
 
 
+# Host time matters for the small ops: a kernel of ~10 us is host-bound when its wrapper costs more.  Measured pieces
+# (tools/wrapper_overhead.py): torch.cuda.current_stream(dev).cuda_stream 1.9 us, `with _on(dev)` 1.35 us,
+# torch.empty 1.65 us each.  The two helpers below cost ~0.3 us each when the tensor's device is the current one.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # what torch's own kernel launchers use
+
+
+def _stream_of(device: torch.device) -> int:
+    """HIP stream handle of torch's current stream on `device`."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _stream_of(t.device)
+
+
+class _on:
+    """`with _on(device):` -- torch.cuda.device(device), free when that device is already the current one."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = torch.device(device).index if not isinstance(device, torch.device) else device.index
+        self.prev = -1
+
+    def __enter__(self):
+        if self.idx is not None:
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                torch.cuda.set_device(self.idx)
+                self.prev = cur
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+            self.prev = -1
+        return False
 
 
 def _dev_f32(t: torch.Tensor, what: str) -> torch.Tensor:
@@ -103,7 +140,7 @@ class CostHandle:
             grid_ptrs = (sdf.data_ptr(), grad.data_ptr())
         desc, keep = _abi.cost_desc(spec, grid_ptrs)
         h = C.c_void_p()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             check(lib().trk_cost_model_create(C.byref(desc), C.byref(h)), "trk_cost_model_create")
         self._h = h
         self.n_links_in = spec.n_links_in
@@ -139,7 +176,7 @@ class PointSetHandle:
         self.model, self.point_link, self.point_offset = model, pl, po
         self.n_points = int(pl.shape[0])
         h = C.c_void_p()
-        with torch.cuda.device(torch.device(device)):
+        with _on(torch.device(device)):
             check(lib().trk_point_set_create(model._h, pl.ctypes.data, po.ctypes.data, self.n_points, C.byref(h)),
                   "trk_point_set_create")
         self._h = h
@@ -173,7 +210,7 @@ def fk_forward(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
     p, ns, keep = _sel(sel)
     ncol = ns if p else model.n_links
     H = torch.empty((n, ncol, 4, 4), device=q.device, dtype=torch.float32)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib().trk_fk_forward(model._h, q.data_ptr(), n, p, ns, H.data_ptr(), _stream(q)), "trk_fk_forward")
     return H
 
@@ -184,7 +221,7 @@ def fk_positions(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
     p, ns, keep = _sel(sel)
     ncol = ns if p else model.n_links
     pos = torch.empty((n, ncol, 3), device=q.device, dtype=torch.float32)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib().trk_fk_positions(model._h, q.data_ptr(), n, p, ns, pos.data_ptr(), _stream(q)), "trk_fk_positions")
     return pos
 
@@ -194,8 +231,8 @@ def fk_backward(model: ModelHandle, q: torch.Tensor, gH: torch.Tensor, sel=None)
     gH = _dev_f32(gH, "fk_backward(gH)")
     n = q.shape[0]
     p, ns, keep = _sel(sel)
-    gq = torch.zeros_like(q)
-    with torch.cuda.device(q.device):
+    gq = torch.empty_like(q)            # the kernel writes every element (zeros where the reference clamps)
+    with _on(q.device):
         check(lib().trk_fk_backward(model._h, q.data_ptr(), gH.data_ptr(), n, p, ns, gq.data_ptr(), _stream(q)),
               "trk_fk_backward")
     return gq
@@ -206,8 +243,8 @@ def fk_positions_backward(model: ModelHandle, q: torch.Tensor, gpos: torch.Tenso
     gpos = _dev_f32(gpos, "fk_positions_backward(gpos)")
     n = q.shape[0]
     p, ns, keep = _sel(sel)
-    gq = torch.zeros_like(q)
-    with torch.cuda.device(q.device):
+    gq = torch.empty_like(q)            # the kernel writes every element (zeros where the reference clamps)
+    with _on(q.device):
         check(lib().trk_fk_positions_backward(model._h, q.data_ptr(), gpos.data_ptr(), n, p, ns, gq.data_ptr(),
                                               _stream(q)), "trk_fk_positions_backward")
     return gq
@@ -219,7 +256,7 @@ def fk_points(ps: PointSetHandle, q: torch.Tensor) -> torch.Tensor:
     q = _dev_f32(q, "fk_points(q)").reshape(-1, model.n_dofs)
     n = q.shape[0]
     pos = torch.empty((n, ps.n_points, 3), device=q.device, dtype=torch.float32)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib().trk_fk_points(model._h, ps._h, q.data_ptr(), n, pos.data_ptr(), _stream(q)), "trk_fk_points")
     return pos
 
@@ -228,8 +265,8 @@ def fk_points_backward(ps: PointSetHandle, q: torch.Tensor, gpos: torch.Tensor) 
     model = ps.model
     q = _dev_f32(q, "fk_points_backward(q)").reshape(-1, model.n_dofs)
     gpos = _dev_f32(gpos, "fk_points_backward(gpos)")
-    gq = torch.zeros_like(q)
-    with torch.cuda.device(q.device):
+    gq = torch.empty_like(q)            # the kernel writes every element (zeros where the reference clamps)
+    with _on(q.device):
         check(lib().trk_fk_points_backward(model._h, ps._h, q.data_ptr(), gpos.data_ptr(), q.shape[0], gq.data_ptr(),
                                            _stream(q)), "trk_fk_points_backward")
     return gq
@@ -244,7 +281,7 @@ def fk_jacobian(model: ModelHandle, q: torch.Tensor, qd: Optional[torch.Tensor],
     lin, ang = torch.empty((n, 3, D), **kw), torch.empty((n, 3, D), **kw)
     vl = torch.empty((n, 3), **kw) if want_vel else None
     va = torch.empty((n, 3), **kw) if want_vel else None
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib().trk_fk_jacobian(model._h, q.data_ptr(), _ptr(qd_t), n, int(link), pos.data_ptr(), quat.data_ptr(),
                                     lin.data_ptr(), ang.data_ptr(), _ptr(vl), _ptr(va), _stream(q)), "trk_fk_jacobian")
     return (pos, quat, lin, ang, vl, va) if want_vel else (pos, quat, lin, ang)
@@ -255,7 +292,7 @@ def fk_analytic_jacobian(model: ModelHandle, q: torch.Tensor) -> torch.Tensor:
     q = _dev_f32(q, "fk_analytic_jacobian(q)").reshape(-1, model.n_dofs)
     n = q.shape[0]
     J = torch.empty((n, model.n_links, 7, model.n_dofs), device=q.device, dtype=torch.float32)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib().trk_fk_analytic_jacobian(model._h, q.data_ptr(), n, J.data_ptr(), _stream(q)), "trk_fk_analytic_jacobian")
     return J
 
@@ -271,7 +308,7 @@ def ik_step(model: ModelHandle, link: int, H_target: torch.Tensor, lower: torch.
     per_sample = int(Ht.dim() == 3)
     if per_sample and Ht.shape[0] != n:
         raise ValueError("ik_step: per-sample target batch mismatch")
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib().trk_ik_step(model._h, int(link), Ht.data_ptr(), per_sample, lower.data_ptr(), upper.data_ptr(),
                                 float(w_joint_limits), float(se3_eps), float(lr), int(step), n, q.data_ptr(),
                                 _ptr(adam_m), _ptr(adam_v), _ptr(loss), _ptr(valid), _stream(q)), "trk_ik_step")
@@ -289,7 +326,7 @@ def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
     batch = R.shape[:-2]
     n = int(np.prod(batch)) if len(batch) else 1
     out = torch.empty(tuple(batch) + (4,), device=R.device, dtype=torch.float32)
-    with torch.cuda.device(R.device):
+    with _on(R.device):
         check(lib().trk_rotmat_to_quat(R.data_ptr(), n, stride, pitch, out.data_ptr(), _stream(R)), "trk_rotmat_to_quat")
     return out
 
@@ -299,7 +336,7 @@ class _AxisRotation(torch.autograd.Function):
     def forward(ctx, kind, angle):
         n = int(angle.shape[0])
         R = torch.empty((n, 3, 3), device=angle.device, dtype=torch.float32)
-        with torch.cuda.device(angle.device):
+        with _on(angle.device):
             check(lib().trk_rotation_from(kind, angle.data_ptr(), n, R.data_ptr(), _stream(angle)), "trk_rotation_from")
         ctx.kind = kind
         ctx.save_for_backward(angle)
@@ -310,7 +347,7 @@ class _AxisRotation(torch.autograd.Function):
         (angle,) = ctx.saved_tensors
         gR = _dev_f32(gR, "axis rotation backward")
         ga = torch.empty_like(angle)
-        with torch.cuda.device(angle.device):
+        with _on(angle.device):
             check(lib().trk_rotation_from_backward(ctx.kind, angle.data_ptr(), gR.data_ptr(), int(angle.shape[0]), ga.data_ptr(),
                                                    _stream(angle)), "trk_rotation_from_backward")
         return None, ga
@@ -330,7 +367,7 @@ def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
     lead = q.shape[:-1]
     flat = q.reshape(-1, 4).contiguous()
     R = torch.empty((flat.shape[0], 3, 3), device=q.device, dtype=torch.float32)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib().trk_rotation_from(3, flat.data_ptr(), int(flat.shape[0]), R.data_ptr(), _stream(q)), "trk_rotation_from")
     return R.reshape(tuple(lead) + (3, 3))
 
@@ -356,7 +393,7 @@ def _frame_compose_raw(op, Ra, ta, Rb, tb):
     n = na if op == FRAME_INVERSE else max(na, nb)
     Ro = torch.empty((n, 3, 3), device=Ra.device, dtype=torch.float32)
     to = torch.empty((n, 3), device=Ra.device, dtype=torch.float32)
-    with torch.cuda.device(Ra.device):
+    with _on(Ra.device):
         check(lib().trk_frame_compose(op, Ra.data_ptr(), ta.data_ptr(), na, _ptr(Rb), _ptr(tb), nb, Ro.data_ptr(),
                                       to.data_ptr(), _stream(Ra)), "trk_frame_compose")
     return Ro, to
@@ -378,7 +415,7 @@ class _FrameCompose(torch.autograd.Function):
         gRa, gta = torch.empty_like(Ra), torch.empty_like(ta)
         two = ctx.op != FRAME_INVERSE
         gRb, gtb = (torch.empty_like(Rb), torch.empty_like(tb)) if two else (None, None)
-        with torch.cuda.device(Ra.device):
+        with _on(Ra.device):
             check(lib().trk_frame_compose_backward(ctx.op, Ra.data_ptr(), ta.data_ptr(), _ptr(Rb) if two else None,
                                                    _ptr(tb) if two else None, gR.data_ptr(), gt.data_ptr(), n, gRa.data_ptr(),
                                                    gta.data_ptr(), _ptr(gRb), _ptr(gtb), _stream(Ra)),
@@ -410,7 +447,7 @@ class _FrameTransformPoints(torch.autograd.Function):
     def forward(ctx, R, t, pts):
         n, P = int(R.shape[0]), int(pts.shape[0])
         out = torch.empty((n, P, 3), device=R.device, dtype=torch.float32)
-        with torch.cuda.device(R.device):
+        with _on(R.device):
             check(lib().trk_frame_transform_points(R.data_ptr(), t.data_ptr(), n, pts.data_ptr(), P, out.data_ptr(), _stream(R)),
                   "trk_frame_transform_points")
         ctx.save_for_backward(pts)
@@ -423,7 +460,7 @@ class _FrameTransformPoints(torch.autograd.Function):
         g = _dev_f32(g, "transform_point backward")
         gR = torch.empty((ctx.n, 3, 3), device=g.device, dtype=torch.float32)
         gt = torch.empty((ctx.n, 3), device=g.device, dtype=torch.float32)
-        with torch.cuda.device(g.device):
+        with _on(g.device):
             check(lib().trk_frame_transform_points_backward(g.data_ptr(), ctx.n, pts.data_ptr(), int(pts.shape[0]),
                                                             gR.data_ptr(), gt.data_ptr(), _stream(g)),
                   "trk_frame_transform_points_backward")
@@ -454,7 +491,7 @@ def frame_quat_euler(R: torch.Tensor, want_quat=True, want_euler=False):
     n = int(np.prod(batch)) if len(batch) else 1
     quat = torch.empty(tuple(batch) + (4,), device=R.device, dtype=torch.float32) if want_quat else None
     eul = torch.empty(tuple(batch) + (3,), device=R.device, dtype=torch.float32) if want_euler else None
-    with torch.cuda.device(R.device):
+    with _on(R.device):
         check(lib().trk_frame_quat_euler(R.data_ptr(), n, stride, pitch, _ptr(quat), _ptr(eul), _stream(R)), "trk_frame_quat_euler")
     return quat, eul
 
@@ -466,7 +503,7 @@ def cost_fields(cm: CostHandle, fields: int, link_pos: torch.Tensor, gcost: Opti
     cost = torch.empty((n,), device=link_pos.device, dtype=torch.float32)
     g = torch.empty_like(link_pos) if want_grad else None
     gc = None if gcost is None else _dev_f32(gcost, "cost_fields(gcost)").reshape(n)
-    with torch.cuda.device(link_pos.device):
+    with _on(link_pos.device):
         check(lib().trk_cost_fields(cm._h, int(fields), link_pos.data_ptr(), n, _ptr(gc), cost.data_ptr(), _ptr(g),
                                     _stream(link_pos)), "trk_cost_fields")
     return (cost, g) if want_grad else cost
@@ -476,7 +513,7 @@ def collision_fields(cm: CostHandle, fields: int, link_pos: torch.Tensor, margin
     link_pos = _dev_f32(link_pos, "collision_fields(link_pos)").reshape(-1, cm.n_links_in, 3)
     n = link_pos.shape[0]
     out = torch.empty((n,), device=link_pos.device, dtype=torch.uint8)
-    with torch.cuda.device(link_pos.device):
+    with _on(link_pos.device):
         check(lib().trk_collision_fields(cm._h, int(fields), link_pos.data_ptr(), n,
                                          float("nan") if margin is None else float(margin), out.data_ptr(),
                                          _stream(link_pos)), "trk_collision_fields")
@@ -495,12 +532,26 @@ def ee_cost(cm: CostHandle, H: torch.Tensor, target: Optional[torch.Tensor] = No
         if per_sample and tgt.shape[0] != n:
             raise ValueError("ee_cost: per-sample target batch mismatch")
     cost = torch.empty((n,), device=H.device, dtype=torch.float32)
-    gH = torch.zeros_like(H) if want_grad else None
+    gH = torch.empty_like(H) if want_grad else None      # all 16 entries are written (bottom row: zeros)
     gc = None if gcost is None else _dev_f32(gcost, "ee_cost(gcost)").reshape(n)
-    with torch.cuda.device(H.device):
+    with _on(H.device):
         check(lib().trk_ee_cost(cm._h, H.data_ptr(), n, 16, _ptr(tgt), per_sample, _ptr(gc), cost.data_ptr(),
                                 _ptr(gH), 16, _stream(H)), "trk_ee_cost")
     return (cost, gH) if want_grad else cost
+
+
+_weights_cache: dict = {}
+
+
+def _weights_struct(weights):
+    """TrkRolloutWeights for a 4-tuple of floats (read-only on the C side, so one struct per distinct tuple is kept)."""
+    key = tuple(float(v) for v in weights)
+    w = _weights_cache.get(key)
+    if w is None:
+        if len(_weights_cache) > 256:
+            _weights_cache.clear()
+        w = _weights_cache[key] = _abi.RolloutWeights(*key)
+    return w
 
 
 def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True,
@@ -523,10 +574,11 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
         q = q.reshape(-1, model.n_dofs)
         B, Hh = int(q.shape[0]), 1
     n, L, D = B * Hh, model.n_links, model.n_dofs
-    if out is None:
-        pos = torch.empty((n, L, 3), device=q.device, dtype=io) if want_pos else None
-        cost = torch.empty((n,), device=q.device, dtype=torch.float32)
-        gq = torch.empty((n, D), device=q.device, dtype=io)
+    if out is None:         # allocated in their final shapes: a reshape of a fresh tensor is ~0.7 us of host time each
+        lt = tuple(lead)
+        pos = torch.empty(lt + (L, 3), device=q.device, dtype=io) if want_pos else None
+        cost = torch.empty(lt, device=q.device, dtype=torch.float32)
+        gq = torch.empty(lt + (D,), device=q.device, dtype=io)
     else:
         pos, cost, gq = out
         _check_buffer(pos, n * L * 3, io, q.device, "rollout_cost_grad(out[0] = link_pos)")
@@ -535,11 +587,13 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
         if cost is None or gq is None:
             raise ValueError("rollout_cost_grad(out): cost and gq buffers are required (link_pos may be None)")
     _check_buffer(cost_sum, n_blocks(n), torch.float32, q.device, "rollout_cost_grad(cost_sum)", at_least=True)
-    w = _abi.RolloutWeights(*[float(v) for v in weights])
+    w = _weights_struct(weights)
     fn = lib().trk_rollout_cost_grad_f16 if f16 else lib().trk_rollout_cost_grad
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(fn(model._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos), cost.data_ptr(),
                  gq.data_ptr(), _ptr(cost_sum), _stream(q)), "trk_rollout_cost_grad")
+    if out is None:
+        return pos, cost, gq
     return (None if pos is None else pos.reshape(tuple(lead) + (L, 3)), cost.reshape(tuple(lead)),
             gq.reshape(tuple(lead) + (D,)))
 
@@ -560,7 +614,7 @@ def rollout_collision(model: ModelHandle, cm: CostHandle, fields: int, q: torch.
     # scratch for the table-driven fallback only (a model / cost model that no generated kernel serves)
     ws = None if model.specialized else torch.empty((n, model.n_links, 3), device=q.device, dtype=torch.float32)
     m = float("nan") if margin is None else float(margin)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         rc = lib().trk_rollout_collision(model._h, cm._h, int(fields), q.data_ptr(), B, Hh, m, out.data_ptr(), _ptr(ws), _stream(q))
         if rc == _abi.TRK_ERR_INVALID_ARG and ws is None:       # a unit exists for the model, but not for this cost model
             ws = torch.empty((n, model.n_links, 3), device=q.device, dtype=torch.float32)
@@ -588,7 +642,7 @@ def rollout_points_cost_grad(ps: PointSetHandle, cm: CostHandle, weights, q: tor
     gq = torch.empty((n, D), device=q.device, dtype=torch.float32)
     _check_buffer(cost_sum, n_blocks(n), torch.float32, q.device, "rollout_points_cost_grad(cost_sum)", at_least=True)
     w = _abi.RolloutWeights(*[float(v) for v in weights])
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib().trk_rollout_points_cost_grad(model._h, ps._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos),
                                                  cost.data_ptr(), gq.data_ptr(), _ptr(cost_sum), _stream(q)),
               "trk_rollout_points_cost_grad")
@@ -615,7 +669,7 @@ def gp_prior_cost_grad(q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: floa
         if gq.shape != q.shape or gqd.shape != q.shape or gq.dtype != q.dtype or gqd.dtype != q.dtype or \
                 not (gq.is_contiguous() and gqd.is_contiguous()):
             raise ValueError("gp_prior_cost_grad: accumulate_into buffers must match q (shape, dtype, contiguous)")
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         check(lib().trk_gp_prior_cost_grad(q.data_ptr(), qd.data_ptr(), B, H, D, int(q.dtype == torch.float16), float(dt),
                                            float(sigma), float(weight), cost.data_ptr(), gq.data_ptr(), gqd.data_ptr(), acc,
                                            _stream(q)), "trk_gp_prior_cost_grad")
@@ -650,7 +704,7 @@ class GPPriorPlan:
 
     def launch(self, stream: Optional[int] = None) -> None:
         if stream is None:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            stream = _stream_of(self.device)
         rc = self._fn(*self._args, stream)
         if rc:
             check(rc, "trk_gp_prior_cost_grad")
@@ -686,7 +740,7 @@ def finite_difference(x: torch.Tensor, dt: float = 1.0, method: str = "forward")
     H, D = int(x.shape[-2]), int(x.shape[-1])
     B = int(x.numel() // max(1, H * D))
     out = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib().trk_finite_difference(x.data_ptr(), B, H, D, float(dt), _FD_METHODS[method], out.data_ptr(), _stream(x)),
               "trk_finite_difference")
     return out
@@ -699,7 +753,7 @@ def traj_diff_norm_sum(x: torch.Tensor, c0: int, dim: int) -> torch.Tensor:
         raise ValueError("traj_diff_norm_sum: x must be (batch, horizon, state_dim)")
     B, H, S = (int(v) for v in x.shape)
     out = torch.empty((B,), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib().trk_traj_diff_norm_sum(x.data_ptr(), B, H, S, int(c0), int(dim), out.data_ptr(), _stream(x)),
               "trk_traj_diff_norm_sum")
     return out
@@ -718,7 +772,7 @@ def interpolate_traj_via_points(trajs: torch.Tensor, num_interpolation: int = 10
     beta = 1 - alpha
     alpha, beta = alpha.to(x.device), beta.to(x.device)
     out = torch.empty(tuple(lead) + ((H - 1) * num_interpolation, D), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib().trk_interpolate_via_points(x.data_ptr(), T, H, D, int(num_interpolation), alpha.data_ptr(),
                                                beta.data_ptr(), out.data_ptr(), _stream(x)), "trk_interpolate_via_points")
     return out
@@ -729,7 +783,7 @@ def reduce_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Ten
     x = _dev_f32(x, "reduce_sum(x)").reshape(-1)
     if out is None:
         out = torch.empty(1, device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         check(lib().trk_reduce_sum(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x)), "trk_reduce_sum")
     return out
 
@@ -745,9 +799,9 @@ def grid_precompute(cm: CostHandle, dims, lim_min, lim_max):
     shape = tuple(int(d) for d in dims_a)
     sdf = torch.empty(shape, device=cm.device, dtype=torch.float32)
     grad = torch.empty(shape + (3,), device=cm.device, dtype=torch.float32)
-    with torch.cuda.device(cm.device):
+    with _on(cm.device):
         check(lib().trk_grid_precompute(cm._h, dims_a.ctypes.data, lo.ctypes.data, hi.ctypes.data, sdf.data_ptr(),
-                                        grad.data_ptr(), torch.cuda.current_stream(cm.device).cuda_stream),
+                                        grad.data_ptr(), _stream_of(cm.device)),
               "trk_grid_precompute")
     return sdf, grad
 
@@ -757,7 +811,7 @@ def sdf_points(cm: CostHandle, pts: torch.Tensor, want_grad=False):
     n = pts.shape[0]
     sdf = torch.empty((n, cm.n_objects), device=pts.device, dtype=torch.float32)
     grad = torch.empty((n, cm.n_objects, 3), device=pts.device, dtype=torch.float32) if want_grad else None
-    with torch.cuda.device(pts.device):
+    with _on(pts.device):
         check(lib().trk_sdf_points(cm._h, pts.data_ptr(), n, sdf.data_ptr(), _ptr(grad), _stream(pts)), "trk_sdf_points")
     return (sdf, grad) if want_grad else sdf
 
@@ -920,7 +974,7 @@ class RolloutPlan:
 
     def launch(self, cost_sum_ptr: Optional[int] = None, stream: Optional[int] = None) -> None:
         if stream is None:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            stream = _stream_of(self.device)
         rc = self._fn(*self._args, cost_sum_ptr, stream)
         if rc:
             check(rc, "trk_rollout_cost_grad")
