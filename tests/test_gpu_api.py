@@ -33,13 +33,15 @@ def test_forward_kinematics_example_plumbing():
     # 1-D q gets a batch dimension; dict output holds Frame-like objects
     d = tree.compute_forward_kinematics_all_links(q.detach()[0], return_dict=True, link_list=["ee_link", "panda_link3"])
     assert set(d) == {"ee_link", "panda_link3"}
-    np.testing.assert_array_equal(d["ee_link"].get_transform_matrix().cpu().numpy(), H[:1, -1].detach().cpu().numpy())
+    # a link subset runs the table-driven kernel, all links the generated one: equal up to fp32 rounding of different FMA orders
+    np.testing.assert_allclose(d["ee_link"].get_transform_matrix().cpu().numpy(), H[:1, -1].detach().cpu().numpy(), rtol=0, atol=2e-6)
     Hs = tree.compute_forward_kinematics_all_links(q.detach(), link_list=["ee_link", "panda_link3", "ee_link"])
-    np.testing.assert_array_equal(Hs[:, 2].cpu().numpy(), H[:, 10].detach().cpu().numpy())
-    np.testing.assert_array_equal(Hs[:, 1].cpu().numpy(), H[:, 3].detach().cpu().numpy())
+    np.testing.assert_array_equal(Hs[:, 2].cpu().numpy(), Hs[:, 0].cpu().numpy())           # a repeated link is the same matrix
+    np.testing.assert_allclose(Hs[:, 2].cpu().numpy(), H[:, 10].detach().cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(Hs[:, 1].cpu().numpy(), H[:, 3].detach().cpu().numpy(), rtol=0, atol=2e-6)
     # state_less single-link call returns the SE(3) matrix (robot_tree.py:207-208)
-    np.testing.assert_array_equal(tree.compute_forward_kinematics(q.detach(), None, "ee_link", state_less=True).cpu().numpy(),
-                                  H[:, 10:11].detach().cpu().numpy())
+    np.testing.assert_allclose(tree.compute_forward_kinematics(q.detach(), None, "ee_link", state_less=True).cpu().numpy(),
+                               H[:, 10:11].detach().cpu().numpy(), rtol=0, atol=2e-6)
 
 
 def test_geometric_jacobian_api():

@@ -761,6 +761,10 @@ def test_generated_fk_positions_and_backward(ops, oracle_lib, ident):
             res = {}
             for use_spec in (True, False):
                 h.enable_specialized(use_spec)
+                Hm = ops.fk_forward(h, dev(q)).cpu().numpy()          # all links: the generated k_fkh / the table-driven kernel
+                assert Hm.shape == (n, L, 4, 4)
+                assert np.abs(Hm - H64).max() / max(1.0, float(np.abs(H64).max())) < TOL_H
+                np.testing.assert_array_equal(Hm[..., 3, :], np.broadcast_to(np.float32([0, 0, 0, 1]), (n, L, 4)))
                 pos = ops.fk_positions(h, dev(q)).cpu().numpy()
                 gq = ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy()
                 scale = max(1.0, float(np.abs(H64[..., :3, 3]).max()))

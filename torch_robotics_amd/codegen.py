@@ -687,6 +687,62 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.extend(E.lines)
         out.append("")
 
+    # ---- FK matrices of ALL links (trk_fk_forward with every link selected = compute_forward_kinematics_all_links,
+    # robot_tree.py:267-301): the same stateless walk as the fused rollout; a link's 4x4 leaves as soon as it exists -- each lane
+    # puts its 16 floats into a [64][17] LDS tile, the wave writes them as 8-byte write-through vectors, eight consecutive lanes
+    # completing one sample's 64 bytes (two whole sectors).  The kernel is a pure write stream (704 B per sample for Panda).
+    # Two links per flush (128 bytes per sample) when rows are whole 128-byte lines (L even) and the walk is the file order:
+    # full-line writes matter once the output exceeds the 256 MB Infinity Cache (UR10+Allegro, 526 MB: 122 - 154 -> 101 us);
+    # with odd L every other row starts mid-line and the pairs straddle lines anyway (Panda, dual Panda: no difference).
+    FKH_PAIR = L % 2 == 0 and [int(v) for v in kin.order] == list(range(L))
+    FKH_LS = 33 if FKH_PAIR else 17
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_fkh_bi" if base_identity else "k_fkh_bg"
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 16 else 2}) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(FKH_LS, D)}];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(FKH_LS, D)});")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        _emit_angles(E, kin)
+        E.raw(f"    float* hrow = lds + lane * {FKH_LS};")
+
+        def emit_h(i, p):
+            vals = []
+            for r in range(3):
+                vals += [E.expr(R[i][r][c]) for c in range(3)] + [E.expr(t[i][r])]
+            vals += ["0.0f", "0.0f", "0.0f", "1.0f"]
+            if FKH_PAIR:
+                off = 16 * (p % 2)
+                E.raw("    " + " ".join(f"hrow[{off + k}] = {v};" for k, v in enumerate(vals)))
+                if p % 2 == 1:
+                    E.raw(f"    spec_flush_chunk<{16 * L}, 32, {FKH_LS}, 2>(A.fk_H, base, {16 * (i - 1)}, rows, lane, lds);")
+                elif p == L - 1:
+                    E.raw(f"    spec_flush_chunk<{16 * L}, 16, {FKH_LS}, 2>(A.fk_H, base, {16 * i}, rows, lane, lds);")
+            else:
+                E.raw("    " + " ".join(f"hrow[{k}] = {v};" for k, v in enumerate(vals)))
+                E.raw(f"    spec_flush_chunk<{16 * L}, 16, {FKH_LS}, 2>(A.fk_H, base, {16 * i}, rows, lane, lds);")
+        emit_h(int(kin.order[0]), 0)
+        for p in range(1, L):
+            i = int(kin.order[p])
+            _emit_fk_link(E, kin, i, R, t, passv, snap)
+            emit_h(i, p)
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
     # ---- stateful FK + geometric Jacobian of ONE link (trk_fk_jacobian; robot_tree.py:136-190, 218-248): the walk unrolled
     # with the stateful path's quirks (clamp wherever limits exist, rotation about the axis with its sign ignored); every
     # joint that can receive a column leaves a record (z, p) in LDS, the target link (a run-time argument) is picked by a
@@ -833,6 +889,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("    if (base_identity) hipLaunchKernelGGL(k_coll_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_coll_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
+    out.append("static void launch_fkh(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+    out.append("    if (base_identity) hipLaunchKernelGGL(k_fkh_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    else hipLaunchKernelGGL(k_fkh_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("}")
     out.append("static void launch_jac(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
     if direct:
@@ -846,7 +907,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     jac_ok = (TRK_WAVE_ * JAC_LDS + 32) * 4 <= 64 * 1024            # default dynamic-LDS limit of a launch
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
-               f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll}};")
+               f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -1311,7 +1372,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
-               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr}};")
+               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out

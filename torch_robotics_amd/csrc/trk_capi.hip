@@ -343,6 +343,18 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
+    if (mode == 0 && spec_all_links(m, sel, ns) && m->spec->launch_fkh) {
+        // generated kernel: the unrolled stateless walk, every link's 4x4 streamed out as it exists
+        SpecArgs a{};
+        rc = blank_spec_args(a);
+        if (rc) return rc;
+        std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+        std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+        a.q = q; a.n = n; a.fk_H = out;
+        m->spec->launch_fkh(a, base_is_identity(m), (hipStream_t)stream);
+        TRK_HIP(hipGetLastError());
+        return TRK_OK;
+    }
     trk_launch_fk_forward(mode, m->hdr, m->d_links, sel, ns, q, n, out, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;

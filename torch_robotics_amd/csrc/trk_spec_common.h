@@ -41,6 +41,8 @@ struct SpecArgs {
     int32_t jac_p_end, jac_n_cols;    // the walk may stop after this pre-order position; number of joints that get a column
     int8_t jac_slot[TRK_MAX_DOFS];    // DOF -> record slot of its column (-1: the column stays zero), in walk order
     float* jac_pos; float* jac_quat; float* jac_lin; float* jac_ang;
+    // all-links FK kernel (trk_fk_forward with every link selected, launch_fkh): H [N, L, 4, 4]
+    float* fk_H;
 };
 
 typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
@@ -48,7 +50,7 @@ typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 9)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 10)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -70,6 +72,7 @@ struct SpecEntry {
     int32_t ee2_link;           // second tracked link baked into the unit (-1 = none)
     SpecLaunchFn launch_jac;    // stateful FK + geometric Jacobian of one link (robot_tree.py:136-248); nullptr if not generated
     SpecLaunchFn launch_coll;   // FK + boolean collision fields (trk_rollout_collision); nullptr if not generated
+    SpecLaunchFn launch_fkh;    // FK matrices of all links (trk_fk_forward, every link selected); nullptr if not generated
 };
 
 // registry filled by static initialisers of the generated translation units
@@ -407,7 +410,7 @@ template <int W, int NF, int LS, int V, class IO = float>
 __device__ __forceinline__ void spec_flush_chunk(IO* __restrict__ out, int64_t base, int c0, int rows, int lane,
                                                  const float* lds) {
     constexpr int NVEC = NF / V;
-    static_assert(NF % V == 0 && W % V == 0 && LS % V == 0, "chunk geometry must keep the vectors aligned");
+    static_assert(NF % V == 0 && W % V == 0 && (V != 4 || LS % 4 == 0), "chunk geometry must keep the vectors aligned");
     spec_wave_sync();
     const int total = rows * NVEC;
     IO* dst0 = out + base * W + c0;
