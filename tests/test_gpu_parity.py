@@ -758,9 +758,12 @@ def test_generated_fk_positions_and_backward(ops, oracle_lib, ident):
             H64 = o.fk(q.astype(np.float64), "f64")
             gH = np.zeros((n, L, 4, 4)); gH[..., :3, 3] = w
             g64 = o.fk_backward(q.astype(np.float64), gH, "f64")
+            wH = rng.standard_normal((n, L, 4, 4)).astype(np.float32)           # a full adjoint: rotations too
+            gH64 = o.fk_backward(q.astype(np.float64), wH.astype(np.float64), "f64")
             res = {}
             for use_spec in (True, False):
                 h.enable_specialized(use_spec)
+                assert rel_err(ops.fk_backward(h, dev(q), dev(wH)).cpu().numpy(), gH64) < TOL_G      # k_fkhbwd / table-driven
                 Hm = ops.fk_forward(h, dev(q)).cpu().numpy()          # all links: the generated k_fkh / the table-driven kernel
                 assert Hm.shape == (n, L, 4, 4)
                 assert np.abs(Hm - H64).max() / max(1.0, float(np.abs(H64).max())) < TOL_H

@@ -29,3 +29,13 @@ for ident in [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigi
         us = e0.elapsed_time(e1) / 100 * 1e3
         nbytes = (4 * D + 64 * L) * n
         print(f"{ident:14s} {'generated' if on else 'table-driven':12s} {us:8.2f} us  {nbytes / 1e6:7.1f} MB  {nbytes / us / 8e4:5.1f} % of 8 TB/s")
+        gq = torch.empty((n, D), **kw)
+        bargs = (h._h, q.data_ptr(), H.data_ptr(), n, None, 0, gq.data_ptr(), st)
+        for _ in range(10): Lb.trk_fk_backward(*bargs)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(100): Lb.trk_fk_backward(*bargs)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 100 * 1e3
+        nbytes = (8 * D + 64 * L) * n
+        print(f"{ident:14s} {'generated' if on else 'table-driven':12s} {us:8.2f} us  {nbytes / 1e6:7.1f} MB  {nbytes / us / 8e4:5.1f} % of 8 TB/s   (reverse mode)")

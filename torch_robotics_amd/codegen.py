@@ -294,7 +294,7 @@ def _emit_joint_gradient(E: "Emitter", kin: KinModel, i: int, R, t, Fi, Ti, mask
 
 
 def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, List[str]], rot_adj: Dict[int, str], masked,
-                        tick=None, order=None) -> Dict[int, S]:
+                        tick=None, order=None, pre_link=None) -> Dict[int, S]:
     """Reverse pass of the link kernels: per-link wrench accumulators (F, T about the world origin) pushed towards the
     root; `tb_names[i]` = the three C expressions holding link i's position adjoint; a tracked link i adds
     axial(Rb R^T) with Rb = the 9-float array named rot_adj[i]."""
@@ -306,6 +306,8 @@ def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, L
     for p in range(L - 1, 0, -1):
         i = int(order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
         E.raw(f"    // reverse: link {i}")
+        if pre_link is not None:
+            pre_link(i)                         # e.g. fetch this link's adjoint just before it is consumed
         if tick is not None and p % 2 == 0:
             E.raw(tick())                       # a callable: every tick carries its own compile-time chunk number
         if i in tb_names:
@@ -743,6 +745,52 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.extend(E.lines)
         out.append("")
 
+    # ---- reverse mode of the all-links FK matrices (trk_fk_backward with every link selected): FK again, then the reverse
+    # walk; a link's adjoint (its 4x4 block of gH, bottom row ignored) comes in through an LDS transpose right before the walk
+    # consumes it, so only one block per lane is live.
+    FKB_LS = 18
+    # every link's rotation stays live until the reverse walk has consumed it: beyond ~24 links the kernel spills (UR10+Allegro:
+    # 252 registers, 347 us against the table-driven kernel's 253) -- such robots keep the table-driven reverse mode
+    fkhbwd_ok = L <= 24
+    for base_identity in ((True, False) if fkhbwd_ok else ()):
+        E = Emitter()
+        kname = "k_fkhbwd_bi" if base_identity else "k_fkhbwd_bg"
+        # two wavefronts per SIMD: the rotation adjoint of EVERY link needs that link's rotation, so all of them stay live (Panda
+        # at four per SIMD: 63 registers spilled, and on this ISA a spill reload waits for every outstanding load)
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(FKB_LS, D)}];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(FKB_LS, D)});")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        _emit_angles(E, kin)
+        for p in range(1, L):
+            _emit_fk_link(E, kin, int(kin.order[p]), R, t, passv, snap)
+        E.raw(f"    const float* gh = lds + lane * {FKB_LS};")
+
+        def fetch_adjoint(i):
+            E.raw(f"    spec_load_chunk<{16 * L}, 16, {FKB_LS}, 2>(A.fk_H, base, {16 * i}, rows, lane, lds);")
+            E.raw(f"    const float gR{i}[9] = {{gh[0], gh[1], gh[2], gh[4], gh[5], gh[6], gh[8], gh[9], gh[10]}};")
+            E.raw(f"    const float gt{i}_0 = gh[3], gt{i}_1 = gh[7], gt{i}_2 = gh[11];")
+        gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"gt{i}_{k}" for k in range(3)] for i in range(1, L)},
+                                      {i: f"gR{i}" for i in range(1, L)}, masked, pre_link=fetch_adjoint)
+        E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
+        E.raw("    spec_store_gq<D>(static_cast<float*>(A.gq), base, rows, lane, lds, gv);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
     # ---- stateful FK + geometric Jacobian of ONE link (trk_fk_jacobian; robot_tree.py:136-190, 218-248): the walk unrolled
     # with the stateful path's quirks (clamp wherever limits exist, rotation about the axis with its sign ignored); every
     # joint that can receive a column leaves a record (z, p) in LDS, the target link (a run-time argument) is picked by a
@@ -894,6 +942,12 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("    if (base_identity) hipLaunchKernelGGL(k_fkh_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_fkh_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
+    if fkhbwd_ok:
+        out.append("static void launch_fkhbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
+        out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+        out.append("    if (base_identity) hipLaunchKernelGGL(k_fkhbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    else hipLaunchKernelGGL(k_fkhbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("}")
     out.append("static void launch_jac(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
     if direct:
@@ -907,7 +961,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     jac_ok = (TRK_WAVE_ * JAC_LDS + 32) * 4 <= 64 * 1024            # default dynamic-LDS limit of a launch
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
-               f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh}};")
+               f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -1372,7 +1426,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
-               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr}};")
+               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out

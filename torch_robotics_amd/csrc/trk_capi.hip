@@ -376,6 +376,17 @@ static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin,
     rc = make_sel(m, link_sel, n_sel, sel, ns, who);
     if (rc) return rc;
     if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    if (mode == 0 && spec_all_links(m, sel, ns) && m->spec->launch_fkhbwd) {
+        SpecArgs a{};
+        rc = blank_spec_args(a);
+        if (rc) return rc;
+        std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+        std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+        a.q = q; a.n = n; a.fk_H = const_cast<float*>(gin); a.gq = gq;
+        m->spec->launch_fkhbwd(a, base_is_identity(m), (hipStream_t)stream);
+        TRK_HIP(hipGetLastError());
+        return TRK_OK;
+    }
     if (mode == 1 && spec_all_links(m, sel, ns) && m->spec->launch_posbwd) {
         SpecArgs a{};
         rc = blank_spec_args(a);

@@ -41,7 +41,8 @@ struct SpecArgs {
     int32_t jac_p_end, jac_n_cols;    // the walk may stop after this pre-order position; number of joints that get a column
     int8_t jac_slot[TRK_MAX_DOFS];    // DOF -> record slot of its column (-1: the column stays zero), in walk order
     float* jac_pos; float* jac_quat; float* jac_lin; float* jac_ang;
-    // all-links FK kernel (trk_fk_forward with every link selected, launch_fkh): H [N, L, 4, 4]
+    // all-links FK kernel (trk_fk_forward with every link selected, launch_fkh): H [N, L, 4, 4] out;
+    // its reverse mode (launch_fkhbwd): the adjoint gH [N, L, 4, 4] in (read only), gq out
     float* fk_H;
 };
 
@@ -50,7 +51,7 @@ typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 10)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 11)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -73,6 +74,7 @@ struct SpecEntry {
     SpecLaunchFn launch_jac;    // stateful FK + geometric Jacobian of one link (robot_tree.py:136-248); nullptr if not generated
     SpecLaunchFn launch_coll;   // FK + boolean collision fields (trk_rollout_collision); nullptr if not generated
     SpecLaunchFn launch_fkh;    // FK matrices of all links (trk_fk_forward, every link selected); nullptr if not generated
+    SpecLaunchFn launch_fkhbwd; // its reverse mode (trk_fk_backward, every link selected): fk_H = gH in, gq out; nullptr if not generated
 };
 
 // registry filled by static initialisers of the generated translation units
@@ -557,6 +559,21 @@ __device__ __forceinline__ void spec_load_chunk(const float* __restrict__ in, in
     spec_wave_sync();           // everybody has consumed the previous chunk
     const int total = rows * NVEC;
     const float* src0 = in + base * W + c0;
+    if (V == 2 && rows == TRK_WAVE) {      // full wave: all loads in flight before the first LDS write (the guarded loop below
+        float2 r[NVEC];                    // waits for every load before it issues the next)
+#pragma unroll
+        for (int j = 0; j < NVEC; ++j) {
+            const int e = lane + TRK_WAVE * j, smp = e / NVEC, v = e - smp * NVEC;
+            r[j] = *reinterpret_cast<const float2*>(src0 + (int64_t)smp * W + v * V);
+        }
+#pragma unroll
+        for (int j = 0; j < NVEC; ++j) {
+            const int e = lane + TRK_WAVE * j, smp = e / NVEC, v = e - smp * NVEC;
+            *reinterpret_cast<float2*>(lds + smp * LS + v * V) = r[j];
+        }
+        spec_wave_sync();
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NVEC; ++j) {
         const int e = lane + TRK_WAVE * j;
