@@ -197,6 +197,14 @@ int trk_ik_step(const TrkModel* model, int32_t link, const float* H_target, int3
                 const float* upper, float w_joint_limits, float se3_eps, float lr, int32_t step, int64_t n, float* q,
                 float* adam_m, float* adam_v, float* loss, uint8_t* valid, trk_stream_t stream);
 
+/* The same for n_steps consecutive iterations first_step, first_step + 1, ... in ONE launch per 32 iterations: the
+ * configurations stay on the chip between iterations (the persistent form of the loop robot_tree.py:345-377).  Exactly
+ * n_steps calls of trk_ik_step, except that loss / valid describe q as passed in (before the FIRST of the updates) -- a
+ * caller that tests the termination condition every n_steps iterations loses nothing. */
+int trk_ik_steps(const TrkModel* model, int32_t link, const float* H_target, int32_t per_sample_target, const float* lower,
+                 const float* upper, float w_joint_limits, float se3_eps, float lr, int32_t first_step, int32_t n_steps,
+                 int64_t n, float* q, float* adam_m, float* adam_v, float* loss, uint8_t* valid, trk_stream_t stream);
+
 /* reference: rotation_matrix_to_q quaternion.py:135-166 (via link_quat_from_link_tensor
  * geometrics/utils.py:341-344).  R: n matrices, `stride` floats apart, 3x3 block with row
  * pitch `row_pitch` (9/3 for packed rotations, 16/4 for 4x4 transforms).  -> quat_wxyz [n,4]. */

@@ -124,7 +124,7 @@ def test_unit_with_another_struct_layout_is_refused():
     assert before >= 3                                            # the ahead-of-time units registered themselves
     stale = (C.c_uint32 * 64)()                                   # abi 0, sizes 0: an old-layout entry
     assert reg(C.addressof(stale)) != 0 and L.trk_spec_count() == before
-    for version in range(1000, 1032):                             # whatever the current version is: wrong sizeof(SpecArgs)
+    for version in range(2000, 2064):                             # whatever the current version is: wrong sizeof(SpecArgs)
         stale[0], stale[1] = version, 8
         assert reg(C.addressof(stale)) != 0 and L.trk_spec_count() == before
     assert reg(None) != 0

@@ -518,6 +518,17 @@ def test_ik_step_vs_reference_adam(ops, oracle_lib):
                 np.testing.assert_array_equal(valid.cpu().numpy().astype(bool), g[f"valid0_{tag}"])
             assert rel_err(loss.cpu().numpy(), g[f"err_steps_{tag}"][it]) < 2e-4
             assert np.abs(q.cpu().numpy() - g[f"q_steps_{tag}"][it]).max() < 2e-4
+        # the persistent form: K iterations in one call == K calls (bit for bit), loss / valid from before the first update;
+        # 40 iterations span two launches of at most 32
+        for K in (5, 40):
+            qa, qb = dev(g["q0"]).clone(), dev(g["q0"]).clone()
+            ma, va, mb, vb = torch.zeros_like(qa), torch.zeros_like(qa), torch.zeros_like(qa), torch.zeros_like(qa)
+            la = torch.empty(48, device=DEV); lb = torch.empty(48, device=DEV); l0 = None
+            for it in range(K):
+                ops.ik_step(h, 10, dev(Ht), lo, hi, qa, ma, va, it + 1, lr=1e-2, loss=la)
+                l0 = la.clone() if it == 0 else l0
+            ops.ik_steps(h, 10, dev(Ht), lo, hi, qb, mb, vb, 1, K, lr=1e-2, loss=lb)
+            assert torch.equal(qa, qb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(l0, lb)
     # ragged size on a tree robot vs the fp64 oracle
     mt = model("ur10_allegro")
     ht, ot = ops.ModelHandle(mt), oracle_lib.Oracle(mt)

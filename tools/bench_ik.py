@@ -23,4 +23,8 @@ for n in (1024, 16384, 262144):
     for it in range(200): ops.ik_step(h, kin.n_links - 1, Ht, lo, hi, q, m, v, it + 21, loss=loss, valid=valid)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 200 * 1e3
-    print(f"n = {n:7d}: {us:8.2f} us per iteration  ({n / us:8.1f} M samples/s)")
+    e0.record()
+    for it in range(10): ops.ik_steps(h, kin.n_links - 1, Ht, lo, hi, q, m, v, 221 + 20 * it, 20, loss=loss, valid=valid)
+    e1.record(); torch.cuda.synchronize()
+    us20 = e0.elapsed_time(e1) / 200 * 1e3
+    print(f"n = {n:7d}: {us:8.2f} us per iteration, one per launch | {us20:8.2f} us per iteration, 20 per call (trk_ik_steps)")

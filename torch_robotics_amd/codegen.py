@@ -294,7 +294,7 @@ def _emit_joint_gradient(E: "Emitter", kin: KinModel, i: int, R, t, Fi, Ti, mask
 
 
 def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, List[str]], rot_adj: Dict[int, str], masked,
-                        tick=None, order=None, pre_link=None) -> Dict[int, S]:
+                        tick=None, order=None, pre_link=None, n_links=None) -> Dict[int, S]:
     """Reverse pass of the link kernels: per-link wrench accumulators (F, T about the world origin) pushed towards the
     root; `tb_names[i]` = the three C expressions holding link i's position adjoint; a tracked link i adds
     axial(Rb R^T) with Rb = the 9-float array named rot_adj[i]."""
@@ -303,7 +303,8 @@ def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, L
     T: Dict[int, List[S]] = {i: [ZERO, ZERO, ZERO] for i in range(L)}
     gq_expr: Dict[int, S] = {}
     order = kin.order if order is None else order       # any order with parents before children (walked backwards here)
-    for p in range(L - 1, 0, -1):
+    # n_links: only the first n_links entries of `order` are walked (a chain that carries every adjoint)
+    for p in range((L if n_links is None else n_links) - 1, 0, -1):
         i = int(order[p]); par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
         E.raw(f"    // reverse: link {i}")
         if pre_link is not None:
@@ -791,6 +792,100 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.extend(E.lines)
         out.append("")
 
+    # ---- Adam IK on the unit's tracked link (trk_ik_steps; robot_tree.py:345-442): the configurations AND the optimiser state
+    # live in registers for all iterations of a launch -- FK, SE3 distance, reverse pass, joint-limit hinge, termination test and
+    # the Adam update per lane, nothing but the result goes back to memory.  (The table-driven kernel keeps them in LDS and walks
+    # the tree from tables: ~9 us per iteration whatever the batch.)
+    # q, m and v of every DOF stay in registers across the loop: beyond ~9 DOF the kernel spills (dual Panda, 14 DOF: 10 registers;
+    # UR10+Allegro, 22 DOF: 377) and those robots keep the table-driven kernel
+    ik_ok = tmpl.ee_link >= 0 and D <= 9
+    for base_identity in ((True, False) if ik_ok else ()):
+        E = Emitter()
+        kname = "k_ik_bi" if base_identity else "k_ik_bg"
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(IkArgs A) {{")
+        E.raw("    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * D];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw("    float* lds = lds_all + wave * (TRK_WAVE * D);")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    float q[D], am[D], av[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        E.raw("    if (A.lr > 0.0f) {")
+        E.raw("        spec_load_q<D>(static_cast<const float*>(A.adam_m), base, rows, lane, lds, am);")
+        E.raw("        spec_load_q<D>(static_cast<const float*>(A.adam_v), base, rows, lane, lds, av);")
+        E.raw("    } else {")
+        E.raw("#pragma unroll")
+        E.raw("        for (int d = 0; d < D; ++d) { am[d] = 0.0f; av[d] = 0.0f; }")
+        E.raw("    }")
+        E.raw("    float Ht[16];")
+        E.raw("    {")
+        E.raw("        const float* tp = A.H_target + (A.per_sample ? min(base + lane, A.n - 1) * 16 : 0);")
+        E.raw("#pragma unroll")
+        E.raw("        for (int k = 0; k < 12; ++k) Ht[k] = tp[k];")
+        E.raw("    }")
+        E.raw("    float loss0 = 0.0f;")
+        E.raw("    bool ok0 = false;")
+        E.raw("    for (int it = 0; it < A.n_steps; ++it) {")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        _emit_angles(E, kin)
+        # only the chain of the tracked link matters: the other branches' poses would be dead code
+        chain, a = set(), tmpl.ee_link
+        while a >= 0:
+            chain.add(a); a = int(kin.parent[a])
+        for p in range(1, L):
+            i = int(kin.order[p])
+            if i in chain:
+                _emit_fk_link(E, kin, i, R, t, passv, snap)
+        ee = tmpl.ee_link
+        E.raw(f"    const float eR[9] = {{{', '.join(E.expr(R[ee][r][c]) for r in range(3) for c in range(3))}}};")
+        E.raw(f"    const float et[3] = {{{', '.join(E.expr(t[ee][k]) for k in range(3))}}};")
+        E.raw("    float gR[9], gt[3];")
+        E.raw("    const float err = ee_cost_eval(eR, et, Ht, 1.0f, 1.0f, 0, gR, gt);      // SE3_distance, w_pos = w_rot = 1 (robot_tree.py:386-417)")
+        order_chain = [int(kin.order[0])] + [int(kin.order[p]) for p in range(1, L) if int(kin.order[p]) in chain]
+        gq_expr = _emit_reverse_links(E, kin, R, t, {ee: ["gt[0]", "gt[1]", "gt[2]"]}, {ee: "gR"}, masked, order=order_chain,
+                                      n_links=len(order_chain))
+        E.raw(f"    const float g_[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
+        E.raw("    bool ok = err < A.se3_eps;")
+        E.raw("    float jl = 0.0f;")
+        E.raw("    const float bc1 = A.sched.bc1[it], rsqrt_bc2 = A.sched.rsqrt_bc2[it];")
+        E.raw("#pragma unroll")
+        E.raw("    for (int d = 0; d < D; ++d) {      // hinge on the (shrunk) limits, validity, torch.optim.Adam's update")
+        E.raw("        const float qv = q[d], lo = cptr(A.lower)[d], hi = cptr(A.upper)[d];")
+        E.raw("        float g = g_[d];")
+        E.raw("        if (qv < lo) { const float e = lo - qv; jl = fmaf(e, e, jl); g = fmaf(-2.0f * A.w_jl, e, g); }")
+        E.raw("        if (qv > hi) { const float e = hi - qv; jl = fmaf(e, e, jl); g = fmaf(-2.0f * A.w_jl, e, g); }")
+        E.raw("        ok = ok && (qv >= lo) && (qv <= hi);")
+        E.raw("        if (A.lr > 0.0f) {")
+        E.raw("            const float m1 = fmaf(0.9f, am[d], 0.1f * g);")
+        E.raw("            const float v1 = fmaf(0.999f, av[d], 0.001f * g * g);")
+        E.raw("            am[d] = m1; av[d] = v1;")
+        E.raw("            const float denom = fmaf(sqrtf(v1), rsqrt_bc2, 1e-8f);")
+        E.raw("            q[d] = qv - (A.lr / bc1) * (m1 / denom);")
+        E.raw("        }")
+        E.raw("    }")
+        E.raw("    if (it == 0) { loss0 = fmaf(A.w_jl, jl, err); ok0 = ok; }")
+        E.raw("    }")
+        E.raw("    if (lane < rows) {")
+        E.raw("        if (A.loss) A.loss[base + lane] = loss0;")
+        E.raw("        if (A.valid) A.valid[base + lane] = ok0 ? 1 : 0;")
+        E.raw("    }")
+        E.raw("    if (A.lr > 0.0f) {")
+        E.raw("        spec_store_gq<D>(A.q, base, rows, lane, lds, q);")
+        E.raw("        spec_store_gq<D>(A.adam_m, base, rows, lane, lds, am);")
+        E.raw("        spec_store_gq<D>(A.adam_v, base, rows, lane, lds, av);")
+        E.raw("    }")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
     # ---- stateful FK + geometric Jacobian of ONE link (trk_fk_jacobian; robot_tree.py:136-190, 218-248): the walk unrolled
     # with the stateful path's quirks (clamp wherever limits exist, rotation about the axis with its sign ignored); every
     # joint that can receive a column leaves a record (z, p) in LDS, the target link (a run-time argument) is picked by a
@@ -948,6 +1043,12 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("    if (base_identity) hipLaunchKernelGGL(k_fkhbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    else hipLaunchKernelGGL(k_fkhbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("}")
+    if ik_ok:
+        out.append("static void launch_ik(const IkArgs& a, int base_identity, hipStream_t st) {")
+        out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+        out.append("    if (base_identity) hipLaunchKernelGGL(k_ik_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    else hipLaunchKernelGGL(k_ik_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("}")
     out.append("static void launch_jac(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
     if direct:
@@ -961,7 +1062,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     jac_ok = (TRK_WAVE_ * JAC_LDS + 32) * 4 <= 64 * 1024            # default dynamic-LDS limit of a launch
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
-               f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}}};")
+               f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}, "
+               f"{'launch_ik' if ik_ok else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -1426,7 +1528,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
-               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr}};")
+               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out

@@ -59,7 +59,7 @@ std::vector<const SpecEntry*>& spec_registry() { static std::vector<const SpecEn
 
 int trk_spec_register(const SpecEntry* e) {
     // the first four fields are the layout stamp in every version of SpecEntry; nothing else is read before they match
-    if (!e || e->spec_abi_version != TRK_SPEC_ABI_VERSION || e->sizeof_args != sizeof(SpecArgs) ||
+    if (!e || e->spec_abi_version != TRK_SPEC_ABI_VERSION || e->sizeof_args != sizeof(SpecArgs) + sizeof(IkArgs) ||
         e->sizeof_entry != sizeof(SpecEntry) || e->sizeof_cost_hdr != sizeof(DevCostHdr)) {
         fprintf(stderr, "libtrk: refusing a generated unit compiled against another SpecArgs/SpecEntry layout "
                         "(stale JIT cache?) -- it will not be dispatched\n");
@@ -565,21 +565,52 @@ int trk_fk_analytic_jacobian(const TrkModel* m, const float* q, int64_t n, float
     return TRK_OK;
 }
 
+int trk_ik_steps(const TrkModel* m, int32_t link, const float* H_target, int32_t per_sample_target, const float* lower,
+                 const float* upper, float w_joint_limits, float se3_eps, float lr, int32_t first_step, int32_t n_steps, int64_t n,
+                 float* q, float* adam_m, float* adam_v, float* loss, uint8_t* valid, trk_stream_t stream) {
+    int rc = check_model(m, "trk_ik_steps");
+    if (rc) return rc;
+    if (link < 0 || link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_ik_steps: link out of range");
+    if (n < 0 || first_step < 1 || n_steps < 1 || !H_target || !lower || !upper || (n > 0 && !q) || (lr > 0.0f && (!adam_m || !adam_v)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_ik_steps: bad argument");
+    if (lr <= 0.0f && n_steps != 1) return fail(TRK_ERR_INVALID_ARG, "trk_ik_steps: lr = 0 only evaluates, n_steps must be 1");
+    if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    // generated kernel (configurations and Adam state in registers) when the target is the link the unit tracks
+    const SpecEntry* gen = (model_spec(m) && m->spec_enabled && m->spec->launch_ik && m->spec->ee_link == link) ? m->spec : nullptr;
+    // at most TRK_IK_MAX_STEPS iterations per launch; loss / valid come from the first launch (q as the caller passed it)
+    for (int32_t done = 0; done < n_steps; done += TRK_IK_MAX_STEPS) {
+        const int32_t k = std::min<int32_t>(TRK_IK_MAX_STEPS, n_steps - done);
+        IkSchedule sched{};
+        for (int32_t i = 0; i < k; ++i) {
+            const float t = (float)(first_step + done + i);
+            sched.bc1[i] = 1.0f - std::pow(0.9f, t);
+            sched.rsqrt_bc2[i] = 1.0f / std::sqrt(1.0f - std::pow(0.999f, t));
+        }
+        if (gen) {
+            IkArgs a{};
+            std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+            std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+            a.H_target = H_target; a.per_sample = per_sample_target; a.n_steps = k; a.lower = lower; a.upper = upper;
+            a.w_jl = w_joint_limits; a.se3_eps = se3_eps; a.lr = lr; a.sched = sched; a.n = n;
+            a.q = q; a.adam_m = adam_m; a.adam_v = adam_v;
+            a.loss = done == 0 ? loss : nullptr; a.valid = done == 0 ? valid : nullptr;
+            gen->launch_ik(a, base_is_identity(m), (hipStream_t)stream);
+            TRK_HIP(hipGetLastError());
+            continue;
+        }
+        trk_launch_ik_step(m->hdr, m->d_links, m->d_fin, link, H_target, per_sample_target, lower, upper, w_joint_limits,
+                           se3_eps, lr, sched, k, n, q, adam_m, adam_v, done == 0 ? loss : nullptr, done == 0 ? valid : nullptr,
+                           (hipStream_t)stream);
+        TRK_HIP(hipGetLastError());
+    }
+    return TRK_OK;
+}
+
 int trk_ik_step(const TrkModel* m, int32_t link, const float* H_target, int32_t per_sample_target, const float* lower,
                 const float* upper, float w_joint_limits, float se3_eps, float lr, int32_t step, int64_t n, float* q,
                 float* adam_m, float* adam_v, float* loss, uint8_t* valid, trk_stream_t stream) {
-    int rc = check_model(m, "trk_ik_step");
-    if (rc) return rc;
-    if (link < 0 || link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_ik_step: link out of range");
-    if (n < 0 || step < 1 || !H_target || !lower || !upper || (n > 0 && !q) || (lr > 0.0f && (!adam_m || !adam_v)))
-        return fail(TRK_ERR_INVALID_ARG, "trk_ik_step: bad argument");
-    if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
-    const float bc1 = 1.0f - std::pow(0.9f, (float)step);
-    const float rsqrt_bc2 = 1.0f / std::sqrt(1.0f - std::pow(0.999f, (float)step));
-    trk_launch_ik_step(m->hdr, m->d_links, m->d_fin, link, H_target, per_sample_target, lower, upper, w_joint_limits,
-                       se3_eps, lr, bc1, rsqrt_bc2, n, q, adam_m, adam_v, loss, valid, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
-    return TRK_OK;
+    return trk_ik_steps(m, link, H_target, per_sample_target, lower, upper, w_joint_limits, se3_eps, lr, step, 1, n, q, adam_m,
+                        adam_v, loss, valid, stream);
 }
 
 int trk_rotmat_to_quat(const float* R, int64_t n, int32_t stride, int32_t row_pitch, float* quat, trk_stream_t stream) {

@@ -439,6 +439,10 @@ __device__ __forceinline__ void scene_rank_pairs(const TRK_CAS float* tab, int n
 
 // `tick` is called once per trip of the sphere loop: the fused kernel uses it to trickle its link-position
 // stores out between the arithmetic instead of issuing them as one burst (see spec_common: PosFlusher).
+// bias corrections of the Adam iterations one launch of the IK kernel runs (passed by value: no device buffer, no copy)
+#define TRK_IK_MAX_STEPS 32
+struct IkSchedule { float bc1[TRK_IK_MAX_STEPS]; float rsqrt_bc2[TRK_IK_MAX_STEPS]; };
+
 #define TRK_LDS_SPHERES 16     // sphere centres a fused kernel may keep in LDS for the arg-min gather
 
 // FAST: the caller guarantees (wave-uniformly, from the cost model header: scene_is_fast) that the scene is 1..16

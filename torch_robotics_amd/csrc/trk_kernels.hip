@@ -471,7 +471,7 @@ struct AdjIK {            // adjoint of the SE(3) distance on one link, evaluate
 __global__ void __launch_bounds__(TRK_WAVE)
 k_ik_step(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, int link,
           const float* __restrict__ H_target, int per_sample, const float* __restrict__ lower,
-          const float* __restrict__ upper, float w_jl, float se3_eps, float lr, float bc1, float rsqrt_bc2, int64_t n,
+          const float* __restrict__ upper, float w_jl, float se3_eps, float lr, IkSchedule sched, int n_steps, int64_t n,
           float* __restrict__ q, float* __restrict__ mom, float* __restrict__ vel, float* __restrict__ loss,
           uint8_t* __restrict__ valid) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -485,8 +485,6 @@ k_ik_step(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __r
     float* slots = jst + 7 * D * TRK_WAVE;
     load_tile(qs, q, base * D, (int64_t)rows * D, lane);
     for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
-    for (int k = lane; k < TRK_WAVE * D; k += TRK_WAVE) gqs[k] = 0.0f;
-    __syncthreads();
     float Ht[16];
     {
         const int64_t s = min(base + lane, n - 1);
@@ -494,32 +492,39 @@ k_ik_step(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __r
 #pragma unroll
         for (int k = 0; k < 12; ++k) Ht[k] = tp[k];
     }
-    AdjIK adj{link, Ht, 0.0f};
-    reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
-    // hinge on the (shrunk) joint limits, termination test, Adam; each lane owns its row of the q / gq tiles
-    bool ok = adj.err < se3_eps;
-    float jl = 0.0f;
     const int64_t s = base + lane;
-    for (int d = 0; d < D; ++d) {
-        const float qv = qs[lane * D + d], lo = lower[d], hi = upper[d];
-        float g = gqs[lane * D + d];
-        if (qv < lo) { const float e = lo - qv; jl = fmaf(e, e, jl); g = fmaf(-2.0f * w_jl, e, g); }
-        if (qv > hi) { const float e = hi - qv; jl = fmaf(e, e, jl); g = fmaf(-2.0f * w_jl, e, g); }
-        ok = ok && (qv >= lo) && (qv <= hi);
-        if (lane < rows && lr > 0.0f) {
-            const int64_t idx = s * D + d;
-            const float m1 = fmaf(0.9f, mom[idx], 0.1f * g);
-            const float v1 = fmaf(0.999f, vel[idx], 0.001f * g * g);
-            mom[idx] = m1; vel[idx] = v1;
-            const float denom = fmaf(sqrtf(v1), rsqrt_bc2, 1e-8f);
-            qs[lane * D + d] = qv - (lr / bc1) * (m1 / denom);
+    // n_steps iterations on the tile in LDS: the configurations never leave the chip between them (the Adam state does, but
+    // every lane re-reads only what it wrote itself).  loss / valid describe q as it was when the launch started.
+    for (int it = 0; it < n_steps; ++it) {
+        for (int k = lane; k < TRK_WAVE * D; k += TRK_WAVE) gqs[k] = 0.0f;
+        __syncthreads();
+        AdjIK adj{link, Ht, 0.0f};
+        reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+        // hinge on the (shrunk) joint limits, termination test, Adam; each lane owns its row of the q / gq tiles
+        bool ok = adj.err < se3_eps;
+        float jl = 0.0f;
+        const float bc1 = sched.bc1[it], rsqrt_bc2 = sched.rsqrt_bc2[it];
+        for (int d = 0; d < D; ++d) {
+            const float qv = qs[lane * D + d], lo = lower[d], hi = upper[d];
+            float g = gqs[lane * D + d];
+            if (qv < lo) { const float e = lo - qv; jl = fmaf(e, e, jl); g = fmaf(-2.0f * w_jl, e, g); }
+            if (qv > hi) { const float e = hi - qv; jl = fmaf(e, e, jl); g = fmaf(-2.0f * w_jl, e, g); }
+            ok = ok && (qv >= lo) && (qv <= hi);
+            if (lane < rows && lr > 0.0f) {
+                const int64_t idx = s * D + d;
+                const float m1 = fmaf(0.9f, mom[idx], 0.1f * g);
+                const float v1 = fmaf(0.999f, vel[idx], 0.001f * g * g);
+                mom[idx] = m1; vel[idx] = v1;
+                const float denom = fmaf(sqrtf(v1), rsqrt_bc2, 1e-8f);
+                qs[lane * D + d] = qv - (lr / bc1) * (m1 / denom);
+            }
         }
+        if (it == 0 && lane < rows) {
+            if (loss) loss[s] = fmaf(w_jl, jl, adj.err);
+            if (valid) valid[s] = ok ? 1 : 0;
+        }
+        __syncthreads();
     }
-    if (lane < rows) {
-        if (loss) loss[s] = fmaf(w_jl, jl, adj.err);
-        if (valid) valid[s] = ok ? 1 : 0;
-    }
-    __syncthreads();
     if (lr > 0.0f) store_tile(q, qs, base * D, (int64_t)rows * D, lane);
 }
 
@@ -1561,11 +1566,11 @@ void trk_launch_fk_backward(int mode, const DevModelHdr& hdr, const DevLink* lin
 
 void trk_launch_ik_step(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, int link, const float* H_target,
                         int per_sample, const float* lower, const float* upper, float w_jl, float se3_eps, float lr,
-                        float bc1, float rsqrt_bc2, int64_t n, float* q, float* mom, float* vel, float* loss,
+                        const IkSchedule& sched, int n_steps, int64_t n, float* q, float* mom, float* vel, float* loss,
                         uint8_t* valid, hipStream_t st) {
     size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE);
     hipLaunchKernelGGL(k_ik_step, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, link, H_target,
-                       per_sample, lower, upper, w_jl, se3_eps, lr, bc1, rsqrt_bc2, n, q, mom, vel, loss, valid);
+                       per_sample, lower, upper, w_jl, se3_eps, lr, sched, n_steps, n, q, mom, vel, loss, valid);
 }
 
 void trk_launch_cost_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, const float* gcost,

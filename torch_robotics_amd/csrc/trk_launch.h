@@ -9,7 +9,7 @@ void trk_launch_fk_backward(int mode, const DevModelHdr& hdr, const DevLink* lin
                             const SelMap& selp, int n_sel, const float* q, const float* gin, int64_t n, float* gq, hipStream_t st);
 void trk_launch_ik_step(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, int link, const float* H_target,
                         int per_sample, const float* lower, const float* upper, float w_jl, float se3_eps, float lr,
-                        float bc1, float rsqrt_bc2, int64_t n, float* q, float* mom, float* vel, float* loss,
+                        const IkSchedule& sched, int n_steps, int64_t n, float* q, float* mom, float* vel, float* loss,
                         uint8_t* valid, hipStream_t st);
 void trk_launch_cost_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, const float* gcost,
                             float* cost, float* g_link_pos, hipStream_t st);

@@ -48,14 +48,33 @@ struct SpecArgs {
 
 typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
 
+// Arguments of the generated IK kernel (trk_ik_steps on the unit's tracked link).  A struct of its own: the 256-byte schedule
+// would otherwise ride in the kernarg segment of every kernel of the unit.
+struct IkArgs {
+    float base_R[9];
+    float base_t[3];
+    const float* H_target;        // DEVICE [16] or [N,16]
+    int32_t per_sample;
+    int32_t n_steps;              // <= TRK_IK_MAX_STEPS
+    const float* lower;           // DEVICE [D]: the (shrunk) limits of the hinge / validity test
+    const float* upper;
+    float w_jl, se3_eps, lr;
+    int32_t _pad;
+    IkSchedule sched;
+    int64_t n;
+    float* q; float* adam_m; float* adam_v;     // [N,D], in place
+    float* loss; uint8_t* valid;                // nullable; q as passed in
+};
+typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_t stream);
+
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 11)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 12)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
-    uint32_t sizeof_args;       // sizeof(SpecArgs) the unit was compiled with
+    uint32_t sizeof_args;       // sizeof(SpecArgs) + sizeof(IkArgs) the unit was compiled with
     uint32_t sizeof_entry;      // sizeof(SpecEntry) the unit was compiled with
     uint32_t sizeof_cost_hdr;   // sizeof(DevCostHdr)
     uint64_t model_hash;        // FNV-1a over the kinematic tables (see trk_capi.hip: model_hash)
@@ -75,12 +94,13 @@ struct SpecEntry {
     SpecLaunchFn launch_coll;   // FK + boolean collision fields (trk_rollout_collision); nullptr if not generated
     SpecLaunchFn launch_fkh;    // FK matrices of all links (trk_fk_forward, every link selected); nullptr if not generated
     SpecLaunchFn launch_fkhbwd; // its reverse mode (trk_fk_backward, every link selected): fk_H = gH in, gq out; nullptr if not generated
+    SpecIkLaunchFn launch_ik;   // Adam IK iterations on ee_link, configurations and optimiser state in registers; nullptr if not generated
 };
 
 // registry filled by static initialisers of the generated translation units
 // returns 0 when the unit was accepted, TRK_ERR_INVALID_ARG (and registers nothing) when its layout stamp differs
 int trk_spec_register(const SpecEntry* e);
-#define SPEC_ENTRY_STAMP TRK_SPEC_ABI_VERSION, (uint32_t)sizeof(SpecArgs), (uint32_t)sizeof(SpecEntry), (uint32_t)sizeof(DevCostHdr)
+#define SPEC_ENTRY_STAMP TRK_SPEC_ABI_VERSION, (uint32_t)(sizeof(SpecArgs) + sizeof(IkArgs)), (uint32_t)sizeof(SpecEntry), (uint32_t)sizeof(DevCostHdr)
 const SpecEntry* trk_spec_find(uint64_t model_hash, int n_links, int n_dofs);
 const SpecEntry* trk_spec_find_points(uint64_t model_hash, uint64_t points_hash, int n_points);
 

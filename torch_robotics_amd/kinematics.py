@@ -259,22 +259,26 @@ class DifferentiableTree(torch.nn.Module):
         loss = torch.empty(batch_size, device=self._device, dtype=torch.float32)
         valid = torch.empty(batch_size, device=self._device, dtype=torch.uint8)
         link = self._name_to_idx_map[link_name]
-        it = 0
-        for it in range(max_iters):
-            q_prev = q.clone() if (it % check_every == 0) else None
-            ops.ik_step(self._handle, link, Ht, lo, hi, q, m, v, it + 1, lr=lr, w_joint_limits=300.0, se3_eps=se3_eps,
-                        loss=loss, valid=valid)
-            if it % check_every == 0 and bool(valid.all()):
+        it, converged = 0, False
+        while it < max_iters:
+            # iterations it .. it + k - 1 in one call: the termination test (a device->host sync) looks at the state before
+            # the first of them, exactly as a loop that tests only every `check_every` iterations would
+            k = max(1, min(int(check_every), max_iters - it))
+            q_prev = q.clone()
+            ops.ik_steps(self._handle, link, Ht, lo, hi, q, m, v, it + 1, k, lr=lr, w_joint_limits=300.0, se3_eps=se3_eps,
+                         loss=loss, valid=valid)
+            if bool(valid.all()):
                 q = q_prev                      # the reference breaks BEFORE updating once every configuration is valid
                 print(f"\nIK converged for all joint configurations in {it} iterations")
+                converged = True
                 break
-            if (it == 0 or (it % print_freq) == 0) and print_freq != -1:
+            if print_freq != -1 and (it == 0 or any((j % print_freq) == 0 for j in range(it, it + k))):
                 print(f"\n---> Iter {it}/{max_iters}")
                 print(f"Error mean, std: {loss.mean():.3f}, {loss.std():.3f}")
                 print(f"idx_valid: {int(valid.sum())}/{batch_size}")
-        else:
-            if max_iters > 0:
-                print("\nIK did not converge for all joint configurations!")
+            it += k
+        if not converged and max_iters > 0:
+            print("\nIK did not converge for all joint configurations!")
         idx_valid = torch.atleast_1d(torch.argwhere(valid.bool()).squeeze())
         return q, idx_valid
 

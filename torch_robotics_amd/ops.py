@@ -314,6 +314,24 @@ def ik_step(model: ModelHandle, link: int, H_target: torch.Tensor, lower: torch.
                                 _ptr(adam_m), _ptr(adam_v), _ptr(loss), _ptr(valid), _stream(q)), "trk_ik_step")
 
 
+def ik_steps(model: ModelHandle, link: int, H_target: torch.Tensor, lower: torch.Tensor, upper: torch.Tensor,
+             q: torch.Tensor, adam_m: torch.Tensor, adam_v: torch.Tensor, first_step: int, n_steps: int, lr: float = 1e-2,
+             w_joint_limits: float = 300.0, se3_eps: float = 1e-1, loss: Optional[torch.Tensor] = None,
+             valid: Optional[torch.Tensor] = None) -> None:
+    """`n_steps` fused IK iterations IN PLACE (one launch per 32 iterations; the configurations stay on the chip in between).
+    Equal to n_steps calls of ik_step, except that loss / valid describe q as passed in."""
+    n, D = q.shape
+    assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and D == model.n_dofs
+    Ht = _dev_f32(H_target, "ik_steps(H_target)")
+    per_sample = int(Ht.dim() == 3)
+    if per_sample and Ht.shape[0] != n:
+        raise ValueError("ik_steps: per-sample target batch mismatch")
+    with _on(q.device):
+        check(lib().trk_ik_steps(model._h, int(link), Ht.data_ptr(), per_sample, lower.data_ptr(), upper.data_ptr(),
+                                 float(w_joint_limits), float(se3_eps), float(lr), int(first_step), int(n_steps), n, q.data_ptr(),
+                                 adam_m.data_ptr(), adam_v.data_ptr(), _ptr(loss), _ptr(valid), _stream(q)), "trk_ik_steps")
+
+
 def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
     """rotation_matrix_to_q on (..., 3, 3) rotations or (..., 4, 4) transforms -> (..., 4) wxyz."""
     R = _dev_f32(R, "rotmat_to_quat(R)")
