@@ -735,3 +735,26 @@ def test_point_mass_robot_like_the_reference():
     np.testing.assert_array_equal(task.compute_collision(q.detach(), margin=0.0).cpu().numpy(), g["coll0"])
     free = task.random_coll_free_q(n_samples=5)
     assert free.shape == (5, 3) and not task.compute_collision(free).any()
+
+
+def test_ops_run_on_torchs_current_stream():
+    """The wrappers launch on torch's CURRENT stream (the raw handle torch's own launchers use): work enqueued on a side stream
+    -- a long matmul, then the copy that produces q -- is ordered before the op there, and the result is ordered before
+    whatever follows on that stream.  On the default stream the op would read q before the copy had run."""
+    from torch_robotics_amd import ops
+    robot = tra.RobotPanda(tensor_args=TA)
+    h = ops.ModelHandle(robot.diff_panda._kin)
+    q_new = robot.random_q(4096)
+    expect = ops.fk_positions(h, q_new).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(DEV)
+    q = torch.zeros_like(q_new)
+    a = torch.randn(4096, 4096, device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(8):
+            a = a @ a * 1e-3                      # several milliseconds of work ahead of the copy
+        q.copy_(q_new)
+        pos = ops.fk_positions(h, q)
+        got = pos.clone()
+    side.synchronize()
+    assert torch.equal(got, expect)
