@@ -779,6 +779,10 @@ def test_generated_fk_positions_and_backward(ops, oracle_lib, ident):
                 assert Hm.shape == (n, L, 4, 4)
                 assert np.abs(Hm - H64).max() / max(1.0, float(np.abs(H64).max())) < TOL_H
                 np.testing.assert_array_equal(Hm[..., 3, :], np.broadcast_to(np.float32([0, 0, 0, 1]), (n, L, 4)))
+                for li in (0, L // 2, L - 1):                         # one link: the generated k_fk1 (walk cut after the target)
+                    H1 = ops.fk_forward(h, dev(q), [li]).cpu().numpy()
+                    assert H1.shape == (n, 1, 4, 4)
+                    assert np.abs(H1[:, 0] - H64[:, li]).max() / max(1.0, float(np.abs(H64).max())) < TOL_H
                 pos = ops.fk_positions(h, dev(q)).cpu().numpy()
                 gq = ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy()
                 scale = max(1.0, float(np.abs(H64[..., :3, 3]).max()))

@@ -746,6 +746,49 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.extend(E.lines)
         out.append("")
 
+    # ---- FK matrix of ONE link (trk_fk_forward with a single link selected: compute_forward_kinematics(..., state_less=True)
+    # robot_tree.py:192-216, RobotPanda.get_EE_pose robot_panda.py:172-184): the stateless walk with a wave-uniform early exit
+    # after the target (a run-time argument, captured by a wave-uniform switch), 64 bytes per sample out through the LDS transpose.
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_fk1_bi" if base_identity else "k_fk1_bg"
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 16 else 2}) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(16, D)}];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(16, D)});")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        _emit_angles(E, kin)
+        E.raw("    float hv[16] = {1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f};")
+
+        def capture_h(i):
+            body = "; ".join(f"hv[{4 * r + c}] = {E.expr(R[i][r][c])}" for r in range(3) for c in range(3))
+            body += "; " + "; ".join(f"hv[{4 * r + 3}] = {E.expr(t[i][r])}" for r in range(3))
+            E.raw(f"    if (A.jac_link == {i}) {{ {body}; }}       // wave-uniform")
+        capture_h(int(kin.order[0]))
+        E.raw("    do {                               // the walk stops after the target's pre-order position")
+        for p in range(1, L):
+            i = int(kin.order[p])
+            E.raw(f"    if (A.jac_p_end <= {p}) break;")
+            _emit_fk_link(E, kin, i, R, t, passv, snap)
+            capture_h(i)
+        E.raw("    } while (0);")
+        E.raw("    spec_store_gq<16>(A.fk_H, base, rows, lane, lds, hv);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
     # ---- reverse mode of the all-links FK matrices (trk_fk_backward with every link selected): FK again, then the reverse
     # walk; a link's adjoint (its 4x4 block of gH, bottom row ignored) comes in through an LDS transpose right before the walk
     # consumes it, so only one block per lane is live.
@@ -1043,6 +1086,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("    if (base_identity) hipLaunchKernelGGL(k_fkhbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    else hipLaunchKernelGGL(k_fkhbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("}")
+    out.append("static void launch_fk1(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+    out.append("    if (base_identity) hipLaunchKernelGGL(k_fk1_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    else hipLaunchKernelGGL(k_fk1_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("}")
     if ik_ok:
         out.append("static void launch_ik(const IkArgs& a, int base_identity, hipStream_t st) {")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
@@ -1063,7 +1111,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
                f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}, "
-               f"{'launch_ik' if ik_ok else 'nullptr'}}};")
+               f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -1528,7 +1576,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
-               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr, nullptr}};")
+               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out

@@ -343,6 +343,23 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
+    if (mode == 0 && ns == 1 && model_spec(m) && m->spec_enabled && m->spec->launch_fk1) {
+        // generated kernel: the unrolled stateless walk up to the one selected link
+        SpecArgs a{};
+        rc = blank_spec_args(a);
+        if (rc) return rc;
+        std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+        std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+        a.q = q; a.n = n; a.fk_H = out;
+        a.jac_link = -1; a.jac_p_end = 1;
+        for (int l = 0; l < m->hdr.n_links; ++l) if (sel.col[l] == 0) a.jac_link = l;
+        for (int p = 0; p < m->hdr.n_links; ++p) if (m->links[p].link == a.jac_link) a.jac_p_end = p + 1;
+        if (a.jac_link >= 0) {
+            m->spec->launch_fk1(a, base_is_identity(m), (hipStream_t)stream);
+            TRK_HIP(hipGetLastError());
+            return TRK_OK;
+        }
+    }
     if (mode == 0 && spec_all_links(m, sel, ns) && m->spec->launch_fkh) {
         // generated kernel: the unrolled stateless walk, every link's 4x4 streamed out as it exists
         SpecArgs a{};

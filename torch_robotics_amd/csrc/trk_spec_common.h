@@ -70,7 +70,7 @@ typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 12)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 13)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -95,6 +95,7 @@ struct SpecEntry {
     SpecLaunchFn launch_fkh;    // FK matrices of all links (trk_fk_forward, every link selected); nullptr if not generated
     SpecLaunchFn launch_fkhbwd; // its reverse mode (trk_fk_backward, every link selected): fk_H = gH in, gq out; nullptr if not generated
     SpecIkLaunchFn launch_ik;   // Adam IK iterations on ee_link, configurations and optimiser state in registers; nullptr if not generated
+    SpecLaunchFn launch_fk1;    // FK matrix of one link (jac_link, jac_p_end) -> fk_H [N,4,4]; nullptr if not generated
 };
 
 // registry filled by static initialisers of the generated translation units
