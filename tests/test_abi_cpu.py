@@ -65,3 +65,13 @@ def test_argument_validation_without_gpu(trk):
     assert trk.trk_model_create(C.byref(desc), C.byref(h)) == _abi.TRK_ERR_UNSUPPORTED
     assert b"n_links" in trk.trk_last_error()
     assert trk.trk_model_create(None, C.byref(h)) == _abi.TRK_ERR_INVALID_ARG
+
+
+def test_every_entry_point_is_documented_for_the_reference_side():
+    """INTEGRATION.md maps each function of include/trk.h to the reference call site it replaces (or names it as a helper)."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    declared = sorted(set(re.findall(r"\b(trk_[a-z0-9_]+)\s*\(", (root / "include" / "trk.h").read_text())))
+    text = (root / "INTEGRATION.md").read_text()
+    assert [n for n in declared if n not in text] == []
