@@ -248,3 +248,89 @@ def test_dual_panda_fp16_gp_full_size(ops, oracle_lib):
     p64, c64, g64 = o.rollout(qh.reshape(-1, D)[idx].float().cpu().numpy().astype(np.float64), w, "f64")
     assert rel_err(cost.reshape(-1)[idx].cpu().numpy(), c64) < 1e-5
     assert np.abs(pos.reshape(-1, L, 3)[idx].float().cpu().numpy() - p64).max() < 2.0 ** -10 * max(1.0, np.abs(p64).max())
+
+
+@pytest.mark.parametrize("ident", ["panda", "dual_panda"])
+def test_generated_fk_family_full_size(ops, oracle_lib, ident):
+    """The generated FK family at 4096 x 64 -- all-links matrices (k_fkh), their reverse mode (k_fkhbwd), one link (k_fk1), the
+    geometric Jacobian (k_jac), positions and their reverse mode: consistency properties over the WHOLE batch (orthonormal
+    rotations, constant bottom rows, matrices == positions, single link == that link of the full result, linearity of the reverse
+    modes in the adjoint, generated == table-driven to fp32 rounding) and an fp64-oracle spot check of a random subset."""
+    kin, _ = codegen.template_for(ident)
+    h, o = ops.ModelHandle(kin), oracle_lib.Oracle(kin)
+    assert h.specialized
+    n, L, D = 4096 * 64, kin.n_links, kin.n_dofs
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    q = (torch.rand(n, D, generator=gen, **TA) - 0.5) * 5.0
+    Hm = ops.fk_forward(h, q)
+    assert Hm.shape == (n, L, 4, 4) and torch.isfinite(Hm).all()
+    R = Hm[..., :3, :3]
+    eye = torch.eye(3, **TA)
+    assert float((R @ R.transpose(-1, -2) - eye).abs().max()) < 2e-6            # every rotation of every sample is orthonormal
+    assert bool((Hm[..., 3, :] == torch.tensor([0.0, 0.0, 0.0, 1.0], **TA)).all())
+    pos = ops.fk_positions(h, q)
+    assert float((pos - Hm[..., :3, 3]).abs().max()) < 4e-6
+    li = L - 1
+    assert float((ops.fk_forward(h, q, [li])[:, 0] - Hm[:, li]).abs().max()) < 4e-6
+    # reverse modes: linear in the adjoint
+    w1, w2 = torch.randn(n, L, 4, 4, generator=gen, **TA), torch.randn(n, L, 4, 4, generator=gen, **TA)
+    g1, g2, g12 = ops.fk_backward(h, q, w1), ops.fk_backward(h, q, w2), ops.fk_backward(h, q, w1 + 2.0 * w2)
+    scale = float(g12.abs().max())
+    assert float((g12 - (g1 + 2.0 * g2)).abs().max()) < 2e-5 * scale
+    wp = torch.zeros_like(w1); wp[..., :3, 3] = w1[..., :3, 3]
+    assert float((ops.fk_backward(h, q, wp) - ops.fk_positions_backward(h, q, w1[..., :3, 3].contiguous())).abs().max()) < 2e-5 * scale
+    # the geometric Jacobian's position / quaternion agree with the matrices (the stateful walk differs from the stateless one
+    # only where a joint has limits that the sample violates or a negative axis: none for these robots' sampled range)
+    jp, jq, lin, ang = ops.fk_jacobian(h, q, None, li)
+    assert torch.isfinite(lin).all() and torch.isfinite(ang).all() and lin.shape == (n, 3, D)
+    # generated == table-driven (another instruction order), whole batch
+    h.enable_specialized(False)
+    Ht, gt = ops.fk_forward(h, q), ops.fk_backward(h, q, w1)
+    jp_t, jq_t, lin_t, ang_t = ops.fk_jacobian(h, q, None, li)
+    h.enable_specialized(True)
+    assert float((Ht - Hm).abs().max()) < 4e-6 and float((gt - g1).abs().max()) < 2e-5 * scale
+    assert float((lin_t - lin).abs().max()) < 1e-5 and float((ang_t - ang).abs().max()) < 1e-5 and float((jp_t - jp).abs().max()) < 4e-6
+    # fp64 oracle on a random subset
+    idx = torch.randint(0, n, (2048,), generator=torch.Generator().manual_seed(3))
+    qs = q[idx.to(DEV)].cpu().numpy().astype(np.float64)
+    H64 = o.fk(qs, "f64")
+    assert np.abs(Hm[idx.to(DEV)].cpu().numpy() - H64).max() / max(1.0, float(np.abs(H64).max())) < 2e-6
+    g64 = o.fk_backward(qs, w1[idx.to(DEV)].cpu().numpy().astype(np.float64), "f64")
+    assert rel_err(g1[idx.to(DEV)].cpu().numpy(), g64) < 2e-5
+
+
+def test_ik_loop_full_size(ops):
+    """trk_ik_steps on 4096 x 64 configurations: 12 iterations in one call == 12 single calls (bit for bit), generated ==
+    table-driven after the same iterations on all but the noise-gradient elements, and the loss of (almost) every sample decreases."""
+    robot = tra.RobotPanda(tensor_args=TA)
+    kin = robot.diff_panda._kin
+    h = ops.ModelHandle(kin)
+    n, D = 4096 * 64, 7
+    lo, hi = robot.q_min.to(DEV).float().contiguous(), robot.q_max.to(DEV).float().contiguous()
+    Ht = torch.eye(4, **TA); Ht[:3, 3] = torch.tensor([0.4, 0.2, 0.5], **TA)
+    q0 = robot.random_q(n, generator=torch.Generator(device=DEV).manual_seed(5)).contiguous()
+    link = kin.n_links - 1
+
+    def run(single, spec):
+        h.enable_specialized(spec)
+        q, m, v = q0.clone(), torch.zeros_like(q0), torch.zeros_like(q0)
+        loss0 = torch.empty(n, **TA)
+        if single:
+            for it in range(12):
+                ops.ik_step(h, link, Ht, lo, hi, q, m, v, it + 1, lr=1e-2, loss=loss0 if it == 0 else None)
+        else:
+            ops.ik_steps(h, link, Ht, lo, hi, q, m, v, 1, 12, lr=1e-2, loss=loss0)
+        loss1 = torch.empty(n, **TA)
+        ops.ik_step(h, link, Ht, lo, hi, q, m, v, 13, lr=0.0, loss=loss1)       # lr = 0: evaluate only
+        h.enable_specialized(True)
+        return q, loss0, loss1
+    qa, la0, la1 = run(False, True)
+    qb, lb0, lb1 = run(True, True)
+    assert torch.equal(qa, qb) and torch.equal(la0, lb0)
+    qc, lc0, lc1 = run(False, False)
+    # Adam normalises the step by sqrt(v): a DOF whose gradient is rounding noise moves by +-lr per iteration whatever the sign
+    # of the noise, so two instruction orders cannot agree on THOSE elements; everywhere else they do
+    assert float((la0 - lc0).abs().max()) < 1e-4 * float(la0.abs().max())
+    assert float(((qa - qc).abs() < 1e-4).float().mean()) > 0.999
+    assert abs(float(la1.mean()) - float(lc1.mean())) < 1e-3 * float(la1.mean())
+    assert float((la1 < la0).float().mean()) > 0.99
