@@ -1065,3 +1065,67 @@ def test_ring_staging_geometries(ops, oracle_lib, tmp_path, n_links):
         plan.launch(); torch.cuda.synchronize()
         p16, _, _ = o.rollout(q.astype(np.float16).astype(np.float64), (0, 1, 0, 1), "f64")
         assert np.abs(plan.link_pos.float().cpu().numpy().reshape(p16.shape) - p16).max() / scale < 2e-3
+
+
+@pytest.mark.parametrize("ident", ["panda", "dual_panda", "ur10_allegro"])
+def test_randomised_generated_vs_table_driven_and_oracle(ops, oracle_lib, ident):
+    """A seeded sweep over what a caller can vary around one generated unit -- batch size (ragged, one wavefront, several
+    workgroups), weights (terms on and off), margins, hinge flags, workspace box, a base pose, positions wanted or not, fp16 I/O --
+    each drawn at random: generated kernel == table-driven kernel == fp64 oracle on every draw."""
+    from torch_robotics_amd import codegen
+    from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+    from torch_robotics_amd.costmodel import CostModelSpec
+    from torch_robotics_amd.environments import EnvSpheres3D
+    kin, tmpl = codegen.template_for(ident)
+    env = EnvSpheres3D(tensor_args=dict(device=DEV, dtype=torch.float32))
+    rng = np.random.default_rng({"panda": 101, "dual_panda": 202, "ur10_allegro": 303}[ident])
+    self_links = sorted({a for p in tmpl.self_pairs for a in p})
+    for draw in range(40):
+        spec = CostModelSpec(n_links_in=kin.n_links)
+        spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+        spec.obj_link_margin = rng.uniform(0.0, 0.15, len(tmpl.obj_links)).astype(np.float32)
+        spec.objects = [o.as_object() for o in env.obj_fixed_list]
+        if rng.random() < 0.5:
+            spec.ws_min, spec.ws_max = rng.uniform(-1.5, -0.3, 3).astype(np.float32), rng.uniform(0.3, 1.5, 3).astype(np.float32)
+        spec.self_link_idx = np.asarray(self_links, np.int32)
+        spec.self_pairs = np.asarray([(self_links.index(a), self_links.index(b)) for a, b in tmpl.self_pairs], np.int32).reshape(-1, 2)
+        spec.self_margin = rng.uniform(0.02, 0.3, len(tmpl.self_pairs)).astype(np.float32)
+        spec.ee_link = tmpl.ee_link
+        Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = rng.uniform(-0.6, 0.6, 3); spec.ee_target = Ht
+        if tmpl.ee2_link >= 0:
+            spec.ee2_link = tmpl.ee2_link
+            Ht2 = np.eye(4, dtype=np.float32); Ht2[:3, 3] = rng.uniform(-0.6, 0.6, 3); spec.ee2_target = Ht2
+        spec.clamp_fields = int(rng.choice([0, FIELD_OBJECTS, FIELD_SELF | FIELD_WS, FIELD_OBJECTS | FIELD_SELF | FIELD_WS]))
+        spec.validate()
+        if rng.random() < 0.4:
+            ang = rng.uniform(-1.0, 1.0)
+            kin.set_base_pose(np.array([*rng.uniform(-0.3, 0.3, 3), np.cos(ang / 2), 0.0, 0.0, np.sin(ang / 2)], np.float32))
+        else:
+            kin.set_base_pose(np.array([0, 0, 0, 1, 0, 0, 0], np.float32))
+        h, cm, o = ops.ModelHandle(kin), ops.CostHandle(spec, DEV), oracle_lib.Oracle(kin, spec)
+        assert h.specialized
+        n = int(rng.choice([1, 7, 64, 65, 129, 300, 1024]))
+        w = tuple(float(v) for v in rng.choice([0.0, 0.5, 1.0, 2.0], 4))
+        q = rng.uniform(-3.0, 3.0, (n, kin.n_dofs)).astype(np.float32)
+        want_pos = bool(rng.random() < 0.7)
+        p64, c64, g64 = o.rollout(q.astype(np.float64), w, "f64")
+        scale = max(1.0, float(np.abs(p64).max()))
+        res = {}
+        for use_spec in (True, False):
+            h.enable_specialized(use_spec)
+            pos, c, gq = ops.rollout_cost_grad(h, cm, w, dev(q), want_pos=want_pos)
+            if want_pos:
+                assert np.abs(pos.cpu().numpy() - p64).max() / scale < TOL_H, (ident, draw, n, use_spec)
+            else:
+                assert pos is None
+            # a single sample's cost can be a small difference of O(1) terms (unclamped margin - sdf): absolute floor of 1
+            assert np.abs(c.cpu().numpy() - c64).max() / max(1.0, float(np.abs(c64).max())) < TOL_C, (ident, draw, n, w, use_spec)
+            assert np.abs(gq.cpu().numpy() - g64).max() / max(1.0, float(np.abs(g64).max())) < TOL_G, (ident, draw, n, w, use_spec)
+            res[use_spec] = (c, gq)
+        h.enable_specialized(True)
+        if rng.random() < 0.5:                                        # fp16 I/O through the generated kernel
+            p16, c16, g16 = o.rollout(q.astype(np.float16).astype(np.float64), w, "f64")
+            pos_h, c_h, gq_h = ops.rollout_cost_grad(h, cm, w, dev(q).half(), want_pos=True)
+            assert np.abs(pos_h.float().cpu().numpy() - p16).max() / scale < 2e-3
+            assert np.abs(c_h.cpu().numpy() - c16).max() / max(1.0, float(np.abs(c16).max())) < 1e-4
+    kin.set_base_pose(np.array([0, 0, 0, 1, 0, 0, 0], np.float32))
