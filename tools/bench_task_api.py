@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""The user-facing calls at 4096 x 64 (host + GPU time per call): PlanningTask.compute_collision_cost with and without autograd,
+compute_collision, RobotPanda.fk_map_collision / get_EE_pose."""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+import torch_robotics_amd as tra
+dev = torch.device("cuda:0"); ta = dict(device=dev, dtype=torch.float32)
+robot = tra.RobotPanda(tensor_args=ta)
+task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=ta), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=ta)
+q = robot.random_q(4096 * 64).reshape(4096, 64, 7).contiguous()
+qg = q.clone().requires_grad_(True)
+def t(name, fn, n=300):
+    for _ in range(20): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    print(f"{name:58s} {(time.perf_counter() - t0) / n * 1e6:8.1f} us per call")
+t("task.compute_collision_cost(q)            [no grad]", lambda: task.compute_collision_cost(q))
+def fb():
+    qg.grad = None
+    task.compute_collision_cost(qg).sum().backward()
+t("task.compute_collision_cost(q).sum().backward()", fb)
+t("task.compute_collision(q)", lambda: task.compute_collision(q))
+t("robot.fk_map_collision(q)", lambda: robot.fk_map_collision(q))
+t("robot.get_EE_pose(q)", lambda: robot.get_EE_pose(q.reshape(-1, 7)))
+t("tree.compute_forward_kinematics_all_links(q)", lambda: robot.diff_panda.compute_forward_kinematics_all_links(q.reshape(-1, 7)))

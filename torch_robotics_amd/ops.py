@@ -912,19 +912,21 @@ class _Rollout(torch.autograd.Function):
     """cost (…), link_pos (…,L,3) from q; backward uses the gradient the fused kernel already produced."""
 
     @staticmethod
-    def forward(ctx, q, model, cm, weights, ps):
+    def forward(ctx, q, model, cm, weights, ps, want_pos):
         if ps is None:
-            pos, cost, gq = rollout_cost_grad(model, cm, weights, q, want_pos=True)
+            pos, cost, gq = rollout_cost_grad(model, cm, weights, q, want_pos=want_pos)
         else:
-            pos, cost, gq = rollout_points_cost_grad(ps, cm, weights, q, want_pos=True)
+            pos, cost, gq = rollout_points_cost_grad(ps, cm, weights, q, want_pos=want_pos)
         ctx.save_for_backward(gq)
+        if pos is None:                              # cost only: the kernel instantiation / launch without the position stream
+            return cost, None
         ctx.mark_non_differentiable(pos)
         return cost, pos
 
     @staticmethod
     def backward(ctx, gcost, _gpos):
         (gq,) = ctx.saved_tensors
-        return gq * gcost.unsqueeze(-1), None, None, None, None
+        return gq * gcost.unsqueeze(-1), None, None, None, None, None
 
 
 def fk(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
@@ -962,9 +964,11 @@ def ee_cost_ad(cm: CostHandle, H: torch.Tensor, target=None) -> torch.Tensor:
     return ee_cost(cm, Hc, target)
 
 
-def rollout_ad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, ps: Optional[PointSetHandle] = None):
-    """Differentiable fused op: returns (cost, link_pos) -- or (cost, point_pos) when a point set is given."""
-    return _Rollout.apply(_dev_f32(q, "rollout(q)"), model, cm, tuple(float(w) for w in weights), ps)
+def rollout_ad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, ps: Optional[PointSetHandle] = None,
+               want_pos: bool = True):
+    """Differentiable fused op: returns (cost, link_pos) -- or (cost, point_pos) when a point set is given; want_pos=False
+    returns (cost, None) and skips the position output (34.6 of the 50 MB a Panda evaluation writes)."""
+    return _Rollout.apply(_dev_f32(q, "rollout(q)"), model, cm, tuple(float(w) for w in weights), ps, bool(want_pos))
 
 
 class RolloutPlan:

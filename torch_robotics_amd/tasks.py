@@ -234,7 +234,7 @@ class PlanningTask(Task):
             return ops.collision_fields(cm, fields, pos, margin=kwargs.get("margin", None)).reshape(q.shape[:-1])
         w = (1.0 if self.df_collision_self is not None else 0.0, 1.0, 1.0, 0.0)
         if torch.is_grad_enabled() and q.requires_grad:
-            cost, _ = ops.rollout_ad(model, cm, w, q, ps)       # one fused kernel; backward reuses its gradient
+            cost, _ = ops.rollout_ad(model, cm, w, q, ps, want_pos=False)   # one fused kernel; backward reuses its gradient
             return cost
         if ps is not None:
             return ops.rollout_points_cost_grad(ps, cm, w, q, want_pos=False)[1]
