@@ -333,6 +333,9 @@ void trk_cost_model_destroy(TrkCostModel* cm);
 /* reference: EESE3DistanceField.update_target distance_fields.py:344-345.  Host pointer, 16 floats. */
 int trk_cost_model_set_ee_target(TrkCostModel* cm, const float* H16);
 int trk_cost_model_set_ee2_target(TrkCostModel* cm, const float* H16);
+/* trk_cost_fields may run a generated unit's field kernel when the cost model's columns and link sets equal a unit's collision
+ * template (default: on); off = always the table-driven kernel (A/B tests). */
+int trk_cost_model_enable_specialized(TrkCostModel* cm, int32_t on);
 
 /* Which field a cost op evaluates. */
 typedef enum TrkField {

@@ -153,9 +153,15 @@ def test_collision_fields_vs_golden(ops, env):
     assert np.abs(pos.cpu().numpy() - robot["fk_map_collision"].reshape(-1, 11, 3)).max() < TOL_H
     pos_g = dev(robot["fk_map_collision"].reshape(-1, 11, 3))
     for fname, fl in (("self", FIELD_SELF), ("objects", FIELD_OBJECTS), ("ws", FIELD_WS)):
-        c, gp = ops.cost_fields(cm, fl, pos_g, want_grad=True)
-        assert rel_err(c.cpu().numpy(), g[f"cost_{fname}"].reshape(-1)) < TOL_C, fname
-        assert rel_err(gp.cpu().numpy(), g[f"gpos_{fname}"].reshape(-1, 11, 3)) < TOL_G, fname
+        for use_unit in (True, False):           # the Panda unit's field kernel (the fused kernel's code on given positions) / table-driven
+            cm.enable_specialized(use_unit)
+            c, gp = ops.cost_fields(cm, fl, pos_g, want_grad=True)
+            assert rel_err(c.cpu().numpy(), g[f"cost_{fname}"].reshape(-1)) < TOL_C, (fname, use_unit)
+            assert rel_err(gp.cpu().numpy(), g[f"gpos_{fname}"].reshape(-1, 11, 3)) < TOL_G, (fname, use_unit)
+            gc = torch.linspace(0.5, 2.0, pos_g.shape[0], device=DEV)              # an upstream gradient per sample
+            _, gp2 = ops.cost_fields(cm, fl, pos_g, want_grad=True, gcost=gc)
+            assert rel_err(gp2.cpu().numpy(), (gp * gc[:, None, None]).cpu().numpy()) < 1e-6
+        cm.enable_specialized(True)
         np.testing.assert_array_equal(ops.collision_fields(cm, fl, pos_g).cpu().numpy(), g[f"coll_{fname}"].reshape(-1))
         np.testing.assert_array_equal(ops.collision_fields(cm, fl, pos_g, margin=0.0).cpu().numpy(),
                                       g[f"coll0_{fname}"].reshape(-1))

@@ -23,7 +23,7 @@ EXPORTS = [
     "trk_abi_version", "trk_last_error", "trk_model_create", "trk_model_destroy", "trk_model_set_base_pose",
     "trk_model_n_links", "trk_model_n_dofs", "trk_model_is_specialized", "trk_model_enable_specialized", "trk_spec_count",
     "trk_fk_forward", "trk_fk_positions", "trk_fk_backward", "trk_fk_positions_backward", "trk_fk_jacobian", "trk_fk_analytic_jacobian", "trk_ik_step", "trk_ik_steps",
-    "trk_rotmat_to_quat", "trk_cost_model_create", "trk_cost_model_destroy", "trk_cost_model_set_ee_target", "trk_cost_model_set_ee2_target",
+    "trk_rotmat_to_quat", "trk_cost_model_create", "trk_cost_model_destroy", "trk_cost_model_set_ee_target", "trk_cost_model_set_ee2_target", "trk_cost_model_enable_specialized",
     "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_reduce_sum", "trk_debug_set_stamp_buffer", "trk_interpolate_via_points",
     "trk_grid_precompute",
     "trk_frame_compose", "trk_frame_compose_backward", "trk_frame_transform_points", "trk_frame_transform_points_backward",
@@ -92,6 +92,7 @@ def lib():
     L.trk_cost_model_destroy.restype = None
     L.trk_cost_model_set_ee_target.argtypes = [vp, vp]
     L.trk_cost_model_set_ee2_target.argtypes = [vp, vp]
+    L.trk_cost_model_enable_specialized.argtypes = [vp, i32]
     L.trk_cost_fields.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp]
     L.trk_collision_fields.argtypes = [vp, i32, vp, i64, f32, vp, vp]
     L.trk_ee_cost.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp, vp, i64, vp]

@@ -388,6 +388,82 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("    template <int A> __device__ __forceinline__ void rest() const { range<A, R::NP>(); }")
         out.append("};")
 
+    def emit_collision_objectives(E, t, next_chunk):
+        """cost + position adjoints (tb<i>_k) of the three collision fields on link positions t[i][k]; the scene evaluation owns
+        OBJ_TICK_SLOTS tick slots of `flush` per group.  Shared by the fused rollout and the positions-in field kernel."""
+        E.raw("    float cost = 0.0f;")
+        for i in adj_links:
+            E.raw(f"    float tb{i}_0 = 0.0f, tb{i}_1 = 0.0f, tb{i}_2 = 0.0f;")
+        if 0 < NL <= LINK_OBJ_GROUP_MAX:
+            for k, nm in enumerate("xyz"):
+                E.raw(f"    const float p{nm}[NL] = {{{', '.join(E.expr(t[i][k]) for i in tmpl.obj_links)}}};")
+            E.raw("    float gx[NL], gy[NL], gz[NL];")
+            E.raw("#pragma unroll")
+            E.raw("    for (int l = 0; l < NL; ++l) { gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }")
+            c0 = next_chunk[0]
+            next_chunk[0] += OBJ_TICK_SLOTS     # the scene evaluation owns these tick slots, used or flushed on every path
+            E.raw(f"    const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
+            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph);")
+            E.raw(f"    else flush.template range<{c0}, {next_chunk[0]}>();")
+            E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
+            for j, i in enumerate(tmpl.obj_links):
+                E.raw(f"    tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
+        elif NL > 0:
+            # many collision links (tree robots): score them in groups so the working set of one scene evaluation
+            # (positions, keys, gradients: ~10 registers per link) does not sit on top of everything the reverse pass keeps
+            n_groups = -(-NL // LINK_OBJ_GROUP)
+            size = -(-NL // n_groups)
+            for g0 in range(0, NL, size):
+                grp = list(tmpl.obj_links[g0:g0 + size])
+                n = len(grp)
+                E.raw("    {")
+                for k, nm in enumerate("xyz"):
+                    E.raw(f"        const float p{nm}[{n}] = {{{', '.join(E.expr(t[i][k]) for i in grp)}}};")
+                E.raw(f"        float gx[{n}], gy[{n}], gz[{n}];")
+                E.raw("#pragma unroll")
+                E.raw(f"        for (int l = 0; l < {n}; ++l) {{ gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }}")
+                c0 = next_chunk[0]
+                next_chunk[0] += OBJ_TICK_SLOTS
+                E.raw(f"        const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
+                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, {g0});")
+                E.raw(f"        else flush.template range<{c0}, {c0 + OBJ_TICK_SLOTS}>();")
+                E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<{n}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {g0});")
+                for j, i in enumerate(grp):
+                    E.raw(f"        tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
+                E.raw("    }")
+        if tmpl.self_pairs:
+            E.raw("    if (A.w.w_self != 0.0f) {")
+            for pi, (a, b) in enumerate(tmpl.self_pairs):
+                pa = ", ".join(E.expr(t[a][k]) for k in range(3))
+                pb = ", ".join(E.expr(t[b][k]) for k in range(3))
+                E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], {pa}, {pb}, "
+                      f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2, (A.C.clamp_fields & TRK_FIELD_SELF) != 0);")
+            E.raw("    }")
+
+    def emit_boolean_fields(E, t):
+        """`hit` = OR of the selected fields' "signed distance < margin" tests on link positions t[i][k] (k_coll after its FK walk,
+        k_collf on the caller's positions)"""
+        E.raw("    bool hit = false;")
+        if NL > 0:
+            grp_size = NL if NL <= LINK_OBJ_GROUP_MAX else -(-NL // (-(-NL // LINK_OBJ_GROUP)))
+            E.raw("    if (A.coll_fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {")
+            for g0 in range(0, NL, grp_size):
+                grp = list(tmpl.obj_links[g0:g0 + grp_size])
+                n = len(grp)
+                E.raw("        {")
+                for k, nm in enumerate("xyz"):
+                    E.raw(f"            const float p{nm}[{n}] = {{{', '.join(E.expr(t[i][k]) for i in grp)}}};")
+                E.raw(f"            hit |= spec_collision_links<{n}>(A.C, A.coll_fields, A.coll_margin, A.coll_use_default, px, py, pz, lds_sph, {g0});")
+                E.raw("        }")
+            E.raw("    }")
+        if tmpl.self_pairs:
+            E.raw("    if (A.coll_fields & TRK_FIELD_SELF) {")
+            for pi, (a_, b_) in enumerate(tmpl.self_pairs):
+                pa = ", ".join(E.expr(t[a_][k]) for k in range(3))
+                pb = ", ".join(E.expr(t[b_][k]) for k in range(3))
+                E.raw(f"        hit |= spec_self_hit(A.coll_use_default ? cptr(A.C.self_margin)[{pi}] : A.coll_margin, {pa}, {pb});")
+            E.raw("    }")
+
     for base_identity in (True, False):
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
@@ -507,54 +583,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw(tick_line())
         E.raw("    spec_stamp(A.stamps, wblock, 3, lane);")
         # ---------------- objectives ----------------
-        E.raw("    float cost = 0.0f;")
-        for i in adj_links:
-            E.raw(f"    float tb{i}_0 = 0.0f, tb{i}_1 = 0.0f, tb{i}_2 = 0.0f;")
-        if 0 < NL <= LINK_OBJ_GROUP_MAX:
-            for k, nm in enumerate("xyz"):
-                E.raw(f"    const float p{nm}[NL] = {{{', '.join(E.expr(t[i][k]) for i in tmpl.obj_links)}}};")
-            E.raw("    float gx[NL], gy[NL], gz[NL];")
-            E.raw("#pragma unroll")
-            E.raw("    for (int l = 0; l < NL; ++l) { gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }")
-            c0 = next_chunk[0]
-            next_chunk[0] += OBJ_TICK_SLOTS     # the scene evaluation owns these tick slots, used or flushed on every path
-            E.raw(f"    const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
-            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph);")
-            E.raw(f"    else flush.template range<{c0}, {next_chunk[0]}>();")
-            E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
-            for j, i in enumerate(tmpl.obj_links):
-                E.raw(f"    tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
-        elif NL > 0:
-            # many collision links (tree robots): score them in groups so the working set of one scene evaluation
-            # (positions, keys, gradients: ~10 registers per link) does not sit on top of everything the reverse pass keeps
-            n_groups = -(-NL // LINK_OBJ_GROUP)
-            size = -(-NL // n_groups)
-            for g0 in range(0, NL, size):
-                grp = list(tmpl.obj_links[g0:g0 + size])
-                n = len(grp)
-                E.raw("    {")
-                for k, nm in enumerate("xyz"):
-                    E.raw(f"        const float p{nm}[{n}] = {{{', '.join(E.expr(t[i][k]) for i in grp)}}};")
-                E.raw(f"        float gx[{n}], gy[{n}], gz[{n}];")
-                E.raw("#pragma unroll")
-                E.raw(f"        for (int l = 0; l < {n}; ++l) {{ gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }}")
-                c0 = next_chunk[0]
-                next_chunk[0] += OBJ_TICK_SLOTS
-                E.raw(f"        const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
-                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, {g0});")
-                E.raw(f"        else flush.template range<{c0}, {c0 + OBJ_TICK_SLOTS}>();")
-                E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<{n}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {g0});")
-                for j, i in enumerate(grp):
-                    E.raw(f"        tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
-                E.raw("    }")
-        if tmpl.self_pairs:
-            E.raw("    if (A.w.w_self != 0.0f) {")
-            for pi, (a, b) in enumerate(tmpl.self_pairs):
-                pa = ", ".join(E.expr(t[a][k]) for k in range(3))
-                pb = ", ".join(E.expr(t[b][k]) for k in range(3))
-                E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], {pa}, {pb}, "
-                      f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2, (A.C.clamp_fields & TRK_FIELD_SELF) != 0);")
-            E.raw("    }")
+        emit_collision_objectives(E, t, next_chunk)
         E.raw("    spec_stamp(A.stamps, wblock, 4, lane);")
         for ee, tgt, rb in tracked:
             E.raw(f"    float {rb}[9] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};")
@@ -665,26 +694,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         _emit_angles(E, kin)
         for p in range(1, L):
             _emit_fk_link(E, kin, int(kin.order[p]), R, t, passv, snap)
-        E.raw("    bool hit = false;")
-        if NL > 0:
-            grp_size = NL if NL <= LINK_OBJ_GROUP_MAX else -(-NL // (-(-NL // LINK_OBJ_GROUP)))
-            E.raw("    if (A.coll_fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {")
-            for g0 in range(0, NL, grp_size):
-                grp = list(tmpl.obj_links[g0:g0 + grp_size])
-                n = len(grp)
-                E.raw("        {")
-                for k, nm in enumerate("xyz"):
-                    E.raw(f"            const float p{nm}[{n}] = {{{', '.join(E.expr(t[i][k]) for i in grp)}}};")
-                E.raw(f"            hit |= spec_collision_links<{n}>(A.C, A.coll_fields, A.coll_margin, A.coll_use_default, px, py, pz, lds_sph, {g0});")
-                E.raw("        }")
-            E.raw("    }")
-        if tmpl.self_pairs:
-            E.raw("    if (A.coll_fields & TRK_FIELD_SELF) {")
-            for pi, (a_, b_) in enumerate(tmpl.self_pairs):
-                pa = ", ".join(E.expr(t[a_][k]) for k in range(3))
-                pb = ", ".join(E.expr(t[b_][k]) for k in range(3))
-                E.raw(f"        hit |= spec_self_hit(A.coll_use_default ? cptr(A.C.self_margin)[{pi}] : A.coll_margin, {pa}, {pb});")
-            E.raw("    }")
+        emit_boolean_fields(E, t)
         E.raw("    if (lane < rows) A.coll_out[base + lane] = hit ? 1 : 0;")
         E.raw("}")
         out.extend(E.lines)
@@ -742,6 +752,63 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             i = int(kin.order[p])
             _emit_fk_link(E, kin, i, R, t, passv, snap)
             emit_h(i, p)
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
+    # ---- the collision fields on GIVEN link positions (trk_cost_fields: EmbodimentDistanceFieldBase.compute_embodiment_cost,
+    # distance_fields.py:107-124, for the fields selected by the caller): positions in through the LDS transpose, the fused
+    # kernel's objective code on them, cost + position gradient out.  No kinematics: the unit is found by its collision
+    # template (columns = all links of the robot), so the reference-style call `field.compute_cost(q, link_pos)` runs the same
+    # arithmetic as the fused rollout.
+    fields_ok = 3 * L <= 96 and (NL > 0 or bool(tmpl.self_pairs))
+    if fields_ok:
+        E = Emitter()
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if 3 * L <= 48 else 2}) k_fields(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {3 * L} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {3 * L});")
+        E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {3 * L}) + wave * TRK_LDS_SPHERES;")
+        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw(f"    float p[{3 * L}];")
+        E.raw(f"    spec_load_q<{3 * L}>(A.fld_pos, base, rows, lane, lds, p);")
+        E.raw("    const NoFlush flush;")
+        tp = {i: [S(1.0, f"p[{3 * i + k}]") for k in range(3)] for i in range(L)}
+        emit_collision_objectives(E, tp, [0])
+        E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
+        E.raw("    if (A.fld_g) {")
+        E.raw("        const float sc = (A.fld_gcost && lane < rows) ? A.fld_gcost[base + lane] : 1.0f;")
+        gl = []
+        for i in range(L):
+            gl += [f"sc * tb{i}_{k}" if i in adj_links else "0.0f" for k in range(3)]
+        E.raw(f"        const float gv[{3 * L}] = {{{', '.join(gl)}}};")
+        E.raw(f"        spec_store_gq<{3 * L}>(A.fld_g, base, rows, lane, lds, gv);")
+        E.raw("    }")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
+    # ---- the same for the boolean fields (trk_collision_fields; distance_fields.py:210-215, 283-291)
+    if fields_ok:
+        E = Emitter()
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if 3 * L <= 48 else 2}) k_collf(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {3 * L} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {3 * L});")
+        E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {3 * L}) + wave * TRK_LDS_SPHERES;")
+        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw(f"    float p[{3 * L}];")
+        E.raw(f"    spec_load_q<{3 * L}>(A.fld_pos, base, rows, lane, lds, p);")
+        emit_boolean_fields(E, {i: [S(1.0, f"p[{3 * i + k}]") for k in range(3)] for i in range(L)})
+        E.raw("    if (lane < rows) A.coll_out[base + lane] = hit ? 1 : 0;")
         E.raw("}")
         out.extend(E.lines)
         out.append("")
@@ -1086,6 +1153,12 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("    if (base_identity) hipLaunchKernelGGL(k_fkhbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    else hipLaunchKernelGGL(k_fkhbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("}")
+    if fields_ok:
+        out.append("static void launch_fields(const SpecArgs& a, int, hipStream_t st) {      // coll_out set: the boolean fields")
+        out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+        out.append("    if (a.coll_out) hipLaunchKernelGGL(k_collf, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    else hipLaunchKernelGGL(k_fields, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("}")
     out.append("static void launch_fk1(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     out.append("    if (base_identity) hipLaunchKernelGGL(k_fk1_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
@@ -1111,7 +1184,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
                f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}, "
-               f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1}};")
+               f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1, {'launch_fields' if fields_ok else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -1576,7 +1649,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
-               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};")
+               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out

@@ -116,6 +116,7 @@ struct TrkCostModel {
     void* d_blob = nullptr;
     std::vector<int32_t> obj_link_idx;   // host copies, to match a specialised kernel's baked link sets
     std::vector<int32_t> self_pairs;     // mapped to link indices
+    bool spec_enabled = true;            // trk_cost_model_enable_specialized: may trk_cost_fields use a generated unit's field kernel
 };
 
 static bool spec_matches(const SpecEntry* e, const TrkCostModel* cm, const TrkRolloutWeights* w) {
@@ -138,6 +139,15 @@ static const SpecEntry* points_spec_for(const TrkPointSet* ps, const TrkCostMode
     for (const SpecEntry* e : spec_registry())
         if (e->n_points == ps->dev.n_points && e->n_points > 0 && e->model_hash == ps->model->hash &&
             e->points_hash == ps->hash && spec_matches(e, cm, w))
+            return e;
+    return nullptr;
+}
+// field kernel on given positions: no kinematic model is involved, the unit is found by its collision template alone
+// (columns = all links of the robot the unit was generated for)
+static const SpecEntry* fields_spec_for(const TrkCostModel* cm, const TrkRolloutWeights* w) {
+    if (!cm->spec_enabled) return nullptr;
+    for (const SpecEntry* e : spec_registry())
+        if (e->n_points == 0 && e->launch_fields && e->n_links == cm->hdr.n_links_in && spec_matches(e, cm, w))
             return e;
     return nullptr;
 }
@@ -908,6 +918,12 @@ void trk_cost_model_destroy(TrkCostModel* cm) {
     delete cm;
 }
 
+int trk_cost_model_enable_specialized(TrkCostModel* cm, int32_t on) {
+    if (!cm) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_enable_specialized: null cost model");
+    cm->spec_enabled = on != 0;
+    return TRK_OK;
+}
+
 int trk_cost_model_set_ee_target(TrkCostModel* cm, const float* H16) {
     if (!cm || !H16) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_set_ee_target: null argument");
     std::memcpy(cm->hdr.ee_target, H16, sizeof(float) * 16);
@@ -925,6 +941,18 @@ int trk_cost_fields(const TrkCostModel* cm, int32_t fields, const float* link_po
     if (!cm) return fail(TRK_ERR_INVALID_ARG, "trk_cost_fields: null cost model");
     if (n < 0 || (n > 0 && (!link_pos || !cost)) || (fields & ~7) || !fields) return fail(TRK_ERR_INVALID_ARG, "trk_cost_fields: bad argument");
     if (n == 0) return TRK_OK;
+    {
+        TrkRolloutWeights w{(fields & TRK_FIELD_SELF) ? 1.0f : 0.0f, (fields & TRK_FIELD_OBJECTS) ? 1.0f : 0.0f,
+                            (fields & TRK_FIELD_WS) ? 1.0f : 0.0f, 0.0f};
+        if (const SpecEntry* e = fields_spec_for(cm, &w)) {      // the fused kernel's objective code on the caller's positions
+            SpecArgs a{};
+            a.C = cm->hdr; a.w = w;
+            a.n = n; a.fld_pos = link_pos; a.fld_gcost = gcost; a.fld_g = g_link_pos; a.cost = cost;
+            e->launch_fields(a, 1, (hipStream_t)stream);
+            TRK_HIP(hipGetLastError());
+            return TRK_OK;
+        }
+    }
     trk_launch_cost_fields(cm->hdr, fields, link_pos, n, gcost, cost, g_link_pos, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
@@ -936,6 +964,19 @@ int trk_collision_fields(const TrkCostModel* cm, int32_t fields, const float* li
     if (n < 0 || (n > 0 && (!link_pos || !in_collision)) || (fields & ~7) || !fields) return fail(TRK_ERR_INVALID_ARG, "trk_collision_fields: bad argument");
     if (n == 0) return TRK_OK;
     const int use_default = std::isnan(margin_override) ? 1 : 0;
+    {
+        TrkRolloutWeights w{(fields & TRK_FIELD_SELF) ? 1.0f : 0.0f, (fields & TRK_FIELD_OBJECTS) ? 1.0f : 0.0f,
+                            (fields & TRK_FIELD_WS) ? 1.0f : 0.0f, 0.0f};
+        if (const SpecEntry* e = fields_spec_for(cm, &w)) {      // the fused boolean kernel's tests on the caller's positions
+            SpecArgs a{};
+            a.C = cm->hdr; a.w = w;
+            a.n = n; a.fld_pos = link_pos; a.coll_out = in_collision; a.coll_fields = fields;
+            a.coll_use_default = use_default; a.coll_margin = use_default ? 0.0f : margin_override;
+            e->launch_fields(a, 1, (hipStream_t)stream);
+            TRK_HIP(hipGetLastError());
+            return TRK_OK;
+        }
+    }
     trk_launch_collision_fields(cm->hdr, fields, link_pos, n, use_default ? 0.0f : margin_override, use_default, in_collision, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;

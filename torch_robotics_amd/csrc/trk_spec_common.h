@@ -41,6 +41,9 @@ struct SpecArgs {
     int32_t jac_p_end, jac_n_cols;    // the walk may stop after this pre-order position; number of joints that get a column
     int8_t jac_slot[TRK_MAX_DOFS];    // DOF -> record slot of its column (-1: the column stays zero), in walk order
     float* jac_pos; float* jac_quat; float* jac_lin; float* jac_ang;
+    // field kernel on given link positions (trk_cost_fields, launch_fields): positions [N, L, 3] in, per-sample upstream gradient
+    // (nullable), cost via `cost`, position gradient [N, L, 3] out (nullable); the fields are selected through `w`
+    const float* fld_pos; const float* fld_gcost; float* fld_g;
     // all-links FK kernel (trk_fk_forward with every link selected, launch_fkh): H [N, L, 4, 4] out;
     // its reverse mode (launch_fkhbwd): the adjoint gH [N, L, 4, 4] in (read only), gq out
     float* fk_H;
@@ -70,7 +73,7 @@ typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 13)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 14)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -96,6 +99,7 @@ struct SpecEntry {
     SpecLaunchFn launch_fkhbwd; // its reverse mode (trk_fk_backward, every link selected): fk_H = gH in, gq out; nullptr if not generated
     SpecIkLaunchFn launch_ik;   // Adam IK iterations on ee_link, configurations and optimiser state in registers; nullptr if not generated
     SpecLaunchFn launch_fk1;    // FK matrix of one link (jac_link, jac_p_end) -> fk_H [N,4,4]; nullptr if not generated
+    SpecLaunchFn launch_fields; // collision fields on given link positions (trk_cost_fields); nullptr if not generated
 };
 
 // registry filled by static initialisers of the generated translation units

@@ -156,6 +156,10 @@ class CostHandle:
         check(lib().trk_cost_model_set_ee2_target(self._h, H.ctypes.data), "trk_cost_model_set_ee2_target")
         self.spec.ee2_target = H.reshape(4, 4).copy()
 
+    def enable_specialized(self, on: bool) -> None:
+        """May `cost_fields` on this cost model run a generated unit's field kernel (default) or only the table-driven one."""
+        check(lib().trk_cost_model_enable_specialized(self._h, int(bool(on))), "trk_cost_model_enable_specialized")
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
@@ -530,12 +534,12 @@ def cost_fields(cm: CostHandle, fields: int, link_pos: torch.Tensor, gcost: Opti
 def collision_fields(cm: CostHandle, fields: int, link_pos: torch.Tensor, margin: Optional[float] = None) -> torch.Tensor:
     link_pos = _dev_f32(link_pos, "collision_fields(link_pos)").reshape(-1, cm.n_links_in, 3)
     n = link_pos.shape[0]
-    out = torch.empty((n,), device=link_pos.device, dtype=torch.uint8)
+    out = torch.empty((n,), device=link_pos.device, dtype=torch.bool)       # the kernel writes 0 / 1 bytes
     with _on(link_pos.device):
         check(lib().trk_collision_fields(cm._h, int(fields), link_pos.data_ptr(), n,
                                          float("nan") if margin is None else float(margin), out.data_ptr(),
                                          _stream(link_pos)), "trk_collision_fields")
-    return out.bool()
+    return out
 
 
 def ee_cost(cm: CostHandle, H: torch.Tensor, target: Optional[torch.Tensor] = None,
