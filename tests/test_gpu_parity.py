@@ -1129,6 +1129,19 @@ def test_randomised_generated_vs_table_driven_and_oracle(ops, oracle_lib, ident)
             assert np.abs(gq.cpu().numpy() - g64).max() / max(1.0, float(np.abs(g64).max())) < TOL_G, (ident, draw, n, w, use_spec)
             res[use_spec] = (c, gq)
         h.enable_specialized(True)
+        # the same fields on GIVEN positions: the unit's field kernels against the table-driven ones
+        posd = ops.fk_positions(h, dev(q))
+        fl = int(rng.choice([1, 2, 4, 3, 6, 7]))
+        mg = None if rng.random() < 0.5 else float(rng.uniform(0.0, 0.1))
+        outs = {}
+        for use_unit in (True, False):
+            cm.enable_specialized(use_unit)
+            outs[use_unit] = ops.cost_fields(cm, fl, posd, want_grad=True) + (ops.collision_fields(cm, fl, posd, margin=mg),)
+        cm.enable_specialized(True)
+        (c1, g1, b1), (c0, g0, b0) = outs[True], outs[False]
+        assert float((c1 - c0).abs().max()) <= TOL_C * max(1.0, float(c0.abs().max())), (ident, draw, fl)
+        assert float((g1 - g0).abs().max()) <= TOL_G * max(1.0, float(g0.abs().max())), (ident, draw, fl)
+        assert int((b1 != b0).sum()) <= max(1, n // 2000), (ident, draw, fl, mg)
         if rng.random() < 0.5:                                        # fp16 I/O through the generated kernel
             p16, c16, g16 = o.rollout(q.astype(np.float16).astype(np.float64), w, "f64")
             pos_h, c_h, gq_h = ops.rollout_cost_grad(h, cm, w, dev(q).half(), want_pos=True)
