@@ -387,6 +387,11 @@ def test_trajectory_validation_like_the_reference():
     """8f rank 1: get_trajs_collision_and_free + stats (tasks.py:234-328) and interpolate_traj_via_points."""
     g, gt = gold("trajs_panda"), gold("traj")
     from torch_robotics_amd import ops
+    # a trajectory too large for one workgroup's LDS takes the element-per-thread kernel: same bits as the per-trajectory kernel
+    big = torch.randn(3, 2100, 7, device=DEV)
+    ib = ops.interpolate_traj_via_points(big, num_interpolation=3)
+    ref = torch.stack([ops.interpolate_traj_via_points(big[:, k:k + 2].contiguous(), num_interpolation=3) for k in (0, 1000, 2098)])
+    assert ib.shape == (3, 2099 * 3, 7) and all(torch.equal(ib[:, 3 * k:3 * k + 3], ref[j]) for j, k in enumerate((0, 1000, 2098)))
     interp = ops.interpolate_traj_via_points(dev(gt["x"]), num_interpolation=5)
     np.testing.assert_array_equal(interp.cpu().numpy(), gt["interp5"])          # bit-exact
     robot = tra.RobotPanda(tensor_args=TA)

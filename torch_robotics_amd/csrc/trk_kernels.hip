@@ -1372,9 +1372,10 @@ k_sdf_points(DevCostHdr C, const float* __restrict__ pts, int64_t n, float* __re
 // x_i * alpha_a + x_{i+1} * (1 - alpha_a) for the n interior alphas (the via points themselves are not emitted).
 // x [T, H, D] -> out [T, (H-1)*n, D]; alpha, beta = 1 - alpha: DEVICE [n] (host computes torch.linspace).
 // Two roundings per product and one for the sum, like the reference's `a * alpha + b * (1 - alpha)`.
+// element-per-thread form: any trajectory size (used when a trajectory's way points do not fit the LDS of a workgroup)
 __global__ void __launch_bounds__(256)
-k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, int n_interp,
-                         const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ out) {
+k_interpolate_via_points_flat(const float* __restrict__ x, int64_t T, int H, int D, int n_interp,
+                              const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ out) {
     const int64_t total = T * (int64_t)(H - 1) * n_interp * D;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -1386,6 +1387,31 @@ k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, i
     const int64_t t = s / (H - 1);
     const float x0 = x[(t * H + i) * D + d], x1 = x[(t * H + i + 1) * D + d];
     out[idx] = __fadd_rn(__fmul_rn(x0, alpha[a]), __fmul_rn(x1, beta[a]));
+}
+
+// One workgroup per trajectory: its H x D way points are staged in LDS once (coalesced), then thread r produces output row
+// r = i * n + a (D consecutive floats) -- one 32-bit division per row instead of four 64-bit ones per element.
+__global__ void __launch_bounds__(256)
+k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, int n_interp,
+                         const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];           // [H * D] way points, then alpha[n], beta[n]
+    const int64_t t = blockIdx.x;
+    const int hd = H * D;
+    const float* xt = x + t * hd;
+    for (int k = threadIdx.x; k < hd; k += blockDim.x) xs[k] = xt[k];
+    float* al = xs + hd;
+    float* be = al + n_interp;
+    for (int k = threadIdx.x; k < n_interp; k += blockDim.x) { al[k] = alpha[k]; be[k] = beta[k]; }
+    __syncthreads();
+    const int rows = (H - 1) * n_interp;
+    float* ot = out + t * (int64_t)rows * D;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const int i = r / n_interp, a = r - i * n_interp;
+        const float fa = al[a], fb = be[a];
+        const float* p0 = xs + i * D;
+        float* o = ot + r * D;
+        for (int d = 0; d < D; ++d) o[d] = __fadd_rn(__fmul_rn(p0[d], fa), __fmul_rn(p0[D + d], fb));
+    }
 }
 
 // ============================================================================================
@@ -1700,8 +1726,13 @@ void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const 
 
 void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_interp, const float* alpha, const float* beta,
                             float* out, hipStream_t st) {
+    const size_t lds = sizeof(float) * ((size_t)H * D + 2 * (size_t)n_interp);
+    if (lds <= 48 * 1024 && T <= 0x7fffffff) {
+        hipLaunchKernelGGL(k_interpolate_via_points, dim3((unsigned)T), dim3(256), lds, st, x, T, H, D, n_interp, alpha, beta, out);
+        return;
+    }
     const int64_t total = T * (int64_t)(H - 1) * n_interp * D;
-    hipLaunchKernelGGL(k_interpolate_via_points, dim3(grid_for(total, 256)), dim3(256), 0, st, x, T, H, D, n_interp, alpha, beta, out);
+    hipLaunchKernelGGL(k_interpolate_via_points_flat, dim3(grid_for(total, 256)), dim3(256), 0, st, x, T, H, D, n_interp, alpha, beta, out);
 }
 
 int trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
