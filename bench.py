@@ -2,28 +2,36 @@
 """Headline benchmark: FK + cost + gradient rollouts/sec (batch x horizon), Franka Panda 7-DOF.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without a launcher: this script starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 --master-port P bench.py ...` itself as a CHILD process, before anything in this process has touched the GPU, and
+exits with the child's code.  Under a launcher (RANK / LOCAL_RANK / WORLD_SIZE in the environment) it is one rank.
 
 One step = one pass of the fused hot path (`trk_rollout_cost_grad`) over one batch of synthetic joint
 trajectories resident in HBM: read q, write link positions, cost and d cost / d q.
 Workload (BASELINE.json configs[1], "c2"): batch 4096 x horizon 64, Panda (11 links / 7 DOF), scene
 EnvSpheres3D (10 spheres, analytic SDF, cutoff 0.03), cost = object collision + EE SE(3) tracking
-(target p=(0.4,0.2,0.5), R=I).  `--config c3` adds self-collision pairs and the workspace box.
+(target p=(0.4,0.2,0.5), R=I).  `--config c3` adds self-collision pairs and the workspace box (configs[2]'s objective stack).
+`--scene grid|shelf|maze` are SURVEY 8(d)'s secondary runs of the same workload: the 200^3 voxel SDF of the same spheres
+(+16 B of gathers per collision link and sample), EnvTableShelf and EnvMazeBoxes3D (box scenes; same algorithmic bytes).
 Multi-GPU: the batch is sharded, each rank owns 4096 x 64 samples (weak scaling); the only exchange is an
 RCCL all-reduce of the packed sums [cost | cost per time step | gradient per time step and joint] (2 kB), issued once per
-`--reduce-every` steps on a side stream.
+`--reduce-every` steps on a side stream.  `value` INCLUDES those collectives; `multi_gpu.kernel_only` is the same loop without them,
+`multi_gpu.full_stack_c3` is configs[2]'s objective stack on the same shards.
 
 Timed region: W untimed warm-up steps, then exactly K steps bracketed on both sides by a barrier (N > 1: a one-element all-reduce
 enqueued on the launch stream -- it completes only when every rank has reached it) + `torch.cuda.synchronize()`; the maximum over the
 ranks is taken.  The whole measurement is rehearsed once and discarded first.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = 192 algorithmic bytes/sample x samples per launch /
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes/sample x samples per launch /
 average launch duration (HIP events around the timed region on the launch stream).
-`cpu_baseline` = the C oracle (OpenMP over samples, all host cores) on a bounded sample of the same input.
+`cpu_baseline` = the C oracle (OpenMP over samples) on a bounded sample of the same input, on all host threads (`value`) and on one.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -32,19 +40,24 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# fp32 vector peak 157.3 TFLOP/s = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flop: one 64-lane VALU instruction takes a SIMD 2 cycles
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
+PMC_FILES = ("r03_pmc.json", "r02_hbm_traffic.json")      # per-launch counters recorded by tools/run_r03_profiles.sh
 
 
-def algorithmic_bytes_per_sample(D, L):
-    # read q (4D) + write link positions (12L) + cost (4) + gradient (4D)
-    return 4 * D + 12 * L + 4 + 4 * D
+def algorithmic_bytes_per_sample(D, L, n_grid_links=0):
+    # read q (4D) + write link positions (12L) + cost (4) + gradient (4D); the voxel-grid scene adds one
+    # 16-byte gather (sdf + stored gradient of the nearest cell) per collision link
+    return 4 * D + 12 * L + 4 + 4 * D + 16 * n_grid_links
 
 
-def main():
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--scene", default="spheres", choices=["spheres", "grid", "shelf", "maze"])
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=64)
     ap.add_argument("--reduce-every", type=int, default=64)
@@ -58,7 +71,70 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' + --single-device lets the N>1 control flow run on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0")
-    args = ap.parse_args()
+    ap.add_argument("--same-q", action="store_true", help="debug: every rank draws the same q (all-reduced sums == N x rank 0's)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 and no launcher around us: start the N ranks as a child `torch.distributed.run` and return its exit code.
+    Nothing in this process has imported torch or touched the GPU yet (a process that has must never exec / be replaced)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL's peer mappings need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")                     # torchrun would set 1; the ranks do no CPU arithmetic anyway
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_model_name():
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def pmc_record(key):
+    """Per-launch PMC figures of a workload from profiles/ (bench.py cannot run rocprofv3 on itself): (record, file name)."""
+    for name in PMC_FILES:
+        try:
+            rec = json.loads((ROOT / "profiles" / name).read_text())["workloads"].get(key)
+        except (OSError, ValueError, KeyError):
+            rec = None
+        if rec:
+            return rec, "profiles/" + name
+    return None, None
+
+
+def make_task(tra, scene, ta):
+    import numpy as np
+    if scene == "spheres":
+        env, what = tra.EnvSpheres3D(tensor_args=ta), "EnvSpheres3D, 10 spheres, analytic SDF"
+    elif scene == "grid":
+        env = tra.EnvSpheres3D(precompute_sdf_obj_fixed=True, sdf_cell_size=0.01, tensor_args=ta)
+        what = "EnvSpheres3D as a 200^3 voxel SDF with stored gradients (GridMapSDF, cell 0.01)"
+    elif scene == "shelf":
+        env, what = tra.EnvTableShelf(tensor_args=ta), "EnvTableShelf, 1 + 10 rounded boxes in 2 posed objects"
+    else:
+        env, what = tra.EnvMazeBoxes3D(tensor_args=ta), "EnvMazeBoxes3D, 14 rounded boxes"
+    robot = tra.RobotPanda(tensor_args=ta)
+    task = tra.PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=0.03, tensor_args=ta)
+    Ht = np.eye(4, dtype=np.float32)
+    Ht[:3, 3] = (0.4, 0.2, 0.5)
+    task.set_ee_target(Ht, w_pos=1.0, w_rot=1.0, square=True)
+    return robot, task, what
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
 
     import numpy as np
     import torch
@@ -69,8 +145,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dev = torch.device("cuda", 0 if args.single_device else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
@@ -81,17 +157,14 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     ta = dict(device=dev, dtype=torch.float32)
-    robot = tra.RobotPanda(tensor_args=ta)
-    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=ta), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=ta)
-    Ht = np.eye(4, dtype=np.float32)
-    Ht[:3, 3] = (0.4, 0.2, 0.5)
-    task.set_ee_target(Ht, w_pos=1.0, w_rot=1.0, square=True)
-    weights = (0.0, 1.0, 0.0, 1.0) if args.config == "c2" else (1.0, 1.0, 1.0, 1.0)
+    robot, task, scene_text = make_task(tra, args.scene, ta)
+    W_C2, W_C3 = (0.0, 1.0, 0.0, 1.0), (1.0, 1.0, 1.0, 1.0)
+    weights = W_C2 if args.config == "c2" else W_C3
     if args.weights:
         weights = tuple(float(v) for v in args.weights.split(","))
     B, H = args.batch, args.horizon
     D, L = robot.q_dim, robot.diff_panda._kin.n_links
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    gen = torch.Generator(device=dev).manual_seed(1234 + (0 if args.same_q else rank))
     q = robot.random_q(B * H, generator=gen).reshape(B, H, D).contiguous()
     model, cm = task._fused_handles(dev)
     plan = ops.RolloutPlan(model, cm, weights, q, want_pos=not args.no_pos)
@@ -103,18 +176,22 @@ def main():
     # the collective fires in the MIDDLE of every `reduce_every`-step interval (a planner consumes the sums a few evaluations
     # later), and the interval shrinks for short runs so that the timed region always contains at least one all-reduce
     R = max(1, min(args.reduce_every, args.steps))
-    n_slots = 2 * ((args.warmup + args.steps) // R + 2) + 8
+    n_slots = 6 * ((args.warmup + args.steps) // R + 2) + 8
     # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
     packed = torch.zeros((n_slots, 1 + H + H * D), **ta)
     stream = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev) if world > 1 else None
 
-    def reduce_slot(k):
+    def pack_sums(pl, buf):
+        """The sums of the latest evaluation of plan `pl` -> buf (three small kernels on the launch stream)."""
+        ops.reduce_sum(block_sums, out=buf[0:1])
+        torch.sum(pl.cost, dim=0, out=buf[1:1 + H])
+        torch.sum(pl.gq, dim=0, out=buf[1 + H:].view(H, D))
+
+    def reduce_slot(pl, k):
         # sums of the latest evaluation -> one small all-reduce (2 kB), off the launch stream
         buf = packed[k]
-        ops.reduce_sum(block_sums, out=buf[0:1])
-        torch.sum(plan.cost, dim=0, out=buf[1:1 + H])
-        torch.sum(plan.gq, dim=0, out=buf[1 + H:].view(H, D))
+        pack_sums(pl, buf)
         ev = torch.cuda.Event()
         ev.record(stream)
         with torch.cuda.stream(side):
@@ -138,7 +215,7 @@ def main():
 
     slot = [0]
 
-    def run(first, count):
+    def run(pl, count, collectives):
         if graph is not None:
             assert count % args.graph == 0
             for _ in range(count // args.graph):
@@ -146,9 +223,9 @@ def main():
             return
         s = stream.cuda_stream
         for j in range(count):
-            plan.launch(bs_ptr, s)
-            if side is not None and j % R == R // 2:        # counted from the start of this (warm-up or timed) region
-                reduce_slot(slot[0])
+            pl.launch(bs_ptr, s)
+            if collectives and j % R == R // 2:        # counted from the start of this (warm-up or timed) region
+                reduce_slot(pl, slot[0])
                 slot[0] += 1
 
     if graph is not None:
@@ -161,16 +238,17 @@ def main():
         only after every rank has reached it, so the `torch.cuda.synchronize()` that follows returns when all ranks are done."""
         dist.all_reduce(flag)
 
-    def measure(first):
-        """W untimed warm-up steps, then exactly K steps between barrier + synchronize brackets; returns (wall s, event ms)."""
-        run(first, args.warmup)
+    def measure(pl, collectives):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize brackets; returns (wall s, event ms),
+        the wall time already as the maximum over the ranks."""
+        run(pl, args.warmup, collectives)
         if world > 1:
             barrier_in_stream()
         torch.cuda.synchronize(dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        run(first + args.warmup, args.steps)
+        run(pl, args.steps, collectives)
         ev1.record(stream)
         ta_ = time.perf_counter()
         if world > 1:
@@ -184,20 +262,23 @@ def main():
         if os.environ.get("TRK_BENCH_TRACE"):
             print(f"[trace] submit {1e6 * (ta_ - t0):.1f} us, wait {1e6 * (tb_ - ta_):.1f} us, sync {1e6 * (wall - (tb_ - t0)):.1f} us, "
                   f"events {1e3 * ev0.elapsed_time(ev1):.1f} us", file=sys.stderr)
-        return wall, (ev0.elapsed_time(ev1) if graph is None else wall * 1e3)
+        ev_ms = ev0.elapsed_time(ev1) if graph is None else wall * 1e3
+        if world > 1:
+            tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall = float(tmax.item())
+        return wall, ev_ms
 
     # one rehearsal of the whole measurement (discarded): the first pass through the event / sync / launch code paths of a
     # fresh process costs ~10 us more, which matters when the driver asks for only 20 timed steps (~200 us of GPU work)
-    measure(0)
-    elapsed, ev_ms = measure(args.warmup + args.steps)
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    measure(plan, world > 1)
+    elapsed, ev_ms = measure(plan, world > 1)
 
     samples_per_step = B * H * world
     value = samples_per_step * args.steps / elapsed
-    bytes_per_launch = algorithmic_bytes_per_sample(D, L) * B * H
+    n_grid_links = len(cm.spec.obj_link_idx) if (cm.spec.grid is not None and weights[1] != 0.0) else 0
+    bps = algorithmic_bytes_per_sample(D, L, n_grid_links)
+    bytes_per_launch = bps * B * H
     launch_s = ev_ms * 1e-3 / args.steps
     achieved = bytes_per_launch / launch_s / 1e9
 
@@ -207,38 +288,78 @@ def main():
     ref = plan.cost.double().sum().item()
     assert abs(last - ref) <= 1e-4 * abs(ref) + 1e-3, (last, ref)
 
-    # HBM traffic per launch from the PMC passes recorded under profiles/ (bench.py cannot run rocprofv3 on itself)
-    traffic = None
-    try:
-        key = f"{args.config}:{B}x{H}:{'specialized' if model.specialized else 'table-driven'}"
-        if not args.weights and not args.no_pos:
-            traffic = json.loads((ROOT / "profiles" / "r02_hbm_traffic.json").read_text())["workloads"][key]["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    # PMC figures of this workload recorded under profiles/ (separate rocprofv3 --pmc passes of this very command)
+    kind = "specialized" if model.specialized else "table-driven"
+    pmc_key = f"{args.config}:{args.scene}:{B}x{H}:{kind}"
+    pmc, pmc_src = (None, None) if (args.weights or args.no_pos) else pmc_record(pmc_key)
+    if pmc is None and args.scene == "spheres" and not (args.weights or args.no_pos):
+        pmc, pmc_src = pmc_record(f"{args.config}:{B}x{H}:{kind}")                  # round-2 key format
+    traffic = pmc.get("traffic_bytes_per_launch") if pmc else None
+    valu_per_wave = pmc.get("valu_insts_per_wave") if pmc else None
+    if valu_per_wave is None and pmc_src and args.scene == "spheres" and args.config == "c2":
+        valu_per_wave = 911.0                                                       # profiles/r02_pmc_sq_raw.txt
+    valu_frac = None if valu_per_wave is None else valu_per_wave * nb / launch_s / VALU_PEAK_WAVE_INSTS_PER_S
 
+    objectives = {"c2": "SDF-obstacle + EE-tracking", "c3": "self-collision + SDF-obstacle + workspace box + EE-tracking"}
     out = {
         "metric": "FK+cost+grad rollouts/sec (batch x horizon), Panda 7-DOF",
         "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: Franka Panda (11 links, 7 DOF), batch={B} x horizon={H} per GPU, "
-                               f"fused FK + " + ("SDF-obstacle (EnvSpheres3D, 10 spheres) + EE-tracking"
-                                                 if args.config == "c2" else
-                                                 "self-collision + SDF-obstacle + workspace box + EE-tracking") +
-                               " cost + gradient, q resident in HBM",
+                               f"fused FK + {objectives[args.config]} cost + gradient ({scene_text}), q resident in HBM",
                    "global_batch": B * world, "horizon": H, "parallelism": f"batch-sharded x{world}",
+                   "scene": args.scene, "objectives": args.config,
                    "launch": "hipGraph x%d" % args.graph if graph is not None else "eager, pre-bound C-ABI call",
-                   "kernel": "specialized" if model.specialized else "table-driven",
+                   "kernel": kind,
                    "reduce_every": R if world > 1 else None,
                    **({"experiment_weights": list(weights)} if args.weights else {}),
                    **({"experiment_no_pos": True} if args.no_pos else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "bytes_per_sample": algorithmic_bytes_per_sample(D, L), "launch_us": launch_s * 1e6,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src if traffic else None,
+                     "bytes_per_sample": bps, "launch_us": launch_s * 1e6,
+                     # second bound: VALU instructions per wavefront (SQ_INSTS_VALU / SQ_WAVES of the same command)
+                     # x wavefronts per launch / launch time, against one 64-lane instruction per 2 cycles per SIMD
+                     # (= the 157.3 TFLOP/s fp32 vector peak when every instruction is an FMA)
+                     "valu_frac": valu_frac, "valu_insts_per_wave": valu_per_wave,
+                     "valu_source": pmc_src if valu_per_wave else None,
                      # the contract prices against the HBM peak; a launch's working set below the 256 MB Infinity Cache is
                      # absorbed by it (61 - 62 % of the same peak at 400 - 600 MB per launch)
                      "working_set_MB": round(bytes_per_launch / 1e6, 1), "infinity_cache_MB": 256},
     }
+
+    if world > 1:
+        # (1) the same loop without the collectives; (2) configs[2]'s objective stack on the same shards, with collectives;
+        # (3) a check of the exchange itself: all-reduced packed sums == the sum of the ranks' local packed sums
+        ko_elapsed, _ = measure(plan, False)
+        plan3 = plan if weights == W_C3 else ops.RolloutPlan(model, cm, W_C3, q, want_pos=not args.no_pos)
+        if plan3 is not plan:
+            measure(plan3, True)
+        c3_elapsed, c3_ev = (elapsed, ev_ms) if plan3 is plan else measure(plan3, True)
+        plan.launch(bs_ptr, stream.cuda_stream)
+        local = torch.zeros(1 + H + H * D, **ta)
+        pack_sums(plan, local)
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        reduced = local.clone()
+        dist.all_reduce(reduced)
+        torch.cuda.synchronize(dev)
+        expect = torch.stack(gathered).double().sum(0)
+        err = float(((reduced.double() - expect).abs() / (expect.abs() + 1.0)).max().item())
+        out["multi_gpu"] = {
+            "backend": dist.get_backend(), "ranks": dist.get_world_size(), "reduce_every": R,
+            "collectives_in_timed_region": args.steps // R + (1 if args.steps % R > R // 2 else 0),
+            "allreduce_floats": int(local.numel()),
+            "with_allreduce": {"value": value, "ms_per_step": elapsed * 1e3 / args.steps},
+            "kernel_only": {"value": samples_per_step * args.steps / ko_elapsed, "ms_per_step": ko_elapsed * 1e3 / args.steps},
+            "full_stack_c3": {"value": samples_per_step * args.steps / c3_elapsed, "ms_per_step": c3_elapsed * 1e3 / args.steps,
+                              "launch_us": c3_ev * 1e3 / args.steps,
+                              "workload": "BASELINE configs[2] objective stack (self-collision + SDF-obstacle + workspace box + "
+                                          f"EE) on the same shards: {B * world} x {H} over {world} GPUs, with the all-reduce"},
+            "allreduce_check": {"ok": bool(err < 1e-5), "max_rel_err": err,
+                                "sum_cost_all_ranks": float(reduced[0].item()), "sum_cost_rank0": float(gathered[0][0].item())},
+        }
+        assert err < 1e-5, f"all-reduced sums differ from the sum of the ranks' sums: {err}"
 
     if rank == 0 and world == 1 and graph is None and args.independent_streams > 1:
         # Secondary figure (never `value`): INDEPENDENT batches alternated over three HIP streams.  With one stream a launch waits
@@ -268,23 +389,39 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:       # CPU baseline: rank 0 at N = 1 only
         from oracle import oracle as orc          # checker / baseline only: never on the product path
-        o = orc.Oracle(robot.diff_panda._kin, task.build_cost_spec())
+        spec = task.build_cost_spec()
+        if spec.grid is not None:                 # the oracle reads host arrays
+            spec.grid = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in spec.grid.items()}
+        o = orc.Oracle(robot.diff_panda._kin, spec)
         q_host = q.reshape(-1, D).cpu().numpy()
         cores = orc.max_threads()
-        probe = q_host[:16384]
-        t = time.perf_counter(); o.rollout(probe, weights, "f32"); dt = time.perf_counter() - t
-        n_s = int(min(len(q_host), max(16384, len(probe) / dt * args.cpu_seconds / 3)))
-        reps, best = 3, 1e30
-        for _ in range(reps):
-            t = time.perf_counter(); o.rollout(q_host[:n_s], weights, "f32"); best = min(best, time.perf_counter() - t)
-        out["cpu_baseline"] = {"value": n_s / best, "unit": "rollouts/s", "cores": cores, "kind": "port",
-                               "sample": f"first {n_s} of the {B * H} samples of rank 0's batch, C oracle (fp32, OpenMP "
-                                         f"over samples, {cores} threads), best of {reps}"}
+
+        def timed(n, reps):
+            best = 1e30
+            for _ in range(reps):
+                t = time.perf_counter(); o.rollout(q_host[:n], weights, "f32"); best = min(best, time.perf_counter() - t)
+            return best
+        # all threads: ~2/3 of the budget; one thread: ~1/3 (both bounded samples of rank 0's batch)
+        probe = min(16384, len(q_host))
+        dt = timed(probe, 1)
+        n_all = int(min(len(q_host), max(probe, probe / dt * args.cpu_seconds * 2 / 9)))
+        t_all = timed(n_all, 3)
+        orc.set_threads(1)
+        dt1 = timed(2048, 1)
+        n_one = int(min(len(q_host), max(2048, 2048 / dt1 * args.cpu_seconds / 6)))
+        t_one = timed(n_one, 2)
+        orc.set_threads(cores)
+        out["cpu_baseline"] = {"value": n_all / t_all, "unit": "rollouts/s", "cores": cores, "kind": "port",
+                               "cpu_model": cpu_model_name(),
+                               "sample": f"first {n_all} of the {B * H} samples of rank 0's batch, C oracle (fp32, OpenMP "
+                                         f"over samples, {cores} threads), best of 3",
+                               "one_core": {"value": n_one / t_one, "unit": "rollouts/s", "cores": 1,
+                                            "sample": f"first {n_one} samples, same code on 1 thread, best of 2"}}
     elif rank == 0:
         out["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,76 @@
+"""bench.py's N > 1 control flow.
+
+CPU: `bench.py --gpus 2` without a launcher must start the two ranks itself as a child `torch.distributed.run` (before it touches
+the GPU) and hand the child's failure through as its own exit code -- in the GPU-less build container the ranks die at
+`torch.cuda.set_device`, which is exactly the failure path.
+GPU: the same command in its debug mode (`--dist-backend gloo --single-device`: two ranks share cuda:0, the collectives go through
+gloo) runs the whole sharded loop on a 1-GPU box; the JSON line is checked, incl. the all-reduce of the packed sums.
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(extra, timeout):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + extra, env=env, cwd=str(ROOT), capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_self_launch_spawns_ranks_and_propagates_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("failure path of the launcher: needs a box without a GPU")
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"], 300)
+    assert p.returncode != 0
+    # both ranks were started by the elastic launcher and reported as failed children
+    assert "torch.distributed" in p.stderr and "ChildFailedError" in p.stderr, p.stderr[-2000:]
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_launcher_rejects_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, cwd=str(ROOT), capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_on_one_gpu_gloo():
+    p = _run(["--gpus", "2", "--dist-backend", "gloo", "--single-device", "--same-q", "--steps", "20", "--warmup", "5",
+              "--cpu-seconds", "0"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 20
+    assert out["config"]["reduce_every"] == 20 and out["config"]["global_batch"] == 8192
+    mg = out["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["ranks"] == 2 and mg["collectives_in_timed_region"] >= 1
+    assert mg["allreduce_floats"] == 1 + 64 + 64 * 7
+    chk = mg["allreduce_check"]
+    assert chk["ok"] and chk["max_rel_err"] < 1e-5
+    # --same-q: both ranks evaluate the same trajectories, so the all-reduced cost sum is exactly twice rank 0's
+    assert chk["sum_cost_all_ranks"] == pytest.approx(2.0 * chk["sum_cost_rank0"], rel=1e-6)
+    for k in ("with_allreduce", "kernel_only", "full_stack_c3"):
+        assert mg[k]["value"] > 0 and mg[k]["ms_per_step"] > 0
+    assert out["value"] == mg["with_allreduce"]["value"]
+    assert out["cpu_baseline"] is None and out["roofline"]["bytes_per_sample"] == 192
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,bps", [("grid", 272), ("shelf", 192), ("maze", 192)])
+def test_bench_scene_variants(scene, bps):
+    p = _run(["--scene", scene, "--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--batch", "512"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["config"]["scene"] == scene and out["roofline"]["bytes_per_sample"] == bps
+    assert out["config"]["kernel"] == "specialized" and out["value"] > 0
