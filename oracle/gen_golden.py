@@ -758,6 +758,113 @@ def frame_goldens():
     np.savez_compressed(GOLD / "frame_algebra.npz", **out)
 
 
+def interp_goldens():
+    """`python oracle/gen_golden.py interp`.  (1) interpolate_points_v1 itself (distance_fields.py:66-69).  (2) The three
+    embodiment fields on interpolated link points, the way RobotBase lays them out (robot_base.py:57-73, 103-108: K = points
+    per link x links, margins repeat_interleave'd, self pairs (i*p+m, j*p+n)).  The reference's own switch for this,
+    `interpolate_link_pos=True`, indexes the interpolated tensor a second time with the LINK indices (:109 after :147), so it is
+    driven here the way that makes it evaluate what it evidently means: the field is built over `arange(K)` columns and fed
+    `interpolate_points_v1(link_pos[..., link_idxs, :], K)` -- the second indexing is then the identity.  What the flag itself
+    does with the Panda's indices is recorded as `flag_result`.  (3) The single-link self distance (:195-198)."""
+    import itertools
+    from torch_robotics.robots.robot_panda import RobotPanda
+    from torch_robotics.environments.env_spheres_3d import EnvSpheres3D
+    from torch_robotics.torch_planning_objectives.fields.distance_fields import (
+        interpolate_points_v1, CollisionObjectDistanceField, CollisionSelfField, CollisionWorkspaceBoundariesDistanceField)
+    out = {}
+    gen = torch.Generator().manual_seed(4242)
+    shapes = [(5, 5), (5, 15), (5, 30), (8, 16), (1, 4), (7, 1), (3, 100), (11, 64)]
+    out["ip_shapes"] = np.asarray(shapes, np.int32)
+    for L, K in shapes:
+        pts = torch.randn(6, L, 3, generator=gen).requires_grad_(True)
+        w = torch.randn(6, K, 3, generator=gen)
+        o = interpolate_points_v1(pts, K)
+        (g,) = torch.autograd.grad((o * w).sum(), pts)
+        out[f"ip_{L}_{K}_in"], out[f"ip_{L}_{K}_w"] = pts.detach().numpy(), w.numpy()
+        out[f"ip_{L}_{K}_out"], out[f"ip_{L}_{K}_gin"] = o.detach().numpy(), g.numpy()
+
+    robot = quiet(RobotPanda, tensor_args=TA)
+    env = EnvSpheres3D(tensor_args=TA)
+    cutoff = 0.03
+    q0 = sample_q(robot.diff_panda, 64, torch.Generator().manual_seed(2024), 0.1).reshape(8, 8, 7)
+    obj_idx = list(robot.link_idxs_for_object_collision_checking)
+    self_idx = list(robot.link_idxs_for_self_collision_checking)
+    p_obj, p_self = 3, 2
+    K_obj, K_self = p_obj * len(obj_idx), p_self * len(self_idx)
+    margins_obj = torch.tensor(robot.link_margins_for_object_collision_checking, **TA).repeat_interleave(p_obj)
+    names = robot.link_names_for_self_collision_checking
+    pairs = []
+    for i, l1 in enumerate(names):
+        if l1 in robot.link_names_pairs_for_self_collision_checking:
+            for l2 in robot.link_names_pairs_for_self_collision_checking[l1]:
+                j = names.index(l2)
+                pairs.extend([(i * p_self + m, j * p_self + n) for m, n in itertools.product(range(p_self), range(p_self))])
+    margins_self = torch.full((len(pairs),), float(robot.self_collision_margin_robot), **TA)
+    f_obj = CollisionObjectDistanceField(robot, df_obj_list_fn=env.get_df_obj_list, link_idxs_for_collision_checking=list(range(K_obj)),
+                                         num_interpolated_points=K_obj, link_margins_for_object_collision_checking_tensor=margins_obj,
+                                         cutoff_margin=cutoff, tensor_args=TA)
+    f_ws = CollisionWorkspaceBoundariesDistanceField(robot, ws_bounds_min=env.limits[0], ws_bounds_max=env.limits[1],
+                                                     link_idxs_for_collision_checking=list(range(K_obj)), num_interpolated_points=K_obj,
+                                                     link_margins_for_object_collision_checking_tensor=margins_obj,
+                                                     cutoff_margin=cutoff, tensor_args=TA)
+    f_self = CollisionSelfField(robot, link_idxs_for_collision_checking=list(range(K_self)), idxs_links_distance_matrix=pairs,
+                                num_interpolated_points=K_self, cutoff_margin=margins_self, tensor_args=TA)
+    out.update(q=q0.numpy(), cutoff=np.float32(cutoff), limits=env.limits.numpy(), obj_link_idxs=np.asarray(obj_idx, np.int32),
+               self_link_idxs=np.asarray(self_idx, np.int32), K_obj=np.int32(K_obj), K_self=np.int32(K_self),
+               obj_margins=margins_obj.numpy(), self_pairs=np.asarray(pairs, np.int32), self_margins=margins_self.numpy())
+
+    def fields_on(link_pos):
+        link_pos = link_pos.reshape(-1, link_pos.shape[-2], 3)      # F.interpolate(mode='linear') wants (N, C, L): fold b x h first,
+        po = interpolate_points_v1(link_pos[..., obj_idx, :], K_obj)  # as DistanceField.compute_cost does before compute_costs_impl
+        ps = interpolate_points_v1(link_pos[..., self_idx, :], K_self)
+        return dict(objects=(f_obj, po), ws=(f_ws, po), self=(f_self, ps))
+
+    q = q0.clone().requires_grad_(True)
+    pos = robot.fk_map_collision(q)
+    pos_leaf = pos.detach().clone().requires_grad_(True)
+    total, gq_total = 0.0, 0.0
+    for fname in ("self", "objects", "ws"):
+        fld, pts = fields_on(pos_leaf)[fname]
+        c = fld.compute_cost(q, pts, field_type="sdf")
+        (gpos,) = torch.autograd.grad(c.sum(), pos_leaf)
+        fld, pts = fields_on(pos)[fname]
+        c2 = fld.compute_cost(q, pts, field_type="sdf")
+        (gq,) = torch.autograd.grad(c2.sum(), q, retain_graph=True)
+        c = c.reshape(8, 8)
+        out[f"cost_{fname}"], out[f"gpos_{fname}"], out[f"gq_{fname}"] = c.detach().numpy(), gpos.numpy(), gq.numpy()
+        out[f"coll_{fname}"] = fld.compute_cost(q, pts.detach(), field_type="occupancy").reshape(8, 8).numpy()
+        out[f"coll0_{fname}"] = fld.compute_cost(q, pts.detach(), field_type="occupancy", margin=0.0).reshape(8, 8).numpy()
+        total, gq_total = total + c.detach(), gq_total + gq
+    out["cost_total"], out["gq_total"] = total.numpy(), gq_total.numpy()
+    out["interp_points_obj"] = interpolate_points_v1(pos.detach().reshape(-1, 11, 3)[..., obj_idx, :], K_obj).numpy()
+
+    # what the reference's own flag does with these link indices (for the record; not a parity target)
+    try:
+        f_flag = CollisionObjectDistanceField(robot, df_obj_list_fn=env.get_df_obj_list, link_idxs_for_collision_checking=obj_idx,
+                                              num_interpolated_points=K_obj, interpolate_link_pos=True,
+                                              link_margins_for_object_collision_checking_tensor=margins_obj,
+                                              cutoff_margin=cutoff, tensor_args=TA)
+        f_flag.compute_cost(q0, pos.detach(), field_type="sdf")
+        out["flag_result"] = np.asarray("ran")
+    except Exception as e:                                      # margins (K) meet the 5 re-indexed points
+        out["flag_result"] = np.asarray(f"{type(e).__name__}: {str(e)[:160]}")
+
+    # (3) one self-collision link: |p|_1 * 1e9 stands in for the distance (distance_fields.py:195-198)
+    f_one = CollisionSelfField(robot, link_idxs_for_collision_checking=[7], idxs_links_distance_matrix=[(0, 0)],
+                               num_interpolated_points=1, cutoff_margin=0.05, tensor_args=TA)
+    q = q0.clone().requires_grad_(True)
+    pos = robot.fk_map_collision(q)
+    pos_leaf = pos.detach().clone().requires_grad_(True)
+    c = f_one.compute_cost(q, pos_leaf, field_type="sdf")
+    (gpos,) = torch.autograd.grad(c.sum(), pos_leaf)
+    (gq,) = torch.autograd.grad(f_one.compute_cost(q, pos, field_type="sdf").sum(), q)
+    out["single_link"], out["single_margin"] = np.int32(7), np.float32(0.05)
+    out["single_cost"], out["single_gpos"], out["single_gq"] = c.detach().numpy(), gpos.numpy(), gq.numpy()
+    out["single_coll"] = f_one.compute_cost(q, pos.detach(), field_type="occupancy").numpy()
+    np.savez_compressed(GOLD / "cost_interp.npz", **out)
+    print("cost_interp: flag_result =", out["flag_result"])
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     URDF_OUT.mkdir(parents=True, exist_ok=True)
@@ -778,6 +885,9 @@ def main():
         return
     if sys.argv[1:] == ["spheres"]:
         sphere_config_data()
+        return
+    if sys.argv[1:] == ["interp"]:
+        interp_goldens()
         return
     trees = {}
     for name, rel in ROBOTS.items():
@@ -811,6 +921,7 @@ def main():
     pointmass_goldens()
     frame_goldens()
     clamp_goldens()
+    interp_goldens()
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
 

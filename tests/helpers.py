@@ -4,7 +4,7 @@ from pathlib import Path
 import numpy as np
 
 from torch_robotics_amd import _abi
-from torch_robotics_amd.costmodel import CostModelSpec, box_prims, grid_object, make_object, sphere_prims
+from torch_robotics_amd.costmodel import CostModelSpec, box_prims, grid_object, interpolation_table, make_object, sphere_prims
 from torch_robotics_amd.kinmodel import KinModel, quat_wxyz_to_rot
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -82,6 +82,26 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
 
 
+GRAD_RTOL, GRAD_ATOL = 1e-4, 5e-6
+
+
+def grad_excess(a, ref):
+    """Element-wise gradient check: the largest |a - ref| / (GRAD_RTOL |ref| + GRAD_ATOL max|ref|) over all elements (<= 1 passes).
+    `rel_err` alone (max |diff| / max |ref|) lets a component 1000x smaller than the largest one be 10 % off; here such a
+    component may deviate by 0.5 % + 1e-4 relative.  The absolute floor is tied to the LARGEST gradient entry because an
+    entry is a sum of terms of that size (q-bar_j = z_j . (tau_j - t_j x f_j)): fp32 cancellation leaves ~eps x |terms|, which
+    is also what the reference's own fp32 arithmetic shows against fp64 (tools/diag_grad_elementwise.py)."""
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    assert a.size == ref.size, (a.shape, ref.shape)
+    a = a.reshape(ref.shape)
+    return float((np.abs(a - ref) / (GRAD_RTOL * np.abs(ref) + GRAD_ATOL * max(1e-30, np.abs(ref).max()))).max()) if ref.size else 0.0
+
+
+def grad_close(a, ref, tol=1e-4):
+    """Both gradient criteria: whole-tensor relative error below `tol` AND the element-wise bound of `grad_excess`."""
+    return rel_err(np.asarray(a).reshape(np.asarray(ref).shape), ref) < tol and grad_excess(a, ref) <= 1.0
+
+
 def grasp_panda_setup():
     """RobotPanda holding GraspedObjectPandaBox (goldens: grasp_panda.npz, scene of cost_spheres3d.npz):
     (KinModel, point_link, point_offset, CostModelSpec over the 12 link + 14 grasped-point columns)."""
@@ -114,5 +134,36 @@ def clamp_cost_spec(name, ee_target=None):
     if name == "spheres3d_tight":
         spec.ws_min, spec.ws_max = gc["tight_ws"][0].astype(np.float32), gc["tight_ws"][1].astype(np.float32)
         spec.self_margin = gc["tight_self_margin"].astype(np.float32)
+    spec.validate()
+    return spec
+
+
+def interp_cost_spec(ee_target=None):
+    """Cost model of tests/golden/cost_interp.npz: RobotPanda on EnvSpheres3D with the object / workspace fields on 15 points
+    interpolated along the 5 object-collision links and the self field on 16 points along the 8 self-collision links
+    (interpolate_link_pos, distance_fields.py:66-69, 145-147; layout of robot_base.py:57-73, 103-108)."""
+    g, gs = gold("cost_interp"), gold("cost_spheres3d")
+    spec = CostModelSpec(n_links_in=11)
+    src, w = interpolation_table(len(g["obj_link_idxs"]), int(g["K_obj"]))
+    spec.obj_link_idx = spec.add_virtual_columns(g["obj_link_idxs"][src], w)
+    spec.obj_link_margin = (g["obj_margins"].astype(np.float32) + np.float32(g["cutoff"])).astype(np.float32)
+    src, w = interpolation_table(len(g["self_link_idxs"]), int(g["K_self"]))
+    spec.self_link_idx = spec.add_virtual_columns(g["self_link_idxs"][src], w)
+    spec.self_pairs, spec.self_margin = g["self_pairs"], g["self_margins"]
+    spec.objects = objects_from_golden(gs, "fixed")
+    spec.ws_min, spec.ws_max = g["limits"][0], g["limits"][1]
+    if ee_target is not None:
+        spec.ee_link, spec.ee_target = 10, ee_target
+    spec.validate()
+    return spec
+
+
+def single_link_self_spec():
+    """One self-collision link (distance_fields.py:195-198): the degenerate pair (0, 0) on link `single_link`."""
+    g = gold("cost_interp")
+    spec = CostModelSpec(n_links_in=11)
+    spec.self_link_idx = np.asarray([int(g["single_link"])], np.int32)
+    spec.self_pairs = np.zeros((1, 2), np.int32)
+    spec.self_margin = np.asarray([g["single_margin"]], np.float32)
     spec.validate()
     return spec

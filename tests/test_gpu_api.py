@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import torch_robotics_amd as tra
-from helpers import gold, rel_err
+from helpers import gold, grad_close, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -100,7 +100,7 @@ def test_planning_task_like_the_reference(env):
         assert cost.shape == (8, 8)
         assert rel_err(cost.detach().cpu().numpy(), g[f"cost_{fname}"]) < TOL_C, fname
         cost.sum().backward()
-        assert rel_err(q.grad.cpu().numpy(), g[f"gq_{fname}"]) < TOL_G, fname
+        assert grad_close(q.grad.cpu().numpy(), g[f"gq_{fname}"]), fname
         coll = fld.compute_cost(q0, pos, field_type="occupancy")
         np.testing.assert_array_equal(coll.cpu().numpy(), g[f"coll_{fname}"])
         coll0 = fld.compute_cost(q0, pos, field_type="occupancy", margin=0.0)
@@ -113,7 +113,7 @@ def test_planning_task_like_the_reference(env):
     assert total.shape == (8, 8)
     assert rel_err(total.detach().cpu().numpy(), g["cost_total"]) < TOL_C
     total.sum().backward()
-    assert rel_err(q.grad.cpu().numpy(), g["gq_total"]) < TOL_G
+    assert grad_close(q.grad.cpu().numpy(), g["gq_total"])
     assert rel_err(task.compute_collision_cost(q0).cpu().numpy(), g["cost_total"]) < TOL_C      # no-grad fast path
     np.testing.assert_array_equal(task.compute_collision(q0).cpu().numpy(), g["coll_total"])
     np.testing.assert_array_equal(task.compute_collision(q0, margin=0.0).cpu().numpy(), g["coll0_total"])
@@ -134,7 +134,7 @@ def test_ee_field_like_the_reference():
             cost = fld.compute_costs_impl(q, H)
             assert rel_err(cost.detach().cpu().numpy(), g["cost_" + key]) < TOL_C
             cost.sum().backward()
-            assert rel_err(q.grad.cpu().numpy(), g["gq_" + key]) < TOL_G
+            assert grad_close(q.grad.cpu().numpy(), g["gq_" + key])
     fld = tra.EESE3DistanceField(dev(g["target_0"]), tensor_args=TA)
     d = fld.compute_distance(tree.compute_forward_kinematics_all_links(dev(g["q"].reshape(-1, 7))))
     assert rel_err(d.cpu().numpy(), g["cost_t0_sq0_w1.0_1.0"]) < TOL_C
@@ -299,7 +299,7 @@ def test_clamp_sdf_fields_and_task():
     total = task.compute_collision_cost(q)
     assert rel_err(total.detach().cpu().numpy(), g["spheres3d_cost_total"]) < TOL_C
     total.sum().backward()
-    assert rel_err(q.grad.cpu().numpy(), g["spheres3d_gq_total"]) < TOL_G
+    assert grad_close(q.grad.cpu().numpy(), g["spheres3d_gq_total"])
     # the unclamped task on the same inputs is a different (unbounded below) objective
     plain = tra.PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA).compute_collision_cost(q0)
     assert (plain < 0).any() and (total >= 0).all()
@@ -343,7 +343,7 @@ def test_se3_distance_function():
             assert d.shape == (64,)
             assert rel_err(d.detach().cpu().numpy(), g[f"cost_t{t}_sq0_w{wp}_{wr}"]) < TOL_C
             d.sum().backward()
-            assert rel_err(H.grad.cpu().numpy()[:, :3, :], g[f"gH_t{t}_sq0_w{wp}_{wr}"][:, -1, :3, :]) < TOL_G
+            assert grad_close(H.grad.cpu().numpy()[:, :3, :], g[f"gH_t{t}_sq0_w{wp}_{wr}"][:, -1, :3, :])
     with pytest.raises(NotImplementedError):
         tra.SE3_distance(H, dev(g["target_0"]), vel_batch=H)
 
@@ -355,10 +355,10 @@ def test_fused_task_rollout():
     task.set_ee_target(g["target"])
     q = dev(g["q"])
     pos, c2, g2 = task.rollout_cost_grad(q, w_self=0, w_obj=1, w_ws=0, w_ee=1)
-    assert rel_err(c2.cpu().numpy(), g["cost_c2"]) < TOL_C and rel_err(g2.cpu().numpy(), g["gq_c2"]) < TOL_G
+    assert rel_err(c2.cpu().numpy(), g["cost_c2"]) < TOL_C and grad_close(g2.cpu().numpy(), g["gq_c2"])
     assert np.abs(pos.cpu().numpy() - g["pos"]).max() < TOL_H
     _, c3, g3 = task.rollout_cost_grad(q, w_self=1, w_obj=1, w_ws=1, w_ee=1, want_pos=False)
-    assert rel_err(c3.cpu().numpy(), g["cost_c3"]) < TOL_C and rel_err(g3.cpu().numpy(), g["gq_c3"]) < TOL_G
+    assert rel_err(c3.cpu().numpy(), g["cost_c3"]) < TOL_C and grad_close(g3.cpu().numpy(), g["gq_c3"])
     # ObjectField.compute_signed_distance on arbitrary points, differentiable
     obj = task.env.obj_fixed_list[0]
     x = dev(g["pos"][0, :, 5]).requires_grad_(True)
@@ -446,7 +446,7 @@ def test_grasped_object_like_the_reference():
     assert pos.shape == (4, 8, 26, 3)
     assert np.abs(pos.detach().cpu().numpy() - g["link_pos"]).max() < TOL_H
     (pos * dev(g["w"])).sum().backward()
-    assert rel_err(q.grad.cpu().numpy(), g["gq"]) < TOL_G
+    assert grad_close(q.grad.cpu().numpy(), g["gq"])
     p2 = robot.fk_map_collision(dev(g["q_out"]))
     assert np.abs(p2.cpu().numpy() - g["link_pos_out"]).max() < TOL_H
     for key, fld in zip(("self", "obj", "ws"), task.get_collision_fields()):
@@ -461,13 +461,13 @@ def test_grasped_object_like_the_reference():
     total = task.compute_collision_cost(q)
     assert rel_err(total.detach().cpu().numpy(), total_ref) < TOL_C
     total.sum().backward()
-    assert rel_err(q.grad.cpu().numpy(), g["gq_cost"]) < TOL_G
+    assert grad_close(q.grad.cpu().numpy(), g["gq_cost"])
     assert rel_err(task.compute_collision_cost(q0).cpu().numpy(), total_ref) < TOL_C
     np.testing.assert_array_equal(task.compute_collision(q0).cpu().numpy(), g["coll_self"] | g["coll_obj"] | g["coll_ws"])
     np.testing.assert_array_equal(task.compute_collision(q0, margin=0.0).cpu().numpy(),
                                   g["coll0_self"] | g["coll0_obj"] | g["coll0_ws"])
     ppos, cost, gq = task.rollout_cost_grad(q0)
-    assert ppos.shape == (4, 8, 26, 3) and rel_err(gq.cpu().numpy(), g["gq_cost"]) < TOL_G
+    assert ppos.shape == (4, 8, 26, 3) and grad_close(gq.cpu().numpy(), g["gq_cost"])
     # generated kernel (spec_panda_grasp) vs table-driven kernel, both against the reference-derived golden
     assert robot._point_set(torch.device(DEV)).specialized
     model, _ = task._fused_handles(torch.device(DEV))
@@ -475,14 +475,14 @@ def test_grasped_object_like_the_reference():
     _, cost_g, gq_g = task.rollout_cost_grad(q0)
     model.enable_specialized(True)
     for c, gr in ((cost, gq), (cost_g, gq_g)):
-        assert rel_err(c.cpu().numpy(), total_ref) < TOL_C and rel_err(gr.cpu().numpy(), g["gq_cost"]) < TOL_G
+        assert rel_err(c.cpu().numpy(), total_ref) < TOL_C and grad_close(gr.cpu().numpy(), g["gq_cost"])
     task.set_ee_target(np.array([[1, 0, 0, 0.4], [0, 1, 0, 0.2], [0, 0, 1, 0.5], [0, 0, 0, 1]], np.float32))
     model, _ = task._fused_handles(torch.device(DEV))
     _, c_s, g_s = task.rollout_cost_grad(q0, w_ee=1.0)
     model.enable_specialized(False)
     _, c_g, g_g = task.rollout_cost_grad(q0, w_ee=1.0)
     model.enable_specialized(True)
-    assert rel_err(c_s.cpu().numpy(), c_g.cpu().numpy()) < TOL_C and rel_err(g_s.cpu().numpy(), g_g.cpu().numpy()) < TOL_G
+    assert rel_err(c_s.cpu().numpy(), c_g.cpu().numpy()) < TOL_C and grad_close(g_s.cpu().numpy(), g_g.cpu().numpy())
 
 
 def test_link_sphere_model(oracle_lib):
@@ -506,18 +506,18 @@ def test_link_sphere_model(oracle_lib):
     total = task.compute_collision_cost(q)
     assert rel_err(total.detach().cpu().numpy().reshape(-1), rc) < TOL_C
     total.sum().backward()
-    assert rel_err(q.grad.cpu().numpy().reshape(-1, 7), rg) < TOL_G
+    assert grad_close(q.grad.cpu().numpy().reshape(-1, 7), rg)
     # unfused chain through the drop-in classes == fused kernel
     q = q0.clone().requires_grad_(True)
     lp = robot.fk_map_collision(q)
     chain = sum(f.compute_cost(q, lp, field_type="sdf") for f in task.get_collision_fields())
     assert rel_err(chain.detach().cpu().numpy().reshape(-1), rc) < TOL_C
     chain.sum().backward()
-    assert rel_err(q.grad.cpu().numpy().reshape(-1, 7), rg) < TOL_G
+    assert grad_close(q.grad.cpu().numpy().reshape(-1, 7), rg)
     # with the EE term
     _, rc4, rg4 = o.rollout_points(pl, po, qn, (1, 1, 1, 1), "f64")
     _, c4, g4 = task.rollout_cost_grad(q0, w_ee=1.0)
-    assert rel_err(c4.cpu().numpy().reshape(-1), rc4) < TOL_C and rel_err(g4.cpu().numpy().reshape(-1, 7), rg4) < TOL_G
+    assert rel_err(c4.cpu().numpy().reshape(-1), rc4) < TOL_C and grad_close(g4.cpu().numpy().reshape(-1, 7), rg4)
     coll = task.compute_collision(q0)
     ref = o.collision_fields(7, rp, None, "f64").reshape(6, 64)
     assert (coll.cpu().numpy() != ref).mean() < 0.01       # fp32 vs fp64 at the threshold
@@ -537,7 +537,7 @@ def test_link_sphere_model(oracle_lib):
             model.enable_specialized(True)
             assert np.abs(ps_.cpu().numpy() - rp[:n_rows]).max() < TOL_H and np.abs(pg.cpu().numpy() - rp[:n_rows]).max() < TOL_H
             assert rel_err(cs.cpu().numpy(), rcw[:n_rows]) < TOL_C and rel_err(cg.cpu().numpy(), rcw[:n_rows]) < TOL_C
-            assert rel_err(gs.cpu().numpy(), rgw[:n_rows]) < TOL_G and rel_err(gg.cpu().numpy(), rgw[:n_rows]) < TOL_G
+            assert grad_close(gs.cpu().numpy(), rgw[:n_rows]) and grad_close(gg.cpu().numpy(), rgw[:n_rows])
         nb = ops.n_blocks(6 * 64)
         sums = torch.zeros(nb, device=DEV)
         _, cs, _ = ops.rollout_points_cost_grad(ps, cm, wts, q0, want_pos=False, cost_sum=sums)
@@ -557,7 +557,7 @@ def test_sphere_model_reduces_to_link_origin_goldens():
     cm = ops.CostHandle(spec, DEV)
     _, cost, gq = ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 0), dev(g["q"]))
     assert rel_err(cost.cpu().numpy(), g["cost_total"]) < TOL_C
-    assert rel_err(gq.cpu().numpy(), g["gq_total"]) < TOL_G
+    assert grad_close(gq.cpu().numpy(), g["gq_total"])
 
 
 def test_spheres_and_grasped_box_together(oracle_lib):
@@ -579,7 +579,7 @@ def test_spheres_and_grasped_box_together(oracle_lib):
         model.enable_specialized(use_spec)
         pos, cost, gq = ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 1), q0)
         assert np.abs(pos.cpu().numpy() - rp).max() < TOL_H
-        assert rel_err(cost.cpu().numpy(), rc) < TOL_C and rel_err(gq.cpu().numpy(), rg) < TOL_G
+        assert rel_err(cost.cpu().numpy(), rc) < TOL_C and grad_close(gq.cpu().numpy(), rg)
     model.enable_specialized(True)
     # fk_map_collision and its reverse mode: generated (positions-only exit / k_posbwd) vs table-driven vs fp64 oracle
     w = torch.randn(q0.shape[0], 71, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
@@ -587,7 +587,7 @@ def test_spheres_and_grasped_box_together(oracle_lib):
     for use_spec in (True, False):
         model.enable_specialized(use_spec)
         assert np.abs(ops.fk_points(ps, q0).cpu().numpy() - rp).max() < TOL_H
-        assert rel_err(ops.fk_points_backward(ps, q0, w).cpu().numpy(), rgq) < TOL_G
+        assert grad_close(ops.fk_points_backward(ps, q0, w).cpu().numpy(), rgq)
     model.enable_specialized(True)
 
 
@@ -611,7 +611,7 @@ def test_planning_task_specialises_itself_at_run_time():
     pos_g, cost_g, gq_g = ref.rollout_cost_grad(q, w_ee=1.0)
     model.enable_specialized(True)
     assert np.abs(pos.cpu().numpy() - pos_g.cpu().numpy()).max() < 2 * TOL_H
-    assert rel_err(cost.cpu().numpy(), cost_g.cpu().numpy()) < TOL_C and rel_err(gq.cpu().numpy(), gq_g.cpu().numpy()) < TOL_G
+    assert rel_err(cost.cpu().numpy(), cost_g.cpu().numpy()) < TOL_C and grad_close(gq.cpu().numpy(), gq_g.cpu().numpy())
 
 
 def test_custom_sphere_table_gets_its_own_kernel(tmp_path, oracle_lib):
@@ -639,7 +639,7 @@ def test_custom_sphere_table_gets_its_own_kernel(tmp_path, oracle_lib):
     model.enable_specialized(True)
     for p_, c_, g_ in ((pos, cost, gq), (pos_g, cost_g, gq_g)):
         assert np.abs(p_.cpu().numpy() - rp).max() < TOL_H
-        assert rel_err(c_.cpu().numpy(), rc) < TOL_C and rel_err(g_.cpu().numpy(), rg) < TOL_G
+        assert rel_err(c_.cpu().numpy(), rc) < TOL_C and grad_close(g_.cpu().numpy(), rg)
 
 
 def test_trajectory_metrics_like_the_reference():
@@ -735,7 +735,7 @@ def test_point_mass_robot_like_the_reference():
     cost = task.compute_collision_cost(q)
     assert cost.shape == (6, 16) and rel_err(cost.detach().cpu().numpy(), g["cost"]) < TOL_C
     cost.sum().backward()
-    assert rel_err(q.grad.cpu().numpy(), g["gq"]) < TOL_G
+    assert grad_close(q.grad.cpu().numpy(), g["gq"])
     np.testing.assert_array_equal(task.compute_collision(q.detach()).cpu().numpy(), g["coll"])
     np.testing.assert_array_equal(task.compute_collision(q.detach(), margin=0.0).cpu().numpy(), g["coll0"])
     free = task.random_coll_free_q(n_samples=5)
@@ -763,3 +763,167 @@ def test_ops_run_on_torchs_current_stream():
         got = pos.clone()
     side.synchronize()
     assert torch.equal(got, expect)
+
+
+def _q_to_rotation_matrix_torch(q):
+    """quaternion.py:102-120 as the reference writes it (plain torch ops; the floating-point reference of this check)."""
+    qw, qx, qy, qz = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    dc = 2.0 / (q ** 2).sum(-1)
+    return torch.stack([1 - dc * (qy * qy + qz * qz), dc * (qx * qy - qz * qw), dc * (qx * qz + qy * qw),
+                        dc * (qx * qy + qz * qw), 1 - dc * (qx * qx + qz * qz), dc * (qy * qz - qx * qw),
+                        dc * (qx * qz - qy * qw), dc * (qy * qz + qx * qw), 1 - dc * (qx * qx + qy * qy)], -1).reshape(q.shape[:-1] + (3, 3))
+
+
+def test_quaternion_and_euler_gradients_flow_like_the_reference():
+    """`q_to_rotation_matrix` and `Frame.get_euler` are differentiable torch expressions in the reference; the
+    kernels behind them have explicit reverse modes (they used to detach silently).  Checked against torch autograd in fp64."""
+    from torch_robotics_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    q = (torch.randn(257, 4, generator=gen) * torch.tensor([1.0, 0.7, 1.3, 0.9])).to(DEV)       # NOT normalised
+    w = torch.randn(257, 3, 3, generator=gen).to(DEV)
+    qa = q.clone().requires_grad_(True)
+    R = ops.quat_to_rotmat(qa)
+    (R * w).sum().backward()
+    qb = q.double().requires_grad_(True)
+    Rb = _q_to_rotation_matrix_torch(qb)
+    (Rb * w.double()).sum().backward()
+    assert np.abs(R.detach().cpu().numpy() - Rb.detach().cpu().numpy()).max() < 2e-6
+    err = (qa.grad.double() - qb.grad).abs() / (qb.grad.abs() + 1e-3 * qb.grad.abs().max())
+    assert float(err.max()) < 1e-4
+    # Frame.set_pose routes through it: the pose's quaternion receives a gradient
+    pose = torch.cat([torch.zeros(4, 3, device=DEV), q[:4]], 1).requires_grad_(True)
+    f = tra.Frame(pose=pose, device=DEV)
+    f.rotation.sum().backward()
+    assert pose.grad is not None and float(pose.grad[:, 3:].abs().max()) > 0
+
+    # Euler angles (frame.py:120-121) and the trace-method quaternion with its scale held constant (frame.py:112)
+    Rn = _q_to_rotation_matrix_torch(q.double()).float().contiguous()
+    we, wq = torch.randn(257, 3, generator=gen).to(DEV), torch.randn(257, 4, generator=gen).to(DEV)
+    Ra = Rn.clone().requires_grad_(True)
+    quat, eul = ops.frame_quat_euler(Ra, want_quat=True, want_euler=True)
+    ((eul * we).sum() + (quat * wq).sum()).backward()
+    Rd = Rn.double().requires_grad_(True)
+    e_ref = torch.stack([torch.atan2(Rd[:, 2, 1], Rd[:, 2, 2]), torch.asin(-Rd[:, 2, 0]), torch.atan2(Rd[:, 1, 0], Rd[:, 0, 0])], -1)
+    qv = quat.detach().double()                       # per-sample branch and scale as taken by the kernel, held constant
+    t = Rd[:, 0, 0] + Rd[:, 1, 1] + Rd[:, 2, 2] + 1.0
+    terms = []
+    for n in range(Rd.shape[0]):
+        M = Rd[n]
+        if float(t[n].detach()) > 1.0:
+            v = torch.stack([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1], t[n]])
+            sc = 0.5 / float(t[n].detach()) ** 0.5
+        else:
+            i, j, k = 0, 1, 2
+            Md = M.detach()
+            if float(Md[1, 1]) > float(Md[0, 0]):
+                i, j, k = 1, 2, 0
+            if float(Md[2, 2]) > float(Md[i, i]):
+                i, j, k = 2, 0, 1
+            tn = M[i, i] - (M[j, j] + M[k, k]) + 1.0
+            v = [None] * 4
+            v[i], v[j], v[k], v[3] = tn, M[i, j] + M[j, i], M[k, i] + M[i, k], M[k, j] - M[j, k]
+            v = torch.stack(v)
+            sc = 0.5 / float(tn.detach()) ** 0.5
+        terms.append(((v * sc) * wq[n].double()).sum())
+        assert torch.allclose(v.detach() * sc, qv[n], atol=5e-6)
+    (torch.stack(terms).sum() + (e_ref * we.double()).sum()).backward()
+    assert np.abs(eul.detach().cpu().numpy() - e_ref.detach().cpu().numpy()).max() < 5e-6
+    gerr = (Ra.grad.double() - Rd.grad).abs() / (Rd.grad.abs() + 1e-3 * Rd.grad.abs().max())
+    # asin'(x) = 1 / sqrt(1 - x^2) amplifies fp32 rounding of x near |x| = 1: exclude those few samples from the tight bound
+    ok = (Rn[:, 2, 0].abs() < 0.999)
+    assert float(gerr[ok].max()) < 2e-4
+    # get_euler of a Frame built from a differentiable pose carries the gradient
+    f2 = tra.Frame(pose=torch.cat([torch.zeros(4, 3, device=DEV), q[:4]], 1).requires_grad_(True), device=DEV)
+    assert all(e.requires_grad for e in f2.get_euler())
+
+
+def test_empty_scene_object_field_is_zero_in_both_kernel_families():
+    """a cost model with collision links but NO objects -- the generated field kernel returned -inf where the
+    table-driven one returns 0; the object term is now switched off at the boundary for both."""
+    from torch_robotics_amd import ops
+    from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+    from helpers import model, panda_cost_spec
+    g, robot = gold("cost_spheres3d"), gold("panda_robot")
+    spec = panda_cost_spec(g, robot)
+    spec.objects = []
+    spec.validate()
+    cm = ops.CostHandle(spec, DEV)
+    pos = dev(robot["fk_map_collision"]).reshape(-1, 11, 3)
+    outs = []
+    for on in (True, False):
+        cm.enable_specialized(on)
+        c_obj = ops.cost_fields(cm, FIELD_OBJECTS, pos)
+        c_all, g_all = ops.cost_fields(cm, FIELD_OBJECTS | FIELD_SELF | FIELD_WS, pos, want_grad=True)
+        assert torch.isfinite(c_all).all() and torch.isfinite(g_all).all()
+        assert float(c_obj.abs().max()) == 0.0
+        outs.append((c_all.cpu().numpy(), g_all.cpu().numpy()))
+    assert rel_err(outs[0][0], outs[1][0]) < TOL_C and grad_close(outs[0][1], outs[1][1])
+    c_sw = ops.cost_fields(cm, FIELD_SELF | FIELD_WS, pos)
+    assert rel_err(outs[0][0], c_sw.cpu().numpy()) < 1e-6
+    # the fused rollout: same rule, specialised and table-driven
+    m = ops.ModelHandle(model("panda_arm_no_gripper"))
+    q = dev(gold("rollout_panda")["q"][:2])
+    res = []
+    for on in (True, False):
+        m.enable_specialized(on)
+        _, c, gq = ops.rollout_cost_grad(m, cm, (1, 1, 1, 0), q)
+        assert torch.isfinite(c).all() and torch.isfinite(gq).all()
+        res.append((c.cpu().numpy(), gq.cpu().numpy()))
+    assert rel_err(res[0][0], res[1][0]) < TOL_C and grad_close(res[0][1], res[1][1])
+
+
+def test_ik_buffers_are_validated():
+    from torch_robotics_amd import ops
+    tree = tra.DifferentiableFrankaPanda(device=DEV)
+    lo, hi, _, _ = tree.get_joint_limit_array()
+    lo, hi = dev(lo.astype(np.float32)), dev(hi.astype(np.float32))
+    q = torch.zeros(8, 7, **TA)
+    Ht = torch.eye(4, **TA)
+    with pytest.raises(ValueError, match="adam_m"):
+        ops.ik_steps(tree._handle, 10, Ht, lo, hi, q, torch.zeros(8, 6, **TA), torch.zeros(8, 7, **TA), 1, 2)
+    with pytest.raises(ValueError, match="lower"):
+        ops.ik_steps(tree._handle, 10, Ht, lo[:5], hi, q, torch.zeros(8, 7, **TA), torch.zeros(8, 7, **TA), 1, 2)
+    with pytest.raises(ValueError):
+        ops.ik_step(tree._handle, 10, Ht, lo, hi, q.double(), None, None, 1)
+    with pytest.raises(ValueError, match="valid"):
+        ops.ik_step(tree._handle, 10, Ht, lo, hi, q, None, None, 1, lr=0.0, valid=torch.zeros(7, device=DEV, dtype=torch.uint8))
+
+
+def test_fields_with_interpolated_link_points_like_the_reference():
+    """`interpolate_link_pos=True`, used the way the reference's constructors are (robot_base.py:57-73 lays out the margins,
+    distance_fields.py:145-147 interpolates): 15 points along the Panda's 5 object-collision links."""
+    g, gr = gold("cost_interp"), gold("panda_robot")
+    robot = tra.RobotPanda(tensor_args=TA)
+    env = tra.EnvSpheres3D(tensor_args=TA)
+    K = int(g["K_obj"])
+    margins = torch.tensor(robot.link_margins_for_object_collision_checking, dtype=torch.float32).repeat_interleave(K // 5)
+    fld = tra.CollisionObjectDistanceField(robot, df_obj_list_fn=env.get_df_obj_list,
+                                           link_idxs_for_collision_checking=robot.link_idxs_for_object_collision_checking,
+                                           num_interpolated_points=K, interpolate_link_pos=True,
+                                           link_margins_for_object_collision_checking_tensor=margins,
+                                           cutoff_margin=float(g["cutoff"]), tensor_args=TA)
+    q = dev(g["q"]).requires_grad_(True)
+    pos = robot.fk_map_collision(q)
+    cost = fld.compute_cost(q, pos, field_type="sdf")
+    assert cost.shape == (8, 8) and rel_err(cost.detach().cpu().numpy(), g["cost_objects"]) < TOL_C
+    cost.sum().backward()
+    assert grad_close(q.grad.cpu().numpy(), g["gq_objects"])
+    assert np.array_equal(fld.compute_cost(q.detach(), pos.detach(), field_type="occupancy").cpu().numpy(), g["coll_objects"])
+    ws = tra.CollisionWorkspaceBoundariesDistanceField(
+        robot, ws_bounds_min=env.limits[0], ws_bounds_max=env.limits[1],
+        link_idxs_for_collision_checking=robot.link_idxs_for_object_collision_checking, num_interpolated_points=K,
+        interpolate_link_pos=True, link_margins_for_object_collision_checking_tensor=margins,
+        cutoff_margin=float(g["cutoff"]), tensor_args=TA)
+    assert rel_err(ws.compute_cost(q.detach(), pos.detach()).cpu().numpy(), g["cost_ws"]) < TOL_C
+    # a robot declared with more interpolated points than links gets the interpolating fields from PlanningTask by itself
+    robot15 = tra.RobotPanda(tensor_args=TA, num_interpolated_points_for_object_collision_checking=K,
+                             num_interpolated_points_for_self_collision_checking=int(g["K_self"]))
+    assert robot15.link_margins_for_object_collision_checking_tensor.shape == (K,)
+    task = tra.PlanningTask(env=env, robot=robot15, obstacle_cutoff_margin=float(g["cutoff"]), tensor_args=TA)
+    q2 = dev(g["q"]).requires_grad_(True)
+    c = task.compute_collision_cost(q2)
+    assert rel_err(c.detach().cpu().numpy(), g["cost_total"]) < TOL_C
+    c.sum().backward()
+    assert grad_close(q2.grad.cpu().numpy(), g["gq_total"])
+    coll = g["coll_self"] | g["coll_objects"] | g["coll_ws"]
+    assert np.array_equal(task.compute_collision(q2.detach()).cpu().numpy(), coll)

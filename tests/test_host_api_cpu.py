@@ -225,8 +225,12 @@ def test_scene_version_follows_object_poses():
     assert v1 != v0 and v1[0] == v0[0]
     env.obj_extra_list[0].set_position_orientation(ori=(0.0, 1.0, 0.0, 0.0))
     assert scene_version(env.get_df_obj_list()) != v1
-    env.obj_extra_list[0].set_position_orientation(pos=(0.0, 0.0, 0.0), ori=(1.0, 0.0, 0.0, 0.0))
-    assert scene_version(env.get_df_obj_list()) == v0
+    v2 = scene_version(env.get_df_obj_list())
+    env.obj_extra_list[0].pos = (0.0, 0.0, 0.0)                 # plain attribute assignment is seen as well
+    v3 = scene_version(env.get_df_obj_list())
+    assert v3 != v2 and (env.obj_extra_list[0].pos == 0).all()
+    # the key is integers only (it is built on every cost evaluation): (id, version) per object
+    assert all(isinstance(x, int) for entry in v3 for x in entry)
     # compute_sdf lives on EnvBase only (the other scene classes have no object list to serve it)
     from torch_robotics_amd import environments as E
     assert hasattr(E.EnvBase, "compute_sdf")

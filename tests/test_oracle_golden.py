@@ -384,3 +384,66 @@ def test_clamp_sdf_costs(oracle_lib, name, prec):
     assert rel_err(c, g[f"{name}_cost_total"].reshape(-1)) < TOL_C
     assert rel_err(gq, g[f"{name}_gq_total"].reshape(-1, 7)) < TOL_G
     assert (g[f"{name}_cost_total"] >= 0).all() and (g[f"{name}_cost_total"] > 0).any()
+
+
+def test_interpolation_table_is_atens(oracle_lib):
+    """costmodel.interpolation_table restates F.interpolate(mode='linear', align_corners=True): against the reference's
+    interpolate_points_v1 outputs and input gradients (goldens), and against torch itself here."""
+    import torch
+    import torch.nn.functional as F
+    from torch_robotics_amd.costmodel import interpolation_table
+    g = gold("cost_interp")
+    for L, K in g["ip_shapes"]:
+        src, w = interpolation_table(L, K)
+        assert src.shape == (K, 2) and w.shape == (K, 2) and src.min() >= 0 and src.max() < L
+        x, wout = g[f"ip_{L}_{K}_in"], g[f"ip_{L}_{K}_w"]
+        out = x[:, src[:, 0]] * w[None, :, 0, None] + x[:, src[:, 1]] * w[None, :, 1, None]
+        assert np.abs(out - g[f"ip_{L}_{K}_out"]).max() < 5e-7          # one ulp: ATen contracts w0 a + w1 b into an FMA
+        gin = np.zeros_like(x)
+        for k in range(K):
+            gin[:, src[k, 0]] += w[k, 0] * wout[:, k]
+            gin[:, src[k, 1]] += w[k, 1] * wout[:, k]
+        assert np.abs(gin - g[f"ip_{L}_{K}_gin"]).max() < 2e-6
+        t = F.interpolate(torch.from_numpy(x).transpose(-2, -1), size=int(K), mode="linear", align_corners=True).transpose(-2, -1)
+        assert np.abs(out - t.numpy()).max() < 5e-7
+    assert "RuntimeError" in str(g["flag_result"])      # the reference's own flag trips over its second indexing (documented)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_interpolated_link_points_fields(oracle_lib, prec):
+    """interpolate_link_pos: the three fields on interpolated link points (virtual columns of the cost model) against the
+    reference's field code fed interpolate_points_v1 of the selected links (goldens), value / d pos / d q / booleans."""
+    from helpers import interp_cost_spec
+    g, robot = gold("cost_interp"), gold("panda_robot")
+    spec = interp_cost_spec()
+    assert spec.n_columns == 11 + 15 + 16
+    m = model("panda_arm_no_gripper")
+    o = oracle_lib.Oracle(m, spec)
+    pos = robot["fk_map_collision"].reshape(-1, 11, 3)
+    tol_c, tol_g = (1e-5, 1e-4) if prec == "f32" else (2e-6, 2e-5)
+    for fname, fl, w in (("self", FIELD_SELF, (1, 0, 0, 0)), ("objects", FIELD_OBJECTS, (0, 1, 0, 0)),
+                         ("ws", FIELD_WS, (0, 0, 1, 0))):
+        c, gp = o.cost_fields(fl, pos, prec)
+        assert rel_err(c, g[f"cost_{fname}"].reshape(-1)) < tol_c, fname
+        assert rel_err(gp, g[f"gpos_{fname}"].reshape(-1, 11, 3)) < tol_g, fname
+        _, c2, gq = o.rollout(g["q"].reshape(-1, 7), w, prec)
+        assert rel_err(c2, g[f"cost_{fname}"].reshape(-1)) < tol_c and rel_err(gq, g[f"gq_{fname}"].reshape(-1, 7)) < tol_g, fname
+        assert np.array_equal(o.collision_fields(fl, pos, None, prec), g[f"coll_{fname}"].reshape(-1)), fname
+        assert np.array_equal(o.collision_fields(fl, pos, 0.0, prec), g[f"coll0_{fname}"].reshape(-1)), fname
+    _, c, gq = o.rollout(g["q"].reshape(-1, 7), (1, 1, 1, 0), prec)
+    assert rel_err(c, g["cost_total"].reshape(-1)) < tol_c and rel_err(gq, g["gq_total"].reshape(-1, 7)) < tol_g
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_single_link_self_distance(oracle_lib, prec):
+    """distance_fields.py:195-198: with one self-collision link the "distance" is |p|_1 * 1e9."""
+    from helpers import single_link_self_spec
+    g, robot = gold("cost_interp"), gold("panda_robot")
+    o = oracle_lib.Oracle(model("panda_arm_no_gripper"), single_link_self_spec())
+    pos = robot["fk_map_collision"].reshape(-1, 11, 3)
+    c, gp = o.cost_fields(FIELD_SELF, pos, prec)
+    assert rel_err(c, g["single_cost"].reshape(-1)) < 1e-6
+    assert np.array_equal(gp, g["single_gpos"].reshape(-1, 11, 3))                # +-1e9 on one link, zeros elsewhere
+    _, c2, gq = o.rollout(g["q"].reshape(-1, 7), (1, 0, 0, 0), prec)
+    assert rel_err(c2, g["single_cost"].reshape(-1)) < 1e-6 and rel_err(gq, g["single_gq"].reshape(-1, 7)) < 1e-5
+    assert np.array_equal(o.collision_fields(FIELD_SELF, pos, None, prec), g["single_coll"].reshape(-1))

@@ -10,7 +10,7 @@ from typing import List, Tuple
 
 import numpy as np
 
-TRK_ABI_VERSION = 2
+TRK_ABI_VERSION = 3
 TRK_MAX_LINKS = 64
 TRK_MAX_DOFS = 32
 TRK_MAX_POSE_SLOTS = 8
@@ -73,7 +73,7 @@ class CostModelDesc(C.Structure):
         ("ee_link", C.c_int32), ("ee_w_pos", C.c_float), ("ee_w_rot", C.c_float), ("ee_square", C.c_int32),
         ("ee_target", C.c_float * 16),
         ("ee2_link", C.c_int32), ("ee2_target", C.c_float * 16),
-        ("clamp_fields", C.c_int32), ("_pad_clamp", C.c_int32),
+        ("clamp_fields", C.c_int32), ("n_virtual", C.c_int32), ("virtual_src", _i32p), ("virtual_w", _f32p),
     ]
 
 
@@ -168,5 +168,9 @@ def cost_desc(spec, grid_ptrs=None) -> Tuple[CostModelDesc, list]:
     d.ee_target = (C.c_float * 16)(*_f32(spec.ee_target).reshape(16))
     d.ee2_link = int(spec.ee2_link)
     d.clamp_fields = int(spec.clamp_fields)
+    vsrc = np.asarray(spec.virtual_src, np.int32).reshape(-1, 2)
+    d.n_virtual = int(vsrc.shape[0])
+    put_i("virtual_src", vsrc.reshape(-1))
+    put_f("virtual_w", np.asarray(spec.virtual_w, np.float32).reshape(-1))
     d.ee2_target = (C.c_float * 16)(*_f32(spec.ee2_target).reshape(16))
     return d, keep

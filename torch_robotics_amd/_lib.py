@@ -27,10 +27,11 @@ EXPORTS = [
     "trk_cost_fields", "trk_collision_fields", "trk_ee_cost", "trk_rollout_cost_grad", "trk_reduce_sum", "trk_debug_set_stamp_buffer", "trk_interpolate_via_points",
     "trk_grid_precompute",
     "trk_frame_compose", "trk_frame_compose_backward", "trk_frame_transform_points", "trk_frame_transform_points_backward",
-    "trk_frame_quat_euler", "trk_rotation_from", "trk_rotation_from_backward",
+    "trk_frame_quat_euler", "trk_frame_quat_euler_backward", "trk_rotation_from", "trk_rotation_from_backward",
     "trk_sdf_points",
     "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_point_set_is_specialized", "trk_fk_points", "trk_fk_points_backward",
     "trk_rollout_points_cost_grad", "trk_rollout_collision", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16", "trk_finite_difference", "trk_traj_diff_norm_sum",
+    "trk_interpolate_columns", "trk_interpolate_columns_backward",
 ]
 
 
@@ -87,6 +88,7 @@ def lib():
     L.trk_frame_transform_points.argtypes = [vp, vp, i64, vp, i32, vp, vp]
     L.trk_frame_transform_points_backward.argtypes = [vp, i64, vp, i32, vp, vp, vp]
     L.trk_frame_quat_euler.argtypes = [vp, i64, i32, i32, vp, vp, vp]
+    L.trk_frame_quat_euler_backward.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp]
     L.trk_cost_model_create.argtypes = [C.POINTER(_abi.CostModelDesc), C.POINTER(vp)]
     L.trk_cost_model_destroy.argtypes = [vp]
     L.trk_cost_model_destroy.restype = None
@@ -107,6 +109,8 @@ def lib():
     L.trk_finite_difference.argtypes = [vp, i64, i32, i32, f32, i32, vp, vp]
     L.trk_traj_diff_norm_sum.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp]
     L.trk_gp_prior_cost_grad.argtypes = [vp, vp, i64, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp]
+    L.trk_interpolate_columns.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
+    L.trk_interpolate_columns_backward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
     L.trk_point_set_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
     L.trk_point_set_destroy.argtypes = [vp]
     L.trk_point_set_destroy.restype = None

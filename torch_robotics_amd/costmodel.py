@@ -73,9 +73,31 @@ class CostModelSpec:
     # FIELD_* mask: fields evaluated with clamp_sdf=True, i.e. relu(margin - signed distance) per link / pair
     # (distance_fields.py:114-117) -- the hinge form a planner optimises
     clamp_fields: int = 0
+    # interpolate_link_pos (distance_fields.py:66-69, 145-147): extra position columns n_links_in + k =
+    # virtual_w[k, 0] * column virtual_src[k, 0] + virtual_w[k, 1] * column virtual_src[k, 1]  (see interpolation_table)
+    virtual_src: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.int32))
+    virtual_w: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))
+
+    @property
+    def n_columns(self) -> int:
+        """Real position columns plus the virtual (interpolated) ones: what the field index tables may address."""
+        return int(self.n_links_in) + int(np.asarray(self.virtual_src).reshape(-1, 2).shape[0])
+
+    def add_virtual_columns(self, src: np.ndarray, w: np.ndarray) -> np.ndarray:
+        """Append interpolated columns; returns their column indices."""
+        src, w = np.asarray(src, np.int32).reshape(-1, 2), np.asarray(w, np.float32).reshape(-1, 2)
+        first = self.n_columns
+        self.virtual_src = np.concatenate([np.asarray(self.virtual_src, np.int32).reshape(-1, 2), src])
+        self.virtual_w = np.concatenate([np.asarray(self.virtual_w, np.float32).reshape(-1, 2), w])
+        return np.arange(first, first + len(src), dtype=np.int32)
 
     def validate(self) -> None:
-        L = self.n_links_in
+        L = self.n_columns
+        vs = np.asarray(self.virtual_src).reshape(-1, 2)
+        if vs.shape != np.asarray(self.virtual_w).reshape(-1, 2).shape:
+            raise ValueError("virtual_src / virtual_w shape mismatch")
+        if vs.size and (vs.min() < 0 or vs.max() >= self.n_links_in):
+            raise ValueError("virtual_src must name real position columns")
         for name in ("obj_link_idx", "self_link_idx"):
             idx = np.asarray(getattr(self, name))
             if idx.size and (idx.min() < 0 or idx.max() >= L):
@@ -87,7 +109,7 @@ class CostModelSpec:
             raise ValueError("self_pairs / self_margin length mismatch")
         if pairs.size and (pairs.min() < 0 or pairs.max() >= len(self.self_link_idx)):
             raise ValueError("self_pairs index out of range")
-        if self.ee_link >= L or self.ee2_link >= L:
+        if self.ee_link >= self.n_links_in or self.ee2_link >= self.n_links_in:
             raise ValueError("ee_link out of range")
         if self.ee2_link >= 0 and self.ee_link < 0:
             raise ValueError("ee2_link needs ee_link")
@@ -96,6 +118,24 @@ class CostModelSpec:
         n_grid = sum(int(o.get("is_grid", 0)) for o in self.objects)
         if n_grid > 1 or (n_grid == 1) != (self.grid is not None):
             raise ValueError("exactly one grid object is required when `grid` is set")
+
+
+def interpolation_table(n_in: int, n_out: int):
+    """`interpolate_points_v1(points, n_out)` (distance_fields.py:66-69) = F.interpolate(mode='linear', align_corners=True)
+    along the link axis, unrolled: output point k = w[k, 0] * point src[k, 0] + w[k, 1] * point src[k, 1].
+    Restates ATen's index / weight computation in fp32 (UpSample.h: area_pixel_compute_scale -> (in - 1) / (out - 1) for
+    align_corners, 0 when out == 1; source index = scale * k; i0 = min(int(src), in - 1), lambda1 = clamp(src - i0, 0, 1),
+    i1 = min(i0 + 1, in - 1), lambda0 = 1 - lambda1), checked against torch itself in tests/test_host_api_cpu.py."""
+    n_in, n_out = int(n_in), int(n_out)
+    if n_in < 1 or n_out < 1:
+        raise ValueError("interpolation_table: sizes must be positive")
+    scale = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+    real = (scale * np.arange(n_out, dtype=np.float32)).astype(np.float32)
+    i0 = np.minimum(real.astype(np.int64), n_in - 1)
+    lam1 = np.clip(real - i0.astype(np.float32), np.float32(0), np.float32(1)).astype(np.float32)
+    i1 = np.minimum(i0 + 1, n_in - 1)
+    return (np.stack([i0, i1], 1).astype(np.int32),
+            np.stack([np.float32(1) - lam1, lam1], 1).astype(np.float32))
 
 
 # ----------------------------------------------------------------------------------------------------------------------

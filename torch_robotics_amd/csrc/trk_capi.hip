@@ -120,6 +120,8 @@ struct TrkCostModel {
 };
 
 static bool spec_matches(const SpecEntry* e, const TrkCostModel* cm, const TrkRolloutWeights* w) {
+    // interpolated (virtual) columns and the single-link self distance exist only in the table-driven kernels
+    if (cm->hdr.n_virtual > 0 || (cm->hdr.self_single && w->w_self != 0.0f)) return false;
     bool ok = true;
     if (w->w_obj != 0.0f || w->w_ws != 0.0f)
         ok = ok && (int)cm->obj_link_idx.size() == e->n_obj_links &&
@@ -129,6 +131,13 @@ static bool spec_matches(const SpecEntry* e, const TrkCostModel* cm, const TrkRo
              std::equal(cm->self_pairs.begin(), cm->self_pairs.end(), e->self_pairs);
     if (w->w_ee != 0.0f) ok = ok && cm->hdr.ee_link == e->ee_link && cm->hdr.ee2_link == e->ee2_link;
     return ok;
+}
+// An object field over an EMPTY scene (no objects, no grid) contributes nothing: the table-driven kernels guard their object
+// loop with n_objects > 0, the generated objective code does not (its minimum over no object would stay +inf), so the term
+// is switched off here -- the result must not depend on which kernel family serves the call.
+static TrkRolloutWeights effective_weights(const TrkCostModel* cm, TrkRolloutWeights w) {
+    if (cm->hdr.n_objects == 0 && !cm->hdr.has_grid) w.w_obj = 0.0f;
+    return w;
 }
 // point-set units: like model_spec / model_spec_for (late registration, several templates per point set)
 static const SpecEntry* points_spec(const TrkPointSet* ps) {
@@ -312,6 +321,8 @@ static int blank_spec_args(SpecArgs& a) {
     h.self_pairs = static_cast<const int32_t*>(g_zero_blob); h.self_margin = static_cast<const float*>(g_zero_blob);
     h.spheres = static_cast<const float4*>(g_zero_blob); h.spheres_sel = static_cast<const float4*>(g_zero_blob);
     h.box_objects = static_cast<const int32_t*>(g_zero_blob);
+    h.sphere_pairs = static_cast<const float*>(g_zero_blob);
+    h.virtual_src = static_cast<const int32_t*>(g_zero_blob); h.virtual_w = static_cast<const float*>(g_zero_blob);
     return TRK_OK;
 }
 
@@ -661,7 +672,7 @@ int trk_rotation_from(int32_t kind, const float* in, int64_t n, float* R_out, tr
 }
 
 int trk_rotation_from_backward(int32_t kind, const float* angle, const float* gR, int64_t n, float* gangle, trk_stream_t stream) {
-    if (kind < TRK_ROT_X || kind > TRK_ROT_Z || n < 0 || (n > 0 && (!angle || !gR || !gangle))) return fail(TRK_ERR_INVALID_ARG, "trk_rotation_from_backward: bad argument");
+    if (kind < TRK_ROT_X || kind > TRK_ROT_QUAT_WXYZ || n < 0 || (n > 0 && (!angle || !gR || !gangle))) return fail(TRK_ERR_INVALID_ARG, "trk_rotation_from_backward: bad argument");
     if (n == 0) return TRK_OK;
     int rc = ensure_init();
     if (rc) return rc;
@@ -741,6 +752,17 @@ int trk_frame_quat_euler(const float* R, int64_t n, int32_t stride, int32_t row_
     return TRK_OK;
 }
 
+int trk_frame_quat_euler_backward(const float* R, int64_t n, int32_t stride, int32_t row_pitch, const float* gquat_xyzw,
+                                  const float* geuler, float* gR, trk_stream_t stream) {
+    if (n < 0 || stride < 9 || row_pitch < 3 || (n > 0 && (!R || !gR))) return fail(TRK_ERR_INVALID_ARG, "trk_frame_quat_euler_backward: bad argument");
+    if (n == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_frame_quat_euler_bwd(R, n, stride, row_pitch, gquat_xyzw, geuler, gR, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     if (!d || !out) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: null argument");
@@ -755,10 +777,15 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
         (d->n_prims && !d->prims) || (d->n_self_links && !d->self_link_idx) ||
         (d->n_self_pairs && (!d->self_pairs || !d->self_margin)))
         return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: null table pointer");
+    if (d->n_virtual < 0 || d->n_virtual > TRK_MAX_VIRTUAL) return fail(TRK_ERR_UNSUPPORTED, "trk_cost_model_create: n_virtual out of range");
+    if (d->n_virtual && (!d->virtual_src || !d->virtual_w)) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: null virtual column table");
+    for (int v = 0; v < 2 * d->n_virtual; ++v)
+        if (d->virtual_src[v] < 0 || d->virtual_src[v] >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: virtual_src must name real columns");
+    const int Lcols = Lin + d->n_virtual;        // what the index tables may address
     for (int l = 0; l < d->n_obj_links; ++l)
-        if (d->obj_link_idx[l] < 0 || d->obj_link_idx[l] >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: obj_link_idx out of range");
+        if (d->obj_link_idx[l] < 0 || d->obj_link_idx[l] >= Lcols) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: obj_link_idx out of range");
     for (int l = 0; l < d->n_self_links; ++l)
-        if (d->self_link_idx[l] < 0 || d->self_link_idx[l] >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: self_link_idx out of range");
+        if (d->self_link_idx[l] < 0 || d->self_link_idx[l] >= Lcols) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: self_link_idx out of range");
     for (int p = 0; p < 2 * d->n_self_pairs; ++p)
         if (d->self_pairs[p] < 0 || d->self_pairs[p] >= d->n_self_links) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: self_pairs out of range");
     if (d->ee_link >= Lin || d->ee2_link >= Lin) return fail(TRK_ERR_INVALID_ARG, "trk_cost_model_create: ee_link out of range");
@@ -790,7 +817,9 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     const size_t o_sel = o_sph + al(sizeof(float4) * (d->n_prims + 1));
     const size_t o_box = o_sel + al(sizeof(float4) * (d->n_prims + 1));
     const size_t o_pair = o_box + al(sizeof(int32_t) * (d->n_objects + 1));
-    const size_t total = o_pair + al(sizeof(float) * 8 * ((d->n_prims + 2) / 2));
+    const size_t o_vsrc = o_pair + al(sizeof(float) * 8 * ((d->n_prims + 2) / 2));
+    const size_t o_vw = o_vsrc + al(sizeof(int32_t) * 2 * (d->n_virtual + 1));
+    const size_t total = o_vw + al(sizeof(float) * 2 * (d->n_virtual + 1));
     std::vector<char> blob(total, 0);
     std::vector<float4> spheres;
     if (d->n_obj_links) {
@@ -829,6 +858,12 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     }
     int32_t* sp = reinterpret_cast<int32_t*>(blob.data() + o_sp);
     for (int p = 0; p < 2 * d->n_self_pairs; ++p) sp[p] = d->self_link_idx[d->self_pairs[p]];
+    bool self_single = false;
+    for (int p = 0; p < d->n_self_pairs; ++p) self_single = self_single || sp[2 * p] == sp[2 * p + 1];
+    if (d->n_virtual) {
+        std::memcpy(blob.data() + o_vsrc, d->virtual_src, sizeof(int32_t) * 2 * d->n_virtual);
+        std::memcpy(blob.data() + o_vw, d->virtual_w, sizeof(float) * 2 * d->n_virtual);
+    }
     if (d->n_self_pairs) std::memcpy(blob.data() + o_sm, d->self_margin, sizeof(float) * d->n_self_pairs);
     const size_t n_real_spheres = spheres.size();
     // An odd table gets a copy of its last sphere appended: the ranking loop then works on whole PAIRS, and whichever index
@@ -899,6 +934,9 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     h.sphere_pairs = reinterpret_cast<const float*>(base + o_pair);
     h.n_sphere_pairs = n_sphere_pairs;
     h.clamp_fields = d->clamp_fields & 7;
+    h.n_virtual = d->n_virtual; h.self_single = self_single ? 1 : 0;
+    h.virtual_src = reinterpret_cast<const int32_t*>(base + o_vsrc);
+    h.virtual_w = reinterpret_cast<const float*>(base + o_vw);
     h.spheres_uniform_r = uniform_r ? 1 : 0;
     h.sphere_r = spheres.empty() ? 0.0f : spheres[0].w;
     if (n_grid) {
@@ -942,8 +980,9 @@ int trk_cost_fields(const TrkCostModel* cm, int32_t fields, const float* link_po
     if (n < 0 || (n > 0 && (!link_pos || !cost)) || (fields & ~7) || !fields) return fail(TRK_ERR_INVALID_ARG, "trk_cost_fields: bad argument");
     if (n == 0) return TRK_OK;
     {
-        TrkRolloutWeights w{(fields & TRK_FIELD_SELF) ? 1.0f : 0.0f, (fields & TRK_FIELD_OBJECTS) ? 1.0f : 0.0f,
-                            (fields & TRK_FIELD_WS) ? 1.0f : 0.0f, 0.0f};
+        const TrkRolloutWeights w = effective_weights(cm, TrkRolloutWeights{(fields & TRK_FIELD_SELF) ? 1.0f : 0.0f,
+                                                                            (fields & TRK_FIELD_OBJECTS) ? 1.0f : 0.0f,
+                                                                            (fields & TRK_FIELD_WS) ? 1.0f : 0.0f, 0.0f});
         if (const SpecEntry* e = fields_spec_for(cm, &w)) {      // the fused kernel's objective code on the caller's positions
             SpecArgs a{};
             a.C = cm->hdr; a.w = w;
@@ -1004,6 +1043,8 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
     const int64_t n = batch * horizon;
     if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null q/cost/gq");
     if (n == 0) return TRK_OK;
+    const TrkRolloutWeights we = effective_weights(cm, *w);
+    w = &we;
     if (m->spec_enabled) {
         // a generated kernel has the robot's collision-link sets baked in: use the unit whose sets equal the cost model's
         if (const SpecEntry* e = model_spec_for(m, cm, w)) {
@@ -1018,6 +1059,7 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
             return TRK_OK;
         }
     }
+    if (trk_lds_rollout(m->hdr, m->hdr.n_links + cm->hdr.n_virtual) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, std::string(who) + ": position tiles (links + interpolated points) exceed the 160 KiB LDS");
     trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, nullptr, cm->hdr, *w, io_f16, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
@@ -1086,10 +1128,12 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
     if (cm->hdr.n_links_in != ps->dev.n_points) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: cost model n_links_in != number of points");
     if (cm->hdr.ee_link >= m->hdr.n_links || cm->hdr.ee2_link >= m->hdr.n_links)
         return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: ee_link is not a link of the model");
-    if (trk_lds_rollout(m->hdr, ps->dev.n_points) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_points_cost_grad: point tiles exceed the 160 KiB LDS");
+    if (trk_lds_rollout(m->hdr, ps->dev.n_points + cm->hdr.n_virtual) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_points_cost_grad: point tiles exceed the 160 KiB LDS");
     const int64_t n = batch * horizon;
     if (n > 0 && (!q || !cost || !gq)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_points_cost_grad: null q/cost/gq");
     if (n == 0) return TRK_OK;
+    const TrkRolloutWeights we = effective_weights(cm, *w);
+    w = &we;
     if (m->spec_enabled && (reinterpret_cast<uintptr_t>(point_pos_out) & 15) == 0) {
         // generated kernel with this point set baked in whose cost columns equal the cost model's
         if (const SpecEntry* e = points_spec_for(ps, cm, w)) {
@@ -1117,6 +1161,30 @@ int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, 
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_interpolate(x, n_traj, horizon, dim, n_interp, alpha, beta, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_interpolate_columns(const float* x, int64_t n, int32_t n_in, int32_t channels, int32_t n_out, const int32_t* src,
+                            const float* w, float* out, trk_stream_t stream) {
+    if (n < 0 || n_in < 1 || channels < 1 || n_out < 1 || !src || !w || (n > 0 && (!x || !out)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_interpolate_columns: bad argument");
+    if (n == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_interpolate_columns(x, n, n_in, channels, n_out, src, w, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_interpolate_columns_backward(const float* gout, int64_t n, int32_t n_in, int32_t channels, int32_t n_out, const int32_t* src,
+                                     const float* w, float* gx, trk_stream_t stream) {
+    if (n < 0 || n_in < 1 || channels < 1 || n_out < 1 || !src || !w || (n > 0 && (!gout || !gx)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_interpolate_columns_backward: bad argument");
+    if (n == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_interpolate_columns_bwd(gout, n, n_in, channels, n_out, src, w, gx, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }

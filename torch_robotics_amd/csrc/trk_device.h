@@ -99,6 +99,12 @@ struct DevCostHdr {
     const float* sphere_pairs;     // device
     int32_t n_sphere_pairs;
     int32_t clamp_fields;          // TRK_FIELD_* mask: relu(margin - sdf) per link / pair (clamp_sdf=True, distance_fields.py:114-117)
+    // interpolate_link_pos (distance_fields.py:66-69, 145-147): position columns n_links_in + k = w[2k] * column src[2k] +
+    // w[2k+1] * column src[2k+1]; the index tables above may name them.  Only the table-driven kernels evaluate them.
+    int32_t n_virtual;
+    int32_t self_single;           // 1: some self pair is (a, a) -- the single-link distance 1e9 |p|_1 (distance_fields.py:195-198)
+    const int32_t* virtual_src;    // device [2 * n_virtual]
+    const float* virtual_w;        // device [2 * n_virtual]
 };
 
 // Points rigidly attached to links (grasped-object points robot_panda.py:154-168, per-link collision spheres):

@@ -607,6 +607,28 @@ __device__ __forceinline__ bool collision_links(const DevCostHdr& C, int fields,
     return hit;
 }
 
+// interpolate_link_pos (interpolate_points_v1 distance_fields.py:66-69, used at :145-147): the virtual columns behind the real
+// ones, column n_links_in + v = w0 * column src0 + w1 * column src1.  Each lane works on its own row of the tile.
+__device__ __forceinline__ void virtual_columns(const DevCostHdr& C, float* pt) {
+    for (int v = 0; v < C.n_virtual; ++v) {
+        const int a = cptr(C.virtual_src)[2 * v], b = cptr(C.virtual_src)[2 * v + 1];
+        const float wa = cptr(C.virtual_w)[2 * v], wb = cptr(C.virtual_w)[2 * v + 1];
+        float* o = pt + 3 * (C.n_links_in + v);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = wa * pt[3 * a + k] + wb * pt[3 * b + k];
+    }
+}
+// reverse mode: the adjoint of an interpolated point goes to its two source columns with its weights
+__device__ __forceinline__ void virtual_columns_adjoint(const DevCostHdr& C, float* gt) {
+    for (int v = 0; v < C.n_virtual; ++v) {
+        const int a = cptr(C.virtual_src)[2 * v], b = cptr(C.virtual_src)[2 * v + 1];
+        const float wa = cptr(C.virtual_w)[2 * v], wb = cptr(C.virtual_w)[2 * v + 1];
+        const float* g = gt + 3 * (C.n_links_in + v);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gt[3 * a + k] = fmaf(wa, g[k], gt[3 * a + k]); gt[3 * b + k] = fmaf(wb, g[k], gt[3 * b + k]); }
+    }
+}
+
 template <bool PRECISE>
 __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, float w_self, float w_obj, float w_ws,
                                              const float* tile, float* gtile, int rs, int lane) {
@@ -645,6 +667,19 @@ __device__ __forceinline__ float fields_eval(const DevCostHdr& C, int fields, fl
     if (fields & TRK_FIELD_SELF) {
         for (int pi = 0; pi < C.n_self_pairs; ++pi) {
             const int a = cptr(C.self_pairs)[2 * pi], b = cptr(C.self_pairs)[2 * pi + 1];
+            if (C.self_single && a == b) {      // one self-collision link: "distance" 1e9 |p|_1 (distance_fields.py:195-198)
+                const float x = pt[3 * a], y = pt[3 * a + 1], z = pt[3 * a + 2];
+                const float vs = cptr(C.self_margin)[pi] - ((__builtin_fabsf(x) + __builtin_fabsf(y)) + __builtin_fabsf(z)) * 1e9f;
+                const float wsf = ((C.clamp_fields & TRK_FIELD_SELF) && !(vs > 0.0f)) ? 0.0f : w_self;
+                cost = fmaf(wsf, vs, cost);
+                if (gt) {       // d|x| / dx = sign(x), 0 at 0 (torch.abs)
+                    const float k9 = wsf * 1e9f;
+                    gt[3 * a] -= x > 0.0f ? k9 : (x < 0.0f ? -k9 : 0.0f);
+                    gt[3 * a + 1] -= y > 0.0f ? k9 : (y < 0.0f ? -k9 : 0.0f);
+                    gt[3 * a + 2] -= z > 0.0f ? k9 : (z < 0.0f ? -k9 : 0.0f);
+                }
+                continue;
+            }
             const float dx = pt[3 * a] - pt[3 * b], dy = pt[3 * a + 1] - pt[3 * b + 1], dz = pt[3 * a + 2] - pt[3 * b + 2];
             const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
             const float nrm = PRECISE ? sqrtf(n2) : trk_sqrt(n2);
@@ -668,7 +703,7 @@ k_cost_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos, int6
               const float* __restrict__ gcost, float* __restrict__ cost, float* __restrict__ g_link_pos) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
-    const int width = C.n_links_in * 3, rs = width | 1;
+    const int width = C.n_links_in * 3, rs = ((C.n_links_in + C.n_virtual) * 3) | 1;     // rows carry the virtual columns too
     const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
     const int rows = (int)min((int64_t)TRK_WAVE, n - base);
     float* tile = smem;
@@ -679,9 +714,11 @@ k_cost_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos, int6
     load_tile_strided(tile, link_pos, base * width, rows, width, rs, lane);
     __syncthreads();
     const float sc = (gcost && lane < rows) ? gcost[base + lane] : 1.0f;
+    if (C.n_virtual) virtual_columns(C, tile + lane * rs);
     const float c = fields_eval<false>(C, fields, 1.0f, 1.0f, 1.0f, tile, g_link_pos ? gtile : nullptr, rs, lane);
     if (lane < rows) cost[base + lane] = c;
     if (g_link_pos) {
+        if (C.n_virtual) virtual_columns_adjoint(C, gtile + lane * rs);
         if (gcost) for (int k = 0; k < width; ++k) gtile[lane * rs + k] *= sc;
         __syncthreads();
         store_tile_strided(g_link_pos, gtile, base * width, rows, width, rs, lane);
@@ -694,7 +731,7 @@ k_collision_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos,
                    float margin_override, int use_default, uint8_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
-    const int width = C.n_links_in * 3, rs = width | 1;
+    const int width = C.n_links_in * 3, rs = ((C.n_links_in + C.n_virtual) * 3) | 1;
     const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
     const int rows = (int)min((int64_t)TRK_WAVE, n - base);
     float* tile = smem;
@@ -702,6 +739,7 @@ k_collision_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos,
     __syncthreads();
     load_tile_strided(tile, link_pos, base * width, rows, width, rs, lane);
     __syncthreads();
+    if (C.n_virtual) virtual_columns(C, tile + lane * rs);
     const float* pt = tile + lane * rs;
     bool hit = false;
     if (fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {
@@ -717,6 +755,10 @@ k_collision_fields(DevCostHdr C, int fields, const float* __restrict__ link_pos,
             const int a = cptr(C.self_pairs)[2 * pi], b = cptr(C.self_pairs)[2 * pi + 1];
             const float dx = pt[3 * a] - pt[3 * b], dy = pt[3 * a + 1] - pt[3 * b + 1], dz = pt[3 * a + 2] - pt[3 * b + 2];
             const float mg = use_default ? cptr(C.self_margin)[pi] : margin_override;
+            if (C.self_single && a == b) {      // distance_fields.py:195-198
+                hit |= ((__builtin_fabsf(pt[3 * a]) + __builtin_fabsf(pt[3 * a + 1])) + __builtin_fabsf(pt[3 * a + 2])) * 1e9f < mg;
+                continue;
+            }
             hit |= sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz))) < mg;
         }
     }
@@ -769,7 +811,7 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     const int D = hdr.n_dofs, L = hdr.n_links;
     const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;
     const int rows = (int)min((int64_t)TRK_WAVE, n - base);
-    const int width = (POINTS ? ps.n_points : L) * 3, rs = width | 1;
+    const int width = (POINTS ? ps.n_points : L) * 3, rs = (width + C.n_virtual * 3) | 1;   // + the interpolated columns
     float* qs = smem;
     float* gqs = qs + TRK_WAVE * D;
     float* jst = gqs + TRK_WAVE * D;
@@ -813,7 +855,9 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     if (w.w_self != 0.0f) fields |= TRK_FIELD_SELF;
     if (w.w_obj != 0.0f) fields |= TRK_FIELD_OBJECTS;
     if (w.w_ws != 0.0f) fields |= TRK_FIELD_WS;
+    if (C.n_virtual) virtual_columns(C, tile + lane * rs);
     float c = fields_eval<false>(C, fields, w.w_self, w.w_obj, w.w_ws, tile, gtile, rs, lane);
+    if (C.n_virtual) virtual_columns_adjoint(C, gtile + lane * rs);
     float eeRb[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, eetb[3] = {0, 0, 0};
     const bool use_ee = (w.w_ee != 0.0f) && (C.ee_link >= 0);
     if (use_ee) {
@@ -1288,8 +1332,68 @@ k_frame_quat_euler(const float* __restrict__ R, int64_t n, int stride, int pitch
     }
 }
 
+// Reverse mode of k_frame_quat_euler w.r.t. the rotation: gR [n,9] = d<gquat, quat> / dR + d<geuler, euler> / dR.
+// Quaternion: the reference scales the trace-method vector by `0.5 / math.sqrt(tn * M[3][3])` -- a PYTHON float, so autograd
+// sees the scale as a constant (frame.py:112); the same is done here: gR = sc * (d v / d R)^T g, v the unscaled vector.
+// Euler (frame.py:120-121): atan2 / asin derivatives as torch gives them.
+__global__ void __launch_bounds__(256)
+k_frame_quat_euler_bwd(const float* __restrict__ R, int64_t n, int stride, int pitch, const float* __restrict__ gquat_xyzw,
+                       const float* __restrict__ geuler, float* __restrict__ gR) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const float* m = R + s * stride;
+    float r[9], g[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r[3 * i + j] = m[i * pitch + j];
+    if (gquat_xyzw) {
+        const float4 gq = reinterpret_cast<const float4*>(gquat_xyzw)[s];
+        float t = r[0] + r[4] + r[8] + 1.0f;
+        // (a, b, c): adjoints of the three difference / sum terms, gd: adjoint of the diagonal term t
+        if (t > 1.0f) {
+            const float sc = 0.5f / sqrtf(t);
+            const float gw = sc * gq.w, gx = sc * gq.x, gy = sc * gq.y, gz = sc * gq.z;
+            g[0] += gw; g[4] += gw; g[8] += gw;
+            g[3] += gz; g[1] -= gz; g[2] += gy; g[6] -= gy; g[7] += gx; g[5] -= gx;
+        } else {
+            int i = 0;
+            if (r[4] > r[0]) i = 1;
+            if (r[8] > (i == 0 ? r[0] : r[4])) i = 2;
+            if (i == 0) {
+                t = r[0] - (r[4] + r[8]) + 1.0f;
+                const float sc = 0.5f / sqrtf(t);
+                const float gw = sc * gq.w, gx = sc * gq.x, gy = sc * gq.y, gz = sc * gq.z;
+                g[0] += gx; g[4] -= gx; g[8] -= gx;
+                g[1] += gy; g[3] += gy; g[6] += gz; g[2] += gz; g[7] += gw; g[5] -= gw;
+            } else if (i == 1) {
+                t = r[4] - (r[8] + r[0]) + 1.0f;
+                const float sc = 0.5f / sqrtf(t);
+                const float gw = sc * gq.w, gx = sc * gq.x, gy = sc * gq.y, gz = sc * gq.z;
+                g[4] += gy; g[8] -= gy; g[0] -= gy;
+                g[5] += gz; g[7] += gz; g[1] += gx; g[3] += gx; g[2] += gw; g[6] -= gw;
+            } else {
+                t = r[8] - (r[0] + r[4]) + 1.0f;
+                const float sc = 0.5f / sqrtf(t);
+                const float gw = sc * gq.w, gx = sc * gq.x, gy = sc * gq.y, gz = sc * gq.z;
+                g[8] += gz; g[0] -= gz; g[4] -= gz;
+                g[6] += gx; g[2] += gx; g[5] += gy; g[7] += gy; g[3] += gw; g[1] -= gw;
+            }
+        }
+    }
+    if (geuler) {
+        const float g0 = geuler[s * 3], g1 = geuler[s * 3 + 1], g2 = geuler[s * 3 + 2];
+        const float d0 = r[7] * r[7] + r[8] * r[8], d2 = r[3] * r[3] + r[0] * r[0];
+        g[7] += g0 * r[8] / d0; g[8] -= g0 * r[7] / d0;            // atan2(r21, r22)
+        g[6] -= g1 / sqrtf(1.0f - r[6] * r[6]);                    // asin(-r20)
+        g[3] += g2 * r[0] / d2; g[0] -= g2 * r[3] / d2;            // atan2(r10, r00)
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gR[s * 9 + k] = g[k];
+}
+
 // x_rot / y_rot / z_rot spatial_vector.py:8-47 (axis 0 / 1 / 2) and q_to_rotation_matrix quaternion.py:102-120 (axis 3, input
-// wxyz [n,4]): -> R [n,9].  gR != nullptr: reverse mode of the axis rotations, gangle[s] = <gR_s, dR/dangle>.
+// wxyz [n,4]): -> R [n,9].  gR != nullptr: reverse mode, gin[s] = <gR_s, dR/d in> (one angle, or the four quaternion components).
 __global__ void __launch_bounds__(256)
 k_rotation_from(int axis, const float* __restrict__ in, int64_t n, float* __restrict__ R, const float* __restrict__ gR,
                 float* __restrict__ gin) {
@@ -1303,6 +1407,19 @@ k_rotation_from(int axis, const float* __restrict__ in, int64_t n, float* __rest
         r[0] = 1.0f - dc * (y * y + z * z); r[1] = dc * (x * y - z * w); r[2] = dc * (x * z + y * w);
         r[3] = dc * (x * y + z * w); r[4] = 1.0f - dc * (x * x + z * z); r[5] = dc * (y * z - x * w);
         r[6] = dc * (x * z - y * w); r[7] = dc * (y * z + x * w); r[8] = 1.0f - dc * (x * x + y * y);
+        if (gR) {
+            // R = I + dc M(q), M quadratic in q, dc = 2 / |q|^2:  d/dq_k <g, R> = dc <g, dM/dq_k> - dc^2 q_k <g, M>
+            const float* g = gR + s * 9;
+            const float gM = -g[0] * (y * y + z * z) + g[1] * (x * y - z * w) + g[2] * (x * z + y * w) +
+                             g[3] * (x * y + z * w) - g[4] * (x * x + z * z) + g[5] * (y * z - x * w) +
+                             g[6] * (x * z - y * w) + g[7] * (y * z + x * w) - g[8] * (x * x + y * y);
+            const float dw = z * (g[3] - g[1]) + y * (g[2] - g[6]) + x * (g[7] - g[5]);
+            const float dx = y * (g[1] + g[3]) + z * (g[2] + g[6]) + w * (g[7] - g[5]) - 2.0f * x * (g[4] + g[8]);
+            const float dy = x * (g[1] + g[3]) + z * (g[5] + g[7]) + w * (g[2] - g[6]) - 2.0f * y * (g[0] + g[8]);
+            const float dz = x * (g[2] + g[6]) + y * (g[5] + g[7]) + w * (g[3] - g[1]) - 2.0f * z * (g[0] + g[4]);
+            const float k2 = dc * dc * gM;
+            reinterpret_cast<float4*>(gin)[s] = make_float4(dc * dw - k2 * w, dc * dx - k2 * x, dc * dy - k2 * y, dc * dz - k2 * z);
+        }
     } else {
         const float a = in[s];
         const float c = cosf(a), sn = sinf(a);
@@ -1412,6 +1529,38 @@ k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, i
         float* o = ot + r * D;
         for (int d = 0; d < D; ++d) o[d] = __fadd_rn(__fmul_rn(p0[d], fa), __fmul_rn(p0[D + d], fb));
     }
+}
+
+// interpolate_points_v1 distance_fields.py:66-69 (F.interpolate linear, align_corners=True, along the link axis) with the index /
+// weight table unrolled on the host: x [N, L, C] -> out [N, K, C], out[n, k] = w[2k] x[n, src[2k]] + w[2k+1] x[n, src[2k+1]].
+// One thread per output element: consecutive threads write consecutive floats.
+__global__ void __launch_bounds__(256)
+k_interpolate_columns(const float* __restrict__ x, int64_t n, int L, int C, int K, const int32_t* __restrict__ src,
+                      const float* __restrict__ w, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * K * C) return;
+    const int c = (int)(idx % C);
+    const int64_t r = idx / C;
+    const int k = (int)(r % K);
+    const float* xs = x + (r / K) * L * C + c;
+    out[idx] = __fadd_rn(__fmul_rn(w[2 * k], xs[src[2 * k] * C]), __fmul_rn(w[2 * k + 1], xs[src[2 * k + 1] * C]));
+}
+// its reverse mode: g [N, K, C] -> gx [N, L, C]; one thread per input element gathers from the output points that read it
+__global__ void __launch_bounds__(256)
+k_interpolate_columns_bwd(const float* __restrict__ g, int64_t n, int L, int C, int K, const int32_t* __restrict__ src,
+                          const float* __restrict__ w, float* __restrict__ gx) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * L * C) return;
+    const int c = (int)(idx % C);
+    const int64_t r = idx / C;
+    const int l = (int)(r % L);
+    const float* gs = g + (r / L) * K * C + c;
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        if (src[2 * k] == l) acc = fmaf(w[2 * k], gs[k * C], acc);
+        if (src[2 * k + 1] == l) acc = fmaf(w[2 * k + 1], gs[k * C], acc);
+    }
+    gx[idx] = acc;
 }
 
 // ============================================================================================
@@ -1601,13 +1750,13 @@ void trk_launch_ik_step(const DevModelHdr& hdr, const DevLink* links, const int3
 
 void trk_launch_cost_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, const float* gcost,
                             float* cost, float* g_link_pos, hipStream_t st) {
-    size_t lds = sizeof(float) * (g_link_pos ? 2 : 1) * (size_t)TRK_WAVE * ((C.n_links_in * 3) | 1);
+    size_t lds = sizeof(float) * (g_link_pos ? 2 : 1) * (size_t)TRK_WAVE * (((C.n_links_in + C.n_virtual) * 3) | 1);
     hipLaunchKernelGGL(k_cost_fields, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, C, fields, link_pos, n, gcost, cost, g_link_pos);
 }
 
 void trk_launch_collision_fields(const DevCostHdr& C, int fields, const float* link_pos, int64_t n, float margin,
                                  int use_default, uint8_t* out, hipStream_t st) {
-    size_t lds = sizeof(float) * (size_t)TRK_WAVE * ((C.n_links_in * 3) | 1);
+    size_t lds = sizeof(float) * (size_t)TRK_WAVE * (((C.n_links_in + C.n_virtual) * 3) | 1);
     hipLaunchKernelGGL(k_collision_fields, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, C, fields, link_pos, n, margin, use_default, out);
 }
 
@@ -1632,9 +1781,9 @@ static void launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links,
     const IO* qq = static_cast<const IO*>(q);
     IO* lp = static_cast<IO*>(link_pos);
     IO* gg = static_cast<IO*>(gq);
-    if (ps) hipLaunchKernelGGL((k_rollout_generic<true, IO>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, ps->n_points), st,
+    if (ps) hipLaunchKernelGGL((k_rollout_generic<true, IO>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, ps->n_points + C.n_virtual), st,
                                hdr, links, fin, SelMap{}, *ps, C, w, qq, n, lp, cost, gg, cost_sum);
-    else hipLaunchKernelGGL((k_rollout_generic<false, IO>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, hdr.n_links), st,
+    else hipLaunchKernelGGL((k_rollout_generic<false, IO>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, hdr.n_links + C.n_virtual), st,
                             hdr, links, fin, SelMap{}, DevPointSet{}, C, w, qq, n, lp, cost, gg, cost_sum);
 }
 
@@ -1712,6 +1861,10 @@ void trk_launch_frame_quat_euler(const float* R, int64_t n, int stride, int pitc
                                  hipStream_t st) {
     hipLaunchKernelGGL(k_frame_quat_euler, dim3(grid_for(n, 256)), dim3(256), 0, st, R, n, stride, pitch, quat_xyzw, euler);
 }
+void trk_launch_frame_quat_euler_bwd(const float* R, int64_t n, int stride, int pitch, const float* gquat_xyzw, const float* geuler,
+                                     float* gR, hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_quat_euler_bwd, dim3(grid_for(n, 256)), dim3(256), 0, st, R, n, stride, pitch, gquat_xyzw, geuler, gR);
+}
 
 void trk_launch_rotation_from(int axis, const float* in, int64_t n, float* R, const float* gR, float* gin, hipStream_t st) {
     hipLaunchKernelGGL(k_rotation_from, dim3(grid_for(n, 256)), dim3(256), 0, st, axis, in, n, R, gR, gin);
@@ -1733,6 +1886,15 @@ void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_inter
     }
     const int64_t total = T * (int64_t)(H - 1) * n_interp * D;
     hipLaunchKernelGGL(k_interpolate_via_points_flat, dim3(grid_for(total, 256)), dim3(256), 0, st, x, T, H, D, n_interp, alpha, beta, out);
+}
+
+void trk_launch_interpolate_columns(const float* x, int64_t n, int L, int C, int K, const int32_t* src, const float* w, float* out,
+                                    hipStream_t st) {
+    hipLaunchKernelGGL(k_interpolate_columns, dim3(grid_for(n * K * C, 256)), dim3(256), 0, st, x, n, L, C, K, src, w, out);
+}
+void trk_launch_interpolate_columns_bwd(const float* g, int64_t n, int L, int C, int K, const int32_t* src, const float* w, float* gx,
+                                        hipStream_t st) {
+    hipLaunchKernelGGL(k_interpolate_columns_bwd, dim3(grid_for(n * L * C, 256)), dim3(256), 0, st, g, n, L, C, K, src, w, gx);
 }
 
 int trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,

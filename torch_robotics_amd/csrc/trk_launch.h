@@ -44,9 +44,15 @@ void trk_launch_frame_transform_points_bwd(const float* g, int64_t n, const floa
                                            hipStream_t st);
 void trk_launch_frame_quat_euler(const float* R, int64_t n, int stride, int pitch, float* quat_xyzw, float* euler,
                                  hipStream_t st);
+void trk_launch_frame_quat_euler_bwd(const float* R, int64_t n, int stride, int pitch, const float* gquat_xyzw, const float* geuler,
+                                     float* gR, hipStream_t st);
 void trk_launch_rotation_from(int axis, const float* in, int64_t n, float* R, const float* gR, float* gin, hipStream_t st);
 void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const float* lo, const float* hi, float* sdf,
                                 float* grad, hipStream_t st);
+void trk_launch_interpolate_columns(const float* x, int64_t n, int L, int C, int K, const int32_t* src, const float* w, float* out,
+                                    hipStream_t st);
+void trk_launch_interpolate_columns_bwd(const float* g, int64_t n, int L, int C, int K, const int32_t* src, const float* w, float* gx,
+                                        hipStream_t st);
 void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_interp, const float* alpha, const float* beta,
                             float* out, hipStream_t st);
 int trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,

@@ -28,17 +28,17 @@ def _np(x):
     return np.asarray(x)
 
 
+_version_counter = itertools.count(1)
+
+
 def scene_version(df_obj_list) -> tuple:
-    """What a device cost model built from these objects depends on: identity AND current pose of every ObjectField, identity
+    """What a device cost model built from these objects depends on: identity AND pose version of every ObjectField, identity
     of a grid's tensors.  The reference evaluates each object from its current pose on every call (primitives.py:387-405), so
-    every cache of a `CostHandle` is keyed by this and a moved object rebuilds it."""
-    out = []
-    for o in df_obj_list:
-        if isinstance(o, GridMapSDF):
-            out.append((id(o), id(o.sdf_tensor)))
-        else:
-            out.append((id(o), o.pos.tobytes(), o.ori.tobytes()))
-    return tuple(out)
+    every cache of a `CostHandle` is keyed by this and a moved object rebuilds it.  Integers only -- this runs on every cost
+    evaluation: an ObjectField takes a fresh version number whenever `pos` / `ori` are assigned (`set_position_orientation`
+    or the attributes).  In-place edits of the arrays (`obj.pos[0] = ...`, a primitive's centres or radii) are NOT seen;
+    assign a new array or call `set_position_orientation`."""
+    return tuple((id(o), id(o.sdf_tensor)) if isinstance(o, GridMapSDF) else (id(o), o._version) for o in df_obj_list)
 
 
 class PrimitiveShapeField:
@@ -109,18 +109,35 @@ class ObjectField(PrimitiveShapeField):                      # primitives.py:346
         super().__init__(dim=primitive_fields[0].dim, tensor_args=primitive_fields[0].tensor_args)
         self.name, self.fields, self.reference_frame = name, primitive_fields, reference_frame
         assert (pos is None and ori is None) or (np.size(_np(pos)) == 3 and np.size(_np(ori)) == 4)
-        self.pos = np.zeros(3, np.float32) if pos is None else _np(pos).astype(np.float32).reshape(3)
-        self.ori = np.array([1, 0, 0, 0], np.float32) if ori is None else _np(ori).astype(np.float32).reshape(4)
-        self._cm = None
+        self.pos = np.zeros(3, np.float32) if pos is None else pos
+        self.ori = np.array([1, 0, 0, 0], np.float32) if ori is None else ori
+
+    # pose attributes: every assignment takes a new version number (scene_version) and drops the object's own cost model
+    @property
+    def pos(self):
+        return self._pos
+
+    @pos.setter
+    def pos(self, value):
+        self._pos = _np(value).astype(np.float32).reshape(3)
+        self._version, self._cm = next(_version_counter), None
+
+    @property
+    def ori(self):
+        return self._ori
+
+    @ori.setter
+    def ori(self, value):
+        self._ori = _np(value).astype(np.float32).reshape(4)
+        self._version, self._cm = next(_version_counter), None
 
     def set_position_orientation(self, pos=None, ori=None):
         if pos is not None:
             assert len(pos) == 3
-            self.pos = _np(pos).astype(np.float32).reshape(3)
+            self.pos = pos
         if ori is not None:
             assert len(ori) == 4, "quaternion wxyz"
-            self.ori = _np(ori).astype(np.float32).reshape(4)
-        self._cm = None
+            self.ori = ori
 
     def as_object(self) -> dict:
         prims = list(itertools.chain.from_iterable(f.prims() for f in self.fields))

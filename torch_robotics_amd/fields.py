@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from ._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
-from .costmodel import CostModelSpec
+from .costmodel import CostModelSpec, interpolation_table
 from .environments import _np, objects_to_spec_parts, scene_version
 
 
@@ -50,6 +50,31 @@ class DistanceField:
         pass
 
 
+class _InterpolateColumns(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, src, w, n_out):
+        ctx.save_for_backward(src, w)
+        ctx.n_in = int(x.shape[-2])
+        return ops.interpolate_columns(x, src, w, n_out)
+
+    @staticmethod
+    def backward(ctx, g):
+        src, w = ctx.saved_tensors
+        return ops.interpolate_columns_backward(g.contiguous(), src, w, ctx.n_in), None, None, None
+
+
+def interpolate_points_v1(points, num_interpolated_points):
+    """distance_fields.py:66-69: `F.interpolate(points.transpose(-2, -1), size=K, mode='linear', align_corners=True)` back
+    transposed -- (..., L, C) -> (..., K, C), linear along the link axis; differentiable w.r.t. the points."""
+    L, K = int(points.shape[-2]), int(num_interpolated_points)
+    src, w = interpolation_table(L, K)
+    src_t = torch.as_tensor(src.reshape(-1), device=points.device)
+    w_t = torch.as_tensor(w.reshape(-1), device=points.device)
+    if torch.is_grad_enabled() and points.requires_grad:
+        return _InterpolateColumns.apply(points, src_t, w_t, K)
+    return ops.interpolate_columns(points, src_t, w_t, K)
+
+
 class EmbodimentDistanceFieldBase(DistanceField):
     _field = 0
 
@@ -58,8 +83,14 @@ class EmbodimentDistanceFieldBase(DistanceField):
                  interpolate_link_pos=False, **kwargs):
         super().__init__(**kwargs)
         assert robot is not None, "You need to pass a robot instance to the embodiment distance fields"
-        if interpolate_link_pos:
-            raise NotImplementedError("interpolate_link_pos double-indexes the links in the reference (never enabled by its callers)")
+        # interpolate_link_pos=True (distance_fields.py:145-147): the field is evaluated on `num_interpolated_points` points
+        # spread linearly along the chain of selected links (interpolate_points_v1, :66-69) instead of the link origins;
+        # margins and self-collision pair rows then refer to those points (robot_base.py:70-73, 103-108).  The reference
+        # indexes the interpolated tensor with `link_idxs_for_collision_checking` a second time (:109) -- with the Panda's link
+        # indices it would evaluate interpolated points no. 2, 3, 5, 7, 9 of the K -- so what is built is the evident intent,
+        # every interpolated point with its own margin, pinned by the reference's own functions called with the index set
+        # that makes them do that (oracle/gen_golden.py: cost_interp.npz).
+        self.interpolate_link_pos = bool(interpolate_link_pos)
         self.clamp_sdf = bool(clamp_sdf)        # relu(margin - sdf) per link / pair (distance_fields.py:114-117)
         self.robot = robot
         self.link_idxs_for_collision_checking = link_idxs_for_collision_checking
@@ -77,7 +108,8 @@ class EmbodimentDistanceFieldBase(DistanceField):
         return 0
 
     def _handle(self, n_links_in: int, device) -> ops.CostHandle:
-        key = (n_links_in, str(device), self._scene_version(), bool(self.clamp_sdf))
+        key = (n_links_in, str(device), self._scene_version(), bool(self.clamp_sdf), self.interpolate_link_pos,
+               int(self.num_interpolated_points) if self.interpolate_link_pos else 0)
         if key not in self._handles:
             spec = CostModelSpec(n_links_in=n_links_in)
             self._fill_spec(spec)
@@ -85,14 +117,21 @@ class EmbodimentDistanceFieldBase(DistanceField):
             self._handles = {key: ops.CostHandle(spec, device)}
         return self._handles[key]
 
-    def _columns(self, n_links_in: int) -> np.ndarray:
+    def _columns(self, n_links_in: int, spec: Optional[CostModelSpec] = None) -> np.ndarray:
         """Columns of the position tensor this field reads: the selected robot links, then -- when the robot holds an
         object -- the grasped points, which fk_map_collision appends after the links (robot_panda.py:154-168).
         The reference's own gather for that case (distance_fields.py:134-155) raises on a shape mismatch; what it
         evidently means (robot links ++ grasped points, margins and pair rows as RobotBase builds them,
         robot_base.py:71-141) is what is implemented, and pinned with the reference's field code in
-        tests/golden/grasp_panda.npz."""
+        tests/golden/grasp_panda.npz.
+        With interpolate_link_pos the selected links are replaced by `num_interpolated_points` virtual columns of `spec`
+        (linear interpolation along the selected links); grasped points are not interpolated (distance_fields.py:149-152)."""
         cols = list(self.link_idxs_for_collision_checking)
+        if self.interpolate_link_pos:
+            if spec is None:
+                raise ValueError("interpolate_link_pos: the cost spec that receives the interpolated columns is required")
+            src, w = interpolation_table(len(cols), int(self.num_interpolated_points))
+            cols = list(spec.add_virtual_columns(np.asarray(cols, np.int32)[src], w))
         go = getattr(self.robot, "grasped_object", None)
         if go is not None:
             G = go.n_base_points_for_collision
@@ -145,9 +184,15 @@ class CollisionSelfField(EmbodimentDistanceFieldBase):        # distance_fields.
         self.idxs_links_distance_matrix_tuple = tuple(zip(*idxs_links_distance_matrix))
 
     def _fill_spec(self, spec):
-        spec.self_link_idx = self._columns(spec.n_links_in)
-        spec.self_pairs = np.asarray(self.idxs_links_distance_matrix, np.int32).reshape(-1, 2)
+        spec.self_link_idx = self._columns(spec.n_links_in, spec)
         cm = _np(self.cutoff_margin).astype(np.float32).reshape(-1)
+        if len(spec.self_link_idx) == 1:
+            # one self-collision point: the reference ignores the pair table and returns |p|_1 * 1e9 as "the distance"
+            # (distance_fields.py:195-198); the degenerate pair (0, 0) is how the cost model says that
+            spec.self_pairs = np.zeros((1, 2), np.int32)
+            spec.self_margin = cm[:1].copy()
+            return
+        spec.self_pairs = np.asarray(self.idxs_links_distance_matrix, np.int32).reshape(-1, 2)
         spec.self_margin = np.broadcast_to(cm, (len(spec.self_pairs),)).copy()
 
 
@@ -167,7 +212,7 @@ class CollisionObjectDistanceField(CollisionObjectBase):      # distance_fields.
         return scene_version(self.df_obj_list_fn() if self.df_obj_list_fn is not None else [])
 
     def _fill_spec(self, spec):
-        spec.obj_link_idx = self._columns(spec.n_links_in)
+        spec.obj_link_idx = self._columns(spec.n_links_in, spec)
         spec.obj_link_margin = self._margin_vector(len(spec.obj_link_idx))
         objs = self.df_obj_list_fn() if self.df_obj_list_fn is not None else []
         spec.objects, spec.grid = objects_to_spec_parts(objs)
@@ -181,7 +226,7 @@ class CollisionWorkspaceBoundariesDistanceField(CollisionObjectBase):    # dista
         self.ws_min, self.ws_max = ws_bounds_min, ws_bounds_max
 
     def _fill_spec(self, spec):
-        spec.obj_link_idx = self._columns(spec.n_links_in)
+        spec.obj_link_idx = self._columns(spec.n_links_in, spec)
         spec.obj_link_margin = self._margin_vector(len(spec.obj_link_idx))
         spec.ws_min = _np(self.ws_min).astype(np.float32).reshape(3)
         spec.ws_max = _np(self.ws_max).astype(np.float32).reshape(3)

@@ -132,8 +132,17 @@ def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tup
     return ident
 
 
+def generatable(spec) -> bool:
+    """False for cost models only the table-driven kernels evaluate (the dispatcher's rule, trk_capi.hip: spec_matches):
+    interpolated (virtual) position columns and the single-link self distance (a degenerate pair)."""
+    if len(np.asarray(getattr(spec, "virtual_src", ())).reshape(-1)) > 0:
+        return False
+    sl = np.asarray(spec.self_link_idx, np.int32)
+    return not any(int(sl[a]) == int(sl[b]) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2))
+
+
 def _template_of(kin: KinModel, spec) -> Optional[codegen.CollisionTemplate]:
-    if spec.n_links_in != kin.n_links:
+    if spec.n_links_in != kin.n_links or not generatable(spec):
         return None
     sl = np.asarray(spec.self_link_idx, np.int32)
     pairs = [(int(sl[a]), int(sl[b])) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2)]
@@ -170,7 +179,7 @@ def has_matching_unit(kin: KinModel, spec) -> bool:
 
 def specialize_for_cost_spec(kin: KinModel, spec, verbose: bool = False) -> Optional[str]:
     """Template from a CostModelSpec whose columns are the links (no attached points)."""
-    if spec.n_links_in != kin.n_links:
+    if spec.n_links_in != kin.n_links or not generatable(spec):
         return None
     sl = np.asarray(spec.self_link_idx, np.int32)
     pairs = [(int(sl[a]), int(sl[b])) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2)]
@@ -183,7 +192,7 @@ def specialize_for_cost_spec(kin: KinModel, spec, verbose: bool = False) -> Opti
 def _points_template_of(kin: KinModel, point_link, point_offset, spec) -> Optional[codegen.PointsTemplate]:
     pl = np.ascontiguousarray(point_link, np.int32).reshape(-1)
     po = np.ascontiguousarray(point_offset, np.float32).reshape(-1, 3)
-    if spec.n_links_in != len(pl):
+    if spec.n_links_in != len(pl) or not generatable(spec):
         return None
     pos_of = {int(kin.order[p]): p for p in range(kin.n_links)}
     rank = [pos_of[int(i)] for i in pl]

@@ -301,13 +301,34 @@ def fk_analytic_jacobian(model: ModelHandle, q: torch.Tensor) -> torch.Tensor:
     return J
 
 
+def _check_ik_buffers(who, model, q, lower, upper, adam_m, adam_v, loss, valid):
+    """The IK kernels update q / adam_m / adam_v in place through raw pointers: refuse anything that is not exactly the
+    buffer they expect (a wrong size would be an out-of-bounds device write)."""
+    if not isinstance(q, torch.Tensor) or not q.is_cuda or q.dim() != 2:
+        raise ValueError(f"{who}: q must be a 2-D CUDA/HIP tensor (there is no CPU path)")
+    n, D = int(q.shape[0]), int(q.shape[1])
+    if D != model.n_dofs:
+        raise ValueError(f"{who}: q has {D} columns, the model has {model.n_dofs} DOF")
+    _check_buffer(q, n * D, torch.float32, q.device, f"{who}(q)")
+    for name, t in (("lower", lower), ("upper", upper)):
+        if t is None:
+            raise ValueError(f"{who}: {name} is required")
+        _check_buffer(t, D, torch.float32, q.device, f"{who}({name})")
+    _check_buffer(adam_m, n * D, torch.float32, q.device, f"{who}(adam_m)")
+    _check_buffer(adam_v, n * D, torch.float32, q.device, f"{who}(adam_v)")
+    _check_buffer(loss, n, torch.float32, q.device, f"{who}(loss)")
+    if valid is not None and (not isinstance(valid, torch.Tensor) or valid.device != q.device or valid.numel() != n or
+                              valid.element_size() != 1 or not valid.is_contiguous()):
+        raise ValueError(f"{who}(valid): expected a contiguous 1-byte tensor of {n} elements on {q.device}")
+    return n, D
+
+
 def ik_step(model: ModelHandle, link: int, H_target: torch.Tensor, lower: torch.Tensor, upper: torch.Tensor,
             q: torch.Tensor, adam_m: Optional[torch.Tensor], adam_v: Optional[torch.Tensor], step: int, lr: float = 1e-2,
             w_joint_limits: float = 300.0, se3_eps: float = 1e-1, loss: Optional[torch.Tensor] = None,
             valid: Optional[torch.Tensor] = None) -> None:
     """One fused IK iteration IN PLACE on q / adam_m / adam_v (all (N, D) float32 contiguous CUDA tensors)."""
-    n, D = q.shape
-    assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and D == model.n_dofs
+    n, D = _check_ik_buffers("ik_step", model, q, lower, upper, adam_m, adam_v, loss, valid)
     Ht = _dev_f32(H_target, "ik_step(H_target)")
     per_sample = int(Ht.dim() == 3)
     if per_sample and Ht.shape[0] != n:
@@ -324,8 +345,9 @@ def ik_steps(model: ModelHandle, link: int, H_target: torch.Tensor, lower: torch
              valid: Optional[torch.Tensor] = None) -> None:
     """`n_steps` fused IK iterations IN PLACE (one launch per 32 iterations; the configurations stay on the chip in between).
     Equal to n_steps calls of ik_step, except that loss / valid describe q as passed in."""
-    n, D = q.shape
-    assert q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and D == model.n_dofs
+    n, D = _check_ik_buffers("ik_steps", model, q, lower, upper, adam_m, adam_v, loss, valid)
+    if adam_m is None or adam_v is None:
+        raise ValueError("ik_steps: adam_m and adam_v are required")
     Ht = _dev_f32(H_target, "ik_steps(H_target)")
     per_sample = int(Ht.dim() == 3)
     if per_sample and Ht.shape[0] != n:
@@ -381,16 +403,42 @@ def axis_rotation(kind: int, angle: torch.Tensor) -> torch.Tensor:
     return _AxisRotation.apply(int(kind), a)
 
 
+def _quat_to_rotmat_raw(flat: torch.Tensor) -> torch.Tensor:
+    R = torch.empty((flat.shape[0], 3, 3), device=flat.device, dtype=torch.float32)
+    with _on(flat.device):
+        check(lib().trk_rotation_from(3, flat.data_ptr(), int(flat.shape[0]), R.data_ptr(), _stream(flat)), "trk_rotation_from")
+    return R
+
+
+class _QuatRotation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flat):
+        ctx.save_for_backward(flat)
+        return _quat_to_rotmat_raw(flat)
+
+    @staticmethod
+    def backward(ctx, gR):
+        (flat,) = ctx.saved_tensors
+        gR = _dev_f32(gR, "quat_to_rotmat backward")
+        gq = torch.empty_like(flat)
+        with _on(flat.device):
+            check(lib().trk_rotation_from_backward(3, flat.data_ptr(), gR.data_ptr(), int(flat.shape[0]), gq.data_ptr(),
+                                                   _stream(flat)), "trk_rotation_from_backward")
+        return gq
+
+
 def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
-    """q_to_rotation_matrix (quaternion.py:102-120): wxyz (..., 4), not necessarily normalised -> (..., 3, 3)."""
-    q = _dev_f32(q.detach(), "quat_to_rotmat(q)")
+    """q_to_rotation_matrix (quaternion.py:102-120): wxyz (..., 4), not necessarily normalised -> (..., 3, 3); differentiable
+    w.r.t. q like the reference's torch expression (explicit backward kernel, incl. the 2 / |q|^2 normalisation)."""
+    q = _dev_f32(q, "quat_to_rotmat(q)")
     if q.dim() == 1:
         q = q.unsqueeze(0)
     lead = q.shape[:-1]
     flat = q.reshape(-1, 4).contiguous()
-    R = torch.empty((flat.shape[0], 3, 3), device=q.device, dtype=torch.float32)
-    with _on(q.device):
-        check(lib().trk_rotation_from(3, flat.data_ptr(), int(flat.shape[0]), R.data_ptr(), _stream(q)), "trk_rotation_from")
+    if torch.is_grad_enabled() and flat.requires_grad:
+        R = _QuatRotation.apply(flat)
+    else:
+        R = _quat_to_rotmat_raw(flat)
     return R.reshape(tuple(lead) + (3, 3))
 
 
@@ -499,23 +547,63 @@ def frame_transform_points(R, t, points):
     return _FrameTransformPoints.apply(R, t, pts)
 
 
-def frame_quat_euler(R: torch.Tensor, want_quat=True, want_euler=False):
-    """Frame.get_quaternion (trace method, XYZW -- frame.py:87-114) / Frame.get_euler (frame.py:120-121) of (n,3,3) rotations
-    or (n,4,4) transforms.  Not differentiable (neither is the reference's per-sample loop in practice)."""
-    R = _dev_f32(R.detach(), "frame_quat_euler(R)")
+def _rot_layout(R: torch.Tensor, what: str):
     if R.shape[-2:] == (3, 3):
         stride, pitch = 9, 3
     elif R.shape[-2:] == (4, 4):
         stride, pitch = 16, 4
     else:
-        raise ValueError("frame_quat_euler: expected (...,3,3) or (...,4,4)")
+        raise ValueError(f"{what}: expected (...,3,3) or (...,4,4)")
     batch = R.shape[:-2]
-    n = int(np.prod(batch)) if len(batch) else 1
-    quat = torch.empty(tuple(batch) + (4,), device=R.device, dtype=torch.float32) if want_quat else None
-    eul = torch.empty(tuple(batch) + (3,), device=R.device, dtype=torch.float32) if want_euler else None
+    return stride, pitch, tuple(batch), (int(np.prod(batch)) if len(batch) else 1)
+
+
+def _frame_quat_euler_raw(R, want_quat, want_euler):
+    stride, pitch, batch, n = _rot_layout(R, "frame_quat_euler")
+    quat = torch.empty(batch + (4,), device=R.device, dtype=torch.float32) if want_quat else None
+    eul = torch.empty(batch + (3,), device=R.device, dtype=torch.float32) if want_euler else None
     with _on(R.device):
         check(lib().trk_frame_quat_euler(R.data_ptr(), n, stride, pitch, _ptr(quat), _ptr(eul), _stream(R)), "trk_frame_quat_euler")
     return quat, eul
+
+
+class _FrameQuatEuler(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R, want_quat, want_euler):
+        quat, eul = _frame_quat_euler_raw(R, want_quat, want_euler)
+        ctx.save_for_backward(R)
+        ctx.want = (want_quat, want_euler)
+        return tuple(t for t in (quat, eul) if t is not None)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (R,) = ctx.saved_tensors
+        grads = list(grads)
+        gq = grads.pop(0) if ctx.want[0] else None
+        ge = grads.pop(0) if ctx.want[1] else None
+        gq = None if gq is None else _dev_f32(gq, "frame_quat_euler backward")
+        ge = None if ge is None else _dev_f32(ge, "frame_quat_euler backward")
+        stride, pitch, batch, n = _rot_layout(R, "frame_quat_euler")
+        g9 = torch.empty((n, 3, 3), device=R.device, dtype=torch.float32)
+        with _on(R.device):
+            check(lib().trk_frame_quat_euler_backward(R.data_ptr(), n, stride, pitch, _ptr(gq), _ptr(ge), g9.data_ptr(),
+                                                      _stream(R)), "trk_frame_quat_euler_backward")
+        if pitch == 3:
+            return g9.reshape(R.shape), None, None
+        gR = torch.zeros_like(R)                      # 4x4 transforms: only the rotation block receives a gradient
+        gR[..., :3, :3] = g9.reshape(batch + (3, 3))
+        return gR, None, None
+
+
+def frame_quat_euler(R: torch.Tensor, want_quat=True, want_euler=False):
+    """Frame.get_quaternion (trace method, XYZW -- frame.py:87-114) / Frame.get_euler (frame.py:120-121) of (n,3,3) rotations
+    or (n,4,4) transforms.  Differentiable w.r.t. R the way the reference is: the Euler angles through atan2 / asin, the
+    quaternion with its normalising scale held constant (the reference computes it with `math.sqrt`, outside autograd)."""
+    R = _dev_f32(R, "frame_quat_euler(R)")
+    if torch.is_grad_enabled() and R.requires_grad and (want_quat or want_euler):
+        outs = list(_FrameQuatEuler.apply(R, bool(want_quat), bool(want_euler)))
+        return (outs.pop(0) if want_quat else None), (outs.pop(0) if want_euler else None)
+    return _frame_quat_euler_raw(R, want_quat, want_euler)
 
 
 def cost_fields(cm: CostHandle, fields: int, link_pos: torch.Tensor, gcost: Optional[torch.Tensor] = None,
@@ -725,9 +813,10 @@ class GPPriorPlan:
                       self.cost.data_ptr(), self.gq.data_ptr(), self.gqd.data_ptr(), acc)
 
     def launch(self, stream: Optional[int] = None) -> None:
-        if stream is None:
-            stream = _stream_of(self.device)
-        rc = self._fn(*self._args, stream)
+        with _on(self.device):                  # free when the device is already current
+            if stream is None:
+                stream = _stream_of(self.device)
+            rc = self._fn(*self._args, stream)
         if rc:
             check(rc, "trk_gp_prior_cost_grad")
 
@@ -798,6 +887,36 @@ def interpolate_traj_via_points(trajs: torch.Tensor, num_interpolation: int = 10
         check(lib().trk_interpolate_via_points(x.data_ptr(), T, H, D, int(num_interpolation), alpha.data_ptr(),
                                                beta.data_ptr(), out.data_ptr(), _stream(x)), "trk_interpolate_via_points")
     return out
+
+
+def interpolate_columns(x: torch.Tensor, src: torch.Tensor, w: torch.Tensor, n_out: int) -> torch.Tensor:
+    """x (..., L, C) -> (..., n_out, C): out[..., k, :] = w[2k] x[..., src[2k], :] + w[2k+1] x[..., src[2k+1], :]
+    (interpolate_points_v1, distance_fields.py:66-69; src / w from costmodel.interpolation_table, on x's device)."""
+    x = _dev_f32(x, "interpolate_columns(x)")
+    if x.dim() < 2:
+        raise ValueError("interpolate_columns: x must be (..., links, channels)")
+    L, Cc = int(x.shape[-2]), int(x.shape[-1])
+    lead = tuple(x.shape[:-2])
+    n = int(np.prod(lead)) if lead else 1
+    _check_buffer(src, 2 * int(n_out), torch.int32, x.device, "interpolate_columns(src)")
+    _check_buffer(w, 2 * int(n_out), torch.float32, x.device, "interpolate_columns(w)")
+    out = torch.empty(lead + (int(n_out), Cc), device=x.device, dtype=torch.float32)
+    with _on(x.device):
+        check(lib().trk_interpolate_columns(x.data_ptr(), n, L, Cc, int(n_out), src.data_ptr(), w.data_ptr(), out.data_ptr(),
+                                            _stream(x)), "trk_interpolate_columns")
+    return out
+
+
+def interpolate_columns_backward(g: torch.Tensor, src: torch.Tensor, w: torch.Tensor, n_in: int) -> torch.Tensor:
+    g = _dev_f32(g, "interpolate_columns_backward(g)")
+    K, Cc = int(g.shape[-2]), int(g.shape[-1])
+    lead = tuple(g.shape[:-2])
+    n = int(np.prod(lead)) if lead else 1
+    gx = torch.empty(lead + (int(n_in), Cc), device=g.device, dtype=torch.float32)
+    with _on(g.device):
+        check(lib().trk_interpolate_columns_backward(g.data_ptr(), n, int(n_in), Cc, K, src.data_ptr(), w.data_ptr(),
+                                                     gx.data_ptr(), _stream(g)), "trk_interpolate_columns_backward")
+    return gx
 
 
 def reduce_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -999,8 +1118,9 @@ class RolloutPlan:
         self.device = q.device
 
     def launch(self, cost_sum_ptr: Optional[int] = None, stream: Optional[int] = None) -> None:
-        if stream is None:
-            stream = _stream_of(self.device)
-        rc = self._fn(*self._args, cost_sum_ptr, stream)
+        with _on(self.device):                  # free when the device is already current
+            if stream is None:
+                stream = _stream_of(self.device)
+            rc = self._fn(*self._args, cost_sum_ptr, stream)
         if rc:
             check(rc, "trk_rollout_cost_grad")

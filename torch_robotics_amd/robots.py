@@ -116,10 +116,13 @@ class RobotBase:
                     idxs.extend([(last_row + m, j * p + n) for m, n in itertools.product(range(n_grasped), range(p))])
                 margin_list.extend([self.self_collision_margin_grasped_object] * (len(idxs) - n_before))
             margins = torch.tensor(margin_list, dtype=torch.float32)
+            # more points than links: the pair rows above index INTERPOLATED points, so the field has to interpolate (the
+            # reference leaves the flag off and its pair rows would then index past the link tensor)
             self.df_collision_self = CollisionSelfField(
                 self, link_idxs_for_collision_checking=self.link_idxs_for_self_collision_checking,
                 idxs_links_distance_matrix=idxs,
                 num_interpolated_points=num_interpolated_points_for_self_collision_checking,
+                interpolate_link_pos=num_interpolated_points_for_self_collision_checking != n_self,
                 cutoff_margin=margins, tensor_args=self.tensor_args)
 
     def random_q(self, n_samples=10, generator=None):
@@ -183,7 +186,10 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
     margins.  Self-collision keeps using the link origins (their columns)."""
 
     def __init__(self, use_self_collision_storm=False, grasped_object=None, tensor_args=None, link_sphere_model=None,
-                 **kwargs):
+                 num_interpolated_points_for_object_collision_checking=None,
+                 num_interpolated_points_for_self_collision_checking=None, **kwargs):
+        # num_interpolated_points_for_*: the reference's RobotPanda fixes both to the number of links (robot_panda.py:117,121);
+        # RobotBase's layout for more points per link (robot_base.py:57-73, 103-108) is reachable here by passing them
         tensor_args = DEFAULT_TENSOR_ARGS if tensor_args is None else tensor_args
         if use_self_collision_storm:
             raise NotImplementedError("the STORM self-collision network needs storm_kit weights (out of scope)")
@@ -224,10 +230,12 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
             name="RobotPanda", q_limits=q_limits, grasped_object=grasped_object,
             link_names_for_object_collision_checking=obj_links, link_margins_for_object_collision_checking=obj_margins,
             link_idxs_for_object_collision_checking=obj_idxs, margin_for_grasped_object_collision_checking=0.001,
-            num_interpolated_points_for_object_collision_checking=len(obj_links),
+            num_interpolated_points_for_object_collision_checking=(num_interpolated_points_for_object_collision_checking
+                                                                   or len(obj_links)),
             link_names_for_self_collision_checking=self_links, link_names_pairs_for_self_collision_checking=pairs,
             link_idxs_for_self_collision_checking=self_idxs,
-            num_interpolated_points_for_self_collision_checking=len(self_links), self_collision_margin_robot=0.05,
+            num_interpolated_points_for_self_collision_checking=(num_interpolated_points_for_self_collision_checking
+                                                                 or len(self_links)), self_collision_margin_robot=0.05,
             link_names_for_self_collision_checking_with_grasped_object=with_grasped,
             self_collision_margin_grasped_object=0.05, tensor_args=tensor_args, **kwargs)
 

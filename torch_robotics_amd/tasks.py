@@ -23,7 +23,7 @@ class Task:
 
 class PlanningTask(Task):
     def __init__(self, ws_limits=None, use_occupancy_map=False, cell_size=0.01, obstacle_cutoff_margin=0.01,
-                 auto_specialize=True, clamp_sdf=False, **kwargs):
+                 auto_specialize=True, clamp_sdf=False, interpolate_link_pos=None, **kwargs):
         super().__init__(**kwargs)
         # the first fused evaluation compiles + loads a generated kernel for this robot / collision model when none is
         # registered yet (~2 s with hipcc, cached on disk); TRK_NO_JIT=1 or auto_specialize=False keeps the table-driven path
@@ -40,7 +40,14 @@ class PlanningTask(Task):
         # clamp_sdf (not a keyword of the reference's PlanningTask, which builds its fields with the default False): the three
         # fields become hinges relu(margin - sdf), the form an optimiser needs -- the plain cost decreases without bound
         self.clamp_sdf = bool(clamp_sdf)
+        # interpolate_link_pos (extension keyword; None = automatic): a robot declared with more collision points than links
+        # (robot_base.py:57-73 repeats its margins accordingly) needs fields that interpolate, distance_fields.py:145-147
+        if interpolate_link_pos is None:
+            interpolate_link_pos = (r.num_interpolated_points_for_object_collision_checking !=
+                                    len(r.link_idxs_for_object_collision_checking))
+        self.interpolate_link_pos = bool(interpolate_link_pos)
         common = dict(link_idxs_for_collision_checking=r.link_idxs_for_object_collision_checking, clamp_sdf=self.clamp_sdf,
+                      interpolate_link_pos=self.interpolate_link_pos,
                       num_interpolated_points=r.num_interpolated_points_for_object_collision_checking,
                       link_margins_for_object_collision_checking_tensor=r.link_margins_for_object_collision_checking_tensor,
                       cutoff_margin=obstacle_cutoff_margin, tensor_args=self.tensor_args)
@@ -127,7 +134,7 @@ class PlanningTask(Task):
     def build_cost_spec(self) -> CostModelSpec:
         r = self.robot
         spec = CostModelSpec(n_links_in=self._n_columns())
-        spec.obj_link_idx = self.df_collision_objects._columns(spec.n_links_in)
+        spec.obj_link_idx = self.df_collision_objects._columns(spec.n_links_in, spec)
         spec.obj_link_margin = self.df_collision_objects._margin_vector(len(spec.obj_link_idx))
         spec.objects, spec.grid = objects_to_spec_parts(self.env.get_df_obj_list())
         spec.ws_min, spec.ws_max = _np(self.ws_min).astype(np.float32), _np(self.ws_max).astype(np.float32)
@@ -152,9 +159,9 @@ class PlanningTask(Task):
                 self._fused = (None, ops.CostHandle(spec, device), key)
                 return self._fused[0], self._fused[1]
             self._fused = (self.robot.diff_panda._handle, ops.CostHandle(spec, device), key)
-            if self.auto_specialize and not self._jit_failed:
+            from . import jit
+            if self.auto_specialize and not self._jit_failed and jit.generatable(spec):
                 try:                                   # a unit whose template equals this cost model may already exist
-                    from . import jit
                     kin = self.robot.diff_panda._kin
                     if getattr(self.robot, "has_extra_points", False):
                         pl, po = self.robot.collision_point_set()
