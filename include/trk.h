@@ -445,6 +445,32 @@ int trk_rollout_points_cost_grad(const TrkModel* model, const TrkPointSet* ps, c
 int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, int32_t dim, int32_t n_interp,
                                const float* alpha, const float* beta, float* out, trk_stream_t stream);
 
+/* Trajectory validation in one pass over the via points: trk_interpolate_via_points + trk_rollout_collision without the
+ * interpolated trajectories ever reaching HBM.  x [n_traj, horizon, state_dim] (the first D columns of a way point are the joint
+ * positions, robot_base.py:148-149); sample (t, i, a) is x[t, i] * alpha[a] + x[t, i + 1] * beta[a], products and sum each rounded
+ * once (trajectory/utils.py:47-49) -> in_collision [n_traj * (horizon - 1) * n_interp].
+ * reference: PlanningTask.get_trajs_collision_and_free tasks.py:244-251 (margin_override = 0 there).
+ * Served by the generated kernels only: TRK_ERR_UNSUPPORTED when no unit matches the model / cost model -- the caller then
+ * runs the two-step form. */
+int trk_rollout_collision_via(const TrkModel* model, const TrkCostModel* cm, int32_t fields, const float* x, int64_t n_traj,
+                              int32_t horizon, int32_t state_dim, int32_t n_interp, const float* alpha, const float* beta,
+                              float margin_override, uint8_t* in_collision, trk_stream_t stream);
+
+/* The rest of get_trajs_collision_and_free (tasks.py:253-299) on the device: three launches, no host round trip.
+ *   flags [n_traj]      bit 0: some way-point byte of the trajectory is set (waypoint_collisions [n_traj, n_waypoints]);
+ *                       bit 1: some joint position x[t, h, d < n_dofs] lies outside [q_min[d], q_max[d]] (NaN = outside)
+ *   free_idx            trajectories with flags == 0, increasing                               (tasks.py:255, 274, 282)
+ *   coll_idx            those with bit 0, increasing, then those with flags == 2, increasing   (tasks.py:256, 278-281)
+ *                       rows are int64 [t] (inner == 0) or [t / inner, t % inner] (a 4-D batch [n_traj / inner, inner, ...]),
+ *                       like torch.argwhere; both buffers hold n_traj rows
+ *   counts [4]          {free, colliding, collision-free but outside the limits, 0}: the only thing the host must read
+ *   trajs_free / _coll  (nullable, both or neither) [n_traj, horizon, state_dim]: x gathered in the order of the two lists;
+ *                       only the first counts[0] / counts[1] + counts[2] rows are written. */
+int trk_traj_validate(const uint8_t* waypoint_collisions, const float* x, int64_t n_traj, int32_t horizon, int32_t state_dim,
+                      int32_t n_waypoints, int32_t n_dofs, const float* q_min, const float* q_max, int64_t inner,
+                      uint8_t* flags, int64_t* free_idx, int64_t* coll_idx, int32_t* counts, float* trajs_free,
+                      float* trajs_coll, trk_stream_t stream);
+
 /* reference: interpolate_points_v1 distance_fields.py:66-69 = F.interpolate(points^T, size=n_out, mode='linear',
  * align_corners=True)^T along the link axis (the link-sphere approximation of interpolate_link_pos, :145-147; also used by
  * robot_panda.py:199).  x [N, n_in, channels] -> out [N, n_out, channels],

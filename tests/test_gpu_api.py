@@ -189,12 +189,12 @@ def test_frame_algebra_vs_reference_golden():
     assert np.abs(tp.detach().cpu().numpy() - g["tp"]).max() < 2e-6
     gRa, gta = torch.autograd.grad((tp * wp).sum(), [leaf["Ra"], leaf["ta"]])
     assert np.abs(gRa.cpu().numpy() - g["tp_gRa"]).max() < 1e-5 and np.abs(gta.cpu().numpy() - g["tp_gta"]).max() < 1e-5
-    quat = fa.get_quaternion()                                  # XYZW like the reference, not WXYZ
+    quat = fa.get_quaternion().detach()                         # XYZW like the reference, not WXYZ (differentiable w.r.t. Ra)
     assert np.abs(quat.cpu().numpy() - g["quat_xyzw"]).max() < 1e-6
     np.testing.assert_array_equal(quat[-4:].cpu().numpy(), [[0, 0, 0, 1], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]])
-    wxyz = fa.get_quaternion_wxyz().cpu().numpy()
+    wxyz = fa.get_quaternion_wxyz().detach().cpu().numpy()
     assert np.abs(np.abs((wxyz[:, [1, 2, 3, 0]] * g["quat_xyzw"]).sum(1)) - 1).max() < 1e-5      # same rotation, other order
-    assert np.abs(torch.stack(fa.get_euler(), -1).cpu().numpy() - g["euler"]).max() < 2e-6
+    assert np.abs(torch.stack(fa.get_euler(), -1).detach().cpu().numpy() - g["euler"]).max() < 2e-6
     assert np.abs(fa.get_transform_matrix().detach().cpu().numpy() - g["H"]).max() == 0
 
 
@@ -927,3 +927,105 @@ def test_fields_with_interpolated_link_points_like_the_reference():
     assert grad_close(q2.grad.cpu().numpy(), g["gq_total"])
     coll = g["coll_self"] | g["coll_objects"] | g["coll_ws"]
     assert np.array_equal(task.compute_collision(q2.detach()).cpu().numpy(), coll)
+
+
+def _expected_partition(coll_any, outside, inner=0):
+    """What get_trajs_collision_and_free's bookkeeping (tasks.py:253-284) yields for given per-trajectory facts, stated directly:
+    free = collision free and inside the limits; the other list = colliding ones, then the collision-free limit violators --
+    except that it is ONLY the violators when nothing is free but something was collision free."""
+    t = np.arange(len(coll_any))
+    free = t[~coll_any & ~outside]
+    viol = t[~coll_any & outside]
+    coll = t[coll_any]
+    if len(free) + len(viol) == 0:
+        other = coll
+    elif len(free) == 0:
+        other = viol
+    else:
+        other = np.concatenate([coll, viol])
+    rows = (lambda a: np.stack([a // inner, a % inner], 1)) if inner else (lambda a: a.reshape(-1, 1))
+    return rows(free), rows(other)
+
+
+@pytest.mark.parametrize("case", ["mixed", "all_free", "none_free", "one_free", "only_violators", "ragged_big", "batched"])
+def test_device_side_trajectory_partition(case):
+    """ops.traj_validate (flags -> ordered index lists -> gathers, one host read) against the bookkeeping stated in numpy."""
+    from torch_robotics_amd import ops
+    rng = np.random.default_rng({"mixed": 1, "all_free": 2, "none_free": 3, "one_free": 4, "only_violators": 5, "ragged_big": 6, "batched": 7}[case])
+    T, H, S, W, D = {"ragged_big": (5003, 9, 10, 37, 7), "batched": (12, 6, 7, 10, 7)}.get(case, (70, 8, 7, 21, 7))
+    lo, hi = np.full(D, -1.0, np.float32), np.full(D, 1.0, np.float32)
+    x = rng.uniform(-0.99, 0.99, (T, H, S)).astype(np.float32)
+    p_c, p_o = {"mixed": (0.4, 0.3), "all_free": (0, 0), "none_free": (1.0, 0.2), "one_free": (0.6, 0.5), "only_violators": (0.5, 1.0),
+                "ragged_big": (0.3, 0.2), "batched": (0.4, 0.3)}[case]
+    coll_any, outside = rng.random(T) < p_c, rng.random(T) < p_o
+    if case == "one_free":
+        coll_any[:], outside[:] = True, False
+        coll_any[41] = False
+        outside[3] = True                       # a colliding trajectory outside the limits stays in the colliding group only
+    wp = np.zeros((T, W), np.uint8)
+    for t in np.flatnonzero(coll_any):
+        wp[t, rng.integers(0, W, rng.integers(1, 4))] = 1
+    for t in np.flatnonzero(outside):
+        h, d = rng.integers(0, H), rng.integers(0, D)
+        x[t, h, d] = [1.5, -1.5, np.nan][rng.integers(0, 3)]
+    if S > D:
+        x[:, :, D:] = 7.0                       # velocities beyond the limits' range are not positions: ignored
+    inner = 4 if case == "batched" else 0
+    part = ops.traj_validate(dev(wp).bool(), dev(x), D, dev(lo), dev(hi), inner=inner)
+    nf, nc, no = part.counts()
+    free_e, other_e = _expected_partition(coll_any, outside, inner)
+    assert (nf, nc, no) == (int((~coll_any & ~outside).sum()), int(coll_any.sum()), int((~coll_any & outside).sum()))
+    np.testing.assert_array_equal(part.flags.cpu().numpy(), coll_any.astype(np.uint8) | (outside.astype(np.uint8) << 1))
+    np.testing.assert_array_equal(part.free_idx[:nf].cpu().numpy(), free_e)
+    full = np.concatenate([np.flatnonzero(coll_any), np.flatnonzero(~coll_any & outside)])
+    got = part.coll_idx[:nc + no].cpu().numpy()
+    np.testing.assert_array_equal(got[:, 0] * inner + got[:, 1] if inner else got[:, 0], full)
+    np.testing.assert_array_equal(part.trajs_free[:nf].cpu().numpy(), x[~coll_any & ~outside])
+    np.testing.assert_array_equal(part.trajs_coll[:nc + no].cpu().numpy(), x[full])
+
+    # through PlanningTask: same lists, the reference's shapes (a single free trajectory gives a 1-D index row)
+    class _Task(tra.PlanningTask):
+        def _waypoint_collisions(self, flat, num_interpolation):
+            return dev(wp).bool()
+    robot = tra.RobotPanda(tensor_args=TA)
+    robot.q_min, robot.q_max = dev(lo), dev(hi)
+    task = _Task(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, tensor_args=TA)
+    trajs = dev(x).reshape((T // inner, inner, H, S)) if inner else dev(x)
+    tc, ci, tf, fi, w_out = task.get_trajs_collision_and_free(trajs, return_indices=True)
+    assert w_out.shape == tuple(trajs.shape[:-2]) + (W,)
+    np.testing.assert_array_equal(ci.cpu().numpy(), other_e)
+    if nf == 1 and not inner:
+        assert fi.shape == (1,) and int(fi[0]) == int(free_e[0, 0])
+    else:
+        np.testing.assert_array_equal(fi.cpu().numpy(), free_e)
+    flat_rows = (lambda a: a[:, 0] * inner + a[:, 1]) if inner else (lambda a: a[:, 0])
+    assert (tf is None) == (nf == 0) and (tc is None) == (len(other_e) == 0)
+    if tf is not None:
+        np.testing.assert_array_equal(tf.cpu().numpy(), x[flat_rows(free_e)])
+    if tc is not None:
+        np.testing.assert_array_equal(tc.cpu().numpy(), x[flat_rows(other_e)])
+
+
+def test_fused_via_point_collision_equals_two_step():
+    """trk_rollout_collision_via (interpolation inside the FK + boolean-field kernel) == trk_interpolate_via_points followed by
+    trk_rollout_collision, bit for bit, incl. a state with velocities, ragged sizes and a trajectory count that splits wavefronts."""
+    from torch_robotics_amd import ops
+    from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    model, cm = task._fused_handles(DEV)
+    fields = FIELD_OBJECTS | FIELD_WS | FIELD_SELF
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    for T, H, S, n in ((12, 16, 7, 5), (7, 2, 7, 1), (33, 64, 14, 5), (257, 5, 9, 3), (4, 3, 7, 70)):
+        x = torch.zeros(T, H, S, device=DEV)
+        x[..., :7] = robot.random_q(T * H, generator=gen).reshape(T, H, 7)
+        x[..., 7:] = 3.0
+        for margin in (0.0, None):
+            fused = ops.rollout_collision_via(model, cm, fields, x, n, margin=margin)
+            assert fused is not None and fused.shape == (T, (H - 1) * n)
+            two = ops.rollout_collision(model, cm, fields, ops.interpolate_traj_via_points(x, n)[..., :7].contiguous(), margin=margin)
+            assert torch.equal(fused, two), (T, H, S, n, margin)
+        assert 0 < int(fused.sum()) < fused.numel() or T < 8
+    model.enable_specialized(False)             # no generated kernel: the call declines and the task falls back to two steps
+    assert ops.rollout_collision_via(model, cm, fields, x, 3, margin=0.0) is None
+    model.enable_specialized(True)

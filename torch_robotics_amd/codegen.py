@@ -683,7 +683,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    float q[D];")
-        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        E.raw("    if (A.via_n > 0) spec_load_q_via<D>(A, base, rows, lane, q);     // trajectory validation: interpolate the via points here")
+        E.raw("    else spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
         R = {}; t = {}; passv = {}
         if base_identity:
             R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]

@@ -1105,6 +1105,64 @@ int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fie
     return TRK_OK;
 }
 
+int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t fields, const float* x, int64_t n_traj,
+                              int32_t horizon, int32_t state_dim, int32_t n_interp, const float* alpha, const float* beta,
+                              float margin_override, uint8_t* in_collision, trk_stream_t stream) {
+    int rc = check_model(m, "trk_rollout_collision_via");
+    if (rc) return rc;
+    if (!cm) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision_via: null cost model");
+    if (n_traj < 0 || horizon < 2 || n_interp < 1 || state_dim < m->hdr.n_dofs || (fields & ~7) || !fields || !alpha || !beta)
+        return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision_via: bad argument");
+    if (cm->hdr.n_links_in != m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision_via: cost model n_links_in != model n_links");
+    const int64_t hi = (int64_t)(horizon - 1) * n_interp;
+    if (hi > 0x7fffffff - 64) return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_collision_via: (horizon - 1) * n_interp too large");
+    const int64_t n = n_traj * hi;
+    if (n > 0 && (!x || !in_collision)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision_via: null x / in_collision");
+    if (n == 0) return TRK_OK;
+    if (!m->spec_enabled) return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_collision_via: generated kernels are disabled for this model");
+    const int use_default = std::isnan(margin_override) ? 1 : 0;
+    TrkRolloutWeights w{};
+    w.w_self = (fields & TRK_FIELD_SELF) ? 1.0f : 0.0f;
+    w.w_obj = (fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) ? 1.0f : 0.0f;
+    w.w_ws = (fields & TRK_FIELD_WS) ? 1.0f : 0.0f;
+    const SpecEntry* e = model_spec_for(m, cm, &w);
+    if (!e || !e->launch_coll)
+        return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_collision_via: no generated kernel serves this model / cost model "
+                                         "(use trk_interpolate_via_points + trk_rollout_collision)");
+    SpecArgs a{};
+    a.C = cm->hdr; a.w = w;
+    std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+    std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+    a.q = x; a.n = n;
+    a.coll_out = in_collision; a.coll_fields = fields; a.coll_use_default = use_default;
+    a.coll_margin = use_default ? 0.0f : margin_override;
+    a.via_alpha = alpha; a.via_beta = beta; a.via_n = n_interp; a.via_H = horizon; a.via_S = state_dim;
+    e->launch_coll(a, base_is_identity(m), (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
+int trk_traj_validate(const uint8_t* waypoint_collisions, const float* x, int64_t n_traj, int32_t horizon, int32_t state_dim,
+                      int32_t n_waypoints, int32_t n_dofs, const float* q_min, const float* q_max, int64_t inner,
+                      uint8_t* flags, int64_t* free_idx, int64_t* coll_idx, int32_t* counts, float* trajs_free, float* trajs_coll,
+                      trk_stream_t stream) {
+    if (n_traj < 0 || n_traj > 0x3fffffff || horizon < 1 || state_dim < 1 || n_waypoints < 0 || n_dofs < 0 || n_dofs > state_dim || inner < 0 ||
+        !counts || (n_dofs > 0 && (!q_min || !q_max)) || (!trajs_free != !trajs_coll) ||
+        (n_traj > 0 && (!x || !flags || !free_idx || !coll_idx || (n_waypoints > 0 && !waypoint_collisions))))
+        return fail(TRK_ERR_INVALID_ARG, "trk_traj_validate: bad argument");
+    if (inner > 0 && n_traj % inner) return fail(TRK_ERR_INVALID_ARG, "trk_traj_validate: n_traj is not a multiple of the inner batch");
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (n_traj == 0) {
+        TRK_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), (hipStream_t)stream));
+        return TRK_OK;
+    }
+    trk_launch_traj_validate(waypoint_collisions, x, n_traj, horizon, state_dim, n_waypoints, n_dofs, q_min, q_max, inner, flags,
+                             free_idx, coll_idx, counts, trajs_free, trajs_coll, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
 int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const float* q,
                           int64_t batch, int32_t horizon, float* link_pos_out, float* cost, float* gq, float* cost_sum,
                           trk_stream_t stream) {

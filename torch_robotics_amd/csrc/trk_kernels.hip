@@ -1531,6 +1531,103 @@ k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, i
     }
 }
 
+// ============================================================================================
+// Trajectory validation, device side (PlanningTask.get_trajs_collision_and_free tasks.py:253-308): the per-way-point collision
+// bytes are folded into per-trajectory flags, the trajectories are partitioned in the reference's order, and the two groups are
+// gathered -- all queued back to back; the host reads three counters once.
+// ============================================================================================
+// one wavefront per trajectory: bit 0 = some interpolated way point is in collision (tasks.py:255-256), bit 1 = some joint
+// position of the ORIGINAL way points lies outside [q_min, q_max] (tasks.py:270-273; a NaN counts as outside, as in torch)
+__global__ void __launch_bounds__(256)
+k_traj_flags(const uint8_t* __restrict__ wp, int Hi, const float* __restrict__ x, int H, int S, int D,
+             const float* __restrict__ qmin, const float* __restrict__ qmax, int64_t T, uint8_t* __restrict__ flags) {
+    const int lane = threadIdx.x & (TRK_WAVE - 1);
+    const int64_t t = (int64_t)blockIdx.x * (blockDim.x / TRK_WAVE) + threadIdx.x / TRK_WAVE;
+    if (t >= T) return;
+    bool coll = false, outside = false;
+    const uint8_t* w = wp + t * Hi;
+    for (int k = lane; k < Hi; k += TRK_WAVE) coll |= w[k] != 0;
+    const float* xt = x + t * (int64_t)H * S;
+    for (int k = lane; k < H * D; k += TRK_WAVE) {
+        const int h = k / D, d = k - h * D;
+        const float v = xt[h * S + d];
+        outside |= !(v >= qmin[d] && v <= qmax[d]);
+    }
+    const bool any_c = __ballot(coll) != 0, any_o = __ballot(outside) != 0;
+    if (lane == 0) flags[t] = (any_c ? 1 : 0) | (any_o ? 2 : 0);
+}
+
+// One workgroup walks the flags twice (count, then place) and writes, in increasing trajectory order,
+//   free_idx: trajectories that are collision free AND inside the joint limits          (tasks.py:274, 282)
+//   coll_idx: the colliding ones, then the collision-free ones outside the limits        (tasks.py:256, 278-281)
+// as int64 rows [t] (inner == 0) or [t / inner, t % inner] (a 4-D batch), like torch.argwhere; counts = {free, colliding, outside}.
+__global__ void __launch_bounds__(1024)
+k_traj_partition(const uint8_t* __restrict__ flags, int64_t T, int64_t inner, int64_t* __restrict__ free_idx,
+                 int64_t* __restrict__ coll_idx, int32_t* __restrict__ counts) {
+    __shared__ int wsum[3][16];
+    __shared__ int run[3];
+    __shared__ int n_coll_total;
+    const int tid = threadIdx.x, lane = tid & (TRK_WAVE - 1), wave = tid / TRK_WAVE;
+    int c = 0;
+    for (int64_t t = tid; t < T; t += 1024) c += flags[t] & 1;
+    for (int o = TRK_WAVE / 2; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) wsum[0][wave] = c;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int k = 0; k < 16; ++k) tot += wsum[0][k];
+        n_coll_total = tot; run[0] = 0; run[1] = 0; run[2] = 0;
+    }
+    __syncthreads();
+    const int cols = inner > 0 ? 2 : 1;
+    for (int64_t t0 = 0; t0 < T; t0 += 1024) {
+        const int64_t t = t0 + tid;
+        const int f = t < T ? flags[t] : 1;
+        const bool is[3] = {t < T && f == 0, t < T && (f & 1) != 0, t < T && f == 2};       // free, colliding, outside only
+        int rank[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long m = __ballot(is[k]);
+            rank[k] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[k][wave] = __popcll(m);
+        }
+        __syncthreads();
+        int off[3] = {run[0], run[1], run[2]};
+        for (int w2 = 0; w2 < wave; ++w2) { off[0] += wsum[0][w2]; off[1] += wsum[1][w2]; off[2] += wsum[2][w2]; }
+        int64_t* dst = nullptr;
+        if (is[0]) dst = free_idx + (int64_t)(off[0] + rank[0]) * cols;
+        else if (is[1]) dst = coll_idx + (int64_t)(off[1] + rank[1]) * cols;
+        else if (is[2]) dst = coll_idx + (int64_t)(n_coll_total + off[2] + rank[2]) * cols;
+        if (dst) {
+            if (inner > 0) { dst[0] = t / inner; dst[1] = t % inner; }
+            else dst[0] = t;
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int k = 0; k < 3; ++k) { int tot = 0; for (int w2 = 0; w2 < 16; ++w2) tot += wsum[k][w2]; run[k] += tot; }
+        __syncthreads();
+    }
+    if (tid == 0) { counts[0] = run[0]; counts[1] = run[1]; counts[2] = run[2]; counts[3] = 0; }
+}
+
+// rows [0, T): trajs_free[r] = x[free_idx[r]] for r < counts[0]; rows [T, 2T): trajs_coll[r - T] = x[coll_idx[r - T]] for
+// r - T < counts[1] + counts[2].  One workgroup per output row; the rest exit at once.
+__global__ void __launch_bounds__(256)
+k_traj_gather(const float* __restrict__ x, int64_t T, int row, int cols, const int64_t* __restrict__ free_idx,
+              const int64_t* __restrict__ coll_idx, int64_t inner, const int32_t* __restrict__ counts,
+              float* __restrict__ out_free, float* __restrict__ out_coll) {
+    int64_t r = blockIdx.x;
+    const bool second = r >= T;
+    if (second) r -= T;
+    const int n = second ? counts[1] + counts[2] : counts[0];
+    if (r >= n) return;
+    const int64_t* ix = (second ? coll_idx : free_idx) + r * cols;
+    const int64_t t = inner > 0 ? ix[0] * inner + ix[1] : ix[0];
+    const float* src = x + t * row;
+    float* dst = (second ? out_coll : out_free) + r * row;
+    for (int k = threadIdx.x; k < row; k += blockDim.x) dst[k] = src[k];
+}
+
 // interpolate_points_v1 distance_fields.py:66-69 (F.interpolate linear, align_corners=True, along the link axis) with the index /
 // weight table unrolled on the host: x [N, L, C] -> out [N, K, C], out[n, k] = w[2k] x[n, src[2k]] + w[2k+1] x[n, src[2k+1]].
 // One thread per output element: consecutive threads write consecutive floats.
@@ -1886,6 +1983,16 @@ void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_inter
     }
     const int64_t total = T * (int64_t)(H - 1) * n_interp * D;
     hipLaunchKernelGGL(k_interpolate_via_points_flat, dim3(grid_for(total, 256)), dim3(256), 0, st, x, T, H, D, n_interp, alpha, beta, out);
+}
+
+void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int H, int S, int Hi, int D, const float* qmin,
+                              const float* qmax, int64_t inner, uint8_t* flags, int64_t* free_idx, int64_t* coll_idx,
+                              int32_t* counts, float* trajs_free, float* trajs_coll, hipStream_t st) {
+    hipLaunchKernelGGL(k_traj_flags, dim3(grid_for(T, 4)), dim3(256), 0, st, wp, Hi, x, H, S, D, qmin, qmax, T, flags);
+    hipLaunchKernelGGL(k_traj_partition, dim3(1), dim3(1024), 0, st, flags, T, inner, free_idx, coll_idx, counts);
+    if (trajs_free && trajs_coll)
+        hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)(2 * T)), dim3(256), 0, st, x, T, H * S, inner > 0 ? 2 : 1, free_idx, coll_idx,
+                           inner, counts, trajs_free, trajs_coll);
 }
 
 void trk_launch_interpolate_columns(const float* x, int64_t n, int L, int C, int K, const int32_t* src, const float* w, float* out,

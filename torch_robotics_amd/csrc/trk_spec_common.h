@@ -47,6 +47,13 @@ struct SpecArgs {
     // all-links FK kernel (trk_fk_forward with every link selected, launch_fkh): H [N, L, 4, 4] out;
     // its reverse mode (launch_fkhbwd): the adjoint gH [N, L, 4, 4] in (read only), gq out
     float* fk_H;
+    // via-point mode of the boolean kernel (trk_rollout_collision_via; get_trajs_collision_and_free tasks.py:244-251): q is then a
+    // batch of trajectories x [T, via_H, via_S] whose first D columns are joint positions, and sample n = (t, i, a) is the
+    // configuration x[t, i] * via_alpha[a] + x[t, i + 1] * via_beta[a] (interpolate_traj_via_points trajectory/utils.py:37-50)
+    const float* via_alpha; const float* via_beta;   // DEVICE [via_n]
+    int32_t via_n;                // interpolated points per segment; 0 = q holds the configurations themselves
+    int32_t via_H, via_S;         // way points per trajectory, floats per way point (>= D)
+    int32_t _pad_via;
 };
 
 typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
@@ -73,7 +80,7 @@ typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 14)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 15)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -258,6 +265,23 @@ __device__ __forceinline__ void spec_load_q(const IO* __restrict__ q, int64_t ba
 #pragma unroll
     for (int j = 0; j < D; ++j) qv[j] = lds[lane * D + j];
     spec_wave_sync();
+}
+
+// q of sample (t, i, a) of the via-point mode: x[t, i, :D] * alpha[a] + x[t, i + 1, :D] * beta[a], each product and the sum rounded
+// once like the reference's `a * alpha + b * (1 - alpha)` (trajectory/utils.py:47-49).  Neighbouring lanes read the same or
+// adjacent way points, so the 2 D dword loads per lane are served by a few cache lines per wavefront.
+template <int D>
+__device__ __forceinline__ void spec_load_q_via(const SpecArgs& A, int64_t base, int rows, int lane, float (&qv)[D]) {
+    const unsigned hi = (unsigned)(A.via_H - 1) * (unsigned)A.via_n;          // interpolated configurations per trajectory
+    const int64_t t0 = base / hi;                                             // wave-uniform: one 64-bit division per wavefront
+    const unsigned r = (unsigned)(base - t0 * hi) + (unsigned)lane;
+    const unsigned dt = r / hi, rr = r - dt * hi;
+    const unsigned i = rr / (unsigned)A.via_n, a = rr - i * (unsigned)A.via_n;
+    const bool on = lane < rows;
+    const float* p0 = static_cast<const float*>(A.q) + ((t0 + dt) * A.via_H + i) * (int64_t)A.via_S;
+    const float fa = on ? A.via_alpha[a] : 0.0f, fb = on ? A.via_beta[a] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) qv[j] = on ? __fadd_rn(__fmul_rn(p0[j], fa), __fmul_rn(p0[A.via_S + j], fb)) : 0.0f;
 }
 
 // spec_load_q in two halves: `issue` starts the wave's 16-byte loads (held in registers, nothing waits), `finish` runs the LDS

@@ -879,9 +879,7 @@ def interpolate_traj_via_points(trajs: torch.Tensor, num_interpolation: int = 10
     H, D = x.shape[-2:]
     lead = x.shape[:-2]
     T = int(np.prod(lead)) if len(lead) else 1
-    alpha = torch.linspace(0, 1, num_interpolation + 2, dtype=torch.float32)[1:num_interpolation + 1]
-    beta = 1 - alpha
-    alpha, beta = alpha.to(x.device), beta.to(x.device)
+    alpha, beta = via_point_weights(num_interpolation, x.device)
     out = torch.empty(tuple(lead) + ((H - 1) * num_interpolation, D), device=x.device, dtype=torch.float32)
     with _on(x.device):
         check(lib().trk_interpolate_via_points(x.data_ptr(), T, H, D, int(num_interpolation), alpha.data_ptr(),
@@ -917,6 +915,79 @@ def interpolate_columns_backward(g: torch.Tensor, src: torch.Tensor, w: torch.Te
         check(lib().trk_interpolate_columns_backward(g.data_ptr(), n, int(n_in), Cc, K, src.data_ptr(), w.data_ptr(),
                                                      gx.data_ptr(), _stream(g)), "trk_interpolate_columns_backward")
     return gx
+
+
+_via_weights: dict = {}
+
+
+def via_point_weights(num_interpolation: int, device) -> tuple:
+    """(alpha, beta) of interpolate_traj_via_points (trajectory/utils.py:43-44) on `device`, cached per (n, device)."""
+    key = (int(num_interpolation), str(device))
+    ab = _via_weights.get(key)
+    if ab is None:
+        alpha = torch.linspace(0, 1, key[0] + 2, dtype=torch.float32)[1:key[0] + 1]
+        ab = _via_weights[key] = (alpha.to(device), (1 - alpha).to(device))
+    return ab
+
+
+def rollout_collision_via(model: ModelHandle, cm: CostHandle, fields: int, trajs: torch.Tensor, num_interpolation: int,
+                          margin: Optional[float] = None) -> Optional[torch.Tensor]:
+    """Boolean collision fields on the interpolated via points of trajs (T, H, S >= D) without materialising them:
+    -> bool (T, (H-1) * num_interpolation), or None when no generated kernel serves this model / cost model (the caller then
+    interpolates first).  tasks.py:244-251."""
+    x = _dev_f32(trajs, "rollout_collision_via(trajs)")
+    T, H, S = (int(v) for v in x.shape)
+    if S < model.n_dofs:
+        raise ValueError(f"rollout_collision_via: way points have {S} columns, the model has {model.n_dofs} DOF")
+    n = int(num_interpolation)
+    alpha, beta = via_point_weights(n, x.device)
+    out = torch.empty((T, (H - 1) * n), device=x.device, dtype=torch.bool)
+    with _on(x.device):
+        rc = lib().trk_rollout_collision_via(model._h, cm._h, int(fields), x.data_ptr(), T, H, S, n, alpha.data_ptr(), beta.data_ptr(),
+                                             float("nan") if margin is None else float(margin), out.data_ptr(), _stream(x))
+    if rc == _abi.TRK_ERR_UNSUPPORTED:
+        return None
+    check(rc, "trk_rollout_collision_via")
+    return out
+
+
+class TrajPartition:
+    """Result buffers of `traj_validate` (device side of get_trajs_collision_and_free): read `counts()` once, then slice."""
+    __slots__ = ("flags", "free_idx", "coll_idx", "_counts", "trajs_free", "trajs_coll", "_host")
+
+    def counts(self):
+        """(n_free, n_colliding, n_outside_limits): the single device -> host read of a validation."""
+        if self._host is None:
+            self._host = tuple(int(v) for v in self._counts.tolist()[:3])
+        return self._host
+
+
+def traj_validate(waypoint_collisions: torch.Tensor, trajs: torch.Tensor, n_dofs: int, q_min: torch.Tensor, q_max: torch.Tensor,
+                  inner: int = 0, gather: bool = True) -> TrajPartition:
+    """Per-trajectory flags, ordered free / colliding index lists and the two gathered groups (tasks.py:253-299), queued as
+    three launches with no host synchronisation.  waypoint_collisions (T, W) bool / uint8; trajs (T, H, S) float32."""
+    x = _dev_f32(trajs, "traj_validate(trajs)")
+    T, H, S = (int(v) for v in x.shape)
+    wp = waypoint_collisions
+    if wp.device != x.device or wp.element_size() != 1 or not wp.is_contiguous() or wp.numel() % max(T, 1):
+        raise ValueError("traj_validate: waypoint_collisions must be a contiguous 1-byte tensor (T, W) on the trajectories' device")
+    W = wp.numel() // max(T, 1)
+    _check_buffer(q_min, int(n_dofs), torch.float32, x.device, "traj_validate(q_min)")
+    _check_buffer(q_max, int(n_dofs), torch.float32, x.device, "traj_validate(q_max)")
+    cols = 2 if inner else 1
+    r = TrajPartition()
+    r._host = None
+    r.flags = torch.empty((T,), device=x.device, dtype=torch.uint8)
+    r.free_idx = torch.empty((T, cols), device=x.device, dtype=torch.int64)
+    r.coll_idx = torch.empty((T, cols), device=x.device, dtype=torch.int64)
+    r._counts = torch.empty((4,), device=x.device, dtype=torch.int32)
+    r.trajs_free = torch.empty((T, H, S), device=x.device, dtype=torch.float32) if gather else None
+    r.trajs_coll = torch.empty((T, H, S), device=x.device, dtype=torch.float32) if gather else None
+    with _on(x.device):
+        check(lib().trk_traj_validate(wp.data_ptr(), x.data_ptr(), T, H, S, W, int(n_dofs), q_min.data_ptr(), q_max.data_ptr(),
+                                      int(inner), r.flags.data_ptr(), r.free_idx.data_ptr(), r.coll_idx.data_ptr(),
+                                      r._counts.data_ptr(), _ptr(r.trajs_free), _ptr(r.trajs_coll), _stream(x)), "trk_traj_validate")
+    return r
 
 
 def reduce_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -249,64 +249,50 @@ class PlanningTask(Task):
         return cost
 
     # ---------------------------------------------------------------------------------------------
-    # trajectory validation (tasks.py:234-328): same index bookkeeping as the reference; the arithmetic
-    # (via-point interpolation, FK, boolean collision fields) runs in the HIP kernels
+    # trajectory validation (tasks.py:234-328): everything up to the final slicing runs on the device -- via-point
+    # interpolation fused into the FK + boolean-field kernel, then per-trajectory flags, the ordered index lists and the two
+    # gathers (ops.traj_validate) -- and the host reads three counters once.  Return values and shapes are the reference's.
     # ---------------------------------------------------------------------------------------------
+    def _waypoint_collisions(self, flat, num_interpolation):
+        """bool (T, W) for trajectories flat (T, H, S): margin 0 on the interpolated via points (tasks.py:244-251)."""
+        if self._has_tree and self._points(flat.device) is None and num_interpolation > 0 and flat.shape[1] >= 2:
+            model, cm = self._fused_handles(flat.device)
+            fields = FIELD_OBJECTS | FIELD_WS | (FIELD_SELF if self.df_collision_self is not None else 0)
+            wp = ops.rollout_collision_via(model, cm, fields, flat, num_interpolation, margin=0.)
+            if wp is not None:
+                return wp
+        return self.compute_collision(ops.interpolate_traj_via_points(flat, num_interpolation=num_interpolation), margin=0.)
+
     def get_trajs_collision_and_free(self, trajs, return_indices=False, num_interpolation=5):
         assert trajs.ndim == 3 or trajs.ndim == 4
-        N = 1
-        if trajs.ndim == 4:
-            N, B, H, D = trajs.shape
-            trajs_new = trajs.reshape(N * B, H, D)
+        batched = trajs.ndim == 4                       # (goals or steps, batch, horizon, state)
+        lead = tuple(trajs.shape[:-2])
+        H, S = int(trajs.shape[-2]), int(trajs.shape[-1])
+        flat = trajs.detach().reshape(-1, H, S).to(torch.float32).contiguous()
+        wp = self._waypoint_collisions(flat, num_interpolation)
+        dev = flat.device
+        part = ops.traj_validate(wp, flat, self.robot.q_dim, self.robot.q_min.to(dev, torch.float32).contiguous(),
+                                 self.robot.q_max.to(dev, torch.float32).contiguous(), inner=lead[1] if batched else 0)
+        n_free, n_coll, n_out = part.counts()                                   # the one host synchronisation
+        free_idxs = part.free_idx[:n_free]
+        if n_free + n_out == 0:                          # no collision-free trajectory: the limits are not looked at (tasks.py:264-265)
+            coll_idxs = part.coll_idx[:n_coll]
+        elif n_free == 0:                                # tasks.py:275-276: the list is REPLACED by the limit violators
+            coll_idxs = part.coll_idx[n_coll:n_coll + n_out]
         else:
-            B, H, D = trajs.shape
-            trajs_new = trajs
-        trajs_interpolated = ops.interpolate_traj_via_points(trajs_new, num_interpolation=num_interpolation)
-        # margin 0: interpolated via points may pass very close to objects without being in collision (tasks.py:247-251)
-        trajs_waypoints_collisions = self.compute_collision(trajs_interpolated, margin=0.)
-        if trajs.ndim == 4:
-            trajs_waypoints_collisions = trajs_waypoints_collisions.reshape(N, B, -1)
-        trajs_free_idxs = torch.argwhere(torch.logical_not(trajs_waypoints_collisions).all(dim=-1))
-        trajs_coll_idxs = torch.argwhere(trajs_waypoints_collisions.any(dim=-1))
-        # trajectories that are collision free must also respect the joint limits (tasks.py:262-284)
-        if trajs_free_idxs.nelement() != 0:
-            if trajs.ndim == 4:
-                trajs_free_tmp = trajs[trajs_free_idxs[:, 0], trajs_free_idxs[:, 1], ...]
-            else:
-                trajs_free_tmp = trajs[trajs_free_idxs.squeeze(), ...]
-            pos = self.robot.get_position(trajs_free_tmp)
-            q_min, q_max = self.robot.q_min.to(pos.device), self.robot.q_max.to(pos.device)
-            inside = torch.logical_and(pos >= q_min, pos <= q_max).all(dim=-1).all(dim=-1)
-            inside = torch.atleast_1d(inside)
-            trajs_free_idxs_try = trajs_free_idxs[torch.argwhere(inside).squeeze()]
-            if trajs_free_idxs_try.nelement() == 0:
-                trajs_coll_idxs = trajs_free_idxs.clone()
-            else:
-                extra = trajs_free_idxs[torch.argwhere(torch.logical_not(inside)).squeeze()]
-                if extra.ndim == 1:
-                    extra = extra[..., None]
-                trajs_coll_idxs = torch.cat((trajs_coll_idxs, extra))
-            trajs_free_idxs = trajs_free_idxs_try
-        if trajs.ndim == 4:
-            trajs_free = trajs[trajs_free_idxs[:, 0], trajs_free_idxs[:, 1], ...]
-            if trajs_free.ndim == 2:
-                trajs_free = trajs_free.unsqueeze(0).unsqueeze(0)
-            trajs_coll = trajs[trajs_coll_idxs[:, 0], trajs_coll_idxs[:, 1], ...]
-            if trajs_coll.ndim == 2:
-                trajs_coll = trajs_coll.unsqueeze(0).unsqueeze(0)
-        else:
-            trajs_free = trajs[trajs_free_idxs.squeeze(), ...]
-            if trajs_free.ndim == 2:
-                trajs_free = trajs_free.unsqueeze(0)
-            trajs_coll = trajs[trajs_coll_idxs.squeeze(), ...]
-            if trajs_coll.ndim == 2:
-                trajs_coll = trajs_coll.unsqueeze(0)
-        if trajs_coll.nelement() == 0:
+            coll_idxs = part.coll_idx[:n_coll + n_out]
+        if n_free == 1 and not batched:                  # argwhere(...).squeeze() of one hit indexes out a 1-D row (tasks.py:274)
+            free_idxs = free_idxs.reshape(-1)
+        n_coll_rows = int(coll_idxs.shape[0])
+        trajs_free = part.trajs_free[:n_free] if n_free else None
+        if n_coll_rows == 0:
             trajs_coll = None
-        if trajs_free.nelement() == 0:
-            trajs_free = None
+        elif n_free == 0 and n_out:                      # the replaced list starts behind the colliding rows of the gather
+            trajs_coll = part.trajs_coll[n_coll:n_coll + n_out]
+        else:
+            trajs_coll = part.trajs_coll[:n_coll_rows]
         if return_indices:
-            return trajs_coll, trajs_coll_idxs, trajs_free, trajs_free_idxs, trajs_waypoints_collisions
+            return trajs_coll, coll_idxs, trajs_free, free_idxs, wp.reshape(lead + (-1,))
         return trajs_coll, trajs_free
 
     def compute_fraction_free_trajs(self, trajs, **kwargs):
