@@ -459,17 +459,21 @@ int trk_rollout_collision_via(const TrkModel* model, const TrkCostModel* cm, int
 /* The rest of get_trajs_collision_and_free (tasks.py:253-299) on the device: three launches, no host round trip.
  *   flags [n_traj]      bit 0: some way-point byte of the trajectory is set (waypoint_collisions [n_traj, n_waypoints]);
  *                       bit 1: some joint position x[t, h, d < n_dofs] lies outside [q_min[d], q_max[d]] (NaN = outside)
- *   free_idx            trajectories with flags == 0, increasing                               (tasks.py:255, 274, 282)
- *   coll_idx            those with bit 0, increasing, then those with flags == 2, increasing   (tasks.py:256, 278-281)
- *                       rows are int64 [t] (inner == 0) or [t / inner, t % inner] (a 4-D batch [n_traj / inner, inner, ...]),
- *                       like torch.argwhere; both buffers hold n_traj rows
- *   counts [4]          {free, colliding, collision-free but outside the limits, 0}: the only thing the host must read
- *   trajs_free / _coll  (nullable, both or neither) [n_traj, horizon, state_dim]: x gathered in the order of the two lists;
- *                       only the first counts[0] / counts[1] + counts[2] rows are written. */
+ *   idx [n_traj rows]   a stable three-way partition of the trajectories, each group in increasing order:
+ *                         rows [0, n_free)              flags == 0: collision free and inside the limits (tasks.py:255, 274, 282)
+ *                         rows [n_free, +n_coll)        bit 0 set: colliding                             (tasks.py:256)
+ *                         rows [.., +n_out)             flags == 2: collision free, outside the limits   (tasks.py:278-281)
+ *                       int64 rows [t] (inner == 0) or [t / inner, t % inner] (a 4-D batch [n_traj / inner, inner, ...]),
+ *                       like torch.argwhere.  The reference's `trajs_coll_idxs` is the last two groups together.
+ *   counts [4]          DEVICE {n_free, n_coll, n_out, ticket}.  counts_host (nullable): PINNED HOST int32[4] that receives the
+ *                       same numbers straight from the kernel (device-addressable under unified addressing), the ticket last
+ *                       with system-scope release semantics: the host polls counts_host[3] for the `ticket` it passed -- no
+ *                       copy call, no event -- and that is the only device -> host traffic of a validation.
+ *   gathered (nullable) [n_traj, horizon, state_dim]: gathered[r] = x[idx[r]] (free trajectories first, then the others). */
 int trk_traj_validate(const uint8_t* waypoint_collisions, const float* x, int64_t n_traj, int32_t horizon, int32_t state_dim,
                       int32_t n_waypoints, int32_t n_dofs, const float* q_min, const float* q_max, int64_t inner,
-                      uint8_t* flags, int64_t* free_idx, int64_t* coll_idx, int32_t* counts, float* trajs_free,
-                      float* trajs_coll, trk_stream_t stream);
+                      uint8_t* flags, int64_t* idx, int32_t* counts, int32_t* counts_host, int32_t ticket, float* gathered,
+                      trk_stream_t stream);
 
 /* reference: interpolate_points_v1 distance_fields.py:66-69 = F.interpolate(points^T, size=n_out, mode='linear',
  * align_corners=True)^T along the link axis (the link-sphere approximation of interpolate_link_pos, :145-147; also used by

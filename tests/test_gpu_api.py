@@ -976,12 +976,13 @@ def test_device_side_trajectory_partition(case):
     free_e, other_e = _expected_partition(coll_any, outside, inner)
     assert (nf, nc, no) == (int((~coll_any & ~outside).sum()), int(coll_any.sum()), int((~coll_any & outside).sum()))
     np.testing.assert_array_equal(part.flags.cpu().numpy(), coll_any.astype(np.uint8) | (outside.astype(np.uint8) << 1))
-    np.testing.assert_array_equal(part.free_idx[:nf].cpu().numpy(), free_e)
+    np.testing.assert_array_equal(part.idx[:nf].cpu().numpy(), free_e)
     full = np.concatenate([np.flatnonzero(coll_any), np.flatnonzero(~coll_any & outside)])
-    got = part.coll_idx[:nc + no].cpu().numpy()
+    got = part.idx[nf:nf + nc + no].cpu().numpy()
     np.testing.assert_array_equal(got[:, 0] * inner + got[:, 1] if inner else got[:, 0], full)
-    np.testing.assert_array_equal(part.trajs_free[:nf].cpu().numpy(), x[~coll_any & ~outside])
-    np.testing.assert_array_equal(part.trajs_coll[:nc + no].cpu().numpy(), x[full])
+    np.testing.assert_array_equal(part.gathered[:nf].cpu().numpy(), x[~coll_any & ~outside])
+    np.testing.assert_array_equal(part.gathered[nf:nf + nc + no].cpu().numpy(), x[full])
+    assert nf + nc + no == T
 
     # through PlanningTask: same lists, the reference's shapes (a single free trajectory gives a 1-D index row)
     class _Task(tra.PlanningTask):

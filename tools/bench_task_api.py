@@ -26,3 +26,12 @@ t("task.compute_collision(q)", lambda: task.compute_collision(q))
 t("robot.fk_map_collision(q)", lambda: robot.fk_map_collision(q))
 t("robot.get_EE_pose(q)", lambda: robot.get_EE_pose(q.reshape(-1, 7)))
 t("tree.compute_forward_kinematics_all_links(q)", lambda: robot.diff_panda.compute_forward_kinematics_all_links(q.reshape(-1, 7)))
+t("task.get_trajs_collision_and_free(4096 x 64, 5 via points)", lambda: task.get_trajs_collision_and_free(q, num_interpolation=5), n=100)
+from torch_robotics_amd import ops
+from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+m_, cm_ = task._fused_handles(dev)
+t("  ops.rollout_collision_via (fused interpolation + FK + boolean fields)", lambda: ops.rollout_collision_via(m_, cm_, FIELD_OBJECTS | FIELD_WS | FIELD_SELF, q, 5, margin=0.0), n=100)
+wp_ = ops.rollout_collision_via(m_, cm_, FIELD_OBJECTS | FIELD_WS | FIELD_SELF, q, 5, margin=0.0)
+qmin_, qmax_ = robot.q_min.to(dev).contiguous(), robot.q_max.to(dev).contiguous()
+t("  ops.traj_validate, no host read (flags + partition + gathers)", lambda: ops.traj_validate(wp_, q, 7, qmin_, qmax_), n=100)
+t("  ops.traj_validate + counts() (the one host read)", lambda: ops.traj_validate(wp_, q, 7, qmin_, qmax_).counts(), n=100)

@@ -112,7 +112,7 @@ def lib():
     L.trk_interpolate_columns.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
     L.trk_interpolate_columns_backward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
     L.trk_rollout_collision_via.argtypes = [vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, f32, vp, vp]
-    L.trk_traj_validate.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.trk_traj_validate.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp, vp]
     L.trk_point_set_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
     L.trk_point_set_destroy.argtypes = [vp]
     L.trk_point_set_destroy.restype = None

@@ -1144,21 +1144,23 @@ int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t
 
 int trk_traj_validate(const uint8_t* waypoint_collisions, const float* x, int64_t n_traj, int32_t horizon, int32_t state_dim,
                       int32_t n_waypoints, int32_t n_dofs, const float* q_min, const float* q_max, int64_t inner,
-                      uint8_t* flags, int64_t* free_idx, int64_t* coll_idx, int32_t* counts, float* trajs_free, float* trajs_coll,
+                      uint8_t* flags, int64_t* idx, int32_t* counts, int32_t* counts_host, int32_t ticket, float* gathered,
                       trk_stream_t stream) {
     if (n_traj < 0 || n_traj > 0x3fffffff || horizon < 1 || state_dim < 1 || n_waypoints < 0 || n_dofs < 0 || n_dofs > state_dim || inner < 0 ||
-        !counts || (n_dofs > 0 && (!q_min || !q_max)) || (!trajs_free != !trajs_coll) ||
-        (n_traj > 0 && (!x || !flags || !free_idx || !coll_idx || (n_waypoints > 0 && !waypoint_collisions))))
+        !counts || (n_dofs > 0 && (!q_min || !q_max)) ||
+        (n_traj > 0 && (!x || !flags || !idx || (n_waypoints > 0 && !waypoint_collisions))))
         return fail(TRK_ERR_INVALID_ARG, "trk_traj_validate: bad argument");
     if (inner > 0 && n_traj % inner) return fail(TRK_ERR_INVALID_ARG, "trk_traj_validate: n_traj is not a multiple of the inner batch");
     int rc = ensure_init();
     if (rc) return rc;
     if (n_traj == 0) {
-        TRK_HIP(hipMemsetAsync(counts, 0, 4 * sizeof(int32_t), (hipStream_t)stream));
+        const int32_t zero[4] = {0, 0, 0, ticket};
+        TRK_HIP(hipMemcpyAsync(counts, zero, sizeof(zero), hipMemcpyHostToDevice, (hipStream_t)stream));
+        if (counts_host) { counts_host[0] = counts_host[1] = counts_host[2] = 0; counts_host[3] = ticket; }
         return TRK_OK;
     }
     trk_launch_traj_validate(waypoint_collisions, x, n_traj, horizon, state_dim, n_waypoints, n_dofs, q_min, q_max, inner, flags,
-                             free_idx, coll_idx, counts, trajs_free, trajs_coll, (hipStream_t)stream);
+                             idx, counts, counts_host, ticket, gathered, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }

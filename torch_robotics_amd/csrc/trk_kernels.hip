@@ -1537,7 +1537,10 @@ k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, i
 // gathered -- all queued back to back; the host reads three counters once.
 // ============================================================================================
 // one wavefront per trajectory: bit 0 = some interpolated way point is in collision (tasks.py:255-256), bit 1 = some joint
-// position of the ORIGINAL way points lies outside [q_min, q_max] (tasks.py:270-273; a NaN counts as outside, as in torch)
+// position of the ORIGINAL way points lies outside [q_min, q_max] (tasks.py:270-273; a NaN counts as outside, as in torch).
+// The loads of a trajectory are issued eight at a time before any is tested: one load per loop round made the kernel a chain
+// of ~12 memory round trips (7.6 us at 4096 x 64 for 9 MB).
+#define TRK_FLAGS_BATCH 8
 __global__ void __launch_bounds__(256)
 k_traj_flags(const uint8_t* __restrict__ wp, int Hi, const float* __restrict__ x, int H, int S, int D,
              const float* __restrict__ qmin, const float* __restrict__ qmax, int64_t T, uint8_t* __restrict__ flags) {
@@ -1546,86 +1549,102 @@ k_traj_flags(const uint8_t* __restrict__ wp, int Hi, const float* __restrict__ x
     if (t >= T) return;
     bool coll = false, outside = false;
     const uint8_t* w = wp + t * Hi;
-    for (int k = lane; k < Hi; k += TRK_WAVE) coll |= w[k] != 0;
     const float* xt = x + t * (int64_t)H * S;
-    for (int k = lane; k < H * D; k += TRK_WAVE) {
-        const int h = k / D, d = k - h * D;
-        const float v = xt[h * S + d];
-        outside |= !(v >= qmin[d] && v <= qmax[d]);
+    const int nx = H * S;
+    for (int k0 = lane; k0 < Hi; k0 += TRK_WAVE * TRK_FLAGS_BATCH) {
+        uint8_t v[TRK_FLAGS_BATCH];
+#pragma unroll
+        for (int j = 0; j < TRK_FLAGS_BATCH; ++j) { const int k = k0 + TRK_WAVE * j; v[j] = k < Hi ? w[k] : 0; }
+#pragma unroll
+        for (int j = 0; j < TRK_FLAGS_BATCH; ++j) coll |= v[j] != 0;
+    }
+    for (int k0 = lane; k0 < nx; k0 += TRK_WAVE * TRK_FLAGS_BATCH) {       // contiguous read; columns >= D are not positions
+        float v[TRK_FLAGS_BATCH];
+#pragma unroll
+        for (int j = 0; j < TRK_FLAGS_BATCH; ++j) { const int k = k0 + TRK_WAVE * j; v[j] = k < nx ? xt[k] : 0.0f; }
+#pragma unroll
+        for (int j = 0; j < TRK_FLAGS_BATCH; ++j) {
+            const int k = k0 + TRK_WAVE * j, d = k % S;
+            if (k < nx && d < D) outside |= !(v[j] >= qmin[d] && v[j] <= qmax[d]);
+        }
     }
     const bool any_c = __ballot(coll) != 0, any_o = __ballot(outside) != 0;
     if (lane == 0) flags[t] = (any_c ? 1 : 0) | (any_o ? 2 : 0);
 }
 
-// One workgroup walks the flags twice (count, then place) and writes, in increasing trajectory order,
-//   free_idx: trajectories that are collision free AND inside the joint limits          (tasks.py:274, 282)
-//   coll_idx: the colliding ones, then the collision-free ones outside the limits        (tasks.py:256, 278-281)
+// One workgroup; thread i owns the contiguous block of trajectories [i * chunk, (i + 1) * chunk), so one exclusive scan of the
+// per-thread counts gives every thread its write positions and the order inside a group is the trajectory order.  A stable
+// three-way partition into ONE index list:
+//   rows [0, n_free)                     collision free AND inside the joint limits         (tasks.py:274, 282)
+//   rows [n_free, n_free + n_coll)       colliding                                          (tasks.py:256)
+//   rows [.., .. + n_out)                collision free but outside the limits              (tasks.py:278-281)
 // as int64 rows [t] (inner == 0) or [t / inner, t % inner] (a 4-D batch), like torch.argwhere; counts = {free, colliding, outside}.
 __global__ void __launch_bounds__(1024)
-k_traj_partition(const uint8_t* __restrict__ flags, int64_t T, int64_t inner, int64_t* __restrict__ free_idx,
-                 int64_t* __restrict__ coll_idx, int32_t* __restrict__ counts) {
+k_traj_partition(const uint8_t* __restrict__ flags, int64_t T, int64_t inner, int64_t* __restrict__ idx,
+                 int32_t* __restrict__ counts, int32_t* __restrict__ counts_host, int32_t ticket) {
     __shared__ int wsum[3][16];
-    __shared__ int run[3];
-    __shared__ int n_coll_total;
     const int tid = threadIdx.x, lane = tid & (TRK_WAVE - 1), wave = tid / TRK_WAVE;
-    int c = 0;
-    for (int64_t t = tid; t < T; t += 1024) c += flags[t] & 1;
-    for (int o = TRK_WAVE / 2; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (lane == 0) wsum[0][wave] = c;
-    __syncthreads();
-    if (tid == 0) {
-        int tot = 0;
-        for (int k = 0; k < 16; ++k) tot += wsum[0][k];
-        n_coll_total = tot; run[0] = 0; run[1] = 0; run[2] = 0;
+    const int64_t chunk = (T + 1023) / 1024;
+    const int64_t t0 = min(T, (int64_t)tid * chunk), t1 = min(T, t0 + chunk);
+    int c[3] = {0, 0, 0};
+    for (int64_t t = t0; t < t1; ++t) {
+        const int f = flags[t];
+        c[0] += f == 0; c[1] += f & 1; c[2] += f == 2;
     }
-    __syncthreads();
-    const int cols = inner > 0 ? 2 : 1;
-    for (int64_t t0 = 0; t0 < T; t0 += 1024) {
-        const int64_t t = t0 + tid;
-        const int f = t < T ? flags[t] : 1;
-        const bool is[3] = {t < T && f == 0, t < T && (f & 1) != 0, t < T && f == 2};       // free, colliding, outside only
-        int rank[3];
+    int incl[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const unsigned long long m = __ballot(is[k]);
-            rank[k] = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) wsum[k][wave] = __popcll(m);
+    for (int k = 0; k < 3; ++k) {               // inclusive scan inside the wavefront, then across the 16 wavefronts
+        int v = c[k];
+        for (int o = 1; o < TRK_WAVE; o <<= 1) {
+            const int u = __shfl_up(v, o);
+            if (lane >= o) v += u;
         }
-        __syncthreads();
-        int off[3] = {run[0], run[1], run[2]};
-        for (int w2 = 0; w2 < wave; ++w2) { off[0] += wsum[0][w2]; off[1] += wsum[1][w2]; off[2] += wsum[2][w2]; }
-        int64_t* dst = nullptr;
-        if (is[0]) dst = free_idx + (int64_t)(off[0] + rank[0]) * cols;
-        else if (is[1]) dst = coll_idx + (int64_t)(off[1] + rank[1]) * cols;
-        else if (is[2]) dst = coll_idx + (int64_t)(n_coll_total + off[2] + rank[2]) * cols;
-        if (dst) {
-            if (inner > 0) { dst[0] = t / inner; dst[1] = t % inner; }
-            else dst[0] = t;
-        }
-        __syncthreads();
-        if (tid == 0)
-            for (int k = 0; k < 3; ++k) { int tot = 0; for (int w2 = 0; w2 < 16; ++w2) tot += wsum[k][w2]; run[k] += tot; }
-        __syncthreads();
+        incl[k] = v;
+        if (lane == TRK_WAVE - 1) wsum[k][wave] = v;
     }
-    if (tid == 0) { counts[0] = run[0]; counts[1] = run[1]; counts[2] = run[2]; counts[3] = 0; }
+    __syncthreads();
+    int off[3], tot[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int before = 0, all = 0;
+        for (int w2 = 0; w2 < 16; ++w2) { const int s = wsum[k][w2]; all += s; before += w2 < wave ? s : 0; }
+        off[k] = before + incl[k] - c[k];
+        tot[k] = all;
+    }
+    off[1] += tot[0]; off[2] += tot[0] + tot[1];
+    const int cols = inner > 0 ? 2 : 1;
+    for (int64_t t = t0; t < t1; ++t) {
+        const int f = flags[t];
+        int64_t* dst = idx + (int64_t)(f == 0 ? off[0]++ : ((f & 1) ? off[1]++ : off[2]++)) * cols;
+        if (inner > 0) { dst[0] = t / inner; dst[1] = t % inner; }
+        else dst[0] = t;
+    }
+    if (tid == 0) {
+        counts[0] = tot[0]; counts[1] = tot[1]; counts[2] = tot[2]; counts[3] = ticket;
+        if (counts_host) {
+            // pinned host memory, written straight from the kernel: the three counters, then -- with system-scope release
+            // semantics -- the caller's ticket, which the host polls for (no copy call, no event)
+            counts_host[0] = tot[0]; counts_host[1] = tot[1]; counts_host[2] = tot[2];
+            __hip_atomic_store(&counts_host[3], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
-// rows [0, T): trajs_free[r] = x[free_idx[r]] for r < counts[0]; rows [T, 2T): trajs_coll[r - T] = x[coll_idx[r - T]] for
-// r - T < counts[1] + counts[2].  One workgroup per output row; the rest exit at once.
+// out[r] = x[idx[r]] for every row of the partitioned list: the free trajectories first, then the others (one workgroup per row)
 __global__ void __launch_bounds__(256)
-k_traj_gather(const float* __restrict__ x, int64_t T, int row, int cols, const int64_t* __restrict__ free_idx,
-              const int64_t* __restrict__ coll_idx, int64_t inner, const int32_t* __restrict__ counts,
-              float* __restrict__ out_free, float* __restrict__ out_coll) {
-    int64_t r = blockIdx.x;
-    const bool second = r >= T;
-    if (second) r -= T;
-    const int n = second ? counts[1] + counts[2] : counts[0];
-    if (r >= n) return;
-    const int64_t* ix = (second ? coll_idx : free_idx) + r * cols;
+k_traj_gather(const float* __restrict__ x, int row, int cols, const int64_t* __restrict__ idx, int64_t inner, float* __restrict__ out) {
+    const int64_t r = blockIdx.x;
+    const int64_t* ix = idx + r * cols;
     const int64_t t = inner > 0 ? ix[0] * inner + ix[1] : ix[0];
     const float* src = x + t * row;
-    float* dst = (second ? out_coll : out_free) + r * row;
-    for (int k = threadIdx.x; k < row; k += blockDim.x) dst[k] = src[k];
+    float* dst = out + r * row;
+    if ((row & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int k = threadIdx.x; k < row / 4; k += blockDim.x) d4[k] = s4[k];
+    } else {
+        for (int k = threadIdx.x; k < row; k += blockDim.x) dst[k] = src[k];
+    }
 }
 
 // interpolate_points_v1 distance_fields.py:66-69 (F.interpolate linear, align_corners=True, along the link axis) with the index /
@@ -1986,13 +2005,11 @@ void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_inter
 }
 
 void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int H, int S, int Hi, int D, const float* qmin,
-                              const float* qmax, int64_t inner, uint8_t* flags, int64_t* free_idx, int64_t* coll_idx,
-                              int32_t* counts, float* trajs_free, float* trajs_coll, hipStream_t st) {
+                              const float* qmax, int64_t inner, uint8_t* flags, int64_t* idx, int32_t* counts,
+                              int32_t* counts_host, int32_t ticket, float* gathered, hipStream_t st) {
     hipLaunchKernelGGL(k_traj_flags, dim3(grid_for(T, 4)), dim3(256), 0, st, wp, Hi, x, H, S, D, qmin, qmax, T, flags);
-    hipLaunchKernelGGL(k_traj_partition, dim3(1), dim3(1024), 0, st, flags, T, inner, free_idx, coll_idx, counts);
-    if (trajs_free && trajs_coll)
-        hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)(2 * T)), dim3(256), 0, st, x, T, H * S, inner > 0 ? 2 : 1, free_idx, coll_idx,
-                           inner, counts, trajs_free, trajs_coll);
+    hipLaunchKernelGGL(k_traj_partition, dim3(1), dim3(1024), 0, st, flags, T, inner, idx, counts, counts_host, ticket);
+    if (gathered) hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)T), dim3(128), 0, st, x, H * S, inner > 0 ? 2 : 1, idx, inner, gathered);
 }
 
 void trk_launch_interpolate_columns(const float* x, int64_t n, int L, int C, int K, const int32_t* src, const float* w, float* out,

@@ -951,42 +951,78 @@ def rollout_collision_via(model: ModelHandle, cm: CostHandle, fields: int, trajs
     return out
 
 
+class _PinnedCounters:
+    """A ring of pinned host int32[4] slots the partition kernel writes its counters into DIRECTLY (pinned host memory is
+    device-addressable under HIP's unified addressing), the caller's ticket last: the host polls that word -- no device-to-host
+    copy call (~20 us for 16 bytes through torch), no event (~5 us to create and record)."""
+    _buf = None
+    _np = None
+    _next = 0
+    SLOTS = 64
+
+    @classmethod
+    def take(cls):
+        """-> (slot pointer, numpy view of the slot, ticket)"""
+        if cls._buf is None:
+            cls._buf = torch.zeros(cls.SLOTS * 4, dtype=torch.int32).pin_memory()
+            cls._np = cls._buf.numpy()
+        cls._next += 1
+        k = cls._next % cls.SLOTS
+        ticket = (cls._next % 0x7ffffff0) + 1                  # never 0 (the slots start zeroed), distinct over many ring turns
+        return cls._buf.data_ptr() + 16 * k, cls._np[4 * k:4 * k + 4], ticket
+
+
 class TrajPartition:
-    """Result buffers of `traj_validate` (device side of get_trajs_collision_and_free): read `counts()` once, then slice."""
-    __slots__ = ("flags", "free_idx", "coll_idx", "_counts", "trajs_free", "trajs_coll", "_host")
+    """Result of `traj_validate` (device side of get_trajs_collision_and_free): buffers to slice after `counts()`.
+    rows [0, n_free) of `idx` / `gathered` are the free trajectories, [n_free, n_free + n_coll) the colliding ones, the next
+    n_out the collision-free ones outside the joint limits (each group in trajectory order)."""
+    __slots__ = ("flags", "idx", "gathered", "_small", "_slot", "_ticket", "_host", "_stream")
 
     def counts(self):
-        """(n_free, n_colliding, n_outside_limits): the single device -> host read of a validation."""
+        """(n_free, n_colliding, n_outside_limits): the single device -> host synchronisation of a validation."""
         if self._host is None:
-            self._host = tuple(int(v) for v in self._counts.tolist()[:3])
+            slot, spins = self._slot, 0
+            while slot[3] != self._ticket:                      # the kernel stores the ticket last (system-scope release)
+                spins += 1
+                if spins > 2_000_000:                           # host memory not coherent on this system: wait for the stream
+                    self._stream.synchronize()
+                    if slot[3] != self._ticket:
+                        raise RuntimeError("traj_validate: the partition kernel did not report its counters")
+            self._host = (int(slot[0]), int(slot[1]), int(slot[2]))
         return self._host
 
 
 def traj_validate(waypoint_collisions: torch.Tensor, trajs: torch.Tensor, n_dofs: int, q_min: torch.Tensor, q_max: torch.Tensor,
                   inner: int = 0, gather: bool = True) -> TrajPartition:
-    """Per-trajectory flags, ordered free / colliding index lists and the two gathered groups (tasks.py:253-299), queued as
-    three launches with no host synchronisation.  waypoint_collisions (T, W) bool / uint8; trajs (T, H, S) float32."""
-    x = _dev_f32(trajs, "traj_validate(trajs)")
-    T, H, S = (int(v) for v in x.shape)
+    """Per-trajectory flags, the stable [free | colliding | outside-limits] partition (`idx`: int64 (T, 1 | 2)) and the
+    trajectories gathered in that order (`gathered`: (T, H, S)) -- tasks.py:253-299 -- queued as three launches with no host
+    synchronisation.  waypoint_collisions (T, W) bool / uint8; trajs (T, H, S) float32 contiguous; q_min / q_max float32
+    (n_dofs,) on the same device."""
+    x = trajs
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3):
+        x = _dev_f32(trajs, "traj_validate(trajs)")
+        if x.dim() != 3:
+            raise ValueError("traj_validate: trajs must be (T, H, S)")
+    T, H, S = x.shape
     wp = waypoint_collisions
     if wp.device != x.device or wp.element_size() != 1 or not wp.is_contiguous() or wp.numel() % max(T, 1):
         raise ValueError("traj_validate: waypoint_collisions must be a contiguous 1-byte tensor (T, W) on the trajectories' device")
     W = wp.numel() // max(T, 1)
     _check_buffer(q_min, int(n_dofs), torch.float32, x.device, "traj_validate(q_min)")
     _check_buffer(q_max, int(n_dofs), torch.float32, x.device, "traj_validate(q_max)")
-    cols = 2 if inner else 1
     r = TrajPartition()
+    r._small = torch.empty(T + 32, device=x.device, dtype=torch.uint8)          # [counts 16 B | pad | flags T]
+    r.flags = r._small[32:]
+    r.idx = torch.empty((T, 2 if inner else 1), device=x.device, dtype=torch.int64)
+    r.gathered = torch.empty((T, H, S), device=x.device, dtype=torch.float32) if gather else None
     r._host = None
-    r.flags = torch.empty((T,), device=x.device, dtype=torch.uint8)
-    r.free_idx = torch.empty((T, cols), device=x.device, dtype=torch.int64)
-    r.coll_idx = torch.empty((T, cols), device=x.device, dtype=torch.int64)
-    r._counts = torch.empty((4,), device=x.device, dtype=torch.int32)
-    r.trajs_free = torch.empty((T, H, S), device=x.device, dtype=torch.float32) if gather else None
-    r.trajs_coll = torch.empty((T, H, S), device=x.device, dtype=torch.float32) if gather else None
+    slot_ptr, r._slot, r._ticket = _PinnedCounters.take()
+    base = r._small.data_ptr()
     with _on(x.device):
+        r._stream = torch.cuda.current_stream(x.device)
         check(lib().trk_traj_validate(wp.data_ptr(), x.data_ptr(), T, H, S, W, int(n_dofs), q_min.data_ptr(), q_max.data_ptr(),
-                                      int(inner), r.flags.data_ptr(), r.free_idx.data_ptr(), r.coll_idx.data_ptr(),
-                                      r._counts.data_ptr(), _ptr(r.trajs_free), _ptr(r.trajs_coll), _stream(x)), "trk_traj_validate")
+                                      int(inner), base + 32, r.idx.data_ptr(), base, slot_ptr, r._ticket, _ptr(r.gathered),
+                                      r._stream.cuda_stream), "trk_traj_validate")
     return r
 
 

@@ -268,29 +268,28 @@ class PlanningTask(Task):
         batched = trajs.ndim == 4                       # (goals or steps, batch, horizon, state)
         lead = tuple(trajs.shape[:-2])
         H, S = int(trajs.shape[-2]), int(trajs.shape[-1])
-        flat = trajs.detach().reshape(-1, H, S).to(torch.float32).contiguous()
+        flat = trajs.detach().reshape(-1, H, S)
+        if flat.dtype != torch.float32 or not flat.is_contiguous():
+            flat = flat.to(torch.float32).contiguous()
         wp = self._waypoint_collisions(flat, num_interpolation)
-        dev = flat.device
-        part = ops.traj_validate(wp, flat, self.robot.q_dim, self.robot.q_min.to(dev, torch.float32).contiguous(),
-                                 self.robot.q_max.to(dev, torch.float32).contiguous(), inner=lead[1] if batched else 0)
+        lim = getattr(self, "_q_lim", None)             # the limits as fp32 device vectors, keyed by the tensors they came from
+        if lim is None or lim[0] is not self.robot.q_min or lim[1] is not self.robot.q_max or lim[2].device != flat.device:
+            lim = self._q_lim = (self.robot.q_min, self.robot.q_max,
+                                 self.robot.q_min.to(flat.device, torch.float32).contiguous(),
+                                 self.robot.q_max.to(flat.device, torch.float32).contiguous())
+        part = ops.traj_validate(wp, flat, self.robot.q_dim, lim[2], lim[3], inner=lead[1] if batched else 0)
         n_free, n_coll, n_out = part.counts()                                   # the one host synchronisation
-        free_idxs = part.free_idx[:n_free]
-        if n_free + n_out == 0:                          # no collision-free trajectory: the limits are not looked at (tasks.py:264-265)
-            coll_idxs = part.coll_idx[:n_coll]
-        elif n_free == 0:                                # tasks.py:275-276: the list is REPLACED by the limit violators
-            coll_idxs = part.coll_idx[n_coll:n_coll + n_out]
-        else:
-            coll_idxs = part.coll_idx[:n_coll + n_out]
+        # the partition is [free | colliding | collision free but outside the limits]; the reference's second list is
+        # "colliding, then the limit violators" -- except that it is only the violators when no trajectory is free although
+        # some were collision free (tasks.py:275-276 replaces the list), and the limits are not looked at when none was (:264)
+        lo, hi = n_free, n_free + n_coll + n_out
+        if n_free == 0 and n_out:
+            lo = n_free + n_coll
+        free_idxs, coll_idxs = part.idx[:n_free], part.idx[lo:hi]
         if n_free == 1 and not batched:                  # argwhere(...).squeeze() of one hit indexes out a 1-D row (tasks.py:274)
             free_idxs = free_idxs.reshape(-1)
-        n_coll_rows = int(coll_idxs.shape[0])
-        trajs_free = part.trajs_free[:n_free] if n_free else None
-        if n_coll_rows == 0:
-            trajs_coll = None
-        elif n_free == 0 and n_out:                      # the replaced list starts behind the colliding rows of the gather
-            trajs_coll = part.trajs_coll[n_coll:n_coll + n_out]
-        else:
-            trajs_coll = part.trajs_coll[:n_coll_rows]
+        trajs_free = part.gathered[:n_free] if n_free else None
+        trajs_coll = part.gathered[lo:hi] if hi > lo else None
         if return_indices:
             return trajs_coll, coll_idxs, trajs_free, free_idxs, wp.reshape(lead + (-1,))
         return trajs_coll, trajs_free
