@@ -510,6 +510,14 @@ int trk_finite_difference(const float* x, int64_t batch, int32_t horizon, int32_
 int trk_traj_diff_norm_sum(const float* x, int64_t batch, int32_t horizon, int32_t state_dim, int32_t c0, int32_t dim,
                            float* out, trk_stream_t stream);
 
+/* The chain rule of the fused rollout under autograd: out[n, :] = g[n, :] * scale[n * scale_stride] -- the saved
+ * d cost[n] / d q[n, :] of trk_rollout_cost_grad times the upstream gradient of cost[n] (what
+ * `PlanningTask.compute_collision_cost(q).sum().backward()`, tasks.py:135-137, asks of the op's backward).  g / out [n, dim] of
+ * io_dtype (TRK_F32 / TRK_F16); scale fp32: [n] with scale_stride 1, or ONE value with scale_stride 0 (`.sum().backward()`
+ * hands down an expanded scalar: no per-row tensor is materialised for it); out may be g. */
+int trk_scale_rows(const void* g, const float* scale, int32_t scale_stride, int64_t n, int32_t dim, int32_t io_dtype, void* out,
+                   trk_stream_t stream);
+
 /* Profiling hook (process-global, NULL = off): DEVICE uint64[ceil(N/64)][8]; the model-specialised fused kernel then
  * records the shader clock (s_memtime) of every wavefront at 8 phase boundaries (entry, q loaded, FK done, positions
  * staged, objects done, objectives done, reverse done, exit).  Used by tools/phase_profile.py; never set in production. */

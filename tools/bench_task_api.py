@@ -35,3 +35,34 @@ wp_ = ops.rollout_collision_via(m_, cm_, FIELD_OBJECTS | FIELD_WS | FIELD_SELF, 
 qmin_, qmax_ = robot.q_min.to(dev).contiguous(), robot.q_max.to(dev).contiguous()
 t("  ops.traj_validate, no host read (flags + partition + gathers)", lambda: ops.traj_validate(wp_, q, 7, qmin_, qmax_), n=100)
 t("  ops.traj_validate + counts() (the one host read)", lambda: ops.traj_validate(wp_, q, 7, qmin_, qmax_).counts(), n=100)
+
+# the same idiom through the dispatcher ops (torch.ops.trk.*; what torch.compile sees) and as a captured hipGraph
+ops._ALWAYS_DISPATCH = True
+t("[dispatcher ops] task.compute_collision_cost(q)   [no grad]", lambda: task.compute_collision_cost(q))
+t("[dispatcher ops] task.compute_collision_cost(q).sum().backward()", fb)
+ops._ALWAYS_DISPATCH = False
+try:
+    cfn = torch.compile(task.compute_collision_cost)
+    cfn(q); cfn(qg).sum().backward()
+    t("[torch.compile] compute_collision_cost(q)   [no grad]", lambda: cfn(q))
+    def fbc():
+        qg.grad = None
+        cfn(qg).sum().backward()
+    t("[torch.compile] compute_collision_cost(q).sum().backward()", fbc)
+except Exception as e:
+    print("torch.compile path failed:", type(e).__name__, str(e)[:200])
+# whole-iteration hipGraph: forward + backward of the idiom captured once, replayed per planner iteration
+qs = q.clone().requires_grad_(True)
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    for _ in range(3):
+        qs.grad = None
+        task.compute_collision_cost(qs).sum().backward()
+torch.cuda.current_stream().wait_stream(side)
+graph = torch.cuda.CUDAGraph()
+qs.grad = None
+with torch.cuda.graph(graph):
+    task.compute_collision_cost(qs).sum().backward()
+t("[hipGraph replay] compute_collision_cost(q).sum().backward()", graph.replay)
+plan = task.rollout_plan(q, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=False)
+t("[reference] pre-bound fused kernel, cost + gradient (RolloutPlan.launch)", plan.launch, n=1000)

@@ -1225,6 +1225,19 @@ int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, 
     return TRK_OK;
 }
 
+int trk_scale_rows(const void* g, const float* scale, int32_t scale_stride, int64_t n, int32_t dim, int32_t io_dtype, void* out,
+                   trk_stream_t stream) {
+    if (n < 0 || dim < 1 || (scale_stride != 0 && scale_stride != 1) || (io_dtype != TRK_F32 && io_dtype != TRK_F16) ||
+        (n > 0 && (!g || !scale || !out)))
+        return fail(TRK_ERR_INVALID_ARG, "trk_scale_rows: bad argument");
+    if (n == 0) return TRK_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_scale_rows(io_dtype == TRK_F16, g, scale, scale_stride, n, dim, out, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
 int trk_interpolate_columns(const float* x, int64_t n, int32_t n_in, int32_t channels, int32_t n_out, const int32_t* src,
                             const float* w, float* out, trk_stream_t stream) {
     if (n < 0 || n_in < 1 || channels < 1 || n_out < 1 || !src || !w || (n > 0 && (!x || !out)))

@@ -1647,6 +1647,16 @@ k_traj_gather(const float* __restrict__ x, int row, int cols, const int64_t* __r
     }
 }
 
+// out[n, :] = g[n, :] * s[n]: the chain rule of the fused rollout under autograd -- its saved d cost[n] / d q[n, :] times the
+// upstream gradient of cost[n] (tasks.py:135-137 followed by .backward()).  fp32 or fp16 rows, fp32 scale; one thread per element.
+template <class IO>
+__global__ void __launch_bounds__(256)
+k_scale_rows(const IO* __restrict__ g, const float* __restrict__ sc, int sc_stride, int64_t n, int D, IO* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * D) return;
+    out[idx] = (IO)((float)g[idx] * (sc_stride ? sc[idx / D] : sc[0]));
+}
+
 // interpolate_points_v1 distance_fields.py:66-69 (F.interpolate linear, align_corners=True, along the link axis) with the index /
 // weight table unrolled on the host: x [N, L, C] -> out [N, K, C], out[n, k] = w[2k] x[n, src[2k]] + w[2k+1] x[n, src[2k+1]].
 // One thread per output element: consecutive threads write consecutive floats.
@@ -2010,6 +2020,11 @@ void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int 
     hipLaunchKernelGGL(k_traj_flags, dim3(grid_for(T, 4)), dim3(256), 0, st, wp, Hi, x, H, S, D, qmin, qmax, T, flags);
     hipLaunchKernelGGL(k_traj_partition, dim3(1), dim3(1024), 0, st, flags, T, inner, idx, counts, counts_host, ticket);
     if (gathered) hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)T), dim3(128), 0, st, x, H * S, inner > 0 ? 2 : 1, idx, inner, gathered);
+}
+
+void trk_launch_scale_rows(int f16, const void* g, const float* sc, int sc_stride, int64_t n, int D, void* out, hipStream_t st) {
+    if (f16) hipLaunchKernelGGL(k_scale_rows<_Float16>, dim3(grid_for(n * D, 256)), dim3(256), 0, st, (const _Float16*)g, sc, sc_stride, n, D, (_Float16*)out);
+    else hipLaunchKernelGGL(k_scale_rows<float>, dim3(grid_for(n * D, 256)), dim3(256), 0, st, (const float*)g, sc, sc_stride, n, D, (float*)out);
 }
 
 void trk_launch_interpolate_columns(const float* x, int64_t n, int L, int C, int K, const int32_t* src, const float* w, float* out,

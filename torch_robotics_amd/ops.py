@@ -6,6 +6,8 @@ floating-point operation of the path happens in the HIP kernels behind the C ABI
 from __future__ import annotations
 
 import ctypes as C
+import os
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -92,6 +94,25 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+# Integer ids of the live handles, for the dispatcher ops (torch.ops.trk.*, custom_ops.py): an op schema carries tensors and
+# scalars only, so a model / cost model / point set travels as the value of its C pointer.
+_handles: "weakref.WeakValueDictionary[int, object]" = weakref.WeakValueDictionary()
+
+
+def _register_handle(obj) -> int:
+    uid = int(obj._h.value)
+    _handles[uid] = obj
+    return uid
+
+
+def handle_of(uid: int):
+    """The live ModelHandle / CostHandle / PointSetHandle behind an integer id (`handle.uid`)."""
+    try:
+        return _handles[int(uid)]
+    except KeyError:
+        raise ValueError(f"torch.ops.trk: {uid} is not a live model / cost-model / point-set handle") from None
+
+
 class ModelHandle:
     """Owns a TrkModel* (device copy of the kinematic tables)."""
 
@@ -102,6 +123,7 @@ class ModelHandle:
         check(lib().trk_model_create(C.byref(desc), C.byref(h)), "trk_model_create")
         self._h = h
         self.n_links, self.n_dofs = kin.n_links, kin.n_dofs
+        self.uid = _register_handle(self)
 
     def set_base_pose(self, R: np.ndarray, t: np.ndarray) -> None:
         R = np.ascontiguousarray(R, np.float32).reshape(9)
@@ -145,6 +167,7 @@ class CostHandle:
         self._h = h
         self.n_links_in = spec.n_links_in
         self.n_objects = len(spec.objects)
+        self.uid = _register_handle(self)
 
     def set_ee_target(self, H) -> None:
         H = np.ascontiguousarray(np.asarray(H, np.float32).reshape(16))
@@ -184,6 +207,7 @@ class PointSetHandle:
             check(lib().trk_point_set_create(model._h, pl.ctypes.data, po.ctypes.data, self.n_points, C.byref(h)),
                   "trk_point_set_create")
         self._h = h
+        self.uid = _register_handle(self)
 
     @property
     def specialized(self) -> bool:
@@ -1026,6 +1050,28 @@ def traj_validate(waypoint_collisions: torch.Tensor, trajs: torch.Tensor, n_dofs
     return r
 
 
+def scale_rows(g: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """g (..., D) fp32 / fp16 times scale (...) per row -> new tensor like g: the backward of the fused rollout's cost output.
+    A scale that is one value expanded over the rows (what `.sum().backward()` hands down) is read as a scalar in the kernel."""
+    if g.device.type != "cuda" or g.dtype not in (torch.float32, torch.float16):
+        raise ValueError("scale_rows: g must be an fp32 / fp16 tensor on the GPU")
+    if not g.is_contiguous():
+        g = g.contiguous()
+    D = int(g.shape[-1])
+    rows = g.numel() // max(1, D)
+    if scale.device != g.device or scale.numel() != rows:
+        raise ValueError("scale_rows: scale must have one entry per row of g, on the same device")
+    if scale.dtype == torch.float32 and (rows == 1 or not any(scale.stride())):
+        sc, stride = scale, 0                       # every stride 0: one element behind data_ptr()
+    else:
+        sc, stride = _dev_f32(scale, "scale_rows(scale)"), 1
+    out = torch.empty_like(g)
+    with _on(g.device):
+        check(lib().trk_scale_rows(g.data_ptr(), sc.data_ptr(), stride, rows, D, int(g.dtype == torch.float16), out.data_ptr(),
+                                   _stream(g)), "trk_scale_rows")
+    return out
+
+
 def reduce_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Deterministic sum of a float32 device vector (fixed association order)."""
     x = _dev_f32(x, "reduce_sum(x)").reshape(-1)
@@ -1156,10 +1202,32 @@ class _Rollout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gcost, _gpos):
         (gq,) = ctx.saved_tensors
-        return gq * gcost.unsqueeze(-1), None, None, None, None, None
+        return scale_rows(gq, gcost), None, None, None, None, None
+
+
+# The differentiable entry points below exist twice: as `torch.autograd.Function`s over the ctypes calls (the eager path: least
+# host time per call) and as dispatcher ops `torch.ops.trk.*` (custom_ops.py: what `torch.compile`, `torch.export` and
+# `torch.library.opcheck` see).  TRK_DISPATCHER_OPS=1 routes eager calls through the dispatcher as well; under a compiler the
+# dispatcher ops are always used (ctypes calls cannot be traced).
+_ALWAYS_DISPATCH = os.environ.get("TRK_DISPATCHER_OPS", "0") == "1"
+
+
+def _dispatch() -> bool:
+    return _ALWAYS_DISPATCH or torch.compiler.is_compiling()
+
+
+def _trk_ops():
+    from . import custom_ops  # noqa: F401  (registers torch.ops.trk.*)
+    return torch.ops.trk
+
+
+def _sel_list(sel):
+    return None if sel is None else [int(i) for i in sel]
 
 
 def fk(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
+    if _dispatch():
+        return _trk_ops().fk(q.reshape(-1, model.n_dofs), model.uid, _sel_list(sel))
     q2 = _dev_f32(q, "fk(q)").reshape(-1, model.n_dofs)
     if torch.is_grad_enabled() and q.requires_grad:
         return _FK.apply(q2, model, sel)
@@ -1167,6 +1235,8 @@ def fk(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
 
 
 def fk_pos(model: ModelHandle, q: torch.Tensor, sel=None) -> torch.Tensor:
+    if _dispatch():
+        return _trk_ops().fk_positions(q.reshape(-1, model.n_dofs), model.uid, _sel_list(sel))
     q2 = _dev_f32(q, "fk_pos(q)").reshape(-1, model.n_dofs)
     if torch.is_grad_enabled() and q.requires_grad:
         return _FKPos.apply(q2, model, sel)
@@ -1181,6 +1251,8 @@ def fk_points_ad(ps: PointSetHandle, q: torch.Tensor) -> torch.Tensor:
 
 
 def cost_fields_ad(cm: CostHandle, fields: int, link_pos: torch.Tensor) -> torch.Tensor:
+    if _dispatch():
+        return _trk_ops().cost_fields(link_pos.reshape(-1, cm.n_links_in, 3), cm.uid, int(fields))
     lp = _dev_f32(link_pos, "cost_fields(link_pos)").reshape(-1, cm.n_links_in, 3)
     if torch.is_grad_enabled() and link_pos.requires_grad:
         return _CostFields.apply(lp, cm, fields)
@@ -1188,6 +1260,8 @@ def cost_fields_ad(cm: CostHandle, fields: int, link_pos: torch.Tensor) -> torch
 
 
 def ee_cost_ad(cm: CostHandle, H: torch.Tensor, target=None) -> torch.Tensor:
+    if _dispatch():
+        return _trk_ops().ee_cost(H.reshape(-1, 4, 4), target, cm.uid)
     Hc = _dev_f32(H, "ee_cost(H)").reshape(-1, 4, 4)
     if torch.is_grad_enabled() and H.requires_grad:
         return _EECost.apply(Hc, cm, target)
@@ -1198,6 +1272,10 @@ def rollout_ad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, ps:
                want_pos: bool = True):
     """Differentiable fused op: returns (cost, link_pos) -- or (cost, point_pos) when a point set is given; want_pos=False
     returns (cost, None) and skips the position output (34.6 of the 50 MB a Panda evaluation writes)."""
+    if _dispatch():
+        cost, _gq, pos = _trk_ops().rollout_cost_grad(q, model.uid, cm.uid, [float(w) for w in weights], bool(want_pos),
+                                                      ps.uid if ps is not None else 0)
+        return cost, (pos if want_pos else None)
     return _Rollout.apply(_dev_f32(q, "rollout(q)"), model, cm, tuple(float(w) for w in weights), ps, bool(want_pos))
 
 
