@@ -287,7 +287,9 @@ typedef struct TrkObject {      /* ObjectField pose, primitives.py:387-405: p' =
     int32_t _pad;
 } TrkObject;
 
-typedef struct TrkGridDesc {    /* GridMapSDF grid_map_sdf.py:9-117 (device pointers, caller-owned) */
+typedef struct TrkGridDesc {    /* GridMapSDF grid_map_sdf.py:9-117 (device pointers, caller-owned).  trk_cost_model_create packs
+                                   the two arrays into its own (grad, sdf) records on the stream-0 timeline: like the host
+                                   tables the grid is a snapshot taken at create(), later writes to sdf / grad are not seen */
     const float* sdf;           /* DEVICE [nx,ny,nz] */
     const float* grad;          /* DEVICE [nx,ny,nz,3] */
     int32_t dims[3];

@@ -114,6 +114,7 @@ struct TrkPointSet {
 struct TrkCostModel {
     DevCostHdr hdr;
     void* d_blob = nullptr;
+    float4* d_cells = nullptr;           // the voxel grid as (gx, gy, gz, sdf) records (a copy of the caller's two arrays)
     std::vector<int32_t> obj_link_idx;   // host copies, to match a specialised kernel's baked link sets
     std::vector<int32_t> self_pairs;     // mapped to link indices
     bool spec_enabled = true;            // trk_cost_model_enable_specialized: may trk_cost_fields use a generated unit's field kernel
@@ -940,6 +941,21 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     h.spheres_uniform_r = uniform_r ? 1 : 0;
     h.sphere_r = spheres.empty() ? 0.0f : spheres[0].w;
     if (n_grid) {
+        // the kernels gather one 16-byte record per point: pack the caller's arrays once (a snapshot, like every other table)
+        const int64_t n_cells = (int64_t)d->grid.dims[0] * d->grid.dims[1] * d->grid.dims[2];
+        e = n_cells > 0 ? hipMalloc(&cm->d_cells, sizeof(float4) * (size_t)n_cells) : hipErrorInvalidValue;
+        if (e == hipSuccess) {
+            trk_launch_grid_pack(d->grid.sdf, d->grid.grad, n_cells, cm->d_cells, nullptr);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        }
+        if (e != hipSuccess) {
+            if (cm->d_cells) (void)hipFree(cm->d_cells);
+            (void)hipFree(cm->d_blob);
+            delete cm;
+            return hip_fail(e, "trk_cost_model_create: packing the voxel grid");
+        }
+        h.grid.cells = cm->d_cells;
         h.grid.sdf = d->grid.sdf; h.grid.grad = d->grid.grad;
         for (int k = 0; k < 3; ++k) {
             h.grid.dims[k] = d->grid.dims[k]; h.grid.lim_min[k] = d->grid.lim_min[k];
@@ -953,6 +969,7 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
 void trk_cost_model_destroy(TrkCostModel* cm) {
     if (!cm) return;
     if (cm->d_blob) (void)hipFree(cm->d_blob);
+    if (cm->d_cells) (void)hipFree(cm->d_cells);
     delete cm;
 }
 

@@ -59,6 +59,8 @@ struct alignas(16) DevObj {    // 16 dwords
 struct DevGrid {
     const float* sdf;
     const float* grad;
+    const float4* cells;        // (gx, gy, gz, sdf) per voxel, built at trk_cost_model_create: ONE 16-byte gather per point instead
+                                // of a 4- and a 12-byte one from two arrays (random cells: every gather is its own cache line)
     int32_t dims[3];
     float lim_min[3];
     float map_dim[3];
@@ -347,8 +349,9 @@ __device__ __forceinline__ float prim_sdf(const DevPrim& P, float x, float y, fl
     return fminf(mu, 0.0f) + nn - P.r;
 }
 
-// grid_map_sdf.py:84-114: nearest-lower cell, stored gradient
-__device__ __forceinline__ float grid_sdf(const DevGrid& G, float x, float y, float z, float& gx, float& gy, float& gz) {
+// grid_map_sdf.py:84-114: nearest-lower cell (linear index), stored gradient
+typedef float trk_f3u __attribute__((ext_vector_type(3), aligned(4)));       // a 12-byte gradient record: one dwordx3 load
+__device__ __forceinline__ int64_t grid_cell(const DevGrid& G, float x, float y, float z) {
     const float p[3] = {x, y, z};
     int idx[3];
 #pragma unroll
@@ -359,9 +362,12 @@ __device__ __forceinline__ float grid_sdf(const DevGrid& G, float x, float y, fl
         v = v > G.dims[k] - 1 ? G.dims[k] - 1 : v;
         idx[k] = v;
     }
-    const int64_t lin = ((int64_t)idx[0] * G.dims[1] + idx[1]) * G.dims[2] + idx[2];
-    gx = G.grad[3 * lin]; gy = G.grad[3 * lin + 1]; gz = G.grad[3 * lin + 2];
-    return G.sdf[lin];
+    return ((int64_t)idx[0] * G.dims[1] + idx[1]) * G.dims[2] + idx[2];
+}
+__device__ __forceinline__ float grid_sdf(const DevGrid& G, float x, float y, float z, float& gx, float& gy, float& gz) {
+    const float4 c = G.cells[grid_cell(G, x, y, z)];
+    gx = c.x; gy = c.y; gz = c.z;
+    return c.w;
 }
 
 // ObjectField primitives.py:387-405: x' = R^T (x - pos), min over primitives, g = R g'.
@@ -467,7 +473,12 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
     // contract with the caller: all TRK_OBJ_TICK_SLOTS tick slots are issued on every path -- interleaved with the pair ranking when
     // that path runs, in one go otherwise
     const bool paired = FAST || (C.n_spheres > 0 && C.spheres_uniform_r && C.n_spheres <= 16);
-    if (!paired) {
+    // A voxel-grid scene gathers per lane from global memory, and on this ISA loads and stores share `vmcnt`: a gather issued
+    // behind position stores waits until HBM has taken them (measured: 37 us per launch for the 200^3 grid against 11 us for the
+    // analytic spheres).  So the tick slots of a grid scene fire AFTER its gathers have returned; box-only scenes read their
+    // tables through the scalar cache (lgkmcnt) and keep the stores in flight under their arithmetic.
+    const bool ticks_last = !FAST && C.has_grid;
+    if (!paired && !ticks_last) {
         scene_all_ticks<0>(tick);
     }
     if (FAST || C.n_spheres > 0) {
@@ -586,13 +597,19 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
     // precomputed voxel grid (kept out of the loop above: its index arithmetic is loop-invariant and the
     // compiler would otherwise hoist 15 IEEE divisions in front of every scene, grid or not)
     if (C.has_grid) {
+        // all NL cells are addressed first and their 4 + 12 bytes requested together: one memory round trip for the group
+        int64_t lin[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) lin[l] = grid_cell(C.grid, px[l], py[l], pz[l]);
+        float4 cell[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) cell[l] = C.grid.cells[lin[l]];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            float ax, ay, az;
-            const float v = grid_sdf(C.grid, px[l], py[l], pz[l], ax, ay, az);
-            const bool take = v < s[l];
-            s[l] = take ? v : s[l]; gx[l] = take ? ax : gx[l]; gy[l] = take ? ay : gy[l]; gz[l] = take ? az : gz[l];
+            const bool take = cell[l].w < s[l];
+            s[l] = take ? cell[l].w : s[l]; gx[l] = take ? cell[l].x : gx[l]; gy[l] = take ? cell[l].y : gy[l]; gz[l] = take ? cell[l].z : gz[l];
         }
+        if (!paired) scene_all_ticks<0>(tick);
     }
 }
 

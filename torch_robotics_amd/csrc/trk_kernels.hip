@@ -1439,6 +1439,14 @@ k_rotation_from(int axis, const float* __restrict__ in, int64_t n, float* __rest
     }
 }
 
+// voxel grid of a cost model: (sdf [n], grad [n, 3]) -> cells [n] = (gx, gy, gz, sdf)
+__global__ void __launch_bounds__(256)
+k_grid_pack(const float* __restrict__ sdf, const float* __restrict__ grad, int64_t n, float4* __restrict__ cells) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cells[i] = make_float4(grad[3 * i], grad[3 * i + 1], grad[3 * i + 2], sdf[i]);
+}
+
 // GridMapSDF.precompute_sdf grid_map_sdf.py:34-63 (analytic objects only) and
 // ObjectField.compute_signed_distance on arbitrary points
 __global__ void __launch_bounds__(256)
@@ -2020,6 +2028,10 @@ void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int 
     hipLaunchKernelGGL(k_traj_flags, dim3(grid_for(T, 4)), dim3(256), 0, st, wp, Hi, x, H, S, D, qmin, qmax, T, flags);
     hipLaunchKernelGGL(k_traj_partition, dim3(1), dim3(1024), 0, st, flags, T, inner, idx, counts, counts_host, ticket);
     if (gathered) hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)T), dim3(128), 0, st, x, H * S, inner > 0 ? 2 : 1, idx, inner, gathered);
+}
+
+void trk_launch_grid_pack(const float* sdf, const float* grad, int64_t n, float4* cells, hipStream_t st) {
+    hipLaunchKernelGGL(k_grid_pack, dim3(grid_for(n, 256)), dim3(256), 0, st, sdf, grad, n, cells);
 }
 
 void trk_launch_scale_rows(int f16, const void* g, const float* sc, int sc_stride, int64_t n, int D, void* out, hipStream_t st) {

@@ -80,7 +80,7 @@ typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 15)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 16)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
