@@ -512,6 +512,15 @@ int trk_finite_difference(const float* x, int64_t batch, int32_t horizon, int32_
 int trk_traj_diff_norm_sum(const float* x, int64_t batch, int32_t horizon, int32_t state_dim, int32_t c0, int32_t dim,
                            float* out, trk_stream_t stream);
 
+/* Gauss-Newton normal equations from the geometric Jacobian of one link (the output of trk_fk_jacobian; reference:
+ * DifferentiableTree.compute_forward_kinematics_and_geometric_jacobian robot_tree.py:218-248 stops at lin_jac / ang_jac).
+ * BUILD-DEFINED: per sample J = [lin_jac; ang_jac] (6 x D):  JtJ [n, D, D] = J^T J,  Jtr [n, D] = J^T residual (nullable;
+ * residual [n, 6] = [linear(3), angular(3)]) -- what a damped least-squares / Gauss-Newton IK step solves (JtJ + lambda I) dq = Jtr.
+ * use_mfma != 0 computes JtJ with v_mfma_f32_4x4x1_16b_f32 (dof <= 8) instead of per-lane FMAs: the same values to fp32 rounding;
+ * both variants exist so that the two can be measured side by side (the op is HBM-bound). */
+int trk_jtj(const float* lin_jac, const float* ang_jac, const float* residual, int64_t n, int32_t dof, int32_t use_mfma,
+            float* JtJ, float* Jtr, trk_stream_t stream);
+
 /* The chain rule of the fused rollout under autograd: out[n, :] = g[n, :] * scale[n * scale_stride] -- the saved
  * d cost[n] / d q[n, :] of trk_rollout_cost_grad times the upstream gradient of cost[n] (what
  * `PlanningTask.compute_collision_cost(q).sum().backward()`, tasks.py:135-137, asks of the op's backward).  g / out [n, dim] of

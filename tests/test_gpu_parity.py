@@ -1261,3 +1261,33 @@ def test_single_link_self_distance(ops, oracle_lib):
         assert rel_err(gq.cpu().numpy(), g["single_gq"].reshape(-1, 7)) < 1e-5
     assert np.array_equal(ops.collision_fields(cm, FIELD_SELF, pos).cpu().numpy(), g["single_coll"].reshape(-1))
     assert ops.collision_fields(cm, FIELD_SELF, torch.zeros(2, 11, 3, device=DEV)).all()       # |0|_1 * 1e9 < margin
+
+
+@pytest.mark.parametrize("robot,link", [("panda_arm_no_gripper", "ee_link"), ("ur10", "ee_link"), ("iiwa7", None), ("dual_panda", None)])
+def test_jtj_normal_equations(ops, oracle_lib, robot, link):
+    """trk_jtj: J^T J and J^T r of the geometric Jacobian (robot_tree.py:238-246), per-lane FMA kernel and the
+    v_mfma_f32_4x4x1_16b_f32 kernel, against fp64 numpy on the Jacobians of trk_fk_jacobian (goldens pin those), ragged sizes."""
+    m = model(robot)
+    h = ops.ModelHandle(m)
+    li = m.name_to_idx[link] if link else m.n_links - 1
+    D = m.n_dofs
+    rng = np.random.default_rng(8)
+    for n in (1, 63, 64, 257, 4099):
+        q = rng.uniform(-2.0, 2.0, (n, D)).astype(np.float32)
+        _, _, lin, ang = ops.fk_jacobian(h, dev(q), None, li)
+        r = dev(rng.standard_normal((n, 6)).astype(np.float32))
+        J = np.concatenate([lin.cpu().numpy(), ang.cpu().numpy()], 1).astype(np.float64)          # (n, 6, D)
+        ref = np.einsum("nki,nkj->nij", J, J)
+        ref_r = np.einsum("nki,nk->ni", J, r.cpu().numpy().astype(np.float64))
+        for mfma in ((False, True) if D <= 8 else (False,)):
+            JtJ, Jtr = ops.jtj(lin, ang, r, mfma=mfma)
+            assert JtJ.shape == (n, D, D) and Jtr.shape == (n, D)
+            assert np.abs(JtJ.cpu().numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (n, mfma)
+            assert np.abs(Jtr.cpu().numpy() - ref_r).max() <= 2e-6 * max(1.0, np.abs(ref_r).max()), (n, mfma)
+            assert torch.equal(JtJ, JtJ.transpose(1, 2))                        # exactly symmetric (a product commutes)
+            assert torch.equal(ops.jtj(lin, ang, mfma=mfma), JtJ)               # without a residual: JtJ alone
+    if D > 8:
+        with pytest.raises(NotImplementedError):
+            ops.jtj(lin, ang, r, mfma=True)
+    with pytest.raises(ValueError):
+        ops.jtj(lin, ang[:, :2], r)

@@ -1655,6 +1655,123 @@ k_traj_gather(const float* __restrict__ x, int row, int cols, const int64_t* __r
     }
 }
 
+// ============================================================================================
+// Gauss-Newton normal equations of one link's geometric Jacobian (robot_tree.py:238-246): per sample J = [lin_jac; ang_jac]
+// (6 x D) -> JtJ (D x D) = J^T J and Jtr (D) = J^T r.  BUILD-DEFINED (the reference stops at the Jacobian; BASELINE's north star
+// names "the small dense Jacobian x Jacobian blocks" as the place for MFMA "where it is a real contraction").
+// Two kernels with the same I/O skeleton (Jacobians in through one coalesced LDS tile, results out through another):
+//   k_jtj<false>  VALU: one lane per sample, the D (D + 1) / 2 distinct entries x 6 FMAs, mirrored on the way out;
+//   k_jtj<true>   MFMA: v_mfma_f32_4x4x1_16b_f32 -- 16 independent 4x4 outer products per instruction; a sample's 8x8-padded
+//                 JtJ is 4 such blocks, so one instruction advances 4 samples by one row k of J, 6 instructions finish them.
+// fp32 MFMA runs at the fp32 VECTOR rate on gfx950 (64 FLOP/clk/SIMD, MI355X_MICROARCH.md), computes the padded and the mirrored
+// entries as well, and the op moves 4 (12 D + 6 + D^2 + D) bytes per sample for ~12 D^2 flops: it is HBM-bound either way
+// (profiles/r03_bench_jtj.txt has both kernels side by side).
+// ============================================================================================
+typedef float trk_v4 __attribute__((ext_vector_type(4)));
+// k / w for 0 <= k < 2^22 and a wave-uniform w: one multiply by the reciprocal and a fix-up instead of a 32-bit division
+__device__ __forceinline__ int trk_div_small(int k, int w, float inv_w) {
+    int s = (int)((float)k * inv_w);
+    s -= (s * w > k); s += ((s + 1) * w <= k);
+    return s;
+}
+#define TRK_JTJ_WAVES 1      // one wavefront per workgroup: the two tiles are 20 - 75 KB per wavefront, LDS decides the occupancy
+template <bool MFMA>
+__global__ void __launch_bounds__(TRK_JTJ_WAVES * TRK_WAVE)
+k_jtj(const float* __restrict__ lin, const float* __restrict__ ang, const float* __restrict__ r6, int64_t n, int D,
+      float* __restrict__ JtJ, float* __restrict__ Jtr) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & (TRK_WAVE - 1), wave = threadIdx.x / TRK_WAVE;
+    const int64_t base = ((int64_t)blockIdx.x * TRK_JTJ_WAVES + wave) * TRK_WAVE;
+    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, n - base));
+    const int DP = MFMA ? 8 : D;                           // padded row length of a Jacobian row in LDS
+    const int js = (6 * DP) | 1;                            // per-sample stride of the Jacobian tile (odd: conflict-free lanes)
+    const int os = (D * D + D) | 1;                         // per-sample stride of the output tile [JtJ | Jtr]
+    float* jt = smem + wave * TRK_WAVE * (js + os);         // [64][js]: a wavefront works on its own tiles, no workgroup barrier
+    float* ot = jt + TRK_WAVE * js;                         // [64][os]
+    if (MFMA) for (int k = lane; k < TRK_WAVE * js; k += TRK_WAVE) jt[k] = 0.0f;      // zero padding columns D..7
+    // J rows 0..2 = lin_jac[s, :, :], 3..5 = ang_jac[s, :, :]: each array is one contiguous run of rows * 3D floats per wavefront
+    const int w3 = 3 * D, dd = D * D;
+    const float inv_w3 = 1.0f / (float)w3, inv_D = 1.0f / (float)D, inv_dd = 1.0f / (float)dd;
+    const float* lsrc = lin + base * w3;
+    const float* asrc = ang + base * w3;
+    auto put = [&](int k, float lv, float av) {            // element k of the wavefront's run -> its place in the tile
+        const int s = trk_div_small(k, w3, inv_w3), e = k - s * w3, row = trk_div_small(e, D, inv_D), d = e - row * D;
+        jt[s * js + row * DP + d] = lv;
+        jt[s * js + (3 + row) * DP + d] = av;
+    };
+    if (rows == TRK_WAVE && ((reinterpret_cast<uintptr_t>(lsrc) | reinterpret_cast<uintptr_t>(asrc)) & 15) == 0) {
+        // 64 * 3D floats = 48 D float4 per array: all of a lane's 16-byte loads are issued before the first LDS write
+        const int nv = 48 * D;                              // float4 count (64 * 3D / 4)
+        for (int v0 = lane; v0 < nv; v0 += TRK_WAVE * 4) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = v0 + TRK_WAVE * j;
+                if (v < nv) { a[j] = reinterpret_cast<const float4*>(lsrc)[v]; b[j] = reinterpret_cast<const float4*>(asrc)[v]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = v0 + TRK_WAVE * j;
+                if (v < nv) { put(4 * v, a[j].x, b[j].x); put(4 * v + 1, a[j].y, b[j].y); put(4 * v + 2, a[j].z, b[j].z); put(4 * v + 3, a[j].w, b[j].w); }
+            }
+        }
+    } else {
+        for (int k = lane; k < rows * w3; k += TRK_WAVE) put(k, lsrc[k], asrc[k]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float* mine = jt + lane * js;
+    float* out = ot + lane * os;
+    if (!MFMA) {
+        for (int i = 0; i < D; ++i)
+            for (int j = i; j < D; ++j) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc = fmaf(mine[k * DP + i], mine[k * DP + j], acc);
+                out[i * D + j] = acc; out[j * D + i] = acc;
+            }
+    } else {
+        // lane l of the instruction: block b = l / 4 (16 blocks), element e = l % 4.  Block b belongs to sample 4 g + b / 4 of
+        // the wavefront and is tile (bi, bj) = ((b % 4) / 2, b % 2) of that sample's 8 x 8 matrix.  Operand A carries
+        // J[k][4 bi + e], operand B J[k][4 bj + e]; accumulator register r then holds JtJ[4 bi + r][4 bj + e].
+        const int b = lane >> 2, e = lane & 3, bi = (b & 3) >> 1, bj = b & 1;
+        for (int g = 0; g < TRK_WAVE / 4; ++g) {
+            const float* src = jt + (4 * g + (b >> 2)) * js;
+            trk_v4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(src[k * 8 + 4 * bi + e], src[k * 8 + 4 * bj + e], acc, 0, 0, 0);
+            float* dst = ot + (4 * g + (b >> 2)) * os;
+            const int col = 4 * bj + e;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * bi + r;
+                if (row < D && col < D) dst[row * D + col] = acc[r];
+            }
+        }
+    }
+    if (Jtr) {
+        float rv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rv[k] = (r6 && lane < rows) ? r6[(base + lane) * 6 + k] : 0.0f;
+        for (int i = 0; i < D; ++i) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc = fmaf(mine[k * DP + i], rv[k], acc);
+            out[D * D + i] = acc;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* jdst = JtJ + base * dd;
+    auto get = [&](int k) { const int s = trk_div_small(k, dd, inv_dd); return ot[s * os + (k - s * dd)]; };
+    if (rows == TRK_WAVE && (reinterpret_cast<uintptr_t>(jdst) & 15) == 0) {
+        for (int v = lane; v < 16 * dd; v += TRK_WAVE)     // 64 * D^2 floats = 16 D^2 float4
+            reinterpret_cast<float4*>(jdst)[v] = make_float4(get(4 * v), get(4 * v + 1), get(4 * v + 2), get(4 * v + 3));
+    } else {
+        for (int k = lane; k < rows * dd; k += TRK_WAVE) jdst[k] = get(k);
+    }
+    if (Jtr) for (int k = lane; k < rows * D; k += TRK_WAVE) { const int s = trk_div_small(k, D, inv_D); Jtr[base * D + k] = ot[s * os + dd + (k - s * D)]; }
+}
+
 // out[n, :] = g[n, :] * s[n]: the chain rule of the fused rollout under autograd -- its saved d cost[n] / d q[n, :] times the
 // upstream gradient of cost[n] (tasks.py:135-137 followed by .backward()).  fp32 or fp16 rows, fp32 scale; one thread per element.
 template <class IO>
@@ -2030,6 +2147,16 @@ void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int 
     if (gathered) hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)T), dim3(128), 0, st, x, H * S, inner > 0 ? 2 : 1, idx, inner, gathered);
 }
 
+int trk_launch_jtj(int mfma, const float* lin, const float* ang, const float* r6, int64_t n, int D, float* JtJ, float* Jtr, hipStream_t st) {
+    if (mfma && D > 8) return -1;
+    const size_t lds = sizeof(float) * TRK_JTJ_WAVES * TRK_WAVE * (((size_t)(6 * (mfma ? 8 : D)) | 1) + ((size_t)(D * D + D) | 1));
+    if (lds > 160 * 1024) return -1;
+    const dim3 grid(grid_for(n, TRK_JTJ_WAVES * TRK_WAVE)), block(TRK_JTJ_WAVES * TRK_WAVE);
+    if (mfma) hipLaunchKernelGGL(k_jtj<true>, grid, block, lds, st, lin, ang, r6, n, D, JtJ, Jtr);
+    else hipLaunchKernelGGL(k_jtj<false>, grid, block, lds, st, lin, ang, r6, n, D, JtJ, Jtr);
+    return 0;
+}
+
 void trk_launch_grid_pack(const float* sdf, const float* grad, int64_t n, float4* cells, hipStream_t st) {
     hipLaunchKernelGGL(k_grid_pack, dim3(grid_for(n, 256)), dim3(256), 0, st, sdf, grad, n, cells);
 }
@@ -2095,6 +2222,7 @@ int trk_kernels_init(void) {
     TRK_SET(k_fk_analytic_jacobian); TRK_SET(k_ik_step);
     TRK_SET((k_gp_prior<float, true>)); TRK_SET((k_gp_prior<float, false>));
     TRK_SET((k_gp_prior<_Float16, true>)); TRK_SET((k_gp_prior<_Float16, false>));
+    TRK_SET(k_jtj<true>); TRK_SET(k_jtj<false>);
 #undef TRK_SET
     return e == hipSuccess ? 0 : -1;
 }

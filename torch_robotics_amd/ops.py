@@ -1050,6 +1050,26 @@ def traj_validate(waypoint_collisions: torch.Tensor, trajs: torch.Tensor, n_dofs
     return r
 
 
+def jtj(lin_jac: torch.Tensor, ang_jac: torch.Tensor, residual: Optional[torch.Tensor] = None, mfma: bool = False):
+    """Normal equations of the geometric Jacobian (robot_tree.py:238-246): lin_jac, ang_jac (N, 3, D) [+ residual (N, 6)] ->
+    JtJ (N, D, D) [, Jtr (N, D)] with J = [lin_jac; ang_jac].  mfma=True runs the matrix-core kernel (D <= 8)."""
+    lin, ang = _dev_f32(lin_jac, "jtj(lin_jac)"), _dev_f32(ang_jac, "jtj(ang_jac)")
+    if lin.dim() != 3 or lin.shape[1] != 3 or ang.shape != lin.shape:
+        raise ValueError("jtj: lin_jac and ang_jac must both be (N, 3, D)")
+    n, D = int(lin.shape[0]), int(lin.shape[2])
+    res = None
+    if residual is not None:
+        res = _dev_f32(residual, "jtj(residual)")
+        if tuple(res.shape) != (n, 6):
+            raise ValueError("jtj: residual must be (N, 6)")
+    JtJ = torch.empty((n, D, D), device=lin.device, dtype=torch.float32)
+    Jtr = torch.empty((n, D), device=lin.device, dtype=torch.float32) if res is not None else None
+    with _on(lin.device):
+        check(lib().trk_jtj(lin.data_ptr(), ang.data_ptr(), _ptr(res), n, D, int(bool(mfma)), JtJ.data_ptr(), _ptr(Jtr), _stream(lin)),
+              "trk_jtj")
+    return (JtJ, Jtr) if res is not None else JtJ
+
+
 def scale_rows(g: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     """g (..., D) fp32 / fp16 times scale (...) per row -> new tensor like g: the backward of the fused rollout's cost output.
     A scale that is one value expanded over the rows (what `.sum().backward()` hands down) is read as a scalar in the kernel."""
