@@ -334,3 +334,74 @@ def test_ik_loop_full_size(ops):
     assert float(((qa - qc).abs() < 1e-4).float().mean()) > 0.999
     assert abs(float(la1.mean()) - float(lc1.mean())) < 1e-3 * float(la1.mean())
     assert float((la1 < la0).float().mean()) > 0.99
+
+
+@pytest.mark.parametrize("scene", ["grid", "shelf", "maze"])
+def test_panda_full_size_other_scenes(ops, oracle_lib, scene):
+    """BASELINE configs[1] at 4096 x 64 on the scenes SURVEY 8(d) names next to the analytic spheres: the 200^3 voxel SDF of the
+    same spheres, EnvTableShelf and EnvMazeBoxes3D (boxes in posed objects).  Size-independent properties + an fp64-oracle subset."""
+    robot = tra.RobotPanda(tensor_args=TA)
+    env = {"grid": lambda: tra.EnvSpheres3D(precompute_sdf_obj_fixed=True, sdf_cell_size=0.01, tensor_args=TA),
+           "shelf": lambda: tra.EnvTableShelf(tensor_args=TA), "maze": lambda: tra.EnvMazeBoxes3D(tensor_args=TA)}[scene]()
+    task = tra.PlanningTask(env=env, robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5)
+    task.set_ee_target(Ht)
+    B, H = 4096, 64
+    n = B * H
+    q = robot.random_q(n, generator=torch.Generator(device=DEV).manual_seed(77)).reshape(B, H, 7).contiguous()
+    model, cm = task._fused_handles(DEV)
+    assert model.specialized
+    if scene == "grid":
+        assert tuple(env.grid_map_sdf_obj_fixed.sdf_tensor.shape) == (200, 200, 200)
+    w = (1.0, 1.0, 1.0, 1.0)
+    sums = torch.zeros(ops.n_blocks(n), **TA)
+    pos, cost, gq = ops.rollout_cost_grad(model, cm, w, q, cost_sum=sums)
+    assert torch.isfinite(pos).all() and torch.isfinite(cost).all() and torch.isfinite(gq).all()
+    # determinism; a checksum of checksums (per-wavefront sums == per-trajectory costs == the total)
+    pos2, cost2, gq2 = ops.rollout_cost_grad(model, cm, w, q)
+    assert torch.equal(pos, pos2) and torch.equal(cost, cost2) and torch.equal(gq, gq2)
+    assert torch.allclose(sums, cost.sum(1), rtol=2e-5, atol=1e-3)
+    assert abs(ops.reduce_sum(sums).item() - cost.double().sum().item()) <= 1e-5 * abs(cost.double().sum().item())
+    # linearity in the weights: cost(w) = sum_k w_k cost(e_k), same for the gradient
+    acc_c, acc_g = torch.zeros_like(cost, dtype=torch.float64), torch.zeros_like(gq, dtype=torch.float64)
+    for k, wk in enumerate((0.5, 2.0, 0.25, 1.5)):
+        e = [0.0, 0.0, 0.0, 0.0]; e[k] = 1.0
+        _, c_k, g_k = ops.rollout_cost_grad(model, cm, e, q, want_pos=False)
+        acc_c += wk * c_k.double(); acc_g += wk * g_k.double()
+    _, c_w, g_w = ops.rollout_cost_grad(model, cm, (0.5, 2.0, 0.25, 1.5), q, want_pos=False)
+    assert rel_err(c_w.cpu().numpy(), acc_c.cpu().numpy()) < 1e-5 and rel_err(g_w.cpu().numpy(), acc_g.cpu().numpy()) < 1e-5
+    # sharding invariance: any contiguous block of trajectories evaluated alone gives the same bits
+    for lo, hi in ((0, 512), (1000, 1003), (4095, 4096)):
+        p_s, c_s, g_s = ops.rollout_cost_grad(model, cm, w, q[lo:hi].contiguous())
+        assert torch.equal(p_s, pos[lo:hi]) and torch.equal(c_s, cost[lo:hi]) and torch.equal(g_s, gq[lo:hi])
+    # generated == table-driven kernel to fp32 rounding (the same function through two code paths); the gradient jumps at SDF kinks
+    # (box faces / edges, arg-min ties, voxel boundaries), where the two roundings may take different branches: a handful of samples
+    model.enable_specialized(False)
+    idx = torch.arange(0, B, 16, device=DEV)
+    _, c_t, g_t = ops.rollout_cost_grad(model, cm, w, q[idx].contiguous(), want_pos=False)
+    model.enable_specialized(True)
+    # (a link within fp32 rounding of a voxel boundary reads the neighbouring cell in one of the two kernels: the VALUE jumps too)
+    bad_c = ((c_t - cost[idx]).abs() > 2e-5 * cost.abs().max()).sum().item()
+    assert bad_c <= (idx.numel() * H // 2000 if scene == "grid" else 0), bad_c
+    bad = ((g_t - gq[idx]).abs().amax(-1) > 2e-4 * gq.abs().max()).sum().item()
+    assert bad <= idx.numel() * H // 2000, bad
+    # boolean fields: fused == positions + field kernel; monotone in the margin
+    fields = FIELD_OBJECTS | FIELD_WS | FIELD_SELF
+    c_def = ops.rollout_collision(model, cm, fields, q)
+    two_step = ops.collision_fields(cm, fields, pos.reshape(-1, 11, 3)).reshape(B, H).bool()
+    assert (c_def != two_step).sum().item() <= 4
+    c0, c1 = ops.rollout_collision(model, cm, fields, q, margin=0.0), ops.rollout_collision(model, cm, fields, q, margin=0.05)
+    assert not (c0 & ~c1).any() and 0 < int(c0.sum()) < n
+    # fp64 oracle on a random subset (the grid's host copy for the oracle)
+    spec = task.build_cost_spec()
+    if spec.grid is not None:
+        spec.grid = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in spec.grid.items()}
+    o = oracle_lib.Oracle(robot.diff_panda._kin, spec)
+    sub = np.random.default_rng(5).choice(n, 1024, replace=False)
+    p64, c64, g64 = o.rollout(q.reshape(-1, 7)[sub].cpu().numpy().astype(np.float64), w, "f64")
+    assert np.abs(pos.reshape(-1, 11, 3)[sub].cpu().numpy() - p64).max() < 2e-6
+    # a link within fp32 rounding of a voxel boundary / box face reads the neighbouring cell or branch: allow a few such samples
+    dc = np.abs(cost.reshape(-1)[sub].cpu().numpy() - c64)
+    assert (dc > 1e-5 * np.abs(c64).max()).sum() <= 4
+    dg = np.abs(gq.reshape(-1, 7)[sub].cpu().numpy() - g64).max(1)
+    assert (dg > 1e-4 * np.abs(g64).max()).sum() <= 8
