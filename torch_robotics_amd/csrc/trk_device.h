@@ -583,15 +583,74 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
         }
     }
     if (FAST) return;
-    // objects that still have non-sphere primitives (boxes): empty loop for sphere-only scenes
+    // objects that still have non-sphere primitives (boxes): empty loop for sphere-only scenes.
+    // Per object and point, the primitive loop computes VALUES only and carries the winner's offset d and u = |d| - half + r along
+    // (six selects instead of a gradient per primitive); the gradient is formed once, for the winner (primitives.py:327-334:
+    // only the arg-min primitive passes a gradient).  Point by point on purpose: the winner's eight registers are live across
+    // the primitive loop, and with all NL points in flight at once the Panda kernel no longer fitted its 128 registers (57
+    // spills in the sphere-scene hot path as well: 10 -> 19.7 us).
     for (int b = 0; b < C.n_box_objects; ++b) {
         const int o = cptr(C.box_objects)[b];
+        const DevObj O = load_obj(C.objects, o);
+        const bool ident = (O.identity & TRK_OBJ_IDENTITY) != 0;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
+            float lx, ly, lz;
+            {
+                const float dx = px[l] - O.pos[0], dy = py[l] - O.pos[1], dz = pz[l] - O.pos[2];
+                if (ident) { lx = dx; ly = dy; lz = dz; }
+                else {
+                    lx = fmaf(O.R[0], dx, fmaf(O.R[3], dy, O.R[6] * dz));
+                    ly = fmaf(O.R[1], dx, fmaf(O.R[4], dy, O.R[7] * dz));
+                    lz = fmaf(O.R[2], dx, fmaf(O.R[5], dy, O.R[8] * dz));
+                }
+            }
+            float bv = __builtin_inff(), bdx = 0.0f, bdy = 0.0f, bdz = 0.0f, bux = 0.0f, buy = 0.0f, buz = 0.0f, bsharp = 0.0f;
+            for (int pi = O.prim_begin; pi < O.prim_end; ++pi) {
+                const DevPrim P = load_prim(C.prims, pi);
+                if (P.type == TRK_PRIM_SPHERE) continue;                     // spheres live in the merged table above
+                const bool sharp = P.type == TRK_PRIM_SHARP_BOX;             // wave-uniform; P.r == 0 for sharp boxes
+                const float dx = lx - P.cx, dy = ly - P.cy, dz = lz - P.cz;
+                const float ux = __builtin_fabsf(dx) - P.hx + P.r, uy = __builtin_fabsf(dy) - P.hy + P.r, uz = __builtin_fabsf(dz) - P.hz + P.r;
+                const float mu = __builtin_fmaxf(__builtin_fmaxf(ux, uy), uz);
+                float v = mu;
+                if (!sharp) {
+                    const float rx = __builtin_fmaxf(ux, 0.0f), ry = __builtin_fmaxf(uy, 0.0f), rz = __builtin_fmaxf(uz, 0.0f);
+                    v = __builtin_fminf(mu, 0.0f) + trk_sqrt(fmaf(rx, rx, fmaf(ry, ry, rz * rz))) - P.r;
+                }
+                const bool take = v < bv;
+                bv = take ? v : bv;
+                bdx = take ? dx : bdx; bdy = take ? dy : bdy; bdz = take ? dz : bdz;
+                bux = take ? ux : bux; buy = take ? uy : buy; buz = take ? uz : buz;
+                bsharp = take ? (sharp ? 1.0f : 0.0f) : bsharp;
+            }
+            if (!(bv < s[l])) continue;                                   // this object does not beat the scene's best for this point
+            // gradient of the winning box in the object frame (prim_sdf's formulas): arg-max with "first maximum wins"
+            int am = 0; float mu = bux;
+            if (buy > mu) { mu = buy; am = 1; }
+            if (buz > mu) { mu = buz; am = 2; }
+            const float sx = bdx > 0.0f ? 1.0f : (bdx < 0.0f ? -1.0f : 0.0f);
+            const float sy = bdy > 0.0f ? 1.0f : (bdy < 0.0f ? -1.0f : 0.0f);
+            const float sz = bdz > 0.0f ? 1.0f : (bdz < 0.0f ? -1.0f : 0.0f);
             float ax, ay, az;
-            const float v = object_sdf<false, true>(C, o, px[l], py[l], pz[l], ax, ay, az);
-            const bool take = v < s[l];
-            s[l] = take ? v : s[l]; gx[l] = take ? ax : gx[l]; gy[l] = take ? ay : gy[l]; gz[l] = take ? az : gz[l];
+            if (bsharp != 0.0f) {
+                ax = am == 0 ? sx : 0.0f; ay = am == 1 ? sy : 0.0f; az = am == 2 ? sz : 0.0f;
+            } else {
+                const float rx = __builtin_fmaxf(bux, 0.0f), ry = __builtin_fmaxf(buy, 0.0f), rz = __builtin_fmaxf(buz, 0.0f);
+                const float nn = trk_sqrt(fmaf(rx, rx, fmaf(ry, ry, rz * rz)));
+                const float inv = nn > 0.0f ? trk_rcp(nn) : 0.0f;
+                const float inside = mu < 0.0f ? 1.0f : 0.0f;
+                ax = (rx * inv + (am == 0 ? inside : 0.0f)) * sx;
+                ay = (ry * inv + (am == 1 ? inside : 0.0f)) * sy;
+                az = (rz * inv + (am == 2 ? inside : 0.0f)) * sz;
+            }
+            s[l] = bv;
+            if (ident) { gx[l] = ax; gy[l] = ay; gz[l] = az; }
+            else {
+                gx[l] = fmaf(O.R[0], ax, fmaf(O.R[1], ay, O.R[2] * az));
+                gy[l] = fmaf(O.R[3], ax, fmaf(O.R[4], ay, O.R[5] * az));
+                gz[l] = fmaf(O.R[6], ax, fmaf(O.R[7], ay, O.R[8] * az));
+            }
         }
     }
     // precomputed voxel grid (kept out of the loop above: its index arithmetic is loop-invariant and the
