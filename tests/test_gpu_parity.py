@@ -1186,7 +1186,8 @@ def test_randomised_generated_vs_table_driven_and_oracle(ops, oracle_lib, ident)
     kin.set_base_pose(np.array([0, 0, 0, 1, 0, 0, 0], np.float32))
 
 
-def test_interpolated_link_points(ops, oracle_lib):
+@pytest.mark.parametrize("generated", [False, True], ids=["table_driven", "generated"])
+def test_interpolated_link_points(ops, oracle_lib, generated):
     """interpolate_link_pos (distance_fields.py:66-69, 145-147): the fields on points interpolated along the selected links --
     virtual columns of the cost model, evaluated (and their adjoints scattered back) inside the field kernels and the fused
     rollout -- against the reference's field code on interpolate_points_v1 of the links (goldens) and the fp64 oracle."""
@@ -1198,6 +1199,13 @@ def test_interpolated_link_points(ops, oracle_lib):
     h, cm, o = ops.ModelHandle(m), ops.CostHandle(spec, DEV), oracle_lib.Oracle(m, spec)
     pos = dev(robot["fk_map_collision"].reshape(-1, 11, 3))
     qg = dev(g["q"].reshape(-1, 7))
+    if generated:
+        # a unit with THIS interpolation table baked in (the lerp of two link registers, the adjoint scattered back to them)
+        from torch_robotics_amd import jit
+        assert jit.specialize_for_cost_spec(m, spec) is not None and jit.has_matching_unit(m, spec)
+    else:
+        h.enable_specialized(False)
+        cm.enable_specialized(False)
     for fname, fl, w in (("self", FIELD_SELF, (1, 0, 0, 0)), ("objects", FIELD_OBJECTS, (0, 1, 0, 0)), ("ws", FIELD_WS, (0, 0, 1, 0))):
         c, gp = ops.cost_fields(cm, fl, pos, want_grad=True)
         assert gp.shape == (64, 11, 3)                              # gradients come back on the REAL columns
@@ -1214,7 +1222,12 @@ def test_interpolated_link_points(ops, oracle_lib):
         assert np.array_equal(ops.rollout_collision(h, cm, fl, qg).cpu().numpy(), g[f"coll_{fname}"].reshape(-1)), fname
     _, c, gq = ops.rollout_cost_grad(h, cm, (1, 1, 1, 0), qg)
     assert rel_err(c.cpu().numpy(), g["cost_total"].reshape(-1)) < TOL_C and grad_close(gq.cpu().numpy(), g["gq_total"].reshape(-1, 7))
-    assert not h.specialized or True                               # a generated unit exists for the Panda, but none serves virtual columns
+    if generated:       # the generated and the table-driven kernels are the same function through two code paths
+        h2, cm2 = ops.ModelHandle(m), ops.CostHandle(spec, DEV)
+        h2.enable_specialized(False)
+        _, c_t, g_t = ops.rollout_cost_grad(h2, cm2, (1, 1, 1, 1), qg)
+        _, c_g, g_g = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), qg)
+        assert rel_err(c_g.cpu().numpy(), c_t.cpu().numpy()) < TOL_C and grad_close(g_g.cpu().numpy(), g_t.cpu().numpy())
     rng = np.random.default_rng(11)
     for n in (1, 63, 1000):
         q = rng.uniform(-3.0, 3.9, (n, 7)).astype(np.float32)

@@ -183,6 +183,9 @@ class CollisionTemplate:
     self_pairs: List[Tuple[int, int]] = field(default_factory=list)   # LINK indices (a, b)
     ee_link: int = -1
     ee2_link: int = -1          # second tracked link (two-arm scenes), same weights
+    # interpolate_link_pos (distance_fields.py:66-69, 145-147): virtual columns L + v = w0 * link src0 + w1 * link src1, which
+    # obj_links / self_pairs may name like links (rows: src0, src1, w0, w1 -- costmodel.interpolation_table)
+    virtual: List[Tuple[int, int, float, float]] = field(default_factory=list)
 
 
 def panda_template(kin: KinModel) -> CollisionTemplate:
@@ -360,7 +363,33 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     masked = _masked_factory(kin)
     tracked = [(l, tgt, rb) for l, tgt, rb in ((tmpl.ee_link, "A.C.ee_target", "eeRb"), (tmpl.ee2_link, "A.C.ee2_target", "ee2Rb"))
                if l >= 0]
-    adj_links = sorted(set(tmpl.obj_links) | {a for p in tmpl.self_pairs for a in p} | {l for l, _, _ in tracked})
+    virt = {L + v: row for v, row in enumerate(tmpl.virtual)}          # virtual column -> (src0, src1, w0, w1)
+    used = set(tmpl.obj_links) | {a for p in tmpl.self_pairs for a in p}
+    assert all(i < L + len(virt) for i in used), "collision column out of range"
+    used_virt = sorted(i for i in used if i >= L)
+    # every column that can receive a position adjoint: the real links among them go to the reverse pass, the virtual ones
+    # hand theirs to their two source links first
+    adj_links = sorted(used | {l for l, _, _ in tracked} | {src for i in used_virt for src in virt[i][:2]})
+    real_adj = [i for i in adj_links if i < L]
+
+    def with_virtual(E, t):
+        """t extended by the interpolated points this template uses (named temporaries: w0 * p_src0 + w1 * p_src1)"""
+        if not used_virt:
+            return t
+        t = dict(t)
+        for i in used_virt:
+            s0, s1, w0, w1 = virt[i]
+            t[i] = [E.named(E.lincomb([(t[s0][k], S(float(np.float32(w0)))), (t[s1][k], S(float(np.float32(w1))))])) for k in range(3)]
+        return t
+
+    def scatter_virtual(E, indent="    "):
+        """adjoint of an interpolated point -> its two source links, with its weights"""
+        for i in used_virt:
+            s0, s1, w0, w1 = virt[i]
+            for src, w in ((s0, w0), (s1, w1)):
+                if float(np.float32(w)) != 0.0:
+                    E.raw(f"{indent}tb{src}_0 = fmaf({flit(float(np.float32(w)))}, tb{i}_0, tb{src}_0); tb{src}_1 = fmaf({flit(float(np.float32(w)))}, tb{i}_1, tb{src}_1); "
+                          f"tb{src}_2 = fmaf({flit(float(np.float32(w)))}, tb{i}_2, tb{src}_2);")
     out: List[str] = []
     out.append(f"// GENERATED by torch_robotics_amd/codegen.py for model '{kin.name}' ({L} links, {D} DOF) -- do not edit.")
     # Value-changing-but-bounded FP freedoms for this unit (NOT finite-math-only): reassociation + contraction turn
@@ -394,6 +423,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    float cost = 0.0f;")
         for i in adj_links:
             E.raw(f"    float tb{i}_0 = 0.0f, tb{i}_1 = 0.0f, tb{i}_2 = 0.0f;")
+        t = with_virtual(E, t)
         if 0 < NL <= LINK_OBJ_GROUP_MAX:
             for k, nm in enumerate("xyz"):
                 E.raw(f"    const float p{nm}[NL] = {{{', '.join(E.expr(t[i][k]) for i in tmpl.obj_links)}}};")
@@ -439,11 +469,13 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], {pa}, {pb}, "
                       f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2, (A.C.clamp_fields & TRK_FIELD_SELF) != 0);")
             E.raw("    }")
+        scatter_virtual(E)
 
     def emit_boolean_fields(E, t):
         """`hit` = OR of the selected fields' "signed distance < margin" tests on link positions t[i][k] (k_coll after its FK walk,
         k_collf on the caller's positions)"""
         E.raw("    bool hit = false;")
+        t = with_virtual(E, t)
         if NL > 0:
             grp_size = NL if NL <= LINK_OBJ_GROUP_MAX else -(-NL // (-(-NL // LINK_OBJ_GROUP)))
             E.raw("    if (A.coll_fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) {")
@@ -614,7 +646,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # ---------------- reverse: wrench accumulators towards the root ----------------
         # (A second FK walk with prefix-sum gradients instead of this reverse pass -- so that the joints' axes / origins need not
         # stay alive -- was measured on UR10+Allegro: 41.3 vs 37.5 us.  These kernels are bound by VALU issue, not by occupancy.)
-        gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"tb{i}_{k}" for k in range(3)] for i in adj_links},
+        gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"tb{i}_{k}" for k in range(3)] for i in real_adj},
                                       {l: rb for l, _, rb in tracked}, masked, tick=tick_line, order=walk)
         E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
         E.raw(f"    flush.template rest<{next_chunk[0]}>();")
@@ -785,7 +817,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("        const float sc = (A.fld_gcost && lane < rows) ? A.fld_gcost[base + lane] : 1.0f;")
         gl = []
         for i in range(L):
-            gl += [f"sc * tb{i}_{k}" if i in adj_links else "0.0f" for k in range(3)]
+            gl += [f"sc * tb{i}_{k}" if i in real_adj else "0.0f" for k in range(3)]
         E.raw(f"        const float gv[{3 * L}] = {{{', '.join(gl)}}};")
         E.raw(f"        spec_store_gq<{3 * L}>(A.fld_g, base, rows, lane, lds, gv);")
         E.raw("    }")
@@ -1112,6 +1144,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     pairs = ", ".join(f"{a}, {b}" for a, b in tmpl.self_pairs) or "0"
     out.append(f"static const int32_t kObjLinks[] = {{{obj}}};")
     out.append(f"static const int32_t kSelfPairs[] = {{{pairs}}};")
+    vsrc = ", ".join(f"{r[0]}, {r[1]}" for r in tmpl.virtual) or "0"
+    vw = ", ".join(f"{flit(float(np.float32(r[2])))}, {flit(float(np.float32(r[3])))}" for r in tmpl.virtual) or "0.0f"
+    out.append(f"static const int32_t kVirtualSrc[] = {{{vsrc}}};")
+    out.append(f"static const float kVirtualW[] = {{{vw}}};")
     out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     if chunked:
@@ -1185,7 +1221,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
                f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}, "
-               f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1, {'launch_fields' if fields_ok else 'nullptr'}}};")
+               f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1, {'launch_fields' if fields_ok else 'nullptr'}, "
+               f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"
@@ -1650,7 +1687,8 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     phash = 0 if link_mode else points_hash(pt.point_link, pt.point_offset)
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, {kin.n_links}, {kin.n_dofs}, {len(pt.obj_cols)}, kObjCols, "
                f"{len(pt.self_pairs)}, kSelfPairs, {pt.ee_link}, \"{ident}\", launch, {n_points}, "
-               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};")
+               f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, "
+               f"0, nullptr, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return out

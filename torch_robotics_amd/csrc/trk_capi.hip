@@ -117,12 +117,19 @@ struct TrkCostModel {
     float4* d_cells = nullptr;           // the voxel grid as (gx, gy, gz, sdf) records (a copy of the caller's two arrays)
     std::vector<int32_t> obj_link_idx;   // host copies, to match a specialised kernel's baked link sets
     std::vector<int32_t> self_pairs;     // mapped to link indices
+    std::vector<int32_t> virtual_src;    // host copies of the interpolated-column table (a generated unit must bake the same one)
+    std::vector<float> virtual_w;
     bool spec_enabled = true;            // trk_cost_model_enable_specialized: may trk_cost_fields use a generated unit's field kernel
 };
 
 static bool spec_matches(const SpecEntry* e, const TrkCostModel* cm, const TrkRolloutWeights* w) {
-    // interpolated (virtual) columns and the single-link self distance exist only in the table-driven kernels
-    if (cm->hdr.n_virtual > 0 || (cm->hdr.self_single && w->w_self != 0.0f)) return false;
+    // the single-link self distance exists only in the table-driven kernels; interpolated (virtual) columns need a unit that
+    // bakes exactly this table (attached-point units bake none)
+    if (cm->hdr.self_single && w->w_self != 0.0f) return false;
+    if (cm->hdr.n_virtual != e->n_virtual) return false;
+    if (e->n_virtual > 0 && (!std::equal(cm->virtual_src.begin(), cm->virtual_src.end(), e->virtual_src) ||
+                             std::memcmp(cm->virtual_w.data(), e->virtual_w, sizeof(float) * 2 * e->n_virtual) != 0))
+        return false;
     bool ok = true;
     if (w->w_obj != 0.0f || w->w_ws != 0.0f)
         ok = ok && (int)cm->obj_link_idx.size() == e->n_obj_links &&
@@ -927,6 +934,10 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     h.self_margin = reinterpret_cast<const float*>(base + o_sm);
     cm->obj_link_idx.assign(d->obj_link_idx, d->obj_link_idx + d->n_obj_links);
     cm->self_pairs.assign(sp, sp + 2 * d->n_self_pairs);
+    if (d->n_virtual) {
+        cm->virtual_src.assign(d->virtual_src, d->virtual_src + 2 * d->n_virtual);
+        cm->virtual_w.assign(d->virtual_w, d->virtual_w + 2 * d->n_virtual);
+    }
     h.spheres = reinterpret_cast<const float4*>(base + o_sph);
     h.spheres_sel = reinterpret_cast<const float4*>(base + o_sel);
     h.box_objects = reinterpret_cast<const int32_t*>(base + o_box);

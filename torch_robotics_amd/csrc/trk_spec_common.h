@@ -80,7 +80,7 @@ typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 16)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 17)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -107,6 +107,11 @@ struct SpecEntry {
     SpecIkLaunchFn launch_ik;   // Adam IK iterations on ee_link, configurations and optimiser state in registers; nullptr if not generated
     SpecLaunchFn launch_fk1;    // FK matrix of one link (jac_link, jac_p_end) -> fk_H [N,4,4]; nullptr if not generated
     SpecLaunchFn launch_fields; // collision fields on given link positions (trk_cost_fields); nullptr if not generated
+    // interpolated link points baked into the unit (interpolate_link_pos): column n_links + v = w[2v] * link src[2v] +
+    // w[2v+1] * link src[2v+1]; obj_link_idx / self_pairs may name them.  A cost model matches only with the same table.
+    int32_t n_virtual;
+    const int32_t* virtual_src; // [2 * n_virtual]
+    const float* virtual_w;     // [2 * n_virtual]
 };
 
 // registry filled by static initialisers of the generated translation units

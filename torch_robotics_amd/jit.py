@@ -44,6 +44,9 @@ def template_hash(tmpl: codegen.CollisionTemplate) -> str:
     h.update(np.asarray(tmpl.obj_links, np.int32).tobytes())
     h.update(np.asarray(tmpl.self_pairs, np.int32).reshape(-1).tobytes())
     h.update(np.asarray([tmpl.ee_link, tmpl.ee2_link], np.int32).tobytes())
+    if tmpl.virtual:
+        h.update(np.asarray([r[:2] for r in tmpl.virtual], np.int32).tobytes())
+        h.update(np.asarray([r[2:] for r in tmpl.virtual], np.float32).tobytes())
     return h.hexdigest()[:8]
 
 
@@ -119,12 +122,12 @@ def build_unit(kin: KinModel, tmpl: codegen.CollisionTemplate, verbose: bool = F
 
 
 def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tuple[int, int]] = (), ee_link: int = -1,
-               verbose: bool = False, pipeline: bool = False, ee2_link: int = -1) -> str:
+               verbose: bool = False, pipeline: bool = False, ee2_link: int = -1, virtual=()) -> str:
     """Make sure a generated fused kernel for (kin, collision template) is registered with libtrk.so.  Idempotent.
     Returns the unit's identifier.  Robots that already have an ahead-of-time unit with the same template need nothing."""
     tmpl = codegen.CollisionTemplate(obj_links=[int(i) for i in obj_links],
                                      self_pairs=[(int(a), int(b)) for a, b in self_pairs], ee_link=int(ee_link),
-                                     ee2_link=int(ee2_link))
+                                     ee2_link=int(ee2_link), virtual=[tuple(r) for r in virtual])
     ident = unit_ident(kin, tmpl, pipeline)
     if ident not in _loaded:
         _loaded[ident] = _load_unit(build_unit(kin, tmpl, verbose, pipeline), ident)
@@ -132,10 +135,16 @@ def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tup
     return ident
 
 
-def generatable(spec) -> bool:
-    """False for cost models only the table-driven kernels evaluate (the dispatcher's rule, trk_capi.hip: spec_matches):
-    interpolated (virtual) position columns and the single-link self distance (a degenerate pair)."""
-    if len(np.asarray(getattr(spec, "virtual_src", ())).reshape(-1)) > 0:
+def _virtual_rows(spec):
+    src = np.asarray(getattr(spec, "virtual_src", ()), np.int32).reshape(-1, 2)
+    w = np.asarray(getattr(spec, "virtual_w", ()), np.float32).reshape(-1, 2)
+    return [(int(a), int(b), float(wa), float(wb)) for (a, b), (wa, wb) in zip(src, w)]
+
+
+def generatable(spec, points: bool = False) -> bool:
+    """False for cost models only the table-driven kernels evaluate (the dispatcher's rule, trk_capi.hip: spec_matches): the
+    single-link self distance (a degenerate pair) and -- for attached-point units -- interpolated (virtual) position columns."""
+    if points and _virtual_rows(spec):
         return False
     sl = np.asarray(spec.self_link_idx, np.int32)
     return not any(int(sl[a]) == int(sl[b]) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2))
@@ -147,12 +156,14 @@ def _template_of(kin: KinModel, spec) -> Optional[codegen.CollisionTemplate]:
     sl = np.asarray(spec.self_link_idx, np.int32)
     pairs = [(int(sl[a]), int(sl[b])) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2)]
     return codegen.CollisionTemplate(obj_links=[int(i) for i in spec.obj_link_idx], self_pairs=pairs,
-                                     ee_link=int(spec.ee_link), ee2_link=int(spec.ee2_link))
+                                     ee_link=int(spec.ee_link), ee2_link=int(spec.ee2_link), virtual=_virtual_rows(spec))
 
 
 def _serves(unit: codegen.CollisionTemplate, want: codegen.CollisionTemplate) -> bool:
     """the dispatcher's rule (trk_capi.hip: spec_matches) for a caller that may use every weight"""
     if list(unit.obj_links) != list(want.obj_links) or [tuple(p) for p in unit.self_pairs] != [tuple(p) for p in want.self_pairs]:
+        return False
+    if [tuple(np.float32(v) for v in r) for r in unit.virtual] != [tuple(np.float32(v) for v in r) for r in want.virtual]:
         return False
     return want.ee_link < 0 or (unit.ee_link == want.ee_link and unit.ee2_link == want.ee2_link)
 
@@ -183,7 +194,8 @@ def specialize_for_cost_spec(kin: KinModel, spec, verbose: bool = False) -> Opti
         return None
     sl = np.asarray(spec.self_link_idx, np.int32)
     pairs = [(int(sl[a]), int(sl[b])) for a, b in np.asarray(spec.self_pairs, np.int32).reshape(-1, 2)]
-    return specialize(kin, [int(i) for i in spec.obj_link_idx], pairs, int(spec.ee_link), verbose, ee2_link=int(spec.ee2_link))
+    return specialize(kin, [int(i) for i in spec.obj_link_idx], pairs, int(spec.ee_link), verbose, ee2_link=int(spec.ee2_link),
+                      virtual=_virtual_rows(spec))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -192,7 +204,7 @@ def specialize_for_cost_spec(kin: KinModel, spec, verbose: bool = False) -> Opti
 def _points_template_of(kin: KinModel, point_link, point_offset, spec) -> Optional[codegen.PointsTemplate]:
     pl = np.ascontiguousarray(point_link, np.int32).reshape(-1)
     po = np.ascontiguousarray(point_offset, np.float32).reshape(-1, 3)
-    if spec.n_links_in != len(pl) or not generatable(spec):
+    if spec.n_links_in != len(pl) or not generatable(spec, points=True):
         return None
     pos_of = {int(kin.order[p]): p for p in range(kin.n_links)}
     rank = [pos_of[int(i)] for i in pl]

@@ -160,7 +160,7 @@ class PlanningTask(Task):
                 return self._fused[0], self._fused[1]
             self._fused = (self.robot.diff_panda._handle, ops.CostHandle(spec, device), key)
             from . import jit
-            if self.auto_specialize and not self._jit_failed and jit.generatable(spec):
+            if self.auto_specialize and not self._jit_failed and jit.generatable(spec, getattr(self.robot, "has_extra_points", False)):
                 try:                                   # a unit whose template equals this cost model may already exist
                     kin = self.robot.diff_panda._kin
                     if getattr(self.robot, "has_extra_points", False):
