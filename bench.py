@@ -72,6 +72,9 @@ def parse_args(argv):
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' + --single-device lets the N>1 control flow run on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--same-q", action="store_true", help="debug: every rank draws the same q (all-reduced sums == N x rank 0's)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: run the N > 1 code path (process group, side-stream all-reduce, in-stream barriers, multi_gpu section) "
+                         "even with ONE rank -- the only way to put the RCCL calls on hardware on a 1-GPU box")
     return ap.parse_args(argv)
 
 
@@ -149,8 +152,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dev = torch.device("cuda", 0 if args.single_device else local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    distributed = world > 1 or args.force_dist
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                     # --force-dist without a launcher: a one-rank group of our own
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -180,7 +190,7 @@ def main():
     # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
     packed = torch.zeros((n_slots, 1 + H + H * D), **ta)
     stream = torch.cuda.current_stream(dev)
-    side = torch.cuda.Stream(dev) if world > 1 else None
+    side = torch.cuda.Stream(dev) if distributed else None
 
     def pack_sums(pl, buf):
         """The sums of the latest evaluation of plan `pl` -> buf (three small kernels on the launch stream)."""
@@ -242,7 +252,7 @@ def main():
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize brackets; returns (wall s, event ms),
         the wall time already as the maximum over the ranks."""
         run(pl, args.warmup, collectives)
-        if world > 1:
+        if distributed:
             barrier_in_stream()
         torch.cuda.synchronize(dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -251,7 +261,7 @@ def main():
         run(pl, args.steps, collectives)
         ev1.record(stream)
         ta_ = time.perf_counter()
-        if world > 1:
+        if distributed:
             barrier_in_stream()         # closing bracket: in-stream barrier, then ONE synchronize (all streams, all ranks done)
         else:
             while not ev1.query():      # spin on the completion signal: a blocking wait adds ~6 us of wake-up latency
@@ -263,7 +273,7 @@ def main():
             print(f"[trace] submit {1e6 * (ta_ - t0):.1f} us, wait {1e6 * (tb_ - ta_):.1f} us, sync {1e6 * (wall - (tb_ - t0)):.1f} us, "
                   f"events {1e3 * ev0.elapsed_time(ev1):.1f} us", file=sys.stderr)
         ev_ms = ev0.elapsed_time(ev1) if graph is None else wall * 1e3
-        if world > 1:
+        if distributed:
             tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             wall = float(tmax.item())
@@ -271,8 +281,8 @@ def main():
 
     # one rehearsal of the whole measurement (discarded): the first pass through the event / sync / launch code paths of a
     # fresh process costs ~10 us more, which matters when the driver asks for only 20 timed steps (~200 us of GPU work)
-    measure(plan, world > 1)
-    elapsed, ev_ms = measure(plan, world > 1)
+    measure(plan, distributed)
+    elapsed, ev_ms = measure(plan, distributed)
 
     samples_per_step = B * H * world
     value = samples_per_step * args.steps / elapsed
@@ -312,7 +322,7 @@ def main():
                    "scene": args.scene, "objectives": args.config,
                    "launch": "hipGraph x%d" % args.graph if graph is not None else "eager, pre-bound C-ABI call",
                    "kernel": kind,
-                   "reduce_every": R if world > 1 else None,
+                   "reduce_every": R if distributed else None,
                    **({"experiment_weights": list(weights)} if args.weights else {}),
                    **({"experiment_no_pos": True} if args.no_pos else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -328,7 +338,7 @@ def main():
                      "working_set_MB": round(bytes_per_launch / 1e6, 1), "infinity_cache_MB": 256},
     }
 
-    if world > 1:
+    if distributed:
         # (1) the same loop without the collectives; (2) configs[2]'s objective stack on the same shards, with collectives;
         # (3) a check of the exchange itself: all-reduced packed sums == the sum of the ranks' local packed sums
         ko_elapsed, _ = measure(plan, False)
@@ -361,7 +371,7 @@ def main():
         }
         assert err < 1e-5, f"all-reduced sums differ from the sum of the ranks' sums: {err}"
 
-    if rank == 0 and world == 1 and graph is None and args.independent_streams > 1:
+    if rank == 0 and not distributed and graph is None and args.independent_streams > 1:
         # Secondary figure (never `value`): INDEPENDENT batches alternated over three HIP streams.  With one stream a launch waits
         # for the previous one's ~2 us write tail; with three, the next launch's dispatch, kernarg / q fetch and FK overlap it.
         # A planner's iterations depend on each other, so the headline keeps one stream; a server evaluating unrelated batches
@@ -387,7 +397,7 @@ def main():
                                       "note": f"secondary: unrelated batches round-robin over {ns} streams (launches overlap); "
                                               "the headline value above is one stream, launch after launch"}
 
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:       # CPU baseline: rank 0 at N = 1 only
+    if rank == 0 and not distributed and args.cpu_seconds > 0:       # CPU baseline: rank 0 at N = 1 only
         from oracle import oracle as orc          # checker / baseline only: never on the product path
         spec = task.build_cost_spec()
         if spec.grid is not None:                 # the oracle reads host arrays
@@ -422,7 +432,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

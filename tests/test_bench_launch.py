@@ -74,3 +74,18 @@ def test_bench_scene_variants(scene, bps):
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["config"]["scene"] == scene and out["roofline"]["bytes_per_sample"] == bps
     assert out["config"]["kernel"] == "specialized" and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_code_path_on_one_rank():
+    """`--force-dist`: the N > 1 code path with ONE rank and the real backend ("nccl" = RCCL on ROCm): process-group creation on
+    the device, the side-stream all-reduce of the packed sums, the in-stream barriers, the MAX over ranks, all_gather -- on hardware."""
+    p = _run(["--force-dist", "--steps", "40", "--warmup", "5", "--reduce-every", "8", "--cpu-seconds", "0"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    mg = out["multi_gpu"]
+    assert out["n_gpus"] == 1 and mg["backend"] == "nccl" and mg["ranks"] == 1
+    assert mg["collectives_in_timed_region"] == 5 and mg["allreduce_check"]["ok"]
+    assert mg["allreduce_check"]["sum_cost_all_ranks"] == pytest.approx(mg["allreduce_check"]["sum_cost_rank0"], rel=1e-6)
+    # one rank: the collectives are tiny copies on a side stream -- they must not slow the launch stream down by much
+    assert mg["with_allreduce"]["ms_per_step"] < 2.0 * mg["kernel_only"]["ms_per_step"]
