@@ -430,11 +430,18 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    # The JSON line is the LAST thing on stdout: librccl announces itself with a printf ("Librccl path : ...") that sits in the
+    # C stdio buffer until it is flushed -- without this it would land behind the line at process exit.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
