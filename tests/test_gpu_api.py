@@ -1030,3 +1030,47 @@ def test_fused_via_point_collision_equals_two_step():
     model.enable_specialized(False)             # no generated kernel: the call declines and the task falls back to two steps
     assert ops.rollout_collision_via(model, cm, fields, x, 3, margin=0.0) is None
     model.enable_specialized(True)
+
+
+def test_empty_and_degenerate_inputs_of_the_round3_ops():
+    """Zero-sized batches and the smallest legal shapes of the ops added in round 3 (the reference's functions accept them)."""
+    from torch_robotics_amd import ops
+    from torch_robotics_amd.fields import interpolate_points_v1
+    from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    model, cm = task._fused_handles(DEV)
+    fields = FIELD_OBJECTS | FIELD_WS | FIELD_SELF
+    # no trajectories at all
+    empty = torch.zeros(0, 16, 7, device=DEV)
+    wp = ops.rollout_collision_via(model, cm, fields, empty, 5, margin=0.0)
+    assert wp is not None and wp.shape == (0, 75)
+    part = ops.traj_validate(wp, empty, 7, robot.q_min.to(DEV).contiguous(), robot.q_max.to(DEV).contiguous())
+    assert part.counts() == (0, 0, 0) and part.idx.shape == (0, 1)
+    tc, ci, tf, fi, w_out = task.get_trajs_collision_and_free(empty, return_indices=True)
+    assert tc is None and tf is None and ci.shape == (0, 1) and fi.shape == (0, 1) and w_out.shape == (0, 75)
+    # one trajectory of two way points, one via point
+    one = robot.random_q(2).reshape(1, 2, 7).contiguous()
+    tc, tf = task.get_trajs_collision_and_free(one, num_interpolation=1)
+    assert (tc is None) != (tf is None)
+    # jtj / interpolate / scale_rows on empty batches
+    assert ops.jtj(torch.zeros(0, 3, 7, device=DEV), torch.zeros(0, 3, 7, device=DEV)).shape == (0, 7, 7)
+    assert interpolate_points_v1(torch.zeros(0, 5, 3, device=DEV), 9).shape == (0, 9, 3)
+    assert interpolate_points_v1(torch.ones(2, 1, 3, device=DEV), 4).eq(1).all()          # one link: every point is that link
+    assert ops.scale_rows(torch.zeros(0, 7, device=DEV), torch.zeros(0, device=DEV)).shape == (0, 7)
+    g = torch.randn(3, 5, 7, device=DEV)
+    assert torch.equal(ops.scale_rows(g, torch.full((3, 5), 2.0, device=DEV)), g * 2.0)
+    assert torch.equal(ops.scale_rows(g, torch.tensor(0.5, device=DEV).expand(3, 5)), g * 0.5)   # an expanded scalar (stride 0)
+    assert torch.equal(ops.scale_rows(g.half(), torch.full((3, 5), 2.0, device=DEV)), (g.half().float() * 2.0).half())
+    with pytest.raises(ValueError):
+        ops.scale_rows(g, torch.ones(4, device=DEV))
+    # a cost model whose fields interpolate, evaluated on an empty batch
+    from helpers import interp_cost_spec
+    cmi = ops.CostHandle(interp_cost_spec(), DEV)
+    c, gp = ops.cost_fields(cmi, fields, torch.zeros(0, 11, 3, device=DEV), want_grad=True)
+    assert c.shape == (0,) and gp.shape == (0, 11, 3)
+    with pytest.raises(ValueError, match="virtual_src"):
+        from torch_robotics_amd.costmodel import CostModelSpec
+        bad = CostModelSpec(n_links_in=11)
+        bad.add_virtual_columns(np.asarray([[2, 11]]), np.asarray([[0.5, 0.5]]))      # a source that is not a real column
+        bad.validate()

@@ -291,7 +291,7 @@ class PlanningTask(Task):
         trajs_free = part.gathered[:n_free] if n_free else None
         trajs_coll = part.gathered[lo:hi] if hi > lo else None
         if return_indices:
-            return trajs_coll, coll_idxs, trajs_free, free_idxs, wp.reshape(lead + (-1,))
+            return trajs_coll, coll_idxs, trajs_free, free_idxs, wp.reshape(lead + (wp.shape[-1],))
         return trajs_coll, trajs_free
 
     def compute_fraction_free_trajs(self, trajs, **kwargs):
