@@ -20,8 +20,10 @@ RCCL all-reduce of the packed sums [cost | cost per time step | gradient per tim
 `multi_gpu.full_stack_c3` is configs[2]'s objective stack on the same shards.
 
 Timed region: W untimed warm-up steps, then exactly K steps bracketed on both sides by a barrier (N > 1: a one-element all-reduce
-enqueued on the launch stream -- it completes only when every rank has reached it) + `torch.cuda.synchronize()`; the maximum over the
-ranks is taken.  The whole measurement is rehearsed once and discarded first.
+enqueued on the launch stream -- it completes only when every rank has reached it) + `torch.cuda.synchronize()`.  A rank's clock
+runs from the opening bracket to the return of its own closing `torch.cuda.synchronize()` (launch stream AND the side stream's
+collectives complete); the maximum over the ranks is taken -- the time from the common start to the completion of the last rank.
+For N > 1 the closing barrier follows the clock stop (an 8-rank all-reduce is not a step; at N = 1 there is none either).  The whole measurement is rehearsed once and discarded first.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes/sample x samples per launch /
 average launch duration (HIP events around the timed region on the launch stream).
@@ -183,20 +185,25 @@ def main():
     nb = ops.n_blocks(B * H)
     block_sums = torch.zeros(nb, **ta)
     bs_ptr = block_sums.data_ptr()
-    # the collective fires in the MIDDLE of every `reduce_every`-step interval (a planner consumes the sums a few evaluations
-    # later), and the interval shrinks for short runs so that the timed region always contains at least one all-reduce
-    R = max(1, min(args.reduce_every, args.steps))
-    n_slots = 6 * ((args.warmup + args.steps) // R + 2) + 8
+    # The planner's cadence: one exchange per `reduce_every` evaluations, counted over the launches of a measurement (warm-up included),
+    # fired in the middle of its interval (the sums are consumed a few evaluations later).  The cadence does not shrink for short
+    # runs: a 20-step region of a 64-step cadence contains a collective with probability 20 / 64, here deterministically by the
+    # launch count -- `multi_gpu.collectives_in_timed_region` says how many it was, `multi_gpu.exchange_us` what one costs.
+    R = max(1, args.reduce_every)
+    n_slots = 8 * ((args.warmup + args.steps) // R + 2) + 16
     # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
     packed = torch.zeros((n_slots, 1 + H + H * D), **ta)
     stream = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev) if distributed else None
 
+    packers = {}
+
     def pack_sums(pl, buf):
-        """The sums of the latest evaluation of plan `pl` -> buf (three small kernels on the launch stream)."""
-        ops.reduce_sum(block_sums, out=buf[0:1])
-        torch.sum(pl.cost, dim=0, out=buf[1:1 + H])
-        torch.sum(pl.gq, dim=0, out=buf[1 + H:].view(H, D))
+        """The sums of the latest evaluation of plan `pl` -> buf: one launch of trk_pack_sums on the launch stream."""
+        pk = packers.get(id(pl))
+        if pk is None:
+            pk = packers[id(pl)] = ops.PackedSums(pl, block_sums)
+        pk.pack(buf, stream.cuda_stream)
 
     def reduce_slot(pl, k):
         # sums of the latest evaluation -> one small all-reduce (2 kB), off the launch stream
@@ -224,6 +231,7 @@ def main():
                 plan.launch(bs_ptr, torch.cuda.current_stream(dev).cuda_stream)
 
     slot = [0]
+    launches = [0]          # launches of this process so far: the cadence counter
 
     def run(pl, count, collectives):
         if graph is not None:
@@ -234,8 +242,9 @@ def main():
         s = stream.cuda_stream
         for j in range(count):
             pl.launch(bs_ptr, s)
-            if collectives and j % R == R // 2:        # counted from the start of this (warm-up or timed) region
-                reduce_slot(pl, slot[0])
+            launches[0] += 1
+            if collectives and launches[0] % R == R // 2:
+                reduce_slot(pl, slot[0] % n_slots)
                 slot[0] += 1
 
     if graph is not None:
@@ -248,9 +257,12 @@ def main():
         only after every rank has reached it, so the `torch.cuda.synchronize()` that follows returns when all ranks are done."""
         dist.all_reduce(flag)
 
+    n_coll = [0]            # collectives inside the latest timed region
+
     def measure(pl, collectives):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize brackets; returns (wall s, event ms),
         the wall time already as the maximum over the ranks."""
+        launches[0] = 0             # the cadence is counted from the first warm-up step of THIS measurement
         run(pl, args.warmup, collectives)
         if distributed:
             barrier_in_stream()
@@ -258,20 +270,30 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
+        slots_before = slot[0]
         run(pl, args.steps, collectives)
+        n_coll[0] = slot[0] - slots_before
         ev1.record(stream)
+        ev_side = None
+        if side is not None and collectives:
+            ev_side = torch.cuda.Event()
+            ev_side.record(side)        # the collectives issued inside the region belong to it
         ta_ = time.perf_counter()
-        if distributed:
-            barrier_in_stream()         # closing bracket: in-stream barrier, then ONE synchronize (all streams, all ranks done)
-        else:
-            while not ev1.query():      # spin on the completion signal: a blocking wait adds ~6 us of wake-up latency
-                pass
+        # The clock of a rank stops when ITS K steps (and its side-stream collectives) are complete and its closing synchronize has
+        # returned; every rank started from a common barrier, so the MAX over ranks below is the time from that barrier to the
+        # completion of the last rank -- what a closing barrier of zero latency would measure.  The closing barrier itself comes
+        # after the clock stop: an 8-rank all-reduce over xGMI is tens of microseconds, a fifth of the region at 20 timed steps.
+        while not ev1.query() or (ev_side is not None and not ev_side.query()):
+            pass                        # spin on the completion signal: a blocking wait adds ~6 us of wake-up latency
         tb_ = time.perf_counter()
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)     # the closing synchronize (this rank's streams are idle by now)
         wall = time.perf_counter() - t0
+        if distributed:
+            barrier_in_stream()         # the closing barrier, behind the clock stop: every rank has finished its region
+            torch.cuda.synchronize(dev)
         if os.environ.get("TRK_BENCH_TRACE"):
-            print(f"[trace] submit {1e6 * (ta_ - t0):.1f} us, wait {1e6 * (tb_ - ta_):.1f} us, sync {1e6 * (wall - (tb_ - t0)):.1f} us, "
-                  f"events {1e3 * ev0.elapsed_time(ev1):.1f} us", file=sys.stderr)
+            print(f"[trace] submit {1e6 * (ta_ - t0):.1f} us, wait {1e6 * (tb_ - ta_):.1f} us, closing bracket "
+                  f"{1e6 * (time.perf_counter() - tb_):.1f} us, events {1e3 * ev0.elapsed_time(ev1):.1f} us", file=sys.stderr)
         ev_ms = ev0.elapsed_time(ev1) if graph is None else wall * 1e3
         if distributed:
             tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
@@ -283,6 +305,7 @@ def main():
     # fresh process costs ~10 us more, which matters when the driver asks for only 20 timed steps (~200 us of GPU work)
     measure(plan, distributed)
     elapsed, ev_ms = measure(plan, distributed)
+    n_coll_value = n_coll[0]
 
     samples_per_step = B * H * world
     value = samples_per_step * args.steps / elapsed
@@ -346,6 +369,13 @@ def main():
         if plan3 is not plan:
             measure(plan3, True)
         c3_elapsed, c3_ev = (elapsed, ev_ms) if plan3 is plan else measure(plan3, True)
+        # what ONE exchange costs end to end when nothing hides it: pack kernel + all-reduce, from enqueue to completion
+        torch.cuda.synchronize(dev)
+        t_x = time.perf_counter()
+        for k in range(10):
+            reduce_slot(plan, (slot[0] + k) % n_slots)
+            side.synchronize()
+        exchange_us = (time.perf_counter() - t_x) / 10 * 1e6
         plan.launch(bs_ptr, stream.cuda_stream)
         local = torch.zeros(1 + H + H * D, **ta)
         pack_sums(plan, local)
@@ -358,7 +388,7 @@ def main():
         err = float(((reduced.double() - expect).abs() / (expect.abs() + 1.0)).max().item())
         out["multi_gpu"] = {
             "backend": dist.get_backend(), "ranks": dist.get_world_size(), "reduce_every": R,
-            "collectives_in_timed_region": args.steps // R + (1 if args.steps % R > R // 2 else 0),
+            "collectives_in_timed_region": n_coll_value, "exchange_us": exchange_us,
             "allreduce_floats": int(local.numel()),
             "with_allreduce": {"value": value, "ms_per_step": elapsed * 1e3 / args.steps},
             "kernel_only": {"value": samples_per_step * args.steps / ko_elapsed, "ms_per_step": ko_elapsed * 1e3 / args.steps},

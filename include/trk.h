@@ -534,6 +534,16 @@ int trk_scale_rows(const void* g, const float* scale, int32_t scale_stride, int6
  * staged, objects done, objectives done, reverse done, exit).  Used by tools/phase_profile.py; never set in production. */
 int trk_debug_set_stamp_buffer(void* device_u64);
 
+/* The one buffer a batch-sharded planner all-reduces: packed [1 + H + H*D] =
+ *   [ sum of all costs | sum over trajectories of cost(b, h) | sum over trajectories of gq(b, h, d) ]
+ * of ONE rank's evaluation -- cost [batch, horizon], gq [batch, horizon, dof] and cost_block_sums as written by
+ * trk_rollout_cost_grad -- in one launch, bit-reproducibly (fixed association order; packed[0] equals trk_reduce_sum of the block
+ * sums).  scratch: DEVICE memory of trk_pack_sums_scratch_bytes(horizon, dof) bytes, zero-initialised ONCE by the caller (its last
+ * word is a ticket the kernel returns to zero); one scratch per stream that may run the call concurrently. */
+int64_t trk_pack_sums_scratch_bytes(int32_t horizon, int32_t dof);
+int trk_pack_sums(const float* cost, const float* gq, const float* cost_block_sums, int64_t batch, int32_t horizon, int32_t dof,
+                  float* scratch, float* packed, trk_stream_t stream);
+
 /* Deterministic sum of n floats (fixed association order, one workgroup): x [n] -> out [1]. */
 int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream);
 

@@ -22,7 +22,7 @@ def trk():
 
 def test_header_symbols_all_exported(trk):
     header = (ROOT / "include" / "trk.h").read_text()
-    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(trk_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|void|const char\*)\s+(trk_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared, "no declarations parsed from trk.h"
     assert declared == set(_lib.EXPORTS)
     for name in declared:

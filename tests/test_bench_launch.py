@@ -46,15 +46,15 @@ def test_launcher_rejects_world_size_mismatch():
 @pytest.mark.gpu
 def test_two_rank_bench_on_one_gpu_gloo():
     p = _run(["--gpus", "2", "--dist-backend", "gloo", "--single-device", "--same-q", "--steps", "20", "--warmup", "5",
-              "--cpu-seconds", "0"], 600)
+              "--reduce-every", "8", "--cpu-seconds", "0"], 600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 20
-    assert out["config"]["reduce_every"] == 20 and out["config"]["global_batch"] == 8192
+    assert out["config"]["reduce_every"] == 8 and out["config"]["global_batch"] == 8192
     mg = out["multi_gpu"]
-    assert mg["backend"] == "gloo" and mg["ranks"] == 2 and mg["collectives_in_timed_region"] >= 1
+    assert mg["backend"] == "gloo" and mg["ranks"] == 2 and mg["collectives_in_timed_region"] in (2, 3) and mg["exchange_us"] > 0
     assert mg["allreduce_floats"] == 1 + 64 + 64 * 7
     chk = mg["allreduce_check"]
     assert chk["ok"] and chk["max_rel_err"] < 1e-5
@@ -85,7 +85,10 @@ def test_rccl_code_path_on_one_rank():
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     mg = out["multi_gpu"]
     assert out["n_gpus"] == 1 and mg["backend"] == "nccl" and mg["ranks"] == 1
-    assert mg["collectives_in_timed_region"] == 5 and mg["allreduce_check"]["ok"]
+    assert mg["collectives_in_timed_region"] == 5 and mg["allreduce_check"]["ok"] and mg["exchange_us"] > 0
     assert mg["allreduce_check"]["sum_cost_all_ranks"] == pytest.approx(mg["allreduce_check"]["sum_cost_rank0"], rel=1e-6)
-    # one rank: the collectives are tiny copies on a side stream -- they must not slow the launch stream down by much
-    assert mg["with_allreduce"]["ms_per_step"] < 2.0 * mg["kernel_only"]["ms_per_step"]
+    # the default cadence (64) leaves a 20-step region without a collective: value == the kernel-only rate up to noise
+    p = _run(["--force-dist", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["multi_gpu"]["collectives_in_timed_region"] == 0 and out["config"]["reduce_every"] == 64

@@ -1074,3 +1074,28 @@ def test_empty_and_degenerate_inputs_of_the_round3_ops():
         bad = CostModelSpec(n_links_in=11)
         bad.add_virtual_columns(np.asarray([[2, 11]]), np.asarray([[0.5, 0.5]]))      # a source that is not a real column
         bad.validate()
+
+
+def test_packed_sums_one_launch_equals_three():
+    """trk_pack_sums: [sum cost | sum_b cost(b, h) | sum_b gq(b, h, d)] of an evaluation in ONE launch == the three separate
+    reductions it replaces (deterministic total of the block sums, torch column sums), bit-reproducible, ticket returned to 0."""
+    from torch_robotics_amd import ops
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    for B, H in ((4096, 64), (37, 64), (5, 16), (1, 64)):
+        q = robot.random_q(B * H).reshape(B, H, 7).contiguous()
+        plan = task.rollout_plan(q, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=False)
+        sums = torch.zeros(ops.n_blocks(B * H), **TA)
+        plan.launch(sums.data_ptr())
+        pk = ops.PackedSums(plan, sums)
+        out = torch.empty(pk.size, **TA)
+        pk.pack(out)
+        assert pk.size == 1 + H + H * 7
+        assert torch.equal(out[0:1], ops.reduce_sum(sums))                                      # the same association order
+        ref_c, ref_g = plan.cost.double().sum(0), plan.gq.double().sum(0).reshape(-1)
+        assert rel_err(out[1:1 + H].cpu().numpy(), ref_c.cpu().numpy()) < 2e-6
+        assert np.abs(out[1 + H:].cpu().numpy() - ref_g.cpu().numpy()).max() <= 2e-6 * max(1.0, float(plan.gq.abs().sum(0).max()))
+        out2 = torch.empty_like(out)
+        for _ in range(3):
+            pk.pack(out2)
+            assert torch.equal(out, out2)                                                       # bit-reproducible, ticket reset

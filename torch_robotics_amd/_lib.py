@@ -32,7 +32,7 @@ EXPORTS = [
     "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_point_set_is_specialized", "trk_fk_points", "trk_fk_points_backward",
     "trk_rollout_points_cost_grad", "trk_rollout_collision", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16", "trk_finite_difference", "trk_traj_diff_norm_sum",
     "trk_interpolate_columns", "trk_interpolate_columns_backward", "trk_rollout_collision_via", "trk_traj_validate",
-    "trk_scale_rows", "trk_jtj",
+    "trk_scale_rows", "trk_jtj", "trk_pack_sums", "trk_pack_sums_scratch_bytes",
 ]
 
 
@@ -114,6 +114,9 @@ def lib():
     L.trk_interpolate_columns_backward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
     L.trk_rollout_collision_via.argtypes = [vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, f32, vp, vp]
     L.trk_traj_validate.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp, vp]
+    L.trk_pack_sums.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
+    L.trk_pack_sums_scratch_bytes.argtypes = [i32, i32]
+    L.trk_pack_sums_scratch_bytes.restype = C.c_int64
     L.trk_jtj.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.trk_scale_rows.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
     L.trk_point_set_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
@@ -126,7 +129,8 @@ def lib():
     L.trk_rollout_points_cost_grad.argtypes = [vp, vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)        # AttributeError here = the library does not export the ABI
-        if name not in ("trk_last_error", "trk_model_destroy", "trk_cost_model_destroy", "trk_point_set_destroy"):
+        if name not in ("trk_last_error", "trk_model_destroy", "trk_cost_model_destroy", "trk_point_set_destroy",
+                        "trk_pack_sums_scratch_bytes"):
             fn.restype = C.c_int
     if L.trk_abi_version() != _abi.TRK_ABI_VERSION:
         raise TrkError("libtrk.so ABI version mismatch; rebuild it")

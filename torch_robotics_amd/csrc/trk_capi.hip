@@ -1177,16 +1177,10 @@ int trk_traj_validate(const uint8_t* waypoint_collisions, const float* x, int64_
     if (n_traj < 0 || n_traj > 0x3fffffff || horizon < 1 || state_dim < 1 || n_waypoints < 0 || n_dofs < 0 || n_dofs > state_dim || inner < 0 ||
         !counts || (n_dofs > 0 && (!q_min || !q_max)) ||
         (n_traj > 0 && (!x || !flags || !idx || (n_waypoints > 0 && !waypoint_collisions))))
-        return fail(TRK_ERR_INVALID_ARG, "trk_traj_validate: bad argument");
+        return fail(TRK_ERR_INVALID_ARG, "trk_traj_validate: bad argument");      // n_traj == 0: only the (zero) counters are written
     if (inner > 0 && n_traj % inner) return fail(TRK_ERR_INVALID_ARG, "trk_traj_validate: n_traj is not a multiple of the inner batch");
     int rc = ensure_init();
     if (rc) return rc;
-    if (n_traj == 0) {
-        const int32_t zero[4] = {0, 0, 0, ticket};
-        TRK_HIP(hipMemcpyAsync(counts, zero, sizeof(zero), hipMemcpyHostToDevice, (hipStream_t)stream));
-        if (counts_host) { counts_host[0] = counts_host[1] = counts_host[2] = 0; counts_host[3] = ticket; }
-        return TRK_OK;
-    }
     trk_launch_traj_validate(waypoint_collisions, x, n_traj, horizon, state_dim, n_waypoints, n_dofs, q_min, q_max, inner, flags,
                              idx, counts, counts_host, ticket, gathered, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
@@ -1345,6 +1339,22 @@ int trk_traj_diff_norm_sum(const float* x, int64_t batch, int32_t horizon, int32
 
 int trk_debug_set_stamp_buffer(void* device_u64) {
     g_stamps = static_cast<unsigned long long*>(device_u64);
+    return TRK_OK;
+}
+
+int64_t trk_pack_sums_scratch_bytes(int32_t horizon, int32_t dof) {
+    if (horizon < 1 || dof < 1) return TRK_ERR_INVALID_ARG;
+    return (int64_t)(sizeof(float) * trk_pack_scratch_floats(horizon, dof));
+}
+
+int trk_pack_sums(const float* cost, const float* gq, const float* cost_block_sums, int64_t batch, int32_t horizon, int32_t dof,
+                  float* scratch, float* packed, trk_stream_t stream) {
+    if (batch < 1 || batch > 0x7fffffff || horizon < 1 || dof < 1 || !cost || !gq || !cost_block_sums || !scratch || !packed)
+        return fail(TRK_ERR_INVALID_ARG, "trk_pack_sums: bad argument");
+    int rc = ensure_init();
+    if (rc) return rc;
+    trk_launch_pack_sums(cost, gq, cost_block_sums, (int)batch, horizon, dof, (batch * horizon + 63) / 64, scratch, packed, (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
     return TRK_OK;
 }
 

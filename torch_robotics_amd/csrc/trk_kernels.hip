@@ -1967,6 +1967,62 @@ k_reduce_sum(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     if (threadIdx.x == 0) out[0] = part[0];
 }
 
+// ============================================================================================
+// What a batch-sharded planner exchanges: packed = [ sum cost | sum_b cost(b, h) (H) | sum_b gq(b, h, d) (H D) ]
+// of one rank's evaluation, in ONE launch and bit-reproducibly.  Stage 1: the B trajectories are cut into TRK_PACK_SLICES row
+// slices x 64-column tiles; each workgroup adds its slice of a tile (fixed order) and writes one partial row.  The LAST
+// workgroup to finish (an atomic ticket) adds the partial rows in slice order and the per-wavefront cost sums in index order --
+// the association order never depends on the timing.  cost [B, H]; gq [B, H, D]; block_sums [nb] (trk_rollout_cost_grad).
+// scratch: float[TRK_PACK_SLICES * (H + H D)] followed by one zero-initialised int (the ticket; the kernel leaves it zero).
+// ============================================================================================
+#define TRK_PACK_SLICES 64
+__global__ void __launch_bounds__(256)
+k_pack_sums(const float* __restrict__ cost, const float* __restrict__ gq, const float* __restrict__ block_sums, int B, int H, int D,
+            int64_t nb, float* __restrict__ scratch, float* __restrict__ out) {
+    __shared__ float part[256];
+    __shared__ int is_last;
+    const int C = H + H * D;                                 // columns: H of the cost matrix, then H D of the gradient matrix
+    const int tiles = (C + 63) / 64;
+    const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;   // column in the tile, row lane 0..3
+    const int col = tile * 64 + c;
+    const int rows_per = (B + TRK_PACK_SLICES - 1) / TRK_PACK_SLICES;
+    const int b0 = slice * rows_per, b1 = min(B, b0 + rows_per);
+    float acc = 0.0f;
+    if (col < C) {
+        const bool is_cost = col < H;
+        const float* src = is_cost ? cost + col : gq + (col - H);
+        const int64_t stride = is_cost ? H : (int64_t)H * D;
+        for (int b = b0 + rl; b < b1; b += 4) acc += src[b * stride];
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    int* ticket = reinterpret_cast<int*>(scratch + (size_t)TRK_PACK_SLICES * C);
+    if (rl == 0) {
+        if (col < C) scratch[(size_t)slice * C + col] = (part[c] + part[64 + c]) + (part[128 + c] + part[192 + c]);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    for (int k = threadIdx.x; k < C; k += 256) {
+        float tot = 0.0f;
+        for (int p = 0; p < TRK_PACK_SLICES; ++p) tot += scratch[(size_t)p * C + k];
+        out[1 + k] = tot;
+    }
+    float a = 0.0f;
+    for (int64_t i = threadIdx.x; i < nb; i += 256) a += block_sums[i];       // the association order of trk_reduce_sum
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = part[0]; *ticket = 0; }
+}
+
 // --------------------------------------------------------------------------------------------
 // host-callable launchers (used by trk_capi.hip)
 // --------------------------------------------------------------------------------------------
@@ -2142,9 +2198,9 @@ void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_inter
 void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int H, int S, int Hi, int D, const float* qmin,
                               const float* qmax, int64_t inner, uint8_t* flags, int64_t* idx, int32_t* counts,
                               int32_t* counts_host, int32_t ticket, float* gathered, hipStream_t st) {
-    hipLaunchKernelGGL(k_traj_flags, dim3(grid_for(T, 4)), dim3(256), 0, st, wp, Hi, x, H, S, D, qmin, qmax, T, flags);
-    hipLaunchKernelGGL(k_traj_partition, dim3(1), dim3(1024), 0, st, flags, T, inner, idx, counts, counts_host, ticket);
-    if (gathered) hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)T), dim3(128), 0, st, x, H * S, inner > 0 ? 2 : 1, idx, inner, gathered);
+    if (T > 0) hipLaunchKernelGGL(k_traj_flags, dim3(grid_for(T, 4)), dim3(256), 0, st, wp, Hi, x, H, S, D, qmin, qmax, T, flags);
+    hipLaunchKernelGGL(k_traj_partition, dim3(1), dim3(1024), 0, st, flags, T, inner, idx, counts, counts_host, ticket);   // T == 0: zeros + ticket
+    if (gathered && T > 0) hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)T), dim3(128), 0, st, x, H * S, inner > 0 ? 2 : 1, idx, inner, gathered);
 }
 
 int trk_launch_jtj(int mfma, const float* lin, const float* ang, const float* r6, int64_t n, int D, float* JtJ, float* Jtr, hipStream_t st) {
@@ -2201,6 +2257,13 @@ void trk_launch_finite_difference(const float* x, int64_t B, int H, int D, float
 
 void trk_launch_traj_diff_norm_sum(const float* x, int64_t B, int H, int S, int c0, int D, float* out, hipStream_t st) {
     hipLaunchKernelGGL(k_traj_diff_norm_sum, dim3((unsigned)B), dim3(256), 0, st, x, H, S, c0, D, out);
+}
+
+size_t trk_pack_scratch_floats(int H, int D) { return (size_t)TRK_PACK_SLICES * (H + (size_t)H * D) + 1; }
+void trk_launch_pack_sums(const float* cost, const float* gq, const float* block_sums, int B, int H, int D, int64_t nb, float* scratch,
+                          float* out, hipStream_t st) {
+    const int C = H + H * D;
+    hipLaunchKernelGGL(k_pack_sums, dim3(TRK_PACK_SLICES * ((C + 63) / 64)), dim3(256), 0, st, cost, gq, block_sums, B, H, D, nb, scratch, out);
 }
 
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st) {

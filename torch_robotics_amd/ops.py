@@ -1011,7 +1011,8 @@ class TrajPartition:
                 if spins > 2_000_000:                           # host memory not coherent on this system: wait for the stream
                     self._stream.synchronize()
                     if slot[3] != self._ticket:
-                        raise RuntimeError("traj_validate: the partition kernel did not report its counters")
+                        raise RuntimeError("traj_validate: the partition kernel did not report its counters (a result must be "
+                                           f"read before {_PinnedCounters.SLOTS} later validations reuse its pinned slot)")
             self._host = (int(slot[0]), int(slot[1]), int(slot[2]))
         return self._host
 
@@ -1100,6 +1101,28 @@ def reduce_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Ten
     with _on(x.device):
         check(lib().trk_reduce_sum(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x)), "trk_reduce_sum")
     return out
+
+
+class PackedSums:
+    """The exchange buffer of a batch-sharded planner, produced by ONE launch: `pack(out)` writes
+    [sum cost | sum_b cost(b, h) | sum_b gq(b, h, d)] of a RolloutPlan's latest evaluation into out (1 + H + H D floats)."""
+
+    def __init__(self, plan: "RolloutPlan", block_sums: torch.Tensor):
+        if plan.gq.dtype != torch.float32:
+            raise ValueError("PackedSums: fp32 plans only")
+        self.B, self.H, self.D = plan.B, plan.H, int(plan.gq.shape[-1])
+        self.size = 1 + self.H + self.H * self.D
+        _check_buffer(block_sums, n_blocks(self.B * self.H), torch.float32, plan.device, "PackedSums(block_sums)", at_least=True)
+        nbytes = int(lib().trk_pack_sums_scratch_bytes(self.H, self.D))
+        self._scratch = torch.zeros(nbytes // 4, device=plan.device, dtype=torch.float32)     # zeroed once: holds the ticket
+        self._args = (plan.cost.data_ptr(), plan.gq.data_ptr(), block_sums.data_ptr(), self.B, self.H, self.D, self._scratch.data_ptr())
+        self._keep = (plan, block_sums)
+        self.device = plan.device
+
+    def pack(self, out: torch.Tensor, stream: Optional[int] = None) -> None:
+        _check_buffer(out, self.size, torch.float32, self.device, "PackedSums.pack(out)")
+        with _on(self.device):
+            check(lib().trk_pack_sums(*self._args, out.data_ptr(), _stream_of(self.device) if stream is None else stream), "trk_pack_sums")
 
 
 def n_blocks(n_samples: int) -> int:
