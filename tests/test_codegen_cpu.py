@@ -23,13 +23,15 @@ def test_generated_source_is_deterministic_and_folded():
 
 
 def test_committed_generated_sources_equal_the_generator_output(tmp_path):
-    """csrc/generated/spec_*.hip are committed so the headline kernels can be read without running the build; they must be
-    exactly what `codegen.generate_all` writes (the build rewrites a file only when it differs, so a clean tree stays clean)."""
+    """csrc/generated/spec_panda.hip is committed so the headline kernel can be read without running the build (the other units
+    are build products only); whatever is present must be exactly what `codegen.generate_all` writes (the build rewrites a file
+    only when it differs, so a clean tree stays clean)."""
     from pathlib import Path
     committed = Path(codegen.__file__).resolve().parent / "csrc" / "generated"
     names = codegen.generate_all(tmp_path)
-    assert sorted(names) == sorted(p.name for p in committed.glob("spec_*.hip"))
-    for n in names:
+    present = sorted(p.name for p in committed.glob("spec_*.hip"))
+    assert "spec_panda.hip" in present and set(present) <= set(names)
+    for n in present:
         assert (tmp_path / n).read_text() == (committed / n).read_text(), f"{n} is stale: run __graft_entry__.build()"
 
 
