@@ -74,6 +74,9 @@ def parse_args(argv):
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' + --single-device lets the N>1 control flow run on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--same-q", action="store_true", help="debug: every rank draws the same q (all-reduced sums == N x rank 0's)")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="issue the planner's exchange straight on librccl (torch_robotics_amd.distributed.RcclAllReduce: one ctypes "
+                         "call per collective) instead of torch.distributed.all_reduce; the barriers stay on torch.distributed")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: run the N > 1 code path (process group, side-stream all-reduce, in-stream barriers, multi_gpu section) "
                          "even with ONE rank -- the only way to put the RCCL calls on hardware on a 1-GPU box")
@@ -205,15 +208,23 @@ def main():
             pk = packers[id(pl)] = ops.PackedSums(pl, block_sums)
         pk.pack(buf, stream.cuda_stream)
 
+    native = None
+    if distributed and args.native_rccl:
+        from torch_robotics_amd.distributed import RcclAllReduce
+        native = RcclAllReduce(dev)
+
     def reduce_slot(pl, k):
         # sums of the latest evaluation -> one small all-reduce (2 kB), off the launch stream
         buf = packed[k]
         pack_sums(pl, buf)
         ev = torch.cuda.Event()
         ev.record(stream)
-        with torch.cuda.stream(side):
-            side.wait_event(ev)
-            dist.all_reduce(buf)
+        side.wait_event(ev)
+        if native is not None:
+            native.all_reduce_sum_(buf, side.cuda_stream)
+        else:
+            with torch.cuda.stream(side):
+                dist.all_reduce(buf)
 
     graph = None
     if args.graph > 0:
@@ -382,12 +393,16 @@ def main():
         gathered = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
         reduced = local.clone()
-        dist.all_reduce(reduced)
+        if native is not None:
+            native.all_reduce_sum_(reduced, stream.cuda_stream)
+        else:
+            dist.all_reduce(reduced)
         torch.cuda.synchronize(dev)
         expect = torch.stack(gathered).double().sum(0)
         err = float(((reduced.double() - expect).abs() / (expect.abs() + 1.0)).max().item())
         out["multi_gpu"] = {
             "backend": dist.get_backend(), "ranks": dist.get_world_size(), "reduce_every": R,
+            "exchange_via": "librccl ncclAllReduce (ctypes)" if native is not None else "torch.distributed.all_reduce",
             "collectives_in_timed_region": n_coll_value, "exchange_us": exchange_us,
             "allreduce_floats": int(local.numel()),
             "with_allreduce": {"value": value, "ms_per_step": elapsed * 1e3 / args.steps},
@@ -461,6 +476,9 @@ def main():
         out["cpu_baseline"] = None
 
     if distributed:
+        if native is not None:
+            torch.cuda.synchronize(dev)
+            native.close()
         dist.barrier()
         dist.destroy_process_group()
     # The JSON line is the LAST thing on stdout: librccl announces itself with a printf ("Librccl path : ...") that sits in the

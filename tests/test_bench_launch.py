@@ -92,3 +92,14 @@ def test_rccl_code_path_on_one_rank():
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["multi_gpu"]["collectives_in_timed_region"] == 0 and out["config"]["reduce_every"] == 64
+
+
+@pytest.mark.gpu
+def test_native_rccl_exchange_on_one_rank():
+    """`--native-rccl`: the exchange issued straight on librccl (ncclAllReduce through ctypes on the side stream)."""
+    p = _run(["--force-dist", "--native-rccl", "--steps", "40", "--warmup", "5", "--reduce-every", "8", "--cpu-seconds", "0"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    mg = out["multi_gpu"]
+    assert mg["exchange_via"].startswith("librccl") and mg["collectives_in_timed_region"] == 5 and mg["allreduce_check"]["ok"]
+    assert mg["allreduce_check"]["sum_cost_all_ranks"] == pytest.approx(mg["allreduce_check"]["sum_cost_rank0"], rel=1e-6)

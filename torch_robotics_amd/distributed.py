@@ -9,6 +9,8 @@ all-reduce -- RCCL over xGMI on the GPU box (`backend="nccl"`), gloo in the CPU 
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -58,3 +60,69 @@ class CostSumReducer:
 
     def wait(self):
         torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class RcclAllReduce:
+    """The planner's one exchange -- an in-place fp32 sum of a small packed buffer over all ranks -- issued straight on librccl
+    (`ncclAllReduce` on a caller-chosen HIP stream) instead of through `torch.distributed`: the collective itself is the same RCCL
+    ring over xGMI, but enqueueing it costs one ctypes call instead of c10d's ~50 us of host work per call, which matters when the
+    exchange is 2 kB and an evaluation is 10 us.  The communicator is this class's own: rank 0 creates a `ncclUniqueId` and the
+    already initialised `torch.distributed` group (any backend) broadcasts its 128 bytes.  Opt-in (`bench.py --native-rccl`);
+    `all_reduce_sum_` remains the default path."""
+
+    NCCL_FLOAT32, NCCL_SUM = 7, 0
+
+    def __init__(self, device, rank: Optional[int] = None, world: Optional[int] = None):
+        self.device = torch.device(device)
+        lib_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._lib = L = C.CDLL(lib_path)
+        L.ncclGetErrorString.restype = C.c_char_p
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclCommDestroy.argtypes = [C.c_void_p]
+        have_group = dist.is_available() and dist.is_initialized()
+        self.rank = int(rank if rank is not None else (dist.get_rank() if have_group else 0))
+        self.world = int(world if world is not None else (dist.get_world_size() if have_group else 1))
+        uid = _NcclUniqueId()
+        if self.rank == 0:
+            self._check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        if self.world > 1:
+            if not have_group:
+                raise RuntimeError("RcclAllReduce: more than one rank needs an initialised torch.distributed group to share the id")
+            box = [bytes(uid.internal) if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            C.memmove(C.byref(uid), box[0], 128)
+        self._comm = C.c_void_p()
+        with torch.cuda.device(self.device):
+            self._check(L.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self._lib.ncclGetErrorString(rc).decode()} (ncclResult {rc})")
+
+    def all_reduce_sum_(self, buf: torch.Tensor, stream: Optional[int] = None) -> None:
+        """In-place sum of a contiguous fp32 device buffer over the ranks, enqueued on `stream` (a raw HIP stream handle; default:
+        torch's current stream on the device).  Asynchronous like a kernel launch."""
+        if buf.device != self.device or buf.dtype != torch.float32 or not buf.is_contiguous():
+            raise ValueError(f"RcclAllReduce: expected a contiguous float32 tensor on {self.device}")
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        p = buf.data_ptr()
+        rc = self._lib.ncclAllReduce(p, p, buf.numel(), self.NCCL_FLOAT32, self.NCCL_SUM, self._comm, stream)
+        if rc:
+            self._check(rc, "ncclAllReduce")
+
+    def close(self) -> None:
+        comm, self._comm = self._comm, None
+        if comm:
+            self._lib.ncclCommDestroy(comm)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
