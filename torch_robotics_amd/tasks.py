@@ -79,27 +79,20 @@ class PlanningTask(Task):
         return self.robot.random_q(**kwargs)
 
     def random_coll_free_q(self, n_samples=1, max_samples=1000, max_tries=1000):   # tasks.py:103-129
-        """Rejection sampling of collision-free configurations: batches of `max_samples` uniform draws go through the
-        boolean collision kernels until `n_samples` survive.  Same control flow and return shapes as the reference."""
-        dev = self.tensor_args["device"]
-        samples = torch.zeros((n_samples, self.robot.q_dim), device=dev, dtype=torch.float32)
-        idx_begin, reject = 0, True
+        """`n_samples` collision-free configurations by rejection: rounds of `max_samples` uniform draws through the fused FK +
+        boolean-field kernel, the survivors of a round compacted with one masked gather.  The draws are i.i.d., so the first
+        survivors of a round are as good as the reference's random subset of them.  Returns (n_samples, q_dim).squeeze() like
+        the reference, and ends the process like it when `max_tries` rounds do not suffice."""
+        kept, missing = [], int(n_samples)
         for _ in range(max_tries):
             qs = self.robot.random_q(max_samples)
-            free = torch.argwhere(self.compute_collision(qs).reshape(-1) == False).reshape(-1)   # noqa: E712
-            if free.nelement() == 0:
-                continue
-            pick = free[torch.randperm(len(free), device=free.device)[:n_samples]]
-            free_qs = qs[pick]
-            idx_end = min(idx_begin + free_qs.shape[0], samples.shape[0])
-            samples[idx_begin:idx_end] = free_qs[:idx_end - idx_begin]
-            idx_begin = idx_end
-            if idx_end >= n_samples:
-                reject = False
-                break
-        if reject:
-            sys.exit("Could not find a collision free configuration")
-        return samples.squeeze()
+            free = qs[~self.compute_collision(qs).reshape(-1)][:missing]
+            if free.shape[0]:
+                kept.append(free)
+                missing -= int(free.shape[0])
+            if missing <= 0:
+                return torch.cat(kept, dim=0).to(torch.float32).squeeze()
+        sys.exit("Could not find a collision free configuration")
 
     # ---------------------------------------------------------------------------------------------
     # one cost model for the fused kernel and for compute_collision(_cost)
