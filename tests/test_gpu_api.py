@@ -1099,3 +1099,36 @@ def test_packed_sums_one_launch_equals_three():
         for _ in range(3):
             pk.pack(out2)
             assert torch.equal(out, out2)                                                       # bit-reproducible, ticket reset
+
+
+def test_interpolated_points_with_a_grasped_object(oracle_lib):
+    """interpolate_link_pos on a robot that holds an object: the interpolated points replace the selected links, the grasped
+    object's points follow un-interpolated (distance_fields.py:139-152), pair rows index both (robot_base.py:103-130).  No
+    reference golden exists for this combination (the reference raises on the grasped-object gather): fp64 oracle."""
+    from torch_robotics_amd import ops
+    go = tra.GraspedObjectPandaBox(tensor_args=TA)
+    robot = tra.RobotPanda(grasped_object=go, tensor_args=TA, num_interpolated_points_for_object_collision_checking=10,
+                           num_interpolated_points_for_self_collision_checking=16)
+    G = go.n_base_points_for_collision
+    assert robot.link_margins_for_object_collision_checking_tensor.shape == (10 + G,)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    assert task.interpolate_link_pos and robot.df_collision_self.interpolate_link_pos
+    spec = task.build_cost_spec()
+    P = len(robot.collision_point_set()[0])
+    assert spec.n_links_in == P and spec.n_columns == P + 10 + 16
+    assert list(spec.obj_link_idx[:10]) == list(range(P, P + 10)) and list(spec.obj_link_idx[10:]) == list(range(P - G, P))
+    q = robot.random_q(300, generator=torch.Generator(device=DEV).manual_seed(3)).reshape(300, 1, 7)
+    pos, cost, gq = task.rollout_cost_grad(q, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0)
+    pl, po = robot.collision_point_set()
+    o = oracle_lib.Oracle(robot.diff_panda._kin, spec)
+    p64, c64, g64 = o.rollout_points(pl, po, q.reshape(-1, 7).cpu().numpy().astype(np.float64), (1, 1, 1, 0), "f64")
+    assert np.abs(pos.reshape(-1, P, 3).cpu().numpy() - p64).max() < TOL_H
+    assert rel_err(cost.reshape(-1).cpu().numpy(), c64) < TOL_C and grad_close(gq.reshape(-1, 7).cpu().numpy(), g64)
+    # autograd through the task API and the boolean path agree with the fused call
+    qg = q.clone().requires_grad_(True)
+    c2 = task.compute_collision_cost(qg)
+    c2.sum().backward()
+    assert torch.allclose(c2, cost, rtol=1e-6, atol=1e-6) and torch.allclose(qg.grad, gq, rtol=1e-5, atol=1e-6)
+    coll = task.compute_collision(q)
+    ref = o.collision_fields(7, p64, None, "f64").reshape(300, 1)
+    assert (coll.cpu().numpy() != ref).sum() <= 1
