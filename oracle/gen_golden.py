@@ -865,6 +865,87 @@ def interp_goldens():
     print("cost_interp: flag_result =", out["flag_result"])
 
 
+def tree_cost_goldens(trees):
+    """`python oracle/gen_golden.py treecost`.  BASELINE configs 4 and 5 pinned to the reference: the authored UR10 + Allegro and
+    dual-Panda robots have no Robot class in the reference, so its OWN pieces are assembled the way RobotBase / PlanningTask
+    assemble them for the Panda (robot_base.py:57-141, tasks.py:44-80): DifferentiableTree FK (all links) -> link positions ->
+    CollisionSelfField / CollisionObjectDistanceField / CollisionWorkspaceBoundariesDistanceField on the link sets of the build's
+    collision templates (torch_robotics_amd/codegen.py: ur10_allegro_template, dual_panda_template -- data, passed in by index
+    lists) + one EESE3DistanceField per tracked link; gradients by the reference's autograd through its FK recursion."""
+    from types import SimpleNamespace
+    from torch_robotics.environments.env_spheres_3d import EnvSpheres3D
+    from torch_robotics.torch_planning_objectives.fields.distance_fields import (
+        CollisionObjectDistanceField, CollisionSelfField, CollisionWorkspaceBoundariesDistanceField, EESE3DistanceField)
+    from torch_robotics.torch_kinematics_tree.geometrics.utils import link_pos_from_link_tensor
+    sys.path.insert(0, str(REPO))
+    from torch_robotics_amd import codegen                      # the collision templates are DATA of the build (index lists)
+    from torch_robotics_amd.kinmodel import KinModel
+    env = EnvSpheres3D(tensor_args=TA)
+    cutoff, self_margin, obj_margin = 0.03, 0.04, 0.07
+    for name, tmpl_fn, n in (("ur10_allegro", codegen.ur10_allegro_template, 24), ("dual_panda", codegen.dual_panda_template, 24)):
+        tree = trees[name]
+        kin = KinModel.from_urdf(str(URDF_OUT / f"{name}.urdf"))
+        tm = tmpl_fn(kin)
+        assert kin.link_names == tree.get_link_names()
+        robot = SimpleNamespace(grasped_object=None)             # what the field code reads of its robot (distance_fields.py:137)
+        obj_idx = list(tm.obj_links)
+        margins = torch.full((len(obj_idx),), obj_margin, **TA)
+        self_links = sorted({a for p in tm.self_pairs for a in p})
+        pairs = [(self_links.index(a), self_links.index(b)) for a, b in tm.self_pairs]
+        f_obj = CollisionObjectDistanceField(robot, df_obj_list_fn=env.get_df_obj_list, link_idxs_for_collision_checking=obj_idx,
+                                             num_interpolated_points=len(obj_idx), link_margins_for_object_collision_checking_tensor=margins,
+                                             cutoff_margin=cutoff, tensor_args=TA)
+        f_ws = CollisionWorkspaceBoundariesDistanceField(robot, ws_bounds_min=env.limits[0], ws_bounds_max=env.limits[1],
+                                                         link_idxs_for_collision_checking=obj_idx, num_interpolated_points=len(obj_idx),
+                                                         link_margins_for_object_collision_checking_tensor=margins,
+                                                         cutoff_margin=cutoff, tensor_args=TA)
+        f_self = CollisionSelfField(robot, link_idxs_for_collision_checking=self_links, idxs_links_distance_matrix=pairs,
+                                    num_interpolated_points=len(self_links),
+                                    cutoff_margin=torch.full((len(pairs),), self_margin, **TA), tensor_args=TA)
+        gen = torch.Generator().manual_seed(808)
+        q0 = sample_q(tree, n, gen, 0.1)
+        # EE targets: poses the tracked links reach for another configuration, pushed a little
+        q_t = sample_q(tree, 1, gen, 0.0)
+        H_t = tree.compute_forward_kinematics_all_links(q_t)[0]
+        tracked = [l for l in (tm.ee_link, tm.ee2_link) if l >= 0]
+        targets = []
+        for l in tracked:
+            Ht = H_t[l].clone(); Ht[:3, 3] += torch.tensor([0.05, -0.03, 0.04])
+            targets.append(Ht)
+        f_ee = [EESE3DistanceField(Ht, w_pos=1.0, w_rot=1.0, square=True, tensor_args=TA) for Ht in targets]
+        out = dict(q=q0.numpy(), cutoff=np.float32(cutoff), limits=env.limits.numpy(), obj_link_idxs=np.asarray(obj_idx, np.int32),
+                   obj_margins=margins.numpy(), self_link_idxs=np.asarray(self_links, np.int32), self_pairs=np.asarray(pairs, np.int32),
+                   self_margins=np.full(len(pairs), self_margin, np.float32), ee_links=np.asarray(tracked, np.int32),
+                   ee_targets=torch.stack(targets).numpy())
+
+        def parts(q):
+            H = tree.compute_forward_kinematics_all_links(q)
+            pos = link_pos_from_link_tensor(H)
+            c = dict(self=f_self.compute_cost(q, pos, field_type="sdf").reshape(-1),
+                     objects=f_obj.compute_cost(q, pos, field_type="sdf").reshape(-1),
+                     ws=f_ws.compute_cost(q, pos, field_type="sdf").reshape(-1))
+            ee = 0.0
+            for l, f in zip(tracked, f_ee):
+                ee = ee + f.compute_costs_impl(q, H[:, l:l + 1]).reshape(-1)
+            c["ee"] = ee
+            return H, pos, c
+        for fname in ("self", "objects", "ws", "ee"):
+            q = q0.clone().requires_grad_(True)
+            _, _, c = parts(q)
+            (gq,) = torch.autograd.grad(c[fname].sum(), q)
+            out[f"cost_{fname}"], out[f"gq_{fname}"] = c[fname].detach().numpy(), gq.numpy()
+        q = q0.clone().requires_grad_(True)
+        H, pos, c = parts(q)
+        total = c["self"] + c["objects"] + c["ws"] + c["ee"]
+        (gq,) = torch.autograd.grad(total.sum(), q)
+        out["cost_total"], out["gq_total"], out["link_pos"] = total.detach().numpy(), gq.numpy(), pos.detach().numpy()
+        for fname, f in (("self", f_self), ("objects", f_obj), ("ws", f_ws)):
+            out[f"coll_{fname}"] = f.compute_cost(q0, pos.detach(), field_type="occupancy").reshape(-1).numpy()
+            out[f"coll0_{fname}"] = f.compute_cost(q0, pos.detach(), field_type="occupancy", margin=0.0).reshape(-1).numpy()
+        np.savez_compressed(GOLD / f"cost_tree_{name}.npz", **out)
+        print(f"cost_tree_{name}: {n} samples, {len(obj_idx)} collision links, {len(pairs)} pairs, {len(tracked)} tracked")
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     URDF_OUT.mkdir(parents=True, exist_ok=True)
@@ -888,6 +969,9 @@ def main():
         return
     if sys.argv[1:] == ["interp"]:
         interp_goldens()
+        return
+    if sys.argv[1:] == ["treecost"]:
+        tree_cost_goldens({n: quiet(DifferentiableTree, str(URDF_OUT / f"{n}.urdf"), n) for n in ("ur10_allegro", "dual_panda")})
         return
     trees = {}
     for name, rel in ROBOTS.items():
@@ -922,6 +1006,7 @@ def main():
     frame_goldens()
     clamp_goldens()
     interp_goldens()
+    tree_cost_goldens(trees)
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
 

@@ -176,3 +176,22 @@ def single_link_self_spec():
     spec.self_margin = np.asarray([g["single_margin"]], np.float32)
     spec.validate()
     return spec
+
+
+def tree_cost_spec(name):
+    """(KinModel, CostModelSpec, golden) of tests/golden/cost_tree_<name>.npz: the UR10 + Allegro / dual-Panda collision models of
+    BASELINE configs 4 / 5 (link sets of codegen.ur10_allegro_template / dual_panda_template) on EnvSpheres3D, as the reference's
+    field classes evaluated them."""
+    g, gs = gold(f"cost_tree_{name}"), gold("cost_spheres3d")
+    m = model(name)
+    spec = CostModelSpec(n_links_in=m.n_links)
+    spec.obj_link_idx = g["obj_link_idxs"]
+    spec.obj_link_margin = (g["obj_margins"].astype(np.float32) + np.float32(g["cutoff"])).astype(np.float32)
+    spec.objects = objects_from_golden(gs, "fixed")
+    spec.ws_min, spec.ws_max = g["limits"][0], g["limits"][1]
+    spec.self_link_idx, spec.self_pairs, spec.self_margin = g["self_link_idxs"], g["self_pairs"], g["self_margins"]
+    spec.ee_link, spec.ee_target = int(g["ee_links"][0]), g["ee_targets"][0]
+    if len(g["ee_links"]) > 1:
+        spec.ee2_link, spec.ee2_target = int(g["ee_links"][1]), g["ee_targets"][1]
+    spec.validate()
+    return m, spec, g

@@ -1304,3 +1304,35 @@ def test_jtj_normal_equations(ops, oracle_lib, robot, link):
             ops.jtj(lin, ang, r, mfma=True)
     with pytest.raises(ValueError):
         ops.jtj(lin, ang[:, :2], r)
+
+
+@pytest.mark.parametrize("name", ["ur10_allegro", "dual_panda"])
+def test_tree_robot_costs_vs_reference_goldens(ops, name):
+    """BASELINE configs 4 / 5: the generated units of UR10 + Allegro and dual Panda (and the table-driven kernels) against costs and
+    gradients the REFERENCE computed for these robots -- its field classes on its own FK, autograd through the FK recursion
+    (tests/golden/cost_tree_<robot>.npz); fused rollout, fp16 I/O within fp16 rounding, boolean fields."""
+    from helpers import tree_cost_spec
+    m, spec, g = tree_cost_spec(name)
+    h, cm = ops.ModelHandle(m), ops.CostHandle(spec, DEV)
+    q = dev(g["q"])
+    for use_spec in (True, False):
+        h.enable_specialized(use_spec)
+        assert h.specialized == use_spec
+        for fname, w in (("self", (1, 0, 0, 0)), ("objects", (0, 1, 0, 0)), ("ws", (0, 0, 1, 0)), ("ee", (0, 0, 0, 1)), ("total", (1, 1, 1, 1))):
+            pos, c, gq = ops.rollout_cost_grad(h, cm, w, q)
+            assert rel_err(c.cpu().numpy(), g[f"cost_{fname}"]) < TOL_C, (fname, use_spec)
+            assert grad_close(gq.cpu().numpy(), g[f"gq_{fname}"]), (fname, use_spec)
+        assert np.abs(pos.cpu().numpy() - g["link_pos"]).max() < TOL_H
+        for fname, fl in (("self", FIELD_SELF), ("objects", FIELD_OBJECTS), ("ws", FIELD_WS)):
+            assert np.array_equal(ops.rollout_collision(h, cm, fl, q).cpu().numpy(), g[f"coll_{fname}"]), (fname, use_spec)
+            assert np.array_equal(ops.rollout_collision(h, cm, fl, q, margin=0.0).cpu().numpy(), g[f"coll0_{fname}"]), (fname, use_spec)
+    h.enable_specialized(True)
+    # fp16 I/O (config 5's storage format): the reference's fp32 values within the rounding of q, positions and gradient to fp16
+    pos16, c16, g16 = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q.half())
+    _, c32, g32 = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q.half().float())
+    assert pos16.dtype == torch.float16 and torch.equal(c16, c32)
+    assert rel_err(g16.float().cpu().numpy(), g32.cpu().numpy()) < 2.0 ** -10
+    # the field kernels on the reference's link positions
+    lp = dev(g["link_pos"])
+    for fname, fl in (("self", FIELD_SELF), ("objects", FIELD_OBJECTS), ("ws", FIELD_WS)):
+        assert rel_err(ops.cost_fields(cm, fl, lp).cpu().numpy(), g[f"cost_{fname}"]) < TOL_C, fname

@@ -447,3 +447,23 @@ def test_single_link_self_distance(oracle_lib, prec):
     _, c2, gq = o.rollout(g["q"].reshape(-1, 7), (1, 0, 0, 0), prec)
     assert rel_err(c2, g["single_cost"].reshape(-1)) < 1e-6 and rel_err(gq, g["single_gq"].reshape(-1, 7)) < 1e-5
     assert np.array_equal(o.collision_fields(FIELD_SELF, pos, None, prec), g["single_coll"].reshape(-1))
+
+
+@pytest.mark.parametrize("name", ["ur10_allegro", "dual_panda"])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_tree_robot_costs_of_configs_4_and_5(oracle_lib, name, prec):
+    """BASELINE configs 4 / 5 robots: self / object / workspace / EE costs and d/dq against the reference's field classes + autograd
+    through its FK on the authored UR10 + Allegro and dual-Panda trees (oracle/gen_golden.py treecost)."""
+    from helpers import tree_cost_spec
+    m, spec, g = tree_cost_spec(name)
+    o = oracle_lib.Oracle(m, spec)
+    q = g["q"]
+    tol_c, tol_g = (1e-5, 1e-4) if prec == "f32" else (3e-6, 3e-5)
+    for fname, w in (("self", (1, 0, 0, 0)), ("objects", (0, 1, 0, 0)), ("ws", (0, 0, 1, 0)), ("ee", (0, 0, 0, 1)), ("total", (1, 1, 1, 1))):
+        pos, c, gq = o.rollout(q, w, prec)
+        assert rel_err(c, g[f"cost_{fname}"]) < tol_c, fname
+        assert rel_err(gq, g[f"gq_{fname}"]) < tol_g, fname
+    assert np.abs(pos - g["link_pos"]).max() < 2e-6
+    for fname, fl in (("self", FIELD_SELF), ("objects", FIELD_OBJECTS), ("ws", FIELD_WS)):
+        assert np.array_equal(o.collision_fields(fl, g["link_pos"], None, prec), g[f"coll_{fname}"]), fname
+        assert np.array_equal(o.collision_fields(fl, g["link_pos"], 0.0, prec), g[f"coll0_{fname}"]), fname
