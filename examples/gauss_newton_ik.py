@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Batched inverse kinematics of the Panda by damped Gauss-Newton (Levenberg-Marquardt) on the geometric Jacobian -- what the
+reference's `compute_forward_kinematics_and_geometric_jacobian` (robot_tree.py:218-248) is for, taken one step further: per
+iteration one Jacobian kernel (`trk_fk_jacobian`: position, quaternion, lin_jac, ang_jac of the end effector), one normal-equation
+kernel (`trk_jtj`: J^T J and J^T r per sample) and a batched 7 x 7 solve.  Converges in ~10 iterations where the Adam loop of
+examples/inverse_kinematics.py takes hundreds.  Needs the MI355X: there is no CPU path.
+
+    python examples/gauss_newton_ik.py [--batch 4096]
+"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import torch
+
+from torch_robotics_amd import DifferentiableFrankaPanda, SE3_distance, ops
+
+
+def pose_residual(pos, quat_wxyz, H_target):
+    """6-vector r = [p* - p, rotation vector of R* R^T] (world frame): the Newton step solves J dq = r."""
+    dp = H_target[:3, 3] - pos
+    # target quaternion (wxyz) from the target rotation, then q_err = q* (x) conj(q): the rotation taking R to R*
+    qt = ops.rotmat_to_quat(H_target[:3, :3].reshape(1, 3, 3)).expand_as(quat_wxyz)
+    w1, v1 = qt[:, :1], qt[:, 1:]
+    w2, v2 = quat_wxyz[:, :1], -quat_wxyz[:, 1:]
+    w = w1 * w2 - (v1 * v2).sum(-1, keepdim=True)
+    v = w1 * v2 + w2 * v1 + torch.linalg.cross(v1, v2)
+    v = torch.where(w < 0, -v, v)
+    w = w.abs().clamp(max=1.0)
+    n = v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    rotvec = v / n * (2.0 * torch.atan2(n, w))
+    return torch.cat([dp, rotvec], -1)
+
+
+def main(batch_size=4096, device="cuda:0", max_iters=40, damping=1e-4, verbose=True, mfma=False):
+    torch.manual_seed(0)
+    tree = DifferentiableFrankaPanda(gripper=False, device=device)
+    lo, hi, _, _ = tree.get_joint_limit_array()
+    lo, hi = (torch.as_tensor(a, device=device, dtype=torch.float32) for a in (lo, hi))
+    # a reachable target: the end-effector pose of a random configuration
+    q_star = lo + torch.rand(1, 7, device=device) * (hi - lo)
+    H_target = tree.compute_forward_kinematics_all_links(q_star, link_list=["ee_link"])[0, 0]
+    q = lo + torch.rand(batch_size, 7, device=device) * (hi - lo)
+    link = tree._name_to_idx_map["ee_link"]
+    def step(q):
+        pos, quat, lin, ang = ops.fk_jacobian(tree._handle, q, None, link)
+        r = pose_residual(pos, quat, H_target)
+        lam = damping + 0.1 * (r * r).sum(-1)             # Levenberg-Marquardt: damp in proportion to the squared error
+        _, _, dq = ops.jtj(lin, ang, r, mfma=mfma, damping=lam, solve=True)     # the 7 x 7 solve happens inside the kernel
+        return torch.minimum(torch.maximum(q + dq, lo), hi)
+
+    step(q)                                               # first use of every kernel (code-object load): not part of the timing
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(max_iters):
+        q = step(q)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    H_ee = tree.compute_forward_kinematics_all_links(q, link_list=["ee_link"])[:, 0]
+    err = SE3_distance(H_ee, H_target)
+    ok = int((err < 1e-3).sum())
+    if verbose:
+        print(f"{max_iters} Gauss-Newton iterations x {batch_size} problems in {elapsed * 1e3:.1f} ms "
+              f"({elapsed / max_iters * 1e6:.0f} us per iteration)")
+        print(f"converged (SE(3) distance < 1e-3): {ok}/{batch_size}; median error {float(err.median()):.2e}")
+    return q, err
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--mfma", action="store_true", help="use the matrix-core kernel of trk_jtj")
+    a = ap.parse_args()
+    main(batch_size=a.batch, mfma=a.mfma)

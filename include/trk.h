@@ -517,9 +517,11 @@ int trk_traj_diff_norm_sum(const float* x, int64_t batch, int32_t horizon, int32
  * BUILD-DEFINED: per sample J = [lin_jac; ang_jac] (6 x D):  JtJ [n, D, D] = J^T J,  Jtr [n, D] = J^T residual (nullable;
  * residual [n, 6] = [linear(3), angular(3)]) -- what a damped least-squares / Gauss-Newton IK step solves (JtJ + lambda I) dq = Jtr.
  * use_mfma != 0 computes JtJ with v_mfma_f32_4x4x1_16b_f32 (dof <= 8) instead of per-lane FMAs: the same values to fp32 rounding;
- * both variants exist so that the two can be measured side by side (the op is HBM-bound). */
+ * both variants exist so that the two can be measured side by side (the op is HBM-bound).
+ * dq (nullable) [n, D]: the damped step itself, (JtJ + lambda I) dq = Jtr solved per sample by a Cholesky factorisation in the
+ * kernel (needs `residual`); damping: DEVICE lambda, [n] with damping_stride 1 or one value with damping_stride 0 (NULL: 0). */
 int trk_jtj(const float* lin_jac, const float* ang_jac, const float* residual, int64_t n, int32_t dof, int32_t use_mfma,
-            float* JtJ, float* Jtr, trk_stream_t stream);
+            float* JtJ, float* Jtr, const float* damping, int32_t damping_stride, float* dq, trk_stream_t stream);
 
 /* The chain rule of the fused rollout under autograd: out[n, :] = g[n, :] * scale[n * scale_stride] -- the saved
  * d cost[n] / d q[n, :] of trk_rollout_cost_grad times the upstream gradient of cost[n] (what

@@ -1299,6 +1299,14 @@ def test_jtj_normal_equations(ops, oracle_lib, robot, link):
             assert np.abs(Jtr.cpu().numpy() - ref_r).max() <= 2e-6 * max(1.0, np.abs(ref_r).max()), (n, mfma)
             assert torch.equal(JtJ, JtJ.transpose(1, 2))                        # exactly symmetric (a product commutes)
             assert torch.equal(ops.jtj(lin, ang, mfma=mfma), JtJ)               # without a residual: JtJ alone
+            # the damped step, solved inside the kernel (Cholesky per sample), against numpy's fp64 solve
+            for lam_t in (torch.tensor([0.05], device=DEV), torch.linspace(0.01, 0.2, n, device=DEV)):
+                J2, r2, dq = ops.jtj(lin, ang, r, mfma=mfma, damping=lam_t, solve=True)
+                assert torch.equal(J2, JtJ) and torch.equal(r2, Jtr)
+                lam = lam_t.cpu().numpy().astype(np.float64).reshape(-1)
+                A = ref + (lam[:, None, None] if lam.size == n else lam[0]) * np.eye(D)
+                x = np.linalg.solve(A, ref_r[..., None])[..., 0]
+                assert np.abs(dq.cpu().numpy() - x).max() <= 2e-4 * max(1.0, np.abs(x).max()), (n, mfma)
     if D > 8:
         with pytest.raises(NotImplementedError):
             ops.jtj(lin, ang, r, mfma=True)

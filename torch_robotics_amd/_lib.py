@@ -117,7 +117,7 @@ def lib():
     L.trk_pack_sums.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.trk_pack_sums_scratch_bytes.argtypes = [i32, i32]
     L.trk_pack_sums_scratch_bytes.restype = C.c_int64
-    L.trk_jtj.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
+    L.trk_jtj.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i32, vp, vp]
     L.trk_scale_rows.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
     L.trk_point_set_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
     L.trk_point_set_destroy.argtypes = [vp]

@@ -1248,14 +1248,15 @@ int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, 
 }
 
 int trk_jtj(const float* lin_jac, const float* ang_jac, const float* residual, int64_t n, int32_t dof, int32_t use_mfma,
-            float* JtJ, float* Jtr, trk_stream_t stream) {
-    if (n < 0 || dof < 1 || dof > TRK_MAX_DOFS || (n > 0 && (!lin_jac || !ang_jac || !JtJ)) || (Jtr && !residual))
+            float* JtJ, float* Jtr, const float* damping, int32_t damping_stride, float* dq, trk_stream_t stream) {
+    if (n < 0 || dof < 1 || dof > TRK_MAX_DOFS || (n > 0 && (!lin_jac || !ang_jac || !JtJ)) || ((Jtr || dq) && !residual) ||
+        (damping && damping_stride != 0 && damping_stride != 1))
         return fail(TRK_ERR_INVALID_ARG, "trk_jtj: bad argument");
     if (use_mfma && dof > 8) return fail(TRK_ERR_UNSUPPORTED, "trk_jtj: the MFMA kernel tiles an 8 x 8 matrix per sample (dof <= 8)");
     if (n == 0) return TRK_OK;
     int rc = ensure_init();
     if (rc) return rc;
-    if (trk_launch_jtj(use_mfma != 0, lin_jac, ang_jac, residual, n, dof, JtJ, Jtr, (hipStream_t)stream))
+    if (trk_launch_jtj(use_mfma != 0, lin_jac, ang_jac, residual, n, dof, JtJ, Jtr, damping, damping_stride, dq, (hipStream_t)stream))
         return fail(TRK_ERR_UNSUPPORTED, "trk_jtj: tiles exceed the 160 KiB LDS");
     TRK_HIP(hipGetLastError());
     return TRK_OK;

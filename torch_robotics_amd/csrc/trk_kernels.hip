@@ -1678,7 +1678,7 @@ __device__ __forceinline__ int trk_div_small(int k, int w, float inv_w) {
 template <bool MFMA>
 __global__ void __launch_bounds__(TRK_JTJ_WAVES * TRK_WAVE)
 k_jtj(const float* __restrict__ lin, const float* __restrict__ ang, const float* __restrict__ r6, int64_t n, int D,
-      float* __restrict__ JtJ, float* __restrict__ Jtr) {
+      float* __restrict__ JtJ, float* __restrict__ Jtr, const float* __restrict__ damping, int damping_stride, float* __restrict__ dq) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & (TRK_WAVE - 1), wave = threadIdx.x / TRK_WAVE;
     const int64_t base = ((int64_t)blockIdx.x * TRK_JTJ_WAVES + wave) * TRK_WAVE;
@@ -1749,7 +1749,7 @@ k_jtj(const float* __restrict__ lin, const float* __restrict__ ang, const float*
             }
         }
     }
-    if (Jtr) {
+    if (Jtr || dq) {
         float rv[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) rv[k] = (r6 && lane < rows) ? r6[(base + lane) * 6 + k] : 0.0f;
@@ -1770,6 +1770,38 @@ k_jtj(const float* __restrict__ lin, const float* __restrict__ ang, const float*
         for (int k = lane; k < rows * dd; k += TRK_WAVE) jdst[k] = get(k);
     }
     if (Jtr) for (int k = lane; k < rows * D; k += TRK_WAVE) { const int s = trk_div_small(k, D, inv_D); Jtr[base * D + k] = ot[s * os + dd + (k - s * D)]; }
+    if (dq) {
+        // damped Gauss-Newton / Levenberg-Marquardt step per sample: (JtJ + lambda I) dq = Jtr by an in-place Cholesky factorisation
+        // in the lane's own row of the output tile (already copied out above), then the two triangular solves
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float lam = (damping && lane < rows) ? damping[(base + lane) * damping_stride] : 0.0f;
+        float* Am = out;                                    // [D][D] row-major, lower triangle becomes L
+        float* bv = out + dd;                               // right-hand side -> y -> x
+        for (int j = 0; j < D; ++j) {
+            float sdiag = Am[j * D + j] + lam;
+            for (int k = 0; k < j; ++k) sdiag = fmaf(-Am[j * D + k], Am[j * D + k], sdiag);
+            const float ljj = sqrtf(fmaxf(sdiag, 1e-20f));
+            const float inv = 1.0f / ljj;
+            Am[j * D + j] = ljj;
+            for (int i = j + 1; i < D; ++i) {
+                float v = Am[i * D + j];
+                for (int k = 0; k < j; ++k) v = fmaf(-Am[i * D + k], Am[j * D + k], v);
+                Am[i * D + j] = v * inv;
+            }
+        }
+        for (int i = 0; i < D; ++i) {                       // L y = b
+            float v = bv[i];
+            for (int k = 0; k < i; ++k) v = fmaf(-Am[i * D + k], bv[k], v);
+            bv[i] = v / Am[i * D + i];
+        }
+        for (int i = D - 1; i >= 0; --i) {                  // L^T x = y
+            float v = bv[i];
+            for (int k = i + 1; k < D; ++k) v = fmaf(-Am[k * D + i], bv[k], v);
+            bv[i] = v / Am[i * D + i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = lane; k < rows * D; k += TRK_WAVE) { const int s = trk_div_small(k, D, inv_D); dq[base * D + k] = ot[s * os + dd + (k - s * D)]; }
+    }
 }
 
 // out[n, :] = g[n, :] * s[n]: the chain rule of the fused rollout under autograd -- its saved d cost[n] / d q[n, :] times the
@@ -2203,13 +2235,14 @@ void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int 
     if (gathered && T > 0) hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)T), dim3(128), 0, st, x, H * S, inner > 0 ? 2 : 1, idx, inner, gathered);
 }
 
-int trk_launch_jtj(int mfma, const float* lin, const float* ang, const float* r6, int64_t n, int D, float* JtJ, float* Jtr, hipStream_t st) {
+int trk_launch_jtj(int mfma, const float* lin, const float* ang, const float* r6, int64_t n, int D, float* JtJ, float* Jtr,
+                   const float* damping, int damping_stride, float* dq, hipStream_t st) {
     if (mfma && D > 8) return -1;
     const size_t lds = sizeof(float) * TRK_JTJ_WAVES * TRK_WAVE * (((size_t)(6 * (mfma ? 8 : D)) | 1) + ((size_t)(D * D + D) | 1));
     if (lds > 160 * 1024) return -1;
     const dim3 grid(grid_for(n, TRK_JTJ_WAVES * TRK_WAVE)), block(TRK_JTJ_WAVES * TRK_WAVE);
-    if (mfma) hipLaunchKernelGGL(k_jtj<true>, grid, block, lds, st, lin, ang, r6, n, D, JtJ, Jtr);
-    else hipLaunchKernelGGL(k_jtj<false>, grid, block, lds, st, lin, ang, r6, n, D, JtJ, Jtr);
+    if (mfma) hipLaunchKernelGGL(k_jtj<true>, grid, block, lds, st, lin, ang, r6, n, D, JtJ, Jtr, damping, damping_stride, dq);
+    else hipLaunchKernelGGL(k_jtj<false>, grid, block, lds, st, lin, ang, r6, n, D, JtJ, Jtr, damping, damping_stride, dq);
     return 0;
 }
 

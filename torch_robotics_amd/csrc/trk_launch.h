@@ -53,7 +53,8 @@ void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int 
                               const float* qmax, int64_t inner, uint8_t* flags, int64_t* idx, int32_t* counts,
                               int32_t* counts_host, int32_t ticket, float* gathered, hipStream_t st);
 void trk_launch_grid_pack(const float* sdf, const float* grad, int64_t n, float4* cells, hipStream_t st);
-int trk_launch_jtj(int mfma, const float* lin, const float* ang, const float* r6, int64_t n, int D, float* JtJ, float* Jtr, hipStream_t st);
+int trk_launch_jtj(int mfma, const float* lin, const float* ang, const float* r6, int64_t n, int D, float* JtJ, float* Jtr,
+                   const float* damping, int damping_stride, float* dq, hipStream_t st);
 size_t trk_pack_scratch_floats(int H, int D);
 void trk_launch_pack_sums(const float* cost, const float* gq, const float* block_sums, int B, int H, int D, int64_t nb, float* scratch,
                           float* out, hipStream_t st);

@@ -1051,9 +1051,12 @@ def traj_validate(waypoint_collisions: torch.Tensor, trajs: torch.Tensor, n_dofs
     return r
 
 
-def jtj(lin_jac: torch.Tensor, ang_jac: torch.Tensor, residual: Optional[torch.Tensor] = None, mfma: bool = False):
+def jtj(lin_jac: torch.Tensor, ang_jac: torch.Tensor, residual: Optional[torch.Tensor] = None, mfma: bool = False,
+        damping: Optional[torch.Tensor] = None, solve: bool = False):
     """Normal equations of the geometric Jacobian (robot_tree.py:238-246): lin_jac, ang_jac (N, 3, D) [+ residual (N, 6)] ->
-    JtJ (N, D, D) [, Jtr (N, D)] with J = [lin_jac; ang_jac].  mfma=True runs the matrix-core kernel (D <= 8)."""
+    JtJ (N, D, D) [, Jtr (N, D)] with J = [lin_jac; ang_jac].  mfma=True runs the matrix-core kernel (D <= 8).
+    solve=True also returns dq (N, D) = (JtJ + damping I)^-1 Jtr, factorised per sample inside the kernel; damping: a device
+    tensor of one value or of N values (None: 0)."""
     lin, ang = _dev_f32(lin_jac, "jtj(lin_jac)"), _dev_f32(ang_jac, "jtj(ang_jac)")
     if lin.dim() != 3 or lin.shape[1] != 3 or ang.shape != lin.shape:
         raise ValueError("jtj: lin_jac and ang_jac must both be (N, 3, D)")
@@ -1063,11 +1066,22 @@ def jtj(lin_jac: torch.Tensor, ang_jac: torch.Tensor, residual: Optional[torch.T
         res = _dev_f32(residual, "jtj(residual)")
         if tuple(res.shape) != (n, 6):
             raise ValueError("jtj: residual must be (N, 6)")
+    if solve and res is None:
+        raise ValueError("jtj(solve=True) needs the residual")
+    dmp, stride = None, 0
+    if damping is not None:
+        dmp = _dev_f32(damping, "jtj(damping)").reshape(-1)
+        if dmp.numel() not in (1, n):
+            raise ValueError("jtj: damping must hold one value or one per sample")
+        stride = int(dmp.numel() == n and n > 1)
     JtJ = torch.empty((n, D, D), device=lin.device, dtype=torch.float32)
     Jtr = torch.empty((n, D), device=lin.device, dtype=torch.float32) if res is not None else None
+    dq = torch.empty((n, D), device=lin.device, dtype=torch.float32) if solve else None
     with _on(lin.device):
-        check(lib().trk_jtj(lin.data_ptr(), ang.data_ptr(), _ptr(res), n, D, int(bool(mfma)), JtJ.data_ptr(), _ptr(Jtr), _stream(lin)),
-              "trk_jtj")
+        check(lib().trk_jtj(lin.data_ptr(), ang.data_ptr(), _ptr(res), n, D, int(bool(mfma)), JtJ.data_ptr(), _ptr(Jtr), _ptr(dmp), stride,
+                            _ptr(dq), _stream(lin)), "trk_jtj")
+    if solve:
+        return JtJ, Jtr, dq
     return (JtJ, Jtr) if res is not None else JtJ
 
 
