@@ -38,6 +38,8 @@ def test_ops_are_registered_with_the_dispatcher(handles):
     assert ops.handle_of(m.uid) is m and ops.handle_of(cm.uid) is cm
     with pytest.raises(ValueError, match="not a live"):
         torch.ops.trk.fk(torch.zeros(2, 7, device=DEV), 12345, None)
+    with pytest.raises(ValueError, match="expected a ModelHandle"):      # a cost model's id where a model's is expected
+        torch.ops.trk.fk(torch.zeros(2, 7, device=DEV), cm.uid, None)
 
 
 def test_opcheck(handles):

@@ -26,8 +26,20 @@ from . import ops
 handle_of = ops.handle_of
 
 
+def _model(uid):
+    return handle_of(uid, ops.ModelHandle)
+
+
+def _cost(uid):
+    return handle_of(uid, ops.CostHandle)
+
+
+def _points(uid):
+    return handle_of(uid, ops.PointSetHandle)
+
+
 def _n_cols(model_uid: int, sel: Optional[Sequence[int]]) -> int:
-    return len(sel) if sel is not None else handle_of(model_uid).n_links
+    return len(sel) if sel is not None else _model(model_uid).n_links
 
 
 def _rows(q: Tensor, d: int) -> int:
@@ -39,18 +51,18 @@ def _rows(q: Tensor, d: int) -> int:
 # ----------------------------------------------------------------------------------------------------------------------
 @torch.library.custom_op("trk::fk", mutates_args=(), device_types="cuda")
 def fk(q: Tensor, model: int, sel: Optional[List[int]]) -> Tensor:
-    return ops.fk_forward(handle_of(model), q, sel)
+    return ops.fk_forward(_model(model), q, sel)
 
 
 @fk.register_fake
 def _(q, model, sel):
-    m = handle_of(model)
+    m = _model(model)
     return q.new_empty((_rows(q, m.n_dofs), _n_cols(model, sel), 4, 4), dtype=torch.float32)
 
 
 @torch.library.custom_op("trk::fk_backward", mutates_args=(), device_types="cuda")
 def fk_backward(q: Tensor, gH: Tensor, model: int, sel: Optional[List[int]]) -> Tensor:
-    return ops.fk_backward(handle_of(model), q, gH.contiguous(), sel).reshape(q.shape)
+    return ops.fk_backward(_model(model), q, gH.contiguous(), sel).reshape(q.shape)
 
 
 @fk_backward.register_fake
@@ -73,18 +85,18 @@ fk.register_autograd(_fk_bwd, setup_context=_fk_setup)
 
 @torch.library.custom_op("trk::fk_positions", mutates_args=(), device_types="cuda")
 def fk_positions(q: Tensor, model: int, sel: Optional[List[int]]) -> Tensor:
-    return ops.fk_positions(handle_of(model), q, sel)
+    return ops.fk_positions(_model(model), q, sel)
 
 
 @fk_positions.register_fake
 def _(q, model, sel):
-    m = handle_of(model)
+    m = _model(model)
     return q.new_empty((_rows(q, m.n_dofs), _n_cols(model, sel), 3), dtype=torch.float32)
 
 
 @torch.library.custom_op("trk::fk_positions_backward", mutates_args=(), device_types="cuda")
 def fk_positions_backward(q: Tensor, gpos: Tensor, model: int, sel: Optional[List[int]]) -> Tensor:
-    return ops.fk_positions_backward(handle_of(model), q, gpos.contiguous(), sel).reshape(q.shape)
+    return ops.fk_positions_backward(_model(model), q, gpos.contiguous(), sel).reshape(q.shape)
 
 
 @fk_positions_backward.register_fake
@@ -105,17 +117,17 @@ fk_positions.register_autograd(_fkp_bwd, setup_context=_fk_setup)
 # ----------------------------------------------------------------------------------------------------------------------
 @torch.library.custom_op("trk::cost_fields", mutates_args=(), device_types="cuda")
 def cost_fields(link_pos: Tensor, cm: int, fields: int) -> Tensor:
-    return ops.cost_fields(handle_of(cm), fields, link_pos)
+    return ops.cost_fields(_cost(cm), fields, link_pos)
 
 
 @cost_fields.register_fake
 def _(link_pos, cm, fields):
-    return link_pos.new_empty((link_pos.numel() // (3 * handle_of(cm).n_links_in),), dtype=torch.float32)
+    return link_pos.new_empty((link_pos.numel() // (3 * _cost(cm).n_links_in),), dtype=torch.float32)
 
 
 @torch.library.custom_op("trk::cost_fields_backward", mutates_args=(), device_types="cuda")
 def cost_fields_backward(link_pos: Tensor, gcost: Tensor, cm: int, fields: int) -> Tensor:
-    _, g = ops.cost_fields(handle_of(cm), fields, link_pos, gcost=gcost.contiguous(), want_grad=True)
+    _, g = ops.cost_fields(_cost(cm), fields, link_pos, gcost=gcost.contiguous(), want_grad=True)
     return g.reshape(link_pos.shape)
 
 
@@ -139,7 +151,7 @@ cost_fields.register_autograd(_cf_bwd, setup_context=_cf_setup)
 
 @torch.library.custom_op("trk::ee_cost", mutates_args=(), device_types="cuda")
 def ee_cost(H: Tensor, target: Optional[Tensor], cm: int) -> Tensor:
-    return ops.ee_cost(handle_of(cm), H, target)
+    return ops.ee_cost(_cost(cm), H, target)
 
 
 @ee_cost.register_fake
@@ -149,7 +161,7 @@ def _(H, target, cm):
 
 @torch.library.custom_op("trk::ee_cost_backward", mutates_args=(), device_types="cuda")
 def ee_cost_backward(H: Tensor, target: Optional[Tensor], gcost: Tensor, cm: int) -> Tensor:
-    _, gH = ops.ee_cost(handle_of(cm), H, target, gcost=gcost.contiguous(), want_grad=True)
+    _, gH = ops.ee_cost(_cost(cm), H, target, gcost=gcost.contiguous(), want_grad=True)
     return gH.reshape(H.shape)
 
 
@@ -180,9 +192,9 @@ ee_cost.register_autograd(_ee_bwd, setup_context=_ee_setup)
 def rollout_cost_grad(q: Tensor, model: int, cm: int, weights: List[float], want_pos: bool, points: int) -> Tuple[Tensor, Tensor, Tensor]:
     """-> (cost (...), gq (..., D), link_pos (..., L | P, 3) or an empty tensor).  points = 0 or a PointSetHandle uid."""
     if points:
-        pos, cost, gq = ops.rollout_points_cost_grad(handle_of(points), handle_of(cm), weights, q, want_pos=want_pos)
+        pos, cost, gq = ops.rollout_points_cost_grad(_points(points), _cost(cm), weights, q, want_pos=want_pos)
     else:
-        pos, cost, gq = ops.rollout_cost_grad(handle_of(model), handle_of(cm), weights, q, want_pos=want_pos)
+        pos, cost, gq = ops.rollout_cost_grad(_model(model), _cost(cm), weights, q, want_pos=want_pos)
     return cost, gq, (pos if pos is not None else q.new_empty((0,)))
 
 
@@ -190,7 +202,7 @@ def rollout_cost_grad(q: Tensor, model: int, cm: int, weights: List[float], want
 def _(q, model, cm, weights, want_pos, points):
     lead = tuple(q.shape[:-1])
     io = q.dtype if q.dtype == torch.float16 and not points else torch.float32
-    n_cols = handle_of(points).n_points if points else handle_of(model).n_links
+    n_cols = _points(points).n_points if points else _model(model).n_links
     pos = q.new_empty(lead + (n_cols, 3), dtype=io) if want_pos else q.new_empty((0,))
     return q.new_empty(lead, dtype=torch.float32), q.new_empty(tuple(q.shape), dtype=io), pos
 

@@ -105,12 +105,17 @@ def _register_handle(obj) -> int:
     return uid
 
 
-def handle_of(uid: int):
-    """The live ModelHandle / CostHandle / PointSetHandle behind an integer id (`handle.uid`)."""
+def handle_of(uid: int, kind=None):
+    """The live ModelHandle / CostHandle / PointSetHandle behind an integer id (`handle.uid`).  `kind`: the class the caller
+    expects -- an id is the value of a C pointer, and a freed handle's address can be handed out again to an object of another
+    kind; a graph compiled against the old id must fail loudly, not run the wrong tables."""
     try:
-        return _handles[int(uid)]
+        h = _handles[int(uid)]
     except KeyError:
         raise ValueError(f"torch.ops.trk: {uid} is not a live model / cost-model / point-set handle") from None
+    if kind is not None and not isinstance(h, kind):
+        raise ValueError(f"torch.ops.trk: handle {uid} is a {type(h).__name__}, expected a {kind.__name__}")
+    return h
 
 
 class ModelHandle:
