@@ -1370,12 +1370,12 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         E.raw("template <bool FAST, class IO>   // FAST: scene_is_fast(A.C) -- only the few-equal-spheres scene path is compiled in")
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_per_lane} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
-        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
-        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
+        E.raw("    const int lane = __builtin_amdgcn_workitem_id_x() & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_workitem_id_x() / TRK_WAVE);   // wave-uniform -> SGPR")
         E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_per_lane});")
         E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {lds_per_lane}) + wave * TRK_LDS_SPHERES;")
         E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
-        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t wblock = (int64_t)__builtin_amdgcn_workgroup_id_x() * SPEC_WAVES + wave;")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    IO* pos_out = static_cast<IO*>(A.link_pos);")
@@ -1573,10 +1573,10 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         kname = "k_posbwd_bi" if base_identity else "k_posbwd_bg"
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_per_lane}];")
-        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
-        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw("    const int lane = __builtin_amdgcn_workitem_id_x() & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_workitem_id_x() / TRK_WAVE);")
         E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_per_lane});")
-        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t wblock = (int64_t)__builtin_amdgcn_workgroup_id_x() * SPEC_WAVES + wave;")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    const float* gpos = static_cast<const float*>(A.link_pos);")

@@ -27,7 +27,7 @@ _CSRC = Path(__file__).resolve().parent / "csrc"
 # e.g. to a per-user directory when the package is installed read-only or shared between users.
 JIT_DIR = Path(os.environ["TRK_JIT_DIR"]).resolve() if os.environ.get("TRK_JIT_DIR") else _CSRC / "jit"
 # same code-generation flags as csrc/Makefile uses for the ahead-of-time units
-GENFLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+GENFLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Xarch_device", "-fno-slp-vectorize"]
 _REPO_INCLUDE = _CSRC.parent.parent / "include"
 _loaded: Dict[str, C.CDLL] = {}
 
