@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Run-time ablation of a generated rollout kernel (no rebuild): python tools/ablate_robot.py [ur10_allegro|dual_panda|panda]
-[first] [stamps]   -- `first`: only the first configuration; `stamps`: also dump the per-wave phase stamps of that configuration
+[first|two] [stamps]   -- `first` / `two`: only the first (two) configuration(s); TRK_ABLATE_LAUNCHES=n timed launches (300); `stamps`: also dump the per-wave phase stamps of that configuration
 to gpurun_out/phase_stamps_<robot>_<k>.npy (read them with tools/phase_analyze.py)."""
+import os
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -27,15 +28,16 @@ q = (torch.rand(B, H, D, device=dev) - 0.5) * 3.0
 print(f"{ident}: {L} links, {D} DOF, {len(tmpl.obj_links)} collision links, {len(tmpl.self_pairs)} self pairs; {8 * D + 12 * L + 4} B/sample")
 for name, w, pos in (("obj+ee, positions", (0, 1, 0, 1), True), ("obj+ee, no positions", (0, 1, 0, 1), False),
                      ("no objectives, positions", (0, 0, 0, 0), True), ("no objectives, no positions", (0, 0, 0, 0), False),
-                     ("objects only", (0, 1, 0, 0), True), ("all four", (1, 1, 1, 1), True))[:1 if "first" in sys.argv else None]:
+                     ("objects only", (0, 1, 0, 0), True), ("all four", (1, 1, 1, 1), True))[:1 if "first" in sys.argv else (2 if "two" in sys.argv else None)]:
     plan = ops.RolloutPlan(h, cm, w, q, want_pos=pos)
-    for _ in range(30): plan.launch()
+    NL = int(os.environ.get("TRK_ABLATE_LAUNCHES", "300"))
+    for _ in range(max(3, NL // 10)): plan.launch()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(300): plan.launch()
+    for _ in range(NL): plan.launch()
     e1.record(); torch.cuda.synchronize()
-    print(f"  {name:30s} {e0.elapsed_time(e1) / 300 * 1e3:7.2f} us")
+    print(f"  {name:30s} {e0.elapsed_time(e1) / NL * 1e3:7.2f} us")
     if "stamps" in sys.argv:
         from torch_robotics_amd._lib import lib
         nb = ops.n_blocks(B * H)

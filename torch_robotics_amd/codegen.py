@@ -595,7 +595,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             assert not pending
             E.raw("    const std::conditional_t<POS, RingTail<decltype(ring)>, NoFlushOf<decltype(ring)>> flush{ring};")
         else:
-            E.raw(f"    PosFlusher<{3 * L}, IO> flush{{nullptr, 0u, 0ull, false, lane}};")
+            E.raw(f"    PosFlusher<{3 * L}, IO> flush{{reinterpret_cast<const float4*>(lds) + lane, 0u, 0ull, 0ull, lane, make_float4(0.0f, 0.0f, 0.0f, 0.0f)}};")
             pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
             E.raw("    if (A.link_pos) {")
             E.raw(f"        const float pv[{3 * L}] = {{{pos_list}}};")

@@ -167,6 +167,15 @@ template <> struct IoQuad<float> {
         const trk_f4 x = {v.x, v.y, v.z, v.w};
         asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n s_nop 1" :: "v"(voff), "v"(x), "s"(base)  TRK_STORE_CLOBBER);
     }
+    // the same under a wave-uniform lane mask applied INSIDE the asm block (exec &= mask; store; restore): no control flow for
+    // the compiler, so the store's LDS read is scheduled like any other load instead of sitting in a three-instruction branch
+    // body right in front of its s_waitcnt
+    static __device__ __forceinline__ void store_wt_sm(unsigned long long base, unsigned voff, const float4& v, unsigned long long mask) {
+        const trk_f4 x = {v.x, v.y, v.z, v.w};
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %4\n global_store_dwordx4 %1, %2, %3 sc1\n s_mov_b64 exec, %0\n s_nop 0"
+                     : "=&s"(saved) : "v"(voff), "v"(x), "s"(base), "s"(mask) : "scc");
+    }
     static __device__ __forceinline__ void store_wt1(float* p, float v) { store_wt_f1(p, v); }
     static __device__ __forceinline__ void store_wt2(float* p, float a, float b) { store_wt_f2(p, a, b); }
     static __device__ __forceinline__ void store_wt2_s(unsigned long long base, unsigned voff, float a, float b) {
@@ -203,6 +212,12 @@ template <> struct IoQuad<_Float16> {
     static __device__ __forceinline__ void store_wt_s(unsigned long long base, unsigned voff, const float4& v) {
         const trk_h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         asm volatile("global_store_dwordx2 %0, %1, %2 sc1\n s_nop 1" :: "v"(voff), "v"(h), "s"(base)  TRK_STORE_CLOBBER);
+    }
+    static __device__ __forceinline__ void store_wt_sm(unsigned long long base, unsigned voff, const float4& v, unsigned long long mask) {
+        const trk_h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %4\n global_store_dwordx2 %1, %2, %3 sc1\n s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(voff), "v"(h), "s"(base), "s"(mask) : "scc");
     }
     static __device__ __forceinline__ void store_wt1(_Float16* p, float v) {
         const _Float16 h = (_Float16)v;
@@ -388,23 +403,28 @@ struct PosFlusher {
     // chunk's address, one ds_read_b128 at an immediate offset, one store with an SGPR base -- no VALU work at all.  (The
     // first version carried a chunk counter and rebuilt a 64-bit per-lane address and an exec mask per tick: ~9 VALU
     // instructions, most of them in the 4-cycle class, 9 ticks per wavefront.)
-    const float4* src;                                           // this lane's vector of chunk 0, in LDS
+    const float4* src;                                           // this lane's vector of chunk 0, in LDS (always a readable address)
     unsigned voff;                                               // lane * bytes per vector in HBM
     unsigned long long g0;                                       // wave-uniform: address of the wave's first byte
-    bool active;                                                 // wave-uniform: false = nothing staged / already written
+    unsigned long long mask;                                     // wave-uniform lane mask of the stores: every lane, or none (nothing staged / already written)
     int lane;
+    mutable float4 nxt;                                          // the next chunk's vector, read from LDS one tick ahead
+    // Straight-line: the lane mask is applied inside the store's asm block, and the LDS read of chunk CH + 1 is issued BEFORE the
+    // store of chunk CH (the stores are `asm volatile`, which no memory operation is scheduled across: read where it is used, a
+    // chunk's ds_read_b128 sat right in front of its own s_waitcnt + store, ~130 cycles of LDS latency exposed at every tick).
+    // Chunks are taken in order, each once (every path of the kernels does).
+    __device__ __forceinline__ const float4* vec(int ch) const {
+        // lanes past the tile in the partial last chunk read their chunk-0 vector instead (their store is masked off)
+        return (ch < NCHUNK - 1 || TAIL == TRK_WAVE || lane < TAIL) ? src + ch * TRK_WAVE : src;
+    }
+    __device__ __forceinline__ void prime() const { nxt = *vec(0); }
     template <int CH>
     __device__ __forceinline__ void chunk() const {
         if constexpr (CH >= 0 && CH < NCHUNK) {
-            if (active) {
-                const unsigned long long g = g0 + (unsigned long long)CH * CB;
-#ifdef TRK_EXP_NO_STORE       // experiment: stage + read back from LDS, but do not issue the global store
-                { const float4 v = src[CH * TRK_WAVE]; asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
-#else
-                if (CH < NCHUNK - 1 || TAIL == TRK_WAVE) IoQuad<IO>::store_wt_s(g, voff, src[CH * TRK_WAVE]);
-                else if (lane < TAIL) IoQuad<IO>::store_wt_s(g, voff, src[CH * TRK_WAVE]);
-#endif
-            }
+            const unsigned long long g = g0 + (unsigned long long)CH * CB;
+            const float4 v = nxt;
+            if constexpr (CH + 1 < NCHUNK) nxt = *vec(CH + 1);
+            IoQuad<IO>::store_wt_sm(g, voff, v, (CH < NCHUNK - 1 || TAIL == TRK_WAVE) ? mask : (mask & ((1ull << (TAIL & 63)) - 1ull)));
         }
     }
     template <int A, int B>                                      // chunks A .. B-1
@@ -444,7 +464,11 @@ __device__ __forceinline__ PosFlusher<W, IO> spec_make_flusher(IO* __restrict__ 
     const unsigned long long g = (unsigned long long)reinterpret_cast<uintptr_t>(dst);
     const unsigned long long gu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) |
                                   (unsigned)__builtin_amdgcn_readfirstlane((int)g);
-    return PosFlusher<W, IO>{reinterpret_cast<const float4*>(lds) + lane, (unsigned)(lane * 4 * sizeof(IO)), gu, fast, lane};
+    // a ballot is scalar by definition (an SGPR pair): all lanes, or none
+    PosFlusher<W, IO> f{reinterpret_cast<const float4*>(lds) + lane, (unsigned)(lane * 4 * sizeof(IO)), gu, __builtin_amdgcn_ballot_w64(fast), lane,
+                        make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
+    f.prime();
+    return f;
 }
 
 // stage the wave's rows in LDS; returns a flusher (fast path) or writes everything now (ragged / unaligned tail)
