@@ -494,6 +494,37 @@ __device__ __forceinline__ void spec_flush_chunk(IO* __restrict__ out, int64_t b
     spec_wave_sync();
     const int total = rows * NVEC;
     IO* dst0 = out + base * W + c0;
+    if (rows == TRK_WAVE) {      // full wave: a batch of LDS reads in flight before the first store (guarded, every read sits in a
+        constexpr int NB = NVEC * V > 36 ? (NVEC + 3) / 4 : NVEC;     // branch body of its own right in front of its s_waitcnt)
+#pragma unroll
+        for (int j0 = 0; j0 < NVEC; j0 += NB) {
+            float a[NB][V];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j0 + j < NVEC) {
+                    const int e = lane + TRK_WAVE * (j0 + j), smp = e / NVEC, v = e - smp * NVEC;
+                    const float* src = lds + smp * LS + v * V;
+                    if (V == 4) { const float4 t = *reinterpret_cast<const float4*>(src); a[j][0] = t.x; a[j][1] = t.y; a[j][2 % V] = t.z; a[j][3 % V] = t.w; }
+                    else {
+#pragma unroll
+                        for (int k = 0; k < V; ++k) a[j][k] = src[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j0 + j < NVEC) {
+                    const int e = lane + TRK_WAVE * (j0 + j), smp = e / NVEC, v = e - smp * NVEC;
+                    IO* dst = dst0 + (int64_t)smp * W + v * V;
+                    if (V == 4) IoQuad<IO>::store_wt(dst, 0, make_float4(a[j][0], a[j][1], a[j][2 % V], a[j][3 % V]));
+                    else if (V == 2) IoQuad<IO>::store_wt2(dst, a[j][0], a[j][1 % V]);
+                    else IoQuad<IO>::store_wt1(dst, a[j][0]);
+                }
+            }
+        }
+        spec_wave_sync();
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NVEC; ++j) {
         const int e = lane + TRK_WAVE * j;
@@ -637,17 +668,26 @@ __device__ __forceinline__ void spec_load_chunk(const float* __restrict__ in, in
     spec_wave_sync();           // everybody has consumed the previous chunk
     const int total = rows * NVEC;
     const float* src0 = in + base * W + c0;
-    if (V == 2 && rows == TRK_WAVE) {      // full wave: all loads in flight before the first LDS write (the guarded loop below
-        float2 r[NVEC];                    // waits for every load before it issues the next)
+    if ((V == 1 || V == 2) && rows == TRK_WAVE) {      // full wave: a batch of loads in flight before the first LDS write (the guarded
+        constexpr int NB = NVEC > 18 ? (NVEC + 3) / 4 : NVEC;     // loop below waits for every load before it issues the next)
+        typedef std::conditional_t<V == 2, float2, float> vec_t;
 #pragma unroll
-        for (int j = 0; j < NVEC; ++j) {
-            const int e = lane + TRK_WAVE * j, smp = e / NVEC, v = e - smp * NVEC;
-            r[j] = *reinterpret_cast<const float2*>(src0 + (int64_t)smp * W + v * V);
-        }
+        for (int j0 = 0; j0 < NVEC; j0 += NB) {
+            vec_t r[NB];
 #pragma unroll
-        for (int j = 0; j < NVEC; ++j) {
-            const int e = lane + TRK_WAVE * j, smp = e / NVEC, v = e - smp * NVEC;
-            *reinterpret_cast<float2*>(lds + smp * LS + v * V) = r[j];
+            for (int j = 0; j < NB; ++j) {
+                if (j0 + j < NVEC) {
+                    const int e = lane + TRK_WAVE * (j0 + j), smp = e / NVEC, v = e - smp * NVEC;
+                    r[j] = *reinterpret_cast<const vec_t*>(src0 + (int64_t)smp * W + v * V);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j0 + j < NVEC) {
+                    const int e = lane + TRK_WAVE * (j0 + j), smp = e / NVEC, v = e - smp * NVEC;
+                    *reinterpret_cast<vec_t*>(lds + smp * LS + v * V) = r[j];
+                }
+            }
         }
         spec_wave_sync();
         return;
