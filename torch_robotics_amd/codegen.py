@@ -517,7 +517,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
         E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_lane});")
         E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {lds_lane}) + wave * TRK_LDS_SPHERES;")
-        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
+        E.raw("    const SpheresInFlight sph = spec_load_spheres_issue(A.C, lane);   // waited for together with the rows below")
         E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;     // index of this wave's 64-sample block")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
@@ -525,6 +525,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    spec_stamp_real(A.stamps, wblock, 2, lane);      // 100 MHz chip-wide clock: aligns the per-CU s_memtime domains")
         E.raw("    float q[D];")
         E.raw("    spec_load_q<D>(static_cast<const IO*>(A.q), base, rows, lane, lds, q);")
+        E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
         E.raw("    spec_stamp(A.stamps, wblock, 1, lane);")
         # ---------------- forward ----------------
         R: Dict[int, List[List[S]]] = {}
@@ -710,13 +711,14 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
         E.raw("    float* lds = lds_all + wave * (TRK_WAVE * D);")
         E.raw("    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * D) + wave * TRK_LDS_SPHERES;")
-        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
+        E.raw("    const SpheresInFlight sph = spec_load_spheres_issue(A.C, lane);   // waited for together with the rows below")
         E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    float q[D];")
         E.raw("    if (A.via_n > 0) spec_load_q_via<D>(A, base, rows, lane, q);     // trajectory validation: interpolate the via points here")
         E.raw("    else spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
         R = {}; t = {}; passv = {}
         if base_identity:
             R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
@@ -803,12 +805,13 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
         E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {3 * L});")
         E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {3 * L}) + wave * TRK_LDS_SPHERES;")
-        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
+        E.raw("    const SpheresInFlight sph = spec_load_spheres_issue(A.C, lane);   // waited for together with the rows below")
         E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw(f"    float p[{3 * L}];")
         E.raw(f"    spec_load_q<{3 * L}>(A.fld_pos, base, rows, lane, lds, p);")
+        E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
         E.raw("    const NoFlush flush;")
         tp = {i: [S(1.0, f"p[{3 * i + k}]") for k in range(3)] for i in range(L)}
         emit_collision_objectives(E, tp, [0])
@@ -834,12 +837,13 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
         E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {3 * L});")
         E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {3 * L}) + wave * TRK_LDS_SPHERES;")
-        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
+        E.raw("    const SpheresInFlight sph = spec_load_spheres_issue(A.C, lane);   // waited for together with the rows below")
         E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw(f"    float p[{3 * L}];")
         E.raw(f"    spec_load_q<{3 * L}>(A.fld_pos, base, rows, lane, lds, p);")
+        E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
         emit_boolean_fields(E, {i: [S(1.0, f"p[{3 * i + k}]") for k in range(3)] for i in range(L)})
         E.raw("    if (lane < rows) A.coll_out[base + lane] = hit ? 1 : 0;")
         E.raw("}")
@@ -1374,13 +1378,14 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_workitem_id_x() / TRK_WAVE);   // wave-uniform -> SGPR")
         E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_per_lane});")
         E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {lds_per_lane}) + wave * TRK_LDS_SPHERES;")
-        E.raw("    spec_load_spheres(A.C, lds_sph, lane);")
+        E.raw("    const SpheresInFlight sph = spec_load_spheres_issue(A.C, lane);   // waited for together with the rows below")
         E.raw("    const int64_t wblock = (int64_t)__builtin_amdgcn_workgroup_id_x() * SPEC_WAVES + wave;")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    IO* pos_out = static_cast<IO*>(A.link_pos);")
         E.raw("    float q[D];")
         E.raw("    spec_load_q<D>(static_cast<const IO*>(A.q), base, rows, lane, lds, q);")
+        E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
         E.raw(f"    float* row = lds + lane * {LS};          // this lane's slice of the chunk buffer")
         E.raw("    NoTick notick;")
         R: Dict[int, List[List[S]]] = {}

@@ -252,10 +252,19 @@ template <> struct IoQuad<_Float16> {
     }
 };
 
-// copy the first TRK_LDS_SPHERES world-frame spheres into this wave's LDS (one 16-byte load per lane, issued together
-// with the q loads so its latency is free)
-__device__ __forceinline__ void spec_load_spheres(const DevCostHdr& C, float4* lds_spheres, int lane) {
-    if (lane < TRK_LDS_SPHERES && lane < 2 * C.n_sphere_pairs) lds_spheres[lane] = C.spheres[lane];     // incl. the pad copy
+// copy the first TRK_LDS_SPHERES world-frame spheres into this wave's LDS (one 16-byte load per lane).  Two halves: the load is
+// issued before the wave's q rows and written to LDS after them, so its latency is the q loads' latency (as one function the
+// write -- and with it an s_waitcnt vmcnt(0) -- sat in the branch body of the load, in front of the first q load).
+struct SpheresInFlight { float4 v; bool on; };
+__device__ __forceinline__ SpheresInFlight spec_load_spheres_issue(const DevCostHdr& C, int lane) {
+    SpheresInFlight s;
+    s.on = lane < TRK_LDS_SPHERES && lane < 2 * C.n_sphere_pairs;     // incl. the pad copy
+    s.v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (s.on) s.v = C.spheres[lane];
+    return s;
+}
+__device__ __forceinline__ void spec_load_spheres_finish(float4* lds_spheres, int lane, const SpheresInFlight& s) {
+    if (s.on) lds_spheres[lane] = s.v;
 }
 
 template <int D, class IO>
