@@ -1902,16 +1902,15 @@ k_gp_prior(const T* __restrict__ q, const T* __restrict__ qd, int H, int D, floa
     __syncthreads();
     float acc = 0.0f;
     auto element = [&](int i, float& gp, float& gv) {
-        const int t = i / D;
         const float p0 = ps[i], v0 = vs[i];
         gp = 0.0f; gv = 0.0f;
-        if (t + 1 < H) {
+        if (i + D < total) {                       // t + 1 < H for t = i / D, without the division
             const float ep = fmaf(dt, v0, p0) - ps[i + D], ev = v0 - vs[i + D];
             const float rp = fmaf(a, ep, b * ev), rv = fmaf(b, ep, c * ev);
             acc = fmaf(0.5f, fmaf(ep, rp, ev * rv), acc);
             gp = rp; gv = fmaf(dt, rp, rv);
         }
-        if (t > 0) {
+        if (i >= D) {                              // t > 0
             const float pm = ps[i - D], vm = vs[i - D];
             const float ep = fmaf(dt, vm, pm) - p0, ev = vm - v0;
             gp -= fmaf(a, ep, b * ev); gv -= fmaf(b, ep, c * ev);
