@@ -417,7 +417,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("    template <int A> __device__ __forceinline__ void rest() const { range<A, R::NP>(); }")
         out.append("};")
 
-    def emit_collision_objectives(E, t, next_chunk):
+    def emit_collision_objectives(E, t, next_chunk, fast_arg=""):
         """cost + position adjoints (tb<i>_k) of the three collision fields on link positions t[i][k]; the scene evaluation owns
         OBJ_TICK_SLOTS tick slots of `flush` per group.  Shared by the fused rollout and the positions-in field kernel."""
         E.raw("    float cost = 0.0f;")
@@ -433,7 +433,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             c0 = next_chunk[0]
             next_chunk[0] += OBJ_TICK_SLOTS     # the scene evaluation owns these tick slots, used or flushed on every path
             E.raw(f"    const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
-            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph);")
+            E.raw(f"    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL{fast_arg}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph);")
             E.raw(f"    else flush.template range<{c0}, {next_chunk[0]}>();")
             E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
             for j, i in enumerate(tmpl.obj_links):
@@ -455,7 +455,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 c0 = next_chunk[0]
                 next_chunk[0] += OBJ_TICK_SLOTS
                 E.raw(f"        const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
-                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, {g0});")
+                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}{fast_arg}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, {g0});")
                 E.raw(f"        else flush.template range<{c0}, {c0 + OBJ_TICK_SLOTS}>();")
                 E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<{n}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {g0});")
                 for j, i in enumerate(grp):
@@ -500,12 +500,16 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E = Emitter()
         kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
         # small arms fit 128 VGPRs (4 waves/SIMD: the whole 4096 x 64 batch resident); big trees get 256 VGPRs
+        # FAST (two-wavefront kernels only): scene_is_fast(A.C) -- a few equal spheres and nothing else -- is decided at the launch and
+        # only that scene path is compiled into the instantiation (5-rep same-box A/B: dual Panda 19.5 -> 18.6 us, UR10 + Allegro
+        # 31.0 -> 30.7; the 128-register Panda kernel measured no gain and keeps the run-time branches)
+        fast_t = D > 8
         if chunked:
             # POS: the launch wants the link positions.  A compile-time switch, because the ring staging costs the launches that
             # only want cost + gradient (the planners' inner loop) 2-4 us even with every store masked off.
-            E.raw("template <class IO, bool POS>      // IO: HBM-side type of q / link_pos / gq (float or _Float16)")
+            E.raw(f"template <class IO, bool POS{', bool FAST' if fast_t else ''}>      // IO: HBM-side type of q / link_pos / gq (float or _Float16)")
         else:
-            E.raw("template <class IO>      // HBM-side type of q / link_pos / gq: float or _Float16")
+            E.raw(f"template <class IO{', bool FAST' if fast_t else ''}>      // HBM-side type of q / link_pos / gq: float or _Float16")
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
         if chunked:
             E.raw(f"    constexpr int LDS_LANE = POS ? {max(rp.stride, D)} : {D};")
@@ -616,7 +620,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw(tick_line())
         E.raw("    spec_stamp(A.stamps, wblock, 3, lane);")
         # ---------------- objectives ----------------
-        emit_collision_objectives(E, t, next_chunk)
+        emit_collision_objectives(E, t, next_chunk, fast_arg=", decltype(ticks), FAST" if fast_t else "")
         E.raw("    spec_stamp(A.stamps, wblock, 4, lane);")
         for ee, tgt, rb in tracked:
             E.raw(f"    float {rb}[9] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};")
@@ -1154,7 +1158,26 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"static const float kVirtualW[] = {{{vw}}};")
     out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
-    if chunked:
+    fast_t = D > 8
+    if fast_t:
+        # every (IO, [POS,] FAST, base) instantiation through one generic lambda per compile-time switch
+        out.append("    const bool fast = scene_is_fast(a.C);")
+        out.append("    auto go = [&](auto io, auto pos_c, auto fast_c) {")
+        out.append("        using IOT = decltype(io);")
+        if chunked:
+            out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<IOT, decltype(pos_c)::value, decltype(fast_c)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+            out.append("        else hipLaunchKernelGGL((k_rollout_bg<IOT, decltype(pos_c)::value, decltype(fast_c)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        else:
+            out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<IOT, decltype(fast_c)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+            out.append("        else hipLaunchKernelGGL((k_rollout_bg<IOT, decltype(fast_c)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    };")
+        out.append("    auto by_fast = [&](auto io, auto pos_c) { if (fast) go(io, pos_c, std::true_type{}); else go(io, pos_c, std::false_type{}); };")
+        if chunked:
+            out.append("    auto by_pos = [&](auto io) { if (a.link_pos != nullptr) by_fast(io, std::true_type{}); else by_fast(io, std::false_type{}); };")
+        else:
+            out.append("    auto by_pos = [&](auto io) { by_fast(io, std::false_type{}); };")
+        out.append("    if (a.io_f16) by_pos(_Float16{}); else by_pos(float{});")
+    elif chunked:
         out.append("    const bool pos = a.link_pos != nullptr;")
         for cond, io in (("a.io_f16", "_Float16"), ("", "float")):
             out.append(f"    {'if (' + cond + ') ' if cond else 'else '}{{")
