@@ -144,6 +144,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, argv))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # a rank started by an outside launcher: dmabuf IPC for RCCL's peer mappings
     import numpy as np
     import torch
     import torch.distributed as dist
