@@ -202,18 +202,20 @@ k_fk_forward(DevModelHdr hdr, const DevLink* __restrict__ links, SelMap sel, int
 // ============================================================================================
 struct JointRec { float a[3], m[3], c; };
 
-template <class ADJ>
+template <bool PREFETCH = true, class ADJ>      // PREFETCH: request link record p + 1 while working on p (32 more live SGPRs)
 __device__ __forceinline__ void reverse_walk(const DevModelHdr& hdr, const DevLink* __restrict__ links,
                                              const int32_t* __restrict__ fin, const float* qs, float* gqs,
                                              float* jst, float* slots, int lane, ADJ& adj) {
     const int D = hdr.n_dofs, L = hdr.n_links;
     float Pf[3] = {0.0f, 0.0f, 0.0f}, Pt[3] = {0.0f, 0.0f, 0.0f};
     Pose cur, par;
-    DevLink nxt = load_link(links, 0);
+    DevLink nxt;
+    if (PREFETCH) nxt = load_link(links, 0);
     adj.prefetch(0);
     for (int p = 0; p < L; ++p) {
-        const DevLink Lk = nxt;
-        nxt = load_link(links, p + 1 < L ? p + 1 : p);
+        DevLink Lk;
+        if (PREFETCH) { Lk = nxt; nxt = load_link(links, p + 1 < L ? p + 1 : p); }
+        else Lk = load_link(links, p);
         const float pass = walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
         if (Lk.dof >= 0) {
             float a[3] = {0.0f, 0.0f, 0.0f}, m[3];
@@ -828,10 +830,10 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     float e2R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, e2t[3] = {0, 0, 0};
     {
         Pose cur, par;
-        DevLink nxt = load_link(links, 0);
         for (int p = 0; p < L; ++p) {
-            const DevLink Lk = nxt;
-            nxt = load_link(links, p + 1 < L ? p + 1 : p);
+            // no record prefetch in this kernel: two records in flight are 64 SGPRs, and with the cost model's header next to
+            // them the kernel spilled ~170 scalars through v_writelane / v_readlane (103 -> 97 us without)
+            const DevLink Lk = load_link(links, p);
             walk_step<false>(hdr, Lk, p, qs, D, lane, slots, cur, par);
             if (POINTS) points_of_link(ps, p, cur, tile + lane * rs);
             else {
@@ -894,10 +896,10 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     // walk 2: reverse pass
     if (POINTS) {
         AdjFromPoints adj{gtile, rs, lane, ps, use_ee ? C.ee_link : -1, eeRb, eetb, use_ee2 ? C.ee2_link : -1, e2Rb, e2tb};
-        reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+        reverse_walk<false>(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
     } else {
         AdjFromTile<true> adj{gtile, rs, lane, sel_unused, use_ee ? C.ee_link : -1, eeRb, use_ee2 ? C.ee2_link : -1, e2Rb};
-        reverse_walk(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
+        reverse_walk<false>(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
     }
     __syncthreads();
     store_tile(gq, gqs, base * D, (int64_t)rows * D, lane);
