@@ -239,7 +239,8 @@ __device__ __forceinline__ void reverse_walk(const DevModelHdr& hdr, const DevLi
             float* j = jst + Lk.dof * TRK_WAVE + lane;
             const int js = D * TRK_WAVE;
             j[0] = a[0]; j[js] = a[1]; j[2 * js] = a[2];
-            j[3 * js] = m[0]; j[4 * js] = m[1]; j[5 * js] = m[2]; j[6 * js] = c;
+            j[3 * js] = m[0]; j[4 * js] = m[1]; j[5 * js] = m[2];
+            gqs[lane * D + Lk.dof] = c;         // the snapshot waits in the gradient's own slot until the joint's subtree ends
         }
         // own wrench
         float Rb[9], tb[3];
@@ -266,7 +267,7 @@ __device__ __forceinline__ void reverse_walk(const DevModelHdr& hdr, const DevLi
             const float* j = jst + d * TRK_WAVE + lane;
             const int js = D * TRK_WAVE;
             const float g = (j[0] * Pt[0] + j[js] * Pt[1] + j[2 * js] * Pt[2]) -
-                            (j[3 * js] * Pf[0] + j[4 * js] * Pf[1] + j[5 * js] * Pf[2]) - j[6 * js];
+                            (j[3 * js] * Pf[0] + j[4 * js] * Pf[1] + j[5 * js] * Pf[2]) - gqs[lane * D + d];
             gqs[lane * D + d] = g;
         }
     }
@@ -329,7 +330,7 @@ k_fk_backward(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t*
     float* qs = smem;
     float* gqs = qs + TRK_WAVE * D;
     float* jst = gqs + TRK_WAVE * D;
-    float* slots = jst + 7 * D * TRK_WAVE;
+    float* slots = jst + 6 * D * TRK_WAVE;
     float* tile = slots + hdr.n_slots * 12 * TRK_WAVE;
     const int width = n_sel * 3, rs = width | 1;
     load_tile(qs, q, base * D, (int64_t)rows * D, lane);
@@ -437,7 +438,7 @@ k_fk_points_backward(DevModelHdr hdr, const DevLink* __restrict__ links, const i
     float* qs = smem;
     float* gqs = qs + TRK_WAVE * D;
     float* jst = gqs + TRK_WAVE * D;
-    float* slots = jst + 7 * D * TRK_WAVE;
+    float* slots = jst + 6 * D * TRK_WAVE;
     float* tile = slots + hdr.n_slots * 12 * TRK_WAVE;
     const int width = ps.n_points * 3, rs = width | 1;
     load_tile(qs, q, base * D, (int64_t)rows * D, lane);
@@ -484,7 +485,7 @@ k_ik_step(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __r
     float* qs = smem;
     float* gqs = qs + TRK_WAVE * D;
     float* jst = gqs + TRK_WAVE * D;
-    float* slots = jst + 7 * D * TRK_WAVE;
+    float* slots = jst + 6 * D * TRK_WAVE;
     load_tile(qs, q, base * D, (int64_t)rows * D, lane);
     for (int k = rows * D + lane; k < TRK_WAVE * D; k += TRK_WAVE) qs[k] = 0.0f;
     float Ht[16];
@@ -817,7 +818,7 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
     float* qs = smem;
     float* gqs = qs + TRK_WAVE * D;
     float* jst = gqs + TRK_WAVE * D;
-    float* slots = jst + 7 * D * TRK_WAVE;
+    float* slots = jst + 6 * D * TRK_WAVE;
     float* tile = slots + hdr.n_slots * 12 * TRK_WAVE;
     float* gtile = tile + TRK_WAVE * rs;
     load_tile(qs, q, base * D, (int64_t)rows * D, lane);
@@ -2073,7 +2074,7 @@ void trk_launch_fk_forward(int mode, const DevModelHdr& hdr, const DevLink* link
 
 void trk_launch_fk_backward(int mode, const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const SelMap& sel,
                             const SelMap& selp, int n_sel, const float* q, const float* gin, int64_t n, float* gq, hipStream_t st) {
-    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
+    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 8 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
                                   (mode == 1 ? (size_t)TRK_WAVE * ((n_sel * 3) | 1) : 0));
     if (mode == 0) hipLaunchKernelGGL(k_fk_backward<0>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, sel, selp, n_sel, q, gin, n, gq);
     else hipLaunchKernelGGL(k_fk_backward<1>, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, sel, selp, n_sel, q, gin, n, gq);
@@ -2083,7 +2084,7 @@ void trk_launch_ik_step(const DevModelHdr& hdr, const DevLink* links, const int3
                         int per_sample, const float* lower, const float* upper, float w_jl, float se3_eps, float lr,
                         const IkSchedule& sched, int n_steps, int64_t n, float* q, float* mom, float* vel, float* loss,
                         uint8_t* valid, hipStream_t st) {
-    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE);
+    size_t lds = sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 8 + (size_t)hdr.n_slots * 12 * TRK_WAVE);
     hipLaunchKernelGGL(k_ik_step, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), lds, st, hdr, links, fin, link, H_target,
                        per_sample, lower, upper, w_jl, se3_eps, lr, sched, n_steps, n, q, mom, vel, loss, valid);
 }
@@ -2106,11 +2107,11 @@ void trk_launch_ee_cost(const DevCostHdr& C, const float* H, int64_t n, int64_t 
 }
 
 size_t trk_lds_rollout(const DevModelHdr& hdr, int n_cols) {
-    return sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 9 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
+    return sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * 8 + (size_t)hdr.n_slots * 12 * TRK_WAVE +
                             2 * (size_t)TRK_WAVE * ((n_cols * 3) | 1));
 }
 size_t trk_lds_fk_points(const DevModelHdr& hdr, int n_points, bool backward) {
-    return sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * (backward ? 9 : 1) + (size_t)hdr.n_slots * 12 * TRK_WAVE +
+    return sizeof(float) * ((size_t)TRK_WAVE * hdr.n_dofs * (backward ? 8 : 1) + (size_t)hdr.n_slots * 12 * TRK_WAVE +
                             (size_t)TRK_WAVE * ((n_points * 3) | 1));
 }
 
