@@ -129,3 +129,31 @@ def test_torch_compile_of_the_reference_call_sites(handles):
     gf = gold("fk_panda_arm_no_gripper")
     fkc = torch.compile(lambda x: tree.compute_forward_kinematics_all_links(x))
     assert np.abs(fkc(dev(gf["q_in"])).cpu().numpy() - gf["H_in"]).max() < 2e-6
+
+
+def test_graphed_cost_backward_replays_the_eager_result():
+    """PlanningTask.capture_cost_backward: `compute_collision_cost(x).sum().backward()` (tasks.py:135-137 under autograd) captured once as a
+    hipGraph; a replay must give what the eager idiom gives -- at the captured q, and after q was updated in place."""
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    q = robot.random_q(256 * 16, generator=gen).reshape(256, 16, 7).contiguous().requires_grad_(True)
+
+    def eager(x):
+        x = x.detach().clone().requires_grad_(True)
+        c = task.compute_collision_cost(x)
+        c.sum().backward()
+        return c.detach().clone(), x.grad.detach().clone()
+
+    g = task.capture_cost_backward(q)
+    assert g.grad is q.grad and g.cost.shape == (256, 16)
+    for trip in range(3):
+        c_ref, g_ref = eager(q)
+        c = g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(c, c_ref) and torch.equal(q.grad, g_ref), f"replay {trip} differs from the eager evaluation"
+        assert torch.equal(g.total, c_ref.sum())
+        with torch.no_grad():                               # what an optimiser step does: q moves in place
+            q.add_(0.05 * torch.randn(q.shape, device=DEV, generator=gen))
+    with pytest.raises(ValueError, match="leaf"):
+        task.capture_cost_backward(q.detach() * 1.0)

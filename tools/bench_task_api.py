@@ -53,16 +53,7 @@ except Exception as e:
     print("torch.compile path failed:", type(e).__name__, str(e)[:200])
 # whole-iteration hipGraph: forward + backward of the idiom captured once, replayed per planner iteration
 qs = q.clone().requires_grad_(True)
-side = torch.cuda.Stream()
-with torch.cuda.stream(side):
-    for _ in range(3):
-        qs.grad = None
-        task.compute_collision_cost(qs).sum().backward()
-torch.cuda.current_stream().wait_stream(side)
-graph = torch.cuda.CUDAGraph()
-qs.grad = None
-with torch.cuda.graph(graph):
-    task.compute_collision_cost(qs).sum().backward()
-t("[hipGraph replay] compute_collision_cost(q).sum().backward()", graph.replay)
+graphed = task.capture_cost_backward(qs)
+t("[hipGraph replay] task.capture_cost_backward(q).replay()  (= compute_collision_cost(q).sum().backward())", graphed.replay)
 plan = task.rollout_plan(q, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=False)
 t("[reference] pre-bound fused kernel, cost + gradient (RolloutPlan.launch)", plan.launch, n=1000)

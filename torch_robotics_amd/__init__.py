@@ -19,6 +19,6 @@ from .environments import (MultiSphereField, MultiBoxField, MultiSharpBoxField, 
 from .fields import (DistanceField, CollisionSelfField, CollisionObjectDistanceField,  # noqa: F401
                      CollisionWorkspaceBoundariesDistanceField, EESE3DistanceField, SE3_distance)
 from .robots import RobotBase, RobotPanda, RobotPointMass, RobotPointMass3D, compute_path_length, compute_smoothness, finite_difference_vector  # noqa: F401
-from .tasks import PlanningTask  # noqa: F401
+from .tasks import PlanningTask, GraphedCostBackward  # noqa: F401
 
 __version__ = "0.1.0"

@@ -205,6 +205,13 @@ class PlanningTask(Task):
         model, cm = self._fused_handles(q.device)
         return ops.RolloutPlan(model, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos)
 
+    def capture_cost_backward(self, x, reduce=torch.sum, warmup: int = 3) -> "GraphedCostBackward":
+        """`reduce(task.compute_collision_cost(x)).backward()` captured ONCE as a hipGraph (a planner's inner loop calls it with
+        the same shapes thousands of times; eagerly the autograd engine's hand-offs cost ~10x the kernels).
+        x must be a leaf tensor that requires grad and keeps its storage: update it IN PLACE between replays (an optimiser's
+        `step()` does).  `replay()` leaves the gradient in `x.grad` and returns the per-sample cost tensor of the capture."""
+        return GraphedCostBackward(self, x, reduce, warmup)
+
     # ---------------------------------------------------------------------------------------------
     def compute_collision(self, x, **kwargs):                  # tasks.py:131-133
         return self._compute_collision_or_cost(self.robot.get_position(x), field_type="occupancy", **kwargs)
@@ -299,3 +306,35 @@ class PlanningTask(Task):
     def compute_success_free_trajs(self, trajs, **kwargs):
         _, trajs_free = self.get_trajs_collision_and_free(trajs)
         return 1 if (trajs_free is not None and trajs_free.nelement() >= 1) else 0
+
+
+class GraphedCostBackward:
+    """One planner iteration's cost + gradient as a replayable hipGraph (PlanningTask.capture_cost_backward).
+
+    The capture follows torch's recipe for whole-network capture: a few eager iterations on a side stream (allocator and
+    autograd warm-up, first-use kernel loads), `x.grad` reset to None so that the backward inside the capture allocates it from the
+    graph's private pool, then `torch.cuda.graph`.  Afterwards `x.grad` and `cost` are static tensors a replay refills."""
+
+    def __init__(self, task: "PlanningTask", x: torch.Tensor, reduce, warmup: int):
+        if not (x.is_leaf and x.requires_grad and x.is_cuda):
+            raise ValueError("capture_cost_backward: x must be a CUDA leaf tensor with requires_grad=True")
+        self.x = x
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                x.grad = None
+                reduce(task.compute_collision_cost(x)).backward()
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        x.grad = None
+        with torch.cuda.graph(self.graph):
+            self.cost = task.compute_collision_cost(x)
+            self.total = reduce(self.cost)
+            self.total.backward()
+        self.grad = x.grad
+
+    def replay(self) -> torch.Tensor:
+        """Re-evaluate at the current contents of x: fills `x.grad` (== `self.grad`), `self.total` and returns `self.cost`."""
+        self.graph.replay()
+        return self.cost
