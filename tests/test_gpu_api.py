@@ -1147,3 +1147,16 @@ def test_gauss_newton_ik_example_converges():
         # from uniformly random starts about half of the problems reach the pose (the projection onto the Panda's tight joint
         # limits traps the rest); the Adam loop of the reference needs hundreds of iterations for the same
         assert float((err < 1e-3).float().mean()) > 0.4 and float(err.median()) < 1e-2
+
+
+def test_reduce_sum_long_vectors_are_deterministic_and_accurate():
+    """trk_reduce_sum beyond 65 536 elements takes the wide single-workgroup kernel: same bits run to run, ragged / unaligned lengths,
+    fp64-accurate to fp32 summation error."""
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for n in (65537, 262144, 262147, 1 << 20):
+        x = torch.randn(n + 1, device=DEV, generator=gen)
+        for v in (x[:n], x[1:n + 1]):                        # 16-byte aligned and not
+            a, b = tra.ops.reduce_sum(v), tra.ops.reduce_sum(v)
+            assert torch.equal(a, b)
+            ref = v.double().sum().item()
+            assert abs(a.item() - ref) <= 2e-6 * v.abs().double().sum().item()

@@ -2001,6 +2001,35 @@ k_reduce_sum(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     if (threadIdx.x == 0) out[0] = part[0];
 }
 
+// the same for long vectors (n > TRK_REDUCE_WIDE_FROM): 1024 threads, 16-byte loads, eight in flight per thread -- one CU streams
+// 1 MB in a few microseconds where the 256-thread loop above needs ~250.  Its own fixed association order (thread t adds the
+// float4s t, t + 1024, ... left to right, lanes x + y + z + w, then the LDS tree); short vectors keep the order k_pack_sums mirrors.
+#define TRK_REDUCE_WIDE_FROM 65536
+__global__ void __launch_bounds__(1024)
+k_reduce_sum_wide(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float part[1024];
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;     // unaligned views take the scalar tail loop for everything
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float acc = 0.0f;
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 1024 < n4; i += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = x4[i + k * 1024];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    for (; i < n4; i += 1024) { const float4 v = x4[i]; acc += (v.x + v.y) + (v.z + v.w); }
+    for (int64_t j = 4 * n4 + threadIdx.x; j < n; j += 1024) acc += x[j];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
+
 // ============================================================================================
 // What a batch-sharded planner exchanges: packed = [ sum cost | sum_b cost(b, h) (H) | sum_b gq(b, h, d) (H D) ]
 // of one rank's evaluation, in ONE launch and bit-reproducibly.  Stage 1: the B trajectories are cut into TRK_PACK_SLICES row
@@ -2302,7 +2331,8 @@ void trk_launch_pack_sums(const float* cost, const float* gq, const float* block
 }
 
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, x, n, out);
+    if (n > TRK_REDUCE_WIDE_FROM) hipLaunchKernelGGL(k_reduce_sum_wide, dim3(1), dim3(1024), 0, st, x, n, out);
+    else hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, st, x, n, out);
 }
 
 void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st) {
