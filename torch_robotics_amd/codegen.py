@@ -417,7 +417,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("    template <int A> __device__ __forceinline__ void rest() const { range<A, R::NP>(); }")
         out.append("};")
 
-    def emit_collision_objectives(E, t, next_chunk, fast_arg=""):
+    def emit_collision_objectives(E, t, next_chunk, fast_arg="", prims_ptr=""):
         """cost + position adjoints (tb<i>_k) of the three collision fields on link positions t[i][k]; the scene evaluation owns
         OBJ_TICK_SLOTS tick slots of `flush` per group.  Shared by the fused rollout and the positions-in field kernel."""
         E.raw("    float cost = 0.0f;")
@@ -433,7 +433,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             c0 = next_chunk[0]
             next_chunk[0] += OBJ_TICK_SLOTS     # the scene evaluation owns these tick slots, used or flushed on every path
             E.raw(f"    const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
-            E.raw(f"    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL{fast_arg}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph);")
+            E.raw(f"    if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL{fast_arg}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph{', 0, ' + prims_ptr if prims_ptr else ''});")
             E.raw(f"    else flush.template range<{c0}, {next_chunk[0]}>();")
             E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
             for j, i in enumerate(tmpl.obj_links):
@@ -455,7 +455,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 c0 = next_chunk[0]
                 next_chunk[0] += OBJ_TICK_SLOTS
                 E.raw(f"        const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
-                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}{fast_arg}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, {g0});")
+                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}{fast_arg}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, {g0}{', ' + prims_ptr if prims_ptr else ''});")
                 E.raw(f"        else flush.template range<{c0}, {c0 + OBJ_TICK_SLOTS}>();")
                 E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<{n}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {g0});")
                 for j, i in enumerate(grp):
@@ -504,24 +504,34 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # only that scene path is compiled into the instantiation (5-rep same-box A/B: dual Panda 19.5 -> 18.6 us, UR10 + Allegro
         # 31.0 -> 30.7; the 128-register Panda kernel measured no gain and keeps the run-time branches)
         fast_t = D > 8
+        # BOX: the scene has boxes and its primitive table fits TRK_LDS_PRIMS -- the instantiation keeps a copy of the table in LDS
+        # and scene_min_sdf carries only (value, index) through its primitive loop (shelf 23.2 -> 22.0 us, maze 24.6 -> 22.2).  The
+        # 128-register kernels get it as a switch of its own, decided at the launch: compiled into the one kernel the sphere scene
+        # runs as well, the headline measured 9.17 -> 9.37 us (register allocation again).  Two-wavefront kernels: BOX = !FAST.
+        box_t = D <= 8
         if chunked:
             # POS: the launch wants the link positions.  A compile-time switch, because the ring staging costs the launches that
             # only want cost + gradient (the planners' inner loop) 2-4 us even with every store masked off.
-            E.raw(f"template <class IO, bool POS{', bool FAST' if fast_t else ''}>      // IO: HBM-side type of q / link_pos / gq (float or _Float16)")
+            E.raw(f"template <class IO, bool POS{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}>      // IO: HBM-side type of q / link_pos / gq (float or _Float16)")
         else:
-            E.raw(f"template <class IO{', bool FAST' if fast_t else ''}>      // HBM-side type of q / link_pos / gq: float or _Float16")
+            E.raw(f"template <class IO{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}>      // HBM-side type of q / link_pos / gq: float or _Float16")
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
+        if not box_t:
+            E.raw("    constexpr bool BOX = !FAST;")
         if chunked:
             E.raw(f"    constexpr int LDS_LANE = POS ? {max(rp.stride, D)} : {D};")
             lds_lane = "LDS_LANE"
         else:
             lds_lane = max(3 * L, D)
-        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_lane} + SPEC_WAVES * TRK_LDS_SPHERES * 4];")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_lane} + SPEC_WAVES * (TRK_LDS_SPHERES * 4 + (BOX ? TRK_LDS_PRIMS * 8 : 0))];")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
         E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_lane});")
-        E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {lds_lane}) + wave * TRK_LDS_SPHERES;")
+        E.raw(f"    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_BLOCK * {lds_lane}) + wave * (TRK_LDS_SPHERES + (BOX ? 2 * TRK_LDS_PRIMS : 0));")
+        E.raw("    float4* lds_prm = BOX ? lds_sph + TRK_LDS_SPHERES : nullptr;        // box scenes: the primitive records, for the winning box's gather")
         E.raw("    const SpheresInFlight sph = spec_load_spheres_issue(A.C, lane);   // waited for together with the rows below")
+        E.raw("    SpheresInFlight prm{};")
+        E.raw("    if constexpr (BOX) prm = spec_load_prims_issue(A.C, lane);")
         E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;     // index of this wave's 64-sample block")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
@@ -530,6 +540,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    float q[D];")
         E.raw("    spec_load_q<D>(static_cast<const IO*>(A.q), base, rows, lane, lds, q);")
         E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
+        E.raw("    if constexpr (BOX) spec_load_spheres_finish(lds_prm, lane, prm);")
         E.raw("    spec_stamp(A.stamps, wblock, 1, lane);")
         # ---------------- forward ----------------
         R: Dict[int, List[List[S]]] = {}
@@ -620,7 +631,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw(tick_line())
         E.raw("    spec_stamp(A.stamps, wblock, 3, lane);")
         # ---------------- objectives ----------------
-        emit_collision_objectives(E, t, next_chunk, fast_arg=", decltype(ticks), FAST" if fast_t else "")
+        emit_collision_objectives(E, t, next_chunk, fast_arg=", decltype(ticks), FAST" if fast_t else "", prims_ptr="lds_prm")
         E.raw("    spec_stamp(A.stamps, wblock, 4, lane);")
         for ee, tgt, rb in tracked:
             E.raw(f"    float {rb}[9] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};")
@@ -1158,43 +1169,31 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"static const float kVirtualW[] = {{{vw}}};")
     out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
-    fast_t = D > 8
-    if fast_t:
-        # every (IO, [POS,] FAST, base) instantiation through one generic lambda per compile-time switch
-        out.append("    const bool fast = scene_is_fast(a.C);")
-        out.append("    auto go = [&](auto io, auto pos_c, auto fast_c) {")
-        out.append("        using IOT = decltype(io);")
-        if chunked:
-            out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<IOT, decltype(pos_c)::value, decltype(fast_c)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-            out.append("        else hipLaunchKernelGGL((k_rollout_bg<IOT, decltype(pos_c)::value, decltype(fast_c)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-        else:
-            out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<IOT, decltype(fast_c)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-            out.append("        else hipLaunchKernelGGL((k_rollout_bg<IOT, decltype(fast_c)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-        out.append("    };")
-        out.append("    auto by_fast = [&](auto io, auto pos_c) { if (fast) go(io, pos_c, std::true_type{}); else go(io, pos_c, std::false_type{}); };")
-        if chunked:
-            out.append("    auto by_pos = [&](auto io) { if (a.link_pos != nullptr) by_fast(io, std::true_type{}); else by_fast(io, std::false_type{}); };")
-        else:
-            out.append("    auto by_pos = [&](auto io) { by_fast(io, std::false_type{}); };")
-        out.append("    if (a.io_f16) by_pos(_Float16{}); else by_pos(float{});")
-    elif chunked:
-        out.append("    const bool pos = a.link_pos != nullptr;")
-        for cond, io in (("a.io_f16", "_Float16"), ("", "float")):
-            out.append(f"    {'if (' + cond + ') ' if cond else 'else '}{{")
-            for bi, kn in (("base_identity && pos", "k_rollout_bi<IOT, true>"), ("base_identity", "k_rollout_bi<IOT, false>"),
-                           ("pos", "k_rollout_bg<IOT, true>"), ("", "k_rollout_bg<IOT, false>")):
-                pre = f"if ({bi}) " if bi else ""
-                el = "" if bi == "base_identity && pos" else "else "
-                out.append(f"        {el}{pre}hipLaunchKernelGGL(({kn.replace('IOT', io)}), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-            out.append("    }")
+    # every (IO, [POS,] [FAST,] [BOX,] base) instantiation: one generic lambda per compile-time switch, in template-parameter order
+    switches = []
+    if chunked:
+        switches.append("a.link_pos != nullptr")
+    if D > 8:
+        switches.append("scene_is_fast(a.C)")
     else:
-        out.append("    if (a.io_f16) {")
-        out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<_Float16>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-        out.append("        else hipLaunchKernelGGL(k_rollout_bg<_Float16>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-        out.append("    } else {")
-        out.append("        if (base_identity) hipLaunchKernelGGL(k_rollout_bi<float>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-        out.append("        else hipLaunchKernelGGL(k_rollout_bg<float>, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-        out.append("    }")
+        switches.append("a.C.n_box_objects > 0 && a.C.n_prims <= TRK_LDS_PRIMS")     # BOX: (value, index) primitive loop + LDS table
+    n_sw = len(switches)
+    targs = ", ".join(f"decltype(c{k})::value" for k in range(n_sw))
+    params = ", ".join(f"auto c{k}" for k in range(n_sw))
+    out.append(f"    auto go = [&](auto io, {params}) {{")
+    out.append("        using IOT = decltype(io);")
+    out.append(f"        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<IOT, {targs}>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append(f"        else hipLaunchKernelGGL((k_rollout_bg<IOT, {targs}>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("    };")
+    prev = "go"
+    for k in range(n_sw - 1, -1, -1):             # innermost lambda decides the LAST switch
+        fixed = ", ".join(f"auto c{m}" for m in range(k))
+        fixed_args = ", ".join(f"c{m}" for m in range(k))
+        sep = ", " if k else ""
+        out.append(f"    auto sw{k} = [&](auto io{sep}{fixed}) {{ if ({switches[k]}) {prev}(io{sep}{fixed_args}, std::true_type{{}}); "
+                   f"else {prev}(io{sep}{fixed_args}, std::false_type{{}}); }};")
+        prev = f"sw{k}"
+    out.append("    if (a.io_f16) sw0(_Float16{}); else sw0(float{});")
     out.append("}")
     out.append("static void launch_posbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")

@@ -930,6 +930,7 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     h.obj_link_margin = reinterpret_cast<const float*>(base + o_mg);
     h.objects = reinterpret_cast<const DevObj*>(base + o_obj);
     h.prims = reinterpret_cast<const DevPrim*>(base + o_pr);
+    h.n_prims = d->n_prims; h._pad_prims = 0;
     h.self_pairs = reinterpret_cast<const int32_t*>(base + o_sp);
     h.self_margin = reinterpret_cast<const float*>(base + o_sm);
     cm->obj_link_idx.assign(d->obj_link_idx, d->obj_link_idx + d->n_obj_links);

@@ -107,6 +107,8 @@ struct DevCostHdr {
     int32_t self_single;           // 1: some self pair is (a, a) -- the single-link distance 1e9 |p|_1 (distance_fields.py:195-198)
     const int32_t* virtual_src;    // device [2 * n_virtual]
     const float* virtual_w;        // device [2 * n_virtual]
+    int32_t n_prims;               // entries of prims[] (a fused kernel keeps up to TRK_LDS_PRIMS of them in LDS)
+    int32_t _pad_prims;
 };
 
 // Points rigidly attached to links (grasped-object points robot_panda.py:154-168, per-link collision spheres):
@@ -456,6 +458,7 @@ __device__ __forceinline__ void scene_rank_pairs(const TRK_CAS float* tab, int n
 struct IkSchedule { float bc1[TRK_IK_MAX_STEPS]; float rsqrt_bc2[TRK_IK_MAX_STEPS]; };
 
 #define TRK_LDS_SPHERES 16     // sphere centres a fused kernel may keep in LDS for the arg-min gather
+#define TRK_LDS_PRIMS 16       // primitive records (two float4s each) a fused kernel may keep in LDS for the winning box's gather
 
 // FAST: the caller guarantees (wave-uniformly, from the cost model header: scene_is_fast) that the scene is 1..16
 // spheres of one radius and nothing else, so only that path is compiled -- a kernel that inlines this function many
@@ -467,7 +470,8 @@ __host__ __device__ inline bool scene_is_fast(const DevCostHdr& C) {
 template <int NL, class Tick = NoTick, bool FAST = false>
 __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (&px)[NL], const float (&py)[NL],
                                               const float (&pz)[NL], float (&s)[NL], float (&gx)[NL], float (&gy)[NL],
-                                              float (&gz)[NL], Tick&& tick = Tick(), const float4* lds_spheres = nullptr) {
+                                              float (&gz)[NL], Tick&& tick = Tick(), const float4* lds_spheres = nullptr,
+                                              const float4* lds_prims = nullptr) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) { s[l] = __builtin_inff(); gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }
     // contract with the caller: all TRK_OBJ_TICK_SLOTS tick slots are issued on every path -- interleaved with the pair ranking when
@@ -606,6 +610,32 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                 }
             }
             float bv = __builtin_inff(), bdx = 0.0f, bdy = 0.0f, bdz = 0.0f, bux = 0.0f, buy = 0.0f, buz = 0.0f, bsharp = 0.0f;
+            if (lds_prims && C.n_prims <= TRK_LDS_PRIMS) {
+                // the loop carries only (value, index) -- compare + two selects per box instead of compare + eight, all half-rate
+                // instructions -- and the winner's offset and u are re-derived from its record in the wave's LDS copy of the table
+                int bi = O.prim_begin;
+                for (int pi = O.prim_begin; pi < O.prim_end; ++pi) {
+                    const DevPrim P = load_prim(C.prims, pi);
+                    if (P.type == TRK_PRIM_SPHERE) continue;
+                    const float dx = lx - P.cx, dy = ly - P.cy, dz = lz - P.cz;
+                    const float ux = __builtin_fabsf(dx) - P.hx + P.r, uy = __builtin_fabsf(dy) - P.hy + P.r, uz = __builtin_fabsf(dz) - P.hz + P.r;
+                    const float mu = __builtin_fmaxf(__builtin_fmaxf(ux, uy), uz);
+                    float v = mu;
+                    if (P.type != TRK_PRIM_SHARP_BOX) {
+                        const float rx = __builtin_fmaxf(ux, 0.0f), ry = __builtin_fmaxf(uy, 0.0f), rz = __builtin_fmaxf(uz, 0.0f);
+                        v = __builtin_fminf(mu, 0.0f) + trk_sqrt(fmaf(rx, rx, fmaf(ry, ry, rz * rz))) - P.r;
+                    }
+                    const bool take = v < bv;
+                    bv = take ? v : bv; bi = take ? pi : bi;
+                }
+                if (!(bv < s[l])) continue;
+                typedef __attribute__((address_space(3))) const float lds_cfloat;
+                lds_cfloat* rec = (lds_cfloat*)reinterpret_cast<const float*>(lds_prims) + 8 * bi;
+                const float cx = rec[1], cy = rec[2], cz = rec[3], hx = rec[4], hy = rec[5], hz = rec[6], r = rec[7];
+                bsharp = __float_as_int(rec[0]) == TRK_PRIM_SHARP_BOX ? 1.0f : 0.0f;
+                bdx = lx - cx; bdy = ly - cy; bdz = lz - cz;
+                bux = __builtin_fabsf(bdx) - hx + r; buy = __builtin_fabsf(bdy) - hy + r; buz = __builtin_fabsf(bdz) - hz + r;
+            } else {
             for (int pi = O.prim_begin; pi < O.prim_end; ++pi) {
                 const DevPrim P = load_prim(C.prims, pi);
                 if (P.type == TRK_PRIM_SPHERE) continue;                     // spheres live in the merged table above
@@ -625,6 +655,7 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                 bsharp = take ? (sharp ? 1.0f : 0.0f) : bsharp;
             }
             if (!(bv < s[l])) continue;                                   // this object does not beat the scene's best for this point
+            }
             // gradient of the winning box in the object frame (prim_sdf's formulas): arg-max with "first maximum wins"
             int am = 0; float mu = bux;
             if (buy > mu) { mu = buy; am = 1; }

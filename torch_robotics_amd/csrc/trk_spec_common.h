@@ -80,7 +80,7 @@ typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 17)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 18)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -265,6 +265,15 @@ __device__ __forceinline__ SpheresInFlight spec_load_spheres_issue(const DevCost
 }
 __device__ __forceinline__ void spec_load_spheres_finish(float4* lds_spheres, int lane, const SpheresInFlight& s) {
     if (s.on) lds_spheres[lane] = s.v;
+}
+// the same for the primitive table of a box scene (two float4s per record, lanes 0 .. 2 n_prims - 1; a table longer than
+// TRK_LDS_PRIMS is not copied and scene_min_sdf keeps its select chain): lds_prims = the wave's TRK_LDS_PRIMS * 2 float4s
+__device__ __forceinline__ SpheresInFlight spec_load_prims_issue(const DevCostHdr& C, int lane) {
+    SpheresInFlight s;
+    s.on = C.n_box_objects > 0 && C.n_prims <= TRK_LDS_PRIMS && lane < 2 * C.n_prims;
+    s.v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (s.on) s.v = reinterpret_cast<const float4*>(C.prims)[lane];
+    return s;
 }
 
 template <int D, class IO>
@@ -755,9 +764,9 @@ template <int NL, class Tick, bool FAST = false>
 __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w, const float (&px)[NL],
                                                    const float (&py)[NL], const float (&pz)[NL], float (&gx)[NL],
                                                    float (&gy)[NL], float (&gz)[NL], const Tick& tick, const float4* lds_spheres,
-                                                   int mbase = 0) {
+                                                   int mbase = 0, const float4* lds_prims = nullptr) {
     float s[NL], ax[NL], ay[NL], az[NL];
-    scene_min_sdf<NL, const Tick&, FAST>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres);
+    scene_min_sdf<NL, const Tick&, FAST>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres, lds_prims);
     float cost = 0.0f;
     if (C.clamp_fields & TRK_FIELD_OBJECTS) {                                  // wave-uniform: the hinge form (clamp_sdf=True)
 #pragma unroll
