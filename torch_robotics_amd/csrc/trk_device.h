@@ -460,6 +460,90 @@ struct IkSchedule { float bc1[TRK_IK_MAX_STEPS]; float rsqrt_bc2[TRK_IK_MAX_STEP
 #define TRK_LDS_SPHERES 16     // sphere centres a fused kernel may keep in LDS for the arg-min gather
 #define TRK_LDS_PRIMS 16       // primitive records (two float4s each) a fused kernel may keep in LDS for the winning box's gather
 
+// Box objects of the scene for the BOX instantiations of the fused kernels (the launch chose them: boxes present, primitive table
+// <= TRK_LDS_PRIMS records, copied to the wave's LDS).  Primitive-major: a record is fetched ONCE for the whole group of points (a
+// scalar load per box instead of per box and point, NL independent chains per record), the loop carries only (value, index) per point
+// -- compare + two selects per box and point instead of compare + eight, all half-rate instructions -- and the winner's offset and
+// u = |d| - half + r are re-derived from its record in LDS.  Same strict-less, first-wins choice and the same gradient formulas as
+// the loop in scene_min_sdf (which the other instantiations keep, textually untouched: the headline kernel's register allocation
+// follows that text).
+template <int NL>
+__device__ __forceinline__ void scene_boxes_lds(const DevCostHdr& C, const float (&px)[NL], const float (&py)[NL], const float (&pz)[NL],
+                                                float (&s)[NL], float (&gx)[NL], float (&gy)[NL], float (&gz)[NL], const float4* lds_prims) {
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    for (int b = 0; b < C.n_box_objects; ++b) {
+        const int o = cptr(C.box_objects)[b];
+        const DevObj O = load_obj(C.objects, o);
+        const bool ident = (O.identity & TRK_OBJ_IDENTITY) != 0;
+        float lx[NL], ly[NL], lz[NL], bv[NL];
+        int bi[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const float dx = px[l] - O.pos[0], dy = py[l] - O.pos[1], dz = pz[l] - O.pos[2];
+            if (ident) { lx[l] = dx; ly[l] = dy; lz[l] = dz; }
+            else {
+                lx[l] = fmaf(O.R[0], dx, fmaf(O.R[3], dy, O.R[6] * dz));
+                ly[l] = fmaf(O.R[1], dx, fmaf(O.R[4], dy, O.R[7] * dz));
+                lz[l] = fmaf(O.R[2], dx, fmaf(O.R[5], dy, O.R[8] * dz));
+            }
+            bv[l] = __builtin_inff(); bi[l] = O.prim_begin;
+        }
+        for (int pi = O.prim_begin; pi < O.prim_end; ++pi) {
+            const DevPrim P = load_prim(C.prims, pi);
+            if (P.type == TRK_PRIM_SPHERE) continue;                     // spheres live in the merged table
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const float dx = lx[l] - P.cx, dy = ly[l] - P.cy, dz = lz[l] - P.cz;
+                const float ux = __builtin_fabsf(dx) - P.hx + P.r, uy = __builtin_fabsf(dy) - P.hy + P.r, uz = __builtin_fabsf(dz) - P.hz + P.r;
+                const float mu = __builtin_fmaxf(__builtin_fmaxf(ux, uy), uz);
+                float v = mu;
+                if (P.type != TRK_PRIM_SHARP_BOX) {
+                    const float rx = __builtin_fmaxf(ux, 0.0f), ry = __builtin_fmaxf(uy, 0.0f), rz = __builtin_fmaxf(uz, 0.0f);
+                    v = __builtin_fminf(mu, 0.0f) + trk_sqrt(fmaf(rx, rx, fmaf(ry, ry, rz * rz))) - P.r;
+                }
+                const bool take = v < bv[l];
+                bv[l] = take ? v : bv[l]; bi[l] = take ? pi : bi[l];
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (!(bv[l] < s[l])) continue;                               // this object does not beat the scene's best for this point
+            lds_cfloat* rec = (lds_cfloat*)reinterpret_cast<const float*>(lds_prims) + 8 * bi[l];
+            const float cx = rec[1], cy = rec[2], cz = rec[3], hx = rec[4], hy = rec[5], hz = rec[6], r = rec[7];
+            const float bsharp = __float_as_int(rec[0]) == TRK_PRIM_SHARP_BOX ? 1.0f : 0.0f;
+            const float bdx = lx[l] - cx, bdy = ly[l] - cy, bdz = lz[l] - cz;
+            const float bux = __builtin_fabsf(bdx) - hx + r, buy = __builtin_fabsf(bdy) - hy + r, buz = __builtin_fabsf(bdz) - hz + r;
+            const float bvl = bv[l];
+            // gradient of the winning box in the object frame (prim_sdf's formulas): arg-max with "first maximum wins"
+            int am = 0; float mu = bux;
+            if (buy > mu) { mu = buy; am = 1; }
+            if (buz > mu) { mu = buz; am = 2; }
+            const float sx = bdx > 0.0f ? 1.0f : (bdx < 0.0f ? -1.0f : 0.0f);
+            const float sy = bdy > 0.0f ? 1.0f : (bdy < 0.0f ? -1.0f : 0.0f);
+            const float sz = bdz > 0.0f ? 1.0f : (bdz < 0.0f ? -1.0f : 0.0f);
+            float ax, ay, az;
+            if (bsharp != 0.0f) {
+                ax = am == 0 ? sx : 0.0f; ay = am == 1 ? sy : 0.0f; az = am == 2 ? sz : 0.0f;
+            } else {
+                const float rx = __builtin_fmaxf(bux, 0.0f), ry = __builtin_fmaxf(buy, 0.0f), rz = __builtin_fmaxf(buz, 0.0f);
+                const float nn = trk_sqrt(fmaf(rx, rx, fmaf(ry, ry, rz * rz)));
+                const float inv = nn > 0.0f ? trk_rcp(nn) : 0.0f;
+                const float inside = mu < 0.0f ? 1.0f : 0.0f;
+                ax = (rx * inv + (am == 0 ? inside : 0.0f)) * sx;
+                ay = (ry * inv + (am == 1 ? inside : 0.0f)) * sy;
+                az = (rz * inv + (am == 2 ? inside : 0.0f)) * sz;
+            }
+            s[l] = bvl;
+            if (ident) { gx[l] = ax; gy[l] = ay; gz[l] = az; }
+            else {
+                gx[l] = fmaf(O.R[0], ax, fmaf(O.R[1], ay, O.R[2] * az));
+                gy[l] = fmaf(O.R[3], ax, fmaf(O.R[4], ay, O.R[5] * az));
+                gz[l] = fmaf(O.R[6], ax, fmaf(O.R[7], ay, O.R[8] * az));
+            }
+        }
+    }
+}
+
 // FAST: the caller guarantees (wave-uniformly, from the cost model header: scene_is_fast) that the scene is 1..16
 // spheres of one radius and nothing else, so only that path is compiled -- a kernel that inlines this function many
 // times (attached-point kernels: once per group of points) would otherwise not fit the instruction cache.
@@ -593,6 +677,9 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
     // only the arg-min primitive passes a gradient).  Point by point on purpose: the winner's eight registers are live across
     // the primitive loop, and with all NL points in flight at once the Panda kernel no longer fitted its 128 registers (57
     // spills in the sphere-scene hot path as well: 10 -> 19.7 us).
+    if (lds_prims && C.n_prims <= TRK_LDS_PRIMS) {
+        scene_boxes_lds<NL>(C, px, py, pz, s, gx, gy, gz, lds_prims);       // BOX instantiations: primitive-major, (value, index)
+    } else
     for (int b = 0; b < C.n_box_objects; ++b) {
         const int o = cptr(C.box_objects)[b];
         const DevObj O = load_obj(C.objects, o);
@@ -610,32 +697,6 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                 }
             }
             float bv = __builtin_inff(), bdx = 0.0f, bdy = 0.0f, bdz = 0.0f, bux = 0.0f, buy = 0.0f, buz = 0.0f, bsharp = 0.0f;
-            if (lds_prims && C.n_prims <= TRK_LDS_PRIMS) {
-                // the loop carries only (value, index) -- compare + two selects per box instead of compare + eight, all half-rate
-                // instructions -- and the winner's offset and u are re-derived from its record in the wave's LDS copy of the table
-                int bi = O.prim_begin;
-                for (int pi = O.prim_begin; pi < O.prim_end; ++pi) {
-                    const DevPrim P = load_prim(C.prims, pi);
-                    if (P.type == TRK_PRIM_SPHERE) continue;
-                    const float dx = lx - P.cx, dy = ly - P.cy, dz = lz - P.cz;
-                    const float ux = __builtin_fabsf(dx) - P.hx + P.r, uy = __builtin_fabsf(dy) - P.hy + P.r, uz = __builtin_fabsf(dz) - P.hz + P.r;
-                    const float mu = __builtin_fmaxf(__builtin_fmaxf(ux, uy), uz);
-                    float v = mu;
-                    if (P.type != TRK_PRIM_SHARP_BOX) {
-                        const float rx = __builtin_fmaxf(ux, 0.0f), ry = __builtin_fmaxf(uy, 0.0f), rz = __builtin_fmaxf(uz, 0.0f);
-                        v = __builtin_fminf(mu, 0.0f) + trk_sqrt(fmaf(rx, rx, fmaf(ry, ry, rz * rz))) - P.r;
-                    }
-                    const bool take = v < bv;
-                    bv = take ? v : bv; bi = take ? pi : bi;
-                }
-                if (!(bv < s[l])) continue;
-                typedef __attribute__((address_space(3))) const float lds_cfloat;
-                lds_cfloat* rec = (lds_cfloat*)reinterpret_cast<const float*>(lds_prims) + 8 * bi;
-                const float cx = rec[1], cy = rec[2], cz = rec[3], hx = rec[4], hy = rec[5], hz = rec[6], r = rec[7];
-                bsharp = __float_as_int(rec[0]) == TRK_PRIM_SHARP_BOX ? 1.0f : 0.0f;
-                bdx = lx - cx; bdy = ly - cy; bdz = lz - cz;
-                bux = __builtin_fabsf(bdx) - hx + r; buy = __builtin_fabsf(bdy) - hy + r; buz = __builtin_fabsf(bdz) - hz + r;
-            } else {
             for (int pi = O.prim_begin; pi < O.prim_end; ++pi) {
                 const DevPrim P = load_prim(C.prims, pi);
                 if (P.type == TRK_PRIM_SPHERE) continue;                     // spheres live in the merged table above
@@ -655,7 +716,6 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                 bsharp = take ? (sharp ? 1.0f : 0.0f) : bsharp;
             }
             if (!(bv < s[l])) continue;                                   // this object does not beat the scene's best for this point
-            }
             // gradient of the winning box in the object frame (prim_sdf's formulas): arg-max with "first maximum wins"
             int am = 0; float mu = bux;
             if (buy > mu) { mu = buy; am = 1; }
