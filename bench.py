@@ -1,32 +1,39 @@
 #!/usr/bin/env python3
-"""Headline benchmark: FK + cost + gradient rollouts/sec (batch x horizon), Franka Panda 7-DOF.
+"""Headline benchmark: FK + cost + gradient rollouts/sec (batch x horizon) -- every BASELINE config as a driver-runnable workload.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5]
 
 N > 1 without a launcher: this script starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
 127.0.0.1 --master-port P bench.py ...` itself as a CHILD process, before anything in this process has touched the GPU, and
 exits with the child's code.  Under a launcher (RANK / LOCAL_RANK / WORLD_SIZE in the environment) it is one rank.
 
-One step = one pass of the fused hot path (`trk_rollout_cost_grad`) over one batch of synthetic joint
-trajectories resident in HBM: read q, write link positions, cost and d cost / d q.
-Workload (BASELINE.json configs[1], "c2"): batch 4096 x horizon 64, Panda (11 links / 7 DOF), scene
-EnvSpheres3D (10 spheres, analytic SDF, cutoff 0.03), cost = object collision + EE SE(3) tracking
-(target p=(0.4,0.2,0.5), R=I).  `--config c3` adds self-collision pairs and the workspace box (configs[2]'s objective stack).
-`--scene grid|shelf|maze` are SURVEY 8(d)'s secondary runs of the same workload: the 200^3 voxel SDF of the same spheres
-(+16 B of gathers per collision link and sample), EnvTableShelf and EnvMazeBoxes3D (box scenes; same algorithmic bytes).
-Multi-GPU: the batch is sharded, each rank owns 4096 x 64 samples (weak scaling); the only exchange is an
-RCCL all-reduce of the packed sums [cost | cost per time step | gradient per time step and joint] (2 kB), issued once per
-`--reduce-every` steps on a side stream.  `value` INCLUDES those collectives; `multi_gpu.kernel_only` is the same loop without them,
-`multi_gpu.full_stack_c3` is configs[2]'s objective stack on the same shards.
+One step = one pass of the hot path over one batch of synthetic joint trajectories resident in HBM.
+  c2 (default; BASELINE configs[1], the headline): Panda (11 links / 7 DOF), batch 4096 x horizon 64, EnvSpheres3D (10 spheres, analytic
+      SDF, cutoff 0.03), object collision + EE SE(3) tracking (target p=(0.4,0.2,0.5), R=I): ONE launch of `trk_rollout_cost_grad`
+      (read q, write link positions, cost and d cost / d q).  `--scene grid|shelf|maze` are SURVEY 8(d)'s secondary runs.
+  c3 (configs[2]'s objective stack): the same + self-collision pairs + workspace box; 32768 x 64 is 8 ranks x this.
+  c4 (configs[3]): UR10 + Allegro hand (30 links / 22 DOF), 4096 x 64, "FK + Jacobian + cost": the fused rollout (FK, obstacle + EE
+      cost, gradient, link positions) and the geometric Jacobian of `ee_link` (`trk_fk_jacobian`) -- two launches per step.
+  c5 (configs[4]): dual Panda (23 links / 14 DOF), horizon 128, fp16 q / qd / link positions / gradients in HBM with fp32 arithmetic
+      and cost, GP-smoothness (sigma_gp = 0.1, dt = 5 / 128) + obstacle + EE on both arms; 2048 trajectories per GPU -- at
+      `--gpus 4` the global batch is BASELINE's 8192.  The gradients carry a power-of-two loss scale (`ops.gp_grad_scale`).
+Multi-GPU: the batch is sharded, each rank owns its block of whole trajectories (weak scaling); the only exchange is an
+all-reduce (RCCL) of the packed sums [cost | cost per time step | gradient per time step and joint] (1 + H + H D floats), issued
+on a side stream once per `--reduce-every` steps -- at most steps // 2, so EVERY timed region contains at least one exchange
+(`multi_gpu.collectives_in_timed_region`).  `value` INCLUDES those collectives; `multi_gpu.kernel_only` is the same loop without
+them, `multi_gpu.every_step` the same loop with one exchange per step, `multi_gpu.full_stack_c3` (c2 / c3 runs) configs[2]'s
+objective stack on the same shards.
 
 Timed region: W untimed warm-up steps, then exactly K steps bracketed on both sides by a barrier (N > 1: a one-element all-reduce
 enqueued on the launch stream -- it completes only when every rank has reached it) + `torch.cuda.synchronize()`.  A rank's clock
 runs from the opening bracket to the return of its own closing `torch.cuda.synchronize()` (launch stream AND the side stream's
 collectives complete); the maximum over the ranks is taken -- the time from the common start to the completion of the last rank.
-For N > 1 the closing barrier follows the clock stop (an 8-rank all-reduce is not a step; at N = 1 there is none either).  The whole measurement is rehearsed once and discarded first.
+For N > 1 the closing barrier FOLLOWS the clock stop (it is outside the clock: an 8-rank all-reduce is not a step; at N = 1 there
+is none either).  The whole measurement is rehearsed once and discarded first.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes/sample x samples per launch /
-average launch duration (HIP events around the timed region on the launch stream).
+Prints ONE JSON line (rank 0).  `roofline` describes the step's dominant kernel (the fused rollout): `achieved` = its algorithmic
+bytes/sample x samples per launch / its average launch duration (HIP events on the launch stream: around the timed region when
+the step is that one launch, around a loop of that kernel alone otherwise); `roofline.step` prices the whole step.
 `cpu_baseline` = the C oracle (OpenMP over samples) on a bounded sample of the same input, on all host threads (`value`) and on one.
 """
 import argparse
@@ -44,13 +51,16 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # fp32 vector peak 157.3 TFLOP/s = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flop: one 64-lane VALU instruction takes a SIMD 2 cycles
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
-PMC_FILES = ("r03_pmc.json", "r02_hbm_traffic.json")      # per-launch counters recorded by tools/run_r03_profiles.sh
+# per-launch counters recorded by tools/run_r04_profiles.sh (earlier rounds' files as fall-backs)
+PMC_FILES = ("r04_pmc.json", "r03_pmc.json", "r02_hbm_traffic.json")
+DEFAULT_SHAPE = {"c2": (4096, 64), "c3": (4096, 64), "c4": (4096, 64), "c5": (2048, 128)}     # per-GPU batch x horizon
+SIGMA_GP, T_GP = 0.1, 5.0        # config 5's GP prior: sigma_gp of the reference's planner parameters (env_spheres_3d.py:57), 5 s trajectories
 
 
-def algorithmic_bytes_per_sample(D, L, n_grid_links=0):
-    # read q (4D) + write link positions (12L) + cost (4) + gradient (4D); the voxel-grid scene adds one
-    # 16-byte gather (sdf + stored gradient of the nearest cell) per collision link
-    return 4 * D + 12 * L + 4 + 4 * D + 16 * n_grid_links
+def algorithmic_bytes_per_sample(D, L, n_grid_links=0, esz=4):
+    # read q (D) + write link positions (3L) + gradient (D), `esz` bytes each, + cost (4); the voxel-grid scene
+    # adds one 16-byte gather (sdf + stored gradient of the nearest cell) per collision link
+    return esz * D + 3 * esz * L + 4 + esz * D + 16 * n_grid_links
 
 
 def parse_args(argv):
@@ -58,19 +68,24 @@ def parse_args(argv):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--scene", default="spheres", choices=["spheres", "grid", "shelf", "maze"])
-    ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--horizon", type=int, default=64)
-    ap.add_argument("--reduce-every", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: 4096; c5: 2048)")
+    ap.add_argument("--horizon", type=int, default=None, help="time steps per trajectory (default: 64; c5: 128)")
+    ap.add_argument("--reduce-every", type=int, default=64,
+                    help="the planner's exchange cadence; a short run uses min(this, steps // 2) so that its timed region contains a collective")
     ap.add_argument("--graph", type=int, default=0, help="capture this many steps per hipGraph replay (0 = eager launches)")
     ap.add_argument("--weights", default=None, help="experiment: w_self,w_obj,w_ws,w_ee override (reported in config)")
     ap.add_argument("--no-pos", action="store_true", help="experiment: do not write link positions")
+    ap.add_argument("--q", default="iid", choices=["iid", "smooth"],
+                    help="c2 / c3 input: independent uniform configurations (default), or trajectories that are smooth along the horizon "
+                         "(a random walk of 0.02 rad steps: what a planner feeds; matters for the voxel-grid scene's gathers)")
     ap.add_argument("--independent-streams", type=int, default=0,
                     help="also report the throughput of unrelated batches alternated over this many HIP streams (secondary "
                          "figure `independent_batches`; off by default so that a rocprofv3 run of the default command sees only "
                          "back-to-back launches of one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-out-of-cache", action="store_true", help="skip the secondary beyond-the-Infinity-Cache measurement (c2, N = 1)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' + --single-device lets the N>1 control flow run on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--same-q", action="store_true", help="debug: every rank draws the same q (all-reduced sums == N x rank 0's)")
@@ -80,7 +95,11 @@ def parse_args(argv):
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: run the N > 1 code path (process group, side-stream all-reduce, in-stream barriers, multi_gpu section) "
                          "even with ONE rank -- the only way to put the RCCL calls on hardware on a 1-GPU box")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    b, h = DEFAULT_SHAPE[args.config]
+    args.batch = b if args.batch is None else args.batch
+    args.horizon = h if args.horizon is None else args.horizon
+    return args
 
 
 def self_launch(args, argv):
@@ -138,6 +157,174 @@ def make_task(tra, scene, ta):
     return robot, task, what
 
 
+W_C2, W_C3 = (0.0, 1.0, 0.0, 1.0), (1.0, 1.0, 1.0, 1.0)
+
+
+class Workload:
+    """One BASELINE config on one rank: the pre-bound launches of a step, what the exchange packs, and the oracle's side of it."""
+    extras = ()             # [(label, launch(stream), algorithmic bytes per sample)]: launches of a step after the fused rollout
+    traj_cost = None        # per-trajectory cost evaluated next to the rollout (GP prior): joins packed[0]
+    plan3 = None            # c2 / c3: configs[2]'s objective stack on the same shard
+    n_grid_links = 0
+    esz = 4
+
+    def step(self, bs_ptr, s):
+        self.plan.launch(bs_ptr, s)
+        for _, fn, _ in self.extras:
+            fn(s)
+
+    @property
+    def bps_step(self):
+        return self.bps + sum(b for _, _, b in self.extras)
+
+
+def smooth_trajectories(torch, B, H, D, gen, dev, lo, hi):
+    """random walks of 0.02 rad steps around a uniform start, clipped to the joint limits"""
+    start = lo + (hi - lo) * torch.rand(B, 1, D, generator=gen, device=dev)
+    walk = torch.cumsum(torch.randn(B, H, D, generator=gen, device=dev) * 0.02, 1)
+    return torch.minimum(torch.maximum(start + walk, lo), hi).contiguous()
+
+
+def build_workload(args, tra, ops, torch, dev, rank):
+    import numpy as np
+    ta = dict(device=dev, dtype=torch.float32)
+    B, H = args.batch, args.horizon
+    gen = torch.Generator(device=dev).manual_seed(1234 + (0 if args.same_q else rank))
+    wl = Workload()
+    wl.B, wl.H, wl.cfg, wl.gen = B, H, args.config, gen
+    if args.config in ("c2", "c3"):
+        robot, task, scene_text = make_task(tra, args.scene, ta)
+        weights = W_C2 if args.config == "c2" else W_C3
+        if args.weights:
+            weights = tuple(float(v) for v in args.weights.split(","))
+        kin = robot.diff_panda._kin
+        D, L = robot.q_dim, kin.n_links
+        if args.q == "smooth":
+            q = smooth_trajectories(torch, B, H, D, gen, dev, robot.q_min.to(dev), robot.q_max.to(dev))
+        else:
+            q = robot.random_q(B * H, generator=gen).reshape(B, H, D).contiguous()
+        model, cm = task._fused_handles(dev)
+        wl.plan = ops.RolloutPlan(model, cm, weights, q, want_pos=not args.no_pos)
+        wl.plan3 = wl.plan if weights == W_C3 else ops.RolloutPlan(model, cm, W_C3, q, want_pos=not args.no_pos)
+        wl.spec_fn = task.build_cost_spec
+        wl.n_grid_links = len(cm.spec.obj_link_idx) if (cm.spec.grid is not None and weights[1] != 0.0) else 0
+        objectives = {"c2": "SDF-obstacle + EE-tracking", "c3": "self-collision + SDF-obstacle + workspace box + EE-tracking"}[args.config]
+        wl.metric = "FK+cost+grad rollouts/sec (batch x horizon), Panda 7-DOF"
+        wl.text = (f"BASELINE configs[{1 if args.config == 'c2' else 2}]{'' if args.config == 'c2' else ' objective stack'}: Franka Panda "
+                   f"({L} links, {D} DOF), batch={B} x horizon={H} per GPU, fused FK + {objectives} cost + gradient ({scene_text}), "
+                   f"q resident in HBM" + (", smooth trajectories" if args.q == "smooth" else ""))
+        wl.dtype, wl.random_q = "f32", lambda n: robot.random_q(n, generator=gen)
+        wl.make_plan = lambda qq: ops.RolloutPlan(model, cm, weights, qq, want_pos=not args.no_pos)
+    else:
+        from torch_robotics_amd import codegen
+        from torch_robotics_amd.costmodel import CostModelSpec
+        ident = "ur10_allegro" if args.config == "c4" else "dual_panda"
+        kin, tmpl = codegen.template_for(ident)
+        env = tra.EnvSpheres3D(tensor_args=ta)
+        spec = CostModelSpec(n_links_in=kin.n_links)
+        spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+        spec.obj_link_margin = np.full(len(tmpl.obj_links), 0.13, np.float32)
+        spec.objects = [o.as_object() for o in env.obj_fixed_list]
+        spec.ee_link = tmpl.ee_link
+        Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5); spec.ee_target = Ht
+        if tmpl.ee2_link >= 0:          # two-arm template: the second arm tracks its own target
+            spec.ee2_link = tmpl.ee2_link
+            Ht2 = np.eye(4, dtype=np.float32); Ht2[:3, 3] = (0.4, -0.3, 0.5); spec.ee2_target = Ht2
+        spec.validate()
+        model, cm = ops.ModelHandle(kin), ops.CostHandle(spec, dev)
+        D, L = kin.n_dofs, kin.n_links
+        weights = W_C2 if not args.weights else tuple(float(v) for v in args.weights.split(","))
+        wl.spec_fn = lambda: spec
+        scene_text = "EnvSpheres3D, 10 spheres, analytic SDF"
+        if args.config == "c4":
+            q = ((torch.rand(B, H, D, generator=gen, **ta) - 0.5) * 3.0).contiguous()
+            wl.plan = ops.RolloutPlan(model, cm, weights, q, want_pos=not args.no_pos)
+            ee = int(kin.name_to_idx["ee_link"])
+            jac = ops.JacobianPlan(model, q.reshape(B * H, D), ee)
+            wl.jac, wl.ee = jac, ee
+            wl.extras = [("geometric Jacobian of ee_link (trk_fk_jacobian: pos, quat, lin_jac, ang_jac)", jac.launch, 4 * D + 28 + 24 * D)]
+            wl.metric = "FK+Jacobian+cost rollouts/sec (batch x horizon), UR10+Allegro 22-DOF"
+            wl.text = (f"BASELINE configs[3]: UR10 + Allegro hand ({L} links, {D} DOF), batch={B} x horizon={H} per GPU, fused FK + "
+                       f"SDF-obstacle + EE-tracking cost + gradient + link positions ({scene_text}), then the geometric Jacobian of ee_link; "
+                       f"q resident in HBM")
+            wl.dtype = "f32"
+        else:
+            dt = T_GP / H
+            q = torch.cumsum(torch.randn(B, H, D, generator=gen, **ta) * 0.02, 1) + (torch.rand(B, 1, D, generator=gen, **ta) - 0.5) * 2.0
+            qd = torch.zeros_like(q)
+            qd[:, :-1] = (q[:, 1:] - q[:, :-1]) / dt                     # the velocities of the same trajectories
+            qd[:, -1] = qd[:, -2]
+            qh, qdh = q.half().contiguous(), qd.half().contiguous()
+            # loss scale: worst case of the GP gradient over trajectories bounded like these, + the collision / EE gradient's size
+            gs = ops.gp_grad_scale(dt, SIGMA_GP, 1.0, float(qh.abs().max()), float(qdh.abs().max()), extra=64.0)
+            wl.plan = ops.RolloutPlan(model, cm, weights, qh, want_pos=not args.no_pos, grad_scale=gs)
+            wl.gqd = torch.zeros_like(qh)
+            wl.gp = ops.GPPriorPlan(qh, qdh, dt, SIGMA_GP, 1.0, accumulate_into=(wl.plan.gq, wl.gqd), grad_scale=gs)
+            wl.traj_cost = wl.gp.cost
+            wl.qd, wl.dt, wl.grad_scale = qdh, dt, gs
+            # GP prior: read q, qd (2 x 2D), read-modify-write gq (2 x 2D), write gqd (2D), cost per trajectory
+            wl.extras = [("GP prior cost + gradient accumulated into gq / gqd (trk_gp_prior_cost_grad, fp16 I/O)", wl.gp.launch, 2 * 5 * D)]
+            wl.metric = "FK+cost+grad rollouts/sec (batch x horizon), dual Panda 14-DOF, fp16 I/O"
+            wl.text = (f"BASELINE configs[4]: dual Panda ({L} links, {D} DOF), batch={B} x horizon={H} per GPU (8192 x 128 over 4 GPUs), "
+                       f"fp16 q / qd / link positions / gradients in HBM (loss scale 2^{int(np.log2(gs))}), fp32 arithmetic and cost: fused FK + "
+                       f"SDF-obstacle + EE-tracking on both arms + gradient, then the GP prior (sigma_gp = {SIGMA_GP}, dt = {T_GP}/{H}) "
+                       f"accumulated into the same gradient; q, qd resident in HBM")
+            wl.dtype, wl.esz, q = "f16", 2, qh
+        wl.random_q = None
+    wl.q, wl.model, wl.cm, wl.kin, wl.weights, wl.D, wl.L = q, model, cm, kin, weights, D, L
+    wl.bps = algorithmic_bytes_per_sample(D, L if not args.no_pos else 0, wl.n_grid_links, wl.esz)
+    return wl
+
+
+def cpu_baseline(wl, args, torch, seconds):
+    """The C oracle on a bounded sample of rank 0's batch: all host threads (`value`) and one thread."""
+    import numpy as np
+    from oracle import oracle as orc          # checker / baseline only: never on the product path
+    spec = wl.spec_fn()
+    if spec.grid is not None:                 # the oracle reads host arrays
+        spec.grid = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in spec.grid.items()}
+    o = orc.Oracle(wl.kin, spec)
+    D, H = wl.D, wl.H
+    q_host = wl.q.reshape(-1, D).float().cpu().numpy()           # c5: the fp16-rounded trajectories, widened
+    qd_host = wl.qd.reshape(-1, D).float().cpu().numpy() if wl.cfg == "c5" else None
+    cores = orc.max_threads()
+    unit = H if wl.cfg == "c5" else 1                            # c5 evaluates whole trajectories (the GP prior couples time steps)
+
+    def one(n):
+        o.rollout(q_host[:n], wl.weights, "f32")
+        if wl.cfg == "c4":
+            o.jacobian(q_host[:n], None, wl.ee, "f32")
+        elif wl.cfg == "c5":
+            orc.gp_prior(q_host[:n].reshape(-1, H, D), qd_host[:n].reshape(-1, H, D), wl.dt, SIGMA_GP, 1.0, "f32")
+
+    def timed(n, reps):
+        best = 1e30
+        for _ in range(reps):
+            t = time.perf_counter(); one(n); best = min(best, time.perf_counter() - t)
+        return best
+
+    def whole(n):
+        return max(unit, int(n) // unit * unit)
+    # all threads: ~2/3 of the budget; one thread: ~1/3 (both bounded samples of rank 0's batch)
+    probe = whole(min(16384, len(q_host)))
+    dt_ = timed(probe, 1)
+    n_all = whole(min(len(q_host), max(probe, probe / dt_ * seconds * 2 / 9)))
+    t_all = timed(n_all, 3)
+    orc.set_threads(1)
+    p1 = whole(2048)
+    dt1 = timed(p1, 1)
+    n_one = whole(min(len(q_host), max(p1, p1 / dt1 * seconds / 6)))
+    t_one = timed(n_one, 2)
+    orc.set_threads(cores)
+    what = {"c2": "fused rollout", "c3": "fused rollout", "c4": "rollout + geometric Jacobian of ee_link",
+            "c5": "rollout (fp32 on the fp16-rounded q) + GP prior"}[wl.cfg]
+    return {"value": n_all / t_all, "unit": "rollouts/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+            "sample": f"first {n_all} of the {wl.B * H} samples of rank 0's batch, C oracle ({what}; fp32, OpenMP over samples, "
+                      f"{cores} threads), best of 3",
+            "one_core": {"value": n_one / t_one, "unit": "rollouts/s", "cores": 1,
+                         "sample": f"first {n_one} samples, same code on 1 thread, best of 2"}}
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -173,29 +360,20 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     ta = dict(device=dev, dtype=torch.float32)
-    robot, task, scene_text = make_task(tra, args.scene, ta)
-    W_C2, W_C3 = (0.0, 1.0, 0.0, 1.0), (1.0, 1.0, 1.0, 1.0)
-    weights = W_C2 if args.config == "c2" else W_C3
-    if args.weights:
-        weights = tuple(float(v) for v in args.weights.split(","))
-    B, H = args.batch, args.horizon
-    D, L = robot.q_dim, robot.diff_panda._kin.n_links
-    gen = torch.Generator(device=dev).manual_seed(1234 + (0 if args.same_q else rank))
-    q = robot.random_q(B * H, generator=gen).reshape(B, H, D).contiguous()
-    model, cm = task._fused_handles(dev)
-    plan = ops.RolloutPlan(model, cm, weights, q, want_pos=not args.no_pos)
+    wl = build_workload(args, tra, ops, torch, dev, rank)
+    B, H, D, L = wl.B, wl.H, wl.D, wl.L
+    plan, model = wl.plan, wl.model
     # the fused kernel leaves one partial cost sum per wavefront (= per trajectory at horizon 64); a rank folds them
     # into a scalar with the deterministic reduce kernel only when a collective needs it
     nb = ops.n_blocks(B * H)
     block_sums = torch.zeros(nb, **ta)
     bs_ptr = block_sums.data_ptr()
-    # The planner's cadence: one exchange per `reduce_every` evaluations, counted over the launches of a measurement (warm-up included),
-    # fired in the middle of its interval (the sums are consumed a few evaluations later).  The cadence does not shrink for short
-    # runs: a 20-step region of a 64-step cadence contains a collective with probability 20 / 64, here deterministically by the
-    # launch count -- `multi_gpu.collectives_in_timed_region` says how many it was, `multi_gpu.exchange_us` what one costs.
-    R = max(1, args.reduce_every)
-    n_slots = 8 * ((args.warmup + args.steps) // R + 2) + 16
+    # The planner's cadence: one exchange per `reduce_every` evaluations, fired in the middle of its interval (the sums are consumed
+    # a few evaluations later).  A run shorter than two intervals shrinks the interval to steps // 2, so that the driver's 20 timed
+    # steps contain two exchanges and `value` is never a kernel-only figure; `multi_gpu.collectives_in_timed_region` counts them.
+    R = max(1, min(args.reduce_every, max(1, args.steps // 2)))
     # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
+    n_slots = 64
     packed = torch.zeros((n_slots, 1 + H + H * D), **ta)
     stream = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev) if distributed else None
@@ -206,7 +384,7 @@ def main():
         """The sums of the latest evaluation of plan `pl` -> buf: one launch of trk_pack_sums on the launch stream."""
         pk = packers.get(id(pl))
         if pk is None:
-            pk = packers[id(pl)] = ops.PackedSums(pl, block_sums)
+            pk = packers[id(pl)] = ops.PackedSums(pl, block_sums, wl.traj_cost if pl is plan else None)
         pk.pack(buf, stream.cuda_stream)
 
     native = None
@@ -214,9 +392,15 @@ def main():
         from torch_robotics_amd.distributed import RcclAllReduce
         native = RcclAllReduce(dev)
 
+    slot_free = [None] * n_slots        # per exchange buffer: the side-stream event after which it may be packed again
+
     def reduce_slot(pl, k):
-        # sums of the latest evaluation -> one small all-reduce (2 kB), off the launch stream
+        # sums of the latest evaluation -> one small all-reduce, off the launch stream.  The buffers are a ring: before a slot is
+        # packed again the launch stream waits for the collective that last used it (a planner's bounded look-ahead) -- with one
+        # exchange per step (`multi_gpu.every_step`) that is what ties the launch rate to the exchange rate.
         buf = packed[k]
+        if slot_free[k] is not None:
+            stream.wait_event(slot_free[k])
         pack_sums(pl, buf)
         ev = torch.cuda.Event()
         ev.record(stream)
@@ -226,6 +410,12 @@ def main():
         else:
             with torch.cuda.stream(side):
                 dist.all_reduce(buf)
+        done = torch.cuda.Event()
+        done.record(side)
+        slot_free[k] = done
+
+    def step_of(pl):
+        return wl.step if pl is plan else pl.launch
 
     graph = None
     if args.graph > 0:
@@ -235,27 +425,27 @@ def main():
         gstream = torch.cuda.Stream(dev)
         with torch.cuda.stream(gstream):
             for i in range(3):
-                plan.launch(bs_ptr, gstream.cuda_stream)
+                wl.step(bs_ptr, gstream.cuda_stream)
         gstream.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=gstream):
             for i in range(G):
-                plan.launch(bs_ptr, torch.cuda.current_stream(dev).cuda_stream)
+                wl.step(bs_ptr, torch.cuda.current_stream(dev).cuda_stream)
 
     slot = [0]
-    launches = [0]          # launches of this process so far: the cadence counter
 
-    def run(pl, count, collectives):
+    def run(pl, count, cadence):
+        """`count` steps; cadence > 0: one exchange per `cadence` steps of this call, fired mid-interval"""
         if graph is not None:
             assert count % args.graph == 0
             for _ in range(count // args.graph):
                 graph.replay()
             return
         s = stream.cuda_stream
-        for j in range(count):
-            pl.launch(bs_ptr, s)
-            launches[0] += 1
-            if collectives and launches[0] % R == R // 2:
+        fn = step_of(pl)
+        for j in range(1, count + 1):
+            fn(bs_ptr, s)
+            if cadence and j % cadence == (cadence + 1) // 2 % cadence:
                 reduce_slot(pl, slot[0] % n_slots)
                 slot[0] += 1
 
@@ -271,11 +461,12 @@ def main():
 
     n_coll = [0]            # collectives inside the latest timed region
 
-    def measure(pl, collectives):
+    def measure(pl, cadence, steps=None, warmup=None):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize brackets; returns (wall s, event ms),
         the wall time already as the maximum over the ranks."""
-        launches[0] = 0             # the cadence is counted from the first warm-up step of THIS measurement
-        run(pl, args.warmup, collectives)
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
+        run(pl, warmup, cadence)
         if distributed:
             barrier_in_stream()
         torch.cuda.synchronize(dev)
@@ -283,11 +474,11 @@ def main():
         t0 = time.perf_counter()
         ev0.record(stream)
         slots_before = slot[0]
-        run(pl, args.steps, collectives)
+        run(pl, steps, cadence)
         n_coll[0] = slot[0] - slots_before
         ev1.record(stream)
         ev_side = None
-        if side is not None and collectives:
+        if side is not None and cadence:
             ev_side = torch.cuda.Event()
             ev_side.record(side)        # the collectives issued inside the region belong to it
         ta_ = time.perf_counter()
@@ -315,53 +506,71 @@ def main():
 
     # one rehearsal of the whole measurement (discarded): the first pass through the event / sync / launch code paths of a
     # fresh process costs ~10 us more, which matters when the driver asks for only 20 timed steps (~200 us of GPU work)
-    measure(plan, distributed)
-    elapsed, ev_ms = measure(plan, distributed)
+    cadence = R if distributed else 0
+    measure(plan, cadence)
+    elapsed, ev_ms = measure(plan, cadence)
     n_coll_value = n_coll[0]
 
     samples_per_step = B * H * world
     value = samples_per_step * args.steps / elapsed
-    n_grid_links = len(cm.spec.obj_link_idx) if (cm.spec.grid is not None and weights[1] != 0.0) else 0
-    bps = algorithmic_bytes_per_sample(D, L, n_grid_links)
+    bps = wl.bps
     bytes_per_launch = bps * B * H
-    launch_s = ev_ms * 1e-3 / args.steps
+    step_s = ev_ms * 1e-3 / args.steps
+    if wl.extras and graph is None:
+        # the step has more launches than the dominant kernel: time that kernel alone, same stream, same brackets
+        def only_rollout(n):
+            for _ in range(n):
+                plan.launch(bs_ptr, stream.cuda_stream)
+        only_rollout(max(3, min(args.warmup, 50)))
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream); only_rollout(args.steps); e1.record(stream)
+        torch.cuda.synchronize(dev)
+        launch_s = e0.elapsed_time(e1) * 1e-3 / args.steps
+        wl.step(bs_ptr, stream.cuda_stream)                     # leave the buffers as a whole step leaves them
+        torch.cuda.synchronize(dev)
+    else:
+        launch_s = step_s
     achieved = bytes_per_launch / launch_s / 1e9
 
     # sanity: the outputs of the last step are finite and the cost sums agree with the per-sample costs
-    assert torch.isfinite(plan.cost).all() and torch.isfinite(plan.gq).all()
+    assert torch.isfinite(plan.cost).all() and torch.isfinite(plan.gq.float()).all()
+    if plan.gq.dtype == torch.float16:          # nothing saturated either: the loss scale holds
+        assert float(plan.gq.float().abs().max()) < 65504.0 and float(wl.gqd.float().abs().max()) < 65504.0
     last = ops.reduce_sum(block_sums).item()
     ref = plan.cost.double().sum().item()
     assert abs(last - ref) <= 1e-4 * abs(ref) + 1e-3, (last, ref)
 
     # PMC figures of this workload recorded under profiles/ (separate rocprofv3 --pmc passes of this very command)
     kind = "specialized" if model.specialized else "table-driven"
-    pmc_key = f"{args.config}:{args.scene}:{B}x{H}:{kind}"
+    pmc_key = f"{args.config}:{args.scene}:{B}x{H}:{kind}" + (":smooth" if args.q == "smooth" else "")
     pmc, pmc_src = (None, None) if (args.weights or args.no_pos) else pmc_record(pmc_key)
-    if pmc is None and args.scene == "spheres" and not (args.weights or args.no_pos):
+    if pmc is None and args.scene == "spheres" and args.q == "iid" and not (args.weights or args.no_pos):
         pmc, pmc_src = pmc_record(f"{args.config}:{B}x{H}:{kind}")                  # round-2 key format
     traffic = pmc.get("traffic_bytes_per_launch") if pmc else None
     valu_per_wave = pmc.get("valu_insts_per_wave") if pmc else None
-    if valu_per_wave is None and pmc_src and args.scene == "spheres" and args.config == "c2":
-        valu_per_wave = 911.0                                                       # profiles/r02_pmc_sq_raw.txt
     valu_frac = None if valu_per_wave is None else valu_per_wave * nb / launch_s / VALU_PEAK_WAVE_INSTS_PER_S
 
-    objectives = {"c2": "SDF-obstacle + EE-tracking", "c3": "self-collision + SDF-obstacle + workspace box + EE-tracking"}
     out = {
-        "metric": "FK+cost+grad rollouts/sec (batch x horizon), Panda 7-DOF",
+        "metric": wl.metric,
         "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: Franka Panda (11 links, 7 DOF), batch={B} x horizon={H} per GPU, "
-                               f"fused FK + {objectives[args.config]} cost + gradient ({scene_text}), q resident in HBM",
+        "dtype": wl.dtype, "data": "synthetic",
+        "config": {"workload": wl.text,
                    "global_batch": B * world, "horizon": H, "parallelism": f"batch-sharded x{world}",
                    "scene": args.scene, "objectives": args.config,
                    "launch": "hipGraph x%d" % args.graph if graph is not None else "eager, pre-bound C-ABI call",
+                   "launches_per_step": 1 + len(wl.extras),
                    "kernel": kind,
-                   "reduce_every": R if distributed else None,
-                   **({"experiment_weights": list(weights)} if args.weights else {}),
+                   "reduce_every": args.reduce_every if distributed else None,
+                   "reduce_every_effective": R if distributed else None,
+                   **({"q": "smooth"} if args.q == "smooth" else {}),
+                   **({"grad_scale": wl.grad_scale} if args.config == "c5" else {}),
+                   **({"experiment_weights": list(wl.weights)} if args.weights else {}),
                    **({"experiment_no_pos": True} if args.no_pos else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src if traffic else None,
+                     "kernel": "fused rollout (trk_rollout_cost_grad%s)" % ("_f16" if wl.esz == 2 else ""),
                      "bytes_per_sample": bps, "launch_us": launch_s * 1e6,
                      # second bound: VALU instructions per wavefront (SQ_INSTS_VALU / SQ_WAVES of the same command)
                      # x wavefronts per launch / launch time, against one 64-lane instruction per 2 cycles per SIMD
@@ -372,15 +581,50 @@ def main():
                      # absorbed by it (61 - 62 % of the same peak at 400 - 600 MB per launch)
                      "working_set_MB": round(bytes_per_launch / 1e6, 1), "infinity_cache_MB": 256},
     }
+    if wl.extras:
+        out["roofline"]["step"] = {"bytes_per_sample": wl.bps_step, "step_us": step_s * 1e6,
+                                   "achieved": wl.bps_step * B * H / step_s / 1e9, "frac": wl.bps_step * B * H / step_s / 1e9 / HBM_PEAK_GBS,
+                                   "launches": ["fused rollout"] + [lbl for lbl, _, _ in wl.extras]}
+
+    if (rank == 0 and not distributed and graph is None and args.config == "c2" and not args.no_out_of_cache and wl.random_q is not None
+            and bytes_per_launch < 256e6):
+        # Secondary figure: the same kernel on a batch whose working set exceeds the 256 MB Infinity Cache (8 x the trajectories:
+        # 403 MB per launch at the default size), i.e. what the DRAM itself sustains for this read / write mix.
+        B_big = 8 * B
+        q_big = wl.random_q(B_big * H).reshape(B_big, H, D).contiguous()
+        big = wl.make_plan(q_big)
+        sums_big = torch.zeros(ops.n_blocks(B_big * H), **ta)
+        n_big = max(20, min(200, args.steps // 8))
+        for _ in range(10):
+            big.launch(sums_big.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(n_big):
+            big.launch(sums_big.data_ptr(), stream.cuda_stream)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        big_s = e0.elapsed_time(e1) * 1e-3 / n_big
+        out["roofline"]["frac_out_of_cache"] = bps * B_big * H / big_s / 1e9 / HBM_PEAK_GBS
+        out["roofline"]["out_of_cache"] = {"batch": B_big, "working_set_MB": round(bps * B_big * H / 1e6, 1), "launch_us": big_s * 1e6,
+                                           "steps": n_big}
+        del big, q_big, sums_big
 
     if distributed:
-        # (1) the same loop without the collectives; (2) configs[2]'s objective stack on the same shards, with collectives;
-        # (3) a check of the exchange itself: all-reduced packed sums == the sum of the ranks' local packed sums
-        ko_elapsed, _ = measure(plan, False)
-        plan3 = plan if weights == W_C3 else ops.RolloutPlan(model, cm, W_C3, q, want_pos=not args.no_pos)
-        if plan3 is not plan:
-            measure(plan3, True)
-        c3_elapsed, c3_ev = (elapsed, ev_ms) if plan3 is plan else measure(plan3, True)
+        # (1) the same loop without the collectives; (2) with one exchange per step; (3) c2 / c3: configs[2]'s objective stack on the
+        # same shards, with collectives; (4) a check of the exchange itself: all-reduced packed sums == the sum of the ranks' local ones
+        ko_elapsed, _ = measure(plan, 0)
+        es_elapsed, _ = measure(plan, 1)
+        n_coll_every = n_coll[0]
+        c3 = None
+        if wl.plan3 is not None:
+            if wl.plan3 is not plan:
+                measure(wl.plan3, R)
+            c3_elapsed, c3_ev = (elapsed, ev_ms) if wl.plan3 is plan else measure(wl.plan3, R)
+            c3 = {"value": samples_per_step * args.steps / c3_elapsed, "ms_per_step": c3_elapsed * 1e3 / args.steps,
+                  "launch_us": c3_ev * 1e3 / args.steps,
+                  "workload": "BASELINE configs[2] objective stack (self-collision + SDF-obstacle + workspace box + "
+                              f"EE) on the same shards: {B * world} x {H} over {world} GPUs, with the all-reduce"}
         # what ONE exchange costs end to end when nothing hides it: pack kernel + all-reduce, from enqueue to completion
         torch.cuda.synchronize(dev)
         t_x = time.perf_counter()
@@ -388,7 +632,7 @@ def main():
             reduce_slot(plan, (slot[0] + k) % n_slots)
             side.synchronize()
         exchange_us = (time.perf_counter() - t_x) / 10 * 1e6
-        plan.launch(bs_ptr, stream.cuda_stream)
+        wl.step(bs_ptr, stream.cuda_stream)
         local = torch.zeros(1 + H + H * D, **ta)
         pack_sums(plan, local)
         gathered = [torch.zeros_like(local) for _ in range(world)]
@@ -402,30 +646,28 @@ def main():
         expect = torch.stack(gathered).double().sum(0)
         err = float(((reduced.double() - expect).abs() / (expect.abs() + 1.0)).max().item())
         out["multi_gpu"] = {
-            "backend": dist.get_backend(), "ranks": dist.get_world_size(), "reduce_every": R,
+            "backend": dist.get_backend(), "ranks": dist.get_world_size(), "reduce_every": args.reduce_every, "reduce_every_effective": R,
             "exchange_via": "librccl ncclAllReduce (ctypes)" if native is not None else "torch.distributed.all_reduce",
             "collectives_in_timed_region": n_coll_value, "exchange_us": exchange_us,
             "allreduce_floats": int(local.numel()),
             "with_allreduce": {"value": value, "ms_per_step": elapsed * 1e3 / args.steps},
             "kernel_only": {"value": samples_per_step * args.steps / ko_elapsed, "ms_per_step": ko_elapsed * 1e3 / args.steps},
-            "full_stack_c3": {"value": samples_per_step * args.steps / c3_elapsed, "ms_per_step": c3_elapsed * 1e3 / args.steps,
-                              "launch_us": c3_ev * 1e3 / args.steps,
-                              "workload": "BASELINE configs[2] objective stack (self-collision + SDF-obstacle + workspace box + "
-                                          f"EE) on the same shards: {B * world} x {H} over {world} GPUs, with the all-reduce"},
+            "every_step": {"value": samples_per_step * args.steps / es_elapsed, "ms_per_step": es_elapsed * 1e3 / args.steps,
+                           "collectives_in_timed_region": n_coll_every},
+            **({"full_stack_c3": c3} if c3 else {}),
             "allreduce_check": {"ok": bool(err < 1e-5), "max_rel_err": err,
                                 "sum_cost_all_ranks": float(reduced[0].item()), "sum_cost_rank0": float(gathered[0][0].item())},
         }
         assert err < 1e-5, f"all-reduced sums differ from the sum of the ranks' sums: {err}"
 
-    if rank == 0 and not distributed and graph is None and args.independent_streams > 1:
+    if rank == 0 and not distributed and graph is None and args.independent_streams > 1 and wl.random_q is not None:
         # Secondary figure (never `value`): INDEPENDENT batches alternated over three HIP streams.  With one stream a launch waits
         # for the previous one's ~2 us write tail; with three, the next launch's dispatch, kernarg / q fetch and FK overlap it.
         # A planner's iterations depend on each other, so the headline keeps one stream; a server evaluating unrelated batches
         # gets this rate.  Kernels overlap here, so this is a throughput, not a kernel duration.
         ns = args.independent_streams
         streams3 = [torch.cuda.Stream(dev) for _ in range(ns)]
-        plans3 = [plan] + [ops.RolloutPlan(model, cm, weights, robot.random_q(B * H, generator=gen).reshape(B, H, D).contiguous(),
-                                           want_pos=not args.no_pos) for _ in range(ns - 1)]
+        plans3 = [plan] + [wl.make_plan(wl.random_q(B * H).reshape(B, H, D).contiguous()) for _ in range(ns - 1)]
         sums3 = [block_sums] + [torch.zeros(nb, **ta) for _ in range(ns - 1)]
         n3 = max(2000, args.steps)
 
@@ -444,35 +686,7 @@ def main():
                                               "the headline value above is one stream, launch after launch"}
 
     if rank == 0 and not distributed and args.cpu_seconds > 0:       # CPU baseline: rank 0 at N = 1 only
-        from oracle import oracle as orc          # checker / baseline only: never on the product path
-        spec = task.build_cost_spec()
-        if spec.grid is not None:                 # the oracle reads host arrays
-            spec.grid = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in spec.grid.items()}
-        o = orc.Oracle(robot.diff_panda._kin, spec)
-        q_host = q.reshape(-1, D).cpu().numpy()
-        cores = orc.max_threads()
-
-        def timed(n, reps):
-            best = 1e30
-            for _ in range(reps):
-                t = time.perf_counter(); o.rollout(q_host[:n], weights, "f32"); best = min(best, time.perf_counter() - t)
-            return best
-        # all threads: ~2/3 of the budget; one thread: ~1/3 (both bounded samples of rank 0's batch)
-        probe = min(16384, len(q_host))
-        dt = timed(probe, 1)
-        n_all = int(min(len(q_host), max(probe, probe / dt * args.cpu_seconds * 2 / 9)))
-        t_all = timed(n_all, 3)
-        orc.set_threads(1)
-        dt1 = timed(2048, 1)
-        n_one = int(min(len(q_host), max(2048, 2048 / dt1 * args.cpu_seconds / 6)))
-        t_one = timed(n_one, 2)
-        orc.set_threads(cores)
-        out["cpu_baseline"] = {"value": n_all / t_all, "unit": "rollouts/s", "cores": cores, "kind": "port",
-                               "cpu_model": cpu_model_name(),
-                               "sample": f"first {n_all} of the {B * H} samples of rank 0's batch, C oracle (fp32, OpenMP "
-                                         f"over samples, {cores} threads), best of 3",
-                               "one_core": {"value": n_one / t_one, "unit": "rollouts/s", "cores": 1,
-                                            "sample": f"first {n_one} samples, same code on 1 thread, best of 2"}}
+        out["cpu_baseline"] = cpu_baseline(wl, args, torch, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TRK_ABI_VERSION 3
+#define TRK_ABI_VERSION 4
 #define TRK_MAX_LINKS 64
 #define TRK_MAX_DOFS 32
 #define TRK_MAX_POSE_SLOTS 8
@@ -425,13 +425,22 @@ int trk_rollout_collision(const TrkModel* model, const TrkCostModel* cm, int32_t
                           int32_t horizon, float margin_override, uint8_t* in_collision, float* link_pos_ws,
                           trk_stream_t stream);
 
-/* trk_rollout_cost_grad with q, link_pos_out and gq stored as IEEE fp16 in HBM -- BASELINE config 5's "fp16 with fp32
+/* element types of the reduced-precision entry points */
+#define TRK_F32 0
+#define TRK_F16 1
+
+/* trk_rollout_cost_grad with q and link_pos_out stored as IEEE fp16 in HBM -- BASELINE config 5's "fp16 with fp32
  * cost accumulate": arithmetic, `cost` and `cost_block_sums` stay fp32; inputs are widened and outputs rounded once
  * (round-to-nearest-even) at the memory boundary.  Build-defined (the reference has no reduced-precision path); the
- * check is the fp64 oracle on the same fp16-rounded q. */
+ * check is the fp64 oracle on the same fp16-rounded q.
+ * The gradient: gq [B,H,D] of grad_dtype (TRK_F16, or TRK_F32 = the mixed mode: fp16 trajectories and positions, fp32
+ * gradient) receives grad_scale * d cost / d q, the product formed in fp32; an fp16 store SATURATES at +-65504 -- it never
+ * writes inf.  grad_scale (> 0, a power of two keeps the mantissa) is the caller's loss scale: the GP prior this gradient
+ * is summed with (trk_gp_prior_cost_grad, same scale) reaches 1e5 .. 1e6 at config 5's sigma_gp = 0.1, dt = 5/128
+ * (env_spheres_3d.py:57), beyond the fp16 range; the consumer divides by the scale (or folds it into its step size). */
 int trk_rollout_cost_grad_f16(const TrkModel* model, const TrkCostModel* cm, const TrkRolloutWeights* w,
                               const void* q_f16, int64_t batch, int32_t horizon, void* link_pos_out_f16, float* cost,
-                              void* gq_f16, float* cost_block_sums, trk_stream_t stream);
+                              void* gq, int32_t grad_dtype, float grad_scale, float* cost_block_sums, trk_stream_t stream);
 
 /* trk_rollout_cost_grad with the collision fields evaluated on attached points instead of link origins: the cost
  * model's position columns (n_links_in, obj_link_idx, self_link_idx) index the points of `ps`; ee_link stays a LINK
@@ -494,13 +503,15 @@ int trk_interpolate_columns_backward(const float* gout, int64_t n, int32_t n_in,
  * planners, env_spheres_3d.py:51-76).  The standard GPMP form is used:  per DOF x_t = (q_t, qd_t),
  * e_t = Phi(dt) x_t - x_{t+1},  Q^-1 = sigma^-2 [[12/dt^3, -6/dt^2], [-6/dt^2, 4/dt]],
  * cost[b] = weight * 1/2 sum_t sum_dof e_t^T Q^-1 e_t   and   gq, gqd = d cost / d q, d cost / d qd.
- * q, qd, gq, gqd: [batch, horizon, dof] of `io_dtype` (TRK_F32 / TRK_F16; arithmetic and `cost` are fp32);
- * accumulate != 0 adds into gq / gqd instead of overwriting (to compose with trk_rollout_cost_grad's gradient). */
-#define TRK_F32 0
-#define TRK_F16 1
+ * q, qd: [batch, horizon, dof] of `io_dtype` (TRK_F32 / TRK_F16; arithmetic and `cost` are fp32); gq, gqd: the same shape
+ * of `grad_dtype` (TRK_F32, or TRK_F16 with fp16 trajectories) and receive grad_scale * the gradient (product in fp32; an
+ * fp16 store saturates at +-65504, see trk_rollout_cost_grad_f16; `cost` is not scaled).  accumulate != 0 adds into
+ * gq / gqd instead of overwriting -- to compose with trk_rollout_cost_grad(_f16)'s gradient, written with the same scale.
+ * fp16-stored q puts a quantisation floor under this term: ulp(q)^2 / 12 * 12 / (sigma^2 dt^3) per
+ * residual -- ~1.6 per time step and joint at sigma = 0.1, dt = 5/128, |q| in [1, 2). */
 int trk_gp_prior_cost_grad(const void* q, const void* qd, int64_t batch, int32_t horizon, int32_t dof, int32_t io_dtype,
-                           float dt, float sigma, float weight, float* cost, void* gq, void* gqd, int32_t accumulate,
-                           trk_stream_t stream);
+                           float dt, float sigma, float weight, float* cost, void* gq, void* gqd, int32_t grad_dtype,
+                           float grad_scale, int32_t accumulate, trk_stream_t stream);
 
 /* reference: finite_difference_vector trajectory/utils.py:53-64 (RobotBase.get_velocity / get_acceleration
  * robot_base.py:151-166): zero-padded differences along the horizon.  x, out [batch, horizon, dim];
@@ -540,11 +551,15 @@ int trk_debug_set_stamp_buffer(void* device_u64);
  *   [ sum of all costs | sum over trajectories of cost(b, h) | sum over trajectories of gq(b, h, d) ]
  * of ONE rank's evaluation -- cost [batch, horizon], gq [batch, horizon, dof] and cost_block_sums as written by
  * trk_rollout_cost_grad -- in one launch, bit-reproducibly (fixed association order; packed[0] equals trk_reduce_sum of the block
- * sums).  scratch: DEVICE memory of trk_pack_sums_scratch_bytes(horizon, dof) bytes, zero-initialised ONCE by the caller (its last
+ * sums).  gq is of grad_dtype (TRK_F32, or TRK_F16: the gradient of trk_rollout_cost_grad_f16) and holds grad_scale x the
+ * gradient; the fp32 column sums are divided by grad_scale once, so `packed` is always unscaled fp32.  traj_cost (nullable)
+ * [batch]: a per-trajectory cost (trk_gp_prior_cost_grad's) whose sum is added to packed[0].
+ * scratch: DEVICE memory of trk_pack_sums_scratch_bytes(horizon, dof) bytes, zero-initialised ONCE by the caller (its last
  * word is a ticket the kernel returns to zero); one scratch per stream that may run the call concurrently. */
 int64_t trk_pack_sums_scratch_bytes(int32_t horizon, int32_t dof);
-int trk_pack_sums(const float* cost, const float* gq, const float* cost_block_sums, int64_t batch, int32_t horizon, int32_t dof,
-                  float* scratch, float* packed, trk_stream_t stream);
+int trk_pack_sums(const float* cost, const void* gq, int32_t grad_dtype, float grad_scale, const float* cost_block_sums,
+                  const float* traj_cost, int64_t batch, int32_t horizon, int32_t dof, float* scratch, float* packed,
+                  trk_stream_t stream);
 
 /* Deterministic sum of n floats (fixed association order, one workgroup): x [n] -> out [1]. */
 int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream);

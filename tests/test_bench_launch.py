@@ -60,10 +60,50 @@ def test_two_rank_bench_on_one_gpu_gloo():
     assert chk["ok"] and chk["max_rel_err"] < 1e-5
     # --same-q: both ranks evaluate the same trajectories, so the all-reduced cost sum is exactly twice rank 0's
     assert chk["sum_cost_all_ranks"] == pytest.approx(2.0 * chk["sum_cost_rank0"], rel=1e-6)
-    for k in ("with_allreduce", "kernel_only", "full_stack_c3"):
+    for k in ("with_allreduce", "kernel_only", "every_step", "full_stack_c3"):
         assert mg[k]["value"] > 0 and mg[k]["ms_per_step"] > 0
+    assert mg["every_step"]["collectives_in_timed_region"] == 20 and mg["reduce_every_effective"] == 8
     assert out["value"] == mg["with_allreduce"]["value"]
     assert out["cpu_baseline"] is None and out["roofline"]["bytes_per_sample"] == 192
+
+
+@pytest.mark.gpu
+def test_two_rank_config5_on_one_gpu_gloo():
+    """configs[4] as a driver-runnable workload, N-rank: dual Panda, fp16 I/O with the loss scale, GP prior; the exchange packs the
+    fp16 gradient (unscaled, fp32) and the GP cost.  Two ranks share cuda:0 over gloo; the driver's 5 + 20 steps at the DEFAULT cadence
+    still contain exchanges."""
+    p = _run(["--config", "c5", "--gpus", "2", "--dist-backend", "gloo", "--single-device", "--same-q", "--steps", "20", "--warmup", "5",
+              "--batch", "256", "--cpu-seconds", "0"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["dtype"] == "f16" and out["config"]["objectives"] == "c5" and out["config"]["horizon"] == 128
+    assert out["config"]["global_batch"] == 512 and out["config"]["launches_per_step"] == 2 and out["config"]["kernel"] == "specialized"
+    assert 0 < out["config"]["grad_scale"] < 1
+    assert out["roofline"]["bytes_per_sample"] == 2 * 14 + 6 * 23 + 4 + 2 * 14 and out["roofline"]["step"]["bytes_per_sample"] == 198 + 140
+    mg = out["multi_gpu"]
+    assert mg["reduce_every"] == 64 and mg["reduce_every_effective"] == 10 and mg["collectives_in_timed_region"] == 2
+    assert mg["allreduce_floats"] == 1 + 128 + 128 * 14 and "full_stack_c3" not in mg
+    chk = mg["allreduce_check"]
+    assert chk["ok"] and chk["sum_cost_all_ranks"] == pytest.approx(2.0 * chk["sum_cost_rank0"], rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,dtype,launches", [("c4", "f32", 2), ("c5", "f16", 2)])
+def test_bench_configs_4_and_5_one_gpu(cfg, dtype, launches):
+    """`bench.py --config c4|c5` on one GPU: a driver-parsable line with the config's own bytes, the dominant kernel's roofline,
+    the step's, and a CPU baseline from the oracle (incl. the Jacobian / the GP term)."""
+    p = _run(["--config", cfg, "--steps", "20", "--warmup", "5", "--cpu-seconds", "1.5", "--batch", "512"], 900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["dtype"] == dtype and out["config"]["launches_per_step"] == launches and out["config"]["kernel"] == "specialized"
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["unit"] == "rollouts/s" and out["vs_baseline"] is None
+    D, L, e = (22, 30, 4) if cfg == "c4" else (14, 23, 2)
+    assert out["roofline"]["bytes_per_sample"] == 2 * e * D + 3 * e * L + 4
+    assert 0 < out["roofline"]["frac"] < 1 and 0 < out["roofline"]["step"]["frac"] < 1
+    assert out["roofline"]["step"]["step_us"] >= out["roofline"]["launch_us"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["one_core"]["value"] > 0
+    assert ("Jacobian" in cb["sample"]) == (cfg == "c4") and ("GP prior" in cb["sample"]) == (cfg == "c5")
 
 
 @pytest.mark.gpu
@@ -87,11 +127,13 @@ def test_rccl_code_path_on_one_rank():
     assert out["n_gpus"] == 1 and mg["backend"] == "nccl" and mg["ranks"] == 1
     assert mg["collectives_in_timed_region"] == 5 and mg["allreduce_check"]["ok"] and mg["exchange_us"] > 0
     assert mg["allreduce_check"]["sum_cost_all_ranks"] == pytest.approx(mg["allreduce_check"]["sum_cost_rank0"], rel=1e-6)
-    # the default cadence (64) leaves a 20-step region without a collective: value == the kernel-only rate up to noise
+    # the driver's settings (20 steps after 5) at the default cadence (64): the interval shrinks to steps // 2, the region contains
+    # two exchanges -- `value` is never a kernel-only figure
     p = _run(["--force-dist", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0"], 600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["multi_gpu"]["collectives_in_timed_region"] == 0 and out["config"]["reduce_every"] == 64
+    assert out["multi_gpu"]["collectives_in_timed_region"] == 2 and out["config"]["reduce_every"] == 64
+    assert out["config"]["reduce_every_effective"] == 10 and out["multi_gpu"]["every_step"]["collectives_in_timed_region"] == 20
 
 
 @pytest.mark.gpu

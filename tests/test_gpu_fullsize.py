@@ -225,23 +225,48 @@ def test_dual_panda_fp16_gp_full_size(ops, oracle_lib):
     assert rel_err(cost.cpu().numpy(), c32.cpu().numpy()) < 2e-6
     assert (pos.float() - p32).abs().max().item() <= 2.0 ** -11 * max(1.0, p32.abs().max().item()) * 1.01
     assert rel_err(gq.float().cpu().numpy(), g32.cpu().numpy()) < 2.0 ** -10
-    # GP prior accumulated into the rollout's gradient == sum of the two gradients
-    gqd = torch.zeros_like(gq)
-    acc = gq.clone()
-    c_gp, _, _ = ops.gp_prior_cost_grad(qh, qdh, 5.0 / H, 0.1, 1.0, accumulate_into=(acc, gqd))
-    c_gp2, g_gp, _ = ops.gp_prior_cost_grad(qh, qdh, 5.0 / H, 0.1, 1.0)
-    assert torch.equal(c_gp, c_gp2) and c_gp.shape == (B,)
-    acc2, gqd2 = gq.clone(), torch.zeros_like(gq)                       # the pre-bound launch gives the same bits
-    gp_plan = ops.GPPriorPlan(qh, qdh, 5.0 / H, 0.1, 1.0, accumulate_into=(acc2, gqd2))
+    # The objective of config 5 at its own parameters: sigma_gp = 0.1 (env_spheres_3d.py:57), dt = 5 / 128.  a = 12 / (sigma^2 dt^3)
+    # = 2e7: the GP gradient reaches 1e5 .. 1e6, beyond the fp16 range -- both kernels write grad_scale x gradient (the loss scale
+    # from the trajectories' bounds), and EVERY element of the sum is finite (no mask).
+    dt, sg = 5.0 / H, 0.1
+    gs = ops.gp_grad_scale(dt, sg, 1.0, float(qh.abs().max()), float(qdh.abs().max()), extra=float(g32.abs().max()))
+    _, _, gq_s = ops.rollout_cost_grad(h, cm, w, qh, want_pos=False, grad_scale=gs)
+    gqd = torch.zeros_like(gq_s)
+    acc = gq_s.clone()
+    c_gp, _, _ = ops.gp_prior_cost_grad(qh, qdh, dt, sg, 1.0, accumulate_into=(acc, gqd), grad_scale=gs)
+    c_gp2, g_gp, gd_gp = ops.gp_prior_cost_grad(qh, qdh, dt, sg, 1.0, grad_scale=gs)
+    assert torch.equal(c_gp, c_gp2) and c_gp.shape == (B,) and torch.equal(gd_gp, gqd)
+    acc2, gqd2 = gq_s.clone(), torch.zeros_like(gq_s)                   # the pre-bound launch gives the same bits
+    gp_plan = ops.GPPriorPlan(qh, qdh, dt, sg, 1.0, accumulate_into=(acc2, gqd2), grad_scale=gs)
     gp_plan.launch()
     assert torch.equal(gp_plan.cost, c_gp) and torch.equal(acc2, acc) and torch.equal(gqd2, gqd)
-    ok = torch.isfinite(g_gp.float()) & torch.isfinite(acc.float())
-    ref = gq.float() + g_gp.float()
-    assert ((acc.float() - ref)[ok].abs() <= 2.0 ** -9 * ref[ok].abs() + 1e-3).all()
+    for t_ in (gq_s, acc, gqd, g_gp):
+        assert torch.isfinite(t_.float()).all()                          # 100 % finite
+    assert float(acc.float().abs().max()) < 65504.0 and float(gqd.float().abs().max()) < 65504.0      # and nothing saturated
+    ref = gq_s.float() + g_gp.float()
+    assert ((acc.float() - ref).abs() <= 2.0 ** -10 * ref.abs() + 2.0 ** -24).all()      # fp16(a + b) of two fp16 numbers: one rounding
+    # fp64 oracle on 8 whole trajectories (1024 samples; the oracle sees the same fp16-rounded q, qd): GP cost, and the UNSCALED
+    # total gradient to one fp16 rounding of each stored term
+    tsel = np.random.default_rng(8).choice(B, 8, replace=False)
+    q8, qd8 = qh[tsel].cpu().numpy().astype(np.float64), qdh[tsel].cpu().numpy().astype(np.float64)
+    rc_gp, rg_gp, rgd_gp = oracle_lib.gp_prior(q8, qd8, dt, sg, 1.0, "f64")
+    o8 = oracle_lib.Oracle(kin, spec)
+    _, _, rg_ro = o8.rollout(q8.reshape(-1, D), w, "f64")
+    assert rel_err(c_gp[tsel].cpu().numpy(), rc_gp) < 2e-5
+    tot = rg_gp + rg_ro.reshape(8, H, D)
+    got = acc[tsel].double().cpu().numpy() / gs
+    assert (np.abs(got - tot) <= 2.0 ** -9 * (np.abs(rg_gp) + np.abs(rg_ro.reshape(8, H, D))) + 2.0 ** -22 / gs + 4e-5 * np.abs(rg_gp).max()).all()
+    gotd = gqd[tsel].double().cpu().numpy() / gs
+    assert (np.abs(gotd - rgd_gp) <= 2.0 ** -10 * np.abs(rgd_gp) + 2.0 ** -24 / gs + 2e-5 * np.abs(rgd_gp).max()).all()
+    # the mixed mode (fp16 trajectories and positions, fp32 gradients, no scale): fp32 accuracy on the same subset
+    _, _, gq_m = ops.rollout_cost_grad(h, cm, w, qh, want_pos=False, grad_dtype=torch.float32)
+    gqd_m = torch.zeros_like(gq_m)
+    ops.gp_prior_cost_grad(qh, qdh, dt, sg, 1.0, accumulate_into=(gq_m, gqd_m))
+    assert gq_m.dtype == torch.float32 and rel_err(gq_m[tsel].cpu().numpy(), tot) < 1e-4 and rel_err(gqd_m[tsel].cpu().numpy(), rgd_gp) < 1e-4
     # sharding invariance of both kernels (whole trajectories stay on one rank)
     _, c_s, g_s = ops.rollout_cost_grad(h, cm, w, qh[B // 2:].contiguous(), want_pos=False)
     assert torch.equal(c_s, cost[B // 2:]) and torch.equal(g_s, gq[B // 2:])
-    assert torch.equal(ops.gp_prior_cost_grad(qh[:7].contiguous(), qdh[:7].contiguous(), 5.0 / H, 0.1, 1.0)[0], c_gp[:7])
+    assert torch.equal(ops.gp_prior_cost_grad(qh[:7].contiguous(), qdh[:7].contiguous(), dt, sg, 1.0, grad_scale=gs)[0], c_gp[:7])
     # oracle subset (the oracle sees the same fp16-rounded q)
     o = oracle_lib.Oracle(kin, spec)
     idx = np.random.default_rng(6).choice(B * H, 512, replace=False)

@@ -698,7 +698,7 @@ def test_gp_prior_vs_fp64_oracle(ops, oracle_lib):
     """Constant-velocity GP prior (build-defined, BASELINE config 5): fp32 and fp16 I/O against the fp64 oracle."""
     rng = np.random.default_rng(22)
     for (B, H, D, dt, sigma, w) in ((5, 64, 7, 0.08, 0.1, 1.0), (3, 128, 14, 5.0 / 128, 0.5, 0.3), (2, 1, 5, 0.1, 0.2, 1.0),
-                                    (300, 37, 22, 0.05, 0.3, 1.0)):
+                                    (300, 37, 22, 0.05, 0.3, 1.0), (6, 128, 14, 5.0 / 128, 0.1, 1.0)):
         q = np.cumsum(rng.standard_normal((B, H, D)) * 0.05, axis=1).astype(np.float32)
         qd = (rng.standard_normal((B, H, D)) * 0.3).astype(np.float32)
         rc, rgq, rgqd = oracle_lib.gp_prior(q.astype(np.float64), qd.astype(np.float64), dt, sigma, w, "f64")
@@ -714,16 +714,42 @@ def test_gp_prior_vs_fp64_oracle(ops, oracle_lib):
         a0, a1 = g0.clone(), g1.clone()
         ops.gp_prior_cost_grad(dev(q), dev(qd), dt, sigma, w, accumulate_into=(a0, a1))
         np.testing.assert_allclose((a0 - g0).cpu().numpy(), gq.cpu().numpy(), rtol=0, atol=1e-4 * max(1.0, float(gq.abs().max())))
-        # fp16 I/O: the oracle sees the same fp16-rounded inputs; outputs are rounded to fp16 once
+        # fp16 I/O: the oracle sees the same fp16-rounded inputs.  The gradient leaves as grad_scale x d cost (product in fp32),
+        # rounded to fp16 once; the scale from the bounds of the trajectories keeps EVERY element finite (config 5's own
+        # parameters sigma = 0.1, dt = 5 / 128 are among the cases: a = 12 / (sigma^2 dt^3) = 2e7)
         qh, qdh = dev(q).half(), dev(qd).half()
         rc, rgq, rgqd = oracle_lib.gp_prior(qh.cpu().numpy().astype(np.float64), qdh.cpu().numpy().astype(np.float64), dt, sigma, w, "f64")
-        c, gq, gqd = ops.gp_prior_cost_grad(qh, qdh, dt, sigma, w)
-        assert gq.dtype == torch.float16 and c.dtype == torch.float32
+        gs = ops.gp_grad_scale(dt, sigma, w, float(qh.abs().max()), float(qdh.abs().max()))
+        assert gs <= 1.0 and np.log2(gs) == np.round(np.log2(gs))
+        c, gq, gqd = ops.gp_prior_cost_grad(qh, qdh, dt, sigma, w, grad_scale=gs)
+        assert gq.dtype == torch.float16 and gqd.dtype == torch.float16 and c.dtype == torch.float32
+        c32, gq32, gqd32 = ops.gp_prior_cost_grad(qh, qdh, dt, sigma, w, grad_dtype=torch.float32)      # mixed mode, unscaled
+        assert gq32.dtype == torch.float32 and torch.equal(c32, c)
         if H > 1:
             assert rel_err(c.cpu().numpy(), rc) < 2e-5
-            ok = np.isfinite(rgq.astype(np.float16)).all()
-            if ok:
-                assert rel_err(gq.float().cpu().numpy(), rgq) < 1e-3 and rel_err(gqd.float().cpu().numpy(), rgqd) < 1e-3
+            assert torch.isfinite(gq.float()).all() and torch.isfinite(gqd.float()).all()          # 100 % finite, no mask
+            assert np.abs(rgq).max() * gs < 65504 and np.abs(rgqd).max() * gs < 65504
+            for got, ref in ((gq, rgq), (gqd, rgqd)):
+                # one fp16 rounding of the scaled value (2^-11 relative; 2^-25 absolute in the subnormal range) + fp32 arithmetic
+                err = np.abs(got.float().cpu().numpy().astype(np.float64) / gs - ref)
+                assert (err <= 2.0 ** -10 * np.abs(ref) + 2.0 ** -24 / gs + 2e-5 * np.abs(ref).max()).all()
+            assert rel_err(gq32.cpu().numpy(), rgq) < 1e-4 and rel_err(gqd32.cpu().numpy(), rgqd) < 1e-4
+            # accumulate into a scaled fp16 gradient: one more fp16 rounding
+            base16 = (torch.randn(B, H, D, device=DEV) * 3.0 * gs).half()
+            a0, a1 = base16.clone(), torch.zeros_like(base16)
+            ops.gp_prior_cost_grad(qh, qdh, dt, sigma, w, accumulate_into=(a0, a1), grad_scale=gs)
+            ref = base16.double().cpu().numpy() / gs + rgq
+            err = np.abs(a0.double().cpu().numpy() / gs - ref)
+            assert torch.isfinite(a0.float()).all() and (err <= 2.0 ** -9 * (np.abs(ref) + np.abs(rgq)) + 2.0 ** -23 / gs + 4e-5 * np.abs(rgq).max()).all()
+            # no scale: whatever exceeds the fp16 range SATURATES at +-65504 (never inf), everything else is the rounded value
+            _, gsat, gdsat = ops.gp_prior_cost_grad(qh, qdh, dt, sigma, w)
+            for got, ref in ((gsat, rgq), (gdsat, rgqd)):
+                g = got.float().cpu().numpy().astype(np.float64)
+                assert np.isfinite(g).all()
+                big = np.abs(ref) > 65504.0 * (1 + 1e-4)
+                assert (g[big] == np.sign(ref[big]) * 65504.0).all()
+                small = np.abs(ref) < 65504.0 * (1 - 1e-3)
+                assert (np.abs(g[small] - ref[small]) <= 2.0 ** -10 * np.abs(ref[small]) + 2.0 ** -24 + 2e-5 * np.abs(ref).max()).all()
     # autograd wrapper
     q = dev(rng.standard_normal((4, 16, 7)).astype(np.float32)).requires_grad_(True)
     qd = dev(rng.standard_normal((4, 16, 7)).astype(np.float32)).requires_grad_(True)
@@ -778,7 +804,24 @@ def test_rollout_fp16_io(ops, oracle_lib, robot, ident):
             assert rel_err(cost.cpu().numpy().reshape(-1), rc) < TOL_C
             assert rel_err(gq.float().cpu().numpy().reshape(rg.shape), rg) < 1e-3
             assert abs(float(sums.sum()) - rc.sum()) < 1e-4 * max(1.0, abs(rc.sum()))
+            # the loss scale and the mixed mode (fp16 trajectories / positions, fp32 gradient): gq = grad_scale * d cost / d q, the
+            # product formed in fp32 -- a power-of-two scale changes nothing but the exponent; a scale that pushes the gradient
+            # out of range saturates at +-65504, never inf
+            _, c2, g2 = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q, want_pos=False, grad_scale=2.0 ** -6)
+            assert torch.equal(c2, cost) and g2.dtype == torch.float16
+            assert rel_err(g2.float().cpu().numpy().reshape(rg.shape) * 64.0, rg) < 1e-3
+            p3, c3, g3 = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q, grad_dtype=torch.float32, grad_scale=0.25)
+            assert g3.dtype == torch.float32 and p3.dtype == torch.float16 and torch.equal(c3, cost) and torch.equal(p3, pos)
+            assert grad_close(g3.cpu().numpy().reshape(rg.shape) * 4.0, rg)
+            _, _, g4 = ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q, want_pos=False, grad_scale=2.0 ** 20)
+            g4 = g4.float().cpu().numpy().reshape(rg.shape)
+            big = np.abs(rg) * 2.0 ** 20 > 65504.0 * 1.01
+            assert np.isfinite(g4).all() and big.any() and (g4[big] == np.sign(rg[big]) * 65504.0).all()
         h.enable_specialized(True)
+    with pytest.raises(ValueError):
+        ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q.float(), grad_scale=0.5)          # fp32 trajectories take no scale
+    with pytest.raises(ValueError):
+        ops.rollout_cost_grad(h, cm, (1, 1, 1, 1), q, grad_scale=0.0)
     # pre-bound plan in fp16
     q = dev(rng.uniform(-2, 2, size=(4, 64, kin.n_dofs)).astype(np.float32)).half()
     plan = ops.RolloutPlan(h, cm, (0, 1, 0, 1), q)

@@ -106,15 +106,15 @@ def lib():
     L.trk_reduce_sum.argtypes = [vp, i64, vp, vp]
     L.trk_grid_precompute.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.trk_sdf_points.argtypes = [vp, vp, i64, vp, vp, vp]
-    L.trk_rollout_cost_grad_f16.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, vp, vp, vp, vp, vp]
+    L.trk_rollout_cost_grad_f16.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, vp, vp, vp, i32, f32, vp, vp]
     L.trk_finite_difference.argtypes = [vp, i64, i32, i32, f32, i32, vp, vp]
     L.trk_traj_diff_norm_sum.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp]
-    L.trk_gp_prior_cost_grad.argtypes = [vp, vp, i64, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, vp]
+    L.trk_gp_prior_cost_grad.argtypes = [vp, vp, i64, i32, i32, i32, f32, f32, f32, vp, vp, vp, i32, f32, i32, vp]
     L.trk_interpolate_columns.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
     L.trk_interpolate_columns_backward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
     L.trk_rollout_collision_via.argtypes = [vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, f32, vp, vp]
     L.trk_traj_validate.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp, vp]
-    L.trk_pack_sums.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
+    L.trk_pack_sums.argtypes = [vp, vp, i32, f32, vp, vp, i64, i32, i32, vp, vp, vp]
     L.trk_pack_sums_scratch_bytes.argtypes = [i32, i32]
     L.trk_pack_sums_scratch_bytes.restype = C.c_int64
     L.trk_jtj.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i32, vp, vp]

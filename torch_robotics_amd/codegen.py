@@ -409,7 +409,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # ring staging: the pieces of the whole chunks leave between the links that follow them; the tail chunk's pieces are what
         # the objectives' tick slots issue (flush.chunk<CH>() -> RingTail)
         rp = ring_plan(3 * L)
-        ring_t = f"RingFlusher<{rp.W}, {rp.V}, {'true' if rp.aligned else 'false'}, IO>"
+        ring_t = f"RingFlusher<{rp.W}, {rp.V}, {'true' if rp.aligned else 'false'}, IOQ>"
         out.append("template <class R> struct RingTail {      // tick slot CH of the objectives -> store piece CH of the tail chunk")
         out.append("    const R& r;")
         out.append("    template <int CH> __device__ __forceinline__ void chunk() const { r.template piece<R::NFULL, CH>(); }")
@@ -524,6 +524,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         else:
             lds_lane = max(3 * L, D)
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_lane} + SPEC_WAVES * (TRK_LDS_SPHERES * 4 + (BOX ? TRK_LDS_PRIMS * 8 : 0))];")
+        E.raw("    typedef typename IoTraits<IO>::Q IOQ;      // q, link_pos in HBM")
+        E.raw("    typedef typename IoTraits<IO>::G IOG;      // gq in HBM (fp16 q: scaled by A.grad_scale, fp16 stores saturate)")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);   // wave-uniform -> SGPR")
         E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_lane});")
@@ -538,7 +540,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    spec_stamp(A.stamps, wblock, 0, lane);")
         E.raw("    spec_stamp_real(A.stamps, wblock, 2, lane);      // 100 MHz chip-wide clock: aligns the per-CU s_memtime domains")
         E.raw("    float q[D];")
-        E.raw("    spec_load_q<D>(static_cast<const IO*>(A.q), base, rows, lane, lds, q);")
+        E.raw("    spec_load_q<D>(static_cast<const IOQ*>(A.q), base, rows, lane, lds, q);")
         E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
         E.raw("    if constexpr (BOX) spec_load_spheres_finish(lds_prm, lane, prm);")
         E.raw("    spec_stamp(A.stamps, wblock, 1, lane);")
@@ -560,8 +562,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             W = 3 * L
             E.raw(f"    static_assert({ring_t}::LS == {rp.stride} && {ring_t}::HX == {rp.hx} && {ring_t}::NFULL == {rp.n_full} && {ring_t}::NP == {rp.pieces}, "
                   '"generator and RingFlusher disagree on the ring geometry");')
-            E.raw(f"    const {ring_t} ring = spec_make_ring<{rp.W}, {rp.V}, {'true' if rp.aligned else 'false'}, IO>("
-                  "static_cast<IO*>(A.link_pos), base, rows, lane, lds);")
+            E.raw(f"    const {ring_t} ring = spec_make_ring<{rp.W}, {rp.V}, {'true' if rp.aligned else 'false'}, IOQ>("
+                  "static_cast<IOQ*>(A.link_pos), base, rows, lane, lds);")
             E.raw("    float* const prow = ring.row();        // this lane's ring; prow_a: the same, shifted by the lane's head")
             E.raw("    float* const prow_a = ring.row_a();")
             E.raw("    spec_wave_sync();")
@@ -611,11 +613,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             assert not pending
             E.raw("    const std::conditional_t<POS, RingTail<decltype(ring)>, NoFlushOf<decltype(ring)>> flush{ring};")
         else:
-            E.raw(f"    PosFlusher<{3 * L}, IO> flush{{reinterpret_cast<const float4*>(lds) + lane, 0u, 0ull, 0ull, lane, make_float4(0.0f, 0.0f, 0.0f, 0.0f)}};")
+            E.raw(f"    PosFlusher<{3 * L}, IOQ> flush{{reinterpret_cast<const float4*>(lds) + lane, 0u, 0ull, 0ull, lane, make_float4(0.0f, 0.0f, 0.0f, 0.0f)}};")
             pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
             E.raw("    if (A.link_pos) {")
             E.raw(f"        const float pv[{3 * L}] = {{{pos_list}}};")
-            E.raw(f"        flush = spec_stage_rows<{3 * L}>(static_cast<IO*>(A.link_pos), base, rows, lane, lds, pv);")
+            E.raw(f"        flush = spec_stage_rows<{3 * L}>(static_cast<IOQ*>(A.link_pos), base, rows, lane, lds, pv);")
             E.raw("    }")
         E.raw("    if (!A.gq) { flush.template rest<0>(); return; }      // positions only (trk_fk_positions): wave-uniform exit")
         # position chunks leave at tick points with COMPILE-TIME chunk numbers (PosFlusher::chunk<CH>); `next_chunk` counts them
@@ -667,7 +669,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
         E.raw(f"    flush.template rest<{next_chunk[0]}>();")
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
-        E.raw("    spec_store_gq<D>(static_cast<IO*>(A.gq), base, rows, lane, lds, gv);")
+        E.raw("    spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gq), base, rows, lane, lds, gv, A.grad_scale);")
         E.raw("    spec_stamp(A.stamps, wblock, 7, lane);")
         E.raw("}")
         out.extend(E.lines)
@@ -1193,7 +1195,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append(f"    auto sw{k} = [&](auto io{sep}{fixed}) {{ if ({switches[k]}) {prev}(io{sep}{fixed_args}, std::true_type{{}}); "
                    f"else {prev}(io{sep}{fixed_args}, std::false_type{{}}); }};")
         prev = f"sw{k}"
-    out.append("    if (a.io_f16) sw0(_Float16{}); else sw0(float{});")
+    out.append("    if (a.io_f16 == TRK_IO_F16) sw0(_Float16{}); else if (a.io_f16 == TRK_IO_F16_G32) sw0(HalfG32{}); else sw0(float{});")
     out.append("}")
     out.append("static void launch_posbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")

@@ -1061,7 +1061,7 @@ int trk_ee_cost(const TrkCostModel* cm, const float* H_ee, int64_t n, int64_t st
     return TRK_OK;
 }
 
-static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, int io_f16,
+static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, int io_f16, float grad_scale,
                         const void* q, int64_t batch, int32_t horizon, void* link_pos_out, float* cost, void* gq,
                         float* cost_sum, trk_stream_t stream) {
     int rc = check_model(m, who);
@@ -1082,14 +1082,14 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
             std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
             a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
-            a.stamps = g_stamps; a.io_f16 = io_f16;
+            a.stamps = g_stamps; a.io_f16 = io_f16; a.grad_scale = grad_scale;
             e->launch(a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }
     }
     if (trk_lds_rollout(m->hdr, m->hdr.n_links + cm->hdr.n_virtual) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, std::string(who) + ": position tiles (links + interpolated points) exceed the 160 KiB LDS");
-    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, nullptr, cm->hdr, *w, io_f16, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
+    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, nullptr, cm->hdr, *w, io_f16, grad_scale, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }
@@ -1191,13 +1191,16 @@ int trk_traj_validate(const uint8_t* waypoint_collisions, const float* x, int64_
 int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const float* q,
                           int64_t batch, int32_t horizon, float* link_pos_out, float* cost, float* gq, float* cost_sum,
                           trk_stream_t stream) {
-    return rollout_impl("trk_rollout_cost_grad", m, cm, w, 0, q, batch, horizon, link_pos_out, cost, gq, cost_sum, stream);
+    return rollout_impl("trk_rollout_cost_grad", m, cm, w, 0, 1.0f, q, batch, horizon, link_pos_out, cost, gq, cost_sum, stream);
 }
 
 int trk_rollout_cost_grad_f16(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const void* q_f16,
-                              int64_t batch, int32_t horizon, void* link_pos_out_f16, float* cost, void* gq_f16,
-                              float* cost_sum, trk_stream_t stream) {
-    return rollout_impl("trk_rollout_cost_grad_f16", m, cm, w, 1, q_f16, batch, horizon, link_pos_out_f16, cost, gq_f16, cost_sum, stream);
+                              int64_t batch, int32_t horizon, void* link_pos_out_f16, float* cost, void* gq,
+                              int32_t grad_dtype, float grad_scale, float* cost_sum, trk_stream_t stream) {
+    if ((grad_dtype != TRK_F32 && grad_dtype != TRK_F16) || !(grad_scale > 0.0f) || !std::isfinite(grad_scale))
+        return fail(TRK_ERR_INVALID_ARG, "trk_rollout_cost_grad_f16: grad_dtype must be TRK_F32 / TRK_F16, grad_scale finite and > 0");
+    return rollout_impl("trk_rollout_cost_grad_f16", m, cm, w, grad_dtype == TRK_F16 ? 1 : 2, grad_scale, q_f16, batch, horizon,
+                        link_pos_out_f16, cost, gq, cost_sum, stream);
 }
 
 int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const TrkCostModel* cm, const TrkRolloutWeights* w,
@@ -1231,7 +1234,7 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
             return TRK_OK;
         }
     }
-    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, &ps->dev, cm->hdr, *w, 0, q, n, point_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
+    trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, &ps->dev, cm->hdr, *w, 0, 1.0f, q, n, point_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }
@@ -1301,15 +1304,19 @@ int trk_interpolate_columns_backward(const float* gout, int64_t n, int32_t n_in,
 }
 
 int trk_gp_prior_cost_grad(const void* q, const void* qd, int64_t batch, int32_t horizon, int32_t dof, int32_t io_dtype,
-                           float dt, float sigma, float weight, float* cost, void* gq, void* gqd, int32_t accumulate,
-                           trk_stream_t stream) {
+                           float dt, float sigma, float weight, float* cost, void* gq, void* gqd, int32_t grad_dtype,
+                           float grad_scale, int32_t accumulate, trk_stream_t stream) {
     if (batch < 0 || horizon < 1 || dof < 1 || (io_dtype != TRK_F32 && io_dtype != TRK_F16) || !(dt > 0.0f) || !(sigma > 0.0f) ||
         batch > 0x7fffffff || (batch > 0 && (!q || !qd || !cost || !gq || !gqd)))
         return fail(TRK_ERR_INVALID_ARG, "trk_gp_prior_cost_grad: bad argument");
+    if ((grad_dtype != TRK_F32 && grad_dtype != TRK_F16) || (io_dtype == TRK_F32 && grad_dtype == TRK_F16) || !(grad_scale > 0.0f) ||
+        !std::isfinite(grad_scale))
+        return fail(TRK_ERR_INVALID_ARG, "trk_gp_prior_cost_grad: grad_dtype must be TRK_F32 or (with fp16 trajectories) TRK_F16, grad_scale finite and > 0");
     if (batch == 0) return TRK_OK;
     int rc = ensure_init();
     if (rc) return rc;
-    if (trk_launch_gp_prior(io_dtype == TRK_F16, q, qd, batch, horizon, dof, dt, sigma, weight, cost, gq, gqd, accumulate, (hipStream_t)stream))
+    if (trk_launch_gp_prior(io_dtype == TRK_F16, grad_dtype == TRK_F16, grad_scale, q, qd, batch, horizon, dof, dt, sigma, weight, cost, gq, gqd,
+                            accumulate, (hipStream_t)stream))
         return fail(TRK_ERR_UNSUPPORTED, "trk_gp_prior_cost_grad: one trajectory (horizon x dof x 2 floats) must fit the 160 KiB LDS");
     TRK_HIP(hipGetLastError());
     return TRK_OK;
@@ -1349,13 +1356,15 @@ int64_t trk_pack_sums_scratch_bytes(int32_t horizon, int32_t dof) {
     return (int64_t)(sizeof(float) * trk_pack_scratch_floats(horizon, dof));
 }
 
-int trk_pack_sums(const float* cost, const float* gq, const float* cost_block_sums, int64_t batch, int32_t horizon, int32_t dof,
-                  float* scratch, float* packed, trk_stream_t stream) {
-    if (batch < 1 || batch > 0x7fffffff || horizon < 1 || dof < 1 || !cost || !gq || !cost_block_sums || !scratch || !packed)
+int trk_pack_sums(const float* cost, const void* gq, int32_t grad_dtype, float grad_scale, const float* cost_block_sums,
+                  const float* traj_cost, int64_t batch, int32_t horizon, int32_t dof, float* scratch, float* packed, trk_stream_t stream) {
+    if (batch < 1 || batch > 0x7fffffff || horizon < 1 || dof < 1 || !cost || !gq || !cost_block_sums || !scratch || !packed ||
+        (grad_dtype != TRK_F32 && grad_dtype != TRK_F16) || !(grad_scale > 0.0f) || !std::isfinite(grad_scale))
         return fail(TRK_ERR_INVALID_ARG, "trk_pack_sums: bad argument");
     int rc = ensure_init();
     if (rc) return rc;
-    trk_launch_pack_sums(cost, gq, cost_block_sums, (int)batch, horizon, dof, (batch * horizon + 63) / 64, scratch, packed, (hipStream_t)stream);
+    trk_launch_pack_sums(cost, gq, grad_dtype == TRK_F16, 1.0f / grad_scale, cost_block_sums, traj_cost, (int)batch, horizon, dof,
+                         (batch * horizon + 63) / 64, scratch, packed, (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }

@@ -45,6 +45,14 @@ __device__ __forceinline__ void store_tile(IO* __restrict__ dst, const float* sr
     for (int64_t k = lane; k < count; k += TRK_WAVE) dst[first + k] = (IO)src[k];
 }
 
+// gradient rows of the fp16-q rollout: multiplied by the caller's grad_scale, an fp16 element saturates at +-65504 (no inf)
+__device__ __forceinline__ void put_scaled(float* p, float v) { *p = v; }
+__device__ __forceinline__ void put_scaled(_Float16* p, float v) { *p = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+template <class G>
+__device__ __forceinline__ void store_tile_scaled(G* __restrict__ dst, const float* src, int64_t first, int64_t count, int lane, float scale) {
+    for (int64_t k = lane; k < count; k += TRK_WAVE) put_scaled(dst + first + k, src[k] * scale);
+}
+
 // copy a [rows][width] tile kept in LDS with an odd row stride `rs` to/from contiguous global memory
 template <class IO>
 __device__ __forceinline__ void store_tile_strided(IO* __restrict__ dst, const float* src, int64_t first, int rows,
@@ -804,11 +812,12 @@ k_ee_cost(DevCostHdr C, const float* __restrict__ H, int64_t n, int64_t stride, 
 // Fused rollout, table-driven: walk 1 (FK -> position tile, EE rotation), costs + position adjoints,
 // walk 2 (reverse pass).  q [N,D] -> link_pos [N,L,3] (nullable), cost [N], gq [N,D], cost_sum (nullable).
 // ============================================================================================
-template <bool POINTS, class IO>     // POINTS: the cost model's columns are the attached points of `ps`, not the links
+// IO: HBM-side type of q / link_pos; G: of the gradient (fp16 q: multiplied by grad_scale, fp16 stores saturate)
+template <bool POINTS, class IO, class G = IO>     // POINTS: the cost model's columns are the attached points of `ps`, not the links
 __global__ void __launch_bounds__(TRK_WAVE)
 k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int32_t* __restrict__ fin, SelMap sel_unused, DevPointSet ps, DevCostHdr C,
                   TrkRolloutWeights w, const IO* __restrict__ q, int64_t n, IO* __restrict__ link_pos,
-                  float* __restrict__ cost, IO* __restrict__ gq, float* __restrict__ cost_sum) {
+                  float* __restrict__ cost, G* __restrict__ gq, float* __restrict__ cost_sum, float grad_scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const int D = hdr.n_dofs, L = hdr.n_links;
@@ -903,7 +912,8 @@ k_rollout_generic(DevModelHdr hdr, const DevLink* __restrict__ links, const int3
         reverse_walk<false>(hdr, links, fin, qs, gqs, jst, slots, lane, adj);
     }
     __syncthreads();
-    store_tile(gq, gqs, base * D, (int64_t)rows * D, lane);
+    if constexpr (std::is_same<IO, float>::value) store_tile(gq, gqs, base * D, (int64_t)rows * D, lane);
+    else store_tile_scaled(gq, gqs, base * D, (int64_t)rows * D, lane, grad_scale);
     if (link_pos) store_tile_strided(link_pos, tile, base * width, rows, width, rs, lane);
 }
 
@@ -1876,18 +1886,23 @@ template <> struct GpVec<_Float16> {
         const h4 h = *reinterpret_cast<const h4*>(p);
         return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
     }
+    // gradients: saturating at the largest finite half (at sigma = 0.1, dt = 5/128 a residual of 0.02 rad is a gradient of 4e5;
+    // the caller's grad_scale keeps the values in range, this keeps a misjudged scale from writing inf)
+    static __device__ __forceinline__ _Float16 sat(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
     static __device__ __forceinline__ void store(_Float16* p, const float4& v) {
-        const h4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        const h4 h = {sat(v.x), sat(v.y), sat(v.z), sat(v.w)};
         asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(h) : "memory");
     }
 };
 
 // One workgroup per trajectory.  VEC: H*D is a multiple of 4 and the buffers are 16-byte aligned -> the trajectory's q
 // and qd go to LDS with 4-element loads, each thread then owns 4 consecutive elements and writes them with one store.
-template <class T, bool VEC>
+// T: HBM-side type of q / qd, G: of gq / gqd.  The gradients are multiplied by `gs` (the caller's grad_scale) before they are
+// stored (or added to what the buffers hold, which the caller scaled the same way); the cost is never scaled.
+template <class T, class G, bool VEC>
 __global__ void __launch_bounds__(256)
-k_gp_prior(const T* __restrict__ q, const T* __restrict__ qd, int H, int D, float dt, float a, float b, float c, float w,
-           float* __restrict__ cost, T* __restrict__ gq, T* __restrict__ gqd, int accumulate) {
+k_gp_prior(const T* __restrict__ q, const T* __restrict__ qd, int H, int D, float dt, float a, float b, float c, float w, float gs,
+           float* __restrict__ cost, G* __restrict__ gq, G* __restrict__ gqd, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t base = (int64_t)blockIdx.x * H * D;
     const int total = H * D;
@@ -1918,7 +1933,7 @@ k_gp_prior(const T* __restrict__ q, const T* __restrict__ qd, int H, int D, floa
             const float ep = fmaf(dt, vm, pm) - p0, ev = vm - v0;
             gp -= fmaf(a, ep, b * ev); gv -= fmaf(b, ep, c * ev);
         }
-        gp *= w; gv *= w;
+        gp *= w * gs; gv *= w * gs;
     };
     if (VEC) {
         for (int i = 4 * threadIdx.x; i < total; i += 4 * 256) {
@@ -1927,19 +1942,19 @@ k_gp_prior(const T* __restrict__ q, const T* __restrict__ qd, int H, int D, floa
             for (int k = 0; k < 4; ++k) element(i + k, gp[k], gv[k]);
             float4 o0 = make_float4(gp[0], gp[1], gp[2], gp[3]), o1 = make_float4(gv[0], gv[1], gv[2], gv[3]);
             if (accumulate) {
-                const float4 c0 = GpVec<T>::load(gq + base + i), c1 = GpVec<T>::load(gqd + base + i);
+                const float4 c0 = GpVec<G>::load(gq + base + i), c1 = GpVec<G>::load(gqd + base + i);
                 o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w;
                 o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
             }
-            GpVec<T>::store(gq + base + i, o0);
-            GpVec<T>::store(gqd + base + i, o1);
+            GpVec<G>::store(gq + base + i, o0);
+            GpVec<G>::store(gqd + base + i, o1);
         }
     } else {
         for (int i = threadIdx.x; i < total; i += 256) {
             float gp, gv;
             element(i, gp, gv);
             if (accumulate) { gp += (float)gq[base + i]; gv += (float)gqd[base + i]; }
-            gq[base + i] = (T)gp; gqd[base + i] = (T)gv;
+            put_scaled(gq + base + i, gp); put_scaled(gqd + base + i, gv);
         }
     }
     acc = wave_sum(acc);
@@ -2039,9 +2054,12 @@ k_reduce_sum_wide(const float* __restrict__ x, int64_t n, float* __restrict__ ou
 // scratch: float[TRK_PACK_SLICES * (H + H D)] followed by one zero-initialised int (the ticket; the kernel leaves it zero).
 // ============================================================================================
 #define TRK_PACK_SLICES 64
+// G: element type of gq (fp32, or the fp16 gradient of the reduced-precision rollout); unscale = 1 / grad_scale of that gradient, applied
+// once to the fp32 column sums; traj_cost (nullable) [B]: a per-trajectory cost (the GP prior's) whose sum joins out[0].
+template <class G>
 __global__ void __launch_bounds__(256)
-k_pack_sums(const float* __restrict__ cost, const float* __restrict__ gq, const float* __restrict__ block_sums, int B, int H, int D,
-            int64_t nb, float* __restrict__ scratch, float* __restrict__ out) {
+k_pack_sums(const float* __restrict__ cost, const G* __restrict__ gq, float unscale, const float* __restrict__ block_sums,
+            const float* __restrict__ traj_cost, int B, int H, int D, int64_t nb, float* __restrict__ scratch, float* __restrict__ out) {
     __shared__ float part[256];
     __shared__ int is_last;
     const int C = H + H * D;                                 // columns: H of the cost matrix, then H D of the gradient matrix
@@ -2053,10 +2071,8 @@ k_pack_sums(const float* __restrict__ cost, const float* __restrict__ gq, const 
     const int b0 = slice * rows_per, b1 = min(B, b0 + rows_per);
     float acc = 0.0f;
     if (col < C) {
-        const bool is_cost = col < H;
-        const float* src = is_cost ? cost + col : gq + (col - H);
-        const int64_t stride = is_cost ? H : (int64_t)H * D;
-        for (int b = b0 + rl; b < b1; b += 4) acc += src[b * stride];
+        if (col < H) { for (int b = b0 + rl; b < b1; b += 4) acc += cost[(int64_t)b * H + col]; }
+        else { const G* src = gq + (col - H); const int64_t stride = (int64_t)H * D; for (int b = b0 + rl; b < b1; b += 4) acc += (float)src[b * stride]; }
     }
     part[threadIdx.x] = acc;
     __syncthreads();
@@ -2073,10 +2089,11 @@ k_pack_sums(const float* __restrict__ cost, const float* __restrict__ gq, const 
     for (int k = threadIdx.x; k < C; k += 256) {
         float tot = 0.0f;
         for (int p = 0; p < TRK_PACK_SLICES; ++p) tot += scratch[(size_t)p * C + k];
-        out[1 + k] = tot;
+        out[1 + k] = k < H ? tot : tot * unscale;
     }
     float a = 0.0f;
     for (int64_t i = threadIdx.x; i < nb; i += 256) a += block_sums[i];       // the association order of trk_reduce_sum
+    if (traj_cost) { float t = 0.0f; for (int i = threadIdx.x; i < B; i += 256) t += traj_cost[i]; a += t; }
     part[threadIdx.x] = a;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -2144,24 +2161,26 @@ size_t trk_lds_fk_points(const DevModelHdr& hdr, int n_points, bool backward) {
                             (size_t)TRK_WAVE * ((n_points * 3) | 1));
 }
 
-template <class IO>
+template <class IO, class G>
 static void launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet* ps,
                                    const DevCostHdr& C, const TrkRolloutWeights& w, const void* q, int64_t n, void* link_pos,
-                                   float* cost, void* gq, float* cost_sum, hipStream_t st) {
+                                   float* cost, void* gq, float* cost_sum, float grad_scale, hipStream_t st) {
     const IO* qq = static_cast<const IO*>(q);
     IO* lp = static_cast<IO*>(link_pos);
-    IO* gg = static_cast<IO*>(gq);
-    if (ps) hipLaunchKernelGGL((k_rollout_generic<true, IO>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, ps->n_points + C.n_virtual), st,
-                               hdr, links, fin, SelMap{}, *ps, C, w, qq, n, lp, cost, gg, cost_sum);
-    else hipLaunchKernelGGL((k_rollout_generic<false, IO>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, hdr.n_links + C.n_virtual), st,
-                            hdr, links, fin, SelMap{}, DevPointSet{}, C, w, qq, n, lp, cost, gg, cost_sum);
+    G* gg = static_cast<G*>(gq);
+    if (ps) hipLaunchKernelGGL((k_rollout_generic<true, IO, G>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, ps->n_points + C.n_virtual), st,
+                               hdr, links, fin, SelMap{}, *ps, C, w, qq, n, lp, cost, gg, cost_sum, grad_scale);
+    else hipLaunchKernelGGL((k_rollout_generic<false, IO, G>), dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), trk_lds_rollout(hdr, hdr.n_links + C.n_virtual), st,
+                            hdr, links, fin, SelMap{}, DevPointSet{}, C, w, qq, n, lp, cost, gg, cost_sum, grad_scale);
 }
 
+// io_mode: 0 fp32 | 1 fp16 q / link_pos / gq | 2 fp16 q / link_pos, fp32 gq (TRK_IO_* of trk_spec_common.h)
 void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet* ps,
-                                const DevCostHdr& C, const TrkRolloutWeights& w, int io_f16, const void* q, int64_t n,
+                                const DevCostHdr& C, const TrkRolloutWeights& w, int io_mode, float grad_scale, const void* q, int64_t n,
                                 void* link_pos, float* cost, void* gq, float* cost_sum, hipStream_t st) {
-    if (io_f16) launch_rollout_generic<_Float16>(hdr, links, fin, ps, C, w, q, n, link_pos, cost, gq, cost_sum, st);
-    else launch_rollout_generic<float>(hdr, links, fin, ps, C, w, q, n, link_pos, cost, gq, cost_sum, st);
+    if (io_mode == 1) launch_rollout_generic<_Float16, _Float16>(hdr, links, fin, ps, C, w, q, n, link_pos, cost, gq, cost_sum, grad_scale, st);
+    else if (io_mode == 2) launch_rollout_generic<_Float16, float>(hdr, links, fin, ps, C, w, q, n, link_pos, cost, gq, cost_sum, grad_scale, st);
+    else launch_rollout_generic<float, float>(hdr, links, fin, ps, C, w, q, n, link_pos, cost, gq, cost_sum, 1.0f, st);
 }
 
 void trk_launch_fk_points(const DevModelHdr& hdr, const DevLink* links, const DevPointSet& ps, const float* q, int64_t n,
@@ -2295,21 +2314,23 @@ void trk_launch_interpolate_columns_bwd(const float* g, int64_t n, int L, int C,
     hipLaunchKernelGGL(k_interpolate_columns_bwd, dim3(grid_for(n * L * C, 256)), dim3(256), 0, st, g, n, L, C, K, src, w, gx);
 }
 
-int trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
+int trk_launch_gp_prior(int f16, int grad_f16, float grad_scale, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
                         float* cost, void* gq, void* gqd, int accumulate, hipStream_t st) {
     const float s2 = 1.0f / (sigma * sigma);
     const float a = 12.0f * s2 / (dt * dt * dt), b = -6.0f * s2 / (dt * dt), c = 4.0f * s2 / dt;
     const size_t total = (size_t)H * D;
     const size_t lds = sizeof(float) * (2 * ((total + 3) & ~(size_t)3) + 4);
     if (lds > 160 * 1024) return -1;
-    const size_t esz = f16 ? 2 : 4;
-    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(qd) | reinterpret_cast<uintptr_t>(gq) |
-                           reinterpret_cast<uintptr_t>(gqd);
-    const bool vec = total % 4 == 0 && (ptrs & (4 * esz - 1)) == 0;
-#define TRK_GP(T, V) hipLaunchKernelGGL((k_gp_prior<T, V>), dim3((unsigned)B), dim3(256), lds, st, (const T*)q, (const T*)qd, H, D, \
-                                        dt, a, b, c, w, cost, (T*)gq, (T*)gqd, accumulate)
-    if (f16) { if (vec) TRK_GP(_Float16, true); else TRK_GP(_Float16, false); }
-    else { if (vec) TRK_GP(float, true); else TRK_GP(float, false); }
+    const size_t esz = f16 ? 2 : 4, gsz = grad_f16 ? 2 : 4;
+    const uintptr_t in_ptrs = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(qd);
+    const uintptr_t out_ptrs = reinterpret_cast<uintptr_t>(gq) | reinterpret_cast<uintptr_t>(gqd);
+    const bool vec = total % 4 == 0 && (in_ptrs & (4 * esz - 1)) == 0 && (out_ptrs & (4 * gsz - 1)) == 0;
+#define TRK_GP(T, G, V) hipLaunchKernelGGL((k_gp_prior<T, G, V>), dim3((unsigned)B), dim3(256), lds, st, (const T*)q, (const T*)qd, H, D, \
+                                           dt, a, b, c, w, grad_scale, cost, (G*)gq, (G*)gqd, accumulate)
+    if (f16 && grad_f16) { if (vec) TRK_GP(_Float16, _Float16, true); else TRK_GP(_Float16, _Float16, false); }
+    else if (f16) { if (vec) TRK_GP(_Float16, float, true); else TRK_GP(_Float16, float, false); }
+    else if (grad_f16) return -2;       // fp32 trajectories with an fp16 gradient: not a mode
+    else { if (vec) TRK_GP(float, float, true); else TRK_GP(float, float, false); }
 #undef TRK_GP
     return 0;
 }
@@ -2324,10 +2345,12 @@ void trk_launch_traj_diff_norm_sum(const float* x, int64_t B, int H, int S, int 
 }
 
 size_t trk_pack_scratch_floats(int H, int D) { return (size_t)TRK_PACK_SLICES * (H + (size_t)H * D) + 1; }
-void trk_launch_pack_sums(const float* cost, const float* gq, const float* block_sums, int B, int H, int D, int64_t nb, float* scratch,
-                          float* out, hipStream_t st) {
+void trk_launch_pack_sums(const float* cost, const void* gq, int grad_f16, float unscale, const float* block_sums, const float* traj_cost,
+                          int B, int H, int D, int64_t nb, float* scratch, float* out, hipStream_t st) {
     const int C = H + H * D;
-    hipLaunchKernelGGL(k_pack_sums, dim3(TRK_PACK_SLICES * ((C + 63) / 64)), dim3(256), 0, st, cost, gq, block_sums, B, H, D, nb, scratch, out);
+    const dim3 grid(TRK_PACK_SLICES * ((C + 63) / 64));
+    if (grad_f16) hipLaunchKernelGGL(k_pack_sums<_Float16>, grid, dim3(256), 0, st, cost, static_cast<const _Float16*>(gq), unscale, block_sums, traj_cost, B, H, D, nb, scratch, out);
+    else hipLaunchKernelGGL(k_pack_sums<float>, grid, dim3(256), 0, st, cost, static_cast<const float*>(gq), unscale, block_sums, traj_cost, B, H, D, nb, scratch, out);
 }
 
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st) {
@@ -2346,10 +2369,12 @@ int trk_kernels_init(void) {
     TRK_SET(k_fk_forward<0>); TRK_SET(k_fk_forward<1>); TRK_SET(k_fk_backward<0>); TRK_SET(k_fk_backward<1>);
     TRK_SET(k_cost_fields); TRK_SET(k_collision_fields); TRK_SET((k_rollout_generic<false, float>)); TRK_SET((k_rollout_generic<true, float>));
     TRK_SET((k_rollout_generic<false, _Float16>)); TRK_SET((k_rollout_generic<true, _Float16>));
+    TRK_SET((k_rollout_generic<false, _Float16, float>)); TRK_SET((k_rollout_generic<true, _Float16, float>));
     TRK_SET(k_fk_jacobian); TRK_SET(k_fk_points); TRK_SET(k_fk_points_backward);
     TRK_SET(k_fk_analytic_jacobian); TRK_SET(k_ik_step);
-    TRK_SET((k_gp_prior<float, true>)); TRK_SET((k_gp_prior<float, false>));
-    TRK_SET((k_gp_prior<_Float16, true>)); TRK_SET((k_gp_prior<_Float16, false>));
+    TRK_SET((k_gp_prior<float, float, true>)); TRK_SET((k_gp_prior<float, float, false>));
+    TRK_SET((k_gp_prior<_Float16, _Float16, true>)); TRK_SET((k_gp_prior<_Float16, _Float16, false>));
+    TRK_SET((k_gp_prior<_Float16, float, true>)); TRK_SET((k_gp_prior<_Float16, float, false>));
     TRK_SET(k_jtj<true>); TRK_SET(k_jtj<false>);
 #undef TRK_SET
     return e == hipSuccess ? 0 : -1;

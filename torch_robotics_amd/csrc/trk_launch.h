@@ -18,9 +18,10 @@ void trk_launch_collision_fields(const DevCostHdr& C, int fields, const float* l
 void trk_launch_ee_cost(const DevCostHdr& C, const float* H, int64_t n, int64_t stride, const float* target, int per_sample,
                         const float* gcost, float* cost, float* gH, int64_t g_stride, hipStream_t st);
 // ps == nullptr: the cost model's columns are the links; otherwise the attached points of *ps
-// io_f16: q / link_pos / gq are _Float16 in HBM (fp32 otherwise); arithmetic, cost and cost_sum are always fp32
+// io_mode: 0 fp32 | 1 q / link_pos / gq are _Float16 in HBM | 2 q / link_pos _Float16, gq fp32; arithmetic, cost and cost_sum are always
+// fp32.  fp16 q: the gradient is multiplied by grad_scale before the store, fp16 gradient stores saturate at +-65504.
 void trk_launch_rollout_generic(const DevModelHdr& hdr, const DevLink* links, const int32_t* fin, const DevPointSet* ps,
-                                const DevCostHdr& C, const TrkRolloutWeights& w, int io_f16, const void* q, int64_t n,
+                                const DevCostHdr& C, const TrkRolloutWeights& w, int io_mode, float grad_scale, const void* q, int64_t n,
                                 void* link_pos, float* cost, void* gq, float* cost_sum, hipStream_t st);
 void trk_launch_fk_points(const DevModelHdr& hdr, const DevLink* links, const DevPointSet& ps, const float* q, int64_t n,
                           float* out, hipStream_t st);
@@ -56,8 +57,8 @@ void trk_launch_grid_pack(const float* sdf, const float* grad, int64_t n, float4
 int trk_launch_jtj(int mfma, const float* lin, const float* ang, const float* r6, int64_t n, int D, float* JtJ, float* Jtr,
                    const float* damping, int damping_stride, float* dq, hipStream_t st);
 size_t trk_pack_scratch_floats(int H, int D);
-void trk_launch_pack_sums(const float* cost, const float* gq, const float* block_sums, int B, int H, int D, int64_t nb, float* scratch,
-                          float* out, hipStream_t st);
+void trk_launch_pack_sums(const float* cost, const void* gq, int grad_f16, float unscale, const float* block_sums, const float* traj_cost,
+                          int B, int H, int D, int64_t nb, float* scratch, float* out, hipStream_t st);
 void trk_launch_scale_rows(int f16, const void* g, const float* sc, int sc_stride, int64_t n, int D, void* out, hipStream_t st);
 void trk_launch_interpolate_columns(const float* x, int64_t n, int L, int C, int K, const int32_t* src, const float* w, float* out,
                                     hipStream_t st);
@@ -65,8 +66,9 @@ void trk_launch_interpolate_columns_bwd(const float* g, int64_t n, int L, int C,
                                         hipStream_t st);
 void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_interp, const float* alpha, const float* beta,
                             float* out, hipStream_t st);
-int trk_launch_gp_prior(int f16, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma, float w,
-                         float* cost, void* gq, void* gqd, int accumulate, hipStream_t st);
+// returns -1: a trajectory does not fit the LDS, -2: fp32 trajectories with fp16 gradients (not a mode)
+int trk_launch_gp_prior(int f16, int grad_f16, float grad_scale, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma,
+                        float w, float* cost, void* gq, void* gqd, int accumulate, hipStream_t st);
 void trk_launch_finite_difference(const float* x, int64_t B, int H, int D, float dt, int method, float* out, hipStream_t st);
 void trk_launch_traj_diff_norm_sum(const float* x, int64_t B, int H, int S, int c0, int D, float* out, hipStream_t st);
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st);

@@ -26,7 +26,7 @@ struct SpecArgs {
     float* cost;
     void* gq;
     float* cost_sum;
-    int32_t io_f16;               // 1: q / link_pos / gq are fp16 in HBM (arithmetic, cost and cost_sum stay fp32)
+    int32_t io_f16;               // TRK_IO_*: 0 all fp32; 1 q / link_pos / gq fp16 in HBM; 2 q / link_pos fp16, gq fp32 (arithmetic, cost, cost_sum: fp32)
     unsigned long long* stamps;   // profiling hook (nullable): [n_waves][8] s_memtime stamps at phase boundaries
     // boolean mode (trk_rollout_collision): when coll_out != nullptr the kernel stops after FK, ORs the selected fields'
     // "signed distance < margin" tests and writes one byte per sample -- no positions, cost or gradient leave the chip
@@ -53,7 +53,9 @@ struct SpecArgs {
     const float* via_alpha; const float* via_beta;   // DEVICE [via_n]
     int32_t via_n;                // interpolated points per segment; 0 = q holds the configurations themselves
     int32_t via_H, via_S;         // way points per trajectory, floats per way point (>= D)
-    int32_t _pad_via;
+    // fp16 q (io_f16 != 0): the gradient is multiplied by grad_scale (fp32) before it is stored, an fp16 store saturates at
+    // +-65504 instead of writing inf ("loss scaling": config 5's GP term reaches 1e5 .. 1e6 at sigma_gp = 0.1, dt = 5/128)
+    float grad_scale;
 };
 
 typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
@@ -80,7 +82,7 @@ typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 18)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 19)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -157,6 +159,18 @@ __device__ __forceinline__ void store_wt_f1(float* p, float v) {
 
 // HBM-side element type of q / link_pos / gq: four consecutive elements <-> one float4 of LDS (fp32 arithmetic always).
 typedef _Float16 trk_h4 __attribute__((ext_vector_type(4)));
+// The I/O mode a rollout kernel is instantiated for: Q = type of q and link_pos, G = type of the gradient, kScaled = the gradient
+// is multiplied by SpecArgs::grad_scale and stored saturating.  `float` / `_Float16` name themselves; HalfG32 is the mixed mode
+// (fp16 trajectories and positions, fp32 gradient).  The fp32 instantiation has no scale: its code is what it was.
+struct HalfG32 {};
+template <class IO> struct IoTraits { typedef IO Q; typedef IO G; static constexpr bool kScaled = false; };
+template <> struct IoTraits<_Float16> { typedef _Float16 Q; typedef _Float16 G; static constexpr bool kScaled = true; };
+template <> struct IoTraits<HalfG32> { typedef _Float16 Q; typedef float G; static constexpr bool kScaled = true; };
+#define TRK_IO_F32 0
+#define TRK_IO_F16 1
+#define TRK_IO_F16_G32 2
+// fp32 -> fp16 that saturates at the largest finite half instead of rounding to inf (v_med3_f32 + v_cvt_f16_f32)
+__device__ __forceinline__ _Float16 trk_sat_f16(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
 template <class IO> struct IoQuad;
 template <> struct IoQuad<float> {
     static constexpr uintptr_t kAlignMask = 15;
@@ -177,6 +191,8 @@ template <> struct IoQuad<float> {
                      : "=&s"(saved) : "v"(voff), "v"(x), "s"(base), "s"(mask) : "scc");
     }
     static __device__ __forceinline__ void store_wt1(float* p, float v) { store_wt_f1(p, v); }
+    static __device__ __forceinline__ void store_wt_sat(float* p, int k, const float4& v) { store_wt(p, k, v); }
+    static __device__ __forceinline__ void store_wt1_sat(float* p, float v) { store_wt_f1(p, v); }
     static __device__ __forceinline__ void store_wt2(float* p, float a, float b) { store_wt_f2(p, a, b); }
     static __device__ __forceinline__ void store_wt2_s(unsigned long long base, unsigned voff, float a, float b) {
         const trk_f2 x = {a, b};
@@ -221,6 +237,15 @@ template <> struct IoQuad<_Float16> {
     }
     static __device__ __forceinline__ void store_wt1(_Float16* p, float v) {
         const _Float16 h = (_Float16)v;
+        asm volatile("global_store_short %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h)  TRK_STORE_CLOBBER);
+    }
+    // gradient stores: saturating (the positions of a robot never leave the fp16 range, a scaled gradient may)
+    static __device__ __forceinline__ void store_wt_sat(_Float16* p, int k, const float4& v) {
+        const trk_h4 h = {trk_sat_f16(v.x), trk_sat_f16(v.y), trk_sat_f16(v.z), trk_sat_f16(v.w)};
+        asm volatile("global_store_dwordx2 %0, %1, off sc1\n s_nop 1" :: "v"(reinterpret_cast<trk_h4*>(p) + k), "v"(h)  TRK_STORE_CLOBBER);
+    }
+    static __device__ __forceinline__ void store_wt1_sat(_Float16* p, float v) {
+        const _Float16 h = trk_sat_f16(v);
         asm volatile("global_store_short %0, %1, off sc1\n s_nop 1" :: "v"(p), "v"(h)  TRK_STORE_CLOBBER);
     }
     static __device__ __forceinline__ void store_wt2(_Float16* p, float a, float b) {
@@ -360,12 +385,13 @@ __device__ __forceinline__ void spec_load_rows_finish(const RowsInFlight<D>& r, 
     spec_wave_sync();
 }
 
-template <int D, class IO>
+// SCALED: the values are multiplied by `scale` on their way into the tile and an fp16 store saturates (IoTraits<IO>::kScaled)
+template <int D, class IO, bool SCALED = false>
 __device__ __forceinline__ void spec_store_gq(IO* __restrict__ gq, int64_t base, int rows, int lane,
-                                              float* lds, const float (&gv)[D]) {
+                                              float* lds, const float (&gv)[D], float scale = 1.0f) {
     spec_wave_sync();
 #pragma unroll
-    for (int j = 0; j < D; ++j) lds[lane * D + j] = gv[j];
+    for (int j = 0; j < D; ++j) lds[lane * D + j] = SCALED ? gv[j] * scale : gv[j];
     spec_wave_sync();
     const int64_t first = base * D;
     IO* dst = gq + first;
@@ -375,14 +401,14 @@ __device__ __forceinline__ void spec_store_gq(IO* __restrict__ gq, int64_t base,
 #pragma unroll
         for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
             const int k = lane + TRK_WAVE * j;
-            if (k < NV) IoQuad<IO>::store_wt(dst, k, lds4[k]);
+            if (k < NV) { if (SCALED) IoQuad<IO>::store_wt_sat(dst, k, lds4[k]); else IoQuad<IO>::store_wt(dst, k, lds4[k]); }
         }
     } else {
         const int count = rows * D;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const int k = lane + TRK_WAVE * j;
-            if (k < count) IoQuad<IO>::store_wt1(dst + k, lds[k]);
+            if (k < count) { if (SCALED) IoQuad<IO>::store_wt1_sat(dst + k, lds[k]); else IoQuad<IO>::store_wt1(dst + k, lds[k]); }
         }
     }
 }

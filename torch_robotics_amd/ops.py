@@ -6,6 +6,7 @@ floating-point operation of the path happens in the HIP kernels behind the C ABI
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import weakref
 from typing import Optional, Sequence
@@ -318,6 +319,33 @@ def fk_jacobian(model: ModelHandle, q: torch.Tensor, qd: Optional[torch.Tensor],
         check(lib().trk_fk_jacobian(model._h, q.data_ptr(), _ptr(qd_t), n, int(link), pos.data_ptr(), quat.data_ptr(),
                                     lin.data_ptr(), ang.data_ptr(), _ptr(vl), _ptr(va), _stream(q)), "trk_fk_jacobian")
     return (pos, quat, lin, ang, vl, va) if want_vel else (pos, quat, lin, ang)
+
+
+class JacobianPlan:
+    """Pre-bound `trk_fk_jacobian` (stateful FK + geometric Jacobian of one link, robot_tree.py:218-248): outputs are allocated once,
+    `launch()` is one C call -- `pos` (N,3), `quat` (N,4 wxyz), `lin_jac` / `ang_jac` (N,3,D) are rewritten in place."""
+
+    def __init__(self, model: ModelHandle, q: torch.Tensor, link: int):
+        q = _dev_f32(q, "JacobianPlan(q)")
+        if q.dim() != 2 or not q.is_contiguous():
+            raise ValueError("JacobianPlan: q must be a contiguous (N, dof) tensor")
+        _check_q_dofs(q, model.n_dofs, "JacobianPlan(q)")
+        n, D = q.shape[0], model.n_dofs
+        kw = dict(device=q.device, dtype=torch.float32)
+        self.model, self.q, self.device = model, q, q.device
+        self.pos, self.quat = torch.empty((n, 3), **kw), torch.empty((n, 4), **kw)
+        self.lin_jac, self.ang_jac = torch.empty((n, 3, D), **kw), torch.empty((n, 3, D), **kw)
+        self._fn = lib().trk_fk_jacobian
+        self._args = (model._h, q.data_ptr(), None, n, int(link), self.pos.data_ptr(), self.quat.data_ptr(), self.lin_jac.data_ptr(),
+                      self.ang_jac.data_ptr(), None, None)
+
+    def launch(self, stream: Optional[int] = None) -> None:
+        with _on(self.device):
+            if stream is None:
+                stream = _stream_of(self.device)
+            rc = self._fn(*self._args, stream)
+        if rc:
+            check(rc, "trk_fk_jacobian")
 
 
 def fk_analytic_jacobian(model: ModelHandle, q: torch.Tensor) -> torch.Tensor:
@@ -693,10 +721,36 @@ def _weights_struct(weights):
     return w
 
 
+def _grad_mode(f16: bool, grad_dtype, grad_scale, who: str):
+    """(torch dtype of the gradient, TRK_F32 / TRK_F16, scale) of a reduced-precision call; fp32 trajectories take no options."""
+    if grad_dtype is None:
+        grad_dtype = torch.float16 if f16 else torch.float32
+    if grad_dtype not in (torch.float16, torch.float32) or (not f16 and grad_dtype != torch.float32):
+        raise ValueError(f"{who}: grad_dtype must be torch.float32, or torch.float16 with float16 trajectories")
+    gs = float(grad_scale)
+    if not (gs > 0.0 and math.isfinite(gs)):
+        raise ValueError(f"{who}: grad_scale must be a finite positive number")
+    return grad_dtype, int(grad_dtype == torch.float16), gs
+
+
+def gp_grad_scale(dt: float, sigma: float, weight: float = 1.0, q_abs_max: float = 3.0, qd_abs_max: float = 2.5,
+                  extra: float = 0.0, limit: float = 32768.0) -> float:
+    """A power-of-two loss scale that keeps an fp16 gradient of the GP prior (+ `extra`: a bound on the other terms' gradient)
+    below `limit` in the worst case of trajectories bounded by |q| <= q_abs_max, |qd| <= qd_abs_max: with
+    a = 12 / (sigma^2 dt^3), b = 6 / (sigma^2 dt^2), c = 4 / (sigma^2 dt) and residual bounds ep = 2 q_abs_max + dt qd_abs_max,
+    ev = 2 qd_abs_max, the two neighbours of a time step give |d/dq| <= 2 (a ep + b ev) and |d/dqd| <= 2 (b ep + c ev) + dt (a ep + b ev)."""
+    s2 = 1.0 / (sigma * sigma)
+    a, b, c = 12.0 * s2 / dt ** 3, 6.0 * s2 / dt ** 2, 4.0 * s2 / dt
+    ep, ev = 2.0 * q_abs_max + dt * qd_abs_max, 2.0 * qd_abs_max
+    bound = abs(weight) * max(2.0 * (a * ep + b * ev), 2.0 * (b * ep + c * ev) + dt * (a * ep + b * ev)) + abs(extra)
+    return 2.0 ** min(0, math.floor(math.log2(limit / bound))) if bound > 0.0 else 1.0
+
+
 def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True,
-                      cost_sum: Optional[torch.Tensor] = None, out=None):
+                      cost_sum: Optional[torch.Tensor] = None, out=None, grad_dtype=None, grad_scale: float = 1.0):
     """q (B,H,D) or (N,D) -> (link_pos (…,L,3) or None, cost (…), gq (…,D)).
-    A float16 q selects the fp16-I/O kernel: link_pos and gq come back as float16, cost stays float32."""
+    A float16 q selects the fp16-I/O kernel: link_pos comes back as float16, cost stays float32, and gq is
+    `grad_scale * d cost / d q` in `grad_dtype` (float16 by default, saturating at +-65504 instead of inf; float32 = the mixed mode)."""
     f16 = q.dtype == torch.float16
     if f16:
         if q.device.type != "cuda":
@@ -705,6 +759,9 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
     else:
         q = _dev_f32(q, "rollout_cost_grad(q)")
     io = torch.float16 if f16 else torch.float32
+    gio, gcode, gs = _grad_mode(f16, grad_dtype, grad_scale, "rollout_cost_grad")
+    if not f16 and gs != 1.0:
+        raise ValueError("rollout_cost_grad: grad_scale applies to float16 trajectories only")
     _check_q_dofs(q, model.n_dofs, "rollout_cost_grad(q)")
     lead = q.shape[:-1]
     if q.dim() == 3:
@@ -717,20 +774,23 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
         lt = tuple(lead)
         pos = torch.empty(lt + (L, 3), device=q.device, dtype=io) if want_pos else None
         cost = torch.empty(lt, device=q.device, dtype=torch.float32)
-        gq = torch.empty(lt + (D,), device=q.device, dtype=io)
+        gq = torch.empty(lt + (D,), device=q.device, dtype=gio)
     else:
         pos, cost, gq = out
         _check_buffer(pos, n * L * 3, io, q.device, "rollout_cost_grad(out[0] = link_pos)")
         _check_buffer(cost, n, torch.float32, q.device, "rollout_cost_grad(out[1] = cost)")
-        _check_buffer(gq, n * D, io, q.device, "rollout_cost_grad(out[2] = gq)")
+        _check_buffer(gq, n * D, gio, q.device, "rollout_cost_grad(out[2] = gq)")
         if cost is None or gq is None:
             raise ValueError("rollout_cost_grad(out): cost and gq buffers are required (link_pos may be None)")
     _check_buffer(cost_sum, n_blocks(n), torch.float32, q.device, "rollout_cost_grad(cost_sum)", at_least=True)
     w = _weights_struct(weights)
-    fn = lib().trk_rollout_cost_grad_f16 if f16 else lib().trk_rollout_cost_grad
     with _on(q.device):
-        check(fn(model._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos), cost.data_ptr(),
-                 gq.data_ptr(), _ptr(cost_sum), _stream(q)), "trk_rollout_cost_grad")
+        if f16:
+            check(lib().trk_rollout_cost_grad_f16(model._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos), cost.data_ptr(),
+                                                  gq.data_ptr(), gcode, gs, _ptr(cost_sum), _stream(q)), "trk_rollout_cost_grad_f16")
+        else:
+            check(lib().trk_rollout_cost_grad(model._h, cm._h, C.byref(w), q.data_ptr(), B, Hh, _ptr(pos), cost.data_ptr(),
+                                              gq.data_ptr(), _ptr(cost_sum), _stream(q)), "trk_rollout_cost_grad")
     if out is None:
         return pos, cost, gq
     return (None if pos is None else pos.reshape(tuple(lead) + (L, 3)), cost.reshape(tuple(lead)),
@@ -790,28 +850,34 @@ def rollout_points_cost_grad(ps: PointSetHandle, cm: CostHandle, weights, q: tor
 
 
 def gp_prior_cost_grad(q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: float, weight: float = 1.0,
-                       accumulate_into=None):
+                       accumulate_into=None, grad_dtype=None, grad_scale: float = 1.0):
     """Constant-velocity GP prior over (B,H,D) trajectories (build-defined; include/trk.h): -> (cost (B,), gq, gqd).
-    fp32 or fp16 tensors (fp32 arithmetic, fp32 cost).  accumulate_into=(gq, gqd) adds the gradient into existing buffers."""
+    fp32 or fp16 tensors (fp32 arithmetic, fp32 cost).  gq / gqd hold `grad_scale` x the gradient in `grad_dtype` (the dtype of q
+    by default; float32 with float16 trajectories = the mixed mode); a float16 gradient saturates at +-65504 instead of inf --
+    `gp_grad_scale(dt, sigma, ...)` picks a scale that keeps it finite.  accumulate_into=(gq, gqd) adds into existing buffers
+    (which hold gradients of the same scale)."""
     if q.device.type != "cuda" or qd.device != q.device:
         raise ValueError("gp_prior_cost_grad: q and qd must be tensors on the same GPU (there is no CPU path)")
     if q.dim() != 3 or qd.shape != q.shape or q.dtype != qd.dtype or q.dtype not in (torch.float32, torch.float16):
         raise ValueError("gp_prior_cost_grad: q, qd must be (batch, horizon, dof) of the same fp32 / fp16 dtype")
     q, qd = q.contiguous(), qd.contiguous()
     B, H, D = (int(v) for v in q.shape)
+    if accumulate_into is not None and grad_dtype is None:
+        grad_dtype = accumulate_into[0].dtype
+    gio, gcode, gs = _grad_mode(q.dtype == torch.float16, grad_dtype, grad_scale, "gp_prior_cost_grad")
     cost = torch.empty((B,), device=q.device, dtype=torch.float32)
     if accumulate_into is None:
-        gq, gqd, acc = torch.empty_like(q), torch.empty_like(q), 0
+        gq, gqd, acc = torch.empty_like(q, dtype=gio), torch.empty_like(q, dtype=gio), 0
     else:
         gq, gqd = accumulate_into
         acc = 1
-        if gq.shape != q.shape or gqd.shape != q.shape or gq.dtype != q.dtype or gqd.dtype != q.dtype or \
+        if gq.shape != q.shape or gqd.shape != q.shape or gq.dtype != gio or gqd.dtype != gio or \
                 not (gq.is_contiguous() and gqd.is_contiguous()):
-            raise ValueError("gp_prior_cost_grad: accumulate_into buffers must match q (shape, dtype, contiguous)")
+            raise ValueError("gp_prior_cost_grad: accumulate_into buffers must match q (shape, contiguous) and grad_dtype")
     with _on(q.device):
         check(lib().trk_gp_prior_cost_grad(q.data_ptr(), qd.data_ptr(), B, H, D, int(q.dtype == torch.float16), float(dt),
-                                           float(sigma), float(weight), cost.data_ptr(), gq.data_ptr(), gqd.data_ptr(), acc,
-                                           _stream(q)), "trk_gp_prior_cost_grad")
+                                           float(sigma), float(weight), cost.data_ptr(), gq.data_ptr(), gqd.data_ptr(), gcode, gs,
+                                           acc, _stream(q)), "trk_gp_prior_cost_grad")
     return cost, gq, gqd
 
 
@@ -820,26 +886,30 @@ class GPPriorPlan:
     C call (~3 us of host time instead of ~12 us through `gp_prior_cost_grad`).  q, qd (B,H,D) are read in place on every launch;
     results land in `cost` (B,), `gq`, `gqd` -- or are ADDED into `accumulate_into=(gq, gqd)`, e.g. a RolloutPlan's `gq`."""
 
-    def __init__(self, q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: float, weight: float = 1.0, accumulate_into=None):
+    def __init__(self, q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: float, weight: float = 1.0, accumulate_into=None,
+                 grad_dtype=None, grad_scale: float = 1.0):
         if q.device.type != "cuda" or qd.device != q.device:
             raise ValueError("GPPriorPlan: q and qd must be tensors on the same GPU (there is no CPU path)")
         if q.dim() != 3 or qd.shape != q.shape or q.dtype != qd.dtype or q.dtype not in (torch.float32, torch.float16) or \
                 not (q.is_contiguous() and qd.is_contiguous()):
             raise ValueError("GPPriorPlan: q, qd must be contiguous (batch, horizon, dof) tensors of the same fp32 / fp16 dtype")
         B, H, D = (int(v) for v in q.shape)
-        self.q, self.qd, self.device = q, qd, q.device
+        if accumulate_into is not None and grad_dtype is None:
+            grad_dtype = accumulate_into[0].dtype
+        gio, gcode, gs = _grad_mode(q.dtype == torch.float16, grad_dtype, grad_scale, "GPPriorPlan")
+        self.q, self.qd, self.device, self.grad_scale = q, qd, q.device, gs
         self.cost = torch.empty((B,), device=q.device, dtype=torch.float32)
         if accumulate_into is None:
-            self.gq, self.gqd, acc = torch.empty_like(q), torch.empty_like(q), 0
+            self.gq, self.gqd, acc = torch.empty_like(q, dtype=gio), torch.empty_like(q, dtype=gio), 0
         else:
             self.gq, self.gqd = accumulate_into
             acc = 1
             for g in (self.gq, self.gqd):
-                if g.numel() != q.numel() or g.dtype != q.dtype or g.device != q.device or not g.is_contiguous():
-                    raise ValueError("GPPriorPlan: accumulate_into buffers must match q (size, dtype, device, contiguous)")
+                if g.numel() != q.numel() or g.dtype != gio or g.device != q.device or not g.is_contiguous():
+                    raise ValueError("GPPriorPlan: accumulate_into buffers must match q (size, device, contiguous) and grad_dtype")
         self._fn = lib().trk_gp_prior_cost_grad
         self._args = (q.data_ptr(), qd.data_ptr(), B, H, D, int(q.dtype == torch.float16), float(dt), float(sigma), float(weight),
-                      self.cost.data_ptr(), self.gq.data_ptr(), self.gqd.data_ptr(), acc)
+                      self.cost.data_ptr(), self.gq.data_ptr(), self.gqd.data_ptr(), gcode, gs, acc)
 
     def launch(self, stream: Optional[int] = None) -> None:
         with _on(self.device):                  # free when the device is already current
@@ -1124,18 +1194,20 @@ def reduce_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Ten
 
 class PackedSums:
     """The exchange buffer of a batch-sharded planner, produced by ONE launch: `pack(out)` writes
-    [sum cost | sum_b cost(b, h) | sum_b gq(b, h, d)] of a RolloutPlan's latest evaluation into out (1 + H + H D floats)."""
+    [sum cost | sum_b cost(b, h) | sum_b gq(b, h, d)] of a RolloutPlan's latest evaluation into out (1 + H + H D floats, always
+    unscaled fp32: an fp16 / loss-scaled gradient is widened and divided by the plan's grad_scale).  traj_cost (B,): a per-trajectory
+    cost evaluated next to the rollout (the GP prior's) whose sum joins out[0]."""
 
-    def __init__(self, plan: "RolloutPlan", block_sums: torch.Tensor):
-        if plan.gq.dtype != torch.float32:
-            raise ValueError("PackedSums: fp32 plans only")
+    def __init__(self, plan: "RolloutPlan", block_sums: torch.Tensor, traj_cost: Optional[torch.Tensor] = None):
         self.B, self.H, self.D = plan.B, plan.H, int(plan.gq.shape[-1])
         self.size = 1 + self.H + self.H * self.D
         _check_buffer(block_sums, n_blocks(self.B * self.H), torch.float32, plan.device, "PackedSums(block_sums)", at_least=True)
+        _check_buffer(traj_cost, self.B, torch.float32, plan.device, "PackedSums(traj_cost)")
         nbytes = int(lib().trk_pack_sums_scratch_bytes(self.H, self.D))
         self._scratch = torch.zeros(nbytes // 4, device=plan.device, dtype=torch.float32)     # zeroed once: holds the ticket
-        self._args = (plan.cost.data_ptr(), plan.gq.data_ptr(), block_sums.data_ptr(), self.B, self.H, self.D, self._scratch.data_ptr())
-        self._keep = (plan, block_sums)
+        self._args = (plan.cost.data_ptr(), plan.gq.data_ptr(), int(plan.gq.dtype == torch.float16), float(plan.grad_scale),
+                      block_sums.data_ptr(), _ptr(traj_cost), self.B, self.H, self.D, self._scratch.data_ptr())
+        self._keep = (plan, block_sums, traj_cost)
         self.device = plan.device
 
     def pack(self, out: torch.Tensor, stream: Optional[int] = None) -> None:
@@ -1345,8 +1417,13 @@ class RolloutPlan:
     """Pre-bound fused-rollout launch: every argument is resolved once, so a step costs one ctypes call
     (a planner's inner loop re-evaluates the same buffers thousands of times)."""
 
-    def __init__(self, model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True):
+    def __init__(self, model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True, grad_dtype=None,
+                 grad_scale: float = 1.0):
         f16 = q.dtype == torch.float16
+        gio, gcode, gs = _grad_mode(f16, grad_dtype, grad_scale, "RolloutPlan")
+        if not f16 and gs != 1.0:
+            raise ValueError("RolloutPlan: grad_scale applies to float16 trajectories only")
+        self.grad_scale = gs
         q = q.contiguous() if (f16 and q.device.type == "cuda") else _dev_f32(q, "RolloutPlan(q)")
         if q.dim() != 3:
             raise ValueError("RolloutPlan: q must be (batch, horizon, dof)")
@@ -1357,11 +1434,11 @@ class RolloutPlan:
         kw = dict(device=q.device, dtype=q.dtype)
         self.link_pos = torch.empty((self.B, self.H, L, 3), **kw) if want_pos else None
         self.cost = torch.empty((self.B, self.H), device=q.device, dtype=torch.float32)
-        self.gq = torch.empty((self.B, self.H, D), **kw)
+        self.gq = torch.empty((self.B, self.H, D), device=q.device, dtype=gio)
         self._w = _abi.RolloutWeights(*[float(v) for v in weights])
         self._fn = lib().trk_rollout_cost_grad_f16 if f16 else lib().trk_rollout_cost_grad
         self._args = (model._h, cm._h, C.byref(self._w), q.data_ptr(), self.B, self.H, _ptr(self.link_pos),
-                      self.cost.data_ptr(), self.gq.data_ptr())
+                      self.cost.data_ptr(), self.gq.data_ptr()) + ((gcode, gs) if f16 else ())
         self.device = q.device
 
     def launch(self, cost_sum_ptr: Optional[int] = None, stream: Optional[int] = None) -> None:
