@@ -368,9 +368,9 @@ def main():
     nb = ops.n_blocks(B * H)
     block_sums = torch.zeros(nb, **ta)
     bs_ptr = block_sums.data_ptr()
-    # The planner's cadence: one exchange per `reduce_every` evaluations, fired in the middle of its interval (the sums are consumed
-    # a few evaluations later).  A run shorter than two intervals shrinks the interval to steps // 2, so that the driver's 20 timed
-    # steps contain two exchanges and `value` is never a kernel-only figure; `multi_gpu.collectives_in_timed_region` counts them.
+    # The planner's cadence: one exchange per `reduce_every` evaluations, fired after the first evaluation of its interval (the sums
+    # are consumed at the interval's end).  A run shorter than two intervals shrinks the interval to steps // 2, so that the driver's
+    # 20 timed steps contain two exchanges and `value` is never a kernel-only figure; `multi_gpu.collectives_in_timed_region` counts them.
     R = max(1, min(args.reduce_every, max(1, args.steps // 2)))
     # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
     n_slots = 64
@@ -435,7 +435,8 @@ def main():
     slot = [0]
 
     def run(pl, count, cadence):
-        """`count` steps; cadence > 0: one exchange per `cadence` steps of this call, fired mid-interval"""
+        """`count` steps; cadence > 0: one exchange per `cadence` steps of this call, fired after the FIRST step of its interval --
+        the sums are consumed at the interval's end, so the collective has the rest of the interval to complete behind the launches"""
         if graph is not None:
             assert count % args.graph == 0
             for _ in range(count // args.graph):
@@ -445,7 +446,7 @@ def main():
         fn = step_of(pl)
         for j in range(1, count + 1):
             fn(bs_ptr, s)
-            if cadence and j % cadence == (cadence + 1) // 2 % cadence:
+            if cadence and j % cadence == 1 % cadence:
                 reduce_slot(pl, slot[0] % n_slots)
                 slot[0] += 1
 

@@ -413,6 +413,11 @@ int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const T
                           float* link_pos_out, float* cost, float* gq, float* cost_block_sums,
                           trk_stream_t stream);
 
+/* 1 when trk_rollout_cost_grad(model, cm, w, ...) is served by a generated (model-specialised) kernel -- one whose baked
+ * collision template equals the cost model's link sets for the terms `w` selects --, 0 when the table-driven kernel would run
+ * (~10 x slower).  A deployment that must not fall back silently asserts this once after building its handles. */
+int trk_rollout_is_specialized(const TrkModel* model, const TrkCostModel* cm, const TrkRolloutWeights* w);
+
 /* Fused FK + boolean collision fields: q [batch*horizon, D] -> in_collision [batch*horizon] (1 = at least one selected field
  * has a signed distance below its margin).  No link positions, costs or gradients are written.
  * reference: PlanningTask.compute_collision tasks.py:131-133 -> _compute_collision_or_cost(field_type='occupancy') tasks.py:139-232

@@ -35,6 +35,22 @@ def test_committed_generated_sources_equal_the_generator_output(tmp_path):
         assert (tmp_path / n).read_text() == (committed / n).read_text(), f"{n} is stale: run __graft_entry__.build()"
 
 
+def test_every_bundled_urdf_has_an_ahead_of_time_unit():
+    """build() compiles a generated unit for EVERY URDF under data/urdf (the benchmark robots with their own collision models, the
+    others with codegen.default_template), so no bundled robot's FK family ever takes the table-driven kernels."""
+    from helpers import ROBOTS, URDF
+    files = {urdf for urdf, _ in codegen.SPEC_ROBOTS.values()}
+    assert files == {f"{r}.urdf" for r in ROBOTS}
+    assert {p.name for p in URDF.glob("*.urdf")} - files == {"panda_arm_no_gripper_grasped_object.urdf"}      # an attached-point unit's
+    hashes = set()
+    for ident, mh, tmpl in codegen.aot_units():
+        kin, t2 = codegen.template_for(ident)
+        assert codegen.model_hash(kin) == mh and t2.obj_links == tmpl.obj_links and 0 <= tmpl.ee_link < kin.n_links
+        assert tmpl.obj_links == sorted(set(tmpl.obj_links)) and all(0 <= i < kin.n_links for i in tmpl.obj_links)
+        hashes.add(mh)
+    assert len(hashes) == len(codegen.SPEC_ROBOTS)
+
+
 def test_model_hash_distinguishes_models():
     hashes = {codegen.model_hash(model(n)) for n in ("panda_arm_no_gripper", "panda_arm_hand", "ur10", "iiwa7")}
     assert len(hashes) == 4

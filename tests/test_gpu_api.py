@@ -1160,3 +1160,71 @@ def test_reduce_sum_long_vectors_are_deterministic_and_accurate():
             assert torch.equal(a, b)
             ref = v.double().sum().item()
             assert abs(a.item() - ref) <= 2e-6 * v.abs().double().sum().item()
+
+
+def test_no_bundled_robot_takes_the_table_driven_kernels_without_a_compiler(tmp_path):
+    """A box without hipcc and with an EMPTY run-time cache: every bundled URDF is served by an ahead-of-time unit of libtrk.so --
+    the FK family by the model alone, the fused rollout on the robot's shipped collision template --, the Panda task needs no
+    compile, and a template that has no unit is an ERROR under PlanningTask (not a silent 10 x slowdown) unless
+    TRK_ALLOW_TABLE_DRIVEN=1."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, warnings
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.environ["TRK_ROOT"], "tests"))
+import torch_robotics_amd as tra
+from torch_robotics_amd import codegen, jit, ops
+from torch_robotics_amd.costmodel import CostModelSpec
+assert not os.path.exists(jit.HIPCC) and not any(jit.JIT_DIR.glob("*.so"))
+TA = dict(device="cuda:0", dtype=torch.float32)
+env = tra.EnvSpheres3D(tensor_args=TA)
+for ident in codegen.SPEC_ROBOTS:
+    kin, tmpl = codegen.template_for(ident)
+    spec = CostModelSpec(n_links_in=kin.n_links)
+    spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+    spec.obj_link_margin = np.full(len(tmpl.obj_links), 0.1, np.float32)
+    spec.objects = [o.as_object() for o in env.obj_fixed_list]
+    spec.ee_link = tmpl.ee_link
+    spec.ee_target = np.eye(4, dtype=np.float32)
+    if tmpl.ee2_link >= 0:
+        spec.ee2_link, spec.ee2_target = tmpl.ee2_link, np.eye(4, dtype=np.float32)
+    h, cm = ops.ModelHandle(kin), ops.CostHandle(spec, "cuda:0")
+    assert h.specialized, ident
+    assert ops.rollout_is_specialized(h, cm, (0, 1, 1, 1)), ident
+    q = torch.zeros(2, 64, kin.n_dofs, **TA)
+    pos, cost, gq = ops.rollout_cost_grad(h, cm, (0, 1, 1, 1), q)
+    assert torch.isfinite(cost).all() and torch.isfinite(gq).all()
+    print("ok", ident)
+robot = tra.RobotPanda(tensor_args=TA)
+task = tra.PlanningTask(env=env, robot=robot, tensor_args=TA)
+q = robot.random_q(128)
+task.compute_collision_cost(q)                       # the shipped Panda template: no compile needed
+model, cm = task._fused_handles(torch.device("cuda:0"))
+assert ops.rollout_is_specialized(model, cm, (1, 1, 1, 0))
+# a robot declared with another collision model has no ahead-of-time unit: without a compiler that is an error ...
+robot2 = tra.RobotPanda(tensor_args=TA, num_interpolated_points_for_object_collision_checking=9)
+task2 = tra.PlanningTask(env=env, robot=robot2, tensor_args=TA)
+try:
+    task2.compute_collision_cost(q)
+    raise SystemExit("expected a RuntimeError")
+except RuntimeError as e:
+    assert "TRK_ALLOW_TABLE_DRIVEN" in str(e)
+# ... unless the caller accepts the table-driven kernels
+os.environ["TRK_ALLOW_TABLE_DRIVEN"] = "1"
+task3 = tra.PlanningTask(env=env, robot=robot2, tensor_args=TA)
+with warnings.catch_warnings(record=True) as rec:
+    warnings.simplefilter("always")
+    c3 = task3.compute_collision_cost(q)
+assert torch.isfinite(c3).all() and any("table-driven" in str(w.message) for w in rec)
+print("done")
+"""
+    root = str(ROOT) if "ROOT" in globals() else os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRK_JIT_DIR=str(tmp_path), TRK_HIPCC=str(tmp_path / "no-such-hipcc"), TRK_ROOT=root,
+               PATH=":".join(p for p in os.environ.get("PATH", "").split(":") if "rocm" not in p))
+    env.pop("TRK_ALLOW_TABLE_DRIVEN", None)
+    env.pop("TRK_NO_JIT", None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "done" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+    assert p.stdout.count("ok ") == len(codegen.SPEC_ROBOTS)

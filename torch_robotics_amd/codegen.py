@@ -1800,11 +1800,32 @@ def dual_panda_template(kin: KinModel) -> CollisionTemplate:
     return CollisionTemplate(obj_links=obj, self_pairs=pairs, ee_link=idx["left_ee_link"], ee2_link=idx["right_ee_link"])
 
 
-# robots that get a specialised kernel at build time: name -> (urdf file, template factory)
+def default_template(kin: KinModel) -> CollisionTemplate:
+    """The collision template of a bundled URDF that has no Robot class of its own (the reference ships RobotPanda only): object /
+    workspace collision on up to five leaf links plus the links at one half and one third of the file order, the last leaf
+    tracked as the end effector, no self pairs.  What `build()` compiles ahead of time for those robots, so that their FK family
+    (matrices, positions, Jacobian, reverse modes) and a fused rollout on this template never take the table-driven kernels;
+    any other template is one `jit.specialize` away."""
+    par = np.asarray(kin.parent, np.int64)
+    leaves = [i for i in range(kin.n_links) if not (par == i).any()]
+    obj = sorted(set(leaves[:5] + [kin.n_links // 2, kin.n_links // 3]))
+    return CollisionTemplate(obj_links=obj, self_pairs=[], ee_link=leaves[-1])
+
+
+# robots that get a specialised kernel at build time: name -> (urdf file, template factory).  Every URDF under data/urdf/ is
+# here: the benchmark robots with their own collision models, the others with `default_template`.
 SPEC_ROBOTS = {
     "panda": ("panda_arm_no_gripper.urdf", panda_template),
     "ur10_allegro": ("ur10_allegro.urdf", ur10_allegro_template),
     "dual_panda": ("dual_panda.urdf", dual_panda_template),
+    "iiwa7": ("iiwa7.urdf", default_template),
+    "ur10": ("ur10.urdf", default_template),
+    "allegro_hand": ("allegro_hand.urdf", default_template),
+    "panda_arm_hand": ("panda_arm_hand.urdf", default_template),
+    "iiwa7_allegro": ("iiwa7_allegro.urdf", default_template),
+    "shadow_hand": ("shadow_hand.urdf", default_template),
+    "tiago": ("tiago_dual_holobase_minimal_holonomic.urdf", default_template),
+    "hab_stretch": ("hab_stretch.urdf", default_template),
 }
 
 
@@ -1855,12 +1876,24 @@ TREE_PIPELINE = False     # measured on MI355X: dual Panda 23.5 -> 37.8 us, UR10
                           # (NL = 1) loses the ILP of the batched NL = 10 evaluation; kept switchable for robots with many links per DOF
 
 
+_template_cache: Dict[str, tuple] = {}
+
+
 def template_for(ident: str):
-    """(KinModel, CollisionTemplate) of a robot in SPEC_ROBOTS."""
+    """(KinModel, CollisionTemplate) of a robot in SPEC_ROBOTS (a fresh KinModel per call: callers may move its base)."""
     from .kinematics import URDF_DIR
     urdf, fn = SPEC_ROBOTS[ident]
     kin = KinModel.from_urdf(str(URDF_DIR / urdf))
     return kin, fn(kin)
+
+
+def aot_units():
+    """[(ident, model hash, CollisionTemplate)] of the ahead-of-time link units, computed once per process."""
+    if not _template_cache:
+        for ident in SPEC_ROBOTS:
+            kin, tmpl = template_for(ident)
+            _template_cache[ident] = (model_hash(kin), tmpl)
+    return [(k, v[0], v[1]) for k, v in _template_cache.items()]
 
 
 def generate_all(out_dir) -> List[str]:

@@ -1094,6 +1094,12 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
     return TRK_OK;
 }
 
+int trk_rollout_is_specialized(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w) {
+    if (!m || !cm || !w || !m->spec_enabled || cm->hdr.n_links_in != m->hdr.n_links) return 0;
+    const TrkRolloutWeights we = effective_weights(cm, *w);
+    return model_spec_for(m, cm, &we) ? 1 : 0;
+}
+
 int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fields, const float* q, int64_t batch, int32_t horizon,
                           float margin_override, uint8_t* in_collision, float* link_pos_ws, trk_stream_t stream) {
     int rc = check_model(m, "trk_rollout_collision");

@@ -32,8 +32,11 @@ _REPO_INCLUDE = _CSRC.parent.parent / "include"
 _loaded: Dict[str, C.CDLL] = {}
 
 
+HIPCC = os.environ.get("TRK_HIPCC", "/opt/rocm/bin/hipcc")      # the compiler driver of the run-time units
+
+
 def _compile_cmd(src: str, out: str):
-    return ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+    return [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
             "-Wno-unused-variable", "-Wno-pass-failed", "-ffp-contract=off", f"-I{_CSRC}", "-Xarch_device", "-fno-honor-nans",
             "-Xarch_device", "-mno-amdgpu-ieee", *GENFLAGS, "-shared", src, "-o", out, f"-L{_CSRC}", "-ltrk",
             "-Wl,-rpath,$ORIGIN/.." if JIT_DIR == _CSRC / "jit" else f"-Wl,-rpath,{_CSRC}"]
@@ -181,9 +184,8 @@ def has_matching_unit(kin: KinModel, spec) -> bool:
     for mh, tm in _loaded_templates.values():
         if mh == h and _serves(tm, want):
             return True
-    for ident in codegen.SPEC_ROBOTS:
-        k2, t2 = codegen.template_for(ident)
-        if codegen.model_hash(k2) == h and _serves(t2, want):
+    for _ident, mh, t2 in codegen.aot_units():
+        if mh == h and _serves(t2, want):
             return True
     return False
 

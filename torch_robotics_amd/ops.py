@@ -797,6 +797,11 @@ def rollout_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tens
             gq.reshape(tuple(lead) + (D,)))
 
 
+def rollout_is_specialized(model: ModelHandle, cm: CostHandle, weights) -> bool:
+    """True when `rollout_cost_grad(model, cm, weights, ...)` runs a generated kernel, False when the table-driven one would."""
+    return bool(lib().trk_rollout_is_specialized(model._h, cm._h, C.byref(_weights_struct(weights))))
+
+
 def rollout_collision(model: ModelHandle, cm: CostHandle, fields: int, q: torch.Tensor, margin: Optional[float] = None) -> torch.Tensor:
     """Fused FK + boolean collision fields: q (B,H,D) or (N,D) -> bool (B,H) / (N,).  One launch, one byte per sample out
     (`PlanningTask.compute_collision`, tasks.py:131-133); `margin=None` uses the fields' own margins."""

@@ -162,10 +162,18 @@ class PlanningTask(Task):
                             jit.specialize_points(kin, pl, po, spec)
                     elif not jit.has_matching_unit(kin, spec):
                         jit.specialize_for_cost_spec(kin, spec)
-                except Exception as e:                 # no hipcc / compile error: the table-driven kernels still serve
-                    import warnings
+                except Exception as e:
+                    # No compiler / a compile error.  The table-driven kernels compute the same function ~10 x slower (7 % of the
+                    # HBM roofline), so running them silently is a performance bug: it is an error unless the caller allows it.
                     self._jit_failed = True
-                    warnings.warn(f"run-time kernel specialisation skipped ({type(e).__name__}: {e}); using the table-driven kernels")
+                    if os.environ.get("TRK_ALLOW_TABLE_DRIVEN", "0") != "1":
+                        raise RuntimeError(
+                            f"PlanningTask: no generated kernel serves this robot / collision model and compiling one failed "
+                            f"({type(e).__name__}: {e}).  Set TRK_ALLOW_TABLE_DRIVEN=1 (or auto_specialize=False / TRK_NO_JIT=1) to run "
+                            f"the ~10 x slower table-driven kernels instead.") from e
+                    import warnings
+                    warnings.warn(f"run-time kernel specialisation failed ({type(e).__name__}: {e}); TRK_ALLOW_TABLE_DRIVEN=1: "
+                                  f"using the table-driven kernels")
         return self._fused[0], self._fused[1]
 
     def specialize(self, verbose: bool = False):
