@@ -131,6 +131,19 @@ class Oracle:
                                             _p(vel), _p(loss), _p(grad), _p(valid))
         return loss, grad, valid.astype(bool)
 
+    def ik_gn_step(self, link, H_target, lower, upper, q, damping=1e-4, lm_gain=0.1, step_scale=1.0, prec="f64"):
+        """One damped Gauss-Newton IK iteration (build-defined; oracle_impl.inc orc_ik_gn_step): -> (q_new, err of q as passed)."""
+        npdt, ct, suf = _dt(prec)
+        D = self.model.n_dofs
+        q = np.ascontiguousarray(q, npdt).reshape(-1, D).copy()
+        n = q.shape[0]
+        Ht = np.ascontiguousarray(H_target, npdt).reshape(-1, 16)
+        lo, hi = np.ascontiguousarray(lower, npdt), np.ascontiguousarray(upper, npdt)
+        err = np.empty(n, npdt)
+        getattr(lib(), "orc_ik_gn_step" + suf)(C.byref(self.kd), C.c_int(int(link)), _p(Ht), C.c_int(int(Ht.shape[0] > 1)), _p(lo), _p(hi),
+                                               ct(damping), ct(lm_gain), ct(step_scale), C.c_int64(n), _p(q), _p(err))
+        return q, err
+
     @staticmethod
     def rotmat_to_quat(R, prec="f32"):
         npdt, _, suf = _dt(prec)

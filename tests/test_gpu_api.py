@@ -1227,4 +1227,5 @@ print("done")
     env.pop("TRK_NO_JIT", None)
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "done" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+    from torch_robotics_amd import codegen
     assert p.stdout.count("ok ") == len(codegen.SPEC_ROBOTS)
