@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Batched inverse kinematics of the Panda by damped Gauss-Newton (Levenberg-Marquardt) on the geometric Jacobian -- what the
-reference's `compute_forward_kinematics_and_geometric_jacobian` (robot_tree.py:218-248) is for, taken one step further: per
-iteration one Jacobian kernel (`trk_fk_jacobian`: position, quaternion, lin_jac, ang_jac of the end effector), one normal-equation
-kernel (`trk_jtj`: J^T J and J^T r per sample) and a batched 7 x 7 solve.  Converges in ~10 iterations where the Adam loop of
-examples/inverse_kinematics.py takes hundreds.  Needs the MI355X: there is no CPU path.
+reference's `compute_forward_kinematics_and_geometric_jacobian` (robot_tree.py:218-248) is for, taken one step further.
+`trk_ik_gn_steps` runs K iterations per launch: FK, Jacobian, pose residual, J^T J + lambda I, Cholesky and the clamped step per
+lane in registers (`--two-launch` runs the round-3 form instead: `trk_fk_jacobian` + `trk_jtj` and ~25 small torch ops for the
+residual, ~236 us per iteration, host-bound).  Converges in ~10 iterations where the Adam loop of examples/inverse_kinematics.py
+takes hundreds.  Needs the MI355X: there is no CPU path.
 
-    python examples/gauss_newton_ik.py [--batch 4096]
+    python examples/gauss_newton_ik.py [--batch 4096] [--two-launch]
 """
 import argparse
 import sys
@@ -35,36 +36,45 @@ def pose_residual(pos, quat_wxyz, H_target):
     return torch.cat([dp, rotvec], -1)
 
 
-def main(batch_size=4096, device="cuda:0", max_iters=40, damping=1e-4, verbose=True, mfma=False):
+def main(batch_size=4096, device="cuda:0", max_iters=40, damping=1e-4, verbose=True, mfma=False, two_launch=False, per_call=10):
     torch.manual_seed(0)
     tree = DifferentiableFrankaPanda(gripper=False, device=device)
     lo, hi, _, _ = tree.get_joint_limit_array()
     lo, hi = (torch.as_tensor(a, device=device, dtype=torch.float32) for a in (lo, hi))
     # a reachable target: the end-effector pose of a random configuration
     q_star = lo + torch.rand(1, 7, device=device) * (hi - lo)
-    H_target = tree.compute_forward_kinematics_all_links(q_star, link_list=["ee_link"])[0, 0]
-    q = lo + torch.rand(batch_size, 7, device=device) * (hi - lo)
+    H_target = tree.compute_forward_kinematics_all_links(q_star, link_list=["ee_link"])[0, 0].contiguous()
+    q = (lo + torch.rand(batch_size, 7, device=device) * (hi - lo)).contiguous()
     link = tree._name_to_idx_map["ee_link"]
-    def step(q):
+
+    def step_two_launch(q):
         pos, quat, lin, ang = ops.fk_jacobian(tree._handle, q, None, link)
         r = pose_residual(pos, quat, H_target)
         lam = damping + 0.1 * (r * r).sum(-1)             # Levenberg-Marquardt: damp in proportion to the squared error
         _, _, dq = ops.jtj(lin, ang, r, mfma=mfma, damping=lam, solve=True)     # the 7 x 7 solve happens inside the kernel
         return torch.minimum(torch.maximum(q + dq, lo), hi)
 
-    step(q)                                               # first use of every kernel (code-object load): not part of the timing
+    def run(q, iters):
+        if two_launch:
+            for _ in range(iters):
+                q = step_two_launch(q)
+            return q
+        for k0 in range(0, iters, per_call):              # K iterations per launch, in place
+            ops.ik_gn_steps(tree._handle, link, H_target, lo, hi, q, min(per_call, iters - k0), damping=damping, lm_gain=0.1)
+        return q
+
+    run(q.clone(), 1)                                     # first use of every kernel (code-object load): not part of the timing
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for it in range(max_iters):
-        q = step(q)
+    q = run(q, max_iters)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     H_ee = tree.compute_forward_kinematics_all_links(q, link_list=["ee_link"])[:, 0]
     err = SE3_distance(H_ee, H_target)
     ok = int((err < 1e-3).sum())
     if verbose:
-        print(f"{max_iters} Gauss-Newton iterations x {batch_size} problems in {elapsed * 1e3:.1f} ms "
-              f"({elapsed / max_iters * 1e6:.0f} us per iteration)")
+        print(f"{max_iters} Gauss-Newton iterations x {batch_size} problems in {elapsed * 1e3:.2f} ms "
+              f"({elapsed / max_iters * 1e6:.1f} us per iteration, {'two launches + torch ops' if two_launch else 'one kernel'})")
         print(f"converged (SE(3) distance < 1e-3): {ok}/{batch_size}; median error {float(err.median()):.2e}")
     return q, err
 
@@ -72,6 +82,7 @@ def main(batch_size=4096, device="cuda:0", max_iters=40, damping=1e-4, verbose=T
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--mfma", action="store_true", help="use the matrix-core kernel of trk_jtj")
+    ap.add_argument("--mfma", action="store_true", help="--two-launch: use the matrix-core kernel of trk_jtj")
+    ap.add_argument("--two-launch", action="store_true", help="the round-3 form: trk_fk_jacobian + trk_jtj + torch ops per iteration")
     a = ap.parse_args()
-    main(batch_size=a.batch, mfma=a.mfma)
+    main(batch_size=a.batch, mfma=a.mfma, two_launch=a.two_launch)

@@ -206,6 +206,22 @@ int trk_ik_steps(const TrkModel* model, int32_t link, const float* H_target, int
                  const float* upper, float w_joint_limits, float se3_eps, float lr, int32_t first_step, int32_t n_steps,
                  int64_t n, float* q, float* adam_m, float* adam_v, float* loss, uint8_t* valid, trk_stream_t stream);
 
+/* K damped Gauss-Newton (Levenberg-Marquardt) iterations of the batched IK in ONE launch -- BUILD-DEFINED: the reference's loop is
+ * Adam (DifferentiableTree.inverse_kinematics robot_tree.py:303-384, served by trk_ik_steps); a Newton step is what its geometric
+ * Jacobian (compute_forward_kinematics_and_geometric_jacobian robot_tree.py:218-248) is for.  Per sample and iteration:
+ *   stateful FK + geometric Jacobian J (6 x D, the reference's column rule) of `link` at q;
+ *   r = [p* - p ; rotation vector of R* R^T]  (world frame);   lambda = damping + lm_gain |r|^2;
+ *   (J^T J + lambda I) dq = J^T r  (Cholesky);   q <- clamp(q + step_scale dq, lower, upper).
+ * The Jacobian, the normal equations and their factor never leave the lane's registers (the two-launch form trk_fk_jacobian +
+ * trk_jtj moves 416 bytes per sample and iteration).  H_target: DEVICE [16] (per_sample_target = 0) or [n,16]; lower / upper:
+ * DEVICE [D]; q [n,D] in place; err [n] / valid [n] (nullable): SE3_distance(w_pos = w_rot = 1) of q AS PASSED IN and
+ * `err < se3_eps and lower <= q <= upper` -- the metric and test of ik_termination (robot_tree.py:419-442), so that a caller
+ * testing every K iterations sees what trk_ik_steps would report.  Checked against oracle/oracle_impl.inc: orc_ik_gn_step.
+ * Served by generated kernels only (robots up to 9 DOF, the link a unit tracks): TRK_ERR_UNSUPPORTED otherwise. */
+int trk_ik_gn_steps(const TrkModel* model, int32_t link, const float* H_target, int32_t per_sample_target, const float* lower,
+                    const float* upper, float damping, float lm_gain, float step_scale, float se3_eps, int32_t n_steps, int64_t n,
+                    float* q, float* err, uint8_t* valid, trk_stream_t stream);
+
 /* reference: rotation_matrix_to_q quaternion.py:135-166 (via link_quat_from_link_tensor
  * geometrics/utils.py:341-344).  R: n matrices, `stride` floats apart, 3x3 block with row
  * pitch `row_pitch` (9/3 for packed rotations, 16/4 for 4x4 transforms).  -> quat_wxyz [n,4]. */

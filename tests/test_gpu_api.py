@@ -1135,14 +1135,15 @@ def test_interpolated_points_with_a_grasped_object(oracle_lib):
 
 
 def test_gauss_newton_ik_example_converges():
-    """examples/gauss_newton_ik.py: trk_fk_jacobian + trk_jtj + a batched solve reach a reachable pose from random starts."""
+    """examples/gauss_newton_ik.py: the one-launch Gauss-Newton kernel (trk_ik_gn_steps) and the two-launch form (trk_fk_jacobian +
+    trk_jtj + torch ops) reach a reachable pose from random starts."""
     import importlib.util
     from pathlib import Path
     spec = importlib.util.spec_from_file_location("gn_ik", Path(__file__).resolve().parent.parent / "examples" / "gauss_newton_ik.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    for mfma in (False, True):
-        q, err = mod.main(batch_size=512, max_iters=40, verbose=False, mfma=mfma)
+    for kw in (dict(), dict(two_launch=True), dict(two_launch=True, mfma=True)):      # trk_ik_gn_steps; the two-launch form, both jtj kernels
+        q, err = mod.main(batch_size=512, max_iters=40, verbose=False, **kw)
         assert q.shape == (512, 7) and torch.isfinite(err).all()
         # from uniformly random starts about half of the problems reach the pose (the projection onto the Panda's tight joint
         # limits traps the rest); the Adam loop of the reference needs hundreds of iterations for the same

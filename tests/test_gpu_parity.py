@@ -587,6 +587,73 @@ def test_ik_step_vs_reference_adam(ops, oracle_lib):
         assert np.abs(q.cpu().numpy() - q64).max() < 2e-4
 
 
+def test_gauss_newton_ik_steps_vs_fp64_oracle(ops, oracle_lib):
+    """trk_ik_gn_steps (build-defined): every iteration == the fp64 oracle's damped Gauss-Newton step (stateful FK + the reference's
+    geometric Jacobian, pose residual, J^T J + lambda I, Cholesky, clamped step) on the SAME configurations; K iterations in one
+    launch == K launches, bit for bit; err / valid are ik_termination's metric for q as passed in; the reference's IK problem
+    (tests/golden/ik_panda.npz: its q0, targets and shrunk limits) converges."""
+    g = gold("ik_panda")
+    m = model("panda_arm_no_gripper")
+    h, o = ops.ModelHandle(m), oracle_lib.Oracle(m)
+    ee = m.name_to_idx["ee_link"]
+    lo, hi = g["lower"], g["upper"]
+    for tag, Ht in (("per_sample", g["H_target"]), ("single", g["H_target"][0])):
+        q = dev(g["q0"]).clone()
+        err = torch.empty(48, device=DEV); valid = torch.empty(48, device=DEV, dtype=torch.uint8)
+        for it in range(6):
+            q_in = q.cpu().numpy().astype(np.float64)
+            q64, e64 = o.ik_gn_step(ee, np.asarray(Ht, np.float64), lo, hi, q_in, 1e-4, 0.1, 1.0, "f64")
+            ops.ik_gn_steps(h, ee, dev(Ht), dev(lo), dev(hi), q, 1, err=err, valid=valid)
+            dq = np.abs(q64 - q_in)
+            # the step solves a system of condition <= (|J|^2 + lambda) / lambda in fp32: relative to the step, plus rounding of q
+            assert (np.abs(q.cpu().numpy() - q64) <= 1e-4 + 5e-3 * dq).all(), (tag, it)
+            assert rel_err(err.cpu().numpy(), e64) < 2e-5
+            inside = ((q_in >= lo) & (q_in <= hi)).all(-1)
+            sure = np.abs(e64 - 0.1) > 1e-5
+            np.testing.assert_array_equal(valid.cpu().numpy().astype(bool)[sure], ((e64 < 0.1) & inside)[sure])
+        for K in (3, 17):
+            qa, qb = dev(g["q0"]).clone(), dev(g["q0"]).clone()
+            ea, eb = torch.empty(48, device=DEV), torch.empty(48, device=DEV)
+            e0 = None
+            for it in range(K):
+                ops.ik_gn_steps(h, ee, dev(Ht), dev(lo), dev(hi), qa, 1, err=ea)
+                e0 = ea.clone() if it == 0 else e0
+            ops.ik_gn_steps(h, ee, dev(Ht), dev(lo), dev(hi), qb, K, err=eb)
+            assert torch.equal(qa, qb) and torch.equal(e0, eb)
+    # convergence on the reference's problem: 40 iterations, then the termination metric of the result
+    q = dev(g["q0"]).clone()
+    err = torch.empty(48, device=DEV); valid = torch.empty(48, device=DEV, dtype=torch.uint8)
+    ops.ik_gn_steps(h, ee, dev(g["H_target"]), dev(lo), dev(hi), q, 40)
+    ops.ik_gn_steps(h, ee, dev(g["H_target"]), dev(lo), dev(hi), q.clone(), 1, err=err, valid=valid)
+    Hq = o.fk(q.cpu().numpy().astype(np.float64), "f64")[:, ee]
+    e_chk = np.array([1 - (np.trace(Hq[i, :3, :3].T @ g["H_target"][i, :3, :3].astype(np.float64)) - 1) / 2 +
+                      np.linalg.norm(Hq[i, :3, 3] - g["H_target"][i, :3, 3]) for i in range(48)])
+    assert rel_err(err.cpu().numpy(), e_chk) < 1e-4
+    # random targets inside shrunk limits: about half of the 48 problems are solved from their q0 by a clamped LM iteration (the
+    # others sit on a joint limit); the fp64 oracle iterated the same way says how many -- fp32 may differ on a few borderline ones
+    q64 = g["q0"].astype(np.float64)
+    for it in range(40):
+        q64, _ = o.ik_gn_step(ee, g["H_target"].astype(np.float64), lo, hi, q64, 1e-4, 0.1, 1.0, "f64")
+    _, e64 = o.ik_gn_step(ee, g["H_target"].astype(np.float64), lo, hi, q64, 1e-4, 0.1, 1.0, "f64")
+    n64 = int((e64 < 0.1).sum())
+    assert n64 >= 20 and abs(int(valid.sum()) - n64) <= 4 and int((e_chk < 1e-3).sum()) >= int((e64 < 1e-3).sum()) - 4
+    # ragged sizes, random targets, other damping parameters, a base pose
+    rng = np.random.default_rng(31)
+    m.set_base_pose(np.array([0.1, -0.2, 0.05, 0.9238795, 0.0, 0.3826834, 0.0], np.float32))
+    h2, o2 = ops.ModelHandle(m), oracle_lib.Oracle(m)
+    for n in (1, 63, 65, 500):
+        q0 = (lo + rng.random((n, 7)) * (hi - lo)).astype(np.float32)
+        Ht = o2.fk((lo + rng.random((n, 7)) * (hi - lo)).astype(np.float64), "f64")[:, ee].astype(np.float32)
+        q64, e64 = o2.ik_gn_step(ee, Ht.astype(np.float64), lo, hi, q0.astype(np.float64), 1e-3, 0.02, 0.7, "f64")
+        q = dev(q0).clone(); err = torch.empty(n, device=DEV)
+        ops.ik_gn_steps(h2, ee, dev(Ht), dev(lo), dev(hi), q, 1, damping=1e-3, lm_gain=0.02, step_scale=0.7, err=err)
+        assert (np.abs(q.cpu().numpy() - q64) <= 1e-4 + 5e-3 * np.abs(q64 - q0)).all() and rel_err(err.cpu().numpy(), e64) < 2e-5
+    m.set_base_pose(np.array([0, 0, 0, 1, 0, 0, 0], np.float32))
+    # a link no unit tracks: refused loudly, never a silent other path
+    with pytest.raises(Exception, match="no generated unit"):
+        ops.ik_gn_steps(h, 5, dev(g["H_target"]), dev(lo), dev(hi), dev(g["q0"]).clone(), 1)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # points fixed in link frames (grasped-object points, per-link spheres)
 # ---------------------------------------------------------------------------------------------------------------------

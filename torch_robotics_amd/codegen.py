@@ -1050,6 +1050,129 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.extend(E.lines)
         out.append("")
 
+    # ---- Gauss-Newton / Levenberg-Marquardt IK on the unit's tracked link (trk_ik_gn_steps; BUILD-DEFINED: the reference's loop is
+    # Adam, robot_tree.py:303-384, its geometric Jacobian :218-248 is what a Newton step is made of; oracle: orc_ik_gn_step).  Per
+    # iteration and lane: stateful FK of the links that matter, the Jacobian columns of the reference's rule, the pose residual,
+    # J^T J + lambda I and J^T r as straight-line FMAs on the symbolic columns (structural zeros fold away), a Cholesky solve in
+    # registers, the clamped step.  The Jacobian never leaves the registers -- the two-launch form (trk_fk_jacobian + trk_jtj)
+    # writes and re-reads 416 bytes per sample and iteration.
+    ikgn_cols = [i for i in range(1, L) if int(kin.dof_idx[i]) >= 0 and int(kin.jac_axis[i]) >= 0 and tmpl.ee_link >= 0 and
+                 (i - 1) <= int(kin.joint_list_idx[tmpl.ee_link])]
+    ikgn_ok = tmpl.ee_link >= 0 and D <= 9 and len(ikgn_cols) > 0
+    for base_identity in ((True, False) if ikgn_ok else ()):
+        E = Emitter()
+        kname = "k_ikgn_bi" if base_identity else "k_ikgn_bg"
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(IkGnArgs A) {{")
+        E.raw("    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * D];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw("    float* lds = lds_all + wave * (TRK_WAVE * D);")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        E.raw("    float Ht[12];")
+        E.raw("    {")
+        E.raw("        const float* tp = A.H_target + (A.per_sample ? min(base + lane, A.n - 1) * 16 : 0);")
+        E.raw("#pragma unroll")
+        E.raw("        for (int k = 0; k < 12; ++k) Ht[k] = tp[k];")
+        E.raw("    }")
+        E.raw("    float lo[D], hi[D];")
+        E.raw("#pragma unroll")
+        E.raw("    for (int d = 0; d < D; ++d) { lo[d] = cptr(A.lower)[d]; hi[d] = cptr(A.upper)[d]; }")
+        E.raw("    float err0 = 0.0f;")
+        E.raw("    bool ok0 = false;")
+        E.raw("    for (int it = 0; it < A.n_steps; ++it) {")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        need = set()
+        for leaf in [tmpl.ee_link] + ikgn_cols:
+            a = leaf
+            while a >= 0 and a not in need:
+                need.add(a); a = int(kin.parent[a])
+        rot_dofs = []
+        for i in range(1, L):
+            jt, d = int(kin.joint_type[i]), int(kin.dof_idx[i])
+            if jt == JOINT_FIXED or i not in need:
+                continue
+            if kin.sf_clamp[i]:                  # rigid_body.py:218-224: the stateful path clamps whenever limits exist
+                E.raw(f"    const float qh{d} = __builtin_amdgcn_fmed3f(q[{d}], {flit(kin.lower[i])}, {flit(kin.upper[i])});")
+            else:
+                E.raw(f"    const float qh{d} = q[{d}];")
+            if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS):
+                rot_dofs.append(d)
+        for d in rot_dofs:
+            E.raw(f"    float sn{d}, cs{d};")
+        for a, b in zip(rot_dofs[0::2], rot_dofs[1::2]):
+            E.raw(f"    trk_sincos2(qh{a}, qh{b}, &sn{a}, &cs{a}, &sn{b}, &cs{b});")
+        if len(rot_dofs) % 2:
+            d = rot_dofs[-1]
+            E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
+        for p in range(1, L):
+            i = int(kin.order[p])
+            if i in need:
+                _emit_fk_link(E, kin, i, R, t, passv, snap, stateful=True)
+        ee = tmpl.ee_link
+        E.raw(f"    const float eR[9] = {{{', '.join(E.expr(R[ee][r][c]) for r in range(3) for c in range(3))}}};")
+        E.raw(f"    const float et[3] = {{{', '.join(E.expr(t[ee][k]) for k in range(3))}}};")
+        # residual r = [p* - p ; rotvec(R* R^T)]
+        E.raw("    float Re[9];")
+        E.raw("#pragma unroll")
+        E.raw("    for (int a = 0; a < 3; ++a)")
+        E.raw("#pragma unroll")
+        E.raw("        for (int b = 0; b < 3; ++b) Re[3 * a + b] = fmaf(Ht[4 * a], eR[3 * b], fmaf(Ht[4 * a + 1], eR[3 * b + 1], Ht[4 * a + 2] * eR[3 * b + 2]));")
+        E.raw("    float r6[6] = {Ht[3] - et[0], Ht[7] - et[1], Ht[11] - et[2], 0.0f, 0.0f, 0.0f};")
+        E.raw("    trk_rotvec(Re, r6 + 3);")
+        E.raw("    if (it == 0) {          // what the caller learns about q as passed in: the metric of ik_termination (robot_tree.py:419-442)")
+        E.raw("        float gR_[9], gt_[3];")
+        E.raw("        err0 = ee_cost_eval(eR, et, Ht, 1.0f, 1.0f, 0, gR_, gt_);")
+        E.raw("        ok0 = err0 < A.se3_eps;")
+        E.raw("#pragma unroll")
+        E.raw("        for (int d = 0; d < D; ++d) ok0 = ok0 && (q[d] >= lo[d]) && (q[d] <= hi[d]);")
+        E.raw("    }")
+        E.raw("    const float lam = fmaf(A.lm_gain, fmaf(r6[0], r6[0], fmaf(r6[1], r6[1], fmaf(r6[2], r6[2], fmaf(r6[3], r6[3], fmaf(r6[4], r6[4], r6[5] * r6[5]))))), A.damping);")
+        # symbolic Jacobian columns: rows 0-2 linear z x (p_ee - p_joint), rows 3-5 angular z
+        col: Dict[int, List[S]] = {}
+        pe = [S(1.0, f"et[{k}]") for k in range(3)]
+        for i in ikgn_cols:
+            d, ax = int(kin.dof_idx[i]), int(kin.jac_axis[i])
+            z = [E.named(R[i][r][ax]) for r in range(3)]
+            rel = [E.named(E.lincomb([(pe[k], ONE), (t[i][k], S(-1.0))])) for k in range(3)]
+            lin = [E.named(v) for v in E.cross(z, rel)]
+            col[d] = lin + z
+        rr = [S(1.0, f"r6[{k}]") for k in range(6)]
+        for d in range(D):
+            if d in col:
+                E.raw(f"    const float g{d}_ = {E.expr(E.lincomb([(col[d][k], rr[k]) for k in range(6)]))};")
+        E.raw(f"    float An[{D * (D + 1) // 2}], gn[D];")
+        for i in range(D):
+            E.raw(f"    gn[{i}] = {f'g{i}_' if i in col else '0.0f'};")
+            for j in range(i + 1):
+                idx = i * (i + 1) // 2 + j
+                if i in col and j in col:
+                    a = E.lincomb([(col[i][k], col[j][k]) for k in range(6)])
+                    E.raw(f"    An[{idx}] = {E.expr(a)}{' + lam' if i == j else ''};")
+                else:
+                    E.raw(f"    An[{idx}] = {'lam' if i == j else '0.0f'};")
+        E.raw("    trk_chol_solve<D>(An, gn);")
+        E.raw("#pragma unroll")
+        E.raw("    for (int d = 0; d < D; ++d) q[d] = __builtin_amdgcn_fmed3f(fmaf(A.step_scale, gn[d], q[d]), lo[d], hi[d]);")
+        E.raw("    }")
+        E.raw("    if (lane < rows) {")
+        E.raw("        if (A.err) A.err[base + lane] = err0;")
+        E.raw("        if (A.valid) A.valid[base + lane] = ok0 ? 1 : 0;")
+        E.raw("    }")
+        E.raw("    spec_store_gq<D>(A.q, base, rows, lane, lds, q);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
     # ---- stateful FK + geometric Jacobian of ONE link (trk_fk_jacobian; robot_tree.py:136-190, 218-248): the walk unrolled
     # with the stateful path's quirks (clamp wherever limits exist, rotation about the axis with its sign ignored); every
     # joint that can receive a column leaves a record (z, p) in LDS, the target link (a run-time argument) is picked by a
@@ -1235,6 +1358,12 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("    if (base_identity) hipLaunchKernelGGL(k_ik_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    else hipLaunchKernelGGL(k_ik_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("}")
+    if ikgn_ok:
+        out.append("static void launch_ikgn(const IkGnArgs& a, int base_identity, hipStream_t st) {")
+        out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+        out.append("    if (base_identity) hipLaunchKernelGGL(k_ikgn_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    else hipLaunchKernelGGL(k_ikgn_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("}")
     out.append("static void launch_jac(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
     if direct:
@@ -1250,7 +1379,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
                f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}, "
                f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1, {'launch_fields' if fields_ok else 'nullptr'}, "
-               f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW}};")
+               f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW, {'launch_ikgn' if ikgn_ok else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"

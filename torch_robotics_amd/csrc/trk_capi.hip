@@ -59,7 +59,7 @@ std::vector<const SpecEntry*>& spec_registry() { static std::vector<const SpecEn
 
 int trk_spec_register(const SpecEntry* e) {
     // the first four fields are the layout stamp in every version of SpecEntry; nothing else is read before they match
-    if (!e || e->spec_abi_version != TRK_SPEC_ABI_VERSION || e->sizeof_args != sizeof(SpecArgs) + sizeof(IkArgs) ||
+    if (!e || e->spec_abi_version != TRK_SPEC_ABI_VERSION || e->sizeof_args != sizeof(SpecArgs) + sizeof(IkArgs) + sizeof(IkGnArgs) ||
         e->sizeof_entry != sizeof(SpecEntry) || e->sizeof_cost_hdr != sizeof(DevCostHdr)) {
         fprintf(stderr, "libtrk: refusing a generated unit compiled against another SpecArgs/SpecEntry layout "
                         "(stale JIT cache?) -- it will not be dispatched\n");
@@ -649,6 +649,38 @@ int trk_ik_steps(const TrkModel* m, int32_t link, const float* H_target, int32_t
                            (hipStream_t)stream);
         TRK_HIP(hipGetLastError());
     }
+    return TRK_OK;
+}
+
+int trk_ik_gn_steps(const TrkModel* m, int32_t link, const float* H_target, int32_t per_sample_target, const float* lower,
+                    const float* upper, float damping, float lm_gain, float step_scale, float se3_eps, int32_t n_steps, int64_t n,
+                    float* q, float* err, uint8_t* valid, trk_stream_t stream) {
+    int rc = check_model(m, "trk_ik_gn_steps");
+    if (rc) return rc;
+    if (link < 0 || link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, "trk_ik_gn_steps: link out of range");
+    if (n < 0 || n_steps < 1 || !H_target || !lower || !upper || (n > 0 && !q) || !(damping >= 0.0f) || !(lm_gain >= 0.0f) ||
+        !(damping + lm_gain > 0.0f) || !std::isfinite(step_scale))
+        return fail(TRK_ERR_INVALID_ARG, "trk_ik_gn_steps: bad argument (damping, lm_gain >= 0 and not both zero)");
+    if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    // the Jacobian, the normal equations and their factor live in one lane's registers: a generated kernel only, for the link a
+    // unit tracks (any link of any robot up to 9 DOF is one jit.specialize away)
+    const SpecEntry* gen = nullptr;
+    if (m->spec_enabled)
+        for (const SpecEntry* e : spec_registry())
+            if (e->n_points == 0 && e->model_hash == m->hash && e->n_links == m->hdr.n_links && e->n_dofs == m->hdr.n_dofs &&
+                e->launch_ikgn && e->ee_link == link) { gen = e; break; }
+    if (!gen)
+        return fail(TRK_ERR_UNSUPPORTED, "trk_ik_gn_steps: no generated unit of this model tracks this link (robots up to 9 DOF: "
+                                         "torch_robotics_amd.jit.specialize(kin, obj_links, ee_link=link)); the two-launch form is "
+                                         "trk_fk_jacobian + trk_jtj");
+    IkGnArgs a{};
+    std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+    std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+    a.H_target = H_target; a.per_sample = per_sample_target; a.n_steps = n_steps; a.lower = lower; a.upper = upper;
+    a.damping = damping; a.lm_gain = lm_gain; a.step_scale = step_scale; a.se3_eps = se3_eps; a.n = n;
+    a.q = q; a.err = err; a.valid = valid;
+    gen->launch_ikgn(a, base_is_identity(m), (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
     return TRK_OK;
 }
 

@@ -850,6 +850,56 @@ __device__ __forceinline__ void frame_quat_wxyz(const float* R, float* out) {
     out[0] = qw * sc; out[1] = qx * sc; out[2] = qy * sc; out[3] = qz * sc;
 }
 
+// Rotation vector of a rotation matrix Re (row-major 3x3) for the Gauss-Newton IK residual (BUILD-DEFINED, oracle_impl.inc
+// orc_ik_gn_step): quaternion (w, v) by Frame.get_quaternion's trace method, sign chosen so that w >= 0, then
+// v / |v| * 2 atan2(|v|, w) -- well conditioned up to a rotation of pi, where |v| -> 1.
+__device__ __forceinline__ void trk_rotvec(const float* Re, float* out) {
+    float qe[4];
+    frame_quat_wxyz(Re, qe);
+    const float sgn = qe[0] < 0.0f ? -1.0f : 1.0f;
+    const float w = __builtin_fminf(qe[0] * sgn, 1.0f);
+    const float vx = qe[1] * sgn, vy = qe[2] * sgn, vz = qe[3] * sgn;
+    const float nv = sqrtf(fmaf(vx, vx, fmaf(vy, vy, vz * vz)));
+    const float sc = 2.0f * atan2f(nv, w) / __builtin_fmaxf(nv, 1e-12f);
+    out[0] = vx * sc; out[1] = vy * sc; out[2] = vz * sc;
+}
+
+// (A + 0) x = g for a symmetric positive definite D x D matrix held by ONE lane in registers: A = the lower triangle, packed
+// row-major (A[i (i + 1) / 2 + j], j <= i), overwritten by its Cholesky factor; g is overwritten by the solution.  Every loop has
+// compile-time bounds, so for D <= 9 the whole factorisation is straight-line register code (D = 7: 28 + 7 registers).
+template <int D>
+__device__ __forceinline__ void trk_chol_solve(float (&A)[D * (D + 1) / 2], float (&g)[D]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        float d = A[j * (j + 1) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d = fmaf(-A[j * (j + 1) / 2 + k], A[j * (j + 1) / 2 + k], d);
+        const float inv = trk_rsq(__builtin_fmaxf(d, 1e-30f));      // 1 / L_jj
+        A[j * (j + 1) / 2 + j] = inv;                                // the diagonal keeps the RECIPROCAL: no division below
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            float a = A[i * (i + 1) / 2 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) a = fmaf(-A[i * (i + 1) / 2 + k], A[j * (j + 1) / 2 + k], a);
+            A[i * (i + 1) / 2 + j] = a * inv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {                                    // L y = g
+        float a = g[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) a = fmaf(-A[i * (i + 1) / 2 + k], g[k], a);
+        g[i] = a * A[i * (i + 1) / 2 + i];
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; --i) {                               // L^T x = y
+        float a = g[i];
+#pragma unroll
+        for (int k = i + 1; k < D; ++k) a = fmaf(-A[k * (k + 1) / 2 + i], g[k], a);
+        g[i] = a * A[i * (i + 1) / 2 + i];
+    }
+}
+
 // workspace box, distance_fields.py:326-332: max_k (margin - sd_k) over the six planes; returns the value,
 // adds scale * d/dp to (ax, ay, az)
 __device__ __forceinline__ float ws_cost_point(const DevCostHdr& C, float mg, float x, float y, float z, float scale,

@@ -79,10 +79,27 @@ struct IkArgs {
 };
 typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_t stream);
 
+// Arguments of the generated Gauss-Newton / Levenberg-Marquardt IK kernel (trk_ik_gn_steps on the unit's tracked link): per iteration
+// stateful FK + geometric Jacobian (robot_tree.py:218-248), pose residual, J^T J + lambda I, Cholesky, step, clamp -- per lane, in registers.
+struct IkGnArgs {
+    float base_R[9];
+    float base_t[3];
+    const float* H_target;        // DEVICE [16] or [N,16]
+    int32_t per_sample;
+    int32_t n_steps;
+    const float* lower;           // DEVICE [D]: the step is clamped to [lower, upper]; also the validity test
+    const float* upper;
+    float damping, lm_gain, step_scale, se3_eps;
+    int64_t n;
+    float* q;                     // [N,D], in place
+    float* err; uint8_t* valid;   // nullable; SE3 distance / validity of q as passed in
+};
+typedef void (*SpecIkGnLaunchFn)(const IkGnArgs& args, int base_identity, hipStream_t stream);
+
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 19)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 20)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -114,12 +131,13 @@ struct SpecEntry {
     int32_t n_virtual;
     const int32_t* virtual_src; // [2 * n_virtual]
     const float* virtual_w;     // [2 * n_virtual]
+    SpecIkGnLaunchFn launch_ikgn;   // Gauss-Newton IK iterations on ee_link (trk_ik_gn_steps); nullptr if not generated
 };
 
 // registry filled by static initialisers of the generated translation units
 // returns 0 when the unit was accepted, TRK_ERR_INVALID_ARG (and registers nothing) when its layout stamp differs
 int trk_spec_register(const SpecEntry* e);
-#define SPEC_ENTRY_STAMP TRK_SPEC_ABI_VERSION, (uint32_t)(sizeof(SpecArgs) + sizeof(IkArgs)), (uint32_t)sizeof(SpecEntry), (uint32_t)sizeof(DevCostHdr)
+#define SPEC_ENTRY_STAMP TRK_SPEC_ABI_VERSION, (uint32_t)(sizeof(SpecArgs) + sizeof(IkArgs) + sizeof(IkGnArgs)), (uint32_t)sizeof(SpecEntry), (uint32_t)sizeof(DevCostHdr)
 const SpecEntry* trk_spec_find(uint64_t model_hash, int n_links, int n_dofs);
 const SpecEntry* trk_spec_find_points(uint64_t model_hash, uint64_t points_hash, int n_points);
 

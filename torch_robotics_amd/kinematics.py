@@ -282,6 +282,58 @@ class DifferentiableTree(torch.nn.Module):
         idx_valid = torch.atleast_1d(torch.argwhere(valid.bool()).squeeze())
         return q, idx_valid
 
+    def inverse_kinematics_gn(self, H_target, link_name="ee_link", batch_size=1, max_iters=40, damping=1e-4, lm_gain=0.1, step_scale=1.0,
+                              se3_eps=1e-1, q0=None, q0_noise=torch.pi / 8, eps_joint_lim=torch.pi / 100, check_every=10):
+        """Batched IK by damped Gauss-Newton (Levenberg-Marquardt) on the geometric Jacobian -- an EXTENSION (the reference's
+        `inverse_kinematics` is Adam, robot_tree.py:303-384): same arguments and return value `(q, idx_valid)`, same termination test
+        (SE3 distance < se3_eps inside the shrunk joint limits, :419-442), evaluated every `check_every` iterations; the iterations
+        between two tests are ONE launch of `trk_ik_gn_steps` (FK, Jacobian, normal equations, Cholesky and the clamped step per lane
+        in registers).  A unit tracking `link_name` is compiled on first use when none is registered (robots up to 9 DOF)."""
+        self._check_supported()
+        H_target = torch.as_tensor(H_target, dtype=torch.float32, device=self._device)
+        if H_target.ndim == 2:
+            H_target = H_target.unsqueeze(0)
+        Ht = H_target[0].contiguous() if H_target.shape[0] == 1 else H_target.contiguous()
+        lo, hi = self._ik_limits(eps_joint_lim, self._device)
+        if q0 is None:
+            q0 = lo + torch.rand(batch_size, self._n_dofs, device=self._device) * (hi - lo)
+        else:
+            q0 = torch.as_tensor(q0, dtype=torch.float32, device=self._device)
+            q0 = torch.clamp(q0 + torch.randn(batch_size, self._n_dofs, device=self._device) * q0_noise, lo, hi)
+            assert q0.shape == (batch_size, self._n_dofs)
+        q = q0.clone().contiguous()
+        err = torch.empty(batch_size, device=self._device, dtype=torch.float32)
+        valid = torch.empty(batch_size, device=self._device, dtype=torch.uint8)
+        link = self._name_to_idx_map[link_name]
+        self._ensure_gn_unit(link)
+        it = 0
+        while it < max_iters:
+            k = max(1, min(int(check_every), max_iters - it))
+            q_prev = q.clone()
+            ops.ik_gn_steps(self._handle, link, Ht, lo, hi, q, k, damping=damping, lm_gain=lm_gain, step_scale=step_scale,
+                            se3_eps=se3_eps, err=err, valid=valid)
+            if bool(valid.all()):
+                q = q_prev                      # like the reference's loop: stop BEFORE updating once every configuration is valid
+                break
+            it += k
+        else:
+            ops.ik_gn_steps(self._handle, link, Ht, lo, hi, q.clone(), 1, damping=damping, lm_gain=lm_gain, step_scale=step_scale,
+                            se3_eps=se3_eps, err=err, valid=valid)          # validity of the final configurations
+        idx_valid = torch.atleast_1d(torch.argwhere(valid.bool()).squeeze())
+        return q, idx_valid
+
+    def _ensure_gn_unit(self, link: int) -> None:
+        """a generated unit of this robot that tracks `link` (the Gauss-Newton IK lives in generated kernels only)"""
+        from . import codegen, jit
+        kin = self._kin
+        h = codegen.model_hash(kin)
+        if any(mh == h and t.ee_link == link for _i, mh, t in codegen.aot_units()):
+            return
+        if any(mh == h and t.ee_link == link for mh, t in jit._loaded_templates.values()):
+            return
+        tmpl = codegen.default_template(kin)
+        jit.specialize(kin, tmpl.obj_links, (), ee_link=link)
+
     # -- model queries ----------------------------------------------------------------------------
     def get_joint_limits(self) -> List[Optional[Dict[str, float]]]:
         k, out = self._kin, []

@@ -415,6 +415,23 @@ def ik_steps(model: ModelHandle, link: int, H_target: torch.Tensor, lower: torch
                                  adam_m.data_ptr(), adam_v.data_ptr(), _ptr(loss), _ptr(valid), _stream(q)), "trk_ik_steps")
 
 
+def ik_gn_steps(model: ModelHandle, link: int, H_target: torch.Tensor, lower: torch.Tensor, upper: torch.Tensor, q: torch.Tensor,
+                n_steps: int, damping: float = 1e-4, lm_gain: float = 0.1, step_scale: float = 1.0, se3_eps: float = 1e-1,
+                err: Optional[torch.Tensor] = None, valid: Optional[torch.Tensor] = None) -> None:
+    """`n_steps` damped Gauss-Newton (Levenberg-Marquardt) IK iterations IN PLACE, one launch (include/trk.h: trk_ik_gn_steps):
+    q (N,D) <- clamp(q + step_scale (J^T J + (damping + lm_gain |r|^2) I)^-1 J^T r, lower, upper) per iteration, the Jacobian in
+    registers.  err (N,) / valid (N, bool or uint8): SE3 distance / validity of q as passed in."""
+    n, D = _check_ik_buffers("ik_gn_steps", model, q, lower, upper, None, None, err, valid)
+    Ht = _dev_f32(H_target, "ik_gn_steps(H_target)")
+    per_sample = int(Ht.dim() == 3)
+    if per_sample and Ht.shape[0] != n:
+        raise ValueError("ik_gn_steps: per-sample target batch mismatch")
+    with _on(q.device):
+        check(lib().trk_ik_gn_steps(model._h, int(link), Ht.data_ptr(), per_sample, lower.data_ptr(), upper.data_ptr(), float(damping),
+                                    float(lm_gain), float(step_scale), float(se3_eps), int(n_steps), n, q.data_ptr(), _ptr(err),
+                                    _ptr(valid), _stream(q)), "trk_ik_gn_steps")
+
+
 def rotmat_to_quat(R: torch.Tensor) -> torch.Tensor:
     """rotation_matrix_to_q on (..., 3, 3) rotations or (..., 4, 4) transforms -> (..., 4) wxyz."""
     R = _dev_f32(R, "rotmat_to_quat(R)")
