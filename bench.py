@@ -85,6 +85,7 @@ def parse_args(argv):
                          "figure `independent_batches`; off by default so that a rocprofv3 run of the default command sees only "
                          "back-to-back launches of one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--two-launch", action="store_true", help="c5: the round-3 form (fp16 rollout, then the GP prior accumulated) instead of the fused launch")
     ap.add_argument("--no-out-of-cache", action="store_true", help="skip the secondary beyond-the-Infinity-Cache measurement (c2, N = 1)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' + --single-device lets the N>1 control flow run on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0")
@@ -167,6 +168,7 @@ class Workload:
     plan3 = None            # c2 / c3: configs[2]'s objective stack on the same shard
     n_grid_links = 0
     esz = 4
+    extra_bps = 0           # bytes per sample the dominant kernel moves beyond q, positions, cost, gradient (c5 fused: qd in, gqd out)
 
     def step(self, bs_ptr, s):
         self.plan.launch(bs_ptr, s)
@@ -257,22 +259,30 @@ def build_workload(args, tra, ops, torch, dev, rank):
             qh, qdh = q.half().contiguous(), qd.half().contiguous()
             # loss scale: worst case of the GP gradient over trajectories bounded like these, + the collision / EE gradient's size
             gs = ops.gp_grad_scale(dt, SIGMA_GP, 1.0, float(qh.abs().max()), float(qdh.abs().max()), extra=64.0)
-            wl.plan = ops.RolloutPlan(model, cm, weights, qh, want_pos=not args.no_pos, grad_scale=gs)
-            wl.gqd = torch.zeros_like(qh)
-            wl.gp = ops.GPPriorPlan(qh, qdh, dt, SIGMA_GP, 1.0, accumulate_into=(wl.plan.gq, wl.gqd), grad_scale=gs)
-            wl.traj_cost = wl.gp.cost
             wl.qd, wl.dt, wl.grad_scale = qdh, dt, gs
-            # GP prior: read q, qd (2 x 2D), read-modify-write gq (2 x 2D), write gqd (2D), cost per trajectory
-            wl.extras = [("GP prior cost + gradient accumulated into gq / gqd (trk_gp_prior_cost_grad, fp16 I/O)", wl.gp.launch, 2 * 5 * D)]
+            if args.two_launch:
+                # the round-3 form: the fp16 rollout, then the prior accumulated into its gradient (a read-modify-write of gq)
+                wl.plan = ops.RolloutPlan(model, cm, weights, qh, want_pos=not args.no_pos, grad_scale=gs)
+                wl.gqd = torch.zeros_like(qh)
+                wl.gp = ops.GPPriorPlan(qh, qdh, dt, SIGMA_GP, 1.0, accumulate_into=(wl.plan.gq, wl.gqd), grad_scale=gs)
+                wl.traj_cost = wl.gp.cost
+                # GP prior: read q, qd (2 x 2D), read-modify-write gq (2 x 2D), write gqd (2D), cost per trajectory
+                wl.extras = [("GP prior cost + gradient accumulated into gq / gqd (trk_gp_prior_cost_grad, fp16 I/O)", wl.gp.launch, 2 * 5 * D)]
+                how = "fused FK + SDF-obstacle + EE-tracking on both arms + gradient, then the GP prior accumulated into the same gradient"
+            else:
+                # ONE launch (trk_rollout_gp_cost_grad): q, qd read once, gq, gqd written once
+                wl.plan = ops.RolloutGpPlan(model, cm, weights, qh, qdh, dt, SIGMA_GP, 1.0, want_pos=not args.no_pos, grad_scale=gs)
+                wl.gqd = wl.plan.gqd
+                wl.extra_bps = 2 * 2 * D                                 # + qd in, gqd out
+                how = "ONE launch: fused FK + SDF-obstacle + EE-tracking on both arms + the GP prior + both gradients"
             wl.metric = "FK+cost+grad rollouts/sec (batch x horizon), dual Panda 14-DOF, fp16 I/O"
             wl.text = (f"BASELINE configs[4]: dual Panda ({L} links, {D} DOF), batch={B} x horizon={H} per GPU (8192 x 128 over 4 GPUs), "
-                       f"fp16 q / qd / link positions / gradients in HBM (loss scale 2^{int(np.log2(gs))}), fp32 arithmetic and cost: fused FK + "
-                       f"SDF-obstacle + EE-tracking on both arms + gradient, then the GP prior (sigma_gp = {SIGMA_GP}, dt = {T_GP}/{H}) "
-                       f"accumulated into the same gradient; q, qd resident in HBM")
+                       f"fp16 q / qd / link positions / gradients in HBM (loss scale 2^{int(np.log2(gs))}), fp32 arithmetic and cost: {how} "
+                       f"(sigma_gp = {SIGMA_GP}, dt = {T_GP}/{H}); q, qd resident in HBM")
             wl.dtype, wl.esz, q = "f16", 2, qh
         wl.random_q = None
     wl.q, wl.model, wl.cm, wl.kin, wl.weights, wl.D, wl.L = q, model, cm, kin, weights, D, L
-    wl.bps = algorithmic_bytes_per_sample(D, L if not args.no_pos else 0, wl.n_grid_links, wl.esz)
+    wl.bps = algorithmic_bytes_per_sample(D, L if not args.no_pos else 0, wl.n_grid_links, wl.esz) + wl.extra_bps
     return wl
 
 
@@ -571,7 +581,8 @@ def main():
                    **({"experiment_no_pos": True} if args.no_pos else {})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src if traffic else None,
-                     "kernel": "fused rollout (trk_rollout_cost_grad%s)" % ("_f16" if wl.esz == 2 else ""),
+                     "kernel": ("fused rollout + GP prior (trk_rollout_gp_cost_grad)" if isinstance(plan, ops.RolloutGpPlan) else
+                                "fused rollout (trk_rollout_cost_grad%s)" % ("_f16" if wl.esz == 2 else "")),
                      "bytes_per_sample": bps, "launch_us": launch_s * 1e6,
                      # second bound: VALU instructions per wavefront (SQ_INSTS_VALU / SQ_WAVES of the same command)
                      # x wavefronts per launch / launch time, against one 64-lane instruction per 2 cycles per SIMD

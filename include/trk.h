@@ -463,6 +463,26 @@ int trk_rollout_cost_grad_f16(const TrkModel* model, const TrkCostModel* cm, con
                               const void* q_f16, int64_t batch, int32_t horizon, void* link_pos_out_f16, float* cost,
                               void* gq, int32_t grad_dtype, float grad_scale, float* cost_block_sums, trk_stream_t stream);
 
+/* BASELINE config 5's objective in ONE launch: trk_rollout_cost_grad(_f16) and the GP prior (trk_gp_prior_cost_grad) fused -- the
+ * trajectory's q / qd rows are read once, gq and gqd are written once (no read-modify-write of the gradient between two launches).
+ * BUILD-DEFINED like its two halves; checked against the fp64 oracle of both.
+ *   q, qd [B,H,D] of io_dtype (TRK_F32 / TRK_F16; samples of a trajectory are consecutive, `horizon` of them);
+ *   cost [B,H] (fp32) = the rollout's cost + weight/2 e_t^T Q^-1 e_t, the prior's factor between t and t+1 attributed to
+ *       sample t (0 at t = H-1): sum_t cost[b,t] = the rollout's total + trk_gp_prior_cost_grad's cost[b];
+ *   gq [B,H,D] = grad_scale (d rollout cost / d q + d prior / d q),  gqd [B,H,D] = grad_scale d prior / d qd, both of grad_dtype
+ *       (fp16 stores saturate; fp32 trajectories: fp32 gradients, grad_scale = 1);  link_pos_out (nullable) [B,H,L,3] of io_dtype;
+ *   cost_block_sums (nullable): as trk_rollout_cost_grad, of the combined cost.
+ * A generated unit serves it with its subtrees scheduled one after the other (the dual Panda's arms: 128 registers, one resident
+ * generation of wavefronts); where no unit does -- no unit for the robot, ring-staged robots, self pairs between the subtrees
+ * with w_self != 0 -- the same result comes from the two-launch form (rollout, then the prior accumulated into its outputs). */
+typedef struct TrkGpPrior {
+    float dt, sigma, weight;
+} TrkGpPrior;
+int trk_rollout_gp_cost_grad(const TrkModel* model, const TrkCostModel* cm, const TrkRolloutWeights* w, const TrkGpPrior* gp,
+                             const void* q, const void* qd, int64_t batch, int32_t horizon, int32_t io_dtype,
+                             void* link_pos_out, float* cost, void* gq, void* gqd, int32_t grad_dtype, float grad_scale,
+                             float* cost_block_sums, trk_stream_t stream);
+
 /* trk_rollout_cost_grad with the collision fields evaluated on attached points instead of link origins: the cost
  * model's position columns (n_links_in, obj_link_idx, self_link_idx) index the points of `ps`; ee_link stays a LINK
  * index of the model.  point_pos_out [batch*horizon, n_points, 3] (nullable).  Same outputs otherwise. */

@@ -326,6 +326,17 @@ def gp_prior(q, qd, dt, sigma, weight=1.0, prec="f64"):
     return cost, gq, gqd
 
 
+def gp_factor_cost(q, qd, dt, sigma, weight=1.0, prec="f64"):
+    """The prior's cost per factor: (B, H), out[b, t] = the factor between t and t + 1 (0 at t = H - 1)."""
+    npdt, ct, suf = _dt(prec)
+    q = np.ascontiguousarray(q, npdt)
+    qd = np.ascontiguousarray(qd, npdt)
+    B, H, D = q.shape
+    out = np.empty((B, H), npdt)
+    getattr(lib(), "orc_gp_factor_cost" + suf)(_p(q), _p(qd), C.c_int64(B), C.c_int(H), C.c_int(D), ct(dt), ct(sigma), ct(weight), _p(out))
+    return out
+
+
 def finite_difference(x, dt=1.0, method="forward", prec="f64"):
     npdt, ct, suf = _dt(prec)
     x = np.ascontiguousarray(x, npdt)

@@ -77,9 +77,10 @@ def test_two_rank_config5_on_one_gpu_gloo():
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["dtype"] == "f16" and out["config"]["objectives"] == "c5" and out["config"]["horizon"] == 128
-    assert out["config"]["global_batch"] == 512 and out["config"]["launches_per_step"] == 2 and out["config"]["kernel"] == "specialized"
+    assert out["config"]["global_batch"] == 512 and out["config"]["launches_per_step"] == 1 and out["config"]["kernel"] == "specialized"
     assert 0 < out["config"]["grad_scale"] < 1
-    assert out["roofline"]["bytes_per_sample"] == 2 * 14 + 6 * 23 + 4 + 2 * 14 and out["roofline"]["step"]["bytes_per_sample"] == 198 + 140
+    # ONE launch: q, qd in (28 + 28), positions (138), cost (4), gq, gqd out (28 + 28)
+    assert out["roofline"]["bytes_per_sample"] == 254 and "step" not in out["roofline"]
     mg = out["multi_gpu"]
     assert mg["reduce_every"] == 64 and mg["reduce_every_effective"] == 10 and mg["collectives_in_timed_region"] == 2
     assert mg["allreduce_floats"] == 1 + 128 + 128 * 14 and "full_stack_c3" not in mg
@@ -88,19 +89,20 @@ def test_two_rank_config5_on_one_gpu_gloo():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,dtype,launches", [("c4", "f32", 2), ("c5", "f16", 2)])
-def test_bench_configs_4_and_5_one_gpu(cfg, dtype, launches):
+@pytest.mark.parametrize("cfg,dtype,launches,extra", [("c4", "f32", 2, []), ("c5", "f16", 1, []), ("c5", "f16", 2, ["--two-launch"])])
+def test_bench_configs_4_and_5_one_gpu(cfg, dtype, launches, extra):
     """`bench.py --config c4|c5` on one GPU: a driver-parsable line with the config's own bytes, the dominant kernel's roofline,
     the step's, and a CPU baseline from the oracle (incl. the Jacobian / the GP term)."""
-    p = _run(["--config", cfg, "--steps", "20", "--warmup", "5", "--cpu-seconds", "1.5", "--batch", "512"], 900)
+    p = _run(["--config", cfg, "--steps", "20", "--warmup", "5", "--cpu-seconds", "1.5", "--batch", "512"] + extra, 900)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["dtype"] == dtype and out["config"]["launches_per_step"] == launches and out["config"]["kernel"] == "specialized"
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["unit"] == "rollouts/s" and out["vs_baseline"] is None
     D, L, e = (22, 30, 4) if cfg == "c4" else (14, 23, 2)
-    assert out["roofline"]["bytes_per_sample"] == 2 * e * D + 3 * e * L + 4
-    assert 0 < out["roofline"]["frac"] < 1 and 0 < out["roofline"]["step"]["frac"] < 1
-    assert out["roofline"]["step"]["step_us"] >= out["roofline"]["launch_us"]
+    assert out["roofline"]["bytes_per_sample"] == 2 * e * D + 3 * e * L + 4 + (4 * D if (cfg == "c5" and launches == 1) else 0)
+    assert 0 < out["roofline"]["frac"] < 1
+    if launches > 1:
+        assert 0 < out["roofline"]["step"]["frac"] < 1 and out["roofline"]["step"]["step_us"] >= out["roofline"]["launch_us"]
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["one_core"]["value"] > 0
     assert ("Jacobian" in cb["sample"]) == (cfg == "c4") and ("GP prior" in cb["sample"]) == (cfg == "c5")

@@ -900,6 +900,79 @@ def test_rollout_fp16_io(ops, oracle_lib, robot, ident):
 
 
 @pytest.mark.parametrize("ident", ["panda", "dual_panda", "ur10_allegro"])
+def test_rollout_gp_fused_vs_fp64_oracle(ops, oracle_lib, ident):
+    """trk_rollout_gp_cost_grad (build-defined: config 5's objective in one launch) == the fp64 oracle's rollout + GP prior on the same
+    (fp16-rounded) trajectories: per-sample cost incl. the prior's factor costs, gq = rollout gradient + prior gradient, gqd, positions,
+    block sums; fp32 / fp16 / mixed I/O; horizons that are not multiples of 64 (trajectories cross wavefront blocks anywhere), H = 1;
+    the generated kernel (Panda: one segment incl. its self pairs; dual Panda: the two arms one after the other) against the two-launch
+    form (what UR10 + Allegro -- ring-staged positions -- and the dual Panda with arm-vs-arm pairs take)."""
+    from torch_robotics_amd import codegen
+    from torch_robotics_amd.costmodel import CostModelSpec
+    from torch_robotics_amd.environments import EnvSpheres3D
+    kin, tmpl = codegen.template_for(ident)
+    env = EnvSpheres3D(tensor_args=dict(device=DEV, dtype=torch.float32))
+    spec = CostModelSpec(n_links_in=kin.n_links)
+    spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+    spec.obj_link_margin = np.linspace(0.08, 0.14, len(tmpl.obj_links)).astype(np.float32)       # distinct margins: the segments' bases matter
+    spec.objects = [o.as_object() for o in env.obj_fixed_list]
+    spec.ws_min, spec.ws_max = np.float32([-1, -1, -1]), np.float32([1, 1, 1])
+    sl = sorted({a for p in tmpl.self_pairs for a in p})
+    spec.self_link_idx = np.asarray(sl, np.int32)
+    spec.self_pairs = np.asarray([(sl.index(a), sl.index(b)) for a, b in tmpl.self_pairs], np.int32).reshape(-1, 2)
+    spec.self_margin = np.linspace(0.04, 0.07, len(tmpl.self_pairs)).astype(np.float32)
+    spec.ee_link = tmpl.ee_link
+    if tmpl.ee2_link >= 0:
+        spec.ee2_link = tmpl.ee2_link
+        Ht2 = np.eye(4, dtype=np.float32); Ht2[:3, 3] = (0.4, -0.3, 0.5); spec.ee2_target = Ht2
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5); spec.ee_target = Ht
+    spec.validate()
+    h, cm, o = ops.ModelHandle(kin), ops.CostHandle(spec, DEV), oracle_lib.Oracle(kin, spec)
+    D, L = kin.n_dofs, kin.n_links
+    rng = np.random.default_rng(41)
+    for (B, H, dt, sigma, gw) in ((3, 64, 0.08, 0.3, 1.0), (2, 128, 5.0 / 128, 0.1, 1.0), (5, 37, 0.05, 0.2, 0.5), (70, 3, 0.1, 0.5, 1.0), (4, 1, 0.1, 0.2, 1.0)):
+        q = (rng.uniform(-1.0, 1.0, (B, 1, D)) + np.cumsum(rng.standard_normal((B, H, D)) * 0.03, axis=1)).astype(np.float32)
+        qd = (rng.standard_normal((B, H, D)) * 0.3).astype(np.float32)
+        for wts in ((0, 1, 0, 1), (1, 1, 1, 1), (0.5, 0, 2, 0)):
+            for io, gdt in (("f32", None), ("f16", None), ("f16", torch.float32)):
+                tq, tqd = dev(q), dev(qd)
+                if io == "f16":
+                    tq, tqd = tq.half(), tqd.half()
+                q64, qd64 = tq.double().cpu().numpy(), tqd.double().cpu().numpy()
+                rp, rc, rg = o.rollout(q64.reshape(-1, D), wts, "f64")
+                gc, ggq, ggqd = oracle_lib.gp_prior(q64, qd64, dt, sigma, gw, "f64")
+                fc = oracle_lib.gp_factor_cost(q64, qd64, dt, sigma, gw, "f64")
+                assert np.allclose(fc.sum(1), gc, rtol=1e-12, atol=1e-9)
+                ref_c = rc.reshape(B, H) + fc
+                ref_g = rg.reshape(B, H, D) + ggq
+                gs = 1.0
+                if io == "f16" and gdt is None:
+                    gs = ops.gp_grad_scale(dt, sigma, gw, float(np.abs(q64).max()), float(np.abs(qd64).max()), extra=float(np.abs(rg).max()))
+                nb = ops.n_blocks(B * H)
+                for use_spec in (True, False):
+                    h.enable_specialized(use_spec)
+                    sums = torch.zeros(nb, device=DEV)
+                    pos, cost, gq, gqd = ops.rollout_gp_cost_grad(h, cm, wts, tq, tqd, dt, sigma, gw, cost_sum=sums, grad_dtype=gdt, grad_scale=gs)
+                    tag = (ident, B, H, wts, io, gdt, use_spec)
+                    assert cost.dtype == torch.float32 and pos.dtype == tq.dtype and gq.dtype == (gdt or tq.dtype) and gqd.dtype == gq.dtype
+                    ptol = (2 * TOL_H if io == "f32" else 1e-3) * max(1.0, np.abs(rp).max())
+                    assert np.abs(pos.float().cpu().numpy().reshape(rp.shape) - rp).max() < ptol, tag
+                    assert rel_err(cost.cpu().numpy(), ref_c) < 2e-5, tag
+                    c_np = np.concatenate([cost.cpu().numpy().reshape(-1), np.zeros(nb * 64 - B * H, np.float32)]).reshape(nb, 64)
+                    assert np.abs(sums.cpu().numpy() - c_np.sum(1)).max() <= 1e-5 * max(1.0, np.abs(c_np).sum(1).max()), tag
+                    for got, ref in ((gq, ref_g), (gqd, ggqd)):
+                        g = got.double().cpu().numpy() / gs
+                        assert np.isfinite(g).all(), tag
+                        if got.dtype == torch.float16:      # one fp16 rounding of the scaled sum (the two-launch form: of each term) + fp32 arithmetic
+                            assert (np.abs(g - ref) <= 2.0 ** -9 * (np.abs(ref) + np.abs(ggq).max() * 2.0 ** -11) + 2.0 ** -22 / gs
+                                    + 4e-5 * max(np.abs(ref).max(), 1e-3)).all(), tag
+                        else:
+                            assert grad_close(g, ref), tag
+                h.enable_specialized(True)
+    # which kernel served what: the generated unit for Panda and (without arm-vs-arm pairs) the dual Panda
+    assert h.specialized
+
+
+@pytest.mark.parametrize("ident", ["panda", "dual_panda", "ur10_allegro"])
 def test_generated_fk_positions_and_backward(ops, oracle_lib, ident):
     """trk_fk_positions / trk_fk_positions_backward with all links selected run the generated kernels for the robots
     that have one: against the fp64 oracle and the table-driven kernels, ragged sizes, with and without a base pose."""

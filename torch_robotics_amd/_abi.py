@@ -81,6 +81,10 @@ class RolloutWeights(C.Structure):
     _fields_ = [("w_self", C.c_float), ("w_obj", C.c_float), ("w_ws", C.c_float), ("w_ee", C.c_float)]
 
 
+class GpPrior(C.Structure):         # TrkGpPrior
+    _fields_ = [("dt", C.c_float), ("sigma", C.c_float), ("weight", C.c_float)]
+
+
 def _i32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.int32)
 

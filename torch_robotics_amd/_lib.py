@@ -32,7 +32,7 @@ EXPORTS = [
     "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_point_set_is_specialized", "trk_fk_points", "trk_fk_points_backward",
     "trk_rollout_points_cost_grad", "trk_rollout_collision", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16", "trk_finite_difference", "trk_traj_diff_norm_sum",
     "trk_interpolate_columns", "trk_interpolate_columns_backward", "trk_rollout_collision_via", "trk_traj_validate",
-    "trk_scale_rows", "trk_jtj", "trk_pack_sums", "trk_pack_sums_scratch_bytes", "trk_rollout_is_specialized", "trk_ik_gn_steps",
+    "trk_scale_rows", "trk_jtj", "trk_pack_sums", "trk_pack_sums_scratch_bytes", "trk_rollout_is_specialized", "trk_ik_gn_steps", "trk_rollout_gp_cost_grad",
 ]
 
 
@@ -101,6 +101,8 @@ def lib():
     L.trk_ee_cost.argtypes = [vp, vp, i64, i64, vp, i32, vp, vp, vp, i64, vp]
     L.trk_rollout_cost_grad.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, vp, vp, vp, vp, vp]
     L.trk_rollout_collision.argtypes = [vp, vp, i32, vp, i64, i32, f32, vp, vp, vp]
+    L.trk_rollout_gp_cost_grad.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights), C.POINTER(_abi.GpPrior), vp, vp, i64, i32, i32, vp, vp, vp, vp,
+                                           i32, f32, vp, vp]
     L.trk_ik_gn_steps.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, f32, f32, i32, i64, vp, vp, vp, vp]
     L.trk_rollout_is_specialized.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights)]
     L.trk_interpolate_via_points.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]

@@ -214,21 +214,24 @@ def _masked_factory(kin: KinModel):
     return masked
 
 
-def _emit_angles(E: "Emitter", kin: KinModel) -> None:
+def _emit_angles(E: "Emitter", kin: KinModel, links=None, declare_passbits: bool = True, qexpr=None) -> None:
     """joint angles: clamp to the URDF limits (torch.clamp, rigid_body.py:157-160; the gradient mask is
-    "q inside the limits" == "clamp left q unchanged"), then all sines / cosines, two angles per call"""
+    "q inside the limits" == "clamp left q unchanged"), then all sines / cosines, two angles per call.
+    links: only the joints of these links (a segment of the tree); qexpr(d): the C expression of q[d] (default: the array q)."""
     L = kin.n_links
     rot_dofs = []
-    E.raw("    unsigned passbits = 0u;      // bit d set: clamp left q[d] unchanged -> gradient passes (one VGPR instead of 2D)")
-    for i in range(1, L):
+    qexpr = qexpr or (lambda d: f"q[{d}]")
+    if declare_passbits:
+        E.raw("    unsigned passbits = 0u;      // bit d set: clamp left q[d] unchanged -> gradient passes (one VGPR instead of 2D)")
+    for i in (range(1, L) if links is None else links):
         jt, d = int(kin.joint_type[i]), int(kin.dof_idx[i])
         if jt == JOINT_FIXED:
             continue
         if kin.clamp[i]:
-            E.raw(f"    const float qh{d} = __builtin_amdgcn_fmed3f(q[{d}], {flit(kin.lower[i])}, {flit(kin.upper[i])});")
-            E.raw(f"    passbits |= (qh{d} == q[{d}]) ? {1 << d}u : 0u;")
+            E.raw(f"    const float qh{d} = __builtin_amdgcn_fmed3f({qexpr(d)}, {flit(kin.lower[i])}, {flit(kin.upper[i])});")
+            E.raw(f"    passbits |= (qh{d} == {qexpr(d)}) ? {1 << d}u : 0u;")
         else:
-            E.raw(f"    const float qh{d} = q[{d}];")
+            E.raw(f"    const float qh{d} = {qexpr(d)};")
         if jt in (JOINT_REVOLUTE, JOINT_CONTINUOUS) and float(kin.rot_sign[i]) != 0.0:
             rot_dofs.append(d)
     # pin the mask in ONE register: without this the compiler re-derives it from q and qh in the reverse pass and
@@ -671,6 +674,252 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gq), base, rows, lane, lds, gv, A.grad_scale);")
         E.raw("    spec_stamp(A.stamps, wblock, 7, lane);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+
+    # ---- the fused rollout with the GP prior fused in (trk_rollout_gp_cost_grad; BASELINE config 5's objective in ONE launch, gq and
+    # gqd written once).  BUILD-DEFINED like the prior itself.  Two things differ from k_rollout:
+    # (1) SEGMENTS.  The subtrees hanging off the root that share no objective (the two arms of the dual Panda when no self pair
+    #     crosses them) are evaluated one after the other -- FK, scene, EE, reverse pass, positions -- so that only ONE arm's poses
+    #     are live at a time: the dual Panda fits the 128 registers and ~10 KB of LDS per wavefront that let all 4096 wavefronts of
+    #     its 2048 x 128 share be resident at once (k_rollout: 189 registers, two generations of workgroups).  Per-lane state that
+    #     must survive a segment lives in LDS: the raw q rows (HBM element type), the gradient accumulator [64][D].
+    # (2) The prior.  A lane is one (trajectory, time step); its neighbours' q / qd rows sit next to its own in the raw tiles (the
+    #     two rows beyond the wavefront's block are fetched with the block), so the prior's gradient is a few FMAs per joint at the
+    #     top of the kernel: d/dqd leaves at once, d/dq seeds the accumulator the segments add their gradients to.
+    # The factor between t and t + 1 is attributed to sample t: cost[b, t] += w/2 e_t^T Q^-1 e_t.
+    par_ = [int(v) for v in kin.parent]
+    gp_ok = (not chunked) and not tmpl.virtual and walk == list(range(L)) and D <= 32 and L >= 2
+    segs: List[dict] = []
+    gp_cross_pairs = False
+    if gp_ok:
+        top = {}
+        for i in range(1, L):
+            a = i
+            while par_[a] != 0:
+                a = par_[a]
+            top[i] = a
+        roots = [i for i in range(1, L) if par_[i] == 0]
+        cand = [[i for i in range(1, L) if top[i] == c] for c in roots]
+        contiguous = all(ls == list(range(ls[0], ls[-1] + 1)) for ls in cand) and [l for ls in cand for l in ls] == list(range(1, L))
+        # each segment's object-collision links must be one consecutive run of the template (their margins are addressed by a base)
+        runs_ok = contiguous
+        if contiguous:
+            pos_in = 0
+            for ls in cand:
+                mine = [i for i in tmpl.obj_links if i in ls or (i == 0 and ls is cand[0])]
+                if tmpl.obj_links[pos_in:pos_in + len(mine)] != mine:
+                    runs_ok = False
+                pos_in += len(mine)
+        if not (contiguous and runs_ok and len(cand) > 1):
+            cand = [list(range(1, L))]
+        gp_cross_pairs = any(a != 0 and b != 0 and top[a] != top[b] for a, b in tmpl.self_pairs) if len(cand) > 1 else False
+        obj_at = 0
+        for k, ls in enumerate(cand):
+            own = set(ls) | ({0} if k == 0 else set())
+            objs = [i for i in tmpl.obj_links if i in own]
+            cols = ([0] if k == 0 else []) + ls                        # links whose positions this segment writes
+            seg = dict(links=ls, cols=cols, col0=3 * cols[0], ncol=3 * len(cols), obj=objs, obj_base=obj_at,
+                       pairs=[(pi, a, b) for pi, (a, b) in enumerate(tmpl.self_pairs)
+                              if (a in own or a == 0) and (b in own or b == 0) and (a in ls or b in ls)],
+                       tracked=[(l, tgt, rb) for l, tgt, rb in tracked if l in own],
+                       dofs=[int(kin.dof_idx[i]) for i in ls if int(kin.dof_idx[i]) >= 0])
+            obj_at += len(objs)
+            segs.append(seg)
+        if len(segs) > 1 and gp_cross_pairs:
+            pass            # served with w_self == 0 only (launch_gp returns 1 otherwise)
+    for base_identity in ((True, False) if gp_ok else ()):
+        E = Emitter()
+        kname = "k_rollout_gp_bi" if base_identity else "k_rollout_gp_bg"
+        fast_t = D > 8
+        box_t = D <= 8
+        occ = 4 if max(len(sg["dofs"]) for sg in segs) <= 8 else 2
+        E.raw(f"template <class IO{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}>")
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {occ}) {kname}(SpecArgs A) {{")
+        if not box_t:
+            E.raw("    constexpr bool BOX = !FAST;")
+        E.raw("    typedef typename IoTraits<IO>::Q IOQ;")
+        E.raw("    typedef typename IoTraits<IO>::G IOG;")
+        E.raw("    typedef RawRowsInFlight<D, IOQ> Raw;")
+        # LDS per wavefront: accumulator | raw q tile | scratch (raw qd tile, then the gqd staging tile, then one segment's positions)
+        seg_ls = []
+        for sg in segs:
+            seg_ls.append((sg["ncol"], (sg["ncol"] + 1) // 2))       # dwords per lane row: fp32, fp16
+        E.raw(f"    constexpr int SEG_DW = sizeof(IOQ) == 4 ? {max(a for a, _ in seg_ls)} : {max(b for _, b in seg_ls)};      // widest segment row, dwords")
+        E.raw("    constexpr int ACC_B = TRK_WAVE * D * 4, QRAW_B = Raw::BYTES;")
+        E.raw("    constexpr int SCR_B0 = TRK_WAVE * SEG_DW * 4 > ACC_B ? TRK_WAVE * SEG_DW * 4 : ACC_B;")
+        E.raw("    constexpr int SCR_B = ((SCR_B0 > Raw::BYTES ? SCR_B0 : Raw::BYTES) + 15) / 16 * 16;")
+        E.raw("    constexpr int WAVE_B = ACC_B + QRAW_B + SCR_B;")
+        E.raw("    // the sphere (and primitive) tables are shared by the workgroup's wavefronts here: one barrier at the top, 192 bytes of LDS per wavefront saved")
+        E.raw("    __shared__ __attribute__((aligned(16))) unsigned char lds_all[SPEC_WAVES * WAVE_B + TRK_LDS_SPHERES * 16 + (BOX ? TRK_LDS_PRIMS * 32 : 0)];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw("    unsigned char* wl = lds_all + wave * WAVE_B;")
+        E.raw("    float* acc = reinterpret_cast<float*>(wl);                      // [64][D] fp32: d cost / d q, prior first, then the segments")
+        E.raw("    IOQ* qtile = reinterpret_cast<IOQ*>(wl + ACC_B);               // raw q rows of the block (+ the neighbouring rows)")
+        E.raw("    float* scr = reinterpret_cast<float*>(wl + ACC_B + QRAW_B);")
+        E.raw("    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_WAVES * WAVE_B);")
+        E.raw("    float4* lds_prm = BOX ? lds_sph + TRK_LDS_SPHERES : nullptr;")
+        E.raw("    {")
+        E.raw("        const int tid = threadIdx.x;")
+        E.raw("        if (tid < TRK_LDS_SPHERES && tid < 2 * A.C.n_sphere_pairs) lds_sph[tid] = A.C.spheres[tid];")
+        E.raw("        if constexpr (BOX) { if (A.C.n_box_objects > 0 && A.C.n_prims <= TRK_LDS_PRIMS && tid < 2 * A.C.n_prims) lds_prm[tid] = reinterpret_cast<const float4*>(A.C.prims)[tid]; }")
+        E.raw("    }")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    // time steps: the block starts at step t0 of its trajectory (wave-uniform), a lane sits at (t0 + lane) mod H")
+        E.raw("    const unsigned Hh = (unsigned)A.gp_H;")
+        E.raw("    const unsigned t0 = (unsigned)(base % (int64_t)A.gp_H);")
+        E.raw("    const unsigned tl = (t0 + (unsigned)lane) % Hh, t_last = (t0 + (unsigned)(TRK_WAVE - 1)) % Hh;")
+        E.raw("    const bool edge_prev = rows > 0 && t0 > 0u, edge_next = rows == TRK_WAVE && t_last + 1u < Hh && base + TRK_WAVE < A.n;")
+        E.raw("    const Raw rq = spec_raw_rows_issue<D, IOQ>(static_cast<const IOQ*>(A.q), base, rows, lane, edge_prev, edge_next);")
+        E.raw("    const Raw rv = spec_raw_rows_issue<D, IOQ>(static_cast<const IOQ*>(A.qd), base, rows, lane, edge_prev, edge_next);")
+        E.raw("    const IOQ* qb = spec_raw_rows_finish<D, IOQ>(rq, static_cast<const IOQ*>(A.q), base, rows, lane, qtile);")
+        E.raw("    const IOQ* vb = spec_raw_rows_finish<D, IOQ>(rv, static_cast<const IOQ*>(A.qd), base, rows, lane, reinterpret_cast<IOQ*>(scr));")
+        E.raw("    __syncthreads();            // the shared scene tables (and, wave-locally, the tiles) are in LDS")
+        E.raw("    float cost;")
+        E.raw("    {")
+        E.raw("        // ---- the prior: e_t = (p_t + dt v_t - p_t+1, v_t - v_t+1), r = Q^-1 e; this sample takes part in factors t-1 and t")
+        E.raw("        const bool on = lane < rows;")
+        E.raw("        const float mn = (on && tl + 1u < Hh) ? 1.0f : 0.0f, mp = (on && tl > 0u) ? 1.0f : 0.0f;")
+        E.raw("        const float dt = A.gp_dt, ga = A.gp_a, gb = A.gp_b, gc = A.gp_c;")
+        E.raw("        float gpv[D], gvv[D], accg = 0.0f;")
+        E.raw("#pragma unroll")
+        E.raw("        for (int d = 0; d < D; ++d) {")
+        E.raw("            const float p0 = (float)qb[lane * D + d], v0 = (float)vb[lane * D + d];")
+        E.raw("            const float pm = (float)qb[(lane - 1) * D + d], vm = (float)vb[(lane - 1) * D + d];")
+        E.raw("            const float pn = (float)qb[(lane + 1) * D + d], vn = (float)vb[(lane + 1) * D + d];")
+        E.raw("            const float ep = fmaf(dt, v0, p0) - pn, ev = v0 - vn;")
+        E.raw("            const float rp = fmaf(ga, ep, gb * ev), rv_ = fmaf(gb, ep, gc * ev);")
+        E.raw("            accg = fmaf(0.5f * mn, fmaf(ep, rp, ev * rv_), accg);")
+        E.raw("            const float em = fmaf(dt, vm, pm) - p0, fm = vm - v0;")
+        E.raw("            gpv[d] = A.gp_w * (mn * rp - mp * fmaf(ga, em, gb * fm));")
+        E.raw("            gvv[d] = A.gp_w * (mn * fmaf(dt, rp, rv_) - mp * fmaf(gb, em, gc * fm));")
+        E.raw("        }")
+        E.raw("        cost = A.gp_w * accg;")
+        E.raw("#pragma unroll")
+        E.raw("        for (int d = 0; d < D; ++d) acc[lane * D + d] = gpv[d];")
+        E.raw("        // d cost / d qd is final: out through the scratch tile (its first line waits for every lane's reads of the qd rows)")
+        E.raw("        spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base, rows, lane, scr, gvv, A.grad_scale);")
+        E.raw("    }")
+        E.raw("    unsigned passbits = 0u;")
+        R: Dict[int, List[List[S]]] = {}
+        t: Dict[int, List[S]] = {}
+        passv: Dict[int, S] = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        for k, sg in enumerate(segs):
+            E.raw(f"    // ================= segment {k}: links {sg['links'][0]} .. {sg['links'][-1]} =================")
+            E.raw("    {")
+            _emit_angles(E, kin, links=sg["links"], declare_passbits=False, qexpr=lambda d: f"(float)qb[lane * D + {d}]")
+            for i in sg["links"]:
+                _emit_fk_link(E, kin, i, R, t, passv, snap)
+            ncol = sg["ncol"]
+            pos_list = ", ".join(E.expr(t[i][kk]) for i in sg["cols"] for kk in range(3))
+            E.raw(f"    const SegFlusher<{3 * L}, {sg['col0']}, {ncol}, IOQ> seg = spec_make_seg<{3 * L}, {sg['col0']}, {ncol}, IOQ>("
+                  "static_cast<IOQ*>(A.link_pos), base, rows, lane, reinterpret_cast<unsigned*>(scr));")
+            E.raw("    spec_wave_sync();          // whatever used the scratch before has been consumed")
+            E.raw("    if (A.link_pos) {")
+            E.raw(f"        const float pv[{ncol}] = {{{pos_list}}};")
+            E.raw("        seg.stage(pv);")
+            E.raw("    }")
+            E.raw("    spec_wave_sync();")
+            # tick slots of this segment: the scene evaluation's, one after the EE term, one per two links of the reverse pass
+            n_obj = len(sg["obj"])
+            if 0 < n_obj <= LINK_OBJ_GROUP_MAX:
+                groups = [sg["obj"]]
+            elif n_obj > 0:
+                n_groups = -(-n_obj // LINK_OBJ_GROUP)
+                size = -(-n_obj // n_groups)
+                groups = [sg["obj"][g0:g0 + size] for g0 in range(0, n_obj, size)]
+            else:
+                groups = []
+            n_slots = OBJ_TICK_SLOTS * len(groups) + 1 + sum(1 for p in range(len(sg["links"]), 0, -1) if p % 2 == 0)
+            # pieces of this segment for both element sizes -> pieces per tick slot
+            E.raw(f"    constexpr int PPT = (decltype(seg)::NP + {n_slots - 1}) / {n_slots};")
+            E.raw("    const SegTicks<decltype(seg), PPT> flush{seg};")
+            next_chunk = [0]
+
+            def tick_line(indent="    "):
+                c = next_chunk[0]
+                next_chunk[0] += 1
+                return f"{indent}flush.template chunk<{c}>();"
+            own = set(sg["links"]) | ({0} if k == 0 else set())
+            adj = sorted(set(sg["obj"]) | {a for _, a, b in sg["pairs"]} | {b for _, a, b in sg["pairs"]} | {l for l, _, _ in sg["tracked"]})
+            for i in adj:
+                E.raw(f"    float tb{i}_0 = 0.0f, tb{i}_1 = 0.0f, tb{i}_2 = 0.0f;")
+            fast_arg = ", decltype(ticks), FAST" if fast_t else ""
+            g_at = 0
+            for grp in groups:
+                n = len(grp)
+                E.raw("    {")
+                for kk, nm in enumerate("xyz"):
+                    E.raw(f"        const float p{nm}[{n}] = {{{', '.join(E.expr(t[i][kk]) for i in grp)}}};")
+                E.raw(f"        float gx[{n}], gy[{n}], gz[{n}];")
+                E.raw("#pragma unroll")
+                E.raw(f"        for (int l = 0; l < {n}; ++l) {{ gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }}")
+                c0 = next_chunk[0]
+                next_chunk[0] += OBJ_TICK_SLOTS
+                E.raw(f"        const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
+                E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<{n}{fast_arg}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, {sg['obj_base'] + g_at}, lds_prm);")
+                E.raw(f"        else flush.template range<{c0}, {c0 + OBJ_TICK_SLOTS}>();")
+                E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<{n}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {sg['obj_base'] + g_at});")
+                for j, i in enumerate(grp):
+                    E.raw(f"        tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
+                E.raw("    }")
+                g_at += n
+            if sg["pairs"]:
+                E.raw("    if (A.w.w_self != 0.0f) {")
+                for pi, a, b in sg["pairs"]:
+                    pa = ", ".join(E.expr(t[a][kk]) for kk in range(3))
+                    pb = ", ".join(E.expr(t[b][kk]) for kk in range(3))
+                    E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], {pa}, {pb}, "
+                          f"tb{a}_0, tb{a}_1, tb{a}_2, tb{b}_0, tb{b}_1, tb{b}_2, (A.C.clamp_fields & TRK_FIELD_SELF) != 0);")
+                E.raw("    }")
+            for ee, tgt, rb in sg["tracked"]:
+                E.raw(f"    float {rb}[9] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};")
+            if sg["tracked"]:
+                E.raw("    if (A.w.w_ee != 0.0f) {")
+                for ee, tgt, rb in sg["tracked"]:
+                    E.raw("      {")
+                    E.raw(f"        const float eR[9] = {{{', '.join(E.expr(R[ee][r][c]) for r in range(3) for c in range(3))}}};")
+                    E.raw(f"        const float et[3] = {{{', '.join(E.expr(t[ee][kk]) for kk in range(3))}}};")
+                    E.raw("        float gR[9], gt[3];")
+                    E.raw(f"        const float ce = ee_cost_eval(eR, et, {tgt}, A.C.ee_w_pos, A.C.ee_w_rot, A.C.ee_square, gR, gt);")
+                    E.raw("        cost = fmaf(A.w.w_ee, ce, cost);")
+                    E.raw("#pragma unroll")
+                    E.raw(f"        for (int k = 0; k < 9; ++k) {rb}[k] = A.w.w_ee * gR[k];")
+                    E.raw(f"        tb{ee}_0 = fmaf(A.w.w_ee, gt[0], tb{ee}_0); tb{ee}_1 = fmaf(A.w.w_ee, gt[1], tb{ee}_1); "
+                          f"tb{ee}_2 = fmaf(A.w.w_ee, gt[2], tb{ee}_2);")
+                    E.raw("      }")
+                E.raw("    }")
+            E.raw(tick_line())
+            real = [i for i in adj if i != 0]
+            gq_expr = _emit_reverse_links(E, kin, R, t, {i: [f"tb{i}_{kk}" for kk in range(3)] for i in real},
+                                          {l: rb for l, _, rb in sg["tracked"]}, masked, tick=tick_line, order=[0] + sg["links"],
+                                          n_links=len(sg["links"]) + 1)
+            assert next_chunk[0] <= n_slots, (next_chunk[0], n_slots)
+            E.raw(f"    flush.template rest<{next_chunk[0]}>();")
+            for d in sg["dofs"]:
+                ex = E.expr(gq_expr.get(d, ZERO))
+                if ex != "0.0f":
+                    E.raw(f"    acc[lane * D + {d}] += {ex};")
+            E.raw("    }")
+            # poses of this segment are dead from here on: drop them so that nothing downstream can reference them by accident
+            for i in sg["links"]:
+                R.pop(i, None); t.pop(i, None)
+        E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
+        E.raw("    if (A.cost_sum) {")
+        E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
+        E.raw("        if (lane == 0 && rows > 0) store_wt_f1(A.cost_sum + wblock, tot);")
+        E.raw("    }")
+        E.raw("    spec_store_acc_tile<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gq), base, rows, lane, acc, A.grad_scale);")
         E.raw("}")
         out.extend(E.lines)
         out.append("")
@@ -1320,6 +1569,21 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         prev = f"sw{k}"
     out.append("    if (a.io_f16 == TRK_IO_F16) sw0(_Float16{}); else if (a.io_f16 == TRK_IO_F16_G32) sw0(HalfG32{}); else sw0(float{});")
     out.append("}")
+    if gp_ok:
+        out.append("static int launch_gp(const SpecArgs& a, int base_identity, hipStream_t st) {")
+        if gp_cross_pairs:
+            out.append("    if (a.w.w_self != 0.0f) return 1;      // self pairs between independently scheduled subtrees: the two-launch form serves them")
+        out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+        sw = "scene_is_fast(a.C)" if D > 8 else "a.C.n_box_objects > 0 && a.C.n_prims <= TRK_LDS_PRIMS"
+        out.append("    auto go = [&](auto io, auto c0) {")
+        out.append("        using IOT = decltype(io);")
+        out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_gp_bi<IOT, decltype(c0)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("        else hipLaunchKernelGGL((k_rollout_gp_bg<IOT, decltype(c0)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    };")
+        out.append(f"    auto sw = [&](auto io) {{ if ({sw}) go(io, std::true_type{{}}); else go(io, std::false_type{{}}); }};")
+        out.append("    if (a.io_f16 == TRK_IO_F16) sw(_Float16{}); else if (a.io_f16 == TRK_IO_F16_G32) sw(HalfG32{}); else sw(float{});")
+        out.append("    return 0;")
+        out.append("}")
     out.append("static void launch_posbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     out.append("    if (base_identity) hipLaunchKernelGGL(k_posbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
@@ -1379,7 +1643,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
                f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}, "
                f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1, {'launch_fields' if fields_ok else 'nullptr'}, "
-               f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW, {'launch_ikgn' if ikgn_ok else 'nullptr'}}};")
+               f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW, {'launch_ikgn' if ikgn_ok else 'nullptr'}, {'launch_gp' if gp_ok else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"

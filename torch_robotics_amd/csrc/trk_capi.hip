@@ -1241,6 +1241,61 @@ int trk_rollout_cost_grad_f16(const TrkModel* m, const TrkCostModel* cm, const T
                         link_pos_out_f16, cost, gq, cost_sum, stream);
 }
 
+int trk_rollout_gp_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const TrkGpPrior* gp,
+                             const void* q, const void* qd, int64_t batch, int32_t horizon, int32_t io_dtype, void* link_pos_out,
+                             float* cost, void* gq, void* gqd, int32_t grad_dtype, float grad_scale, float* cost_sum, trk_stream_t stream) {
+    const char* who = "trk_rollout_gp_cost_grad";
+    int rc = check_model(m, who);
+    if (rc) return rc;
+    if (!cm || !w || !gp) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null argument");
+    if (batch < 0 || horizon < 1) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": bad batch/horizon");
+    if ((io_dtype != TRK_F32 && io_dtype != TRK_F16) || (grad_dtype != TRK_F32 && grad_dtype != TRK_F16) ||
+        (io_dtype == TRK_F32 && (grad_dtype != TRK_F32 || grad_scale != 1.0f)) || !(grad_scale > 0.0f) || !std::isfinite(grad_scale))
+        return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": io_dtype / grad_dtype must be TRK_F32 / TRK_F16 (fp32 trajectories: fp32 gradient, "
+                                         "grad_scale 1), grad_scale finite and > 0");
+    if (!(gp->dt > 0.0f) || !(gp->sigma > 0.0f)) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": the prior needs dt > 0 and sigma > 0");
+    if (cm->hdr.n_links_in != m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": cost model n_links_in != model n_links");
+    const int64_t n = batch * horizon;
+    if (n > 0 && (!q || !qd || !cost || !gq || !gqd)) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null q/qd/cost/gq/gqd");
+    if (n == 0) return TRK_OK;
+    const int io_mode = io_dtype == TRK_F32 ? 0 : (grad_dtype == TRK_F16 ? 1 : 2);
+    const TrkRolloutWeights we = effective_weights(cm, *w);
+    if (m->spec_enabled) {
+        const SpecEntry* e = model_spec_for(m, cm, &we);
+        if (e && e->launch_gp) {
+            SpecArgs a{};
+            a.C = cm->hdr; a.w = we;
+            std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+            std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+            a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
+            a.io_f16 = io_mode; a.grad_scale = grad_scale;
+            const float s2 = 1.0f / (gp->sigma * gp->sigma);
+            a.qd = qd; a.gqd = gqd; a.gp_dt = gp->dt; a.gp_w = gp->weight; a.gp_H = horizon;
+            a.gp_a = 12.0f * s2 / (gp->dt * gp->dt * gp->dt); a.gp_b = -6.0f * s2 / (gp->dt * gp->dt); a.gp_c = 4.0f * s2 / gp->dt;
+            if (e->launch_gp(a, base_is_identity(m), (hipStream_t)stream) == 0) {
+                TRK_HIP(hipGetLastError());
+                return TRK_OK;
+            }
+        }
+    }
+    // the two-launch form: the rollout, then the prior accumulated into its gradient, its factor costs into the per-sample costs
+    rc = rollout_impl(who, m, cm, w, io_mode, grad_scale, q, batch, horizon, link_pos_out, cost, gq, nullptr, stream);
+    if (rc) return rc;
+    rc = ensure_init();
+    if (rc) return rc;
+    if (batch > 0x7fffffff) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": batch too large");
+    // gqd is overwritten, gq accumulated: two calls of the prior kernel would read q twice, so gqd is zeroed and both are accumulated
+    TRK_HIP(hipMemsetAsync(gqd, 0, (size_t)n * m->hdr.n_dofs * (grad_dtype == TRK_F16 ? 2 : 4), (hipStream_t)stream));
+    // (the prior kernel's per-trajectory cost is not an output of this entry point: nullptr)
+    if (trk_launch_gp_prior(io_dtype == TRK_F16, grad_dtype == TRK_F16, io_dtype == TRK_F16 ? grad_scale : 1.0f, q, qd, batch, horizon,
+                            m->hdr.n_dofs, gp->dt, gp->sigma, gp->weight, nullptr, gq, gqd, 1, (hipStream_t)stream))
+        return fail(TRK_ERR_UNSUPPORTED, std::string(who) + ": one trajectory (horizon x dof x 2 floats) must fit the 160 KiB LDS");
+    trk_launch_gp_sample_cost(io_dtype == TRK_F16, q, qd, n, horizon, m->hdr.n_dofs, gp->dt, gp->sigma, gp->weight, cost, cost_sum,
+                              (hipStream_t)stream);
+    TRK_HIP(hipGetLastError());
+    return TRK_OK;
+}
+
 int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const TrkCostModel* cm, const TrkRolloutWeights* w,
                                  const float* q, int64_t batch, int32_t horizon, float* point_pos_out, float* cost, float* gq,
                                  float* cost_sum, trk_stream_t stream) {

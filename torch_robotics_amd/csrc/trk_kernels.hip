@@ -1960,7 +1960,36 @@ k_gp_prior(const T* __restrict__ q, const T* __restrict__ qd, int H, int D, floa
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) cost[blockIdx.x] = w * ((part[0] + part[1]) + (part[2] + part[3]));
+    if (threadIdx.x == 0 && cost) cost[blockIdx.x] = w * ((part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// The two small kernels of the TWO-LAUNCH form of trk_rollout_gp_cost_grad (robots / cost models the fused generated kernel does not
+// serve): the prior's factor between t and t + 1 is attributed to sample (b, t), cost[b, t] += w/2 e_t^T Q^-1 e_t, and the
+// per-wavefront cost sums are re-formed from the finished costs (same association order as the fused kernels' DPP reduction is not
+// needed: the sums are a convenience output, compared to rounding).
+template <class T>
+__global__ void __launch_bounds__(256)
+k_gp_sample_cost(const T* __restrict__ q, const T* __restrict__ qd, int64_t n, int H, int D, float dt, float a, float b, float c, float w,
+                 float* __restrict__ cost) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int t = (int)(s % H);
+    if (t + 1 >= H) return;
+    const T* p = q + s * D; const T* v = qd + s * D;
+    float acc = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float p0 = (float)p[d], v0 = (float)v[d];
+        const float ep = fmaf(dt, v0, p0) - (float)p[D + d], ev = v0 - (float)v[D + d];
+        const float rp = fmaf(a, ep, b * ev), rv = fmaf(b, ep, c * ev);
+        acc = fmaf(0.5f, fmaf(ep, rp, ev * rv), acc);
+    }
+    cost[s] += w * acc;
+}
+__global__ void __launch_bounds__(TRK_WAVE)
+k_block_sums(const float* __restrict__ cost, int64_t n, float* __restrict__ sums) {
+    const int64_t s = (int64_t)blockIdx.x * TRK_WAVE + threadIdx.x;
+    const float tot = wave_sum(s < n ? cost[s] : 0.0f);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
 // ============================================================================================
@@ -2333,6 +2362,15 @@ int trk_launch_gp_prior(int f16, int grad_f16, float grad_scale, const void* q, 
     else { if (vec) TRK_GP(float, float, true); else TRK_GP(float, float, false); }
 #undef TRK_GP
     return 0;
+}
+
+void trk_launch_gp_sample_cost(int f16, const void* q, const void* qd, int64_t n, int H, int D, float dt, float sigma, float w, float* cost,
+                               float* block_sums, hipStream_t st) {
+    const float s2 = 1.0f / (sigma * sigma);
+    const float a = 12.0f * s2 / (dt * dt * dt), b = -6.0f * s2 / (dt * dt), c = 4.0f * s2 / dt;
+    if (f16) hipLaunchKernelGGL(k_gp_sample_cost<_Float16>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const _Float16*)q, (const _Float16*)qd, n, H, D, dt, a, b, c, w, cost);
+    else hipLaunchKernelGGL(k_gp_sample_cost<float>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const float*)q, (const float*)qd, n, H, D, dt, a, b, c, w, cost);
+    if (block_sums) hipLaunchKernelGGL(k_block_sums, dim3(grid_for(n, TRK_WAVE)), dim3(TRK_WAVE), 0, st, cost, n, block_sums);
 }
 
 void trk_launch_finite_difference(const float* x, int64_t B, int H, int D, float dt, int method, float* out, hipStream_t st) {

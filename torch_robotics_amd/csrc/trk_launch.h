@@ -69,6 +69,8 @@ void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_inter
 // returns -1: a trajectory does not fit the LDS, -2: fp32 trajectories with fp16 gradients (not a mode)
 int trk_launch_gp_prior(int f16, int grad_f16, float grad_scale, const void* q, const void* qd, int64_t B, int H, int D, float dt, float sigma,
                         float w, float* cost, void* gq, void* gqd, int accumulate, hipStream_t st);
+void trk_launch_gp_sample_cost(int f16, const void* q, const void* qd, int64_t n, int H, int D, float dt, float sigma, float w, float* cost,
+                               float* block_sums, hipStream_t st);
 void trk_launch_finite_difference(const float* x, int64_t B, int H, int D, float dt, int method, float* out, hipStream_t st);
 void trk_launch_traj_diff_norm_sum(const float* x, int64_t B, int H, int S, int c0, int D, float* out, hipStream_t st);
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st);

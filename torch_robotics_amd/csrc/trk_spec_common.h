@@ -56,6 +56,12 @@ struct SpecArgs {
     // fp16 q (io_f16 != 0): the gradient is multiplied by grad_scale (fp32) before it is stored, an fp16 store saturates at
     // +-65504 instead of writing inf ("loss scaling": config 5's GP term reaches 1e5 .. 1e6 at sigma_gp = 0.1, dt = 5/128)
     float grad_scale;
+    // GP-prior fused into the rollout (launch_gp: trk_rollout_gp_cost_grad): velocities in, their gradient out, the prior's
+    // parameters a = 12 / (sigma^2 dt^3), b = -6 / (sigma^2 dt^2), c = 4 / (sigma^2 dt), its weight and the horizon (a lane's time
+    // step is sample % gp_H; samples of one trajectory are consecutive)
+    const void* qd; void* gqd;
+    float gp_dt, gp_a, gp_b, gp_c, gp_w;
+    int32_t gp_H;
 };
 
 typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
@@ -99,7 +105,7 @@ typedef void (*SpecIkGnLaunchFn)(const IkGnArgs& args, int base_identity, hipStr
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 20)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 21)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -132,6 +138,9 @@ struct SpecEntry {
     const int32_t* virtual_src; // [2 * n_virtual]
     const float* virtual_w;     // [2 * n_virtual]
     SpecIkGnLaunchFn launch_ikgn;   // Gauss-Newton IK iterations on ee_link (trk_ik_gn_steps); nullptr if not generated
+    // fused rollout + GP prior in one launch (trk_rollout_gp_cost_grad): returns 0, or 1 when this unit cannot serve the call
+    // (self-collision pairs between independently scheduled subtrees with w_self != 0) -- the caller then runs the two-launch form
+    int (*launch_gp)(const SpecArgs& args, int base_identity, hipStream_t stream);
 };
 
 // registry filled by static initialisers of the generated translation units
@@ -776,6 +785,171 @@ __device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows_prefilled(IO* __res
                                                                        float* lds) {
     spec_wave_sync();
     return spec_make_flusher<W, IO>(out, base, rows, lane, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pieces of the GP-fused rollout (k_rollout_gp): the wave's rows of q / qd as a RAW tile (HBM element type kept: an fp16 trajectory
+// costs 2 bytes per element of LDS), the rows of the two neighbouring samples next to it, and position blocks that leave segment
+// by segment.
+// ---------------------------------------------------------------------------------------------------------
+// Layout of a raw tile: PAD elements (a multiple of 16 bytes, >= D), then the 64 rows of the block, then one more row:
+//   body = tile + PAD (16-byte aligned);  body[r * D + j] = src[(base + r) * D + j] for r = -1 .. 64
+// rows -1 and 64 are the previous / next sample of the trajectory when it continues beyond this wavefront's block (else zero; the
+// caller masks them by the time step anyway).  Two halves like spec_load_rows_issue / finish: every load of both tiles is in
+// flight before the first LDS write.
+template <int D, class IO>
+struct RawRowsInFlight {
+    static constexpr int VE = 16 / sizeof(IO);                          // elements per 16-byte vector
+    static constexpr int PAD = (D + VE - 1) / VE * VE;
+    static constexpr int ELEMS = PAD + (TRK_WAVE + 1) * D;              // elements of a tile
+    static constexpr int BYTES = (ELEMS * (int)sizeof(IO) + 15) / 16 * 16;
+    static constexpr int NV = TRK_WAVE * D / VE, NJ = (NV + TRK_WAVE - 1) / TRK_WAVE;
+    trk_f4 v[NJ];
+    IO edge;                                                            // lanes 0 .. D-1: row -1; lanes 32 .. 32+D-1: row 64
+    bool fast;
+};
+template <int D, class IO>
+__device__ __forceinline__ RawRowsInFlight<D, IO> spec_raw_rows_issue(const IO* __restrict__ in, int64_t base, int rows, int lane,
+                                                                      bool has_prev, bool has_next) {
+    static_assert(D <= 32, "edge rows are fetched by one half-wave each");
+    RawRowsInFlight<D, IO> r;
+    const IO* src = in + base * D;
+    r.fast = rows == TRK_WAVE && (TRK_WAVE * D * sizeof(IO)) % 16 == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+#pragma unroll
+    for (int j = 0; j < RawRowsInFlight<D, IO>::NJ; ++j) {
+        const int k = lane + TRK_WAVE * j;
+        r.v[j] = (r.fast && k < RawRowsInFlight<D, IO>::NV) ? reinterpret_cast<const trk_f4*>(src)[k] : trk_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    r.edge = (IO)0.0f;
+    if (lane < D && has_prev) r.edge = src[lane - D];                   // the D elements in front of the block
+    if (lane >= 32 && lane < 32 + D && has_next) r.edge = src[TRK_WAVE * D + (lane - 32)];
+    return r;
+}
+template <int D, class IO>
+__device__ __forceinline__ IO* spec_raw_rows_finish(const RawRowsInFlight<D, IO>& r, const IO* __restrict__ in, int64_t base, int rows,
+                                                    int lane, IO* tile) {
+    IO* body = tile + RawRowsInFlight<D, IO>::PAD;
+    if (r.fast) {
+        trk_f4* b4 = reinterpret_cast<trk_f4*>(body);
+#pragma unroll
+        for (int j = 0; j < RawRowsInFlight<D, IO>::NJ; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            if (k < RawRowsInFlight<D, IO>::NV) b4[k] = r.v[j];
+        }
+    } else {
+        const IO* src = in + base * D;
+        const int count = rows * D;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            body[k] = k < count ? src[k] : (IO)0.0f;
+        }
+    }
+    if (lane < D) body[lane - D] = r.edge;
+    if (lane >= 32 && lane < 32 + D) body[TRK_WAVE * D + (lane - 32)] = r.edge;
+    return body;
+}
+
+// the wave's [64][D] fp32 tile (each lane wrote its own row) -> out rows [base, base + rows), multiplied by `scale` (SCALED)
+template <int D, class IO, bool SCALED>
+__device__ __forceinline__ void spec_store_acc_tile(IO* __restrict__ out, int64_t base, int rows, int lane, const float* tile, float scale) {
+    spec_wave_sync();
+    IO* dst = out + base * D;
+    constexpr int NV = TRK_WAVE * D / 4;
+    if (rows == TRK_WAVE && (TRK_WAVE * D) % 4 == 0 && ((reinterpret_cast<uintptr_t>(dst) & IoQuad<IO>::kAlignMask) == 0)) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile);
+#pragma unroll
+        for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            if (k < NV) {
+                float4 v = t4[k];
+                if (SCALED) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; IoQuad<IO>::store_wt_sat(dst, k, v); }
+                else IoQuad<IO>::store_wt(dst, k, v);
+            }
+        }
+    } else {
+        const int count = rows * D;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int k = lane + TRK_WAVE * j;
+            if (k < count) { if (SCALED) IoQuad<IO>::store_wt1_sat(dst + k, tile[k] * scale); else IoQuad<IO>::store_wt1(dst + k, tile[k]); }
+        }
+    }
+}
+
+// A segment's positions: columns [C0, C0 + C) of every sample's row of W elements, staged by each lane in its own LDS row and
+// written out as NU-element units (4 bytes: two halves or one float), unit e = 64 j + lane of store instruction j -> sample
+// e / UPS, unit e % UPS.  A sample's block is contiguous; an fp16 row of odd length starts 2-byte aligned for odd samples --
+// the dword stores are then unaligned, which gfx9+ in HSA mode handles (alignment mode = unaligned).  An odd block length (fp16)
+// leaves one trailing element per sample: one extra 2-byte store instruction.
+template <int W, int C0, int C, class IO>
+struct SegFlusher {
+    static constexpr int EPU = 4 / sizeof(IO);                          // elements per unit
+    static constexpr int UPS = C / EPU;                                 // whole units per sample
+    static constexpr bool ODD = (C % EPU) != 0;                         // fp16, odd block: a trailing half per sample
+    static constexpr int LS = UPS + (ODD ? 1 : 0);                      // dwords per lane row in LDS
+    static constexpr int NP = (TRK_WAVE * UPS + TRK_WAVE - 1) / TRK_WAVE + (ODD ? 1 : 0);     // store instructions
+    unsigned* lds;                                                      // this wave's staging region: [64][LS] dwords
+    unsigned long long g0;                                              // wave-uniform: address of element (base, C0) of the output
+    unsigned long long on;                                              // wave-uniform lane mask: all lanes (full, wanted) or none
+    int lane;
+    // stage this lane's C values (fp32 in registers) as IO elements
+    __device__ __forceinline__ void stage(const float (&v)[C]) const {
+        unsigned* row = lds + lane * LS;
+        if constexpr (sizeof(IO) == 4) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) row[k] = __builtin_bit_cast(unsigned, v[k]);
+        } else {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int k = 0; k < UPS; ++k) { const h2 h = {(_Float16)v[2 * k], (_Float16)v[2 * k + 1]}; row[k] = __builtin_bit_cast(unsigned, h); }
+            if constexpr (ODD) { const h2 h = {(_Float16)v[C - 1], (_Float16)0.0f}; row[UPS] = __builtin_bit_cast(unsigned, h); }
+        }
+    }
+    template <int J>
+    __device__ __forceinline__ void piece() const {
+        if constexpr (J >= 0 && J < NP) {
+            if constexpr (ODD && J == NP - 1) {                          // the trailing half of every sample's block
+                const unsigned v = lds[lane * LS + UPS];
+                const unsigned voff = (unsigned)((lane * W + C - 1) * (int)sizeof(IO));
+                unsigned long long saved;
+                asm volatile("s_and_saveexec_b64 %0, %3\n global_store_short %1, %2, %4 sc1\n s_mov_b64 exec, %0"
+                             : "=&s"(saved) : "v"(voff), "v"(v), "s"(on), "s"(g0) : "scc");
+            } else {
+                const int e = TRK_WAVE * J + lane, smp = e / UPS, u = e - smp * UPS;
+                const bool in = TRK_WAVE * J + TRK_WAVE <= TRK_WAVE * UPS || e < TRK_WAVE * UPS;
+                const unsigned v = lds[(in ? smp : 0) * LS + (in ? u : 0)];
+                const unsigned voff = (unsigned)((smp * W) * (int)sizeof(IO) + u * 4);
+                unsigned long long saved;
+                asm volatile("s_and_saveexec_b64 %0, %3\n global_store_dword %1, %2, %4 sc1\n s_mov_b64 exec, %0"
+                             : "=&s"(saved) : "v"(voff), "v"(v), "s"(in ? on : 0ull), "s"(g0) : "scc");
+            }
+        }
+    }
+    // tick slot CH of PPT pieces
+    template <int PPT, int CH>
+    __device__ __forceinline__ void tick() const { run<CH * PPT, CH * PPT + PPT>(); }
+    template <int A, int B>
+    __device__ __forceinline__ void run() const {
+        if constexpr (A < B && A < NP) { piece<A>(); run<A + 1, B>(); }
+    }
+};
+// the `flush` object the objective helpers see: tick slot CH = pieces [CH * PPT, CH * PPT + PPT) of a SegFlusher
+template <class F, int PPT>
+struct SegTicks {
+    const F& f;
+    template <int CH> __device__ __forceinline__ void chunk() const { f.template tick<PPT, CH>(); }
+    template <int A, int B> __device__ __forceinline__ void range() const { f.template run<A * PPT, B * PPT>(); }
+    template <int A> __device__ __forceinline__ void rest() const { f.template run<A * PPT, F::NP>(); }
+};
+
+template <int W, int C0, int C, class IO>
+__device__ __forceinline__ SegFlusher<W, C0, C, IO> spec_make_seg(IO* __restrict__ out, int64_t base, int rows, int lane, unsigned* lds) {
+    IO* dst = out ? out + base * W + C0 : nullptr;
+    const unsigned long long g = (unsigned long long)reinterpret_cast<uintptr_t>(dst);
+    const unsigned long long gu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+    return SegFlusher<W, C0, C, IO>{lds, gu, __builtin_amdgcn_ballot_w64(out != nullptr && lane < rows), lane};
 }
 
 // profiling hook: lane 0 of a wave records the shader clock at phase `k` (no-op when A.stamps == nullptr)

@@ -903,6 +903,60 @@ def gp_prior_cost_grad(q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: floa
     return cost, gq, gqd
 
 
+def _gp_args(model, q, qd, who):
+    if q.device.type != "cuda" or qd.device != q.device:
+        raise ValueError(f"{who}: q and qd must be tensors on the same GPU (there is no CPU path)")
+    if q.dim() != 3 or qd.shape != q.shape or q.dtype != qd.dtype or q.dtype not in (torch.float32, torch.float16) or \
+            not (q.is_contiguous() and qd.is_contiguous()):
+        raise ValueError(f"{who}: q, qd must be contiguous (batch, horizon, dof) tensors of the same fp32 / fp16 dtype")
+    _check_q_dofs(q, model.n_dofs, f"{who}(q)")
+    return (int(v) for v in q.shape)
+
+
+class RolloutGpPlan:
+    """BASELINE config 5's objective as ONE pre-bound launch (include/trk.h: trk_rollout_gp_cost_grad): fused FK + collision / EE
+    objectives + the constant-velocity GP prior + both gradients.  q, qd (B,H,D) fp32 or fp16 are read in place on every `launch()`;
+    `cost` (B,H) fp32 is the rollout's cost plus the prior's factor t -> t+1 at sample t, `gq` / `gqd` hold grad_scale x the gradients
+    in grad_dtype (fp16 by default for fp16 trajectories, saturating), `link_pos` (B,H,L,3) the positions (want_pos)."""
+
+    def __init__(self, model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: float,
+                 gp_weight: float = 1.0, want_pos: bool = True, grad_dtype=None, grad_scale: float = 1.0):
+        B, H, D = _gp_args(model, q, qd, "RolloutGpPlan")
+        f16 = q.dtype == torch.float16
+        gio, gcode, gs = _grad_mode(f16, grad_dtype, grad_scale, "RolloutGpPlan")
+        if not f16 and gs != 1.0:
+            raise ValueError("RolloutGpPlan: grad_scale applies to float16 trajectories only")
+        self.model, self.cm, self.q, self.qd, self.device, self.grad_scale = model, cm, q, qd, q.device, gs
+        self.B, self.H = B, H
+        self.link_pos = torch.empty((B, H, model.n_links, 3), device=q.device, dtype=q.dtype) if want_pos else None
+        self.cost = torch.empty((B, H), device=q.device, dtype=torch.float32)
+        self.gq = torch.empty((B, H, D), device=q.device, dtype=gio)
+        self.gqd = torch.empty((B, H, D), device=q.device, dtype=gio)
+        self._w = _abi.RolloutWeights(*[float(v) for v in weights])
+        self._gp = _abi.GpPrior(float(dt), float(sigma), float(gp_weight))
+        self._fn = lib().trk_rollout_gp_cost_grad
+        self._args = (model._h, cm._h, C.byref(self._w), C.byref(self._gp), q.data_ptr(), qd.data_ptr(), B, H, int(f16), _ptr(self.link_pos),
+                      self.cost.data_ptr(), self.gq.data_ptr(), self.gqd.data_ptr(), gcode, gs)
+
+    def launch(self, cost_sum_ptr: Optional[int] = None, stream: Optional[int] = None) -> None:
+        with _on(self.device):
+            if stream is None:
+                stream = _stream_of(self.device)
+            rc = self._fn(*self._args, cost_sum_ptr, stream)
+        if rc:
+            check(rc, "trk_rollout_gp_cost_grad")
+
+
+def rollout_gp_cost_grad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: float,
+                         gp_weight: float = 1.0, want_pos: bool = True, cost_sum: Optional[torch.Tensor] = None, grad_dtype=None,
+                         grad_scale: float = 1.0):
+    """One fused launch: -> (link_pos or None, cost (B,H), gq, gqd); see RolloutGpPlan."""
+    plan = RolloutGpPlan(model, cm, weights, q.contiguous(), qd.contiguous(), dt, sigma, gp_weight, want_pos, grad_dtype, grad_scale)
+    _check_buffer(cost_sum, n_blocks(plan.B * plan.H), torch.float32, q.device, "rollout_gp_cost_grad(cost_sum)", at_least=True)
+    plan.launch(_ptr(cost_sum))
+    return plan.link_pos, plan.cost, plan.gq, plan.gqd
+
+
 class GPPriorPlan:
     """Pre-bound GP-prior launch (the counterpart of `RolloutPlan`): buffers and arguments are resolved once, `launch()` is one
     C call (~3 us of host time instead of ~12 us through `gp_prior_cost_grad`).  q, qd (B,H,D) are read in place on every launch;
