@@ -468,6 +468,10 @@ def main():
     def barrier_in_stream():
         """A barrier that costs no host round trip: a one-element all-reduce enqueued on the launch stream completes on a rank
         only after every rank has reached it, so the `torch.cuda.synchronize()` that follows returns when all ranks are done."""
+        if native is not None:
+            # two communicators on one device (torch's and RcclAllReduce's own) must not run collectives concurrently: the barrier
+            # goes behind whatever the side stream still has in flight
+            stream.wait_stream(side)
         dist.all_reduce(flag)
 
     n_coll = [0]            # collectives inside the latest timed region

@@ -987,9 +987,12 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
     if (n_grid) {
         // the kernels gather one 16-byte record per point: pack the caller's arrays once (a snapshot, like every other table)
         const int64_t n_cells = (int64_t)d->grid.dims[0] * d->grid.dims[1] * d->grid.dims[2];
-        e = n_cells > 0 ? hipMalloc(&cm->d_cells, sizeof(float4) * (size_t)n_cells) : hipErrorInvalidValue;
+        const int nb0 = (d->grid.dims[0] + 3) / 4, nb1 = (d->grid.dims[1] + 3) / 4, nb2 = (d->grid.dims[2] + 3) / 4;
+        const int64_t n_rec = (int64_t)nb0 * nb1 * nb2 * 64;           // whole 4 x 4 x 4 bricks (grid_record)
+        h.grid.nb1 = nb1; h.grid.nb2 = nb2;
+        e = n_cells > 0 ? hipMalloc(&cm->d_cells, sizeof(float4) * (size_t)n_rec) : hipErrorInvalidValue;
         if (e == hipSuccess) {
-            trk_launch_grid_pack(d->grid.sdf, d->grid.grad, n_cells, cm->d_cells, nullptr);
+            trk_launch_grid_pack(d->grid.sdf, d->grid.grad, d->grid.dims, nb1, nb2, n_rec, cm->d_cells, nullptr);
             e = hipGetLastError();
             if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         }
@@ -1000,7 +1003,6 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
             return hip_fail(e, "trk_cost_model_create: packing the voxel grid");
         }
         h.grid.cells = cm->d_cells;
-        h.grid.sdf = d->grid.sdf; h.grid.grad = d->grid.grad;
         for (int k = 0; k < 3; ++k) {
             h.grid.dims[k] = d->grid.dims[k]; h.grid.lim_min[k] = d->grid.lim_min[k];
             h.grid.map_dim[k] = d->grid.map_dim[k]; h.grid.fdims[k] = (float)d->grid.dims[k];

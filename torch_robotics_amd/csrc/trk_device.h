@@ -57,8 +57,9 @@ struct alignas(16) DevObj {    // 16 dwords
 // the cost kernels (they live in DevCostHdr::spheres), and visited only by the per-object SDF queries.
 
 struct DevGrid {
-    const float* sdf;
-    const float* grad;
+    // bricks along y and z (the record table is tiled, see grid_cell); two spare words keep the struct's size
+    int32_t nb1, nb2;
+    int32_t _pad[2];
     const float4* cells;        // (gx, gy, gz, sdf) per voxel, built at trk_cost_model_create: ONE 16-byte gather per point instead
                                 // of a 4- and a 12-byte one from two arrays (random cells: every gather is its own cache line)
     int32_t dims[3];
@@ -351,7 +352,13 @@ __device__ __forceinline__ float prim_sdf(const DevPrim& P, float x, float y, fl
     return fminf(mu, 0.0f) + nn - P.r;
 }
 
-// grid_map_sdf.py:84-114: nearest-lower cell (linear index), stored gradient
+// position of voxel (i, j, k) in the tiled record table (host and device: trk_cost_model_create packs with the same function)
+__host__ __device__ __forceinline__ int64_t grid_record(int nb1, int nb2, int i, int j, int k) {
+    const int64_t brick = ((int64_t)(i >> 2) * nb1 + (j >> 2)) * nb2 + (k >> 2);
+    const int in = ((i & 2) << 4) | ((j & 2) << 3) | ((k & 2) << 2) | ((i & 1) << 2) | ((j & 1) << 1) | (k & 1);
+    return brick * 64 + in;
+}
+// grid_map_sdf.py:84-114: nearest-lower cell, stored gradient
 typedef float trk_f3u __attribute__((ext_vector_type(3), aligned(4)));       // a 12-byte gradient record: one dwordx3 load
 __device__ __forceinline__ int64_t grid_cell(const DevGrid& G, float x, float y, float z) {
     const float p[3] = {x, y, z};
@@ -364,7 +371,11 @@ __device__ __forceinline__ int64_t grid_cell(const DevGrid& G, float x, float y,
         v = v > G.dims[k] - 1 ? G.dims[k] - 1 : v;
         idx[k] = v;
     }
-    return ((int64_t)idx[0] * G.dims[1] + idx[1]) * G.dims[2] + idx[2];
+    // The records are TILED: 4 x 4 x 4 bricks of 1 KiB, inside a brick 2 x 2 x 2 cubes of 128 bytes (one L2 line).  A planner's
+    // trajectories are smooth along the horizon -- the 64 lanes of a wavefront are consecutive time steps --, so neighbouring lanes
+    // ask for neighbouring cells: in x-major order a step along x or y lands 640 KB / 3.2 KB away, here it stays in the line or
+    // the brick.  (The values gathered are the same: nearest-lower cell, stored gradient.)
+    return grid_record(G.nb1, G.nb2, idx[0], idx[1], idx[2]);
 }
 __device__ __forceinline__ float grid_sdf(const DevGrid& G, float x, float y, float z, float& gx, float& gy, float& gz) {
     const float4 c = G.cells[grid_cell(G, x, y, z)];

@@ -1452,12 +1452,23 @@ k_rotation_from(int axis, const float* __restrict__ in, int64_t n, float* __rest
     }
 }
 
-// voxel grid of a cost model: (sdf [n], grad [n, 3]) -> cells [n] = (gx, gy, gz, sdf)
+// voxel grid of a cost model: (sdf [n0,n1,n2], grad [n0,n1,n2,3]) -> the tiled record table (grid_record), record = (gx, gy, gz, sdf);
+// the dimensions are padded to whole 4 x 4 x 4 bricks (the padding is never addressed: cell indices are clamped to the grid)
 __global__ void __launch_bounds__(256)
-k_grid_pack(const float* __restrict__ sdf, const float* __restrict__ grad, int64_t n, float4* __restrict__ cells) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    cells[i] = make_float4(grad[3 * i], grad[3 * i + 1], grad[3 * i + 2], sdf[i]);
+k_grid_pack(const float* __restrict__ sdf, const float* __restrict__ grad, int n0, int n1, int n2, int nb1, int nb2, int64_t n_rec,
+            float4* __restrict__ cells) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    const int64_t brick = r >> 6;
+    const int in = (int)(r & 63);
+    const int bk = (int)(brick % nb2), bj = (int)((brick / nb2) % nb1), bi = (int)(brick / ((int64_t)nb1 * nb2));
+    const int i = 4 * bi + ((in >> 4) & 2) + ((in >> 2) & 1), j = 4 * bj + ((in >> 3) & 2) + ((in >> 1) & 1), k = 4 * bk + ((in >> 2) & 2) + (in & 1);
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (i < n0 && j < n1 && k < n2) {
+        const int64_t c = ((int64_t)i * n1 + j) * n2 + k;
+        v = make_float4(grad[3 * c], grad[3 * c + 1], grad[3 * c + 2], sdf[c]);
+    }
+    cells[r] = v;
 }
 
 // GridMapSDF.precompute_sdf grid_map_sdf.py:34-63 (analytic objects only) and
@@ -2325,8 +2336,8 @@ int trk_launch_jtj(int mfma, const float* lin, const float* ang, const float* r6
     return 0;
 }
 
-void trk_launch_grid_pack(const float* sdf, const float* grad, int64_t n, float4* cells, hipStream_t st) {
-    hipLaunchKernelGGL(k_grid_pack, dim3(grid_for(n, 256)), dim3(256), 0, st, sdf, grad, n, cells);
+void trk_launch_grid_pack(const float* sdf, const float* grad, const int32_t dims[3], int nb1, int nb2, int64_t n_rec, float4* cells, hipStream_t st) {
+    hipLaunchKernelGGL(k_grid_pack, dim3(grid_for(n_rec, 256)), dim3(256), 0, st, sdf, grad, dims[0], dims[1], dims[2], nb1, nb2, n_rec, cells);
 }
 
 void trk_launch_scale_rows(int f16, const void* g, const float* sc, int sc_stride, int64_t n, int D, void* out, hipStream_t st) {

@@ -53,7 +53,7 @@ void trk_launch_grid_precompute(const DevCostHdr& C, const int32_t* dims, const 
 void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int H, int S, int Hi, int D, const float* qmin,
                               const float* qmax, int64_t inner, uint8_t* flags, int64_t* idx, int32_t* counts,
                               int32_t* counts_host, int32_t ticket, float* gathered, hipStream_t st);
-void trk_launch_grid_pack(const float* sdf, const float* grad, int64_t n, float4* cells, hipStream_t st);
+void trk_launch_grid_pack(const float* sdf, const float* grad, const int32_t dims[3], int nb1, int nb2, int64_t n_rec, float4* cells, hipStream_t st);
 int trk_launch_jtj(int mfma, const float* lin, const float* ang, const float* r6, int64_t n, int D, float* JtJ, float* Jtr,
                    const float* damping, int damping_stride, float* dq, hipStream_t st);
 size_t trk_pack_scratch_floats(int H, int D);

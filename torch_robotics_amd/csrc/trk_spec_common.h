@@ -105,7 +105,7 @@ typedef void (*SpecIkGnLaunchFn)(const IkGnArgs& args, int base_identity, hipStr
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 21)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 22)
 
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
@@ -891,8 +891,8 @@ struct SegFlusher {
     static constexpr int NP = (TRK_WAVE * UPS + TRK_WAVE - 1) / TRK_WAVE + (ODD ? 1 : 0);     // store instructions
     unsigned* lds;                                                      // this wave's staging region: [64][LS] dwords
     unsigned long long g0;                                              // wave-uniform: address of element (base, C0) of the output
-    unsigned long long on;                                              // wave-uniform lane mask: all lanes (full, wanted) or none
-    int lane;
+    unsigned long long on;                                              // wave-uniform: ~0 when the positions are wanted, else 0
+    int lane, rows;
     // stage this lane's C values (fp32 in registers) as IO elements
     __device__ __forceinline__ void stage(const float (&v)[C]) const {
         unsigned* row = lds + lane * LS;
@@ -914,15 +914,15 @@ struct SegFlusher {
                 const unsigned voff = (unsigned)((lane * W + C - 1) * (int)sizeof(IO));
                 unsigned long long saved;
                 asm volatile("s_and_saveexec_b64 %0, %3\n global_store_short %1, %2, %4 sc1\n s_mov_b64 exec, %0"
-                             : "=&s"(saved) : "v"(voff), "v"(v), "s"(on), "s"(g0) : "scc");
+                             : "=&s"(saved) : "v"(voff), "v"(v), "s"(on & __builtin_amdgcn_ballot_w64(lane < rows)), "s"(g0) : "scc");
             } else {
                 const int e = TRK_WAVE * J + lane, smp = e / UPS, u = e - smp * UPS;
-                const bool in = TRK_WAVE * J + TRK_WAVE <= TRK_WAVE * UPS || e < TRK_WAVE * UPS;
+                const bool in = smp < rows;                              // rows <= 64: also masks the units past the last sample
                 const unsigned v = lds[(in ? smp : 0) * LS + (in ? u : 0)];
                 const unsigned voff = (unsigned)((smp * W) * (int)sizeof(IO) + u * 4);
                 unsigned long long saved;
                 asm volatile("s_and_saveexec_b64 %0, %3\n global_store_dword %1, %2, %4 sc1\n s_mov_b64 exec, %0"
-                             : "=&s"(saved) : "v"(voff), "v"(v), "s"(in ? on : 0ull), "s"(g0) : "scc");
+                             : "=&s"(saved) : "v"(voff), "v"(v), "s"(on & __builtin_amdgcn_ballot_w64(in)), "s"(g0) : "scc");
             }
         }
     }
@@ -949,7 +949,7 @@ __device__ __forceinline__ SegFlusher<W, C0, C, IO> spec_make_seg(IO* __restrict
     const unsigned long long g = (unsigned long long)reinterpret_cast<uintptr_t>(dst);
     const unsigned long long gu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) |
                                   (unsigned)__builtin_amdgcn_readfirstlane((int)g);
-    return SegFlusher<W, C0, C, IO>{lds, gu, __builtin_amdgcn_ballot_w64(out != nullptr && lane < rows), lane};
+    return SegFlusher<W, C0, C, IO>{lds, gu, out != nullptr ? ~0ull : 0ull, lane, rows};
 }
 
 // profiling hook: lane 0 of a wave records the shader clock at phase `k` (no-op when A.stamps == nullptr)

@@ -72,7 +72,10 @@ class RcclAllReduce:
     ring over xGMI, but enqueueing it costs one ctypes call instead of c10d's ~50 us of host work per call, which matters when the
     exchange is 2 kB and an evaluation is 10 us.  The communicator is this class's own: rank 0 creates a `ncclUniqueId` and the
     already initialised `torch.distributed` group (any backend) broadcasts its 128 bytes.  Opt-in (`bench.py --native-rccl`);
-    `all_reduce_sum_` remains the default path."""
+    `all_reduce_sum_` remains the default path.
+    Two communicators on one device must not have collectives in flight at the same time (RCCL / NCCL: deadlock-prone): a caller
+    that also uses `torch.distributed` on the device orders them -- the stream of one waits for the other's (`bench.py`: the
+    in-stream barriers wait for the side stream this class's all-reduces run on)."""
 
     NCCL_FLOAT32, NCCL_SUM = 7, 0
 

@@ -36,8 +36,8 @@ def scene_version(df_obj_list) -> tuple:
     of a grid's tensors.  The reference evaluates each object from its current pose on every call (primitives.py:387-405), so
     every cache of a `CostHandle` is keyed by this and a moved object rebuilds it.  Integers only -- this runs on every cost
     evaluation: an ObjectField takes a fresh version number whenever `pos` / `ori` are assigned (`set_position_orientation`
-    or the attributes).  In-place edits of the arrays (`obj.pos[0] = ...`, a primitive's centres or radii) are NOT seen;
-    assign a new array or call `set_position_orientation`."""
+    or the attributes).  The pose arrays are read-only (`obj.pos[0] = ...` raises: assign a new array or call
+    `set_position_orientation`); in-place edits of a primitive's centres or radii are NOT seen."""
     return tuple((id(o), id(o.sdf_tensor)) if isinstance(o, GridMapSDF) else (id(o), o._version) for o in df_obj_list)
 
 
@@ -120,6 +120,7 @@ class ObjectField(PrimitiveShapeField):                      # primitives.py:346
     @pos.setter
     def pos(self, value):
         self._pos = _np(value).astype(np.float32).reshape(3)
+        self._pos.setflags(write=False)     # an in-place edit would not be seen by scene_version: it raises instead (assign a new pose)
         self._version, self._cm = next(_version_counter), None
 
     @property
@@ -129,6 +130,7 @@ class ObjectField(PrimitiveShapeField):                      # primitives.py:346
     @ori.setter
     def ori(self, value):
         self._ori = _np(value).astype(np.float32).reshape(4)
+        self._ori.setflags(write=False)
         self._version, self._cm = next(_version_counter), None
 
     def set_position_orientation(self, pos=None, ori=None):

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
 import weakref
 from typing import Optional, Sequence
 
@@ -153,7 +154,7 @@ class ModelHandle:
 
 
 class CostHandle:
-    """Owns a TrkCostModel* (device copy of the objective tables; keeps grid tensors alive)."""
+    """Owns a TrkCostModel* (device copy of the objective tables, incl. a tiled snapshot of the voxel grid)."""
 
     def __init__(self, spec: CostModelSpec, device):
         spec.validate()
@@ -169,7 +170,12 @@ class CostHandle:
         desc, keep = _abi.cost_desc(spec, grid_ptrs)
         h = C.c_void_p()
         with _on(self.device):
+            if self._grid is not None:
+                # trk_cost_model_create snapshots the grid into its own record table on the NULL stream: the uploads above ran on
+                # torch's current stream, which may be a non-blocking side stream -- wait for them first
+                torch.cuda.current_stream(self.device).synchronize()
             check(lib().trk_cost_model_create(C.byref(desc), C.byref(h)), "trk_cost_model_create")
+        self._grid = None          # the kernels read the handle's own copy: do not keep 2 x the grid in HBM
         self._h = h
         self.n_links_in = spec.n_links_in
         self.n_objects = len(spec.objects)
@@ -1134,16 +1140,19 @@ class _PinnedCounters:
     _np = None
     _next = 0
     SLOTS = 64
+    _lock = threading.Lock()        # two threads validating trajectories at once must not be handed the same slot and ticket
 
     @classmethod
     def take(cls):
         """-> (slot pointer, numpy view of the slot, ticket)"""
-        if cls._buf is None:
-            cls._buf = torch.zeros(cls.SLOTS * 4, dtype=torch.int32).pin_memory()
-            cls._np = cls._buf.numpy()
-        cls._next += 1
-        k = cls._next % cls.SLOTS
-        ticket = (cls._next % 0x7ffffff0) + 1                  # never 0 (the slots start zeroed), distinct over many ring turns
+        with cls._lock:
+            if cls._buf is None:
+                cls._buf = torch.zeros(cls.SLOTS * 4, dtype=torch.int32).pin_memory()
+                cls._np = cls._buf.numpy()
+            cls._next += 1
+            n = cls._next
+        k = n % cls.SLOTS
+        ticket = (n % 0x7ffffff0) + 1                          # never 0 (the slots start zeroed), distinct over many ring turns
         return cls._buf.data_ptr() + 16 * k, cls._np[4 * k:4 * k + 4], ticket
 
 
