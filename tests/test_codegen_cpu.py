@@ -51,6 +51,22 @@ def test_every_bundled_urdf_has_an_ahead_of_time_unit():
     assert len(hashes) == len(codegen.SPEC_ROBOTS)
 
 
+def test_gp_fused_kernels_are_generated(monkeypatch):
+    """trk_rollout_gp_cost_grad's generated kernels: the tree schedule (k_rollout_gpt) is part of every unit that stages whole rows;
+    the segment schedule (k_rollout_gp: the dual Panda's arms one after the other, measured slower) only on request."""
+    kin, tmpl = codegen.template_for("dual_panda")
+    src = codegen.generate_rollout_source(kin, tmpl, "dual_panda")
+    assert "k_rollout_gpt_bi" in src and "launch_gp" in src and "k_rollout_gp_bi" not in src
+    monkeypatch.setenv("TRK_GP_SCHEDULE", "segments")
+    seg = codegen.generate_rollout_source(kin, tmpl, "dual_panda")
+    assert "k_rollout_gp_bi" in seg and "segment 0: links 1 .. 11" in seg and "segment 1: links 12 .. 22" in seg
+    assert "if (a.w.w_self != 0.0f) return 1;" in seg          # arm-vs-arm pairs: served by the two-launch form
+    monkeypatch.delenv("TRK_GP_SCHEDULE")
+    kin2, tmpl2 = codegen.template_for("ur10_allegro")           # ring-staged positions: no fused kernel, the C ABI takes the two-launch form
+    src2 = codegen.generate_rollout_source(kin2, tmpl2, "ur10_allegro")
+    assert "k_rollout_gpt_bi" not in src2 and "static int launch_gp" not in src2
+
+
 def test_model_hash_distinguishes_models():
     hashes = {codegen.model_hash(model(n)) for n in ("panda_arm_no_gripper", "panda_arm_hand", "ur10", "iiwa7")}
     assert len(hashes) == 4

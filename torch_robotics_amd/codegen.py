@@ -499,9 +499,12 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 E.raw(f"        hit |= spec_self_hit(A.coll_use_default ? cptr(A.C.self_margin)[{pi}] : A.coll_margin, {pa}, {pb});")
             E.raw("    }")
 
-    for base_identity in (True, False):
+    # GPT: the same kernel with the GP prior fused in ("tree" schedule of trk_rollout_gp_cost_grad: the whole tree at once, like
+    # k_rollout -- see k_rollout_gp below for the segment schedule and for what the prior adds)
+    gpt_ok = (not chunked) and not tmpl.virtual and D <= 32
+    for base_identity, GPT in ((True, False), (False, False)) + (((True, True), (False, True)) if gpt_ok else ()):
         E = Emitter()
-        kname = "k_rollout_bi" if base_identity else "k_rollout_bg"
+        kname = ("k_rollout_gpt_" if GPT else "k_rollout_") + ("bi" if base_identity else "bg")
         # small arms fit 128 VGPRs (4 waves/SIMD: the whole 4096 x 64 batch resident); big trees get 256 VGPRs
         # FAST (two-wavefront kernels only): scene_is_fast(A.C) -- a few equal spheres and nothing else -- is decided at the launch and
         # only that scene path is compiled into the instantiation (5-rep same-box A/B: dual Panda 19.5 -> 18.6 us, UR10 + Allegro
@@ -543,7 +546,45 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    spec_stamp(A.stamps, wblock, 0, lane);")
         E.raw("    spec_stamp_real(A.stamps, wblock, 2, lane);      // 100 MHz chip-wide clock: aligns the per-CU s_memtime domains")
         E.raw("    float q[D];")
-        E.raw("    spec_load_q<D>(static_cast<const IOQ*>(A.q), base, rows, lane, lds, q);")
+        if not GPT:
+            E.raw("    spec_load_q<D>(static_cast<const IOQ*>(A.q), base, rows, lane, lds, q);")
+        else:
+            E.raw("    typedef RawRowsInFlight<D, IOQ> Raw;")
+            E.raw(f"    static_assert(2 * Raw::BYTES <= TRK_WAVE * {lds_lane} * 4 && TRK_WAVE * D * 4 <= TRK_WAVE * {lds_lane} * 4, \"the raw q / qd tiles share the staging tile\");")
+            E.raw("    const unsigned Hh = (unsigned)A.gp_H;")
+            E.raw("    const unsigned t0 = (unsigned)(base % (int64_t)A.gp_H);")
+            E.raw("    const unsigned tl = (t0 + (unsigned)lane) % Hh, t_last = (t0 + (unsigned)(TRK_WAVE - 1)) % Hh;")
+            E.raw("    const bool edge_prev = rows > 0 && t0 > 0u, edge_next = rows == TRK_WAVE && t_last + 1u < Hh && base + TRK_WAVE < A.n;")
+            E.raw("    const Raw rq = spec_raw_rows_issue<D, IOQ>(static_cast<const IOQ*>(A.q), base, rows, lane, edge_prev, edge_next);")
+            E.raw("    const Raw rv = spec_raw_rows_issue<D, IOQ>(static_cast<const IOQ*>(A.qd), base, rows, lane, edge_prev, edge_next);")
+            E.raw("    const IOQ* qb = spec_raw_rows_finish<D, IOQ>(rq, static_cast<const IOQ*>(A.q), base, rows, lane, reinterpret_cast<IOQ*>(lds));")
+            E.raw("    const IOQ* vb = spec_raw_rows_finish<D, IOQ>(rv, static_cast<const IOQ*>(A.qd), base, rows, lane, reinterpret_cast<IOQ*>(reinterpret_cast<unsigned char*>(lds) + Raw::BYTES));")
+            E.raw("    spec_wave_sync();")
+            E.raw("    float gpv[D], cost_gp;")
+            E.raw("    {")
+            E.raw("        // ---- the prior: e_t = (p_t + dt v_t - p_t+1, v_t - v_t+1), r = Q^-1 e; this sample takes part in factors t-1 and t")
+            E.raw("        const bool on = lane < rows;")
+            E.raw("        const float mn = (on && tl + 1u < Hh) ? 1.0f : 0.0f, mp = (on && tl > 0u) ? 1.0f : 0.0f;")
+            E.raw("        const float dt = A.gp_dt, ga = A.gp_a, gb = A.gp_b, gc = A.gp_c;")
+            E.raw("        float gvv[D], accg = 0.0f;")
+            E.raw("#pragma unroll")
+            E.raw("        for (int d = 0; d < D; ++d) {")
+            E.raw("            const float p0 = (float)qb[lane * D + d], v0 = (float)vb[lane * D + d];")
+            E.raw("            const float pm = (float)qb[(lane - 1) * D + d], vm = (float)vb[(lane - 1) * D + d];")
+            E.raw("            const float pn = (float)qb[(lane + 1) * D + d], vn = (float)vb[(lane + 1) * D + d];")
+            E.raw("            const float ep = fmaf(dt, v0, p0) - pn, ev = v0 - vn;")
+            E.raw("            const float rp = fmaf(ga, ep, gb * ev), rv_ = fmaf(gb, ep, gc * ev);")
+            E.raw("            accg = fmaf(0.5f * mn, fmaf(ep, rp, ev * rv_), accg);")
+            E.raw("            const float em = fmaf(dt, vm, pm) - p0, fm = vm - v0;")
+            E.raw("            gpv[d] = A.gp_w * (mn * rp - mp * fmaf(ga, em, gb * fm));")
+            E.raw("            gvv[d] = A.gp_w * (mn * fmaf(dt, rp, rv_) - mp * fmaf(gb, em, gc * fm));")
+            E.raw("            q[d] = p0;")
+            E.raw("        }")
+            E.raw("        cost_gp = A.gp_w * accg;")
+            E.raw("        // d cost / d qd is final: out through the staging tile (its first line waits for every lane's reads of the raw rows)")
+            E.raw("        spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base, rows, lane, lds, gvv, A.grad_scale);")
+            E.raw("        spec_wave_sync();")
+            E.raw("    }")
         E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
         E.raw("    if constexpr (BOX) spec_load_spheres_finish(lds_prm, lane, prm);")
         E.raw("    spec_stamp(A.stamps, wblock, 1, lane);")
@@ -657,6 +698,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw("    }")
         E.raw(tick_line())
         E.raw("    spec_stamp(A.stamps, wblock, 5, lane);")
+        if GPT:
+            E.raw("    cost += cost_gp;           // the prior's factor t -> t + 1, attributed to this sample")
         E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
         E.raw("    if (A.cost_sum) {")
         E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
@@ -671,7 +714,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                                       {l: rb for l, _, rb in tracked}, masked, tick=tick_line, order=walk)
         E.raw("    spec_stamp(A.stamps, wblock, 6, lane);")
         E.raw(f"    flush.template rest<{next_chunk[0]}>();")
-        E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
+        if GPT:
+            E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) + f' + gpv[{d}]' for d in range(D))}}};")
+        else:
+            E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gq), base, rows, lane, lds, gv, A.grad_scale);")
         E.raw("    spec_stamp(A.stamps, wblock, 7, lane);")
         E.raw("}")
@@ -729,7 +775,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             segs.append(seg)
         if len(segs) > 1 and gp_cross_pairs:
             pass            # served with w_self == 0 only (launch_gp returns 1 otherwise)
-    for base_identity in ((True, False) if gp_ok else ()):
+    # The segment schedule is compiled only on request (TRK_GP_SCHEDULE=segments at generation time): measured on the dual Panda it
+    # is slower than the tree schedule above -- its wavefronts are VALU-bound either way, and what one resident
+    # generation gains the serial arms lose in instruction-level parallelism.
+    use_seg = gp_ok and (os.environ.get("TRK_GP_SCHEDULE", "tree") == "segments" or not gpt_ok)
+    for base_identity in ((True, False) if use_seg else ()):
         E = Emitter()
         kname = "k_rollout_gp_bi" if base_identity else "k_rollout_gp_bg"
         fast_t = D > 8
@@ -742,23 +792,26 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    typedef typename IoTraits<IO>::Q IOQ;")
         E.raw("    typedef typename IoTraits<IO>::G IOG;")
         E.raw("    typedef RawRowsInFlight<D, IOQ> Raw;")
-        # LDS per wavefront: accumulator | raw q tile | scratch (raw qd tile, then the gqd staging tile, then one segment's positions)
-        seg_ls = []
-        for sg in segs:
-            seg_ls.append((sg["ncol"], (sg["ncol"] + 1) // 2))       # dwords per lane row: fp32, fp16
-        E.raw(f"    constexpr int SEG_DW = sizeof(IOQ) == 4 ? {max(a for a, _ in seg_ls)} : {max(b for _, b in seg_ls)};      // widest segment row, dwords")
-        E.raw("    constexpr int ACC_B = TRK_WAVE * D * 4, QRAW_B = Raw::BYTES;")
-        E.raw("    constexpr int SCR_B0 = TRK_WAVE * SEG_DW * 4 > ACC_B ? TRK_WAVE * SEG_DW * 4 : ACC_B;")
-        E.raw("    constexpr int SCR_B = ((SCR_B0 > Raw::BYTES ? SCR_B0 : Raw::BYTES) + 15) / 16 * 16;")
-        E.raw("    constexpr int WAVE_B = ACC_B + QRAW_B + SCR_B;")
+        # LDS per wavefront: accumulator [64][D] fp32 | raw q of the later segments [64][DL] | image: first the raw q and qd tiles, then
+        # the gqd staging tile, then the positions as they will lie in HBM
+        later_dofs = [d for sg in segs[1:] for d in sg["dofs"]]
+        DL = len(later_dofs)
+        E.raw(f"    constexpr int DL = {DL};            // joints of the segments after the first: their raw q waits in LDS")
+        E.raw("    constexpr int ACC_B = TRK_WAVE * D * 4, QL_B = (TRK_WAVE * DL * (int)sizeof(IOQ) + 15) / 16 * 16;")
+        E.raw(f"    constexpr int IMG_B0 = TRK_WAVE * {3 * L} * (int)sizeof(IOQ);")
+        E.raw("    constexpr int IMG_B1 = IMG_B0 > 2 * Raw::BYTES ? IMG_B0 : 2 * Raw::BYTES;")
+        E.raw("    constexpr int IMG_B = ((IMG_B1 > ACC_B ? IMG_B1 : ACC_B) + 15) / 16 * 16;")
+        E.raw("    constexpr int WAVE_B = ACC_B + QL_B + IMG_B;")
         E.raw("    // the sphere (and primitive) tables are shared by the workgroup's wavefronts here: one barrier at the top, 192 bytes of LDS per wavefront saved")
         E.raw("    __shared__ __attribute__((aligned(16))) unsigned char lds_all[SPEC_WAVES * WAVE_B + TRK_LDS_SPHERES * 16 + (BOX ? TRK_LDS_PRIMS * 32 : 0)];")
         E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
         E.raw("    unsigned char* wl = lds_all + wave * WAVE_B;")
         E.raw("    float* acc = reinterpret_cast<float*>(wl);                      // [64][D] fp32: d cost / d q, prior first, then the segments")
-        E.raw("    IOQ* qtile = reinterpret_cast<IOQ*>(wl + ACC_B);               // raw q rows of the block (+ the neighbouring rows)")
-        E.raw("    float* scr = reinterpret_cast<float*>(wl + ACC_B + QRAW_B);")
+        E.raw("    IOQ* qlater = reinterpret_cast<IOQ*>(wl + ACC_B);              // [64][DL]: raw q of the later segments' joints")
+        E.raw("    IOQ* img = reinterpret_cast<IOQ*>(wl + ACC_B + QL_B);          // the output image; before that: scratch")
+        E.raw("    IOQ* qtile = img;                                               // raw q rows of the block (+ the neighbouring rows)")
+        E.raw("    float* scr = reinterpret_cast<float*>(wl + ACC_B + QL_B);")
         E.raw("    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_WAVES * WAVE_B);")
         E.raw("    float4* lds_prm = BOX ? lds_sph + TRK_LDS_SPHERES : nullptr;")
         E.raw("    {")
@@ -777,9 +830,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const Raw rq = spec_raw_rows_issue<D, IOQ>(static_cast<const IOQ*>(A.q), base, rows, lane, edge_prev, edge_next);")
         E.raw("    const Raw rv = spec_raw_rows_issue<D, IOQ>(static_cast<const IOQ*>(A.qd), base, rows, lane, edge_prev, edge_next);")
         E.raw("    const IOQ* qb = spec_raw_rows_finish<D, IOQ>(rq, static_cast<const IOQ*>(A.q), base, rows, lane, qtile);")
-        E.raw("    const IOQ* vb = spec_raw_rows_finish<D, IOQ>(rv, static_cast<const IOQ*>(A.qd), base, rows, lane, reinterpret_cast<IOQ*>(scr));")
+        E.raw("    const IOQ* vb = spec_raw_rows_finish<D, IOQ>(rv, static_cast<const IOQ*>(A.qd), base, rows, lane, reinterpret_cast<IOQ*>(wl + ACC_B + QL_B + Raw::BYTES));")
         E.raw("    __syncthreads();            // the shared scene tables (and, wave-locally, the tiles) are in LDS")
         E.raw("    float cost;")
+        E.raw("    float " + ", ".join(f"q0_{d}" for d in segs[0]["dofs"]) + ";")
         E.raw("    {")
         E.raw("        // ---- the prior: e_t = (p_t + dt v_t - p_t+1, v_t - v_t+1), r = Q^-1 e; this sample takes part in factors t-1 and t")
         E.raw("        const bool on = lane < rows;")
@@ -801,10 +855,17 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("        cost = A.gp_w * accg;")
         E.raw("#pragma unroll")
         E.raw("        for (int d = 0; d < D; ++d) acc[lane * D + d] = gpv[d];")
+        E.raw("        // the raw q tile is about to be overwritten: the first segment's joints go to registers, the others' wait in LDS")
+        for d in segs[0]["dofs"]:
+            E.raw(f"        q0_{d} = (float)qb[lane * D + {d}];")
+        for k_, d in enumerate(later_dofs):
+            E.raw(f"        qlater[lane * DL + {k_}] = qb[lane * D + {d}];")
         E.raw("        // d cost / d qd is final: out through the scratch tile (its first line waits for every lane's reads of the qd rows)")
         E.raw("        spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base, rows, lane, scr, gvv, A.grad_scale);")
         E.raw("    }")
         E.raw("    unsigned passbits = 0u;")
+        E.raw(f"    const ImgFlusher<{3 * L}, IOQ> pimg = spec_make_img<{3 * L}, IOQ>(static_cast<IOQ*>(A.link_pos), base, rows, lane, img);")
+        E.raw("    spec_wave_sync();          // the gqd staging tile has been read out: the image may be written")
         R: Dict[int, List[List[S]]] = {}
         t: Dict[int, List[S]] = {}
         passv: Dict[int, S] = {}
@@ -817,19 +878,18 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         for k, sg in enumerate(segs):
             E.raw(f"    // ================= segment {k}: links {sg['links'][0]} .. {sg['links'][-1]} =================")
             E.raw("    {")
-            _emit_angles(E, kin, links=sg["links"], declare_passbits=False, qexpr=lambda d: f"(float)qb[lane * D + {d}]")
+            if k == 0:
+                _emit_angles(E, kin, links=sg["links"], declare_passbits=False, qexpr=lambda d: f"q0_{d}")
+            else:
+                _emit_angles(E, kin, links=sg["links"], declare_passbits=False,
+                             qexpr=lambda d: f"(float)qlater[lane * DL + {later_dofs.index(d)}]")
             for i in sg["links"]:
                 _emit_fk_link(E, kin, i, R, t, passv, snap)
-            ncol = sg["ncol"]
-            pos_list = ", ".join(E.expr(t[i][kk]) for i in sg["cols"] for kk in range(3))
-            E.raw(f"    const SegFlusher<{3 * L}, {sg['col0']}, {ncol}, IOQ> seg = spec_make_seg<{3 * L}, {sg['col0']}, {ncol}, IOQ>("
-                  "static_cast<IOQ*>(A.link_pos), base, rows, lane, reinterpret_cast<unsigned*>(scr));")
-            E.raw("    spec_wave_sync();          // whatever used the scratch before has been consumed")
             E.raw("    if (A.link_pos) {")
-            E.raw(f"        const float pv[{ncol}] = {{{pos_list}}};")
-            E.raw("        seg.stage(pv);")
+            for i in sg["cols"]:
+                E.raw("        " + " ".join(f"pimg.put({3 * i + kk}, {E.expr(t[i][kk])});" for kk in range(3)))
             E.raw("    }")
-            E.raw("    spec_wave_sync();")
+            last = k == len(segs) - 1
             # tick slots of this segment: the scene evaluation's, one after the EE term, one per two links of the reverse pass
             n_obj = len(sg["obj"])
             if 0 < n_obj <= LINK_OBJ_GROUP_MAX:
@@ -841,9 +901,13 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             else:
                 groups = []
             n_slots = OBJ_TICK_SLOTS * len(groups) + 1 + sum(1 for p in range(len(sg["links"]), 0, -1) if p % 2 == 0)
-            # pieces of this segment for both element sizes -> pieces per tick slot
-            E.raw(f"    constexpr int PPT = (decltype(seg)::NP + {n_slots - 1}) / {n_slots};")
-            E.raw("    const SegTicks<decltype(seg), PPT> flush{seg};")
+            if last:
+                E.raw("    spec_wave_sync();          // the image is complete")
+                E.raw("    spec_img_copy_slow(pimg, static_cast<IOQ*>(A.link_pos), base, rows);       // ragged last wavefront / unaligned view only")
+                E.raw(f"    constexpr int PPT = (decltype(pimg)::NP + {n_slots - 1}) / {n_slots};")
+            else:
+                E.raw("    constexpr int PPT = 0;     // the image is not complete before the last segment has staged its links")
+            E.raw("    const ImgTicks<decltype(pimg), PPT> flush{pimg};")
             next_chunk = [0]
 
             def tick_line(indent="    "):
@@ -1569,16 +1633,17 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         prev = f"sw{k}"
     out.append("    if (a.io_f16 == TRK_IO_F16) sw0(_Float16{}); else if (a.io_f16 == TRK_IO_F16_G32) sw0(HalfG32{}); else sw0(float{});")
     out.append("}")
-    if gp_ok:
+    if gp_ok or gpt_ok:
         out.append("static int launch_gp(const SpecArgs& a, int base_identity, hipStream_t st) {")
-        if gp_cross_pairs:
-            out.append("    if (a.w.w_self != 0.0f) return 1;      // self pairs between independently scheduled subtrees: the two-launch form serves them")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
         sw = "scene_is_fast(a.C)" if D > 8 else "a.C.n_box_objects > 0 && a.C.n_prims <= TRK_LDS_PRIMS"
+        if use_seg and gp_cross_pairs:
+            out.append("    if (a.w.w_self != 0.0f) return 1;      // self pairs between independently scheduled subtrees: the two-launch form serves them")
+        kn = "k_rollout_gp_" if use_seg else "k_rollout_gpt_"
         out.append("    auto go = [&](auto io, auto c0) {")
         out.append("        using IOT = decltype(io);")
-        out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_gp_bi<IOT, decltype(c0)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-        out.append("        else hipLaunchKernelGGL((k_rollout_gp_bg<IOT, decltype(c0)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append(f"        if (base_identity) hipLaunchKernelGGL(({kn}bi<IOT, decltype(c0)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append(f"        else hipLaunchKernelGGL(({kn}bg<IOT, decltype(c0)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    };")
         out.append(f"    auto sw = [&](auto io) {{ if ({sw}) go(io, std::true_type{{}}); else go(io, std::false_type{{}}); }};")
         out.append("    if (a.io_f16 == TRK_IO_F16) sw(_Float16{}); else if (a.io_f16 == TRK_IO_F16_G32) sw(HalfG32{}); else sw(float{});")
@@ -1643,7 +1708,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
                f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}, "
                f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1, {'launch_fields' if fields_ok else 'nullptr'}, "
-               f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW, {'launch_ikgn' if ikgn_ok else 'nullptr'}, {'launch_gp' if gp_ok else 'nullptr'}}};")
+               f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW, {'launch_ikgn' if ikgn_ok else 'nullptr'}, {'launch_gp' if (gp_ok or gpt_ok) else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append(f"}}  // namespace spec_{ident}")
     return "\n".join(out) + "\n"

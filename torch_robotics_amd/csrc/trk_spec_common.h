@@ -877,56 +877,39 @@ __device__ __forceinline__ void spec_store_acc_tile(IO* __restrict__ out, int64_
     }
 }
 
-// A segment's positions: columns [C0, C0 + C) of every sample's row of W elements, staged by each lane in its own LDS row and
-// written out as NU-element units (4 bytes: two halves or one float), unit e = 64 j + lane of store instruction j -> sample
-// e / UPS, unit e % UPS.  A sample's block is contiguous; an fp16 row of odd length starts 2-byte aligned for odd samples --
-// the dword stores are then unaligned, which gfx9+ in HSA mode handles (alignment mode = unaligned).  An odd block length (fp16)
-// leaves one trailing element per sample: one extra 2-byte store instruction.
-template <int W, int C0, int C, class IO>
-struct SegFlusher {
-    static constexpr int EPU = 4 / sizeof(IO);                          // elements per unit
-    static constexpr int UPS = C / EPU;                                 // whole units per sample
-    static constexpr bool ODD = (C % EPU) != 0;                         // fp16, odd block: a trailing half per sample
-    static constexpr int LS = UPS + (ODD ? 1 : 0);                      // dwords per lane row in LDS
-    static constexpr int NP = (TRK_WAVE * UPS + TRK_WAVE - 1) / TRK_WAVE + (ODD ? 1 : 0);     // store instructions
-    unsigned* lds;                                                      // this wave's staging region: [64][LS] dwords
-    unsigned long long g0;                                              // wave-uniform: address of element (base, C0) of the output
-    unsigned long long on;                                              // wave-uniform: ~0 when the positions are wanted, else 0
-    int lane, rows;
-    // stage this lane's C values (fp32 in registers) as IO elements
-    __device__ __forceinline__ void stage(const float (&v)[C]) const {
-        unsigned* row = lds + lane * LS;
-        if constexpr (sizeof(IO) == 4) {
-#pragma unroll
-            for (int k = 0; k < C; ++k) row[k] = __builtin_bit_cast(unsigned, v[k]);
-        } else {
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int k = 0; k < UPS; ++k) { const h2 h = {(_Float16)v[2 * k], (_Float16)v[2 * k + 1]}; row[k] = __builtin_bit_cast(unsigned, h); }
-            if constexpr (ODD) { const h2 h = {(_Float16)v[C - 1], (_Float16)0.0f}; row[UPS] = __builtin_bit_cast(unsigned, h); }
-        }
-    }
+// The positions of the GP-fused kernel: every lane stages its sample's elements AS HBM ELEMENTS (IO) at their place in the
+// wavefront's output image -- img[lane * W + c], the 64 rows back to back exactly as they lie in HBM (an fp16 image is half the
+// size of the fp32 tile spec_stage_rows keeps: 8.8 KB for the dual Panda) -- segment by segment; once the last segment is staged
+// the image leaves as contiguous 16-byte vectors, one LDS read at an immediate offset and one store with an SGPR base per piece.
+// (First version: each segment's columns left on their own as 4-byte pieces -- a sample's block is contiguous but the blocks of
+// one store instruction are not, every 64-byte line was written in parts by several instructions: 7.7 us for the dual Panda's
+// 36 MB where these whole-line stores take 2.5; as write-back stores 26 us more.)
+template <int W, class IO>
+struct ImgFlusher {
+    static constexpr int BYTES = TRK_WAVE * W * (int)sizeof(IO);
+    static constexpr int NV = BYTES / 16;                                // whole 16-byte vectors (64 W elements: always a multiple of 16 bytes)
+    static constexpr int NP = (NV + TRK_WAVE - 1) / TRK_WAVE;            // store instructions
+    static constexpr int TAIL = NV - (NP - 1) * TRK_WAVE;                // lanes of the last one
+    static_assert(BYTES % 16 == 0, "64 rows of W elements are whole 16-byte vectors");
+    IO* img;                                                             // this wave's image
+    const trk_f4* src;                                                   // this lane's vector of piece 0
+    unsigned voff;                                                       // lane * 16
+    unsigned long long g0;                                               // wave-uniform: address of the wave's first output byte
+    unsigned long long on;                                               // wave-uniform: all lanes (full wavefront, positions wanted) or none
+    int lane;
+    // a lane's own row, element c
+    __device__ __forceinline__ void put(int c, float v) const { img[lane * W + c] = (IO)v; }
     template <int J>
     __device__ __forceinline__ void piece() const {
         if constexpr (J >= 0 && J < NP) {
-            if constexpr (ODD && J == NP - 1) {                          // the trailing half of every sample's block
-                const unsigned v = lds[lane * LS + UPS];
-                const unsigned voff = (unsigned)((lane * W + C - 1) * (int)sizeof(IO));
-                unsigned long long saved;
-                asm volatile("s_and_saveexec_b64 %0, %3\n global_store_short %1, %2, %4 sc1\n s_mov_b64 exec, %0"
-                             : "=&s"(saved) : "v"(voff), "v"(v), "s"(on & __builtin_amdgcn_ballot_w64(lane < rows)), "s"(g0) : "scc");
-            } else {
-                const int e = TRK_WAVE * J + lane, smp = e / UPS, u = e - smp * UPS;
-                const bool in = smp < rows;                              // rows <= 64: also masks the units past the last sample
-                const unsigned v = lds[(in ? smp : 0) * LS + (in ? u : 0)];
-                const unsigned voff = (unsigned)((smp * W) * (int)sizeof(IO) + u * 4);
-                unsigned long long saved;
-                asm volatile("s_and_saveexec_b64 %0, %3\n global_store_dword %1, %2, %4 sc1\n s_mov_b64 exec, %0"
-                             : "=&s"(saved) : "v"(voff), "v"(v), "s"(on & __builtin_amdgcn_ballot_w64(in)), "s"(g0) : "scc");
-            }
+            const trk_f4 v = (J < NP - 1 || TAIL == TRK_WAVE || lane < TAIL) ? src[J * TRK_WAVE] : src[0];
+            const unsigned long long g = g0 + (unsigned long long)J * (TRK_WAVE * 16);
+            const unsigned long long m = (J < NP - 1 || TAIL == TRK_WAVE) ? on : (on & ((1ull << (TAIL & 63)) - 1ull));
+            unsigned long long saved;
+            asm volatile("s_and_saveexec_b64 %0, %4\n global_store_dwordx4 %1, %2, %3 sc1\n s_mov_b64 exec, %0\n s_nop 0"
+                         : "=&s"(saved) : "v"(voff), "v"(v), "s"(g), "s"(m) : "scc");
         }
     }
-    // tick slot CH of PPT pieces
     template <int PPT, int CH>
     __device__ __forceinline__ void tick() const { run<CH * PPT, CH * PPT + PPT>(); }
     template <int A, int B>
@@ -934,22 +917,30 @@ struct SegFlusher {
         if constexpr (A < B && A < NP) { piece<A>(); run<A + 1, B>(); }
     }
 };
-// the `flush` object the objective helpers see: tick slot CH = pieces [CH * PPT, CH * PPT + PPT) of a SegFlusher
+// the `flush` object the objective helpers see: tick slot CH = pieces [CH * PPT, CH * PPT + PPT) of an ImgFlusher (PPT = 0: the
+// image is not complete yet -- an earlier segment's ticks do nothing)
 template <class F, int PPT>
-struct SegTicks {
+struct ImgTicks {
     const F& f;
-    template <int CH> __device__ __forceinline__ void chunk() const { f.template tick<PPT, CH>(); }
-    template <int A, int B> __device__ __forceinline__ void range() const { f.template run<A * PPT, B * PPT>(); }
-    template <int A> __device__ __forceinline__ void rest() const { f.template run<A * PPT, F::NP>(); }
+    template <int CH> __device__ __forceinline__ void chunk() const { if constexpr (PPT > 0) f.template tick<PPT, CH>(); }
+    template <int A, int B> __device__ __forceinline__ void range() const { if constexpr (PPT > 0) f.template run<A * PPT, B * PPT>(); }
+    template <int A> __device__ __forceinline__ void rest() const { if constexpr (PPT > 0) f.template run<A * PPT, F::NP>(); }
 };
-
-template <int W, int C0, int C, class IO>
-__device__ __forceinline__ SegFlusher<W, C0, C, IO> spec_make_seg(IO* __restrict__ out, int64_t base, int rows, int lane, unsigned* lds) {
-    IO* dst = out ? out + base * W + C0 : nullptr;
+template <int W, class IO>
+__device__ __forceinline__ ImgFlusher<W, IO> spec_make_img(IO* __restrict__ out, int64_t base, int rows, int lane, IO* img) {
+    IO* dst = out ? out + base * W : nullptr;
     const unsigned long long g = (unsigned long long)reinterpret_cast<uintptr_t>(dst);
     const unsigned long long gu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) |
                                   (unsigned)__builtin_amdgcn_readfirstlane((int)g);
-    return SegFlusher<W, C0, C, IO>{lds, gu, out != nullptr ? ~0ull : 0ull, lane, rows};
+    const bool fast = out != nullptr && rows == TRK_WAVE && (g & 15) == 0;
+    return ImgFlusher<W, IO>{img, reinterpret_cast<const trk_f4*>(img) + lane, (unsigned)lane * 16u, gu,
+                             __builtin_amdgcn_ballot_w64(fast), lane};      // a ballot is scalar by definition: all lanes, or none
+}
+// ragged last wavefront / unaligned view: the staged image is copied with plain stores (wave-uniform branch, after the last staging)
+template <int W, class IO>
+__device__ __forceinline__ void spec_img_copy_slow(const ImgFlusher<W, IO>& f, IO* __restrict__ out, int64_t base, int rows) {
+    if (out == nullptr || f.on != 0ull) return;
+    for (int e = f.lane; e < rows * W; e += TRK_WAVE) out[base * W + e] = f.img[e];
 }
 
 // profiling hook: lane 0 of a wave records the shader clock at phase `k` (no-op when A.stamps == nullptr)
