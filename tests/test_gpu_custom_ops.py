@@ -85,7 +85,7 @@ def test_gradients_through_dispatcher_ops_match_goldens(handles, monkeypatch):
                             obstacle_cutoff_margin=float(gc["cutoff"]), tensor_args=TA)
     q = dev(gc["q"]).requires_grad_(True)
     cost = task.compute_collision_cost(q)
-    assert "RolloutCostGrad" in type(cost.grad_fn).__name__ or "trk" in str(type(cost.grad_fn)).lower()
+    assert "Rollout" in type(cost.grad_fn).__name__ or "trk" in str(type(cost.grad_fn)).lower()
     assert rel_err(cost.detach().cpu().numpy(), gc["cost_total"]) < 1e-5
     (cost * 1.0).sum().backward()
     assert grad_close(q.grad.cpu().numpy(), gc["gq_total"])
@@ -129,6 +129,50 @@ def test_torch_compile_of_the_reference_call_sites(handles):
     gf = gold("fk_panda_arm_no_gripper")
     fkc = torch.compile(lambda x: tree.compute_forward_kinematics_all_links(x))
     assert np.abs(fkc(dev(gf["q_in"])).cpu().numpy() - gf["H_in"]).max() < 2e-6
+
+
+def test_native_rollout_op(handles):
+    """csrc/trk_torch_ops.cpp: trk::rollout as a C++ dispatcher op with a C++ autograd node (backward = trk_scale_rows): opcheck, the
+    reference's idiom eager and under torch.compile(fullgraph=True) against the goldens, a gradient on a by-product output is an error."""
+    from torch_robotics_amd import _lib
+    native = _lib.torch_ops()
+    assert native is not None, "libtrk_torch.so is part of the build"
+    m, cm, g, _ = handles
+    q3 = dev(g["q"][:2]).requires_grad_(True)                                   # (2, 64, 7)
+    for args in ((q3, m.ptr, cm.ptr, 1.0, 1.0, 1.0, 1.0, True), (q3, m.ptr, cm.ptr, 0.0, 1.0, 0.0, 1.0, False)):
+        torch.library.opcheck(native.rollout.default, args, test_utils=CHECKS)
+    torch.library.opcheck(native.rollout.default, (q3.detach().half(), m.ptr, cm.ptr, 0.0, 1.0, 0.0, 1.0, True), test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(native.scale_rows_native.default, (torch.randn(2, 64, 7, device=DEV), torch.rand(2, 64, device=DEV)),
+                          test_utils=("test_schema", "test_faketensor"))
+    # == the ctypes path, value and gradient
+    pos_r, cost_r, gq_r = ops.rollout_cost_grad(m, cm, (1, 1, 1, 1), q3.detach())
+    cost, gq, pos = native.rollout(q3, m.ptr, cm.ptr, 1.0, 1.0, 1.0, 1.0, True)
+    assert torch.equal(cost, cost_r) and torch.equal(gq, gq_r) and torch.equal(pos, pos_r) and "Rollout" in type(cost.grad_fn).__name__
+    wgt = torch.linspace(0.5, 2.0, 128, device=DEV).reshape(2, 64)
+    (cost * wgt).sum().backward()
+    assert torch.allclose(q3.grad, gq_r * wgt.unsqueeze(-1), rtol=1e-6, atol=1e-7)
+    q3.grad = None
+    native.rollout(q3, m.ptr, cm.ptr, 1.0, 1.0, 1.0, 1.0, False)[0].sum().backward()      # an expanded scalar comes down: read as one value
+    assert torch.equal(q3.grad, gq_r)
+    with pytest.raises(RuntimeError, match="by-products"):
+        c2, g2, p2 = native.rollout(q3, m.ptr, cm.ptr, 1.0, 1.0, 1.0, 1.0, True)
+        (c2.sum() + p2.sum()).backward()
+    # the reference's call site: routed through the native op by default, traceable as ONE graph
+    gc = gold("cost_spheres3d")
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=tra.RobotPanda(tensor_args=TA),
+                            obstacle_cutoff_margin=float(gc["cutoff"]), tensor_args=TA)
+    q = dev(gc["q"]).requires_grad_(True)
+    cost = task.compute_collision_cost(q)
+    assert "Rollout" in type(cost.grad_fn).__name__ and rel_err(cost.detach().cpu().numpy(), gc["cost_total"]) < 1e-5
+    cost.sum().backward()
+    assert grad_close(q.grad.cpu().numpy(), gc["gq_total"])
+    task.compute_collision_cost(q.detach())                     # handles exist before tracing
+    fn = torch.compile(task.compute_collision_cost, fullgraph=True)
+    q2 = dev(gc["q"]).requires_grad_(True)
+    out = fn(q2)
+    assert torch.equal(out.detach(), cost.detach())
+    out.sum().backward()
+    assert grad_close(q2.grad.cpu().numpy(), gc["gq_total"])
 
 
 def test_graphed_cost_backward_replays_the_eager_result():

@@ -53,6 +53,23 @@ def build(verbose: bool = False) -> Path:
     return LIB_PATH
 
 
+TORCH_OPS_PATH = _CSRC / "libtrk_torch.so"
+_torch_ops_loaded = None
+
+
+def torch_ops():
+    """`torch.ops.trk` with the NATIVE ops of csrc/trk_torch_ops.cpp registered (trk::rollout, trk::scale_rows_native), or None when
+    libtrk_torch.so has not been built -- the callers then use the Python-registered ops / autograd Functions over the same kernels."""
+    global _torch_ops_loaded
+    if _torch_ops_loaded is None:
+        _torch_ops_loaded = False
+        if TORCH_OPS_PATH.exists() and os.environ.get("TRK_NO_NATIVE_OPS", "0") != "1":
+            lib()                                   # libtrk.so first: the op library links against it
+            torch.ops.load_library(str(TORCH_OPS_PATH))
+            _torch_ops_loaded = True
+    return torch.ops.trk if _torch_ops_loaded else None
+
+
 def lib():
     global _lib
     if _lib is not None:

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _abi
+from . import _lib as _lib_mod
 from ._lib import check, lib
 from .costmodel import CostModelSpec
 from .kinmodel import KinModel
@@ -129,6 +130,7 @@ class ModelHandle:
         h = C.c_void_p()
         check(lib().trk_model_create(C.byref(desc), C.byref(h)), "trk_model_create")
         self._h = h
+        self.ptr = int(h.value)           # the C handle as an integer: what the native dispatcher ops take
         self.n_links, self.n_dofs = kin.n_links, kin.n_dofs
         self.uid = _register_handle(self)
 
@@ -177,6 +179,7 @@ class CostHandle:
             check(lib().trk_cost_model_create(C.byref(desc), C.byref(h)), "trk_cost_model_create")
         self._grid = None          # the kernels read the handle's own copy: do not keep 2 x the grid in HBM
         self._h = h
+        self.ptr = int(h.value)
         self.n_links_in = spec.n_links_in
         self.n_objects = len(spec.objects)
         self.uid = _register_handle(self)
@@ -1491,6 +1494,14 @@ def rollout_ad(model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, ps:
                want_pos: bool = True):
     """Differentiable fused op: returns (cost, link_pos) -- or (cost, point_pos) when a point set is given; want_pos=False
     returns (cost, None) and skips the position output (34.6 of the 50 MB a Panda evaluation writes)."""
+    if ps is None and q.is_cuda and q.dtype in (torch.float32, torch.float16):
+        native = _lib_mod.torch_ops()
+        if native is not None:
+            # the native dispatcher op (csrc/trk_torch_ops.cpp): one C++ autograd node whose backward is trk_scale_rows; the handles
+            # travel as their C pointers -- eager, torch.compile (fullgraph) and export see the same op
+            cost, _gq, pos = native.rollout(q, model.ptr, cm.ptr, float(weights[0]), float(weights[1]), float(weights[2]),
+                                            float(weights[3]), bool(want_pos))
+            return cost, (pos if want_pos else None)
     if _dispatch():
         cost, _gq, pos = _trk_ops().rollout_cost_grad(q, model.uid, cm.uid, [float(w) for w in weights], bool(want_pos),
                                                       ps.uid if ps is not None else 0)
