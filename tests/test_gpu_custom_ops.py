@@ -154,9 +154,13 @@ def test_native_rollout_op(handles):
     q3.grad = None
     native.rollout(q3, m.ptr, cm.ptr, 1.0, 1.0, 1.0, 1.0, False)[0].sum().backward()      # an expanded scalar comes down: read as one value
     assert torch.equal(q3.grad, gq_r)
-    with pytest.raises(RuntimeError, match="by-products"):
-        c2, g2, p2 = native.rollout(q3, m.ptr, cm.ptr, 1.0, 1.0, 1.0, 1.0, True)
-        (c2.sum() + p2.sum()).backward()
+    # gq and link_pos are by-products: flagged non-differentiable (no made-up zero gradients) -- also on the Python-registered twin
+    c2, g2, p2 = native.rollout(q3, m.ptr, cm.ptr, 1.0, 1.0, 1.0, 1.0, True)
+    assert c2.requires_grad and not g2.requires_grad and not p2.requires_grad
+    with pytest.raises(RuntimeError, match="does not require grad"):
+        p2.sum().backward()
+    c4, g4, p4 = torch.ops.trk.rollout_cost_grad(q3, m.uid, cm.uid, [1.0, 1.0, 1.0, 1.0], True, 0)
+    assert c4.requires_grad and not g4.requires_grad and not p4.requires_grad
     # the reference's call site: routed through the native op by default, traceable as ONE graph
     gc = gold("cost_spheres3d")
     task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=tra.RobotPanda(tensor_args=TA),

@@ -51,13 +51,15 @@ def test_fk_forward_backward_vs_golden(ops, robot):
     wfull = np.zeros_like(g["w_in"]); wfull[:, sel] = w
     gq_a = ops.fk_backward(h, dev(g["q_in"]), dev(w), sel).cpu().numpy()
     gq_b = ops.fk_backward(h, dev(g["q_in"]), dev(wfull)).cpu().numpy()
-    np.testing.assert_allclose(gq_a, gq_b, rtol=1e-5, atol=1e-5)
+    # (the full form may run a generated kernel, the subset the table-driven one: equal to fp32 rounding of terms of size |t| -- the
+    # tolerance convention of DESIGN.md section 2: the floor scales with max(1, |t|); Tiago's base moves up to 100 m from the origin)
+    np.testing.assert_allclose(gq_a, gq_b, rtol=1e-5, atol=1e-5 * scale)
     gq_p = ops.fk_positions_backward(h, dev(g["q_in"]), dev(w[..., :3, 3]), sel).cpu().numpy()
     wpos = np.zeros_like(wfull)
     for c, li in enumerate(sel):
         wpos[:, li, :3, 3] = w[:, c, :3, 3]
     gq_pb = ops.fk_backward(h, dev(g["q_in"]), dev(wpos)).cpu().numpy()
-    np.testing.assert_allclose(gq_p, gq_pb, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gq_p, gq_pb, rtol=1e-5, atol=1e-5 * scale)
 
 
 @pytest.mark.parametrize("robot", ["panda_arm_no_gripper", "ur10_allegro", "hab_stretch"])

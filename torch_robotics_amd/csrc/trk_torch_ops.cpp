@@ -9,8 +9,8 @@
 //       reference call site: PlanningTask.compute_collision_cost tasks.py:135-137 (FK + three collision fields [+ EE])
 //       CUDA(HIP) kernel: trk_rollout_cost_grad / trk_rollout_cost_grad_f16 of libtrk.so (include/trk.h)
 //       Autograd: backward = trk::scale_rows_native(saved gq, grad of cost) -- the explicit backward kernel trk_scale_rows; the forward
-//                 kernel already produced d cost / d q.  A gradient arriving on gq or link_pos is an ERROR (they are by-products:
-//                 the reference's graph would not differentiate its own gradient either), not silently dropped.
+//                 kernel already produced d cost / d q.  gq and link_pos are by-products (the reference's graph would not differentiate
+//                 its own gradient either): they are marked non-differentiable, not given made-up zero gradients.
 //       Meta: shapes only (torch.compile / fake tensors).
 //   trk::scale_rows_native(g, scale) -> g * scale[..., None]   (scale may be an expanded scalar: `.sum().backward()` hands one down;
 //       the Python-registered twin is trk::scale_rows of custom_ops.py)
@@ -20,7 +20,7 @@
 //
 // torch is plumbing here as everywhere: tensors, streams, the autograd graph.  All arithmetic is in libtrk.so.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
@@ -75,7 +75,7 @@ std::tuple<Tensor, Tensor, Tensor> rollout_hip(const Tensor& q_in, int64_t model
     Tensor gq = at::empty(g_shape, q.options());
     Tensor pos = want_pos ? at::empty(pos_shape, q.options()) : at::empty({0}, q.options());
     const TrkRolloutWeights w{(float)w_self, (float)w_obj, (float)w_ws, (float)w_ee};
-    c10::hip::HIPGuard guard(q.device());
+    c10::DeviceGuard guard(q.device());      // the generic guard: PyTorch-ROCm registers its HIP implementation under the "cuda" device type
     if (f16)
         trk_check(trk_rollout_cost_grad_f16(m, c, &w, q.data_ptr(), s.batch, s.horizon, want_pos ? pos.data_ptr() : nullptr,
                                             cost.data_ptr<float>(), gq.data_ptr(), TRK_F16, 1.0f, nullptr, current_stream(q)),
@@ -113,7 +113,7 @@ Tensor scale_rows_hip(const Tensor& g_in, const Tensor& scale_in) {
     const Tensor scale = scalar ? scale_in : scale_in.contiguous();
     Tensor out = at::empty_like(g);
     if (n == 0) return out;
-    c10::hip::HIPGuard guard(g.device());
+    c10::DeviceGuard guard(g.device());
     trk_check(trk_scale_rows(g.data_ptr(), scale.data_ptr<float>(), scalar ? 0 : 1, n, (int32_t)D,
                              g.scalar_type() == at::kHalf ? TRK_F16 : TRK_F32, out.data_ptr(), current_stream(g)),
               "trk_scale_rows");
@@ -134,13 +134,13 @@ struct RolloutFn : public torch::autograd::Function<RolloutFn> {
         auto [cost, gq, pos] = op.call(q, model, cm, w_self, w_obj, w_ws, w_ee, want_pos);
         ctx->save_for_backward({gq});
         ctx->set_materialize_grads(false);
+        // gq (d cost / d q itself) and link_pos are by-products of the fused kernel: flagged non-differentiable -- `requires_grad` is
+        // False on them, differentiating through them alone raises, no zero gradient is made up (fk_map_collision gives
+        // differentiable link positions)
+        ctx->mark_non_differentiable({gq, pos});
         return {cost, gq, pos};
     }
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
-        TORCH_CHECK(!grads[1].defined() && !grads[2].defined(),
-                    "trk::rollout: a gradient arrived on gq or link_pos -- they are by-products of the fused kernel (d cost / d q itself "
-                    "and the link positions), not differentiable outputs; differentiate `cost`, or use fk_map_collision for "
-                    "differentiable link positions");
         Tensor out;
         if (grads[0].defined()) {
             static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("trk::scale_rows_native", "").typed<Tensor(const Tensor&, const Tensor&)>();

@@ -220,15 +220,15 @@ def _(g, scale):
 def _ro_setup(ctx, inputs, output):
     ctx.save_for_backward(output[1])        # d cost / d q, produced by the forward kernel
     ctx.set_materialize_grads(False)
+    # gq and link_pos are by-products of the fused kernel: flagged non-differentiable (requires_grad False; differentiating through them
+    # alone raises) instead of receiving made-up zero gradients -- fk_map_collision gives differentiable link positions
+    ctx.mark_non_differentiable(output[1], output[2])
 
 
 def _ro_bwd(ctx, gcost, _ggq, _gpos):
     # only `cost` carries a gradient back to q (gq and link_pos are by-products: the reference's autograd graph would not
     # differentiate its own gradient either -- no double backward)
     (gq,) = ctx.saved_tensors
-    if _ggq is not None or _gpos is not None:
-        raise RuntimeError("trk::rollout_cost_grad: a gradient arrived on gq or link_pos -- they are by-products of the fused kernel, not "
-                           "differentiable outputs; differentiate `cost`, or use fk_map_collision for differentiable link positions")
     if gcost is None:
         return None, None, None, None, None, None
     return torch.ops.trk.scale_rows(gq, gcost), None, None, None, None, None
