@@ -22,6 +22,14 @@ def fb():
     qg.grad = None
     task.compute_collision_cost(qg).sum().backward()
 t("task.compute_collision_cost(q).sum().backward()", fb)
+def floor():
+    qg.grad = None
+    (qg * 2.0).sum().backward()
+t("[torch floor] (q * 2).sum().backward()  -- no op of ours", floor)
+torch.autograd.set_multithreading_enabled(False)
+t("task.compute_collision_cost(q).sum().backward(), autograd multithreading off", fb)
+t("[torch floor] (q * 2).sum().backward(), autograd multithreading off", floor)
+torch.autograd.set_multithreading_enabled(True)
 t("task.compute_collision(q)", lambda: task.compute_collision(q))
 t("robot.fk_map_collision(q)", lambda: robot.fk_map_collision(q))
 t("robot.get_EE_pose(q)", lambda: robot.get_EE_pose(q.reshape(-1, 7)))
@@ -42,7 +50,7 @@ t("[dispatcher ops] task.compute_collision_cost(q)   [no grad]", lambda: task.co
 t("[dispatcher ops] task.compute_collision_cost(q).sum().backward()", fb)
 ops._ALWAYS_DISPATCH = False
 try:
-    cfn = torch.compile(task.compute_collision_cost)
+    cfn = torch.compile(task.compute_collision_cost, fullgraph=True)       # one graph: the native op takes the handles as integers
     cfn(q); cfn(qg).sum().backward()
     t("[torch.compile] compute_collision_cost(q)   [no grad]", lambda: cfn(q))
     def fbc():

@@ -248,8 +248,10 @@ class PlanningTask(Task):
             pos = ops.fk_points(ps, q.detach())
             return ops.collision_fields(cm, fields, pos, margin=kwargs.get("margin", None)).reshape(q.shape[:-1])
         w = (1.0 if self.df_collision_self is not None else 0.0, 1.0, 1.0, 0.0)
-        if torch.is_grad_enabled() and q.requires_grad:
-            cost, _ = ops.rollout_ad(model, cm, w, q, ps, want_pos=False)   # one fused kernel; backward reuses its gradient
+        if (torch.is_grad_enabled() and q.requires_grad) or ops._dispatch():
+            # one fused kernel; backward reuses its gradient.  Under a compiler (torch.compile) also without autograd: the dispatcher
+            # op is what a tracer can see (the ctypes call below is not)
+            cost, _ = ops.rollout_ad(model, cm, w, q, ps, want_pos=False)
             return cost
         if ps is not None:
             return ops.rollout_points_cost_grad(ps, cm, w, q, want_pos=False)[1]
