@@ -16,7 +16,9 @@ One step = one pass of the hot path over one batch of synthetic joint trajectori
       cost, gradient, link positions) and the geometric Jacobian of `ee_link` (`trk_fk_jacobian`) -- two launches per step.
   c5 (configs[4]): dual Panda (23 links / 14 DOF), horizon 128, fp16 q / qd / link positions / gradients in HBM with fp32 arithmetic
       and cost, GP-smoothness (sigma_gp = 0.1, dt = 5 / 128) + obstacle + EE on both arms; 2048 trajectories per GPU -- at
-      `--gpus 4` the global batch is BASELINE's 8192.  The gradients carry a power-of-two loss scale (`ops.gp_grad_scale`).
+      `--gpus 4` the global batch is BASELINE's 8192.  ONE launch per step (`trk_rollout_gp_cost_grad`: q / qd read once, gq / gqd
+      written once; `--two-launch` = the rollout, then the prior accumulated into its gradient).  The gradients carry a
+      power-of-two loss scale (`ops.gp_grad_scale`).
 Multi-GPU: the batch is sharded, each rank owns its block of whole trajectories (weak scaling); the only exchange is an
 all-reduce (RCCL) of the packed sums [cost | cost per time step | gradient per time step and joint] (1 + H + H D floats), issued
 on a side stream once per `--reduce-every` steps -- at most steps // 2, so EVERY timed region contains at least one exchange
