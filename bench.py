@@ -405,26 +405,67 @@ def main():
         native = RcclAllReduce(dev)
 
     slot_free = [None] * n_slots        # per exchange buffer: the side-stream event after which it may be packed again
+    slot_busy = [False] * n_slots       # submitted to the communication thread, not yet enqueued by it
+
+    # The exchange is ENQUEUED by a communication thread: handing a collective to torch.distributed costs ~60 us of host time
+    # (c10d bookkeeping + RCCL's enqueue), six launches' worth -- issued from the launch loop it starves the GPU whenever the host is
+    # not that far ahead (measured with one RCCL rank at the driver's 20 steps: 12.4 -> 19.4 us per step for two exchanges, all of it
+    # the host's stall).  The launch loop only packs the sums (one kernel on the launch stream) and records an event; the thread
+    # makes the side stream wait for that event and issues the all-reduce there (the C++ side of both calls releases the GIL).
+    import queue
+    import threading
+    xq = queue.Queue()
+    xerr = []
+
+    def exchange_worker():
+        torch.cuda.set_device(dev)
+        while True:
+            item = xq.get()
+            try:
+                if item is None:
+                    return
+                k, ev = item
+                buf = packed[k]
+                side.wait_event(ev)
+                if native is not None:
+                    native.all_reduce_sum_(buf, side.cuda_stream)
+                else:
+                    with torch.cuda.stream(side):
+                        dist.all_reduce(buf)
+                done = torch.cuda.Event()
+                done.record(side)
+                slot_free[k] = done
+                slot_busy[k] = False
+            except BaseException as e:       # surfaced by exchanges_enqueued()
+                xerr.append(e)
+            finally:
+                xq.task_done()
+
+    xthread = None
+    if distributed:
+        xthread = threading.Thread(target=exchange_worker, name="trk-exchange", daemon=True)
+        xthread.start()
+
+    def exchanges_enqueued():
+        """every submitted exchange has been handed to the side stream (host-side wait; the collectives themselves may still run)"""
+        xq.join()
+        if xerr:
+            raise xerr[0]
 
     def reduce_slot(pl, k):
-        # sums of the latest evaluation -> one small all-reduce, off the launch stream.  The buffers are a ring: before a slot is
-        # packed again the launch stream waits for the collective that last used it (a planner's bounded look-ahead) -- with one
-        # exchange per step (`multi_gpu.every_step`) that is what ties the launch rate to the exchange rate.
+        # sums of the latest evaluation -> one small all-reduce, off the launch stream AND off the launch thread.  The buffers are a
+        # ring: before a slot is packed again the launch stream waits for the collective that last used it (a planner's bounded
+        # look-ahead) -- with one exchange per step (`multi_gpu.every_step`) that ties the launch rate to the exchange rate.
         buf = packed[k]
+        if slot_busy[k]:
+            exchanges_enqueued()            # the ring has turned once and this slot's collective is not even enqueued yet
         if slot_free[k] is not None:
             stream.wait_event(slot_free[k])
         pack_sums(pl, buf)
         ev = torch.cuda.Event()
         ev.record(stream)
-        side.wait_event(ev)
-        if native is not None:
-            native.all_reduce_sum_(buf, side.cuda_stream)
-        else:
-            with torch.cuda.stream(side):
-                dist.all_reduce(buf)
-        done = torch.cuda.Event()
-        done.record(side)
-        slot_free[k] = done
+        slot_busy[k] = True
+        xq.put((k, ev))
 
     def step_of(pl):
         return wl.step if pl is plan else pl.launch
@@ -470,6 +511,7 @@ def main():
     def barrier_in_stream():
         """A barrier that costs no host round trip: a one-element all-reduce enqueued on the launch stream completes on a rank
         only after every rank has reached it, so the `torch.cuda.synchronize()` that follows returns when all ranks are done."""
+        exchanges_enqueued()            # the communication thread is idle: one thread at a time talks to the process group
         if native is not None:
             # two communicators on one device (torch's and RcclAllReduce's own) must not run collectives concurrently: the barrier
             # goes behind whatever the side stream still has in flight
@@ -496,6 +538,7 @@ def main():
         ev1.record(stream)
         ev_side = None
         if side is not None and cadence:
+            exchanges_enqueued()        # host-side: the region's collectives are all on the side stream (they were handed over steps ago)
             ev_side = torch.cuda.Event()
             ev_side.record(side)        # the collectives issued inside the region belong to it
         ta_ = time.perf_counter()
@@ -648,6 +691,7 @@ def main():
         t_x = time.perf_counter()
         for k in range(10):
             reduce_slot(plan, (slot[0] + k) % n_slots)
+            exchanges_enqueued()
             side.synchronize()
         exchange_us = (time.perf_counter() - t_x) / 10 * 1e6
         wl.step(bs_ptr, stream.cuda_stream)
@@ -709,6 +753,9 @@ def main():
         out["cpu_baseline"] = None
 
     if distributed:
+        exchanges_enqueued()
+        xq.put(None)
+        xthread.join()
         if native is not None:
             torch.cuda.synchronize(dev)
             native.close()

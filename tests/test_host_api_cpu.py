@@ -251,3 +251,25 @@ def test_q_width_check():
     for bad in (torch.zeros(7), torch.zeros(8, dtype=torch.float64), torch.zeros(16)[::2]):
         with pytest.raises(ValueError):
             _check_buffer(bad, 8, torch.float32, dev, "b")
+
+
+def test_gp_grad_scale_bounds_the_fp16_gradient():
+    """ops.gp_grad_scale: a power of two that keeps the worst-case GP-prior gradient of bounded trajectories below half the fp16 range
+    (config 5's parameters: sigma_gp = 0.1, dt = 5 / 128 -> a = 12 / (sigma^2 dt^3) = 2e7)."""
+    import numpy as np
+    from torch_robotics_amd import ops
+    dt, sigma = 5.0 / 128, 0.1
+    gs = ops.gp_grad_scale(dt, sigma, 1.0, q_abs_max=2.0, qd_abs_max=1.0)
+    assert 0 < gs < 1 and np.log2(gs) == np.round(np.log2(gs))
+    # brute force over the corners of the box |q| <= 2, |qd| <= 1 for one joint and three consecutive time steps
+    s2 = 1.0 / sigma ** 2
+    a, b, c = 12 * s2 / dt ** 3, -6 * s2 / dt ** 2, 4 * s2 / dt
+    worst = 0.0
+    for bits in range(64):
+        pm, p0, pn, vm, v0, vn = [(1 if (bits >> k) & 1 else -1) * (2.0 if k < 3 else 1.0) for k in range(6)]
+        ep, ev, em, fm = p0 + dt * v0 - pn, v0 - vn, pm + dt * vm - p0, vm - v0
+        rp, rv = a * ep + b * ev, b * ep + c * ev
+        worst = max(worst, abs(rp - (a * em + b * fm)), abs(dt * rp + rv - (b * em + c * fm)))
+    assert worst * gs <= 32768.0 and worst * gs * 4 > 32768.0 * 0.2          # safe, and not needlessly small
+    assert ops.gp_grad_scale(0.1, 10.0, 1.0, 1.0, 1.0) == 1.0               # a weak prior needs no scale
+    assert ops.gp_grad_scale(dt, sigma, 1.0, 2.0, 1.0, extra=1e9) < gs       # the other terms' gradient counts too
