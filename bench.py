@@ -21,7 +21,7 @@ One step = one pass of the hot path over one batch of synthetic joint trajectori
       power-of-two loss scale (`ops.gp_grad_scale`).
 Multi-GPU: the batch is sharded, each rank owns its block of whole trajectories (weak scaling); the only exchange is an
 all-reduce (RCCL) of the packed sums [cost | cost per time step | gradient per time step and joint] (1 + H + H D floats), issued
-on a side stream once per `--reduce-every` steps -- at most steps // 2, so EVERY timed region contains at least one exchange
+on a side stream once per `--reduce-every` steps -- at most `steps`, so EVERY timed region contains at least one exchange
 (`multi_gpu.collectives_in_timed_region`).  `value` INCLUDES those collectives; `multi_gpu.kernel_only` is the same loop without
 them, `multi_gpu.every_step` the same loop with one exchange per step, `multi_gpu.full_stack_c3` (c2 / c3 runs) configs[2]'s
 objective stack on the same shards.
@@ -75,7 +75,7 @@ def parse_args(argv):
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: 4096; c5: 2048)")
     ap.add_argument("--horizon", type=int, default=None, help="time steps per trajectory (default: 64; c5: 128)")
     ap.add_argument("--reduce-every", type=int, default=64,
-                    help="the planner's exchange cadence; a short run uses min(this, steps // 2) so that its timed region contains a collective")
+                    help="the planner's exchange cadence; a short run uses min(this, steps) so that its timed region contains a collective")
     ap.add_argument("--graph", type=int, default=0, help="capture this many steps per hipGraph replay (0 = eager launches)")
     ap.add_argument("--weights", default=None, help="experiment: w_self,w_obj,w_ws,w_ee override (reported in config)")
     ap.add_argument("--no-pos", action="store_true", help="experiment: do not write link positions")
@@ -381,9 +381,13 @@ def main():
     block_sums = torch.zeros(nb, **ta)
     bs_ptr = block_sums.data_ptr()
     # The planner's cadence: one exchange per `reduce_every` evaluations, fired after the first evaluation of its interval (the sums
-    # are consumed at the interval's end).  A run shorter than two intervals shrinks the interval to steps // 2, so that the driver's
-    # 20 timed steps contain two exchanges and `value` is never a kernel-only figure; `multi_gpu.collectives_in_timed_region` counts them.
-    R = max(1, min(args.reduce_every, max(1, args.steps // 2)))
+    # are consumed at the interval's end).  A run shorter than an interval shrinks the interval to the run, so that the driver's 20
+    # timed steps contain an exchange and `value` is never a kernel-only figure (`multi_gpu.collectives_in_timed_region` counts them).
+    # What an exchange costs a region is NOT host time (enqueueing it from a communication thread changed nothing: measured, DESIGN.md
+    # 6d) but the all-reduce kernel's company: an evaluation is sized to fill the chip with exactly one generation of workgroups, and
+    # while the collective's workgroups hold a few CUs every launch that overlaps them runs a second generation there (~0.7 of a
+    # launch each, ~65 us per exchange with one RCCL rank whose all-reduce takes ~100 us end to end).
+    R = max(1, min(args.reduce_every, args.steps))
     # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
     n_slots = 64
     packed = torch.zeros((n_slots, 1 + H + H * D), **ta)
@@ -405,67 +409,26 @@ def main():
         native = RcclAllReduce(dev)
 
     slot_free = [None] * n_slots        # per exchange buffer: the side-stream event after which it may be packed again
-    slot_busy = [False] * n_slots       # submitted to the communication thread, not yet enqueued by it
-
-    # The exchange is ENQUEUED by a communication thread: handing a collective to torch.distributed costs ~60 us of host time
-    # (c10d bookkeeping + RCCL's enqueue), six launches' worth -- issued from the launch loop it starves the GPU whenever the host is
-    # not that far ahead (measured with one RCCL rank at the driver's 20 steps: 12.4 -> 19.4 us per step for two exchanges, all of it
-    # the host's stall).  The launch loop only packs the sums (one kernel on the launch stream) and records an event; the thread
-    # makes the side stream wait for that event and issues the all-reduce there (the C++ side of both calls releases the GIL).
-    import queue
-    import threading
-    xq = queue.Queue()
-    xerr = []
-
-    def exchange_worker():
-        torch.cuda.set_device(dev)
-        while True:
-            item = xq.get()
-            try:
-                if item is None:
-                    return
-                k, ev = item
-                buf = packed[k]
-                side.wait_event(ev)
-                if native is not None:
-                    native.all_reduce_sum_(buf, side.cuda_stream)
-                else:
-                    with torch.cuda.stream(side):
-                        dist.all_reduce(buf)
-                done = torch.cuda.Event()
-                done.record(side)
-                slot_free[k] = done
-                slot_busy[k] = False
-            except BaseException as e:       # surfaced by exchanges_enqueued()
-                xerr.append(e)
-            finally:
-                xq.task_done()
-
-    xthread = None
-    if distributed:
-        xthread = threading.Thread(target=exchange_worker, name="trk-exchange", daemon=True)
-        xthread.start()
-
-    def exchanges_enqueued():
-        """every submitted exchange has been handed to the side stream (host-side wait; the collectives themselves may still run)"""
-        xq.join()
-        if xerr:
-            raise xerr[0]
 
     def reduce_slot(pl, k):
-        # sums of the latest evaluation -> one small all-reduce, off the launch stream AND off the launch thread.  The buffers are a
-        # ring: before a slot is packed again the launch stream waits for the collective that last used it (a planner's bounded
-        # look-ahead) -- with one exchange per step (`multi_gpu.every_step`) that ties the launch rate to the exchange rate.
+        # sums of the latest evaluation -> one small all-reduce, off the launch stream.  The buffers are a ring: before a slot is
+        # packed again the launch stream waits for the collective that last used it (a planner's bounded look-ahead) -- with one
+        # exchange per step (`multi_gpu.every_step`) that is what ties the launch rate to the exchange rate.
         buf = packed[k]
-        if slot_busy[k]:
-            exchanges_enqueued()            # the ring has turned once and this slot's collective is not even enqueued yet
         if slot_free[k] is not None:
             stream.wait_event(slot_free[k])
         pack_sums(pl, buf)
         ev = torch.cuda.Event()
         ev.record(stream)
-        slot_busy[k] = True
-        xq.put((k, ev))
+        side.wait_event(ev)
+        if native is not None:
+            native.all_reduce_sum_(buf, side.cuda_stream)
+        else:
+            with torch.cuda.stream(side):
+                dist.all_reduce(buf)
+        done = torch.cuda.Event()
+        done.record(side)
+        slot_free[k] = done
 
     def step_of(pl):
         return wl.step if pl is plan else pl.launch
@@ -511,7 +474,6 @@ def main():
     def barrier_in_stream():
         """A barrier that costs no host round trip: a one-element all-reduce enqueued on the launch stream completes on a rank
         only after every rank has reached it, so the `torch.cuda.synchronize()` that follows returns when all ranks are done."""
-        exchanges_enqueued()            # the communication thread is idle: one thread at a time talks to the process group
         if native is not None:
             # two communicators on one device (torch's and RcclAllReduce's own) must not run collectives concurrently: the barrier
             # goes behind whatever the side stream still has in flight
@@ -538,7 +500,6 @@ def main():
         ev1.record(stream)
         ev_side = None
         if side is not None and cadence:
-            exchanges_enqueued()        # host-side: the region's collectives are all on the side stream (they were handed over steps ago)
             ev_side = torch.cuda.Event()
             ev_side.record(side)        # the collectives issued inside the region belong to it
         ta_ = time.perf_counter()
@@ -691,7 +652,6 @@ def main():
         t_x = time.perf_counter()
         for k in range(10):
             reduce_slot(plan, (slot[0] + k) % n_slots)
-            exchanges_enqueued()
             side.synchronize()
         exchange_us = (time.perf_counter() - t_x) / 10 * 1e6
         wl.step(bs_ptr, stream.cuda_stream)
@@ -753,9 +713,6 @@ def main():
         out["cpu_baseline"] = None
 
     if distributed:
-        exchanges_enqueued()
-        xq.put(None)
-        xthread.join()
         if native is not None:
             torch.cuda.synchronize(dev)
             native.close()
