@@ -380,13 +380,9 @@ def main():
     nb = ops.n_blocks(B * H)
     block_sums = torch.zeros(nb, **ta)
     bs_ptr = block_sums.data_ptr()
-    # The planner's cadence: one exchange per `reduce_every` evaluations, fired after the first evaluation of its interval (the sums
-    # are consumed at the interval's end).  A run shorter than an interval shrinks the interval to the run, so that the driver's 20
-    # timed steps contain an exchange and `value` is never a kernel-only figure (`multi_gpu.collectives_in_timed_region` counts them).
-    # What an exchange costs a region is NOT host time (enqueueing it from a communication thread changed nothing: measured, DESIGN.md
-    # 6d) but the all-reduce kernel's company: an evaluation is sized to fill the chip with exactly one generation of workgroups, and
-    # while the collective's workgroups hold a few CUs every launch that overlaps them runs a second generation there (~0.7 of a
-    # launch each, ~65 us per exchange with one RCCL rank whose all-reduce takes ~100 us end to end).
+    # The planner's cadence: one exchange per `reduce_every` evaluations, fired in the middle of its interval (see run()).  A run shorter
+    # than an interval shrinks the interval to the run, so that the driver's 20 timed steps contain an exchange and `value` is never a
+    # kernel-only figure (`multi_gpu.collectives_in_timed_region` counts them).
     R = max(1, min(args.reduce_every, args.steps))
     # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
     n_slots = 64
@@ -451,8 +447,11 @@ def main():
     slot = [0]
 
     def run(pl, count, cadence):
-        """`count` steps; cadence > 0: one exchange per `cadence` steps of this call, fired after the FIRST step of its interval --
-        the sums are consumed at the interval's end, so the collective has the rest of the interval to complete behind the launches"""
+        """`count` steps; cadence > 0: one exchange per `cadence` steps of this call, fired in the MIDDLE of its interval: handing a
+        collective to torch.distributed costs the launch thread ~60 us (six launches' worth), which the GPU does not notice only when
+        the host is that far ahead -- at the start of a region it is not (fired after the first step, the one exchange of a 20-step
+        region cost all of its 78 us: 11.8 -> 15.7 us per step with one RCCL rank); the second half of the interval is left for the
+        collective itself to complete behind the launches"""
         if graph is not None:
             assert count % args.graph == 0
             for _ in range(count // args.graph):
@@ -462,7 +461,7 @@ def main():
         fn = step_of(pl)
         for j in range(1, count + 1):
             fn(bs_ptr, s)
-            if cadence and j % cadence == 1 % cadence:
+            if cadence and j % cadence == cadence // 2:
                 reduce_slot(pl, slot[0] % n_slots)
                 slot[0] += 1
 

@@ -23,8 +23,8 @@ for f in O.glob("bench_*"):
 for d in O.glob("prof_*"):
     for f in d.rglob("*kernel_stats.csv"):
         shutil.copy(f, P / f"r04_kernel_stats_{d.name[5:]}.csv")
-calib_f, nf = mean_counter(O / "pmc" / "calib_FETCH_SIZE", "elementwise")
-calib_w, nw = mean_counter(O / "pmc" / "calib_WRITE_SIZE", "elementwise")
+calib_f, nf = mean_counter(O / "pmc" / "calib_FETCH_SIZE", "vectorized_elementwise_kernel")     # the 20 copies, not the initialising rand kernel
+calib_w, nw = mean_counter(O / "pmc" / "calib_WRITE_SIZE", "vectorized_elementwise_kernel")
 copy_bytes = 50331648
 assert calib_f and calib_w, "the calibration kernel was not found in the counter files"
 fc = copy_bytes / 1024 / calib_f["FETCH_SIZE"]          # how many bytes one counted KiB of reads stands for
