@@ -447,11 +447,10 @@ def main():
     slot = [0]
 
     def run(pl, count, cadence):
-        """`count` steps; cadence > 0: one exchange per `cadence` steps of this call, fired in the MIDDLE of its interval: handing a
-        collective to torch.distributed costs the launch thread ~60 us (six launches' worth), which the GPU does not notice only when
-        the host is that far ahead -- at the start of a region it is not (fired after the first step, the one exchange of a 20-step
-        region cost all of its 78 us: 11.8 -> 15.7 us per step with one RCCL rank); the second half of the interval is left for the
-        collective itself to complete behind the launches"""
+        """`count` steps; cadence > 0: one exchange per `cadence` steps of this call, fired in the MIDDLE of its interval: the host is then
+        several launches ahead of the GPU (handing a collective to torch.distributed costs the launch thread ~60 us) and half an
+        interval is left for the collective to complete.  (In a 20-step region one exchange still costs ~50 us whatever its position:
+        the GPU time of the pack kernel + the collective, which the launches behind it wait for -- DESIGN.md 6d.)"""
         if graph is not None:
             assert count % args.graph == 0
             for _ in range(count // args.graph):
