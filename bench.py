@@ -95,6 +95,7 @@ def parse_args(argv):
     ap.add_argument("--native-rccl", action="store_true",
                     help="issue the planner's exchange straight on librccl (torch_robotics_amd.distributed.RcclAllReduce: one ctypes "
                          "call per collective) instead of torch.distributed.all_reduce; the barriers stay on torch.distributed")
+    ap.add_argument("--side-priority", type=int, default=0, help="experiment: HIP priority of the side stream the exchanges run on (-1 = high)")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: run the N > 1 code path (process group, side-stream all-reduce, in-stream barriers, multi_gpu section) "
                          "even with ONE rank -- the only way to put the RCCL calls on hardware on a 1-GPU box")
@@ -388,7 +389,7 @@ def main():
     n_slots = 64
     packed = torch.zeros((n_slots, 1 + H + H * D), **ta)
     stream = torch.cuda.current_stream(dev)
-    side = torch.cuda.Stream(dev) if distributed else None
+    side = torch.cuda.Stream(dev, priority=args.side_priority) if distributed else None
 
     packers = {}
 
