@@ -27,7 +27,9 @@
 #ifndef TRK_H
 #define TRK_H
 
+#ifndef __HIPCC_RTC__       /* in-process device compilation of a generated unit: the integer types are built in */
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -433,6 +435,31 @@ int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const T
  * collision template equals the cost model's link sets for the terms `w` selects --, 0 when the table-driven kernel would run
  * (~10 x slower).  A deployment that must not fall back silently asserts this once after building its handles. */
 int trk_rollout_is_specialized(const TrkModel* model, const TrkCostModel* cm, const TrkRolloutWeights* w);
+
+/* Registers a generated unit that was compiled to a CODE OBJECT in-process (torch_robotics_amd/jit.py: hipRTC, the fall-back when
+ * no hipcc is installed) -- the unit's device half only; libtrk.so's generic launchers play its host half.  Used by the package's
+ * run-time compiler, not by applications.  code: the code object (kept mapped by the HIP module); name_exprs / lowered_names
+ * [n_kernels]: the kernels' C++ name expressions (as codegen.py lists them) and their mangled names; the *_ok / chunked /
+ * fast_switch / jac_direct flags and the layout stamp come from the generator and the headers the object was compiled with
+ * (a stamp of another layout is refused). */
+typedef struct TrkModuleUnitDesc {
+    int32_t spec_abi_version;
+    uint32_t sizeof_args, sizeof_cost_hdr;
+    const char* ident;
+    uint64_t model_hash;
+    int32_t n_links, n_dofs;
+    int32_t n_obj_links; const int32_t* obj_link_idx;
+    int32_t n_self_pairs; const int32_t* self_pairs;          /* [2 * n_self_pairs] LINK indices */
+    int32_t ee_link, ee2_link;
+    int32_t n_virtual; const int32_t* virtual_src; const float* virtual_w;
+    int32_t chunked, fast_switch, fkhbwd_ok, fields_ok, ik_ok, ikgn_ok, jac_ok, jac_direct, gp_ok;
+    const void* code; uint64_t code_size;
+    int32_t n_kernels; const char* const* name_exprs; const char* const* lowered_names;
+} TrkModuleUnitDesc;
+int trk_spec_register_module(const TrkModuleUnitDesc* desc);
+/* The layout stamp the generated units of this library carry (TRK_SPEC_ABI_VERSION, sizeof(SpecArgs) + sizeof(IkArgs) +
+ * sizeof(IkGnArgs), sizeof(DevCostHdr)): what a TrkModuleUnitDesc must repeat.  out [3]. */
+int trk_spec_layout_stamp(int64_t* out);
 
 /* Fused FK + boolean collision fields: q [batch*horizon, D] -> in_collision [batch*horizon] (1 = at least one selected field
  * has a signed distance below its margin).  No link positions, costs or gradients are written.

@@ -1166,8 +1166,9 @@ def test_reduce_sum_long_vectors_are_deterministic_and_accurate():
 def test_no_bundled_robot_takes_the_table_driven_kernels_without_a_compiler(tmp_path):
     """A box without hipcc and with an EMPTY run-time cache: every bundled URDF is served by an ahead-of-time unit of libtrk.so --
     the FK family by the model alone, the fused rollout on the robot's shipped collision template --, the Panda task needs no
-    compile, and a template that has no unit is an ERROR under PlanningTask (not a silent 10 x slowdown) unless
-    TRK_ALLOW_TABLE_DRIVEN=1."""
+    compile; a collision model that has no unit is compiled IN-PROCESS with hipRTC (the unit's device half as a code object,
+    libtrk.so's generic launchers as its host half); and when that is not available either it is an ERROR under PlanningTask
+    (not a silent 10 x slowdown) unless TRK_ALLOW_TABLE_DRIVEN=1."""
     import os
     import subprocess
     import sys
@@ -1178,7 +1179,7 @@ sys.path.insert(0, os.path.join(os.environ["TRK_ROOT"], "tests"))
 import torch_robotics_amd as tra
 from torch_robotics_amd import codegen, jit, ops
 from torch_robotics_amd.costmodel import CostModelSpec
-assert not os.path.exists(jit.HIPCC) and not any(jit.JIT_DIR.glob("*.so"))
+assert not jit.hipcc_available() and not any(jit.JIT_DIR.glob("*.so"))
 TA = dict(device="cuda:0", dtype=torch.float32)
 env = tra.EnvSpheres3D(tensor_args=TA)
 for ident in codegen.SPEC_ROBOTS:
@@ -1204,8 +1205,9 @@ q = robot.random_q(128)
 task.compute_collision_cost(q)                       # the shipped Panda template: no compile needed
 model, cm = task._fused_handles(torch.device("cuda:0"))
 assert ops.rollout_is_specialized(model, cm, (1, 1, 1, 0))
-# a robot declared with another collision model has no ahead-of-time unit: without a compiler that is an error ...
+# a robot declared with another collision model has no ahead-of-time unit.  (1) neither compiler: an error ...
 robot2 = tra.RobotPanda(tensor_args=TA, num_interpolated_points_for_object_collision_checking=9)
+os.environ["TRK_NO_HIPRTC"] = "1"
 task2 = tra.PlanningTask(env=env, robot=robot2, tensor_args=TA)
 try:
     task2.compute_collision_cost(q)
@@ -1219,14 +1221,91 @@ with warnings.catch_warnings(record=True) as rec:
     warnings.simplefilter("always")
     c3 = task3.compute_collision_cost(q)
 assert torch.isfinite(c3).all() and any("table-driven" in str(w.message) for w in rec)
+m3, cm3 = task3._fused_handles(torch.device("cuda:0"))
+assert not ops.rollout_is_specialized(m3, cm3, (1, 1, 1, 0))
+# (2) hipRTC: the same collision model compiled in-process -- same values as the table-driven kernels, now from a generated unit
+del os.environ["TRK_NO_HIPRTC"], os.environ["TRK_ALLOW_TABLE_DRIVEN"]
+task4 = tra.PlanningTask(env=env, robot=robot2, tensor_args=TA)
+c4 = task4.compute_collision_cost(q)
+m4, cm4 = task4._fused_handles(torch.device("cuda:0"))
+assert ops.rollout_is_specialized(m4, cm4, (1, 1, 1, 0)) and any(jit.JIT_DIR.glob("*.hsaco")) and not any(jit.JIT_DIR.glob("*.so"))
+assert float((c4 - c3).abs().max()) <= 1e-5 * float(c3.abs().max())
+print("rtc ok")
+# (3) a robot NO unit exists for (a modified iiwa7: another model hash): every kernel family of its hipRTC unit, through libtrk.so's
+# generic launchers, against the table-driven kernels
+from torch_robotics_amd.kinematics import URDF_DIR
+from torch_robotics_amd.kinmodel import KinModel
+text = (URDF_DIR / "iiwa7.urdf").read_text().replace('xyz="0 0 0.15"', 'xyz="0 0 0.1625"', 1)
+path = os.path.join(os.environ["TRK_JIT_DIR"], "iiwa7_mod.urdf")
+open(path, "w").write(text)
+kin = KinModel.from_urdf(path)
+assert codegen.model_hash(kin) not in {mh for _i, mh, _t in codegen.aot_units()}
+tmpl = codegen.default_template(kin)
+spec = CostModelSpec(n_links_in=kin.n_links)
+spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+spec.obj_link_margin = np.full(len(tmpl.obj_links), 0.1, np.float32)
+spec.objects = [o.as_object() for o in env.obj_fixed_list]
+spec.ws_min, spec.ws_max = np.float32([-1, -1, -1]), np.float32([1, 1, 1])
+spec.ee_link = tmpl.ee_link
+Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.3, 0.1, 0.6); spec.ee_target = Ht
+h, cm = ops.ModelHandle(kin), ops.CostHandle(spec, "cuda:0")
+assert not h.specialized
+jit.specialize(kin, tmpl.obj_links, (), ee_link=tmpl.ee_link)
+assert h.specialized and ops.rollout_is_specialized(h, cm, (0, 1, 1, 1))
+gen = torch.Generator(device="cuda:0").manual_seed(5)
+D, L = kin.n_dofs, kin.n_links
+qq = (torch.rand(3, 64, D, generator=gen, **TA) - 0.5) * 3.0
+q2 = qq.reshape(-1, D)
+def both(fn):
+    h.enable_specialized(True); a = fn()
+    h.enable_specialized(False); b = fn()
+    h.enable_specialized(True)
+    return a, b
+def close(a, b, tol):
+    a, b = (a.float(), b.float())
+    assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+a, b = both(lambda: ops.rollout_cost_grad(h, cm, (0, 1, 1, 1), qq))
+close(a[0], b[0], 3e-6); close(a[1], b[1], 1e-5); close(a[2], b[2], 1e-4)
+a, b = both(lambda: ops.rollout_cost_grad(h, cm, (0, 1, 1, 1), qq.half()))
+close(a[0], b[0], 2e-3); close(a[1], b[1], 1e-5); close(a[2], b[2], 2e-3)
+a, b = both(lambda: ops.rollout_collision(h, cm, 6, qq))
+assert int((a != b).sum()) <= 1
+a, b = both(lambda: ops.fk_forward(h, q2)); close(a, b, 3e-6)
+a, b = both(lambda: ops.fk_forward(h, q2, [tmpl.ee_link])); close(a, b, 3e-6)
+gH = torch.randn(q2.shape[0], L, 4, 4, generator=gen, **TA)
+a, b = both(lambda: ops.fk_backward(h, q2, gH)); close(a, b, 1e-4)
+a, b = both(lambda: ops.fk_positions(h, q2)); close(a, b, 3e-6)
+gp = torch.randn(q2.shape[0], L, 3, generator=gen, **TA)
+a, b = both(lambda: ops.fk_positions_backward(h, q2, gp)); close(a, b, 1e-4)
+a, b = both(lambda: ops.fk_jacobian(h, q2, None, tmpl.ee_link))
+for x, y in zip(a, b): close(x, y, 1e-5)
+pos = ops.fk_positions(h, q2)
+a = ops.cost_fields(cm, 6, pos, want_grad=True)
+cm.enable_specialized(False); b = ops.cost_fields(cm, 6, pos, want_grad=True); cm.enable_specialized(True)
+close(a[0], b[0], 1e-5); close(a[1], b[1], 1e-4)
+lo, hi = torch.full((D,), -2.0, **TA), torch.full((D,), 2.0, **TA)
+Hq = ops.fk_forward(h, (torch.rand(1, D, generator=gen, **TA) - 0.5) * 2.0, [tmpl.ee_link]).reshape(4, 4).contiguous()
+def ik():
+    q_ = q2.clone(); m_, v_ = torch.zeros_like(q_), torch.zeros_like(q_)
+    ops.ik_steps(h, tmpl.ee_link, Hq, lo, hi, q_, m_, v_, 1, 5)
+    return q_
+a, b = both(ik); close(a, b, 2e-3)
+qg = q2.clone(); err = torch.empty(q2.shape[0], **TA)
+ops.ik_gn_steps(h, tmpl.ee_link, Hq, lo, hi, qg, 20)
+ops.ik_gn_steps(h, tmpl.ee_link, Hq, lo, hi, qg.clone(), 1, err=err)
+assert torch.isfinite(qg).all() and float(err.median()) < 0.2
+qd = torch.randn(3, 64, D, generator=gen, **TA) * 0.3
+a, b = both(lambda: ops.rollout_gp_cost_grad(h, cm, (0, 1, 1, 1), qq, qd, 0.08, 0.3))
+close(a[1], b[1], 2e-5); close(a[2], b[2], 1e-4); close(a[3], b[3], 1e-4)
+print("generic launchers ok")
 print("done")
 """
     root = str(ROOT) if "ROOT" in globals() else os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TRK_JIT_DIR=str(tmp_path), TRK_HIPCC=str(tmp_path / "no-such-hipcc"), TRK_ROOT=root,
                PATH=":".join(p for p in os.environ.get("PATH", "").split(":") if "rocm" not in p))
-    env.pop("TRK_ALLOW_TABLE_DRIVEN", None)
-    env.pop("TRK_NO_JIT", None)
-    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    for k in ("TRK_ALLOW_TABLE_DRIVEN", "TRK_NO_JIT", "TRK_NO_HIPRTC"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=1800)
     assert p.returncode == 0 and "done" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
     from torch_robotics_amd import codegen
-    assert p.stdout.count("ok ") == len(codegen.SPEC_ROBOTS)
+    assert p.stdout.count("ok ") >= len(codegen.SPEC_ROBOTS) and "rtc ok" in p.stdout and "generic launchers ok" in p.stdout

@@ -81,6 +81,19 @@ class RolloutWeights(C.Structure):
     _fields_ = [("w_self", C.c_float), ("w_obj", C.c_float), ("w_ws", C.c_float), ("w_ee", C.c_float)]
 
 
+class ModuleUnitDesc(C.Structure):  # TrkModuleUnitDesc
+    _fields_ = [("spec_abi_version", C.c_int32), ("sizeof_args", C.c_uint32), ("sizeof_cost_hdr", C.c_uint32), ("ident", C.c_char_p),
+                ("model_hash", C.c_uint64), ("n_links", C.c_int32), ("n_dofs", C.c_int32),
+                ("n_obj_links", C.c_int32), ("obj_link_idx", C.POINTER(C.c_int32)),
+                ("n_self_pairs", C.c_int32), ("self_pairs", C.POINTER(C.c_int32)),
+                ("ee_link", C.c_int32), ("ee2_link", C.c_int32),
+                ("n_virtual", C.c_int32), ("virtual_src", C.POINTER(C.c_int32)), ("virtual_w", C.POINTER(C.c_float)),
+                ("chunked", C.c_int32), ("fast_switch", C.c_int32), ("fkhbwd_ok", C.c_int32), ("fields_ok", C.c_int32), ("ik_ok", C.c_int32),
+                ("ikgn_ok", C.c_int32), ("jac_ok", C.c_int32), ("jac_direct", C.c_int32), ("gp_ok", C.c_int32),
+                ("code", C.c_void_p), ("code_size", C.c_uint64),
+                ("n_kernels", C.c_int32), ("name_exprs", C.POINTER(C.c_char_p)), ("lowered_names", C.POINTER(C.c_char_p))]
+
+
 class GpPrior(C.Structure):         # TrkGpPrior
     _fields_ = [("dt", C.c_float), ("sigma", C.c_float), ("weight", C.c_float)]
 

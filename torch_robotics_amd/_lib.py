@@ -33,6 +33,7 @@ EXPORTS = [
     "trk_rollout_points_cost_grad", "trk_rollout_collision", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16", "trk_finite_difference", "trk_traj_diff_norm_sum",
     "trk_interpolate_columns", "trk_interpolate_columns_backward", "trk_rollout_collision_via", "trk_traj_validate",
     "trk_scale_rows", "trk_jtj", "trk_pack_sums", "trk_pack_sums_scratch_bytes", "trk_rollout_is_specialized", "trk_ik_gn_steps", "trk_rollout_gp_cost_grad",
+    "trk_spec_register_module", "trk_spec_layout_stamp",
 ]
 
 
@@ -90,6 +91,8 @@ def lib():
     L.trk_model_is_specialized.argtypes = [vp]
     L.trk_model_enable_specialized.argtypes = [vp, C.c_int]
     L.trk_spec_count.argtypes = []
+    L.trk_spec_register_module.argtypes = [C.POINTER(_abi.ModuleUnitDesc)]
+    L.trk_spec_layout_stamp.argtypes = [C.POINTER(C.c_int64)]
     L.trk_fk_forward.argtypes = [vp, vp, i64, vp, i32, vp, vp]
     L.trk_fk_positions.argtypes = [vp, vp, i64, vp, i32, vp, vp]
     L.trk_fk_backward.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp]

@@ -360,7 +360,10 @@ JAC_DIRECT_MAX_DOFS = 16    # k_jac: robots up to this many DOF write their colu
 OBJ_TICK_SLOTS = int(os.environ.get("TRK_EXP_OBJ_SLOTS", "5"))
 
 
-def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, snap: float = SNAP) -> str:
+def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, snap: float = SNAP, meta: Optional[dict] = None) -> str:
+    """meta (optional): receives what a loader of the unit's DEVICE code alone needs (jit.py's hipRTC fall-back: the host half of the
+    unit -- launchers, registry entry -- is then played by libtrk.so's generic launchers): the kernels' name expressions and the
+    unit's traits."""
     L, D = kin.n_links, kin.n_dofs
     NL = len(tmpl.obj_links)
     masked = _masked_factory(kin)
@@ -655,7 +658,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # ---------------- outputs that depend only on FK ----------------
         if chunked:
             assert not pending
-            E.raw("    const std::conditional_t<POS, RingTail<decltype(ring)>, NoFlushOf<decltype(ring)>> flush{ring};")
+            E.raw("    const typename TrkIf<POS, RingTail<decltype(ring)>, NoFlushOf<decltype(ring)>>::type flush{ring};")
         else:
             E.raw(f"    PosFlusher<{3 * L}, IOQ> flush{{reinterpret_cast<const float4*>(lds) + lane, 0u, 0ull, 0ull, lane, make_float4(0.0f, 0.0f, 0.0f, 0.0f)}};")
             pos_list = ", ".join(E.expr(t[i][k]) for i in range(L) for k in range(3))
@@ -1597,6 +1600,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.extend(E.lines)
         out.append("")
 
+    out.append("#ifndef __HIPCC_RTC__          // the unit's host half: launchers and its registry entry")
     obj = ", ".join(str(i) for i in tmpl.obj_links) or "0"
     pairs = ", ".join(f"{a}, {b}" for a, b in tmpl.self_pairs) or "0"
     out.append(f"static const int32_t kObjLinks[] = {{{obj}}};")
@@ -1605,7 +1609,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     vw = ", ".join(f"{flit(float(np.float32(r[2])))}, {flit(float(np.float32(r[3])))}" for r in tmpl.virtual) or "0.0f"
     out.append(f"static const int32_t kVirtualSrc[] = {{{vsrc}}};")
     out.append(f"static const float kVirtualW[] = {{{vw}}};")
-    out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("static void launch(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     # every (IO, [POS,] [FAST,] [BOX,] base) instantiation: one generic lambda per compile-time switch, in template-parameter order
     switches = []
@@ -1634,7 +1638,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("    if (a.io_f16 == TRK_IO_F16) sw0(_Float16{}); else if (a.io_f16 == TRK_IO_F16_G32) sw0(HalfG32{}); else sw0(float{});")
     out.append("}")
     if gp_ok or gpt_ok:
-        out.append("static int launch_gp(const SpecArgs& a, int base_identity, hipStream_t st) {")
+        out.append("static int launch_gp(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
         sw = "scene_is_fast(a.C)" if D > 8 else "a.C.n_box_objects > 0 && a.C.n_prims <= TRK_LDS_PRIMS"
         if use_seg and gp_cross_pairs:
@@ -1649,51 +1653,51 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("    if (a.io_f16 == TRK_IO_F16) sw(_Float16{}); else if (a.io_f16 == TRK_IO_F16_G32) sw(HalfG32{}); else sw(float{});")
         out.append("    return 0;")
         out.append("}")
-    out.append("static void launch_posbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("static void launch_posbwd(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     out.append("    if (base_identity) hipLaunchKernelGGL(k_posbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_posbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
-    out.append("static void launch_coll(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("static void launch_coll(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     out.append("    if (base_identity) hipLaunchKernelGGL(k_coll_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_coll_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
-    out.append("static void launch_fkh(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("static void launch_fkh(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     out.append("    if (base_identity) hipLaunchKernelGGL(k_fkh_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_fkh_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
     if fkhbwd_ok:
-        out.append("static void launch_fkhbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
+        out.append("static void launch_fkhbwd(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
         out.append("    if (base_identity) hipLaunchKernelGGL(k_fkhbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    else hipLaunchKernelGGL(k_fkhbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("}")
     if fields_ok:
-        out.append("static void launch_fields(const SpecArgs& a, int, hipStream_t st) {      // coll_out set: the boolean fields")
+        out.append("static void launch_fields(const SpecEntry*, const SpecArgs& a, int, hipStream_t st) {      // coll_out set: the boolean fields")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
         out.append("    if (a.coll_out) hipLaunchKernelGGL(k_collf, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    else hipLaunchKernelGGL(k_fields, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("}")
-    out.append("static void launch_fk1(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("static void launch_fk1(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     out.append("    if (base_identity) hipLaunchKernelGGL(k_fk1_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_fk1_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("}")
     if ik_ok:
-        out.append("static void launch_ik(const IkArgs& a, int base_identity, hipStream_t st) {")
+        out.append("static void launch_ik(const SpecEntry*, const IkArgs& a, int base_identity, hipStream_t st) {")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
         out.append("    if (base_identity) hipLaunchKernelGGL(k_ik_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    else hipLaunchKernelGGL(k_ik_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("}")
     if ikgn_ok:
-        out.append("static void launch_ikgn(const IkGnArgs& a, int base_identity, hipStream_t st) {")
+        out.append("static void launch_ikgn(const SpecEntry*, const IkGnArgs& a, int base_identity, hipStream_t st) {")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
         out.append("    if (base_identity) hipLaunchKernelGGL(k_ikgn_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    else hipLaunchKernelGGL(k_ikgn_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("}")
-    out.append("static void launch_jac(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("static void launch_jac(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
     if direct:
         out.append(f"    const size_t lds = sizeof(float) * (size_t)TRK_WAVE * {6 * D};")
@@ -1710,7 +1714,36 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1, {'launch_fields' if fields_ok else 'nullptr'}, "
                f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW, {'launch_ikgn' if ikgn_ok else 'nullptr'}, {'launch_gp' if (gp_ok or gpt_ok) else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
+    out.append("#endif      // !__HIPCC_RTC__")
     out.append(f"}}  // namespace spec_{ident}")
+    if meta is not None:
+        ns = f"spec_{ident}::"
+        ios = ("float", "_Float16", "HalfG32")
+        n_sw = (1 if chunked else 0) + 1
+        sw_sets = [[]]
+        for _ in range(n_sw):
+            sw_sets = [v + [b] for v in sw_sets for b in ("false", "true")]
+        names = []
+        for b in ("bi", "bg"):
+            for io in ios:
+                for sw in sw_sets:
+                    names.append(f"{ns}k_rollout_{b}<{', '.join([io] + sw)}>")
+                if gpt_ok and not use_seg:
+                    names += [f"{ns}k_rollout_gpt_{b}<{io}, {v}>" for v in ("false", "true")]
+            names += [f"{ns}k_posbwd_{b}", f"{ns}k_coll_{b}", f"{ns}k_fkh_{b}", f"{ns}k_fk1_{b}"]
+            if fkhbwd_ok:
+                names.append(f"{ns}k_fkhbwd_{b}")
+            if ik_ok:
+                names.append(f"{ns}k_ik_{b}")
+            if ikgn_ok:
+                names.append(f"{ns}k_ikgn_{b}")
+            if jac_ok:
+                names.append(f"{ns}k_jac_{b}")
+        if fields_ok:
+            names += [f"{ns}k_fields", f"{ns}k_collf"]
+        meta.update(ident=ident, kernels=names, chunked=bool(chunked), fast_switch=bool(D > 8), fkhbwd_ok=bool(fkhbwd_ok), fields_ok=bool(fields_ok),
+                    ik_ok=bool(ik_ok), ikgn_ok=bool(ikgn_ok), jac_ok=bool(jac_ok), jac_direct=bool(direct), gp_ok=bool(gpt_ok and not use_seg),
+                    n_links=L, n_dofs=D)
     return "\n".join(out) + "\n"
 
 
@@ -2159,13 +2192,13 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     out.append("        else hipLaunchKernelGGL((k_rollout_bg<false, IO>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    }")
     out.append("}")
-    out.append("static void launch(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("static void launch(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
     if link_mode:
         out.append("    if (a.io_f16) launch_io<_Float16>(a, base_identity, st); else launch_io<float>(a, base_identity, st);")
     else:
         out.append("    launch_io<float>(a, base_identity, st);")
     out.append("}")
-    out.append("static void launch_posbwd(const SpecArgs& a, int base_identity, hipStream_t st) {")
+    out.append("static void launch_posbwd(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
     out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
     out.append("    if (base_identity) hipLaunchKernelGGL(k_posbwd_bi, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    else hipLaunchKernelGGL(k_posbwd_bg, dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
@@ -2320,14 +2353,14 @@ def _is_tree(kin: KinModel) -> bool:
     return bool((kids > 1).any())
 
 
-def generate_link_kernel_source(kin: KinModel, tmpl: CollisionTemplate, ident: str) -> str:
+def generate_link_kernel_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, meta: Optional[dict] = None) -> str:
     """Serial chains: generate_rollout_source (FK, batched objectives, reverse pass).  Trees whose file order is a
     pre-order walk with increasing collision links: the per-link pipeline of generate_points_rollout_source."""
     use_pipeline = (_is_tree(kin) and [int(v) for v in kin.order] == list(range(kin.n_links)) and
                     sorted(tmpl.obj_links) == list(tmpl.obj_links) and TREE_PIPELINE)
     if use_pipeline:
         return generate_points_rollout_source(kin, link_points_template(kin, tmpl), ident, link_mode=True)
-    return generate_rollout_source(kin, tmpl, ident)
+    return generate_rollout_source(kin, tmpl, ident, meta=meta)
 
 
 TREE_PIPELINE = False     # measured on MI355X: dual Panda 23.5 -> 37.8 us, UR10+Allegro 36.9 -> 41.7 us: one scene evaluation per link

@@ -69,6 +69,11 @@ int trk_spec_register(const SpecEntry* e) {
     return 0;
 }
 int trk_spec_count(void) { return (int)spec_registry().size(); }
+int trk_spec_layout_stamp(int64_t* out) {
+    if (!out) return TRK_ERR_INVALID_ARG;
+    out[0] = TRK_SPEC_ABI_VERSION; out[1] = (int64_t)(sizeof(SpecArgs) + sizeof(IkArgs) + sizeof(IkGnArgs)); out[2] = (int64_t)sizeof(DevCostHdr);
+    return 0;
+}
 const SpecEntry* trk_spec_find(uint64_t h, int n_links, int n_dofs) {
     for (const SpecEntry* e : spec_registry())
         if (e->n_points == 0 && e->model_hash == h && e->n_links == n_links && e->n_dofs == n_dofs) return e;
@@ -78,6 +83,151 @@ const SpecEntry* trk_spec_find_points(uint64_t h, uint64_t points_hash, int n_po
     for (const SpecEntry* e : spec_registry())
         if (e->n_points == n_points && n_points > 0 && e->model_hash == h && e->points_hash == points_hash) return e;
     return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// A generated unit loaded as a CODE OBJECT (jit.py's hipRTC fall-back: the unit's device half compiled in-process when no hipcc is
+// around).  The unit's host half -- its launchers -- is played by the generic functions below: same kernel choice by (I/O mode,
+// compile-time switches, base pose), same grids, looked up in a table of hipFunction_t filled at registration.
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct ModuleUnit {
+    hipModule_t mod = nullptr;
+    std::string ident;
+    std::vector<int32_t> obj, pairs, vsrc;
+    std::vector<float> vw;
+    bool chunked = false, fast_switch = false, jac_direct = false;
+    int D = 0;
+    hipFunction_t rollout[3][2][2][2] = {};     // [io][POS (chunked units, else 0)][FAST or BOX][base identity]
+    hipFunction_t gp[3][2][2] = {};             // [io][FAST or BOX][base identity]
+    hipFunction_t posbwd[2] = {}, coll[2] = {}, fkh[2] = {}, fkhbwd[2] = {}, fk1[2] = {}, ik[2] = {}, ikgn[2] = {}, jac[2] = {};
+    hipFunction_t fields = nullptr, collf = nullptr;
+    SpecEntry entry{};
+};
+std::vector<ModuleUnit*>& module_units() { static std::vector<ModuleUnit*> v; return v; }
+
+template <class Args>
+void mod_launch(hipFunction_t f, unsigned grid, unsigned block, size_t lds, const Args& a, hipStream_t st) {
+    Args copy = a;
+    size_t size = sizeof(Args);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    (void)hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds, st, nullptr, extra);
+}
+inline const ModuleUnit* unit_of(const SpecEntry* self) { return static_cast<const ModuleUnit*>(self->module_ctx); }
+inline unsigned blocks_of(int64_t n) { return (unsigned)((n + SPEC_BLOCK - 1) / SPEC_BLOCK); }
+inline int scene_switch(const ModuleUnit* u, const SpecArgs& a) {
+    return u->fast_switch ? (scene_is_fast(a.C) ? 1 : 0) : ((a.C.n_box_objects > 0 && a.C.n_prims <= TRK_LDS_PRIMS) ? 1 : 0);
+}
+void mod_rollout(const SpecEntry* self, const SpecArgs& a, int bi, hipStream_t st) {
+    const ModuleUnit* u = unit_of(self);
+    const int io = a.io_f16 == TRK_IO_F16 ? 1 : (a.io_f16 == TRK_IO_F16_G32 ? 2 : 0);
+    mod_launch(u->rollout[io][u->chunked && a.link_pos ? 1 : 0][scene_switch(u, a)][bi ? 1 : 0], blocks_of(a.n), SPEC_BLOCK, 0, a, st);
+}
+int mod_gp(const SpecEntry* self, const SpecArgs& a, int bi, hipStream_t st) {
+    const ModuleUnit* u = unit_of(self);
+    const int io = a.io_f16 == TRK_IO_F16 ? 1 : (a.io_f16 == TRK_IO_F16_G32 ? 2 : 0);
+    mod_launch(u->gp[io][scene_switch(u, a)][bi ? 1 : 0], blocks_of(a.n), SPEC_BLOCK, 0, a, st);
+    return 0;
+}
+#define TRK_MOD_SIMPLE(NAME, FIELD) \
+    void NAME(const SpecEntry* self, const SpecArgs& a, int bi, hipStream_t st) { \
+        mod_launch(unit_of(self)->FIELD[bi ? 1 : 0], blocks_of(a.n), SPEC_BLOCK, 0, a, st); }
+TRK_MOD_SIMPLE(mod_posbwd, posbwd)
+TRK_MOD_SIMPLE(mod_coll, coll)
+TRK_MOD_SIMPLE(mod_fkh, fkh)
+TRK_MOD_SIMPLE(mod_fkhbwd, fkhbwd)
+TRK_MOD_SIMPLE(mod_fk1, fk1)
+#undef TRK_MOD_SIMPLE
+void mod_fields(const SpecEntry* self, const SpecArgs& a, int, hipStream_t st) {
+    const ModuleUnit* u = unit_of(self);
+    mod_launch(a.coll_out ? u->collf : u->fields, blocks_of(a.n), SPEC_BLOCK, 0, a, st);
+}
+void mod_ik(const SpecEntry* self, const IkArgs& a, int bi, hipStream_t st) {
+    mod_launch(unit_of(self)->ik[bi ? 1 : 0], blocks_of(a.n), SPEC_BLOCK, 0, a, st);
+}
+void mod_ikgn(const SpecEntry* self, const IkGnArgs& a, int bi, hipStream_t st) {
+    mod_launch(unit_of(self)->ikgn[bi ? 1 : 0], blocks_of(a.n), SPEC_BLOCK, 0, a, st);
+}
+void mod_jac(const SpecEntry* self, const SpecArgs& a, int bi, hipStream_t st) {
+    const ModuleUnit* u = unit_of(self);
+    size_t lds;
+    if (u->jac_direct) lds = sizeof(float) * (size_t)TRK_WAVE * 6 * u->D;
+    else {
+        const int rstride = (6 * a.jac_n_cols + 3) | 1;
+        lds = sizeof(float) * ((size_t)TRK_WAVE * (rstride > u->D ? rstride : u->D) + TRK_MAX_DOFS);
+    }
+    mod_launch(u->jac[bi ? 1 : 0], (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE), TRK_WAVE, lds, a, st);
+}
+}  // namespace
+
+int trk_spec_register_module(const TrkModuleUnitDesc* d) {
+    if (!d || !d->ident || !d->code || d->code_size == 0 || d->n_kernels < 1 || !d->name_exprs || !d->lowered_names || d->n_dofs < 0 ||
+        d->n_links < 1 || d->n_obj_links < 0 || d->n_self_pairs < 0 || d->n_virtual < 0)
+        return fail(TRK_ERR_INVALID_ARG, "trk_spec_register_module: bad descriptor");
+    if (d->spec_abi_version != TRK_SPEC_ABI_VERSION || d->sizeof_args != sizeof(SpecArgs) + sizeof(IkArgs) + sizeof(IkGnArgs) ||
+        d->sizeof_cost_hdr != sizeof(DevCostHdr))
+        return fail(TRK_ERR_INVALID_ARG, "trk_spec_register_module: the code object was built against another SpecArgs / DevCostHdr layout");
+    ModuleUnit* u = new (std::nothrow) ModuleUnit();
+    if (!u) return fail(TRK_ERR_HIP, "trk_spec_register_module: out of memory");
+    hipError_t e = hipModuleLoadData(&u->mod, d->code);
+    if (e != hipSuccess) { delete u; return hip_fail(e, "trk_spec_register_module: hipModuleLoadData"); }
+    u->ident = d->ident;
+    u->chunked = d->chunked != 0; u->fast_switch = d->fast_switch != 0; u->jac_direct = d->jac_direct != 0; u->D = d->n_dofs;
+    u->obj.assign(d->obj_link_idx, d->obj_link_idx + d->n_obj_links);
+    u->pairs.assign(d->self_pairs, d->self_pairs + 2 * d->n_self_pairs);
+    if (d->n_virtual) { u->vsrc.assign(d->virtual_src, d->virtual_src + 2 * d->n_virtual); u->vw.assign(d->virtual_w, d->virtual_w + 2 * d->n_virtual); }
+    const std::string ns = "spec_" + u->ident + "::";
+    auto find = [&](const std::string& expr, hipFunction_t* out) -> bool {
+        for (int k = 0; k < d->n_kernels; ++k)
+            if (expr == d->name_exprs[k]) return hipModuleGetFunction(out, u->mod, d->lowered_names[k]) == hipSuccess;
+        return false;
+    };
+    bool ok = true;
+    const char* ios[3] = {"float", "_Float16", "HalfG32"};
+    const char* tf[2] = {"false", "true"};
+    const char* bs[2] = {"bg", "bi"};
+    for (int b = 0; b < 2 && ok; ++b) {
+        for (int io = 0; io < 3 && ok; ++io)
+            for (int sw = 0; sw < 2 && ok; ++sw) {
+                for (int pos = 0; pos < (u->chunked ? 2 : 1) && ok; ++pos) {
+                    const std::string sws = u->chunked ? std::string(tf[pos]) + ", " + tf[sw] : std::string(tf[sw]);
+                    ok = find(ns + "k_rollout_" + bs[b] + "<" + ios[io] + ", " + sws + ">", &u->rollout[io][pos][sw][b]);
+                }
+                if (ok && d->gp_ok) ok = find(ns + "k_rollout_gpt_" + bs[b] + "<" + ios[io] + ", " + tf[sw] + ">", &u->gp[io][sw][b]);
+            }
+        ok = ok && find(ns + "k_posbwd_" + bs[b], &u->posbwd[b]) && find(ns + "k_coll_" + bs[b], &u->coll[b]) &&
+             find(ns + "k_fkh_" + bs[b], &u->fkh[b]) && find(ns + "k_fk1_" + bs[b], &u->fk1[b]);
+        if (ok && d->fkhbwd_ok) ok = find(ns + "k_fkhbwd_" + bs[b], &u->fkhbwd[b]);
+        if (ok && d->ik_ok) ok = find(ns + "k_ik_" + bs[b], &u->ik[b]);
+        if (ok && d->ikgn_ok) ok = find(ns + "k_ikgn_" + bs[b], &u->ikgn[b]);
+        if (ok && d->jac_ok) ok = find(ns + "k_jac_" + bs[b], &u->jac[b]);
+    }
+    if (ok && d->fields_ok) ok = find(ns + "k_fields", &u->fields) && find(ns + "k_collf", &u->collf);
+    if (!ok) {
+        (void)hipModuleUnload(u->mod);
+        delete u;
+        return fail(TRK_ERR_INVALID_ARG, "trk_spec_register_module: a kernel of the unit is missing from the code object");
+    }
+    SpecEntry& E = u->entry;
+    E.spec_abi_version = TRK_SPEC_ABI_VERSION;
+    E.sizeof_args = (uint32_t)(sizeof(SpecArgs) + sizeof(IkArgs) + sizeof(IkGnArgs));
+    E.sizeof_entry = (uint32_t)sizeof(SpecEntry); E.sizeof_cost_hdr = (uint32_t)sizeof(DevCostHdr);
+    E.model_hash = d->model_hash; E.n_links = d->n_links; E.n_dofs = d->n_dofs;
+    E.n_obj_links = d->n_obj_links; E.obj_link_idx = u->obj.data();
+    E.n_self_pairs = d->n_self_pairs; E.self_pairs = u->pairs.data();
+    E.ee_link = d->ee_link; E.ee2_link = d->ee2_link; E.name = u->ident.c_str();
+    E.n_points = 0; E.points_hash = 0;
+    E.n_virtual = d->n_virtual; E.virtual_src = u->vsrc.data(); E.virtual_w = u->vw.data();
+    E.launch = mod_rollout; E.launch_posbwd = mod_posbwd; E.launch_coll = mod_coll; E.launch_fkh = mod_fkh; E.launch_fk1 = mod_fk1;
+    E.launch_fkhbwd = d->fkhbwd_ok ? mod_fkhbwd : nullptr;
+    E.launch_jac = d->jac_ok ? mod_jac : nullptr;
+    E.launch_ik = d->ik_ok ? mod_ik : nullptr;
+    E.launch_ikgn = d->ikgn_ok ? mod_ikgn : nullptr;
+    E.launch_fields = d->fields_ok ? mod_fields : nullptr;
+    E.launch_gp = d->gp_ok ? mod_gp : nullptr;
+    E.module_ctx = u;
+    module_units().push_back(u);
+    return trk_spec_register(&u->entry);
 }
 
 struct TrkModel {
@@ -368,7 +518,7 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = out;
-        m->spec->launch(a, base_is_identity(m), (hipStream_t)stream);
+        m->spec->launch(m->spec, a, base_is_identity(m), (hipStream_t)stream);
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
@@ -384,7 +534,7 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
         for (int l = 0; l < m->hdr.n_links; ++l) if (sel.col[l] == 0) a.jac_link = l;
         for (int p = 0; p < m->hdr.n_links; ++p) if (m->links[p].link == a.jac_link) a.jac_p_end = p + 1;
         if (a.jac_link >= 0) {
-            m->spec->launch_fk1(a, base_is_identity(m), (hipStream_t)stream);
+            m->spec->launch_fk1(m->spec, a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }
@@ -397,7 +547,7 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.fk_H = out;
-        m->spec->launch_fkh(a, base_is_identity(m), (hipStream_t)stream);
+        m->spec->launch_fkh(m->spec, a, base_is_identity(m), (hipStream_t)stream);
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
@@ -429,7 +579,7 @@ static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin,
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.fk_H = const_cast<float*>(gin); a.gq = gq;
-        m->spec->launch_fkhbwd(a, base_is_identity(m), (hipStream_t)stream);
+        m->spec->launch_fkhbwd(m->spec, a, base_is_identity(m), (hipStream_t)stream);
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
@@ -440,7 +590,7 @@ static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin,
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = const_cast<float*>(gin); a.gq = gq;
-        m->spec->launch_posbwd(a, base_is_identity(m), (hipStream_t)stream);
+        m->spec->launch_posbwd(m->spec, a, base_is_identity(m), (hipStream_t)stream);
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
@@ -531,7 +681,7 @@ int trk_fk_points(const TrkModel* m, const TrkPointSet* ps, const float* q, int6
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = pos_out;
-        ps->spec->launch(a, base_is_identity(m), (hipStream_t)stream);
+        ps->spec->launch(ps->spec, a, base_is_identity(m), (hipStream_t)stream);
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
@@ -555,7 +705,7 @@ int trk_fk_points_backward(const TrkModel* m, const TrkPointSet* ps, const float
         std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = const_cast<float*>(gpos); a.gq = gq;
-        ps->spec->launch_posbwd(a, base_is_identity(m), (hipStream_t)stream);
+        ps->spec->launch_posbwd(ps->spec, a, base_is_identity(m), (hipStream_t)stream);
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
@@ -591,7 +741,7 @@ int trk_fk_jacobian(const TrkModel* m, const float* q, const float* qd, int64_t 
             }
         }
         a.jac_pos = pos; a.jac_quat = quat; a.jac_lin = lin_jac; a.jac_ang = ang_jac;
-        m->spec->launch_jac(a, base_is_identity(m), (hipStream_t)stream);
+        m->spec->launch_jac(m->spec, a, base_is_identity(m), (hipStream_t)stream);
         TRK_HIP(hipGetLastError());
         return TRK_OK;
     }
@@ -640,7 +790,7 @@ int trk_ik_steps(const TrkModel* m, int32_t link, const float* H_target, int32_t
             a.w_jl = w_joint_limits; a.se3_eps = se3_eps; a.lr = lr; a.sched = sched; a.n = n;
             a.q = q; a.adam_m = adam_m; a.adam_v = adam_v;
             a.loss = done == 0 ? loss : nullptr; a.valid = done == 0 ? valid : nullptr;
-            gen->launch_ik(a, base_is_identity(m), (hipStream_t)stream);
+            gen->launch_ik(gen, a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             continue;
         }
@@ -679,7 +829,7 @@ int trk_ik_gn_steps(const TrkModel* m, int32_t link, const float* H_target, int3
     a.H_target = H_target; a.per_sample = per_sample_target; a.n_steps = n_steps; a.lower = lower; a.upper = upper;
     a.damping = damping; a.lm_gain = lm_gain; a.step_scale = step_scale; a.se3_eps = se3_eps; a.n = n;
     a.q = q; a.err = err; a.valid = valid;
-    gen->launch_ikgn(a, base_is_identity(m), (hipStream_t)stream);
+    gen->launch_ikgn(gen, a, base_is_identity(m), (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }
@@ -1050,7 +1200,7 @@ int trk_cost_fields(const TrkCostModel* cm, int32_t fields, const float* link_po
             SpecArgs a{};
             a.C = cm->hdr; a.w = w;
             a.n = n; a.fld_pos = link_pos; a.fld_gcost = gcost; a.fld_g = g_link_pos; a.cost = cost;
-            e->launch_fields(a, 1, (hipStream_t)stream);
+            e->launch_fields(e, a, 1, (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }
@@ -1074,7 +1224,7 @@ int trk_collision_fields(const TrkCostModel* cm, int32_t fields, const float* li
             a.C = cm->hdr; a.w = w;
             a.n = n; a.fld_pos = link_pos; a.coll_out = in_collision; a.coll_fields = fields;
             a.coll_use_default = use_default; a.coll_margin = use_default ? 0.0f : margin_override;
-            e->launch_fields(a, 1, (hipStream_t)stream);
+            e->launch_fields(e, a, 1, (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }
@@ -1117,7 +1267,7 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
             a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
             a.stamps = g_stamps; a.io_f16 = io_f16; a.grad_scale = grad_scale;
-            e->launch(a, base_is_identity(m), (hipStream_t)stream);
+            e->launch(e, a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }
@@ -1160,7 +1310,7 @@ int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fie
             a.q = q; a.n = n;
             a.coll_out = in_collision; a.coll_fields = fields; a.coll_use_default = use_default;
             a.coll_margin = use_default ? 0.0f : margin_override;
-            e->launch_coll(a, base_is_identity(m), (hipStream_t)stream);
+            e->launch_coll(e, a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }
@@ -1206,7 +1356,7 @@ int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t
     a.coll_out = in_collision; a.coll_fields = fields; a.coll_use_default = use_default;
     a.coll_margin = use_default ? 0.0f : margin_override;
     a.via_alpha = alpha; a.via_beta = beta; a.via_n = n_interp; a.via_H = horizon; a.via_S = state_dim;
-    e->launch_coll(a, base_is_identity(m), (hipStream_t)stream);
+    e->launch_coll(e, a, base_is_identity(m), (hipStream_t)stream);
     TRK_HIP(hipGetLastError());
     return TRK_OK;
 }
@@ -1274,7 +1424,7 @@ int trk_rollout_gp_cost_grad(const TrkModel* m, const TrkCostModel* cm, const Tr
             const float s2 = 1.0f / (gp->sigma * gp->sigma);
             a.qd = qd; a.gqd = gqd; a.gp_dt = gp->dt; a.gp_w = gp->weight; a.gp_H = horizon;
             a.gp_a = 12.0f * s2 / (gp->dt * gp->dt * gp->dt); a.gp_b = -6.0f * s2 / (gp->dt * gp->dt); a.gp_c = 4.0f * s2 / gp->dt;
-            if (e->launch_gp(a, base_is_identity(m), (hipStream_t)stream) == 0) {
+            if (e->launch_gp(e, a, base_is_identity(m), (hipStream_t)stream) == 0) {
                 TRK_HIP(hipGetLastError());
                 return TRK_OK;
             }
@@ -1324,7 +1474,7 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
             a.q = q; a.n = n; a.link_pos = point_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
             a.stamps = nullptr; a.io_f16 = 0;
-            e->launch(a, base_is_identity(m), (hipStream_t)stream);
+            e->launch(e, a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(hipGetLastError());
             return TRK_OK;
         }

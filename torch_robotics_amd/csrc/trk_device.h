@@ -6,8 +6,14 @@
 // the q / gq / link-position transposes that make HBM accesses coalesced, the pose stack of
 // branched trees, and the per-joint records of the reverse pass.
 #pragma once
+#ifndef __HIPCC_RTC__                  // hipRTC (jit.py's fall-back when hipcc is absent) brings its own runtime header
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else                                  // ... but no <stdint.h> names in the global namespace
+typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;
+typedef int int32_t; typedef unsigned int uint32_t; typedef long long int64_t; typedef unsigned long long uint64_t;
+typedef unsigned long uintptr_t;
+#endif
 #include "../../include/trk.h"
 
 #define TRK_WAVE 64

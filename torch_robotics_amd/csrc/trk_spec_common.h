@@ -15,6 +15,11 @@
 #pragma once
 #include "trk_device.h"
 
+template <bool B, class T, class F> struct TrkIf { typedef T type; };        // std::conditional (no <type_traits> under hipRTC)
+template <class T, class F> struct TrkIf<false, T, F> { typedef F type; };
+template <class A, class B> struct TrkSame { static constexpr bool value = false; };
+template <class A> struct TrkSame<A, A> { static constexpr bool value = true; };
+
 struct SpecArgs {
     DevCostHdr C;
     TrkRolloutWeights w;
@@ -64,7 +69,12 @@ struct SpecArgs {
     int32_t gp_H;
 };
 
-typedef void (*SpecLaunchFn)(const SpecArgs& args, int base_identity, hipStream_t stream);
+#ifndef __HIPCC_RTC__          // host side of a unit (launchers, registry): not part of an in-process device compilation
+struct SpecEntry;
+// `self`: the entry the function was taken from -- the generated launchers ignore it, the generic launchers of a unit loaded as a
+// code object (hipRTC fall-back, trk_spec_register_module) find their kernels through it
+typedef void (*SpecLaunchFn)(const SpecEntry* self, const SpecArgs& args, int base_identity, hipStream_t stream);
+#endif
 
 // Arguments of the generated IK kernel (trk_ik_steps on the unit's tracked link).  A struct of its own: the 256-byte schedule
 // would otherwise ride in the kernarg segment of every kernel of the unit.
@@ -83,7 +93,9 @@ struct IkArgs {
     float* q; float* adam_m; float* adam_v;     // [N,D], in place
     float* loss; uint8_t* valid;                // nullable; q as passed in
 };
-typedef void (*SpecIkLaunchFn)(const IkArgs& args, int base_identity, hipStream_t stream);
+#ifndef __HIPCC_RTC__
+typedef void (*SpecIkLaunchFn)(const SpecEntry* self, const IkArgs& args, int base_identity, hipStream_t stream);
+#endif
 
 // Arguments of the generated Gauss-Newton / Levenberg-Marquardt IK kernel (trk_ik_gn_steps on the unit's tracked link): per iteration
 // stateful FK + geometric Jacobian (robot_tree.py:218-248), pose residual, J^T J + lambda I, Cholesky, step, clamp -- per lane, in registers.
@@ -100,13 +112,16 @@ struct IkGnArgs {
     float* q;                     // [N,D], in place
     float* err; uint8_t* valid;   // nullable; SE3 distance / validity of q as passed in
 };
-typedef void (*SpecIkGnLaunchFn)(const IkGnArgs& args, int base_identity, hipStream_t stream);
+#ifndef __HIPCC_RTC__
+typedef void (*SpecIkGnLaunchFn)(const SpecEntry* self, const IkGnArgs& args, int base_identity, hipStream_t stream);
+#endif
 
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 22)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 23)
 
+#ifndef __HIPCC_RTC__
 struct SpecEntry {
     int32_t spec_abi_version;   // TRK_SPEC_ABI_VERSION the unit was compiled with
     uint32_t sizeof_args;       // sizeof(SpecArgs) + sizeof(IkArgs) the unit was compiled with
@@ -140,7 +155,8 @@ struct SpecEntry {
     SpecIkGnLaunchFn launch_ikgn;   // Gauss-Newton IK iterations on ee_link (trk_ik_gn_steps); nullptr if not generated
     // fused rollout + GP prior in one launch (trk_rollout_gp_cost_grad): returns 0, or 1 when this unit cannot serve the call
     // (self-collision pairs between independently scheduled subtrees with w_self != 0) -- the caller then runs the two-launch form
-    int (*launch_gp)(const SpecArgs& args, int base_identity, hipStream_t stream);
+    int (*launch_gp)(const SpecEntry* self, const SpecArgs& args, int base_identity, hipStream_t stream);
+    void* module_ctx;           // nullptr for a linked / dlopen-ed unit; the code-object unit's kernel table otherwise
 };
 
 // registry filled by static initialisers of the generated translation units
@@ -149,6 +165,7 @@ int trk_spec_register(const SpecEntry* e);
 #define SPEC_ENTRY_STAMP TRK_SPEC_ABI_VERSION, (uint32_t)(sizeof(SpecArgs) + sizeof(IkArgs) + sizeof(IkGnArgs)), (uint32_t)sizeof(SpecEntry), (uint32_t)sizeof(DevCostHdr)
 const SpecEntry* trk_spec_find(uint64_t model_hash, int n_links, int n_dofs);
 const SpecEntry* trk_spec_find_points(uint64_t model_hash, uint64_t points_hash, int n_points);
+#endif      // !__HIPCC_RTC__
 
 // ---------------------------------------------------------------------------------------------------------
 // I/O transposes (one wavefront, `lane` = lane id; `lds` = this wave's private region)
@@ -741,7 +758,7 @@ __device__ __forceinline__ void spec_load_chunk(const float* __restrict__ in, in
     const float* src0 = in + base * W + c0;
     if ((V == 1 || V == 2) && rows == TRK_WAVE) {      // full wave: a batch of loads in flight before the first LDS write (the guarded
         constexpr int NB = NVEC > 18 ? (NVEC + 3) / 4 : NVEC;     // loop below waits for every load before it issues the next)
-        typedef std::conditional_t<V == 2, float2, float> vec_t;
+        typedef typename TrkIf<V == 2, float2, float>::type vec_t;
 #pragma unroll
         for (int j0 = 0; j0 < NVEC; j0 += NB) {
             vec_t r[NB];

@@ -106,6 +106,132 @@ def _compile_unit(source: str, ident: str, verbose: bool) -> Path:
     return so
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# hipRTC fall-back: no hipcc on the box (a runtime-only ROCm installation has libhiprtc.so but no compiler driver).  The unit's
+# DEVICE half is compiled in-process to a code object; libtrk.so's generic launchers play its host half
+# (trk_spec_register_module).  Same generator, same headers, same device flags; the code object is cached next to the .so units.
+# ----------------------------------------------------------------------------------------------------------------------
+RTC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-honor-nans",
+             "-mno-amdgpu-ieee", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+_rtc_keep = []          # descriptors' buffers of the registered code-object units (libtrk.so copies what it needs; the code stays mapped)
+
+
+def hipcc_available() -> bool:
+    return os.path.exists(HIPCC) and os.access(HIPCC, os.X_OK)
+
+
+def _hiprtc():
+    if os.environ.get("TRK_NO_HIPRTC", "0") == "1":
+        raise _lib.TrkError("no hipcc, and the hipRTC fall-back is switched off (TRK_NO_HIPRTC=1)")
+    for name in ("libhiprtc.so", "/opt/rocm/lib/libhiprtc.so", os.path.join(os.path.dirname(__import__("torch").__file__), "lib", "libhiprtc.so")):
+        try:
+            L = C.CDLL(name)
+            L.hiprtcGetErrorString.restype = C.c_char_p
+            return L
+        except OSError:
+            continue
+    raise _lib.TrkError("neither hipcc nor libhiprtc.so is available: a generated unit cannot be compiled on this box")
+
+
+def _rtc_compile(source: str, ident: str, kernels) -> Tuple[bytes, list]:
+    """device half of a unit -> (code object, lowered kernel names in the order of `kernels`)"""
+    R = _hiprtc()
+
+    def ck(rc, what):
+        if rc != 0:
+            raise _lib.TrkError(f"hipRTC {what}: {R.hiprtcGetErrorString(rc).decode()}")
+    prog = C.c_void_p()
+    ck(R.hiprtcCreateProgram(C.byref(prog), source.encode(), f"spec_{ident}.hip".encode(), 0, None, None), "hiprtcCreateProgram")
+    try:
+        for k in kernels:
+            ck(R.hiprtcAddNameExpression(prog, k.encode()), f"hiprtcAddNameExpression({k})")
+        opts = [o.encode() for o in RTC_FLAGS + [f"-I{_CSRC}", f"-I{_REPO_INCLUDE}"]]
+        arr = (C.c_char_p * len(opts))(*opts)
+        rc = R.hiprtcCompileProgram(prog, len(opts), arr)
+        if rc != 0:
+            n = C.c_size_t()
+            R.hiprtcGetProgramLogSize(prog, C.byref(n))
+            log = C.create_string_buffer(max(1, n.value))
+            R.hiprtcGetProgramLog(prog, log)
+            raise _lib.TrkError(f"hipRTC compilation of spec_{ident}.hip failed:\n{log.value.decode()[-4000:]}")
+        sz = C.c_size_t()
+        ck(R.hiprtcGetCodeSize(prog, C.byref(sz)), "hiprtcGetCodeSize")
+        code = C.create_string_buffer(sz.value)
+        ck(R.hiprtcGetCode(prog, code), "hiprtcGetCode")
+        lowered = []
+        for k in kernels:
+            p = C.c_char_p()
+            ck(R.hiprtcGetLoweredName(prog, k.encode(), C.byref(p)), f"hiprtcGetLoweredName({k})")
+            lowered.append(p.value.decode())
+        return code.raw, lowered
+    finally:
+        R.hiprtcDestroyProgram(C.byref(prog))
+
+
+def _rtc_stamp() -> str:
+    h = hashlib.sha1(_generator_stamp().encode())
+    h.update(" ".join(RTC_FLAGS).encode())
+    return "rtc-" + h.hexdigest()[:12]
+
+
+def _load_unit_rtc(kin: KinModel, tmpl: codegen.CollisionTemplate, ident: str) -> object:
+    """generate + hipRTC-compile (or take from the cache) + register the code object with libtrk.so"""
+    import json
+    JIT_DIR.mkdir(parents=True, exist_ok=True)
+    co, js = JIT_DIR / f"spec_{ident}.hsaco", JIT_DIR / f"spec_{ident}.rtc.json"
+    meta: dict = {}
+    source = codegen.generate_link_kernel_source(kin, tmpl, ident, meta=meta)
+    if not meta:
+        raise _lib.TrkError("the hipRTC fall-back serves link units only")
+    want = _rtc_stamp()
+    code = lowered = None
+    if co.exists() and js.exists():
+        try:
+            rec = json.loads(js.read_text())
+            if rec.get("stamp") == want and rec.get("kernels") == meta["kernels"]:
+                code, lowered = co.read_bytes(), rec["lowered"]
+        except (OSError, ValueError):
+            pass
+    if code is None:
+        code, lowered = _rtc_compile(source, ident, meta["kernels"])
+        tag = f".tmp{os.getpid()}"
+        (JIT_DIR / f"spec_{ident}{tag}.hsaco").write_bytes(code)
+        os.replace(JIT_DIR / f"spec_{ident}{tag}.hsaco", co)
+        (JIT_DIR / f"spec_{ident}{tag}.json").write_text(json.dumps({"stamp": want, "kernels": meta["kernels"], "lowered": lowered}))
+        os.replace(JIT_DIR / f"spec_{ident}{tag}.json", js)
+    L = _lib.lib()
+    from . import _abi
+    stamp = (C.c_int64 * 3)()
+    L.trk_spec_layout_stamp(stamp)
+    d = _abi.ModuleUnitDesc()
+    d.spec_abi_version, d.sizeof_args, d.sizeof_cost_hdr = int(stamp[0]), int(stamp[1]), int(stamp[2])
+    d.ident = ident.encode()
+    d.model_hash = codegen.model_hash(kin)
+    d.n_links, d.n_dofs = kin.n_links, kin.n_dofs
+    obj = np.ascontiguousarray(tmpl.obj_links, np.int32)
+    pairs = np.ascontiguousarray(tmpl.self_pairs, np.int32).reshape(-1)
+    vsrc = np.ascontiguousarray([r[:2] for r in tmpl.virtual], np.int32).reshape(-1)
+    vw = np.ascontiguousarray([r[2:] for r in tmpl.virtual], np.float32).reshape(-1)
+    i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    d.n_obj_links, d.obj_link_idx = len(obj), obj.ctypes.data_as(i32p)
+    d.n_self_pairs, d.self_pairs = len(pairs) // 2, pairs.ctypes.data_as(i32p)
+    d.ee_link, d.ee2_link = int(tmpl.ee_link), int(tmpl.ee2_link)
+    d.n_virtual, d.virtual_src, d.virtual_w = len(tmpl.virtual), vsrc.ctypes.data_as(i32p), vw.ctypes.data_as(f32p)
+    for k in ("chunked", "fast_switch", "fkhbwd_ok", "fields_ok", "ik_ok", "ikgn_ok", "jac_ok", "jac_direct", "gp_ok"):
+        setattr(d, k, int(bool(meta[k])))
+    buf = C.create_string_buffer(code, len(code))
+    d.code, d.code_size = C.cast(buf, C.c_void_p), len(code)
+    names = (C.c_char_p * len(meta["kernels"]))(*[k.encode() for k in meta["kernels"]])
+    lows = (C.c_char_p * len(lowered))(*[k.encode() for k in lowered])
+    d.n_kernels, d.name_exprs, d.lowered_names = len(lowered), names, lows
+    before = L.trk_spec_count()
+    _lib.check(L.trk_spec_register_module(C.byref(d)), "trk_spec_register_module")
+    if L.trk_spec_count() != before + 1:
+        raise _lib.TrkError(f"spec_{ident}: libtrk.so refused the code-object unit")
+    _rtc_keep.append((buf, names, lows, obj, pairs, vsrc, vw, d))
+    return d
+
+
 def unit_ident(kin: KinModel, tmpl: codegen.CollisionTemplate, pipeline: bool = False) -> str:
     return f"jit_{codegen.model_hash(kin):016x}_{template_hash(tmpl)}" + ("_p" if pipeline else "")
 
@@ -133,7 +259,10 @@ def specialize(kin: KinModel, obj_links: Sequence[int], self_pairs: Sequence[Tup
                                      ee2_link=int(ee2_link), virtual=[tuple(r) for r in virtual])
     ident = unit_ident(kin, tmpl, pipeline)
     if ident not in _loaded:
-        _loaded[ident] = _load_unit(build_unit(kin, tmpl, verbose, pipeline), ident)
+        if hipcc_available() or pipeline:
+            _loaded[ident] = _load_unit(build_unit(kin, tmpl, verbose, pipeline), ident)
+        else:                               # no compiler driver on this box: the in-process fall-back
+            _loaded[ident] = _load_unit_rtc(kin, tmpl, ident)
         _loaded_templates[ident] = (codegen.model_hash(kin), tmpl)
     return ident
 
