@@ -524,7 +524,12 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw(f"template <class IO, bool POS{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}>      // IO: HBM-side type of q / link_pos / gq (float or _Float16)")
         else:
             E.raw(f"template <class IO{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}>      // HBM-side type of q / link_pos / gq: float or _Float16")
-        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
+        if GPT and box_t:
+            # the prior's gradient (D registers) lives across the whole kernel: the box-scene instantiation of a small arm would spill
+            # 26 registers at four wavefronts per SIMD -- it runs at three
+            E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, BOX ? 3 : 4) {kname}(SpecArgs A) {{")
+        else:
+            E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
         if not box_t:
             E.raw("    constexpr bool BOX = !FAST;")
         if chunked:
@@ -532,6 +537,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             lds_lane = "LDS_LANE"
         else:
             lds_lane = max(3 * L, D)
+            if GPT:     # the raw q / qd tiles (fp32 at worst) and the factor tile of the prior phase must fit the staging tile
+                pad = -(-D // 4) * 4
+                need = 2 * (-(-((pad + 65 * D) * 4) // 16) * 16) + (65 * (2 * D + 1) + 2) * 4
+                lds_lane = max(lds_lane, -(-need // 256))
         E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_lane} + SPEC_WAVES * (TRK_LDS_SPHERES * 4 + (BOX ? TRK_LDS_PRIMS * 8 : 0))];")
         E.raw("    typedef typename IoTraits<IO>::Q IOQ;      // q, link_pos in HBM")
         E.raw("    typedef typename IoTraits<IO>::G IOG;      // gq in HBM (fp16 q: scaled by A.grad_scale, fp16 stores saturate)")
@@ -553,7 +562,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw("    spec_load_q<D>(static_cast<const IOQ*>(A.q), base, rows, lane, lds, q);")
         else:
             E.raw("    typedef RawRowsInFlight<D, IOQ> Raw;")
-            E.raw(f"    static_assert(2 * Raw::BYTES <= TRK_WAVE * {lds_lane} * 4 && TRK_WAVE * D * 4 <= TRK_WAVE * {lds_lane} * 4, \"the raw q / qd tiles share the staging tile\");")
+            E.raw("    constexpr int RS = 2 * D + 1;         // floats per row of the factor tile (odd: conflict-free)")
+            E.raw(f"    static_assert(2 * Raw::BYTES + ((TRK_WAVE + 1) * RS + 2) * 4 <= TRK_WAVE * {lds_lane} * 4 && TRK_WAVE * D * 4 <= TRK_WAVE * {lds_lane} * 4, \"the raw q / qd tiles and the factor tile share the staging tile\");")
             E.raw("    const unsigned Hh = (unsigned)A.gp_H;")
             E.raw("    const unsigned t0 = (unsigned)(base % (int64_t)A.gp_H);")
             E.raw("    const unsigned tl = (t0 + (unsigned)lane) % Hh, t_last = (t0 + (unsigned)(TRK_WAVE - 1)) % Hh;")
@@ -562,29 +572,47 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw("    const Raw rv = spec_raw_rows_issue<D, IOQ>(static_cast<const IOQ*>(A.qd), base, rows, lane, edge_prev, edge_next);")
             E.raw("    const IOQ* qb = spec_raw_rows_finish<D, IOQ>(rq, static_cast<const IOQ*>(A.q), base, rows, lane, reinterpret_cast<IOQ*>(lds));")
             E.raw("    const IOQ* vb = spec_raw_rows_finish<D, IOQ>(rv, static_cast<const IOQ*>(A.qd), base, rows, lane, reinterpret_cast<IOQ*>(reinterpret_cast<unsigned char*>(lds) + Raw::BYTES));")
+            E.raw("    float* rt = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + 2 * Raw::BYTES);     // [65][RS]: row l + 1 = lane l's factor")
             E.raw("    spec_wave_sync();")
             E.raw("    float gpv[D], cost_gp;")
             E.raw("    {")
-            E.raw("        // ---- the prior: e_t = (p_t + dt v_t - p_t+1, v_t - v_t+1), r = Q^-1 e; this sample takes part in factors t-1 and t")
-            E.raw("        const bool on = lane < rows;")
-            E.raw("        const float mn = (on && tl + 1u < Hh) ? 1.0f : 0.0f, mp = (on && tl > 0u) ? 1.0f : 0.0f;")
+            E.raw("        // ---- the prior.  A lane computes ONLY the factor it starts: e_t = (p_t + dt v_t - p_t+1, v_t - v_t+1), r_t = w Q^-1 e_t (zero")
+            E.raw("        // when the trajectory ends here); the factor that ends at this sample is the previous lane's, fetched through LDS (the one in")
+            E.raw("        // front of the block: lanes 0 .. D-1, one joint each).  d/dq_t = r_t.p - r_t-1.p,  d/dqd_t = dt r_t.p + r_t.v - r_t-1.v.")
+            E.raw("        const float wm = (lane < rows && tl + 1u < Hh) ? A.gp_w : 0.0f;")
             E.raw("        const float dt = A.gp_dt, ga = A.gp_a, gb = A.gp_b, gc = A.gp_c;")
             E.raw("        float gvv[D], accg = 0.0f;")
             E.raw("#pragma unroll")
             E.raw("        for (int d = 0; d < D; ++d) {")
             E.raw("            const float p0 = (float)qb[lane * D + d], v0 = (float)vb[lane * D + d];")
-            E.raw("            const float pm = (float)qb[(lane - 1) * D + d], vm = (float)vb[(lane - 1) * D + d];")
             E.raw("            const float pn = (float)qb[(lane + 1) * D + d], vn = (float)vb[(lane + 1) * D + d];")
             E.raw("            const float ep = fmaf(dt, v0, p0) - pn, ev = v0 - vn;")
-            E.raw("            const float rp = fmaf(ga, ep, gb * ev), rv_ = fmaf(gb, ep, gc * ev);")
-            E.raw("            accg = fmaf(0.5f * mn, fmaf(ep, rp, ev * rv_), accg);")
-            E.raw("            const float em = fmaf(dt, vm, pm) - p0, fm = vm - v0;")
-            E.raw("            gpv[d] = A.gp_w * (mn * rp - mp * fmaf(ga, em, gb * fm));")
-            E.raw("            gvv[d] = A.gp_w * (mn * fmaf(dt, rp, rv_) - mp * fmaf(gb, em, gc * fm));")
+            E.raw("            const float rp = wm * fmaf(ga, ep, gb * ev), rv_ = wm * fmaf(gb, ep, gc * ev);")
+            E.raw("            accg = fmaf(0.5f, fmaf(ep, rp, ev * rv_), accg);")
+            E.raw("            rt[(lane + 1) * RS + 2 * d] = rp; rt[(lane + 1) * RS + 2 * d + 1] = rv_;")
             E.raw("            q[d] = p0;")
+            E.raw("            if (d % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four joints in flight: the max-ILP scheduler would hoist all 4 D tile reads (and spill)")
             E.raw("        }")
-            E.raw("        cost_gp = A.gp_w * accg;")
-            E.raw("        // d cost / d qd is final: out through the staging tile (its first line waits for every lane's reads of the raw rows)")
+            E.raw("        {       // the factor between the sample in front of the block and its first sample: lanes 0 .. D-1, joint `lane`.  Branch-free")
+            E.raw("                // (the other lanes compute joint 0 again and write a scratch slot behind the tile): as a divergent branch this")
+            E.raw("                // block cost the whole kernel 38 registers (217 -> 255, spills in the box-scene instantiation)")
+            E.raw("            const int dj = lane < D ? lane : 0;")
+            E.raw("            const float pm = (float)qb[dj - D], vm = (float)vb[dj - D], pf = (float)qb[dj], vf = (float)vb[dj];")
+            E.raw("            const float wp = edge_prev ? A.gp_w : 0.0f;")
+            E.raw("            const float ep = fmaf(dt, vm, pm) - pf, ev = vm - vf;")
+            E.raw("            float* slot = rt + (lane < D ? 2 * lane : (TRK_WAVE + 1) * RS);")
+            E.raw("            slot[0] = wp * fmaf(ga, ep, gb * ev); slot[1] = wp * fmaf(gb, ep, gc * ev);")
+            E.raw("        }")
+            E.raw("        spec_wave_sync();")
+            E.raw("#pragma unroll")
+            E.raw("        for (int d = 0; d < D; ++d) {")
+            E.raw("            const float rp = rt[(lane + 1) * RS + 2 * d], rv_ = rt[(lane + 1) * RS + 2 * d + 1];      // re-read: 2 D registers less across the sync")
+            E.raw("            gpv[d] = rp - rt[lane * RS + 2 * d];")
+            E.raw("            gvv[d] = fmaf(dt, rp, rv_) - rt[lane * RS + 2 * d + 1];")
+            E.raw("            if (d % 4 == 3) __builtin_amdgcn_sched_barrier(0);")
+            E.raw("        }")
+            E.raw("        cost_gp = accg;")
+            E.raw("        // d cost / d qd is final: out through the staging tile (its first line waits for every lane's reads of the tiles)")
             E.raw("        spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base, rows, lane, lds, gvv, A.grad_scale);")
             E.raw("        spec_wave_sync();")
             E.raw("    }")
