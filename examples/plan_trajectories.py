@@ -4,8 +4,8 @@
 
 B straight-line initial trajectories from a start configuration to B sampled collision-free goals are improved by Adam
 on   w_obj * (self + object + workspace collision hinges)  +  (constant-velocity GP prior on q, qd)
-where every cost / gradient evaluation is ONE `trk_rollout_cost_grad` launch over all (B x H) configurations plus one
-`trk_gp_prior_cost_grad` launch; the result is validated the way the reference does it after planning
+where every cost / gradient evaluation is ONE launch of `trk_rollout_gp_cost_grad` over all (B x H) configurations (the fused rollout
+with the GP prior fused in: `task.rollout_gp_plan`); the result is validated the way the reference does it after planning
 (`get_trajs_collision_and_free`: 5 via points per segment, fused FK + boolean fields).  Needs the MI355X: there is no CPU path.
 
     python examples/plan_trajectories.py [--batch 256] [--horizon 64] [--iters 200]
@@ -38,9 +38,9 @@ def main(batch=256, horizon=64, iters=200, device="cuda:0", verbose=True, seed=0
     q = (q_start + s * (q_goal - q_start)).contiguous()                  # (B, H, D) straight lines in configuration space
     qd = ((q_goal - q_start) / T).expand(batch, horizon, -1).contiguous()
 
-    plan = task.rollout_plan(q, w_self=1.0, w_obj=1.0, w_ws=1.0, want_pos=False)      # pre-bound launch: reads q in place
-    g_gp_q, g_gp_qd = torch.zeros_like(q), torch.zeros_like(qd)
     w_obj, sigma_gp, lr = 50.0, 2.0, 1e-2
+    # pre-bound launch: reads q, qd in place; cost = w_obj * (self + object + workspace hinges) + the prior's factor costs
+    plan = task.rollout_gp_plan(q, qd, dt, sigma_gp, gp_weight=1.0, w_self=w_obj, w_obj=w_obj, w_ws=w_obj)
     free_mask = torch.ones(1, horizon, 1, **ta)
     free_mask[:, 0] = 0.0
     free_mask[:, -1] = 0.0                                               # start and goal stay fixed
@@ -49,13 +49,13 @@ def main(batch=256, horizon=64, iters=200, device="cuda:0", verbose=True, seed=0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(iters):
-        plan.launch()                                                    # plan.cost (B,H), plan.gq (B,H,D)
-        c_gp, gq_gp, gqd_gp = ops.gp_prior_cost_grad(q, qd, dt, sigma_gp)
-        q.grad = free_mask * (w_obj * plan.gq + gq_gp)                   # gradients come from the kernels, not from autograd
-        qd.grad = gqd_gp
-        opt.step()                                                       # in place: the plan keeps reading q's buffer
+        plan.launch()                                                    # plan.cost (B,H), plan.gq, plan.gqd (B,H,D)
+        q.grad = free_mask * plan.gq                                     # gradients come from the kernel, not from autograd
+        qd.grad = plan.gqd
+        opt.step()                                                       # in place: the plan keeps reading q's and qd's buffers
         if verbose and (it % 50 == 0 or it == iters - 1):
-            hist.append((it, float(plan.cost.sum(1).mean()), float(c_gp.mean())))
+            c_gp = ops.gp_prior_cost_grad(q, qd, dt, sigma_gp)[0]
+            hist.append((it, float((plan.cost.sum(1) - c_gp).mean()) / w_obj, float(c_gp.mean())))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     coll0 = task.compute_collision(q_start + s * (q_goal - q_start)).any(1).float().mean().item()

@@ -1134,6 +1134,25 @@ def test_interpolated_points_with_a_grasped_object(oracle_lib):
     assert (coll.cpu().numpy() != ref).sum() <= 1
 
 
+def test_inverse_kinematics_gn_api():
+    """DifferentiableTree.inverse_kinematics_gn (extension: the reference's IK contract on trk_ik_gn_steps): (q, idx_valid) like
+    `inverse_kinematics`, every returned valid configuration reaches the target inside the shrunk limits; a link no ahead-of-time
+    unit tracks gets its unit compiled on first use."""
+    torch.manual_seed(3)
+    tree = tra.DifferentiableFrankaPanda(gripper=False, device=DEV)
+    lo, hi, _, _ = tree.get_joint_limit_array()
+    q_star = torch.as_tensor((lo + hi) / 2 + 0.3 * (hi - lo) * (np.random.default_rng(2).random(7) - 0.5), **TA).reshape(1, 7)
+    for link_name in ("ee_link", "panda_link7"):
+        H = tree.compute_forward_kinematics_all_links(q_star, link_list=[link_name])[0, 0]
+        q, idx = tree.inverse_kinematics_gn(H, link_name=link_name, batch_size=256, max_iters=60, se3_eps=5e-2, check_every=15)
+        assert q.shape == (256, 7) and idx.ndim == 1 and idx.numel() >= 64
+        Hq = tree.compute_forward_kinematics_all_links(q[idx], link_list=[link_name])[:, 0]
+        err = tra.SE3_distance(Hq, H)
+        eps = np.pi / 100
+        assert float(err.max()) < 5e-2 * 1.001
+        assert (q[idx] >= torch.as_tensor(lo + eps, **TA) - 1e-6).all() and (q[idx] <= torch.as_tensor(hi - eps, **TA) + 1e-6).all()
+
+
 def test_gauss_newton_ik_example_converges():
     """examples/gauss_newton_ik.py: the one-launch Gauss-Newton kernel (trk_ik_gn_steps) and the two-launch form (trk_fk_jacobian +
     trk_jtj + torch ops) reach a reachable pose from random starts."""

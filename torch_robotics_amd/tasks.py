@@ -213,6 +213,17 @@ class PlanningTask(Task):
         model, cm = self._fused_handles(q.device)
         return ops.RolloutPlan(model, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos)
 
+    def rollout_gp_plan(self, q, qd, dt, sigma_gp, gp_weight=1.0, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=False,
+                        grad_dtype=None, grad_scale=1.0) -> "ops.RolloutGpPlan":
+        """The planner's whole objective as ONE pre-bound launch (`trk_rollout_gp_cost_grad`): the collision / EE terms of
+        `rollout_plan` plus the constant-velocity GP prior on (q, qd) -- `plan.cost` (B,H) incl. the prior's factor costs, `plan.gq`,
+        `plan.gqd`.  q, qd (B,H,D) fp32 or fp16 are read in place on every launch."""
+        if self._points(q.device) is not None:
+            raise NotImplementedError("rollout_gp_plan is for link-column cost models (no grasped object / link spheres)")
+        model, cm = self._fused_handles(q.device)
+        return ops.RolloutGpPlan(model, cm, (w_self, w_obj, w_ws, w_ee), q, qd, dt, sigma_gp, gp_weight, want_pos=want_pos,
+                                 grad_dtype=grad_dtype, grad_scale=grad_scale)
+
     def capture_cost_backward(self, x, reduce=torch.sum, warmup: int = 3) -> "GraphedCostBackward":
         """`reduce(task.compute_collision_cost(x)).backward()` captured ONCE as a hipGraph (a planner's inner loop calls it with
         the same shapes thousands of times; eagerly the autograd engine's hand-offs cost ~10x the kernels).
