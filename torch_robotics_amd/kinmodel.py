@@ -65,7 +65,7 @@ def fixed_rotation_from_rpy(rpy) -> np.ndarray:
 
 def quat_wxyz_to_rot(q) -> np.ndarray:
     """Reference quaternion.py:102-120 `q_to_rotation_matrix` (fp32)."""
-    q = torch.as_tensor(q, dtype=torch.float32).reshape(4)
+    q = torch.tensor(np.asarray(q, np.float32).reshape(4))      # a copy: the caller's array may be read-only (ObjectField poses)
     w, x, y, z = q.unbind(-1)
     dc = 2.0 / (q ** 2).sum(-1)
     o = torch.stack((1 - dc * (y * y + z * z), dc * (x * y - z * w), dc * (x * z + y * w),
