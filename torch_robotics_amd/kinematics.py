@@ -372,7 +372,7 @@ def _tree(urdf_name: str, name: str):
 def quat_wxyz_to_rpy(q) -> Tuple[float, float, float]:
     """Roll / pitch / yaw of a wxyz quaternion in fp32 (what the reference writes into the grasped object's fixed
     joint: q_to_euler quaternion.py:203-215 via robots.py:25-37)."""
-    w, x, y, z = torch.as_tensor(np.asarray(q, np.float32).reshape(4)).unbind(-1)
+    w, x, y, z = torch.tensor(np.asarray(q, np.float32).reshape(4)).unbind(-1)
     roll = torch.atan2(2.0 * (w * x + y * z), 1.0 - 2.0 * (x * x + y * y))
     pitch = torch.asin(torch.clamp(2.0 * (w * y - z * x), -1.0, 1.0))
     yaw = torch.atan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z))
