@@ -1,6 +1,6 @@
 # same-box A/B of the headline bench lines only (5 alternations, c2 + c3): every directory under _ab/
 R=$GRAFT_REPO_ROOT
-for rep in 1 2 3 4 5; do
+for rep in 1 2 3; do
   for side in $(ls $R/_ab); do
     cd $R/_ab/$side
     echo "== $side (rep $rep)"

@@ -517,6 +517,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # and scene_min_sdf carries only (value, index) through its primitive loop (shelf 23.2 -> 22.0 us, maze 24.6 -> 22.2).  The
         # 128-register kernels get it as a switch of its own, decided at the launch: compiled into the one kernel the sphere scene
         # runs as well, the headline measured 9.17 -> 9.37 us (register allocation again).  Two-wavefront kernels: BOX = !FAST.
+        # The BOX instantiation is the GENERAL scene kernel: launches choose it with scene_is_general (any box object, or a voxel grid),
+        # and only it carries the box and grid text of scene_min_sdf (GENERAL = BOX there).  Behind run-time branches in the
+        # sphere-scene kernel the brick-tiled cell index alone cost the headline 9.2 -> 9.55 us (same-box A/B,
+        # profiles/r04_ab_headline_*.txt).
         box_t = D <= 8
         if chunked:
             # POS: the launch wants the link positions.  A compile-time switch, because the ring staging costs the launches that
@@ -708,7 +712,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw(tick_line())
         E.raw("    spec_stamp(A.stamps, wblock, 3, lane);")
         # ---------------- objectives ----------------
-        emit_collision_objectives(E, t, next_chunk, fast_arg=", decltype(ticks), FAST" if fast_t else "", prims_ptr="lds_prm")
+        emit_collision_objectives(E, t, next_chunk, fast_arg=f", decltype(ticks), {'FAST' if fast_t else 'false'}, BOX", prims_ptr="lds_prm")
         E.raw("    spec_stamp(A.stamps, wblock, 4, lane);")
         for ee, tgt, rb in tracked:
             E.raw(f"    float {rb}[9] = {{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}};")
@@ -949,7 +953,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             adj = sorted(set(sg["obj"]) | {a for _, a, b in sg["pairs"]} | {b for _, a, b in sg["pairs"]} | {l for l, _, _ in sg["tracked"]})
             for i in adj:
                 E.raw(f"    float tb{i}_0 = 0.0f, tb{i}_1 = 0.0f, tb{i}_2 = 0.0f;")
-            fast_arg = ", decltype(ticks), FAST" if fast_t else ""
+            fast_arg = f", decltype(ticks), {'FAST' if fast_t else 'false'}, BOX"
             g_at = 0
             for grp in groups:
                 n = len(grp)
@@ -1646,7 +1650,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     if D > 8:
         switches.append("scene_is_fast(a.C)")
     else:
-        switches.append("a.C.n_box_objects > 0 && a.C.n_prims <= TRK_LDS_PRIMS")     # BOX: (value, index) primitive loop + LDS table
+        switches.append("scene_is_general(a.C)")     # BOX: box objects ((value, index) primitive loop over the LDS table) and / or a voxel grid
     n_sw = len(switches)
     targs = ", ".join(f"decltype(c{k})::value" for k in range(n_sw))
     params = ", ".join(f"auto c{k}" for k in range(n_sw))
@@ -1668,7 +1672,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     if gp_ok or gpt_ok:
         out.append("static int launch_gp(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
-        sw = "scene_is_fast(a.C)" if D > 8 else "a.C.n_box_objects > 0 && a.C.n_prims <= TRK_LDS_PRIMS"
+        sw = "scene_is_fast(a.C)" if D > 8 else "scene_is_general(a.C)"
         if use_seg and gp_cross_pairs:
             out.append("    if (a.w.w_self != 0.0f) return 1;      // self pairs between independently scheduled subtrees: the two-launch form serves them")
         kn = "k_rollout_gp_" if use_seg else "k_rollout_gpt_"

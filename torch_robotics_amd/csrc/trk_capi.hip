@@ -116,7 +116,7 @@ void mod_launch(hipFunction_t f, unsigned grid, unsigned block, size_t lds, cons
 inline const ModuleUnit* unit_of(const SpecEntry* self) { return static_cast<const ModuleUnit*>(self->module_ctx); }
 inline unsigned blocks_of(int64_t n) { return (unsigned)((n + SPEC_BLOCK - 1) / SPEC_BLOCK); }
 inline int scene_switch(const ModuleUnit* u, const SpecArgs& a) {
-    return u->fast_switch ? (scene_is_fast(a.C) ? 1 : 0) : ((a.C.n_box_objects > 0 && a.C.n_prims <= TRK_LDS_PRIMS) ? 1 : 0);
+    return u->fast_switch ? (scene_is_fast(a.C) ? 1 : 0) : (scene_is_general(a.C) ? 1 : 0);
 }
 void mod_rollout(const SpecEntry* self, const SpecArgs& a, int bi, hipStream_t st) {
     const ModuleUnit* u = unit_of(self);

@@ -568,7 +568,14 @@ __host__ __device__ inline bool scene_is_fast(const DevCostHdr& C) {
     return C.n_spheres > 0 && C.n_spheres <= 16 && C.spheres_uniform_r && C.n_box_objects == 0 && !C.has_grid;
 }
 
-template <int NL, class Tick = NoTick, bool FAST = false>
+// The generated rollout kernels have two scene instantiations, chosen at the launch: SPHERES ONLY (GENERAL = false: the text below
+// stops after the sphere table) and the GENERAL one (boxes -- held in LDS when the table fits TRK_LDS_PRIMS -- and / or a voxel
+// grid).  Same-box A/B on the headline (profiles/r04_ab_headline_*.txt): with the brick-tiled grid index compiled in behind a
+// run-time `if (C.has_grid)` the Panda sphere-scene kernel allocated 126 registers + 16 SGPR spills and took 9.55 us per launch;
+// without any box / grid text 118 + 0 and 9.45 us (configuration 3: 10.5 -> 9.95 us).
+__host__ __device__ inline bool scene_is_general(const DevCostHdr& C) { return C.n_box_objects > 0 || C.has_grid; }
+
+template <int NL, class Tick = NoTick, bool FAST = false, bool GENERAL = true>
 __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (&px)[NL], const float (&py)[NL],
                                               const float (&pz)[NL], float (&s)[NL], float (&gx)[NL], float (&gy)[NL],
                                               float (&gz)[NL], Tick&& tick = Tick(), const float4* lds_spheres = nullptr,
@@ -582,7 +589,7 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
     // behind position stores waits until HBM has taken them (measured: 37 us per launch for the 200^3 grid against 11 us for the
     // analytic spheres).  So the tick slots of a grid scene fire AFTER its gathers have returned; box-only scenes read their
     // tables through the scalar cache (lgkmcnt) and keep the stores in flight under their arithmetic.
-    const bool ticks_last = !FAST && C.has_grid;
+    const bool ticks_last = !FAST && GENERAL && C.has_grid;
     if (!paired && !ticks_last) {
         scene_all_ticks<0>(tick);
     }
@@ -687,7 +694,7 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
             }
         }
     }
-    if (FAST) return;
+    if (FAST || !GENERAL) return;
     // objects that still have non-sphere primitives (boxes): empty loop for sphere-only scenes.
     // Per object and point, the primitive loop computes VALUES only and carries the winner's offset d and u = |d| - half + r along
     // (six selects instead of a gradient per primitive); the gradient is formed once, for the winner (primitives.py:327-334:

@@ -986,13 +986,13 @@ __device__ __forceinline__ float spec_wave_sum(float v) { return trk_wave_sum(v)
 // collision objectives on NL link points held in registers.  Adds w * cost to `cost` and
 // w * d cost / d p to (gx, gy, gz) (accumulating).  Margins are C.obj_link_margin[0..NL) in baked order.
 // ---------------------------------------------------------------------------------------------------------
-template <int NL, class Tick, bool FAST = false>
+template <int NL, class Tick, bool FAST = false, bool GENERAL = true>
 __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w, const float (&px)[NL],
                                                    const float (&py)[NL], const float (&pz)[NL], float (&gx)[NL],
                                                    float (&gy)[NL], float (&gz)[NL], const Tick& tick, const float4* lds_spheres,
                                                    int mbase = 0, const float4* lds_prims = nullptr) {
     float s[NL], ax[NL], ay[NL], az[NL];
-    scene_min_sdf<NL, const Tick&, FAST>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres, lds_prims);
+    scene_min_sdf<NL, const Tick&, FAST, GENERAL>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres, lds_prims);
     float cost = 0.0f;
     if (C.clamp_fields & TRK_FIELD_OBJECTS) {                                  // wave-uniform: the hinge form (clamp_sdf=True)
 #pragma unroll
