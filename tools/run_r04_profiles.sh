@@ -6,7 +6,7 @@
 set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd $R
 B="timeout 400 python bench.py"
 $B --steps 2000 --warmup 200 > $O/bench_c2.json 2> $O/bench.err
@@ -23,6 +23,8 @@ timeout 600 python bench.py --gpus 2 --dist-backend gloo --single-device --steps
 timeout 600 python bench.py --gpus 2 --dist-backend gloo --single-device --config c5 --steps 1000 --warmup 100 > $O/bench_c5_2rank_gloo_one_gpu.json 2>> $O/bench.err
 timeout 600 python bench.py --force-dist --steps 20 --warmup 5 --cpu-seconds 0 > $O/bench_rccl_one_rank_driver_settings.json 2>> $O/bench.err
 timeout 600 python bench.py --force-dist --steps 2000 --warmup 200 --cpu-seconds 0 > $O/bench_rccl_one_rank.json 2>> $O/bench.err
+timeout 600 python bench.py --force-dist --config c5 --steps 20 --warmup 5 --cpu-seconds 0 > $O/bench_c5_rccl_one_rank_driver_settings.json 2>> $O/bench.err
+for s in shelf maze; do $B --steps 1000 --warmup 100 --scene $s --q smooth --cpu-seconds 0 --no-out-of-cache > $O/bench_c2_${s}_smooth.json 2>> $O/bench.err; done
 for b in 2048 8192 16384 32768 49152; do timeout 300 python bench.py --steps 300 --warmup 30 --batch $b --cpu-seconds 0 --no-out-of-cache >> $O/bench_batches.jsonl 2>> $O/bench.err; done
 cd /tmp; export TMPDIR=/tmp
 P="timeout 400 rocprofv3 --kernel-trace --stats --output-format csv"
@@ -33,7 +35,7 @@ $P -d $O/prof_c5 -o r04 -- python3 $R/bench.py --steps 1000 --warmup 100 --cpu-s
 for s in grid shelf maze; do
   $P -d $O/prof_$s -o r04 -- python3 $R/bench.py --steps 1000 --warmup 100 --cpu-seconds 0 --scene $s --no-out-of-cache > /dev/null 2>> $O/prof.err
 done
-$P -d $O/prof_grid_smooth -o r04 -- python3 $R/bench.py --steps 1000 --warmup 100 --cpu-seconds 0 --scene grid --q smooth > /dev/null 2>> $O/prof.err
+$P -d $O/prof_grid_smooth -o r04 -- python3 $R/bench.py --steps 1000 --warmup 100 --cpu-seconds 0 --scene grid --q smooth --no-out-of-cache > /dev/null 2>> $O/prof.err
 cat > /tmp/calib.py <<'PY'
 import torch
 x = torch.rand(50331648 // 4, device="cuda"); y = torch.empty_like(x)
@@ -46,7 +48,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE
   for s in spheres grid shelf maze; do
     $Q -d $O/pmc/${s}_$n -o p -- python3 $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --scene $s --no-out-of-cache > /dev/null 2>> $O/pmc.err
   done
-  $Q -d $O/pmc/gridsmooth_$n -o p -- python3 $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --scene grid --q smooth > /dev/null 2>> $O/pmc.err
+  $Q -d $O/pmc/gridsmooth_$n -o p -- python3 $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --scene grid --q smooth --no-out-of-cache > /dev/null 2>> $O/pmc.err
   for cfg in c3 c4 c5; do
     $Q -d $O/pmc/${cfg}_$n -o p -- python3 $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 --config $cfg > /dev/null 2>> $O/pmc.err
   done
