@@ -273,3 +273,21 @@ def test_gp_grad_scale_bounds_the_fp16_gradient():
     assert worst * gs <= 32768.0 and worst * gs * 4 > 32768.0 * 0.2          # safe, and not needlessly small
     assert ops.gp_grad_scale(0.1, 10.0, 1.0, 1.0, 1.0) == 1.0               # a weak prior needs no scale
     assert ops.gp_grad_scale(dt, sigma, 1.0, 2.0, 1.0, extra=1e9) < gs       # the other terms' gradient counts too
+
+
+def test_primitive_geometry_is_read_only_and_part_of_the_scene_key():
+    """ADVICE r3: an in-place edit of a pose or of a primitive's geometry must not leave a stale device model behind -- it raises;
+    a re-assigned array changes the key every CostHandle cache uses (environments.scene_version)."""
+    from torch_robotics_amd.environments import scene_version
+    f = tra.MultiSphereField(np.zeros((2, 3), np.float32), np.full(2, 0.1, np.float32))
+    b = tra.MultiBoxField(np.zeros((1, 3), np.float32), np.full((1, 3), 0.2, np.float32))
+    o = tra.ObjectField([f, b], "o")
+    for arr in (f.centers, f.radii, b.centers, b.sizes, b.half_sizes, b.radius, o.pos, o.ori):
+        with pytest.raises(ValueError):
+            arr[0] = 1.0
+    k0 = scene_version([o])
+    f.centers = f.centers + 0.5
+    k1 = scene_version([o])
+    assert k1 != k0 and not f.centers.flags.writeable
+    o.pos = (0.1, 0.0, 0.0)
+    assert scene_version([o]) != k1

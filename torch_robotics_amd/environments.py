@@ -36,9 +36,11 @@ def scene_version(df_obj_list) -> tuple:
     of a grid's tensors.  The reference evaluates each object from its current pose on every call (primitives.py:387-405), so
     every cache of a `CostHandle` is keyed by this and a moved object rebuilds it.  Integers only -- this runs on every cost
     evaluation: an ObjectField takes a fresh version number whenever `pos` / `ori` are assigned (`set_position_orientation`
-    or the attributes).  The pose arrays are read-only (`obj.pos[0] = ...` raises: assign a new array or call
-    `set_position_orientation`); in-place edits of a primitive's centres or radii are NOT seen."""
-    return tuple((id(o), id(o.sdf_tensor)) if isinstance(o, GridMapSDF) else (id(o), o._version) for o in df_obj_list)
+    or the attributes).  The pose arrays and the primitives' centre / radius / size arrays are read-only (`obj.pos[0] = ...`,
+    `field.centers[0] = ...` raise: assign a new array or call `set_position_orientation`), and the key carries the version number
+    of every primitive field's latest geometry assignment, so a re-assigned `field.centers` rebuilds the device model as well."""
+    return tuple((id(o), id(o.sdf_tensor)) if isinstance(o, GridMapSDF)
+                 else (id(o), o._version) + tuple(k for f in o.fields for k in f.array_ids()) for o in df_obj_list)
 
 
 class PrimitiveShapeField:
@@ -49,11 +51,27 @@ class PrimitiveShapeField:
     def prims(self) -> List[dict]:
         raise NotImplementedError
 
+    _ARRAYS = ()
+
+    def __setattr__(self, name, value):
+        # the geometry arrays are read-only copies: an in-place edit raises instead of leaving a stale device model behind
+        if name in self._ARRAYS:
+            value = np.array(value, dtype=np.float32)
+            value.setflags(write=False)
+            object.__setattr__(self, "_geometry_version", next(_version_counter))
+        object.__setattr__(self, name, value)
+
+    def array_ids(self) -> tuple:
+        """what scene_version adds for this field: the number its latest geometry assignment took"""
+        return (getattr(self, "_geometry_version", 0),)
+
     def compute_signed_distance(self, x):
         return ObjectField([self]).compute_signed_distance(x)
 
 
 class MultiSphereField(PrimitiveShapeField):                 # primitives.py:88-121
+    _ARRAYS = ("centers", "radii")
+
     def __init__(self, centers, radii, tensor_args=None):
         centers = _np(centers).astype(np.float32)
         super().__init__(dim=centers.shape[-1], tensor_args=tensor_args)
@@ -66,6 +84,7 @@ class MultiSphereField(PrimitiveShapeField):                 # primitives.py:88-
 
 class MultiSharpBoxField(PrimitiveShapeField):               # primitives.py:197-228
     rounded = False
+    _ARRAYS = ("centers", "sizes", "half_sizes", "radius")
 
     def __init__(self, centers, sizes, tensor_args=None):
         centers = _np(centers).astype(np.float32)
