@@ -33,6 +33,11 @@ collectives complete); the maximum over the ranks is taken -- the time from the 
 For N > 1 the closing barrier FOLLOWS the clock stop (it is outside the clock: an 8-rank all-reduce is not a step; at N = 1 there
 is none either).  The whole measurement is rehearsed once and discarded first.
 
+Launch mode: the step loop is captured -- every run of consecutive steps between two exchanges is replayed as hipGraphs of at most
+`--graph` (default 100) evaluations, each graph captured once per (plan, length) from the same pre-bound C-ABI calls and launched
+once before any timed region.  W and K are exact (a remainder gets a graph of its own).  `--graph 0` = the eager loop, one call per step
+(the default for c4, whose two-kernel step measured slower captured).
+
 Prints ONE JSON line (rank 0).  `roofline` describes the step's dominant kernel (the fused rollout): `achieved` = its algorithmic
 bytes/sample x samples per launch / its average launch duration (HIP events on the launch stream: around the timed region when
 the step is that one launch, around a loop of that kernel alone otherwise); `roofline.step` prices the whole step.
@@ -76,7 +81,9 @@ def parse_args(argv):
     ap.add_argument("--horizon", type=int, default=None, help="time steps per trajectory (default: 64; c5: 128)")
     ap.add_argument("--reduce-every", type=int, default=64,
                     help="the planner's exchange cadence; a short run uses min(this, steps) so that its timed region contains a collective")
-    ap.add_argument("--graph", type=int, default=0, help="capture this many steps per hipGraph replay (0 = eager launches)")
+    ap.add_argument("--graph", type=int, default=None,
+                    help="launch mode: the steps are captured into hipGraphs of at most this many evaluations and replayed; 0 = eager "
+                         "launches, one pre-bound C-ABI call per step.  Default: 100 for one-launch steps, eager for c4's two-kernel step")
     ap.add_argument("--weights", default=None, help="experiment: w_self,w_obj,w_ws,w_ee override (reported in config)")
     ap.add_argument("--no-pos", action="store_true", help="experiment: do not write link positions")
     ap.add_argument("--q", default="iid", choices=["iid", "smooth"],
@@ -430,20 +437,64 @@ def main():
     def step_of(pl):
         return wl.step if pl is plan else pl.launch
 
-    graph = None
-    if args.graph > 0:
-        # launch-bound inner loop -> hipGraph: G consecutive evaluations per replay (each into its own sum slot
-        # of a G-wide window; the window is copied out by the caller when it needs the values)
-        G = args.graph
-        gstream = torch.cuda.Stream(dev)
-        with torch.cuda.stream(gstream):
-            for i in range(3):
-                wl.step(bs_ptr, gstream.cuda_stream)
-        gstream.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=gstream):
-            for i in range(G):
-                wl.step(bs_ptr, torch.cuda.current_stream(dev).cuda_stream)
+    # Launch mode.  The inner loop is launch-bound bookkeeping around a 9 us kernel, so by default it is captured: every run of
+    # consecutive evaluations between two exchanges becomes hipGraph replays of at most `--graph` evaluations each (the same pre-bound
+    # C-ABI calls, captured once per (plan, length) and replayed).  Same-box, 4096 x 64 Panda: 2000 steps 9.39 - 9.43 us eager, 9.08 us as
+    # 100-evaluation graphs; the driver's 20 steps 10.9 - 11.7 us eager, 10.5 us as one graph; c5 21.6 -> 21.0 us; c3 unchanged.  c4's step
+    # alternates two different kernels and measured SLOWER captured (60.6 -> 63.7 us): it stays eager unless asked (profiles/
+    # r04_graph_vs_eager.txt).  `--graph 0` keeps the eager loop everywhere.
+    # The gloo debug mode (ranks sharing one GPU, exchanges through host copies) also stays eager: a graph launch between synchronous
+    # copies from two processes costs milliseconds there (every_step 0.37 -> 6.2 ms).
+    S = max(0, args.graph) if args.graph is not None else (0 if (wl.extras or (distributed and args.dist_backend == "gloo")) else 100)
+    graphs = {}
+    S_live = [S]                 # becomes 0 if a capture fails
+    gstream = torch.cuda.Stream(dev) if S else None
+
+    def graph_for(pl, n):
+        """the graph of n consecutive steps of plan pl (captured once, launched once), or None when capture is off / failed"""
+        if not S_live[0]:
+            return None
+        g = graphs.get((id(pl), n))
+        if g is None:
+            fn = step_of(pl)
+            try:
+                with torch.cuda.stream(gstream):
+                    for i in range(3):                          # nothing lazy may happen inside the capture
+                        fn(bs_ptr, gstream.cuda_stream)
+                gstream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                # thread-local capture mode: the process group's watchdog thread may query events while this thread captures
+                with torch.cuda.graph(g, stream=gstream, capture_error_mode="thread_local"):
+                    for i in range(n):
+                        fn(bs_ptr, torch.cuda.current_stream(dev).cuda_stream)
+                g.replay()                                      # the first launch of an instantiated graph uploads it
+                torch.cuda.synchronize(dev)
+            except Exception as e:                              # a box whose runtime refuses the capture still measures: eager loop
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+                S_live[0] = 0
+                torch.cuda.synchronize(dev)
+                return None
+            graphs[(id(pl), n)] = g
+        return g
+
+    def pieces(count, cadence):
+        """the exchange schedule of `count` steps: [(steps, exchange afterwards?)] -- one exchange per `cadence` steps, fired in the
+        middle of its interval"""
+        if not cadence:
+            return [(count, False)] if count else []
+        out_, last = [], 0
+        for j in range(1, count + 1):
+            if j % cadence == cadence // 2:
+                out_.append((j - last, True)); last = j
+        if last < count:
+            out_.append((count - last, False))
+        return out_
+
+    def prepare(pl, count, cadence):
+        """capture (and launch once) every graph run(pl, count, cadence) will replay -- outside any timed region"""
+        for n, _ in pieces(count, cadence):
+            while n > 0 and S_live[0]:
+                graph_for(pl, min(n, S)); n -= min(n, S)
 
     slot = [0]
 
@@ -452,22 +503,20 @@ def main():
         several launches ahead of the GPU (handing a collective to torch.distributed costs the launch thread ~60 us) and half an
         interval is left for the collective to complete.  (In a 20-step region one exchange still costs ~50 us whatever its position:
         the GPU time of the pack kernel + the collective, which the launches behind it wait for -- DESIGN.md 6d.)"""
-        if graph is not None:
-            assert count % args.graph == 0
-            for _ in range(count // args.graph):
-                graph.replay()
-            return
         s = stream.cuda_stream
         fn = step_of(pl)
-        for j in range(1, count + 1):
-            fn(bs_ptr, s)
-            if cadence and j % cadence == cadence // 2:
+        for n, exchange in pieces(count, cadence):
+            while n > 0 and S_live[0]:
+                g = graph_for(pl, min(n, S))
+                if g is None:
+                    break
+                g.replay(); n -= min(n, S)
+            for _ in range(n):                                  # eager mode, or what a failed capture left
+                fn(bs_ptr, s)
+            if exchange:
                 reduce_slot(pl, slot[0] % n_slots)
                 slot[0] += 1
 
-    if graph is not None:
-        args.steps = max(args.graph, args.steps // args.graph * args.graph)
-        args.warmup = max(args.graph, args.warmup // args.graph * args.graph)
     flag = torch.zeros(1, **ta)
 
     def barrier_in_stream():
@@ -486,6 +535,7 @@ def main():
         the wall time already as the maximum over the ranks."""
         steps = args.steps if steps is None else steps
         warmup = args.warmup if warmup is None else warmup
+        prepare(pl, warmup, cadence); prepare(pl, steps, cadence)
         run(pl, warmup, cadence)
         if distributed:
             barrier_in_stream()
@@ -517,7 +567,7 @@ def main():
         if os.environ.get("TRK_BENCH_TRACE"):
             print(f"[trace] submit {1e6 * (ta_ - t0):.1f} us, wait {1e6 * (tb_ - ta_):.1f} us, closing bracket "
                   f"{1e6 * (time.perf_counter() - tb_):.1f} us, events {1e3 * ev0.elapsed_time(ev1):.1f} us", file=sys.stderr)
-        ev_ms = ev0.elapsed_time(ev1) if graph is None else wall * 1e3
+        ev_ms = ev0.elapsed_time(ev1)
         if distributed:
             tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -536,7 +586,7 @@ def main():
     bps = wl.bps
     bytes_per_launch = bps * B * H
     step_s = ev_ms * 1e-3 / args.steps
-    if wl.extras and graph is None:
+    if wl.extras:
         # the step has more launches than the dominant kernel: time that kernel alone, same stream, same brackets
         def only_rollout(n):
             for _ in range(n):
@@ -579,7 +629,7 @@ def main():
         "config": {"workload": wl.text,
                    "global_batch": B * world, "horizon": H, "parallelism": f"batch-sharded x{world}",
                    "scene": args.scene, "objectives": args.config,
-                   "launch": "hipGraph x%d" % args.graph if graph is not None else "eager, pre-bound C-ABI call",
+                   "launch": ("hipGraph replays of <= %d captured evaluations (pre-bound C-ABI calls)" % S) if S_live[0] else "eager, pre-bound C-ABI call",
                    "launches_per_step": 1 + len(wl.extras),
                    "kernel": kind,
                    "reduce_every": args.reduce_every if distributed else None,
@@ -607,7 +657,7 @@ def main():
                                    "achieved": wl.bps_step * B * H / step_s / 1e9, "frac": wl.bps_step * B * H / step_s / 1e9 / HBM_PEAK_GBS,
                                    "launches": ["fused rollout"] + [lbl for lbl, _, _ in wl.extras]}
 
-    if (rank == 0 and not distributed and graph is None and args.config == "c2" and not args.no_out_of_cache and wl.random_q is not None
+    if (rank == 0 and not distributed and args.config == "c2" and not args.no_out_of_cache and wl.random_q is not None
             and bytes_per_launch < 256e6):
         # Secondary figure: the same kernel on a batch whose working set exceeds the 256 MB Infinity Cache (8 x the trajectories:
         # 403 MB per launch at the default size), i.e. what the DRAM itself sustains for this read / write mix.
@@ -681,7 +731,7 @@ def main():
         }
         assert err < 1e-5, f"all-reduced sums differ from the sum of the ranks' sums: {err}"
 
-    if rank == 0 and not distributed and graph is None and args.independent_streams > 1 and wl.random_q is not None:
+    if rank == 0 and not distributed and args.independent_streams > 1 and wl.random_q is not None:
         # Secondary figure (never `value`): INDEPENDENT batches alternated over three HIP streams.  With one stream a launch waits
         # for the previous one's ~2 us write tail; with three, the next launch's dispatch, kernarg / q fetch and FK overlap it.
         # A planner's iterations depend on each other, so the headline keeps one stream; a server evaluating unrelated batches

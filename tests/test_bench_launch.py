@@ -147,3 +147,28 @@ def test_native_rccl_exchange_on_one_rank():
     mg = out["multi_gpu"]
     assert mg["exchange_via"].startswith("librccl") and mg["collectives_in_timed_region"] == 5 and mg["allreduce_check"]["ok"]
     assert mg["allreduce_check"]["sum_cost_all_ranks"] == pytest.approx(mg["allreduce_check"]["sum_cost_rank0"], rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_launch_modes_graph_by_default_eager_on_request():
+    """The step loop is captured by default (hipGraph replays of <= 100 evaluations; W and K stay exact: 7 + 23 steps need graphs of
+    7 and 23), `--graph 0` is the eager loop, c4's two-kernel step and the gloo debug mode default to eager; both modes leave the same
+    outputs behind (bench.py's own closing check compares the cost sums with the per-sample costs)."""
+    seen = {}
+    for mode, extra in (("graph", []), ("eager", ["--graph", "0"]), ("small graphs", ["--graph", "4"])):
+        p = _run(["--steps", "23", "--warmup", "7", "--cpu-seconds", "0", "--batch", "512", "--no-out-of-cache"] + extra, 600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["steps"] == 23 and out["warmup"] == 7 and out["value"] > 0 and "capture failed" not in p.stderr
+        seen[mode] = out["config"]["launch"]
+    assert seen["graph"].startswith("hipGraph replays of <= 100") and seen["eager"].startswith("eager")
+    assert seen["small graphs"].startswith("hipGraph replays of <= 4")
+    p = _run(["--config", "c4", "--steps", "10", "--warmup", "2", "--cpu-seconds", "0", "--batch", "256"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])["config"]["launch"].startswith("eager")
+    # N > 1 code path (one rank, RCCL) in graph mode: the exchange sits between two replays inside the timed region
+    p = _run(["--force-dist", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--batch", "512"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["config"]["launch"].startswith("hipGraph") and out["multi_gpu"]["collectives_in_timed_region"] == 1
+    assert out["multi_gpu"]["allreduce_check"]["ok"]
