@@ -1032,6 +1032,47 @@ def test_fused_via_point_collision_equals_two_step():
     model.enable_specialized(True)
 
 
+def test_empty_and_degenerate_inputs_of_the_round4_ops():
+    """Zero-sized batches and the smallest legal shapes of the entry points added in round 4: the fused rollout + GP prior, the fp16
+    rollout with a gradient scale, the GP prior alone, the Gauss-Newton IK and the packed sums."""
+    from torch_robotics_amd import ops
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    model, cm = task._fused_handles(DEV)
+    w = (0.0, 1.0, 0.0, 1.0)
+    for dt_ in (torch.float32, torch.float16):
+        e = torch.zeros(0, 16, 7, device=DEV, dtype=dt_)
+        pos, cost, gq, gqd = ops.rollout_gp_cost_grad(model, cm, w, e, e.clone(), 0.1, 0.3, 1.0, grad_scale=0.5 if dt_ == torch.float16 else 1.0)
+        assert pos.shape == (0, 16, 11, 3) and cost.shape == (0, 16) and gq.shape == (0, 16, 7) and gqd.shape == (0, 16, 7)
+        pos, cost, gq = ops.rollout_cost_grad(model, cm, w, e, grad_scale=0.25 if dt_ == torch.float16 else 1.0)
+        assert pos.shape == (0, 16, 11, 3) and cost.shape == (0, 16) and gq.dtype == dt_
+        c, g, gd = ops.gp_prior_cost_grad(e, e.clone(), 0.1, 0.3)
+        assert c.shape == (0,) and g.shape == e.shape and gd.shape == e.shape
+    # one trajectory of one time step: no GP factor at all -> the fused call equals the plain rollout, gqd is zero
+    q1 = robot.random_q(1).reshape(1, 1, 7).contiguous()
+    pos, cost, gq, gqd = ops.rollout_gp_cost_grad(model, cm, w, q1, torch.ones_like(q1), 0.1, 0.3, 1.0)
+    pos0, cost0, gq0 = ops.rollout_cost_grad(model, cm, w, q1)
+    assert torch.equal(cost, cost0) and torch.equal(gq, gq0) and torch.equal(pos, pos0) and float(gqd.abs().max()) == 0.0
+    # Gauss-Newton IK: an empty batch is a no-op, one problem converges
+    lo, hi = robot.q_min.to(DEV).contiguous(), robot.q_max.to(DEV).contiguous()
+    H_t = torch.eye(4, device=DEV); H_t[:3, 3] = torch.tensor([0.4, 0.1, 0.5])
+    ops.ik_gn_steps(model, model.n_links - 1, H_t, lo, hi, torch.zeros(0, 7, device=DEV), 4)
+    qs = robot.random_q(1).contiguous()
+    err = torch.zeros(1, device=DEV)
+    ops.ik_gn_steps(model, model.n_links - 1, H_t, lo, hi, qs, 64, err=err)
+    ops.ik_gn_steps(model, model.n_links - 1, H_t, lo, hi, qs, 1, err=err)
+    assert torch.isfinite(qs).all() and (qs >= lo - 1e-6).all() and (qs <= hi + 1e-6).all() and torch.isfinite(err).all()
+    # packed sums of a one-sample plan
+    plan = ops.RolloutPlan(model, cm, w, q1)
+    sums = torch.zeros(ops.n_blocks(1), device=DEV)
+    plan.launch(sums.data_ptr())
+    pk = ops.PackedSums(plan, sums)
+    out = torch.empty(pk.size, device=DEV)
+    pk.pack(out)
+    torch.cuda.synchronize()
+    assert out[0].item() == pytest.approx(plan.cost.sum().item(), rel=1e-6) and torch.allclose(out[2:], plan.gq.reshape(-1), rtol=1e-6, atol=1e-7)
+
+
 def test_empty_and_degenerate_inputs_of_the_round3_ops():
     """Zero-sized batches and the smallest legal shapes of the ops added in round 3 (the reference's functions accept them)."""
     from torch_robotics_amd import ops
