@@ -57,6 +57,12 @@ try:
         qg.grad = None
         cfn(qg).sum().backward()
     t("[torch.compile] compute_collision_cost(q).sum().backward()", fbc)
+    cfloor = torch.compile(lambda x: x * 2.0, fullgraph=True)             # what a compiled function + its compiled backward cost with no op of ours
+    cfloor(qg).sum().backward()
+    def fbf():
+        qg.grad = None
+        cfloor(qg).sum().backward()
+    t("[torch floor, compiled] torch.compile(lambda x: x * 2)(q).sum().backward()", fbf)
 except Exception as e:
     print("torch.compile path failed:", type(e).__name__, str(e)[:200])
 # whole-iteration hipGraph: forward + backward of the idiom captured once, replayed per planner iteration
