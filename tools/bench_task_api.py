@@ -12,11 +12,17 @@ task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=ta), robot=robot, obsta
 q = robot.random_q(4096 * 64).reshape(4096, 64, 7).contiguous()
 qg = q.clone().requires_grad_(True)
 def t(name, fn, n=300):
-    for _ in range(20): fn()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n): fn()
-    torch.cuda.synchronize()
-    print(f"{name:58s} {(time.perf_counter() - t0) / n * 1e6:8.1f} us per call")
+    """median of five blocks of n calls after 100 warm-up calls (the first milliseconds of a process -- clocks, the autograd engine's
+    device thread, allocator pools -- measured up to 25 us per call slower than the steady state)"""
+    for _ in range(100): fn()
+    blocks = []
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): fn()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / n * 1e6)
+    blocks.sort()
+    print(f"{name:58s} {blocks[2]:8.1f} us per call   (blocks {blocks[0]:.1f} .. {blocks[-1]:.1f})")
 t("task.compute_collision_cost(q)            [no grad]", lambda: task.compute_collision_cost(q))
 def fb():
     qg.grad = None
