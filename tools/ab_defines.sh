@@ -2,7 +2,7 @@
 # generated/spec_panda.o with the extra flags, relink libtrk.so and run the default bench three times.
 # usage (on the GPU box): bash tools/ab_defines.sh "base:" "exp1:-DTRK_EXP_FOO" ...
 cd $GRAFT_REPO_ROOT/torch_robotics_amd/csrc
-CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -ffp-contract=off -I. -Xarch_device -fno-honor-nans -Xarch_device -mno-amdgpu-ieee -mllvm -amdgpu-sched-strategy=max-ilp"
+CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -ffp-contract=off -Xarch_device -fno-slp-vectorize -I. -Xarch_device -fno-honor-nans -Xarch_device -mno-amdgpu-ieee -mllvm -amdgpu-sched-strategy=max-ilp"
 cp generated/spec_panda.o /tmp/spec_panda.o.orig
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
@@ -10,7 +10,7 @@ for v in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libtrk.so trk_capi.o trk_kernels.o generated/*.o
   printf "%-28s" "$name"
   for i in 1 2 3; do
-    (cd $GRAFT_REPO_ROOT && python bench.py --cpu-seconds 0 --steps 3000 $BENCH_ARGS 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(' %6.2f' % d['roofline']['launch_us'], end='')")
+    (cd $GRAFT_REPO_ROOT && python bench.py --cpu-seconds 0 --steps 3000 --no-out-of-cache $BENCH_ARGS 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(' %6.2f' % d['roofline']['launch_us'], end='')")
   done
   echo
 done
