@@ -2,10 +2,12 @@
 # generated/spec_panda.o with the extra flags, relink libtrk.so and run the default bench three times.
 # usage (on the GPU box): bash tools/ab_defines.sh "base:" "exp1:-DTRK_EXP_FOO" ...
 cd $GRAFT_REPO_ROOT/torch_robotics_amd/csrc
-CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -ffp-contract=off -Xarch_device -fno-slp-vectorize -I. -Xarch_device -fno-honor-nans -Xarch_device -mno-amdgpu-ieee -mllvm -amdgpu-sched-strategy=max-ilp"
+CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -ffp-contract=off -Xarch_device -fno-slp-vectorize -I. -Xarch_device -fno-honor-nans -Xarch_device -mno-amdgpu-ieee"
+ILP="-mllvm -amdgpu-sched-strategy=max-ilp"      # the Makefile's GENFLAGS; a variant whose flags contain NOILP is compiled without it
 cp generated/spec_panda.o /tmp/spec_panda.o.orig
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
+  case "$flags" in *NOILP*) flags=${flags/NOILP/};; *) flags="$ILP $flags";; esac
   $CXX $flags -c generated/spec_panda.hip -o generated/spec_panda.o 2>/tmp/ab_err.txt || { echo "$name: BUILD FAILED"; tail -5 /tmp/ab_err.txt; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libtrk.so trk_capi.o trk_kernels.o generated/*.o
   printf "%-28s" "$name"
