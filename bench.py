@@ -99,6 +99,11 @@ def parse_args(argv):
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' + --single-device lets the N>1 control flow run on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--same-q", action="store_true", help="debug: every rank draws the same q (all-reduced sums == N x rank 0's)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "rccl"],
+                    help="how the packed sums travel: 'p2p' = the peer-to-peer mailbox (trk_mailbox_*: every rank stores its row into every "
+                         "peer's device memory over xGMI and adds the rows in rank order; one kernel, captured into the step graphs), "
+                         "'rccl' = an all-reduce on a side stream, 'auto' (default) = p2p when its known-answer validation passes on "
+                         "every rank, else rccl")
     ap.add_argument("--native-rccl", action="store_true",
                     help="issue the planner's exchange straight on librccl (torch_robotics_amd.distributed.RcclAllReduce: one ctypes "
                          "call per collective) instead of torch.distributed.all_reduce; the barriers stay on torch.distributed")
@@ -393,24 +398,44 @@ def main():
     # kernel-only figure (`multi_gpu.collectives_in_timed_region` counts them).
     R = max(1, min(args.reduce_every, args.steps))
     # what a sharded planner exchanges: one packed fp32 buffer [sum cost | sum_b cost(h) | sum_b grad(h, d)]
-    n_slots = 64
+    n_slots = 128
     packed = torch.zeros((n_slots, 1 + H + H * D), **ta)
     stream = torch.cuda.current_stream(dev)
     side = torch.cuda.Stream(dev, priority=args.side_priority) if distributed else None
 
     packers = {}
 
-    def pack_sums(pl, buf):
+    def pack_sums(pl, buf, s=None):
         """The sums of the latest evaluation of plan `pl` -> buf: one launch of trk_pack_sums on the launch stream."""
         pk = packers.get(id(pl))
         if pk is None:
             pk = packers[id(pl)] = ops.PackedSums(pl, block_sums, wl.traj_cost if pl is plan else None)
-        pk.pack(buf, stream.cuda_stream)
+        pk.pack(buf, stream.cuda_stream if s is None else s)
 
     native = None
     if distributed and args.native_rccl:
         from torch_robotics_amd.distributed import RcclAllReduce
         native = RcclAllReduce(dev)
+
+    # The peer-to-peer mailbox (SURVEY 8e's alternative; csrc/trk_exchange.hip).  Every rank constructs it (the handles travel through
+    # the process group); a known-answer validation on all ranks decides whether it is used -- a box where peer stores do not arrive
+    # times out inside the kernel (no hang) and the run keeps the all-reduce.
+    mailbox, mailbox_note = None, None
+    if distributed and args.exchange in ("auto", "p2p"):
+        from torch_robotics_amd.distributed import MailboxAllReduce
+        try:
+            mailbox = MailboxAllReduce(dev, 1 + H + H * D, n_slots=8)
+            if not mailbox.validate():
+                mailbox_note = "validation failed (a peer's stores did not arrive / wrong sums): " + repr(mailbox.status())
+                mailbox.close(); mailbox = None
+        except Exception as e:                                   # e.g. hipIpcOpenMemHandle refused
+            mailbox_note, mailbox = f"{type(e).__name__}: {e}", None
+        if mailbox is None:
+            if args.exchange == "p2p":
+                raise SystemExit(f"--exchange p2p: the mailbox is not usable here: {mailbox_note}")
+            if rank == 0:
+                print(f"[bench] peer-to-peer mailbox not usable ({mailbox_note}); the exchange stays an all-reduce", file=sys.stderr)
+    reduced = torch.zeros((n_slots, 1 + H + H * D), **ta) if mailbox is not None else None      # the mailbox's results (ring, like `packed`)
 
     slot_free = [None] * n_slots        # per exchange buffer: the side-stream event after which it may be packed again
 
@@ -425,7 +450,9 @@ def main():
         ev = torch.cuda.Event()
         ev.record(stream)
         side.wait_event(ev)
-        if native is not None:
+        if mailbox is not None:
+            mailbox.exchange(buf, reduced[k], side.cuda_stream)
+        elif native is not None:
             native.all_reduce_sum_(buf, side.cuda_stream)
         else:
             with torch.cuda.stream(side):
@@ -450,23 +477,40 @@ def main():
     S_live = [S]                 # becomes 0 if a capture fails
     gstream = torch.cuda.Stream(dev) if S else None
 
-    def graph_for(pl, n):
-        """the graph of n consecutive steps of plan pl (captured once, launched once), or None when capture is off / failed"""
+    gside = torch.cuda.Stream(dev) if (S and mailbox is not None) else None      # the exchange branch of a captured interval
+
+    def graph_for(pl, segs):
+        """The graph of `segs` = (a0, a1, ..., ak): a0 steps of plan pl, exchange, a1 steps, exchange, ..., ak steps (k exchanges; an int
+        = that many plain steps).  An exchange inside a graph is the mailbox form: trk_pack_sums on the launch branch, then
+        trk_mailbox_exchange on a forked branch that runs beside the following steps and joins at the end of the graph; the exchanges of
+        a graph are chained on that branch (a rank's exchanges run in order).  Captured once, launched once; None when capture is off / failed."""
         if not S_live[0]:
             return None
-        g = graphs.get((id(pl), n))
+        segs = (segs,) if isinstance(segs, int) else tuple(segs)
+        g = graphs.get((id(pl), segs))
         if g is None:
             fn = step_of(pl)
             try:
                 with torch.cuda.stream(gstream):
                     for i in range(3):                          # nothing lazy may happen inside the capture
                         fn(bs_ptr, gstream.cuda_stream)
+                    if len(segs) > 1:
+                        pack_sums(pl, packed[0], gstream.cuda_stream)
                 gstream.synchronize()
                 g = torch.cuda.CUDAGraph()
                 # thread-local capture mode: the process group's watchdog thread may query events while this thread captures
                 with torch.cuda.graph(g, stream=gstream, capture_error_mode="thread_local"):
-                    for i in range(n):
-                        fn(bs_ptr, torch.cuda.current_stream(dev).cuda_stream)
+                    cur = torch.cuda.current_stream(dev)
+                    for j, n in enumerate(segs):
+                        if j > 0:                               # exchange j - 1: pack here, the mailbox kernel on the side branch
+                            k = (j - 1) % n_slots
+                            pack_sums(pl, packed[k], cur.cuda_stream)
+                            gside.wait_stream(cur)
+                            mailbox.exchange(packed[k], reduced[k], gside.cuda_stream)
+                        for i in range(n):
+                            fn(bs_ptr, cur.cuda_stream)
+                    if len(segs) > 1:
+                        cur.wait_stream(gside)                   # join
                 g.replay()                                      # the first launch of an instantiated graph uploads it
                 torch.cuda.synchronize(dev)
             except Exception as e:                              # a box whose runtime refuses the capture still measures: eager loop
@@ -474,7 +518,7 @@ def main():
                 S_live[0] = 0
                 torch.cuda.synchronize(dev)
                 return None
-            graphs[(id(pl), n)] = g
+            graphs[(id(pl), segs)] = g
         return g
 
     def pieces(count, cadence):
@@ -490,30 +534,68 @@ def main():
             out_.append((count - last, False))
         return out_
 
+    def schedule(count, cadence):
+        """What run() issues for `count` steps: a list of ("graph", segs) / ("steps", n) / ("exchange",) items.  With the mailbox and
+        capture on, the exchanges ride INSIDE the graphs (whole intervals per graph, <= S steps each, so the driver's 20 timed steps
+        with their exchange are ONE graph launch); otherwise plain-step graphs with an eager exchange between them."""
+        items = []
+        in_graph = bool(S_live[0]) and mailbox is not None and cadence
+        if in_graph:
+            segs, steps_in = [0], 0
+            for n, ex in pieces(count, cadence):
+                while n > 0:
+                    take = min(n, S - steps_in)
+                    if take == 0:                                # the graph is full: close it (an exchange never ends a graph unless the run ends)
+                        items.append(("graph", tuple(segs))); segs, steps_in = [0], 0
+                        continue
+                    segs[-1] += take; steps_in += take; n -= take
+                if ex:
+                    if len(segs) > n_slots or steps_in >= S:    # start a new graph; the exchange opens it (its pack reads the previous graph's last step)
+                        items.append(("graph", tuple(segs))); segs, steps_in = [0], 0
+                    segs.append(0)
+            if steps_in or len(segs) > 1:
+                items.append(("graph", tuple(segs)))
+            return items
+        for n, ex in pieces(count, cadence):
+            while n > 0 and S_live[0]:
+                items.append(("graph", (min(n, S),))); n -= min(n, S)
+            if n:
+                items.append(("steps", n))
+            if ex:
+                items.append(("exchange",))
+        return items
+
     def prepare(pl, count, cadence):
         """capture (and launch once) every graph run(pl, count, cadence) will replay -- outside any timed region"""
-        for n, _ in pieces(count, cadence):
-            while n > 0 and S_live[0]:
-                graph_for(pl, min(n, S)); n -= min(n, S)
+        for it in schedule(count, cadence):
+            if it[0] == "graph" and S_live[0]:
+                graph_for(pl, it[1])
 
     slot = [0]
 
     def run(pl, count, cadence):
-        """`count` steps; cadence > 0: one exchange per `cadence` steps of this call, fired in the MIDDLE of its interval: the host is then
-        several launches ahead of the GPU (handing a collective to torch.distributed costs the launch thread ~60 us) and half an
-        interval is left for the collective to complete.  (In a 20-step region one exchange still costs ~50 us whatever its position:
-        the GPU time of the pack kernel + the collective, which the launches behind it wait for -- DESIGN.md 6d.)"""
+        """`count` steps; cadence > 0: one exchange per `cadence` steps of this call, fired in the MIDDLE of its interval.  Mailbox mode:
+        the exchange is part of the captured interval (no host work at all).  All-reduce mode: the host is then several launches ahead
+        of the GPU (handing a collective to torch.distributed costs the launch thread ~60 us) and half an interval is left for the
+        collective to complete."""
         s = stream.cuda_stream
         fn = step_of(pl)
-        for n, exchange in pieces(count, cadence):
-            while n > 0 and S_live[0]:
-                g = graph_for(pl, min(n, S))
-                if g is None:
-                    break
-                g.replay(); n -= min(n, S)
-            for _ in range(n):                                  # eager mode, or what a failed capture left
-                fn(bs_ptr, s)
-            if exchange:
+        for it in schedule(count, cadence):
+            if it[0] == "graph":
+                g = graph_for(pl, it[1])
+                if g is not None:
+                    g.replay()
+                    slot[0] += len(it[1]) - 1
+                    continue
+                for j, n in enumerate(it[1]):                   # a failed capture: the same items eagerly
+                    if j > 0:
+                        reduce_slot(pl, slot[0] % n_slots); slot[0] += 1
+                    for _ in range(n):
+                        fn(bs_ptr, s)
+            elif it[0] == "steps":
+                for _ in range(it[1]):
+                    fn(bs_ptr, s)
+            else:
                 reduce_slot(pl, slot[0] % n_slots)
                 slot[0] += 1
 
@@ -708,17 +790,42 @@ def main():
         pack_sums(plan, local)
         gathered = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
-        reduced = local.clone()
-        if native is not None:
-            native.all_reduce_sum_(reduced, stream.cuda_stream)
+        check_out = local.clone()
+        if mailbox is not None:
+            mailbox.exchange(local, check_out, stream.cuda_stream)
+        elif native is not None:
+            native.all_reduce_sum_(check_out, stream.cuda_stream)
         else:
-            dist.all_reduce(reduced)
+            dist.all_reduce(check_out)
         torch.cuda.synchronize(dev)
         expect = torch.stack(gathered).double().sum(0)
-        err = float(((reduced.double() - expect).abs() / (expect.abs() + 1.0)).max().item())
+        err = float(((check_out.double() - expect).abs() / (expect.abs() + 1.0)).max().item())
+        # the mailbox adds the rows in rank order in fp32: every rank must hold the SAME bits as that sum computed here
+        bitwise = None
+        if mailbox is not None:
+            acc = gathered[0].clone()
+            for g_ in gathered[1:]:
+                acc += g_
+            bitwise = bool(torch.equal(acc, check_out))
+        # the all-reduce path measured next to the mailbox (the mailbox switched off for one measurement)
+        rccl_cmp = None
+        if mailbox is not None:
+            mb_keep, mailbox = mailbox, None
+            measure(plan, R)
+            rc_elapsed, _ = measure(plan, R)
+            mailbox = mb_keep
+            rccl_cmp = {"value": samples_per_step * args.steps / rc_elapsed, "ms_per_step": rc_elapsed * 1e3 / args.steps,
+                        "collectives_in_timed_region": n_coll[0],
+                        "via": "librccl ncclAllReduce (ctypes)" if native is not None else "torch.distributed.all_reduce"}
+        mb_status = mailbox.status() if mailbox is not None else None
         out["multi_gpu"] = {
             "backend": dist.get_backend(), "ranks": dist.get_world_size(), "reduce_every": args.reduce_every, "reduce_every_effective": R,
-            "exchange_via": "librccl ncclAllReduce (ctypes)" if native is not None else "torch.distributed.all_reduce",
+            "exchange_via": ("peer-to-peer mailbox (trk_mailbox_exchange: stores into every peer's device memory, rows added in rank order"
+                             + ("; captured into the step graphs)" if S_live[0] else "; eager, on a side stream)")) if mailbox is not None else
+                            "librccl ncclAllReduce (ctypes)" if native is not None else "torch.distributed.all_reduce",
+            **({"mailbox": {"exchanges": mb_status[0], "timeouts": mb_status[1], "memory": mb_status[2], "sums_bit_identical_to_rank_order": bitwise}}
+               if mailbox is not None else {"mailbox": None, "mailbox_note": mailbox_note}),
+            **({"rccl_allreduce": rccl_cmp} if rccl_cmp else {}),
             "collectives_in_timed_region": n_coll_value, "exchange_us": exchange_us,
             "allreduce_floats": int(local.numel()),
             "with_allreduce": {"value": value, "ms_per_step": elapsed * 1e3 / args.steps},
@@ -727,9 +834,15 @@ def main():
                            "collectives_in_timed_region": n_coll_every},
             **({"full_stack_c3": c3} if c3 else {}),
             "allreduce_check": {"ok": bool(err < 1e-5), "max_rel_err": err,
-                                "sum_cost_all_ranks": float(reduced[0].item()), "sum_cost_rank0": float(gathered[0][0].item())},
+                                "sum_cost_all_ranks": float(check_out[0].item()), "sum_cost_rank0": float(gathered[0][0].item())},
         }
+        mg = out["multi_gpu"]
+        # what the exchange leaves of ideal weak scaling: N x (a step without any exchange) / (a step of the timed region with its exchange)
+        mg["scaling_bound"] = world * mg["kernel_only"]["ms_per_step"] / mg["with_allreduce"]["ms_per_step"]
+        mg["exchange_overhead_us_per_step"] = 1e3 * (mg["with_allreduce"]["ms_per_step"] - mg["kernel_only"]["ms_per_step"])
         assert err < 1e-5, f"all-reduced sums differ from the sum of the ranks' sums: {err}"
+        assert mb_status is None or mb_status[1] == 0, f"the mailbox exchange timed out {mb_status[1]} times"
+        assert bitwise is not False, "the mailbox sums differ from the rows added in rank order"
 
     if rank == 0 and not distributed and args.independent_streams > 1 and wl.random_q is not None:
         # Secondary figure (never `value`): INDEPENDENT batches alternated over three HIP streams.  With one stream a launch waits
@@ -762,8 +875,12 @@ def main():
         out["cpu_baseline"] = None
 
     if distributed:
+        torch.cuda.synchronize(dev)
+        if mailbox is not None:
+            dist.barrier()                # no rank unmaps a mailbox a peer may still store into
+            graphs.clear()
+            mailbox.close()
         if native is not None:
-            torch.cuda.synchronize(dev)
             native.close()
         dist.barrier()
         dist.destroy_process_group()

@@ -629,6 +629,32 @@ int trk_pack_sums(const float* cost, const void* gq, int32_t grad_dtype, float g
                   const float* traj_cost, int64_t batch, int32_t horizon, int32_t dof, float* scratch, float* packed,
                   trk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * The exchange step of a batch-sharded planner as a PEER-TO-PEER MAILBOX ("alternative = peer-to-peer write of
+ * 8 partials + local sum"; what is sharded is PlanningTask._compute_collision_or_cost's batch, tasks.py:206-230; the reference
+ * itself is single-device and has no exchange).  One process per GPU; every rank owns a mailbox in device memory with
+ * n_slots x world rows of n_floats; trk_mailbox_exchange stores the caller's packed row (trk_pack_sums' output) into the
+ * rank's row of EVERY mailbox (one xGMI hop, all peers in parallel), raises a sequence flag, waits for the `world` flags of
+ * its own mailbox and writes the sum of the `world` rows, added in rank order (bit-identical on every rank and run), to out.
+ * One single-workgroup kernel per call, asynchronous on `stream`; the sequence number lives in device memory, so the call can
+ * be captured into a hipGraph and replayed.  All ranks must issue the same sequence of exchanges; the exchanges of one rank
+ * must run in stream order.  A rank that waits longer than TRK_MAILBOX_TIMEOUT_S (environment, default 5 s) for a flag
+ * gives up, counts a time-out (trk_mailbox_status) and writes an incomplete sum instead of hanging the GPU.
+ *   create:     allocates the local mailbox (uncached / fine-grained device memory that hipIpcGetMemHandle accepts).
+ *   ipc_handle: writes the TRK_MAILBOX_HANDLE_BYTES bytes another process passes to connect (exchange them with any host
+ *               transport, e.g. torch.distributed.all_gather_object).
+ *   connect:    handles [world][TRK_MAILBOX_HANDLE_BYTES] (HOST; the entry of this rank is ignored): maps the peers' mailboxes.
+ *   status:     synchronises with the device; exchanges issued, time-outs seen, allocation kind (0 uncached, 1 fine-grained, 2 plain).
+ * world == 1 needs no connect.  2 <= n_slots <= 64, world <= 16. */
+#define TRK_MAILBOX_HANDLE_BYTES 64
+typedef struct TrkMailbox TrkMailbox;
+int trk_mailbox_create(int32_t world, int32_t rank, int32_t n_floats, int32_t n_slots, TrkMailbox** out);
+int trk_mailbox_ipc_handle(const TrkMailbox* mb, void* handle /* host, TRK_MAILBOX_HANDLE_BYTES */);
+int trk_mailbox_connect(TrkMailbox* mb, const void* handles /* host */);
+int trk_mailbox_exchange(TrkMailbox* mb, const float* packed, float* out, trk_stream_t stream);
+int trk_mailbox_status(const TrkMailbox* mb, int64_t* n_exchanges, int64_t* n_timeouts, int32_t* alloc_kind);
+void trk_mailbox_destroy(TrkMailbox* mb);
+
 /* Deterministic sum of n floats (fixed association order, one workgroup): x [n] -> out [1]. */
 int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream);
 

@@ -946,6 +946,80 @@ def tree_cost_goldens(trees):
         print(f"cost_tree_{name}: {n} samples, {len(obj_idx)} collision links, {len(pairs)} pairs, {len(tracked)} tracked")
 
 
+def builddef_goldens(trees=None):
+    """SECOND, independent statements of the two BUILD-DEFINED terms (no reference counterpart: SURVEY.md 8a), so that the C oracle
+    and the HIP kernels are not checked against a single restatement by the same author:
+
+    * gp_prior.npz -- the constant-velocity GP prior from its DENSE definition in torch fp64: state x_t = [q_t; qd_t], transition
+      Phi(dt) = [[I, dt I], [0, I]], process noise Q = sigma^2 [[dt^3/3 I, dt^2/2 I], [dt^2/2 I, dt I]] (white noise on the
+      acceleration), Q^-1 by `torch.linalg.inv` of the 2D x 2D matrix (NOT the closed form 12/dt^3, -6/dt^2, 4/dt the kernels
+      use), cost = w/2 sum_t e_t^T Q^-1 e_t with e_t = Phi x_t - x_t+1; gradients by autograd.
+    * ik_gn_panda.npz -- one damped Gauss-Newton step built from the REFERENCE's own stateful FK + geometric Jacobian
+      (compute_forward_kinematics_and_geometric_jacobian, robot_tree.py:218-248, fp32) with `torch.linalg.solve` in fp64 and
+      scipy's rotation vector; the termination metric from the reference's SE3_distance (geometrics/utils.py:130-154)."""
+    from scipy.spatial.transform import Rotation
+    out = {}
+    gen = torch.Generator().manual_seed(515)
+    cases = [(3, 16, 7, 0.08, 0.3, 1.0), (2, 128, 14, 5.0 / 128, 0.1, 1.0), (4, 5, 3, 0.25, 1.5, 0.5), (2, 2, 7, 0.1, 0.2, 2.0), (3, 1, 7, 0.1, 0.2, 1.0)]
+    out["n_cases"] = np.int32(len(cases))
+    for k, (B, H, D, dt, sigma, w) in enumerate(cases):
+        q32 = (torch.rand(B, 1, D, generator=gen) * 2 - 1 + torch.cumsum(torch.randn(B, H, D, generator=gen) * 0.03, 1)).float()
+        qd32 = (torch.randn(B, H, D, generator=gen) * 0.3).float()
+        q = q32.double().requires_grad_(True)
+        qd = qd32.double().requires_grad_(True)
+        I, Z = torch.eye(D, dtype=torch.float64), torch.zeros(D, D, dtype=torch.float64)
+        Phi = torch.cat([torch.cat([I, dt * I], 1), torch.cat([Z, I], 1)], 0)
+        Q = sigma ** 2 * torch.cat([torch.cat([dt ** 3 / 3 * I, dt ** 2 / 2 * I], 1), torch.cat([dt ** 2 / 2 * I, dt * I], 1)], 0)
+        Qinv = torch.linalg.inv(Q)
+        x = torch.cat([q, qd], -1)                                       # (B, H, 2D)
+        if H > 1:
+            e = x[:, :-1] @ Phi.T - x[:, 1:]                             # (B, H-1, 2D)
+            fac = 0.5 * w * torch.einsum("bti,ij,btj->bt", e, Qinv, e)
+            fac = torch.cat([fac, torch.zeros(B, 1, dtype=torch.float64)], 1)
+        else:
+            fac = torch.zeros(B, 1, dtype=torch.float64) + 0.0 * x.sum()
+        cost = fac.sum(1)
+        gq, gqd = torch.autograd.grad(cost.sum(), (q, qd), allow_unused=True)
+        gq = torch.zeros_like(q) if gq is None else gq
+        gqd = torch.zeros_like(qd) if gqd is None else gqd
+        out.update({f"q_{k}": q32.numpy(), f"qd_{k}": qd32.numpy(), f"params_{k}": np.array([dt, sigma, w], np.float64),
+                    f"cost_{k}": cost.detach().numpy(), f"factor_{k}": fac.detach().numpy(), f"gq_{k}": gq.numpy(), f"gqd_{k}": gqd.numpy()})
+    np.savez_compressed(GOLD / "gp_prior.npz", **out)
+
+    if trees is None:
+        trees = {"panda_arm_no_gripper": quiet(DifferentiableTree, str(URDF_OUT / "panda_arm_no_gripper.urdf"), "panda_arm_no_gripper")}
+    tree = trees["panda_arm_no_gripper"]
+    gen = torch.Generator().manual_seed(616)
+    lower, upper, _, _ = tree.get_joint_limit_array()
+    eps = np.pi / 100
+    lo, hi = (lower + eps).astype(np.float32), (upper - eps).astype(np.float32)
+    n = 40
+    q0 = sample_q(tree, n, gen, 0.0)
+    q0[:8] = sample_q(tree, 8, gen, 0.1)                                # a few start outside the (shrunk) limits: the stateful FK clamps
+    q_goal = sample_q(tree, n, gen, 0.0)
+    H_target = tree.compute_forward_kinematics_all_links(q_goal, link_list=["ee_link"]).squeeze(1).detach()
+    out = dict(q0=q0.numpy(), H_target=H_target.numpy(), lower=lo, upper=hi, link="ee_link")
+    for tag, (damping, lm_gain, step_scale) in (("a", (1e-4, 0.1, 1.0)), ("b", (1e-3, 0.02, 0.7))):
+        tree.reset()
+        pos, quat, lin, ang = tree.compute_forward_kinematics_and_geometric_jacobian(q0, torch.zeros_like(q0), "ee_link")
+        tree.reset()
+        J = torch.cat([lin, ang], 1).double()                            # (n, 6, D): the reference's geometric Jacobian
+        R = torch.as_tensor(Rotation.from_quat(quat.numpy()[:, [1, 2, 3, 0]].astype(np.float64)).as_matrix())     # wxyz -> scipy's xyzw
+        Rt = H_target[:, :3, :3].double()
+        rot = Rotation.from_matrix((Rt @ R.transpose(1, 2)).numpy()).as_rotvec()
+        r = torch.cat([H_target[:, :3, 3].double() - pos.double(), torch.as_tensor(rot)], 1)       # (n, 6)
+        lam = damping + lm_gain * (r * r).sum(1)
+        A = J.transpose(1, 2) @ J + lam[:, None, None] * torch.eye(J.shape[-1], dtype=torch.float64)
+        dq = torch.linalg.solve(A, (J.transpose(1, 2) @ r[:, :, None])).squeeze(-1)
+        q_new = torch.minimum(torch.maximum(q0.double() + step_scale * dq, torch.as_tensor(lo).double()), torch.as_tensor(hi).double())
+        Hq = torch.eye(4).repeat(n, 1, 1)
+        Hq[:, :3, :3] = R.float(); Hq[:, :3, 3] = pos
+        err = SE3_distance(Hq, H_target, w_pos=1.0, w_rot=1.0)
+        out.update({f"params_{tag}": np.array([damping, lm_gain, step_scale], np.float64), f"q_new_{tag}": q_new.numpy(), f"dq_{tag}": dq.numpy(),
+                    f"err_{tag}": err.reshape(n).numpy(), f"residual_{tag}": r.numpy()})
+    np.savez_compressed(GOLD / "ik_gn_panda.npz", **out)
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
     URDF_OUT.mkdir(parents=True, exist_ok=True)
@@ -969,6 +1043,9 @@ def main():
         return
     if sys.argv[1:] == ["interp"]:
         interp_goldens()
+        return
+    if sys.argv[1:] == ["builddef"]:
+        builddef_goldens()
         return
     if sys.argv[1:] == ["treecost"]:
         tree_cost_goldens({n: quiet(DifferentiableTree, str(URDF_OUT / f"{n}.urdf"), n) for n in ("ur10_allegro", "dual_panda")})
@@ -1007,6 +1084,7 @@ def main():
     clamp_goldens()
     interp_goldens()
     tree_cost_goldens(trees)
+    builddef_goldens(trees)
     total = sum(p.stat().st_size for p in GOLD.glob("*.npz"))
     print(f"golden dir: {len(list(GOLD.glob('*.npz')))} files, {total/1024:.0f} kB")
 

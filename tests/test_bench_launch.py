@@ -122,16 +122,16 @@ def test_bench_scene_variants(scene, bps):
 def test_rccl_code_path_on_one_rank():
     """`--force-dist`: the N > 1 code path with ONE rank and the real backend ("nccl" = RCCL on ROCm): process-group creation on
     the device, the side-stream all-reduce of the packed sums, the in-stream barriers, the MAX over ranks, all_gather -- on hardware."""
-    p = _run(["--force-dist", "--steps", "40", "--warmup", "5", "--reduce-every", "8", "--cpu-seconds", "0"], 600)
+    p = _run(["--force-dist", "--exchange", "rccl", "--steps", "40", "--warmup", "5", "--reduce-every", "8", "--cpu-seconds", "0"], 600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     mg = out["multi_gpu"]
-    assert out["n_gpus"] == 1 and mg["backend"] == "nccl" and mg["ranks"] == 1
+    assert out["n_gpus"] == 1 and mg["backend"] == "nccl" and mg["ranks"] == 1 and mg["exchange_via"].startswith("torch.distributed")
     assert mg["collectives_in_timed_region"] == 5 and mg["allreduce_check"]["ok"] and mg["exchange_us"] > 0
     assert mg["allreduce_check"]["sum_cost_all_ranks"] == pytest.approx(mg["allreduce_check"]["sum_cost_rank0"], rel=1e-6)
     # the driver's settings (20 steps after 5) at the default cadence (64): the interval shrinks to the run, the region contains
     # an exchange -- `value` is never a kernel-only figure
-    p = _run(["--force-dist", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0"], 600)
+    p = _run(["--force-dist", "--exchange", "rccl", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0"], 600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["multi_gpu"]["collectives_in_timed_region"] == 1 and out["config"]["reduce_every"] == 64
@@ -141,7 +141,7 @@ def test_rccl_code_path_on_one_rank():
 @pytest.mark.gpu
 def test_native_rccl_exchange_on_one_rank():
     """`--native-rccl`: the exchange issued straight on librccl (ncclAllReduce through ctypes on the side stream)."""
-    p = _run(["--force-dist", "--native-rccl", "--steps", "40", "--warmup", "5", "--reduce-every", "8", "--cpu-seconds", "0"], 600)
+    p = _run(["--force-dist", "--exchange", "rccl", "--native-rccl", "--steps", "40", "--warmup", "5", "--reduce-every", "8", "--cpu-seconds", "0"], 600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     mg = out["multi_gpu"]
@@ -167,8 +167,44 @@ def test_launch_modes_graph_by_default_eager_on_request():
     assert p.returncode == 0, p.stderr[-3000:]
     assert json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])["config"]["launch"].startswith("eager")
     # N > 1 code path (one rank, RCCL) in graph mode: the exchange sits between two replays inside the timed region
-    p = _run(["--force-dist", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--batch", "512"], 600)
+    p = _run(["--force-dist", "--exchange", "rccl", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--batch", "512"], 600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["config"]["launch"].startswith("hipGraph") and out["multi_gpu"]["collectives_in_timed_region"] == 1
     assert out["multi_gpu"]["allreduce_check"]["ok"]
+
+
+@pytest.mark.gpu
+def test_mailbox_exchange_is_the_default_and_rides_in_the_graph():
+    """`--exchange auto` (default): the peer-to-peer mailbox passes its known-answer validation and carries the exchange; at the
+    driver's settings the 20 timed steps AND their exchange are one captured graph; the all-reduce path is measured next to it."""
+    p = _run(["--force-dist", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    mg = out["multi_gpu"]
+    assert mg["exchange_via"].startswith("peer-to-peer mailbox") and "captured" in mg["exchange_via"]
+    assert mg["collectives_in_timed_region"] == 1 and mg["every_step"]["collectives_in_timed_region"] == 20
+    assert mg["mailbox"]["timeouts"] == 0 and mg["mailbox"]["exchanges"] > 40 and mg["mailbox"]["sums_bit_identical_to_rank_order"]
+    assert mg["allreduce_check"]["ok"] and mg["rccl_allreduce"]["ms_per_step"] > 0 and mg["rccl_allreduce"]["collectives_in_timed_region"] == 1
+    assert 0 < mg["scaling_bound"] <= 1.05 and mg["exchange_overhead_us_per_step"] < 3.0
+    # eager loop: the same exchange on a side stream
+    p = _run(["--force-dist", "--exchange", "p2p", "--graph", "0", "--steps", "24", "--warmup", "4", "--reduce-every", "8", "--cpu-seconds", "0",
+              "--batch", "512"], 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    mg = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])["multi_gpu"]
+    assert "eager" in mg["exchange_via"] and mg["collectives_in_timed_region"] == 3 and mg["mailbox"]["timeouts"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,extra", [("c2", []), ("c2", ["--graph", "20"]), ("c5", ["--batch", "256", "--graph", "20"])])
+def test_two_rank_mailbox_exchange_on_one_gpu(cfg, extra):
+    """Two processes share cuda:0 and exchange through each other's mailboxes (hipIpc handles): the sums every rank reads equal the
+    rows added in rank order bit for bit, equal gloo's all-reduce of the same rows, nothing times out -- eager and captured."""
+    p = _run(["--config", cfg, "--gpus", "2", "--dist-backend", "gloo", "--single-device", "--exchange", "p2p", "--steps", "20", "--warmup", "5",
+              "--reduce-every", "8", "--cpu-seconds", "0"] + extra, 600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    mg = out["multi_gpu"]
+    assert mg["ranks"] == 2 and mg["exchange_via"].startswith("peer-to-peer mailbox") and ("captured" in mg["exchange_via"]) == bool(extra and "--graph" in extra)
+    assert mg["mailbox"]["timeouts"] == 0 and mg["mailbox"]["sums_bit_identical_to_rank_order"] and mg["allreduce_check"]["ok"]
+    assert mg["collectives_in_timed_region"] in (2, 3) and mg["every_step"]["collectives_in_timed_region"] == 20

@@ -280,6 +280,40 @@ def test_moved_scene_object_is_seen_by_every_cached_cost_model():
     np.testing.assert_array_equal(task.compute_collision_cost(q).cpu().numpy(), c0.cpu().numpy())
 
 
+def test_reassigned_primitive_geometry_is_seen_by_object_sdf(oracle_lib):
+    """`field.centers = new` (the supported edit) must reach `ObjectField.compute_signed_distance` and its autograd path --
+    the object's own device cost model is keyed by the fields' geometry versions, not only by device and pose."""
+    from torch_robotics_amd.costmodel import CostModelSpec
+    from helpers import model
+    f = tra.MultiSphereField(np.array([[0.3, 0.0, 0.2], [-0.2, 0.4, 0.5]], np.float32), np.array([0.1, 0.2], np.float32), tensor_args=TA)
+    b = tra.MultiBoxField(np.array([[0.0, -0.4, 0.3]], np.float32), np.array([[0.2, 0.3, 0.4]], np.float32), tensor_args=TA)
+    o = tra.ObjectField([f, b], "o", pos=(0.1, 0.0, 0.0), ori=(0.9238795, 0.0, 0.3826834, 0.0))
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    X = (torch.rand(300, 3, device=DEV, generator=gen) - 0.5) * 2.0
+
+    def check():
+        x = X.clone().requires_grad_(True)
+        s = o.compute_signed_distance(x)
+        s.sum().backward()
+        orc = oracle_lib.Oracle(model("panda_arm_no_gripper"), CostModelSpec(n_links_in=1, objects=[o.as_object()]))
+        rs, rg = orc.sdf_points(X.cpu().numpy(), "f64")
+        assert np.abs(s.detach().cpu().numpy() - rs[:, 0]).max() < 2e-6
+        assert np.abs(o.compute_signed_distance(X).cpu().numpy() - rs[:, 0]).max() < 2e-6
+        gerr = np.abs(x.grad.cpu().numpy() - rg[:, 0, :]).max(1)
+        assert (gerr > 1e-4).sum() <= 3                        # arg-min ties between primitives / box faces flip in fp32
+        return s.detach().clone()
+
+    s0 = check()
+    f.centers = f.centers + np.array([0.0, 0.3, -0.1], np.float32)
+    s1 = check()
+    assert (s1 - s0).abs().max() > 1e-2
+    f.radii = f.radii * 0.5
+    s2 = check()
+    b.sizes = b.sizes * 1.5
+    s3 = check()
+    assert (s2 - s1).abs().max() > 1e-2 and (s3 - s2).abs().max() > 1e-3
+
+
 def test_clamp_sdf_fields_and_task():
     """`clamp_sdf=True` on the fields (distance_fields.py:114-117) and on a PlanningTask: hinge costs like the reference's."""
     g, rg = gold("cost_clamp"), gold("panda_robot")
@@ -1274,6 +1308,12 @@ try:
     raise SystemExit("expected a RuntimeError")
 except RuntimeError as e:
     assert "TRK_ALLOW_TABLE_DRIVEN" in str(e)
+for call in (lambda: task2.compute_collision_cost(q), lambda: task2.rollout_plan(q.reshape(2, 64, 7))):   # a retried call raises too
+    try:
+        call()
+        raise SystemExit("expected a RuntimeError on the second call as well (no silent table-driven fall-back)")
+    except RuntimeError as e:
+        assert "TRK_ALLOW_TABLE_DRIVEN" in str(e)
 # ... unless the caller accepts the table-driven kernels
 os.environ["TRK_ALLOW_TABLE_DRIVEN"] = "1"
 task3 = tra.PlanningTask(env=env, robot=robot2, tensor_args=TA)

@@ -1,0 +1,102 @@
+"""The peer-to-peer mailbox exchange (csrc/trk_exchange.hip, SURVEY.md 8e's alternative to the all-reduce) and the packed sums it carries.
+
+Two PROCESSES share cuda:0 and map each other's mailbox through hipIpc handles -- the same code path as two GPUs of one node, minus
+the xGMI hop.  Checked: the sums equal gloo's all-reduce of the same rows bit for bit (two ranks: a + b in either order), more
+exchanges than slots (slot reuse), a hipGraph replay of the exchange, bad arguments.
+"""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = r"""
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["TRK_ROOT"])
+from torch_robotics_amd.distributed import MailboxAllReduce
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+n = 1 + 64 + 64 * 7
+mb = MailboxAllReduce(dev, n, n_slots=3)
+assert mb.validate()
+gen = torch.Generator(device=dev).manual_seed(100 + rank)
+out = torch.empty(n, device=dev)
+for it in range(11):                                   # > n_slots: every slot is reused several times
+    row = torch.randn(n, device=dev, generator=gen) * (10.0 ** (it % 5))
+    mb.exchange(row, out)
+    ref = row.cpu().clone()
+    dist.all_reduce(ref)                               # gloo, on the host: a + b
+    assert torch.equal(out.cpu(), ref), (it, float((out.cpu() - ref).abs().max()))
+# captured: the sequence number lives in device memory, a replayed exchange is a new exchange
+row = torch.randn(n, device=dev, generator=gen)
+side = torch.cuda.Stream(dev)
+with torch.cuda.stream(side):
+    mb.exchange(row, out, side.cuda_stream)
+side.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+    mb.exchange(row, out, torch.cuda.current_stream(dev).cuda_stream)
+ref = row.cpu().clone(); dist.all_reduce(ref)
+for it in range(7):
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
+n_ex, n_to, kind = mb.status()
+assert n_ex == 6 + 11 + 1 + 7 and n_to == 0, (n_ex, n_to)
+dist.barrier()
+mb.close()
+print("rank", rank, "ok", kind, flush=True)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_mailbox_two_processes_one_gpu(tmp_path):
+    env = dict(os.environ, TRK_ROOT=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    script = tmp_path / "mailbox_worker.py"
+    script.write_text(WORKER)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29561", str(script)], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "rank 0 ok" in p.stdout and "rank 1 ok" in p.stdout
+
+
+@pytest.mark.gpu
+def test_mailbox_single_rank_and_argument_checks():
+    import ctypes as C
+    import torch
+    from torch_robotics_amd import _abi
+    from torch_robotics_amd._lib import lib
+    from torch_robotics_amd.distributed import MailboxAllReduce
+    dev = torch.device("cuda:0")
+    mb = MailboxAllReduce(dev, 513, rank=0, world=1)
+    assert mb.validate(rounds=9)
+    x = torch.randn(513, device=dev)
+    out = torch.empty_like(x)
+    mb.exchange(x, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, x)                         # one rank: the sum of one row
+    with pytest.raises(ValueError):
+        mb.exchange(x[:100], out)
+    with pytest.raises(ValueError):
+        mb.exchange(x.double(), out)
+    assert mb.status()[:2] == (10, 0)
+    mb.close()
+    L, h = lib(), C.c_void_p()
+    for world, rank, n, slots in ((0, 0, 8, 4), (17, 0, 8, 4), (2, 2, 8, 4), (2, 0, 0, 4), (2, 0, 8, 1), (2, 0, 8, 65)):
+        assert L.trk_mailbox_create(world, rank, n, slots, C.byref(h)) == _abi.TRK_ERR_INVALID_ARG
+    assert L.trk_mailbox_exchange(None, None, None, None) == _abi.TRK_ERR_INVALID_ARG
+    # a two-rank mailbox that was never connected refuses to exchange
+    assert L.trk_mailbox_create(2, 0, 8, 4, C.byref(h)) == 0
+    assert L.trk_mailbox_exchange(h, x.data_ptr(), out.data_ptr(), None) == _abi.TRK_ERR_INVALID_ARG
+    assert b"connect" in L.trk_last_error()
+    L.trk_mailbox_destroy(h)

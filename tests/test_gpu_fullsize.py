@@ -263,6 +263,44 @@ def test_dual_panda_fp16_gp_full_size(ops, oracle_lib):
     gqd_m = torch.zeros_like(gq_m)
     ops.gp_prior_cost_grad(qh, qdh, dt, sg, 1.0, accumulate_into=(gq_m, gqd_m))
     assert gq_m.dtype == torch.float32 and rel_err(gq_m[tsel].cpu().numpy(), tot) < 1e-4 and rel_err(gqd_m[tsel].cpu().numpy(), rgd_gp) < 1e-4
+    # THE KERNEL bench.py --config c5 TIMES -- the fused one-launch form (trk_rollout_gp_cost_grad -> k_rollout_gpt) -- at this very size
+    # against the fp64 oracle on the same 8 trajectories: cost per sample (rollout + GP factor), positions, both UNSCALED gradients; loss-
+    # scaled fp16 gradients and the mixed mode (fp32 gradients).  (Until round 5 the fused op met the oracle only at B <= 70.)
+    assert h.specialized
+    rp8, rc8, _ = o8.rollout(q8.reshape(-1, D), w, "f64")
+    fc8 = oracle_lib.gp_factor_cost(q8, qd8, dt, sg, 1.0, "f64")
+    ref_c8 = rc8.reshape(8, H) + fc8
+    for gdt, gsc in ((None, gs), (torch.float32, 1.0)):
+        sums = torch.zeros(ops.n_blocks(B * H), device=DEV)
+        fpos, fcost, fgq, fgqd = ops.rollout_gp_cost_grad(h, cm, w, qh, qdh, dt, sg, 1.0, cost_sum=sums, grad_dtype=gdt, grad_scale=gsc)
+        assert fpos.dtype == torch.float16 and fcost.dtype == torch.float32 and fgq.dtype == (gdt or torch.float16) and fgqd.dtype == fgq.dtype
+        for t_ in (fcost, fgq, fgqd, fpos):
+            assert torch.isfinite(t_.float()).all()
+        assert float(fgq.float().abs().max()) < 65504.0 and float(fgqd.float().abs().max()) < 65504.0
+        assert rel_err(fcost[tsel].cpu().numpy(), ref_c8) < 2e-5
+        assert np.abs(fpos[tsel].float().cpu().numpy().reshape(-1, L, 3) - rp8).max() < 2.0 ** -10 * max(1.0, np.abs(rp8).max())
+        # whole-batch consistency with the two-launch form: the per-trajectory cost and the per-wavefront sums (a checksum of checksums)
+        two = cost.double().sum(1) + c_gp.double()
+        assert rel_err(fcost.double().sum(1).cpu().numpy(), two.cpu().numpy()) < 1e-5
+        assert rel_err(sums.double().reshape(B, H // 64).sum(1).cpu().numpy(), fcost.double().sum(1).cpu().numpy()) < 1e-5
+        got, gotd = fgq[tsel].double().cpu().numpy() / gsc, fgqd[tsel].double().cpu().numpy() / gsc
+        if gdt is None:       # ONE fp16 rounding of the scaled sum (+ fp32 arithmetic on terms of the prior's size)
+            assert (np.abs(got - tot) <= 2.0 ** -9 * (np.abs(tot) + np.abs(rg_gp).max() * 2.0 ** -11) + 2.0 ** -22 / gsc + 4e-5 * np.abs(tot).max()).all()
+            assert (np.abs(gotd - rgd_gp) <= 2.0 ** -9 * (np.abs(rgd_gp) + np.abs(rgd_gp).max() * 2.0 ** -11) + 2.0 ** -22 / gsc + 4e-5 * np.abs(rgd_gp).max()).all()
+            # the collision / EE component under the loss scale: at gs ~ 2^-13 the O(1) collision gradient is ~1e-4 in the
+            # scaled fp16 domain -- it is part of the SUM that is rounded once, so what is left of it is bounded by the sum's ulp:
+            # |(total - GP) - collision| <= ulp_fp16(scaled total) / gs, element by element
+            coll = rg_ro.reshape(8, H, D)
+            ulp = np.maximum(2.0 ** (np.floor(np.log2(np.maximum(np.abs(tot) * gsc, 2.0 ** -24))) - 10), 2.0 ** -24) / gsc
+            assert (np.abs((got - rg_gp) - coll) <= 1.01 * ulp + 4e-5 * np.abs(rg_gp).max()).all()
+        else:
+            assert rel_err(got, tot) < 1e-4 and rel_err(gotd, rgd_gp) < 1e-4
+            # the collision / EE component inside the fp32 sum: a few fp32 ulps of the prior's terms (which are 1e5 x larger)
+            assert (np.abs((got - rg_gp) - rg_ro.reshape(8, H, D)) <= 4e-7 * np.abs(tot) + 2e-6 * np.abs(rg_gp).max()).all()
+    # sharding invariance of the fused launch: the second half of the batch alone gives the same bits
+    _, c_h, g_h, gd_h = ops.rollout_gp_cost_grad(h, cm, w, qh[B // 2:].contiguous(), qdh[B // 2:].contiguous(), dt, sg, 1.0, want_pos=False,
+                                                  grad_dtype=torch.float32)
+    assert torch.equal(c_h, fcost[B // 2:]) and torch.equal(g_h, fgq[B // 2:]) and torch.equal(gd_h, fgqd[B // 2:])
     # sharding invariance of both kernels (whole trajectories stay on one rank)
     _, c_s, g_s = ops.rollout_cost_grad(h, cm, w, qh[B // 2:].contiguous(), want_pos=False)
     assert torch.equal(c_s, cost[B // 2:]) and torch.equal(g_s, gq[B // 2:])

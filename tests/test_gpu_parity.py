@@ -974,6 +974,60 @@ def test_rollout_gp_fused_vs_fp64_oracle(ops, oracle_lib, ident):
     assert h.specialized
 
 
+def test_build_defined_terms_vs_independent_goldens(ops):
+    """The two build-defined terms pinned a second way (oracle/gen_golden.py builddef; SURVEY.md 8a has no reference counterpart):
+    * GP prior: `trk_gp_prior_cost_grad` and the fused `trk_rollout_gp_cost_grad` (objective weights 0: what is left IS the prior,
+      factor by factor) against the DENSE constant-velocity definition in torch fp64 with a numerically inverted Q (gp_prior.npz);
+    * damped Gauss-Newton IK: `trk_ik_gn_steps` against one step built from the REFERENCE's geometric Jacobian (robot_tree.py:218-248)
+      with `torch.linalg.solve` + scipy's rotation vector, error metric from the reference's SE3_distance (ik_gn_panda.npz)."""
+    from torch_robotics_amd import codegen
+    from torch_robotics_amd.costmodel import CostModelSpec
+    from torch_robotics_amd.environments import EnvSpheres3D
+    g = gold("gp_prior")
+    for k in range(int(g["n_cases"])):
+        q, qd = g[f"q_{k}"], g[f"qd_{k}"]
+        B, H, D = q.shape
+        dt, sigma, w = (float(v) for v in g[f"params_{k}"])
+        big = max(np.abs(g[f"gq_{k}"]).max(), np.abs(g[f"gqd_{k}"]).max(), 1e-30)
+        c, gq, gqd = ops.gp_prior_cost_grad(dev(q), dev(qd), dt, sigma, w)
+        assert rel_err(c.cpu().numpy(), g[f"cost_{k}"]) < 2e-5 or H == 1, k
+        assert np.abs(gq.cpu().numpy() - g[f"gq_{k}"]).max() < 2e-5 * big and np.abs(gqd.cpu().numpy() - g[f"gqd_{k}"]).max() < 2e-5 * big, k
+        ident = {7: "panda", 14: "dual_panda"}.get(D)
+        if ident is None:
+            continue
+        kin, tmpl = codegen.template_for(ident)
+        spec = CostModelSpec(n_links_in=kin.n_links)
+        spec.obj_link_idx = np.asarray(tmpl.obj_links, np.int32)
+        spec.obj_link_margin = np.full(len(tmpl.obj_links), 0.1, np.float32)
+        spec.objects = [o.as_object() for o in EnvSpheres3D(tensor_args=dict(device=DEV, dtype=torch.float32)).obj_fixed_list]
+        spec.ee_link, spec.ee_target = tmpl.ee_link, np.eye(4, dtype=np.float32)
+        if tmpl.ee2_link >= 0:
+            spec.ee2_link, spec.ee2_target = tmpl.ee2_link, np.eye(4, dtype=np.float32)
+        spec.validate()
+        h, cm = ops.ModelHandle(kin), ops.CostHandle(spec, DEV)
+        for use_spec in (True, False):
+            h.enable_specialized(use_spec)
+            _, cost, fgq, fgqd = ops.rollout_gp_cost_grad(h, cm, (0.0, 0.0, 0.0, 0.0), dev(q), dev(qd), dt, sigma, w, want_pos=False)
+            assert cost.shape == (B, H)
+            assert np.abs(cost.cpu().numpy() - g[f"factor_{k}"]).max() <= 2e-5 * max(np.abs(g[f"factor_{k}"]).max(), 1e-30), (k, use_spec)
+            assert np.abs(fgq.cpu().numpy() - g[f"gq_{k}"]).max() < 2e-5 * big and np.abs(fgqd.cpu().numpy() - g[f"gqd_{k}"]).max() < 2e-5 * big, (k, use_spec)
+        h.enable_specialized(True)
+    g = gold("ik_gn_panda")
+    m = model("panda_arm_no_gripper")
+    h = ops.ModelHandle(m)
+    ee = m.name_to_idx[str(g["link"])]
+    n = g["q0"].shape[0]
+    for tag in ("a", "b"):
+        damping, lm_gain, step = (float(v) for v in g[f"params_{tag}"])
+        for Ht in (g["H_target"],):
+            q = dev(g["q0"]).clone()
+            err = torch.empty(n, device=DEV)
+            ops.ik_gn_steps(h, ee, dev(Ht), dev(g["lower"]), dev(g["upper"]), q, 1, damping=damping, lm_gain=lm_gain, step_scale=step, err=err)
+            dq = np.abs(g[f"q_new_{tag}"] - g["q0"])
+            assert (np.abs(q.cpu().numpy() - g[f"q_new_{tag}"]) <= 1e-4 + 5e-3 * dq).all(), tag
+            assert rel_err(err.cpu().numpy(), g[f"err_{tag}"]) < 2e-5, tag
+
+
 @pytest.mark.parametrize("ident", ["panda", "dual_panda", "ur10_allegro"])
 def test_generated_fk_positions_and_backward(ops, oracle_lib, ident):
     """trk_fk_positions / trk_fk_positions_backward with all links selected run the generated kernels for the robots

@@ -467,3 +467,42 @@ def test_tree_robot_costs_of_configs_4_and_5(oracle_lib, name, prec):
     for fname, fl in (("self", FIELD_SELF), ("objects", FIELD_OBJECTS), ("ws", FIELD_WS)):
         assert np.array_equal(o.collision_fields(fl, g["link_pos"], None, prec), g[f"coll_{fname}"]), fname
         assert np.array_equal(o.collision_fields(fl, g["link_pos"], 0.0, prec), g[f"coll0_{fname}"]), fname
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_gp_prior_against_dense_definition_golden(oracle_lib, prec):
+    """The build-defined GP prior pinned a SECOND way (tests/golden/gp_prior.npz, oracle/gen_golden.py builddef): the dense
+    constant-velocity definition -- Phi(dt), Q = sigma^2 [[dt^3/3, dt^2/2], [dt^2/2, dt]] (x) I inverted NUMERICALLY, torch fp64
+    autograd -- against the oracle's closed-form factors: cost per trajectory, per factor, both gradients."""
+    g = gold("gp_prior")
+    for k in range(int(g["n_cases"])):
+        q, qd = g[f"q_{k}"], g[f"qd_{k}"]
+        dt, sigma, w = (float(v) for v in g[f"params_{k}"])
+        c, gq, gqd = oracle_lib.gp_prior(q, qd, dt, sigma, w, prec)
+        fc = oracle_lib.gp_factor_cost(q, qd, dt, sigma, w, prec)
+        tol = 2e-5 if prec == "f32" else 1e-9
+        big = max(np.abs(g[f"gq_{k}"]).max(), np.abs(g[f"gqd_{k}"]).max(), 1e-30)
+        assert rel_err(c, g[f"cost_{k}"]) < tol and rel_err(fc, g[f"factor_{k}"]) < tol, k
+        # a state's gradient is the difference of two factors' terms, each of the size of the largest entry
+        assert np.abs(gq - g[f"gq_{k}"]).max() < tol * big and np.abs(gqd - g[f"gqd_{k}"]).max() < tol * big, k
+        if q.shape[1] == 1:
+            assert np.all(c == 0) and np.all(gq == 0) and np.all(gqd == 0)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_gauss_newton_step_against_reference_jacobian_golden(oracle_lib, prec):
+    """The build-defined damped Gauss-Newton IK step pinned a SECOND way (tests/golden/ik_gn_panda.npz): the REFERENCE's stateful FK +
+    geometric Jacobian (robot_tree.py:218-248, fp32), scipy's rotation vector, `torch.linalg.solve` in fp64, the reference's
+    SE3_distance as the termination metric -- against orc_ik_gn_step (own FK walk, own quaternion log, own Cholesky)."""
+    g = gold("ik_gn_panda")
+    m = model("panda_arm_no_gripper")
+    o = oracle_lib.Oracle(m)
+    ee = m.name_to_idx[str(g["link"])]
+    for tag in ("a", "b"):
+        damping, lm_gain, step = (float(v) for v in g[f"params_{tag}"])
+        q_new, err = o.ik_gn_step(ee, g["H_target"], g["lower"], g["upper"], g["q0"], damping, lm_gain, step, prec)
+        dq = np.abs(g[f"q_new_{tag}"] - g["q0"])
+        # the golden's Jacobian and pose are the reference's fp32 numbers: the step agrees to fp32 accuracy x the system's conditioning
+        assert (np.abs(q_new - g[f"q_new_{tag}"]) <= 2e-5 + 2e-3 * dq).all(), tag
+        assert rel_err(err, g[f"err_{tag}"]) < 2e-5, tag
+    assert (np.abs(g["q_new_a"] - g["q0"]).max(1) > 1e-2).sum() >= 30           # the steps are real steps, not clamped no-ops

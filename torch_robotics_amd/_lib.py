@@ -34,6 +34,7 @@ EXPORTS = [
     "trk_interpolate_columns", "trk_interpolate_columns_backward", "trk_rollout_collision_via", "trk_traj_validate",
     "trk_scale_rows", "trk_jtj", "trk_pack_sums", "trk_pack_sums_scratch_bytes", "trk_rollout_is_specialized", "trk_ik_gn_steps", "trk_rollout_gp_cost_grad",
     "trk_spec_register_module", "trk_spec_layout_stamp",
+    "trk_mailbox_create", "trk_mailbox_ipc_handle", "trk_mailbox_connect", "trk_mailbox_exchange", "trk_mailbox_status", "trk_mailbox_destroy",
 ]
 
 
@@ -51,6 +52,12 @@ def build(verbose: bool = False) -> Path:
         raise TrkError(f"building libtrk.so failed:\n{res.stdout}\n{res.stderr}")
     if verbose:
         print(res.stdout)
+    # the native dispatcher ops are optional (torch_ops() returns None without them): a box without g++ or the torch headers keeps libtrk.so
+    res2 = subprocess.run(["make", "-C", str(_CSRC), "torch_ops"], capture_output=True, text=True)
+    if res2.returncode != 0:
+        import warnings
+        warnings.warn("libtrk_torch.so (native PyTorch dispatcher ops) was not built; the Python-registered ops serve instead:\n"
+                      + (res2.stdout + res2.stderr)[-2000:])
     return LIB_PATH
 
 
@@ -66,8 +73,12 @@ def torch_ops():
         _torch_ops_loaded = False
         if TORCH_OPS_PATH.exists() and os.environ.get("TRK_NO_NATIVE_OPS", "0") != "1":
             lib()                                   # libtrk.so first: the op library links against it
-            torch.ops.load_library(str(TORCH_OPS_PATH))
-            _torch_ops_loaded = True
+            try:
+                torch.ops.load_library(str(TORCH_OPS_PATH))
+                _torch_ops_loaded = True
+            except OSError as e:                    # e.g. built against another torch: say so once, use the Python-registered ops
+                import warnings
+                warnings.warn(f"{TORCH_OPS_PATH.name} could not be loaded ({e}); using the Python-registered dispatcher ops")
     return torch.ops.trk if _torch_ops_loaded else None
 
 
@@ -141,6 +152,13 @@ def lib():
     L.trk_pack_sums.argtypes = [vp, vp, i32, f32, vp, vp, i64, i32, i32, vp, vp, vp]
     L.trk_pack_sums_scratch_bytes.argtypes = [i32, i32]
     L.trk_pack_sums_scratch_bytes.restype = C.c_int64
+    L.trk_mailbox_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+    L.trk_mailbox_ipc_handle.argtypes = [vp, vp]
+    L.trk_mailbox_connect.argtypes = [vp, vp]
+    L.trk_mailbox_exchange.argtypes = [vp, vp, vp, vp]
+    L.trk_mailbox_status.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]
+    L.trk_mailbox_destroy.argtypes = [vp]
+    L.trk_mailbox_destroy.restype = None
     L.trk_jtj.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, i32, vp, vp]
     L.trk_scale_rows.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp]
     L.trk_point_set_create.argtypes = [vp, vp, vp, i32, C.POINTER(vp)]
@@ -154,7 +172,7 @@ def lib():
     for name in EXPORTS:
         fn = getattr(L, name)        # AttributeError here = the library does not export the ABI
         if name not in ("trk_last_error", "trk_model_destroy", "trk_cost_model_destroy", "trk_point_set_destroy",
-                        "trk_pack_sums_scratch_bytes"):
+                        "trk_pack_sums_scratch_bytes", "trk_mailbox_destroy"):
             fn.restype = C.c_int
     if L.trk_abi_version() != _abi.TRK_ABI_VERSION:
         raise TrkError("libtrk.so ABI version mismatch; rebuild it")

@@ -57,6 +57,11 @@ uint64_t model_hash(const TrkKinModelDesc* d) {
 std::vector<const SpecEntry*>& spec_registry() { static std::vector<const SpecEntry*> r; return r; }
 }  // namespace
 
+// error reporting / one-time initialisation for the library's other translation units (trk_exchange.hip)
+int trk_fail(int code, const char* msg) { return fail(code, msg); }
+int trk_hip_fail(int hip_error, const char* what) { return hip_fail((hipError_t)hip_error, what); }
+int trk_ensure_init(void) { return ensure_init(); }
+
 int trk_spec_register(const SpecEntry* e) {
     // the first four fields are the layout stamp in every version of SpecEntry; nothing else is read before they match
     if (!e || e->spec_abi_version != TRK_SPEC_ABI_VERSION || e->sizeof_args != sizeof(SpecArgs) + sizeof(IkArgs) + sizeof(IkGnArgs) ||

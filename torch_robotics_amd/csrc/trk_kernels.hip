@@ -2087,60 +2087,122 @@ k_reduce_sum_wide(const float* __restrict__ x, int64_t n, float* __restrict__ ou
 
 // ============================================================================================
 // What a batch-sharded planner exchanges: packed = [ sum cost | sum_b cost(b, h) (H) | sum_b gq(b, h, d) (H D) ]
-// of one rank's evaluation, in ONE launch and bit-reproducibly.  Stage 1: the B trajectories are cut into TRK_PACK_SLICES row
-// slices x 64-column tiles; each workgroup adds its slice of a tile (fixed order) and writes one partial row.  The LAST
-// workgroup to finish (an atomic ticket) adds the partial rows in slice order and the per-wavefront cost sums in index order --
-// the association order never depends on the timing.  cost [B, H]; gq [B, H, D]; block_sums [nb] (trk_rollout_cost_grad).
-// scratch: float[TRK_PACK_SLICES * (H + H D)] followed by one zero-initialised int (the ticket; the kernel leaves it zero).
+// of one rank's evaluation, in ONE launch and bit-reproducibly.  cost [B, H]; gq [B, H, D]; block_sums [nb] (trk_rollout_cost_grad).
+// The C = H + H D columns are cut into tiles of 64 UNITS (a unit = V consecutive columns: V = 4 -- one 16-byte load, 8 bytes of an fp16
+// gradient -- when H is a multiple of 4 and the arrays are aligned, else 1) and the B trajectories into `slices` row slices.  A workgroup
+// (512 threads = 64 units x 8 row lanes) adds its slice of a tile -- every load of a thread is independent, so the whole 8 MB of a
+// 4096 x 64 x 7 evaluation is in flight at once -- and writes one partial row piece.  The LAST workgroup of a tile to finish (one atomic
+// ticket per tile) adds the tile's partial rows in slice order (8 groups x slices / 8, then the groups in order): the association order
+// never depends on the timing, and the tail is one batch of <= 16 loads per thread instead of a serial pass over every slice.  Tile 0's
+// last workgroup also folds the per-wavefront cost sums (the association order of trk_reduce_sum) and traj_cost into out[0].
+// Round 5: 46 us -> ~4 us at 4096 x 64 x 7 (profiles/r05_exchange_trace_c2.csv has the old kernel, r05_kernel_stats_exchange_* the new one).
+// scratch: float[TRK_PACK_SLICES * C] followed by one zero-initialised int per tile (the tickets; the kernel leaves them zero).
 // ============================================================================================
-#define TRK_PACK_SLICES 64
+#define TRK_PACK_SLICES 128
+#define TRK_PACK_THREADS 512
 // G: element type of gq (fp32, or the fp16 gradient of the reduced-precision rollout); unscale = 1 / grad_scale of that gradient, applied
 // once to the fp32 column sums; traj_cost (nullable) [B]: a per-trajectory cost (the GP prior's) whose sum joins out[0].
-template <class G>
-__global__ void __launch_bounds__(256)
+template <class G, int V> struct PackVec;
+template <> struct PackVec<float, 4> { typedef float4 T; static __device__ __forceinline__ void add(float (&a)[4], const T& v) { a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w; } };
+template <> struct PackVec<float, 1> { typedef float T; static __device__ __forceinline__ void add(float (&a)[1], const T& v) { a[0] += v; } };
+typedef _Float16 trk_half4 __attribute__((ext_vector_type(4)));
+template <> struct PackVec<_Float16, 4> { typedef trk_half4 T; static __device__ __forceinline__ void add(float (&a)[4], const T& v) { a[0] += (float)v[0]; a[1] += (float)v[1]; a[2] += (float)v[2]; a[3] += (float)v[3]; } };
+template <> struct PackVec<_Float16, 1> { typedef _Float16 T; static __device__ __forceinline__ void add(float (&a)[1], const T& v) { a[0] += (float)v; } };
+
+template <class G, int V>
+__global__ void __launch_bounds__(TRK_PACK_THREADS)
 k_pack_sums(const float* __restrict__ cost, const G* __restrict__ gq, float unscale, const float* __restrict__ block_sums,
-            const float* __restrict__ traj_cost, int B, int H, int D, int64_t nb, float* __restrict__ scratch, float* __restrict__ out) {
-    __shared__ float part[256];
+            const float* __restrict__ traj_cost, int B, int H, int D, int64_t nb, int slices, float* __restrict__ scratch, float* __restrict__ out) {
+    __shared__ float part[8][64][V];
     __shared__ int is_last;
     const int C = H + H * D;                                 // columns: H of the cost matrix, then H D of the gradient matrix
-    const int tiles = (C + 63) / 64;
+    const int CU = C / V;                                    // units (V divides H, hence C)
+    const int tiles = (CU + 63) / 64;
     const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;   // column in the tile, row lane 0..3
-    const int col = tile * 64 + c;
-    const int rows_per = (B + TRK_PACK_SLICES - 1) / TRK_PACK_SLICES;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;   // unit in the tile, row lane 0..7
+    const int u = tile * 64 + c;
+    const int rows_per = (B + slices - 1) / slices;
     const int b0 = slice * rows_per, b1 = min(B, b0 + rows_per);
-    float acc = 0.0f;
-    if (col < C) {
-        if (col < H) { for (int b = b0 + rl; b < b1; b += 4) acc += cost[(int64_t)b * H + col]; }
-        else { const G* src = gq + (col - H); const int64_t stride = (int64_t)H * D; for (int b = b0 + rl; b < b1; b += 4) acc += (float)src[b * stride]; }
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.0f;
+    if (u < CU) {
+        const int col = u * V;
+        if (col < H) {
+            typedef typename PackVec<float, V>::T T;
+            const T* src = reinterpret_cast<const T*>(cost + col);
+            const int64_t stride = H / V;
+#pragma unroll 4
+            for (int b = b0 + rl; b < b1; b += 8) PackVec<float, V>::add(acc, src[b * stride]);
+        } else {
+            typedef typename PackVec<G, V>::T T;
+            const T* src = reinterpret_cast<const T*>(gq + (col - H));
+            const int64_t stride = (int64_t)H * D / V;
+#pragma unroll 4
+            for (int b = b0 + rl; b < b1; b += 8) PackVec<G, V>::add(acc, src[b * stride]);
+        }
     }
-    part[threadIdx.x] = acc;
+#pragma unroll
+    for (int k = 0; k < V; ++k) part[rl][c][k] = acc[k];
     __syncthreads();
-    int* ticket = reinterpret_cast<int*>(scratch + (size_t)TRK_PACK_SLICES * C);
-    if (rl == 0) {
-        if (col < C) scratch[(size_t)slice * C + col] = (part[c] + part[64 + c]) + (part[128 + c] + part[192 + c]);
+    int* ticket = reinterpret_cast<int*>(scratch + (size_t)TRK_PACK_SLICES * C) + tile;
+    if (rl == 0 && u < CU) {
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            scratch[(size_t)slice * C + u * V + k] = ((part[0][c][k] + part[1][c][k]) + (part[2][c][k] + part[3][c][k])) +
+                                                     ((part[4][c][k] + part[5][c][k]) + (part[6][c][k] + part[7][c][k]));
     }
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == slices - 1;
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    for (int k = threadIdx.x; k < C; k += 256) {
-        float tot = 0.0f;
-        for (int p = 0; p < TRK_PACK_SLICES; ++p) tot += scratch[(size_t)p * C + k];
-        out[1 + k] = k < H ? tot : tot * unscale;
-    }
-    float a = 0.0f;
-    for (int64_t i = threadIdx.x; i < nb; i += 256) a += block_sums[i];       // the association order of trk_reduce_sum
-    if (traj_cost) { float t = 0.0f; for (int i = threadIdx.x; i < B; i += 256) t += traj_cost[i]; a += t; }
-    part[threadIdx.x] = a;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+    // the tile's partial rows: row lane g adds the slices g * per .. (g + 1) * per - 1 in order, then the 8 groups in order
+    {
+        const int per = (slices + 7) / 8;
+        const int p0 = rl * per, p1 = min(slices, p0 + per);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.0f;
+        if (u < CU) {
+            typedef typename PackVec<float, V>::T T;
+            const T* src = reinterpret_cast<const T*>(scratch + u * V);
+            const int64_t stride = C / V;
+#pragma unroll 4
+            for (int p = p0; p < p1; ++p) PackVec<float, V>::add(acc, src[p * stride]);
+        }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < V; ++k) part[rl][c][k] = acc[k];
+        __syncthreads();
+        if (rl == 0 && u < CU) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) tot += part[g][c][k];
+                const int col = u * V + k;
+                out[1 + col] = col < H ? tot : tot * unscale;
+            }
+        }
     }
-    if (threadIdx.x == 0) { out[0] = part[0]; *ticket = 0; }
+    if (tile == 0) {
+        __syncthreads();
+        float* flat = &part[0][0][0];                           // >= 512 floats
+        float a = 0.0f;
+        if (threadIdx.x < 256) {
+            for (int64_t i = threadIdx.x; i < nb; i += 256) a += block_sums[i];       // the association order of trk_reduce_sum
+            if (traj_cost) { float t = 0.0f; for (int i = threadIdx.x; i < B; i += 256) t += traj_cost[i]; a += t; }
+            flat[threadIdx.x] = a;
+        }
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) flat[threadIdx.x] += flat[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[0] = flat[0];
+    }
+    if (threadIdx.x == 0) *ticket = 0;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2393,13 +2455,24 @@ void trk_launch_traj_diff_norm_sum(const float* x, int64_t B, int H, int S, int 
     hipLaunchKernelGGL(k_traj_diff_norm_sum, dim3((unsigned)B), dim3(256), 0, st, x, H, S, c0, D, out);
 }
 
-size_t trk_pack_scratch_floats(int H, int D) { return (size_t)TRK_PACK_SLICES * (H + (size_t)H * D) + 1; }
+size_t trk_pack_scratch_floats(int H, int D) { const size_t C = H + (size_t)H * D; return (size_t)TRK_PACK_SLICES * C + (C + 63) / 64 + 1; }
+template <class G, int V>
+static void launch_pack(const float* cost, const void* gq, float unscale, const float* block_sums, const float* traj_cost, int B, int H, int D,
+                        int64_t nb, float* scratch, float* out, hipStream_t st) {
+    const int C = H + H * D, tiles = (C / V + 63) / 64;
+    const int slices = max(1, min(TRK_PACK_SLICES, (B + 7) / 8));
+    hipLaunchKernelGGL((k_pack_sums<G, V>), dim3(slices * tiles), dim3(TRK_PACK_THREADS), 0, st, cost, static_cast<const G*>(gq), unscale,
+                       block_sums, traj_cost, B, H, D, nb, slices, scratch, out);
+}
 void trk_launch_pack_sums(const float* cost, const void* gq, int grad_f16, float unscale, const float* block_sums, const float* traj_cost,
                           int B, int H, int D, int64_t nb, float* scratch, float* out, hipStream_t st) {
-    const int C = H + H * D;
-    const dim3 grid(TRK_PACK_SLICES * ((C + 63) / 64));
-    if (grad_f16) hipLaunchKernelGGL(k_pack_sums<_Float16>, grid, dim3(256), 0, st, cost, static_cast<const _Float16*>(gq), unscale, block_sums, traj_cost, B, H, D, nb, scratch, out);
-    else hipLaunchKernelGGL(k_pack_sums<float>, grid, dim3(256), 0, st, cost, static_cast<const float*>(gq), unscale, block_sums, traj_cost, B, H, D, nb, scratch, out);
+    // the 16-byte (fp16: 8-byte) unit path needs whole units per row and aligned rows
+    const bool vec = (H % 4 == 0) && (reinterpret_cast<uintptr_t>(cost) % 16 == 0) && (reinterpret_cast<uintptr_t>(scratch) % 16 == 0) &&
+                     (reinterpret_cast<uintptr_t>(gq) % (grad_f16 ? 8 : 16) == 0);
+    if (grad_f16) { if (vec) launch_pack<_Float16, 4>(cost, gq, unscale, block_sums, traj_cost, B, H, D, nb, scratch, out, st);
+                    else launch_pack<_Float16, 1>(cost, gq, unscale, block_sums, traj_cost, B, H, D, nb, scratch, out, st); }
+    else { if (vec) launch_pack<float, 4>(cost, gq, unscale, block_sums, traj_cost, B, H, D, nb, scratch, out, st);
+           else launch_pack<float, 1>(cost, gq, unscale, block_sums, traj_cost, B, H, D, nb, scratch, out, st); }
 }
 
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st) {

@@ -77,3 +77,7 @@ void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st
 void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st);
 // raises the dynamic-LDS ceiling of every kernel once (gfx950: 160 KiB per workgroup)
 int trk_kernels_init(void);
+// trk_capi.hip's error string / initialisation, for the other translation units of the library
+int trk_fail(int code, const char* msg);
+int trk_hip_fail(int hip_error, const char* what);
+int trk_ensure_init(void);

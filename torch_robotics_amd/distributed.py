@@ -129,3 +129,107 @@ class RcclAllReduce:
             self.close()
         except Exception:
             pass
+
+
+class MailboxAllReduce:
+    """The planner's one exchange as a PEER-TO-PEER MAILBOX (`trk_mailbox_*`, csrc/trk_exchange.hip; SURVEY.md 8e's alternative to
+    the all-reduce): every rank stores its packed row of partial sums straight into a slot of every peer's mailbox -- device memory
+    mapped through hipIpc handles, one xGMI hop, all peers in parallel --, raises a sequence flag, waits for the flags of its own
+    mailbox and adds the rows in RANK ORDER (bit-identical on every rank and on every run).  One single-workgroup kernel per
+    exchange, capturable into a hipGraph; no host work, no collective library on the data path.  The handles travel once, at
+    construction, through the already initialised `torch.distributed` group (any backend).
+
+        mb = MailboxAllReduce(device, n_floats)          # collective over the group: every rank constructs it
+        mb.exchange(packed, out, stream)                  # out = sum over ranks of packed; asynchronous
+
+    `validate()` runs a known-answer exchange on all ranks and returns False (instead of hanging) when the peer stores do not
+    arrive -- the caller then keeps the RCCL path (`all_reduce_sum_`)."""
+
+    ALLOC_KINDS = ("uncached", "fine-grained", "plain")
+
+    def __init__(self, device, n_floats: int, n_slots: int = 4, group: Optional[dist.ProcessGroup] = None,
+                 rank: Optional[int] = None, world: Optional[int] = None):
+        from ._lib import check, lib
+        self._lib, self._check = lib(), check
+        self.device = torch.device(device)
+        have_group = dist.is_available() and dist.is_initialized()
+        self.rank = int(rank if rank is not None else (dist.get_rank(group) if have_group else 0))
+        self.world = int(world if world is not None else (dist.get_world_size(group) if have_group else 1))
+        self.n_floats, self.group = int(n_floats), group
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self._lib.trk_mailbox_create(self.world, self.rank, self.n_floats, int(n_slots), C.byref(self._h))
+            err = None if rc == 0 else self._lib.trk_last_error().decode("utf-8", "replace")
+            handle = C.create_string_buffer(64)
+            if err is None and self.world > 1:
+                rc = self._lib.trk_mailbox_ipc_handle(self._h, handle)
+                err = None if rc == 0 else self._lib.trk_last_error().decode("utf-8", "replace")
+            if self.world > 1:
+                # every rank takes part in the gather even when its own allocation failed: the others must not wait for it forever
+                if not have_group:
+                    raise RuntimeError("MailboxAllReduce: more than one rank needs an initialised torch.distributed group to share the handles")
+                box = [None] * self.world
+                dist.all_gather_object(box, (err, bytes(handle.raw)), group=group)
+                errs = [e for e, _ in box if e is not None]
+                if errs:
+                    self.close()
+                    raise RuntimeError(f"MailboxAllReduce: a rank could not create its mailbox: {errs[0]}")
+                blob = b"".join(h for _, h in box)
+                rc = self._lib.trk_mailbox_connect(self._h, blob)
+                err = None if rc == 0 else self._lib.trk_last_error().decode("utf-8", "replace")
+                box2 = [None] * self.world
+                dist.all_gather_object(box2, err, group=group)
+                errs = [e for e in box2 if e is not None]
+                if errs:
+                    self.close()
+                    raise RuntimeError(f"MailboxAllReduce: a rank could not map its peers' mailboxes: {errs[0]}")
+            elif err is not None:
+                self.close()
+                raise RuntimeError(f"MailboxAllReduce: {err}")
+
+    def exchange(self, packed: torch.Tensor, out: torch.Tensor, stream: Optional[int] = None) -> None:
+        """out[i] = sum over ranks (in rank order) of packed[i]; both contiguous fp32 device buffers of n_floats; asynchronous on
+        `stream` (raw HIP stream handle; default: torch's current stream).  out may not alias packed."""
+        for name, t in (("packed", packed), ("out", out)):
+            if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != self.n_floats:
+                raise ValueError(f"MailboxAllReduce.exchange({name}): expected a contiguous float32 tensor of {self.n_floats} elements on {self.device}")
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.trk_mailbox_exchange(self._h, packed.data_ptr(), out.data_ptr(), stream), "trk_mailbox_exchange")
+
+    def status(self):
+        """(exchanges issued, time-outs seen, allocation kind); synchronises with the device."""
+        n, t, k = C.c_int64(), C.c_int64(), C.c_int32()
+        with torch.cuda.device(self.device):
+            self._check(self._lib.trk_mailbox_status(self._h, C.byref(n), C.byref(t), C.byref(k)), "trk_mailbox_status")
+        return int(n.value), int(t.value), self.ALLOC_KINDS[k.value] if 0 <= k.value < 3 else "?"
+
+    def validate(self, rounds: int = 6) -> bool:
+        """Known-answer exchanges (more rounds than slots, so that slot reuse is exercised): every rank contributes
+        (rank + 1) * (i + round) and must read world (world + 1) / 2 * (i + round).  Collective: True only if EVERY rank saw the
+        right sums and no time-out."""
+        idx = torch.arange(self.n_floats, device=self.device, dtype=torch.float32)
+        out = torch.empty(self.n_floats, device=self.device, dtype=torch.float32)
+        ok = True
+        for r in range(rounds):
+            packed = (idx + float(r)) * float(self.rank + 1)
+            self.exchange(packed, out)
+            expect = (idx + float(r)) * float(self.world * (self.world + 1) // 2)
+            ok = ok and bool(torch.equal(out, expect))          # the comparison synchronises
+        ok = ok and self.status()[1] == 0
+        if self.world > 1:
+            flag = torch.tensor([1.0 if ok else 0.0], device=self.device if dist.get_backend(self.group) != "gloo" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = bool(flag.item() > 0.5)
+        return ok
+
+    def close(self) -> None:
+        h, self._h = self._h, C.c_void_p()
+        if h:
+            self._lib.trk_mailbox_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

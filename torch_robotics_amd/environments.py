@@ -166,8 +166,11 @@ class ObjectField(PrimitiveShapeField):                      # primitives.py:346
 
     def compute_signed_distance(self, x):
         """x (..., 3) on the GPU -> (...) signed distance (differentiable w.r.t. x)."""
-        if self._cm is None or self._cm.device != x.device:
+        # keyed by the device, the pose version AND the primitive fields' geometry versions: `field.centers = new` must be seen here
+        key = (x.device, self._version) + tuple(k for f in self.fields for k in f.array_ids())
+        if self._cm is None or self._cm_key != key:
             self._cm = ops.CostHandle(CostModelSpec(n_links_in=1, objects=[self.as_object()]), x.device)
+            self._cm_key = key
         flat = x.reshape(-1, 3)
         if torch.is_grad_enabled() and x.requires_grad:
             return _SDFPoints.apply(flat.contiguous(), self._cm).reshape(x.shape[:-1])

@@ -151,6 +151,10 @@ class PlanningTask(Task):
             if not self._has_tree:                         # no kinematics: only the cost model is needed
                 self._fused = (None, ops.CostHandle(spec, device), key)
                 return self._fused[0], self._fused[1]
+            if self._jit_failed and getattr(self, "_jit_error", None) is not None and os.environ.get("TRK_ALLOW_TABLE_DRIVEN", "0") != "1":
+                raise RuntimeError(f"PlanningTask: no generated kernel serves this robot / collision model and compiling one failed earlier "
+                                   f"({type(self._jit_error).__name__}: {self._jit_error}).  Set TRK_ALLOW_TABLE_DRIVEN=1 to run the ~10 x "
+                                   f"slower table-driven kernels instead.") from self._jit_error
             self._fused = (self.robot.diff_panda._handle, ops.CostHandle(spec, device), key)
             from . import jit
             if self.auto_specialize and not self._jit_failed and jit.generatable(spec, getattr(self.robot, "has_extra_points", False)):
@@ -167,6 +171,8 @@ class PlanningTask(Task):
                     # HBM roofline), so running them silently is a performance bug: it is an error unless the caller allows it.
                     self._jit_failed = True
                     if os.environ.get("TRK_ALLOW_TABLE_DRIVEN", "0") != "1":
+                        self._fused = None          # EVERY later call raises too (below): a caught / retried error must not degrade silently
+                        self._jit_error = e
                         raise RuntimeError(
                             f"PlanningTask: no generated kernel serves this robot / collision model and compiling one failed "
                             f"({type(e).__name__}: {e}).  Set TRK_ALLOW_TABLE_DRIVEN=1 (or auto_specialize=False / TRK_NO_JIT=1) to run "
