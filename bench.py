@@ -439,20 +439,33 @@ def main():
 
     slot_free = [None] * n_slots        # per exchange buffer: the side-stream event after which it may be packed again
 
+    mb_pending = [None]                 # eager mailbox mode: the ring slot whose rows have been sent but not yet received
+
+    def mailbox_flush():
+        if mb_pending[0] is not None:
+            mailbox.recv(reduced[mb_pending[0]], stream.cuda_stream)
+            mb_pending[0] = None
+
     def reduce_slot(pl, k):
         # sums of the latest evaluation -> one small all-reduce, off the launch stream.  The buffers are a ring: before a slot is
         # packed again the launch stream waits for the collective that last used it (a planner's bounded look-ahead) -- with one
         # exchange per step (`multi_gpu.every_step`) that is what ties the launch rate to the exchange rate.
         buf = packed[k]
+        if mailbox is not None:
+            # the mailbox needs no second stream: SEND (stores + flag, never waits) right behind the pack; the RECEIVE of this exchange
+            # is issued later on the same stream -- before the next exchange or at the end of run() -- when the peers' rows have arrived
+            mailbox_flush()
+            pack_sums(pl, buf)
+            mailbox.send(buf, stream.cuda_stream)
+            mb_pending[0] = k
+            return
         if slot_free[k] is not None:
             stream.wait_event(slot_free[k])
         pack_sums(pl, buf)
         ev = torch.cuda.Event()
         ev.record(stream)
         side.wait_event(ev)
-        if mailbox is not None:
-            mailbox.exchange(buf, reduced[k], side.cuda_stream)
-        elif native is not None:
+        if native is not None:
             native.all_reduce_sum_(buf, side.cuda_stream)
         else:
             with torch.cuda.stream(side):
@@ -477,13 +490,13 @@ def main():
     S_live = [S]                 # becomes 0 if a capture fails
     gstream = torch.cuda.Stream(dev) if S else None
 
-    gside = torch.cuda.Stream(dev) if (S and mailbox is not None) else None      # the exchange branch of a captured interval
-
     def graph_for(pl, segs):
         """The graph of `segs` = (a0, a1, ..., ak): a0 steps of plan pl, exchange, a1 steps, exchange, ..., ak steps (k exchanges; an int
-        = that many plain steps).  An exchange inside a graph is the mailbox form: trk_pack_sums on the launch branch, then
-        trk_mailbox_exchange on a forked branch that runs beside the following steps and joins at the end of the graph; the exchanges of
-        a graph are chained on that branch (a rank's exchanges run in order).  Captured once, launched once; None when capture is off / failed."""
+        = that many plain steps).  An exchange inside a graph is the mailbox form, all on ONE stream: trk_pack_sums + trk_mailbox_send
+        behind the step whose sums travel, trk_mailbox_recv behind the steps of the next segment -- by then the peers' rows are there,
+        the wait costs nothing.  (A forked branch for the exchange was measured first: HIP serialised the branch in front of the
+        following steps anyway and the forked graph's launches came in bursts with 4 - 9 us gaps, profiles/r05_exchange_trace_c2_fork.txt.)
+        Captured once, launched once; None when capture is off / failed."""
         if not S_live[0]:
             return None
         segs = (segs,) if isinstance(segs, int) else tuple(segs)
@@ -500,17 +513,16 @@ def main():
                 g = torch.cuda.CUDAGraph()
                 # thread-local capture mode: the process group's watchdog thread may query events while this thread captures
                 with torch.cuda.graph(g, stream=gstream, capture_error_mode="thread_local"):
-                    cur = torch.cuda.current_stream(dev)
+                    cur = torch.cuda.current_stream(dev).cuda_stream
                     for j, n in enumerate(segs):
-                        if j > 0:                               # exchange j - 1: pack here, the mailbox kernel on the side branch
+                        if j > 0:                               # exchange j - 1: pack + send here, its receive behind the NEXT segment
                             k = (j - 1) % n_slots
-                            pack_sums(pl, packed[k], cur.cuda_stream)
-                            gside.wait_stream(cur)
-                            mailbox.exchange(packed[k], reduced[k], gside.cuda_stream)
+                            pack_sums(pl, packed[k], cur)
+                            mailbox.send(packed[k], cur)
                         for i in range(n):
-                            fn(bs_ptr, cur.cuda_stream)
-                    if len(segs) > 1:
-                        cur.wait_stream(gside)                   # join
+                            fn(bs_ptr, cur)
+                        if j > 0:
+                            mailbox.recv(reduced[(j - 1) % n_slots], cur)
                 g.replay()                                      # the first launch of an instantiated graph uploads it
                 torch.cuda.synchronize(dev)
             except Exception as e:                              # a box whose runtime refuses the capture still measures: eager loop
@@ -598,6 +610,8 @@ def main():
             else:
                 reduce_slot(pl, slot[0] % n_slots)
                 slot[0] += 1
+        if mailbox is not None:
+            mailbox_flush()
 
     flag = torch.zeros(1, **ta)
 
@@ -783,7 +797,9 @@ def main():
         t_x = time.perf_counter()
         for k in range(10):
             reduce_slot(plan, (slot[0] + k) % n_slots)
-            side.synchronize()
+            if mailbox is not None:
+                mailbox_flush()
+            torch.cuda.synchronize(dev)
         exchange_us = (time.perf_counter() - t_x) / 10 * 1e6
         wl.step(bs_ptr, stream.cuda_stream)
         local = torch.zeros(1 + H + H * D, **ta)
@@ -821,7 +837,7 @@ def main():
         out["multi_gpu"] = {
             "backend": dist.get_backend(), "ranks": dist.get_world_size(), "reduce_every": args.reduce_every, "reduce_every_effective": R,
             "exchange_via": ("peer-to-peer mailbox (trk_mailbox_exchange: stores into every peer's device memory, rows added in rank order"
-                             + ("; captured into the step graphs)" if S_live[0] else "; eager, on a side stream)")) if mailbox is not None else
+                             + ("; captured into the step graphs)" if S_live[0] else "; eager, on the launch stream)")) if mailbox is not None else
                             "librccl ncclAllReduce (ctypes)" if native is not None else "torch.distributed.all_reduce",
             **({"mailbox": {"exchanges": mb_status[0], "timeouts": mb_status[1], "memory": mb_status[2], "sums_bit_identical_to_rank_order": bitwise}}
                if mailbox is not None else {"mailbox": None, "mailbox_note": mailbox_note}),

@@ -618,12 +618,12 @@ int trk_debug_set_stamp_buffer(void* device_u64);
 /* The one buffer a batch-sharded planner all-reduces: packed [1 + H + H*D] =
  *   [ sum of all costs | sum over trajectories of cost(b, h) | sum over trajectories of gq(b, h, d) ]
  * of ONE rank's evaluation -- cost [batch, horizon], gq [batch, horizon, dof] and cost_block_sums as written by
- * trk_rollout_cost_grad -- in one launch, bit-reproducibly (fixed association order; packed[0] equals trk_reduce_sum of the block
- * sums).  gq is of grad_dtype (TRK_F32, or TRK_F16: the gradient of trk_rollout_cost_grad_f16) and holds grad_scale x the
+ * trk_rollout_cost_grad -- bit-reproducibly (fixed association order; packed[0] equals trk_reduce_sum of the block sums; two
+ * small launches: partial column sums of row slices, then their fold).  gq is of grad_dtype (TRK_F32, or TRK_F16: the gradient of trk_rollout_cost_grad_f16) and holds grad_scale x the
  * gradient; the fp32 column sums are divided by grad_scale once, so `packed` is always unscaled fp32.  traj_cost (nullable)
  * [batch]: a per-trajectory cost (trk_gp_prior_cost_grad's) whose sum is added to packed[0].
- * scratch: DEVICE memory of trk_pack_sums_scratch_bytes(horizon, dof) bytes, zero-initialised ONCE by the caller (its last
- * word is a ticket the kernel returns to zero); one scratch per stream that may run the call concurrently. */
+ * scratch: DEVICE memory of trk_pack_sums_scratch_bytes(horizon, dof) bytes (the partial rows); one scratch per stream that may
+ * run the call concurrently. */
 int64_t trk_pack_sums_scratch_bytes(int32_t horizon, int32_t dof);
 int trk_pack_sums(const float* cost, const void* gq, int32_t grad_dtype, float grad_scale, const float* cost_block_sums,
                   const float* traj_cost, int64_t batch, int32_t horizon, int32_t dof, float* scratch, float* packed,
@@ -636,10 +636,13 @@ int trk_pack_sums(const float* cost, const void* gq, int32_t grad_dtype, float g
  * n_slots x world rows of n_floats; trk_mailbox_exchange stores the caller's packed row (trk_pack_sums' output) into the
  * rank's row of EVERY mailbox (one xGMI hop, all peers in parallel), raises a sequence flag, waits for the `world` flags of
  * its own mailbox and writes the sum of the `world` rows, added in rank order (bit-identical on every rank and run), to out.
- * One single-workgroup kernel per call, asynchronous on `stream`; the sequence number lives in device memory, so the call can
- * be captured into a hipGraph and replayed.  All ranks must issue the same sequence of exchanges; the exchanges of one rank
- * must run in stream order.  A rank that waits longer than TRK_MAILBOX_TIMEOUT_S (environment, default 5 s) for a flag
- * gives up, counts a time-out (trk_mailbox_status) and writes an incomplete sum instead of hanging the GPU.
+ * trk_mailbox_exchange = trk_mailbox_send (the stores and the flag: never waits) + trk_mailbox_recv (the wait and the sum); a
+ * planner sends right after the evaluation whose sums travel and receives some evaluations later, when the peers' rows have
+ * arrived -- the wait leaves the critical path without a second stream.  Single-workgroup kernels, asynchronous on `stream`;
+ * the sequence numbers live in device memory, so the calls can be captured into a hipGraph and replayed.  All ranks must issue
+ * the same sequence of exchanges; on one rank send k, recv k, send k + 1, ... must run in that (stream) order.  A rank that
+ * waits longer than TRK_MAILBOX_TIMEOUT_S (environment, default 5 s) for a flag gives up, counts a time-out
+ * (trk_mailbox_status) and writes an incomplete sum instead of hanging the GPU.
  *   create:     allocates the local mailbox (uncached / fine-grained device memory that hipIpcGetMemHandle accepts).
  *   ipc_handle: writes the TRK_MAILBOX_HANDLE_BYTES bytes another process passes to connect (exchange them with any host
  *               transport, e.g. torch.distributed.all_gather_object).
@@ -651,6 +654,8 @@ typedef struct TrkMailbox TrkMailbox;
 int trk_mailbox_create(int32_t world, int32_t rank, int32_t n_floats, int32_t n_slots, TrkMailbox** out);
 int trk_mailbox_ipc_handle(const TrkMailbox* mb, void* handle /* host, TRK_MAILBOX_HANDLE_BYTES */);
 int trk_mailbox_connect(TrkMailbox* mb, const void* handles /* host */);
+int trk_mailbox_send(TrkMailbox* mb, const float* packed, trk_stream_t stream);
+int trk_mailbox_recv(TrkMailbox* mb, float* out, trk_stream_t stream);
 int trk_mailbox_exchange(TrkMailbox* mb, const float* packed, float* out, trk_stream_t stream);
 int trk_mailbox_status(const TrkMailbox* mb, int64_t* n_exchanges, int64_t* n_timeouts, int32_t* alloc_kind);
 void trk_mailbox_destroy(TrkMailbox* mb);

@@ -203,5 +203,31 @@ def test_graphed_cost_backward_replays_the_eager_result():
         assert torch.equal(g.total, c_ref.sum())
         with torch.no_grad():                               # what an optimiser step does: q moves in place
             q.add_(0.05 * torch.randn(q.shape, device=DEV, generator=gen))
+    assert g.plan is not None and g.graph is None           # reduce=torch.sum is recognised: a replay is ONE launch of the fused rollout
+    assert q.grad.data_ptr() == g.plan.gq.data_ptr()         # ... writing straight into q.grad's storage
+    q.grad = None                                            # an optimiser's zero_grad(set_to_none=True): the next replay rebinds it
+    c = g.replay()
+    c_ref, g_ref = eager(q)
+    assert q.grad is g.grad and torch.equal(q.grad, g_ref) and torch.equal(c, c_ref)
+    # any other reduction is captured as a graph (torch's whole-network recipe) and replays the eager result too
+    q2 = q.detach().clone().requires_grad_(True)
+    g2 = task.capture_cost_backward(q2, reduce=torch.mean)
+    assert g2.plan is None and g2.graph is not None
+    for trip in range(2):
+        x = q2.detach().clone().requires_grad_(True)
+        c_e = task.compute_collision_cost(x)
+        c_e.mean().backward()
+        c = g2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(c, c_e.detach()) and torch.equal(q2.grad, x.grad) and torch.equal(g2.total, c_e.mean())
+        with torch.no_grad():
+            q2.add_(0.05 * torch.randn(q2.shape, device=DEV, generator=gen))
+    # (N, D) input: cost comes back as (N, 1) like the eager call
+    q3 = robot.random_q(300, generator=gen).contiguous().requires_grad_(True)
+    g3 = task.capture_cost_backward(q3)
+    x = q3.detach().clone().requires_grad_(True)
+    c_e = task.compute_collision_cost(x)
+    c_e.sum().backward()
+    assert g3.plan is not None and torch.equal(g3.replay(), c_e.detach()) and torch.equal(q3.grad, x.grad)
     with pytest.raises(ValueError, match="leaf"):
         task.capture_cost_backward(q.detach() * 1.0)

@@ -48,11 +48,19 @@ for it in range(7):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), ref)
+# send now, receive later (what a planner does: the wait is then off the critical path); nothing but the order is required
+for it in range(5):
+    row = torch.randn(n, device=dev, generator=gen)
+    mb.send(row)
+    filler = torch.randn(1 << 20, device=dev).sum()    # unrelated work between the halves
+    mb.recv(out)
+    ref = row.cpu().clone(); dist.all_reduce(ref)
+    assert torch.equal(out.cpu(), ref)
 n_ex, n_to, kind = mb.status()
-assert n_ex == 6 + 11 + 1 + 7 and n_to == 0, (n_ex, n_to)
+assert n_ex == 6 + 11 + 1 + 7 + 5 and n_to == 0, (n_ex, n_to)
 dist.barrier()
 mb.close()
-print("rank", rank, "ok", kind, flush=True)
+sys.stdout.write(f"rank-{rank}-ok-{kind}\n"); sys.stdout.flush()
 dist.destroy_process_group()
 """
 
@@ -67,7 +75,7 @@ def test_mailbox_two_processes_one_gpu(tmp_path):
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29561", str(script)], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
-    assert "rank 0 ok" in p.stdout and "rank 1 ok" in p.stdout
+    assert "rank-0-ok" in p.stdout and "rank-1-ok" in p.stdout, p.stdout[-500:]
 
 
 @pytest.mark.gpu

@@ -6,13 +6,15 @@
 // kernel and host enqueue (~50 - 80 us end to end through RCCL at this size).  Here every rank STORES its packed row straight into a
 // slot of every peer's mailbox (device memory mapped through hipIpc*; one xGMI hop, all peers in parallel), then a sequence flag;
 // the consumer waits for the N flags of its own mailbox and adds the N rows IN RANK ORDER -- every rank computes the same bits, and
-// the same bits on every run.  One single-workgroup kernel per exchange; it takes its sequence number from a device counter, so it
-// can be captured into a hipGraph and replayed.
+// the same bits on every run.  Two single-workgroup kernels per exchange -- SEND (stores + flag, never waits) and RECEIVE (waits for
+// the flags, adds the rows) -- so that a planner can send right after the evaluation whose sums travel and receive several
+// evaluations later, when the peers' rows have long arrived: the wait is then off the critical path without a second stream.  Both
+// take their sequence numbers from device counters, so they can be captured into a hipGraph and replayed.
 //
 // Memory: the mailbox is allocated uncached / fine-grained (hipExtMallocWithFlags) so that a peer's stores over xGMI are visible to
 // the owner's loads without a kernel boundary; all mailbox accesses are system-scope atomics (sc0 sc1 loads / stores) on top of that.
-// Slot reuse: with >= 2 slots and the exchange kernels of a rank running in stream order, slot s is overwritten for exchange
-// k + n_slots only after every peer has finished exchange k + n_slots - 2 >= k, i.e. has read exchange k's rows.
+// Slot reuse: a rank alternates send k, receive k in stream order.  When it sends k it has finished receive k - 1, which needed every
+// peer's send k - 1, which followed that peer's receive k - 2: with >= 2 slots nobody overwrites a row that has not been read.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -31,7 +33,7 @@ struct TrkMailbox {
     int alloc_kind = -1;                      // 0 uncached, 1 fine-grained, 2 plain hipMalloc
     void* local = nullptr;
     void* peers[TRK_MAILBOX_MAX_RANKS] = {};
-    unsigned* counter = nullptr;              // [0] exchange sequence number, [1] time-outs seen
+    unsigned* counter = nullptr;              // [0] rows sent, [1] time-outs seen, [2] sums received
     bool connected = false;
     double timeout_s = 5.0;
 };
@@ -50,17 +52,17 @@ struct MailboxArgs {
 __device__ __forceinline__ void st_sys(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ unsigned ld_sys(const unsigned* p) { return __hip_atomic_load(const_cast<unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// counter[0]: rows sent, counter[1]: time-outs seen, counter[2]: sums received.  A rank alternates send k, receive k in stream order.
 __global__ void __launch_bounds__(256)
-k_mailbox_exchange(MailboxArgs a) {
+k_mailbox_send(MailboxArgs a) {
     __shared__ unsigned s_seq;
-    __shared__ int s_timed_out;
     const int tid = threadIdx.x;
-    if (tid == 0) { const unsigned v = a.counter[0] + 1u; a.counter[0] = v; s_seq = v; s_timed_out = 0; }
+    if (tid == 0) { const unsigned v = a.counter[0] + 1u; a.counter[0] = v; s_seq = v; }
     __syncthreads();
     const unsigned seq = s_seq;
     const unsigned slot = seq % (unsigned)a.n_slots;
     const size_t row = ((size_t)slot * a.world + a.rank) * a.stride;
-    // send: my row into slot [slot][rank] of every mailbox (my own included), then the flag
+    // my row into slot [slot][rank] of every mailbox (my own included), then the flag
     for (int p = 0; p < a.world; ++p) {
         unsigned* dst = a.base[p] + row;
         for (int i = tid; i < a.n; i += 256) st_sys(dst + i, __float_as_uint(a.packed[i]));
@@ -70,7 +72,18 @@ k_mailbox_exchange(MailboxArgs a) {
     if (tid < a.world)
         __hip_atomic_store(a.base[tid] + a.flag_off + ((size_t)slot * a.world + a.rank) * TRK_MAILBOX_FLAG_STRIDE, seq, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
-    // receive: the flags of all writers in MY mailbox
+}
+
+__global__ void __launch_bounds__(256)
+k_mailbox_recv(MailboxArgs a) {
+    __shared__ unsigned s_seq;
+    __shared__ int s_timed_out;
+    const int tid = threadIdx.x;
+    if (tid == 0) { const unsigned v = a.counter[2] + 1u; a.counter[2] = v; s_seq = v; s_timed_out = 0; }
+    __syncthreads();
+    const unsigned seq = s_seq;
+    const unsigned slot = seq % (unsigned)a.n_slots;
+    // the flags of all writers in MY mailbox
     if (tid < a.world) {
         unsigned* f = a.base[a.rank] + a.flag_off + ((size_t)slot * a.world + tid) * TRK_MAILBOX_FLAG_STRIDE;
         const unsigned long long t0 = wall_clock64();
@@ -170,23 +183,44 @@ int trk_mailbox_connect(TrkMailbox* mb, const void* handles) {
     return TRK_OK;
 }
 
-int trk_mailbox_exchange(TrkMailbox* mb, const float* packed, float* out, trk_stream_t stream) {
-    if (!mb || !packed || !out) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_exchange: null argument");
-    if (!mb->connected) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_exchange: trk_mailbox_connect has not been called");
+namespace {
+MailboxArgs mailbox_args(const TrkMailbox* mb, const float* packed, float* out) {
     MailboxArgs a;
     for (int p = 0; p < TRK_MAILBOX_MAX_RANKS; ++p) a.base[p] = static_cast<unsigned*>(p < mb->world ? mb->peers[p] : nullptr);
     a.world = mb->world; a.rank = mb->rank; a.n = mb->n_floats; a.stride = mb->stride; a.n_slots = mb->n_slots;
     a.flag_off = (unsigned)mb->flag_off; a.counter = mb->counter; a.packed = packed; a.out = out;
     a.timeout_ticks = (unsigned long long)(mb->timeout_s * 1e8);
-    hipLaunchKernelGGL(k_mailbox_exchange, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    return a;
+}
+}  // namespace
+
+int trk_mailbox_send(TrkMailbox* mb, const float* packed, trk_stream_t stream) {
+    if (!mb || !packed) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_send: null argument");
+    if (!mb->connected) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_send: trk_mailbox_connect has not been called");
+    hipLaunchKernelGGL(k_mailbox_send, dim3(1), dim3(256), 0, (hipStream_t)stream, mailbox_args(mb, packed, nullptr));
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return trk_hip_fail((int)e, "trk_mailbox_exchange: launch");
+    if (e != hipSuccess) return trk_hip_fail((int)e, "trk_mailbox_send: launch");
     return TRK_OK;
+}
+
+int trk_mailbox_recv(TrkMailbox* mb, float* out, trk_stream_t stream) {
+    if (!mb || !out) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_recv: null argument");
+    if (!mb->connected) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_recv: trk_mailbox_connect has not been called");
+    hipLaunchKernelGGL(k_mailbox_recv, dim3(1), dim3(256), 0, (hipStream_t)stream, mailbox_args(mb, nullptr, out));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return trk_hip_fail((int)e, "trk_mailbox_recv: launch");
+    return TRK_OK;
+}
+
+int trk_mailbox_exchange(TrkMailbox* mb, const float* packed, float* out, trk_stream_t stream) {
+    if (!mb || !packed || !out) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_exchange: null argument");
+    int rc = trk_mailbox_send(mb, packed, stream);
+    return rc ? rc : trk_mailbox_recv(mb, out, stream);
 }
 
 int trk_mailbox_status(const TrkMailbox* mb, int64_t* n_exchanges, int64_t* n_timeouts, int32_t* alloc_kind) {
     if (!mb) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_status: null mailbox");
-    unsigned host[2] = {0, 0};
+    unsigned host[3] = {0, 0, 0};
     hipError_t e = hipMemcpy(host, mb->counter, sizeof(host), hipMemcpyDeviceToHost);     // synchronises with the device
     if (e != hipSuccess) return trk_hip_fail((int)e, "trk_mailbox_status: hipMemcpy");
     if (n_exchanges) *n_exchanges = host[0];

@@ -2087,16 +2087,18 @@ k_reduce_sum_wide(const float* __restrict__ x, int64_t n, float* __restrict__ ou
 
 // ============================================================================================
 // What a batch-sharded planner exchanges: packed = [ sum cost | sum_b cost(b, h) (H) | sum_b gq(b, h, d) (H D) ]
-// of one rank's evaluation, in ONE launch and bit-reproducibly.  cost [B, H]; gq [B, H, D]; block_sums [nb] (trk_rollout_cost_grad).
+// of one rank's evaluation, bit-reproducibly.  cost [B, H]; gq [B, H, D]; block_sums [nb] (trk_rollout_cost_grad).
 // The C = H + H D columns are cut into tiles of 64 UNITS (a unit = V consecutive columns: V = 4 -- one 16-byte load, 8 bytes of an fp16
-// gradient -- when H is a multiple of 4 and the arrays are aligned, else 1) and the B trajectories into `slices` row slices.  A workgroup
-// (512 threads = 64 units x 8 row lanes) adds its slice of a tile -- every load of a thread is independent, so the whole 8 MB of a
-// 4096 x 64 x 7 evaluation is in flight at once -- and writes one partial row piece.  The LAST workgroup of a tile to finish (one atomic
-// ticket per tile) adds the tile's partial rows in slice order (8 groups x slices / 8, then the groups in order): the association order
-// never depends on the timing, and the tail is one batch of <= 16 loads per thread instead of a serial pass over every slice.  Tile 0's
-// last workgroup also folds the per-wavefront cost sums (the association order of trk_reduce_sum) and traj_cost into out[0].
-// Round 5: 46 us -> ~4 us at 4096 x 64 x 7 (profiles/r05_exchange_trace_c2.csv has the old kernel, r05_kernel_stats_exchange_* the new one).
-// scratch: float[TRK_PACK_SLICES * C] followed by one zero-initialised int per tile (the tickets; the kernel leaves them zero).
+// gradient -- when H is a multiple of 4 and the arrays are aligned, else 1) and the B trajectories into `slices` row slices.
+// k_pack_partial: a workgroup (512 threads = 64 units x 8 row lanes) adds its slice of a tile -- every load of a thread is independent,
+// so the whole 8 MB of a 4096 x 64 x 7 evaluation is in flight at once -- and writes one partial row piece to scratch.
+// k_pack_finish (the next launch on the stream: the kernel boundary makes the partial rows visible): one workgroup per tile adds the
+// tile's partial rows in slice order (8 groups x slices / 8, then the groups in order); workgroup 0 also folds the per-wavefront cost
+// sums (the association order of trk_reduce_sum) and traj_cost into out[0].  The association order never depends on the timing.
+// Round 5: the one-launch form this replaces (a ticket per workgroup behind a __threadfence) took 46 us at 4096 x 64 x 7 and 146 us
+// for config 5 -- 90 ns per WORKGROUP whatever it read (profiles/r05_exchange_trace_*_before.txt: 512 and 1920 workgroups): an
+// agent-scope release on this chip writes back and invalidates the XCD's whole L2, and the workgroups' fences serialise.
+// scratch: float[TRK_PACK_SLICES * C] (trk_pack_sums_scratch_bytes keeps a few spare words: earlier versions kept tickets there).
 // ============================================================================================
 #define TRK_PACK_SLICES 128
 #define TRK_PACK_THREADS 512
@@ -2111,10 +2113,8 @@ template <> struct PackVec<_Float16, 1> { typedef _Float16 T; static __device__ 
 
 template <class G, int V>
 __global__ void __launch_bounds__(TRK_PACK_THREADS)
-k_pack_sums(const float* __restrict__ cost, const G* __restrict__ gq, float unscale, const float* __restrict__ block_sums,
-            const float* __restrict__ traj_cost, int B, int H, int D, int64_t nb, int slices, float* __restrict__ scratch, float* __restrict__ out) {
+k_pack_partial(const float* __restrict__ cost, const G* __restrict__ gq, int B, int H, int D, int slices, float* __restrict__ scratch) {
     __shared__ float part[8][64][V];
-    __shared__ int is_last;
     const int C = H + H * D;                                 // columns: H of the cost matrix, then H D of the gradient matrix
     const int CU = C / V;                                    // units (V divides H, hence C)
     const int tiles = (CU + 63) / 64;
@@ -2145,45 +2145,47 @@ k_pack_sums(const float* __restrict__ cost, const G* __restrict__ gq, float unsc
 #pragma unroll
     for (int k = 0; k < V; ++k) part[rl][c][k] = acc[k];
     __syncthreads();
-    int* ticket = reinterpret_cast<int*>(scratch + (size_t)TRK_PACK_SLICES * C) + tile;
     if (rl == 0 && u < CU) {
 #pragma unroll
         for (int k = 0; k < V; ++k)
             scratch[(size_t)slice * C + u * V + k] = ((part[0][c][k] + part[1][c][k]) + (part[2][c][k] + part[3][c][k])) +
                                                      ((part[4][c][k] + part[5][c][k]) + (part[6][c][k] + part[7][c][k]));
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1) == slices - 1;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
+}
+
+template <int V>
+__global__ void __launch_bounds__(TRK_PACK_THREADS)
+k_pack_finish(const float* __restrict__ scratch, float unscale, const float* __restrict__ block_sums, const float* __restrict__ traj_cost,
+              int B, int H, int D, int64_t nb, int slices, float* __restrict__ out) {
+    __shared__ float part[8][64][V];
+    const int C = H + H * D, CU = C / V;
+    const int tile = blockIdx.x;
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int u = tile * 64 + c;
     // the tile's partial rows: row lane g adds the slices g * per .. (g + 1) * per - 1 in order, then the 8 groups in order
-    {
-        const int per = (slices + 7) / 8;
-        const int p0 = rl * per, p1 = min(slices, p0 + per);
+    const int per = (slices + 7) / 8;
+    const int p0 = rl * per, p1 = min(slices, p0 + per);
+    float acc[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) acc[k] = 0.0f;
-        if (u < CU) {
-            typedef typename PackVec<float, V>::T T;
-            const T* src = reinterpret_cast<const T*>(scratch + u * V);
-            const int64_t stride = C / V;
+    for (int k = 0; k < V; ++k) acc[k] = 0.0f;
+    if (u < CU) {
+        typedef typename PackVec<float, V>::T T;
+        const T* src = reinterpret_cast<const T*>(scratch + u * V);
+        const int64_t stride = C / V;
 #pragma unroll 4
-            for (int p = p0; p < p1; ++p) PackVec<float, V>::add(acc, src[p * stride]);
-        }
-        __syncthreads();
+        for (int p = p0; p < p1; ++p) PackVec<float, V>::add(acc, src[p * stride]);
+    }
 #pragma unroll
-        for (int k = 0; k < V; ++k) part[rl][c][k] = acc[k];
-        __syncthreads();
-        if (rl == 0 && u < CU) {
+    for (int k = 0; k < V; ++k) part[rl][c][k] = acc[k];
+    __syncthreads();
+    if (rl == 0 && u < CU) {
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                float tot = 0.0f;
+        for (int k = 0; k < V; ++k) {
+            float tot = 0.0f;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) tot += part[g][c][k];
-                const int col = u * V + k;
-                out[1 + col] = col < H ? tot : tot * unscale;
-            }
+            for (int g = 0; g < 8; ++g) tot += part[g][c][k];
+            const int col = u * V + k;
+            out[1 + col] = col < H ? tot : tot * unscale;
         }
     }
     if (tile == 0) {
@@ -2202,7 +2204,6 @@ k_pack_sums(const float* __restrict__ cost, const G* __restrict__ gq, float unsc
         }
         if (threadIdx.x == 0) out[0] = flat[0];
     }
-    if (threadIdx.x == 0) *ticket = 0;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2461,8 +2462,8 @@ static void launch_pack(const float* cost, const void* gq, float unscale, const 
                         int64_t nb, float* scratch, float* out, hipStream_t st) {
     const int C = H + H * D, tiles = (C / V + 63) / 64;
     const int slices = max(1, min(TRK_PACK_SLICES, (B + 7) / 8));
-    hipLaunchKernelGGL((k_pack_sums<G, V>), dim3(slices * tiles), dim3(TRK_PACK_THREADS), 0, st, cost, static_cast<const G*>(gq), unscale,
-                       block_sums, traj_cost, B, H, D, nb, slices, scratch, out);
+    hipLaunchKernelGGL((k_pack_partial<G, V>), dim3(slices * tiles), dim3(TRK_PACK_THREADS), 0, st, cost, static_cast<const G*>(gq), B, H, D, slices, scratch);
+    hipLaunchKernelGGL((k_pack_finish<V>), dim3(tiles), dim3(TRK_PACK_THREADS), 0, st, scratch, unscale, block_sums, traj_cost, B, H, D, nb, slices, out);
 }
 void trk_launch_pack_sums(const float* cost, const void* gq, int grad_f16, float unscale, const float* block_sums, const float* traj_cost,
                           int B, int H, int D, int64_t nb, float* scratch, float* out, hipStream_t st) {

@@ -135,8 +135,9 @@ class MailboxAllReduce:
     """The planner's one exchange as a PEER-TO-PEER MAILBOX (`trk_mailbox_*`, csrc/trk_exchange.hip; SURVEY.md 8e's alternative to
     the all-reduce): every rank stores its packed row of partial sums straight into a slot of every peer's mailbox -- device memory
     mapped through hipIpc handles, one xGMI hop, all peers in parallel --, raises a sequence flag, waits for the flags of its own
-    mailbox and adds the rows in RANK ORDER (bit-identical on every rank and on every run).  One single-workgroup kernel per
-    exchange, capturable into a hipGraph; no host work, no collective library on the data path.  The handles travel once, at
+    mailbox and adds the rows in RANK ORDER (bit-identical on every rank and on every run).  Two single-workgroup kernels per
+    exchange (`send`: stores + flag, never waits; `recv`: wait + sum -- a planner issues it a few evaluations later, when the wait is
+    free), capturable into a hipGraph; no host work, no collective library on the data path.  The handles travel once, at
     construction, through the already initialised `torch.distributed` group (any backend).
 
         mb = MailboxAllReduce(device, n_floats)          # collective over the group: every rank constructs it
@@ -196,6 +197,23 @@ class MailboxAllReduce:
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         self._check(self._lib.trk_mailbox_exchange(self._h, packed.data_ptr(), out.data_ptr(), stream), "trk_mailbox_exchange")
+
+    def send(self, packed: torch.Tensor, stream: Optional[int] = None) -> None:
+        """The first half of `exchange`: this rank's row into every mailbox + the flag.  Never waits."""
+        if packed.device != self.device or packed.dtype != torch.float32 or not packed.is_contiguous() or packed.numel() != self.n_floats:
+            raise ValueError(f"MailboxAllReduce.send(packed): expected a contiguous float32 tensor of {self.n_floats} elements on {self.device}")
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.trk_mailbox_send(self._h, packed.data_ptr(), stream), "trk_mailbox_send")
+
+    def recv(self, out: torch.Tensor, stream: Optional[int] = None) -> None:
+        """The second half: waits for the rows of the oldest send not yet received and writes their sum (rank order) to out.  Must
+        follow its send in stream order (the same stream, or a stream that waits for it); send k + 1 must follow recv k."""
+        if out.device != self.device or out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != self.n_floats:
+            raise ValueError(f"MailboxAllReduce.recv(out): expected a contiguous float32 tensor of {self.n_floats} elements on {self.device}")
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self._lib.trk_mailbox_recv(self._h, out.data_ptr(), stream), "trk_mailbox_recv")
 
     def status(self):
         """(exchanges issued, time-outs seen, allocation kind); synchronises with the device."""

@@ -1514,7 +1514,9 @@ class RolloutPlan:
     (a planner's inner loop re-evaluates the same buffers thousands of times)."""
 
     def __init__(self, model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True, grad_dtype=None,
-                 grad_scale: float = 1.0):
+                 grad_scale: float = 1.0, gq_out: Optional[torch.Tensor] = None):
+        """gq_out: a caller-owned (B, H, D) buffer the gradient is written to (e.g. the storage of `q.grad`: the kernel then IS the
+        backward of `sum(cost)`); default: a buffer of the plan's own."""
         f16 = q.dtype == torch.float16
         gio, gcode, gs = _grad_mode(f16, grad_dtype, grad_scale, "RolloutPlan")
         if not f16 and gs != 1.0:
@@ -1530,7 +1532,11 @@ class RolloutPlan:
         kw = dict(device=q.device, dtype=q.dtype)
         self.link_pos = torch.empty((self.B, self.H, L, 3), **kw) if want_pos else None
         self.cost = torch.empty((self.B, self.H), device=q.device, dtype=torch.float32)
-        self.gq = torch.empty((self.B, self.H, D), device=q.device, dtype=gio)
+        if gq_out is not None:
+            _check_buffer(gq_out, n * D, gio, q.device, "RolloutPlan(gq_out)")
+            self.gq = gq_out.view(self.B, self.H, D)
+        else:
+            self.gq = torch.empty((self.B, self.H, D), device=q.device, dtype=gio)
         self._w = _abi.RolloutWeights(*[float(v) for v in weights])
         self._fn = lib().trk_rollout_cost_grad_f16 if f16 else lib().trk_rollout_cost_grad
         self._args = (model._h, cm._h, C.byref(self._w), q.data_ptr(), self.B, self.H, _ptr(self.link_pos),
