@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Batched forward kinematics of six robots -- the plumbing of the reference's examples/forward_kinematics.py with
 `torch_robotics` replaced by `torch_robotics_amd` (same class names, methods and tensor layouts; the compute is one HIP kernel
-launch per call instead of ~117 batched matmuls).  Needs the MI355X: there is no CPU path.
+launch per call instead of ~117 batched matmuls).  Needs the MI355X: there is no CPU COMPUTE path -- `--device cpu` (the reference
+example's own setting, examples/forward_kinematics.py:15) keeps the tensors on the host and copies them to the GPU and back around
+every call (differentiably), so the reference's script runs with only its imports changed.
 
-    python examples/forward_kinematics.py [--batch 10]
+    python examples/forward_kinematics.py [--batch 10] [--device cpu|cuda:0]
 """
 import argparse
 import sys

@@ -250,6 +250,59 @@ def test_examples_run_like_the_reference_examples():
     assert coll0 > 0.5 and n_free >= 40                                # most straight lines collide; most optimised ones do not
 
 
+def test_host_tensors_round_trip_like_the_reference_example():
+    """The reference's own example constructs its trees with device="cpu" (examples/forward_kinematics.py:13-25; robot_tree.py:77
+    defaults to it).  Here the COMPUTE stays on the GPU: host tensors are copied over, the HIP kernels run, results come back to the
+    host with autograd intact -- bit-identical to the same call on GPU tensors.  Trees, robot, fields, task and scene queries."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("ex_fk", Path(__file__).resolve().parent.parent / "examples" / "forward_kinematics.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    res_cpu = mod.main(batch_size=10, device="cpu", verbose=False)
+    res_gpu = mod.main(batch_size=10, device="cuda:0", verbose=False)
+    assert set(res_cpu) == set(res_gpu) and len(res_cpu) == 6
+    for k in res_cpu:
+        H_c, g_c = res_cpu[k]
+        H_g, g_g = res_gpu[k]
+        assert H_c.device.type == "cpu" and g_c.device.type == "cpu" and H_g.is_cuda
+        assert torch.equal(H_c, H_g.cpu()) and torch.equal(g_c, g_g.cpu())
+    # the signature's default is the reference's
+    tree = tra.DifferentiableFrankaPanda()
+    assert tree._device.type == "cpu"
+    q = torch.rand(5, 7)
+    q.requires_grad_(True)
+    d = tree.compute_forward_kinematics_all_links(q, return_dict=True, link_list=["ee_link"])
+    assert d["ee_link"].rotation.device.type == "cpu" and d["ee_link"].get_transform_matrix().shape == (5, 4, 4)
+    assert d["ee_link"].get_quaternion().device.type == "cpu"              # the Frame algebra round-trips too
+    pos, quat, lin, ang = tree.compute_forward_kinematics_and_geometric_jacobian(q.detach(), torch.zeros(5, 7), "ee_link")
+    assert all(t.device.type == "cpu" for t in (pos, quat, lin, ang)) and lin.shape == (5, 3, 7)
+    assert tra.link_quat_from_link_tensor(tree.compute_forward_kinematics_all_links(q.detach())).device.type == "cpu"
+    q_ik, idx = tree.inverse_kinematics(torch.eye(4), batch_size=8, max_iters=3, print_freq=-1)
+    assert q_ik.device.type == "cpu" and q_ik.shape == (8, 7)
+    # robot / fields / task built with the reference's default tensor_args (host)
+    TAc = dict(device="cpu", dtype=torch.float32)
+    robot_c, robot_g = tra.RobotPanda(tensor_args=TAc), tra.RobotPanda(tensor_args=TA)
+    task_c = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TAc), robot=robot_c, obstacle_cutoff_margin=0.03, tensor_args=TAc)
+    task_g = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot_g, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    qh = robot_c.random_q(64).reshape(4, 16, 7)
+    assert qh.device.type == "cpu"
+    qc = qh.clone().requires_grad_(True)
+    qg = qh.to(DEV).requires_grad_(True)
+    c_c, c_g = task_c.compute_collision_cost(qc), task_g.compute_collision_cost(qg)
+    c_c.sum().backward(); c_g.sum().backward()
+    assert c_c.device.type == "cpu" and torch.equal(c_c.detach(), c_g.detach().cpu()) and torch.equal(qc.grad, qg.grad.cpu())
+    assert torch.equal(task_c.compute_collision(qh), task_g.compute_collision(qh.to(DEV)).cpu())
+    lp_c = robot_c.fk_map_collision(qh)
+    assert lp_c.device.type == "cpu" and torch.equal(lp_c, robot_g.fk_map_collision(qh.to(DEV)).cpu())
+    f_c = task_c.df_collision_objects.compute_cost(qh, lp_c)
+    assert f_c.device.type == "cpu" and torch.equal(f_c, task_g.df_collision_objects.compute_cost(qh.to(DEV), lp_c.to(DEV)).cpu())
+    X = torch.rand(20, 3) - 0.5
+    assert torch.equal(task_c.env.compute_sdf(X), task_g.env.compute_sdf(X.to(DEV)).cpu())
+    assert torch.equal(tra.SE3_distance(torch.eye(4).repeat(3, 1, 1), torch.eye(4)), tra.SE3_distance(torch.eye(4, device=DEV).repeat(3, 1, 1), torch.eye(4, device=DEV)).cpu())
+    tc, tf = task_c.get_trajs_collision_and_free(qh, num_interpolation=2)
+    assert all(t is None or t.device.type == "cpu" for t in (tc, tf))
+
+
 def test_moved_scene_object_is_seen_by_every_cached_cost_model():
     """`ObjectField.set_position_orientation` between two evaluations: the reference reads the pose on every call
     (primitives.py:387-405), so PlanningTask's fused cost model, the per-field one and EnvBase.compute_sdf must all follow."""

@@ -276,7 +276,8 @@ def test_dual_panda_fp16_gp_full_size(ops, oracle_lib):
         assert fpos.dtype == torch.float16 and fcost.dtype == torch.float32 and fgq.dtype == (gdt or torch.float16) and fgqd.dtype == fgq.dtype
         for t_ in (fcost, fgq, fgqd, fpos):
             assert torch.isfinite(t_.float()).all()
-        assert float(fgq.float().abs().max()) < 65504.0 and float(fgqd.float().abs().max()) < 65504.0
+        if gdt is None:                    # fp16 gradients: the loss scale keeps every element below the saturation value
+            assert float(fgq.float().abs().max()) < 65504.0 and float(fgqd.float().abs().max()) < 65504.0
         assert rel_err(fcost[tsel].cpu().numpy(), ref_c8) < 2e-5
         assert np.abs(fpos[tsel].float().cpu().numpy().reshape(-1, L, 3) - rp8).max() < 2.0 ** -10 * max(1.0, np.abs(rp8).max())
         # whole-batch consistency with the two-launch form: the per-trajectory cost and the per-wavefront sums (a checksum of checksums)

@@ -2093,7 +2093,7 @@ k_reduce_sum_wide(const float* __restrict__ x, int64_t n, float* __restrict__ ou
 // k_pack_partial: a workgroup (512 threads = 64 units x 8 row lanes) adds its slice of a tile -- every load of a thread is independent,
 // so the whole 8 MB of a 4096 x 64 x 7 evaluation is in flight at once -- and writes one partial row piece to scratch.
 // k_pack_finish (the next launch on the stream: the kernel boundary makes the partial rows visible): one workgroup per tile adds the
-// tile's partial rows in slice order (8 groups x slices / 8, then the groups in order); workgroup 0 also folds the per-wavefront cost
+// tile's partial rows in slice order (8 groups x slices / 8, then the groups in order); one more workgroup folds the per-wavefront cost
 // sums (the association order of trk_reduce_sum) and traj_cost into out[0].  The association order never depends on the timing.
 // Round 5: the one-launch form this replaces (a ticket per workgroup behind a __threadfence) took 46 us at 4096 x 64 x 7 and 146 us
 // for config 5 -- 90 ns per WORKGROUP whatever it read (profiles/r05_exchange_trace_*_before.txt: 512 and 1920 workgroups): an
@@ -2162,6 +2162,23 @@ k_pack_finish(const float* __restrict__ scratch, float unscale, const float* __r
     const int tile = blockIdx.x;
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int u = tile * 64 + c;
+    if (tile == (int)gridDim.x - 1) {
+        // the extra workgroup: out[0] = the per-wavefront cost sums (the association order of trk_reduce_sum) + traj_cost, beside the tiles
+        float* flat = &part[0][0][0];                           // >= 512 floats
+        float a = 0.0f;
+        if (threadIdx.x < 256) {
+            for (int64_t i = threadIdx.x; i < nb; i += 256) a += block_sums[i];
+            if (traj_cost) { float t = 0.0f; for (int i = threadIdx.x; i < B; i += 256) t += traj_cost[i]; a += t; }
+            flat[threadIdx.x] = a;
+        }
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) flat[threadIdx.x] += flat[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[0] = flat[0];
+        return;
+    }
     // the tile's partial rows: row lane g adds the slices g * per .. (g + 1) * per - 1 in order, then the 8 groups in order
     const int per = (slices + 7) / 8;
     const int p0 = rl * per, p1 = min(slices, p0 + per);
@@ -2172,7 +2189,7 @@ k_pack_finish(const float* __restrict__ scratch, float unscale, const float* __r
         typedef typename PackVec<float, V>::T T;
         const T* src = reinterpret_cast<const T*>(scratch + u * V);
         const int64_t stride = C / V;
-#pragma unroll 4
+#pragma unroll 8
         for (int p = p0; p < p1; ++p) PackVec<float, V>::add(acc, src[p * stride]);
     }
 #pragma unroll
@@ -2187,22 +2204,6 @@ k_pack_finish(const float* __restrict__ scratch, float unscale, const float* __r
             const int col = u * V + k;
             out[1 + col] = col < H ? tot : tot * unscale;
         }
-    }
-    if (tile == 0) {
-        __syncthreads();
-        float* flat = &part[0][0][0];                           // >= 512 floats
-        float a = 0.0f;
-        if (threadIdx.x < 256) {
-            for (int64_t i = threadIdx.x; i < nb; i += 256) a += block_sums[i];       // the association order of trk_reduce_sum
-            if (traj_cost) { float t = 0.0f; for (int i = threadIdx.x; i < B; i += 256) t += traj_cost[i]; a += t; }
-            flat[threadIdx.x] = a;
-        }
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if ((int)threadIdx.x < st) flat[threadIdx.x] += flat[threadIdx.x + st];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[0] = flat[0];
     }
 }
 
@@ -2463,7 +2464,7 @@ static void launch_pack(const float* cost, const void* gq, float unscale, const 
     const int C = H + H * D, tiles = (C / V + 63) / 64;
     const int slices = max(1, min(TRK_PACK_SLICES, (B + 7) / 8));
     hipLaunchKernelGGL((k_pack_partial<G, V>), dim3(slices * tiles), dim3(TRK_PACK_THREADS), 0, st, cost, static_cast<const G*>(gq), B, H, D, slices, scratch);
-    hipLaunchKernelGGL((k_pack_finish<V>), dim3(tiles), dim3(TRK_PACK_THREADS), 0, st, scratch, unscale, block_sums, traj_cost, B, H, D, nb, slices, out);
+    hipLaunchKernelGGL((k_pack_finish<V>), dim3(tiles + 1), dim3(TRK_PACK_THREADS), 0, st, scratch, unscale, block_sums, traj_cost, B, H, D, nb, slices, out);
 }
 void trk_launch_pack_sums(const float* cost, const void* gq, int grad_f16, float unscale, const float* block_sums, const float* traj_cost,
                           int B, int H, int D, int64_t nb, float* scratch, float* out, hipStream_t st) {

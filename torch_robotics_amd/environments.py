@@ -65,6 +65,7 @@ class PrimitiveShapeField:
         """what scene_version adds for this field: the number its latest geometry assignment took"""
         return (getattr(self, "_geometry_version", 0),)
 
+    @ops.host_round_trip
     def compute_signed_distance(self, x):
         return ObjectField([self]).compute_signed_distance(x)
 
@@ -164,6 +165,7 @@ class ObjectField(PrimitiveShapeField):                      # primitives.py:346
         prims = list(itertools.chain.from_iterable(f.prims() for f in self.fields))
         return make_object(prims, self.pos, quat_wxyz_to_rot(self.ori))
 
+    @ops.host_round_trip
     def compute_signed_distance(self, x):
         """x (..., 3) on the GPU -> (...) signed distance (differentiable w.r.t. x)."""
         # keyed by the device, the pose version AND the primitive fields' geometry versions: `field.centers = new` must be seen here
@@ -226,7 +228,7 @@ class GridMapSDF:                                            # grid_map_sdf.py:9
 
     def precompute_sdf(self):
         spec = CostModelSpec(n_links_in=1, objects=[o.as_object() for o in self.obj_list])
-        cm = ops.CostHandle(spec, self.tensor_args["device"])
+        cm = ops.CostHandle(spec, ops.compute_device(self.tensor_args["device"]))      # the grid lives where it is computed and queried: on the GPU
         self.sdf_tensor, self.grad_sdf_tensor = ops.grid_precompute(
             cm, self.cmap_dim.numpy(), self.limits[0].numpy(), self.limits[1].numpy())
 
@@ -241,6 +243,7 @@ class GridMapSDF:                                            # grid_map_sdf.py:9
             self._qcm = ops.CostHandle(spec, device)
         return self._qcm
 
+    @ops.host_round_trip
     def compute_signed_distance(self, X, **kwargs):           # grid_map_sdf.py:81-114
         """Nearest-lower-cell lookup; differentiable w.r.t. X with the STORED gradient of that cell, like the reference's
         `sdf[idx] + (X * g).sum() - (X.detach() * g).sum()`."""
@@ -286,6 +289,7 @@ class EnvBase:                                               # env_base.py:17-10
             out.extend(self.obj_extra_list)
         return out
 
+    @ops.host_round_trip
     def compute_sdf(self, x, reshape_shape=None):             # env_base.py:140-169
         """Signed distance of the scene (min over the fixed objects -- or their precomputed grid -- and the extra objects) at
         points x (..., 3); differentiable w.r.t. x.  One `trk_sdf_points` launch for all objects."""

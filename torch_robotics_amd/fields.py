@@ -22,6 +22,7 @@ class DistanceField:
     def __init__(self, tensor_args=None):
         self.tensor_args = tensor_args
 
+    @ops.host_round_trip
     def compute_cost(self, q, link_pos, *args, **kwargs):
         """Rank normaliser of distance_fields.py:26-55: (b,d) | (b,t,d) | (b,h,t,3) | (b,h,t,4,4) -> cost (b,h)."""
         shape = link_pos.shape
@@ -63,6 +64,7 @@ class _InterpolateColumns(torch.autograd.Function):
         return ops.interpolate_columns_backward(g.contiguous(), src, w, ctx.n_in), None, None, None
 
 
+@ops.host_round_trip
 def interpolate_points_v1(points, num_interpolated_points):
     """distance_fields.py:66-69: `F.interpolate(points.transpose(-2, -1), size=K, mode='linear', align_corners=True)` back
     transposed -- (..., L, C) -> (..., K, C), linear along the link axis; differentiable w.r.t. the points."""
@@ -151,6 +153,7 @@ class EmbodimentDistanceFieldBase(DistanceField):
     def compute_costs_impl(self, q, link_pos, **kwargs):        # distance_fields.py:134-155
         return self.compute_embodiment_cost(q, link_pos, **kwargs)
 
+    @ops.host_round_trip
     def compute_embodiment_cost(self, q, link_pos, field_type=None, **kwargs):   # distance_fields.py:107-130
         if field_type is None:
             field_type = self.field_type
@@ -162,6 +165,7 @@ class EmbodimentDistanceFieldBase(DistanceField):
             return self.compute_embodiment_collision(q, link_pos, **kwargs)
         raise NotImplementedError("field_type {} not implemented".format(field_type))
 
+    @ops.host_round_trip
     def compute_embodiment_collision(self, q, link_pos, **kwargs):
         lead = link_pos.shape[:-2]
         cm = self._handle(link_pos.shape[-2], link_pos.device)
@@ -171,6 +175,7 @@ class EmbodimentDistanceFieldBase(DistanceField):
     def compute_embodiment_signed_distances(self, *args, **kwargs):
         raise NotImplementedError
 
+    @ops.host_round_trip
     def compute_distance(self, q, link_pos, **kwargs):
         raise NotImplementedError
 
@@ -260,6 +265,7 @@ class EESE3DistanceField(DistanceField):                      # distance_fields.
         cost = ops.ee_cost_ad(self._handle(H.device, square), H, tgt)
         return cost.reshape(lead)
 
+    @ops.host_round_trip
     def compute_distance(self, link_tensor):
         return self._eval(link_tensor, square=False)
 
@@ -273,6 +279,7 @@ class EESE3DistanceField(DistanceField):                      # distance_fields.
 _se3_handles = {}
 
 
+@ops.host_round_trip
 def SE3_distance(H_batch, H_target, vel_batch=None, vel_target=None, w_pos=1.0, w_rot=1.0, **kwargs):
     """geometrics/utils.py:130-178 on the pose part: w_rot (1 - (tr(R R_t^T) - 1) / 2) + w_pos ||p - p_t|| for H_batch (..., 4, 4)
     against one (4, 4) or per-sample (..., 4, 4) target; differentiable w.r.t. H_batch (`trk_ee_cost`).  The velocity terms of the

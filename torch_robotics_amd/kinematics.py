@@ -110,7 +110,10 @@ class Frame:
 
 class DifferentiableTree(torch.nn.Module):
 
-    def __init__(self, model_path: str, name="", link_list=None, device="cuda"):
+    def __init__(self, model_path: str, name="", link_list=None, device="cpu"):
+        """Same signature and default as the reference (robot_tree.py:77).  `device` is where the tensors this object CREATES live
+        (IK start configurations and results); computation is always on the GPU -- tensors handed in on the host are copied to
+        `ops.compute_device()`, the kernels run there, the results come back to the host (`ops.host_round_trip`, differentiable)."""
         super().__init__()
         self.name = name
         self.link_list = link_list
@@ -168,6 +171,7 @@ class DifferentiableTree(torch.nn.Module):
         return ops.fk(self._handle, q, sel)
 
     # -- stateless FK (robot_tree.py:267-301) ---------------------------------------------------
+    @ops.host_round_trip
     def compute_forward_kinematics_all_links(self, q: torch.Tensor, return_dict=False, link_list=None):
         self._check_supported()
         if q.ndim == 1:
@@ -187,6 +191,7 @@ class DifferentiableTree(torch.nn.Module):
         return {n: Frame(H[:, k, :3, :3], H[:, k, :3, 3]) for k, n in enumerate(names)}
 
     # -- stateful path (robot_tree.py:192-248) --------------------------------------------------
+    @ops.host_round_trip
     def compute_forward_kinematics(self, q: torch.Tensor, qd: torch.Tensor, link_name: str, state_less: bool = False):
         assert q.ndim == 2
         if state_less:
@@ -201,9 +206,11 @@ class DifferentiableTree(torch.nn.Module):
             assert qd.ndim == 2 and qd.shape[1] == self._n_dofs
         return ops.fk_jacobian(self._handle, q, qd, self._name_to_idx_map[link_name])
 
+    @ops.host_round_trip
     def compute_forward_kinematics_and_geometric_jacobian(self, q: torch.Tensor, qd: torch.Tensor, link_name: str):
         return self._stateful(q, qd, link_name)
 
+    @ops.host_round_trip
     def compute_analytical_jacobian_all_links(self, q: torch.Tensor):
         """(N, L, 7, D) Jacobian of [pos, quat_wxyz] of every link (robot_tree.py:250-265): one kernel launch
         instead of 7L autograd traversals."""
@@ -220,6 +227,7 @@ class DifferentiableTree(torch.nn.Module):
         hi = torch.as_tensor(upper - eps_joint_lim, dtype=torch.float32, device=device)
         return lo, hi
 
+    @ops.host_round_trip
     def loss_fn_ik_per_q(self, q, H_target, link_name, w_se3=1.0, w_joint_limits=1.0, lower=None, upper=None,
                          w_q_rest=1.0, q_rest=None, debug=False):
         if w_se3 != 1.0 or q_rest is not None:
@@ -230,6 +238,7 @@ class DifferentiableTree(torch.nn.Module):
                     w_joint_limits=w_joint_limits, loss=loss)
         return loss
 
+    @ops.host_round_trip
     def ik_termination(self, q, H_target, link_name, lower, upper, se3_eps=1e-1, debug=False):
         q = q.detach().contiguous()
         valid = torch.empty(q.shape[0], device=q.device, dtype=torch.uint8)
@@ -243,21 +252,22 @@ class DifferentiableTree(torch.nn.Module):
         """Same contract as the reference: returns (q, idx_valid).  `check_every` > 1 tests the termination condition
         (a device->host sync) only every so many iterations instead of every iteration."""
         self._check_supported()
-        H_target = torch.as_tensor(H_target, dtype=torch.float32, device=self._device)
+        cdev = ops.compute_device(self._device)          # tensors this call creates: on the GPU while it iterates, returned on self._device
+        H_target = torch.as_tensor(H_target, dtype=torch.float32, device=cdev)
         if H_target.ndim == 2:
             H_target = H_target.unsqueeze(0)
         Ht = H_target[0].contiguous() if H_target.shape[0] == 1 else H_target.contiguous()
-        lo, hi = self._ik_limits(eps_joint_lim, self._device)
+        lo, hi = self._ik_limits(eps_joint_lim, cdev)
         if q0 is None:
-            q0 = lo + torch.rand(batch_size, self._n_dofs, device=self._device) * (hi - lo)
+            q0 = lo + torch.rand(batch_size, self._n_dofs, device=cdev) * (hi - lo)
         else:
-            q0 = torch.as_tensor(q0, dtype=torch.float32, device=self._device)
-            q0 = torch.clamp(q0 + torch.randn(batch_size, self._n_dofs, device=self._device) * q0_noise, lo, hi)
+            q0 = torch.as_tensor(q0, dtype=torch.float32, device=cdev)
+            q0 = torch.clamp(q0 + torch.randn(batch_size, self._n_dofs, device=cdev) * q0_noise, lo, hi)
             assert q0.shape == (batch_size, self._n_dofs)
         q = q0.clone().contiguous()
         m, v = torch.zeros_like(q), torch.zeros_like(q)
-        loss = torch.empty(batch_size, device=self._device, dtype=torch.float32)
-        valid = torch.empty(batch_size, device=self._device, dtype=torch.uint8)
+        loss = torch.empty(batch_size, device=cdev, dtype=torch.float32)
+        valid = torch.empty(batch_size, device=cdev, dtype=torch.uint8)
         link = self._name_to_idx_map[link_name]
         it, converged = 0, False
         while it < max_iters:
@@ -280,7 +290,7 @@ class DifferentiableTree(torch.nn.Module):
         if not converged and max_iters > 0:
             print("\nIK did not converge for all joint configurations!")
         idx_valid = torch.atleast_1d(torch.argwhere(valid.bool()).squeeze())
-        return q, idx_valid
+        return q.to(self._device), idx_valid.to(self._device)
 
     def inverse_kinematics_gn(self, H_target, link_name="ee_link", batch_size=1, max_iters=40, damping=1e-4, lm_gain=0.1, step_scale=1.0,
                               se3_eps=1e-1, q0=None, q0_noise=torch.pi / 8, eps_joint_lim=torch.pi / 100, check_every=10):
@@ -290,20 +300,21 @@ class DifferentiableTree(torch.nn.Module):
         between two tests are ONE launch of `trk_ik_gn_steps` (FK, Jacobian, normal equations, Cholesky and the clamped step per lane
         in registers).  A unit tracking `link_name` is compiled on first use when none is registered (robots up to 9 DOF)."""
         self._check_supported()
-        H_target = torch.as_tensor(H_target, dtype=torch.float32, device=self._device)
+        cdev = ops.compute_device(self._device)          # tensors this call creates: on the GPU while it iterates, returned on self._device
+        H_target = torch.as_tensor(H_target, dtype=torch.float32, device=cdev)
         if H_target.ndim == 2:
             H_target = H_target.unsqueeze(0)
         Ht = H_target[0].contiguous() if H_target.shape[0] == 1 else H_target.contiguous()
-        lo, hi = self._ik_limits(eps_joint_lim, self._device)
+        lo, hi = self._ik_limits(eps_joint_lim, cdev)
         if q0 is None:
-            q0 = lo + torch.rand(batch_size, self._n_dofs, device=self._device) * (hi - lo)
+            q0 = lo + torch.rand(batch_size, self._n_dofs, device=cdev) * (hi - lo)
         else:
-            q0 = torch.as_tensor(q0, dtype=torch.float32, device=self._device)
-            q0 = torch.clamp(q0 + torch.randn(batch_size, self._n_dofs, device=self._device) * q0_noise, lo, hi)
+            q0 = torch.as_tensor(q0, dtype=torch.float32, device=cdev)
+            q0 = torch.clamp(q0 + torch.randn(batch_size, self._n_dofs, device=cdev) * q0_noise, lo, hi)
             assert q0.shape == (batch_size, self._n_dofs)
         q = q0.clone().contiguous()
-        err = torch.empty(batch_size, device=self._device, dtype=torch.float32)
-        valid = torch.empty(batch_size, device=self._device, dtype=torch.uint8)
+        err = torch.empty(batch_size, device=cdev, dtype=torch.float32)
+        valid = torch.empty(batch_size, device=cdev, dtype=torch.uint8)
         link = self._name_to_idx_map[link_name]
         self._ensure_gn_unit(link)
         it = 0
@@ -320,7 +331,7 @@ class DifferentiableTree(torch.nn.Module):
             ops.ik_gn_steps(self._handle, link, Ht, lo, hi, q.clone(), 1, damping=damping, lm_gain=lm_gain, step_scale=step_scale,
                             se3_eps=se3_eps, err=err, valid=valid)          # validity of the final configurations
         idx_valid = torch.atleast_1d(torch.argwhere(valid.bool()).squeeze())
-        return q, idx_valid
+        return q.to(self._device), idx_valid.to(self._device)
 
     def _ensure_gn_unit(self, link: int) -> None:
         """a generated unit of this robot that tracks `link` (the Gauss-Newton IK lives in generated kernels only)"""
@@ -363,7 +374,7 @@ class DifferentiableTree(torch.nn.Module):
 
 def _tree(urdf_name: str, name: str):
     class _Robot(DifferentiableTree):
-        def __init__(self, link_list: Optional[List[str]] = None, device="cuda", **kwargs):
+        def __init__(self, link_list: Optional[List[str]] = None, device="cpu", **kwargs):
             self.model_path = (URDF_DIR / urdf_name).as_posix()
             super().__init__(self.model_path, name, link_list=link_list, device=device)
     return _Robot
@@ -380,7 +391,7 @@ def quat_wxyz_to_rpy(q) -> Tuple[float, float, float]:
 
 
 class DifferentiableFrankaPanda(DifferentiableTree):          # robots.py:56-69
-    def __init__(self, link_list=None, gripper=False, device="cuda", grasped_object=None):
+    def __init__(self, link_list=None, gripper=False, device="cpu", grasped_object=None):
         fname = "panda_arm_hand.urdf" if gripper else "panda_arm_no_gripper.urdf"
         self._grasped_object = grasped_object
         super().__init__((URDF_DIR / fname).as_posix(), "differentiable_franka_panda", link_list=link_list, device=device)
@@ -409,7 +420,7 @@ DifferentiableDualPanda = _tree("dual_panda.urdf", "differentiable_dual_panda")
 
 
 class DifferentiableTiagoDualHoloMove(DifferentiableTree):     # robots.py:104-112
-    def __init__(self, link_list=None, device="cuda"):
+    def __init__(self, link_list=None, device="cpu"):
         super().__init__((URDF_DIR / "tiago_dual_holobase_minimal_holonomic.urdf").as_posix(),
                          "differentiable_tiago_dual_holo_move", link_list=link_list, device=device)
 

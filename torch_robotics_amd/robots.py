@@ -150,6 +150,7 @@ class RobotBase:
     def distance_q(self, q1, q2):
         return torch.linalg.norm(q1 - q2, dim=-1)
 
+    @ops.host_round_trip
     def fk_map_collision(self, q, **kwargs):                   # robot_base.py:171-174
         if q.ndim == 1:
             q = q.unsqueeze(0)
@@ -270,12 +271,15 @@ class RobotPanda(RobotBase):                                   # robot_panda.py:
             pos = ops.fk_points_ad(self._point_set(q.device), q)    # (N, L + G, 3), one launch
         return pos.reshape(tuple(shape[:-1]) + (pos.shape[-2], 3))
 
+    @ops.host_round_trip
     def get_EE_pose(self, q):
         return self.diff_panda.compute_forward_kinematics_all_links(q, link_list=[self.link_name_ee])
 
+    @ops.host_round_trip
     def get_EE_position(self, q):
         return link_pos_from_link_tensor(self.get_EE_pose(q))
 
+    @ops.host_round_trip
     def get_EE_orientation(self, q, rotation_matrix=True):
         ee = self.get_EE_pose(q)
         return link_rot_from_link_tensor(ee) if rotation_matrix else link_quat_from_link_tensor(ee)

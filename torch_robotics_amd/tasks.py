@@ -199,6 +199,7 @@ class PlanningTask(Task):
             return None
         return self.robot._point_set(device)
 
+    @ops.host_round_trip
     def rollout_cost_grad(self, x, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=True, cost_sum=None, out=None):
         """Fused FK + objectives + gradient.  x (B,H,>=D) or (N,>=D) -> (link_pos, cost, d cost/d q)."""
         q = self.robot.get_position(x)
@@ -238,9 +239,11 @@ class PlanningTask(Task):
         return GraphedCostBackward(self, x, reduce, warmup)
 
     # ---------------------------------------------------------------------------------------------
+    @ops.host_round_trip
     def compute_collision(self, x, **kwargs):                  # tasks.py:131-133
         return self._compute_collision_or_cost(self.robot.get_position(x), field_type="occupancy", **kwargs)
 
+    @ops.host_round_trip
     def compute_collision_cost(self, x, **kwargs):             # tasks.py:135-137
         return self._compute_collision_or_cost(self.robot.get_position(x), field_type="sdf", **kwargs)
 
@@ -290,6 +293,7 @@ class PlanningTask(Task):
                 return wp
         return self.compute_collision(ops.interpolate_traj_via_points(flat, num_interpolation=num_interpolation), margin=0.)
 
+    @ops.host_round_trip
     def get_trajs_collision_and_free(self, trajs, return_indices=False, num_interpolation=5):
         assert trajs.ndim == 3 or trajs.ndim == 4
         batched = trajs.ndim == 4                       # (goals or steps, batch, horizon, state)
