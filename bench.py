@@ -343,7 +343,17 @@ def cpu_baseline(wl, args, torch, seconds):
     orc.set_threads(cores)
     what = {"c2": "fused rollout", "c3": "fused rollout", "c4": "rollout + geometric Jacobian of ee_link",
             "c5": "rollout (fp32 on the fp16-rounded q) + GP prior"}[wl.cfg]
+    # BASELINE.md section 2 (measured once, in the survey container, by importing the reference itself; it cannot travel to this box):
+    # labelled so that the C restatement above is not mistaken for the (much slower) reference
+    survey = {"c2": {"value": 8.3e4, "what": "Task-API path (fk_map_collision + EE pose: 2 x FK), object + EE cost + backward, N = 262 144: 3.17 s",
+                     "single_fk": {"value": 1.53e5, "what": "1 x FK + object-SDF + EE cost + backward, N = 32 768: 214 ms"}},
+              "c3": {"value": 5.5e4, "what": "Task-API path, self + object + workspace box + EE + backward, N = 262 144: 4.79 s",
+                     "single_fk": {"value": 1.36e5, "what": "1 x FK + full stack + backward, N = 32 768: 242 ms"}}}.get(wl.cfg)
+    ref_fig = None if survey is None else {
+        "label": "reference PyTorch-CPU, 8 vCPU (Intel Xeon 2.1 GHz, 8 torch threads), survey container -- NOT measured on this box",
+        "unit": "rollouts/s", "source": "BASELINE.md section 2", **survey}
     return {"value": n_all / t_all, "unit": "rollouts/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
+            "reference_pytorch_cpu_survey": ref_fig,
             "sample": f"first {n_all} of the {wl.B * H} samples of rank 0's batch, C oracle ({what}; fp32, OpenMP over samples, "
                       f"{cores} threads), best of 3",
             "one_core": {"value": n_one / t_one, "unit": "rollouts/s", "cores": 1,

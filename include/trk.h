@@ -660,6 +660,11 @@ int trk_mailbox_exchange(TrkMailbox* mb, const float* packed, float* out, trk_st
 int trk_mailbox_status(const TrkMailbox* mb, int64_t* n_exchanges, int64_t* n_timeouts, int32_t* alloc_kind);
 void trk_mailbox_destroy(TrkMailbox* mb);
 
+/* What a pointer VALUE is to this library, without dereferencing it: 0 = not a live handle (never created here, or destroyed),
+ * 1 = TrkModel, 2 = TrkCostModel, 3 = TrkPointSet.  For bindings that carry handles as integers (a PyTorch dispatcher op's schema
+ * has tensors and scalars only, csrc/trk_torch_ops.cpp): a stale integer becomes an error instead of a segfault.  Thread-safe. */
+int trk_handle_kind(const void* handle);
+
 /* Deterministic sum of n floats (fixed association order, one workgroup): x [n] -> out [1]. */
 int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream);
 

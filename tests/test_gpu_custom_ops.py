@@ -144,6 +144,18 @@ def test_native_rollout_op(handles):
     torch.library.opcheck(native.rollout.default, (q3.detach().half(), m.ptr, cm.ptr, 0.0, 1.0, 0.0, 1.0, True), test_utils=("test_schema", "test_faketensor"))
     torch.library.opcheck(native.scale_rows_native.default, (torch.randn(2, 64, 7, device=DEV), torch.rand(2, 64, device=DEV)),
                           test_utils=("test_schema", "test_faketensor"))
+    # handles travel as integers: a stale / foreign integer is an ERROR from the op, not a segfault inside it (libtrk.so's registry)
+    from torch_robotics_amd.costmodel import CostModelSpec
+    tmp = ops.CostHandle(CostModelSpec(n_links_in=11), DEV)
+    stale = tmp.ptr
+    assert _lib.lib().trk_handle_kind(stale) == 2 and _lib.lib().trk_handle_kind(m.ptr) == 1
+    del tmp
+    import gc as _gc
+    _gc.collect()
+    assert _lib.lib().trk_handle_kind(stale) == 0 and _lib.lib().trk_handle_kind(12345) == 0
+    for bad_m, bad_c in ((m.ptr, stale), (m.ptr, 12345), (cm.ptr, cm.ptr), (0, cm.ptr)):
+        with pytest.raises(RuntimeError, match="not a live"):
+            native.rollout(q3.detach(), bad_m, bad_c, 1.0, 1.0, 1.0, 1.0, False)
     # == the ctypes path, value and gradient
     pos_r, cost_r, gq_r = ops.rollout_cost_grad(m, cm, (1, 1, 1, 1), q3.detach())
     cost, gq, pos = native.rollout(q3, m.ptr, cm.ptr, 1.0, 1.0, 1.0, 1.0, True)

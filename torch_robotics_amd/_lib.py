@@ -34,7 +34,7 @@ EXPORTS = [
     "trk_interpolate_columns", "trk_interpolate_columns_backward", "trk_rollout_collision_via", "trk_traj_validate",
     "trk_scale_rows", "trk_jtj", "trk_pack_sums", "trk_pack_sums_scratch_bytes", "trk_rollout_is_specialized", "trk_ik_gn_steps", "trk_rollout_gp_cost_grad",
     "trk_spec_register_module", "trk_spec_layout_stamp",
-    "trk_mailbox_create", "trk_mailbox_ipc_handle", "trk_mailbox_connect", "trk_mailbox_send", "trk_mailbox_recv", "trk_mailbox_exchange", "trk_mailbox_status", "trk_mailbox_destroy",
+    "trk_handle_kind", "trk_mailbox_create", "trk_mailbox_ipc_handle", "trk_mailbox_connect", "trk_mailbox_send", "trk_mailbox_recv", "trk_mailbox_exchange", "trk_mailbox_status", "trk_mailbox_destroy",
 ]
 
 
@@ -152,6 +152,7 @@ def lib():
     L.trk_pack_sums.argtypes = [vp, vp, i32, f32, vp, vp, i64, i32, i32, vp, vp, vp]
     L.trk_pack_sums_scratch_bytes.argtypes = [i32, i32]
     L.trk_pack_sums_scratch_bytes.restype = C.c_int64
+    L.trk_handle_kind.argtypes = [vp]
     L.trk_mailbox_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
     L.trk_mailbox_ipc_handle.argtypes = [vp, vp]
     L.trk_mailbox_connect.argtypes = [vp, vp]

@@ -6,8 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "trk_launch.h"
 #include "trk_spec_common.h"
@@ -56,6 +58,20 @@ uint64_t model_hash(const TrkKinModelDesc* d) {
 }
 std::vector<const SpecEntry*>& spec_registry() { static std::vector<const SpecEntry*> r; return r; }
 }  // namespace
+
+// Registry of live handles: a dispatcher op (csrc/trk_torch_ops.cpp) receives handles as plain integers, and a stale integer must be
+// an error, not a segfault -- trk_handle_kind answers for any pointer value without dereferencing it.
+namespace {
+std::mutex g_live_mu;
+std::unordered_map<const void*, int> g_live;             // pointer -> 1 model, 2 cost model, 3 point set
+void live_add(const void* p, int kind) { std::lock_guard<std::mutex> l(g_live_mu); g_live[p] = kind; }
+void live_del(const void* p) { std::lock_guard<std::mutex> l(g_live_mu); g_live.erase(p); }
+}  // namespace
+int trk_handle_kind(const void* handle) {
+    std::lock_guard<std::mutex> l(g_live_mu);
+    auto it = g_live.find(handle);
+    return it == g_live.end() ? 0 : it->second;
+}
 
 // error reporting / one-time initialisation for the library's other translation units (trk_exchange.hip)
 int trk_fail(int code, const char* msg) { return fail(code, msg); }
@@ -419,12 +435,14 @@ int trk_model_create(const TrkKinModelDesc* d, TrkModel** out) {
     }
     m->hash = model_hash(d);
     m->spec = trk_spec_find(m->hash, L, D);
+    live_add(m, 1);
     *out = m;
     return TRK_OK;
 }
 
 void trk_model_destroy(TrkModel* m) {
     if (!m) return;
+    live_del(m);
     if (m->d_links) (void)hipFree(m->d_links);
     if (m->d_fin) (void)hipFree(m->d_fin);
     if (m->d_dofs) (void)hipFree(m->d_dofs);
@@ -656,12 +674,14 @@ int trk_point_set_create(const TrkModel* m, const int32_t* point_link, const flo
         ps->hash = h;
         ps->spec = trk_spec_find_points(m->hash, h, n_points);
     }
+    live_add(ps, 3);
     *out = ps;
     return TRK_OK;
 }
 
 void trk_point_set_destroy(TrkPointSet* ps) {
     if (!ps) return;
+    live_del(ps);
     if (ps->d_blob) (void)hipFree(ps->d_blob);
     delete ps;
 }
@@ -1163,12 +1183,14 @@ int trk_cost_model_create(const TrkCostModelDesc* d, TrkCostModel** out) {
             h.grid.map_dim[k] = d->grid.map_dim[k]; h.grid.fdims[k] = (float)d->grid.dims[k];
         }
     }
+    live_add(cm, 2);
     *out = cm;
     return TRK_OK;
 }
 
 void trk_cost_model_destroy(TrkCostModel* cm) {
     if (!cm) return;
+    live_del(cm);
     if (cm->d_blob) (void)hipFree(cm->d_blob);
     if (cm->d_cells) (void)hipFree(cm->d_cells);
     delete cm;

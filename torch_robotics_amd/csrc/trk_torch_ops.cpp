@@ -59,9 +59,11 @@ Shapes shapes_of(const Tensor& q, int64_t n_dofs) {
 // ---------------------------------------------------------------------------------------------------------------------------
 std::tuple<Tensor, Tensor, Tensor> rollout_hip(const Tensor& q_in, int64_t model, int64_t cm, double w_self, double w_obj, double w_ws,
                                                double w_ee, bool want_pos) {
+    // the handles travel as integers: validate them against libtrk.so's registry of live handles before they are dereferenced
+    TORCH_CHECK(trk_handle_kind(reinterpret_cast<const void*>(model)) == 1, "trk::rollout: ", model, " is not a live TrkModel handle (destroyed, or never created)");
+    TORCH_CHECK(trk_handle_kind(reinterpret_cast<const void*>(cm)) == 2, "trk::rollout: ", cm, " is not a live TrkCostModel handle (destroyed, or never created)");
     const TrkModel* m = reinterpret_cast<const TrkModel*>(model);
     const TrkCostModel* c = reinterpret_cast<const TrkCostModel*>(cm);
-    TORCH_CHECK(m && c, "trk::rollout: null model / cost model handle");
     const bool f16 = q_in.scalar_type() == at::kHalf;
     TORCH_CHECK(f16 || q_in.scalar_type() == at::kFloat, "trk::rollout: q must be float32 or float16");
     const Tensor q = q_in.contiguous();
@@ -88,8 +90,8 @@ std::tuple<Tensor, Tensor, Tensor> rollout_hip(const Tensor& q_in, int64_t model
 }
 
 std::tuple<Tensor, Tensor, Tensor> rollout_meta(const Tensor& q, int64_t model, int64_t cm, double, double, double, double, bool want_pos) {
+    TORCH_CHECK(trk_handle_kind(reinterpret_cast<const void*>(model)) == 1, "trk::rollout: ", model, " is not a live TrkModel handle");
     const TrkModel* m = reinterpret_cast<const TrkModel*>(model);
-    TORCH_CHECK(m, "trk::rollout: null model handle");
     const int64_t D = trk_model_n_dofs(m), L = trk_model_n_links(m);     // host-side queries of the handle: no device work
     const Shapes s = shapes_of(q, D);
     std::vector<int64_t> pos_shape = s.lead, g_shape = s.lead;

@@ -234,6 +234,8 @@ class MailboxAllReduce:
             self.exchange(packed, out)
             expect = (idx + float(r)) * float(self.world * (self.world + 1) // 2)
             ok = ok and bool(torch.equal(out, expect))          # the comparison synchronises
+            if not ok:                                           # (a time-out costs TRK_MAILBOX_TIMEOUT_S: do not pay it `rounds` times)
+                break
         ok = ok and self.status()[1] == 0
         if self.world > 1:
             flag = torch.tensor([1.0 if ok else 0.0], device=self.device if dist.get_backend(self.group) != "gloo" else "cpu")
