@@ -50,12 +50,13 @@ def main(batch=256, horizon=64, iters=200, device="cuda:0", verbose=True, seed=0
     t0 = time.perf_counter()
     for it in range(iters):
         plan.launch()                                                    # plan.cost (B,H), plan.gq, plan.gqd (B,H,D)
+        if verbose and (it % 50 == 0 or it == iters - 1):
+            # the prior's share of plan.cost, from the SAME q / qd the launch read (before the step moves them in place)
+            c_gp = ops.gp_prior_cost_grad(q, qd, dt, sigma_gp)[0]
+            hist.append((it, float((plan.cost.sum(1) - c_gp).mean()) / w_obj, float(c_gp.mean())))
         q.grad = free_mask * plan.gq                                     # gradients come from the kernel, not from autograd
         qd.grad = plan.gqd
         opt.step()                                                       # in place: the plan keeps reading q's and qd's buffers
-        if verbose and (it % 50 == 0 or it == iters - 1):
-            c_gp = ops.gp_prior_cost_grad(q, qd, dt, sigma_gp)[0]
-            hist.append((it, float((plan.cost.sum(1) - c_gp).mean()) / w_obj, float(c_gp.mean())))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     coll0 = task.compute_collision(q_start + s * (q_goal - q_start)).any(1).float().mean().item()

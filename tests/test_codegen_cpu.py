@@ -174,3 +174,24 @@ def test_unit_with_another_struct_layout_is_refused():
     finally:
         real.write_bytes(orig)
     assert jit._generator_stamp() == stamp
+
+
+def test_hiprtc_flags_follow_the_makefile():
+    """the hipRTC fall-back compiles a unit's device half with a hard-coded flag list (jit.RTC_FLAGS); ahead-of-time and
+    hipcc units take theirs from csrc/Makefile.  Every DEVICE code-generation flag of the Makefile must be in the hipRTC list, so the
+    two kinds of unit cannot drift apart."""
+    import re
+    from pathlib import Path
+    from torch_robotics_amd import jit
+    mk = (Path(jit.__file__).resolve().parent / "csrc" / "Makefile").read_text()
+    cxx = re.search(r"^CXXFLAGS \?= (.*)$", mk, re.M).group(1).split()
+    gen = re.search(r"^GENFLAGS \?= (.*)$", mk, re.M).group(1).split()
+    rule = re.search(r"^generated/%\.o:.*\n\t(.*)$", mk, re.M).group(1).split()
+    device_flags = [f for f in cxx if f.startswith(("-O", "-std=", "-ffp-contract"))]
+    device_flags += [cxx[i + 1] for i, f in enumerate(cxx) if f == "-Xarch_device"]
+    device_flags += [rule[i + 1] for i, f in enumerate(rule) if f == "-Xarch_device"]
+    device_flags += [f for f in gen if f != "-mllvm"]
+    assert "-fno-slp-vectorize" in device_flags and "-mno-amdgpu-ieee" in device_flags and any("max-ilp" in f for f in device_flags)
+    missing = [f for f in device_flags if f not in jit.RTC_FLAGS]
+    assert missing == [], f"device flags of csrc/Makefile missing from jit.RTC_FLAGS: {missing}"
+    assert "--offload-arch=gfx950" in jit.RTC_FLAGS

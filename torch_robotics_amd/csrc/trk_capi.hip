@@ -127,12 +127,23 @@ struct ModuleUnit {
 };
 std::vector<ModuleUnit*>& module_units() { static std::vector<ModuleUnit*> v; return v; }
 
+hipError_t g_module_launch_error = hipSuccess;     // the latest failure of a code-object launch: picked up by last_launch_error()
+hipError_t last_launch_error() {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = g_module_launch_error;
+    g_module_launch_error = hipSuccess;
+    return e;
+}
 template <class Args>
 void mod_launch(hipFunction_t f, unsigned grid, unsigned block, size_t lds, const Args& a, hipStream_t st) {
     Args copy = a;
     size_t size = sizeof(Args);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &copy, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    (void)hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds, st, nullptr, extra);
+    // a failed launch is reported like a failed <<< >>> launch: through hipGetLastError, which every C-ABI entry point checks after
+    // its launcher returns (hipModuleLaunchKernel hands its status back instead of latching it: a code object loaded on another
+    // device than the current one, an unresolved function)
+    const hipError_t e = hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, (unsigned)lds, st, nullptr, extra);
+    if (e != hipSuccess) g_module_launch_error = e;
 }
 inline const ModuleUnit* unit_of(const SpecEntry* self) { return static_cast<const ModuleUnit*>(self->module_ctx); }
 inline unsigned blocks_of(int64_t n) { return (unsigned)((n + SPEC_BLOCK - 1) / SPEC_BLOCK); }
@@ -542,7 +553,7 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = out;
         m->spec->launch(m->spec, a, base_is_identity(m), (hipStream_t)stream);
-        TRK_HIP(hipGetLastError());
+        TRK_HIP(last_launch_error());
         return TRK_OK;
     }
     if (mode == 0 && ns == 1 && model_spec(m) && m->spec_enabled && m->spec->launch_fk1) {
@@ -558,7 +569,7 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
         for (int p = 0; p < m->hdr.n_links; ++p) if (m->links[p].link == a.jac_link) a.jac_p_end = p + 1;
         if (a.jac_link >= 0) {
             m->spec->launch_fk1(m->spec, a, base_is_identity(m), (hipStream_t)stream);
-            TRK_HIP(hipGetLastError());
+            TRK_HIP(last_launch_error());
             return TRK_OK;
         }
     }
@@ -571,11 +582,11 @@ static int fk_fwd(int mode, const TrkModel* m, const float* q, int64_t n, const 
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.fk_H = out;
         m->spec->launch_fkh(m->spec, a, base_is_identity(m), (hipStream_t)stream);
-        TRK_HIP(hipGetLastError());
+        TRK_HIP(last_launch_error());
         return TRK_OK;
     }
     trk_launch_fk_forward(mode, m->hdr, m->d_links, sel, ns, q, n, out, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -603,7 +614,7 @@ static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin,
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.fk_H = const_cast<float*>(gin); a.gq = gq;
         m->spec->launch_fkhbwd(m->spec, a, base_is_identity(m), (hipStream_t)stream);
-        TRK_HIP(hipGetLastError());
+        TRK_HIP(last_launch_error());
         return TRK_OK;
     }
     if (mode == 1 && spec_all_links(m, sel, ns) && m->spec->launch_posbwd) {
@@ -614,14 +625,14 @@ static int fk_bwd(int mode, const TrkModel* m, const float* q, const float* gin,
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = const_cast<float*>(gin); a.gq = gq;
         m->spec->launch_posbwd(m->spec, a, base_is_identity(m), (hipStream_t)stream);
-        TRK_HIP(hipGetLastError());
+        TRK_HIP(last_launch_error());
         return TRK_OK;
     }
     SelMap selp;
     for (int k = 0; k < TRK_MAX_LINKS; ++k) selp.col[k] = -1;
     for (int p = 0; p < m->hdr.n_links; ++p) selp.col[p] = sel.col[m->links[p].link];
     trk_launch_fk_backward(mode, m->hdr, m->d_links, m->d_fin, sel, selp, ns, q, gin, n, gq, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -707,11 +718,11 @@ int trk_fk_points(const TrkModel* m, const TrkPointSet* ps, const float* q, int6
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = pos_out;
         ps->spec->launch(ps->spec, a, base_is_identity(m), (hipStream_t)stream);
-        TRK_HIP(hipGetLastError());
+        TRK_HIP(last_launch_error());
         return TRK_OK;
     }
     trk_launch_fk_points(m->hdr, m->d_links, ps->dev, q, n, pos_out, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -731,11 +742,11 @@ int trk_fk_points_backward(const TrkModel* m, const TrkPointSet* ps, const float
         std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
         a.q = q; a.n = n; a.link_pos = const_cast<float*>(gpos); a.gq = gq;
         ps->spec->launch_posbwd(ps->spec, a, base_is_identity(m), (hipStream_t)stream);
-        TRK_HIP(hipGetLastError());
+        TRK_HIP(last_launch_error());
         return TRK_OK;
     }
     trk_launch_fk_points_backward(m->hdr, m->d_links, m->d_fin, ps->dev, q, gpos, n, gq, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -767,12 +778,12 @@ int trk_fk_jacobian(const TrkModel* m, const float* q, const float* qd, int64_t 
         }
         a.jac_pos = pos; a.jac_quat = quat; a.jac_lin = lin_jac; a.jac_ang = ang_jac;
         m->spec->launch_jac(m->spec, a, base_is_identity(m), (hipStream_t)stream);
-        TRK_HIP(hipGetLastError());
+        TRK_HIP(last_launch_error());
         return TRK_OK;
     }
     trk_launch_fk_jacobian(m->hdr, m->d_links, m->links.data(), q, qd, n, link, m->joint_list_idx[link], pos, quat, lin_jac, ang_jac,
                            vel_lin, vel_ang, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -782,7 +793,7 @@ int trk_fk_analytic_jacobian(const TrkModel* m, const float* q, int64_t n, float
     if (n < 0 || (n > 0 && (!J || (!q && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_analytic_jacobian: bad q/J/n");
     if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
     trk_launch_fk_analytic_jacobian(m->hdr, m->d_links, m->d_dofs, q, n, J, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -816,13 +827,13 @@ int trk_ik_steps(const TrkModel* m, int32_t link, const float* H_target, int32_t
             a.q = q; a.adam_m = adam_m; a.adam_v = adam_v;
             a.loss = done == 0 ? loss : nullptr; a.valid = done == 0 ? valid : nullptr;
             gen->launch_ik(gen, a, base_is_identity(m), (hipStream_t)stream);
-            TRK_HIP(hipGetLastError());
+            TRK_HIP(last_launch_error());
             continue;
         }
         trk_launch_ik_step(m->hdr, m->d_links, m->d_fin, link, H_target, per_sample_target, lower, upper, w_joint_limits,
                            se3_eps, lr, sched, k, n, q, adam_m, adam_v, done == 0 ? loss : nullptr, done == 0 ? valid : nullptr,
                            (hipStream_t)stream);
-        TRK_HIP(hipGetLastError());
+        TRK_HIP(last_launch_error());
     }
     return TRK_OK;
 }
@@ -855,7 +866,7 @@ int trk_ik_gn_steps(const TrkModel* m, int32_t link, const float* H_target, int3
     a.damping = damping; a.lm_gain = lm_gain; a.step_scale = step_scale; a.se3_eps = se3_eps; a.n = n;
     a.q = q; a.err = err; a.valid = valid;
     gen->launch_ikgn(gen, a, base_is_identity(m), (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -872,7 +883,7 @@ int trk_rotmat_to_quat(const float* R, int64_t n, int32_t stride, int32_t row_pi
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_rotmat_to_quat(R, n, stride, row_pitch, quat, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -882,7 +893,7 @@ int trk_rotation_from(int32_t kind, const float* in, int64_t n, float* R_out, tr
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_rotation_from(kind, in, n, R_out, nullptr, nullptr, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -892,7 +903,7 @@ int trk_rotation_from_backward(int32_t kind, const float* angle, const float* gR
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_rotation_from(kind, angle, n, nullptr, gR, gangle, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -913,7 +924,7 @@ int trk_frame_compose(int32_t op, const float* Ra, const float* ta, int64_t na, 
     if (rc) return rc;
     trk_launch_frame_compose(op, Ra, ta, two && na == 1 && n > 1, Rb, tb, two && nb == 1 && n > 1, n, R_out, t_out,
                              (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -928,7 +939,7 @@ int trk_frame_compose_backward(int32_t op, const float* Ra, const float* ta, con
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_frame_compose_bwd(op, Ra, ta, Rb, tb, gR, gt, n, gRa, gta, gRb, gtb, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -940,7 +951,7 @@ int trk_frame_transform_points(const float* R, const float* t, int64_t n, const 
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_frame_transform_points(R, t, n, points, P, out, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -952,7 +963,7 @@ int trk_frame_transform_points_backward(const float* gout, int64_t n, const floa
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_frame_transform_points_bwd(gout, n, points, P, gR, gt, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -963,7 +974,7 @@ int trk_frame_quat_euler(const float* R, int64_t n, int32_t stride, int32_t row_
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_frame_quat_euler(R, n, stride, row_pitch, quat_xyzw, euler, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -974,7 +985,7 @@ int trk_frame_quat_euler_backward(const float* R, int64_t n, int32_t stride, int
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_frame_quat_euler_bwd(R, n, stride, row_pitch, gquat_xyzw, geuler, gR, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1228,12 +1239,12 @@ int trk_cost_fields(const TrkCostModel* cm, int32_t fields, const float* link_po
             a.C = cm->hdr; a.w = w;
             a.n = n; a.fld_pos = link_pos; a.fld_gcost = gcost; a.fld_g = g_link_pos; a.cost = cost;
             e->launch_fields(e, a, 1, (hipStream_t)stream);
-            TRK_HIP(hipGetLastError());
+            TRK_HIP(last_launch_error());
             return TRK_OK;
         }
     }
     trk_launch_cost_fields(cm->hdr, fields, link_pos, n, gcost, cost, g_link_pos, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1252,12 +1263,12 @@ int trk_collision_fields(const TrkCostModel* cm, int32_t fields, const float* li
             a.n = n; a.fld_pos = link_pos; a.coll_out = in_collision; a.coll_fields = fields;
             a.coll_use_default = use_default; a.coll_margin = use_default ? 0.0f : margin_override;
             e->launch_fields(e, a, 1, (hipStream_t)stream);
-            TRK_HIP(hipGetLastError());
+            TRK_HIP(last_launch_error());
             return TRK_OK;
         }
     }
     trk_launch_collision_fields(cm->hdr, fields, link_pos, n, use_default ? 0.0f : margin_override, use_default, in_collision, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1268,7 +1279,7 @@ int trk_ee_cost(const TrkCostModel* cm, const float* H_ee, int64_t n, int64_t st
         return fail(TRK_ERR_INVALID_ARG, "trk_ee_cost: bad argument (strides must be multiples of 4 floats, >= 16)");
     if (n == 0) return TRK_OK;
     trk_launch_ee_cost(cm->hdr, H_ee, n, stride, target, per_sample, gcost, cost, gH, g_stride, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1295,13 +1306,13 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
             a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
             a.stamps = g_stamps; a.io_f16 = io_f16; a.grad_scale = grad_scale;
             e->launch(e, a, base_is_identity(m), (hipStream_t)stream);
-            TRK_HIP(hipGetLastError());
+            TRK_HIP(last_launch_error());
             return TRK_OK;
         }
     }
     if (trk_lds_rollout(m->hdr, m->hdr.n_links + cm->hdr.n_virtual) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, std::string(who) + ": position tiles (links + interpolated points) exceed the 160 KiB LDS");
     trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, nullptr, cm->hdr, *w, io_f16, grad_scale, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1338,7 +1349,7 @@ int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fie
             a.coll_out = in_collision; a.coll_fields = fields; a.coll_use_default = use_default;
             a.coll_margin = use_default ? 0.0f : margin_override;
             e->launch_coll(e, a, base_is_identity(m), (hipStream_t)stream);
-            TRK_HIP(hipGetLastError());
+            TRK_HIP(last_launch_error());
             return TRK_OK;
         }
     }
@@ -1347,7 +1358,7 @@ int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fie
     rc = trk_fk_positions(m, q, n, nullptr, 0, link_pos_ws, stream);
     if (rc) return rc;
     trk_launch_collision_fields(cm->hdr, fields, link_pos_ws, n, use_default ? 0.0f : margin_override, use_default, in_collision, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1384,7 +1395,7 @@ int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t
     a.coll_margin = use_default ? 0.0f : margin_override;
     a.via_alpha = alpha; a.via_beta = beta; a.via_n = n_interp; a.via_H = horizon; a.via_S = state_dim;
     e->launch_coll(e, a, base_is_identity(m), (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1401,7 +1412,7 @@ int trk_traj_validate(const uint8_t* waypoint_collisions, const float* x, int64_
     if (rc) return rc;
     trk_launch_traj_validate(waypoint_collisions, x, n_traj, horizon, state_dim, n_waypoints, n_dofs, q_min, q_max, inner, flags,
                              idx, counts, counts_host, ticket, gathered, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1452,7 +1463,7 @@ int trk_rollout_gp_cost_grad(const TrkModel* m, const TrkCostModel* cm, const Tr
             a.qd = qd; a.gqd = gqd; a.gp_dt = gp->dt; a.gp_w = gp->weight; a.gp_H = horizon;
             a.gp_a = 12.0f * s2 / (gp->dt * gp->dt * gp->dt); a.gp_b = -6.0f * s2 / (gp->dt * gp->dt); a.gp_c = 4.0f * s2 / gp->dt;
             if (e->launch_gp(e, a, base_is_identity(m), (hipStream_t)stream) == 0) {
-                TRK_HIP(hipGetLastError());
+                TRK_HIP(last_launch_error());
                 return TRK_OK;
             }
         }
@@ -1471,7 +1482,7 @@ int trk_rollout_gp_cost_grad(const TrkModel* m, const TrkCostModel* cm, const Tr
         return fail(TRK_ERR_UNSUPPORTED, std::string(who) + ": one trajectory (horizon x dof x 2 floats) must fit the 160 KiB LDS");
     trk_launch_gp_sample_cost(io_dtype == TRK_F16, q, qd, n, horizon, m->hdr.n_dofs, gp->dt, gp->sigma, gp->weight, cost, cost_sum,
                               (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1502,12 +1513,12 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
             a.q = q; a.n = n; a.link_pos = point_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
             a.stamps = nullptr; a.io_f16 = 0;
             e->launch(e, a, base_is_identity(m), (hipStream_t)stream);
-            TRK_HIP(hipGetLastError());
+            TRK_HIP(last_launch_error());
             return TRK_OK;
         }
     }
     trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, &ps->dev, cm->hdr, *w, 0, 1.0f, q, n, point_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1519,7 +1530,7 @@ int trk_interpolate_via_points(const float* x, int64_t n_traj, int32_t horizon, 
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_interpolate(x, n_traj, horizon, dim, n_interp, alpha, beta, out, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1534,7 +1545,7 @@ int trk_jtj(const float* lin_jac, const float* ang_jac, const float* residual, i
     if (rc) return rc;
     if (trk_launch_jtj(use_mfma != 0, lin_jac, ang_jac, residual, n, dof, JtJ, Jtr, damping, damping_stride, dq, (hipStream_t)stream))
         return fail(TRK_ERR_UNSUPPORTED, "trk_jtj: tiles exceed the 160 KiB LDS");
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1547,7 +1558,7 @@ int trk_scale_rows(const void* g, const float* scale, int32_t scale_stride, int6
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_scale_rows(io_dtype == TRK_F16, g, scale, scale_stride, n, dim, out, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1559,7 +1570,7 @@ int trk_interpolate_columns(const float* x, int64_t n, int32_t n_in, int32_t cha
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_interpolate_columns(x, n, n_in, channels, n_out, src, w, out, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1571,7 +1582,7 @@ int trk_interpolate_columns_backward(const float* gout, int64_t n, int32_t n_in,
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_interpolate_columns_bwd(gout, n, n_in, channels, n_out, src, w, gx, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1590,7 +1601,7 @@ int trk_gp_prior_cost_grad(const void* q, const void* qd, int64_t batch, int32_t
     if (trk_launch_gp_prior(io_dtype == TRK_F16, grad_dtype == TRK_F16, grad_scale, q, qd, batch, horizon, dof, dt, sigma, weight, cost, gq, gqd,
                             accumulate, (hipStream_t)stream))
         return fail(TRK_ERR_UNSUPPORTED, "trk_gp_prior_cost_grad: one trajectory (horizon x dof x 2 floats) must fit the 160 KiB LDS");
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1602,7 +1613,7 @@ int trk_finite_difference(const float* x, int64_t batch, int32_t horizon, int32_
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_finite_difference(x, batch, horizon, dim, dt, method, out, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1614,7 +1625,7 @@ int trk_traj_diff_norm_sum(const float* x, int64_t batch, int32_t horizon, int32
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_traj_diff_norm_sum(x, batch, horizon, state_dim, c0, dim, out, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1637,7 +1648,7 @@ int trk_pack_sums(const float* cost, const void* gq, int32_t grad_dtype, float g
     if (rc) return rc;
     trk_launch_pack_sums(cost, gq, grad_dtype == TRK_F16, 1.0f / grad_scale, cost_block_sums, traj_cost, (int)batch, horizon, dof,
                          (batch * horizon + 63) / 64, scratch, packed, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1646,7 +1657,7 @@ int trk_reduce_sum(const float* x, int64_t n, float* out, trk_stream_t stream) {
     int rc = ensure_init();
     if (rc) return rc;
     trk_launch_reduce_sum(x, n, out, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1655,7 +1666,7 @@ int trk_grid_precompute(const TrkCostModel* cm, const int32_t dims[3], const flo
     if (!cm || !dims || !lim_min || !lim_max || !sdf || !grad) return fail(TRK_ERR_INVALID_ARG, "trk_grid_precompute: null argument");
     for (int k = 0; k < 3; ++k) if (dims[k] < 1) return fail(TRK_ERR_INVALID_ARG, "trk_grid_precompute: bad dims");
     trk_launch_grid_precompute(cm->hdr, dims, lim_min, lim_max, sdf, grad, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
@@ -1664,7 +1675,7 @@ int trk_sdf_points(const TrkCostModel* cm, const float* points, int64_t n, float
     if (n < 0 || (n > 0 && (!points || !sdf))) return fail(TRK_ERR_INVALID_ARG, "trk_sdf_points: bad argument");
     if (n == 0 || cm->hdr.n_objects == 0) return TRK_OK;
     trk_launch_sdf_points(cm->hdr, points, n, sdf, grad, (hipStream_t)stream);
-    TRK_HIP(hipGetLastError());
+    TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
