@@ -206,6 +206,35 @@ def test_ur10_allegro_full_size(ops, oracle_lib):
     assert rel_err(cost.reshape(-1)[idx].cpu().numpy(), c64) < 1e-5 and grad_close(gq.reshape(-1, D)[idx].cpu().numpy(), g64)
 
 
+def test_stream_store_instantiation_gives_the_same_bits(ops):
+    """Launches whose working set exceeds the Infinity Cache take the F32Stream instantiation of the fused rollout (non-temporal output
+    stores, chosen by spec_stream_stores from the launch's bytes): the cache policy of a store must not change a single bit.  Forced on
+    and off at a small size, and crossed by size at 24576 x 64 (302 MB) against the write-through kernel."""
+    import os
+    kin, tmpl = codegen.template_for("panda")
+    from helpers import gold, panda_cost_spec
+    spec = panda_cost_spec(gold("cost_spheres3d"), gold("panda_robot"), ee_target=gold("rollout_panda")["target"])
+    h, cm = ops.ModelHandle(kin), ops.CostHandle(spec, DEV)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    w = (1.0, 1.0, 1.0, 1.0)
+    try:
+        for B, H in ((37, 64), (24576, 64)):
+            q = (torch.rand(B, H, 7, generator=gen, **TA) - 0.5) * 5.0
+            res = {}
+            for mode in ("0", "1"):
+                os.environ["TRK_STREAM_STORES"] = mode
+                pos, cost, gq = ops.rollout_cost_grad(h, cm, w, q)
+                torch.cuda.synchronize()
+                res[mode] = (pos.clone(), cost.clone(), gq.clone())
+            for a, b in zip(res["0"], res["1"]):
+                assert torch.equal(a, b)
+            del os.environ["TRK_STREAM_STORES"]
+            pos, cost, gq = ops.rollout_cost_grad(h, cm, w, q)          # the launch's own choice (by bytes)
+            assert torch.equal(pos, res["0"][0]) and torch.equal(cost, res["0"][1]) and torch.equal(gq, res["0"][2])
+    finally:
+        os.environ.pop("TRK_STREAM_STORES", None)
+
+
 def test_dual_panda_fp16_gp_full_size(ops, oracle_lib):
     """configs[4]: dual Panda, one GPU's 2048 x 128 share of the 8192 x 128 batch, fp16 q / link positions / gradient in HBM,
     fp32 arithmetic and cost, GP prior accumulated into the same gradient."""

@@ -1657,7 +1657,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"    auto go = [&](auto io, {params}) {{")
     out.append("        using IOT = decltype(io);")
     out.append(f"        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<IOT, {targs}>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-    out.append(f"        else hipLaunchKernelGGL((k_rollout_bg<IOT, {targs}>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+    out.append("        // (a robot moved by update_base_pose keeps the write-through stores beyond the cache: one instantiation less per unit)")
+    out.append(f"        else hipLaunchKernelGGL((k_rollout_bg<typename TrkIf<TrkSame<IOT, F32Stream>::value, float, IOT>::type, {targs}>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
     out.append("    };")
     prev = "go"
     for k in range(n_sw - 1, -1, -1):             # innermost lambda decides the LAST switch
@@ -1667,7 +1668,9 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append(f"    auto sw{k} = [&](auto io{sep}{fixed}) {{ if ({switches[k]}) {prev}(io{sep}{fixed_args}, std::true_type{{}}); "
                    f"else {prev}(io{sep}{fixed_args}, std::false_type{{}}); }};")
         prev = f"sw{k}"
-    out.append("    if (a.io_f16 == TRK_IO_F16) sw0(_Float16{}); else if (a.io_f16 == TRK_IO_F16_G32) sw0(HalfG32{}); else sw0(float{});")
+    out.append("    // fp32 launches whose working set exceeds the Infinity Cache take the non-temporal-store instantiation (spec_stream_stores)")
+    out.append(f"    if (a.io_f16 == TRK_IO_F16) sw0(_Float16{{}}); else if (a.io_f16 == TRK_IO_F16_G32) sw0(HalfG32{{}}); "
+               f"else if (spec_stream_stores(a, {L}, {D})) sw0(F32Stream{{}}); else sw0(float{{}});")
     out.append("}")
     if gp_ok or gpt_ok:
         out.append("static int launch_gp(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
@@ -2048,23 +2051,43 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                 E.raw("            pt0 += py[l] * gz[l] - pz[l] * gy[l]; pt1 += pz[l] * gx[l] - px[l] * gz[l]; pt2 += px[l] * gy[l] - py[l] * gx[l];")
                 E.raw("        }")
                 E.raw("    }")
-            # ---- self-collision pairs whose later column belongs to this link
+            # ---- self-collision pairs whose later column belongs to this link.  Round 5: FACTORISED.  A pair hands back only
+            # s = w / ||d|| (spec_self_pair_s); the force on a point is a sum over its pairs, sum_e s_e (p_e - p) = V - p S with
+            # S = sum s_e, V = sum s_e p_e -- one add per pair (+ one FMA per non-zero component of the partner, which is often a
+            # constant: link origins on the base's axis), and ONE wrench update (9 instructions) per point instead of one per pair;
+            # the partner's force is U - p_e T the same way.  The grasped-box model has 66 pairs on 14 + 4 points: 2061 of the kernel's
+            # 5532 static vector instructions were this phase (tools/isa_valu_count.sh).
             if pairs_at[i]:
                 E.raw("    if (A.w.w_self != 0.0f) {")
-                E.raw("        float gl0, gl1, gl2;")
+                E.raw("        const bool sclamp = (A.C.clamp_fields & TRK_FIELD_SELF) != 0;")
                 earlies = sorted({early for _, _, early, _ in pairs_at[i]})
-                for e in earlies:             # all pairs of one earlier column push on the same point: sum the forces first
-                    E.raw(f"        float ge{e}_0 = 0.0f, ge{e}_1 = 0.0f, ge{e}_2 = 0.0f;")
-                for pi, late, early, late_is_a in pairs_at[i]:
-                    pa, pb = (late, early) if late_is_a else (early, late)
-                    gl, ge = "gl0, gl1, gl2", f"ge{early}_0, ge{early}_1, ge{early}_2"
-                    ga, gb = (gl, ge) if late_is_a else (ge, gl)
-                    E.raw("        gl0 = gl1 = gl2 = 0.0f;")
-                    E.raw(f"        cost += spec_self_pair(A.w.w_self, cptr(A.C.self_margin)[{pi}], "
-                          f"{', '.join(E.expr(colpos[pa][k]) for k in range(3))}, {', '.join(E.expr(colpos[pb][k]) for k in range(3))}, "
-                          f"{ga}, {gb}, (A.C.clamp_fields & TRK_FIELD_SELF) != 0);")
-                    in_order(colpos[late], ["gl0", "gl1", "gl2"])
+                lates = sorted({late for _, late, _, _ in pairs_at[i]})
+                for e in earlies:             # all pairs of one earlier column push on the same point
+                    E.raw(f"        float gT{e} = 0.0f, gU{e}_0 = 0.0f, gU{e}_1 = 0.0f, gU{e}_2 = 0.0f;")
+                for c in lates:
+                    E.raw("        {")
+                    E.raw("        float gS = 0.0f, gV0 = 0.0f, gV1 = 0.0f, gV2 = 0.0f;")
+                    pc = [E.expr(colpos[c][k]) for k in range(3)]
+                    for pi, late, early, late_is_a in pairs_at[i]:
+                        if late != c:
+                            continue
+                        pe = [E.expr(colpos[early][k]) for k in range(3)]
+                        E.raw(f"        {{ const float s_ = spec_self_pair_s(A.w.w_self, cptr(A.C.self_margin)[{pi}], {', '.join(pc)}, {', '.join(pe)}, sclamp, cost);")
+                        upd = ["gS += s_;"]
+                        for k in range(3):
+                            if not (colpos[early][k].is_const and colpos[early][k].is_zero):
+                                upd.append(f"gV{k} = fmaf(s_, {pe[k]}, gV{k});")
+                        upd.append(f"gT{early} += s_;")
+                        for k in range(3):
+                            if not (colpos[c][k].is_const and colpos[c][k].is_zero):
+                                upd.append(f"gU{early}_{k} = fmaf(s_, {pc[k]}, gU{early}_{k});")
+                        E.raw("          " + " ".join(upd) + " }")
+                    E.raw(f"        const float gl0 = fmaf(-gS, {pc[0]}, gV0), gl1 = fmaf(-gS, {pc[1]}, gV1), gl2 = fmaf(-gS, {pc[2]}, gV2);")
+                    in_order(colpos[c], ["gl0", "gl1", "gl2"])
+                    E.raw("        }")
                 for e in earlies:
+                    pe = [E.expr(colpos[e][k]) for k in range(3)]
+                    E.raw(f"        const float ge{e}_0 = fmaf(-gT{e}, {pe[0]}, gU{e}_0), ge{e}_1 = fmaf(-gT{e}, {pe[1]}, gU{e}_1), ge{e}_2 = fmaf(-gT{e}, {pe[2]}, gU{e}_2);")
                     g = [f"ge{e}_0", f"ge{e}_1", f"ge{e}_2"]
                     if pl[e] == i:
                         in_order(colpos[e], g)

@@ -14,6 +14,9 @@
 #define SPEC_BLOCK (SPEC_WAVES * TRK_WAVE)
 #pragma once
 #include "trk_device.h"
+#ifndef __HIPCC_RTC__
+#include <cstdlib>
+#endif
 
 template <bool B, class T, class F> struct TrkIf { typedef T type; };        // std::conditional (no <type_traits> under hipRTC)
 template <class T, class F> struct TrkIf<false, T, F> { typedef F type; };
@@ -159,6 +162,18 @@ struct SpecEntry {
     void* module_ctx;           // nullptr for a linked / dlopen-ed unit; the code-object unit's kernel table otherwise
 };
 
+// Does this launch take the F32Stream instantiation (non-temporal output stores)?  Its working set -- q in, positions, cost and
+// gradient out -- exceeds the Infinity Cache.  TRK_STREAM_STORES=0 / 1 forces the answer, TRK_STREAM_STORE_BYTES moves the threshold
+// (default 256 MiB; measured: 201 MB per launch is faster write-through, 403 MB 27 % faster non-temporal).
+inline bool spec_stream_stores(const SpecArgs& a, int n_links, int n_dofs) {
+    // read per launch (two getenv calls, ~0.1 us): tests and A/B runs flip the switch inside one process
+    if (const char* e = std::getenv("TRK_STREAM_STORES")) return std::atoi(e) != 0;
+    const char* t = std::getenv("TRK_STREAM_STORE_BYTES");
+    const double threshold = t ? std::atof(t) : 256.0 * 1024 * 1024;
+    const double bytes = (double)a.n * (4.0 * n_dofs * 2 + 4.0 + (a.link_pos ? 12.0 * n_links : 0.0));
+    return bytes > threshold;
+}
+
 // registry filled by static initialisers of the generated translation units
 // returns 0 when the unit was accepted, TRK_ERR_INVALID_ARG (and registers nothing) when its layout stamp differs
 int trk_spec_register(const SpecEntry* e);
@@ -210,6 +225,19 @@ struct HalfG32 {};
 template <class IO> struct IoTraits { typedef IO Q; typedef IO G; static constexpr bool kScaled = false; };
 template <> struct IoTraits<_Float16> { typedef _Float16 Q; typedef _Float16 G; static constexpr bool kScaled = true; };
 template <> struct IoTraits<HalfG32> { typedef _Float16 Q; typedef float G; static constexpr bool kScaled = true; };
+// F32Stream: fp32 I/O whose output stores are NON-TEMPORAL (`nt`) instead of write-through (`sc1`) -- for launches whose working set
+// exceeds the 256 MB Infinity Cache.  Same-box A/B of the headline kernel (profiles/r05_ab_store_modifiers.txt): at 32768 x 64 (403 MB
+// per launch) `nt` 66 us against `sc1` 84 us (0.76 against 0.60 of the HBM peak); inside the cache it is the other way round (4096 x 64:
+// 11.4 against 9.15 us; 16384 x 64, 201 MB: 34.4 against 32.5), so the LAUNCH chooses (spec_stream_stores).  The HBM-side element type
+// is a 4-byte wrapper, so that IoQuad -- where every store instruction of the generated kernels lives -- can be specialised on it.
+struct trk_f32s {
+    float v;
+    __host__ __device__ trk_f32s() = default;
+    __host__ __device__ trk_f32s(float x) : v(x) {}
+    __host__ __device__ operator float() const { return v; }
+};
+struct F32Stream {};
+template <> struct IoTraits<F32Stream> { typedef trk_f32s Q; typedef trk_f32s G; static constexpr bool kScaled = false; };
 #define TRK_IO_F32 0
 #define TRK_IO_F16 1
 #define TRK_IO_F16_G32 2
@@ -256,6 +284,49 @@ template <> struct IoQuad<float> {
     static __device__ __forceinline__ void store_wt1_sm(unsigned long long base, unsigned voff, float a, unsigned long long mask) {
         unsigned long long saved;
         asm volatile("s_and_saveexec_b64 %0, %3\n global_store_dword %1, %2, %4 sc1\n s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(voff), "v"(a), "s"(mask), "s"(base) : "scc");
+    }
+};
+template <> struct IoQuad<trk_f32s> {      // IoQuad<float> with `nt` stores (generated from it: keep the two in step)
+    static constexpr uintptr_t kAlignMask = 15;
+    static __device__ __forceinline__ float4 load(const trk_f32s* p, int k) { return reinterpret_cast<const float4*>(p)[k]; }
+    static __device__ __forceinline__ void store_wt(trk_f32s* p, int k, const float4& v) { { const trk_f4 x = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off nt\n s_nop 1" :: "v"(reinterpret_cast<float4*>(p) + k), "v"(x)  TRK_STORE_CLOBBER); } }
+    // SGPR base + 32-bit per-lane byte offset: no 64-bit address arithmetic per lane
+    static __device__ __forceinline__ void store_wt_s(unsigned long long base, unsigned voff, const float4& v) {
+        const trk_f4 x = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n s_nop 1" :: "v"(voff), "v"(x), "s"(base)  TRK_STORE_CLOBBER);
+    }
+    // the same under a wave-uniform lane mask applied INSIDE the asm block (exec &= mask; store; restore): no control flow for
+    // the compiler, so the store's LDS read is scheduled like any other load instead of sitting in a three-instruction branch
+    // body right in front of its s_waitcnt
+    static __device__ __forceinline__ void store_wt_sm(unsigned long long base, unsigned voff, const float4& v, unsigned long long mask) {
+        const trk_f4 x = {v.x, v.y, v.z, v.w};
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %4\n global_store_dwordx4 %1, %2, %3 nt\n s_mov_b64 exec, %0\n s_nop 0"
+                     : "=&s"(saved) : "v"(voff), "v"(x), "s"(base), "s"(mask) : "scc");
+    }
+    static __device__ __forceinline__ void store_wt1(trk_f32s* p, float v) { asm volatile("global_store_dword %0, %1, off nt\n s_nop 1" :: "v"(p), "v"(v)  TRK_STORE_CLOBBER); }
+    static __device__ __forceinline__ void store_wt_sat(trk_f32s* p, int k, const float4& v) { store_wt(p, k, v); }
+    static __device__ __forceinline__ void store_wt1_sat(trk_f32s* p, float v) { store_wt1(p, v); }
+    static __device__ __forceinline__ void store_wt2(trk_f32s* p, float a, float b) { const trk_f2 x = {a, b}; asm volatile("global_store_dwordx2 %0, %1, off nt\n s_nop 1" :: "v"(p), "v"(x)  TRK_STORE_CLOBBER); }
+    static __device__ __forceinline__ void store_wt2_s(unsigned long long base, unsigned voff, float a, float b) {
+        const trk_f2 x = {a, b};
+        asm volatile("global_store_dwordx2 %0, %1, %2 nt\n s_nop 1" :: "v"(voff), "v"(x), "s"(base)  TRK_STORE_CLOBBER);
+    }
+    static __device__ __forceinline__ void store_wt1_s(unsigned long long base, unsigned voff, float a) {
+        asm volatile("global_store_dword %0, %1, %2 nt\n s_nop 1" :: "v"(voff), "v"(a), "s"(base)  TRK_STORE_CLOBBER);
+    }
+    // the same under a lane mask applied INSIDE the asm block (exec &= mask; store; restore): no control flow for the compiler,
+    // so a masked store does not end a scheduling region; an all-zero mask makes it a no-op
+    static __device__ __forceinline__ void store_wt2_sm(unsigned long long base, unsigned voff, float a, float b, unsigned long long mask) {
+        const trk_f2 x = {a, b};
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %4\n global_store_dwordx2 %1, %2, %3 nt\n s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "v"(voff), "v"(x), "s"(base), "s"(mask) : "scc");
+    }
+    static __device__ __forceinline__ void store_wt1_sm(unsigned long long base, unsigned voff, float a, unsigned long long mask) {
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %3\n global_store_dword %1, %2, %4 nt\n s_mov_b64 exec, %0"
                      : "=&s"(saved) : "v"(voff), "v"(a), "s"(mask), "s"(base) : "scc");
     }
 };
@@ -1051,6 +1122,18 @@ __device__ __forceinline__ bool spec_collision_links(const DevCostHdr& C, int fi
                    (C.ws_max[0] - px[l] < mg[l]) | (C.ws_max[1] - py[l] < mg[l]) | (C.ws_max[2] - pz[l] < mg[l]);
     }
     return hit;
+}
+// the same pair for the FACTORISED accumulation of the attached-point kernels: adds w * (margin - ||pa - pb||) to `cost` and returns
+// s = w / ||pa - pb|| (0 at coincident points / behind the hinge) -- the force on a is sum_pairs s (pb - pa), on b the opposite
+__device__ __forceinline__ float spec_self_pair_s(float w, float margin, float ax, float ay, float az, float bx, float by, float bz,
+                                                  bool clamp, float& cost) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const float rs = n2 > 0.0f ? trk_rsq(n2) : 0.0f;
+    const float nrm = n2 * rs;
+    if (clamp) w = margin - nrm > 0.0f ? w : 0.0f;
+    cost = fmaf(w, margin - nrm, cost);
+    return w * rs;
 }
 // one self-collision pair, boolean (distance_fields.py:210-215): ||pa - pb|| < margin, IEEE sqrt like torch.linalg.norm
 __device__ __forceinline__ bool spec_self_hit(float margin, float ax, float ay, float az, float bx, float by, float bz) {
