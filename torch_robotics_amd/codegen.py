@@ -1155,6 +1155,9 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("}")
         out.extend(E.lines)
         out.append("")
+        # (Round 5: a copy of this kernel with NON-TEMPORAL stores for outputs beyond the Infinity Cache -- what pays for the fused rollout's
+        # contiguous 1 KiB chunks, trk_spec_common.h F32Stream -- was built and measured: SLOWER for these 8-byte pieces, dual Panda 90.3 ->
+        # 116.1 us, UR10 + Allegro 96.9 -> 101.5 us, Panda (in cache) 27.4 -> 47.2 us; profiles/r05_bench_fkh_stream.txt.  Dropped.)
 
     # ---- the collision fields on GIVEN link positions (trk_cost_fields: EmbodimentDistanceFieldBase.compute_embodiment_cost,
     # distance_fields.py:107-124, for the fields selected by the caller): positions in through the LDS transpose, the fused

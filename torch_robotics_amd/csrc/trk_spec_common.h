@@ -165,13 +165,14 @@ struct SpecEntry {
 // Does this launch take the F32Stream instantiation (non-temporal output stores)?  Its working set -- q in, positions, cost and
 // gradient out -- exceeds the Infinity Cache.  TRK_STREAM_STORES=0 / 1 forces the answer, TRK_STREAM_STORE_BYTES moves the threshold
 // (default 256 MiB; measured: 201 MB per launch is faster write-through, 403 MB 27 % faster non-temporal).
-inline bool spec_stream_stores(const SpecArgs& a, int n_links, int n_dofs) {
+inline bool spec_stream_bytes(double bytes) {
     // read per launch (two getenv calls, ~0.1 us): tests and A/B runs flip the switch inside one process
     if (const char* e = std::getenv("TRK_STREAM_STORES")) return std::atoi(e) != 0;
     const char* t = std::getenv("TRK_STREAM_STORE_BYTES");
-    const double threshold = t ? std::atof(t) : 256.0 * 1024 * 1024;
-    const double bytes = (double)a.n * (4.0 * n_dofs * 2 + 4.0 + (a.link_pos ? 12.0 * n_links : 0.0));
-    return bytes > threshold;
+    return bytes > (t ? std::atof(t) : 256.0 * 1024 * 1024);
+}
+inline bool spec_stream_stores(const SpecArgs& a, int n_links, int n_dofs) {
+    return spec_stream_bytes((double)a.n * (4.0 * n_dofs * 2 + 4.0 + (a.link_pos ? 12.0 * n_links : 0.0)));
 }
 
 // registry filled by static initialisers of the generated translation units
