@@ -58,8 +58,8 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # fp32 vector peak 157.3 TFLOP/s = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flop: one 64-lane VALU instruction takes a SIMD 2 cycles
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
-# per-launch counters recorded by tools/run_r04_profiles.sh (earlier rounds' files as fall-backs)
-PMC_FILES = ("r04_pmc.json", "r03_pmc.json", "r02_hbm_traffic.json")
+# per-launch counters recorded by tools/run_r05_profiles.sh (earlier rounds' files as fall-backs)
+PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_hbm_traffic.json")
 DEFAULT_SHAPE = {"c2": (4096, 64), "c3": (4096, 64), "c4": (4096, 64), "c5": (2048, 128)}     # per-GPU batch x horizon
 SIGMA_GP, T_GP = 0.1, 5.0        # config 5's GP prior: sigma_gp of the reference's planner parameters (env_spheres_3d.py:57), 5 s trajectories
 

@@ -455,6 +455,9 @@ typedef struct TrkModuleUnitDesc {
     int32_t chunked, fast_switch, fkhbwd_ok, fields_ok, ik_ok, ikgn_ok, jac_ok, jac_direct, gp_ok;
     const void* code; uint64_t code_size;
     int32_t n_kernels; const char* const* name_exprs; const char* const* lowered_names;
+    /* n_points > 0: an ATTACHED-POINT unit (link spheres, grasped-object points): obj_link_idx / self_pairs are COLUMN indices of the
+     * point set, points_hash identifies it (codegen.points_hash); its kernels are the fused rollout and the positions' reverse mode */
+    int32_t n_points; uint64_t points_hash;
 } TrkModuleUnitDesc;
 int trk_spec_register_module(const TrkModuleUnitDesc* desc);
 /* The layout stamp the generated units of this library carry (TRK_SPEC_ABI_VERSION, sizeof(SpecArgs) + sizeof(IkArgs) +

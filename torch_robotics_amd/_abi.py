@@ -91,7 +91,8 @@ class ModuleUnitDesc(C.Structure):  # TrkModuleUnitDesc
                 ("chunked", C.c_int32), ("fast_switch", C.c_int32), ("fkhbwd_ok", C.c_int32), ("fields_ok", C.c_int32), ("ik_ok", C.c_int32),
                 ("ikgn_ok", C.c_int32), ("jac_ok", C.c_int32), ("jac_direct", C.c_int32), ("gp_ok", C.c_int32),
                 ("code", C.c_void_p), ("code_size", C.c_uint64),
-                ("n_kernels", C.c_int32), ("name_exprs", C.POINTER(C.c_char_p)), ("lowered_names", C.POINTER(C.c_char_p))]
+                ("n_kernels", C.c_int32), ("name_exprs", C.POINTER(C.c_char_p)), ("lowered_names", C.POINTER(C.c_char_p)),
+                ("n_points", C.c_int32), ("points_hash", C.c_uint64)]
 
 
 class GpPrior(C.Structure):         # TrkGpPrior

@@ -1861,7 +1861,7 @@ OBJ_GROUP = 6              # points evaluated against the scene together (regist
 
 
 def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str, snap: float = SNAP,
-                                   link_mode: bool = False) -> str:
+                                   link_mode: bool = False, meta: Optional[dict] = None) -> str:
     """Fused FK + objectives + gradient with the collision fields on attached points.  Differences to the link kernel:
 
     * each link's points are produced, scored against the scene and folded into ONE running wrench (f, p x f about the
@@ -2228,6 +2228,10 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         out.extend(E.lines)
         out.append("")
 
+    if meta is not None and not link_mode:
+        # what a code-object (hipRTC) build of this unit must contain: the name expressions of its kernels (jit.py, trk_spec_register_module)
+        meta["kernels"] = [f"spec_{ident}::k_rollout_{b}<{f}, float>" for b in ("bi", "bg") for f in ("true", "false")] + \
+                          [f"spec_{ident}::k_posbwd_{b}" for b in ("bi", "bg")]
     out.extend(_points_entry_lines(kin, pt, ident, link_mode))
     return "\n".join(out) + "\n"
 
@@ -2236,6 +2240,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
     out: List[str] = []
     obj = ", ".join(str(c) for c in pt.obj_cols) or "0"
     pairs = ", ".join(f"{a}, {b}" for a, b in pt.self_pairs) or "0"
+    out.append("#ifndef __HIPCC_RTC__          // the unit's host half: launchers and its registry entry")
     out.append(f"static const int32_t kObjCols[] = {{{obj}}};")
     out.append(f"static const int32_t kSelfPairs[] = {{{pairs}}};")
     out.append("template <class IO>")
@@ -2268,6 +2273,7 @@ def _points_entry_lines(kin: KinModel, pt: PointsTemplate, ident: str, link_mode
                f"0x{phash:016x}ull, launch_posbwd, {pt.ee2_link}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, "
                f"0, nullptr, nullptr}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
+    out.append("#endif      // !__HIPCC_RTC__")
     out.append(f"}}  // namespace spec_{ident}")
     return out
 

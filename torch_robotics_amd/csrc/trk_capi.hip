@@ -123,6 +123,7 @@ struct ModuleUnit {
     hipFunction_t gp[3][2][2] = {};             // [io][FAST or BOX][base identity]
     hipFunction_t posbwd[2] = {}, coll[2] = {}, fkh[2] = {}, fkhbwd[2] = {}, fk1[2] = {}, ik[2] = {}, ikgn[2] = {}, jac[2] = {};
     hipFunction_t fields = nullptr, collf = nullptr;
+    hipFunction_t prollout[2][2] = {};          // attached-point units: [FAST][base identity]
     SpecEntry entry{};
 };
 std::vector<ModuleUnit*>& module_units() { static std::vector<ModuleUnit*> v; return v; }
@@ -190,6 +191,12 @@ void mod_jac(const SpecEntry* self, const SpecArgs& a, int bi, hipStream_t st) {
     }
     mod_launch(u->jac[bi ? 1 : 0], (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE), TRK_WAVE, lds, a, st);
 }
+// an attached-point unit's fused rollout: the choice its generated launcher makes (codegen._points_entry_lines)
+void mod_points_rollout(const SpecEntry* self, const SpecArgs& a, int bi, hipStream_t st) {
+    const ModuleUnit* u = unit_of(self);
+    const bool fast = scene_is_fast(a.C) || a.w.w_obj == 0.0f;
+    mod_launch(u->prollout[fast ? 1 : 0][bi ? 1 : 0], blocks_of(a.n), SPEC_BLOCK, 0, a, st);
+}
 }  // namespace
 
 int trk_spec_register_module(const TrkModuleUnitDesc* d) {
@@ -218,6 +225,31 @@ int trk_spec_register_module(const TrkModuleUnitDesc* d) {
     const char* ios[3] = {"float", "_Float16", "HalfG32"};
     const char* tf[2] = {"false", "true"};
     const char* bs[2] = {"bg", "bi"};
+    if (d->n_points > 0) {
+        // attached-point unit: fused rollout (FAST / general scene, identity / general base) + the positions' reverse mode
+        for (int b = 0; b < 2 && ok; ++b) {
+            for (int f = 0; f < 2 && ok; ++f) ok = find(ns + "k_rollout_" + bs[b] + "<" + tf[f] + ", float>", &u->prollout[f][b]);
+            ok = ok && find(ns + "k_posbwd_" + bs[b], &u->posbwd[b]);
+        }
+        if (!ok) {
+            (void)hipModuleUnload(u->mod);
+            delete u;
+            return fail(TRK_ERR_INVALID_ARG, "trk_spec_register_module: a kernel of the attached-point unit is missing from the code object");
+        }
+        SpecEntry& E = u->entry;
+        E.spec_abi_version = TRK_SPEC_ABI_VERSION;
+        E.sizeof_args = (uint32_t)(sizeof(SpecArgs) + sizeof(IkArgs) + sizeof(IkGnArgs));
+        E.sizeof_entry = (uint32_t)sizeof(SpecEntry); E.sizeof_cost_hdr = (uint32_t)sizeof(DevCostHdr);
+        E.model_hash = d->model_hash; E.n_links = d->n_links; E.n_dofs = d->n_dofs;
+        E.n_obj_links = d->n_obj_links; E.obj_link_idx = u->obj.data();
+        E.n_self_pairs = d->n_self_pairs; E.self_pairs = u->pairs.data();
+        E.ee_link = d->ee_link; E.ee2_link = d->ee2_link; E.name = u->ident.c_str();
+        E.n_points = d->n_points; E.points_hash = d->points_hash;
+        E.launch = mod_points_rollout; E.launch_posbwd = mod_posbwd;
+        E.module_ctx = u;
+        module_units().push_back(u);
+        return trk_spec_register(&u->entry);
+    }
     for (int b = 0; b < 2 && ok; ++b) {
         for (int io = 0; io < 3 && ok; ++io)
             for (int sw = 0; sw < 2 && ok; ++sw) {

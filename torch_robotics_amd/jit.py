@@ -174,6 +174,66 @@ def _rtc_stamp() -> str:
     return "rtc-" + h.hexdigest()[:12]
 
 
+def _rtc_code_object(source: str, ident: str, kernels) -> tuple:
+    """hipRTC-compile `source` (or take the code object from the cache): (code bytes, lowered kernel names)"""
+    import json
+    JIT_DIR.mkdir(parents=True, exist_ok=True)
+    co, js = JIT_DIR / f"spec_{ident}.hsaco", JIT_DIR / f"spec_{ident}.rtc.json"
+    want = _rtc_stamp()
+    code = lowered = None
+    if co.exists() and js.exists():
+        try:
+            rec = json.loads(js.read_text())
+            if rec.get("stamp") == want and rec.get("kernels") == list(kernels):
+                code, lowered = co.read_bytes(), rec["lowered"]
+        except (OSError, ValueError):
+            pass
+    if code is None:
+        code, lowered = _rtc_compile(source, ident, list(kernels))
+        tag = f".tmp{os.getpid()}"
+        (JIT_DIR / f"spec_{ident}{tag}.hsaco").write_bytes(code)
+        os.replace(JIT_DIR / f"spec_{ident}{tag}.hsaco", co)
+        (JIT_DIR / f"spec_{ident}{tag}.json").write_text(json.dumps({"stamp": want, "kernels": list(kernels), "lowered": lowered}))
+        os.replace(JIT_DIR / f"spec_{ident}{tag}.json", js)
+    return code, lowered
+
+
+def _load_points_unit_rtc(kin: KinModel, pt: "codegen.PointsTemplate", ident: str) -> object:
+    """An ATTACHED-POINT unit (link spheres, grasped-object points) without hipcc: its device half compiled in-process, libtrk.so's
+    generic launchers as its host half (trk_spec_register_module with n_points > 0)."""
+    meta: dict = {}
+    source = codegen.generate_points_rollout_source(kin, pt, ident, meta=meta)
+    code, lowered = _rtc_code_object(source, ident, meta["kernels"])
+    L = _lib.lib()
+    from . import _abi
+    stamp = (C.c_int64 * 3)()
+    L.trk_spec_layout_stamp(stamp)
+    d = _abi.ModuleUnitDesc()
+    d.spec_abi_version, d.sizeof_args, d.sizeof_cost_hdr = int(stamp[0]), int(stamp[1]), int(stamp[2])
+    d.ident = ident.encode()
+    d.model_hash = codegen.model_hash(kin)
+    d.n_links, d.n_dofs = kin.n_links, kin.n_dofs
+    obj = np.ascontiguousarray(pt.obj_cols, np.int32)
+    pairs = np.ascontiguousarray(pt.self_pairs, np.int32).reshape(-1)
+    i32p = C.POINTER(C.c_int32)
+    d.n_obj_links, d.obj_link_idx = len(obj), obj.ctypes.data_as(i32p)
+    d.n_self_pairs, d.self_pairs = len(pairs) // 2, pairs.ctypes.data_as(i32p)
+    d.ee_link, d.ee2_link = int(pt.ee_link), int(pt.ee2_link)
+    d.n_virtual = 0
+    d.n_points, d.points_hash = len(pt.point_link), codegen.points_hash(pt.point_link, pt.point_offset)
+    buf = C.create_string_buffer(code, len(code))
+    d.code, d.code_size = C.cast(buf, C.c_void_p), len(code)
+    names = (C.c_char_p * len(meta["kernels"]))(*[k.encode() for k in meta["kernels"]])
+    lows = (C.c_char_p * len(lowered))(*[k.encode() for k in lowered])
+    d.n_kernels, d.name_exprs, d.lowered_names = len(lowered), names, lows
+    before = L.trk_spec_count()
+    _lib.check(L.trk_spec_register_module(C.byref(d)), "trk_spec_register_module")
+    if L.trk_spec_count() != before + 1:
+        raise _lib.TrkError(f"spec_{ident}: libtrk.so refused the code-object unit")
+    _rtc_keep.append((buf, names, lows, obj, pairs, d))
+    return d
+
+
 def _load_unit_rtc(kin: KinModel, tmpl: codegen.CollisionTemplate, ident: str) -> object:
     """generate + hipRTC-compile (or take from the cache) + register the code object with libtrk.so"""
     import json
@@ -182,7 +242,7 @@ def _load_unit_rtc(kin: KinModel, tmpl: codegen.CollisionTemplate, ident: str) -
     meta: dict = {}
     source = codegen.generate_link_kernel_source(kin, tmpl, ident, meta=meta)
     if not meta:
-        raise _lib.TrkError("the hipRTC fall-back serves link units only")
+        raise _lib.TrkError("this robot's link unit comes from the per-link pipeline generator, which the hipRTC fall-back does not serve")
     want = _rtc_stamp()
     code = lowered = None
     if co.exists() and js.exists():
@@ -393,9 +453,12 @@ def specialize_points(kin: KinModel, point_link, point_offset, spec, verbose: bo
              f"{_points_template_hash(pt)}")
     if ident in _loaded:
         return ident
-    so, stamp = JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
-    if not (so.exists() and stamp.exists() and stamp.read_text() == _generator_stamp()):
-        so = _compile_unit(codegen.generate_points_rollout_source(kin, pt, ident), ident, verbose)
-    _loaded[ident] = _load_unit(so, ident)
+    if hipcc_available():
+        so, stamp = JIT_DIR / f"spec_{ident}.so", JIT_DIR / f"spec_{ident}.stamp"
+        if not (so.exists() and stamp.exists() and stamp.read_text() == _generator_stamp()):
+            so = _compile_unit(codegen.generate_points_rollout_source(kin, pt, ident), ident, verbose)
+        _loaded[ident] = _load_unit(so, ident)
+    else:           # no compiler driver on this box: the unit's device half through hipRTC (round 5: attached-point units too)
+        _loaded[ident] = _load_points_unit_rtc(kin, pt, ident)
     _loaded_point_templates[ident] = (codegen.model_hash(kin), pt)
     return ident
