@@ -1451,6 +1451,28 @@ qd = torch.randn(3, 64, D, generator=gen, **TA) * 0.3
 a, b = both(lambda: ops.rollout_gp_cost_grad(h, cm, (0, 1, 1, 1), qq, qd, 0.08, 0.3))
 close(a[1], b[1], 2e-5); close(a[2], b[2], 1e-4); close(a[3], b[3], 1e-4)
 print("generic launchers ok")
+# (4) round 5: an ATTACHED-POINT unit through hipRTC -- a Panda holding another box (the grasp golden's point set, stretched: another
+# points hash, no ahead-of-time unit): table-driven result first, then the unit compiled in-process, registered as a code object
+from helpers import grasp_panda_setup
+mg, pl, po, gspec = grasp_panda_setup()
+po = (po * np.float32(1.25)).astype(np.float32)
+hg = ops.ModelHandle(mg)
+psg, cmg = ops.PointSetHandle(hg, pl, po, "cuda:0"), ops.CostHandle(gspec, "cuda:0")
+assert not psg.specialized
+qg3 = (torch.rand(3, 64, 7, generator=gen, **TA) - 0.5) * 4.0
+ref = [t.clone() for t in ops.rollout_points_cost_grad(psg, cmg, (1, 1, 1, 0), qg3)]
+ref_pos = ops.fk_points(psg, qg3.reshape(-1, 7)).clone()
+wpt = torch.randn(192, len(pl), 3, generator=gen, **TA)
+ref_bwd = ops.fk_points_backward(psg, qg3.reshape(-1, 7), wpt).clone()
+ident = jit.specialize_points(mg, pl, po, gspec)
+assert ident and any(jit.JIT_DIR.glob(f"spec_{ident}.hsaco")) and not any(jit.JIT_DIR.glob("*.so"))
+psg2 = ops.PointSetHandle(hg, pl, po, "cuda:0")
+assert psg2.specialized
+got = ops.rollout_points_cost_grad(psg2, cmg, (1, 1, 1, 0), qg3)
+close(got[0], ref[0], 3e-6); close(got[1], ref[1], 1e-5); close(got[2], ref[2], 1e-4)
+close(ops.fk_points(psg2, qg3.reshape(-1, 7)), ref_pos, 3e-6)
+close(ops.fk_points_backward(psg2, qg3.reshape(-1, 7), wpt), ref_bwd, 1e-4)
+print("rtc points ok")
 print("done")
 """
     root = str(ROOT) if "ROOT" in globals() else os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1461,4 +1483,4 @@ print("done")
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=1800)
     assert p.returncode == 0 and "done" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
     from torch_robotics_amd import codegen
-    assert p.stdout.count("ok ") >= len(codegen.SPEC_ROBOTS) and "rtc ok" in p.stdout and "generic launchers ok" in p.stdout
+    assert p.stdout.count("ok ") >= len(codegen.SPEC_ROBOTS) and "rtc ok" in p.stdout and "generic launchers ok" in p.stdout and "rtc points ok" in p.stdout
