@@ -430,7 +430,61 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         for i in adj_links:
             E.raw(f"    float tb{i}_0 = 0.0f, tb{i}_1 = 0.0f, tb{i}_2 = 0.0f;")
         t = with_virtual(E, t)
-        if 0 < NL <= LINK_OBJ_GROUP_MAX:
+        # leading collision links whose position is a CONSTANT of the model (identity base: the Panda's first link origin): in the
+        # GENERAL-scene instantiation (boxes / grid: scene_is_general) their object cost is evaluated once per wavefront, cooperatively
+        # (scene_min_sdf_uniform_point), instead of 64 times through the primitive loop; they get no gradient (no joint moves them).
+        # The spheres-only instantiation keeps its text (its register allocation is the headline's).
+        n_const = 0
+        if prims_ptr and os.environ.get("TRK_EXP_NO_UNIFORM_POINT", "0") != "1":
+            for i in tmpl.obj_links:
+                if all(t[i][k].is_const for k in range(3)) and i not in used_virt:
+                    n_const += 1
+                else:
+                    break
+        if 0 < n_const < NL <= LINK_OBJ_GROUP_MAX:
+            rest = list(tmpl.obj_links[n_const:])
+            nr = len(rest)
+            c0 = next_chunk[0]
+            next_chunk[0] += OBJ_TICK_SLOTS
+            E.raw(f"    const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
+            # (a voxel-grid scene keeps all links in one batch: its cost is the gathers' latency, and a separate gather for the constant
+            # link in front of the others only adds a second exposed latency: 22.8 -> 23.8 us measured)
+            E.raw("    if (BOX && !A.C.has_grid) {")
+            for k, nm in enumerate("xyz"):
+                E.raw(f"        const float p{nm}[{nr}] = {{{', '.join(E.expr(t[i][k]) for i in rest)}}};")
+            E.raw(f"        float gx[{nr}], gy[{nr}], gz[{nr}];")
+            E.raw("#pragma unroll")
+            E.raw(f"        for (int l = 0; l < {nr}; ++l) {{ gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }}")
+            fa = fast_arg.replace("NL", str(nr))
+            E.raw(f"        if (A.w.w_obj != 0.0f) {{")
+            for j in range(n_const):      # first: its table reads (LDS) / grid gather are issued before this phase's position ticks
+                i = tmpl.obj_links[j]
+                E.raw(f"            cost += spec_object_cost_uniform_point(A.C, A.w.w_obj, {', '.join(E.expr(t[i][k]) for k in range(3))}, {j}, lane, {prims_ptr});")
+            E.raw(f"            cost += spec_objects_cost<{nr}{fa}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, {n_const}, {prims_ptr});")
+            E.raw("        }")
+            E.raw(f"        else flush.template range<{c0}, {next_chunk[0]}>();")
+            E.raw(f"        if (A.w.w_ws != 0.0f && A.C.has_ws) {{")
+            E.raw(f"            cost += spec_ws_cost<{nr}>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, {n_const});")
+            for j in range(n_const):
+                i = tmpl.obj_links[j]
+                E.raw(f"            {{ float ux_ = 0.0f, uy_ = 0.0f, uz_ = 0.0f; cost += A.w.w_ws * ws_cost_point(A.C, cptr(A.C.obj_link_margin)[{j}], "
+                      f"{', '.join(E.expr(t[i][k]) for k in range(3))}, A.w.w_ws, ux_, uy_, uz_); }}")
+            E.raw("        }")
+            for j, i in enumerate(rest):
+                E.raw(f"        tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
+            E.raw("    } else {")
+            for k, nm in enumerate("xyz"):
+                E.raw(f"        const float p{nm}[NL] = {{{', '.join(E.expr(t[i][k]) for i in tmpl.obj_links)}}};")
+            E.raw("        float gx[NL], gy[NL], gz[NL];")
+            E.raw("#pragma unroll")
+            E.raw("        for (int l = 0; l < NL; ++l) { gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }")
+            E.raw(f"        if (A.w.w_obj != 0.0f) cost += spec_objects_cost<NL{fast_arg}>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, 0, {prims_ptr});")
+            E.raw(f"        else flush.template range<{c0}, {next_chunk[0]}>();")
+            E.raw("        if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost<NL>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz);")
+            for j, i in enumerate(tmpl.obj_links):
+                E.raw(f"        tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
+            E.raw("    }")
+        elif 0 < NL <= LINK_OBJ_GROUP_MAX:
             for k, nm in enumerate("xyz"):
                 E.raw(f"    const float p{nm}[NL] = {{{', '.join(E.expr(t[i][k]) for i in tmpl.obj_links)}}};")
             E.raw("    float gx[NL], gy[NL], gz[NL];")

@@ -564,6 +564,54 @@ __device__ __forceinline__ void scene_boxes_lds(const DevCostHdr& C, const float
     }
 }
 
+// The scene's minimum signed distance at ONE point that is the same for every lane of the wavefront (a collision link whose position is
+// a constant of the model: the Panda's first link origin sits on the base's axis) -- evaluated COOPERATIVELY instead of 64 times: lane k
+// takes sphere k / primitive k of each box object, then a wave-wide minimum.  Value only: a point no joint moves has no gradient to
+// hand back.  Same functions as scene_min_sdf (prim_sdf, grid_sdf); the association order of the minimum does not matter to a min.
+// Box scenes spend a fifth of their primitive loop on such a link (11 - 14 boxes x 20 instructions + the winner blocks: ~300 of 2600
+// vector instructions per wavefront on the Panda); here it is ~45.
+// lds_prims (nullable): the wave's LDS copy of the primitive table (spec_load_prims_issue: tables up to TRK_LDS_PRIMS records) -- a
+// per-lane record then comes from LDS (lgkmcnt) instead of a vector load, whose s_waitcnt vmcnt would also wait for every position
+// store the wave has in flight (first version: shelf 17.59 -> 17.54 us, i.e. nothing; loads and stores share vmcnt on this ISA).
+__device__ __forceinline__ float scene_min_sdf_uniform_point(const DevCostHdr& C, float x, float y, float z, int lane,
+                                                             const float4* lds_prims = nullptr) {
+    float v = __builtin_inff();
+    for (int k = lane; k < C.n_spheres; k += TRK_WAVE) {
+        const float4 S = C.spheres[k];
+        const float dx = x - S.x, dy = y - S.y, dz = z - S.z;
+        const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+        v = __builtin_fminf(v, fmaf(n2, trk_rsq(__builtin_fmaxf(n2, 1.17549435e-38f)), -S.w));
+    }
+    for (int b = 0; b < C.n_box_objects; ++b) {
+        const int o = cptr(C.box_objects)[b];
+        const DevObj O = load_obj(C.objects, o);
+        const float dx = x - O.pos[0], dy = y - O.pos[1], dz = z - O.pos[2];
+        float lx = dx, ly = dy, lz = dz;
+        if (!(O.identity & TRK_OBJ_IDENTITY)) {
+            lx = fmaf(O.R[0], dx, fmaf(O.R[3], dy, O.R[6] * dz));
+            ly = fmaf(O.R[1], dx, fmaf(O.R[4], dy, O.R[7] * dz));
+            lz = fmaf(O.R[2], dx, fmaf(O.R[5], dy, O.R[8] * dz));
+        }
+        for (int pi = O.prim_begin + lane; pi < O.prim_end; pi += TRK_WAVE) {
+            DevPrim P;
+            if (lds_prims && C.n_prims <= TRK_LDS_PRIMS) {
+                typedef __attribute__((address_space(3))) const float lds_cfloat;
+                lds_cfloat* rec = (lds_cfloat*)reinterpret_cast<const float*>(lds_prims) + 8 * pi;
+                P.type = __float_as_int(rec[0]); P.cx = rec[1]; P.cy = rec[2]; P.cz = rec[3]; P.hx = rec[4]; P.hy = rec[5]; P.hz = rec[6]; P.r = rec[7];
+            } else {
+                P = C.prims[pi];                                 // per-lane record: a vector load, 32 bytes
+            }
+            if (P.type == TRK_PRIM_SPHERE) continue;             // spheres live in the merged table
+            float gx, gy, gz;
+            v = __builtin_fminf(v, prim_sdf<false>(P, lx, ly, lz, gx, gy, gz));
+        }
+    }
+#pragma unroll
+    for (int m = TRK_WAVE / 2; m > 0; m >>= 1) v = __builtin_fminf(v, __shfl_xor(v, m, TRK_WAVE));
+    if (C.has_grid) { float gx, gy, gz; v = __builtin_fminf(v, grid_sdf(C.grid, x, y, z, gx, gy, gz)); }   // the same cell for every lane
+    return v;
+}
+
 // FAST: the caller guarantees (wave-uniformly, from the cost model header: scene_is_fast) that the scene is 1..16
 // spheres of one radius and nothing else, so only that path is compiled -- a kernel that inlines this function many
 // times (attached-point kernels: once per group of points) would otherwise not fit the instruction cache.

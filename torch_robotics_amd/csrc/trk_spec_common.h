@@ -1084,6 +1084,13 @@ __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w,
     return w * cost;
 }
 
+// the object field's cost of ONE collision link at a wave-uniform (constant) position: w * (margin - sdf) [hinge if clamped]; no gradient
+__device__ __forceinline__ float spec_object_cost_uniform_point(const DevCostHdr& C, float w, float x, float y, float z, int m_index, int lane,
+                                                                const float4* lds_prims = nullptr) {
+    const float v = cptr(C.obj_link_margin)[m_index] - scene_min_sdf_uniform_point(C, x, y, z, lane, lds_prims);
+    return w * ((C.clamp_fields & TRK_FIELD_OBJECTS) ? __builtin_fmaxf(v, 0.0f) : v);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // boolean collision fields on NL link points held in registers (distance_fields.py:210-215, 283-291; tasks.py:227-228 ORs the
 // fields).  Objects: the scene's minimum signed distance comes from the same ranking as the cost (one rsq per point); a
