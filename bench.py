@@ -635,6 +635,7 @@ def main():
         dist.all_reduce(flag)
 
     n_coll = [0]            # collectives inside the latest timed region
+    per_rank = [None]       # the latest timed region: every rank's wall clock and launch-stream time
 
     def measure(pl, cadence, steps=None, warmup=None):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize brackets; returns (wall s, event ms),
@@ -675,9 +676,12 @@ def main():
                   f"{1e6 * (time.perf_counter() - tb_):.1f} us, events {1e3 * ev0.elapsed_time(ev1):.1f} us", file=sys.stderr)
         ev_ms = ev0.elapsed_time(ev1)
         if distributed:
-            tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            wall = float(tmax.item())
+            # every rank's own figures (wall clock, launch stream by events): the MAX is the result, the spread says who was late
+            mine = torch.tensor([wall, ev_ms * 1e-3], device=dev, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank[0] = {"wall_us": [round(float(t[0]) * 1e6, 1) for t in allr], "launch_stream_us": [round(float(t[1]) * 1e6, 1) for t in allr]}
+            wall = max(float(t[0]) for t in allr)
         return wall, ev_ms
 
     # one rehearsal of the whole measurement (discarded): the first pass through the event / sync / launch code paths of a
@@ -705,6 +709,7 @@ def main():
         measure(plan, cadence)
         elapsed, ev_ms = measure(plan, cadence)
     n_coll_value = n_coll[0]
+    per_rank_value = per_rank[0]
 
     samples_per_step = B * H * world
     value = samples_per_step * args.steps / elapsed
@@ -890,7 +895,7 @@ def main():
             **({"rccl_allreduce": rccl_cmp} if rccl_cmp else {}),
             "collectives_in_timed_region": n_coll_value, "exchange_us": exchange_us,
             "allreduce_floats": int(local.numel()),
-            "with_allreduce": {"value": value, "ms_per_step": elapsed * 1e3 / args.steps},
+            "with_allreduce": {"value": value, "ms_per_step": elapsed * 1e3 / args.steps, "per_rank": per_rank_value},
             "kernel_only": {"value": samples_per_step * args.steps / ko_elapsed, "ms_per_step": ko_elapsed * 1e3 / args.steps},
             "every_step": {"value": samples_per_step * args.steps / es_elapsed, "ms_per_step": es_elapsed * 1e3 / args.steps,
                            "collectives_in_timed_region": n_coll_every},
