@@ -108,3 +108,19 @@ def test_mailbox_single_rank_and_argument_checks():
     assert L.trk_mailbox_exchange(h, x.data_ptr(), out.data_ptr(), None) == _abi.TRK_ERR_INVALID_ARG
     assert b"connect" in L.trk_last_error()
     L.trk_mailbox_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,floats", [(2, 513), (3, 1921)])
+def test_mailbox_soak_small(ranks, floats):
+    """tools/mailbox_soak.py with a few thousand exchanges: every rank computes every expected sum by itself (rank-order fp32 sum of
+    rows it can regenerate), eager send / receive pairs and replayed graphs with the receive one exchange behind its send; no
+    mismatch, no time-out.  (The long form -- 50 000 exchanges on 2 ranks, 12 500 on 4 -- ran clean in round 5.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29580 + ranks), str(ROOT / "tools" / "mailbox_soak.py"), "--single-device", "--exchanges", "3000",
+                        "--floats", str(floats)], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "mismatching exchanges 0, time-outs 0" in p.stdout
