@@ -646,7 +646,8 @@ int trk_pack_sums(const float* cost, const void* gq, int32_t grad_dtype, float g
  * the same sequence of exchanges; on one rank send k, recv k, send k + 1, ... must run in that (stream) order.  A rank that
  * waits longer than TRK_MAILBOX_TIMEOUT_S (environment, default 5 s) for a flag gives up, counts a time-out
  * (trk_mailbox_status) and writes an incomplete sum instead of hanging the GPU.
- *   create:     allocates the local mailbox (uncached / fine-grained device memory that hipIpcGetMemHandle accepts).
+ *   create:     allocates the local mailbox (uncached, else fine-grained, else plain device memory -- the first kind that
+ *               hipIpcGetMemHandle accepts; TRK_MAILBOX_ALLOC=uncached|finegrained|plain in the environment forces one).
  *   ipc_handle: writes the TRK_MAILBOX_HANDLE_BYTES bytes another process passes to connect (exchange them with any host
  *               transport, e.g. torch.distributed.all_gather_object).
  *   connect:    handles [world][TRK_MAILBOX_HANDLE_BYTES] (HOST; the entry of this rank is ignored): maps the peers' mailboxes.
