@@ -360,6 +360,55 @@ def cpu_baseline(wl, args, torch, seconds):
                          "sample": f"first {n_one} samples, same code on 1 thread, best of 2"}}
 
 
+def exchange_pieces(count, cadence):
+    """The exchange schedule of `count` steps: [(steps, exchange afterwards?)] -- one exchange per `cadence` steps, fired in the middle of
+    its interval (after step j whenever j % cadence == cadence // 2); cadence 0 = no exchange."""
+    if not cadence:
+        return [(count, False)] if count else []
+    out_, last = [], 0
+    for j in range(1, count + 1):
+        if j % cadence == cadence // 2:
+            out_.append((j - last, True)); last = j
+    if last < count:
+        out_.append((count - last, False))
+    return out_
+
+
+def exchange_schedule(count, cadence, graph_steps, mailbox, n_slots):
+    """What one call of run() issues for `count` steps: a list of ("graph", segs) / ("steps", n) / ("exchange",) items.
+    graph_steps: evaluations per captured graph at most (0 = eager launches).  segs = (a0, a1, ..., ak): a0 steps, exchange, a1 steps,
+    exchange, ..., ak steps.  With the mailbox and capture on, the exchanges ride INSIDE the graphs (<= graph_steps steps and <= n_slots
+    exchanges each: the driver's 20 timed steps with their exchange are ONE graph launch; an exchange that falls on a graph boundary
+    opens the next graph -- its pack reads the previous graph's last step); otherwise plain-step graphs (or eager steps) with an eager
+    exchange between them.  Pure function: tests/test_bench_launch.py checks step and exchange counts for many (count, cadence, size)."""
+    items = []
+    S = int(graph_steps)
+    if S and mailbox and cadence:
+        segs, steps_in = [0], 0
+        for n, ex in exchange_pieces(count, cadence):
+            while n > 0:
+                take = min(n, S - steps_in)
+                if take == 0:                                # the graph is full: close it
+                    items.append(("graph", tuple(segs))); segs, steps_in = [0], 0
+                    continue
+                segs[-1] += take; steps_in += take; n -= take
+            if ex:
+                if len(segs) > n_slots or steps_in >= S:    # start a new graph; the exchange opens it
+                    items.append(("graph", tuple(segs))); segs, steps_in = [0], 0
+                segs.append(0)
+        if steps_in or len(segs) > 1:
+            items.append(("graph", tuple(segs)))
+        return items
+    for n, ex in exchange_pieces(count, cadence):
+        while n > 0 and S:
+            items.append(("graph", (min(n, S),))); n -= min(n, S)
+        if n:
+            items.append(("steps", n))
+        if ex:
+            items.append(("exchange",))
+    return items
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -544,48 +593,10 @@ def main():
         return g
 
     def pieces(count, cadence):
-        """the exchange schedule of `count` steps: [(steps, exchange afterwards?)] -- one exchange per `cadence` steps, fired in the
-        middle of its interval"""
-        if not cadence:
-            return [(count, False)] if count else []
-        out_, last = [], 0
-        for j in range(1, count + 1):
-            if j % cadence == cadence // 2:
-                out_.append((j - last, True)); last = j
-        if last < count:
-            out_.append((count - last, False))
-        return out_
+        return exchange_pieces(count, cadence)
 
     def schedule(count, cadence):
-        """What run() issues for `count` steps: a list of ("graph", segs) / ("steps", n) / ("exchange",) items.  With the mailbox and
-        capture on, the exchanges ride INSIDE the graphs (whole intervals per graph, <= S steps each, so the driver's 20 timed steps
-        with their exchange are ONE graph launch); otherwise plain-step graphs with an eager exchange between them."""
-        items = []
-        in_graph = bool(S_live[0]) and mailbox is not None and cadence
-        if in_graph:
-            segs, steps_in = [0], 0
-            for n, ex in pieces(count, cadence):
-                while n > 0:
-                    take = min(n, S - steps_in)
-                    if take == 0:                                # the graph is full: close it (an exchange never ends a graph unless the run ends)
-                        items.append(("graph", tuple(segs))); segs, steps_in = [0], 0
-                        continue
-                    segs[-1] += take; steps_in += take; n -= take
-                if ex:
-                    if len(segs) > n_slots or steps_in >= S:    # start a new graph; the exchange opens it (its pack reads the previous graph's last step)
-                        items.append(("graph", tuple(segs))); segs, steps_in = [0], 0
-                    segs.append(0)
-            if steps_in or len(segs) > 1:
-                items.append(("graph", tuple(segs)))
-            return items
-        for n, ex in pieces(count, cadence):
-            while n > 0 and S_live[0]:
-                items.append(("graph", (min(n, S),))); n -= min(n, S)
-            if n:
-                items.append(("steps", n))
-            if ex:
-                items.append(("exchange",))
-        return items
+        return exchange_schedule(count, cadence, S if S_live[0] else 0, mailbox is not None, n_slots)
 
     def prepare(pl, count, cadence):
         """capture (and launch once) every graph run(pl, count, cadence) will replay -- outside any timed region"""

@@ -208,3 +208,35 @@ def test_two_rank_mailbox_exchange_on_one_gpu(cfg, extra):
     assert mg["ranks"] == 2 and mg["exchange_via"].startswith("peer-to-peer mailbox") and ("captured" in mg["exchange_via"]) == bool(extra and "--graph" in extra)
     assert mg["mailbox"]["timeouts"] == 0 and mg["mailbox"]["sums_bit_identical_to_rank_order"] and mg["allreduce_check"]["ok"]
     assert mg["collectives_in_timed_region"] in (2, 3) and mg["every_step"]["collectives_in_timed_region"] == 20
+
+
+def test_exchange_schedule_is_exact():
+    """bench.exchange_schedule (pure): whatever the step count, cadence, graph size and mode, a run issues exactly `count` steps and
+    exactly one exchange per `cadence` steps (the ones of exchange_pieces), graphs hold at most `graph_steps` steps and `n_slots`
+    exchanges, and the driver's 5 + 20 steps in mailbox mode are one plain graph and ONE graph with the exchange in its middle."""
+    sys.path.insert(0, str(ROOT))
+    import importlib
+    bench = importlib.import_module("bench")
+    assert bench.exchange_schedule(20, 20, 100, True, 128) == [("graph", (10, 10))]
+    assert bench.exchange_schedule(5, 20, 100, True, 128) == [("graph", (5,))]
+    assert bench.exchange_schedule(20, 20, 100, False, 128) == [("graph", (10,)), ("exchange",), ("graph", (10,))]
+    assert bench.exchange_schedule(20, 20, 0, True, 128) == [("steps", 10), ("exchange",), ("steps", 10)]
+    assert bench.exchange_schedule(20, 1, 100, True, 128) == [("graph", (1,) * 20 + (0,))]
+    assert bench.exchange_schedule(0, 8, 100, True, 128) == []
+    for count in (1, 5, 20, 23, 64, 100, 101, 777, 2000):
+        for cadence in (0, 1, 2, 7, 8, 20, 64, 500):
+            want_ex = sum(1 for _, ex in bench.exchange_pieces(count, cadence) if ex)
+            assert sum(n for n, _ in bench.exchange_pieces(count, cadence)) == count
+            assert want_ex == (0 if not cadence else len([j for j in range(1, count + 1) if j % cadence == cadence // 2]))
+            for S in (0, 4, 20, 100):
+                for mailbox in (False, True):
+                    for n_slots in (4, 128):
+                        items = bench.exchange_schedule(count, cadence, S, mailbox, n_slots)
+                        steps = sum(sum(it[1]) if it[0] == "graph" else (it[1] if it[0] == "steps" else 0) for it in items)
+                        exch = sum((len(it[1]) - 1) if it[0] == "graph" else (1 if it[0] == "exchange" else 0) for it in items)
+                        assert steps == count and exch == want_ex, (count, cadence, S, mailbox, n_slots, items)
+                        for it in items:
+                            if it[0] == "graph":
+                                assert sum(it[1]) <= S and len(it[1]) - 1 <= n_slots and (sum(it[1]) > 0 or len(it[1]) > 1)
+                                assert mailbox or len(it[1]) == 1          # all-reduce mode: graphs hold plain steps only
+                            assert S or it[0] != "graph"
