@@ -104,19 +104,19 @@ def host_round_trip(fn):
     def wrapper(*args, **kwargs):
         host = False
         for v in args:
-            if isinstance(v, torch.Tensor) and v.device.type == "cpu":
+            if isinstance(v, torch.Tensor) and v.is_cpu:
                 host = True
                 break
-        if not host:
+        if not host and kwargs:
             for v in kwargs.values():
-                if isinstance(v, torch.Tensor) and v.device.type == "cpu":
+                if isinstance(v, torch.Tensor) and v.is_cpu:
                     host = True
                     break
         if not host or not torch.cuda.is_available():
             # (no GPU: the call's own argument checks come first -- the reference's exception types --, then the raw ops refuse host tensors)
             return fn(*args, **kwargs)
         dev = compute_device("cpu")
-        up = lambda t: t.to(dev) if t.device.type == "cpu" else t          # noqa: E731
+        up = lambda t: t.to(dev) if t.is_cpu else t          # noqa: E731
         out = fn(*[_map_tensors(a, up) if isinstance(a, (torch.Tensor, tuple, list)) else a for a in args],
                  **{k: (_map_tensors(v, up) if isinstance(v, (torch.Tensor, tuple, list)) else v) for k, v in kwargs.items()})
         return _map_tensors(out, lambda t: t.cpu())
