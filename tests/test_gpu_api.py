@@ -1226,7 +1226,24 @@ def test_packed_sums_one_launch_equals_three():
         out2 = torch.empty_like(out)
         for _ in range(3):
             pk.pack(out2)
-            assert torch.equal(out, out2)                                                       # bit-reproducible, ticket reset
+            assert torch.equal(out, out2)                                                       # bit-reproducible
+    # an fp16, loss-scaled gradient (config 5's exchange): widened, summed in fp32, divided by the scale once; + a per-trajectory cost
+    for B, H in ((512, 64), (33, 128), (7, 6)):
+        q = robot.random_q(B * H).reshape(B, H, 7).contiguous().half()
+        gs = 2.0 ** -6
+        model, cm = task._fused_handles(DEV)
+        plan = ops.RolloutPlan(model, cm, (1.0, 1.0, 1.0, 0.0), q, want_pos=False, grad_scale=gs)
+        sums = torch.zeros(ops.n_blocks(B * H), **TA)
+        plan.launch(sums.data_ptr())
+        tc = torch.rand(B, **TA)
+        pk = ops.PackedSums(plan, sums, tc)
+        out = torch.empty(pk.size, **TA)
+        pk.pack(out)
+        assert plan.gq.dtype == torch.float16
+        assert rel_err(out[0:1].cpu().numpy(), (plan.cost.double().sum() + tc.double().sum()).reshape(1).cpu().numpy()) < 1e-5
+        assert rel_err(out[1:1 + H].cpu().numpy(), plan.cost.double().sum(0).cpu().numpy()) < 2e-6
+        ref_g = (plan.gq.double().sum(0) / gs).reshape(-1)
+        assert np.abs(out[1 + H:].cpu().numpy() - ref_g.cpu().numpy()).max() <= 2e-6 * max(1.0, float(plan.gq.float().abs().sum(0).max()) / gs)
 
 
 def test_interpolated_points_with_a_grasped_object(oracle_lib):
