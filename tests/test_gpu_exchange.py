@@ -124,3 +124,64 @@ def test_mailbox_soak_small(ranks, floats):
                         "--floats", str(floats)], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     assert "mismatching exchanges 0, time-outs 0" in p.stdout
+
+
+SHARDED_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["TRK_ROOT"])
+import torch_robotics_amd as tra
+from torch_robotics_amd.distributed import ShardedRollout, shard_batch
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+TA = dict(device=dev, dtype=torch.float32)
+robot = tra.RobotPanda(tensor_args=TA)
+task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+B, H = 96, 64
+q_all = robot.random_q(B * H, generator=torch.Generator(device=dev).manual_seed(5)).reshape(B, H, 7)      # the same on every rank
+lo, hi = shard_batch(B, rank, world)
+plan = task.rollout_plan(q_all[lo:hi].contiguous(), w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=False)
+ref_plan = task.rollout_plan(q_all.contiguous(), w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=False)
+ref_plan.launch(); torch.cuda.synchronize()
+ref = torch.cat([ref_plan.cost.double().sum().reshape(1), ref_plan.cost.double().sum(0), ref_plan.gq.double().sum(0).reshape(-1)])
+for mode in ("auto", "allreduce"):
+    sh = ShardedRollout(plan, exchange=mode)
+    assert (sh.mailbox is not None) == (mode == "auto"), sh.mailbox_note
+    for it in range(3):
+        sh.launch()
+        tot = sh.exchange().clone()
+        torch.cuda.synchronize()
+        assert float((tot.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (mode, it)
+        # sharding invariance of the per-sample outputs: this rank's block equals the same rows of the unsharded evaluation
+        assert torch.equal(plan.cost, ref_plan.cost[lo:hi]) and torch.equal(plan.gq, ref_plan.gq[lo:hi])
+    # every rank holds the same bits
+    mine = tot.cpu(); other = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(other, mine)
+    assert all(torch.equal(o, other[0]) for o in other)
+    sh.launch(); sh.send()
+    try:
+        sh.send(); raise SystemExit("expected a RuntimeError")
+    except RuntimeError:
+        pass
+    sh.recv(); torch.cuda.synchronize()
+    dist.barrier(); sh.close()
+sys.stdout.write(f"sharded-{rank}-ok\n"); sys.stdout.flush()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_sharded_rollout_two_processes_one_gpu(tmp_path):
+    """distributed.ShardedRollout: two ranks evaluate their blocks of one batch and exchange the packed sums (mailbox, and the
+    all-reduce path): the totals equal the unsharded evaluation's sums, every rank holds the same bits, the per-sample outputs of a
+    block equal the same rows of the unsharded evaluation bit for bit."""
+    env = dict(os.environ, TRK_ROOT=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    script = tmp_path / "sharded_worker.py"
+    script.write_text(SHARDED_WORKER)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29591", str(script)], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "sharded-0-ok" in p.stdout and "sharded-1-ok" in p.stdout

@@ -3,9 +3,11 @@
 Every (batch, horizon) sample is independent for FK and for the collision / EE objectives, and the terms that
 couple time steps stay inside one trajectory, so the batch dimension is split in contiguous blocks of whole
 trajectories.  Models, cost tables and the SDF grid are replicated.  The only exchange
-step is the sum of the per-rank cost scalars (and, if a caller wants them, other packed partial sums): one small
-all-reduce -- RCCL over xGMI on the GPU box (`backend="nccl"`), gloo in the CPU tests.  Per-sample outputs
-(cost, gradient, link positions) stay sharded.
+step is the sum of the per-rank packed partial sums [sum cost | cost per time step | gradient per time step and joint]: either a
+PEER-TO-PEER MAILBOX (`MailboxAllReduce`: every rank stores its row into every peer's device memory over xGMI and adds the rows in
+rank order; capturable into a hipGraph) or one small all-reduce -- RCCL over xGMI on the GPU box (`backend="nccl"`), gloo in the
+tests.  `ShardedRollout` is the whole thing as one object (evaluate this rank's block, send, receive).  Per-sample outputs (cost,
+gradient, link positions) stay sharded.
 """
 from __future__ import annotations
 
@@ -253,3 +255,90 @@ class MailboxAllReduce:
             self.close()
         except Exception:
             pass
+
+
+class ShardedRollout:
+    """A batch-sharded planner's evaluation + exchange as ONE object (what is sharded is the batch of
+    `PlanningTask._compute_collision_or_cost`, tasks.py:206-230): this rank's block of whole trajectories is evaluated by a pre-bound
+    fused rollout (`ops.RolloutPlan` / `ops.RolloutGpPlan`), and `exchange()` makes the packed sums
+
+        [ sum cost | sum_b cost(b, h) (H) | sum_b d cost / d q (b, h, d) (H D) ]
+
+    of ALL ranks available on every rank -- through the peer-to-peer mailbox when it validates on every rank (default), else through an
+    all-reduce of the process group (RCCL on the GPU box, gloo in tests).  Per-sample outputs (cost, gradient, link positions) stay
+    sharded.  Everything is asynchronous on torch's current stream (or `stream`):
+
+        sh = ShardedRollout(plan)                 # collective: every rank constructs it
+        for it in range(n_iters):
+            sh.launch()                           # plan.cost / plan.gq / plan.link_pos of THIS rank's trajectories
+            sh.send()                             # pack + (mailbox) store into every peer -- never waits
+            ...                                   # more work of this iteration
+            total = sh.recv()                     # (1 + H + H D,) fp32, the sums over all ranks; same bits on every rank (mailbox)
+
+    `exchange()` = `send()` + `recv()`.  With one rank (no process group) the sums are this rank's own."""
+
+    def __init__(self, plan, traj_cost: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None, exchange: str = "auto"):
+        from . import ops
+        if exchange not in ("auto", "p2p", "allreduce"):
+            raise ValueError("ShardedRollout: exchange must be 'auto', 'p2p' or 'allreduce'")
+        self.plan, self.group, self.device = plan, group, plan.device
+        have_group = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if have_group else 1
+        self.rank = dist.get_rank(group) if have_group else 0
+        B, H = plan.B, plan.H
+        self.block_sums = torch.zeros(ops.n_blocks(B * H), device=self.device, dtype=torch.float32)
+        self._packer = ops.PackedSums(plan, self.block_sums, traj_cost)
+        self.size = self._packer.size
+        self.packed = torch.zeros(self.size, device=self.device, dtype=torch.float32)
+        self.total = torch.zeros(self.size, device=self.device, dtype=torch.float32)
+        self.mailbox, self.mailbox_note = None, None
+        if self.world > 1 and exchange in ("auto", "p2p"):
+            try:
+                mb = MailboxAllReduce(self.device, self.size, n_slots=4, group=group)
+                if mb.validate():
+                    self.mailbox = mb
+                else:
+                    self.mailbox_note = "validation failed: " + repr(mb.status())
+                    mb.close()
+            except Exception as e:          # noqa: BLE001 -- any failure to share memory means: use the collective
+                self.mailbox_note = f"{type(e).__name__}: {e}"
+            if self.mailbox is None and exchange == "p2p":
+                raise RuntimeError(f"ShardedRollout(exchange='p2p'): the mailbox is not usable: {self.mailbox_note}")
+        self._sent = False
+
+    def launch(self, stream: Optional[int] = None) -> None:
+        self.plan.launch(self.block_sums.data_ptr(), stream)
+
+    def send(self, stream: Optional[int] = None) -> None:
+        """pack this rank's sums of the latest `launch()`; mailbox mode: store them into every peer's mailbox.  Never waits."""
+        if self._sent:
+            raise RuntimeError("ShardedRollout.send: the previous exchange has not been received yet (send / recv alternate)")
+        self._packer.pack(self.packed, stream)
+        if self.mailbox is not None:
+            self.mailbox.send(self.packed, stream)
+        self._sent = True
+
+    def recv(self, stream: Optional[int] = None) -> torch.Tensor:
+        """the sums over all ranks of the latest `send()` -> `self.total` (returned; valid once the stream has run)"""
+        if not self._sent:
+            raise RuntimeError("ShardedRollout.recv: nothing has been sent")
+        self._sent = False
+        if self.mailbox is not None:
+            self.mailbox.recv(self.total, stream)
+            return self.total
+        cur = torch.cuda.current_stream(self.device)
+        if stream is not None and stream != cur.cuda_stream:
+            raise ValueError("ShardedRollout.recv: the all-reduce path runs on torch's current stream")
+        self.total.copy_(self.packed)
+        if self.world > 1:
+            dist.all_reduce(self.total, group=self.group)
+        return self.total
+
+    def exchange(self, stream: Optional[int] = None) -> torch.Tensor:
+        self.send(stream)
+        return self.recv(stream)
+
+    def close(self) -> None:
+        if self.mailbox is not None:
+            self.mailbox.close()
+            self.mailbox = None
