@@ -1,0 +1,145 @@
+"""Random robots through the model compiler: seeded random URDF trees (revolute / continuous / prismatic / fixed joints; axes +-x, +-y,
++-z, non-axis-aligned ones -- which the reference degenerates to +-z, rigid_body.py:162-168 -- and missing ones; joints with and
+without limits; arbitrary origins; a file order that is or is not a pre-order walk), a random collision model on each (object links,
+self pairs, tracked link, sphere and box scenes, hinge flags), and then: run-time generated kernels == table-driven kernels == fp64
+oracle for the fused rollout (positions, cost, gradient), the boolean fields, the FK matrices and the positions' reverse mode.
+
+The reference-pinned robots are in test_gpu_parity.py; this file is about the generator's corner cases (structural zeros, sign folds,
+constant links, branch bookkeeping) on shapes nobody wrote by hand."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import grad_close, rel_err
+from torch_robotics_amd.costmodel import CostModelSpec, box_prims, make_object, sphere_prims
+from torch_robotics_amd.kinmodel import KinModel
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TOL_H, TOL_C = 2e-6, 1e-5
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from torch_robotics_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def oracle_lib():
+    from oracle import oracle as _o
+    return _o
+
+
+def random_urdf(path, rng, n_links, preorder):
+    """a random tree; returns the text's link count.  Parents are earlier links (a valid tree); with preorder=False the LINK lines are
+    shuffled (the joint list keeps parents before children), so the file order is not a walk order."""
+    axes = ["1 0 0", "0 1 0", "0 0 1", "-1 0 0", "0 -1 0", "0 0 -1", "0.574 0 0.819", "0.3 -0.4 0.5", None]
+    parents = [None] + [int(rng.integers(max(0, i - 3), i)) for i in range(1, n_links)]
+    joints = []
+    for i in range(1, n_links):
+        kind = rng.choice(["revolute", "revolute", "revolute", "continuous", "prismatic", "fixed", "fixed"])
+        xyz = " ".join(f"{v:.4f}" for v in rng.uniform(-0.15, 0.15, 3))
+        rpy = " ".join(f"{v:.4f}" for v in rng.choice([0.0, 0.0, 1.5707963, -1.5707963, 3.14159265, 0.3, -0.7], 3))
+        lines = [f'  <joint name="j{i}" type="{kind}">', f'    <parent link="l{parents[i]}"/><child link="l{i}"/>',
+                 f'    <origin xyz="{xyz}" rpy="{rpy}"/>']
+        if kind != "fixed":
+            ax = axes[int(rng.integers(0, len(axes)))]
+            if ax is not None:
+                lines.append(f'    <axis xyz="{ax}"/>')
+            if kind == "continuous":
+                pass
+            elif kind == "prismatic" or rng.random() < 0.8:
+                lo, hi = sorted(rng.uniform(-2.5, 2.5, 2)) if kind == "revolute" else sorted(rng.uniform(-0.2, 0.3, 2))
+                lines.append(f'    <limit lower="{lo:.4f}" upper="{hi:.4f}" effort="1" velocity="1"/>')
+        lines.append("  </joint>")
+        joints.append("\n".join(lines))
+    order = list(range(1, n_links))
+    if not preorder:
+        rng.shuffle(order)
+    text = ['<?xml version="1.0"?>', '<robot name="fuzz">', '  <link name="l0"/>'] + [f'  <link name="l{i}"/>' for i in order] + joints + ["</robot>"]
+    path.write_text("\n".join(text))
+
+
+def random_cost_spec(m, rng, scene):
+    L = m.n_links
+    n_obj = int(rng.integers(1, min(L, 7)))
+    obj = np.sort(rng.choice(np.arange(L), size=n_obj, replace=False)).astype(np.int32)
+    spec = CostModelSpec(n_links_in=L)
+    spec.obj_link_idx = obj
+    spec.obj_link_margin = rng.uniform(0.03, 0.12, n_obj).astype(np.float32)
+    objects = []
+    if scene in ("spheres", "mixed"):
+        r = np.full(6, 0.12, np.float32) if scene == "spheres" else rng.uniform(0.05, 0.2, 6).astype(np.float32)
+        objects.append(make_object(sphere_prims(rng.uniform(-0.6, 0.6, (6, 3)).astype(np.float32), r)))
+    if scene in ("boxes", "mixed"):
+        c, sz = rng.uniform(-0.5, 0.5, (4, 3)).astype(np.float32), rng.uniform(0.1, 0.4, (4, 3)).astype(np.float32)
+        qw = rng.standard_normal(4); qw /= np.linalg.norm(qw)
+        from torch_robotics_amd.kinmodel import quat_wxyz_to_rot
+        objects.append(make_object(box_prims(c, sz, rounded=bool(rng.integers(0, 2))), rng.uniform(-0.2, 0.2, 3).astype(np.float32),
+                                   quat_wxyz_to_rot(qw.astype(np.float32))))
+    spec.objects = objects
+    if rng.random() < 0.7:
+        spec.ws_min, spec.ws_max = np.float32([-0.8, -0.9, -0.7]), np.float32([0.9, 0.8, 1.0])
+    if L >= 4 and rng.random() < 0.8:
+        sl = np.sort(rng.choice(np.arange(L), size=min(L, int(rng.integers(2, 6))), replace=False))
+        pairs = [(a, b) for a in range(len(sl)) for b in range(a) if rng.random() < 0.6][:6]
+        if pairs:
+            spec.self_link_idx = sl.astype(np.int32)
+            spec.self_pairs = np.asarray(pairs, np.int32)
+            spec.self_margin = rng.uniform(0.03, 0.08, len(pairs)).astype(np.float32)
+    spec.ee_link = int(rng.integers(1, L))
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = rng.uniform(-0.4, 0.4, 3); spec.ee_target = T
+    spec.ee_w_pos, spec.ee_w_rot, spec.ee_square = float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 2)), bool(rng.integers(0, 2))
+    spec.clamp_fields = int(rng.integers(0, 8))
+    spec.validate()
+    return spec
+
+
+@pytest.mark.parametrize("seed", list(range(8)))          # (seeds 8 - 11 ran clean too; eight keep the suite short: each draw is a run-time compile)
+def test_random_robot_generated_vs_table_driven_vs_oracle(ops, oracle_lib, tmp_path, seed):
+    from torch_robotics_amd import jit
+    rng = np.random.default_rng(9000 + seed)
+    n_links = int(rng.integers(4, 15))
+    urdf = tmp_path / f"fuzz{seed}.urdf"
+    random_urdf(urdf, rng, n_links, preorder=bool(seed % 3))
+    m = KinModel.from_urdf(str(urdf))
+    if m.n_dofs == 0:
+        pytest.skip("the draw has no movable joint")
+    scene = ("spheres", "boxes", "mixed")[seed % 3]
+    spec = random_cost_spec(m, rng, scene)
+    h, cm, o = ops.ModelHandle(m), ops.CostHandle(spec, DEV), oracle_lib.Oracle(m, spec)
+    assert jit.specialize_for_cost_spec(m, spec) is not None and h.specialized
+    D, L = m.n_dofs, m.n_links
+    weights = [(1, 1, 1, 1), (0, 1, 0, 1), (1, 0, 1, 0)][seed % 3]
+    for n in (1, 64, 130):
+        q = rng.uniform(-3.0, 3.0, size=(n, D)).astype(np.float32)              # beyond most limits: the clamps and their zero gradients
+        rp, rc, rg = o.rollout(q.astype(np.float64), weights, "f64")
+        scale = max(1.0, float(np.abs(rp).max()))
+        H64 = o.fk(q.astype(np.float64), "f64")
+        got = {}
+        for use_spec in (True, False):
+            h.enable_specialized(use_spec)
+            pos, cost, gq = ops.rollout_cost_grad(h, cm, weights, dev(q))
+            tag = (seed, n, use_spec)
+            assert np.abs(pos.cpu().numpy() - rp).max() / scale < TOL_H, tag
+            assert rel_err(cost.cpu().numpy(), rc) < TOL_C or np.abs(cost.cpu().numpy() - rc).max() < 1e-5, tag
+            # kinks (arg-min ties between primitives, box faces, hinges at zero) may flip single samples: bound their number
+            bad = ~np.isclose(gq.cpu().numpy(), rg, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(rg).max())).all(-1)
+            assert bad.sum() <= max(1, n // 50), (tag, int(bad.sum()))
+            Hm = ops.fk_forward(h, dev(q)).cpu().numpy()
+            assert np.abs(Hm - H64).max() / scale < TOL_H, tag
+            got[use_spec] = ops.rollout_collision(h, cm, 7, dev(q)).cpu().numpy()
+        assert (got[True] != got[False]).sum() <= max(1, n // 60), seed          # a byte differs only within rounding of a margin
+        h.enable_specialized(True)
+        w = rng.standard_normal((n, L, 3)).astype(np.float32)
+        gH = np.zeros((n, L, 4, 4)); gH[..., :3, 3] = w
+        ref_b = o.fk_backward(q.astype(np.float64), gH, "f64")
+        for use_spec in (True, False):
+            h.enable_specialized(use_spec)
+            assert grad_close(ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy(), ref_b, scale=scale), (seed, n, use_spec)
+        h.enable_specialized(True)
