@@ -143,3 +143,59 @@ def test_random_robot_generated_vs_table_driven_vs_oracle(ops, oracle_lib, tmp_p
             h.enable_specialized(use_spec)
             assert grad_close(ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy(), ref_b, scale=scale), (seed, n, use_spec)
         h.enable_specialized(True)
+
+
+@pytest.mark.parametrize("seed,robot", [(0, "panda_arm_no_gripper"), (1, "dual_panda"), (2, "panda_arm_no_gripper")])
+def test_random_point_sets_generated_vs_table_driven_vs_oracle(ops, oracle_lib, seed, robot):
+    """Attached-point units compiled at run time for RANDOM point sets (points per link 0 .. 5 with random offsets incl. exact zeros,
+    walk-ordered columns) and random self pairs -- pairs between two points of ONE link, pairs whose earlier point sits on a fixed link,
+    points paired many times (the factorised pair phase accumulates per point) --: generated == table-driven == fp64 oracle."""
+    from helpers import model
+    from torch_robotics_amd import jit
+    rng = np.random.default_rng(7700 + seed)
+    m = model(robot)
+    pl, po = [], []
+    for i in (int(v) for v in m.order):                       # walk order, origins first like link_sorted_point_set
+        pl.append(i); po.append((0.0, 0.0, 0.0))
+        for _ in range(int(rng.integers(0, 6 if seed != 1 else 3))):
+            off = rng.uniform(-0.12, 0.12, 3) * (rng.random(3) < 0.7)      # some components exactly zero
+            pl.append(i); po.append(tuple(off))
+    pl, po = np.asarray(pl, np.int32), np.asarray(po, np.float32)
+    P = len(pl)
+    spec = CostModelSpec(n_links_in=P)
+    obj = np.sort(rng.choice(np.arange(P), size=min(P, int(rng.integers(6, 20))), replace=False)).astype(np.int32)
+    spec.obj_link_idx, spec.obj_link_margin = obj, rng.uniform(0.02, 0.1, len(obj)).astype(np.float32)
+    spec.objects = [make_object(sphere_prims(rng.uniform(-0.7, 0.7, (8, 3)).astype(np.float32), np.full(8, 0.1, np.float32)))]
+    spec.ws_min, spec.ws_max = np.float32([-1, -1, -0.5]), np.float32([1, 1, 1.5])
+    sl = np.sort(rng.choice(np.arange(P), size=min(P, 12), replace=False))
+    pairs = [(a, b) for a in range(len(sl)) for b in range(a) if rng.random() < 0.45][:30]
+    # a pair inside one link, if the draw has a link with two selected points
+    same = [(a, b) for a in range(len(sl)) for b in range(a) if pl[sl[a]] == pl[sl[b]]]
+    pairs = (same[:2] + pairs)[:30]
+    spec.self_link_idx, spec.self_pairs = sl.astype(np.int32), np.asarray(pairs, np.int32).reshape(-1, 2)
+    spec.self_margin = rng.uniform(0.03, 0.08, len(pairs)).astype(np.float32)
+    spec.ee_link = int(m.n_links - 1)
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.3, 0.2, 0.6); spec.ee_target = T
+    spec.clamp_fields = int(rng.integers(0, 8))
+    spec.validate()
+    h = ops.ModelHandle(m)
+    ps0, cm = ops.PointSetHandle(h, pl, po, DEV), ops.CostHandle(spec, DEV)
+    assert not ps0.specialized
+    o = oracle_lib.Oracle(m, spec)
+    q = rng.uniform(-2.8, 2.8, size=(130, m.n_dofs)).astype(np.float32)
+    ref = {w: o.rollout_points(pl, po, q.astype(np.float64), w, "f64") for w in ((1, 1, 1, 1), (1, 0, 0, 0), (0, 1, 1, 0))}
+    table = {w: [t.cpu().numpy() for t in ops.rollout_points_cost_grad(ps0, cm, w, dev(q))] for w in ref}
+    assert jit.specialize_points(m, pl, po, spec) is not None
+    ps = ops.PointSetHandle(h, pl, po, DEV)
+    assert ps.specialized
+    for w, (rp, rc, rg) in ref.items():
+        pos, cost, gq = (t.cpu().numpy() for t in ops.rollout_points_cost_grad(ps, cm, w, dev(q)))
+        for name, (p_, c_, g_) in (("generated", (pos, cost, gq)), ("table-driven", table[w])):
+            assert np.abs(p_ - rp).max() < 2 * TOL_H, (seed, w, name)
+            assert rel_err(c_, rc) < TOL_C, (seed, w, name)
+            bad = ~np.isclose(g_, rg, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(rg).max())).all(-1)
+            assert bad.sum() <= 2, (seed, w, name, int(bad.sum()))              # arg-min ties / hinges at zero
+    wpt = rng.standard_normal((130, P, 3)).astype(np.float32)
+    a = ops.fk_points_backward(ps, dev(q), dev(wpt)).cpu().numpy()
+    b = ops.fk_points_backward(ps0, dev(q), dev(wpt)).cpu().numpy()
+    assert grad_close(a, b)
