@@ -449,7 +449,9 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw(f"    const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
             # (a voxel-grid scene keeps all links in one batch: its cost is the gathers' latency, and a separate gather for the constant
             # link in front of the others only adds a second exposed latency: 22.8 -> 23.8 us measured)
-            E.raw("    if (BOX && !A.C.has_grid) {")
+            # (TRK_EXP_UNIFORM_SPHERES=1 at generation time: the spheres-only instantiation too -- an experiment knob)
+            cond = "!A.C.has_grid" if os.environ.get("TRK_EXP_UNIFORM_SPHERES", "0") == "1" else "BOX && !A.C.has_grid"
+            E.raw(f"    if ({cond}) {{")
             for k, nm in enumerate("xyz"):
                 E.raw(f"        const float p{nm}[{nr}] = {{{', '.join(E.expr(t[i][k]) for i in rest)}}};")
             E.raw(f"        float gx[{nr}], gy[{nr}], gz[{nr}];")
