@@ -1870,7 +1870,12 @@ class PointsTemplate:
 CHUNKED_STAGING_MIN_FLOATS = 80       # link kernels with more position floats per sample than this stream them out in chunks
 LINK_OBJ_GROUP_MAX = 12    # link kernels: up to this many collision links are scored in one scene evaluation (more ILP: dual Panda 5+5 was ~1 us slower) ...
 LINK_OBJ_GROUP = 5         # ... more are split into groups of about this size
-CHUNK_FLOATS = 36          # 12 columns: 144 B per sample and chunk, a multiple of 16 B
+CHUNK_FLOATS = 36          # 12 columns: 144 B per sample and chunk, a multiple of 16 B (rounds 2 - 4; the baseline of tools/ab_chunk_floats.sh)
+# The fused point rollout stages 64 floats per sample and chunk (256 B: one store instruction writes whole 256-byte segments of 4 / 2 / 1
+# samples, and the lane -> (sample, vector) map is a shift).  Same-box A/B (tools/ab_chunk_floats.sh, profiles/r05_ab_chunk_floats.txt),
+# 36 -> 64 floats: 45 spheres 67.0 -> 60.9 us, grasped box 44.6 -> 41.9, both 98.1 -> 86.3; positions only 36.2 -> 30.5, 25.0 -> 21.2,
+# 61.1 -> 46.5 (a row's 144-byte pieces were partial lines for two instructions each).  17.4 KB of LDS per wavefront: still two workgroups per CU.
+ROLLOUT_CHUNK_FLOATS = 64
 RING_FLOATS = 32           # link kernels with ring staging (RingFlusher in trk_spec_common.h): floats per chunk
 @dataclass
 class RingPlan:
@@ -1927,7 +1932,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
       s z_j . ((Pt1 - Pt0) - t_j x (Pf1 - Pf0)) with the running wrench sampled at the range's start and end;
       a force that lands on an EARLIER link (the far side of a self-collision pair) is applied directly to that link's
       ancestor joints, s z_j . ((p - t_j) x f), instead of entering the running sums;
-    * positions leave through one 36-float chunk buffer per wavefront (spec_flush_chunk).
+    * positions leave through one 64-float chunk buffer per wavefront (spec_flush_chunk; ROLLOUT_CHUNK_FLOATS).
 
     The kernel needs the full 256-VGPR budget (2 wavefronts per SIMD).  A two-sweep variant for serial chains (root->tip
     for the positions, then tip->root stepping the pose back through the inverse joint transforms with a single suffix
@@ -1960,7 +1965,13 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         late, early = (a, b) if late_is_a else (b, a)
         pairs_at[pl[late]].append((pi, late, early, late_is_a))
     masked = _masked_factory(kin)
-    LS = CHUNK_FLOATS
+    # the rollout's chunk: NF floats of every sample's row leave together; LS = the per-lane stride of the staging buffer (a multiple of
+    # 4 floats for the 16-byte reads, and NOT a multiple of 32: the per-lane row writes would all hit one bank)
+    NF = int(os.environ.get("TRK_EXP_CHUNK_FLOATS", str(ROLLOUT_CHUNK_FLOATS)))
+    LS = NF if NF % 32 else NF + 4
+    BNF = int(os.environ.get("TRK_EXP_BWD_CHUNK_FLOATS", str(ROLLOUT_CHUNK_FLOATS)))  # the positions' reverse mode (k_posbwd): 36 -> 64 measured 43.7 -> 42.8, 21.3 -> 19.9, 66.7 -> 47.5 us
+    BLS = BNF if BNF % 32 else BNF + 4
+    WIDE = (not link_mode) and os.environ.get("TRK_EXP_CHUNK_WIDE", "0") != "0"
     lds_per_lane = max(LS, D)
     joint_links = [i for i in range(1, L) if int(kin.joint_type[i]) != JOINT_FIXED]
     ancestors: Dict[int, List[int]] = {}
@@ -2085,9 +2096,13 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                 for k in range(3):
                     f = 3 * c + k
                     E.raw(f"    row[{f - chunk_start}] = {E.expr(colpos[c][k])};")
-                    if f + 1 - chunk_start == LS or f + 1 == W:
+                    if f + 1 - chunk_start == NF or f + 1 == W:
                         nf = f + 1 - chunk_start
-                        E.raw(f"    if (pos_out) spec_flush_chunk<W, {nf}, {LS}, {V}, IO>(pos_out, base, {chunk_start}, rows, lane, lds);")
+                        # vector width of this chunk's stores.  The LDS side is always aligned (LS and the chunk start are multiples of
+                        # 4 floats); the HBM side is aligned only when the row length is a multiple of the vector too -- this chip takes
+                        # the 4- / 8-byte-aligned wide stores of the other row lengths as they are (half / a quarter of the instructions)
+                        Vc = V if not WIDE else (4 if nf % 4 == 0 else (2 if nf % 2 == 0 else 1))
+                        E.raw(f"    if (pos_out) spec_flush_chunk<W, {nf}, {LS}, {Vc}, IO, {'true' if Vc > V else 'false'}>(pos_out, base, {chunk_start}, rows, lane, lds);")
                         chunk_start = f + 1
             # ---- objects / workspace box on this link's collision columns, a few at a time
             ocols = [c for c in cols if c in obj_rank]
@@ -2188,7 +2203,6 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
             g = E.lincomb([(gfin[i], ONE), (S(1.0, f"late{d}"), ONE)])
             gq_expr[d] = masked(E, i, d, S(g.c * sg, g.n))
         E.raw("    if (!A.gq) return;                       // positions only (trk_fk_points): weights are zero, nothing else to write")
-        E.raw("    if (!A.gq) return;                       // positions only (trk_fk_points): weights are zero, nothing else to write")
         E.raw("    if (lane < rows) store_wt_f1(A.cost + base + lane, cost);")
         E.raw("    if (A.cost_sum) {")
         E.raw("        const float tot = spec_wave_sum(lane < rows ? cost : 0.0f);")
@@ -2206,17 +2220,17 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         E = Emitter()
         kname = "k_posbwd_bi" if base_identity else "k_posbwd_bg"
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
-        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {lds_per_lane}];")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(BLS, D)}];")
         E.raw("    const int lane = __builtin_amdgcn_workitem_id_x() & (TRK_WAVE - 1);")
         E.raw("    const int wave = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_workitem_id_x() / TRK_WAVE);")
-        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {lds_per_lane});")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(BLS, D)});")
         E.raw("    const int64_t wblock = (int64_t)__builtin_amdgcn_workgroup_id_x() * SPEC_WAVES + wave;")
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    const float* gpos = static_cast<const float*>(A.link_pos);")
         E.raw("    float q[D];")
         E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
-        E.raw(f"    const float* row = lds + lane * {LS};")
+        E.raw(f"    const float* row = lds + lane * {BLS};")
         R = {}; t = {}; passv = {}
         if base_identity:
             R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
@@ -2254,10 +2268,10 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                 comp = []
                 for k in range(3):
                     f = f0 + k
-                    cs = (f // LS) * LS
+                    cs = (f // BNF) * BNF
                     if cs != chunk_start:
-                        nf = min(LS, W - cs)
-                        E.raw(f"    spec_load_chunk<W, {nf}, {LS}, {V}>(gpos, base, {cs}, rows, lane, lds);")
+                        nf = min(BNF, W - cs)
+                        E.raw(f"    spec_load_chunk<W, {nf}, {BLS}, {V}>(gpos, base, {cs}, rows, lane, lds);")
                         chunk_start = cs
                     comp.append(E.tmp(f"row[{f - cs}]"))
                 if p == 0:

@@ -436,6 +436,9 @@ __device__ __forceinline__ float object_sdf(const DevCostHdr& C, int o, float x,
 #define TRK_OBJ_TICK_SLOTS 5
 #endif
 struct NoTick { template <int J> __device__ __forceinline__ void at() const {} };
+#ifndef TRK_EXP_UNROLLED_RANK
+#define TRK_EXP_UNROLLED_RANK 0     // experiment (tools/ab_defines_points.sh): the guarded, unrolled pair ranking for the NoTick callers too
+#endif
 
 template <class T> struct TickIsNoTick { static constexpr bool value = false; };
 template <> struct TickIsNoTick<NoTick> { static constexpr bool value = true; };
@@ -664,7 +667,7 @@ __device__ __forceinline__ void scene_min_sdf(const DevCostHdr& C, const float (
                 // eight tick slots are interleaved one per pair whatever the sphere count is.
                 const TRK_CAS float* tab = cptr(C.sphere_pairs);
                 const int np = C.n_sphere_pairs;
-                if constexpr (TickIsNoTick<Tick>::value) {
+                if constexpr (TickIsNoTick<Tick>::value && !TRK_EXP_UNROLLED_RANK) {
                     // nothing to interleave (table-driven kernels, attached-point kernels that evaluate the scene once
                     // per group of points): a rolled loop keeps those kernels inside the instruction cache
                     for (int j = 0; j < np; ++j) {

@@ -642,28 +642,64 @@ __device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows(IO* __restrict__ ou
     return spec_make_flusher<W, IO>(out, base, rows, lane, lds);
 }
 
+// a wave-uniform address, said to be so: held in an SGPR pair
+template <class T>
+__device__ __forceinline__ unsigned long long spec_uniform_address(T* p) {
+    const unsigned long long g = (unsigned long long)reinterpret_cast<uintptr_t>(p);
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+}
+
+// lane -> (sample, vector) bookkeeping of the chunk copies below: vector j of a lane is element lane + 64 j of a [64][NVEC] block
+template <int NVEC>
+struct ChunkLane {
+    int s0, r0;                 // lane = NVEC s0 + r0
+    __device__ __forceinline__ explicit ChunkLane(int lane) : s0(lane / NVEC), r0(lane - (lane / NVEC) * NVEC) {}
+    // index of vector j when samples are S elements apart and a vector is V elements: (s0 + a + c) S + (r0 + b - c NVEC) V, given
+    // l0 = s0 S + r0 V; j is a constant after unrolling, so a, b and both products are immediates
+    template <int S, int V>
+    __device__ __forceinline__ int offset(int l0, int j) const {
+        const int a = (TRK_WAVE * j) / NVEC, b = (TRK_WAVE * j) % NVEC;
+        return l0 + (a * S + b * V) + ((b != 0 && r0 >= NVEC - b) ? S - NVEC * V : 0);
+    }
+    template <int S, int V, int BYTES>
+    __device__ __forceinline__ unsigned offset_bytes(unsigned g0, int j) const {
+        const int a = (TRK_WAVE * j) / NVEC, b = (TRK_WAVE * j) % NVEC;
+        return g0 + (unsigned)((a * S + b * V) * BYTES) + ((b != 0 && r0 >= NVEC - b) ? (unsigned)((S - NVEC * V) * BYTES) : 0u);
+    }
+};
+
 // Wide rows (attached points: W = 3P floats per sample) do not fit a whole-row staging buffer, so they leave in column
 // chunks: a chunk is the NF consecutive floats [c0, c0 + NF) of every sample's row.  Each lane has put its NF floats at
 // lds[lane * LS ...]; the wave then streams the rows' segments as V-float vectors (V | NF, V | W, V | c0: 16/8/4-byte
 // aligned), vector e -> sample e / (NF / V).  A sample's segment is contiguous, neighbouring chunks complete its lines.
-template <int W, int NF, int LS, int V, class IO = float>
+// UNALIGNED: the row length is not a multiple of the vector (the generator's choice for fp32 rows: a wide store whose address is only 4- or
+// 8-byte aligned is legal on this chip and halves / quarters the store instructions of such rows); the LDS side stays aligned.
+template <int W, int NF, int LS, int V, class IO = float, bool UNALIGNED = false>
 __device__ __forceinline__ void spec_flush_chunk(IO* __restrict__ out, int64_t base, int c0, int rows, int lane,
                                                  const float* lds) {
     constexpr int NVEC = NF / V;
-    static_assert(NF % V == 0 && W % V == 0 && (V != 4 || LS % 4 == 0), "chunk geometry must keep the vectors aligned");
+    static_assert(NF % V == 0 && (UNALIGNED || W % V == 0) && (V != 4 || LS % 4 == 0), "chunk geometry must keep the vectors aligned");
     spec_wave_sync();
     const int total = rows * NVEC;
     IO* dst0 = out + base * W + c0;
     if (rows == TRK_WAVE) {      // full wave: a batch of LDS reads in flight before the first store (guarded, every read sits in a
         constexpr int NB = NVEC * V > 36 ? (NVEC + 3) / 4 : NVEC;     // branch body of its own right in front of its s_waitcnt)
+        // Vector j of a lane is e = lane + 64 j -> (sample e / NVEC, vector e % NVEC).  As a division per vector that was ~14 integer
+        // instructions per store (multiply-high, shifts, a 64-bit address: 546 of the grasped-box kernel's 2827 vector instructions per
+        // wavefront, 2980 of 7231 with the 213 four-byte stores of the 71-point model).  Incrementally: 64 j = NVEC a + b at compile
+        // time, so sample = s0 + a + c and vector = r0 + b - c NVEC with c = (r0 >= NVEC - b) -- one compare and a select per offset,
+        // the wave-uniform destination in SGPRs (store with a 32-bit lane offset).
+        const ChunkLane<NVEC> cl(lane);
+        const int l0 = cl.s0 * LS + cl.r0 * V;
+        const unsigned g0 = (unsigned)((cl.s0 * W + cl.r0 * V) * (int)sizeof(IO));
+        const unsigned long long gu = spec_uniform_address(dst0);
 #pragma unroll
         for (int j0 = 0; j0 < NVEC; j0 += NB) {
             float a[NB][V];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (j0 + j < NVEC) {
-                    const int e = lane + TRK_WAVE * (j0 + j), smp = e / NVEC, v = e - smp * NVEC;
-                    const float* src = lds + smp * LS + v * V;
+                    const float* src = lds + cl.template offset<LS, V>(l0, j0 + j);
                     if (V == 4) { const float4 t = *reinterpret_cast<const float4*>(src); a[j][0] = t.x; a[j][1] = t.y; a[j][2 % V] = t.z; a[j][3 % V] = t.w; }
                     else {
 #pragma unroll
@@ -674,11 +710,10 @@ __device__ __forceinline__ void spec_flush_chunk(IO* __restrict__ out, int64_t b
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (j0 + j < NVEC) {
-                    const int e = lane + TRK_WAVE * (j0 + j), smp = e / NVEC, v = e - smp * NVEC;
-                    IO* dst = dst0 + (int64_t)smp * W + v * V;
-                    if (V == 4) IoQuad<IO>::store_wt(dst, 0, make_float4(a[j][0], a[j][1], a[j][2 % V], a[j][3 % V]));
-                    else if (V == 2) IoQuad<IO>::store_wt2(dst, a[j][0], a[j][1 % V]);
-                    else IoQuad<IO>::store_wt1(dst, a[j][0]);
+                    const unsigned voff = cl.template offset_bytes<W, V, (int)sizeof(IO)>(g0, j0 + j);
+                    if (V == 4) IoQuad<IO>::store_wt_s(gu, voff, make_float4(a[j][0], a[j][1], a[j][2 % V], a[j][3 % V]));
+                    else if (V == 2) IoQuad<IO>::store_wt2_s(gu, voff, a[j][0], a[j][1 % V]);
+                    else IoQuad<IO>::store_wt1_s(gu, voff, a[j][0]);
                 }
             }
         }
@@ -828,25 +863,21 @@ __device__ __forceinline__ void spec_load_chunk(const float* __restrict__ in, in
     spec_wave_sync();           // everybody has consumed the previous chunk
     const int total = rows * NVEC;
     const float* src0 = in + base * W + c0;
-    if ((V == 1 || V == 2) && rows == TRK_WAVE) {      // full wave: a batch of loads in flight before the first LDS write (the guarded
-        constexpr int NB = NVEC > 18 ? (NVEC + 3) / 4 : NVEC;     // loop below waits for every load before it issues the next)
-        typedef typename TrkIf<V == 2, float2, float>::type vec_t;
+    if (rows == TRK_WAVE) {      // full wave: a batch of loads in flight before the first LDS write (the guarded
+        constexpr int NB = NVEC * V > 36 ? (NVEC + 3) / 4 : NVEC;     // loop below waits for every load before it issues the next)
+        typedef typename TrkIf<V == 4, float4, typename TrkIf<V == 2, float2, float>::type>::type vec_t;
+        const ChunkLane<NVEC> cl(lane);        // (sample, vector) of a lane's vectors without a division per vector: see spec_flush_chunk
+        const int l0 = cl.s0 * LS + cl.r0 * V, g0 = cl.s0 * W + cl.r0 * V;
 #pragma unroll
         for (int j0 = 0; j0 < NVEC; j0 += NB) {
             vec_t r[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if (j0 + j < NVEC) {
-                    const int e = lane + TRK_WAVE * (j0 + j), smp = e / NVEC, v = e - smp * NVEC;
-                    r[j] = *reinterpret_cast<const vec_t*>(src0 + (int64_t)smp * W + v * V);
-                }
+                if (j0 + j < NVEC) r[j] = *reinterpret_cast<const vec_t*>(src0 + cl.template offset<W, V>(g0, j0 + j));
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if (j0 + j < NVEC) {
-                    const int e = lane + TRK_WAVE * (j0 + j), smp = e / NVEC, v = e - smp * NVEC;
-                    *reinterpret_cast<vec_t*>(lds + smp * LS + v * V) = r[j];
-                }
+                if (j0 + j < NVEC) *reinterpret_cast<vec_t*>(lds + cl.template offset<LS, V>(l0, j0 + j)) = r[j];
             }
         }
         spec_wave_sync();
