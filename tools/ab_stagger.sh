@@ -6,7 +6,7 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05stag; mkdir -p $O
 b() { ( cd $1 && python bench.py --cpu-seconds 0 --no-out-of-cache "${@:2}" 2>/dev/null | python3 -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); print('   %-40s step %8.3f us  kernel %8.3f us' % (' '.join(sys.argv[1:]), d['ms_per_step']*1e3, d['roofline']['launch_us']))" "${@:2}" ); }
-run() { echo "tree $2"; b $1 --config c5 --steps 1000 --warmup 100; b $1 --config c4 --steps 500 --warmup 50; ( cd $1 && python tools/bench_points.py 2>/dev/null | grep "fused rollout" ); }
+run() { echo "tree $2"; if [ -z "$POINTS_ONLY" ]; then b $1 --config c5 --steps 1000 --warmup 100; b $1 --config c4 --steps 500 --warmup 50; fi; ( cd $1 && python tools/bench_points.py 2>/dev/null | grep "fused rollout\|fk_map_collision  " ); }
 {
 for N in ${1:-64}; do
   B=/tmp/treeB_$N
