@@ -1080,8 +1080,15 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("")
 
     # ---- explicit reverse mode of the link positions (trk_fk_positions_backward with all links selected):
-    # FK again (cheaper than storing poses), the adjoint rows [64][3L] come in through the LDS transpose, reverse pass
-    for base_identity in (True, False):
+    # FK again (cheaper than storing poses), the adjoint rows [64][3L] come in through the LDS transpose, reverse pass.
+    # Many links (the ring-staged units): the whole-row tile is 92 KB per workgroup for 30 links -- one wavefront per SIMD -- and 3L adjoint
+    # registers per lane.  Those units take the attached-point generator's kernel instead (columns = the links, chunked loads, prefix-sum
+    # gradients; needs the file order to be the pre-order walk): UR10 + Allegro 34.1 -> 29.8 us, iiwa7 + Allegro 33.4 -> 30.9, Shadow hand 32.6 -> 30.4
+    # (profiles/r05_bench_positions.txt).
+    posbwd_chunked = chunked and [int(v) for v in kin.order] == list(range(L)) and os.environ.get("TRK_EXP_POSBWD_TILE", "0") == "0"
+    if posbwd_chunked:
+        out.extend(_chunked_posbwd_lines(kin, list(range(L)), np.zeros((L, 3), np.float32), snap, w_expr=str(3 * L)))
+    for base_identity in (() if posbwd_chunked else (True, False)):
         E = Emitter()
         kname = "k_posbwd_bi" if base_identity else "k_posbwd_bg"
         E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, {4 if D <= 8 else 2}) {kname}(SpecArgs A) {{")
@@ -1921,6 +1928,111 @@ def ring_plan(W: int) -> RingPlan:
 OBJ_GROUP = 6              # points evaluated against the scene together (register arrays of this size)
 
 
+def _chunked_posbwd_lines(kin: KinModel, point_link, point_offset, snap: float = SNAP, w_expr: Optional[str] = None) -> List[str]:
+    """k_posbwd_bi / k_posbwd_bg: explicit reverse mode of point (or link) positions, d sum(gpos . pos) / dq, for columns in walk order.
+    FK again, the adjoint rows arrive through a chunk buffer in column order (spec_load_chunk: ROLLOUT_CHUNK_FLOATS floats of every
+    sample's row per trip), each adjoint g at point p joins the running wrench (g, p x g); a joint's gradient is the prefix-sum form
+    s z . ((Pt1 - Pt0) - t x (Pf1 - Pf0)) over its subtree's range of the walk.  17 KB of LDS per wavefront whatever the row length and
+    no per-sample adjoint array in registers: also what the many-link robots' trk_fk_positions_backward runs (their whole-row tile was
+    92 KB per workgroup = one wavefront per SIMD: UR10 + Allegro 34.1 us = 0.51 of the roofline)."""
+    L, D, P = kin.n_links, kin.n_dofs, len(point_link)
+    W = 3 * P
+    Wx = w_expr or "W"
+    V = 4 if W % 4 == 0 else (2 if W % 2 == 0 else 1)
+    pl = [int(v) for v in point_link]
+    po = np.asarray(point_offset, np.float32).reshape(-1, 3)
+    pos_of = {int(kin.order[p]): p for p in range(L)}
+    cols_of_link: Dict[int, List[int]] = {i: [c for c in range(P) if pl[c] == i] for i in range(L)}
+    masked = _masked_factory(kin)
+    BNF = int(os.environ.get("TRK_EXP_BWD_CHUNK_FLOATS", str(ROLLOUT_CHUNK_FLOATS)))  # 36 -> 64 measured 43.7 -> 42.8, 21.3 -> 19.9, 66.7 -> 47.5 us
+    BLS = BNF if BNF % 32 else BNF + 4
+    out: List[str] = []
+    # ---- explicit reverse mode of the point positions (trk_fk_points_backward): FK again, the adjoint rows arrive through
+    # the chunk buffer in column order, each adjoint g at point p joins the running wrench (g, p x g); prefix-sum gradients
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_posbwd_bi" if base_identity else "k_posbwd_bg"
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
+        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(BLS, D)}];")
+        E.raw("    const int lane = __builtin_amdgcn_workitem_id_x() & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_workitem_id_x() / TRK_WAVE);")
+        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(BLS, D)});")
+        E.raw("    const int64_t wblock = (int64_t)__builtin_amdgcn_workgroup_id_x() * SPEC_WAVES + wave;")
+        E.raw("    const int64_t base = wblock * TRK_WAVE;")
+        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+        E.raw("    const float* gpos = static_cast<const float*>(A.link_pos);")
+        E.raw("    float q[D];")
+        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+        E.raw(f"    const float* row = lds + lane * {BLS};")
+        R = {}; t = {}; passv = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        _emit_angles(E, kin)
+        E.raw("    float pf0 = 0.0f, pf1 = 0.0f, pf2 = 0.0f, pt0 = 0.0f, pt1 = 0.0f, pt2 = 0.0f;")
+        PF = [S(1.0, f"pf{k}") for k in range(3)]
+        PT = [S(1.0, f"pt{k}") for k in range(3)]
+        snap_c = {}; gq_expr = {}
+    
+        def functional(i: int) -> S:
+            jt = int(kin.joint_type[i])
+            if jt == JOINT_PRISMATIC:
+                par = int(kin.parent[i])
+                dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
+                return E.dot(dirw, PF)
+            ax = int(kin.rot_axis[i])
+            z = [R[i][r][ax] for r in range(3)]
+            cr = E.cross(t[i], PF)
+            return E.dot(z, [E.lincomb([(PT[k], ONE), (cr[k], S(-1.0))]) for k in range(3)])
+    
+        chunk_start = -1
+        for p in range(L):
+            i = int(kin.order[p])
+            if p > 0:
+                _emit_fk_link(E, kin, i, R, t, passv, snap)
+                if int(kin.joint_type[i]) != JOINT_FIXED:
+                    snap_c[i] = S(1.0, E.tmp(E.expr(functional(i))))
+            for c in cols_of_link[i]:
+                f0 = 3 * c
+                # the three floats of a column may straddle two chunks: fetch component by component
+                comp = []
+                for k in range(3):
+                    f = f0 + k
+                    cs = (f // BNF) * BNF
+                    if cs != chunk_start:
+                        nf = min(BNF, W - cs)
+                        E.raw(f"    spec_load_chunk<{Wx}, {nf}, {BLS}, {V}>(gpos, base, {cs}, rows, lane, lds);")
+                        chunk_start = cs
+                    comp.append(E.tmp(f"row[{f - cs}]"))
+                if p == 0:
+                    continue                        # the root does not move with q
+                off = [S(snap_const(po[c][k], 0.0)) for k in range(3)]
+                pc = t[i] if all(o.is_zero for o in off) else \
+                    [E.named(E.lincomb([(R[i][r][k], off[k]) for k in range(3)], t[i][r])) for r in range(3)]
+                px, py, pz = (E.expr(v) for v in pc)
+                E.raw(f"    pf0 += {comp[0]}; pf1 += {comp[1]}; pf2 += {comp[2]};")
+                E.raw(f"    pt0 += {py} * {comp[2]} - {pz} * {comp[1]}; pt1 += {pz} * {comp[0]} - {px} * {comp[2]}; "
+                      f"pt2 += {px} * {comp[1]} - {py} * {comp[0]};")
+            for j in [j for j in range(1, L) if int(kin.joint_type[j]) != JOINT_FIXED]:
+                if int(kin.subtree_end[pos_of[j]]) == p + 1:
+                    d = int(kin.dof_idx[j]); jt = int(kin.joint_type[j])
+                    sg = 1.0 if jt == JOINT_PRISMATIC else float(kin.rot_sign[j])
+                    if sg == 0.0:
+                        gq_expr[d] = ZERO
+                    else:
+                        g = E.lincomb([(functional(j), ONE), (snap_c[j], S(-1.0))])
+                        gq_expr[d] = masked(E, j, d, S(g.c * sg, g.n))
+        E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
+        E.raw("    spec_store_gq<D>(static_cast<float*>(A.gq), base, rows, lane, lds, gv);")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+    return out
+
+
 def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str, snap: float = SNAP,
                                    link_mode: bool = False, meta: Optional[dict] = None) -> str:
     """Fused FK + objectives + gradient with the collision fields on attached points.  Differences to the link kernel:
@@ -1969,8 +2081,6 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
     # 4 floats for the 16-byte reads, and NOT a multiple of 32: the per-lane row writes would all hit one bank)
     NF = int(os.environ.get("TRK_EXP_CHUNK_FLOATS", str(ROLLOUT_CHUNK_FLOATS)))
     LS = NF if NF % 32 else NF + 4
-    BNF = int(os.environ.get("TRK_EXP_BWD_CHUNK_FLOATS", str(ROLLOUT_CHUNK_FLOATS)))  # the positions' reverse mode (k_posbwd): 36 -> 64 measured 43.7 -> 42.8, 21.3 -> 19.9, 66.7 -> 47.5 us
-    BLS = BNF if BNF % 32 else BNF + 4
     WIDE = (not link_mode) and os.environ.get("TRK_EXP_CHUNK_WIDE", "0") != "0"
     lds_per_lane = max(LS, D)
     joint_links = [i for i in range(1, L) if int(kin.joint_type[i]) != JOINT_FIXED]
@@ -2214,89 +2324,7 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
         out.extend(E.lines)
         out.append("")
 
-    # ---- explicit reverse mode of the point positions (trk_fk_points_backward): FK again, the adjoint rows arrive through
-    # the chunk buffer in column order, each adjoint g at point p joins the running wrench (g, p x g); prefix-sum gradients
-    for base_identity in (True, False):
-        E = Emitter()
-        kname = "k_posbwd_bi" if base_identity else "k_posbwd_bg"
-        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 2) {kname}(SpecArgs A) {{")
-        E.raw(f"    __shared__ __attribute__((aligned(16))) float lds_all[SPEC_BLOCK * {max(BLS, D)}];")
-        E.raw("    const int lane = __builtin_amdgcn_workitem_id_x() & (TRK_WAVE - 1);")
-        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_workitem_id_x() / TRK_WAVE);")
-        E.raw(f"    float* lds = lds_all + wave * (TRK_WAVE * {max(BLS, D)});")
-        E.raw("    const int64_t wblock = (int64_t)__builtin_amdgcn_workgroup_id_x() * SPEC_WAVES + wave;")
-        E.raw("    const int64_t base = wblock * TRK_WAVE;")
-        E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
-        E.raw("    const float* gpos = static_cast<const float*>(A.link_pos);")
-        E.raw("    float q[D];")
-        E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
-        E.raw(f"    const float* row = lds + lane * {BLS};")
-        R = {}; t = {}; passv = {}
-        if base_identity:
-            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
-            t[0] = [ZERO, ZERO, ZERO]
-        else:
-            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
-            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
-        _emit_angles(E, kin)
-        E.raw("    float pf0 = 0.0f, pf1 = 0.0f, pf2 = 0.0f, pt0 = 0.0f, pt1 = 0.0f, pt2 = 0.0f;")
-        PF = [S(1.0, f"pf{k}") for k in range(3)]
-        PT = [S(1.0, f"pt{k}") for k in range(3)]
-        snap_c = {}; gq_expr = {}
-
-        def functional(i: int) -> S:
-            jt = int(kin.joint_type[i])
-            if jt == JOINT_PRISMATIC:
-                par = int(kin.parent[i])
-                dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
-                return E.dot(dirw, PF)
-            ax = int(kin.rot_axis[i])
-            z = [R[i][r][ax] for r in range(3)]
-            cr = E.cross(t[i], PF)
-            return E.dot(z, [E.lincomb([(PT[k], ONE), (cr[k], S(-1.0))]) for k in range(3)])
-
-        chunk_start = -1
-        for p in range(L):
-            i = int(kin.order[p])
-            if p > 0:
-                _emit_fk_link(E, kin, i, R, t, passv, snap)
-                if int(kin.joint_type[i]) != JOINT_FIXED:
-                    snap_c[i] = S(1.0, E.tmp(E.expr(functional(i))))
-            for c in cols_of_link[i]:
-                f0 = 3 * c
-                # the three floats of a column may straddle two chunks: fetch component by component
-                comp = []
-                for k in range(3):
-                    f = f0 + k
-                    cs = (f // BNF) * BNF
-                    if cs != chunk_start:
-                        nf = min(BNF, W - cs)
-                        E.raw(f"    spec_load_chunk<W, {nf}, {BLS}, {V}>(gpos, base, {cs}, rows, lane, lds);")
-                        chunk_start = cs
-                    comp.append(E.tmp(f"row[{f - cs}]"))
-                if p == 0:
-                    continue                        # the root does not move with q
-                off = [S(snap_const(po[c][k], 0.0)) for k in range(3)]
-                pc = t[i] if all(o.is_zero for o in off) else \
-                    [E.named(E.lincomb([(R[i][r][k], off[k]) for k in range(3)], t[i][r])) for r in range(3)]
-                px, py, pz = (E.expr(v) for v in pc)
-                E.raw(f"    pf0 += {comp[0]}; pf1 += {comp[1]}; pf2 += {comp[2]};")
-                E.raw(f"    pt0 += {py} * {comp[2]} - {pz} * {comp[1]}; pt1 += {pz} * {comp[0]} - {px} * {comp[2]}; "
-                      f"pt2 += {px} * {comp[1]} - {py} * {comp[0]};")
-            for j in [j for j in range(1, L) if int(kin.joint_type[j]) != JOINT_FIXED]:
-                if int(kin.subtree_end[pos_of[j]]) == p + 1:
-                    d = int(kin.dof_idx[j]); jt = int(kin.joint_type[j])
-                    sg = 1.0 if jt == JOINT_PRISMATIC else float(kin.rot_sign[j])
-                    if sg == 0.0:
-                        gq_expr[d] = ZERO
-                    else:
-                        g = E.lincomb([(functional(j), ONE), (snap_c[j], S(-1.0))])
-                        gq_expr[d] = masked(E, j, d, S(g.c * sg, g.n))
-        E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
-        E.raw("    spec_store_gq<D>(static_cast<float*>(A.gq), base, rows, lane, lds, gv);")
-        E.raw("}")
-        out.extend(E.lines)
-        out.append("")
+    out.extend(_chunked_posbwd_lines(kin, pl, po, snap))
 
     if meta is not None and not link_mode:
         # what a code-object (hipRTC) build of this unit must contain: the name expressions of its kernels (jit.py, trk_spec_register_module)
