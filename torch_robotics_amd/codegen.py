@@ -1925,7 +1925,7 @@ def ring_plan(W: int) -> RingPlan:
     return RingPlan(W=W, V=V, aligned=False, hx=0, n_full=n_full, tail=W - RING_FLOATS * n_full, pieces=64 // (64 // (RING_FLOATS // V)))
 
 
-OBJ_GROUP = 6              # points evaluated against the scene together (register arrays of this size)
+OBJ_GROUP = int(os.environ.get("TRK_EXP_OBJ_GROUP", "6"))     # points evaluated against the scene together (register arrays of this size)
 
 
 def _chunked_posbwd_lines(kin: KinModel, point_link, point_offset, snap: float = SNAP, w_expr: Optional[str] = None) -> List[str]:
