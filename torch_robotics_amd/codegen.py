@@ -634,48 +634,88 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw("    const IOQ* vb = spec_raw_rows_finish<D, IOQ>(rv, static_cast<const IOQ*>(A.qd), base, rows, lane, reinterpret_cast<IOQ*>(reinterpret_cast<unsigned char*>(lds) + Raw::BYTES));")
             E.raw("    float* rt = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + 2 * Raw::BYTES);     // [65][RS]: row l + 1 = lane l's factor")
             E.raw("    spec_wave_sync();")
-            E.raw("    float gpv[D], cost_gp;")
-            E.raw("    {")
-            E.raw("        // ---- the prior.  A lane computes ONLY the factor it starts: e_t = (p_t + dt v_t - p_t+1, v_t - v_t+1), r_t = w Q^-1 e_t (zero")
-            E.raw("        // when the trajectory ends here); the factor that ends at this sample is the previous lane's, fetched through LDS (the one in")
-            E.raw("        // front of the block: lanes 0 .. D-1, one joint each).  d/dq_t = r_t.p - r_t-1.p,  d/dqd_t = dt r_t.p + r_t.v - r_t-1.v.")
-            E.raw("        const float wm = (lane < rows && tl + 1u < Hh) ? A.gp_w : 0.0f;")
-            E.raw("        const float dt = A.gp_dt, ga = A.gp_a, gb = A.gp_b, gc = A.gp_c;")
-            E.raw("        float gvv[D], accg = 0.0f;")
-            E.raw("#pragma unroll")
-            E.raw("        for (int d = 0; d < D; ++d) {")
-            E.raw("            const float p0 = (float)qb[lane * D + d], v0 = (float)vb[lane * D + d];")
-            E.raw("            const float pn = (float)qb[(lane + 1) * D + d], vn = (float)vb[(lane + 1) * D + d];")
-            E.raw("            const float ep = fmaf(dt, v0, p0) - pn, ev = v0 - vn;")
-            E.raw("            const float rp = wm * fmaf(ga, ep, gb * ev), rv_ = wm * fmaf(gb, ep, gc * ev);")
-            E.raw("            accg = fmaf(0.5f, fmaf(ep, rp, ev * rv_), accg);")
-            E.raw("            rt[(lane + 1) * RS + 2 * d] = rp; rt[(lane + 1) * RS + 2 * d + 1] = rv_;")
-            E.raw("            q[d] = p0;")
-            E.raw("            if (d % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four joints in flight: the max-ILP scheduler would hoist all 4 D tile reads (and spill)")
-            E.raw("        }")
-            E.raw("        {       // the factor between the sample in front of the block and its first sample: lanes 0 .. D-1, joint `lane`.  Branch-free")
-            E.raw("                // (the other lanes compute joint 0 again and write a scratch slot behind the tile): as a divergent branch this")
-            E.raw("                // block cost the whole kernel 38 registers (217 -> 255, spills in the box-scene instantiation)")
-            E.raw("            const int dj = lane < D ? lane : 0;")
-            E.raw("            const float pm = (float)qb[dj - D], vm = (float)vb[dj - D], pf = (float)qb[dj], vf = (float)vb[dj];")
-            E.raw("            const float wp = edge_prev ? A.gp_w : 0.0f;")
-            E.raw("            const float ep = fmaf(dt, vm, pm) - pf, ev = vm - vf;")
-            E.raw("            float* slot = rt + (lane < D ? 2 * lane : (TRK_WAVE + 1) * RS);")
-            E.raw("            slot[0] = wp * fmaf(ga, ep, gb * ev); slot[1] = wp * fmaf(gb, ep, gc * ev);")
-            E.raw("        }")
-            E.raw("        spec_wave_sync();")
-            E.raw("#pragma unroll")
-            E.raw("        for (int d = 0; d < D; ++d) {")
-            E.raw("            const float rp = rt[(lane + 1) * RS + 2 * d], rv_ = rt[(lane + 1) * RS + 2 * d + 1];      // re-read: 2 D registers less across the sync")
-            E.raw("            gpv[d] = rp - rt[lane * RS + 2 * d];")
-            E.raw("            gvv[d] = fmaf(dt, rp, rv_) - rt[lane * RS + 2 * d + 1];")
-            E.raw("            if (d % 4 == 3) __builtin_amdgcn_sched_barrier(0);")
-            E.raw("        }")
-            E.raw("        cost_gp = accg;")
-            E.raw("        // d cost / d qd is final: out through the staging tile (its first line waits for every lane's reads of the tiles)")
-            E.raw("        spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base, rows, lane, lds, gvv, A.grad_scale);")
-            E.raw("        spec_wave_sync();")
-            E.raw("    }")
+            if os.environ.get("TRK_EXP_GP_PRIOR", "dpp") == "lds":
+                E.raw("    float gpv[D], cost_gp;")
+                E.raw("    {")
+                E.raw("        // ---- the prior.  A lane computes ONLY the factor it starts: e_t = (p_t + dt v_t - p_t+1, v_t - v_t+1), r_t = w Q^-1 e_t (zero")
+                E.raw("        // when the trajectory ends here); the factor that ends at this sample is the previous lane's, fetched through LDS (the one in")
+                E.raw("        // front of the block: lanes 0 .. D-1, one joint each).  d/dq_t = r_t.p - r_t-1.p,  d/dqd_t = dt r_t.p + r_t.v - r_t-1.v.")
+                E.raw("        const float wm = (lane < rows && tl + 1u < Hh) ? A.gp_w : 0.0f;")
+                E.raw("        const float dt = A.gp_dt, ga = A.gp_a, gb = A.gp_b, gc = A.gp_c;")
+                E.raw("        float gvv[D], accg = 0.0f;")
+                E.raw("#pragma unroll")
+                E.raw("        for (int d = 0; d < D; ++d) {")
+                E.raw("            const float p0 = (float)qb[lane * D + d], v0 = (float)vb[lane * D + d];")
+                E.raw("            const float pn = (float)qb[(lane + 1) * D + d], vn = (float)vb[(lane + 1) * D + d];")
+                E.raw("            const float ep = fmaf(dt, v0, p0) - pn, ev = v0 - vn;")
+                E.raw("            const float rp = wm * fmaf(ga, ep, gb * ev), rv_ = wm * fmaf(gb, ep, gc * ev);")
+                E.raw("            accg = fmaf(0.5f, fmaf(ep, rp, ev * rv_), accg);")
+                E.raw("            rt[(lane + 1) * RS + 2 * d] = rp; rt[(lane + 1) * RS + 2 * d + 1] = rv_;")
+                E.raw("            q[d] = p0;")
+                E.raw("            if (d % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // four joints in flight: the max-ILP scheduler would hoist all 4 D tile reads (and spill)")
+                E.raw("        }")
+                E.raw("        {       // the factor between the sample in front of the block and its first sample: lanes 0 .. D-1, joint `lane`.  Branch-free")
+                E.raw("                // (the other lanes compute joint 0 again and write a scratch slot behind the tile): as a divergent branch this")
+                E.raw("                // block cost the whole kernel 38 registers (217 -> 255, spills in the box-scene instantiation)")
+                E.raw("            const int dj = lane < D ? lane : 0;")
+                E.raw("            const float pm = (float)qb[dj - D], vm = (float)vb[dj - D], pf = (float)qb[dj], vf = (float)vb[dj];")
+                E.raw("            const float wp = edge_prev ? A.gp_w : 0.0f;")
+                E.raw("            const float ep = fmaf(dt, vm, pm) - pf, ev = vm - vf;")
+                E.raw("            float* slot = rt + (lane < D ? 2 * lane : (TRK_WAVE + 1) * RS);")
+                E.raw("            slot[0] = wp * fmaf(ga, ep, gb * ev); slot[1] = wp * fmaf(gb, ep, gc * ev);")
+                E.raw("        }")
+                E.raw("        spec_wave_sync();")
+                E.raw("#pragma unroll")
+                E.raw("        for (int d = 0; d < D; ++d) {")
+                E.raw("            const float rp = rt[(lane + 1) * RS + 2 * d], rv_ = rt[(lane + 1) * RS + 2 * d + 1];      // re-read: 2 D registers less across the sync")
+                E.raw("            gpv[d] = rp - rt[lane * RS + 2 * d];")
+                E.raw("            gvv[d] = fmaf(dt, rp, rv_) - rt[lane * RS + 2 * d + 1];")
+                E.raw("            if (d % 4 == 3) __builtin_amdgcn_sched_barrier(0);")
+                E.raw("        }")
+                E.raw("        cost_gp = accg;")
+                E.raw("        // d cost / d qd is final: out through the staging tile (its first line waits for every lane's reads of the tiles)")
+                E.raw("        spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base, rows, lane, lds, gvv, A.grad_scale);")
+                E.raw("        spec_wave_sync();")
+                E.raw("    }")
+            else:
+                # Round 5: the neighbours come through DPP wave shifts instead of LDS.  The phase stamps put "rows in + prior + gqd out" at 36 - 42 %
+                # of a config-5 wavefront's life (7300 - 8200 of 20 000 ticks): per joint the LDS form cost four reads, two writes and four
+                # more reads behind a second sync -- ten dependent round trips' worth of instructions at two wavefronts per SIMD.  Now a lane
+                # reads its own row, the next sample's (p, v) arrive by `wave_shl:1` (lane 63: the row behind the block, handed to the
+                # shift as its `old` operand, which a lane without a source keeps), the finished factor (rp, rv) goes to the next lane by
+                # `wave_shr:1` (lane 0: the factor in front of the block, computed by lanes 0 .. D-1 as before and read back broadcast).
+                # Same expressions on the same values as the LDS form: bit-identical results.
+                E.raw("    float gpv[D], cost_gp;")
+                E.raw("    {")
+                E.raw("        const float wm = (lane < rows && tl + 1u < Hh) ? A.gp_w : 0.0f;")
+                E.raw("        const float dt = A.gp_dt, ga = A.gp_a, gb = A.gp_b, gc = A.gp_c;")
+                E.raw("        {       // the factor between the sample in front of the block and its first sample: lanes 0 .. D-1, joint `lane`.  Branch-free")
+                E.raw("                // (the other lanes compute joint 0 again and write a scratch slot behind the records)")
+                E.raw("            const int dj = lane < D ? lane : 0;")
+                E.raw("            const float pm = (float)qb[dj - D], vm = (float)vb[dj - D], pf = (float)qb[dj], vf = (float)vb[dj];")
+                E.raw("            const float wp = edge_prev ? A.gp_w : 0.0f;")
+                E.raw("            const float ep = fmaf(dt, vm, pm) - pf, ev = vm - vf;")
+                E.raw("            float* slot = rt + (lane < D ? 2 * lane : 2 * D);")
+                E.raw("            slot[0] = wp * fmaf(ga, ep, gb * ev); slot[1] = wp * fmaf(gb, ep, gc * ev);")
+                E.raw("        }")
+                E.raw("        spec_wave_sync();")
+                E.raw("        float gvv[D], accg = 0.0f;")
+                E.raw("#pragma unroll")
+                E.raw("        for (int d = 0; d < D; ++d) {")
+                E.raw("            const float p0 = (float)qb[lane * D + d], v0 = (float)vb[lane * D + d];")
+                E.raw("            const float pn = trk_dpp_from_next((float)qb[TRK_WAVE * D + d], p0), vn = trk_dpp_from_next((float)vb[TRK_WAVE * D + d], v0);")
+                E.raw("            const float ep = fmaf(dt, v0, p0) - pn, ev = v0 - vn;")
+                E.raw("            const float rp = wm * fmaf(ga, ep, gb * ev), rv_ = wm * fmaf(gb, ep, gc * ev);")
+                E.raw("            accg = fmaf(0.5f, fmaf(ep, rp, ev * rv_), accg);")
+                E.raw("            gpv[d] = rp - trk_dpp_from_prev(rt[2 * d], rp);")
+                E.raw("            gvv[d] = fmaf(dt, rp, rv_) - trk_dpp_from_prev(rt[2 * d + 1], rv_);")
+                E.raw("            q[d] = p0;")
+                E.raw("        }")
+                E.raw("        cost_gp = accg;")
+                E.raw("        // d cost / d qd is final: out through the staging tile (its first line waits for every lane's reads of the tiles)")
+                E.raw("        spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base, rows, lane, lds, gvv, A.grad_scale);")
+                E.raw("        spec_wave_sync();")
+                E.raw("    }")
         E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
         E.raw("    if constexpr (BOX) spec_load_spheres_finish(lds_prm, lane, prm);")
         E.raw("    spec_stamp(A.stamps, wblock, 1, lane);")

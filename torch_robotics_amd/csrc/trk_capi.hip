@@ -1490,7 +1490,7 @@ int trk_rollout_gp_cost_grad(const TrkModel* m, const TrkCostModel* cm, const Tr
             std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
             std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
             a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
-            a.io_f16 = io_mode; a.grad_scale = grad_scale;
+            a.stamps = g_stamps; a.io_f16 = io_mode; a.grad_scale = grad_scale;
             const float s2 = 1.0f / (gp->sigma * gp->sigma);
             a.qd = qd; a.gqd = gqd; a.gp_dt = gp->dt; a.gp_w = gp->weight; a.gp_H = horizon;
             a.gp_a = 12.0f * s2 / (gp->dt * gp->dt * gp->dt); a.gp_b = -6.0f * s2 / (gp->dt * gp->dt); a.gp_c = 4.0f * s2 / gp->dt;

@@ -177,6 +177,15 @@ __device__ __forceinline__ float trk_sqrt(float x) { return __builtin_amdgcn_sqr
 __device__ __forceinline__ float trk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
 __device__ __forceinline__ float trk_rsq(float x) { return __builtin_amdgcn_rsqf(x); }     // v_rsq_f32, 1 ulp
 
+// Neighbour exchange along the wavefront as a DPP operand (gfx9 `wave_shl:1` / `wave_shr:1`; tools/microbench/dpp_wave_shift.hip): lane l
+// receives v of lane l + 1 (l - 1); the lane without a source -- 63 (0) -- keeps `edge`.  All 64 lanes must be active.
+__device__ __forceinline__ float trk_dpp_from_next(float edge, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float trk_dpp_from_prev(float edge, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
 // Sum over the wavefront, broadcast to every lane.  DPP adds (row_shr 1/2/4/8, row_bcast 15/31) run at VALU speed; the
 // __shfl_xor butterfly is six dependent ds_bpermute round trips (~100 cycles each) at the very end of the kernel, where no
 // other work is left to hide them.  Deterministic (fixed association), result taken from lane 63.
