@@ -63,6 +63,10 @@ def _generator_stamp() -> str:
               _REPO_INCLUDE / "trk.h"):
         h.update(f.read_bytes())
     h.update(" ".join(_compile_cmd("<src>", "<out>")).replace(str(_CSRC), "<csrc>").encode())   # location-independent
+    # generation-time experiment knobs change the text the generator writes: a unit generated under one is not the default unit
+    knobs = sorted((k, v) for k, v in os.environ.items() if k.startswith(("TRK_EXP_", "TRK_GP_SCHEDULE")))
+    if knobs:
+        h.update(repr(knobs).encode())
     return h.hexdigest()[:12]
 
 
