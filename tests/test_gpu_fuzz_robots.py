@@ -6,6 +6,8 @@ oracle for the fused rollout (positions, cost, gradient), the boolean fields, th
 
 The reference-pinned robots are in test_gpu_parity.py; this file is about the generator's corner cases (structural zeros, sign folds,
 constant links, branch bookkeeping) on shapes nobody wrote by hand."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -145,7 +147,18 @@ def test_random_robot_generated_vs_table_driven_vs_oracle(ops, oracle_lib, tmp_p
         h.enable_specialized(True)
 
 
-@pytest.mark.parametrize("seed,robot", [(0, "panda_arm_no_gripper"), (1, "dual_panda"), (2, "panda_arm_no_gripper")])
+def _point_set_draws():
+    """four draws keep the suite short (each is a run-time compile); TRK_FUZZ_POINT_SEEDS="10-21" adds more for a one-off soak"""
+    draws = [(0, "panda_arm_no_gripper"), (1, "dual_panda"), (2, "panda_arm_no_gripper"),
+             (30, "iiwa7")]        # two paired points 1 mm apart on one link: what the first factorised pair accumulation (V - p S) got wrong
+    extra = os.environ.get("TRK_FUZZ_POINT_SEEDS", "")
+    if extra:
+        a, b = (int(v) for v in extra.split("-"))
+        draws += [(k, ("panda_arm_no_gripper", "ur10", "iiwa7", "panda_arm_no_gripper")[k % 4]) for k in range(a, b + 1)]
+    return draws
+
+
+@pytest.mark.parametrize("seed,robot", _point_set_draws())
 def test_random_point_sets_generated_vs_table_driven_vs_oracle(ops, oracle_lib, seed, robot):
     """Attached-point units compiled at run time for RANDOM point sets (points per link 0 .. 5 with random offsets incl. exact zeros,
     walk-ordered columns) and random self pairs -- pairs between two points of ONE link, pairs whose earlier point sits on a fixed link,
@@ -192,7 +205,9 @@ def test_random_point_sets_generated_vs_table_driven_vs_oracle(ops, oracle_lib, 
         pos, cost, gq = (t.cpu().numpy() for t in ops.rollout_points_cost_grad(ps, cm, w, dev(q)))
         for name, (p_, c_, g_) in (("generated", (pos, cost, gq)), ("table-driven", table[w])):
             assert np.abs(p_ - rp).max() < 2 * TOL_H, (seed, w, name)
-            assert rel_err(c_, rc) < TOL_C, (seed, w, name)
+            # a hinged cost is a small DIFFERENCE (margin - distance, both ~0.05): its error scales with those, not with what the hinge
+            # leaves -- seeds whose self-only costs are all < 2e-3 otherwise fail on the 1e-7 a fp32 position is worth (soak seeds 15, 35, 40)
+            assert np.abs(c_ - rc).max() < TOL_C * max(float(np.abs(rc).max()), 0.05), (seed, w, name)
             bad = ~np.isclose(g_, rg, rtol=1e-3, atol=1e-4 * max(1.0, np.abs(rg).max())).all(-1)
             assert bad.sum() <= 2, (seed, w, name, int(bad.sum()))              # arg-min ties / hinges at zero
     wpt = rng.standard_normal((130, P, 3)).astype(np.float32)

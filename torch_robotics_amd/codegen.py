@@ -2275,43 +2275,33 @@ def generate_points_rollout_source(kin: KinModel, pt: PointsTemplate, ident: str
                 E.raw("            pt0 += py[l] * gz[l] - pz[l] * gy[l]; pt1 += pz[l] * gx[l] - px[l] * gz[l]; pt2 += px[l] * gy[l] - py[l] * gx[l];")
                 E.raw("        }")
                 E.raw("    }")
-            # ---- self-collision pairs whose later column belongs to this link.  Round 5: FACTORISED.  A pair hands back only
-            # s = w / ||d|| (spec_self_pair_s); the force on a point is a sum over its pairs, sum_e s_e (p_e - p) = V - p S with
-            # S = sum s_e, V = sum s_e p_e -- one add per pair (+ one FMA per non-zero component of the partner, which is often a
-            # constant: link origins on the base's axis), and ONE wrench update (9 instructions) per point instead of one per pair;
-            # the partner's force is U - p_e T the same way.  The grasped-box model has 66 pairs on 14 + 4 points: 2061 of the kernel's
-            # 5532 static vector instructions were this phase (tools/isa_valu_count.sh).
+            # ---- self-collision pairs whose later column belongs to this link.  Round 5: the force on a point is ACCUMULATED over its
+            # pairs (a pair hands back s = w / ||d|| and d = p_late - p_early: one FMA per component and side) and enters the running
+            # wrench ONCE per point (9 instructions) instead of once per pair and side.  The grasped-box model has 66 pairs on 14 + 4
+            # points: 2061 of the kernel's 5532 static vector instructions were this phase (tools/isa_valu_count.sh).  (First built as
+            # S = sum s, V = sum s p_e, force = V - p S: a few instructions fewer, but it cancels when the points are close and far from
+            # the origin -- spec_self_pair_sd's comment.)
             if pairs_at[i]:
                 E.raw("    if (A.w.w_self != 0.0f) {")
                 E.raw("        const bool sclamp = (A.C.clamp_fields & TRK_FIELD_SELF) != 0;")
                 earlies = sorted({early for _, _, early, _ in pairs_at[i]})
                 lates = sorted({late for _, late, _, _ in pairs_at[i]})
                 for e in earlies:             # all pairs of one earlier column push on the same point
-                    E.raw(f"        float gT{e} = 0.0f, gU{e}_0 = 0.0f, gU{e}_1 = 0.0f, gU{e}_2 = 0.0f;")
+                    E.raw(f"        float ge{e}_0 = 0.0f, ge{e}_1 = 0.0f, ge{e}_2 = 0.0f;")
                 for c in lates:
                     E.raw("        {")
-                    E.raw("        float gS = 0.0f, gV0 = 0.0f, gV1 = 0.0f, gV2 = 0.0f;")
+                    E.raw("        float gl0 = 0.0f, gl1 = 0.0f, gl2 = 0.0f;")
                     pc = [E.expr(colpos[c][k]) for k in range(3)]
                     for pi, late, early, late_is_a in pairs_at[i]:
                         if late != c:
                             continue
                         pe = [E.expr(colpos[early][k]) for k in range(3)]
-                        E.raw(f"        {{ const float s_ = spec_self_pair_s(A.w.w_self, cptr(A.C.self_margin)[{pi}], {', '.join(pc)}, {', '.join(pe)}, sclamp, cost);")
-                        upd = ["gS += s_;"]
-                        for k in range(3):
-                            if not (colpos[early][k].is_const and colpos[early][k].is_zero):
-                                upd.append(f"gV{k} = fmaf(s_, {pe[k]}, gV{k});")
-                        upd.append(f"gT{early} += s_;")
-                        for k in range(3):
-                            if not (colpos[c][k].is_const and colpos[c][k].is_zero):
-                                upd.append(f"gU{early}_{k} = fmaf(s_, {pc[k]}, gU{early}_{k});")
-                        E.raw("          " + " ".join(upd) + " }")
-                    E.raw(f"        const float gl0 = fmaf(-gS, {pc[0]}, gV0), gl1 = fmaf(-gS, {pc[1]}, gV1), gl2 = fmaf(-gS, {pc[2]}, gV2);")
+                        E.raw(f"        {{ float d0_, d1_, d2_; const float s_ = spec_self_pair_sd(A.w.w_self, cptr(A.C.self_margin)[{pi}], {', '.join(pc)}, {', '.join(pe)}, sclamp, cost, d0_, d1_, d2_);")
+                        E.raw(f"          gl0 = fmaf(-s_, d0_, gl0); gl1 = fmaf(-s_, d1_, gl1); gl2 = fmaf(-s_, d2_, gl2); "
+                              f"ge{early}_0 = fmaf(s_, d0_, ge{early}_0); ge{early}_1 = fmaf(s_, d1_, ge{early}_1); ge{early}_2 = fmaf(s_, d2_, ge{early}_2); }}")
                     in_order(colpos[c], ["gl0", "gl1", "gl2"])
                     E.raw("        }")
                 for e in earlies:
-                    pe = [E.expr(colpos[e][k]) for k in range(3)]
-                    E.raw(f"        const float ge{e}_0 = fmaf(-gT{e}, {pe[0]}, gU{e}_0), ge{e}_1 = fmaf(-gT{e}, {pe[1]}, gU{e}_1), ge{e}_2 = fmaf(-gT{e}, {pe[2]}, gU{e}_2);")
                     g = [f"ge{e}_0", f"ge{e}_1", f"ge{e}_2"]
                     if pl[e] == i:
                         in_order(colpos[e], g)

@@ -1174,6 +1174,21 @@ __device__ __forceinline__ float spec_self_pair_s(float w, float margin, float a
     cost = fmaf(w, margin - nrm, cost);
     return w * rs;
 }
+// the same, handing back the difference d = pa - pb as well: the force on a is -s d, on b +s d.  The attached-point kernels accumulate THESE
+// per point (one FMA per component and side).  The first factorised form accumulated S = sum s and V = sum s pb and formed V - pa S at the
+// end -- fewer instructions when components are constants, but s (pb - pa) computed as s pb - s pa cancels catastrophically when the two
+// points are close and far from the origin (two points 1 mm apart on one link: relative error 1e-7 |p| / |d| = 1e-4 of the force, found by
+// the point-set fuzz with more seeds); differences first is translation invariant like the reference's own expression.
+__device__ __forceinline__ float spec_self_pair_sd(float w, float margin, float ax, float ay, float az, float bx, float by, float bz,
+                                                   bool clamp, float& cost, float& dx, float& dy, float& dz) {
+    dx = ax - bx; dy = ay - by; dz = az - bz;
+    const float n2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+    const float rs = n2 > 0.0f ? trk_rsq(n2) : 0.0f;
+    const float nrm = n2 * rs;
+    if (clamp) w = margin - nrm > 0.0f ? w : 0.0f;
+    cost = fmaf(w, margin - nrm, cost);
+    return w * rs;
+}
 // one self-collision pair, boolean (distance_fields.py:210-215): ||pa - pb|| < margin, IEEE sqrt like torch.linalg.norm
 __device__ __forceinline__ bool spec_self_hit(float margin, float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
