@@ -102,7 +102,17 @@ def random_cost_spec(m, rng, scene):
     return spec
 
 
-@pytest.mark.parametrize("seed", list(range(8)))          # (seeds 8 - 11 ran clean too; eight keep the suite short: each draw is a run-time compile)
+def _robot_seeds():
+    """eight draws keep the suite short (each is a run-time compile); TRK_FUZZ_ROBOT_SEEDS="8-40" adds more for a one-off soak"""
+    seeds = list(range(8))
+    extra = os.environ.get("TRK_FUZZ_ROBOT_SEEDS", "")
+    if extra:
+        a, b = (int(v) for v in extra.split("-"))
+        seeds += list(range(a, b + 1))
+    return seeds
+
+
+@pytest.mark.parametrize("seed", _robot_seeds())
 def test_random_robot_generated_vs_table_driven_vs_oracle(ops, oracle_lib, tmp_path, seed):
     from torch_robotics_amd import jit
     rng = np.random.default_rng(9000 + seed)
@@ -143,7 +153,10 @@ def test_random_robot_generated_vs_table_driven_vs_oracle(ops, oracle_lib, tmp_p
         ref_b = o.fk_backward(q.astype(np.float64), gH, "f64")
         for use_spec in (True, False):
             h.enable_specialized(use_spec)
-            assert grad_close(ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy(), ref_b, scale=scale), (seed, n, use_spec)
+            gb = ops.fk_positions_backward(h, dev(q), dev(w)).cpu().numpy()
+            # (a draw whose gradient is zero everywhere -- one sample, every joint beyond its limit or turning about the only point it
+            # carries -- leaves grad_close no scale: the wrench form's rounding, ~1e-8 |t| |f|, is then all there is; soak seeds 12, 20, 21, 31, 42)
+            assert grad_close(gb, ref_b, scale=scale) or np.abs(gb - ref_b).max() < 1e-6 * scale, (seed, n, use_spec)
         h.enable_specialized(True)
 
 
