@@ -436,6 +436,25 @@ int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const T
  * (~10 x slower).  A deployment that must not fall back silently asserts this once after building its handles. */
 int trk_rollout_is_specialized(const TrkModel* model, const TrkCostModel* cm, const TrkRolloutWeights* w);
 
+/* Which kernel family served the CALLING THREAD's latest rollout call (trk_rollout_cost_grad[_f16], trk_rollout_gp_cost_grad,
+ * trk_rollout_points_cost_grad, trk_rollout_collision[_via]).  No reference counterpart: the reference has one code path
+ * (tasks.py:139-232); here a cost model whose link sets no generated unit bakes is served by the table-driven kernels, 10 - 30 x slower. */
+enum {
+    TRK_DISPATCH_NONE = 0,                  /* no rollout call yet on this thread (or a call that had nothing to launch) */
+    TRK_DISPATCH_GENERATED = 1,             /* one launch of a generated (model-specialised) kernel */
+    TRK_DISPATCH_TABLE = 2,                 /* the table-driven kernels */
+    TRK_DISPATCH_GENERATED_PLUS_PRIOR = 3   /* trk_rollout_gp_cost_grad only: generated rollout, the GP prior as launches of its own */
+};
+int trk_last_dispatch(void);
+/* trk_rollout_is_specialized for trk_rollout_points_cost_grad(ps->model, ps, cm, w, ...) (16-byte aligned point_pos_out assumed). */
+int trk_rollout_points_is_specialized(const TrkPointSet* ps, const TrkCostModel* cm, const TrkRolloutWeights* w);
+/* Strict mode (process-wide; also TRK_STRICT_SPECIALIZED=1 in the environment, read once): the rollout entry points above return
+ * TRK_ERR_UNSUPPORTED instead of launching a table-driven kernel when the model HAS generated units but none matches the call.
+ * Models without any generated unit are served as before.  Returns the previous setting. */
+int trk_set_strict_specialized(int on);
+/* A weight on a term the cost model does not have (w_self without self pairs, w_ws without a workspace box, w_obj on an empty
+ * scene, w_ee without a tracked link) contributes nothing in either kernel family and never influences the dispatch. */
+
 /* Registers a generated unit that was compiled to a CODE OBJECT in-process (torch_robotics_amd/jit.py: hipRTC, the fall-back when
  * no hipcc is installed) -- the unit's device half only; libtrk.so's generic launchers play its host half.  Used by the package's
  * run-time compiler, not by applications.  code: the code object (kept mapped by the HIP module); name_exprs / lowered_names
@@ -643,16 +662,20 @@ int trk_pack_sums(const float* cost, const void* gq, int32_t grad_dtype, float g
  * planner sends right after the evaluation whose sums travel and receives some evaluations later, when the peers' rows have
  * arrived -- the wait leaves the critical path without a second stream.  Single-workgroup kernels, asynchronous on `stream`;
  * the sequence numbers live in device memory, so the calls can be captured into a hipGraph and replayed.  All ranks must issue
- * the same sequence of exchanges; on one rank send k, recv k, send k + 1, ... must run in that (stream) order.  A rank that
- * waits longer than TRK_MAILBOX_TIMEOUT_S (environment, default 5 s) for a flag gives up, counts a time-out
- * (trk_mailbox_status) and writes an incomplete sum instead of hanging the GPU.
+ * the same sequence of exchanges, with EQUAL (world, n_floats, n_slots) on every rank (the offsets of a peer's rows follow from
+ * them: exchange the triple with the handles and compare before connect); on one rank send k, recv k, send k + 1, ... run in
+ * that (stream) order, with bounded look-ahead: send k + a may be issued before recv k only for a <= (n_slots - 2) / 2 (two
+ * slots = strict alternation, four = one send ahead) -- a send beyond that is refused (TRK_ERR_INVALID_ARG), as is a recv without
+ * a send (the host counts launches; a captured graph counts once and must therefore be balanced).  A rank that waits longer than
+ * TRK_MAILBOX_TIMEOUT_S (environment, default 5 s) for a flag gives up, counts a time-out (sticky, trk_mailbox_status) and writes
+ * NaN to every element of `out` -- never an incomplete sum -- instead of hanging the GPU.
  *   create:     allocates the local mailbox (uncached, else fine-grained, else plain device memory -- the first kind that
  *               hipIpcGetMemHandle accepts; TRK_MAILBOX_ALLOC=uncached|finegrained|plain in the environment forces one).
  *   ipc_handle: writes the TRK_MAILBOX_HANDLE_BYTES bytes another process passes to connect (exchange them with any host
  *               transport, e.g. torch.distributed.all_gather_object).
  *   connect:    handles [world][TRK_MAILBOX_HANDLE_BYTES] (HOST; the entry of this rank is ignored): maps the peers' mailboxes.
  *   status:     synchronises with the device; exchanges issued, time-outs seen, allocation kind (0 uncached, 1 fine-grained, 2 plain).
- * world == 1 needs no connect.  2 <= n_slots <= 64, world <= 16. */
+ * world == 1 needs no connect.  2 <= n_slots <= 64, world <= 16, n_floats <= 2^22. */
 #define TRK_MAILBOX_HANDLE_BYTES 64
 typedef struct TrkMailbox TrkMailbox;
 int trk_mailbox_create(int32_t world, int32_t rank, int32_t n_floats, int32_t n_slots, TrkMailbox** out);

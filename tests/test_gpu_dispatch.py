@@ -1,0 +1,143 @@
+"""Which kernel family serves a rollout call (round 6): a weight on a term the cost model does not have must never send the call to
+the table-driven kernels (the silent 28 x cliff of round 5: UR10 + Allegro 26.8 -> 743 us with w_self = 1 on a cost model without
+self pairs), `trk_last_dispatch` says which family ran, and the strict mode turns a REAL mismatch into an error.
+Reference call path that is being dispatched: PlanningTask._compute_collision_or_cost, tasks.py:139-232."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import gold, model, panda_cost_spec, tree_cost_spec
+from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from torch_robotics_amd import ops as o
+    return o
+
+
+def _strip(spec, self_pairs=False, ws=False, ee=False):
+    """the same cost model without some of its terms"""
+    import copy
+    s = copy.deepcopy(spec)
+    if self_pairs:
+        s.self_link_idx = np.zeros((0,), np.int32)
+        s.self_pairs = np.zeros((0, 2), np.int32)
+        s.self_margin = np.zeros((0,), np.float32)
+    if ws:
+        s.ws_min = s.ws_max = None
+    if ee:
+        s.ee_link, s.ee2_link = -1, -1
+    s.validate()
+    return s
+
+
+@pytest.mark.parametrize("name", ["ur10_allegro", "panda"])
+def test_vacuous_weights_stay_on_the_generated_kernel(ops, name):
+    if name == "panda":
+        g, robot = gold("cost_spheres3d"), gold("panda_robot")
+        T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.2, 0.5)
+        m, spec = model("panda_arm_no_gripper"), panda_cost_spec(g, robot, ee_target=T)
+    else:
+        m, spec, _ = tree_cost_spec(name)
+    h = ops.ModelHandle(m)
+    assert h.specialized
+    rng = np.random.default_rng(5)
+    q = torch.as_tensor(rng.uniform(-1.5, 1.5, size=(64, 64, m.n_dofs)).astype(np.float32), device=DEV)
+    full = ops.CostHandle(spec, DEV)
+    assert ops.rollout_is_specialized(h, full, (1, 1, 1, 1))
+    for strip in (dict(self_pairs=True), dict(ws=True), dict(ee=True), dict(self_pairs=True, ws=True, ee=True)):
+        cm = ops.CostHandle(_strip(spec, **strip), DEV)
+        w_all = (1.0, 1.0, 1.0, 1.0)
+        w_eff = (0.0 if strip.get("self_pairs") else 1.0, 1.0, 0.0 if strip.get("ws") else 1.0, 0.0 if strip.get("ee") else 1.0)
+        assert ops.rollout_is_specialized(h, cm, w_all), strip
+        pos, c, g_ = ops.rollout_cost_grad(h, cm, w_all, q)
+        assert ops.last_dispatch() == "generated", strip
+        pos2, c2, g2 = ops.rollout_cost_grad(h, cm, w_eff, q)          # the explicit zero weight: the same launch
+        assert ops.last_dispatch() == "generated"
+        assert torch.equal(c, c2) and torch.equal(g_, g2) and torch.equal(pos, pos2), strip
+        # ... and the same function as the table-driven kernel computes for these weights (the vacuous terms contribute nothing there)
+        h.enable_specialized(False)
+        _, ct, gt = ops.rollout_cost_grad(h, cm, w_all, q)
+        assert ops.last_dispatch() == "table-driven"
+        h.enable_specialized(True)
+        assert float((c - ct).abs().max()) <= 2e-5 * max(1.0, float(ct.abs().max())), strip
+        assert float((g_ - gt).abs().max()) <= 2e-4 * max(1.0, float(gt.abs().max())), strip
+        # the boolean exit: a field with nothing to test is dropped from the mask, not sent to the two-step table-driven form
+        hit = ops.rollout_collision(h, cm, FIELD_SELF | FIELD_OBJECTS | FIELD_WS, q)
+        assert ops.last_dispatch() == "generated", strip
+        keep = (0 if strip.get("self_pairs") else FIELD_SELF) | FIELD_OBJECTS | (0 if strip.get("ws") else FIELD_WS)
+        assert torch.equal(hit, ops.rollout_collision(h, cm, keep, q)), strip
+    # a cost model with NOTHING to test: nobody collides, nothing is launched
+    s0 = _strip(spec, self_pairs=True, ws=True)
+    s0.objects = []
+    s0.validate()
+    cm0 = ops.CostHandle(s0, DEV)
+    assert not bool(ops.rollout_collision(h, cm0, FIELD_SELF | FIELD_OBJECTS | FIELD_WS, q).any())
+    assert ops.last_dispatch() == "none"
+
+
+def test_strict_mode_refuses_a_real_mismatch(ops):
+    """another collision-link set than the unit bakes: table-driven by default, TRK_ERR_UNSUPPORTED (NotImplementedError) in strict mode;
+    the pre-bound plans are strict by default"""
+    g, robot = gold("cost_spheres3d"), gold("panda_robot")
+    m = model("panda_arm_no_gripper")
+    spec = panda_cost_spec(g, robot)
+    spec.obj_link_idx = np.asarray(spec.obj_link_idx)[:-1].copy()            # one collision link less than RobotPanda's template
+    spec.obj_link_margin = np.asarray(spec.obj_link_margin)[:-1].copy()
+    spec.validate()
+    h, cm = ops.ModelHandle(m), ops.CostHandle(spec, DEV)
+    q = torch.zeros(2, 64, 7, device=DEV)
+    assert h.specialized and not ops.rollout_is_specialized(h, cm, (0, 1, 0, 0))
+    _, c, _ = ops.rollout_cost_grad(h, cm, (0, 1, 0, 0), q)
+    assert ops.last_dispatch() == "table-driven"
+    with ops.strict_specialized():
+        with pytest.raises(NotImplementedError, match="strict mode"):
+            ops.rollout_cost_grad(h, cm, (0, 1, 0, 0), q)
+        with pytest.raises(NotImplementedError, match="strict mode"):
+            ops.rollout_collision(h, cm, FIELD_OBJECTS, q)
+        # terms the unit does serve are not affected: the self pairs are RobotPanda's
+        ops.rollout_cost_grad(h, cm, (1, 0, 0, 0), q)
+        assert ops.last_dispatch() == "generated"
+        # a model WITHOUT generated units is served as before (strict mode is about silent fall-backs, not about coverage)
+        h.enable_specialized(False)
+        _, c2, _ = ops.rollout_cost_grad(h, cm, (0, 1, 0, 0), q)
+        h.enable_specialized(True)
+        assert torch.equal(c, c2)
+    assert ops.set_strict_specialized(False) is False                          # the context manager restored the default
+    with pytest.raises(NotImplementedError, match="strict=True"):
+        ops.RolloutPlan(h, cm, (0, 1, 0, 0), q)
+    plan = ops.RolloutPlan(h, cm, (0, 1, 0, 0), q, strict=False)
+    assert not plan.generated
+    plan.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.cost, c)
+
+
+def test_points_rollout_plan_matches_the_eager_call(ops):
+    """F3 / F4 (robot_panda.py:154-168, the link-sphere table): the attached-point models are pre-bound like the link models"""
+    import torch_robotics_amd as tra
+    TA = dict(device=DEV, dtype=torch.float32)
+    robot = tra.RobotPanda(tensor_args=TA, grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA))
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    q = robot.random_q(3 * 64).reshape(3, 64, 7).contiguous()
+    plan = task.rollout_plan(q)
+    assert isinstance(plan, ops.PointsRolloutPlan) and plan.generated
+    for _ in range(2):
+        plan.launch()
+        pos, cost, gq = task.rollout_cost_grad(q)
+        torch.cuda.synchronize()
+        assert ops.last_dispatch() == "generated"
+        assert torch.equal(plan.cost, cost) and torch.equal(plan.gq, gq) and torch.equal(plan.link_pos, pos)
+        q.copy_(robot.random_q(3 * 64).reshape(3, 64, 7))
+    # the sharded exchange takes it like any plan
+    sums = torch.zeros(ops.n_blocks(3 * 64), **TA)
+    plan.launch(sums.data_ptr())
+    pk = ops.PackedSums(plan, sums)
+    out = torch.empty(pk.size, **TA)
+    pk.pack(out)
+    torch.cuda.synchronize()
+    assert abs(float(out[0]) - float(plan.cost.double().sum())) <= 2e-6 * abs(float(plan.cost.double().sum()))

@@ -97,10 +97,29 @@ def test_mailbox_single_rank_and_argument_checks():
         mb.exchange(x[:100], out)
     with pytest.raises(ValueError):
         mb.exchange(x.double(), out)
-    assert mb.status()[:2] == (10, 0)
+    assert mb.status()[:2] == (10, 0) and mb.healthy()
     mb.close()
+    # the look-ahead rule (include/trk.h): send k + a may precede recv k only for a <= (n_slots - 2) / 2 -- refused, not corrupted
+    for slots, ahead in ((2, 0), (3, 0), (4, 1), (6, 2)):
+        mb = MailboxAllReduce(dev, 64, n_slots=slots, rank=0, world=1)
+        y = torch.arange(64, device=dev, dtype=torch.float32)
+        with pytest.raises(ValueError, match="nothing has been sent"):
+            mb.recv(out[:64].contiguous())
+        for a in range(ahead + 1):
+            mb.send(y + a)
+        with pytest.raises(ValueError, match="ahead of their receives"):
+            mb.send(y)
+        o64 = torch.empty(64, device=dev)
+        for a in range(ahead + 1):                     # the receives come back in order
+            mb.recv(o64)
+            torch.cuda.synchronize()
+            assert torch.equal(o64, y + a)
+        mb.send(y)                                     # ... and the window is open again
+        mb.recv(o64)
+        assert mb.healthy()
+        mb.close()
     L, h = lib(), C.c_void_p()
-    for world, rank, n, slots in ((0, 0, 8, 4), (17, 0, 8, 4), (2, 2, 8, 4), (2, 0, 0, 4), (2, 0, 8, 1), (2, 0, 8, 65)):
+    for world, rank, n, slots in ((0, 0, 8, 4), (17, 0, 8, 4), (2, 2, 8, 4), (2, 0, 0, 4), (2, 0, 8, 1), (2, 0, 8, 65), (2, 0, (1 << 22) + 1, 4)):
         assert L.trk_mailbox_create(world, rank, n, slots, C.byref(h)) == _abi.TRK_ERR_INVALID_ARG
     assert L.trk_mailbox_exchange(None, None, None, None) == _abi.TRK_ERR_INVALID_ARG
     # a two-rank mailbox that was never connected refuses to exchange
@@ -185,3 +204,50 @@ def test_sharded_rollout_two_processes_one_gpu(tmp_path):
                         "--master-port", "29591", str(script)], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     assert "sharded-0-ok" in p.stdout and "sharded-1-ok" in p.stdout
+
+
+TIMEOUT_WORKER = r"""
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["TRK_ROOT"])
+from torch_robotics_amd.distributed import MailboxAllReduce
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+n = 257
+# the ranks must agree on the mailbox's shape: a mismatch is refused on EVERY rank before any peer memory is mapped
+try:
+    MailboxAllReduce(dev, n + rank, n_slots=4)
+    raise SystemExit("expected a RuntimeError: the ranks disagree on n_floats")
+except RuntimeError as e:
+    assert "disagree" in str(e)
+mb = MailboxAllReduce(dev, n, n_slots=4)
+assert mb.validate()
+dist.barrier()
+row = torch.ones(n, device=dev)
+out = torch.zeros(n, device=dev)
+if rank == 0:                       # rank 1 never sends this exchange: a dead / late peer
+    mb.send(row); mb.recv(out)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out).all()), out[:4]                 # NaN everywhere: never a plausible sum with stale rows in it
+    assert not mb.healthy() and mb.status()[1] == 1
+dist.barrier()
+mb.close()
+sys.stdout.write(f"timeout-{rank}-ok\n"); sys.stdout.flush()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_mailbox_timeout_writes_nan_and_shapes_must_agree(tmp_path):
+    """a receive that times out must not hand back a sum that includes a late peer's stale rows; the ranks' (world, n_floats,
+    n_slots) are compared before any peer memory is mapped."""
+    env = dict(os.environ, TRK_ROOT=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", TRK_MAILBOX_TIMEOUT_S="0.5")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    script = tmp_path / "mailbox_timeout_worker.py"
+    script.write_text(TIMEOUT_WORKER)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29567", str(script)], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "timeout-0-ok" in p.stdout and "timeout-1-ok" in p.stdout, p.stdout[-500:]

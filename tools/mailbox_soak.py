@@ -70,7 +70,8 @@ with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
     for j in range(G):
         mb.send(rows_in[j], cur)
         if j > 0:
-            mb.recv(outs[j - 1], cur)           # a receive one exchange behind its send, like the bench's step graphs
+            mb.recv(outs[j - 1], cur)           # a receive one exchange behind its send, like the bench's step graphs: ONE send of
+                                                # look-ahead, which needs n_slots >= 4 (include/trk.h: a <= (n_slots - 2) / 2); the library refuses more
     mb.recv(outs[G - 1], cur)
 n_rep = max(1, a.exchanges // (4 * G))
 t0 = time.perf_counter()

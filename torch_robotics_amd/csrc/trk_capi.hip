@@ -17,6 +17,15 @@
 namespace {
 thread_local std::string g_err;
 unsigned long long* g_stamps = nullptr;   // profiling hook, see trk_debug_set_stamp_buffer
+// Which kernel family served this thread's latest rollout call (trk_last_dispatch), and the strict mode in which a rollout entry
+// point refuses the table-driven kernels for a model that HAS generated units (trk_set_strict_specialized / TRK_STRICT_SPECIALIZED=1):
+// the table-driven fused rollout is 10 - 30 x slower, and a planner that silently lands on it has a configuration problem.
+thread_local int g_last_dispatch = TRK_DISPATCH_NONE;
+int g_strict = -1;                        // -1: not decided yet (the environment is read once)
+bool strict_specialized() {
+    if (g_strict < 0) { const char* e = std::getenv("TRK_STRICT_SPECIALIZED"); g_strict = (e && std::atoi(e) != 0) ? 1 : 0; }
+    return g_strict == 1;
+}
 
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 int hip_fail(hipError_t e, const char* what) {
@@ -128,7 +137,7 @@ struct ModuleUnit {
 };
 std::vector<ModuleUnit*>& module_units() { static std::vector<ModuleUnit*> v; return v; }
 
-hipError_t g_module_launch_error = hipSuccess;     // the latest failure of a code-object launch: picked up by last_launch_error()
+thread_local hipError_t g_module_launch_error = hipSuccess;     // the latest failure of a code-object launch ON THIS THREAD (like g_err): picked up by last_launch_error()
 hipError_t last_launch_error() {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = g_module_launch_error;
@@ -357,9 +366,30 @@ static bool spec_matches(const SpecEntry* e, const TrkCostModel* cm, const TrkRo
 // An object field over an EMPTY scene (no objects, no grid) contributes nothing: the table-driven kernels guard their object
 // loop with n_objects > 0, the generated objective code does not (its minimum over no object would stay +inf), so the term
 // is switched off here -- the result must not depend on which kernel family serves the call.
+// The same rule for every VACUOUS term: a self-collision weight on a cost model without self pairs, a workspace weight without a
+// workspace box, an EE weight without a tracked link.  Each contributes exactly nothing in the table-driven kernels (empty loops /
+// `has_ws` / `ee_link >= 0` guards) -- but a non-zero weight used to demand that the generated unit's baked set equal the cost
+// model's EMPTY one, which sent the call to the table-driven kernel: UR10 + Allegro 26.8 -> 743 us with w_self = 1 on a cost model
+// without self pairs (profiles/r05_ablation_c4.txt).
 static TrkRolloutWeights effective_weights(const TrkCostModel* cm, TrkRolloutWeights w) {
     if (cm->hdr.n_objects == 0 && !cm->hdr.has_grid) w.w_obj = 0.0f;
+    if (cm->hdr.n_self_pairs == 0) w.w_self = 0.0f;
+    if (!cm->hdr.has_ws) w.w_ws = 0.0f;
+    if (cm->hdr.ee_link < 0 && cm->hdr.ee2_link < 0) w.w_ee = 0.0f;
     return w;
+}
+// the boolean fields' counterpart: a field that has nothing to test is dropped from the mask (its answer is "no collision")
+static int32_t effective_fields(const TrkCostModel* cm, int32_t fields) {
+    if (cm->hdr.n_self_pairs == 0) fields &= ~TRK_FIELD_SELF;
+    if (!cm->hdr.has_ws) fields &= ~TRK_FIELD_WS;
+    if (cm->hdr.n_objects == 0 && !cm->hdr.has_grid) fields &= ~TRK_FIELD_OBJECTS;
+    return fields;
+}
+// strict mode: a model with generated units whose call no unit matches is an error, not a 10 - 30 x slower launch
+static int strict_refusal(const char* who, const TrkModel* m) {
+    if (!strict_specialized() || !m->spec_enabled || !model_spec(m)) return TRK_OK;
+    return fail(TRK_ERR_UNSUPPORTED, std::string(who) + ": strict mode (TRK_STRICT_SPECIALIZED / trk_set_strict_specialized): the model has generated "
+                                     "kernels but none bakes this cost model's link sets for the non-zero weights -- the call would take the table-driven kernel");
 }
 // point-set units: like model_spec / model_spec_for (late registration, several templates per point set)
 static const SpecEntry* points_spec(const TrkPointSet* ps) {
@@ -1339,19 +1369,35 @@ static int rollout_impl(const char* who, const TrkModel* m, const TrkCostModel* 
             a.stamps = g_stamps; a.io_f16 = io_f16; a.grad_scale = grad_scale;
             e->launch(e, a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(last_launch_error());
+            g_last_dispatch = TRK_DISPATCH_GENERATED;
             return TRK_OK;
         }
     }
+    if ((rc = strict_refusal(who, m)) != TRK_OK) return rc;
+    g_last_dispatch = TRK_DISPATCH_TABLE;
     if (trk_lds_rollout(m->hdr, m->hdr.n_links + cm->hdr.n_virtual) > kMaxLds) return fail(TRK_ERR_UNSUPPORTED, std::string(who) + ": position tiles (links + interpolated points) exceed the 160 KiB LDS");
     trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, nullptr, cm->hdr, *w, io_f16, grad_scale, q, n, link_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(last_launch_error());
     return TRK_OK;
 }
 
+int trk_last_dispatch(void) { return g_last_dispatch; }
+int trk_set_strict_specialized(int on) {
+    const int prev = strict_specialized() ? 1 : 0;
+    g_strict = on ? 1 : 0;
+    return prev;
+}
+
 int trk_rollout_is_specialized(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w) {
     if (!m || !cm || !w || !m->spec_enabled || cm->hdr.n_links_in != m->hdr.n_links) return 0;
     const TrkRolloutWeights we = effective_weights(cm, *w);
     return model_spec_for(m, cm, &we) ? 1 : 0;
+}
+
+int trk_rollout_points_is_specialized(const TrkPointSet* ps, const TrkCostModel* cm, const TrkRolloutWeights* w) {
+    if (!ps || !ps->model || !cm || !w || !ps->model->spec_enabled || cm->hdr.n_links_in != ps->dev.n_points) return 0;
+    const TrkRolloutWeights we = effective_weights(cm, *w);
+    return points_spec_for(ps, cm, &we) ? 1 : 0;
 }
 
 int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fields, const float* q, int64_t batch, int32_t horizon,
@@ -1365,6 +1411,12 @@ int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fie
     if (n > 0 && (!q || !in_collision)) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision: null q / in_collision");
     if (n == 0) return TRK_OK;
     const int use_default = std::isnan(margin_override) ? 1 : 0;
+    fields = effective_fields(cm, fields);
+    if (!fields) {                              // nothing to test: nobody collides
+        TRK_HIP(hipMemsetAsync(in_collision, 0, (size_t)n, (hipStream_t)stream));
+        g_last_dispatch = TRK_DISPATCH_NONE;
+        return TRK_OK;
+    }
     if (m->spec_enabled) {
         // the unit's baked link sets must equal the cost model's for every field that is asked for
         TrkRolloutWeights w{};
@@ -1382,9 +1434,12 @@ int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fie
             a.coll_margin = use_default ? 0.0f : margin_override;
             e->launch_coll(e, a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(last_launch_error());
+            g_last_dispatch = TRK_DISPATCH_GENERATED;
             return TRK_OK;
         }
     }
+    if ((rc = strict_refusal("trk_rollout_collision", m)) != TRK_OK) return rc;
+    g_last_dispatch = TRK_DISPATCH_TABLE;
     // no generated unit serves this model / cost model: table-driven FK into the caller's scratch, then the field kernel
     if (!link_pos_ws) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision: no generated kernel for this model and no link_pos_ws scratch given");
     rc = trk_fk_positions(m, q, n, nullptr, 0, link_pos_ws, stream);
@@ -1410,6 +1465,12 @@ int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t
     if (n == 0) return TRK_OK;
     if (!m->spec_enabled) return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_collision_via: generated kernels are disabled for this model");
     const int use_default = std::isnan(margin_override) ? 1 : 0;
+    fields = effective_fields(cm, fields);
+    if (!fields) {
+        TRK_HIP(hipMemsetAsync(in_collision, 0, (size_t)n, (hipStream_t)stream));
+        g_last_dispatch = TRK_DISPATCH_NONE;
+        return TRK_OK;
+    }
     TrkRolloutWeights w{};
     w.w_self = (fields & TRK_FIELD_SELF) ? 1.0f : 0.0f;
     w.w_obj = (fields & (TRK_FIELD_OBJECTS | TRK_FIELD_WS)) ? 1.0f : 0.0f;
@@ -1428,6 +1489,7 @@ int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t
     a.via_alpha = alpha; a.via_beta = beta; a.via_n = n_interp; a.via_H = horizon; a.via_S = state_dim;
     e->launch_coll(e, a, base_is_identity(m), (hipStream_t)stream);
     TRK_HIP(last_launch_error());
+    g_last_dispatch = TRK_DISPATCH_GENERATED;
     return TRK_OK;
 }
 
@@ -1496,6 +1558,7 @@ int trk_rollout_gp_cost_grad(const TrkModel* m, const TrkCostModel* cm, const Tr
             a.gp_a = 12.0f * s2 / (gp->dt * gp->dt * gp->dt); a.gp_b = -6.0f * s2 / (gp->dt * gp->dt); a.gp_c = 4.0f * s2 / gp->dt;
             if (e->launch_gp(e, a, base_is_identity(m), (hipStream_t)stream) == 0) {
                 TRK_HIP(last_launch_error());
+                g_last_dispatch = TRK_DISPATCH_GENERATED;
                 return TRK_OK;
             }
         }
@@ -1503,6 +1566,7 @@ int trk_rollout_gp_cost_grad(const TrkModel* m, const TrkCostModel* cm, const Tr
     // the two-launch form: the rollout, then the prior accumulated into its gradient, its factor costs into the per-sample costs
     rc = rollout_impl(who, m, cm, w, io_mode, grad_scale, q, batch, horizon, link_pos_out, cost, gq, nullptr, stream);
     if (rc) return rc;
+    if (g_last_dispatch == TRK_DISPATCH_GENERATED) g_last_dispatch = TRK_DISPATCH_GENERATED_PLUS_PRIOR;     // generated rollout, the prior as launches of its own
     rc = ensure_init();
     if (rc) return rc;
     if (batch > 0x7fffffff) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": batch too large");
@@ -1546,9 +1610,14 @@ int trk_rollout_points_cost_grad(const TrkModel* m, const TrkPointSet* ps, const
             a.stamps = nullptr; a.io_f16 = 0;
             e->launch(e, a, base_is_identity(m), (hipStream_t)stream);
             TRK_HIP(last_launch_error());
+            g_last_dispatch = TRK_DISPATCH_GENERATED;
             return TRK_OK;
         }
     }
+    if (strict_specialized() && m->spec_enabled && points_spec(ps))
+        return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_points_cost_grad: strict mode: the point set has generated kernels but none bakes this cost model's columns "
+                                         "for the non-zero weights (or point_pos_out is not 16-byte aligned) -- the call would take the table-driven kernel");
+    g_last_dispatch = TRK_DISPATCH_TABLE;
     trk_launch_rollout_generic(m->hdr, m->d_links, m->d_fin, &ps->dev, cm->hdr, *w, 0, 1.0f, q, n, point_pos_out, cost, gq, cost_sum, (hipStream_t)stream);
     TRK_HIP(last_launch_error());
     return TRK_OK;

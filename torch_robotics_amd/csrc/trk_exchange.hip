@@ -15,6 +15,14 @@
 // the owner's loads without a kernel boundary; all mailbox accesses are system-scope atomics (sc0 sc1 loads / stores) on top of that.
 // Slot reuse: a rank alternates send k, receive k in stream order.  When it sends k it has finished receive k - 1, which needed every
 // peer's send k - 1, which followed that peer's receive k - 2: with >= 2 slots nobody overwrites a row that has not been read.
+// LOOK-AHEAD RULE (enforced on the host, trk_mailbox_send): with `o` sends not yet received on this rank, the next send m has seen
+// receive m - 1 - o, hence every peer's send m - 1 - o, which that peer issued after ITS receive m - 2 - 2 o; the send overwrites the
+// row of sequence m - n_slots in every mailbox, which every peer must have read: m - n_slots <= m - 2 - 2 o, i.e.
+// o <= (n_slots - 2) / 2.  Two slots: strict alternation; four slots: one send of look-ahead (send k + 1 before receive k -- the
+// bench's step graphs and tools/mailbox_soak.py); six: two.  A violating send is refused with TRK_ERR_INVALID_ARG instead of
+// overwriting a row a peer has not read.
+// TIME-OUT: a receive whose flags do not arrive within TRK_MAILBOX_TIMEOUT_S writes NaN to EVERY element of its output (never a
+// plausible partial sum with a late peer's stale rows) and counts the event in counter[1], which is sticky (trk_mailbox_status).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +33,7 @@
 
 #define TRK_MAILBOX_MAX_RANKS 16
 #define TRK_MAILBOX_FLAG_STRIDE 16            // uint32 words between two flags: one 64-byte line per (slot, writer)
+#define TRK_MAILBOX_MAX_FLOATS (1 << 22)      // 16 MiB per row: far beyond any packed exchange (7.7 kB for config 5), keeps every offset sane
 
 struct TrkMailbox {
     int world = 0, rank = 0, n_floats = 0, n_slots = 0, stride = 0;
@@ -36,13 +45,14 @@ struct TrkMailbox {
     unsigned* counter = nullptr;              // [0] rows sent, [1] time-outs seen, [2] sums received
     bool connected = false;
     double timeout_s = 5.0;
+    long long host_sends = 0, host_recvs = 0; // launches issued from the host (a captured launch counts once: a graph must be balanced)
 };
 
 namespace {
 struct MailboxArgs {
     unsigned* base[TRK_MAILBOX_MAX_RANKS];    // every rank's mailbox as mapped HERE (base[rank] = the local one)
     int world, rank, n, stride, n_slots;
-    unsigned flag_off;
+    size_t flag_off;                           // in 4-byte words (n_slots x world x stride: may exceed 32 bits for long rows)
     unsigned* counter;
     const float* packed;
     float* out;
@@ -94,7 +104,11 @@ k_mailbox_recv(MailboxArgs a) {
     }
     __syncthreads();
     __threadfence_system();
-    if (s_timed_out && tid == 0) a.counter[1] += 1u;
+    if (s_timed_out) {                         // a dead or slow peer: NaN everywhere -- never a plausible sum with stale rows in it
+        if (tid == 0) a.counter[1] += 1u;
+        for (int i = tid; i < a.n; i += 256) a.out[i] = __uint_as_float(0x7fc00000u);
+        return;
+    }
     // sum in rank order: the same association on every rank
     const unsigned* mine = a.base[a.rank] + (size_t)slot * a.world * a.stride;
     for (int i = tid; i < a.n; i += 256) {
@@ -131,8 +145,9 @@ int alloc_mailbox(TrkMailbox* mb) {
 extern "C" {
 
 int trk_mailbox_create(int32_t world, int32_t rank, int32_t n_floats, int32_t n_slots, TrkMailbox** out) {
-    if (!out || world < 1 || world > TRK_MAILBOX_MAX_RANKS || rank < 0 || rank >= world || n_floats < 1 || n_slots < 2 || n_slots > 64)
-        return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_create: bad argument (1 <= world <= 16, 0 <= rank < world, n_floats >= 1, 2 <= n_slots <= 64)");
+    if (!out || world < 1 || world > TRK_MAILBOX_MAX_RANKS || rank < 0 || rank >= world || n_floats < 1 || n_floats > TRK_MAILBOX_MAX_FLOATS ||
+        n_slots < 2 || n_slots > 64)
+        return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_create: bad argument (1 <= world <= 16, 0 <= rank < world, 1 <= n_floats <= 2^22, 2 <= n_slots <= 64)");
     int rc = trk_ensure_init();
     if (rc) return rc;
     TrkMailbox* mb = new (std::nothrow) TrkMailbox();
@@ -188,7 +203,7 @@ MailboxArgs mailbox_args(const TrkMailbox* mb, const float* packed, float* out) 
     MailboxArgs a;
     for (int p = 0; p < TRK_MAILBOX_MAX_RANKS; ++p) a.base[p] = static_cast<unsigned*>(p < mb->world ? mb->peers[p] : nullptr);
     a.world = mb->world; a.rank = mb->rank; a.n = mb->n_floats; a.stride = mb->stride; a.n_slots = mb->n_slots;
-    a.flag_off = (unsigned)mb->flag_off; a.counter = mb->counter; a.packed = packed; a.out = out;
+    a.flag_off = mb->flag_off; a.counter = mb->counter; a.packed = packed; a.out = out;
     a.timeout_ticks = (unsigned long long)(mb->timeout_s * 1e8);
     return a;
 }
@@ -197,6 +212,10 @@ MailboxArgs mailbox_args(const TrkMailbox* mb, const float* packed, float* out) 
 int trk_mailbox_send(TrkMailbox* mb, const float* packed, trk_stream_t stream) {
     if (!mb || !packed) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_send: null argument");
     if (!mb->connected) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_send: trk_mailbox_connect has not been called");
+    if (2 * (mb->host_sends - mb->host_recvs) > mb->n_slots - 2)
+        return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_send: too many sends ahead of their receives for this mailbox's slots (send k + a may precede "
+                                             "receive k only for a <= (n_slots - 2) / 2): the send could overwrite a row a peer has not read");
+    mb->host_sends += 1;
     hipLaunchKernelGGL(k_mailbox_send, dim3(1), dim3(256), 0, (hipStream_t)stream, mailbox_args(mb, packed, nullptr));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return trk_hip_fail((int)e, "trk_mailbox_send: launch");
@@ -206,6 +225,8 @@ int trk_mailbox_send(TrkMailbox* mb, const float* packed, trk_stream_t stream) {
 int trk_mailbox_recv(TrkMailbox* mb, float* out, trk_stream_t stream) {
     if (!mb || !out) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_recv: null argument");
     if (!mb->connected) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_recv: trk_mailbox_connect has not been called");
+    if (mb->host_recvs >= mb->host_sends) return trk_fail(TRK_ERR_INVALID_ARG, "trk_mailbox_recv: nothing has been sent that is not received yet");
+    mb->host_recvs += 1;
     hipLaunchKernelGGL(k_mailbox_recv, dim3(1), dim3(256), 0, (hipStream_t)stream, mailbox_args(mb, nullptr, out));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return trk_hip_fail((int)e, "trk_mailbox_recv: launch");

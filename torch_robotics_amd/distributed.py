@@ -172,12 +172,19 @@ class MailboxAllReduce:
                 if not have_group:
                     raise RuntimeError("MailboxAllReduce: more than one rank needs an initialised torch.distributed group to share the handles")
                 box = [None] * self.world
-                dist.all_gather_object(box, (err, bytes(handle.raw)), group=group)
-                errs = [e for e, _ in box if e is not None]
+                shape = (self.world, self.n_floats, int(n_slots))
+                dist.all_gather_object(box, (err, bytes(handle.raw), shape), group=group)
+                errs = [e for e, _, _ in box if e is not None]
                 if errs:
                     self.close()
                     raise RuntimeError(f"MailboxAllReduce: a rank could not create its mailbox: {errs[0]}")
-                blob = b"".join(h for _, h in box)
+                # the row and flag offsets inside a PEER's mailbox follow from (world, n_floats, n_slots): ranks that disagree would
+                # store past each other's rows -- silent corruption of another process's device memory.  Every rank sees the same
+                # list, so every rank raises.
+                if any(sh != shape for _, _, sh in box):
+                    self.close()
+                    raise RuntimeError(f"MailboxAllReduce: the ranks disagree on (world, n_floats, n_slots): {[sh for _, _, sh in box]}")
+                blob = b"".join(h for _, h, _ in box)
                 rc = self._lib.trk_mailbox_connect(self._h, blob)
                 err = None if rc == 0 else self._lib.trk_last_error().decode("utf-8", "replace")
                 box2 = [None] * self.world
@@ -196,26 +203,35 @@ class MailboxAllReduce:
         for name, t in (("packed", packed), ("out", out)):
             if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != self.n_floats:
                 raise ValueError(f"MailboxAllReduce.exchange({name}): expected a contiguous float32 tensor of {self.n_floats} elements on {self.device}")
-        if stream is None:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self._lib.trk_mailbox_exchange(self._h, packed.data_ptr(), out.data_ptr(), stream), "trk_mailbox_exchange")
+        with torch.cuda.device(self.device):             # the launch goes to the CURRENT device: make it the mailbox's
+            if stream is None:
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._check(self._lib.trk_mailbox_exchange(self._h, packed.data_ptr(), out.data_ptr(), stream), "trk_mailbox_exchange")
 
     def send(self, packed: torch.Tensor, stream: Optional[int] = None) -> None:
         """The first half of `exchange`: this rank's row into every mailbox + the flag.  Never waits."""
         if packed.device != self.device or packed.dtype != torch.float32 or not packed.is_contiguous() or packed.numel() != self.n_floats:
             raise ValueError(f"MailboxAllReduce.send(packed): expected a contiguous float32 tensor of {self.n_floats} elements on {self.device}")
-        if stream is None:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self._lib.trk_mailbox_send(self._h, packed.data_ptr(), stream), "trk_mailbox_send")
+        with torch.cuda.device(self.device):
+            if stream is None:
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._check(self._lib.trk_mailbox_send(self._h, packed.data_ptr(), stream), "trk_mailbox_send")
 
     def recv(self, out: torch.Tensor, stream: Optional[int] = None) -> None:
         """The second half: waits for the rows of the oldest send not yet received and writes their sum (rank order) to out.  Must
-        follow its send in stream order (the same stream, or a stream that waits for it); send k + 1 must follow recv k."""
+        follow its send in stream order (the same stream, or a stream that waits for it); send k + a may precede recv k only for
+        a <= (n_slots - 2) / 2 (the library refuses a send beyond that).  A wait that times out writes NaN to all of `out` and counts in
+        `status()[1]` (sticky) -- `healthy()` is the cheap check."""
         if out.device != self.device or out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != self.n_floats:
             raise ValueError(f"MailboxAllReduce.recv(out): expected a contiguous float32 tensor of {self.n_floats} elements on {self.device}")
-        if stream is None:
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self._lib.trk_mailbox_recv(self._h, out.data_ptr(), stream), "trk_mailbox_recv")
+        with torch.cuda.device(self.device):
+            if stream is None:
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._check(self._lib.trk_mailbox_recv(self._h, out.data_ptr(), stream), "trk_mailbox_recv")
+
+    def healthy(self) -> bool:
+        """No receive of this mailbox has timed out so far (synchronises with the device)."""
+        return self.status()[1] == 0
 
     def status(self):
         """(exchanges issued, time-outs seen, allocation kind); synchronises with the device."""
@@ -305,6 +321,15 @@ class ShardedRollout:
             if self.mailbox is None and exchange == "p2p":
                 raise RuntimeError(f"ShardedRollout(exchange='p2p'): the mailbox is not usable: {self.mailbox_note}")
         self._sent = False
+        self.check_every = int(os.environ.get("TRK_MAILBOX_CHECK_EVERY", "256"))      # receives between two health checks (0: only in close())
+        self._recvs = 0
+
+    def _check_mailbox(self) -> None:
+        """A timed-out receive wrote NaN sums: raise instead of letting a planner iterate on them.  Synchronises with the device."""
+        if self.mailbox is not None and not self.mailbox.healthy():
+            n, t, kind = self.mailbox.status()
+            raise RuntimeError(f"ShardedRollout: {t} mailbox receive(s) of {n} exchanges timed out on rank {self.rank} (a peer is dead or more than "
+                               f"TRK_MAILBOX_TIMEOUT_S late); the sums of those receives are NaN.  Rebuild with exchange='allreduce' or restart the job.")
 
     def launch(self, stream: Optional[int] = None) -> None:
         self.plan.launch(self.block_sums.data_ptr(), stream)
@@ -325,6 +350,9 @@ class ShardedRollout:
         self._sent = False
         if self.mailbox is not None:
             self.mailbox.recv(self.total, stream)
+            self._recvs += 1
+            if self.check_every > 0 and self._recvs % self.check_every == 0:
+                self._check_mailbox()
             return self.total
         cur = torch.cuda.current_stream(self.device)
         if stream is not None and stream != cur.cuda_stream:
@@ -339,6 +367,10 @@ class ShardedRollout:
         return self.recv(stream)
 
     def close(self) -> None:
+        """Releases the mailbox; raises if any of its receives had timed out (their sums were NaN)."""
         if self.mailbox is not None:
-            self.mailbox.close()
-            self.mailbox = None
+            try:
+                self._check_mailbox()
+            finally:
+                self.mailbox.close()
+                self.mailbox = None

@@ -894,6 +894,51 @@ def rollout_is_specialized(model: ModelHandle, cm: CostHandle, weights) -> bool:
     return bool(lib().trk_rollout_is_specialized(model._h, cm._h, C.byref(_weights_struct(weights))))
 
 
+DISPATCH_NAMES = {0: "none", 1: "generated", 2: "table-driven", 3: "generated + prior launches"}
+
+
+def rollout_points_is_specialized(ps: "PointSetHandle", cm: CostHandle, weights) -> bool:
+    """The same question for `rollout_points_cost_grad(ps, cm, weights, ...)`."""
+    return bool(lib().trk_rollout_points_is_specialized(ps._h, cm._h, C.byref(_weights_struct(weights))))
+
+
+def _require_generated(who: str, model: ModelHandle, served: bool) -> None:
+    """strict=True of the pre-bound plans: a model that has generated kernels must not be bound to the table-driven one silently."""
+    if model.specialized and not served:
+        raise NotImplementedError(
+            f"{who}(strict=True): the model has generated kernels, but none bakes this cost model's link sets for the non-zero weights -- "
+            "every launch of this plan would take the table-driven kernel (10 - 30 x slower).  Match the robot's collision template, "
+            "compile a unit for this one (jit.specialize / PlanningTask.specialize), or pass strict=False.")
+
+
+def last_dispatch() -> str:
+    """Which kernel family served this thread's latest rollout call (`trk_last_dispatch`): 'generated', 'table-driven',
+    'generated + prior launches' (the two-launch form of the GP-fused rollout) or 'none'."""
+    return DISPATCH_NAMES[int(lib().trk_last_dispatch())]
+
+
+def set_strict_specialized(on: bool) -> bool:
+    """Strict mode (`trk_set_strict_specialized`; TRK_STRICT_SPECIALIZED=1 sets it from the environment): a rollout call on a model
+    that HAS generated kernels raises NotImplementedError instead of silently taking the 10 - 30 x slower table-driven kernel when
+    no unit bakes the cost model's link sets.  Returns the previous setting."""
+    return bool(lib().trk_set_strict_specialized(1 if on else 0))
+
+
+class strict_specialized:
+    """`with ops.strict_specialized():` -- strict mode for a block (bench.py and RolloutPlan bind their launches under it)."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = set_strict_specialized(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        set_strict_specialized(self.prev)
+        return False
+
+
 def rollout_collision(model: ModelHandle, cm: CostHandle, fields: int, q: torch.Tensor, margin: Optional[float] = None) -> torch.Tensor:
     """Fused FK + boolean collision fields: q (B,H,D) or (N,D) -> bool (B,H) / (N,).  One launch, one byte per sample out
     (`PlanningTask.compute_collision`, tasks.py:131-133); `margin=None` uses the fields' own margins."""
@@ -995,7 +1040,10 @@ class RolloutGpPlan:
     in grad_dtype (fp16 by default for fp16 trajectories, saturating), `link_pos` (B,H,L,3) the positions (want_pos)."""
 
     def __init__(self, model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, qd: torch.Tensor, dt: float, sigma: float,
-                 gp_weight: float = 1.0, want_pos: bool = True, grad_dtype=None, grad_scale: float = 1.0):
+                 gp_weight: float = 1.0, want_pos: bool = True, grad_dtype=None, grad_scale: float = 1.0, strict: bool = True):
+        self.generated = rollout_is_specialized(model, cm, weights)
+        if strict:
+            _require_generated("RolloutGpPlan", model, self.generated)
         B, H, D = _gp_args(model, q, qd, "RolloutGpPlan")
         f16 = q.dtype == torch.float16
         gio, gcode, gs = _grad_mode(f16, grad_dtype, grad_scale, "RolloutGpPlan")
@@ -1583,9 +1631,14 @@ class RolloutPlan:
     (a planner's inner loop re-evaluates the same buffers thousands of times)."""
 
     def __init__(self, model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True, grad_dtype=None,
-                 grad_scale: float = 1.0, gq_out: Optional[torch.Tensor] = None):
+                 grad_scale: float = 1.0, gq_out: Optional[torch.Tensor] = None, strict: bool = True):
         """gq_out: a caller-owned (B, H, D) buffer the gradient is written to (e.g. the storage of `q.grad`: the kernel then IS the
-        backward of `sum(cost)`); default: a buffer of the plan's own."""
+        backward of `sum(cost)`); default: a buffer of the plan's own.
+        strict: raise (NotImplementedError) when the model has generated kernels but this cost model / weights would be served by the
+        table-driven one; `self.generated` says which family the plan's launches take."""
+        self.generated = rollout_is_specialized(model, cm, weights)
+        if strict:
+            _require_generated("RolloutPlan", model, self.generated)
         f16 = q.dtype == torch.float16
         gio, gcode, gs = _grad_mode(f16, grad_dtype, grad_scale, "RolloutPlan")
         if not f16 and gs != 1.0:
@@ -1619,3 +1672,44 @@ class RolloutPlan:
             rc = self._fn(*self._args, cost_sum_ptr, stream)
         if rc:
             check(rc, "trk_rollout_cost_grad")
+
+
+class PointsRolloutPlan:
+    """RolloutPlan for the attached-point models (link spheres, grasped-object points; `trk_rollout_points_cost_grad`): the collision
+    fields' columns are the points of `ps`, `link_pos` (B, H, P, 3) their world positions.  Same interface as RolloutPlan (launch(),
+    link_pos / cost / gq), so step graphs, `ShardedRollout` and `PackedSums` take it unchanged."""
+
+    def __init__(self, ps: PointSetHandle, cm: CostHandle, weights, q: torch.Tensor, want_pos: bool = True,
+                 gq_out: Optional[torch.Tensor] = None, strict: bool = True):
+        model = ps.model
+        self.generated = rollout_points_is_specialized(ps, cm, weights)
+        if strict and ps.specialized and not self.generated:
+            _require_generated("PointsRolloutPlan", model, False)
+        q = _dev_f32(q, "PointsRolloutPlan(q)")
+        if q.dim() != 3:
+            raise ValueError("PointsRolloutPlan: q must be (batch, horizon, dof)")
+        _check_q_dofs(q, model.n_dofs, "PointsRolloutPlan(q)")
+        self.model, self.ps, self.cm, self.q = model, ps, cm, q
+        self.B, self.H = int(q.shape[0]), int(q.shape[1])
+        n, P, D = self.B * self.H, ps.n_points, model.n_dofs
+        self.link_pos = torch.empty((self.B, self.H, P, 3), device=q.device, dtype=torch.float32) if want_pos else None
+        self.cost = torch.empty((self.B, self.H), device=q.device, dtype=torch.float32)
+        if gq_out is not None:
+            _check_buffer(gq_out, n * D, torch.float32, q.device, "PointsRolloutPlan(gq_out)")
+            self.gq = gq_out.view(self.B, self.H, D)
+        else:
+            self.gq = torch.empty((self.B, self.H, D), device=q.device, dtype=torch.float32)
+        self.grad_scale = 1.0
+        self._w = _abi.RolloutWeights(*[float(v) for v in weights])
+        self._fn = lib().trk_rollout_points_cost_grad
+        self._args = (model._h, ps._h, cm._h, C.byref(self._w), q.data_ptr(), self.B, self.H, _ptr(self.link_pos),
+                      self.cost.data_ptr(), self.gq.data_ptr())
+        self.device = q.device
+
+    def launch(self, cost_sum_ptr: Optional[int] = None, stream: Optional[int] = None) -> None:
+        with _on(self.device):
+            if stream is None:
+                stream = _stream_of(self.device)
+            rc = self._fn(*self._args, cost_sum_ptr, stream)
+        if rc:
+            check(rc, "trk_rollout_points_cost_grad")

@@ -215,10 +215,12 @@ class PlanningTask(Task):
         """Pre-bound fused evaluation for a planner's inner loop: buffers and arguments are resolved once, `plan.launch()`
         is one C call (~3 us of host time instead of ~18 us through `rollout_cost_grad`); results land in
         `plan.link_pos / plan.cost / plan.gq`.  q (B,H,D) is read in place on every launch (update it between launches)."""
-        if self._points(q.device) is not None:
-            raise NotImplementedError("rollout_plan is for link-column cost models (no grasped object / link spheres)")
         model, cm = self._fused_handles(q.device)
-        return ops.RolloutPlan(model, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos)
+        strict = os.environ.get("TRK_ALLOW_TABLE_DRIVEN", "0") != "1"
+        ps = self._points(q.device)
+        if ps is not None:          # grasped object / link spheres: the columns are attached points (round 6: pre-bound like the link models)
+            return ops.PointsRolloutPlan(ps, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos, strict=strict)
+        return ops.RolloutPlan(model, cm, (w_self, w_obj, w_ws, w_ee), q, want_pos=want_pos, strict=strict)
 
     def rollout_gp_plan(self, q, qd, dt, sigma_gp, gp_weight=1.0, w_self=1.0, w_obj=1.0, w_ws=1.0, w_ee=0.0, want_pos=False,
                         grad_dtype=None, grad_scale=1.0) -> "ops.RolloutGpPlan":
@@ -229,7 +231,7 @@ class PlanningTask(Task):
             raise NotImplementedError("rollout_gp_plan is for link-column cost models (no grasped object / link spheres)")
         model, cm = self._fused_handles(q.device)
         return ops.RolloutGpPlan(model, cm, (w_self, w_obj, w_ws, w_ee), q, qd, dt, sigma_gp, gp_weight, want_pos=want_pos,
-                                 grad_dtype=grad_dtype, grad_scale=grad_scale)
+                                 grad_dtype=grad_dtype, grad_scale=grad_scale, strict=os.environ.get("TRK_ALLOW_TABLE_DRIVEN", "0") != "1")
 
     def capture_cost_backward(self, x, reduce=torch.sum, warmup: int = 3) -> "GraphedCostBackward":
         """`reduce(task.compute_collision_cost(x)).backward()` captured ONCE as a hipGraph (a planner's inner loop calls it with
@@ -364,7 +366,7 @@ class GraphedCostBackward:
             q3 = x.detach() if x.dim() == 3 else x.detach().unsqueeze(1)
             w = (1.0 if task.df_collision_self is not None else 0.0, 1.0, 1.0, 0.0)      # compute_collision_cost's weights
             x.grad = torch.empty_like(x)
-            self.plan = ops.RolloutPlan(model, cm, w, q3, want_pos=False, gq_out=x.grad)
+            self.plan = ops.RolloutPlan(model, cm, w, q3, want_pos=False, gq_out=x.grad, strict=False)    # the eager idiom's own dispatch rules apply
             assert self.plan.q.data_ptr() == x.data_ptr()        # the plan reads x's storage in place
             self.block_sums = torch.zeros(ops.n_blocks(q3.shape[0] * q3.shape[1]), device=x.device, dtype=torch.float32)
             self._bs_ptr = self.block_sums.data_ptr()
