@@ -915,6 +915,15 @@ def main():
                                 "sum_cost_all_ranks": float(check_out[0].item()), "sum_cost_rank0": float(gathered[0][0].item())},
         }
         mg = out["multi_gpu"]
+        # north_star: "HBM GB/s vs peak at 1/2/4/8 GPUs" -- every rank's own figure: the step's algorithmic bytes x the timed steps over
+        # THAT rank's launch-stream time (HIP events around its timed region, exchange included)
+        if per_rank_value:
+            step_bytes = wl.bps_step * B * H
+            mg["per_rank"] = [{"rank": r, "wall_us": per_rank_value["wall_us"][r], "launch_stream_us": t_us,
+                               "achieved_GBps": round(step_bytes * args.steps / (t_us * 1e-6) / 1e9, 1),
+                               "frac": round(step_bytes * args.steps / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                              for r, t_us in enumerate(per_rank_value["launch_stream_us"])]
+            mg["per_rank_bytes_per_step"] = step_bytes
         # what the exchange leaves of ideal weak scaling: N x (a step without any exchange) / (a step of the timed region with its exchange)
         mg["scaling_bound"] = world * mg["kernel_only"]["ms_per_step"] / mg["with_allreduce"]["ms_per_step"]
         mg["exchange_overhead_us_per_step"] = 1e3 * (mg["with_allreduce"]["ms_per_step"] - mg["kernel_only"]["ms_per_step"])
@@ -948,7 +957,7 @@ def main():
                                       "note": f"secondary: unrelated batches round-robin over {ns} streams (launches overlap); "
                                               "the headline value above is one stream, launch after launch"}
 
-    if rank == 0 and not distributed and args.cpu_seconds > 0:       # CPU baseline: rank 0 at N = 1 only
+    if rank == 0 and not distributed and args.cpu_seconds > 0:       # CPU baseline at N = 1: here; at N > 1: below, once the ranks are done
         out["cpu_baseline"] = cpu_baseline(wl, args, torch, args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
@@ -963,6 +972,13 @@ def main():
             native.close()
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0 and args.cpu_seconds > 0:
+            # N > 1: rank 0's host threads are free only now -- the other ranks have left their last barrier and are exiting (they do
+            # no CPU arithmetic).  A shorter sample than at N = 1: the line must not wait long for a baseline that N = 1 already carries.
+            from oracle import oracle as orc_
+            orc_.set_threads(len(os.sched_getaffinity(0)))         # the launcher pinned OMP_NUM_THREADS for the ranks; the baseline uses the host
+            out["cpu_baseline"] = cpu_baseline(wl, args, torch, min(args.cpu_seconds, 6.0))
+            out["cpu_baseline"]["note"] = f"rank 0 of {world}, after the process group was destroyed; sample bounded to {min(args.cpu_seconds, 6.0):g} s per leg"
     # The JSON line is the LAST thing on stdout: librccl announces itself with a printf ("Librccl path : ...") that sits in the
     # C stdio buffer until it is flushed -- without this it would land behind the line at process exit.
     try:

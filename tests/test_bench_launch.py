@@ -210,6 +210,31 @@ def test_two_rank_mailbox_exchange_on_one_gpu(cfg, extra):
     assert mg["collectives_in_timed_region"] in (2, 3) and mg["every_step"]["collectives_in_timed_region"] == 20
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,ranks,extra", [("c2", 8, ["--batch", "256"]), ("c5", 4, ["--batch", "128"])])
+def test_many_rank_dress_rehearsal_on_one_gpu(cfg, ranks, extra):
+    """The 8-GPU run (and config 5's 4-GPU split) rehearsed on ONE GPU: N processes share cuda:0, the packed sums travel through the
+    world-N mailbox (hipIpc handles, the N-rank argument struct, slot reuse), captured into the step graphs; the line carries what a
+    SCALE line must carry -- `roofline`, `cpu_baseline` (rank 0, after the process group is gone), per-rank bandwidth fractions."""
+    p = _run(["--config", cfg, "--gpus", str(ranks), "--single-device", "--dist-backend", "gloo", "--exchange", "p2p", "--graph", "20",
+              "--steps", "20", "--warmup", "5", "--cpu-seconds", "1.5"] + extra, 1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    mg = out["multi_gpu"]
+    assert out["n_gpus"] == ranks and mg["ranks"] == ranks and out["scaling"] == "weak"
+    assert mg["exchange_via"].startswith("peer-to-peer mailbox") and "captured" in mg["exchange_via"]
+    assert mg["mailbox"]["timeouts"] == 0 and mg["mailbox"]["sums_bit_identical_to_rank_order"] and mg["allreduce_check"]["ok"]
+    assert mg["collectives_in_timed_region"] == 1 and mg["every_step"]["collectives_in_timed_region"] == 20
+    pr = mg["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(ranks))
+    for r in pr:
+        assert r["launch_stream_us"] > 0 and r["achieved_GBps"] > 0 and 0 < r["frac"] < 1
+        assert r["achieved_GBps"] == pytest.approx(mg["per_rank_bytes_per_step"] * 20 / (r["launch_stream_us"] * 1e-6) / 1e9, rel=1e-3)
+    assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["bytes_per_sample"] == (192 if cfg == "c2" else 254)
+    cb = out["cpu_baseline"]
+    assert cb is not None and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "rank 0" in cb["note"]
+
+
 def test_exchange_schedule_is_exact():
     """bench.exchange_schedule (pure): whatever the step count, cadence, graph size and mode, a run issues exactly `count` steps and
     exactly one exchange per `cadence` steps (the ones of exchange_pieces), graphs hold at most `graph_steps` steps and `n_slots`

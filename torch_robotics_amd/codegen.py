@@ -247,14 +247,18 @@ def _emit_angles(E: "Emitter", kin: KinModel, links=None, declare_passbits: bool
         E.raw(f"    trk_sincos(qh{d}, &sn{d}, &cs{d});")
 
 
-def _emit_fk_link(E: "Emitter", kin: KinModel, i: int, R, t, passv, snap: float, stateful: bool = False) -> None:
+def _emit_fk_link(E: "Emitter", kin: KinModel, i: int, R, t, passv, snap: float, stateful: bool = False, fixed_override=None) -> None:
     """world pose of link i from its parent's (rigid_body.py:162-182), URDF constants folded symbolically.
     stateful: the stateful path's joint transform (rigid_body.py:213-251): rotation about `sf_rot_axis` with the axis SIGN
-    IGNORED, whatever the stateless rule says (a missing axis still rotates about z)."""
+    IGNORED, whatever the stateless rule says (a missing axis still rotates about z).
+    fixed_override: {link: (Rf 3x3 of S, tl 3 of S)} -- the link's fixed transform given symbolically (arm-per-lane kernels: the entries
+    that differ between the two arms are per-lane registers)."""
     par = int(kin.parent[i]); jt = int(kin.joint_type[i]); d = int(kin.dof_idx[i])
     E.raw(f"    // link {i} '{kin.link_names[i]}' (parent {par})")
     Rf = [[S(snap_const(kin.R_fixed[i][r][c], snap)) for c in range(3)] for r in range(3)]
     tl = [S(snap_const(kin.trans[i][k], 0.0)) for k in range(3)]
+    if fixed_override is not None and i in fixed_override:
+        Rf, tl = fixed_override[i]
     qh = None
     if jt != JOINT_FIXED:
         passv[i] = S(1.0, f"pass{d}") if kin.clamp[i] else ONE
@@ -352,6 +356,252 @@ def _emit_reverse_links(E: "Emitter", kin: KinModel, R, t, tb_names: Dict[int, L
         F[par] = [E.add(F[par][k], F[i][k]) for k in range(3)]
         T[par] = [E.add(T[par][k], T[i][k]) for k in range(3)]
     return gq_expr
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Arm-per-lane schedule of the GP-fused rollout (round 6; BASELINE config 5, the dual Panda): a robot that is two ISOMORPHIC arms on one
+# base is evaluated with lanes 2s / 2s + 1 of a wavefront holding the two arms of sample s -- each lane walks ONE arm (a Panda-sized
+# problem: ~120 registers, four wavefronts per SIMD like the headline kernel) instead of one lane walking both (217 registers, two).
+# The memory side needs no new layout: q / qd / gq / gqd (N, D) are read and written through their (2N, D/2) view, a half row per lane;
+# the prior's neighbours in time are the half rows two lanes away in the same raw tile; the positions of a sample -- world link, arm 0,
+# arm 1 -- are staged by its two lanes into one row of the wavefront's output image.  What differs between the arms (the mount of the
+# arm's root link, the collision margins, the EE target) is a per-lane select of two scalars.
+# ----------------------------------------------------------------------------------------------------------------------
+@dataclass
+class ArmLanePlan:
+    n: int                      # links per arm (arm 0 = links 1 .. n, arm 1 = links n + 1 .. 2n; link 0 is the common base)
+    DA: int                     # joints per arm (arm 0 = DOFs 0 .. DA - 1)
+    arm: object                 # the one-arm model: link 0 + arm 0 (what the generator's FK / reverse emitters walk)
+    obj: List[int]              # arm 0's collision links (the template's first half; arm 1's are these + n)
+    ee: int                     # the tracked link of arm 0 (arm 1 tracks ee + n), -1 = none
+    differ: List[Tuple[str, int, int, float, float]]    # entries of the arm root's fixed transform that differ: (R|t, r, c, arm 0, arm 1)
+
+
+def arm_lane_plan(kin: KinModel, tmpl: CollisionTemplate) -> Optional[ArmLanePlan]:
+    """The plan when `kin` is two isomorphic subtrees hanging off link 0 and the template treats them alike, else None."""
+    from types import SimpleNamespace
+    L, D = kin.n_links, kin.n_dofs
+    if L < 3 or (L - 1) % 2 or D % 2 or D == 0 or tmpl.virtual:
+        return None
+    n, DA = (L - 1) // 2, D // 2
+    par = [int(v) for v in kin.parent]
+    if [int(v) for v in kin.order] != list(range(L)) or par[1] != 0 or par[1 + n] != 0:
+        return None
+    f32 = lambda a: np.asarray(a, np.float32)
+    for i in range(1, n + 1):
+        j = i + n
+        if i > 1 and not (1 <= par[i] < i and par[j] == par[i] + n):
+            return None
+        di, dj = int(kin.dof_idx[i]), int(kin.dof_idx[j])
+        if (di < 0) != (dj < 0) or (di >= 0 and not (di < DA and dj == di + DA)):
+            return None
+        for name in ("joint_type", "rot_axis", "sf_rot_axis", "clamp"):
+            if int(getattr(kin, name)[i]) != int(getattr(kin, name)[j]):
+                return None
+        for name in ("rot_sign", "lower", "upper", "axis"):
+            if not np.array_equal(f32(getattr(kin, name)[i]), f32(getattr(kin, name)[j])):
+                return None
+        if i > 1 and not (np.array_equal(f32(kin.R_fixed[i]), f32(kin.R_fixed[j])) and np.array_equal(f32(kin.trans[i]), f32(kin.trans[j]))):
+            return None
+    differ = []
+    for r in range(3):
+        for c in range(3):
+            a, b = snap_const(kin.R_fixed[1][r][c], SNAP), snap_const(kin.R_fixed[1 + n][r][c], SNAP)
+            if a != b:
+                differ.append(("R", r, c, a, b))
+        a, b = snap_const(kin.trans[1][r], 0.0), snap_const(kin.trans[1 + n][r], 0.0)
+        if a != b:
+            differ.append(("t", r, 0, a, b))
+    obj = list(tmpl.obj_links)
+    h = len(obj) // 2
+    if len(obj) % 2 or any(not (1 <= i <= n) for i in obj[:h]) or obj[h:] != [i + n for i in obj[:h]]:
+        return None
+    if (tmpl.ee_link >= 0) != (tmpl.ee2_link >= 0) or (tmpl.ee_link >= 0 and not (1 <= tmpl.ee_link <= n and tmpl.ee2_link == tmpl.ee_link + n)):
+        return None
+    arm = SimpleNamespace(n_links=n + 1, n_dofs=DA, name=kin.name, link_names=list(kin.link_names[:n + 1]), order=np.arange(n + 1, dtype=np.int32),
+                          name_to_idx={k: v for k, v in kin.name_to_idx.items() if v <= n})
+    for name in ("parent", "joint_type", "dof_idx", "R_fixed", "trans", "axis", "rot_axis", "sf_rot_axis", "rot_sign", "clamp", "lower", "upper"):
+        setattr(arm, name, np.asarray(getattr(kin, name))[:n + 1])
+    return ArmLanePlan(n=n, DA=DA, arm=arm, obj=obj[:h], ee=int(tmpl.ee_link), differ=differ)
+
+
+def _arm_lane_kernel_lines(kin: KinModel, tmpl: CollisionTemplate, plan: ArmLanePlan, snap: float) -> List[str]:
+    """k_rollout_gpa_bi / _bg: the GP-fused rollout (trk_rollout_gp_cost_grad) with one ARM per lane.  Serves the sphere scenes
+    (scene_is_fast) without self-collision pairs (w_self == 0: the template's pairs cross the arms; the launcher hands those calls to
+    k_rollout_gpt); BUILD-DEFINED like the prior itself, same oracle (orc_rollout + orc_gp_prior)."""
+    L, D = kin.n_links, kin.n_dofs
+    n, DA, arm = plan.n, plan.DA, plan.arm
+    LA, NLA, W = n + 1, len(plan.obj), 3 * L
+    masked = _masked_factory(arm)
+    n_rev_ticks = sum(1 for p in range(LA - 1, 0, -1) if p % 2 == 0)
+    n_slots = (OBJ_TICK_SLOTS if NLA else 0) + 1 + n_rev_ticks
+    out: List[str] = []
+    for base_identity in (True, False):
+        E = Emitter()
+        kname = "k_rollout_gpa_bi" if base_identity else "k_rollout_gpa_bg"
+        E.raw("template <class IO>      // HBM-side type of q / qd / link_pos / gradients: float, _Float16 or HalfG32")
+        E.raw(f"__global__ void __launch_bounds__(SPEC_BLOCK, 4) {kname}(SpecArgs A) {{")
+        E.raw(f"    constexpr int DA = {DA}, NLA = {NLA}, ROWS = TRK_WAVE / 2, W = {W};      // joints / collision links per arm, samples per wavefront, position floats per sample")
+        E.raw("    typedef typename IoTraits<IO>::Q IOQ;")
+        E.raw("    typedef typename IoTraits<IO>::G IOG;")
+        E.raw("    typedef RawRowsInFlight<D, IOQ, ROWS> Raw;       // the block's 32 sample rows (+ one in front, one behind) = 64 half rows of DA")
+        E.raw("    typedef ImgFlusher<W, IOQ, ROWS> Img;")
+        E.raw("    constexpr int GQ_B = TRK_WAVE * DA * 4;")
+        E.raw("    constexpr int WAVE_B0 = Img::BYTES > 2 * Raw::BYTES ? Img::BYTES : 2 * Raw::BYTES;")
+        E.raw("    constexpr int WAVE_B = ((WAVE_B0 > GQ_B ? WAVE_B0 : GQ_B) + 15) / 16 * 16;      // one region per wavefront: raw tiles -> gqd tile -> image -> gq tile")
+        E.raw("    __shared__ __attribute__((aligned(16))) unsigned char lds_all[SPEC_WAVES * (WAVE_B + TRK_LDS_SPHERES * 16) + SPEC_WAVES * 4];")
+        E.raw("    const int lane = threadIdx.x & (TRK_WAVE - 1);")
+        E.raw("    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TRK_WAVE);")
+        E.raw("    unsigned char* wl = lds_all + wave * WAVE_B;")
+        E.raw("    float* lds = reinterpret_cast<float*>(wl);")
+        E.raw("    float4* lds_sph = reinterpret_cast<float4*>(lds_all + SPEC_WAVES * WAVE_B) + wave * TRK_LDS_SPHERES;")
+        E.raw("    float* wsum = reinterpret_cast<float*>(lds_all + SPEC_WAVES * (WAVE_B + TRK_LDS_SPHERES * 16));      // the wavefronts' cost sums: two of them make one 64-sample block")
+        E.raw("    const SpheresInFlight sph = spec_load_spheres_issue(A.C, lane);   // waited for together with the rows below")
+        E.raw("    const int64_t wblock = (int64_t)blockIdx.x * SPEC_WAVES + wave;     // index of this wave's 32-sample block")
+        E.raw("    const int64_t base_s = wblock * ROWS, base_h = wblock * TRK_WAVE;   // first sample; first half row of the (2N, DA) view")
+        E.raw("    const int rows_s = (int)max((int64_t)0, min((int64_t)ROWS, A.n - base_s)), rows = 2 * rows_s;")
+        E.raw("    const bool odd = (lane & 1) != 0;                                   // the arm this lane evaluates")
+        E.raw("    const int srow = lane >> 1;                                         // its sample within the block")
+        E.raw("    // time steps: the block starts at step t0 of its trajectory (wave-uniform), a lane's sample sits at (t0 + srow) mod H")
+        E.raw("    const unsigned Hh = (unsigned)A.gp_H;")
+        E.raw("    const unsigned t0 = (unsigned)(base_s % (int64_t)A.gp_H);")
+        E.raw("    const unsigned tl = (t0 + (unsigned)srow) % Hh, t_last = (t0 + (unsigned)(ROWS - 1)) % Hh;")
+        E.raw("    const bool edge_prev = rows_s > 0 && t0 > 0u, edge_next = rows_s == ROWS && t_last + 1u < Hh && base_s + ROWS < A.n;")
+        E.raw("    const Raw rq = spec_raw_rows_issue<D, IOQ, ROWS>(static_cast<const IOQ*>(A.q), base_s, rows_s, lane, edge_prev, edge_next);")
+        E.raw("    const Raw rv = spec_raw_rows_issue<D, IOQ, ROWS>(static_cast<const IOQ*>(A.qd), base_s, rows_s, lane, edge_prev, edge_next);")
+        E.raw("    const IOQ* qb = spec_raw_rows_finish<D, IOQ, ROWS>(rq, static_cast<const IOQ*>(A.q), base_s, rows_s, lane, reinterpret_cast<IOQ*>(wl));")
+        E.raw("    const IOQ* vb = spec_raw_rows_finish<D, IOQ, ROWS>(rv, static_cast<const IOQ*>(A.qd), base_s, rows_s, lane, reinterpret_cast<IOQ*>(wl + Raw::BYTES));")
+        E.raw("    spec_wave_sync();")
+        E.raw("    float q[DA], gpv[DA], cost_gp;")
+        E.raw("    {")
+        E.raw("        // ---- the prior on this arm's DA joints.  e_t = (p_t + dt v_t - p_t+1, v_t - v_t+1), r = Q^-1 e; this sample takes part in the")
+        E.raw("        // factors t-1 -> t and t -> t+1; its neighbours in time are the half rows two lanes away (D = 2 DA elements) in the raw tiles.")
+        E.raw("        // d/dq_t = r_t.p - r_t-1.p,  d/dqd_t = dt r_t.p + r_t.v - r_t-1.v;  the factor t -> t+1 is attributed to sample t.")
+        E.raw("        const bool on = lane < rows;")
+        E.raw("        const float mn = (on && tl + 1u < Hh) ? A.gp_w : 0.0f, mp = (on && tl > 0u) ? A.gp_w : 0.0f;")
+        E.raw("        const float dt = A.gp_dt, ga = A.gp_a, gb = A.gp_b, gc = A.gp_c;")
+        E.raw("        const IOQ* qr = qb + lane * DA;")
+        E.raw("        const IOQ* vr = vb + lane * DA;")
+        E.raw("        float gvv[DA], accg = 0.0f;")
+        E.raw("#pragma unroll")
+        E.raw("        for (int d = 0; d < DA; ++d) {")
+        E.raw("            const float p0 = (float)qr[d], v0 = (float)vr[d];")
+        E.raw("            const float pm = (float)qr[d - D], vm = (float)vr[d - D], pn = (float)qr[d + D], vn = (float)vr[d + D];")
+        E.raw("            const float ep = fmaf(dt, v0, p0) - pn, ev = v0 - vn;")
+        E.raw("            const float rp = mn * fmaf(ga, ep, gb * ev), rv_ = mn * fmaf(gb, ep, gc * ev);")
+        E.raw("            accg = fmaf(0.5f, fmaf(ep, rp, ev * rv_), accg);")
+        E.raw("            const float em = fmaf(dt, vm, pm) - p0, fm = vm - v0;")
+        E.raw("            gpv[d] = rp - mp * fmaf(ga, em, gb * fm);")
+        E.raw("            gvv[d] = fmaf(dt, rp, rv_) - mp * fmaf(gb, em, gc * fm);")
+        E.raw("            q[d] = p0;")
+        E.raw("        }")
+        E.raw("        cost_gp = accg;")
+        E.raw("        // d cost / d qd is final: out through the staging tile (its first line waits for every lane's reads of the raw tiles)")
+        E.raw("        spec_store_gq<DA, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base_h, rows, lane, lds, gvv, A.grad_scale);")
+        E.raw("    }")
+        E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
+        # ---------------- what differs between the arms: per-lane selects ----------------
+        R: Dict[int, List[List[S]]] = {}
+        t: Dict[int, List[S]] = {}
+        passv: Dict[int, S] = {}
+        if base_identity:
+            R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+            t[0] = [ZERO, ZERO, ZERO]
+        else:
+            R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+            t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+        Rf = [[S(snap_const(arm.R_fixed[1][r][c], snap)) for c in range(3)] for r in range(3)]
+        tlv = [S(snap_const(arm.trans[1][k], 0.0)) for k in range(3)]
+        for kind, r, c, a, b in plan.differ:
+            nm = f"mnt{kind}{r}{c}"
+            E.raw(f"    const float {nm} = odd ? {flit(b)} : {flit(a)};      // the arm root's fixed transform, entry {kind}[{r}][{c}]: arm 1 / arm 0")
+            if kind == "R":
+                Rf[r][c] = S(1.0, nm)
+            else:
+                tlv[r] = S(1.0, nm)
+        _emit_angles(E, arm)
+        for i in range(1, LA):
+            _emit_fk_link(E, arm, i, R, t, passv, snap, fixed_override={1: (Rf, tlv)})
+        # ---------------- positions: the two lanes of a sample stage its row of the wavefront's output image ----------------
+        E.raw("    const Img pimg = spec_make_img<W, IOQ, ROWS>(static_cast<IOQ*>(A.link_pos), base_s, rows_s, lane, reinterpret_cast<IOQ*>(wl));")
+        E.raw("    spec_wave_sync();          // the gqd staging tile has been read out: the image may be written")
+        E.raw("    if (A.link_pos) {")
+        E.raw(f"        IOQ* prow = reinterpret_cast<IOQ*>(wl) + srow * W + (odd ? {3 + 3 * n} : 3);      // row = [link 0 | arm 0's links | arm 1's links]")
+        E.raw("        if (!odd) { " + " ".join(f"prow[{k - 3}] = (IOQ)({E.expr(t[0][k])});" for k in range(3)) + " }")
+        for i in range(1, LA):
+            E.raw("        " + " ".join(f"prow[{3 * (i - 1) + k}] = (IOQ)({E.expr(t[i][k])});" for k in range(3)))
+        E.raw("    }")
+        E.raw("    spec_wave_sync();          // the image is complete")
+        E.raw("    spec_img_copy_slow(pimg, static_cast<IOQ*>(A.link_pos), base_s, rows_s);       // ragged last wavefront / unaligned view only")
+        E.raw(f"    constexpr int PPT = (Img::NP + {n_slots - 1}) / {n_slots};")
+        E.raw("    const ImgTicks<Img, PPT> flush{pimg};")
+        E.raw("    if (!A.gq) { flush.template rest<0>(); return; }      // positions only: wave-uniform exit (the whole grid takes it: no barrier is missed)")
+        next_chunk = [0]
+
+        def tick_line(indent="    "):
+            c = next_chunk[0]
+            next_chunk[0] += 1
+            return f"{indent}flush.template chunk<{c}>();"
+        # ---------------- objectives of this lane's arm ----------------
+        adj = sorted(set(plan.obj) | ({plan.ee} if plan.ee >= 0 else set()))
+        E.raw("    float cost = 0.0f;")
+        for i in adj:
+            E.raw(f"    float tb{i}_0 = 0.0f, tb{i}_1 = 0.0f, tb{i}_2 = 0.0f;")
+        if NLA:
+            for k, nm in enumerate("xyz"):
+                E.raw(f"    const float p{nm}[NLA] = {{{', '.join(E.expr(t[i][k]) for i in plan.obj)}}};")
+            E.raw("    float gx[NLA], gy[NLA], gz[NLA];")
+            E.raw("#pragma unroll")
+            E.raw("    for (int l = 0; l < NLA; ++l) { gx[l] = 0.0f; gy[l] = 0.0f; gz[l] = 0.0f; }")
+            c0 = next_chunk[0]
+            next_chunk[0] += OBJ_TICK_SLOTS
+            E.raw(f"    const TickFrom<decltype(flush), {c0}> ticks{{flush}};")
+            E.raw("    if (A.w.w_obj != 0.0f) cost += spec_objects_cost_arm<NLA, decltype(ticks), true, false>(A.C, A.w.w_obj, px, py, pz, gx, gy, gz, ticks, lds_sph, odd);")
+            E.raw(f"    else flush.template range<{c0}, {next_chunk[0]}>();")
+            E.raw("    if (A.w.w_ws != 0.0f && A.C.has_ws) cost += spec_ws_cost_arm<NLA>(A.C, A.w.w_ws, px, py, pz, gx, gy, gz, odd);")
+            for j, i in enumerate(plan.obj):
+                E.raw(f"    tb{i}_0 += gx[{j}]; tb{i}_1 += gy[{j}]; tb{i}_2 += gz[{j}];")
+        if plan.ee >= 0:
+            ee = plan.ee
+            E.raw("    float eeRb[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};")
+            E.raw("    if (A.w.w_ee != 0.0f) {")
+            E.raw("        float Ht[16];      // this arm's target: rows 0 .. 2 of ee_target (arm 0) / ee2_target (arm 1)")
+            E.raw("#pragma unroll")
+            E.raw("        for (int k = 0; k < 12; ++k) Ht[k] = odd ? A.C.ee2_target[k] : A.C.ee_target[k];")
+            E.raw("        Ht[12] = 0.0f; Ht[13] = 0.0f; Ht[14] = 0.0f; Ht[15] = 1.0f;")
+            E.raw(f"        const float eR[9] = {{{', '.join(E.expr(R[ee][r][c]) for r in range(3) for c in range(3))}}};")
+            E.raw(f"        const float et[3] = {{{', '.join(E.expr(t[ee][k]) for k in range(3))}}};")
+            E.raw("        float gR[9], gt[3];")
+            E.raw("        const float ce = ee_cost_eval(eR, et, Ht, A.C.ee_w_pos, A.C.ee_w_rot, A.C.ee_square, gR, gt);")
+            E.raw("        cost = fmaf(A.w.w_ee, ce, cost);")
+            E.raw("#pragma unroll")
+            E.raw("        for (int k = 0; k < 9; ++k) eeRb[k] = A.w.w_ee * gR[k];")
+            E.raw(f"        tb{ee}_0 = fmaf(A.w.w_ee, gt[0], tb{ee}_0); tb{ee}_1 = fmaf(A.w.w_ee, gt[1], tb{ee}_1); tb{ee}_2 = fmaf(A.w.w_ee, gt[2], tb{ee}_2);")
+            E.raw("    }")
+        E.raw(tick_line())
+        # ---------------- cost: the sample's cost is the sum over its two lanes; a 64-sample block sum is two wavefronts' ----------------
+        E.raw("    cost += cost_gp;           // the prior's factor t -> t + 1 (this arm's joints), attributed to this sample")
+        E.raw("    const float cs = cost + trk_dpp_partner(cost);      // both lanes of a sample hold its cost (a + b == b + a: the same bits)")
+        E.raw("    if (!odd && lane < rows) store_wt_f1(A.cost + base_s + srow, cs);")
+        E.raw("    if (A.cost_sum) {")
+        E.raw("        const float tot = spec_wave_sum((!odd && lane < rows) ? cs : 0.0f);")
+        E.raw("        if (lane == 0) wsum[wave] = tot;")
+        E.raw("    }")
+        # ---------------- reverse ----------------
+        gq_expr = _emit_reverse_links(E, arm, R, t, {i: [f"tb{i}_{k}" for k in range(3)] for i in adj},
+                                      ({plan.ee: "eeRb"} if plan.ee >= 0 else {}), masked, tick=tick_line, order=list(range(LA)))
+        assert next_chunk[0] <= n_slots, (next_chunk[0], n_slots)
+        E.raw(f"    flush.template rest<{next_chunk[0]}>();")
+        E.raw(f"    const float gv[DA] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) + f' + gpv[{d}]' for d in range(DA))}}};")
+        E.raw("    spec_store_gq<DA, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gq), base_h, rows, lane, lds, gv, A.grad_scale);")
+        E.raw("    if (A.cost_sum) {          // wave-uniform for the whole workgroup")
+        E.raw("        __syncthreads();")
+        E.raw("        if ((wave & 1) == 0 && lane == 0 && rows > 0) store_wt_f1(A.cost_sum + (wblock >> 1), wsum[wave] + wsum[wave + 1]);")
+        E.raw("    }")
+        E.raw("}")
+        out.extend(E.lines)
+        out.append("")
+    return out
 
 
 TRK_WAVE_ = 64
@@ -854,6 +1104,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("}")
         out.extend(E.lines)
         out.append("")
+
+    # ---- the same objective with one ARM per lane (two isomorphic arms on one base: the dual Panda of BASELINE config 5)
+    arm_plan = arm_lane_plan(kin, tmpl) if (gpt_ok and os.environ.get("TRK_EXP_NO_ARM_LANES", "0") != "1") else None
+    if arm_plan is not None:
+        out.extend(_arm_lane_kernel_lines(kin, tmpl, arm_plan, snap))
 
     # ---- the fused rollout with the GP prior fused in (trk_rollout_gp_cost_grad; BASELINE config 5's objective in ONE launch, gq and
     # gqd written once).  BUILD-DEFINED like the prior itself.  Two things differ from k_rollout:
@@ -1785,6 +2040,26 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         if use_seg and gp_cross_pairs:
             out.append("    if (a.w.w_self != 0.0f) return 1;      // self pairs between independently scheduled subtrees: the two-launch form serves them")
         kn = "k_rollout_gp_" if use_seg else "k_rollout_gpt_"
+        if arm_plan is not None:
+            # one arm per lane: sphere scenes, no (cross-arm) self pairs -- and fp32 I/O only by default.  Measured on one box, alternating
+            # (profiles/r06_ab_c5_arm_lanes.txt): fp32 I/O 23.2 -> 21.2 us, but fp16 I/O 21.0 -> 22.4 us and mixed 21.0 -> 22.2: at four
+            # wavefronts per SIMD the lone-wavefront latency drops (9.1 -> 7.6 us) while every wavefront of 32 samples costs 1.9 us of issue
+            # time against 2.3 us for 64 samples -- 19 % more instructions per arm (SQ counters: profiles/r06_sq_c5_arm_vs_robot_lane.txt).
+            # TRK_GP_ARM_LANES=0 / 1 in the environment forces the choice (read per launch, like TRK_STREAM_STORES: same-process A/Bs).
+            out.append("    {")
+            out.append("        const char* env_ = std::getenv(\"TRK_GP_ARM_LANES\");")
+            out.append("        const bool want_ = env_ ? std::atoi(env_) != 0 : a.io_f16 == TRK_IO_F32;")
+            out.append("        if (a.w.w_self == 0.0f && scene_is_fast(a.C) && want_) {")
+            out.append("            const unsigned grid2 = (unsigned)((a.n + SPEC_WAVES * (TRK_WAVE / 2) - 1) / (SPEC_WAVES * (TRK_WAVE / 2)));")
+            out.append("            auto ga = [&](auto io) {")
+            out.append("                using IOT = decltype(io);")
+            out.append("                if (base_identity) hipLaunchKernelGGL((k_rollout_gpa_bi<IOT>), dim3(grid2), dim3(SPEC_BLOCK), 0, st, a);")
+            out.append("                else hipLaunchKernelGGL((k_rollout_gpa_bg<IOT>), dim3(grid2), dim3(SPEC_BLOCK), 0, st, a);")
+            out.append("            };")
+            out.append("            if (a.io_f16 == TRK_IO_F16) ga(_Float16{}); else if (a.io_f16 == TRK_IO_F16_G32) ga(HalfG32{}); else ga(float{});")
+            out.append("            return 0;")
+            out.append("        }")
+            out.append("    }")
         out.append("    auto go = [&](auto io, auto c0) {")
         out.append("        using IOT = decltype(io);")
         out.append(f"        if (base_identity) hipLaunchKernelGGL(({kn}bi<IOT, decltype(c0)::value>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")

@@ -917,56 +917,61 @@ __device__ __forceinline__ PosFlusher<W, IO> spec_stage_rows_prefilled(IO* __res
 // rows -1 and 64 are the previous / next sample of the trajectory when it continues beyond this wavefront's block (else zero; the
 // caller masks them by the time step anyway).  Two halves like spec_load_rows_issue / finish: every load of both tiles is in
 // flight before the first LDS write.
-template <int D, class IO>
+// ROWS (default 64): rows of the block.  The arm-per-lane kernels (k_rollout_gpa) give a wavefront 32 samples -- two lanes per sample --
+// and read the same tile through the (2 ROWS, D / 2) view: lane l's half row starts at element l * (D / 2).
+template <int D, class IO, int ROWS = TRK_WAVE>
 struct RawRowsInFlight {
     static constexpr int VE = 16 / sizeof(IO);                          // elements per 16-byte vector
     static constexpr int PAD = (D + VE - 1) / VE * VE;
-    static constexpr int ELEMS = PAD + (TRK_WAVE + 1) * D;              // elements of a tile
+    static constexpr int ELEMS = PAD + (ROWS + 1) * D;                  // elements of a tile
     static constexpr int BYTES = (ELEMS * (int)sizeof(IO) + 15) / 16 * 16;
-    static constexpr int NV = TRK_WAVE * D / VE, NJ = (NV + TRK_WAVE - 1) / TRK_WAVE;
+    static constexpr int NV = ROWS * D / VE, NJ = (NV + TRK_WAVE - 1) / TRK_WAVE;
+    static constexpr int NSLOW = (ROWS * D + TRK_WAVE - 1) / TRK_WAVE;  // element-wise trips of the ragged / unaligned path
     trk_f4 v[NJ];
-    IO edge;                                                            // lanes 0 .. D-1: row -1; lanes 32 .. 32+D-1: row 64
+    IO edge;                                                            // lanes 0 .. D-1: row -1; lanes 32 .. 32+D-1: row ROWS
     bool fast;
 };
-template <int D, class IO>
-__device__ __forceinline__ RawRowsInFlight<D, IO> spec_raw_rows_issue(const IO* __restrict__ in, int64_t base, int rows, int lane,
-                                                                      bool has_prev, bool has_next) {
+template <int D, class IO, int ROWS = TRK_WAVE>
+__device__ __forceinline__ RawRowsInFlight<D, IO, ROWS> spec_raw_rows_issue(const IO* __restrict__ in, int64_t base, int rows, int lane,
+                                                                            bool has_prev, bool has_next) {
     static_assert(D <= 32, "edge rows are fetched by one half-wave each");
-    RawRowsInFlight<D, IO> r;
+    typedef RawRowsInFlight<D, IO, ROWS> Raw;
+    Raw r;
     const IO* src = in + base * D;
-    r.fast = rows == TRK_WAVE && (TRK_WAVE * D * sizeof(IO)) % 16 == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    r.fast = rows == ROWS && (ROWS * D * sizeof(IO)) % 16 == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
 #pragma unroll
-    for (int j = 0; j < RawRowsInFlight<D, IO>::NJ; ++j) {
+    for (int j = 0; j < Raw::NJ; ++j) {
         const int k = lane + TRK_WAVE * j;
-        r.v[j] = (r.fast && k < RawRowsInFlight<D, IO>::NV) ? reinterpret_cast<const trk_f4*>(src)[k] : trk_f4{0.0f, 0.0f, 0.0f, 0.0f};
+        r.v[j] = (r.fast && k < Raw::NV) ? reinterpret_cast<const trk_f4*>(src)[k] : trk_f4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     r.edge = (IO)0.0f;
     if (lane < D && has_prev) r.edge = src[lane - D];                   // the D elements in front of the block
-    if (lane >= 32 && lane < 32 + D && has_next) r.edge = src[TRK_WAVE * D + (lane - 32)];
+    if (lane >= 32 && lane < 32 + D && has_next) r.edge = src[ROWS * D + (lane - 32)];
     return r;
 }
-template <int D, class IO>
-__device__ __forceinline__ IO* spec_raw_rows_finish(const RawRowsInFlight<D, IO>& r, const IO* __restrict__ in, int64_t base, int rows,
+template <int D, class IO, int ROWS = TRK_WAVE>
+__device__ __forceinline__ IO* spec_raw_rows_finish(const RawRowsInFlight<D, IO, ROWS>& r, const IO* __restrict__ in, int64_t base, int rows,
                                                     int lane, IO* tile) {
-    IO* body = tile + RawRowsInFlight<D, IO>::PAD;
+    typedef RawRowsInFlight<D, IO, ROWS> Raw;
+    IO* body = tile + Raw::PAD;
     if (r.fast) {
         trk_f4* b4 = reinterpret_cast<trk_f4*>(body);
 #pragma unroll
-        for (int j = 0; j < RawRowsInFlight<D, IO>::NJ; ++j) {
+        for (int j = 0; j < Raw::NJ; ++j) {
             const int k = lane + TRK_WAVE * j;
-            if (k < RawRowsInFlight<D, IO>::NV) b4[k] = r.v[j];
+            if (k < Raw::NV) b4[k] = r.v[j];
         }
     } else {
         const IO* src = in + base * D;
         const int count = rows * D;
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
+        for (int j = 0; j < Raw::NSLOW; ++j) {
             const int k = lane + TRK_WAVE * j;
-            body[k] = k < count ? src[k] : (IO)0.0f;
+            if (k < ROWS * D) body[k] = k < count ? src[k] : (IO)0.0f;
         }
     }
     if (lane < D) body[lane - D] = r.edge;
-    if (lane >= 32 && lane < 32 + D) body[TRK_WAVE * D + (lane - 32)] = r.edge;
+    if (lane >= 32 && lane < 32 + D) body[ROWS * D + (lane - 32)] = r.edge;
     return body;
 }
 
@@ -1004,20 +1009,20 @@ __device__ __forceinline__ void spec_store_acc_tile(IO* __restrict__ out, int64_
 // (First version: each segment's columns left on their own as 4-byte pieces -- a sample's block is contiguous but the blocks of
 // one store instruction are not, every 64-byte line was written in parts by several instructions: 7.7 us for the dual Panda's
 // 36 MB where these whole-line stores take 2.5; as write-back stores 26 us more.)
-template <int W, class IO>
+template <int W, class IO, int ROWS = TRK_WAVE>
 struct ImgFlusher {
-    static constexpr int BYTES = TRK_WAVE * W * (int)sizeof(IO);
-    static constexpr int NV = BYTES / 16;                                // whole 16-byte vectors (64 W elements: always a multiple of 16 bytes)
+    static constexpr int BYTES = ROWS * W * (int)sizeof(IO);
+    static constexpr int NV = BYTES / 16;                                // whole 16-byte vectors
     static constexpr int NP = (NV + TRK_WAVE - 1) / TRK_WAVE;            // store instructions
     static constexpr int TAIL = NV - (NP - 1) * TRK_WAVE;                // lanes of the last one
-    static_assert(BYTES % 16 == 0, "64 rows of W elements are whole 16-byte vectors");
+    static_assert(BYTES % 16 == 0, "the rows of a wavefront must be whole 16-byte vectors");
     IO* img;                                                             // this wave's image
     const trk_f4* src;                                                   // this lane's vector of piece 0
     unsigned voff;                                                       // lane * 16
     unsigned long long g0;                                               // wave-uniform: address of the wave's first output byte
     unsigned long long on;                                               // wave-uniform: all lanes (full wavefront, positions wanted) or none
     int lane;
-    // a lane's own row, element c
+    // a lane's own row, element c (one lane per row: ROWS == 64)
     __device__ __forceinline__ void put(int c, float v) const { img[lane * W + c] = (IO)v; }
     template <int J>
     __device__ __forceinline__ void piece() const {
@@ -1046,19 +1051,19 @@ struct ImgTicks {
     template <int A, int B> __device__ __forceinline__ void range() const { if constexpr (PPT > 0) f.template run<A * PPT, B * PPT>(); }
     template <int A> __device__ __forceinline__ void rest() const { if constexpr (PPT > 0) f.template run<A * PPT, F::NP>(); }
 };
-template <int W, class IO>
-__device__ __forceinline__ ImgFlusher<W, IO> spec_make_img(IO* __restrict__ out, int64_t base, int rows, int lane, IO* img) {
+template <int W, class IO, int ROWS = TRK_WAVE>
+__device__ __forceinline__ ImgFlusher<W, IO, ROWS> spec_make_img(IO* __restrict__ out, int64_t base, int rows, int lane, IO* img) {
     IO* dst = out ? out + base * W : nullptr;
     const unsigned long long g = (unsigned long long)reinterpret_cast<uintptr_t>(dst);
     const unsigned long long gu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) |
                                   (unsigned)__builtin_amdgcn_readfirstlane((int)g);
-    const bool fast = out != nullptr && rows == TRK_WAVE && (g & 15) == 0;
-    return ImgFlusher<W, IO>{img, reinterpret_cast<const trk_f4*>(img) + lane, (unsigned)lane * 16u, gu,
-                             __builtin_amdgcn_ballot_w64(fast), lane};      // a ballot is scalar by definition: all lanes, or none
+    const bool fast = out != nullptr && rows == ROWS && (g & 15) == 0;
+    return ImgFlusher<W, IO, ROWS>{img, reinterpret_cast<const trk_f4*>(img) + lane, (unsigned)lane * 16u, gu,
+                                   __builtin_amdgcn_ballot_w64(fast), lane};      // a ballot is scalar by definition: all lanes, or none
 }
 // ragged last wavefront / unaligned view: the staged image is copied with plain stores (wave-uniform branch, after the last staging)
-template <int W, class IO>
-__device__ __forceinline__ void spec_img_copy_slow(const ImgFlusher<W, IO>& f, IO* __restrict__ out, int64_t base, int rows) {
+template <int W, class IO, int ROWS>
+__device__ __forceinline__ void spec_img_copy_slow(const ImgFlusher<W, IO, ROWS>& f, IO* __restrict__ out, int64_t base, int rows) {
     if (out == nullptr || f.on != 0ull) return;
     for (int e = f.lane; e < rows * W; e += TRK_WAVE) out[base * W + e] = f.img[e];
 }
@@ -1113,6 +1118,42 @@ __device__ __forceinline__ float spec_objects_cost(const DevCostHdr& C, float w,
         gx[l] = fmaf(-w, ax[l], gx[l]); gy[l] = fmaf(-w, ay[l], gy[l]); gz[l] = fmaf(-w, az[l], gz[l]);
     }
     return w * cost;
+}
+
+// Arm-per-lane kernels (k_rollout_gpa): lanes 2s / 2s + 1 of a wavefront hold the two ISOMORPHIC arms of sample s, each with the NL
+// collision links of ITS arm; the margins of arm a are C.obj_link_margin[a * NL .. a * NL + NL) -- two scalar loads and a select per link.
+template <int NL, class Tick, bool FAST = false, bool GENERAL = true>
+__device__ __forceinline__ float spec_objects_cost_arm(const DevCostHdr& C, float w, const float (&px)[NL], const float (&py)[NL],
+                                                       const float (&pz)[NL], float (&gx)[NL], float (&gy)[NL], float (&gz)[NL],
+                                                       const Tick& tick, const float4* lds_spheres, bool odd, const float4* lds_prims = nullptr) {
+    float s[NL], ax[NL], ay[NL], az[NL];
+    scene_min_sdf<NL, const Tick&, FAST, GENERAL>(C, px, py, pz, s, ax, ay, az, tick, lds_spheres, lds_prims);
+    float cost = 0.0f;
+    const bool hinge = (C.clamp_fields & TRK_FIELD_OBJECTS) != 0;             // wave-uniform: clamp_sdf=True
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const float m0 = cptr(C.obj_link_margin)[l], m1 = cptr(C.obj_link_margin)[NL + l];
+        const float v = (odd ? m1 : m0) - s[l];
+        const float wl = (hinge && !(v > 0.0f)) ? 0.0f : w;                     // relu: value and gradient vanish at or below zero
+        cost += hinge ? __builtin_fmaxf(v, 0.0f) : v;
+        gx[l] = fmaf(-wl, ax[l], gx[l]); gy[l] = fmaf(-wl, ay[l], gy[l]); gz[l] = fmaf(-wl, az[l], gz[l]);
+    }
+    return w * cost;
+}
+template <int NL>
+__device__ __forceinline__ float spec_ws_cost_arm(const DevCostHdr& C, float w, const float (&px)[NL], const float (&py)[NL],
+                                                  const float (&pz)[NL], float (&gx)[NL], float (&gy)[NL], float (&gz)[NL], bool odd) {
+    float cost = 0.0f;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const float m0 = cptr(C.obj_link_margin)[l], m1 = cptr(C.obj_link_margin)[NL + l];
+        cost += ws_cost_point(C, odd ? m1 : m0, px[l], py[l], pz[l], w, gx[l], gy[l], gz[l]);
+    }
+    return w * cost;
+}
+// the partner lane of an arm pair (lane ^ 1) as a DPP operand: quad_perm:[1,0,3,2]
+__device__ __forceinline__ float trk_dpp_partner(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
 }
 
 // the object field's cost of ONE collision link at a wave-uniform (constant) position: w * (margin - sdf) [hinge if clamped]; no gradient
