@@ -557,7 +557,22 @@ int trk_rollout_collision_via(const TrkModel* model, const TrkCostModel* cm, int
                               int32_t horizon, int32_t state_dim, int32_t n_interp, const float* alpha, const float* beta,
                               float margin_override, uint8_t* in_collision, trk_stream_t stream);
 
-/* The rest of get_trajs_collision_and_free (tasks.py:253-299) on the device: three launches, no host round trip.
+/* The same launch also folds the per-trajectory FLAGS of trk_traj_validate (round 6) -- bit 0 = some interpolated configuration of the
+ * trajectory collides (tasks.py:255-256), bit 1 = some joint position x[t, h, d < D] lies outside [q_min[d], q_max[d]] (DEVICE float[D];
+ * NaN = outside; tasks.py:270-273; every way point is an end of some segment the kernel has loaded anyway) -- as per-WAVEFRONT partial
+ * results: partial_flags [trk_via_partial_flags_bytes(n_traj, horizon, n_interp)] uint8, a row of hi / 64 + 2 bytes per trajectory
+ * (hi = (horizon - 1) n_interp samples), one byte per wavefront of 64 consecutive samples that holds samples of it; every byte a reader
+ * looks at is written by plain stores on every call (no atomics, nothing to zero).  Hand the buffer to trk_traj_validate as `waypoint_collisions` with n_waypoints = -(horizon - 1) * n_interp: its partition
+ * launch ORs the few bytes that cover a trajectory, and the separate flags launch disappears. */
+int64_t trk_via_partial_flags_bytes(int64_t n_traj, int32_t horizon, int32_t n_interp);
+int trk_rollout_collision_via_flags(const TrkModel* model, const TrkCostModel* cm, int32_t fields, const float* x, int64_t n_traj,
+                                    int32_t horizon, int32_t state_dim, int32_t n_interp, const float* alpha, const float* beta,
+                                    float margin_override, const float* q_min, const float* q_max, uint8_t* in_collision,
+                                    uint8_t* partial_flags, trk_stream_t stream);
+
+/* The rest of get_trajs_collision_and_free (tasks.py:253-299) on the device: three launches, no host round trip (two when
+ * `waypoint_collisions` is the partial_flags buffer of trk_rollout_collision_via_flags and n_waypoints = -(samples per trajectory):
+ * the partition launch assembles flags [n_traj] itself; q_min / q_max are then unused).
  *   flags [n_traj]      bit 0: some way-point byte of the trajectory is set (waypoint_collisions [n_traj, n_waypoints]);
  *                       bit 1: some joint position x[t, h, d < n_dofs] lies outside [q_min[d], q_max[d]] (NaN = outside)
  *   idx [n_traj rows]   a stable three-way partition of the trajectories, each group in increasing order:

@@ -141,3 +141,48 @@ def test_points_rollout_plan_matches_the_eager_call(ops):
     pk.pack(out)
     torch.cuda.synchronize()
     assert abs(float(out[0]) - float(plan.cost.double().sum())) <= 2e-6 * abs(float(plan.cost.double().sum()))
+
+
+@pytest.mark.parametrize("T,H,n_interp", [(4096, 64, 5), (37, 64, 5), (1, 2, 1), (203, 3, 2), (50, 17, 7), (1027, 9, 3)])
+def test_trajectory_flags_folded_into_the_via_launch(ops, T, H, n_interp):
+    """Round 6 (F1; tasks.py:244-299): `rollout_collision_via(..., limits=...)` produces the per-trajectory flags in the launch that
+    evaluates the via points -- the SAME flags, partition and gathers as the three-launch form, for trajectories that are free, colliding,
+    outside the joint limits (incl. NaN way points) or both; a wavefront may span one trajectory or dozens."""
+    g, robot = gold("cost_spheres3d"), gold("panda_robot")
+    m = model("panda_arm_no_gripper")
+    spec = panda_cost_spec(g, robot)
+    h, cm = ops.ModelHandle(m), ops.CostHandle(spec, DEV)
+    rng = np.random.default_rng(T + H)
+    lo, hi = np.asarray(m.lower[m.dof_idx >= 0], np.float32), np.asarray(m.upper[m.dof_idx >= 0], np.float32)
+    lo, hi = lo[np.argsort(m.dof_idx[m.dof_idx >= 0])], hi[np.argsort(m.dof_idx[m.dof_idx >= 0])]
+    S = 14                                                       # positions + velocities, like the planners' states
+    x = np.zeros((T, H, S), np.float32)
+    base = rng.uniform(lo * 0.5, hi * 0.5, size=(T, 1, 7))
+    x[..., :7] = np.clip(base + np.cumsum(rng.standard_normal((T, H, 7)) * 0.01, axis=1), lo + 1e-3, hi - 1e-3)
+    x[..., 7:] = rng.standard_normal((T, H, 7)) * 100.0          # velocities are not positions: never tested against the limits
+    viol = rng.random(T) < 0.2                                   # a way point outside the limits, somewhere (also the last one)
+    for t in np.nonzero(viol)[0]:
+        hh, d = (H - 1 if t % 3 == 0 else rng.integers(0, H)), rng.integers(0, 7)
+        x[t, hh, d] = hi[d] + 0.01 if t % 2 else (np.nan if t % 5 == 0 else lo[d] - 0.01)
+    xt = torch.as_tensor(x, device=DEV)
+    qmin, qmax = torch.as_tensor(lo, device=DEV), torch.as_tensor(hi, device=DEV)
+    fields = FIELD_SELF | FIELD_OBJECTS | FIELD_WS
+    wp0 = ops.rollout_collision_via(h, cm, fields, xt, n_interp, margin=0.0)
+    wp1, buf = ops.rollout_collision_via(h, cm, fields, xt, n_interp, margin=0.0, limits=(qmin, qmax))
+    assert torch.equal(wp0, wp1)
+    ref = ops.traj_validate(wp0, xt, 7, qmin, qmax)
+    got = ops.traj_validate(None, xt, 7, qmin, qmax, flags=buf)
+    assert torch.equal(ref.flags, got.flags)
+    expect = (wp0.any(1).to(torch.uint8) | (torch.as_tensor(viol, device=DEV).to(torch.uint8) << 1))
+    assert torch.equal(got.flags, expect)
+    assert ref.counts() == got.counts()
+    n = sum(got.counts())
+    assert n == T and torch.equal(ref.idx, got.idx) and torch.equal(ref.gathered.nan_to_num(7.0), got.gathered.nan_to_num(7.0))
+    # a cost model with nothing to test still reports the joint limits
+    s0 = _strip(spec, self_pairs=True, ws=True)
+    s0.objects = []
+    s0.validate()
+    cm0 = ops.CostHandle(s0, DEV)
+    wp2, buf2 = ops.rollout_collision_via(h, cm0, fields, xt, n_interp, margin=0.0, limits=(qmin, qmax))
+    assert not bool(wp2.any()) and torch.equal(ops.traj_validate(None, xt, 7, qmin, qmax, flags=buf2).flags,
+                                               torch.as_tensor(viol, device=DEV).to(torch.uint8) << 1)

@@ -327,6 +327,18 @@ def test_dual_panda_fp16_gp_full_size(ops, oracle_lib):
             assert rel_err(got, tot) < 1e-4 and rel_err(gotd, rgd_gp) < 1e-4
             # the collision / EE component inside the fp32 sum: a few fp32 ulps of the prior's terms (which are 1e5 x larger)
             assert (np.abs((got - rg_gp) - rg_ro.reshape(8, H, D)) <= 4e-7 * np.abs(tot) + 2e-6 * np.abs(rg_gp).max()).all()
+    # the two generated schedules of the fused launch at full size (round 6): one ARM per lane (k_rollout_gpa, forced here; the default
+    # for fp32 I/O) against one ROBOT per lane (what just ran) -- the same positions, gradients within one rounding of the stored type
+    import os
+    os.environ["TRK_GP_ARM_LANES"] = "1"
+    try:
+        sums_a = torch.zeros(ops.n_blocks(B * H), device=DEV)
+        apos, acost, agq, agqd = ops.rollout_gp_cost_grad(h, cm, w, qh, qdh, dt, sg, 1.0, cost_sum=sums_a, grad_dtype=torch.float32)
+    finally:
+        os.environ.pop("TRK_GP_ARM_LANES", None)
+    assert torch.equal(apos, fpos) and rel_err(acost.cpu().numpy(), fcost.cpu().numpy()) < 2e-6
+    assert rel_err(sums_a.cpu().numpy(), sums.cpu().numpy()) < 2e-6
+    assert rel_err(agq.cpu().numpy(), fgq.cpu().numpy()) < 2e-6 and rel_err(agqd.cpu().numpy(), fgqd.cpu().numpy()) < 2e-6
     # sharding invariance of the fused launch: the second half of the batch alone gives the same bits
     _, c_h, g_h, gd_h = ops.rollout_gp_cost_grad(h, cm, w, qh[B // 2:].contiguous(), qdh[B // 2:].contiguous(), dt, sg, 1.0, want_pos=False,
                                                   grad_dtype=torch.float32)

@@ -2,6 +2,8 @@
 (a) golden vectors produced by the reference itself and (b) the fp64 CPU oracle on fresh seeded inputs.
 
 Tolerances (fp32): |dH| <= 2e-6 * max(1,|t|), cost rel 1e-5, gradient rel 1e-4."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -950,11 +952,19 @@ def test_rollout_gp_fused_vs_fp64_oracle(ops, oracle_lib, ident):
                 if io == "f16" and gdt is None:
                     gs = ops.gp_grad_scale(dt, sigma, gw, float(np.abs(q64).max()), float(np.abs(qd64).max()), extra=float(np.abs(rg).max()))
                 nb = ops.n_blocks(B * H)
-                for use_spec in (True, False):
+                # the dual Panda has two generated schedules (round 6): one ROBOT per lane (k_rollout_gpt) and one ARM per lane
+                # (k_rollout_gpa: two lanes per sample, sphere scenes without arm-vs-arm pairs); the launch picks by I/O mode,
+                # TRK_GP_ARM_LANES forces either -- both are held to the oracle in every I/O mode
+                variants = [(True, None), (False, None)] + ([(True, "1"), (True, "0")] if ident == "dual_panda" else [])
+                for use_spec, arm_lanes in variants:
                     h.enable_specialized(use_spec)
+                    os.environ.pop("TRK_GP_ARM_LANES", None)
+                    if arm_lanes is not None:
+                        os.environ["TRK_GP_ARM_LANES"] = arm_lanes
                     sums = torch.zeros(nb, device=DEV)
                     pos, cost, gq, gqd = ops.rollout_gp_cost_grad(h, cm, wts, tq, tqd, dt, sigma, gw, cost_sum=sums, grad_dtype=gdt, grad_scale=gs)
-                    tag = (ident, B, H, wts, io, gdt, use_spec)
+                    os.environ.pop("TRK_GP_ARM_LANES", None)
+                    tag = (ident, B, H, wts, io, gdt, use_spec, arm_lanes)
                     assert cost.dtype == torch.float32 and pos.dtype == tq.dtype and gq.dtype == (gdt or tq.dtype) and gqd.dtype == gq.dtype
                     ptol = (2 * TOL_H if io == "f32" else 1e-3) * max(1.0, np.abs(rp).max())
                     assert np.abs(pos.float().cpu().numpy().reshape(rp.shape) - rp).max() < ptol, tag

@@ -49,6 +49,11 @@ wp_ = ops.rollout_collision_via(m_, cm_, FIELD_OBJECTS | FIELD_WS | FIELD_SELF, 
 qmin_, qmax_ = robot.q_min.to(dev).contiguous(), robot.q_max.to(dev).contiguous()
 t("  ops.traj_validate, no host read (flags + partition + gathers)", lambda: ops.traj_validate(wp_, q, 7, qmin_, qmax_), n=100)
 t("  ops.traj_validate + counts() (the one host read)", lambda: ops.traj_validate(wp_, q, 7, qmin_, qmax_).counts(), n=100)
+# round 6: the per-trajectory flags folded into the via-point launch (what get_trajs_collision_and_free runs now)
+t("  ops.rollout_collision_via(limits=...) (+ per-wavefront partial flags)", lambda: ops.rollout_collision_via(m_, cm_, FIELD_OBJECTS | FIELD_WS | FIELD_SELF, q, 5, margin=0.0, limits=(qmin_, qmax_)), n=100)
+_, fl_ = ops.rollout_collision_via(m_, cm_, FIELD_OBJECTS | FIELD_WS | FIELD_SELF, q, 5, margin=0.0, limits=(qmin_, qmax_))
+t("  ops.traj_validate(flags=...), no host read (partition + gathers)", lambda: ops.traj_validate(None, q, 7, qmin_, qmax_, flags=fl_), n=100)
+t("  ops.traj_validate(flags=...) + counts()", lambda: ops.traj_validate(None, q, 7, qmin_, qmax_, flags=fl_).counts(), n=100)
 
 # the same idiom through the dispatcher ops (torch.ops.trk.*; what torch.compile sees) and as a captured hipGraph
 ops._ALWAYS_DISPATCH = True

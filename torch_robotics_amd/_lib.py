@@ -31,7 +31,7 @@ EXPORTS = [
     "trk_sdf_points",
     "trk_point_set_create", "trk_point_set_destroy", "trk_point_set_size", "trk_point_set_is_specialized", "trk_fk_points", "trk_fk_points_backward",
     "trk_rollout_points_cost_grad", "trk_rollout_collision", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16", "trk_finite_difference", "trk_traj_diff_norm_sum",
-    "trk_interpolate_columns", "trk_interpolate_columns_backward", "trk_rollout_collision_via", "trk_traj_validate",
+    "trk_interpolate_columns", "trk_interpolate_columns_backward", "trk_rollout_collision_via", "trk_rollout_collision_via_flags", "trk_via_partial_flags_bytes", "trk_traj_validate",
     "trk_scale_rows", "trk_jtj", "trk_pack_sums", "trk_pack_sums_scratch_bytes", "trk_rollout_is_specialized", "trk_ik_gn_steps", "trk_rollout_gp_cost_grad",
     "trk_spec_register_module", "trk_spec_layout_stamp", "trk_last_dispatch", "trk_set_strict_specialized", "trk_rollout_points_is_specialized",
     "trk_handle_kind", "trk_mailbox_create", "trk_mailbox_ipc_handle", "trk_mailbox_connect", "trk_mailbox_send", "trk_mailbox_recv", "trk_mailbox_exchange", "trk_mailbox_status", "trk_mailbox_destroy",
@@ -151,6 +151,9 @@ def lib():
     L.trk_interpolate_columns.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
     L.trk_interpolate_columns_backward.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]
     L.trk_rollout_collision_via.argtypes = [vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, f32, vp, vp]
+    L.trk_rollout_collision_via_flags.argtypes = [vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]
+    L.trk_via_partial_flags_bytes.argtypes = [i64, i32, i32]
+    L.trk_via_partial_flags_bytes.restype = C.c_int64
     L.trk_traj_validate.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp, vp]
     L.trk_pack_sums.argtypes = [vp, vp, i32, f32, vp, vp, i64, i32, i32, vp, vp, vp]
     L.trk_pack_sums_scratch_bytes.argtypes = [i32, i32]
@@ -178,7 +181,7 @@ def lib():
     for name in EXPORTS:
         fn = getattr(L, name)        # AttributeError here = the library does not export the ABI
         if name not in ("trk_last_error", "trk_model_destroy", "trk_cost_model_destroy", "trk_point_set_destroy",
-                        "trk_pack_sums_scratch_bytes", "trk_mailbox_destroy"):
+                        "trk_pack_sums_scratch_bytes", "trk_mailbox_destroy", "trk_via_partial_flags_bytes"):
             fn.restype = C.c_int
     if L.trk_abi_version() != _abi.TRK_ABI_VERSION:
         raise TrkError("libtrk.so ABI version mismatch; rebuild it")

@@ -1439,7 +1439,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         E.raw("    const int64_t base = wblock * TRK_WAVE;")
         E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
         E.raw("    float q[D];")
-        E.raw("    if (A.via_n > 0) spec_load_q_via<D>(A, base, rows, lane, q);     // trajectory validation: interpolate the via points here")
+        E.raw("    unsigned via_slot = 0u;")
+        E.raw("    int64_t via_traj0 = 0;")
+        E.raw("    bool via_outside = false;")
+        E.raw("    if (A.via_n > 0) spec_load_q_via<D>(A, base, rows, lane, q, via_slot, via_traj0, via_outside);     // trajectory validation: interpolate the via points here")
         E.raw("    else spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
         E.raw("    spec_load_spheres_finish(lds_sph, lane, sph);")
         R = {}; t = {}; passv = {}
@@ -1454,6 +1457,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             _emit_fk_link(E, kin, int(kin.order[p]), R, t, passv, snap)
         emit_boolean_fields(E, t)
         E.raw("    if (lane < rows) A.coll_out[base + lane] = hit ? 1 : 0;")
+        E.raw("    if (A.via_n > 0 && A.via_partial) spec_via_partial_flags(A, wblock, via_traj0, via_slot, hit, via_outside, lane < rows, lane);     // wave-uniform")
         E.raw("}")
         out.extend(E.lines)
         out.append("")

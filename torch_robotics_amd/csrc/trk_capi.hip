@@ -1449,9 +1449,39 @@ int trk_rollout_collision(const TrkModel* m, const TrkCostModel* cm, int32_t fie
     return TRK_OK;
 }
 
+static int rollout_collision_via_impl(const TrkModel* m, const TrkCostModel* cm, int32_t fields, const float* x, int64_t n_traj,
+                                      int32_t horizon, int32_t state_dim, int32_t n_interp, const float* alpha, const float* beta,
+                                      float margin_override, uint8_t* in_collision, uint8_t* traj_flags, const float* q_min, const float* q_max,
+                                      trk_stream_t stream);
+
 int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t fields, const float* x, int64_t n_traj,
                               int32_t horizon, int32_t state_dim, int32_t n_interp, const float* alpha, const float* beta,
                               float margin_override, uint8_t* in_collision, trk_stream_t stream) {
+    return rollout_collision_via_impl(m, cm, fields, x, n_traj, horizon, state_dim, n_interp, alpha, beta, margin_override, in_collision,
+                                      nullptr, nullptr, nullptr, stream);
+}
+
+int64_t trk_via_partial_flags_bytes(int64_t n_traj, int32_t horizon, int32_t n_interp) {
+    if (n_traj < 0 || horizon < 2 || n_interp < 1) return 0;
+    const int64_t hi = (int64_t)(horizon - 1) * n_interp, n = n_traj * hi;
+    (void)n;
+    return n_traj * (hi / TRK_WAVE + 2);          // one byte per trajectory and wavefront that can hold samples of it
+}
+
+int trk_rollout_collision_via_flags(const TrkModel* m, const TrkCostModel* cm, int32_t fields, const float* x, int64_t n_traj,
+                                    int32_t horizon, int32_t state_dim, int32_t n_interp, const float* alpha, const float* beta,
+                                    float margin_override, const float* q_min, const float* q_max, uint8_t* in_collision,
+                                    uint8_t* traj_flags, trk_stream_t stream) {
+    if (!traj_flags || !q_min || !q_max)
+        return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision_via_flags: partial_flags (trk_via_partial_flags_bytes), q_min and q_max are required");
+    return rollout_collision_via_impl(m, cm, fields, x, n_traj, horizon, state_dim, n_interp, alpha, beta, margin_override, in_collision,
+                                      traj_flags, q_min, q_max, stream);
+}
+
+static int rollout_collision_via_impl(const TrkModel* m, const TrkCostModel* cm, int32_t fields, const float* x, int64_t n_traj,
+                                      int32_t horizon, int32_t state_dim, int32_t n_interp, const float* alpha, const float* beta,
+                                      float margin_override, uint8_t* in_collision, uint8_t* traj_flags, const float* q_min, const float* q_max,
+                                      trk_stream_t stream) {
     int rc = check_model(m, "trk_rollout_collision_via");
     if (rc) return rc;
     if (!cm) return fail(TRK_ERR_INVALID_ARG, "trk_rollout_collision_via: null cost model");
@@ -1466,7 +1496,8 @@ int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t
     if (!m->spec_enabled) return fail(TRK_ERR_UNSUPPORTED, "trk_rollout_collision_via: generated kernels are disabled for this model");
     const int use_default = std::isnan(margin_override) ? 1 : 0;
     fields = effective_fields(cm, fields);
-    if (!fields) {
+    // (the fused flags need the generated kernel even when no field has anything to test: the joint limits are looked at there)
+    if (!fields && !traj_flags) {
         TRK_HIP(hipMemsetAsync(in_collision, 0, (size_t)n, (hipStream_t)stream));
         g_last_dispatch = TRK_DISPATCH_NONE;
         return TRK_OK;
@@ -1487,6 +1518,7 @@ int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t
     a.coll_out = in_collision; a.coll_fields = fields; a.coll_use_default = use_default;
     a.coll_margin = use_default ? 0.0f : margin_override;
     a.via_alpha = alpha; a.via_beta = beta; a.via_n = n_interp; a.via_H = horizon; a.via_S = state_dim;
+    if (traj_flags) { a.via_partial = traj_flags; a.via_slots = trk_via_slots(hi); a.via_qmin = q_min; a.via_qmax = q_max; }
     e->launch_coll(e, a, base_is_identity(m), (hipStream_t)stream);
     TRK_HIP(last_launch_error());
     g_last_dispatch = TRK_DISPATCH_GENERATED;
@@ -1497,9 +1529,10 @@ int trk_traj_validate(const uint8_t* waypoint_collisions, const float* x, int64_
                       int32_t n_waypoints, int32_t n_dofs, const float* q_min, const float* q_max, int64_t inner,
                       uint8_t* flags, int64_t* idx, int32_t* counts, int32_t* counts_host, int32_t ticket, float* gathered,
                       trk_stream_t stream) {
-    if (n_traj < 0 || n_traj > 0x3fffffff || horizon < 1 || state_dim < 1 || n_waypoints < 0 || n_dofs < 0 || n_dofs > state_dim || inner < 0 ||
-        !counts || (n_dofs > 0 && (!q_min || !q_max)) ||
-        (n_traj > 0 && (!x || !flags || !idx || (n_waypoints > 0 && !waypoint_collisions))))
+    const bool have_flags = n_waypoints < 0;         // waypoint_collisions = the via-point launch's per-wavefront partial flags, -n_waypoints samples per trajectory
+    if (n_traj < 0 || n_traj > 0x3fffffff || horizon < 1 || state_dim < 1 || n_dofs < 0 || n_dofs > state_dim || inner < 0 ||
+        !counts || (!have_flags && n_dofs > 0 && (!q_min || !q_max)) ||
+        (n_traj > 0 && (!x || !flags || !idx || (n_waypoints != 0 && !waypoint_collisions))))
         return fail(TRK_ERR_INVALID_ARG, "trk_traj_validate: bad argument");      // n_traj == 0: only the (zero) counters are written
     if (inner > 0 && n_traj % inner) return fail(TRK_ERR_INVALID_ARG, "trk_traj_validate: n_traj is not a multiple of the inner batch");
     int rc = ensure_init();

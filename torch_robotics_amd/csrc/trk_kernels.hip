@@ -1611,16 +1611,44 @@ k_traj_flags(const uint8_t* __restrict__ wp, int Hi, const float* __restrict__ x
 //   rows [n_free, n_free + n_coll)       colliding                                          (tasks.py:256)
 //   rows [.., .. + n_out)                collision free but outside the limits              (tasks.py:278-281)
 // as int64 rows [t] (inner == 0) or [t / inner, t % inner] (a 4-D batch), like torch.argwhere; counts = {free, colliding, outside}.
+// partial != nullptr (round 6): the flags are first assembled from the per-wavefront bytes of the via-point launch
+// (trk_rollout_collision_via_flags; SpecArgs::via_partial: one short row per trajectory).
+#define TRK_PARTITION_LDS_FLAGS 32768
 __global__ void __launch_bounds__(1024)
-k_traj_partition(const uint8_t* __restrict__ flags, int64_t T, int64_t inner, int64_t* __restrict__ idx,
-                 int32_t* __restrict__ counts, int32_t* __restrict__ counts_host, int32_t ticket) {
+k_traj_partition(uint8_t* __restrict__ flags, const uint8_t* __restrict__ partial, int64_t hi, int n_slots, int64_t T, int64_t inner,
+                 int64_t* __restrict__ idx, int32_t* __restrict__ counts, int32_t* __restrict__ counts_host, int32_t ticket) {
     __shared__ int wsum[3][16];
+    __shared__ uint8_t sflags[TRK_PARTITION_LDS_FLAGS];          // the assembled flags of up to this many trajectories stay on the CU
     const int tid = threadIdx.x, lane = tid & (TRK_WAVE - 1), wave = tid / TRK_WAVE;
     const int64_t chunk = (T + 1023) / 1024;
     const int64_t t0 = min(T, (int64_t)tid * chunk), t1 = min(T, t0 + chunk);
+    const bool in_lds = partial != nullptr && T <= TRK_PARTITION_LDS_FLAGS;
+    if (partial) {
+        // phase 0: the flags, assembled cooperatively (consecutive threads take consecutive trajectories): trajectory t is covered by the
+        // wavefronts floor(t hi / 64) .. floor(((t + 1) hi - 1) / 64), whose bytes are the first entries of its row of K = hi / 64 + 2
+        const int64_t K = hi / TRK_WAVE + 2;
+        for (int64_t t = tid; t < T; t += 1024) {
+            const int nj = (int)(((t + 1) * hi - 1) / TRK_WAVE - t * hi / TRK_WAVE) + 1;
+            const uint8_t* row = partial + t * K;
+            int f = 0;
+            if (K <= 8) {                       // the common case (up to 384 samples per trajectory): the whole row in flight at once
+                uint8_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = row[k < nj ? k : 0];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f |= v[k];
+            } else {
+                for (int k = 0; k < nj; ++k) f |= row[k];
+            }
+            flags[t] = (uint8_t)f;
+            if (in_lds) sflags[t] = (uint8_t)f;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     int c[3] = {0, 0, 0};
     for (int64_t t = t0; t < t1; ++t) {
-        const int f = flags[t];
+        const int f = in_lds ? sflags[t] : flags[t];
         c[0] += f == 0; c[1] += f & 1; c[2] += f == 2;
     }
     int incl[3];
@@ -1646,7 +1674,7 @@ k_traj_partition(const uint8_t* __restrict__ flags, int64_t T, int64_t inner, in
     off[1] += tot[0]; off[2] += tot[0] + tot[1];
     const int cols = inner > 0 ? 2 : 1;
     for (int64_t t = t0; t < t1; ++t) {
-        const int f = flags[t];
+        const int f = in_lds ? sflags[t] : flags[t];
         int64_t* dst = idx + (int64_t)(f == 0 ? off[0]++ : ((f & 1) ? off[1]++ : off[2]++)) * cols;
         if (inner > 0) { dst[0] = t / inner; dst[1] = t % inner; }
         else dst[0] = t;
@@ -2384,8 +2412,12 @@ void trk_launch_interpolate(const float* x, int64_t T, int H, int D, int n_inter
 void trk_launch_traj_validate(const uint8_t* wp, const float* x, int64_t T, int H, int S, int Hi, int D, const float* qmin,
                               const float* qmax, int64_t inner, uint8_t* flags, int64_t* idx, int32_t* counts,
                               int32_t* counts_host, int32_t ticket, float* gathered, hipStream_t st) {
-    if (T > 0) hipLaunchKernelGGL(k_traj_flags, dim3(grid_for(T, 4)), dim3(256), 0, st, wp, Hi, x, H, S, D, qmin, qmax, T, flags);
-    hipLaunchKernelGGL(k_traj_partition, dim3(1), dim3(1024), 0, st, flags, T, inner, idx, counts, counts_host, ticket);   // T == 0: zeros + ticket
+    // Hi < 0: wp holds the per-wavefront partial flags of the via-point launch for trajectories of -Hi interpolated configurations
+    const bool have_partial = Hi < 0;
+    const int64_t hi = have_partial ? -(int64_t)Hi : 1;
+    if (T > 0 && !have_partial) hipLaunchKernelGGL(k_traj_flags, dim3(grid_for(T, 4)), dim3(256), 0, st, wp, Hi, x, H, S, D, qmin, qmax, T, flags);
+    hipLaunchKernelGGL(k_traj_partition, dim3(1), dim3(1024), 0, st, flags, have_partial ? wp : nullptr, hi, trk_via_slots(hi), T, inner, idx, counts,
+                       counts_host, ticket);   // T == 0: zeros + ticket
     if (gathered && T > 0) hipLaunchKernelGGL(k_traj_gather, dim3((unsigned)T), dim3(128), 0, st, x, H * S, inner > 0 ? 2 : 1, idx, inner, gathered);
 }
 

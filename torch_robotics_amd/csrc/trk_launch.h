@@ -75,6 +75,8 @@ void trk_launch_finite_difference(const float* x, int64_t B, int H, int D, float
 void trk_launch_traj_diff_norm_sum(const float* x, int64_t B, int H, int S, int c0, int D, float* out, hipStream_t st);
 void trk_launch_reduce_sum(const float* x, int64_t n, float* out, hipStream_t st);
 void trk_launch_sdf_points(const DevCostHdr& C, const float* pts, int64_t n, float* sdf, float* grad, hipStream_t st);
+// trajectories that 64 consecutive samples can touch when a trajectory has `hi` samples: floor((hi - 1 + 63) / hi) + 1 (SpecArgs::via_slots)
+inline int trk_via_slots(int64_t hi) { return (int)((hi + 62) / hi) + 1; }
 // raises the dynamic-LDS ceiling of every kernel once (gfx950: 160 KiB per workgroup)
 int trk_kernels_init(void);
 // trk_capi.hip's error string / initialisation, for the other translation units of the library

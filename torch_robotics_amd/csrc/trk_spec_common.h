@@ -61,6 +61,14 @@ struct SpecArgs {
     const float* via_alpha; const float* via_beta;   // DEVICE [via_n]
     int32_t via_n;                // interpolated points per segment; 0 = q holds the configurations themselves
     int32_t via_H, via_S;         // way points per trajectory, floats per way point (>= D)
+    // round 6 (trk_rollout_collision_via_flags): the per-trajectory flags of trk_traj_validate folded into the via-point launch --
+    // bit 0: some interpolated configuration of the trajectory collides, bit 1: some joint position of its way points lies outside
+    // [via_qmin, via_qmax] (NaN = outside).  A trajectory of hi samples is covered by at most K = hi / 64 + 2 wavefronts; wavefront w
+    // writes what IT has seen of trajectory t to via_partial[t K + (w - floor(t hi / 64))] -- plain stores, every byte a reader looks at
+    // is written on every launch: no atomics, nothing to zero.  k_traj_partition ORs a trajectory's bytes (one short row).
+    uint8_t* via_partial;         // nullable
+    int32_t via_slots; int32_t _pad_via;      // trajectories 64 consecutive samples can touch (trk_via_slots)
+    const float* via_qmin; const float* via_qmax;    // DEVICE [D]
     // fp16 q (io_f16 != 0): the gradient is multiplied by grad_scale (fp32) before it is stored, an fp16 store saturates at
     // +-65504 instead of writing inf ("loss scaling": config 5's GP term reaches 1e5 .. 1e6 at sigma_gp = 0.1, dt = 5/128)
     float grad_scale;
@@ -122,7 +130,7 @@ typedef void (*SpecIkGnLaunchFn)(const SpecEntry* self, const IkGnArgs& args, in
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 23)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 24)
 
 #ifndef __HIPCC_RTC__
 struct SpecEntry {
@@ -450,7 +458,8 @@ __device__ __forceinline__ void spec_load_q(const IO* __restrict__ q, int64_t ba
 // once like the reference's `a * alpha + b * (1 - alpha)` (trajectory/utils.py:47-49).  Neighbouring lanes read the same or
 // adjacent way points, so the 2 D dword loads per lane are served by a few cache lines per wavefront.
 template <int D>
-__device__ __forceinline__ void spec_load_q_via(const SpecArgs& A, int64_t base, int rows, int lane, float (&qv)[D]) {
+__device__ __forceinline__ void spec_load_q_via(const SpecArgs& A, int64_t base, int rows, int lane, float (&qv)[D], unsigned& slot, int64_t& traj0,
+                                                bool& outside) {
     const unsigned hi = (unsigned)(A.via_H - 1) * (unsigned)A.via_n;          // interpolated configurations per trajectory
     const int64_t t0 = base / hi;                                             // wave-uniform: one 64-bit division per wavefront
     const unsigned r = (unsigned)(base - t0 * hi) + (unsigned)lane;
@@ -459,8 +468,54 @@ __device__ __forceinline__ void spec_load_q_via(const SpecArgs& A, int64_t base,
     const bool on = lane < rows;
     const float* p0 = static_cast<const float*>(A.q) + ((t0 + dt) * A.via_H + i) * (int64_t)A.via_S;
     const float fa = on ? A.via_alpha[a] : 0.0f, fb = on ? A.via_beta[a] : 0.0f;
+    float pa[D], pb[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) qv[j] = on ? __fadd_rn(__fmul_rn(p0[j], fa), __fmul_rn(p0[A.via_S + j], fb)) : 0.0f;
+    for (int j = 0; j < D; ++j) { pa[j] = on ? p0[j] : 0.0f; pb[j] = on ? p0[A.via_S + j] : 0.0f; }
+#pragma unroll
+    for (int j = 0; j < D; ++j) qv[j] = on ? __fadd_rn(__fmul_rn(pa[j], fa), __fmul_rn(pb[j], fb)) : 0.0f;
+    slot = dt;                          // this lane's trajectory, counted from the wavefront's first one
+    traj0 = t0;
+    outside = false;
+    if (A.via_partial) {                // wave-uniform: the joint-limit test of tasks.py:270-273 on way points this lane has loaded anyway.  Every
+                                        // way point but a trajectory's last is the START of a segment: all lanes test theirs; the last one is
+                                        // the END of the last segment -- tested only by the wavefronts that hold such a segment (wave-uniform
+                                        // branch: one wavefront in ~60).  "v outside [lo, hi] or NaN" == "the BITS of clamp(v) differ from v's"
+                                        // (v_med3 returns a bound for a NaN input; the generated units are compiled with -fno-honor-nans, so
+                                        // no floating-point comparison is asked about a NaN): three instructions per value
+        unsigned acc = 0u;
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            acc |= __float_as_uint(__builtin_amdgcn_fmed3f(pa[j], cptr(A.via_qmin)[j], cptr(A.via_qmax)[j])) ^ __float_as_uint(pa[j]);
+        const bool last_seg = on && i == (unsigned)(A.via_H - 2);
+        if (__builtin_amdgcn_ballot_w64(last_seg) != 0ull) {
+            unsigned accb = 0u;
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                accb |= __float_as_uint(__builtin_amdgcn_fmed3f(pb[j], cptr(A.via_qmin)[j], cptr(A.via_qmax)[j])) ^ __float_as_uint(pb[j]);
+            acc |= last_seg ? accb : 0u;
+        }
+        outside = acc != 0u && on;
+    }
+}
+// The wavefront's share of the per-trajectory flags (see SpecArgs::via_partial): the byte of slot s -- trajectory t = traj0 + s, traj0 = the
+// trajectory of the wavefront's first sample -- is written by lane s, and only when the wavefront holds samples of that trajectory.  The
+// loop is wave-uniform (two trips when a trajectory has >= 64 interpolated configurations).
+__device__ __forceinline__ void spec_via_partial_flags(const SpecArgs& A, int64_t wblock, int64_t traj0, unsigned slot, bool hit, bool outside,
+                                                       bool on, int lane) {
+    const unsigned long long hm = __builtin_amdgcn_ballot_w64(on && hit), om = __builtin_amdgcn_ballot_w64(on && outside);
+    unsigned mine = 0u;
+    bool have = false;
+    for (int s = 0; s < A.via_slots; ++s) {
+        const unsigned long long grp = __builtin_amdgcn_ballot_w64(on && slot == (unsigned)s);
+        const unsigned bits = ((hm & grp) ? 1u : 0u) | ((om & grp) ? 2u : 0u);
+        mine = lane == s ? bits : mine;
+        have = lane == s ? grp != 0ull : have;
+    }
+    if (have) {
+        const int64_t hi = (int64_t)(A.via_H - 1) * A.via_n;
+        const int64_t t = traj0 + lane;                                      // lane == slot here
+        A.via_partial[t * (hi / TRK_WAVE + 2) + (wblock - ((t * hi) >> 6))] = (uint8_t)mine;
+    }
 }
 
 // spec_load_q in two halves: `issue` starts the wave's 16-byte loads (held in registers, nothing waits), `finish` runs the LDS
@@ -1170,6 +1225,9 @@ __device__ __forceinline__ float spec_object_cost_uniform_point(const DevCostHdr
 // reference's sqrt could flip the comparison -- re-evaluates that point with IEEE sqrt object by object, so the byte equals
 // the table-driven kernel's (and the oracle's) on every input.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef TRK_COLL_FAST_SPHERES
+#define TRK_COLL_FAST_SPHERES 1      // 0: experiment / A-B -- every scene takes the ranking path with the arg-min index
+#endif
 template <int NL>
 __device__ __forceinline__ bool spec_collision_links(const DevCostHdr& C, int fields, float margin, int use_default,
                                                      const float (&px)[NL], const float (&py)[NL], const float (&pz)[NL],
@@ -1178,7 +1236,42 @@ __device__ __forceinline__ bool spec_collision_links(const DevCostHdr& C, int fi
     float mg[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) mg[l] = use_default ? cptr(C.obj_link_margin)[mbase + l] : margin;
-    if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
+    if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0 && scene_is_fast(C) && TRK_COLL_FAST_SPHERES) {
+        // Round 6 -- a scene of <= 16 spheres of one radius r and nothing else (wave-uniform): the boolean needs the nearest sphere's
+        // DISTANCE, not the sphere.  min_c |p - c|^2 = min_c (p.(-2c) + |c|^2) + |p|^2: the ranking keys without an index riding in
+        // their mantissas (no v_and_or per sphere and point), no gather of the winner's centre, no second evaluation -- and the test
+        // d < margin + r in squared form.  A lane within 1e-5 of its threshold (in d: |d^2 - thr^2| = (d + thr) |d - thr|) re-evaluates
+        // object by object with IEEE sqrt exactly like the general path below, so the byte is the same on every input.
+        float bk[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) bk[l] = __builtin_inff();
+        const TRK_CAS float* tab = cptr(C.sphere_pairs);
+        for (int j = 0; j < C.n_sphere_pairs; ++j) {
+            const F8 rec = load_f8_uniform(tab, j);
+            const trk_f2 cx = {rec.v[0], rec.v[1]}, cy = {rec.v[2], rec.v[3]}, cz = {rec.v[4], rec.v[5]}, cw = {rec.v[6], rec.v[7]};
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const trk_f2 key = __builtin_elementwise_fma(trk_f2{px[l], px[l]}, cx,
+                                   __builtin_elementwise_fma(trk_f2{py[l], py[l]}, cy,
+                                   __builtin_elementwise_fma(trk_f2{pz[l], pz[l]}, cz, cw)));
+                bk[l] = __builtin_fminf(bk[l], __builtin_fminf(key.x, key.y));
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const float thr = mg[l] + C.sphere_r;                          // wave-uniform
+            const float d2 = fmaf(px[l], px[l], fmaf(py[l], py[l], fmaf(pz[l], pz[l], bk[l])));
+            bool h = thr > 0.0f && d2 < thr * thr;
+            if (__builtin_fabsf(d2 - thr * thr) < 2.5e-5f * __builtin_fmaxf(thr, 0.04f) || !(thr > 1e-4f)) {      // rare: exact, object by object
+                h = false;
+                for (int o = 0; o < C.n_objects; ++o) {
+                    float gx, gy, gz;
+                    h |= object_sdf<true>(C, o, px[l], py[l], pz[l], gx, gy, gz) < mg[l];
+                }
+            }
+            hit |= h;
+        }
+    } else if ((fields & TRK_FIELD_OBJECTS) && C.n_objects > 0) {
         float s[NL], ax[NL], ay[NL], az[NL];
         NoTick nt;
         scene_min_sdf<NL, const NoTick&, false>(C, px, py, pz, s, ax, ay, az, nt, lds_spheres);

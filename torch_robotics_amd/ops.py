@@ -1232,10 +1232,13 @@ def via_point_weights(num_interpolation: int, device) -> tuple:
 
 
 def rollout_collision_via(model: ModelHandle, cm: CostHandle, fields: int, trajs: torch.Tensor, num_interpolation: int,
-                          margin: Optional[float] = None) -> Optional[torch.Tensor]:
+                          margin: Optional[float] = None, limits=None):
     """Boolean collision fields on the interpolated via points of trajs (T, H, S >= D) without materialising them:
     -> bool (T, (H-1) * num_interpolation), or None when no generated kernel serves this model / cost model (the caller then
-    interpolates first).  tasks.py:244-251."""
+    interpolates first).  tasks.py:244-251.
+    limits=(q_min, q_max) (float32 device vectors of n_dofs): the launch also folds the per-trajectory flags of `traj_validate` --
+    bit 0 some via point collides, bit 1 some way point lies outside the limits -- and the result is (bool tensor, flags buffer): hand
+    the buffer to `traj_validate(..., flags=...)`, which then skips its own flags launch."""
     x = _dev_f32(trajs, "rollout_collision_via(trajs)")
     T, H, S = (int(v) for v in x.shape)
     if S < model.n_dofs:
@@ -1243,13 +1246,25 @@ def rollout_collision_via(model: ModelHandle, cm: CostHandle, fields: int, trajs
     n = int(num_interpolation)
     alpha, beta = via_point_weights(n, x.device)
     out = torch.empty((T, (H - 1) * n), device=x.device, dtype=torch.bool)
+    m = float("nan") if margin is None else float(margin)
     with _on(x.device):
-        rc = lib().trk_rollout_collision_via(model._h, cm._h, int(fields), x.data_ptr(), T, H, S, n, alpha.data_ptr(), beta.data_ptr(),
-                                             float("nan") if margin is None else float(margin), out.data_ptr(), _stream(x))
+        if limits is None:
+            rc = lib().trk_rollout_collision_via(model._h, cm._h, int(fields), x.data_ptr(), T, H, S, n, alpha.data_ptr(), beta.data_ptr(),
+                                                 m, out.data_ptr(), _stream(x))
+        else:
+            q_min, q_max = limits
+            _check_buffer(q_min, model.n_dofs, torch.float32, x.device, "rollout_collision_via(q_min)")
+            _check_buffer(q_max, model.n_dofs, torch.float32, x.device, "rollout_collision_via(q_max)")
+            # [counts 16 B | pad 16 B | flags T, padded to 16 | per-wavefront partial flags]: the layout traj_validate carries on with
+            nb = int(lib().trk_via_partial_flags_bytes(T, H, n))
+            small = torch.empty(32 + (T + 15) // 16 * 16 + nb, device=x.device, dtype=torch.uint8)
+            rc = lib().trk_rollout_collision_via_flags(model._h, cm._h, int(fields), x.data_ptr(), T, H, S, n, alpha.data_ptr(), beta.data_ptr(),
+                                                       m, q_min.data_ptr(), q_max.data_ptr(), out.data_ptr(),
+                                                       small.data_ptr() + 32 + (T + 15) // 16 * 16, _stream(x))
     if rc == _abi.TRK_ERR_UNSUPPORTED:
         return None
-    check(rc, "trk_rollout_collision_via")
-    return out
+    check(rc, "trk_rollout_collision_via" + ("" if limits is None else "_flags"))
+    return out if limits is None else (out, (small, (H - 1) * n))
 
 
 class _PinnedCounters:
@@ -1297,27 +1312,36 @@ class TrajPartition:
         return self._host
 
 
-def traj_validate(waypoint_collisions: torch.Tensor, trajs: torch.Tensor, n_dofs: int, q_min: torch.Tensor, q_max: torch.Tensor,
-                  inner: int = 0, gather: bool = True) -> TrajPartition:
+def traj_validate(waypoint_collisions: Optional[torch.Tensor], trajs: torch.Tensor, n_dofs: int, q_min: torch.Tensor, q_max: torch.Tensor,
+                  inner: int = 0, gather: bool = True, flags: Optional[torch.Tensor] = None) -> TrajPartition:
     """Per-trajectory flags, the stable [free | colliding | outside-limits] partition (`idx`: int64 (T, 1 | 2)) and the
     trajectories gathered in that order (`gathered`: (T, H, S)) -- tasks.py:253-299 -- queued as three launches with no host
     synchronisation.  waypoint_collisions (T, W) bool / uint8; trajs (T, H, S) float32 contiguous; q_min / q_max float32
-    (n_dofs,) on the same device."""
+    (n_dofs,) on the same device.
+    flags: the buffer `rollout_collision_via(..., limits=...)` returned -- the flags are then an input and two launches remain
+    (waypoint_collisions is not read and may be None)."""
     x = trajs
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3):
         x = _dev_f32(trajs, "traj_validate(trajs)")
         if x.dim() != 3:
             raise ValueError("traj_validate: trajs must be (T, H, S)")
     T, H, S = x.shape
-    wp = waypoint_collisions
-    if wp.device != x.device or wp.element_size() != 1 or not wp.is_contiguous() or wp.numel() % max(T, 1):
-        raise ValueError("traj_validate: waypoint_collisions must be a contiguous 1-byte tensor (T, W) on the trajectories' device")
-    W = wp.numel() // max(T, 1)
     _check_buffer(q_min, int(n_dofs), torch.float32, x.device, "traj_validate(q_min)")
     _check_buffer(q_max, int(n_dofs), torch.float32, x.device, "traj_validate(q_max)")
     r = TrajPartition()
-    r._small = torch.empty(T + 32, device=x.device, dtype=torch.uint8)          # [counts 16 B | pad | flags T]
-    r.flags = r._small[32:]
+    if flags is not None:
+        buf, hi = flags
+        if buf.device != x.device or buf.dtype != torch.uint8 or buf.numel() < 32 + (T + 15) // 16 * 16 or hi < 1:
+            raise ValueError("traj_validate(flags): expected what rollout_collision_via(..., limits=...) returned for these trajectories")
+        # the per-wavefront partial flags ride in as `waypoint_collisions`, n_waypoints = -(samples per trajectory)
+        wp_ptr, W, r._small = buf.data_ptr() + 32 + (T + 15) // 16 * 16, -int(hi), buf
+    else:
+        wp = waypoint_collisions
+        if wp.device != x.device or wp.element_size() != 1 or not wp.is_contiguous() or wp.numel() % max(T, 1):
+            raise ValueError("traj_validate: waypoint_collisions must be a contiguous 1-byte tensor (T, W) on the trajectories' device")
+        wp_ptr, W = wp.data_ptr(), wp.numel() // max(T, 1)
+        r._small = torch.empty(T + 32, device=x.device, dtype=torch.uint8)      # [counts 16 B | pad | flags T]
+    r.flags = r._small[32:32 + T]
     r.idx = torch.empty((T, 2 if inner else 1), device=x.device, dtype=torch.int64)
     r.gathered = torch.empty((T, H, S), device=x.device, dtype=torch.float32) if gather else None
     r._host = None
@@ -1325,7 +1349,7 @@ def traj_validate(waypoint_collisions: torch.Tensor, trajs: torch.Tensor, n_dofs
     base = r._small.data_ptr()
     with _on(x.device):
         r._stream = torch.cuda.current_stream(x.device)
-        check(lib().trk_traj_validate(wp.data_ptr(), x.data_ptr(), T, H, S, W, int(n_dofs), q_min.data_ptr(), q_max.data_ptr(),
+        check(lib().trk_traj_validate(wp_ptr, x.data_ptr(), T, H, S, W, int(n_dofs), q_min.data_ptr(), q_max.data_ptr(),
                                       int(inner), base + 32, r.idx.data_ptr(), base, slot_ptr, r._ticket, _ptr(r.gathered),
                                       r._stream.cuda_stream), "trk_traj_validate")
     return r

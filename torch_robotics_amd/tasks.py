@@ -287,13 +287,22 @@ class PlanningTask(Task):
     # ---------------------------------------------------------------------------------------------
     def _waypoint_collisions(self, flat, num_interpolation):
         """bool (T, W) for trajectories flat (T, H, S): margin 0 on the interpolated via points (tasks.py:244-251)."""
+        return self._waypoint_collisions_and_flags(flat, num_interpolation)
+
+    def _waypoint_collisions_and_flags(self, flat, num_interpolation, limits=None):
+        """`_waypoint_collisions`; with limits=(q_min, q_max): -> (bool (T, W), flags or None) -- the per-trajectory flags folded into
+        the same launch when a generated kernel serves the call (ops.rollout_collision_via)."""
         if self._has_tree and self._points(flat.device) is None and num_interpolation > 0 and flat.shape[1] >= 2:
             model, cm = self._fused_handles(flat.device)
             fields = FIELD_OBJECTS | FIELD_WS | (FIELD_SELF if self.df_collision_self is not None else 0)
-            wp = ops.rollout_collision_via(model, cm, fields, flat, num_interpolation, margin=0.)
-            if wp is not None:
-                return wp
-        return self.compute_collision(ops.interpolate_traj_via_points(flat, num_interpolation=num_interpolation), margin=0.)
+            res = ops.rollout_collision_via(model, cm, fields, flat, num_interpolation, margin=0.,
+                                            limits=limits if (limits is not None and limits[0].numel() == model.n_dofs) else None)
+            if res is not None:
+                if limits is None:
+                    return res
+                return res if isinstance(res, tuple) else (res, None)
+        wp = self.compute_collision(ops.interpolate_traj_via_points(flat, num_interpolation=num_interpolation), margin=0.)
+        return wp if limits is None else (wp, None)
 
     @ops.host_round_trip
     def get_trajs_collision_and_free(self, trajs, return_indices=False, num_interpolation=5):
@@ -304,13 +313,17 @@ class PlanningTask(Task):
         flat = trajs.detach().reshape(-1, H, S)
         if flat.dtype != torch.float32 or not flat.is_contiguous():
             flat = flat.to(torch.float32).contiguous()
-        wp = self._waypoint_collisions(flat, num_interpolation)
         lim = getattr(self, "_q_lim", None)             # the limits as fp32 device vectors, keyed by the tensors they came from
         if lim is None or lim[0] is not self.robot.q_min or lim[1] is not self.robot.q_max or lim[2].device != flat.device:
             lim = self._q_lim = (self.robot.q_min, self.robot.q_max,
                                  self.robot.q_min.to(flat.device, torch.float32).contiguous(),
                                  self.robot.q_max.to(flat.device, torch.float32).contiguous())
-        part = ops.traj_validate(wp, flat, self.robot.q_dim, lim[2], lim[3], inner=lead[1] if batched else 0)
+        # round 6: the via-point launch also produces the per-trajectory flags (collision, joint limits) -- one launch less
+        if type(self)._waypoint_collisions is PlanningTask._waypoint_collisions:
+            wp, flags = self._waypoint_collisions_and_flags(flat, num_interpolation, limits=(lim[2], lim[3]))
+        else:                                           # a subclass supplies the way-point collisions itself: the three-launch form
+            wp, flags = self._waypoint_collisions(flat, num_interpolation), None
+        part = ops.traj_validate(wp, flat, self.robot.q_dim, lim[2], lim[3], inner=lead[1] if batched else 0, flags=flags)
         n_free, n_coll, n_out = part.counts()                                   # the one host synchronisation
         # the partition is [free | colliding | collision free but outside the limits]; the reference's second list is
         # "colliding, then the limit violators" -- except that it is only the violators when no trajectory is free although
