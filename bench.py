@@ -13,7 +13,8 @@ One step = one pass of the hot path over one batch of synthetic joint trajectori
       (read q, write link positions, cost and d cost / d q).  `--scene grid|shelf|maze` are SURVEY 8(d)'s secondary runs.
   c3 (configs[2]'s objective stack): the same + self-collision pairs + workspace box; 32768 x 64 is 8 ranks x this.
   c4 (configs[3]): UR10 + Allegro hand (30 links / 22 DOF), 4096 x 64, "FK + Jacobian + cost": the fused rollout (FK, obstacle + EE
-      cost, gradient, link positions) and the geometric Jacobian of `ee_link` (`trk_fk_jacobian`) -- two launches per step.
+      cost, gradient, link positions) and the geometric Jacobian of `ee_link` in ONE launch (`trk_rollout_jacobian_cost_grad`: the
+      columns are read out of the poses the rollout holds; `--two-launch` = the rollout, then `trk_fk_jacobian`: rounds 2 - 5).
   c5 (configs[4]): dual Panda (23 links / 14 DOF), horizon 128, fp16 q / qd / link positions / gradients in HBM with fp32 arithmetic
       and cost, GP-smoothness (sigma_gp = 0.1, dt = 5 / 128) + obstacle + EE on both arms; 2048 trajectories per GPU -- at
       `--gpus 4` the global batch is BASELINE's 8192.  ONE launch per step (`trk_rollout_gp_cost_grad`: q / qd read once, gq / gqd
@@ -36,7 +37,7 @@ is none either).  The whole measurement is rehearsed once and discarded first.
 Launch mode: the step loop is captured -- every run of consecutive steps between two exchanges is replayed as hipGraphs of at most
 `--graph` (default 100) evaluations, each graph captured once per (plan, length) from the same pre-bound C-ABI calls and launched
 once before any timed region.  W and K are exact (a remainder gets a graph of its own).  `--graph 0` = the eager loop, one call per step
-(the default for c4, whose two-kernel step measured slower captured).
+(the default for a step of more than one launch: c4 / c5 with `--two-launch` measured slower captured).
 
 Prints ONE JSON line (rank 0).  `roofline` describes the step's dominant kernel (the fused rollout): `achieved` = its algorithmic
 bytes/sample x samples per launch / its average launch duration (HIP events on the launch stream: around the timed region when
@@ -94,7 +95,8 @@ def parse_args(argv):
                          "figure `independent_batches`; off by default so that a rocprofv3 run of the default command sees only "
                          "back-to-back launches of one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--two-launch", action="store_true", help="c5: the round-3 form (fp16 rollout, then the GP prior accumulated) instead of the fused launch")
+    ap.add_argument("--two-launch", action="store_true", help="c5: the round-3 form (fp16 rollout, then the GP prior accumulated) instead of the fused launch; "
+                                                              "c4: the fused rollout, then the Jacobian kernel, instead of the one-launch form")
     ap.add_argument("--no-out-of-cache", action="store_true", help="skip the secondary beyond-the-Infinity-Cache measurement (c2, N = 1)")
     ap.add_argument("--dist-backend", default="nccl", help="debug: 'gloo' + --single-device lets the N>1 control flow run on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="debug: every rank uses cuda:0")
@@ -255,14 +257,24 @@ def build_workload(args, tra, ops, torch, dev, rank):
         scene_text = "EnvSpheres3D, 10 spheres, analytic SDF"
         if args.config == "c4":
             q = ((torch.rand(B, H, D, generator=gen, **ta) - 0.5) * 3.0).contiguous()
-            wl.plan = ops.RolloutPlan(model, cm, weights, q, want_pos=not args.no_pos)
             ee = int(kin.name_to_idx["ee_link"])
-            jac = ops.JacobianPlan(model, q.reshape(B * H, D), ee)
-            wl.jac, wl.ee = jac, ee
-            wl.extras = [("geometric Jacobian of ee_link (trk_fk_jacobian: pos, quat, lin_jac, ang_jac)", jac.launch, 4 * D + 28 + 24 * D)]
+            wl.ee = ee
+            if args.two_launch or args.no_pos:
+                # the round-2 .. 5 form: the fused rollout, then the Jacobian kernel (a second walk of the chain, q read twice)
+                wl.plan = ops.RolloutPlan(model, cm, weights, q, want_pos=not args.no_pos)
+                jac = ops.JacobianPlan(model, q.reshape(B * H, D), ee)
+                wl.jac = jac
+                wl.extras = [("geometric Jacobian of ee_link (trk_fk_jacobian: pos, quat, lin_jac, ang_jac)", jac.launch, 4 * D + 28 + 24 * D)]
+                how = "then the geometric Jacobian of ee_link (two launches)"
+            else:
+                # ONE launch (trk_rollout_jacobian_cost_grad, round 6): the Jacobian's columns are read out of the poses the rollout holds
+                wl.plan = ops.RolloutJacobianPlan(model, cm, weights, q, ee)
+                wl.jac = wl.plan
+                wl.extra_bps = 28 + 24 * D                                # + pos, quat, lin_jac, ang_jac out (q is read once)
+                how = "and the geometric Jacobian of ee_link in the SAME launch"
             wl.metric = "FK+Jacobian+cost rollouts/sec (batch x horizon), UR10+Allegro 22-DOF"
             wl.text = (f"BASELINE configs[3]: UR10 + Allegro hand ({L} links, {D} DOF), batch={B} x horizon={H} per GPU, fused FK + "
-                       f"SDF-obstacle + EE-tracking cost + gradient + link positions ({scene_text}), then the geometric Jacobian of ee_link; "
+                       f"SDF-obstacle + EE-tracking cost + gradient + link positions ({scene_text}), {how}; "
                        f"q resident in HBM")
             wl.dtype = "f32"
         else:
@@ -782,6 +794,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src if traffic else None,
                      "kernel": ("fused rollout + GP prior (trk_rollout_gp_cost_grad)" if isinstance(plan, ops.RolloutGpPlan) else
+                                "fused rollout + geometric Jacobian (trk_rollout_jacobian_cost_grad)" if isinstance(plan, ops.RolloutJacobianPlan) else
                                 "fused rollout (trk_rollout_cost_grad%s)" % ("_f16" if wl.esz == 2 else "")),
                      "bytes_per_sample": bps, "launch_us": launch_s * 1e6,
                      # second bound: VALU instructions per wavefront (SQ_INSTS_VALU / SQ_WAVES of the same command)

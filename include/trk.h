@@ -431,6 +431,18 @@ int trk_rollout_cost_grad(const TrkModel* model, const TrkCostModel* cm, const T
                           float* link_pos_out, float* cost, float* gq, float* cost_block_sums,
                           trk_stream_t stream);
 
+/* BASELINE config 4's step -- "FK + Jacobian + cost" -- as ONE call: trk_rollout_cost_grad plus the stateful FK + geometric Jacobian
+ * of `link` (trk_fk_jacobian without velocities: pos [N,3], quat_wxyz [N,4], lin_jac / ang_jac [N,3,D], N = batch*horizon).
+ * reference: PlanningTask._compute_collision_or_cost tasks.py:139-232 followed by
+ * DifferentiableTree.compute_forward_kinematics_and_geometric_jacobian robot_tree.py:218-248 on the same q.
+ * ONE launch when a generated unit serves the cost model, `link` is the unit's tracked link, link_pos_out is given and the stateful
+ * walk coincides with the stateless one on the columns' chains (UR10 + Allegro: the Jacobian columns are read out of the poses the
+ * rollout already holds -- no second walk, q read once); otherwise the two launches, same results (trk_last_dispatch tells). */
+int trk_rollout_jacobian_cost_grad(const TrkModel* model, const TrkCostModel* cm, const TrkRolloutWeights* w, const float* q,
+                                   int64_t batch, int32_t horizon, int32_t link, float* link_pos_out, float* cost, float* gq,
+                                   float* cost_block_sums, float* pos, float* quat_wxyz, float* lin_jac, float* ang_jac,
+                                   trk_stream_t stream);
+
 /* 1 when trk_rollout_cost_grad(model, cm, w, ...) is served by a generated (model-specialised) kernel -- one whose baked
  * collision template equals the cost model's link sets for the terms `w` selects --, 0 when the table-driven kernel would run
  * (~10 x slower).  A deployment that must not fall back silently asserts this once after building its handles. */
@@ -443,7 +455,8 @@ enum {
     TRK_DISPATCH_NONE = 0,                  /* no rollout call yet on this thread (or a call that had nothing to launch) */
     TRK_DISPATCH_GENERATED = 1,             /* one launch of a generated (model-specialised) kernel */
     TRK_DISPATCH_TABLE = 2,                 /* the table-driven kernels */
-    TRK_DISPATCH_GENERATED_PLUS_PRIOR = 3   /* trk_rollout_gp_cost_grad only: generated rollout, the GP prior as launches of its own */
+    TRK_DISPATCH_GENERATED_PLUS_PRIOR = 3   /* trk_rollout_gp_cost_grad: generated rollout, the GP prior as launches of its own;
+                                             * trk_rollout_jacobian_cost_grad: generated rollout, the Jacobian as a launch of its own */
 };
 int trk_last_dispatch(void);
 /* trk_rollout_is_specialized for trk_rollout_points_cost_grad(ps->model, ps, cm, w, ...) (16-byte aligned point_pos_out assumed). */

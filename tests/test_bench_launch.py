@@ -89,7 +89,8 @@ def test_two_rank_config5_on_one_gpu_gloo():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,dtype,launches,extra", [("c4", "f32", 2, []), ("c5", "f16", 1, []), ("c5", "f16", 2, ["--two-launch"])])
+@pytest.mark.parametrize("cfg,dtype,launches,extra", [("c4", "f32", 1, []), ("c4", "f32", 2, ["--two-launch"]), ("c5", "f16", 1, []),
+                                                      ("c5", "f16", 2, ["--two-launch"])])
 def test_bench_configs_4_and_5_one_gpu(cfg, dtype, launches, extra):
     """`bench.py --config c4|c5` on one GPU: a driver-parsable line with the config's own bytes, the dominant kernel's roofline,
     the step's, and a CPU baseline from the oracle (incl. the Jacobian / the GP term)."""
@@ -99,7 +100,10 @@ def test_bench_configs_4_and_5_one_gpu(cfg, dtype, launches, extra):
     assert out["dtype"] == dtype and out["config"]["launches_per_step"] == launches and out["config"]["kernel"] == "specialized"
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["unit"] == "rollouts/s" and out["vs_baseline"] is None
     D, L, e = (22, 30, 4) if cfg == "c4" else (14, 23, 2)
-    assert out["roofline"]["bytes_per_sample"] == 2 * e * D + 3 * e * L + 4 + (4 * D if (cfg == "c5" and launches == 1) else 0)
+    # one-launch forms move the step's extra bytes in the dominant kernel: c5 qd in + gqd out, c4 pos / quat / lin_jac / ang_jac out
+    fused_extra = (4 * D if cfg == "c5" else 28 + 24 * D) if launches == 1 else 0
+    assert out["roofline"]["bytes_per_sample"] == 2 * e * D + 3 * e * L + 4 + fused_extra
+    assert ("Jacobian" in out["roofline"]["kernel"]) == (cfg == "c4" and launches == 1)
     assert 0 < out["roofline"]["frac"] < 1
     if launches > 1:
         assert 0 < out["roofline"]["step"]["frac"] < 1 and out["roofline"]["step"]["step_us"] >= out["roofline"]["launch_us"]
@@ -163,9 +167,12 @@ def test_launch_modes_graph_by_default_eager_on_request():
         seen[mode] = out["config"]["launch"]
     assert seen["graph"].startswith("hipGraph replays of <= 100") and seen["eager"].startswith("eager")
     assert seen["small graphs"].startswith("hipGraph replays of <= 4")
-    p = _run(["--config", "c4", "--steps", "10", "--warmup", "2", "--cpu-seconds", "0", "--batch", "256"], 600)
+    p = _run(["--config", "c4", "--two-launch", "--steps", "10", "--warmup", "2", "--cpu-seconds", "0", "--batch", "256"], 600)
     assert p.returncode == 0, p.stderr[-3000:]
     assert json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])["config"]["launch"].startswith("eager")
+    p = _run(["--config", "c4", "--steps", "10", "--warmup", "2", "--cpu-seconds", "0", "--batch", "256"], 600)      # one launch per step: captured
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])["config"]["launch"].startswith("hipGraph")
     # N > 1 code path (one rank, RCCL) in graph mode: the exchange sits between two replays inside the timed region
     p = _run(["--force-dist", "--exchange", "rccl", "--steps", "20", "--warmup", "5", "--cpu-seconds", "0", "--batch", "512"], 600)
     assert p.returncode == 0, p.stderr[-3000:]

@@ -186,3 +186,57 @@ def test_trajectory_flags_folded_into_the_via_launch(ops, T, H, n_interp):
     wp2, buf2 = ops.rollout_collision_via(h, cm0, fields, xt, n_interp, margin=0.0, limits=(qmin, qmax))
     assert not bool(wp2.any()) and torch.equal(ops.traj_validate(None, xt, 7, qmin, qmax, flags=buf2).flags,
                                                torch.as_tensor(viol, device=DEV).to(torch.uint8) << 1)
+
+
+@pytest.mark.parametrize("name,base_pose", [("ur10_allegro", False), ("ur10_allegro", True), ("panda", False)])
+def test_rollout_and_jacobian_in_one_launch(ops, name, base_pose):
+    """Round 6, BASELINE config 4 ("FK + Jacobian + cost"): trk_rollout_jacobian_cost_grad == trk_rollout_cost_grad followed by
+    trk_fk_jacobian (robot_tree.py:218-248) == the fp64 oracle.  UR10 + Allegro: ONE launch of the generated unit (the Jacobian's columns
+    are read out of the poses the rollout holds), also with a moved base; the Panda's unit has no such kernel: the same call runs the two
+    launches and says so."""
+    from oracle import oracle as orc
+    if name == "panda":
+        g, robot = gold("cost_spheres3d"), gold("panda_robot")
+        T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.2, 0.5)
+        m, spec = model("panda_arm_no_gripper"), panda_cost_spec(g, robot, ee_target=T)
+    else:
+        m, spec, _ = tree_cost_spec(name)
+    if base_pose:
+        c, s_ = np.cos(0.3), np.sin(0.3)
+        m.base_R = np.asarray([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+        m.base_t = np.asarray([0.1, -0.2, 0.05], np.float32)
+    h, cm = ops.ModelHandle(m), ops.CostHandle(spec, DEV)
+    if base_pose:
+        h.set_base_pose(m.base_R, m.base_t)
+    o = orc.Oracle(m, spec)
+    link = int(spec.ee_link)
+    w = (0.0, 1.0, 0.0, 1.0)
+    rng = np.random.default_rng(17)
+    for B, H in ((5, 64), (3, 37), (1, 1)):
+        q = torch.as_tensor(rng.uniform(-2.0, 2.0, size=(B, H, m.n_dofs)).astype(np.float32), device=DEV)
+        plan = ops.RolloutJacobianPlan(h, cm, w, q, link)
+        sums = torch.zeros(ops.n_blocks(B * H), device=DEV)
+        plan.launch(sums.data_ptr())
+        torch.cuda.synchronize()
+        assert ops.last_dispatch() == ("generated" if name == "ur10_allegro" else "generated + prior launches")
+        pos, cost, gq = ops.rollout_cost_grad(h, cm, w, q)
+        jp, jq, lin, ang = ops.fk_jacobian(h, q.reshape(-1, m.n_dofs), None, link)[:4]
+        scale = max(1.0, float(pos.abs().max()))
+        assert float((plan.link_pos - pos).abs().max()) <= 2e-6 * scale
+        assert float((plan.cost - cost).abs().max()) <= 1e-5 * max(1.0, float(cost.abs().max()))
+        assert float((plan.gq - gq).abs().max()) <= 1e-4 * max(1e-3, float(gq.abs().max()))
+        assert float((plan.pos.reshape(-1, 3) - jp).abs().max()) <= 2e-6 * scale
+        assert float((plan.lin_jac.reshape(lin.shape) - lin).abs().max()) <= 4e-6 * scale and float((plan.ang_jac.reshape(ang.shape) - ang).abs().max()) <= 2e-6
+        # a quaternion and its negative are the same rotation
+        dq = torch.minimum((plan.quat.reshape(-1, 4) - jq).abs().amax(1), (plan.quat.reshape(-1, 4) + jq).abs().amax(1))
+        assert float(dq.max()) <= 5e-6
+        rp, rq, rl, ra, _, _ = o.jacobian(q.reshape(-1, m.n_dofs).cpu().numpy().astype(np.float64), None, link, "f64")
+        assert np.abs(plan.pos.reshape(-1, 3).cpu().numpy() - rp).max() <= 3e-6 * scale
+        assert np.abs(plan.lin_jac.reshape(rl.shape).cpu().numpy() - rl).max() <= 6e-6 * scale
+        assert np.abs(plan.ang_jac.reshape(ra.shape).cpu().numpy() - ra).max() <= 3e-6
+        # the structural zeros are written, not left over: poison the buffers and evaluate again
+        plan.lin_jac.fill_(7.0); plan.ang_jac.fill_(7.0)
+        plan.launch()
+        torch.cuda.synchronize()
+        assert np.abs(plan.lin_jac.reshape(rl.shape).cpu().numpy() - rl).max() <= 6e-6 * scale
+        assert np.abs(plan.ang_jac.reshape(ra.shape).cpu().numpy() - ra).max() <= 3e-6

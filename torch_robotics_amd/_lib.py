@@ -33,7 +33,7 @@ EXPORTS = [
     "trk_rollout_points_cost_grad", "trk_rollout_collision", "trk_gp_prior_cost_grad", "trk_rollout_cost_grad_f16", "trk_finite_difference", "trk_traj_diff_norm_sum",
     "trk_interpolate_columns", "trk_interpolate_columns_backward", "trk_rollout_collision_via", "trk_rollout_collision_via_flags", "trk_via_partial_flags_bytes", "trk_traj_validate",
     "trk_scale_rows", "trk_jtj", "trk_pack_sums", "trk_pack_sums_scratch_bytes", "trk_rollout_is_specialized", "trk_ik_gn_steps", "trk_rollout_gp_cost_grad",
-    "trk_spec_register_module", "trk_spec_layout_stamp", "trk_last_dispatch", "trk_set_strict_specialized", "trk_rollout_points_is_specialized",
+    "trk_spec_register_module", "trk_spec_layout_stamp", "trk_last_dispatch", "trk_set_strict_specialized", "trk_rollout_points_is_specialized", "trk_rollout_jacobian_cost_grad",
     "trk_handle_kind", "trk_mailbox_create", "trk_mailbox_ipc_handle", "trk_mailbox_connect", "trk_mailbox_send", "trk_mailbox_recv", "trk_mailbox_exchange", "trk_mailbox_status", "trk_mailbox_destroy",
 ]
 
@@ -137,6 +137,7 @@ def lib():
     L.trk_ik_gn_steps.argtypes = [vp, i32, vp, i32, vp, vp, f32, f32, f32, f32, i32, i64, vp, vp, vp, vp]
     L.trk_rollout_is_specialized.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights)]
     L.trk_last_dispatch.argtypes = []
+    L.trk_rollout_jacobian_cost_grad.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights), vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.trk_rollout_points_is_specialized.argtypes = [vp, vp, C.POINTER(_abi.RolloutWeights)]
     L.trk_set_strict_specialized.argtypes = [i32]
     L.trk_interpolate_via_points.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp]

@@ -673,6 +673,25 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.append("    template <int A> __device__ __forceinline__ void rest() const { range<A, R::NP>(); }")
         out.append("};")
 
+    # Fused rollout + geometric Jacobian of the tracked link (round 6; BASELINE config 4: "FK + Jacobian + cost" in ONE launch).  The
+    # Jacobian's stateful walk (robot_tree.py:136-248: clamp wherever limits exist, rotation about sf_rot_axis with the axis sign ignored)
+    # must coincide with the rollout's stateless one on every link the columns need -- then the columns z_j x (p_ee - p_j) | z_j are read
+    # out of the poses this kernel already holds.  Columns: the reference's rule (idx - 1) <= joint_list_idx (robot_tree.py:239-240).
+    jacf_cols: List[int] = []
+    jacf_ok = False
+    if chunked and tmpl.ee_link >= 0 and not tmpl.virtual and os.environ.get("TRK_EXP_NO_JAC_FUSE", "0") != "1":
+        ee_ = tmpl.ee_link
+        jacf_cols = [i for i in range(1, L) if int(kin.dof_idx[i]) >= 0 and int(kin.jac_axis[i]) >= 0 and (i - 1) <= int(kin.joint_list_idx[ee_])]
+        need_ = set()
+        for leaf in [ee_] + jacf_cols:
+            a = leaf
+            while a > 0 and a not in need_:
+                need_.add(a); a = int(kin.parent[a])
+        same_ = all(int(kin.joint_type[i]) == JOINT_FIXED or
+                    (int(kin.joint_type[i]) in (JOINT_REVOLUTE, JOINT_CONTINUOUS) and int(kin.clamp[i]) == int(kin.sf_clamp[i]) and
+                     int(kin.rot_axis[i]) == int(kin.sf_rot_axis[i]) and float(kin.rot_sign[i]) == 1.0) for i in need_)
+        jacf_ok = bool(jacf_cols) and same_
+
     def emit_collision_objectives(E, t, next_chunk, fast_arg="", prims_ptr=""):
         """cost + position adjoints (tb<i>_k) of the three collision fields on link positions t[i][k]; the scene evaluation owns
         OBJ_TICK_SLOTS tick slots of `flush` per group.  Shared by the fused rollout and the positions-in field kernel."""
@@ -831,7 +850,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         if chunked:
             # POS: the launch wants the link positions.  A compile-time switch, because the ring staging costs the launches that
             # only want cost + gradient (the planners' inner loop) 2-4 us even with every store masked off.
-            E.raw(f"template <class IO, bool POS{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}>      // IO: HBM-side type of q / link_pos / gq (float or _Float16)")
+            # JAC (units with jacf_ok): the same launch also writes the geometric Jacobian of the tracked link (launch_rjac).
+            E.raw(f"template <class IO, bool POS{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}{', bool JAC = false' if (jacf_ok and not GPT) else ''}>      // IO: HBM-side type of q / link_pos / gq (float or _Float16)")
         else:
             E.raw(f"template <class IO{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}>      // HBM-side type of q / link_pos / gq: float or _Float16")
         if GPT and box_t:
@@ -843,7 +863,11 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         if not box_t:
             E.raw("    constexpr bool BOX = !FAST;")
         if chunked:
-            E.raw(f"    constexpr int LDS_LANE = POS ? {max(rp.stride, D)} : {D};")
+            if jacf_ok and not GPT:
+                E.raw(f"    constexpr int LDS_LANE = JAC ? {max(rp.stride, D, 3 * D)} : (POS ? {max(rp.stride, D)} : {D});      // JAC: the [64][3D] Jacobian tiles reuse the region")
+                E.raw('    static_assert(!JAC || TrkSame<IO, float>::value, "the fused Jacobian is an fp32 output");')
+            else:
+                E.raw(f"    constexpr int LDS_LANE = POS ? {max(rp.stride, D)} : {D};")
             lds_lane = "LDS_LANE"
         else:
             lds_lane = max(3 * L, D)
@@ -1101,6 +1125,40 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gq), base, rows, lane, lds, gv, A.grad_scale);")
         E.raw("    spec_stamp(A.stamps, wblock, 7, lane);")
+        if chunked and jacf_ok and not GPT:
+            ee = tmpl.ee_link
+            E.raw("    if constexpr (JAC) {")
+            E.raw(f"        // ---- geometric Jacobian of link {ee} '{kin.link_names[ee]}' (robot_tree.py:218-248) from the poses of this walk: column d of a")
+            E.raw("        // joint with a column = [z x (p_link - p_joint) ; z], every other column zero; lin_jac / ang_jac [N, 3, D] leave as the")
+            E.raw("        // wavefront's contiguous 64 x 3D floats through one LDS tile each (16-byte write-through stores, like k_jac's)")
+            pe = [E.named(t[ee][k]) for k in range(3)]
+            colz: Dict[int, List[S]] = {}
+            coll: Dict[int, List[S]] = {}
+            for i in jacf_cols:
+                d, ax = int(kin.dof_idx[i]), int(kin.jac_axis[i])
+                z = [E.named(R[i][r][ax]) for r in range(3)]
+                rel = [E.named(E.lincomb([(pe[k], ONE), (t[i][k], S(-1.0))])) for k in range(3)]
+                colz[d] = z
+                coll[d] = [E.named(v) for v in E.cross(z, rel)]
+            E.raw(f"        float* jrow = lds + lane * {3 * D};")
+            for nm, cols, dst in (("lin", coll, "A.jac_lin"), ("ang", colz, "A.jac_ang")):
+                E.raw(f"        spec_wave_sync();          // the region's previous readers are done ({nm}_jac)")
+                vals = []
+                for r in range(3):
+                    for d in range(D):
+                        vals.append(E.expr(cols[d][r]) if d in cols else "0.0f")
+                E.raw("        " + " ".join(f"jrow[{k}] = {v};" for k, v in enumerate(vals)))
+                E.raw("        spec_wave_sync();")
+                E.raw(f"        spec_store_tile<{3 * D}>({dst}, base, rows, lane, lds);")
+            E.raw("        if (lane < rows) {")
+            E.raw("            const int64_t s_ = base + lane;")
+            E.raw(f"            const float jR[9] = {{{', '.join(E.expr(R[ee][r][c]) for r in range(3) for c in range(3))}}};")
+            E.raw("            " + " ".join(f"A.jac_pos[s_ * 3 + {k}] = {E.expr(pe[k])};" for k in range(3)))
+            E.raw("            float qo[4];")
+            E.raw("            frame_quat_wxyz(jR, qo);")
+            E.raw("            *reinterpret_cast<float4*>(A.jac_quat + s_ * 4) = make_float4(qo[0], qo[1], qo[2], qo[3]);")
+            E.raw("        }")
+            E.raw("    }")
         E.raw("}")
         out.extend(E.lines)
         out.append("")
@@ -2037,6 +2095,21 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append(f"    if (a.io_f16 == TRK_IO_F16) sw0(_Float16{{}}); else if (a.io_f16 == TRK_IO_F16_G32) sw0(HalfG32{{}}); "
                f"else if (spec_stream_stores(a, {L}, {D})) sw0(F32Stream{{}}); else sw0(float{{}});")
     out.append("}")
+    if jacf_ok:
+        # fused rollout + geometric Jacobian of the tracked link (trk_rollout_jacobian_cost_grad): fp32 I/O, positions wanted;
+        # returns 1 when this call is not served (the C ABI then runs the two launches)
+        out.append("static int launch_rjac(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
+        out.append(f"    if (a.io_f16 != TRK_IO_F32 || !a.link_pos || a.jac_link != {tmpl.ee_link}) return 1;")
+        out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+        out.append(f"    if ({'scene_is_fast(a.C)' if D > 8 else 'scene_is_general(a.C)'}) {{")
+        out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<float, true, true, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("        else hipLaunchKernelGGL((k_rollout_bg<float, true, true, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    } else {")
+        out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<float, true, false, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("        else hipLaunchKernelGGL((k_rollout_bg<float, true, false, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append("    }")
+        out.append("    return 0;")
+        out.append("}")
     if gp_ok or gpt_ok:
         out.append("static int launch_gp(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
@@ -2132,7 +2205,8 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
                f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}, "
                f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1, {'launch_fields' if fields_ok else 'nullptr'}, "
-               f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW, {'launch_ikgn' if ikgn_ok else 'nullptr'}, {'launch_gp' if (gp_ok or gpt_ok) else 'nullptr'}}};")
+               f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW, {'launch_ikgn' if ikgn_ok else 'nullptr'}, {'launch_gp' if (gp_ok or gpt_ok) else 'nullptr'}, nullptr, "
+               f"{'launch_rjac' if jacf_ok else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append("#endif      // !__HIPCC_RTC__")
     out.append(f"}}  // namespace spec_{ident}")

@@ -1543,6 +1543,46 @@ int trk_traj_validate(const uint8_t* waypoint_collisions, const float* x, int64_
     return TRK_OK;
 }
 
+int trk_rollout_jacobian_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const float* q, int64_t batch,
+                                   int32_t horizon, int32_t link, float* link_pos_out, float* cost, float* gq, float* cost_sum, float* pos,
+                                   float* quat, float* lin_jac, float* ang_jac, trk_stream_t stream) {
+    const char* who = "trk_rollout_jacobian_cost_grad";
+    int rc = check_model(m, who);
+    if (rc) return rc;
+    if (!cm || !w) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null argument");
+    if (batch < 0 || horizon < 1 || link < 0 || link >= m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": bad batch / horizon / link");
+    if (cm->hdr.n_links_in != m->hdr.n_links) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": cost model n_links_in != model n_links");
+    const int64_t n = batch * horizon;
+    if (n > 0 && (!q || !cost || !gq || !pos || !quat || !lin_jac || !ang_jac)) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null q / cost / gq / Jacobian output");
+    if (n == 0) return TRK_OK;
+    const TrkRolloutWeights we = effective_weights(cm, *w);
+    if (m->spec_enabled && link_pos_out) {
+        const SpecEntry* e = model_spec_for(m, cm, &we);
+        if (e && e->launch_rjac) {
+            SpecArgs a{};
+            a.C = cm->hdr; a.w = we;
+            std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+            std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+            a.q = q; a.n = n; a.link_pos = link_pos_out; a.cost = cost; a.gq = gq; a.cost_sum = cost_sum;
+            a.stamps = g_stamps; a.io_f16 = 0; a.grad_scale = 1.0f;
+            a.jac_link = link; a.jac_joint_idx = m->joint_list_idx[link];
+            a.jac_pos = pos; a.jac_quat = quat; a.jac_lin = lin_jac; a.jac_ang = ang_jac;
+            if (e->launch_rjac(e, a, base_is_identity(m), (hipStream_t)stream) == 0) {
+                TRK_HIP(last_launch_error());
+                g_last_dispatch = TRK_DISPATCH_GENERATED;
+                return TRK_OK;
+            }
+        }
+    }
+    // the two-launch form: the fused rollout, then the Jacobian kernel (a second walk of the chain)
+    rc = rollout_impl(who, m, cm, w, 0, 1.0f, q, batch, horizon, link_pos_out, cost, gq, cost_sum, stream);
+    if (rc) return rc;
+    const int d = g_last_dispatch;
+    rc = trk_fk_jacobian(m, q, nullptr, n, link, pos, quat, lin_jac, ang_jac, nullptr, nullptr, stream);
+    g_last_dispatch = d == TRK_DISPATCH_GENERATED ? TRK_DISPATCH_GENERATED_PLUS_PRIOR : d;
+    return rc;
+}
+
 int trk_rollout_cost_grad(const TrkModel* m, const TrkCostModel* cm, const TrkRolloutWeights* w, const float* q,
                           int64_t batch, int32_t horizon, float* link_pos_out, float* cost, float* gq, float* cost_sum,
                           trk_stream_t stream) {

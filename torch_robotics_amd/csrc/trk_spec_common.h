@@ -168,6 +168,10 @@ struct SpecEntry {
     // (self-collision pairs between independently scheduled subtrees with w_self != 0) -- the caller then runs the two-launch form
     int (*launch_gp)(const SpecEntry* self, const SpecArgs& args, int base_identity, hipStream_t stream);
     void* module_ctx;           // nullptr for a linked / dlopen-ed unit; the code-object unit's kernel table otherwise
+    // fused rollout + geometric Jacobian of the unit's tracked link in one launch (trk_rollout_jacobian_cost_grad; many-link units whose
+    // stateful and stateless walks coincide on the columns' chains): returns 0, or 1 when this unit does not serve the call; nullptr if
+    // not generated
+    int (*launch_rjac)(const SpecEntry* self, const SpecArgs& args, int base_identity, hipStream_t stream);
 };
 
 // Does this launch take the F32Stream instantiation (non-temporal output stores)?  Its working set -- q in, positions, cost and

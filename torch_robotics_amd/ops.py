@@ -1698,6 +1698,35 @@ class RolloutPlan:
             check(rc, "trk_rollout_cost_grad")
 
 
+class RolloutJacobianPlan(RolloutPlan):
+    """BASELINE config 4's step -- fused FK + objectives + gradient AND the stateful FK + geometric Jacobian of `link`
+    (robot_tree.py:218-248) -- as one pre-bound call (`trk_rollout_jacobian_cost_grad`): ONE launch when a generated unit tracks
+    `link` (UR10 + Allegro: the columns are read out of the poses the rollout already holds), else the two launches.  Outputs of a
+    RolloutPlan plus `pos` (B, H, 3), `quat` (B, H, 4 wxyz), `lin_jac` / `ang_jac` (B, H, 3, D)."""
+
+    def __init__(self, model: ModelHandle, cm: CostHandle, weights, q: torch.Tensor, link: int, strict: bool = True):
+        if q.dtype != torch.float32:
+            raise ValueError("RolloutJacobianPlan: float32 trajectories (the Jacobian is an fp32 output)")
+        super().__init__(model, cm, weights, q, want_pos=True, strict=strict)
+        kw = dict(device=self.q.device, dtype=torch.float32)
+        B, H, D = self.B, self.H, model.n_dofs
+        self.link = int(link)
+        self.pos, self.quat = torch.empty((B, H, 3), **kw), torch.empty((B, H, 4), **kw)
+        self.lin_jac, self.ang_jac = torch.empty((B, H, 3, D), **kw), torch.empty((B, H, 3, D), **kw)
+        self._fn = lib().trk_rollout_jacobian_cost_grad
+        self._args = (model._h, cm._h, C.byref(self._w), self.q.data_ptr(), B, H, self.link, _ptr(self.link_pos), self.cost.data_ptr(),
+                      self.gq.data_ptr())
+        self._tail = (self.pos.data_ptr(), self.quat.data_ptr(), self.lin_jac.data_ptr(), self.ang_jac.data_ptr())
+
+    def launch(self, cost_sum_ptr: Optional[int] = None, stream: Optional[int] = None) -> None:
+        with _on(self.device):
+            if stream is None:
+                stream = _stream_of(self.device)
+            rc = self._fn(*self._args, cost_sum_ptr, *self._tail, stream)
+        if rc:
+            check(rc, "trk_rollout_jacobian_cost_grad")
+
+
 class PointsRolloutPlan:
     """RolloutPlan for the attached-point models (link spheres, grasped-object points; `trk_rollout_points_cost_grad`): the collision
     fields' columns are the points of `ps`, `link_pos` (B, H, P, 3) their world positions.  Same interface as RolloutPlan (launch(),
