@@ -59,8 +59,8 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 # fp32 vector peak 157.3 TFLOP/s = 1024 SIMDs x 2.4 GHz x 32 lanes x 2 flop: one 64-lane VALU instruction takes a SIMD 2 cycles
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
-# per-launch counters recorded by tools/run_r05_profiles.sh (earlier rounds' files as fall-backs)
-PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_hbm_traffic.json")
+# per-launch counters recorded by tools/run_r06_profiles.sh (earlier rounds' files as fall-backs)
+PMC_FILES = ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_hbm_traffic.json")
 DEFAULT_SHAPE = {"c2": (4096, 64), "c3": (4096, 64), "c4": (4096, 64), "c5": (2048, 128)}     # per-GPU batch x horizon
 SIGMA_GP, T_GP = 0.1, 5.0        # config 5's GP prior: sigma_gp of the reference's planner parameters (env_spheres_3d.py:57), 5 s trajectories
 
@@ -132,6 +132,26 @@ def self_launch(args, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
     return subprocess.run(cmd, env=env).returncode
+
+
+def physical_cores():
+    """Physical cores this process may run on: distinct (package, core) pairs of /proc/cpuinfo among the CPUs of the affinity mask
+    (SMT siblings count once -- what the OpenMP runtime picks by default on the N = 1 run); the mask's size when that cannot be read."""
+    allowed = os.sched_getaffinity(0)
+    try:
+        cores, cpu, pkg = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu, pkg = int(v), None
+            elif k == "physical id":
+                pkg = int(v)
+            elif k == "core id" and cpu in allowed:
+                cores.add((pkg, int(v)))
+        return len(cores) or len(allowed)
+    except Exception:
+        return len(allowed)
 
 
 def cpu_model_name():
@@ -933,8 +953,8 @@ def main():
         if per_rank_value:
             step_bytes = wl.bps_step * B * H
             mg["per_rank"] = [{"rank": r, "wall_us": per_rank_value["wall_us"][r], "launch_stream_us": t_us,
-                               "achieved_GBps": round(step_bytes * args.steps / (t_us * 1e-6) / 1e9, 1),
-                               "frac": round(step_bytes * args.steps / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                               "achieved_GBps": step_bytes * args.steps / (t_us * 1e-6) / 1e9,
+                               "frac": step_bytes * args.steps / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
                               for r, t_us in enumerate(per_rank_value["launch_stream_us"])]
             mg["per_rank_bytes_per_step"] = step_bytes
         # what the exchange leaves of ideal weak scaling: N x (a step without any exchange) / (a step of the timed region with its exchange)
@@ -989,7 +1009,7 @@ def main():
             # N > 1: rank 0's host threads are free only now -- the other ranks have left their last barrier and are exiting (they do
             # no CPU arithmetic).  A shorter sample than at N = 1: the line must not wait long for a baseline that N = 1 already carries.
             from oracle import oracle as orc_
-            orc_.set_threads(len(os.sched_getaffinity(0)))         # the launcher pinned OMP_NUM_THREADS for the ranks; the baseline uses the host
+            orc_.set_threads(physical_cores())                     # the launcher pinned OMP_NUM_THREADS for the ranks; the baseline uses the host's cores
             out["cpu_baseline"] = cpu_baseline(wl, args, torch, min(args.cpu_seconds, 6.0))
             out["cpu_baseline"]["note"] = f"rank 0 of {world}, after the process group was destroyed; sample bounded to {min(args.cpu_seconds, 6.0):g} s per leg"
     # The JSON line is the LAST thing on stdout: librccl announces itself with a printf ("Librccl path : ...") that sits in the

@@ -236,7 +236,7 @@ def test_many_rank_dress_rehearsal_on_one_gpu(cfg, ranks, extra):
     assert [r["rank"] for r in pr] == list(range(ranks))
     for r in pr:
         assert r["launch_stream_us"] > 0 and r["achieved_GBps"] > 0 and 0 < r["frac"] < 1
-        assert r["achieved_GBps"] == pytest.approx(mg["per_rank_bytes_per_step"] * 20 / (r["launch_stream_us"] * 1e-6) / 1e9, rel=1e-3)
+        assert r["achieved_GBps"] == pytest.approx(mg["per_rank_bytes_per_step"] * 20 / (r["launch_stream_us"] * 1e-6) / 1e9, rel=1e-2)
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["bytes_per_sample"] == (192 if cfg == "c2" else 254)
     cb = out["cpu_baseline"]
     assert cb is not None and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "rank 0" in cb["note"]
