@@ -191,9 +191,9 @@ def test_trajectory_flags_folded_into_the_via_launch(ops, T, H, n_interp):
 @pytest.mark.parametrize("name,base_pose", [("ur10_allegro", False), ("ur10_allegro", True), ("panda", False)])
 def test_rollout_and_jacobian_in_one_launch(ops, name, base_pose):
     """Round 6, BASELINE config 4 ("FK + Jacobian + cost"): trk_rollout_jacobian_cost_grad == trk_rollout_cost_grad followed by
-    trk_fk_jacobian (robot_tree.py:218-248) == the fp64 oracle.  UR10 + Allegro: ONE launch of the generated unit (the Jacobian's columns
-    are read out of the poses the rollout holds), also with a moved base; the Panda's unit has no such kernel: the same call runs the two
-    launches and says so."""
+    trk_fk_jacobian (robot_tree.py:218-248) == the fp64 oracle.  ONE launch of the generated unit (the Jacobian's columns are read out of
+    the poses the rollout holds) for UR10 + Allegro (ring-staged positions), also with a moved base, and for the Panda (whole-row staging);
+    a link the unit does not track, or a model without generated kernels, runs the two launches behind the same call and says so."""
     from oracle import oracle as orc
     if name == "panda":
         g, robot = gold("cost_spheres3d"), gold("panda_robot")
@@ -218,7 +218,7 @@ def test_rollout_and_jacobian_in_one_launch(ops, name, base_pose):
         sums = torch.zeros(ops.n_blocks(B * H), device=DEV)
         plan.launch(sums.data_ptr())
         torch.cuda.synchronize()
-        assert ops.last_dispatch() == ("generated" if name == "ur10_allegro" else "generated + prior launches")
+        assert ops.last_dispatch() == "generated"
         pos, cost, gq = ops.rollout_cost_grad(h, cm, w, q)
         jp, jq, lin, ang = ops.fk_jacobian(h, q.reshape(-1, m.n_dofs), None, link)[:4]
         scale = max(1.0, float(pos.abs().max()))
@@ -234,6 +234,16 @@ def test_rollout_and_jacobian_in_one_launch(ops, name, base_pose):
         assert np.abs(plan.pos.reshape(-1, 3).cpu().numpy() - rp).max() <= 3e-6 * scale
         assert np.abs(plan.lin_jac.reshape(rl.shape).cpu().numpy() - rl).max() <= 6e-6 * scale
         assert np.abs(plan.ang_jac.reshape(ra.shape).cpu().numpy() - ra).max() <= 3e-6
+        # another link than the tracked one: the same call, two launches, the same function
+        other = link - 1
+        plan2 = ops.RolloutJacobianPlan(h, cm, w, q, other)
+        plan2.launch()
+        torch.cuda.synchronize()
+        assert ops.last_dispatch() == "generated + prior launches"
+        rp2, _, rl2, ra2, _, _ = o.jacobian(q.reshape(-1, m.n_dofs).cpu().numpy().astype(np.float64), None, other, "f64")
+        assert np.abs(plan2.pos.reshape(-1, 3).cpu().numpy() - rp2).max() <= 3e-6 * scale
+        assert np.abs(plan2.lin_jac.reshape(rl2.shape).cpu().numpy() - rl2).max() <= 6e-6 * scale
+        assert torch.equal(plan2.cost, plan.cost) or float((plan2.cost - plan.cost).abs().max()) <= 1e-5 * max(1.0, float(cost.abs().max()))
         # the structural zeros are written, not left over: poison the buffers and evaluate again
         plan.lin_jac.fill_(7.0); plan.ang_jac.fill_(7.0)
         plan.launch()

@@ -679,7 +679,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     # out of the poses this kernel already holds.  Columns: the reference's rule (idx - 1) <= joint_list_idx (robot_tree.py:239-240).
     jacf_cols: List[int] = []
     jacf_ok = False
-    if chunked and tmpl.ee_link >= 0 and not tmpl.virtual and os.environ.get("TRK_EXP_NO_JAC_FUSE", "0") != "1":
+    if tmpl.ee_link >= 0 and not tmpl.virtual and os.environ.get("TRK_EXP_NO_JAC_FUSE", "0") != "1":
         ee_ = tmpl.ee_link
         jacf_cols = [i for i in range(1, L) if int(kin.dof_idx[i]) >= 0 and int(kin.jac_axis[i]) >= 0 and (i - 1) <= int(kin.joint_list_idx[ee_])]
         need_ = set()
@@ -853,7 +853,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             # JAC (units with jacf_ok): the same launch also writes the geometric Jacobian of the tracked link (launch_rjac).
             E.raw(f"template <class IO, bool POS{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}{', bool JAC = false' if (jacf_ok and not GPT) else ''}>      // IO: HBM-side type of q / link_pos / gq (float or _Float16)")
         else:
-            E.raw(f"template <class IO{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}>      // HBM-side type of q / link_pos / gq: float or _Float16")
+            E.raw(f"template <class IO{', bool FAST' if fast_t else ''}{', bool BOX' if box_t else ''}{', bool JAC = false' if (jacf_ok and not GPT) else ''}>      // HBM-side type of q / link_pos / gq: float or _Float16")
         if GPT and box_t:
             # the prior's gradient (D registers) lives across the whole kernel: the box-scene instantiation of a small arm would spill
             # 26 registers at four wavefronts per SIMD -- it runs at three
@@ -870,7 +870,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 E.raw(f"    constexpr int LDS_LANE = POS ? {max(rp.stride, D)} : {D};")
             lds_lane = "LDS_LANE"
         else:
-            lds_lane = max(3 * L, D)
+            lds_lane = max(3 * L, D)      # (>= 3 D: the [64][3D] Jacobian tiles of a JAC instantiation fit the staging tile, L > D)
+            if jacf_ok and not GPT:
+                assert 3 * D <= lds_lane
+                E.raw('    static_assert(!JAC || TrkSame<IO, float>::value, "the fused Jacobian is an fp32 output");')
             if GPT:     # the raw q / qd tiles (fp32 at worst) and the factor tile of the prior phase must fit the staging tile
                 pad = -(-D // 4) * 4
                 need = 2 * (-(-((pad + 65 * D) * 4) // 16) * 16) + (65 * (2 * D + 1) + 2) * 4
@@ -1125,7 +1128,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
             E.raw(f"    const float gv[D] = {{{', '.join(E.expr(gq_expr.get(d, ZERO)) for d in range(D))}}};")
         E.raw("    spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gq), base, rows, lane, lds, gv, A.grad_scale);")
         E.raw("    spec_stamp(A.stamps, wblock, 7, lane);")
-        if chunked and jacf_ok and not GPT:
+        if jacf_ok and not GPT:
             ee = tmpl.ee_link
             E.raw("    if constexpr (JAC) {")
             E.raw(f"        // ---- geometric Jacobian of link {ee} '{kin.link_names[ee]}' (robot_tree.py:218-248) from the poses of this walk: column d of a")
@@ -2099,14 +2102,16 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         # fused rollout + geometric Jacobian of the tracked link (trk_rollout_jacobian_cost_grad): fp32 I/O, positions wanted;
         # returns 1 when this call is not served (the C ABI then runs the two launches)
         out.append("static int launch_rjac(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
-        out.append(f"    if (a.io_f16 != TRK_IO_F32 || !a.link_pos || a.jac_link != {tmpl.ee_link}) return 1;")
+        # ring-staged units instantiate JAC with positions (POS = true) only; the others take the positions as a run-time option
+        out.append(f"    if (a.io_f16 != TRK_IO_F32 || {'!a.link_pos || ' if chunked else ''}a.jac_link != {tmpl.ee_link}) return 1;")
         out.append("    const unsigned grid = (unsigned)((a.n + SPEC_BLOCK - 1) / SPEC_BLOCK);")
+        pos_t = "true, " if chunked else ""
         out.append(f"    if ({'scene_is_fast(a.C)' if D > 8 else 'scene_is_general(a.C)'}) {{")
-        out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<float, true, true, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-        out.append("        else hipLaunchKernelGGL((k_rollout_bg<float, true, true, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append(f"        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<float, {pos_t}true, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append(f"        else hipLaunchKernelGGL((k_rollout_bg<float, {pos_t}true, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    } else {")
-        out.append("        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<float, true, false, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
-        out.append("        else hipLaunchKernelGGL((k_rollout_bg<float, true, false, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append(f"        if (base_identity) hipLaunchKernelGGL((k_rollout_bi<float, {pos_t}false, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
+        out.append(f"        else hipLaunchKernelGGL((k_rollout_bg<float, {pos_t}false, true>), dim3(grid), dim3(SPEC_BLOCK), 0, st, a);")
         out.append("    }")
         out.append("    return 0;")
         out.append("}")

@@ -1556,7 +1556,7 @@ int trk_rollout_jacobian_cost_grad(const TrkModel* m, const TrkCostModel* cm, co
     if (n > 0 && (!q || !cost || !gq || !pos || !quat || !lin_jac || !ang_jac)) return fail(TRK_ERR_INVALID_ARG, std::string(who) + ": null q / cost / gq / Jacobian output");
     if (n == 0) return TRK_OK;
     const TrkRolloutWeights we = effective_weights(cm, *w);
-    if (m->spec_enabled && link_pos_out) {
+    if (m->spec_enabled) {
         const SpecEntry* e = model_spec_for(m, cm, &we);
         if (e && e->launch_rjac) {
             SpecArgs a{};
