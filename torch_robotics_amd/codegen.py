@@ -483,19 +483,20 @@ def _arm_lane_kernel_lines(kin: KinModel, tmpl: CollisionTemplate, plan: ArmLane
         E.raw("        const IOQ* qr = qb + lane * DA;")
         E.raw("        const IOQ* vr = vb + lane * DA;")
         E.raw("        float gvv[DA], accg = 0.0f;")
+        E.raw("        const float gan = mn * ga, gbn = mn * gb, gcn = mn * gc, gap = mp * ga, gbp = mp * gb, gcp = mp * gc;")
         E.raw("#pragma unroll")
         E.raw("        for (int d = 0; d < DA; ++d) {")
         E.raw("            const float p0 = (float)qr[d], v0 = (float)vr[d];")
         E.raw("            const float pm = (float)qr[d - D], vm = (float)vr[d - D], pn = (float)qr[d + D], vn = (float)vr[d + D];")
         E.raw("            const float ep = fmaf(dt, v0, p0) - pn, ev = v0 - vn;")
-        E.raw("            const float rp = mn * fmaf(ga, ep, gb * ev), rv_ = mn * fmaf(gb, ep, gc * ev);")
-        E.raw("            accg = fmaf(0.5f, fmaf(ep, rp, ev * rv_), accg);")
+        E.raw("            const float rp = fmaf(gan, ep, gbn * ev), rv_ = fmaf(gbn, ep, gcn * ev);      // the weight (and the time-step mask) folded into Q^-1 once per lane")
+        E.raw("            accg = fmaf(ep, rp, fmaf(ev, rv_, accg));                                      // 2 x the factor's cost: halved once, below")
         E.raw("            const float em = fmaf(dt, vm, pm) - p0, fm = vm - v0;")
-        E.raw("            gpv[d] = rp - mp * fmaf(ga, em, gb * fm);")
-        E.raw("            gvv[d] = fmaf(dt, rp, rv_) - mp * fmaf(gb, em, gc * fm);")
+        E.raw("            gpv[d] = rp - fmaf(gap, em, gbp * fm);")
+        E.raw("            gvv[d] = fmaf(dt, rp, rv_) - fmaf(gbp, em, gcp * fm);")
         E.raw("            q[d] = p0;")
         E.raw("        }")
-        E.raw("        cost_gp = accg;")
+        E.raw("        cost_gp = 0.5f * accg;")
         E.raw("        // d cost / d qd is final: out through the staging tile (its first line waits for every lane's reads of the raw tiles)")
         E.raw("        spec_store_gq<DA, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base_h, rows, lane, lds, gvv, A.grad_scale);")
         E.raw("    }")
@@ -977,18 +978,19 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                 E.raw("        }")
                 E.raw("        spec_wave_sync();")
                 E.raw("        float gvv[D], accg = 0.0f;")
+                E.raw("        const float gaw = wm * ga, gbw = wm * gb, gcw = wm * gc;")
                 E.raw("#pragma unroll")
                 E.raw("        for (int d = 0; d < D; ++d) {")
                 E.raw("            const float p0 = (float)qb[lane * D + d], v0 = (float)vb[lane * D + d];")
                 E.raw("            const float pn = trk_dpp_from_next((float)qb[TRK_WAVE * D + d], p0), vn = trk_dpp_from_next((float)vb[TRK_WAVE * D + d], v0);")
                 E.raw("            const float ep = fmaf(dt, v0, p0) - pn, ev = v0 - vn;")
-                E.raw("            const float rp = wm * fmaf(ga, ep, gb * ev), rv_ = wm * fmaf(gb, ep, gc * ev);")
-                E.raw("            accg = fmaf(0.5f, fmaf(ep, rp, ev * rv_), accg);")
+                E.raw("            const float rp = fmaf(gaw, ep, gbw * ev), rv_ = fmaf(gbw, ep, gcw * ev);      // w Q^-1 e with the weight folded into Q^-1 once per lane")
+                E.raw("            accg = fmaf(ep, rp, fmaf(ev, rv_, accg));                                      // 2 x the factor's cost: halved once, below")
                 E.raw("            gpv[d] = rp - trk_dpp_from_prev(rt[2 * d], rp);")
                 E.raw("            gvv[d] = fmaf(dt, rp, rv_) - trk_dpp_from_prev(rt[2 * d + 1], rv_);")
                 E.raw("            q[d] = p0;")
                 E.raw("        }")
-                E.raw("        cost_gp = accg;")
+                E.raw("        cost_gp = 0.5f * accg;")
                 E.raw("        // d cost / d qd is final: out through the staging tile (its first line waits for every lane's reads of the tiles)")
                 E.raw("        spec_store_gq<D, IOG, IoTraits<IO>::kScaled>(static_cast<IOG*>(A.gqd), base, rows, lane, lds, gvv, A.grad_scale);")
                 E.raw("        spec_wave_sync();")
