@@ -195,3 +195,44 @@ def test_hiprtc_flags_follow_the_makefile():
     missing = [f for f in device_flags if f not in jit.RTC_FLAGS]
     assert missing == [], f"device flags of csrc/Makefile missing from jit.RTC_FLAGS: {missing}"
     assert "--offload-arch=gfx950" in jit.RTC_FLAGS
+
+
+def test_arm_per_lane_schedule_is_planned_only_for_isomorphic_arms(monkeypatch):
+    """Round 6: `arm_lane_plan` recognises a robot that is two isomorphic subtrees on one base (the dual Panda: only the arms' mounts
+    differ) whose template treats the arms alike -- the unit then carries k_rollout_gpa, dispatched by I/O mode; anything else gets
+    no such kernel."""
+    import copy
+    import numpy as np
+    kin, tmpl = codegen.template_for("dual_panda")
+    plan = codegen.arm_lane_plan(kin, tmpl)
+    assert plan is not None and plan.n == 11 and plan.DA == 7 and plan.obj == tmpl.obj_links[:5] and plan.ee == tmpl.ee_link
+    assert [(k, r) for k, r, _, _, _ in plan.differ] == [("t", 1)] and plan.differ[0][3] == -plan.differ[0][4]      # the mounts: y = +-0.35
+    src = codegen.generate_rollout_source(kin, tmpl, "dual_panda")
+    assert "k_rollout_gpa_bi" in src and "TRK_GP_ARM_LANES" in src and "a.io_f16 == TRK_IO_F32" in src
+    for ident in ("panda", "ur10_allegro", "tiago"):
+        k2, t2 = codegen.template_for(ident)
+        assert codegen.arm_lane_plan(k2, t2) is None
+    # arms that differ in a joint limit, or a template that treats them differently: no plan
+    k3 = copy.deepcopy(kin)
+    k3.upper = np.array(k3.upper, copy=True); k3.upper[14] += 0.1
+    assert codegen.arm_lane_plan(k3, tmpl) is None
+    t3 = copy.deepcopy(tmpl); t3.obj_links = tmpl.obj_links[:-1]
+    assert codegen.arm_lane_plan(kin, t3) is None
+    t4 = copy.deepcopy(tmpl); t4.ee2_link = -1
+    assert codegen.arm_lane_plan(kin, t4) is None
+    monkeypatch.setenv("TRK_EXP_NO_ARM_LANES", "1")
+    assert "k_rollout_gpa" not in codegen.generate_rollout_source(kin, tmpl, "dual_panda")
+
+
+def test_fused_jacobian_is_generated_where_the_two_walks_coincide():
+    """Round 6: the JAC instantiation (trk_rollout_jacobian_cost_grad in one launch) exists exactly for the units whose stateful walk
+    (clamp wherever limits exist, axis sign ignored: rigid_body.py:218-233) equals the stateless one on the chains of the tracked
+    link's Jacobian columns."""
+    have = {}
+    for ident in codegen.SPEC_ROBOTS:
+        kin, tmpl = codegen.template_for(ident)
+        src = codegen.generate_link_kernel_source(kin, tmpl, ident)
+        have[ident] = "launch_rjac" in src
+        assert ("bool JAC = false" in src) == have[ident]
+    assert have["panda"] and have["ur10_allegro"] and have["dual_panda"] and have["ur10"] and have["iiwa7"]
+    assert not have["tiago"] and not have["hab_stretch"]          # prismatic joints / continuous wheels: the stateful walk differs
