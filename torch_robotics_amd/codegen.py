@@ -2126,7 +2126,7 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         kn = "k_rollout_gp_" if use_seg else "k_rollout_gpt_"
         if arm_plan is not None:
             # one arm per lane: sphere scenes, no (cross-arm) self pairs -- and fp32 I/O only by default.  Measured on one box, alternating
-            # (profiles/r06_ab_c5_arm_lanes.txt): fp32 I/O 23.2 -> 21.2 us, but fp16 I/O 21.0 -> 22.4 us and mixed 21.0 -> 22.2: at four
+            # (profiles/r06_ab_c5_arm_lanes.txt, _box1.txt): fp32 I/O 23.0 - 23.5 -> 20.5 - 22.7 us box to box, but fp16 I/O 21.0 -> 22.1 - 22.4 us and mixed 20.8 -> 22.2: at four
             # wavefronts per SIMD the lone-wavefront latency drops (9.1 -> 7.6 us) while every wavefront of 32 samples costs 1.9 us of issue
             # time against 2.3 us for 64 samples -- 19 % more instructions per arm (SQ counters: profiles/r06_sq_c5_arm_vs_robot_lane.txt).
             # TRK_GP_ARM_LANES=0 / 1 in the environment forces the choice (read per launch, like TRK_STREAM_STORES: same-process A/Bs).
