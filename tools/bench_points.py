@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Attached-point paths at 4096 x 64: Panda with the 45-sphere link model and with a grasped box.
-Reports the fused point rollout, fk_map_collision and its backward against their HBM rooflines."""
+Reports the fused point rollout, fk_map_collision and its backward against their HBM rooflines.
+`--only fused|plan|positions|backward` runs one row per model: under `rocprofv3 --kernel-trace --stats` the fused rollout and the positions-only
+launch are the SAME kernel (the positions-only exit), so a trace of all rows averages them; one row per run separates them."""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -24,6 +26,7 @@ def t(fn, n=100, w=10):
 
 
 B, H = 4096, 64
+ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
 for tag, kw in (("45 link spheres", dict(link_sphere_model="panda")),
                 ("grasped box", dict(grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA))),
                 ("spheres + grasped box", dict(link_sphere_model="panda", grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA)))):
@@ -37,9 +40,13 @@ for tag, kw in (("45 link spheres", dict(link_sphere_model="panda")),
     n = B * H
     gpos = torch.randn(n, P, 3, device=dev)
     q2 = q.reshape(n, D)
-    rows = (("fused rollout (self+obj+ws+ee)", lambda: ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 1), q), 8 * D + 12 * P + 4),
-            ("fk_map_collision", lambda: ops.fk_points(ps, q2), 4 * D + 12 * P),
-            ("fk_map_collision backward", lambda: ops.fk_points_backward(ps, q2, gpos), 8 * D + 12 * P))
-    for name, fn, bytes_per in rows:
+    plan = ops.PointsRolloutPlan(ps, cm, (1, 1, 1, 1), q.contiguous())
+    rows = (("fused", "fused rollout (self+obj+ws+ee)", lambda: ops.rollout_points_cost_grad(ps, cm, (1, 1, 1, 1), q), 8 * D + 12 * P + 4),
+            ("plan", "fused rollout, pre-bound (PointsRolloutPlan)", plan.launch, 8 * D + 12 * P + 4),
+            ("positions", "fk_map_collision", lambda: ops.fk_points(ps, q2), 4 * D + 12 * P),
+            ("backward", "fk_map_collision backward", lambda: ops.fk_points_backward(ps, q2, gpos), 8 * D + 12 * P))
+    for key, name, fn, bytes_per in rows:
+        if ONLY is not None and key != ONLY:
+            continue
         us = t(fn)
-        print(f"{tag:22s} P={P:3d} {name:32s} {us:8.1f} us  {bytes_per * n / us / 1e3 / 8e3 * 100:5.1f} % of 8 TB/s  ({n / us * 1e6:.3g} /s)")
+        print(f"{tag:22s} P={P:3d} {name:44s} {us:8.1f} us  {bytes_per * n / us / 1e3 / 8e3 * 100:5.1f} % of 8 TB/s  ({n / us * 1e6:.3g} /s)")
