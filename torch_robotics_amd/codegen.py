@@ -1154,7 +1154,10 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
                         vals.append(E.expr(cols[d][r]) if d in cols else "0.0f")
                 E.raw("        " + " ".join(f"jrow[{k}] = {v};" for k, v in enumerate(vals)))
                 E.raw("        spec_wave_sync();")
-                E.raw(f"        spec_store_tile<{3 * D}>({dst}, base, rows, lane, lds);")
+                # beyond the Infinity Cache the contiguous tiles are faster as non-temporal stores (UR10 + Allegro, 287 MB per launch, same box,
+                # three alternations: 46.4 - 47.7 -> 45.3 - 45.4 us; inside the cache write-through wins, as for the headline's chunks): the launch decides
+                E.raw(f"        if (A.jac_stream) spec_store_tile<{3 * D}, true>({dst}, base, rows, lane, lds);")
+                E.raw(f"        else spec_store_tile<{3 * D}>({dst}, base, rows, lane, lds);")
             E.raw("        if (lane < rows) {")
             E.raw("            const int64_t s_ = base + lane;")
             E.raw(f"            const float jR[9] = {{{', '.join(E.expr(R[ee][r][c]) for r in range(3) for c in range(3))}}};")

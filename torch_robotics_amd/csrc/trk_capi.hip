@@ -1567,6 +1567,9 @@ int trk_rollout_jacobian_cost_grad(const TrkModel* m, const TrkCostModel* cm, co
             a.stamps = g_stamps; a.io_f16 = 0; a.grad_scale = 1.0f;
             a.jac_link = link; a.jac_joint_idx = m->joint_list_idx[link];
             a.jac_pos = pos; a.jac_quat = quat; a.jac_lin = lin_jac; a.jac_ang = ang_jac;
+            // q in; positions, cost, gradient, pos, quat, lin_jac, ang_jac out: beyond the Infinity Cache the Jacobian tiles stream
+            a.jac_stream = spec_stream_bytes((double)n * (8.0 * m->hdr.n_dofs + 4.0 + (link_pos_out ? 12.0 * m->hdr.n_links : 0.0) + 28.0 +
+                                                          24.0 * m->hdr.n_dofs)) ? 1 : 0;
             if (e->launch_rjac(e, a, base_is_identity(m), (hipStream_t)stream) == 0) {
                 TRK_HIP(last_launch_error());
                 g_last_dispatch = TRK_DISPATCH_GENERATED;

@@ -42,7 +42,8 @@ struct SpecArgs {
     int32_t coll_fields;          // TRK_FIELD_* mask
     int32_t coll_use_default;     // 1: per-link margins + cutoff of the cost model, 0: coll_margin for every test
     float coll_margin;
-    int32_t _pad_coll;
+    int32_t jac_stream;           // fused rollout + Jacobian (launch_rjac): 1 = the Jacobian tiles leave as non-temporal stores (the launch's
+                                  // working set exceeds the Infinity Cache: spec_stream_bytes), 0 = write-through like every in-cache output
     // geometric-Jacobian kernel (trk_fk_jacobian, launch_jac): target link, index of its parent joint in the file's joint
     // list (the reference's column rule), outputs pos [N,3], quat_wxyz [N,4], lin_jac / ang_jac [N,3,D]
     int32_t jac_link, jac_joint_idx;
@@ -589,7 +590,8 @@ __device__ __forceinline__ void spec_store_gq(IO* __restrict__ gq, int64_t base,
 }
 
 // copy this wave's [64][W] tile (rows contiguous in LDS, 16-byte aligned) to out[base .. base + rows) as 16-byte write-through stores
-template <int W>
+// (NT: non-temporal instead -- for outputs of launches whose working set exceeds the Infinity Cache)
+template <int W, bool NT = false>
 __device__ __forceinline__ void spec_store_tile(float* __restrict__ out, int64_t base, int rows, int lane, const float* tile) {
     float* dst = out + base * W;
     constexpr int NV = TRK_WAVE * W / 4;
@@ -598,7 +600,7 @@ __device__ __forceinline__ void spec_store_tile(float* __restrict__ out, int64_t
 #pragma unroll
         for (int j = 0; j < (NV + TRK_WAVE - 1) / TRK_WAVE; ++j) {
             const int k = lane + TRK_WAVE * j;
-            if (k < NV) IoQuad<float>::store_wt(dst, k, t4[k]);
+            if (k < NV) { if (NT) IoQuad<trk_f32s>::store_wt(reinterpret_cast<trk_f32s*>(dst), k, t4[k]); else IoQuad<float>::store_wt(dst, k, t4[k]); }
         }
     } else {
         const int count = rows * W;
