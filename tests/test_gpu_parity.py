@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import ROBOTS, gold, grad_close, model, panda_cost_spec, rel_err
+from helpers import ROBOTS, gold, grad_close, grad_close_kinks, kink_rows_ok, model, panda_cost_spec, rel_err
 from torch_robotics_amd._abi import FIELD_OBJECTS, FIELD_SELF, FIELD_WS
 
 pytestmark = pytest.mark.gpu
@@ -336,7 +336,14 @@ def test_grid_precompute_and_sdf_points(ops, oracle_lib):
         assert (d < 1e-5).mean() > 0.995
         for n, ob in np.argwhere(d >= 1e-5):
             _, gp = o.sdf_points(pts[n].astype(np.float64) + _KINK_PROBES, "f64")
-            assert np.abs(gp[:, ob] - gr[n, ob]).max(-1).min() < 1e-5, (env, n, ob)
+            if np.abs(gp[:, ob] - gr[n, ob]).max(-1).min() < 1e-5:
+                continue
+            # not a branch switch: an ill-conditioned normal.  Just inside a rounded edge / corner region the normal is r / |r| with |r|
+            # small, and the fp32 rounding of the point's offsets (~6e-8) turns it by 6e-8 / |r| (found by the seed soak: 1.7e-5 at
+            # |r| = 3e-3).  The result must then lie inside the envelope of the fp64 gradients over the point's rounding neighbourhood.
+            _, gn = o.sdf_points(pts[n].astype(np.float64) + 0.125 * _KINK_PROBES, "f64")
+            lo, hi = gn[:, ob].min(0) - 1e-5, gn[:, ob].max(0) + 1e-5
+            assert ((gr[n, ob] >= lo) & (gr[n, ob] <= hi)).all(), (env, n, ob, gr[n, ob], lo, hi)
 
 
 def test_ee_cost_vs_golden(ops):
@@ -1411,8 +1418,10 @@ def test_randomised_generated_vs_table_driven_and_oracle(ops, oracle_lib, ident)
                 assert pos is None
             # a single sample's cost can be a small difference of O(1) terms (unclamped margin - sdf): absolute floor of 1
             assert np.abs(c.cpu().numpy() - c64).max() / max(1.0, float(np.abs(c64).max())) < TOL_C, (ident, draw, n, w, use_spec)
-            assert np.abs(gq.cpu().numpy() - g64).max() / max(1.0, float(np.abs(g64).max())) < TOL_G, (ident, draw, n, w, use_spec)
-            res[use_spec] = (c, gq)
+            # per sample; a sample on a kink (arg-min tie within fp32 rounding) must carry the gradient of one of its tied branches
+            gerr = np.abs(gq.cpu().numpy() - g64).max(-1) / max(1.0, float(np.abs(g64).max()))
+            assert kink_rows_ok(gq.cpu().numpy(), g64, q, lambda qq: o.rollout(qq, w, "f64")[2], gerr >= TOL_G), (ident, draw, n, w, use_spec)
+            res[use_spec] = (c, gq, gerr >= TOL_G)
         h.enable_specialized(True)
         # the same fields on GIVEN positions: the unit's field kernels against the table-driven ones
         posd = ops.fk_positions(h, dev(q))
@@ -1425,7 +1434,8 @@ def test_randomised_generated_vs_table_driven_and_oracle(ops, oracle_lib, ident)
         cm.enable_specialized(True)
         (c1, g1, b1), (c0, g0, b0) = outs[True], outs[False]
         assert float((c1 - c0).abs().max()) <= TOL_C * max(1.0, float(c0.abs().max())), (ident, draw, fl)
-        assert float((g1 - g0).abs().max()) <= TOL_G * max(1.0, float(g0.abs().max())), (ident, draw, fl)
+        off = ((g1 - g0).abs().flatten(1).max(1)[0] > TOL_G * max(1.0, float(g0.abs().max()))).sum()
+        assert int(off) <= max(1, n // 500), (ident, draw, fl)          # the two kernel families rank the primitives by different arithmetic: ties may split
         assert int((b1 != b0).sum()) <= max(1, n // 2000), (ident, draw, fl, mg)
         if rng.random() < 0.5:                                        # fp16 I/O through the generated kernel
             p16, c16, g16 = o.rollout(q.astype(np.float16).astype(np.float64), w, "f64")
@@ -1484,10 +1494,15 @@ def test_interpolated_link_points(ops, oracle_lib, generated):
             p64, c64, g64 = o.rollout(q.astype(np.float64), w, "f64")
             ppos, c, gq = ops.rollout_cost_grad(h, cm, w, dev(q))
             assert np.abs(ppos.cpu().numpy() - p64).max() < TOL_H
-            assert rel_err(c.cpu().numpy(), c64) < TOL_C and grad_close(gq.cpu().numpy(), g64), (n, w)
-            c_f, gp_f = ops.cost_fields(cm, FIELD_SELF | FIELD_OBJECTS | FIELD_WS, ppos, want_grad=True)
-            c_o, gp_o = o.cost_fields(FIELD_SELF | FIELD_OBJECTS | FIELD_WS, p64, "f64")
-            assert rel_err(c_f.cpu().numpy(), c_o) < TOL_C and grad_close(gp_f.cpu().numpy(), gp_o), (n, w)
+            # (random batches: a sample on an arg-min tie may take the other branch in fp32 -- helpers.kink_rows_ok bounds what it may return)
+            assert rel_err(c.cpu().numpy(), c64) < TOL_C, (n, w)
+            assert grad_close_kinks(gq.cpu().numpy(), g64, q, lambda qq: o.rollout(qq, w, "f64")[2]), (n, w)
+            fl3 = FIELD_SELF | FIELD_OBJECTS | FIELD_WS
+            c_f, gp_f = ops.cost_fields(cm, fl3, ppos, want_grad=True)
+            c_o, gp_o = o.cost_fields(fl3, p64, "f64")
+            assert rel_err(c_f.cpu().numpy(), c_o) < TOL_C, (n, w)
+            assert grad_close_kinks(gp_f.cpu().numpy(), gp_o, p64, lambda pp: o.cost_fields(fl3, pp.reshape(-1, 11, 3), "f64")[1].reshape(len(pp), -1),
+                                    radius=1e-6), (n, w)
 
 
 def test_interpolate_points_v1_op(ops):

@@ -1463,8 +1463,7 @@ int trk_rollout_collision_via(const TrkModel* m, const TrkCostModel* cm, int32_t
 
 int64_t trk_via_partial_flags_bytes(int64_t n_traj, int32_t horizon, int32_t n_interp) {
     if (n_traj < 0 || horizon < 2 || n_interp < 1) return 0;
-    const int64_t hi = (int64_t)(horizon - 1) * n_interp, n = n_traj * hi;
-    (void)n;
+    const int64_t hi = (int64_t)(horizon - 1) * n_interp;
     return n_traj * (hi / TRK_WAVE + 2);          // one byte per trajectory and wavefront that can hold samples of it
 }
 
