@@ -204,6 +204,33 @@ def test_ur10_allegro_full_size(ops, oracle_lib):
     p64, c64, g64 = o.rollout(qf[idx].cpu().numpy().astype(np.float64), w, "f64")
     assert np.abs(pos.reshape(-1, L, 3)[idx].cpu().numpy() - p64).max() < 3e-6
     assert rel_err(cost.reshape(-1)[idx].cpu().numpy(), c64) < 1e-5 and grad_close(gq.reshape(-1, D)[idx].cpu().numpy(), g64)
+    # THE launch `bench.py --config c4` times: rollout + Jacobian in one kernel (trk_rollout_jacobian_cost_grad).  At this size the
+    # launch's working set (287 MB) exceeds the Infinity Cache and the Jacobian tiles leave as non-temporal stores (SpecArgs::jac_stream).
+    plan = ops.RolloutJacobianPlan(h, cm, w, q, ee)
+    plan.lin_jac.fill_(7.0); plan.ang_jac.fill_(7.0)                # the structural zeros are written, not left over
+    sums = torch.zeros(ops.n_blocks(B * H), **TA)
+    plan.launch(sums.data_ptr())
+    torch.cuda.synchronize()
+    assert ops.last_dispatch() == "generated"
+    assert (plan.link_pos - pos).abs().max().item() <= 3e-6 and rel_err(plan.cost.cpu().numpy(), cost.cpu().numpy()) < 1e-5
+    assert rel_err(plan.gq.cpu().numpy(), gq.cpu().numpy()) < 1e-4
+    assert abs(float(sums.double().sum()) - float(cost.double().sum())) <= 1e-5 * float(cost.double().abs().sum())
+    assert (plan.pos.reshape(-1, 3) - p_ee).abs().max().item() <= 3e-6
+    assert (plan.lin_jac.reshape(lin.shape) - lin).abs().max().item() <= 4e-6 and (plan.ang_jac.reshape(ang.shape) - ang).abs().max().item() <= 2e-6
+    dqt = torch.minimum((plan.quat.reshape(-1, 4) - quat).abs().amax(1), (plan.quat.reshape(-1, 4) + quat).abs().amax(1))
+    assert dqt.max().item() <= 5e-6
+    rp, _, rl, ra, _, _ = o.jacobian(qf[idx].cpu().numpy().astype(np.float64), None, ee, "f64")
+    assert np.abs(plan.pos.reshape(-1, 3)[idx].cpu().numpy() - rp).max() <= 3e-6
+    assert np.abs(plan.lin_jac.reshape(-1, 3, D)[idx].cpu().numpy() - rl).max() <= 6e-6
+    assert np.abs(plan.ang_jac.reshape(-1, 3, D)[idx].cpu().numpy() - ra).max() <= 3e-6
+    # the store policy must not change a bit: the first 64 trajectories as a launch of their own (in cache: write-through tiles)
+    small = ops.RolloutJacobianPlan(h, cm, w, q[:64].contiguous(), ee)
+    small.launch()
+    torch.cuda.synchronize()
+    n64 = 64 * H
+    for a, b in ((small.link_pos, plan.link_pos), (small.cost, plan.cost), (small.gq, plan.gq), (small.pos, plan.pos), (small.quat, plan.quat),
+                 (small.lin_jac, plan.lin_jac), (small.ang_jac, plan.ang_jac)):
+        assert torch.equal(a.reshape(n64, -1), b.reshape(B * H, -1)[:n64])
 
 
 def test_stream_store_instantiation_gives_the_same_bits(ops):
