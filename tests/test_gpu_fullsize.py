@@ -537,3 +537,94 @@ def test_panda_full_size_other_scenes(ops, oracle_lib, scene):
     assert (dc > 1e-5 * np.abs(c64).max()).sum() <= 4
     dg = np.abs(gq.reshape(-1, 7)[sub].cpu().numpy() - g64).max(1)
     assert (dg > 1e-4 * np.abs(g64).max()).sum() <= 8
+
+
+@pytest.mark.parametrize("kind", ["link_spheres", "grasped_box", "both"])
+def test_attached_points_full_size(ops, oracle_lib, kind):
+    """SURVEY 8(f) ranks 3 / 4 at the size tools/bench_points.py times: Panda with the 45-sphere link model, with a grasped box, and with
+    both (56 / 26 / 71 attached points), 4096 x 64, all four terms.  The pre-bound launch (PointsRolloutPlan) == the op; sharding
+    invariance; the positions-only launch of the same kernel writes the same positions; the per-wavefront cost sums are a checksum of the
+    costs; an fp64-oracle subset."""
+    kw = dict(link_spheres=dict(link_sphere_model="panda"), grasped_box=dict(grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA)),
+              both=dict(link_sphere_model="panda", grasped_object=tra.GraspedObjectPandaBox(tensor_args=TA)))[kind]
+    robot = tra.RobotPanda(tensor_args=TA, **kw)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    Ht = np.eye(4, dtype=np.float32); Ht[:3, 3] = (0.4, 0.2, 0.5)
+    task.set_ee_target(Ht)
+    B, H, D = 4096, 64, 7
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    q = robot.random_q(B * H, generator=gen).reshape(B, H, D).contiguous()
+    ps = robot._point_set(DEV)
+    P = ps.n_points
+    assert ps.specialized and P == dict(link_spheres=56, grasped_box=26, both=71)[kind]
+    model, cm = task._fused_handles(DEV)
+    w = (1.0, 1.0, 1.0, 1.0)
+    plan = ops.PointsRolloutPlan(ps, cm, w, q)
+    assert plan.generated
+    sums = torch.zeros(ops.n_blocks(B * H), **TA)
+    plan.launch(sums.data_ptr())
+    torch.cuda.synchronize()
+    assert ops.last_dispatch() == "generated"
+    pos, cost, gq = plan.link_pos.reshape(B, H, P, 3), plan.cost.reshape(B, H), plan.gq.reshape(B, H, D)
+    assert torch.isfinite(cost).all() and torch.isfinite(gq).all() and torch.isfinite(pos).all()
+    p1, c1, g1 = ops.rollout_points_cost_grad(ps, cm, w, q)                              # the op allocates and calls the same entry point
+    assert torch.equal(p1.reshape(pos.shape), pos) and torch.equal(c1.reshape(cost.shape), cost) and torch.equal(g1.reshape(gq.shape), gq)
+    p2, c2, g2 = ops.rollout_points_cost_grad(ps, cm, w, q[B // 2:].contiguous())        # sharding invariance
+    assert torch.equal(p2.reshape(B // 2, H, P, 3), pos[B // 2:]) and torch.equal(c2.reshape(B // 2, H), cost[B // 2:])
+    assert torch.equal(g2.reshape(B // 2, H, D), gq[B // 2:])
+    assert torch.equal(ops.fk_points(ps, q.reshape(-1, D)).reshape(pos.shape), pos)      # the positions-only exit of the same kernel
+    assert abs(float(sums.double().sum()) - float(cost.double().sum())) <= 1e-5 * float(cost.double().abs().sum())
+    pl, po = robot.collision_point_set()
+    o = oracle_lib.Oracle(robot.diff_panda._kin, task.build_cost_spec())
+    idx = np.random.default_rng(8).choice(B * H, 384, replace=False)
+    qs = q.reshape(-1, D)[idx].cpu().numpy().astype(np.float64)
+    rp, rc, rg = o.rollout_points(pl, po, qs, w, "f64")
+    assert np.abs(pos.reshape(-1, P, 3)[idx].cpu().numpy() - rp).max() < 3e-6
+    assert rel_err(cost.reshape(-1)[idx].cpu().numpy(), rc) < 1e-5
+    from helpers import grad_close_kinks
+    assert grad_close_kinks(gq.reshape(-1, D)[idx].cpu().numpy(), rg, qs, lambda qq: o.rollout_points(pl, po, qq, w, "f64")[2])
+
+
+def test_trajectory_validation_full_size(ops, oracle_lib):
+    """SURVEY 8(f) rank 1 at the size tools/bench_task_api.py times: get_trajs_collision_and_free on 4096 trajectories x 64 states, 5 via
+    points per segment (1.29 M configurations).  The one-launch form (way-point collisions + per-trajectory flags) against the three-launch
+    form bit for bit; the partition against the bookkeeping of tasks.py:253-284 stated in numpy; the way-point booleans of a random
+    subset of trajectories against the fp64 oracle on the interpolated configurations."""
+    robot = tra.RobotPanda(tensor_args=TA)
+    task = tra.PlanningTask(env=tra.EnvSpheres3D(tensor_args=TA), robot=robot, obstacle_cutoff_margin=0.03, tensor_args=TA)
+    T, H, D, n_interp = 4096, 64, 7, 5
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    # smooth trajectories (a straight line between two random configurations + a little noise): about half are collision free
+    a, b = robot.random_q(T, generator=gen), robot.random_q(T, generator=gen)
+    s = torch.linspace(0.0, 1.0, H, **TA)[None, :, None]
+    trajs = (a[:, None] * (1 - s) + (0.35 * a + 0.65 * b)[:, None] * s).contiguous()
+    trajs[::97, 13, 2] += 9.0                                             # some leave the joint limits
+    trajs = torch.cat([trajs, torch.zeros(T, H, D, **TA)], -1).contiguous()      # states with velocities
+    tc, ci, tf, fi, wp = task.get_trajs_collision_and_free(trajs, return_indices=True, num_interpolation=n_interp)
+    W = (H - 1) * n_interp
+    assert wp.shape == (T, W)
+    # the three-launch form of round 5 (way-point collisions, then flags from the bytes, then partition + gathers)
+    qmin, qmax = robot.q_min.to(DEV, torch.float32).contiguous(), robot.q_max.to(DEV, torch.float32).contiguous()
+    wp3 = task._waypoint_collisions(trajs, n_interp)
+    assert torch.equal(wp3.reshape(T, W), wp.reshape(T, W))
+    part3 = ops.traj_validate(wp3, trajs, D, qmin, qmax)
+    nf, nc, no = part3.counts()
+    assert nf > T // 10 and nc > T // 10 and no > 0                         # a mixed batch, or the test says little
+    assert fi.numel() == nf and torch.equal(fi.reshape(-1), part3.idx[:nf].reshape(-1))
+    assert torch.equal(tf, part3.gathered[:nf]) and torch.equal(tf, trajs[fi.reshape(-1)])
+    assert ci.numel() == nc + no and torch.equal(tc, trajs[ci.reshape(-1)])
+    coll_any = wp.reshape(T, W).bool().any(1).cpu().numpy()
+    x = trajs[..., :D]
+    outside = ((x < qmin) | (x > qmax)).any(-1).any(-1).cpu().numpy()
+    np.testing.assert_array_equal(fi.reshape(-1).cpu().numpy(), np.flatnonzero(~coll_any & ~outside))
+    np.testing.assert_array_equal(ci.reshape(-1).cpu().numpy(), np.concatenate([np.flatnonzero(coll_any), np.flatnonzero(~coll_any & outside)]))
+    # oracle subset: the interpolated configurations of 24 trajectories, the boolean fields at margin 0 (tasks.py:296-306)
+    sub = np.random.default_rng(5).choice(T, 24, replace=False)
+    dense = ops.interpolate_traj_via_points(trajs[torch.as_tensor(sub, device=DEV)][..., :D].contiguous(), n_interp)
+    assert dense.shape[1] == W
+    o = oracle_lib.Oracle(robot.diff_panda._kin, task.build_cost_spec())
+    qd = dense.reshape(-1, D).cpu().numpy().astype(np.float64)
+    p64 = o.rollout(qd, (0, 0, 0, 0), "f64")[0]
+    ref = o.collision_fields(FIELD_SELF | FIELD_OBJECTS | FIELD_WS, p64, 0.0, "f64").reshape(24, W)
+    got = wp.reshape(T, W)[torch.as_tensor(sub, device=DEV)].cpu().numpy()
+    assert (got != ref).mean() < 2e-3                                       # fp32 against fp64 at the threshold
