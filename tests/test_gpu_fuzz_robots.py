@@ -148,6 +148,26 @@ def test_random_robot_generated_vs_table_driven_vs_oracle(ops, oracle_lib, tmp_p
             got[use_spec] = ops.rollout_collision(h, cm, 7, dev(q)).cpu().numpy()
         assert (got[True] != got[False]).sum() <= max(1, n // 60), seed          # a byte differs only within rounding of a margin
         h.enable_specialized(True)
+        if n > 1:
+            # round 6: rollout + geometric Jacobian of the tracked link behind ONE call.  Whether the unit serves it in one launch depends
+            # on the tree (the generator demands that the Jacobian's stateful walk coincide with the rollout's on the link's chain: limits,
+            # axes, joint types); either way the call must equal the two ops and the fp64 oracle.
+            link = int(spec.ee_link)
+            plan = ops.RolloutJacobianPlan(h, cm, weights, dev(q).reshape(1, n, D), link, strict=False)
+            plan.lin_jac.fill_(7.0); plan.ang_jac.fill_(7.0)
+            plan.launch()
+            torch.cuda.synchronize()
+            assert ops.last_dispatch() in ("generated", "generated + prior launches"), (seed, ops.last_dispatch())
+            if os.environ.get("TRK_FUZZ_VERBOSE"):
+                print(f"[fuzz] seed {seed} n {n}: rollout + Jacobian of link {link} served by: {ops.last_dispatch()}")
+            jp, jq, jl, ja = o.jacobian(q.astype(np.float64), None, link, "f64")[:4]
+            assert np.abs(plan.pos.reshape(n, 3).cpu().numpy() - jp).max() / scale < TOL_H, (seed, n)
+            assert np.abs(plan.lin_jac.reshape(n, 3, D).cpu().numpy() - jl).max() / scale < 3 * TOL_H, (seed, n, ops.last_dispatch())
+            assert np.abs(plan.ang_jac.reshape(n, 3, D).cpu().numpy() - ja).max() < 3 * TOL_H, (seed, n, ops.last_dispatch())
+            qd_ = plan.quat.reshape(n, 4).cpu().numpy()
+            assert np.minimum(np.abs(qd_ - jq).max(-1), np.abs(qd_ + jq).max(-1)).max() < 5e-6, (seed, n)
+            assert np.abs(plan.link_pos.reshape(n, L, 3).cpu().numpy() - rp).max() / scale < TOL_H, (seed, n)
+            assert rel_err(plan.cost.reshape(-1).cpu().numpy(), rc) < TOL_C or np.abs(plan.cost.reshape(-1).cpu().numpy() - rc).max() < 1e-5, (seed, n)
         w = rng.standard_normal((n, L, 3)).astype(np.float32)
         gH = np.zeros((n, L, 4, 4)); gH[..., :3, 3] = w
         ref_b = o.fk_backward(q.astype(np.float64), gH, "f64")
