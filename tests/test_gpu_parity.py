@@ -507,6 +507,25 @@ def test_analytic_jacobian_all_links(ops, oracle_lib, robot):
     bad = np.abs(J - J64).max(axis=(2, 3)) > 1e-4
     assert bad.mean() < 0.01
     assert np.abs((J - J64)[~bad]).max() < 5e-6
+    # round 6: the call above ran the GENERATED kernel (k_ajac: unrolled walk, the row staged through the ring in memory order); the
+    # table-driven kernel is the same function -- also with a moved base (the other instantiation), ragged and multi-wavefront sizes
+    assert h.specialized
+    h.enable_specialized(False)
+    Jt = ops.fk_analytic_jacobian(h, dev(q)).cpu().numpy()
+    h.enable_specialized(True)
+    sw = np.abs(J - Jt).max(axis=(2, 3)) > 1e-4
+    assert sw.mean() < 0.01 and np.abs((J - Jt)[~sw]).max() < 5e-6
+    c, s_ = np.cos(0.4), np.sin(0.4)
+    m.base_R = np.asarray([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+    m.base_t = np.asarray([0.2, -0.1, 0.3], np.float32)
+    hb, ob = ops.ModelHandle(m), oracle_lib.Oracle(m)
+    hb.set_base_pose(m.base_R, m.base_t)
+    for n in (1, 64, 200):
+        qb = np.random.default_rng(3 + n).uniform(-2.5, 2.5, (n, m.n_dofs)).astype(np.float32)
+        Jb = ops.fk_analytic_jacobian(hb, dev(qb)).cpu().numpy()
+        Jb64 = ob.analytic_jacobian(qb.astype(np.float64), "f64")
+        swb = np.abs(Jb - Jb64).max(axis=(2, 3)) > 1e-4
+        assert swb.mean() < 0.02 and (swb.all() or np.abs((Jb - Jb64)[~swb]).max() < 5e-6), n
 
 
 @pytest.mark.parametrize("ident,urdf", [("ur10_allegro", "ur10_allegro"), ("dual_panda", "dual_panda")])

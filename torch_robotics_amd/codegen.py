@@ -2063,6 +2063,124 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
         out.extend(E.lines)
         out.append("")
 
+    # ---- analytic Jacobian of EVERY link (trk_fk_analytic_jacobian; robot_tree.py:250-265): d [pos, quat_wxyz] / d q, [N, L, 7, D].  The
+    # stateless walk unrolled; a joint leaves (omega = pass * sign * its axis in the world, its origin) in registers, every link combines the
+    # joints of its chain into its 7 x D block in an LDS tile (off-chain columns are literal zeros), and the block leaves as the sample's
+    # contiguous run of 7 D floats (spec_store_link_block).  One wavefront per workgroup.  The table-driven kernel walks the same
+    # tables at one instruction per ~25 cycles (Panda 4096 x 64: 340 us for 572 MB).
+    ajac_ok = D <= 16 and L <= 24 and 7 * D * L >= RING_FLOATS and os.environ.get("TRK_EXP_NO_AJAC", "0") != "1"
+    AJ_W = 7 * D * L                        # floats of a sample's output row
+    arp = ring_plan(AJ_W) if ajac_ok else None
+    if ajac_ok:
+        out.append("#ifndef __HIPCC_RTC__          // (linked / dlopen-ed units only: a code-object unit keeps the table-driven kernel)")
+        dof_link = {int(kin.dof_idx[i]): i for i in range(1, L) if int(kin.dof_idx[i]) >= 0}
+        chain: Dict[int, set] = {}
+        for i in range(L):
+            c_, a_ = set(), i
+            while a_ > 0:
+                c_.add(a_); a_ = int(kin.parent[a_])
+            chain[i] = c_
+        aring_t = f"RingFlusher<{arp.W}, {arp.V}, {'true' if arp.aligned else 'false'}, float>"
+        for base_identity in (True, False):
+            E = Emitter()
+            kname = "k_ajac_bi" if base_identity else "k_ajac_bg"
+            E.raw(f"__global__ void __launch_bounds__(TRK_WAVE) {kname}(SpecArgs A) {{")
+            E.raw(f"    extern __shared__ __attribute__((aligned(16))) float lds[];     // the wavefront's ring [64][{arp.stride}] (first: the q transpose)")
+            E.raw("    const int lane = threadIdx.x;")
+            E.raw("    const int64_t base = (int64_t)blockIdx.x * TRK_WAVE;")
+            E.raw("    const int rows = (int)max((int64_t)0, min((int64_t)TRK_WAVE, A.n - base));")
+            E.raw("    float q[D];")
+            E.raw("    spec_load_q<D>(static_cast<const float*>(A.q), base, rows, lane, lds, q);")
+            _emit_angles(E, kin)
+            E.raw(f"    static_assert({aring_t}::LS == {arp.stride} && {aring_t}::HX == {arp.hx} && {aring_t}::NFULL == {arp.n_full} && {aring_t}::NP == {arp.pieces}, "
+                  '"generator and RingFlusher disagree on the ring geometry");')
+            E.raw("    spec_wave_sync();                  // the q transpose is done with this LDS")
+            # (write-through pieces.  Non-temporal ones were measured for outputs beyond the Infinity Cache: 2.4 -> 1.8 TB/s -- an 8-byte piece
+            # is not the 1 KiB contiguous store that policy pays for)
+            E.raw(f"    const {aring_t} ring = spec_make_ring<{arp.W}, {arp.V}, {'true' if arp.aligned else 'false'}, float>(A.jac_lin, base, rows, lane, lds);")
+            E.raw("    float* const prow = ring.row();        // this lane's ring; prow_a: the same, shifted by the lane's head")
+            E.raw("    float* const prow_a = ring.row_a();")
+            R = {}; t = {}; passv = {}
+            if base_identity:
+                R[0] = [[ONE if r == c else ZERO for c in range(3)] for r in range(3)]
+                t[0] = [ZERO, ZERO, ZERO]
+            else:
+                R[0] = [[S(1.0, f"A.base_R[{3 * r + c}]") for c in range(3)] for r in range(3)]
+                t[0] = [S(1.0, f"A.base_t[{r}]") for r in range(3)]
+            ready_at: Dict[int, List[int]] = {}
+            for c in range(arp.n_full + 1):
+                ready_at.setdefault(arp.ready_float(c), []).append(c)
+
+            def stage_float(f, x):
+                """float f of the sample's row into the ring; a chunk that is complete leaves at once (its 16 pieces back to back: the next
+                floats overwrite the OTHER half of the ring, nothing waits for these stores)"""
+                if arp.regular(f):
+                    E.raw(f"        prow_a[{f & 63}] = {x};")
+                else:
+                    E.raw(f"        prow[ring.slot({f})] = {x};")
+                if f < arp.hx:
+                    E.raw(f"        prow[{64 + f}] = {x};")
+                for c in ready_at.get(f, []):
+                    E.raw(f"        ring.template done<{c}>();")
+                    for kk in range(arp.pieces):
+                        E.raw(f"        ring.template piece<{c}, {kk}>();")
+
+            def emit_block(i):
+                E.raw(f"    {{   // link {i}: its 7 x D block of the Jacobian")
+                on = []
+                for d in range(D):
+                    jd = dof_link[d]
+                    if jd in chain[i] and (int(kin.joint_type[jd]) == JOINT_PRISMATIC or float(kin.rot_sign[jd]) != 0.0):
+                        on.append(d)
+                if any(int(kin.joint_type[dof_link[d]]) != JOINT_PRISMATIC for d in on):
+                    E.raw("        const float Ri[9] = {" + ", ".join(E.expr(R[i][r][c]) for r in range(3) for c in range(3)) + "};")
+                    E.raw("        const QuatSel qs = quat_sel(Ri);")
+                tt = ", ".join(E.expr(t[i][r]) for r in range(3))
+                for d in on:
+                    if int(kin.joint_type[dof_link[d]]) == JOINT_PRISMATIC:
+                        E.raw(f"        const float c{d}[7] = {{aw{d}_0, aw{d}_1, aw{d}_2, 0.0f, 0.0f, 0.0f, 0.0f}};")
+                    else:
+                        E.raw(f"        float c{d}[7];")
+                        E.raw(f"        spec_ajac_col_revolute(c{d}, Ri, qs, {tt}, aw{d}_0, aw{d}_1, aw{d}_2, ap{d}_0, ap{d}_1, ap{d}_2);")
+                for k in range(7):
+                    for d in range(D):
+                        stage_float(7 * D * i + k * D + d, f"c{d}[{k}]" if d in on else "0.0f")
+                E.raw("    }")
+            # the row is staged in MEMORY order (link index), the walk visits the links in pre-order: a link's block is emitted when every
+            # link in front of it (by index) has been walked
+            walked = {int(kin.order[0])}
+            next_block = [0]
+
+            def flush_blocks():
+                while next_block[0] < L and next_block[0] in walked:
+                    emit_block(next_block[0])
+                    next_block[0] += 1
+            flush_blocks()
+            for p in range(1, L):
+                i = int(kin.order[p])
+                _emit_fk_link(E, kin, i, R, t, passv, snap)
+                jt, d = int(kin.joint_type[i]), int(kin.dof_idx[i])
+                if jt != JOINT_FIXED and d >= 0:
+                    mask = (lambda e, d=d: f"((passbits & {1 << d}u) ? {e} : 0.0f)") if kin.clamp[i] else (lambda e: e)
+                    if jt == JOINT_PRISMATIC:
+                        par = int(kin.parent[i])
+                        dirw = [E.lincomb([(R[par][r][k], S(float(kin.axis[i][k]))) for k in range(3)]) for r in range(3)]
+                        for k in range(3):
+                            E.raw(f"    const float aw{d}_{k} = {mask(E.expr(dirw[k]))};")
+                    elif float(kin.rot_sign[i]) != 0.0:
+                        sg, ax = float(kin.rot_sign[i]), int(kin.rot_axis[i])
+                        for k in range(3):
+                            z = R[i][k][ax]
+                            E.raw(f"    const float aw{d}_{k} = {mask(E.expr(S(z.c * sg, z.n)))};")
+                            E.raw(f"    const float ap{d}_{k} = {E.expr(t[i][k])};")
+                walked.add(i)
+                flush_blocks()
+            assert next_block[0] == L
+            E.raw("}")                      # (the tail chunk -- what is left of every row and the head of the next one -- left with the last float)
+            out.extend(E.lines)
+            out.append("")
+        out.append("#endif      // !__HIPCC_RTC__")
+
     out.append("#ifndef __HIPCC_RTC__          // the unit's host half: launchers and its registry entry")
     obj = ", ".join(str(i) for i in tmpl.obj_links) or "0"
     pairs = ", ".join(f"{a}, {b}" for a, b in tmpl.self_pairs) or "0"
@@ -2210,13 +2328,20 @@ def generate_rollout_source(kin: KinModel, tmpl: CollisionTemplate, ident: str, 
     out.append("    if (base_identity) hipLaunchKernelGGL(k_jac_bi, dim3(grid), dim3(TRK_WAVE), lds, st, a);")
     out.append("    else hipLaunchKernelGGL(k_jac_bg, dim3(grid), dim3(TRK_WAVE), lds, st, a);")
     out.append("}")
+    if ajac_ok:
+        out.append("static void launch_ajac(const SpecEntry*, const SpecArgs& a, int base_identity, hipStream_t st) {")
+        out.append("    const unsigned grid = (unsigned)((a.n + TRK_WAVE - 1) / TRK_WAVE);")
+        out.append(f"    const size_t lds = sizeof(float) * (size_t)TRK_WAVE * {max(arp.stride, D)};")
+        out.append("    if (base_identity) hipLaunchKernelGGL(k_ajac_bi, dim3(grid), dim3(TRK_WAVE), lds, st, a);")
+        out.append("    else hipLaunchKernelGGL(k_ajac_bg, dim3(grid), dim3(TRK_WAVE), lds, st, a);")
+        out.append("}")
     jac_ok = (TRK_WAVE_ * JAC_LDS + 32) * 4 <= 64 * 1024            # default dynamic-LDS limit of a launch
     out.append(f"static const SpecEntry kEntry = {{SPEC_ENTRY_STAMP, 0x{model_hash(kin):016x}ull, L, D, NL, kObjLinks, "
                f"{len(tmpl.self_pairs)}, kSelfPairs, {tmpl.ee_link}, \"{ident}\", launch, 0, 0ull, launch_posbwd, {tmpl.ee2_link}, "
                f"{'launch_jac' if jac_ok else 'nullptr'}, launch_coll, launch_fkh, {'launch_fkhbwd' if fkhbwd_ok else 'nullptr'}, "
                f"{'launch_ik' if ik_ok else 'nullptr'}, launch_fk1, {'launch_fields' if fields_ok else 'nullptr'}, "
                f"{len(tmpl.virtual)}, kVirtualSrc, kVirtualW, {'launch_ikgn' if ikgn_ok else 'nullptr'}, {'launch_gp' if (gp_ok or gpt_ok) else 'nullptr'}, nullptr, "
-               f"{'launch_rjac' if jacf_ok else 'nullptr'}}};")
+               f"{'launch_rjac' if jacf_ok else 'nullptr'}, {'launch_ajac' if ajac_ok else 'nullptr'}}};")
     out.append("static struct Reg { Reg() { trk_spec_register(&kEntry); } } reg;")
     out.append("#endif      // !__HIPCC_RTC__")
     out.append(f"}}  // namespace spec_{ident}")

@@ -854,6 +854,15 @@ int trk_fk_analytic_jacobian(const TrkModel* m, const float* q, int64_t n, float
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!J || (!q && m->hdr.n_dofs > 0)))) return fail(TRK_ERR_INVALID_ARG, "trk_fk_analytic_jacobian: bad q/J/n");
     if (n == 0 || m->hdr.n_dofs == 0) return TRK_OK;
+    if (m->spec_enabled && model_spec(m) && m->spec->launch_ajac) {
+        SpecArgs a{};
+        std::memcpy(a.base_R, m->hdr.base_R, sizeof(a.base_R));
+        std::memcpy(a.base_t, m->hdr.base_t, sizeof(a.base_t));
+        a.q = q; a.n = n; a.jac_lin = J;
+        m->spec->launch_ajac(m->spec, a, base_is_identity(m), (hipStream_t)stream);
+        TRK_HIP(last_launch_error());
+        return TRK_OK;
+    }
     trk_launch_fk_analytic_jacobian(m->hdr, m->d_links, m->d_dofs, q, n, J, (hipStream_t)stream);
     TRK_HIP(last_launch_error());
     return TRK_OK;

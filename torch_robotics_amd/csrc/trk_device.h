@@ -1033,3 +1033,69 @@ __device__ __forceinline__ float ee_cost_eval(const float* R, const float* t, co
     gt[0] = kp * dx; gt[1] = kp * dy; gt[2] = kp * dz;
     return square ? d * d : d;
 }
+
+// d quat (wxyz) of rotation_matrix_to_q (quaternion.py:135-166) for a rotation m (row-major 9) moving by dm: the derivative of the
+// selected candidate (shared by the table-driven analytic-Jacobian kernel and the generated one)
+__device__ __forceinline__ void quat_jvp(const float* m, const float* dm, float* dq) {
+    const float a[4] = {1.0f + m[0] + m[4] + m[8], 1.0f + m[0] - m[4] - m[8], 1.0f - m[0] + m[4] - m[8], 1.0f - m[0] - m[4] + m[8]};
+    const float da[4] = {dm[0] + dm[4] + dm[8], dm[0] - dm[4] - dm[8], -dm[0] + dm[4] - dm[8], -dm[0] - dm[4] + dm[8]};
+    float qa[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) qa[k] = a[k] > 0.0f ? sqrtf(a[k]) : 0.0f;
+    int b = 0; float qb = qa[0], ab = a[0], dab = da[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (qa[k] > qb) { qb = qa[k]; ab = a[k]; dab = da[k]; b = k; }
+    const bool posa = ab > 0.0f;
+    ab = posa ? ab : 0.0f; dab = posa ? dab : 0.0f;
+    float N[4], dN[4];
+    if (b == 0)      { N[0] = ab; N[1] = m[7] - m[5]; N[2] = m[2] - m[6]; N[3] = m[3] - m[1];
+                       dN[0] = dab; dN[1] = dm[7] - dm[5]; dN[2] = dm[2] - dm[6]; dN[3] = dm[3] - dm[1]; }
+    else if (b == 1) { N[0] = m[7] - m[5]; N[1] = ab; N[2] = m[3] + m[1]; N[3] = m[2] + m[6];
+                       dN[0] = dm[7] - dm[5]; dN[1] = dab; dN[2] = dm[3] + dm[1]; dN[3] = dm[2] + dm[6]; }
+    else if (b == 2) { N[0] = m[2] - m[6]; N[1] = m[3] + m[1]; N[2] = ab; N[3] = m[5] + m[7];
+                       dN[0] = dm[2] - dm[6]; dN[1] = dm[3] + dm[1]; dN[2] = dab; dN[3] = dm[5] + dm[7]; }
+    else             { N[0] = m[3] - m[1]; N[1] = m[6] + m[2]; N[2] = m[7] + m[5]; N[3] = ab;
+                       dN[0] = dm[3] - dm[1]; dN[1] = dm[6] + dm[2]; dN[2] = dm[7] + dm[5]; dN[3] = dab; }
+    const float den = 2.0f * fmaxf(qb, 0.1f);
+    const float dden = (qb > 0.1f && posa) ? dab / qb : 0.0f;
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dq[k] = dN[k] * inv - N[k] * dden * inv * inv;
+}
+
+// quat_jvp factored for callers that differentiate ONE rotation along many directions (the generated analytic-Jacobian kernel: every
+// joint of a link's chain): the candidate selection of rotation_matrix_to_q depends on the rotation only.  sqrt is monotone, so the
+// candidate with the largest a_k IS the one with the largest sqrt(a_k) (first wins on ties, as there): one square root instead of four.
+struct QuatSel { int b; float N[4]; float inv, kden, pos; };      // dq = dN * inv - N * (dab * kden)
+__device__ __forceinline__ QuatSel quat_sel(const float* m) {
+    const float a[4] = {1.0f + m[0] + m[4] + m[8], 1.0f + m[0] - m[4] - m[8], 1.0f - m[0] + m[4] - m[8], 1.0f - m[0] - m[4] + m[8]};
+    int b = 0; float ab = a[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (a[k] > ab && a[k] > 0.0f) { ab = a[k]; b = k; }
+    const bool posa = ab > 0.0f;
+    ab = posa ? ab : 0.0f;
+    const float qb = sqrtf(ab);
+    QuatSel s;
+    s.b = b;
+    if (b == 0)      { s.N[0] = ab; s.N[1] = m[7] - m[5]; s.N[2] = m[2] - m[6]; s.N[3] = m[3] - m[1]; }
+    else if (b == 1) { s.N[0] = m[7] - m[5]; s.N[1] = ab; s.N[2] = m[3] + m[1]; s.N[3] = m[2] + m[6]; }
+    else if (b == 2) { s.N[0] = m[2] - m[6]; s.N[1] = m[3] + m[1]; s.N[2] = ab; s.N[3] = m[5] + m[7]; }
+    else             { s.N[0] = m[3] - m[1]; s.N[1] = m[6] + m[2]; s.N[2] = m[7] + m[5]; s.N[3] = ab; }
+    const float den = 2.0f * fmaxf(qb, 0.1f);
+    s.inv = 1.0f / den;
+    s.kden = (qb > 0.1f && posa) ? s.inv * s.inv / qb : 0.0f;
+    s.pos = posa ? 1.0f : 0.0f;
+    return s;
+}
+__device__ __forceinline__ void quat_jvp_sel(const QuatSel& s, const float* dm, float* dq) {
+    float dN[4];
+    float dab;
+    if (s.b == 0)      { dab = dm[0] + dm[4] + dm[8];  dN[0] = dab; dN[1] = dm[7] - dm[5]; dN[2] = dm[2] - dm[6]; dN[3] = dm[3] - dm[1]; }
+    else if (s.b == 1) { dab = dm[0] - dm[4] - dm[8];  dN[0] = dm[7] - dm[5]; dN[1] = dab; dN[2] = dm[3] + dm[1]; dN[3] = dm[2] + dm[6]; }
+    else if (s.b == 2) { dab = -dm[0] + dm[4] - dm[8]; dN[0] = dm[2] - dm[6]; dN[1] = dm[3] + dm[1]; dN[2] = dab; dN[3] = dm[5] + dm[7]; }
+    else               { dab = -dm[0] - dm[4] + dm[8]; dN[0] = dm[3] - dm[1]; dN[1] = dm[6] + dm[2]; dN[2] = dm[7] + dm[5]; dN[3] = dab; }
+    dN[s.b] *= s.pos;                           // (the selected a_k is positive for every rotation; the reference's guard is kept)
+    const float kd = dab * s.kden;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dq[k] = dN[k] * s.inv - s.N[k] * kd;
+}

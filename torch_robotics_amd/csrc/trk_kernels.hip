@@ -1050,33 +1050,12 @@ k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, JacCols cols, 
 // ============================================================================================
 struct DofRec { int32_t pos, end, type, _pad; };   // pre-order position of the joint's link, end of its subtree
 
-__device__ __forceinline__ void quat_jvp(const float* m, const float* dm, float* dq) {
-    const float a[4] = {1.0f + m[0] + m[4] + m[8], 1.0f + m[0] - m[4] - m[8], 1.0f - m[0] + m[4] - m[8], 1.0f - m[0] - m[4] + m[8]};
-    const float da[4] = {dm[0] + dm[4] + dm[8], dm[0] - dm[4] - dm[8], -dm[0] + dm[4] - dm[8], -dm[0] - dm[4] + dm[8]};
-    float qa[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) qa[k] = a[k] > 0.0f ? sqrtf(a[k]) : 0.0f;
-    int b = 0; float qb = qa[0], ab = a[0], dab = da[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) if (qa[k] > qb) { qb = qa[k]; ab = a[k]; dab = da[k]; b = k; }
-    const bool posa = ab > 0.0f;
-    ab = posa ? ab : 0.0f; dab = posa ? dab : 0.0f;
-    float N[4], dN[4];
-    if (b == 0)      { N[0] = ab; N[1] = m[7] - m[5]; N[2] = m[2] - m[6]; N[3] = m[3] - m[1];
-                       dN[0] = dab; dN[1] = dm[7] - dm[5]; dN[2] = dm[2] - dm[6]; dN[3] = dm[3] - dm[1]; }
-    else if (b == 1) { N[0] = m[7] - m[5]; N[1] = ab; N[2] = m[3] + m[1]; N[3] = m[2] + m[6];
-                       dN[0] = dm[7] - dm[5]; dN[1] = dab; dN[2] = dm[3] + dm[1]; dN[3] = dm[2] + dm[6]; }
-    else if (b == 2) { N[0] = m[2] - m[6]; N[1] = m[3] + m[1]; N[2] = ab; N[3] = m[5] + m[7];
-                       dN[0] = dm[2] - dm[6]; dN[1] = dm[3] + dm[1]; dN[2] = dab; dN[3] = dm[5] + dm[7]; }
-    else             { N[0] = m[3] - m[1]; N[1] = m[6] + m[2]; N[2] = m[7] + m[5]; N[3] = ab;
-                       dN[0] = dm[3] - dm[1]; dN[1] = dm[6] + dm[2]; dN[2] = dm[7] + dm[5]; dN[3] = dab; }
-    const float den = 2.0f * fmaxf(qb, 0.1f);
-    const float dden = (qb > 0.1f && posa) ? dab / qb : 0.0f;
-    const float inv = 1.0f / den;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dq[k] = dN[k] * inv - N[k] * dden * inv * inv;
+// k / w for 0 <= k < 2^22 and a wave-uniform w: one multiply by the reciprocal and a fix-up instead of a 32-bit division
+__device__ __forceinline__ int trk_div_small(int k, int w, float inv_w) {
+    int s = (int)((float)k * inv_w);
+    s -= (s * w > k); s += ((s + 1) * w <= k);
+    return s;
 }
-
 __global__ void __launch_bounds__(TRK_WAVE)
 k_fk_analytic_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, const DofRec* __restrict__ dofs,
                        const float* __restrict__ q, int64_t n, float* __restrict__ J) {
@@ -1139,10 +1118,26 @@ k_fk_analytic_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, const
             row[3 * D + d] = dq[0]; row[4 * D + d] = dq[1]; row[5 * D + d] = dq[2]; row[6 * D + d] = dq[3];
         }
         __syncthreads();
-        // sample r of the wave owns the contiguous run J[base + r][link][:, :] of 7D floats
-        for (int r = 0; r < rows; ++r) {
-            float* dst = J + ((base + r) * L + Lk.link) * W;
-            for (int k = lane; k < W; k += TRK_WAVE) dst[k] = tile[r * rs + k];
+        // sample r of the wave owns the contiguous run J[base + r][link][:, :] of 7D floats.  Element e = lane + 64 i of the [rows][W] tile
+        // -> (sample e / W, k = e % W): every lane stores, four LDS reads in flight per trip (round 6; before: one 49-lane store per
+        // sample, 64 dependent read -> store trips per link: Panda 378 us for 572 MB at 4096 x 64)
+        {
+            const int total = rows * W;
+            const float inv_W = 1.0f / (float)W;
+            float* dst0 = J + (base * L + Lk.link) * W;
+            const int64_t sstride = (int64_t)L * W;
+            for (int e0 = lane; e0 < total; e0 += 4 * TRK_WAVE) {
+                float v[4]; int sm[4], kk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = e0 + TRK_WAVE * j;
+                    sm[j] = trk_div_small(e < total ? e : 0, W, inv_W); kk[j] = (e < total ? e : 0) - sm[j] * W;
+                    v[j] = tile[sm[j] * rs + kk[j]];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (e0 + TRK_WAVE * j < total) dst0[sm[j] * sstride + kk[j]] = v[j];
+            }
         }
         __syncthreads();
     }
@@ -1720,12 +1715,6 @@ k_traj_gather(const float* __restrict__ x, int row, int cols, const int64_t* __r
 // (profiles/r03_bench_jtj.txt has both kernels side by side).
 // ============================================================================================
 typedef float trk_v4 __attribute__((ext_vector_type(4)));
-// k / w for 0 <= k < 2^22 and a wave-uniform w: one multiply by the reciprocal and a fix-up instead of a 32-bit division
-__device__ __forceinline__ int trk_div_small(int k, int w, float inv_w) {
-    int s = (int)((float)k * inv_w);
-    s -= (s * w > k); s += ((s + 1) * w <= k);
-    return s;
-}
 #define TRK_JTJ_WAVES 1      // one wavefront per workgroup: the two tiles are 20 - 75 KB per wavefront, LDS decides the occupancy
 // DT > 0 (round 6): the DOF count as a compile-time constant for the common arms (6, 7) -- a lane takes its 6 x D Jacobian out of the
 // tile ONCE (42 LDS reads instead of 12 per entry = 336), the D (D + 1) / 2 + D results stay in registers, and the output tile REUSES the

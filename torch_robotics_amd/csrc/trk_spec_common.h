@@ -131,7 +131,7 @@ typedef void (*SpecIkGnLaunchFn)(const SpecEntry* self, const IkGnArgs& args, in
 // Layout version of SpecArgs / SpecEntry / DevCostHdr as seen by a generated unit.  A unit compiled against another layout
 // (a stale on-disk JIT object) must never be dispatched: trk_spec_register refuses it.  Bump on ANY change to these structs,
 // to TrkRolloutWeights or to the TRK_MAX_* limits in include/trk.h.
-#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 24)
+#define TRK_SPEC_ABI_VERSION (TRK_ABI_VERSION * 1000 + 25)
 
 #ifndef __HIPCC_RTC__
 struct SpecEntry {
@@ -173,6 +173,8 @@ struct SpecEntry {
     // stateful and stateless walks coincide on the columns' chains): returns 0, or 1 when this unit does not serve the call; nullptr if
     // not generated
     int (*launch_rjac)(const SpecEntry* self, const SpecArgs& args, int base_identity, hipStream_t stream);
+    // analytic Jacobian of every link (trk_fk_analytic_jacobian: d [pos, quat] / d q, [N, L, 7, D] -> args.jac_lin); nullptr if not generated
+    SpecLaunchFn launch_ajac;
 };
 
 // Does this launch take the F32Stream instantiation (non-temporal output stores)?  Its working set -- q in, positions, cost and
@@ -614,6 +616,25 @@ __device__ __forceinline__ void spec_store_tile(float* __restrict__ out, int64_t
 // time, and 16 waves x 8.25 KiB per CU saturate the store path for ~6 us during which nothing computes.
 // `tick()` issues one chunk; the kernel calls it between blocks of arithmetic so the 34.6 MB trickle out at
 // roughly the rate HBM absorbs them.
+// ---- analytic Jacobian of every link (generated k_ajac; the table-driven kernel is k_fk_analytic_jacobian): a link's 7 x D block, rows
+// 0 .. 2 = d pos / d q, rows 3 .. 6 = d quat_wxyz / d q; a sample's row of the output is its L blocks back to back (49 L floats for 7 DOF),
+// staged through the ring (RingFlusher) in memory order.
+// Column d of a link whose chain holds the REVOLUTE joint d: omega = pass * sign * (the joint's axis in the world), pj = the joint link's
+// origin; d p = omega x (p - pj), d R = [omega]x R -> d quat through the selected candidate of rotation_matrix_to_q (quat_jvp).
+__device__ __forceinline__ void spec_ajac_col_revolute(float (&c)[7], const float (&Ri)[9], const QuatSel& qs, float t0, float t1, float t2,
+                                                       float w0, float w1, float w2, float p0, float p1, float p2) {
+    const float r0 = t0 - p0, r1 = t1 - p1, r2 = t2 - p2;
+    c[0] = w1 * r2 - w2 * r1; c[1] = w2 * r0 - w0 * r2; c[2] = w0 * r1 - w1 * r0;
+    float dR[9], dq[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v0 = Ri[k], v1 = Ri[3 + k], v2 = Ri[6 + k];
+        dR[k] = w1 * v2 - w2 * v1; dR[3 + k] = w2 * v0 - w0 * v2; dR[6 + k] = w0 * v1 - w1 * v0;
+    }
+    quat_jvp_sel(qs, dR, dq);       // the candidate of rotation_matrix_to_q was selected once for the link (quat_sel)
+    c[3] = dq[0]; c[4] = dq[1]; c[5] = dq[2]; c[6] = dq[3];
+}
+
 template <int W, class IO>
 struct PosFlusher {
     static constexpr int NV = W * TRK_WAVE / 4;                  // 4-element vectors per wave
