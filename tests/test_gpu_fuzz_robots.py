@@ -168,6 +168,18 @@ def test_random_robot_generated_vs_table_driven_vs_oracle(ops, oracle_lib, tmp_p
             assert np.minimum(np.abs(qd_ - jq).max(-1), np.abs(qd_ + jq).max(-1)).max() < 5e-6, (seed, n)
             assert np.abs(plan.link_pos.reshape(n, L, 3).cpu().numpy() - rp).max() / scale < TOL_H, (seed, n)
             assert rel_err(plan.cost.reshape(-1).cpu().numpy(), rc) < TOL_C or np.abs(plan.cost.reshape(-1).cpu().numpy() - rc).max() < 1e-5, (seed, n)
+        if n > 1:
+            # round 6: the analytic Jacobian of every link has a generated kernel too (prismatic joints, reversed axes, joints without
+            # limits, pre-order != file order are what the bundled robots do not exercise): generated == table-driven == fp64 oracle,
+            # except where fp32 and fp64 pick different quaternion candidates (a discontinuity of rotation_matrix_to_q)
+            J64 = o.analytic_jacobian(q.astype(np.float64), "f64")
+            for use_spec in (True, False):
+                h.enable_specialized(use_spec)
+                Jg = ops.fk_analytic_jacobian(h, dev(q)).cpu().numpy()
+                sw = np.abs(Jg - J64).max(axis=(2, 3)) > 1e-4 * scale
+                assert sw.mean() < 0.03, (seed, n, use_spec, float(sw.mean()))
+                assert sw.all() or np.abs((Jg - J64)[~sw]).max() < 6e-6 * scale, (seed, n, use_spec)
+            h.enable_specialized(True)
         w = rng.standard_normal((n, L, 3)).astype(np.float32)
         gH = np.zeros((n, L, 4, 4)); gH[..., :3, 3] = w
         ref_b = o.fk_backward(q.astype(np.float64), gH, "f64")
