@@ -259,6 +259,9 @@ template <> struct IoTraits<F32Stream> { typedef trk_f32s Q; typedef trk_f32s G;
 #define TRK_IO_F16_G32 2
 // fp32 -> fp16 that saturates at the largest finite half instead of rounding to inf (v_med3_f32 + v_cvt_f16_f32)
 __device__ __forceinline__ _Float16 trk_sat_f16(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+#ifndef TRK_EXP_PIECE_MOD
+#define TRK_EXP_PIECE_MOD "sc1"     // experiment: the cache policy of the ring's 8-byte pieces
+#endif
 template <class IO> struct IoQuad;
 template <> struct IoQuad<float> {
     static constexpr uintptr_t kAlignMask = 15;
@@ -294,7 +297,7 @@ template <> struct IoQuad<float> {
     static __device__ __forceinline__ void store_wt2_sm(unsigned long long base, unsigned voff, float a, float b, unsigned long long mask) {
         const trk_f2 x = {a, b};
         unsigned long long saved;
-        asm volatile("s_and_saveexec_b64 %0, %4\n global_store_dwordx2 %1, %2, %3 sc1\n s_mov_b64 exec, %0"
+        asm volatile("s_and_saveexec_b64 %0, %4\n global_store_dwordx2 %1, %2, %3 " TRK_EXP_PIECE_MOD "\n s_mov_b64 exec, %0"
                      : "=&s"(saved) : "v"(voff), "v"(x), "s"(base), "s"(mask) : "scc");
     }
     static __device__ __forceinline__ void store_wt1_sm(unsigned long long base, unsigned voff, float a, unsigned long long mask) {
