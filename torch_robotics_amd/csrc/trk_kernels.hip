@@ -15,6 +15,13 @@
 #include <algorithm>
 #include "trk_device.h"
 
+// k / w for 0 <= k < 2^22 and a wave-uniform w: one multiply by the reciprocal and a fix-up instead of a 32-bit division
+__device__ __forceinline__ int trk_div_small(int k, int w, float inv_w) {
+    int s = (int)((float)k * inv_w);
+    s -= (s * w > k); s += ((s + 1) * w <= k);
+    return s;
+}
+
 namespace {
 
 // IO = HBM-side element type (float, or _Float16 for the fp16-I/O rollout); LDS and arithmetic are fp32.
@@ -1050,12 +1057,6 @@ k_fk_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, JacCols cols, 
 // ============================================================================================
 struct DofRec { int32_t pos, end, type, _pad; };   // pre-order position of the joint's link, end of its subtree
 
-// k / w for 0 <= k < 2^22 and a wave-uniform w: one multiply by the reciprocal and a fix-up instead of a 32-bit division
-__device__ __forceinline__ int trk_div_small(int k, int w, float inv_w) {
-    int s = (int)((float)k * inv_w);
-    s -= (s * w > k); s += ((s + 1) * w <= k);
-    return s;
-}
 __global__ void __launch_bounds__(TRK_WAVE)
 k_fk_analytic_jacobian(DevModelHdr hdr, const DevLink* __restrict__ links, const DofRec* __restrict__ dofs,
                        const float* __restrict__ q, int64_t n, float* __restrict__ J) {
@@ -1549,12 +1550,17 @@ k_interpolate_via_points(const float* __restrict__ x, int64_t T, int H, int D, i
     __syncthreads();
     const int rows = (H - 1) * n_interp;
     float* ot = out + t * (int64_t)rows * D;
-    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
-        const int i = r / n_interp, a = r - i * n_interp;
-        const float fa = al[a], fb = be[a];
-        const float* p0 = xs + i * D;
-        float* o = ot + r * D;
-        for (int d = 0; d < D; ++d) o[d] = __fadd_rn(__fmul_rn(p0[d], fa), __fmul_rn(p0[D + d], fb));
+    // one output ELEMENT per thread and trip (round 6; before: one row of D floats per thread, every store instruction a 4-byte-in-4D
+    // stride pattern): consecutive threads write consecutive floats.  e = r D + d, r = i n + a: two small divisions by wave-uniform
+    // divisors (reciprocal + fix-up, exact for e < 2^22; larger trajectories take the integer divisions)
+    const int total = rows * D;
+    const float inv_D = 1.0f / (float)D, inv_n = 1.0f / (float)n_interp;
+    const bool small = total < (1 << 22);
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int r = small ? trk_div_small(e, D, inv_D) : e / D, d = e - r * D;
+        const int i = small ? trk_div_small(r, n_interp, inv_n) : r / n_interp, a = r - i * n_interp;
+        const float* p0 = xs + i * D + d;
+        ot[e] = __fadd_rn(__fmul_rn(p0[0], al[a]), __fmul_rn(p0[D], be[a]));
     }
 }
 
